@@ -1,0 +1,191 @@
+/*
+ * mpc_abi.h — C-ABI of the MI355X-native receding-horizon ProxDDP solver (drop-in boundary).
+ *
+ * What this replaces on the reference side: the Boost.Python/eigenpy module `aligator`
+ * (README.md:10) as it is used by the three driver scripts, i.e. the calls
+ *     solver = aligator.SolverProxDDP(TOL, mu_init)          fulldynamic_talos.py:379, kinodynamic_talos.py:285, centroidal_talos.py:270
+ *     solver.setup(problem); solver.run(problem, xs, us)     fulldynamic_talos.py:539-540, kinodynamic_talos.py:490, centroidal_talos.py:461-462
+ *     problem.replaceStageCircular / solver.cycleProblem     fulldynamic_talos.py:496-497, kinodynamic_talos.py:488, centroidal_talos.py:459-460
+ *     residual.setReference(...), contact_poses[i] = ...     fulldynamic_talos.py:461-463, centroidal_talos.py:374-384
+ *     results.xs / results.us / controlFeedbacks()[0]        fulldynamic_talos.py:548-550
+ *     workspace...stage_data[0]...xdot / contact_force       fulldynamic_talos.py:465-485, kinodynamic_talos.py:432, centroidal_talos.py:409
+ * The Python package `mpc_benchmark_amd.aligator` keeps that Python surface and lowers a
+ * TrajOptProblem to the flat tables below; nothing but plain pointers and sizes crosses this boundary.
+ *
+ * Two shared libraries export exactly these symbols:
+ *   mpc_benchmark_amd/csrc/libmpc_hip.so   — the product: hand-written HIP kernels for gfx950
+ *   oracle/libmpc_oracle.so                — TEST INFRASTRUCTURE ONLY: CPU restatement used as the checker
+ *
+ * Conventions: all functions return 0 on success, <0 on error (mpc_last_error gives text); no
+ * exceptions cross the boundary; host buffers are caller-owned, C-contiguous float64/int32, copied
+ * during the call and never retained.  One handle = one device stream = one host thread at a time.
+ * Every array carries a leading ensemble ("batch") dimension B: B independent MPC instances that
+ * share the stage tables and differ in x0 / warm start / multipliers.
+ */
+#ifndef MPC_ABI_H
+#define MPC_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPC_ABI_VERSION 1
+
+/* ---- state manifolds -------------------------------------------------------------------- */
+#define MPC_SPACE_VECTOR 0     /* aligator.manifolds.VectorSpace(n)            centroidal_talos.py:46   */
+#define MPC_SPACE_MULTIBODY 1  /* aligator.manifolds.MultibodyPhaseSpace(model) fulldynamic_talos.py:62 */
+
+/* ---- joint kinds in the model table ------------------------------------------------------- */
+#define MPC_JOINT_FREEFLYER 0
+#define MPC_JOINT_RX 1
+#define MPC_JOINT_RY 2
+#define MPC_JOINT_RZ 3
+
+/* ---- dynamics kinds (stage descriptor word 0) ---------------------------------------------- */
+#define MPC_DYN_NONE 0              /* terminal node */
+#define MPC_DYN_CENTROIDAL_EULER 1  /* CentroidalFwdDynamics + IntegratorEuler            centroidal_talos.py:203-204 */
+#define MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER 2 /* MultibodyConstraintFwdDynamics + IntegratorSemiImplEuler  fulldynamic_talos.py:103-110 */
+#define MPC_DYN_KINODYNAMICS_SEMIEULER 3         /* KinodynamicsFwdDynamics + IntegratorSemiImplEuler         kinodynamic_talos.py:108-111 */
+
+/* ---- residual ("term") types --------------------------------------------------------------- */
+#define MPC_TERM_STATE_ERROR 1          /* r = (x (-) x_ref)[i0 : i0+dim]      params: x_ref[nx]                         */
+#define MPC_TERM_CONTROL_ERROR 2        /* r = (u - u_ref)[i0 : i0+dim]        params: u_ref[nu]                         */
+#define MPC_TERM_FRAME_PLACEMENT 3      /* r = log6(Mref^-1 oMf)               iarg0=frame, params: R[9] p[3]            */
+#define MPC_TERM_FRAME_TRANSLATION 4    /* r = (oMf.t - p_ref)[i1:i1+dim]      iarg0=frame, params: p[3]                 */
+#define MPC_TERM_FRAME_VELOCITY 5       /* r = v_frame(LOCAL) - v_ref          iarg0=frame, params: v_ref[6]             */
+#define MPC_TERM_COM_TRANSLATION 6      /* r = (com(q) - p_ref)[i1:i1+dim]     params: p[3]                              */
+#define MPC_TERM_CENTROIDAL_MOMENTUM 7  /* r = hg(q,v) - h_ref                 params: h_ref[6]                          */
+#define MPC_TERM_CONTACT_FORCE 8        /* r = lambda_c(x,u) - f_ref           iarg0=slot in stage contact list, params: f_ref[6] */
+#define MPC_TERM_MB_WRENCH_CONE 9       /* r = A lambda_c(x,u)                 iarg0=slot, params: A[dim*6]              */
+#define MPC_TERM_CENTROIDAL_WRENCH_CONE 10 /* r = A u[6k:6k+6]                 iarg0=k,    params: A[dim*6]              */
+#define MPC_TERM_CENTROIDAL_LIN_ACC 11  /* r = sum_active f_i / m + g          params: m, g[3], then per contact: state, p[3] */
+#define MPC_TERM_CENTROIDAL_ANG_ACC 12  /* r = sum_active (p_i - c) x f_i + tau_i   same params                          */
+#define MPC_TERM_CENTROIDAL_MOMENTUM_DER 13 /* r = d/dt hg from contact wrenches (kinodynamic) params: g[3], states, frames */
+
+/* ---- term roles ---------------------------------------------------------------------------- */
+#define MPC_ROLE_COST 0            /* 1/2 r^T W r ; weight at woff: dense dim*dim row-major, or diag[dim] if flags&1 */
+#define MPC_ROLE_EQUALITY 1        /* r = 0        (constraints.EqualityConstraintSet) */
+#define MPC_ROLE_NEG_ORTHANT 2     /* r <= 0       (constraints.NegativeOrthant)       */
+#define MPC_ROLE_BOX 3             /* lo <= r <= hi (constraints.BoxConstraint) ; lo[dim], hi[dim] at woff */
+
+#define MPC_TERM_FLAG_DIAG_WEIGHT 1
+
+/* Stage descriptor, int32 words:
+ *   [0] dynamics kind   [1] number of contacts listed   [2],[3] contact entries
+ *       (multibody: indices into the model's contact table of the ACTIVE contacts;
+ *        centroidal / kinodynamic: contact state flag of foot 0 / foot 1)
+ *   [4] offset of the dynamics parameters in the stage's double table
+ *       centroidal : mass, g[3], dt, p0[3], p1[3]     multibody: dt     kinodynamic: dt, g[3], mass, frame0, frame1
+ *   [5] number of terms T   [6] total constraint rows   [7] reserved
+ *   then T records of MPC_TERM_WORDS words: type, role, dim, iarg0, iarg1, poff, woff, flags
+ */
+#define MPC_STAGE_HEADER_WORDS 8
+#define MPC_TERM_WORDS 8
+
+/* Model table.
+ *  int32: [0] njoints (moving joints, joint 0 is the first moving joint) [1] nq [2] nv [3] nframes [4] ncontacts
+ *         then per joint: parent (-1 = world), kind, idx_q, idx_v ; per frame: parent joint ; per contact: joint
+ *  f64  : gravity[3], prox_mu, then per joint: R[9] p[3] mass lever[3] I_com[9]  (25 doubles);
+ *         per frame: R[9] p[3] (12) ; per contact: R1[9] p1[3] R2[9] p2[3] Kp[6] Kd[6] (36)
+ */
+#define MPC_MODEL_HEADER_WORDS 5
+#define MPC_MODEL_JOINT_WORDS 4
+#define MPC_MODEL_HEADER_DOUBLES 4
+#define MPC_MODEL_JOINT_DOUBLES 25
+#define MPC_MODEL_FRAME_DOUBLES 12
+#define MPC_MODEL_CONTACT_DOUBLES 36
+
+typedef struct mpc_dims {
+  int32_t horizon;   /* N: number of stages (knots 0..N, N is terminal)      */
+  int32_t batch;     /* B: ensemble size                                     */
+  int32_t space;     /* MPC_SPACE_*                                          */
+  int32_t nx, ndx, nu;
+  int32_t nc_max;    /* upper bound on constraint rows of any knot           */
+  int32_t max_stage_ints, max_stage_doubles; /* capacity of one stage table  */
+  int32_t device;    /* HIP device ordinal (ignored by the oracle)           */
+} mpc_dims;
+
+/* SolverProxDDP knobs (fulldynamic_talos.py:374-386); values not set by the scripts keep the
+ * defaults documented in DESIGN.md. */
+typedef struct mpc_options {
+  double tol;              /* SolverProxDDP(tol, .) target tolerance                  */
+  double mu_init;          /* SolverProxDDP(., mu_init)                                */
+  double dyn_al_scale;     /* mu_dyn = mu * dyn_al_scale                               */
+  double reg_init;         /* primal regularisation added to diag(Q), diag(R)          */
+  double ls_armijo_c1;
+  double ls_alpha_min;
+  double bcl_prim_alpha, bcl_prim_beta, bcl_dual_alpha, bcl_dual_beta;
+  double bcl_mu_update_factor, bcl_mu_lower_bound;
+  double inner_tol0, prim_tol0;
+  int32_t max_iters;       /* solver.max_iters (100 cold, 1 in the MPC loop)           */
+  int32_t max_al_iters;
+  int32_t force_initial_condition;
+  int32_t rollout_linear;  /* ROLLOUT_LINEAR = 1 (only mode implemented)               */
+  int32_t ls_max_steps;    /* number of backtracking candidates alpha = 2^-i           */
+  int32_t num_threads;     /* oracle: OpenMP threads ; HIP: ignored                    */
+  int32_t riccati_legs;    /* HIP: legs of the parallel-in-time Riccati (LQ_SOLVER_PARALLEL) ; 1 = serial */
+  int32_t reserved;
+} mpc_options;
+
+typedef struct mpc_stats {
+  int32_t num_iters;
+  int32_t converged;
+  int32_t al_iters;
+  int32_t ls_steps;        /* index of the accepted backtracking candidate in the last iteration */
+  double traj_cost;
+  double merit;
+  double prim_infeas;
+  double dual_infeas;
+  double mu;
+  double alpha;
+} mpc_stats;
+
+typedef struct mpc_solver mpc_solver;
+
+int mpc_abi_version(void);
+const char* mpc_backend_name(void); /* "hip-gfx950" or "oracle-cpu" */
+
+int mpc_create(const mpc_dims* dims, mpc_solver** out);
+void mpc_destroy(mpc_solver* s);
+const char* mpc_last_error(mpc_solver* s);
+
+int mpc_set_options(mpc_solver* s, const mpc_options* opt);
+int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double* dtab, int32_t n_d);
+
+/* TrajOptProblem(x0, stages, term_cost): k in [0, N]; k == N is the terminal node (cost + terminal constraints). */
+int mpc_set_stage(mpc_solver* s, int32_t k, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params);
+/* setReference / contact_poses[i] = ... : overwrite n doubles of stage k's parameter table. */
+int mpc_update_stage_params(mpc_solver* s, int32_t k, int32_t offset, const double* vals, int32_t n);
+/* replaceStageCircular + cycleAppend/cycleProblem: drop stage 0, shift, install the new stage at N-1. */
+int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params);
+
+/* problem.x0_init = x : x0[B][nx] */
+int mpc_set_x0(mpc_solver* s, const double* x0);
+/* solver.setup(problem): reset multipliers, penalty and tolerances (no re-allocation). */
+int mpc_setup(mpc_solver* s);
+/* solver.run(problem, xs, us): xs[B][N+1][nx], us[B][N][nu]; stats[B] (may be NULL). */
+int mpc_run(mpc_solver* s, const double* xs_init, const double* us_init, mpc_stats* stats);
+/* Re-run from the solver's own shifted solution: xs <- [xs[1:], xs[-1]], us likewise, xs[0] <- x0
+ * (the warm-start shift of fulldynamic_talos.py:532-534 done on the device). */
+int mpc_run_shifted(mpc_solver* s, mpc_stats* stats);
+
+/* results.xs / results.us / controlFeedbacks() / feed-forwards / multipliers. Any pointer may be NULL.
+ * xs[B][N+1][nx] us[B][N][nu] K[B][N][nu][ndx] kff[B][N][nu] vs[B][N+1][nc_max] lams[B][N+1][ndx] */
+int mpc_get_results(mpc_solver* s, double* xs, double* us, double* K, double* kff, double* vs, double* lams);
+/* workspace.problem_data.stage_data[k].dynamics_data.continuous_data.{xdot, constraint_datas[i].contact_force}
+ * xdot[B][ndx], wrenches[B][2][6] (inactive contacts zero). */
+int mpc_get_stage_data(mpc_solver* s, int32_t k, double* xdot, double* wrenches);
+
+/* Phase dumps for parity tests: copies the named per-knot quantity of instance b, knot k into out
+ * (capacity cap doubles) and returns the number of doubles written (<0 on error).  Names:
+ * "H" "grad" "AB" "f" "E6" "cval" "CD" "cost" "P" "p" "K" "kff" "Knu" "knu" "dx" "du" "dvs" "dlams" "xnext". */
+int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double* out, int32_t cap);
+/* Evaluate (value + derivatives) at the current iterate without stepping; fills the LQ knots. */
+int mpc_debug_evaluate(mpc_solver* s, const double* xs, const double* us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_ABI_H */

@@ -1,0 +1,241 @@
+"""ctypes binding of the C-ABI declared in ``include/mpc_abi.h``.
+
+The product loads exactly one library: ``mpc_benchmark_amd/csrc/libmpc_hip.so`` (hand-written HIP for
+gfx950).  There is no CPU fallback: if the library is missing or fails to load, ``load_hip_library``
+raises.  ``bind_library`` is the generic binder; tests use it to bind the CPU oracle
+(``oracle/libmpc_oracle.so``) as the *checker* — the package itself never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIBRARY_PATH = os.path.join(_HERE, "csrc", "libmpc_hip.so")
+
+ABI_VERSION = 1
+
+# constants mirrored from include/mpc_abi.h
+SPACE_VECTOR, SPACE_MULTIBODY = 0, 1
+JOINT_FREEFLYER, JOINT_RX, JOINT_RY, JOINT_RZ = 0, 1, 2, 3
+DYN_NONE, DYN_CENTROIDAL_EULER, DYN_MULTIBODY_CONSTRAINT_SEMIEULER, DYN_KINODYNAMICS_SEMIEULER = 0, 1, 2, 3
+(TERM_STATE_ERROR, TERM_CONTROL_ERROR, TERM_FRAME_PLACEMENT, TERM_FRAME_TRANSLATION, TERM_FRAME_VELOCITY,
+ TERM_COM_TRANSLATION, TERM_CENTROIDAL_MOMENTUM, TERM_CONTACT_FORCE, TERM_MB_WRENCH_CONE,
+ TERM_CENTROIDAL_WRENCH_CONE, TERM_CENTROIDAL_LIN_ACC, TERM_CENTROIDAL_ANG_ACC,
+ TERM_CENTROIDAL_MOMENTUM_DER) = range(1, 14)
+ROLE_COST, ROLE_EQUALITY, ROLE_NEG_ORTHANT, ROLE_BOX = 0, 1, 2, 3
+TERM_FLAG_DIAG_WEIGHT = 1
+STAGE_HEADER_WORDS, TERM_WORDS = 8, 8
+
+
+class MpcDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "horizon", "batch", "space", "nx", "ndx", "nu", "nc_max", "max_stage_ints", "max_stage_doubles", "device")]
+
+
+class MpcOptions(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "tol", "mu_init", "dyn_al_scale", "reg_init", "ls_armijo_c1", "ls_alpha_min",
+        "bcl_prim_alpha", "bcl_prim_beta", "bcl_dual_alpha", "bcl_dual_beta",
+        "bcl_mu_update_factor", "bcl_mu_lower_bound", "inner_tol0", "prim_tol0")] + [(n, C.c_int32) for n in (
+        "max_iters", "max_al_iters", "force_initial_condition", "rollout_linear", "ls_max_steps",
+        "num_threads", "riccati_legs", "reserved")]
+
+
+def default_options(tol=1e-5, mu_init=1e-8):
+    """Defaults of the knobs the scripts do not touch (documented in DESIGN.md; upstream values unpinned)."""
+    o = MpcOptions()
+    o.tol, o.mu_init, o.dyn_al_scale, o.reg_init = tol, mu_init, 1e-3, 1e-9
+    o.ls_armijo_c1, o.ls_alpha_min = 1e-4, 1e-7
+    o.bcl_prim_alpha, o.bcl_prim_beta, o.bcl_dual_alpha, o.bcl_dual_beta = 0.1, 0.9, 1.0, 1.0
+    o.bcl_mu_update_factor, o.bcl_mu_lower_bound = 0.01, 1e-8
+    o.inner_tol0, o.prim_tol0 = 1.0, 1.0
+    o.max_iters, o.max_al_iters = 1000, 100
+    o.force_initial_condition, o.rollout_linear, o.ls_max_steps = 0, 0, 8
+    o.num_threads, o.riccati_legs, o.reserved = 1, 1, 0
+    return o
+
+
+class MpcStats(C.Structure):
+    _fields_ = [("num_iters", C.c_int32), ("converged", C.c_int32), ("al_iters", C.c_int32), ("ls_steps", C.c_int32),
+                ("traj_cost", C.c_double), ("merit", C.c_double), ("prim_infeas", C.c_double),
+                ("dual_infeas", C.c_double), ("mu", C.c_double), ("alpha", C.c_double)]
+
+
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int32)
+
+_SIGNATURES = {
+    "mpc_abi_version": (C.c_int, []),
+    "mpc_backend_name": (C.c_char_p, []),
+    "mpc_create": (C.c_int, [C.POINTER(MpcDims), C.POINTER(C.c_void_p)]),
+    "mpc_destroy": (None, [C.c_void_p]),
+    "mpc_last_error": (C.c_char_p, [C.c_void_p]),
+    "mpc_set_options": (C.c_int, [C.c_void_p, C.POINTER(MpcOptions)]),
+    "mpc_set_model": (C.c_int, [C.c_void_p, _IP, C.c_int32, _DP, C.c_int32]),
+    "mpc_set_stage": (C.c_int, [C.c_void_p, C.c_int32, _IP, C.c_int32, _DP, C.c_int32]),
+    "mpc_update_stage_params": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _DP, C.c_int32]),
+    "mpc_cycle": (C.c_int, [C.c_void_p, _IP, C.c_int32, _DP, C.c_int32]),
+    "mpc_set_x0": (C.c_int, [C.c_void_p, _DP]),
+    "mpc_setup": (C.c_int, [C.c_void_p]),
+    "mpc_run": (C.c_int, [C.c_void_p, _DP, _DP, C.POINTER(MpcStats)]),
+    "mpc_run_shifted": (C.c_int, [C.c_void_p, C.POINTER(MpcStats)]),
+    "mpc_get_results": (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP, _DP, _DP]),
+    "mpc_get_stage_data": (C.c_int, [C.c_void_p, C.c_int32, _DP, _DP]),
+    "mpc_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, _DP, C.c_int32]),
+    "mpc_debug_evaluate": (C.c_int, [C.c_void_p, _DP, _DP]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def bind_library(path):
+    """dlopen ``path`` and attach the argument/return types of every entry point of mpc_abi.h."""
+    lib = C.CDLL(path, mode=getattr(os, "RTLD_LOCAL", 0) | getattr(os, "RTLD_NOW", 2))
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mpc_abi_version() != ABI_VERSION:
+        raise RuntimeError("%s: ABI version %d, expected %d" % (path, lib.mpc_abi_version(), ABI_VERSION))
+    return lib
+
+
+_hip_lib = None
+
+
+def load_hip_library():
+    """Load the HIP product library. Fails loudly — there is deliberately no CPU fallback."""
+    global _hip_lib
+    if _hip_lib is None:
+        if not os.path.exists(HIP_LIBRARY_PATH):
+            raise RuntimeError(
+                "HIP solver library not built: %s is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C mpc_benchmark_amd/csrc`). No CPU fallback exists." % HIP_LIBRARY_PATH)
+        _hip_lib = bind_library(HIP_LIBRARY_PATH)
+    return _hip_lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(_DP)
+
+
+class NativeSolver:
+    """Thin object wrapper over one ``mpc_solver*`` handle of a bound library."""
+
+    def __init__(self, lib, dims: MpcDims):
+        self.lib = lib
+        self.dims = dims
+        self._h = C.c_void_p()
+        rc = lib.mpc_create(C.byref(dims), C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError("mpc_create failed (rc=%d)" % rc)
+        self.backend = lib.mpc_backend_name().decode()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.mpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise RuntimeError("%s failed: %s" % (what, self.lib.mpc_last_error(self._h).decode(errors="replace")))
+        return rc
+
+    # -- problem upload ------------------------------------------------------------------------
+    def set_options(self, opt: MpcOptions):
+        self._check(self.lib.mpc_set_options(self._h, C.byref(opt)), "mpc_set_options")
+
+    def set_model(self, itab, dtab):
+        itab, dtab = _i32(itab), _f64(dtab)
+        self._check(self.lib.mpc_set_model(self._h, itab.ctypes.data_as(_IP), itab.size, _dp(dtab), dtab.size), "mpc_set_model")
+
+    def set_stage(self, k, desc, params):
+        desc, params = _i32(desc), _f64(params)
+        self._check(self.lib.mpc_set_stage(self._h, k, desc.ctypes.data_as(_IP), desc.size, _dp(params), params.size), "mpc_set_stage")
+
+    def update_stage_params(self, k, offset, vals):
+        vals = _f64(vals).ravel()
+        self._check(self.lib.mpc_update_stage_params(self._h, k, offset, _dp(vals), vals.size), "mpc_update_stage_params")
+
+    def cycle(self, desc, params):
+        desc, params = _i32(desc), _f64(params)
+        self._check(self.lib.mpc_cycle(self._h, desc.ctypes.data_as(_IP), desc.size, _dp(params), params.size), "mpc_cycle")
+
+    def set_x0(self, x0):
+        x0 = _f64(x0)
+        x0 = np.ascontiguousarray(np.broadcast_to(x0.reshape(-1, self.dims.nx), (self.dims.batch, self.dims.nx)))
+        self._check(self.lib.mpc_set_x0(self._h, _dp(x0)), "mpc_set_x0")
+
+    def setup(self):
+        self._check(self.lib.mpc_setup(self._h), "mpc_setup")
+
+    # -- solve ----------------------------------------------------------------------------------
+    def _bcast(self, a, shape):
+        a = _f64(a)
+        if a.shape != shape:
+            a = np.ascontiguousarray(np.broadcast_to(a.reshape(shape[1:]), shape))
+        return a
+
+    def run(self, xs, us):
+        d = self.dims
+        xs = self._bcast(xs, (d.batch, d.horizon + 1, d.nx))
+        us = self._bcast(us, (d.batch, d.horizon, d.nu))
+        stats = (MpcStats * d.batch)()
+        self._check(self.lib.mpc_run(self._h, _dp(xs), _dp(us), stats), "mpc_run")
+        return list(stats)
+
+    def run_shifted(self):
+        stats = (MpcStats * self.dims.batch)()
+        self._check(self.lib.mpc_run_shifted(self._h, stats), "mpc_run_shifted")
+        return list(stats)
+
+    def get_results(self, gains=True, multipliers=False):
+        d = self.dims
+        B, N = d.batch, d.horizon
+        out = {"xs": np.zeros((B, N + 1, d.nx)), "us": np.zeros((B, N, d.nu))}
+        if gains:
+            out["K"] = np.zeros((B, N, d.nu, d.ndx))
+            out["kff"] = np.zeros((B, N, d.nu))
+        if multipliers:
+            out["vs"] = np.zeros((B, N + 1, d.nc_max))
+            out["lams"] = np.zeros((B, N + 1, d.ndx))
+        self._check(self.lib.mpc_get_results(self._h, _dp(out["xs"]), _dp(out["us"]), _dp(out.get("K")), _dp(out.get("kff")),
+                                             _dp(out.get("vs")), _dp(out.get("lams"))), "mpc_get_results")
+        return out
+
+    def get_stage_data(self, k):
+        d = self.dims
+        xdot = np.zeros((d.batch, d.ndx))
+        wr = np.zeros((d.batch, 2, 6))
+        self._check(self.lib.mpc_get_stage_data(self._h, k, _dp(xdot), _dp(wr)), "mpc_get_stage_data")
+        return xdot, wr
+
+    # -- parity hooks ---------------------------------------------------------------------------
+    def debug_evaluate(self, xs, us):
+        d = self.dims
+        xs = self._bcast(xs, (d.batch, d.horizon + 1, d.nx))
+        us = self._bcast(us, (d.batch, d.horizon, d.nu))
+        self._check(self.lib.mpc_debug_evaluate(self._h, _dp(xs), _dp(us)), "mpc_debug_evaluate")
+
+    def debug_get(self, name, k, b=0):
+        cap = 4 * (self.dims.ndx + self.dims.nu + self.dims.nc_max + 8) ** 2
+        buf = np.zeros(cap)
+        n = self._check(self.lib.mpc_debug_get(self._h, name.encode(), b, k, _dp(buf), cap), "mpc_debug_get(%s)" % name)
+        return buf[:n].copy()

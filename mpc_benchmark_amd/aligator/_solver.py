@@ -1,0 +1,276 @@
+"""``aligator.SolverProxDDP`` mirror (fulldynamic_talos.py:374-397, 539-550): lowers the problem, keeps the
+device copy in sync with in-place mutations of the Python objects, and calls the native solver through the
+C-ABI.  The default backend is the HIP library; it is loaded on first use and there is no CPU fallback."""
+from __future__ import annotations
+
+import numpy as np
+
+from .. import _capi as K
+from . import _core as core
+from . import manifolds as _manifolds
+
+ROLLOUT_NONLINEAR = 0
+ROLLOUT_LINEAR = 1
+LQ_SOLVER_SERIAL = 0
+LQ_SOLVER_PARALLEL = 1
+LQ_SOLVER_STAGEDENSE = 2
+
+
+class VerboseLevel:
+    QUIET = 0
+    VERBOSE = 1
+    VERYVERBOSE = 2
+
+
+class _ArrayList(list):
+    """``results.xs`` / ``results.us``: a sequence of 1-D arrays with the ``.tolist()`` the scripts call."""
+
+    def tolist(self):
+        return list(self)
+
+
+class Results:
+    def __init__(self):
+        self.xs = _ArrayList()
+        self.us = _ArrayList()
+        self.vs = _ArrayList()
+        self.lams = _ArrayList()
+        self._K = []
+        self._kff = []
+        self.num_iters = 0
+        self.conv = False
+        self.traj_cost = 0.0
+        self.merit_value = 0.0
+        self.prim_infeas = 0.0
+        self.dual_infeas = 0.0
+        self.al_iter = 0
+
+    def controlFeedbacks(self):
+        return self._K
+
+    def controlFeedforwards(self):
+        return self._kff
+
+    def __str__(self):
+        return ("Results {\n  num_iters:    %d,\n  converged:    %s,\n  traj. cost:   %.6e,\n  merit.value:  %.6e,\n"
+                "  prim_infeas:  %.6e,\n  dual_infeas:  %.6e,\n}" % (self.num_iters, self.conv, self.traj_cost,
+                                                                  self.merit_value, self.prim_infeas, self.dual_infeas))
+
+
+class _ContactForce:
+    def __init__(self, w):
+        self.linear = np.array(w[:3])
+        self.angular = np.array(w[3:])
+
+
+class _ConstraintData:
+    def __init__(self, w):
+        self.contact_force = _ContactForce(w)
+
+
+class _ContinuousData:
+    def __init__(self, xdot, wrenches):
+        self.xdot = xdot
+        self.constraint_datas = [_ConstraintData(w) for w in wrenches]
+
+
+class _DynamicsData:
+    def __init__(self, cont):
+        self.continuous_data = cont
+
+
+class _StageDataView:
+    def __init__(self, cont):
+        self.dynamics_data = _DynamicsData(cont)
+
+
+class _StageDataSeq:
+    """``workspace.problem_data.stage_data[k]`` fetched lazily from the native workspace."""
+
+    def __init__(self, solver):
+        self._solver = solver
+
+    def __len__(self):
+        return self._solver._dims.horizon
+
+    def __getitem__(self, k):
+        s = self._solver
+        xdot, wr = s._native.get_stage_data(int(k))
+        stage = s._problem.stages[int(k)]
+        ode = stage.dynamics.differential_dynamics
+        if isinstance(ode, core.MultibodyConstraintFwdDynamics):
+            ids = [s._ctx.contact_index(cm) for cm in ode.constraint_models]
+            wrenches = [wr[0, i] for i in ids]
+        else:
+            wrenches = []
+        return _StageDataView(_ContinuousData(xdot[0].copy(), wrenches))
+
+
+class _ProblemData:
+    def __init__(self, solver):
+        self.stage_data = _StageDataSeq(solver)
+
+
+class Workspace:
+    def __init__(self, solver):
+        self.problem_data = _ProblemData(solver)
+
+    def cycleAppend(self, stage_data):
+        """Data rotation is implicit in the native ring buffer (fulldynamic_talos.py:497)."""
+
+
+class SolverProxDDP:
+    def __init__(self, tol=1e-6, mu_init=1e-2, max_iters=1000, verbose=VerboseLevel.QUIET, _native_library=None):
+        self.target_tol = float(tol)
+        self.mu_init = float(mu_init)
+        self.max_iters = int(max_iters)
+        self.verbose = verbose
+        self.rollout_type = ROLLOUT_NONLINEAR
+        self.linear_solver_choice = LQ_SOLVER_SERIAL
+        self.force_initial_condition = False
+        self.reg_init = 1e-9
+        self.num_threads = 1
+        self.batch = 1
+        self.results = Results()
+        self.workspace = None
+        # dependency injection for tests (the CPU oracle); product code never passes this
+        self._lib = _native_library
+        self._native = None
+        self._problem = None
+        self._dims = None
+        self._ctx = None
+        self._uploaded = None
+
+    def setNumThreads(self, n):
+        self.num_threads = int(n)
+
+    # -- option block ---------------------------------------------------------------------------
+    def _options(self):
+        o = K.default_options(self.target_tol, self.mu_init)
+        o.reg_init = self.reg_init
+        o.max_iters = self.max_iters
+        o.force_initial_condition = 1 if self.force_initial_condition else 0
+        o.rollout_linear = 1 if self.rollout_type == ROLLOUT_LINEAR else 0
+        o.num_threads = self.num_threads
+        o.riccati_legs = self.num_threads if self.linear_solver_choice == LQ_SOLVER_PARALLEL else 1
+        return o
+
+    # -- lowering / device sync -----------------------------------------------------------------
+    def _lower_node(self, node, cost, dynamics, constraints):
+        if node._dirty or node._lowered is None:
+            node._lowered = core.lower_stage(self._ctx, cost, dynamics, constraints)
+            node._dirty = False
+            return True
+        return False
+
+    def _lower_all(self, problem):
+        changed = []
+        for k, st in enumerate(problem.stages):
+            if self._lower_node(st, st.cost, st.dynamics, st.constraints):
+                changed.append(k)
+        t = problem._term
+        if self._lower_node(t, problem.term_cost, None, problem.term_constraints):
+            changed.append(len(problem.stages))
+        return changed
+
+    def _node(self, problem, k):
+        return problem.stages[k] if k < len(problem.stages) else problem._term
+
+    def setup(self, problem):
+        if self.rollout_type != ROLLOUT_LINEAR or not self.force_initial_condition:
+            raise NotImplementedError("only rollout_type=ROLLOUT_LINEAR with force_initial_condition=True is "
+                                      "implemented (the configuration of fulldynamic_talos.py:381-384)")
+        if self._lib is None:
+            self._lib = K.load_hip_library()
+        N = problem.num_steps
+        first = problem.stages[0]
+        space = first.xspace
+        if self._problem is not problem or self._native is None:
+            self._ctx = core.LoweringContext()
+            for st in problem.stages:
+                st._dirty = True
+            problem._term._dirty = True
+            problem._cycled = []
+            self._lower_all(problem)
+            nodes = [self._node(problem, k) for k in range(N + 1)]
+            nc_max = max(int(nd._lowered[0][6]) for nd in nodes)
+            d = K.MpcDims()
+            d.horizon, d.batch = N, int(self.batch)
+            d.space = K.SPACE_MULTIBODY if isinstance(space, _manifolds.MultibodyPhaseSpace) else K.SPACE_VECTOR
+            d.nx, d.ndx, d.nu = space.nx, space.ndx, first.nu
+            d.nc_max = max(nc_max, 2 * 17 + 2 * first.nu + space.ndx)  # room for later stages with more rows
+            d.max_stage_ints = 8 + 8 * 24
+            d.max_stage_doubles = max(nd._lowered[1].size for nd in nodes) + 1024
+            d.device = 0
+            self._dims = d
+            self._native = K.NativeSolver(self._lib, d)
+            self._problem = problem
+            self._uploaded = [None] * (N + 1)
+            self.workspace = Workspace(self)
+            self._model_uploaded = False
+        self._native.set_options(self._options())
+        self._sync(problem)
+        self._native.setup()
+
+    def _sync(self, problem):
+        """Bring the device copy of the stage tables up to date with the Python objects."""
+        N = problem.num_steps
+        nat = self._native
+        # 1. stages rotated in by replaceStageCircular
+        for st in problem._cycled:
+            self._lower_node(st, st.cost, st.dynamics, st.constraints)
+        if self._ctx.model is not None and (self._ctx.changed or not self._model_uploaded):
+            nat.set_model(*self._ctx.model_tables())
+            self._ctx.changed = False
+            self._model_uploaded = True
+        for st in problem._cycled:
+            desc, params = st._lowered
+            nat.cycle(desc, params)
+            self._uploaded = self._uploaded[1:N] + [(desc, params), self._uploaded[N]]
+        problem._cycled = []
+        # 2. dirty nodes: re-lower; upload the parameter table, or the whole stage if its structure changed
+        self._lower_all(problem)
+        if self._ctx.changed:
+            nat.set_model(*self._ctx.model_tables())
+            self._ctx.changed = False
+        for k in range(N + 1):
+            desc, params = self._node(problem, k)._lowered
+            up = self._uploaded[k]
+            if up is not None and up[0] is desc and up[1] is params:
+                continue
+            if up is not None and np.array_equal(up[0], desc) and up[1].size == params.size:
+                nat.update_stage_params(k, 0, params)
+            else:
+                nat.set_stage(k, desc, params)
+            self._uploaded[k] = (desc, params)
+
+    def cycleProblem(self, problem, stage_data=None):
+        """kinodynamic_talos.py:488 / centroidal_talos.py:460 — the rotation itself was recorded by
+        ``problem.replaceStageCircular``; nothing else to do until the next run."""
+
+    # -- solve ----------------------------------------------------------------------------------
+    def run(self, problem, xs_init=None, us_init=None):
+        if self._native is None or self._problem is not problem:
+            raise RuntimeError("call solver.setup(problem) before solver.run")
+        d = self._dims
+        self._native.set_options(self._options())
+        self._sync(problem)
+        self._native.set_x0(problem.x0_init)
+        xs = np.array([np.asarray(x, dtype=float) for x in xs_init]).reshape(d.horizon + 1, d.nx)
+        us = np.array([np.asarray(u, dtype=float) for u in us_init]).reshape(d.horizon, d.nu)
+        stats = self._native.run(xs, us)
+        self._fetch(stats)
+        return bool(self.results.conv)
+
+    def _fetch(self, stats):
+        out = self._native.get_results(gains=True, multipliers=False)
+        r = self.results
+        r.xs = _ArrayList(out["xs"][0].copy())
+        r.us = _ArrayList(out["us"][0].copy())
+        r._K = list(out["K"][0].copy())
+        r._kff = list(out["kff"][0].copy())
+        s = stats[0]
+        r.num_iters, r.conv, r.al_iter = s.num_iters, bool(s.converged), s.al_iters
+        r.traj_cost, r.merit_value, r.prim_infeas, r.dual_infeas = s.traj_cost, s.merit, s.prim_infeas, s.dual_infeas
+        self._last_stats = stats
+        self._last_results = out

@@ -1,0 +1,506 @@
+"""Minimal duck-typed stand-ins for the handful of `pinocchio` objects the reference scripts hand to
+`aligator`.  Host-side glue only: the hot path never runs through this file.
+
+The reference builds its problems from a real ``pin.Model`` (talos_utils.py:31-41) which does not exist
+in this environment; the shim in ``mpc_benchmark_amd.aligator`` reads models by *attribute name*, so either a
+real ``pin.Model`` or the ``Model`` defined here works.  Conventions follow Pinocchio:
+
+* free-flyer configuration ``q = [x y z, qx qy qz qw]``, velocity ``v = [v_lin(body), w(body)]``;
+* spatial motion = ``[linear; angular]``, spatial force = ``[force; torque]``;
+* ``SE3 * SE3`` composes, ``SE3.act(p)`` maps a point.
+"""
+from __future__ import annotations
+
+import copy as _copy
+import numpy as np
+
+LOCAL = 0
+WORLD = 1
+LOCAL_WORLD_ALIGNED = 2
+
+
+class ContactType:
+    CONTACT_3D = 1
+    CONTACT_6D = 2
+
+
+def skew(w):
+    return np.array([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def exp3(w):
+    th = float(np.linalg.norm(w))
+    K = skew(w)
+    if th < 1e-10:
+        return np.eye(3) + K + 0.5 * K @ K
+    return np.eye(3) + np.sin(th) / th * K + (1.0 - np.cos(th)) / th ** 2 * (K @ K)
+
+
+def log3(R):
+    c = 0.5 * (np.trace(R) - 1.0)
+    c = min(1.0, max(-1.0, c))
+    th = np.arccos(c)
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    if th < 1e-8:
+        return 0.5 * v * (1.0 + th * th / 6.0)
+    if th > np.pi - 1e-6:
+        # near pi: use the diagonal
+        A = 0.5 * (R + np.eye(3))
+        ax = np.sqrt(np.maximum(np.diag(A), 0.0))
+        k = int(np.argmax(ax))
+        ax = A[:, k] / ax[k]
+        if v @ ax < 0:
+            ax = -ax
+        return th * ax / np.linalg.norm(ax)
+    return th / (2.0 * np.sin(th)) * v
+
+
+def quat_to_rot(qxyzw):
+    x, y, z, w = np.asarray(qxyzw, dtype=float) / np.linalg.norm(qxyzw)
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def rot_to_quat(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        w = 0.25 * s
+        x = (R[2, 1] - R[1, 2]) / s
+        y = (R[0, 2] - R[2, 0]) / s
+        z = (R[1, 0] - R[0, 1]) / s
+    elif R[0, 0] > R[1, 1] and R[0, 0] > R[2, 2]:
+        s = np.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        w = (R[2, 1] - R[1, 2]) / s
+        x = 0.25 * s
+        y = (R[0, 1] + R[1, 0]) / s
+        z = (R[0, 2] + R[2, 0]) / s
+    elif R[1, 1] > R[2, 2]:
+        s = np.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        w = (R[0, 2] - R[2, 0]) / s
+        x = (R[0, 1] + R[1, 0]) / s
+        y = 0.25 * s
+        z = (R[1, 2] + R[2, 1]) / s
+    else:
+        s = np.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        w = (R[1, 0] - R[0, 1]) / s
+        x = (R[0, 2] + R[2, 0]) / s
+        y = (R[1, 2] + R[2, 1]) / s
+        z = 0.25 * s
+    q = np.array([x, y, z, w])
+    if w < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+class SE3:
+    """Rigid placement (rotation, translation) — mirrors the part of ``pin.SE3`` the scripts touch."""
+
+    def __init__(self, rotation=None, translation=None):
+        self.rotation = np.eye(3) if rotation is None else np.array(rotation, dtype=float)
+        self.translation = np.zeros(3) if translation is None else np.array(translation, dtype=float)
+
+    @staticmethod
+    def Identity():
+        return SE3()
+
+    def copy(self):
+        return SE3(self.rotation.copy(), self.translation.copy())
+
+    def __mul__(self, other):
+        return SE3(self.rotation @ other.rotation, self.rotation @ other.translation + self.translation)
+
+    def inverse(self):
+        return SE3(self.rotation.T, -self.rotation.T @ self.translation)
+
+    def act(self, p):
+        return self.rotation @ np.asarray(p, dtype=float) + self.translation
+
+    def actInv(self, other):
+        return self.inverse() * other
+
+    @property
+    def homogeneous(self):
+        H = np.eye(4)
+        H[:3, :3] = self.rotation
+        H[:3, 3] = self.translation
+        return H
+
+    def action(self):
+        """6x6 motion action matrix Ad(M) on [lin; ang] vectors."""
+        A = np.zeros((6, 6))
+        A[:3, :3] = self.rotation
+        A[3:, 3:] = self.rotation
+        A[:3, 3:] = skew(self.translation) @ self.rotation
+        return A
+
+    def __repr__(self):
+        return "SE3(R=\n%s,\n p=%s)" % (self.rotation, self.translation)
+
+
+def exp6(nu):
+    v = np.asarray(nu[:3], dtype=float)
+    w = np.asarray(nu[3:], dtype=float)
+    th = float(np.linalg.norm(w))
+    K = skew(w)
+    R = exp3(w)
+    if th < 1e-10:
+        V = np.eye(3) + 0.5 * K + K @ K / 6.0
+    else:
+        V = np.eye(3) + (1 - np.cos(th)) / th ** 2 * K + (th - np.sin(th)) / th ** 3 * (K @ K)
+    return SE3(R, V @ v)
+
+
+def log6(M):
+    w = log3(M.rotation)
+    th = float(np.linalg.norm(w))
+    K = skew(w)
+    if th < 1e-8:
+        Vinv = np.eye(3) - 0.5 * K + K @ K / 12.0
+    else:
+        Vinv = np.eye(3) - 0.5 * K + (1.0 / th ** 2 - (1 + np.cos(th)) / (2 * th * np.sin(th))) * (K @ K)
+    return np.concatenate((Vinv @ M.translation, w))
+
+
+class Motion:
+    def __init__(self, linear=None, angular=None):
+        self.np = np.zeros(6)
+        if linear is not None:
+            self.np[:3] = linear
+        if angular is not None:
+            self.np[3:] = angular
+
+    @staticmethod
+    def Zero():
+        return Motion()
+
+    @property
+    def linear(self):
+        return self.np[:3]
+
+    @property
+    def angular(self):
+        return self.np[3:]
+
+    @property
+    def vector(self):
+        return self.np
+
+
+class Force(Motion):
+    pass
+
+
+class Inertia:
+    """mass, lever (CoM in the joint frame) and rotational inertia about the CoM."""
+
+    def __init__(self, mass, lever, inertia):
+        self.mass = float(mass)
+        self.lever = np.array(lever, dtype=float)
+        self.inertia = np.array(inertia, dtype=float)
+
+    def copy(self):
+        return Inertia(self.mass, self.lever.copy(), self.inertia.copy())
+
+    def se3Action(self, M):
+        """Inertia expressed in the frame a, given this inertia in frame b and aMb = M."""
+        R = M.rotation
+        return Inertia(self.mass, M.act(self.lever), R @ self.inertia @ R.T)
+
+    def __add__(self, o):
+        m = self.mass + o.mass
+        if m <= 0:
+            return Inertia(0.0, np.zeros(3), np.zeros((3, 3)))
+        c = (self.mass * self.lever + o.mass * o.lever) / m
+        I = np.zeros((3, 3))
+        for b in (self, o):
+            d = b.lever - c
+            I += b.inertia + b.mass * (d @ d * np.eye(3) - np.outer(d, d))
+        return Inertia(m, c, I)
+
+    def matrix(self):
+        """6x6 spatial inertia at the frame origin, [lin; ang] ordering."""
+        S = skew(self.lever)
+        Y = np.zeros((6, 6))
+        Y[:3, :3] = self.mass * np.eye(3)
+        Y[:3, 3:] = -self.mass * S
+        Y[3:, :3] = self.mass * S
+        Y[3:, 3:] = self.inertia - self.mass * S @ S
+        return Y
+
+
+_JOINT_NQ = {"JointModelFreeFlyer": 7, "JointModelRX": 1, "JointModelRY": 1, "JointModelRZ": 1}
+_JOINT_NV = {"JointModelFreeFlyer": 6, "JointModelRX": 1, "JointModelRY": 1, "JointModelRZ": 1}
+
+
+class JointModel:
+    def __init__(self, kind, idx_q, idx_v):
+        self._kind = kind
+        self.idx_q = idx_q
+        self.idx_v = idx_v
+        self.nq = _JOINT_NQ.get(kind, 0)
+        self.nv = _JOINT_NV.get(kind, 0)
+
+    def shortname(self):
+        return self._kind
+
+
+class Frame:
+    def __init__(self, name, parentJoint, placement, parentFrame=0):
+        self.name = name
+        self.parentJoint = int(parentJoint)
+        self.parent = int(parentJoint)
+        self.parentFrame = parentFrame
+        self.placement = placement
+
+
+class _Names(list):
+    def tolist(self):
+        return list(self)
+
+
+class Data:
+    def __init__(self, model):
+        self.oMi = [SE3() for _ in range(model.njoints)]
+        self.oMf = [SE3() for _ in range(len(model.frames))]
+        self.com = [np.zeros(3)]
+        self.hg = Force()
+
+
+class Model:
+    """Kinematic tree with the attribute names of ``pin.Model`` that the shim reads."""
+
+    def __init__(self):
+        self.names = _Names(["universe"])
+        self.parents = [0]
+        self.jointPlacements = [SE3()]
+        self.inertias = [Inertia(0.0, np.zeros(3), np.zeros((3, 3)))]
+        self.joints = [JointModel("JointModelUniverse", -1, -1)]
+        self.frames = [Frame("universe", 0, SE3())]
+        self.nq = 0
+        self.nv = 0
+        self.effortLimit = np.zeros(0)
+        self.velocityLimit = np.zeros(0)
+        self.upperPositionLimit = np.zeros(0)
+        self.lowerPositionLimit = np.zeros(0)
+        self.referenceConfigurations = {}
+        self.gravity = Motion(linear=[0, 0, -9.81])
+
+    @property
+    def njoints(self):
+        return len(self.parents)
+
+    @property
+    def nframes(self):
+        return len(self.frames)
+
+    def addJoint(self, parent, kind, placement, name, effort=0.0, lower=None, upper=None):
+        nq, nv = _JOINT_NQ[kind], _JOINT_NV[kind]
+        self.names.append(name)
+        self.parents.append(int(parent))
+        self.jointPlacements.append(placement.copy())
+        self.inertias.append(Inertia(0.0, np.zeros(3), np.zeros((3, 3))))
+        self.joints.append(JointModel(kind, self.nq, self.nv))
+        self.nq += nq
+        self.nv += nv
+        big = 1e30
+        lo = np.full(nq, -big) if lower is None else np.atleast_1d(np.asarray(lower, dtype=float))
+        hi = np.full(nq, big) if upper is None else np.atleast_1d(np.asarray(upper, dtype=float))
+        self.effortLimit = np.concatenate((self.effortLimit, np.full(nv, float(effort))))
+        self.velocityLimit = np.concatenate((self.velocityLimit, np.full(nv, big)))
+        self.lowerPositionLimit = np.concatenate((self.lowerPositionLimit, lo))
+        self.upperPositionLimit = np.concatenate((self.upperPositionLimit, hi))
+        jid = self.njoints - 1
+        self.frames.append(Frame(name, jid, SE3()))
+        return jid
+
+    def appendBodyToJoint(self, jid, inertia, placement=None):
+        Y = inertia if placement is None else inertia.se3Action(placement)
+        self.inertias[jid] = self.inertias[jid] + Y if self.inertias[jid].mass > 0 else Y.copy()
+
+    def addFrame(self, frame):
+        self.frames.append(frame)
+        return len(self.frames) - 1
+
+    def getFrameId(self, name):
+        for i, f in enumerate(self.frames):
+            if f.name == name:
+                return i
+        return len(self.frames)
+
+    def getJointId(self, name):
+        for i, n in enumerate(self.names):
+            if n == name:
+                return i
+        return len(self.names)
+
+    def existFrame(self, name):
+        return self.getFrameId(name) < len(self.frames)
+
+    def copy(self):
+        return _copy.deepcopy(self)
+
+    def createData(self):
+        return Data(self)
+
+
+def neutral(model):
+    q = np.zeros(model.nq)
+    for j in model.joints[1:]:
+        if j.shortname() == "JointModelFreeFlyer":
+            q[j.idx_q + 6] = 1.0
+    return q
+
+
+def _joint_transform(jm, q):
+    k = jm.shortname()
+    if k == "JointModelFreeFlyer":
+        return SE3(quat_to_rot(q[jm.idx_q + 3: jm.idx_q + 7]), q[jm.idx_q: jm.idx_q + 3])
+    ax = {"JointModelRX": 0, "JointModelRY": 1, "JointModelRZ": 2}[k]
+    w = np.zeros(3)
+    w[ax] = q[jm.idx_q]
+    return SE3(exp3(w), np.zeros(3))
+
+
+def forwardKinematics(model, data, q, v=None):
+    for i in range(1, model.njoints):
+        liMi = model.jointPlacements[i] * _joint_transform(model.joints[i], q)
+        p = model.parents[i]
+        data.oMi[i] = liMi if p == 0 else data.oMi[p] * liMi
+
+
+def updateFramePlacements(model, data):
+    for i, f in enumerate(model.frames):
+        data.oMf[i] = data.oMi[f.parentJoint] * f.placement if f.parentJoint > 0 else f.placement.copy()
+
+
+def framesForwardKinematics(model, data, q):
+    forwardKinematics(model, data, q)
+    updateFramePlacements(model, data)
+
+
+def computeTotalMass(model):
+    return float(sum(Y.mass for Y in model.inertias))
+
+
+def centerOfMass(model, data, q, v=None):
+    forwardKinematics(model, data, q)
+    m = 0.0
+    c = np.zeros(3)
+    for i in range(1, model.njoints):
+        Y = model.inertias[i]
+        c += Y.mass * data.oMi[i].act(Y.lever)
+        m += Y.mass
+    data.com[0] = c / m
+    return data.com[0].copy()
+
+
+def integrate(model, q, dv):
+    """q (+) dv with Pinocchio's free-flyer convention (body-frame twist, right multiplication)."""
+    out = np.array(q, dtype=float)
+    for j in model.joints[1:]:
+        if j.shortname() == "JointModelFreeFlyer":
+            M = SE3(quat_to_rot(q[j.idx_q + 3: j.idx_q + 7]), q[j.idx_q: j.idx_q + 3]) * exp6(dv[j.idx_v: j.idx_v + 6])
+            out[j.idx_q: j.idx_q + 3] = M.translation
+            out[j.idx_q + 3: j.idx_q + 7] = rot_to_quat(M.rotation)
+        else:
+            out[j.idx_q] = q[j.idx_q] + dv[j.idx_v]
+    return out
+
+
+def difference(model, q0, q1):
+    """Tangent vector d such that q0 (+) d = q1."""
+    d = np.zeros(model.nv)
+    for j in model.joints[1:]:
+        if j.shortname() == "JointModelFreeFlyer":
+            M0 = SE3(quat_to_rot(q0[j.idx_q + 3: j.idx_q + 7]), q0[j.idx_q: j.idx_q + 3])
+            M1 = SE3(quat_to_rot(q1[j.idx_q + 3: j.idx_q + 7]), q1[j.idx_q: j.idx_q + 3])
+            d[j.idx_v: j.idx_v + 6] = log6(M0.inverse() * M1)
+        else:
+            d[j.idx_v] = q1[j.idx_q] - q0[j.idx_q]
+    return d
+
+
+class _Corrector:
+    def __init__(self, n):
+        self.Kp = np.zeros(n)
+        self.Kd = np.zeros(n)
+
+
+class RigidConstraintData:
+    def __init__(self):
+        self.contact_force = Force()
+
+
+class RigidConstraintModel:
+    """Mirror of the constructor used at fulldynamic_talos.py:84-92."""
+
+    def __init__(self, type, model, joint1_id, joint1_placement, joint2_id=0, joint2_placement=None,
+                 reference_frame=LOCAL):
+        self.type = type
+        self.joint1_id = int(joint1_id)
+        self.joint1_placement = joint1_placement.copy()
+        self.joint2_id = int(joint2_id)
+        self.joint2_placement = SE3() if joint2_placement is None else joint2_placement.copy()
+        self.reference_frame = reference_frame
+        self.corrector = _Corrector(6 if type == ContactType.CONTACT_6D else 3)
+        self.name = ""
+
+    def size(self):
+        return 6 if self.type == ContactType.CONTACT_6D else 3
+
+    def createData(self):
+        return RigidConstraintData()
+
+
+class ProximalSettings:
+    def __init__(self, accuracy=1e-12, mu=0.0, max_iter=1):
+        self.absolute_accuracy = accuracy
+        self.accuracy = accuracy
+        self.mu = mu
+        self.max_iter = max_iter
+
+
+def buildReducedModel(model, locked_joint_ids, q_ref):
+    """Lock the given joints at ``q_ref`` and fold their bodies into the parents
+    (what ``robot.buildReducedRobot`` does at talos_utils.py:37)."""
+    locked = set(int(j) for j in locked_joint_ids)
+    red = Model()
+    data = model.createData()
+    # placement of every original joint w.r.t. its closest kept ancestor (or universe)
+    kept_id = {0: 0}
+    rel = {0: SE3()}
+    qmap = []
+    for i in range(1, model.njoints):
+        p = model.parents[i]
+        liMi = model.jointPlacements[i]
+        if i in locked:
+            M = rel[p] * liMi * _joint_transform(model.joints[i], q_ref)
+            kept_id[i] = kept_id[p]
+            rel[i] = M
+            red.appendBodyToJoint(kept_id[i], model.inertias[i], M) if kept_id[i] > 0 else None
+        else:
+            jm = model.joints[i]
+            sl = slice(jm.idx_q, jm.idx_q + jm.nq)
+            slv = slice(jm.idx_v, jm.idx_v + jm.nv)
+            jid = red.addJoint(kept_id[p], jm.shortname(), rel[p] * liMi, model.names[i],
+                               effort=0.0, lower=model.lowerPositionLimit[sl], upper=model.upperPositionLimit[sl])
+            red.effortLimit[red.joints[jid].idx_v: red.joints[jid].idx_v + jm.nv] = model.effortLimit[slv]
+            red.appendBodyToJoint(jid, model.inertias[i])
+            kept_id[i] = jid
+            rel[i] = SE3()
+            qmap.append((sl, slice(red.joints[jid].idx_q, red.joints[jid].idx_q + jm.nq)))
+    red.frames = [Frame("universe", 0, SE3())]
+    for f in model.frames[1:]:
+        pj = f.parentJoint
+        red.frames.append(Frame(f.name, kept_id[pj], rel[pj] * f.placement))
+    for name, q in model.referenceConfigurations.items():
+        qr = np.zeros(red.nq)
+        for src, dst in qmap:
+            qr[dst] = q[src]
+        red.referenceConfigurations[name] = qr
+    del data
+    return red

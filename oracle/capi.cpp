@@ -1,0 +1,221 @@
+// oracle/capi.cpp — TEST INFRASTRUCTURE (CPU oracle). Not part of the product path.
+// Exports the C-ABI of include/mpc_abi.h on top of the CPU restatement (oracle/solver.hpp).  Only
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load this library; the product
+// (mpc_benchmark_amd) never does.  PARITY UNPINNED: the reference's arithmetic lives in un-vendored
+// Aligator/Pinocchio (README.md:10-16) and no golden vectors exist.
+#include <cstring>
+#include <string>
+#include "solver.hpp"
+
+using namespace orc;
+
+struct mpc_solver {
+  Solver s;
+  std::string err;
+};
+
+#define MPC_TRY(h, ...)                  \
+  try {                                  \
+    __VA_ARGS__;                         \
+    return 0;                            \
+  } catch (const std::exception& e) {    \
+    if (h) (h)->err = e.what();          \
+    return -1;                           \
+  }
+
+extern "C" {
+
+int mpc_abi_version(void) { return MPC_ABI_VERSION; }
+const char* mpc_backend_name(void) { return "oracle-cpu"; }
+
+int mpc_create(const mpc_dims* dims, mpc_solver** out) {
+  if (!dims || !out) return -2;
+  mpc_solver* h = nullptr;
+  try {
+    h = new mpc_solver();
+    h->s.init(*dims);
+    *out = h;
+    return 0;
+  } catch (const std::exception&) {
+    delete h;
+    return -1;
+  }
+}
+void mpc_destroy(mpc_solver* h) { delete h; }
+const char* mpc_last_error(mpc_solver* h) { return h ? h->err.c_str() : "null handle"; }
+
+int mpc_set_options(mpc_solver* h, const mpc_options* opt) { MPC_TRY(h, h->s.opt = *opt) }
+
+int mpc_set_model(mpc_solver* h, const int32_t* itab, int32_t n_i, const double* dtab, int32_t n_d) {
+  MPC_TRY(h, { h->s.model.parse(itab, n_i, dtab, n_d); h->s.have_model = true; })
+}
+
+int mpc_set_stage(mpc_solver* h, int32_t k, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params) {
+  MPC_TRY(h, {
+    if (k < 0 || k > h->s.N()) throw std::runtime_error("stage index out of range");
+    h->s.stages[k].parse(desc, n_desc, params, n_params);
+  })
+}
+
+int mpc_update_stage_params(mpc_solver* h, int32_t k, int32_t offset, const double* vals, int32_t n) {
+  MPC_TRY(h, {
+    if (k < 0 || k > h->s.N()) throw std::runtime_error("stage index out of range");
+    auto& p = h->s.stages[k].params;
+    if (offset < 0 || offset + n > (int)p.size()) throw std::runtime_error("parameter update out of range");
+    std::memcpy(p.data() + offset, vals, n * sizeof(double));
+  })
+}
+
+int mpc_cycle(mpc_solver* h, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params) {
+  MPC_TRY(h, {
+    const int N = h->s.N();
+    StageDesc sd;
+    sd.parse(desc, n_desc, params, n_params);
+    for (int k = 0; k + 1 < N; ++k) h->s.stages[k] = std::move(h->s.stages[k + 1]);
+    h->s.stages[N - 1] = std::move(sd);
+  })
+}
+
+int mpc_set_x0(mpc_solver* h, const double* x0) {
+  MPC_TRY(h, {
+    const int nx = h->s.dims.nx;
+    for (int b = 0; b < h->s.dims.batch; ++b) h->s.inst[b].x0.assign(x0 + b * nx, x0 + (b + 1) * nx);
+  })
+}
+
+int mpc_setup(mpc_solver* h) { MPC_TRY(h, h->s.setup()) }
+
+static void run_all(mpc_solver* h, mpc_stats* stats) {
+  Solver& s = h->s;
+  for (int b = 0; b < s.dims.batch; ++b) {
+    s.run_instance(s.inst[b]);
+    if (stats) stats[b] = s.inst[b].stats;
+  }
+}
+
+int mpc_run(mpc_solver* h, const double* xs, const double* us, mpc_stats* stats) {
+  MPC_TRY(h, {
+    Solver& s = h->s;
+    const int N = s.N(), nx = s.dims.nx, nu = s.dims.nu;
+    for (int b = 0; b < s.dims.batch; ++b) {
+      Instance& in = s.inst[b];
+      for (int k = 0; k <= N; ++k) in.xs[k].assign(xs + ((size_t)b * (N + 1) + k) * nx, xs + ((size_t)b * (N + 1) + k + 1) * nx);
+      for (int k = 0; k < N; ++k) in.us[k].assign(us + ((size_t)b * N + k) * nu, us + ((size_t)b * N + k + 1) * nu);
+    }
+    run_all(h, stats);
+  })
+}
+
+int mpc_run_shifted(mpc_solver* h, mpc_stats* stats) {
+  MPC_TRY(h, {
+    Solver& s = h->s;
+    const int N = s.N();
+    for (int b = 0; b < s.dims.batch; ++b) {
+      Instance& in = s.inst[b];
+      for (int k = 0; k < N; ++k) in.xs[k] = in.xs[k + 1];
+      for (int k = 0; k + 1 < N; ++k) in.us[k] = in.us[k + 1];
+      in.xs[0] = in.x0;
+    }
+    run_all(h, stats);
+  })
+}
+
+int mpc_get_results(mpc_solver* h, double* xs, double* us, double* K, double* kff, double* vs, double* lams) {
+  MPC_TRY(h, {
+    Solver& s = h->s;
+    const int N = s.N(), nx = s.dims.nx, nu = s.dims.nu, n = s.dims.ndx, nc = s.dims.nc_max;
+    for (int b = 0; b < s.dims.batch; ++b) {
+      const Instance& in = s.inst[b];
+      for (int k = 0; k <= N; ++k) {
+        if (xs) std::memcpy(xs + ((size_t)b * (N + 1) + k) * nx, in.xs[k].data(), nx * sizeof(double));
+        if (vs) std::memcpy(vs + ((size_t)b * (N + 1) + k) * nc, in.vs[k].data(), nc * sizeof(double));
+        if (lams) std::memcpy(lams + ((size_t)b * (N + 1) + k) * n, in.lams[k].data(), n * sizeof(double));
+      }
+      for (int k = 0; k < N; ++k) {
+        if (us) std::memcpy(us + ((size_t)b * N + k) * nu, in.us[k].data(), nu * sizeof(double));
+        if (K) {
+          double* dst = K + ((size_t)b * N + k) * nu * n;
+          if ((int)in.gains[k].K.size() == nu * n) std::memcpy(dst, in.gains[k].K.data(), nu * n * sizeof(double));
+          else std::memset(dst, 0, nu * n * sizeof(double));
+        }
+        if (kff) {
+          double* dst = kff + ((size_t)b * N + k) * nu;
+          if ((int)in.gains[k].kff.size() == nu) std::memcpy(dst, in.gains[k].kff.data(), nu * sizeof(double));
+          else std::memset(dst, 0, nu * sizeof(double));
+        }
+      }
+    }
+  })
+}
+
+int mpc_get_stage_data(mpc_solver* h, int32_t k, double* xdot, double* wrenches) {
+  MPC_TRY(h, {
+    Solver& s = h->s;
+    if (k < 0 || k >= s.N()) throw std::runtime_error("stage index out of range");
+    for (int b = 0; b < s.dims.batch; ++b) {
+      const Knot& kn = s.inst[b].knots[k];
+      if (xdot) for (int i = 0; i < s.dims.ndx; ++i) xdot[b * s.dims.ndx + i] = i < (int)kn.xdot.size() ? kn.xdot[i] : 0.0;
+      if (wrenches) std::memcpy(wrenches + b * 12, kn.wrench, 12 * sizeof(double));
+    }
+  })
+}
+
+int mpc_debug_evaluate(mpc_solver* h, const double* xs, const double* us) {
+  MPC_TRY(h, {
+    Solver& s = h->s;
+    const int N = s.N(), nx = s.dims.nx, nu = s.dims.nu;
+    for (int b = 0; b < s.dims.batch; ++b) {
+      Instance& in = s.inst[b];
+      for (int k = 0; k <= N; ++k) in.xs[k].assign(xs + ((size_t)b * (N + 1) + k) * nx, xs + ((size_t)b * (N + 1) + k + 1) * nx);
+      for (int k = 0; k < N; ++k) in.us[k].assign(us + ((size_t)b * N + k) * nu, us + ((size_t)b * N + k + 1) * nu);
+      s.evaluate(in, in.xs, in.us, in.knots, true);
+    }
+  })
+}
+
+int mpc_debug_get(mpc_solver* h, const char* name, int32_t b, int32_t k, double* out, int32_t cap) {
+  if (!h) return -2;
+  try {
+    Solver& s = h->s;
+    if (b < 0 || b >= s.dims.batch || k < 0 || k > s.N()) throw std::runtime_error("debug_get: index out of range");
+    const Instance& in = s.inst[b];
+    const Knot& kn = in.knots[k];
+    const Gains& g = in.gains[k];
+    const std::string nm(name);
+    const std::vector<double>* v = nullptr;
+    std::vector<double> tmp;
+    if (nm == "H") v = &kn.H;
+    else if (nm == "grad") v = &kn.grad;
+    else if (nm == "AB") v = &kn.AB;
+    else if (nm == "f") v = &kn.f;
+    else if (nm == "E6") { tmp.assign(kn.E6, kn.E6 + 36); v = &tmp; }
+    else if (nm == "cval") v = &kn.cval;
+    else if (nm == "CD") v = &kn.CD;
+    else if (nm == "cost") { tmp.assign(1, kn.cost); v = &tmp; }
+    else if (nm == "xnext") v = &kn.xnext;
+    else if (nm == "xdot") v = &kn.xdot;
+    else if (nm == "wrench") { tmp.assign(kn.wrench, kn.wrench + 12); v = &tmp; }
+    else if (nm == "P") v = &g.P;
+    else if (nm == "p") v = &g.p;
+    else if (nm == "K") v = &g.K;
+    else if (nm == "kff") v = &g.kff;
+    else if (nm == "Knu") v = &g.Knu;
+    else if (nm == "knu") v = &g.knu;
+    else if (nm == "Mx") v = &g.Mx;
+    else if (nm == "mx") v = &g.mx;
+    else if (nm == "dx") v = &in.dxs[k];
+    else if (nm == "du") { if (k >= s.N()) throw std::runtime_error("no du at the terminal knot"); v = &in.dus[k]; }
+    else if (nm == "dvs") v = &in.dvs[k];
+    else if (nm == "dlams") v = &in.dlams[k];
+    else throw std::runtime_error("debug_get: unknown quantity " + nm);
+    const int cnt = (int)v->size();
+    if (cnt > cap) throw std::runtime_error("debug_get: output buffer too small");
+    std::memcpy(out, v->data(), cnt * sizeof(double));
+    return cnt;
+  } catch (const std::exception& e) {
+    h->err = e.what();
+    return -1;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,513 @@
+// oracle/solver.hpp — TEST INFRASTRUCTURE (CPU oracle). Not part of the product path.
+// CPU restatement of one SolverProxDDP.run (SURVEY.md §3.3 phases P1-P9, App. B.3-B.4):
+// primal-dual augmented-Lagrangian (ProxDDP, Jallet et al.) with BCL outer loop, Gauss-Newton Hessians,
+// proximal Riccati backward/forward sweep, ROLLOUT_LINEAR Armijo backtracking, forced initial condition
+// — the configuration the reference sets at fulldynamic_talos.py:374-386.
+// Upstream Aligator is not vendored (README.md:10) -> PARITY UNPINNED; the LQ step is cross-checked against
+// a dense KKT solve and the iteration against its own optimality conditions in tests/.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "stage.hpp"
+
+namespace orc {
+
+// ---------------------------------------------------------------------------------------------
+// small dense helpers (row-major)
+// ---------------------------------------------------------------------------------------------
+inline bool chol_lower(double* A, int n) {  // in place, lower triangle; returns false if not SPD
+  for (int j = 0; j < n; ++j) {
+    double d = A[j * n + j];
+    for (int k = 0; k < j; ++k) d -= A[j * n + k] * A[j * n + k];
+    if (!(d > 0.0)) return false;
+    d = std::sqrt(d);
+    A[j * n + j] = d;
+    for (int i = j + 1; i < n; ++i) {
+      double s = A[i * n + j];
+      for (int k = 0; k < j; ++k) s -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = s / d;
+    }
+  }
+  return true;
+}
+// solve L Y = B (forward), B is n x r
+inline void trsm_lower(const double* L, int n, double* B, int r) {
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < i; ++k) { const double l = L[i * n + k]; if (l != 0.0) for (int j = 0; j < r; ++j) B[i * r + j] -= l * B[k * r + j]; }
+    const double inv = 1.0 / L[i * n + i];
+    for (int j = 0; j < r; ++j) B[i * r + j] *= inv;
+  }
+}
+// solve L^T X = B (backward)
+inline void trsm_lower_t(const double* L, int n, double* B, int r) {
+  for (int i = n - 1; i >= 0; --i) {
+    for (int k = i + 1; k < n; ++k) { const double l = L[k * n + i]; if (l != 0.0) for (int j = 0; j < r; ++j) B[i * r + j] -= l * B[k * r + j]; }
+    const double inv = 1.0 / L[i * n + i];
+    for (int j = 0; j < r; ++j) B[i * r + j] *= inv;
+  }
+}
+inline void inv6(const double* A, double* Ainv) {
+  std::vector<double> M(A, A + 36), I(36, 0.0);
+  for (int i = 0; i < 6; ++i) I[i * 6 + i] = 1.0;
+  solve_dense(M, 6, I, 6);
+  std::memcpy(Ainv, I.data(), 36 * sizeof(double));
+}
+
+// projection of z on the normal cone of the constraint set of one row; returns value and active flag
+inline double proj_normal(int role, double z, double lo, double hi, bool& active) {
+  switch (role) {
+    case MPC_ROLE_EQUALITY: active = true; return z;
+    case MPC_ROLE_NEG_ORTHANT: active = z > 0.0; return active ? z : 0.0;
+    case MPC_ROLE_BOX:
+      if (z < lo) { active = true; return z - lo; }
+      if (z > hi) { active = true; return z - hi; }
+      active = false; return 0.0;
+  }
+  active = false;
+  return 0.0;
+}
+
+struct Gains {
+  std::vector<double> P, p, K, kff, Knu, knu, Mx, mx;
+  double T6[36];  // Ebar^{-1} base block (Ebar = -E6)
+};
+
+struct Instance {
+  std::vector<double> x0;
+  std::vector<std::vector<double>> xs, us, vs, lams, vs_e, lams_e;
+  std::vector<std::vector<double>> dxs, dus, dvs, dlams;
+  std::vector<std::vector<double>> txs, tus, tvs, tlams;  // trial point
+  std::vector<Knot> knots, tknots;
+  std::vector<Gains> gains;
+  double mu = 0, inner_tol = 0, prim_tol = 0;
+  mpc_stats stats{};
+};
+
+struct Solver {
+  mpc_dims dims{};
+  mpc_options opt{};
+  Model model;
+  std::vector<StageDesc> stages;  // N + 1
+  std::vector<Instance> inst;
+  std::string err;
+  bool have_model = false;
+
+  int N() const { return dims.horizon; }
+
+  void set_default_options() {
+    opt.tol = 1e-5; opt.mu_init = 1e-8; opt.dyn_al_scale = 1e-3; opt.reg_init = 1e-9;
+    opt.ls_armijo_c1 = 1e-4; opt.ls_alpha_min = 1e-7;
+    opt.bcl_prim_alpha = 0.1; opt.bcl_prim_beta = 0.9; opt.bcl_dual_alpha = 1.0; opt.bcl_dual_beta = 1.0;
+    opt.bcl_mu_update_factor = 0.01; opt.bcl_mu_lower_bound = 1e-8;
+    opt.inner_tol0 = 1.0; opt.prim_tol0 = 1.0;
+    opt.max_iters = 100; opt.max_al_iters = 100; opt.force_initial_condition = 1; opt.rollout_linear = 1;
+    opt.ls_max_steps = 8; opt.num_threads = 1; opt.riccati_legs = 1;
+  }
+
+  void init(const mpc_dims& d) {
+    dims = d;
+    set_default_options();
+    stages.assign(d.horizon + 1, StageDesc());
+    inst.assign(d.batch, Instance());
+    for (auto& in : inst) {
+      in.x0.assign(d.nx, 0.0);
+      alloc(in);
+    }
+  }
+  void alloc(Instance& in) {
+    const int N = dims.horizon;
+    auto mk = [&](std::vector<std::vector<double>>& v, int cnt, int len) { v.assign(cnt, std::vector<double>(len, 0.0)); };
+    mk(in.xs, N + 1, dims.nx); mk(in.us, N, dims.nu); mk(in.vs, N + 1, dims.nc_max); mk(in.lams, N + 1, dims.ndx);
+    mk(in.vs_e, N + 1, dims.nc_max); mk(in.lams_e, N + 1, dims.ndx);
+    mk(in.dxs, N + 1, dims.ndx); mk(in.dus, N, dims.nu); mk(in.dvs, N + 1, dims.nc_max); mk(in.dlams, N + 1, dims.ndx);
+    mk(in.txs, N + 1, dims.nx); mk(in.tus, N, dims.nu); mk(in.tvs, N + 1, dims.nc_max); mk(in.tlams, N + 1, dims.ndx);
+    in.knots.assign(N + 1, Knot()); in.tknots.assign(N + 1, Knot()); in.gains.assign(N + 1, Gains());
+  }
+
+  // ---- manifold ops -------------------------------------------------------------------------
+  void integrate(const double* x, const double* dx, double* out) const {
+    if (dims.space == MPC_SPACE_VECTOR) for (int i = 0; i < dims.nx; ++i) out[i] = x[i] + dx[i];
+    else mb_integrate(model, x, dx, out);
+  }
+
+  void eval_knot(int k, const double* x, const double* u, const double* xnext, Knot& kn, bool derivs) const {
+    const StageDesc& sd = stages[k];
+    if (sd.nc > dims.nc_max) throw std::runtime_error("stage has more constraint rows than nc_max");
+    if (dims.space == MPC_SPACE_VECTOR) eval_centroidal(sd, dims.nx, dims.nu, x, u, xnext, kn, derivs);
+    else eval_multibody(model, sd, dims.nu, x, u, xnext, kn, derivs);
+    if (derivs) {
+      const int nz = kn.n + kn.m;
+      for (int i = 0; i < nz; ++i) kn.H[i * nz + i] += opt.reg_init;
+    }
+  }
+
+  // P1 + P3: evaluate every knot of one instance (values, and derivatives when requested)
+  void evaluate(Instance& in, const std::vector<std::vector<double>>& xs, const std::vector<std::vector<double>>& us,
+                std::vector<Knot>& knots, bool derivs) const {
+    const int N = dims.horizon;
+    std::string omp_err;
+#pragma omp parallel for schedule(dynamic) num_threads(opt.num_threads > 0 ? opt.num_threads : 1)
+    for (int k = 0; k <= N; ++k) {
+      try {
+        eval_knot(k, xs[k].data(), k < N ? us[k].data() : nullptr, k < N ? xs[k + 1].data() : nullptr, knots[k], derivs);
+      } catch (const std::exception& e) {
+#pragma omp critical
+        omp_err = e.what();
+      }
+    }
+    if (!omp_err.empty()) throw std::runtime_error(omp_err);
+    (void)in;
+  }
+
+  double mu_dyn(const Instance& in) const { return in.mu * opt.dyn_al_scale; }
+
+  // P2 + merit: first-order multiplier estimates and primal-dual AL merit at (knots, vs, lams)
+  //   M = sum l + sum_k mu/2 |v+|^2 + mu/2 |v+ - v|^2 + sum_k mud/2 |l+|^2 + mud/2 |l+ - l|^2
+  double merit(const Instance& in, const std::vector<Knot>& knots, const std::vector<std::vector<double>>& vs,
+               const std::vector<std::vector<double>>& lams, double* cost_out = nullptr, double* prim_out = nullptr) const {
+    const int N = dims.horizon;
+    const double mu = in.mu, mud = mu_dyn(in);
+    double cost = 0, pen = 0, prim = 0;
+    for (int k = 0; k <= N; ++k) {
+      const Knot& kn = knots[k];
+      cost += kn.cost;
+      for (int i = 0; i < kn.c; ++i) {
+        bool act;
+        const double z = kn.cval[i] + mu * in.vs_e[k][i];
+        const double pn = proj_normal(kn.ctype[i], z, kn.lo[i], kn.hi[i], act);
+        const double vp = pn / mu;
+        pen += 0.5 * mu * vp * vp + 0.5 * mu * (vp - vs[k][i]) * (vp - vs[k][i]);
+        prim = std::max(prim, std::fabs(pn - mu * in.vs_e[k][i]));
+      }
+      if (k < N) {
+        for (int i = 0; i < kn.n; ++i) {
+          const double lp = in.lams_e[k + 1][i] + kn.f[i] / mud;
+          pen += 0.5 * mud * lp * lp + 0.5 * mud * (lp - lams[k + 1][i]) * (lp - lams[k + 1][i]);
+          prim = std::max(prim, std::fabs(kn.f[i]));
+        }
+      }
+    }
+    if (cost_out) *cost_out = cost;
+    if (prim_out) *prim_out = prim;
+    return cost + pen;
+  }
+
+  // P4: dual infeasibility (gradient of the Lagrangian) and inner criterion at the current iterate
+  void lagrangian_residuals(const Instance& in, double& dual_infeas, double& inner_crit) const {
+    const int N = dims.horizon, n = dims.ndx;
+    const double mu = in.mu, mud = mu_dyn(in);
+    dual_infeas = 0; inner_crit = 0;
+    for (int k = 0; k <= N; ++k) {
+      const Knot& kn = in.knots[k];
+      const int nz = kn.n + kn.m;
+      std::vector<double> L(kn.grad);
+      for (int i = 0; i < kn.c; ++i) { const double v = in.vs[k][i]; if (v != 0.0) for (int a = 0; a < nz; ++a) L[a] += kn.CD[i * nz + a] * v; }
+      if (k < N) for (int i = 0; i < n; ++i) { const double l = in.lams[k + 1][i]; if (l != 0.0) for (int a = 0; a < nz; ++a) L[a] += kn.AB[i * nz + a] * l; }
+      if (k > 0) {
+        // E_{k-1}^T lambda_k : E = blockdiag(E6, -I)
+        const Knot& kp = in.knots[k - 1];
+        std::vector<double> El(n);
+        for (int i = 0; i < n; ++i) El[i] = -in.lams[k][i];
+        if (dims.space == MPC_SPACE_MULTIBODY && model.has_freeflyer())
+          for (int j = 0; j < 6; ++j) { double s = 0; for (int i = 0; i < 6; ++i) s += kp.E6[i * 6 + j] * in.lams[k][i]; El[j] = s; }
+        for (int i = 0; i < n; ++i) L[i] += El[i];
+      }
+      const int a0 = (k == 0 && opt.force_initial_condition) ? kn.n : 0;  // x0 is fixed
+      for (int a = a0; a < nz; ++a) dual_infeas = std::max(dual_infeas, std::fabs(L[a]));
+      for (int i = 0; i < kn.c; ++i) {
+        bool act;
+        const double pn = proj_normal(kn.ctype[i], kn.cval[i] + mu * in.vs_e[k][i], kn.lo[i], kn.hi[i], act);
+        inner_crit = std::max(inner_crit, std::fabs(pn - mu * in.vs[k][i]));
+      }
+      if (k < N) for (int i = 0; i < n; ++i) inner_crit = std::max(inner_crit, std::fabs(kn.f[i] + mud * (in.lams_e[k + 1][i] - in.lams[k + 1][i])));
+    }
+    inner_crit = std::max(inner_crit, dual_infeas);
+  }
+
+  // P6: proximal Riccati backward sweep, unpivoted quasi-definite elimination
+  // (controls first, then constraint multipliers).
+  void backward(Instance& in) const {
+    const int N = dims.horizon, n = dims.ndx;
+    const double mu = in.mu, mud = mu_dyn(in);
+    const bool ff = dims.space == MPC_SPACE_MULTIBODY && model.has_freeflyer();
+    // terminal node
+    {
+      const Knot& kn = in.knots[N];
+      Gains& g = in.gains[N];
+      g.P.assign(kn.H.begin(), kn.H.end()); g.p.assign(kn.grad.begin(), kn.grad.end());
+      g.Knu.assign(kn.c * n, 0.0); g.knu.assign(kn.c, 0.0);
+      for (int i = 0; i < kn.c; ++i) {
+        bool act;
+        const double pn = proj_normal(kn.ctype[i], kn.cval[i] + mu * in.vs_e[N][i], kn.lo[i], kn.hi[i], act);
+        g.knu[i] = pn / mu;
+        if (!act) continue;
+        for (int a = 0; a < n; ++a) g.Knu[i * n + a] = kn.CD[i * n + a] / mu;
+        for (int a = 0; a < n; ++a) {
+          g.p[a] += kn.CD[i * n + a] * g.knu[i];
+          for (int b = 0; b < n; ++b) g.P[a * n + b] += kn.CD[i * n + a] * g.Knu[i * n + b];
+        }
+      }
+    }
+    for (int k = N - 1; k >= 0; --k) {
+      const Knot& kn = in.knots[k];
+      const Gains& gn = in.gains[k + 1];
+      Gains& g = in.gains[k];
+      const int m = kn.m, c = kn.c, nz = n + m;
+      // 1. change of variable y = Ebar x'
+      for (int i = 0; i < 36; ++i) g.T6[i] = (i % 7 == 0) ? 1.0 : 0.0;
+      std::vector<double> Ph(gn.P), ph(gn.p);
+      if (ff) {
+        double Eb[36];
+        for (int i = 0; i < 36; ++i) Eb[i] = -kn.E6[i];
+        inv6(Eb, g.T6);
+        // Ph = T^T P T, ph = T^T p with T = blockdiag(T6, I)
+        std::vector<double> tmp(n * n);
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j) {
+            if (j < 6) { double s = 0; for (int l = 0; l < 6; ++l) s += gn.P[i * n + l] * g.T6[l * 6 + j]; tmp[i * n + j] = s; }
+            else tmp[i * n + j] = gn.P[i * n + j];
+          }
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j) {
+            if (i < 6) { double s = 0; for (int l = 0; l < 6; ++l) s += g.T6[l * 6 + i] * tmp[l * n + j]; Ph[i * n + j] = s; }
+            else Ph[i * n + j] = tmp[i * n + j];
+          }
+        for (int i = 0; i < 6; ++i) { double s = 0; for (int l = 0; l < 6; ++l) s += g.T6[l * 6 + i] * gn.p[l]; ph[i] = s; }
+      }
+      // 2. Lam = (I + mud Ph)^-1 ; Pt = Lam Ph ; pt = Lam (Ph ft + ph)
+      std::vector<double> Lp(n * n);
+      for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Lp[i * n + j] = mud * 0.5 * (Ph[i * n + j] + Ph[j * n + i]) + (i == j ? 1.0 : 0.0);
+      if (!chol_lower(Lp.data(), n)) throw std::runtime_error("Riccati: I + mu_dyn P not positive definite");
+      std::vector<double> Pt(Ph), ft(n), w(n);
+      for (int i = 0; i < n; ++i) ft[i] = kn.f[i] + mud * in.lams_e[k + 1][i];
+      for (int i = 0; i < n; ++i) { double s = ph[i]; for (int j = 0; j < n; ++j) s += Ph[i * n + j] * ft[j]; w[i] = s; }
+      trsm_lower(Lp.data(), n, Pt.data(), n); trsm_lower_t(Lp.data(), n, Pt.data(), n);
+      trsm_lower(Lp.data(), n, w.data(), 1); trsm_lower_t(Lp.data(), n, w.data(), 1);
+      for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) { const double s = 0.5 * (Pt[i * n + j] + Pt[j * n + i]); Pt[i * n + j] = Pt[j * n + i] = s; }
+      // 3. Hh = H + AB^T Pt AB ; gh = grad + AB^T pt
+      std::vector<double> G(n * nz, 0.0), Hh(kn.H), gh(kn.grad);
+      for (int i = 0; i < n; ++i) for (int l = 0; l < n; ++l) { const double pv = Pt[i * n + l]; if (pv != 0.0) for (int a = 0; a < nz; ++a) G[i * nz + a] += pv * kn.AB[l * nz + a]; }
+      for (int i = 0; i < n; ++i)
+        for (int a = 0; a < nz; ++a) {
+          const double ab = kn.AB[i * nz + a];
+          if (ab == 0.0) continue;
+          gh[a] += ab * w[i];
+          for (int b = 0; b < nz; ++b) Hh[a * nz + b] += ab * G[i * nz + b];
+        }
+      // 4. stage KKT  [[R, D^T],[D, -mu I]] [U; V] = -[[S^T r],[C d]]
+      std::vector<double> Lr(m * m), Ct(c * nz, 0.0), dt_(c, 0.0);
+      for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Lr[i * m + j] = 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]);
+      if (!chol_lower(Lr.data(), m)) throw std::runtime_error("Riccati: reduced control Hessian not positive definite");
+      for (int i = 0; i < c; ++i) {
+        bool act;
+        dt_[i] = proj_normal(kn.ctype[i], kn.cval[i] + mu * in.vs_e[k][i], kn.lo[i], kn.hi[i], act);
+        if (act) for (int a = 0; a < nz; ++a) Ct[i * nz + a] = kn.CD[i * nz + a];
+      }
+      const int nr = n + 1;
+      std::vector<double> W(m * nr), Y(m * (c > 0 ? c : 1), 0.0);
+      for (int i = 0; i < m; ++i) { for (int a = 0; a < n; ++a) W[i * nr + a] = -Hh[(n + i) * nz + a]; W[i * nr + n] = -gh[n + i]; }
+      trsm_lower(Lr.data(), m, W.data(), nr);  // W = L^-1 T
+      std::vector<double> V(c * nr > 0 ? c * nr : 1, 0.0);
+      if (c > 0) {
+        for (int i = 0; i < m; ++i) for (int j = 0; j < c; ++j) Y[i * c + j] = Ct[j * nz + n + i];
+        trsm_lower(Lr.data(), m, Y.data(), c);  // Y = L^-1 D^T
+        std::vector<double> Sc(c * c, 0.0);
+        for (int i = 0; i < c; ++i) for (int j = 0; j < c; ++j) { double s = (i == j) ? mu : 0.0; for (int l = 0; l < m; ++l) s += Y[l * c + i] * Y[l * c + j]; Sc[i * c + j] = s; }
+        if (!chol_lower(Sc.data(), c)) throw std::runtime_error("Riccati: constraint Schur complement not positive definite");
+        // V = Sc^-1 (Y^T W - Bt),  Bt = -[C d]
+        for (int i = 0; i < c; ++i)
+          for (int a = 0; a < nr; ++a) {
+            double s = (a < n) ? Ct[i * nz + a] : dt_[i];
+            for (int l = 0; l < m; ++l) s += Y[l * c + i] * W[l * nr + a];
+            V[i * nr + a] = s;
+          }
+        trsm_lower(Sc.data(), c, V.data(), nr); trsm_lower_t(Sc.data(), c, V.data(), nr);
+        for (int l = 0; l < m; ++l) for (int a = 0; a < nr; ++a) { double s = 0; for (int i = 0; i < c; ++i) s += Y[l * c + i] * V[i * nr + a]; W[l * nr + a] -= s; }
+      }
+      trsm_lower_t(Lr.data(), m, W.data(), nr);  // U = L^-T (W - Y V)
+      g.K.assign(m * n, 0.0); g.kff.assign(m, 0.0); g.Knu.assign(c * n, 0.0); g.knu.assign(c, 0.0);
+      for (int i = 0; i < m; ++i) { for (int a = 0; a < n; ++a) g.K[i * n + a] = W[i * nr + a]; g.kff[i] = W[i * nr + n]; }
+      for (int i = 0; i < c; ++i) { for (int a = 0; a < n; ++a) g.Knu[i * n + a] = V[i * nr + a]; g.knu[i] = V[i * nr + n]; }
+      // 5. value function  P = Qh + Sh K + C^T Knu ,  p = qh + Sh k + C^T knu
+      g.P.assign(n * n, 0.0); g.p.assign(n, 0.0);
+      for (int a = 0; a < n; ++a) {
+        double s = gh[a];
+        for (int i = 0; i < m; ++i) s += Hh[a * nz + n + i] * g.kff[i];
+        for (int i = 0; i < c; ++i) s += Ct[i * nz + a] * g.knu[i];
+        g.p[a] = s;
+        for (int b = 0; b < n; ++b) {
+          double t = Hh[a * nz + b];
+          for (int i = 0; i < m; ++i) t += Hh[a * nz + n + i] * g.K[i * n + b];
+          for (int i = 0; i < c; ++i) t += Ct[i * nz + a] * g.Knu[i * n + b];
+          g.P[a * n + b] = t;
+        }
+      }
+      for (int a = 0; a < n; ++a) for (int b = a + 1; b < n; ++b) { const double s = 0.5 * (g.P[a * n + b] + g.P[b * n + a]); g.P[a * n + b] = g.P[b * n + a] = s; }
+      // 6. closed-loop next-state map  x' = T Lam (A x + B u + ft - mud ph)  =  Mx x + mx
+      std::vector<double> Acl((size_t)n * nr, 0.0);
+      for (int i = 0; i < n; ++i) {
+        for (int a = 0; a < n; ++a) { double s = kn.AB[i * nz + a]; for (int l = 0; l < m; ++l) s += kn.AB[i * nz + n + l] * g.K[l * n + a]; Acl[i * nr + a] = s; }
+        double s = ft[i] - mud * ph[i];
+        for (int l = 0; l < m; ++l) s += kn.AB[i * nz + n + l] * g.kff[l];
+        Acl[i * nr + n] = s;
+      }
+      trsm_lower(Lp.data(), n, Acl.data(), nr); trsm_lower_t(Lp.data(), n, Acl.data(), nr);
+      if (ff) {
+        std::vector<double> top(6 * nr);
+        for (int i = 0; i < 6; ++i) for (int a = 0; a < nr; ++a) { double s2 = 0; for (int l = 0; l < 6; ++l) s2 += g.T6[i * 6 + l] * Acl[l * nr + a]; top[i * nr + a] = s2; }
+        std::memcpy(Acl.data(), top.data(), 6 * nr * sizeof(double));
+      }
+      g.Mx.assign(n * n, 0.0); g.mx.assign(n, 0.0);
+      for (int i = 0; i < n; ++i) { for (int a = 0; a < n; ++a) g.Mx[i * n + a] = Acl[i * nr + a]; g.mx[i] = Acl[i * nr + n]; }
+    }
+  }
+
+  // P7: forward sweep -> steps (dx, du) and NEW multipliers, converted to increments
+  void forward(Instance& in) const {
+    const int N = dims.horizon, n = dims.ndx;
+    const bool ff = dims.space == MPC_SPACE_MULTIBODY && model.has_freeflyer();
+    std::fill(in.dxs[0].begin(), in.dxs[0].end(), 0.0);  // force_initial_condition
+    std::fill(in.dlams[0].begin(), in.dlams[0].end(), 0.0);
+    for (int k = 0; k <= N; ++k) {
+      const Gains& g = in.gains[k];
+      const Knot& kn = in.knots[k];
+      const double* dx = in.dxs[k].data();
+      for (int i = 0; i < kn.c; ++i) { double s = g.knu[i]; for (int a = 0; a < n; ++a) s += g.Knu[i * n + a] * dx[a]; in.dvs[k][i] = s - in.vs[k][i]; }
+      for (int i = kn.c; i < dims.nc_max; ++i) in.dvs[k][i] = 0.0;
+      if (k == N) break;
+      for (int i = 0; i < kn.m; ++i) { double s = g.kff[i]; for (int a = 0; a < n; ++a) s += g.K[i * n + a] * dx[a]; in.dus[k][i] = s; }
+      double* dxn = in.dxs[k + 1].data();
+      for (int i = 0; i < n; ++i) { double s = g.mx[i]; for (int a = 0; a < n; ++a) s += g.Mx[i * n + a] * dx[a]; dxn[i] = s; }
+      const Gains& gn = in.gains[k + 1];
+      std::vector<double> l(n);
+      for (int i = 0; i < n; ++i) { double s = gn.p[i]; for (int a = 0; a < n; ++a) s += gn.P[i * n + a] * dxn[a]; l[i] = s; }
+      if (ff) { double t[6]; for (int i = 0; i < 6; ++i) { double s = 0; for (int a = 0; a < 6; ++a) s += g.T6[a * 6 + i] * l[a]; t[i] = s; } for (int i = 0; i < 6; ++i) l[i] = t[i]; }
+      for (int i = 0; i < n; ++i) in.dlams[k + 1][i] = l[i] - in.lams[k + 1][i];
+    }
+  }
+
+  // directional derivative of the merit along the step
+  double dmerit(const Instance& in) const {
+    const int N = dims.horizon, n = dims.ndx;
+    const double mu = in.mu, mud = mu_dyn(in);
+    const bool ff = dims.space == MPC_SPACE_MULTIBODY && model.has_freeflyer();
+    double d = 0;
+    for (int k = 0; k <= N; ++k) {
+      const Knot& kn = in.knots[k];
+      const int nz = kn.n + kn.m;
+      std::vector<double> dz(nz);
+      for (int a = 0; a < kn.n; ++a) dz[a] = in.dxs[k][a];
+      for (int a = 0; a < kn.m; ++a) dz[kn.n + a] = in.dus[k][a];
+      for (int a = 0; a < nz; ++a) d += kn.grad[a] * dz[a];
+      for (int i = 0; i < kn.c; ++i) {
+        bool act;
+        const double pn = proj_normal(kn.ctype[i], kn.cval[i] + mu * in.vs_e[k][i], kn.lo[i], kn.hi[i], act);
+        const double vp = pn / mu, v = in.vs[k][i];
+        double jd = 0;
+        for (int a = 0; a < nz; ++a) jd += kn.CD[i * nz + a] * dz[a];
+        d += (vp + (act ? (vp - v) : 0.0)) * jd - mu * (vp - v) * in.dvs[k][i];
+      }
+      if (k < N) {
+        for (int i = 0; i < n; ++i) {
+          const double lp = in.lams_e[k + 1][i] + kn.f[i] / mud, l = in.lams[k + 1][i];
+          double jd = 0;
+          for (int a = 0; a < nz; ++a) jd += kn.AB[i * nz + a] * dz[a];
+          if (ff && i < 6) { for (int a = 0; a < 6; ++a) jd += kn.E6[i * 6 + a] * in.dxs[k + 1][a]; }
+          else jd -= in.dxs[k + 1][i];
+          d += (2 * lp - l) * jd - mud * (lp - l) * in.dlams[k + 1][i];
+        }
+      }
+    }
+    return d;
+  }
+
+  void make_trial(Instance& in, double alpha) const {
+    const int N = dims.horizon;
+    std::vector<double> sd(dims.ndx);
+    for (int k = 0; k <= N; ++k) {
+      for (int i = 0; i < dims.ndx; ++i) sd[i] = alpha * in.dxs[k][i];
+      integrate(in.xs[k].data(), sd.data(), in.txs[k].data());
+      for (int i = 0; i < dims.nc_max; ++i) in.tvs[k][i] = in.vs[k][i] + alpha * in.dvs[k][i];
+      for (int i = 0; i < dims.ndx; ++i) in.tlams[k][i] = in.lams[k][i] + alpha * in.dlams[k][i];
+      if (k < N) for (int i = 0; i < dims.nu; ++i) in.tus[k][i] = in.us[k][i] + alpha * in.dus[k][i];
+    }
+  }
+
+  void update_tols_on_failure(Instance& in) const {
+    in.prim_tol = opt.prim_tol0 * std::pow(in.mu, opt.bcl_prim_alpha);
+    in.inner_tol = opt.inner_tol0 * std::pow(in.mu, opt.bcl_dual_alpha);
+  }
+  void update_tols_on_success(Instance& in) const {
+    in.prim_tol *= std::pow(in.mu, opt.bcl_prim_beta);
+    in.inner_tol *= std::pow(in.mu, opt.bcl_dual_beta);
+  }
+
+  void setup() {
+    for (auto& in : inst) {
+      in.mu = opt.mu_init;
+      for (auto& v : in.vs) std::fill(v.begin(), v.end(), 0.0);
+      for (auto& v : in.lams) std::fill(v.begin(), v.end(), 0.0);
+      for (auto& v : in.vs_e) std::fill(v.begin(), v.end(), 0.0);
+      for (auto& v : in.lams_e) std::fill(v.begin(), v.end(), 0.0);
+      in.stats = mpc_stats{};
+    }
+  }
+
+  // one inner iteration; returns true if the inner criterion was already met (no step taken)
+  bool iterate(Instance& in) {
+    evaluate(in, in.xs, in.us, in.knots, true);
+    double cost, prim, dual, crit;
+    const double phi0 = merit(in, in.knots, in.vs, in.lams, &cost, &prim);
+    lagrangian_residuals(in, dual, crit);
+    in.stats.traj_cost = cost; in.stats.merit = phi0; in.stats.prim_infeas = prim; in.stats.dual_infeas = dual; in.stats.mu = in.mu;
+    if (crit <= in.inner_tol) return true;
+    backward(in);
+    forward(in);
+    const double dphi0 = dmerit(in);
+    double alpha = 1.0, phi = 0.0;
+    int step = 0;
+    for (;; ++step) {
+      make_trial(in, alpha);
+      evaluate(in, in.txs, in.tus, in.tknots, false);
+      phi = merit(in, in.tknots, in.tvs, in.tlams);
+      if (phi <= phi0 + opt.ls_armijo_c1 * alpha * dphi0) break;
+      if (step + 1 >= opt.ls_max_steps || 0.5 * alpha < opt.ls_alpha_min) break;
+      alpha *= 0.5;
+    }
+    in.xs.swap(in.txs); in.us.swap(in.tus); in.vs.swap(in.tvs); in.lams.swap(in.tlams);
+    in.stats.alpha = alpha; in.stats.ls_steps = step; in.stats.num_iters += 1;
+    return false;
+  }
+
+  // SolverProxDDP::run for one instance (xs/us already installed)
+  void run_instance(Instance& in) {
+    if (opt.force_initial_condition) in.xs[0] = in.x0;
+    in.stats.num_iters = 0; in.stats.converged = 0; in.stats.al_iters = 0;
+    update_tols_on_failure(in);
+    in.inner_tol = std::max(in.inner_tol, opt.tol); in.prim_tol = std::max(in.prim_tol, opt.tol);
+    while (in.stats.al_iters < opt.max_al_iters && in.stats.num_iters < opt.max_iters) {
+      bool inner_conv = false;
+      while (in.stats.num_iters < opt.max_iters) {
+        if (iterate(in)) { inner_conv = true; break; }
+      }
+      if (!inner_conv) break;
+      if (in.stats.prim_infeas <= in.prim_tol) {
+        update_tols_on_success(in);
+        in.vs_e = in.vs; in.lams_e = in.lams;
+        if (std::max(in.stats.prim_infeas, in.stats.dual_infeas) <= opt.tol) { in.stats.converged = 1; break; }
+      } else {
+        in.mu = std::max(in.mu * opt.bcl_mu_update_factor, opt.bcl_mu_lower_bound);
+        update_tols_on_failure(in);
+      }
+      in.inner_tol = std::max(in.inner_tol, opt.tol); in.prim_tol = std::max(in.prim_tol, opt.tol);
+      in.stats.al_iters += 1;
+    }
+    in.stats.mu = in.mu;
+  }
+};
+
+}  // namespace orc

@@ -1,0 +1,30 @@
+"""Test-side loader of the CPU oracle (oracle/libmpc_oracle.so).  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may use this; the product package never imports it."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libmpc_oracle.so")
+
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".hpp"))]
+        stale = (not os.path.exists(ORACLE_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in srcs)
+        if stale:
+            try:
+                build()
+            except Exception:
+                if not os.path.exists(ORACLE_LIB):
+                    raise
+        from mpc_benchmark_amd import _capi
+        _lib = _capi.bind_library(ORACLE_LIB)
+    return _lib
