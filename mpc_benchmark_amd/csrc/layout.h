@@ -1,0 +1,53 @@
+// layout.h — HBM data layout of the MI355X ProxDDP solver (see DESIGN.md §"Data layout in HBM").
+// Everything is fp64, row-major, batch-major: [instance][knot][block].  One LQ knot record holds what the
+// per-knot evaluation kernel produces and the Riccati kernel consumes; one gain record
+// holds what the backward sweep produces and the forward sweep consumes (K8/K9).
+#pragma once
+#include <stdint.h>
+
+struct Layout {
+  int N, B, space, nx, n, m, c, nz;
+  int nj;  // moving joints of the multibody model (0 for vector spaces)
+  // offsets inside one knot record (doubles)
+  int oH, oG, oAB, oF, oE6, oCV, oCD, oLO, oHI, oDT, oACT, oCT, oMISC, oXD, oWR, oXN, knot_stride;
+  // offsets inside one gain record
+  int oP, op, oK, ok, oKnu, oknu, oMx, omx, oT6, gain_stride;
+  // backward-sweep scratch per instance
+  int wPh, wPt, wLp, wG, wHh, wgh, wCt, wW, wY, wSc, wV, wAcl, wvec, work_stride;
+  int max_stage_ints, max_stage_doubles;
+  int n_alpha;  // number of linesearch candidates evaluated per iteration
+  int sc_cap;   // active-constraint Schur complements up to sc_cap x sc_cap are factorised in LDS, larger ones in HBM scratch
+};
+
+// misc slots of a knot record
+enum { MISC_COST = 0, MISC_PEN = 1, MISC_PRIM = 2, MISC_NC = 3, MISC_M = 4, MISC_DUAL = 5, MISC_CRIT = 6, MISC_DMERIT = 7, MISC_COUNT = 8 };
+
+// per-instance solver state kept on the device (the BCL outer loop runs there)
+struct InstState {
+  double mu, inner_tol, prim_tol;
+  double phi0, dphi0, alpha, cost, prim, dual, crit;
+  int32_t num_iters, al_iters, converged, done, skip_step, ls_step, pad0, pad1;
+};
+
+static inline int align2(int x) { return (x + 1) & ~1; }
+
+static inline void make_layout(Layout& L) {
+  const int n = L.n, m = L.m, c = L.c, nz = L.nz = n + m;
+  int o = 0;
+  auto take = [&](int cnt) { int r = o; o += align2(cnt); return r; };
+  L.oH = take(nz * nz); L.oG = take(nz); L.oAB = take(n * nz); L.oF = take(n); L.oE6 = take(36);
+  L.oCV = take(c); L.oCD = take(c * nz); L.oLO = take(c); L.oHI = take(c); L.oDT = take(c); L.oACT = take(c); L.oCT = take(c);
+  L.oMISC = take(MISC_COUNT); L.oXD = take(n); L.oWR = take(12); L.oXN = take(L.nx);
+  L.knot_stride = o;
+  o = 0;
+  L.oP = take(n * n); L.op = take(n); L.oK = take(m * n); L.ok = take(m); L.oKnu = take(c * n); L.oknu = take(c);
+  L.oMx = take(n * n); L.omx = take(n); L.oT6 = take(36);
+  L.gain_stride = o;
+  o = 0;
+  const int nr = n + 1;
+  L.wPh = take(n * n); L.wPt = take(n * n); L.wLp = take(n * n); L.wG = take(n * nz); L.wHh = take(nz * nz); L.wgh = take(nz);
+  L.wCt = take(c * nz); L.wW = take(m * nr); L.wY = take(m * c); L.wSc = take(c * c); L.wV = take(c * nr); L.wAcl = take(n * nr);
+  L.wvec = take(8 * (nz + c));
+  L.work_stride = o;
+  L.sc_cap = c < 48 ? c : 48;
+}

@@ -1,0 +1,428 @@
+// mpc_hip.hip — the product library: C-ABI of include/mpc_abi.h on top of hand-written HIP kernels for
+// gfx950 (MI355X).  Host side = thin orchestration (allocation, table upload, kernel sequence of one
+// ProxDDP iteration, result download); every floating-point operation of the hot path runs on the device.
+// There is no CPU fallback in this file: any HIP failure is reported through the return code.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "eval_multibody.h"
+#include "eval_vector.h"
+
+#define HIP_OK(expr)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+struct mpc_solver {
+  mpc_dims dims{};
+  mpc_options opt{};
+  Layout L{}, LT{};
+  int head = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // device buffers
+  int32_t* d_stage_desc = nullptr;
+  double* d_stage_params = nullptr;
+  int32_t* d_model_i = nullptr;
+  double* d_model_d = nullptr;
+  double *d_xs = nullptr, *d_us = nullptr, *d_vs = nullptr, *d_lams = nullptr, *d_vs_e = nullptr, *d_lams_e = nullptr, *d_x0 = nullptr;
+  double *d_dxs = nullptr, *d_dus = nullptr, *d_dvs = nullptr, *d_dlams = nullptr;
+  double *d_knots = nullptr, *d_tknots = nullptr, *d_gains = nullptr, *d_work = nullptr, *d_trial_phi = nullptr, *d_mbwork = nullptr;
+  InstState* d_inst = nullptr;
+  int* d_all_done = nullptr;
+  std::vector<void*> allocs;
+  // host mirrors of the stage tables (needed for ring-buffer bookkeeping and debug)
+  std::vector<int32_t> h_desc;
+  std::vector<int> h_model_i;
+  bool have_model = false;
+  size_t mb_work_stride = 0;
+
+  template <class T> T* alloc(size_t count) {
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, count * sizeof(T) + 64));
+    HIP_OK(hipMemsetAsync(p, 0, count * sizeof(T) + 64, stream));
+    allocs.push_back(p);
+    return (T*)p;
+  }
+
+  SolverArgs args() const {
+    SolverArgs a;
+    a.L = L; a.opt = opt; a.head = head;
+    a.stage_desc = d_stage_desc; a.stage_params = d_stage_params; a.model_i = d_model_i; a.model_d = d_model_d;
+    a.xs = d_xs; a.us = d_us; a.vs = d_vs; a.lams = d_lams; a.vs_e = d_vs_e; a.lams_e = d_lams_e; a.x0 = d_x0;
+    a.dxs = d_dxs; a.dus = d_dus; a.dvs = d_dvs; a.dlams = d_dlams;
+    a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done;
+    return a;
+  }
+  size_t riccati_lds() const {
+    return ((size_t)L.n * L.n + (size_t)L.m * L.m + (size_t)L.sc_cap * L.sc_cap) * sizeof(double) + ((size_t)L.c + 4) * sizeof(int);
+  }
+};
+
+static void create_impl(mpc_solver* s, const mpc_dims& d) {
+  s->dims = d;
+  HIP_OK(hipSetDevice(d.device));
+  HIP_OK(hipStreamCreate(&s->stream));
+  Layout& L = s->L;
+  L.N = d.horizon; L.B = d.batch; L.space = d.space; L.nx = d.nx; L.n = d.ndx; L.m = d.nu; L.c = d.nc_max > 0 ? d.nc_max : 1;
+  L.nj = 0;
+  L.max_stage_ints = d.max_stage_ints; L.max_stage_doubles = d.max_stage_doubles;
+  L.n_alpha = 8;
+  make_layout(L);
+  // compact record for linesearch candidates: only what the value-only pass writes
+  Layout& T = s->LT;
+  T = L;
+  {
+    int o = 0;
+    auto take = [&](int cnt) { int r = o; o += align2(cnt); return r; };
+    T.oCV = take(L.c); T.oCT = take(L.c); T.oLO = take(L.c); T.oHI = take(L.c); T.oDT = take(L.c); T.oACT = take(L.c);
+    T.oF = take(L.n); T.oMISC = take(MISC_COUNT);
+    T.oH = T.oG = T.oAB = T.oE6 = T.oCD = T.oXD = T.oWR = T.oXN = 0;  // never written in value-only mode
+    T.knot_stride = o;
+  }
+  if (s->riccati_lds() > 160 * 1024) throw std::runtime_error("problem dimensions exceed the LDS budget of the Riccati kernel");
+  const size_t B = d.batch, N1 = d.horizon + 1, N = d.horizon;
+  s->d_stage_desc = s->alloc<int32_t>(N1 * L.max_stage_ints);
+  s->d_stage_params = s->alloc<double>(N1 * L.max_stage_doubles);
+  s->d_xs = s->alloc<double>(B * N1 * L.nx); s->d_us = s->alloc<double>(B * N * L.m + 1);
+  s->d_vs = s->alloc<double>(B * N1 * L.c); s->d_lams = s->alloc<double>(B * (N1 + 1) * L.n);
+  s->d_vs_e = s->alloc<double>(B * N1 * L.c); s->d_lams_e = s->alloc<double>(B * (N1 + 1) * L.n);
+  s->d_x0 = s->alloc<double>(B * L.nx);
+  s->d_dxs = s->alloc<double>(B * (N1 + 1) * L.n); s->d_dus = s->alloc<double>(B * N * L.m + 1);
+  s->d_dvs = s->alloc<double>(B * N1 * L.c); s->d_dlams = s->alloc<double>(B * (N1 + 1) * L.n);
+  s->d_knots = s->alloc<double>(B * N1 * L.knot_stride);
+  s->d_tknots = s->alloc<double>(B * L.n_alpha * N1 * T.knot_stride);
+  s->d_gains = s->alloc<double>(B * N1 * L.gain_stride);
+  s->d_work = s->alloc<double>(B * L.work_stride);
+  s->d_trial_phi = s->alloc<double>(B * L.n_alpha * N1);
+  s->d_inst = s->alloc<InstState>(B);
+  s->d_all_done = s->alloc<int>(4);
+  s->h_desc.assign(N1 * L.max_stage_ints, 0);
+  // default options
+  mpc_options& o = s->opt;
+  o.tol = 1e-5; o.mu_init = 1e-8; o.dyn_al_scale = 1e-3; o.reg_init = 1e-9; o.ls_armijo_c1 = 1e-4; o.ls_alpha_min = 1e-7;
+  o.bcl_prim_alpha = 0.1; o.bcl_prim_beta = 0.9; o.bcl_dual_alpha = 1.0; o.bcl_dual_beta = 1.0;
+  o.bcl_mu_update_factor = 0.01; o.bcl_mu_lower_bound = 1e-8; o.inner_tol0 = 1.0; o.prim_tol0 = 1.0;
+  o.max_iters = 100; o.max_al_iters = 100; o.force_initial_condition = 1; o.rollout_linear = 1; o.ls_max_steps = 8;
+  o.num_threads = 1; o.riccati_legs = 1; o.reserved = 0;
+  HIP_OK(hipFuncSetAttribute((const void*)k_riccati_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  HIP_OK(hipStreamSynchronize(s->stream));
+}
+
+static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_desc, const double* params, int n_params) {
+  const Layout& L = s->L;
+  if (n_desc > L.max_stage_ints || n_params > L.max_stage_doubles) throw std::runtime_error("stage table exceeds the capacity given at mpc_create");
+  if (n_desc < MPC_STAGE_HEADER_WORDS || n_desc < MPC_STAGE_HEADER_WORDS + MPC_TERM_WORDS * desc[5]) throw std::runtime_error("stage descriptor truncated");
+  if (desc[6] > L.c) throw std::runtime_error("stage has more constraint rows than nc_max");
+  int nc = 0;
+  for (int t = 0; t < desc[5]; ++t) {
+    const int32_t* w = desc + MPC_STAGE_HEADER_WORDS + MPC_TERM_WORDS * t;
+    if (w[1] != MPC_ROLE_COST) nc += w[2];
+    if (w[2] > 24 && s->dims.space == MPC_SPACE_VECTOR) throw std::runtime_error("residual dimension too large for the vector-space kernel");
+  }
+  if (nc != desc[6]) throw std::runtime_error("stage descriptor: constraint row count mismatch");
+  std::memcpy(s->h_desc.data() + (size_t)slot * L.max_stage_ints, desc, n_desc * sizeof(int32_t));
+  HIP_OK(hipMemcpyAsync(s->d_stage_desc + (size_t)slot * L.max_stage_ints, desc, n_desc * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+  if (n_params > 0)
+    HIP_OK(hipMemcpyAsync(s->d_stage_params + (size_t)slot * L.max_stage_doubles, params, n_params * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIP_OK(hipStreamSynchronize(s->stream));  // host buffers are not retained past the call
+}
+
+static int slot_of(const mpc_solver* s, int k) { return k < s->L.N ? (s->head + k) % s->L.N : s->L.N; }
+
+// ---- kernel sequences -----------------------------------------------------------------------------
+static void launch_eval(mpc_solver* s, bool trial) {
+  const Layout& L = s->L;
+  SolverArgs a = s->args();
+  if (L.space == MPC_SPACE_VECTOR) {
+    if (!trial) hipLaunchKernelGGL(k_eval_vector<0>, dim3(L.N + 1, L.B, 1), dim3(64), 0, s->stream, a, s->L, s->d_knots);
+    else hipLaunchKernelGGL(k_eval_vector<1>, dim3(L.N + 1, L.B, L.n_alpha), dim3(64), 0, s->stream, a, s->LT, s->d_tknots);
+  } else {
+    launch_eval_multibody(s->stream, a, s->LT, trial ? s->d_tknots : s->d_knots, s->d_mbwork, s->mb_work_stride, trial);
+  }
+  HIP_OK(hipGetLastError());
+}
+
+// one pass of the inner loop for every instance that is not done
+static void launch_pass(mpc_solver* s) {
+  const Layout& L = s->L;
+  SolverArgs a = s->args();
+  HIP_OK(hipMemsetAsync(s->d_all_done, 0xff, sizeof(int), s->stream));  // all_done = -1 (true) unless cleared
+  launch_eval(s, false);
+  hipLaunchKernelGGL(k_lagrangian, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a);
+  hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(1), 0, s->stream, a);
+  hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);
+  hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(128), 2 * L.n * sizeof(double), s->stream, a);
+  hipLaunchKernelGGL(k_duals, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a);
+  launch_eval(s, true);
+  hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(1), 0, s->stream, a);
+  hipLaunchKernelGGL(k_accept, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a);
+  hipLaunchKernelGGL(k_after_step, dim3(L.B), dim3(1), 0, s->stream, a);
+  HIP_OK(hipGetLastError());
+}
+
+static void run_impl(mpc_solver* s, mpc_stats* stats) {
+  const Layout& L = s->L;
+  SolverArgs a = s->args();
+  hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, a);
+  const int max_passes = s->opt.max_iters + s->opt.max_al_iters + 1;
+  for (int pass = 0; pass < max_passes; ++pass) {
+    launch_pass(s);
+    int done = 0;
+    HIP_OK(hipMemcpyAsync(&done, s->d_all_done, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    if (done != 0) break;
+  }
+  std::vector<InstState> st(L.B);
+  HIP_OK(hipMemcpy(st.data(), s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost));
+  for (int b = 0; b < L.B; ++b) {
+    if (st[b].done >= 2) throw std::runtime_error("Riccati factorisation failed on instance " + std::to_string(b) + " (code " + std::to_string(st[b].done) + ")");
+    if (!stats) continue;
+    mpc_stats& o = stats[b];
+    o.num_iters = st[b].num_iters; o.converged = st[b].converged; o.al_iters = st[b].al_iters; o.ls_steps = st[b].ls_step;
+    o.traj_cost = st[b].cost; o.merit = st[b].phi0; o.prim_infeas = st[b].prim; o.dual_infeas = st[b].dual; o.mu = st[b].mu; o.alpha = st[b].alpha;
+  }
+}
+
+#define MPC_TRY(h, ...)                 \
+  try {                                 \
+    __VA_ARGS__;                        \
+    return 0;                           \
+  } catch (const std::exception& e) {   \
+    if (h) (h)->err = e.what();         \
+    return -1;                          \
+  }
+
+extern "C" {
+
+int mpc_abi_version(void) { return MPC_ABI_VERSION; }
+const char* mpc_backend_name(void) { return "hip-gfx950"; }
+
+int mpc_create(const mpc_dims* dims, mpc_solver** out) {
+  if (!dims || !out) return -2;
+  mpc_solver* s = new mpc_solver();
+  try {
+    create_impl(s, *dims);
+    *out = s;
+    return 0;
+  } catch (const std::exception& e) {
+    fprintf(stderr, "mpc_create: %s\n", e.what());
+    for (void* p : s->allocs) (void)hipFree(p);
+    delete s;
+    return -1;
+  }
+}
+
+void mpc_destroy(mpc_solver* s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s->stream);
+  for (void* p : s->allocs) (void)hipFree(p);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+const char* mpc_last_error(mpc_solver* s) { return s ? s->err.c_str() : "null handle"; }
+
+int mpc_set_options(mpc_solver* s, const mpc_options* opt) {
+  MPC_TRY(s, {
+    if (!opt->rollout_linear || !opt->force_initial_condition) throw std::runtime_error("only ROLLOUT_LINEAR with force_initial_condition is implemented");
+    s->opt = *opt;
+    if (s->opt.ls_max_steps > s->L.n_alpha) s->opt.ls_max_steps = s->L.n_alpha;
+  })
+}
+
+int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double* dtab, int32_t n_d) {
+  MPC_TRY(s, {
+    if (n_i < MPC_MODEL_HEADER_WORDS) throw std::runtime_error("model table too short");
+    const int nj = itab[0], nf = itab[3], ncn = itab[4];
+    if (n_i < MPC_MODEL_HEADER_WORDS + MPC_MODEL_JOINT_WORDS * nj + nf + ncn ||
+        n_d < MPC_MODEL_HEADER_DOUBLES + MPC_MODEL_JOINT_DOUBLES * nj + MPC_MODEL_FRAME_DOUBLES * nf + MPC_MODEL_CONTACT_DOUBLES * ncn)
+      throw std::runtime_error("model table size mismatch");
+    HIP_OK(hipStreamSynchronize(s->stream));
+    s->d_model_i = s->alloc<int32_t>(n_i);
+    s->d_model_d = s->alloc<double>(n_d);
+    HIP_OK(hipMemcpy(s->d_model_i, itab, n_i * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(s->d_model_d, dtab, n_d * sizeof(double), hipMemcpyHostToDevice));
+    s->h_model_i.assign(itab, itab + n_i);
+    s->L.nj = nj; s->LT.nj = nj;
+    if (s->dims.space == MPC_SPACE_MULTIBODY) {
+      if (itab[2] * 2 != s->L.n || itab[1] + itab[2] != s->L.nx) throw std::runtime_error("model dimensions do not match the state space");
+      check_multibody_model(itab, n_i);
+      if (!s->d_mbwork) {
+        s->mb_work_stride = multibody_work_doubles(s->L);
+        s->d_mbwork = s->alloc<double>((size_t)s->L.B * s->L.n_alpha * (s->L.N + 1) * 1 + 8);  // placeholder: kernel keeps its state in LDS
+      }
+    }
+    s->have_model = true;
+    HIP_OK(hipStreamSynchronize(s->stream));
+  })
+}
+
+int mpc_set_stage(mpc_solver* s, int32_t k, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params) {
+  MPC_TRY(s, {
+    if (k < 0 || k > s->L.N) throw std::runtime_error("stage index out of range");
+    upload_stage(s, slot_of(s, k), desc, n_desc, params, n_params);
+  })
+}
+
+int mpc_update_stage_params(mpc_solver* s, int32_t k, int32_t offset, const double* vals, int32_t n) {
+  MPC_TRY(s, {
+    if (k < 0 || k > s->L.N) throw std::runtime_error("stage index out of range");
+    if (offset < 0 || offset + n > s->L.max_stage_doubles) throw std::runtime_error("parameter update out of range");
+    HIP_OK(hipMemcpyAsync(s->d_stage_params + (size_t)slot_of(s, k) * s->L.max_stage_doubles + offset, vals, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+  })
+}
+
+int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params) {
+  MPC_TRY(s, {
+    // the slot of stage 0 is recycled for the new last stage: no data movement, only the ring head moves
+    const int slot = s->head;
+    upload_stage(s, slot, desc, n_desc, params, n_params);
+    s->head = (s->head + 1) % s->L.N;
+  })
+}
+
+int mpc_set_x0(mpc_solver* s, const double* x0) {
+  MPC_TRY(s, {
+    HIP_OK(hipMemcpyAsync(s->d_x0, x0, (size_t)s->L.B * s->L.nx * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+  })
+}
+
+int mpc_setup(mpc_solver* s) {
+  MPC_TRY(s, {
+    const Layout& L = s->L;
+    const size_t B = L.B, N1 = L.N + 1;
+    HIP_OK(hipMemsetAsync(s->d_vs, 0, B * N1 * L.c * sizeof(double), s->stream));
+    HIP_OK(hipMemsetAsync(s->d_vs_e, 0, B * N1 * L.c * sizeof(double), s->stream));
+    HIP_OK(hipMemsetAsync(s->d_lams, 0, B * (N1 + 1) * L.n * sizeof(double), s->stream));
+    HIP_OK(hipMemsetAsync(s->d_lams_e, 0, B * (N1 + 1) * L.n * sizeof(double), s->stream));
+    std::vector<InstState> st(B);
+    std::memset(st.data(), 0, B * sizeof(InstState));
+    for (auto& i : st) i.mu = s->opt.mu_init;
+    HIP_OK(hipMemcpyAsync(s->d_inst, st.data(), B * sizeof(InstState), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+  })
+}
+
+int mpc_run(mpc_solver* s, const double* xs, const double* us, mpc_stats* stats) {
+  MPC_TRY(s, {
+    const Layout& L = s->L;
+    HIP_OK(hipMemcpyAsync(s->d_xs, xs, (size_t)L.B * (L.N + 1) * L.nx * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipMemcpyAsync(s->d_us, us, (size_t)L.B * L.N * L.m * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    run_impl(s, stats);
+  })
+}
+
+int mpc_run_shifted(mpc_solver* s, mpc_stats* stats) {
+  MPC_TRY(s, {
+    hipLaunchKernelGGL(k_shift, dim3(s->L.B), dim3(64), 0, s->stream, s->args());
+    run_impl(s, stats);
+  })
+}
+
+int mpc_get_results(mpc_solver* s, double* xs, double* us, double* K, double* kff, double* vs, double* lams) {
+  MPC_TRY(s, {
+    const Layout& L = s->L;
+    const size_t B = L.B, N1 = L.N + 1, N = L.N;
+    HIP_OK(hipStreamSynchronize(s->stream));
+    if (xs) HIP_OK(hipMemcpy(xs, s->d_xs, B * N1 * L.nx * sizeof(double), hipMemcpyDeviceToHost));
+    if (us) HIP_OK(hipMemcpy(us, s->d_us, B * N * L.m * sizeof(double), hipMemcpyDeviceToHost));
+    if (vs) HIP_OK(hipMemcpy(vs, s->d_vs, B * N1 * L.c * sizeof(double), hipMemcpyDeviceToHost));
+    if (lams) HIP_OK(hipMemcpy(lams, s->d_lams, B * N1 * L.n * sizeof(double), hipMemcpyDeviceToHost));
+    if (K || kff) {
+      // gains live inside the gain records: strided 2-D copies
+      for (size_t b = 0; b < B; ++b) {
+        const double* g0 = s->d_gains + b * N1 * L.gain_stride;
+        if (K) HIP_OK(hipMemcpy2D(K + b * N * L.m * L.n, (size_t)L.m * L.n * sizeof(double), g0 + L.oK, (size_t)L.gain_stride * sizeof(double),
+                                  (size_t)L.m * L.n * sizeof(double), N, hipMemcpyDeviceToHost));
+        if (kff) HIP_OK(hipMemcpy2D(kff + b * N * L.m, (size_t)L.m * sizeof(double), g0 + L.ok, (size_t)L.gain_stride * sizeof(double),
+                                    (size_t)L.m * sizeof(double), N, hipMemcpyDeviceToHost));
+      }
+    }
+  })
+}
+
+int mpc_get_stage_data(mpc_solver* s, int32_t k, double* xdot, double* wrenches) {
+  MPC_TRY(s, {
+    const Layout& L = s->L;
+    if (k < 0 || k >= L.N) throw std::runtime_error("stage index out of range");
+    HIP_OK(hipStreamSynchronize(s->stream));
+    for (int b = 0; b < L.B; ++b) {
+      const double* kn = s->d_knots + ((size_t)b * (L.N + 1) + k) * L.knot_stride;
+      if (xdot) HIP_OK(hipMemcpy(xdot + (size_t)b * L.n, kn + L.oXD, L.n * sizeof(double), hipMemcpyDeviceToHost));
+      if (wrenches) HIP_OK(hipMemcpy(wrenches + (size_t)b * 12, kn + L.oWR, 12 * sizeof(double), hipMemcpyDeviceToHost));
+    }
+  })
+}
+
+int mpc_debug_evaluate(mpc_solver* s, const double* xs, const double* us) {
+  MPC_TRY(s, {
+    const Layout& L = s->L;
+    HIP_OK(hipMemcpyAsync(s->d_xs, xs, (size_t)L.B * (L.N + 1) * L.nx * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipMemcpyAsync(s->d_us, us, (size_t)L.B * L.N * L.m * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    // evaluate with every instance marked active
+    std::vector<InstState> st(L.B);
+    HIP_OK(hipMemcpyAsync(st.data(), s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    for (auto& i : st) { i.done = 0; i.skip_step = 0; if (i.mu <= 0) i.mu = s->opt.mu_init; }
+    HIP_OK(hipMemcpyAsync(s->d_inst, st.data(), L.B * sizeof(InstState), hipMemcpyHostToDevice, s->stream));
+    launch_eval(s, false);
+    HIP_OK(hipStreamSynchronize(s->stream));
+  })
+}
+
+int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double* out, int32_t cap) {
+  if (!s) return -2;
+  try {
+    const Layout& L = s->L;
+    if (b < 0 || b >= L.B || k < 0 || k > L.N) throw std::runtime_error("debug_get: index out of range");
+    HIP_OK(hipStreamSynchronize(s->stream));
+    std::vector<double> kn(L.knot_stride), g(L.gain_stride);
+    HIP_OK(hipMemcpy(kn.data(), s->d_knots + ((size_t)b * (L.N + 1) + k) * L.knot_stride, L.knot_stride * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(g.data(), s->d_gains + ((size_t)b * (L.N + 1) + k) * L.gain_stride, L.gain_stride * sizeof(double), hipMemcpyDeviceToHost));
+    const int n = L.n, nz = L.nz, c = (int)kn[L.oMISC + MISC_NC], m = (int)kn[L.oMISC + MISC_M], nzk = n + m;
+    const std::string nm(name);
+    std::vector<double> v;
+    auto mat = [&](const double* src, int rows, int cols, int ld) { v.resize((size_t)rows * cols); for (int i = 0; i < rows; ++i) for (int j = 0; j < cols; ++j) v[(size_t)i * cols + j] = src[(size_t)i * ld + j]; };
+    auto dev_vec = [&](const double* d_ptr, int len) { v.resize(len); HIP_OK(hipMemcpy(v.data(), d_ptr, len * sizeof(double), hipMemcpyDeviceToHost)); };
+    if (nm == "H") mat(kn.data() + L.oH, nzk, nzk, nz);
+    else if (nm == "grad") mat(kn.data() + L.oG, 1, nzk, nz);
+    else if (nm == "AB") mat(kn.data() + L.oAB, k < L.N ? n : 0, nzk, nz);
+    else if (nm == "f") mat(kn.data() + L.oF, 1, k < L.N ? n : 0, n);
+    else if (nm == "E6") mat(kn.data() + L.oE6, 6, 6, 6);
+    else if (nm == "cval") mat(kn.data() + L.oCV, 1, c, c);
+    else if (nm == "CD") mat(kn.data() + L.oCD, c, nzk, nz);
+    else if (nm == "cost") mat(kn.data() + L.oMISC + MISC_COST, 1, 1, 1);
+    else if (nm == "xnext") mat(kn.data() + L.oXN, 1, L.nx, L.nx);
+    else if (nm == "xdot") mat(kn.data() + L.oXD, 1, n, n);
+    else if (nm == "wrench") mat(kn.data() + L.oWR, 1, 12, 12);
+    else if (nm == "P") mat(g.data() + L.oP, n, n, n);
+    else if (nm == "p") mat(g.data() + L.op, 1, n, n);
+    else if (nm == "K") mat(g.data() + L.oK, m, n, n);
+    else if (nm == "kff") mat(g.data() + L.ok, 1, m, m);
+    else if (nm == "Knu") mat(g.data() + L.oKnu, c, n, n);
+    else if (nm == "knu") mat(g.data() + L.oknu, 1, c, c);
+    else if (nm == "Mx") mat(g.data() + L.oMx, k < L.N ? n : 0, n, n);
+    else if (nm == "mx") mat(g.data() + L.omx, 1, k < L.N ? n : 0, n);
+    else if (nm == "dx") dev_vec(s->d_dxs + ((size_t)b * (L.N + 1) + k) * n, n);
+    else if (nm == "du") { if (k >= L.N) throw std::runtime_error("no du at the terminal knot"); dev_vec(s->d_dus + ((size_t)b * L.N + k) * L.m, L.m); }
+    else if (nm == "dvs") dev_vec(s->d_dvs + ((size_t)b * (L.N + 1) + k) * L.c, L.c);
+    else if (nm == "dlams") dev_vec(s->d_dlams + ((size_t)b * (L.N + 1) + k) * n, n);
+    else throw std::runtime_error("debug_get: unknown quantity " + nm);
+    if ((int)v.size() > cap) throw std::runtime_error("debug_get: output buffer too small");
+    if (!v.empty()) std::memcpy(out, v.data(), v.size() * sizeof(double));
+    return (int)v.size();
+  } catch (const std::exception& e) {
+    s->err = e.what();
+    return -1;
+  }
+}
+
+}  // extern "C"

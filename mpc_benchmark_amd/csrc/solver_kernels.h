@@ -1,0 +1,543 @@
+// solver_kernels.h — stage-kind independent kernels of the on-device ProxDDP iteration:
+//   k_lagrangian      (P4)  gradient of the Lagrangian per knot -> dual infeasibility / inner criterion
+//   k_decide          (P4)  per-instance reductions + BCL outer-loop bookkeeping (no host round trip)
+//   k_riccati_backward(P6)  proximal Riccati sweep, one workgroup per MPC instance, sequential over knots
+//   k_forward         (P7)  state/control steps along the horizon
+//   k_duals           (P7)  multiplier steps + merit directional derivative, parallel over knots
+//   k_linesearch      (P8)  deterministic reductions of the candidate merits, Armijo choice
+//   k_accept          (P9)  apply the accepted step
+// Phase names follow SURVEY.md §3.3; the algebra follows SURVEY.md App. B.3/B.4 as restated in DESIGN.md.
+#pragma once
+#include "device_common.h"
+
+struct SolverArgs {
+  Layout L;
+  mpc_options opt;
+  int head;  // ring-buffer head of the stage table
+  // stage tables
+  const int32_t* stage_desc;
+  const double* stage_params;
+  const int32_t* model_i;
+  const double* model_d;
+  // iterate
+  double *xs, *us, *vs, *lams, *vs_e, *lams_e, *x0;
+  double *dxs, *dus, *dvs, *dlams;
+  double *knots, *gains, *work;
+  double *trial_phi;  // [B][n_alpha][N+1]
+  InstState* inst;
+  int* all_done;
+};
+
+DEV double* knot_ptr(const SolverArgs& a, int b, int k) { return a.knots + ((size_t)b * (a.L.N + 1) + k) * a.L.knot_stride; }
+DEV double* gain_ptr(const SolverArgs& a, int b, int k) { return a.gains + ((size_t)b * (a.L.N + 1) + k) * a.L.gain_stride; }
+DEV int stage_slot(const SolverArgs& a, int k) { return k < a.L.N ? (a.head + k) % a.L.N : a.L.N; }
+
+// ------------------------------------------------------------------------------------------------
+// P4: L_z = grad + CD^T v + AB^T lam' + [E_{k-1}^T lam_k; 0]   (current multipliers), inner criterion
+// grid (N+1, B), block 64
+// ------------------------------------------------------------------------------------------------
+__global__ void k_lagrangian(SolverArgs a) {
+  const Layout& L = a.L;
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+  const InstState& st = a.inst[b];
+  if (st.done) return;
+  double* kn = knot_ptr(a, b, k);
+  const int n = L.n, nz = L.nz, N = L.N;
+  const int c = (int)kn[L.oMISC + MISC_NC], m = (int)kn[L.oMISC + MISC_M], nzk = n + m;
+  const double mu = st.mu, mud = mu * a.opt.dyn_al_scale;
+  const double* v = a.vs + ((size_t)b * (N + 1) + k) * L.c;
+  const double* lamn = a.lams + ((size_t)b * (N + 1) + k + 1) * n;
+  const double* lamk = a.lams + ((size_t)b * (N + 1) + k) * n;
+  __shared__ double red[64];
+  double dual = 0.0, crit = 0.0;
+  for (int z = tid; z < nzk; z += nthr) {
+    double s = kn[L.oG + z];
+    for (int i = 0; i < c; ++i) s += kn[L.oCD + i * nz + z] * v[i];
+    if (k < N) for (int i = 0; i < n; ++i) s += kn[L.oAB + i * nz + z] * lamn[i];
+    if (k > 0 && z < n) {
+      if (L.space == MPC_SPACE_MULTIBODY && z < 6) {
+        const double* E6 = knot_ptr(a, b, k - 1) + L.oE6;
+        for (int i = 0; i < 6; ++i) s += E6[i * 6 + z] * lamk[i];
+      } else {
+        s -= lamk[z];
+      }
+    }
+    const bool fixed = (k == 0 && a.opt.force_initial_condition && z < n);
+    if (!fixed) dual = fmax(dual, fabs(s));
+  }
+  for (int i = tid; i < c; i += nthr) crit = fmax(crit, fabs(kn[L.oDT + i] - mu * v[i]));
+  if (k < N) {
+    const double* le = a.lams_e + ((size_t)b * (N + 1) + k + 1) * n;
+    for (int i = tid; i < n; i += nthr) crit = fmax(crit, fabs(kn[L.oF + i] + mud * (le[i] - lamn[i])));
+  }
+  red[tid] = dual;
+  __syncthreads();
+  if (tid == 0) { double r = 0; for (int i = 0; i < nthr; ++i) r = fmax(r, red[i]); kn[L.oMISC + MISC_DUAL] = r; }
+  __syncthreads();
+  red[tid] = crit;
+  __syncthreads();
+  if (tid == 0) { double r = 0; for (int i = 0; i < nthr; ++i) r = fmax(r, red[i]); kn[L.oMISC + MISC_CRIT] = r; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// P4 (cont.): per-instance reductions in fixed order + the BCL bookkeeping of SolverProxDDP::run.
+// grid B, block 1
+// ------------------------------------------------------------------------------------------------
+__global__ void k_decide(SolverArgs a) {
+  const Layout& L = a.L;
+  const int b = blockIdx.x;
+  InstState& st = a.inst[b];
+  if (st.done) return;
+  const mpc_options& o = a.opt;
+  double cost = 0, pen = 0, prim = 0, dual = 0, crit = 0;
+  for (int k = 0; k <= L.N; ++k) {
+    const double* ms = knot_ptr(a, b, k) + L.oMISC;
+    cost += ms[MISC_COST]; pen += ms[MISC_PEN];
+    prim = fmax(prim, ms[MISC_PRIM]); dual = fmax(dual, ms[MISC_DUAL]); crit = fmax(crit, ms[MISC_CRIT]);
+  }
+  crit = fmax(crit, dual);
+  st.cost = cost; st.phi0 = cost + pen; st.prim = prim; st.dual = dual; st.crit = crit;
+  st.skip_step = 0;
+  if (crit <= st.inner_tol) {
+    // inner problem solved: outer (BCL) update, no step this pass
+    st.skip_step = 1;
+    const size_t nv = (size_t)(L.N + 1) * L.c, nl = (size_t)(L.N + 1) * L.n;
+    if (prim <= st.prim_tol) {
+      st.prim_tol *= pow(st.mu, o.bcl_prim_beta);
+      st.inner_tol *= pow(st.mu, o.bcl_dual_beta);
+      for (size_t i = 0; i < nv; ++i) a.vs_e[b * nv + i] = a.vs[b * nv + i];
+      for (size_t i = 0; i < nl; ++i) a.lams_e[b * nl + i] = a.lams[b * nl + i];
+      if (fmax(prim, dual) <= o.tol) { st.converged = 1; st.done = 1; }
+    } else {
+      st.mu = fmax(st.mu * o.bcl_mu_update_factor, o.bcl_mu_lower_bound);
+      st.prim_tol = o.prim_tol0 * pow(st.mu, o.bcl_prim_alpha);
+      st.inner_tol = o.inner_tol0 * pow(st.mu, o.bcl_dual_alpha);
+    }
+    st.inner_tol = fmax(st.inner_tol, o.tol);
+    st.prim_tol = fmax(st.prim_tol, o.tol);
+    st.al_iters += 1;
+    if (st.al_iters >= o.max_al_iters) st.done = 1;
+  }
+  if (!st.done) atomicExch(a.all_done, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// P6: proximal Riccati backward sweep.  grid B, block 256, dynamic LDS: Lp[n*n] Lr[m*m] Sc[c*c] + small.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_riccati_backward(SolverArgs a) {
+  const Layout& L = a.L;
+  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const InstState& st = a.inst[b];
+  if (st.done || st.skip_step) return;
+  const int n = L.n, nz = L.nz, N = L.N, nr = n + 1;
+  const double mu = st.mu, mud = mu * a.opt.dyn_al_scale;
+  const bool ff = L.space == MPC_SPACE_MULTIBODY;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* Lp = lds;                 // n*n
+  double* Lr = Lp + n * n;          // m*m
+  double* ScL = Lr + L.m * L.m;     // sc_cap^2: Schur complement of the ACTIVE constraint rows when it fits
+  int* act_idx = (int*)(ScL + L.sc_cap * L.sc_cap);  // c
+  int* iflag = act_idx + L.c;       // 2
+  double* wk = a.work + (size_t)b * L.work_stride;
+  double *Ph = wk + L.wPh, *Pt = wk + L.wPt, *G = wk + L.wG, *Hh = wk + L.wHh, *gh = wk + L.wgh, *Ct = wk + L.wCt;
+  double *W = wk + L.wW, *Y = wk + L.wY, *V = wk + L.wV, *Acl = wk + L.wAcl, *vec = wk + L.wvec;
+  double *ph = vec, *ft = vec + n, *w = vec + 2 * n;
+
+  // ---- terminal node ----
+  {
+    const double* kn = knot_ptr(a, b, N);
+    double* g = gain_ptr(a, b, N);
+    const int c = (int)kn[L.oMISC + MISC_NC];
+    for (int i = tid; i < c; i += nthr) g[L.oknu + i] = kn[L.oDT + i] / mu;
+    for (int idx = tid; idx < c * n; idx += nthr) {
+      const int i = idx / n, z = idx % n;
+      g[L.oKnu + idx] = (kn[L.oACT + i] != 0.0) ? kn[L.oCD + i * nz + z] / mu : 0.0;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += nthr) {
+      const int r = idx / n, s = idx % n;
+      double t = kn[L.oH + r * nz + s];
+      for (int i = 0; i < c; ++i) if (kn[L.oACT + i] != 0.0) t += kn[L.oCD + i * nz + r] * g[L.oKnu + i * n + s];
+      g[L.oP + idx] = t;
+    }
+    for (int r = tid; r < n; r += nthr) {
+      double t = kn[L.oG + r];
+      for (int i = 0; i < c; ++i) t += kn[L.oCD + i * nz + r] * g[L.oknu + i];
+      g[L.op + r] = t;
+    }
+    __syncthreads();
+  }
+
+  for (int k = N - 1; k >= 0; --k) {
+    const double* kn = knot_ptr(a, b, k);
+    const double* gn = gain_ptr(a, b, k + 1);
+    double* g = gain_ptr(a, b, k);
+    const int m = (int)kn[L.oMISC + MISC_M], c = (int)kn[L.oMISC + MISC_NC];
+    const double* AB = kn + L.oAB;
+    const double* le = a.lams_e + ((size_t)b * (N + 1) + k + 1) * n;
+    // 1. y = Ebar x' : T6 = (-E6)^-1 ; Ph = T^T P' T ; ph = T^T p'
+    if (tid == 0) {
+      if (ff) {
+        double Eb[36];
+        for (int i = 0; i < 36; ++i) Eb[i] = -kn[L.oE6 + i];
+        inv6_serial(Eb, g + L.oT6);
+      } else {
+        for (int i = 0; i < 36; ++i) g[L.oT6 + i] = (i % 7 == 0) ? 1.0 : 0.0;
+      }
+      int ca = 0;
+      for (int i = 0; i < c; ++i) if (kn[L.oACT + i] != 0.0) act_idx[ca++] = i;
+      iflag[1] = ca;
+    }
+    __syncthreads();
+    const int ca = iflag[1];
+    double* Sc = (ca <= L.sc_cap) ? ScL : (wk + L.wSc);
+    const double* T6 = g + L.oT6;
+    if (ff) {
+      // Pt used as temporary: tmp = P' T
+      for (int idx = tid; idx < n * n; idx += nthr) {
+        const int i = idx / n, j = idx % n;
+        double s;
+        if (j < 6) { s = 0; for (int l = 0; l < 6; ++l) s += gn[L.oP + i * n + l] * T6[l * 6 + j]; }
+        else s = gn[L.oP + idx];
+        Pt[idx] = s;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < n * n; idx += nthr) {
+        const int i = idx / n, j = idx % n;
+        double s;
+        if (i < 6) { s = 0; for (int l = 0; l < 6; ++l) s += T6[l * 6 + i] * Pt[l * n + j]; }
+        else s = Pt[idx];
+        Ph[idx] = s;
+      }
+      for (int i = tid; i < n; i += nthr) {
+        double s;
+        if (i < 6) { s = 0; for (int l = 0; l < 6; ++l) s += T6[l * 6 + i] * gn[L.op + l]; }
+        else s = gn[L.op + i];
+        ph[i] = s;
+      }
+    } else {
+      for (int idx = tid; idx < n * n; idx += nthr) Ph[idx] = gn[L.oP + idx];
+      for (int i = tid; i < n; i += nthr) ph[i] = gn[L.op + i];
+    }
+    for (int i = tid; i < n; i += nthr) ft[i] = kn[L.oF + i] + mud * le[i];
+    __syncthreads();
+    // 2. Lp = chol(I + mud sym(Ph)) ; Pt = Lam Ph ; w = Lam (Ph ft + ph)
+    for (int idx = tid; idx < n * n; idx += nthr) {
+      const int i = idx / n, j = idx % n;
+      Lp[idx] = mud * 0.5 * (Ph[idx] + Ph[j * n + i]) + (i == j ? 1.0 : 0.0);
+      Pt[idx] = Ph[idx];
+    }
+    for (int i = tid; i < n; i += nthr) { double s = ph[i]; for (int j = 0; j < n; ++j) s += Ph[i * n + j] * ft[j]; w[i] = s; }
+    __syncthreads();
+    if (!chol_block(Lp, n, n, tid, nthr, iflag)) { if (tid == 0) a.inst[b].done = 2; return; }
+    potrs_block(Lp, n, n, Pt, n, n, tid, nthr);
+    potrs_block(Lp, n, n, w, 1, 1, tid, nthr);
+    for (int idx = tid; idx < n * n; idx += nthr) {
+      const int i = idx / n, j = idx % n;
+      if (j > i) { const double s = 0.5 * (Pt[idx] + Pt[j * n + i]); Pt[idx] = s; Pt[j * n + i] = s; }
+    }
+    __syncthreads();
+    // 3. G = Pt AB ; Hh = H + AB^T G ; gh = grad + AB^T w
+    const int nzk = n + m;
+    for (int idx = tid; idx < n * nzk; idx += nthr) {
+      const int i = idx / nzk, z = idx % nzk;
+      double s = 0;
+      for (int l = 0; l < n; ++l) s += Pt[i * n + l] * AB[l * nz + z];
+      G[i * nz + z] = s;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nzk * nzk; idx += nthr) {
+      const int r = idx / nzk, z = idx % nzk;
+      double s = kn[L.oH + r * nz + z];
+      for (int i = 0; i < n; ++i) s += AB[i * nz + r] * G[i * nz + z];
+      Hh[r * nz + z] = s;
+    }
+    for (int z = tid; z < nzk; z += nthr) {
+      double s = kn[L.oG + z];
+      for (int i = 0; i < n; ++i) s += AB[i * nz + z] * w[i];
+      gh[z] = s;
+    }
+    __syncthreads();
+    // 4. stage KKT, controls first then the ACTIVE constraint rows (compacted)
+    for (int idx = tid; idx < m * m; idx += nthr) {
+      const int i = idx / m, j = idx % m;
+      Lr[idx] = 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]);
+    }
+    for (int idx = tid; idx < ca * nzk; idx += nthr) {
+      const int i = idx / nzk, z = idx % nzk;
+      Ct[i * nz + z] = kn[L.oCD + act_idx[i] * nz + z];
+    }
+    for (int idx = tid; idx < m * nr; idx += nthr) {
+      const int i = idx / nr, z = idx % nr;
+      W[idx] = (z < n) ? -Hh[(n + i) * nz + z] : -gh[n + i];
+    }
+    for (int idx = tid; idx < m * ca; idx += nthr) {
+      const int i = idx / ca, j = idx % ca;
+      Y[i * ca + j] = kn[L.oCD + act_idx[j] * nz + n + i];
+    }
+    __syncthreads();
+    if (!chol_block(Lr, m, m, tid, nthr, iflag)) { if (tid == 0) a.inst[b].done = 3; return; }
+    trsm_lower_block(Lr, m, m, W, nr, nr, tid, nthr);
+    if (ca > 0) {
+      trsm_lower_block(Lr, m, m, Y, ca, ca, tid, nthr);
+      for (int idx = tid; idx < ca * ca; idx += nthr) {
+        const int i = idx / ca, j = idx % ca;
+        double s = (i == j) ? mu : 0.0;
+        for (int l = 0; l < m; ++l) s += Y[l * ca + i] * Y[l * ca + j];
+        Sc[idx] = s;
+      }
+      for (int idx = tid; idx < ca * nr; idx += nthr) {
+        const int i = idx / nr, z = idx % nr;
+        double s = (z < n) ? Ct[i * nz + z] : kn[L.oDT + act_idx[i]];
+        for (int l = 0; l < m; ++l) s += Y[l * ca + i] * W[l * nr + z];
+        V[idx] = s;
+      }
+      __syncthreads();
+      if (!chol_block(Sc, ca, ca, tid, nthr, iflag)) { if (tid == 0) a.inst[b].done = 4; return; }
+      potrs_block(Sc, ca, ca, V, nr, nr, tid, nthr);
+      for (int idx = tid; idx < m * nr; idx += nthr) {
+        const int l = idx / nr, z = idx % nr;
+        double s = 0;
+        for (int i = 0; i < ca; ++i) s += Y[l * ca + i] * V[i * nr + z];
+        W[idx] -= s;
+      }
+      __syncthreads();
+    }
+    trsm_lower_t_block(Lr, m, m, W, nr, nr, tid, nthr);
+    for (int idx = tid; idx < m * n; idx += nthr) g[L.oK + idx] = W[(idx / n) * nr + idx % n];
+    for (int i = tid; i < m; i += nthr) g[L.ok + i] = W[i * nr + n];
+    for (int idx = tid; idx < c * n; idx += nthr) g[L.oKnu + idx] = 0.0;
+    for (int i = tid; i < c; i += nthr) g[L.oknu + i] = 0.0;
+    __syncthreads();
+    for (int idx = tid; idx < ca * n; idx += nthr) g[L.oKnu + act_idx[idx / n] * n + idx % n] = V[(idx / n) * nr + idx % n];
+    for (int i = tid; i < ca; i += nthr) g[L.oknu + act_idx[i]] = V[i * nr + n];
+    __syncthreads();
+    // 5. value function
+    for (int idx = tid; idx < n * n; idx += nthr) {
+      const int r = idx / n, s = idx % n;
+      double t = Hh[r * nz + s];
+      for (int i = 0; i < m; ++i) t += Hh[r * nz + n + i] * W[i * nr + s];
+      for (int i = 0; i < ca; ++i) t += Ct[i * nz + r] * V[i * nr + s];
+      g[L.oP + idx] = t;
+    }
+    for (int r = tid; r < n; r += nthr) {
+      double t = gh[r];
+      for (int i = 0; i < m; ++i) t += Hh[r * nz + n + i] * W[i * nr + n];
+      for (int i = 0; i < ca; ++i) t += Ct[i * nz + r] * V[i * nr + n];
+      g[L.op + r] = t;
+    }
+    // 6. closed-loop next-state map (uses AB, K, Lp, T6): Acl = Lam [A + B K | B k + ft - mud ph]
+    for (int idx = tid; idx < n * nr; idx += nthr) {
+      const int i = idx / nr, z = idx % nr;
+      double s = (z < n) ? AB[i * nz + z] : (ft[i] - mud * ph[i]);
+      for (int l = 0; l < m; ++l) s += AB[i * nz + n + l] * W[l * nr + z];
+      Acl[idx] = s;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += nthr) {
+      const int r = idx / n, s = idx % n;
+      if (s > r) { const double t = 0.5 * (g[L.oP + idx] + g[L.oP + s * n + r]); g[L.oP + idx] = t; g[L.oP + s * n + r] = t; }
+    }
+    potrs_block(Lp, n, n, Acl, nr, nr, tid, nthr);
+    for (int idx = tid; idx < n * nr; idx += nthr) {
+      const int i = idx / nr, z = idx % nr;
+      double s;
+      if (ff && i < 6) { s = 0; for (int l = 0; l < 6; ++l) s += T6[i * 6 + l] * Acl[l * nr + z]; }
+      else s = Acl[idx];
+      if (z < n) g[L.oMx + i * n + z] = s; else g[L.omx + i] = s;
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// P7: dx_{k+1} = Mx dx_k + mx ; du_k = K dx_k + k.  grid B, block 128
+// ------------------------------------------------------------------------------------------------
+__global__ void k_forward(SolverArgs a) {
+  const Layout& L = a.L;
+  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const InstState& st = a.inst[b];
+  if (st.done || st.skip_step) return;
+  const int n = L.n, N = L.N, m = L.m;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* dx = lds;
+  double* dxn = lds + n;
+  for (int i = tid; i < n; i += nthr) { dx[i] = 0.0; a.dxs[(size_t)b * (N + 1) * n + i] = 0.0; }
+  __syncthreads();
+  for (int k = 0; k < N; ++k) {
+    const double* g = gain_ptr(a, b, k);
+    for (int i = tid; i < n + m; i += nthr) {
+      if (i < n) {
+        double s = g[L.omx + i];
+        for (int z = 0; z < n; ++z) s += g[L.oMx + i * n + z] * dx[z];
+        dxn[i] = s;
+        a.dxs[((size_t)b * (N + 1) + k + 1) * n + i] = s;
+      } else {
+        const int j = i - n;
+        double s = g[L.ok + j];
+        for (int z = 0; z < n; ++z) s += g[L.oK + j * n + z] * dx[z];
+        a.dus[((size_t)b * N + k) * m + j] = s;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nthr) dx[i] = dxn[i];
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// P7 (cont.): multiplier steps and the merit directional derivative, parallel over knots.
+// grid (N+1, B), block 64
+// ------------------------------------------------------------------------------------------------
+__global__ void k_duals(SolverArgs a) {
+  const Layout& L = a.L;
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+  const InstState& st = a.inst[b];
+  if (st.done || st.skip_step) return;
+  const int n = L.n, nz = L.nz, N = L.N;
+  double* kn = knot_ptr(a, b, k);
+  const double* g = gain_ptr(a, b, k);
+  const int c = (int)kn[L.oMISC + MISC_NC], m = (int)kn[L.oMISC + MISC_M];
+  const double mu = st.mu, mud = mu * a.opt.dyn_al_scale;
+  const bool ff = L.space == MPC_SPACE_MULTIBODY;
+  const double* dx = a.dxs + ((size_t)b * (N + 1) + k) * n;
+  const double* du = a.dus + ((size_t)b * N + k) * L.m;
+  const double* v = a.vs + ((size_t)b * (N + 1) + k) * L.c;
+  double* dv = a.dvs + ((size_t)b * (N + 1) + k) * L.c;
+  __shared__ double red[64];
+  __shared__ double lnew[128];
+  double acc = 0.0;
+  // cost gradient part
+  for (int z = tid; z < n + m; z += nthr) acc += kn[L.oG + z] * (z < n ? dx[z] : du[z - n]);
+  // constraints
+  for (int i = tid; i < L.c; i += nthr) {
+    if (i >= c) { dv[i] = 0.0; continue; }
+    double s = g[L.oknu + i];
+    for (int z = 0; z < n; ++z) s += g[L.oKnu + i * n + z] * dx[z];
+    const double dvi = s - v[i];
+    dv[i] = dvi;
+    const double vp = kn[L.oDT + i] / mu;
+    double jd = 0;
+    for (int z = 0; z < n + m; ++z) jd += kn[L.oCD + i * nz + z] * (z < n ? dx[z] : du[z - n]);
+    acc += (vp + (kn[L.oACT + i] != 0.0 ? (vp - v[i]) : 0.0)) * jd - mu * (vp - v[i]) * dvi;
+  }
+  if (k == 0) for (int i = tid; i < n; i += nthr) a.dlams[(size_t)b * (N + 1) * n + i] = 0.0;
+  if (k < N) {
+    const double* gn = gain_ptr(a, b, k + 1);
+    const double* dxn = a.dxs + ((size_t)b * (N + 1) + k + 1) * n;
+    const double* lam = a.lams + ((size_t)b * (N + 1) + k + 1) * n;
+    const double* le = a.lams_e + ((size_t)b * (N + 1) + k + 1) * n;
+    double* dl = a.dlams + ((size_t)b * (N + 1) + k + 1) * n;
+    for (int i = tid; i < n; i += nthr) {
+      double s = gn[L.op + i];
+      for (int z = 0; z < n; ++z) s += gn[L.oP + i * n + z] * dxn[z];
+      lnew[i] = s;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += nthr) {
+      double ln = lnew[i];
+      if (ff && i < 6) { ln = 0; for (int l = 0; l < 6; ++l) ln += g[L.oT6 + l * 6 + i] * lnew[l]; }
+      const double dli = ln - lam[i];
+      dl[i] = dli;
+      const double lp = le[i] + kn[L.oF + i] / mud;
+      double jd = 0;
+      for (int z = 0; z < n + m; ++z) jd += kn[L.oAB + i * nz + z] * (z < n ? dx[z] : du[z - n]);
+      if (ff && i < 6) { for (int l = 0; l < 6; ++l) jd += kn[L.oE6 + i * 6 + l] * dxn[l]; }
+      else jd -= dxn[i];
+      acc += (2.0 * lp - lam[i]) * jd - mud * (lp - lam[i]) * dli;
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  if (tid == 0) { double r = 0; for (int i = 0; i < nthr; ++i) r += red[i]; kn[L.oMISC + MISC_DMERIT] = r; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// P8: Armijo backtracking over the pre-evaluated candidates alpha_i = 2^-i.  grid B, block 1
+// ------------------------------------------------------------------------------------------------
+__global__ void k_linesearch(SolverArgs a) {
+  const Layout& L = a.L;
+  const int b = blockIdx.x;
+  InstState& st = a.inst[b];
+  if (st.done || st.skip_step) return;
+  double d = 0;
+  for (int k = 0; k <= L.N; ++k) d += knot_ptr(a, b, k)[L.oMISC + MISC_DMERIT];
+  st.dphi0 = d;
+  double alpha = 1.0;
+  int step = 0;
+  for (;; ++step) {
+    double phi = 0;
+    const double* tp = a.trial_phi + ((size_t)b * L.n_alpha + step) * (L.N + 1);
+    for (int k = 0; k <= L.N; ++k) phi += tp[k];
+    if (phi <= st.phi0 + a.opt.ls_armijo_c1 * alpha * d) break;
+    if (step + 1 >= a.opt.ls_max_steps || step + 1 >= L.n_alpha || 0.5 * alpha < a.opt.ls_alpha_min) break;
+    alpha *= 0.5;
+  }
+  st.alpha = alpha;
+  st.ls_step = step;
+}
+
+// ------------------------------------------------------------------------------------------------
+// P9: accept the step.  grid (N+1, B), block 64
+// ------------------------------------------------------------------------------------------------
+__global__ void k_accept(SolverArgs a) {
+  const Layout& L = a.L;
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+  InstState& st = a.inst[b];
+  if (st.done || st.skip_step) return;
+  const int n = L.n, N = L.N, nx = L.nx, m = L.m;
+  const double alpha = st.alpha;
+  double* x = a.xs + ((size_t)b * (N + 1) + k) * nx;
+  const double* dx = a.dxs + ((size_t)b * (N + 1) + k) * n;
+  __shared__ double xn[160];
+  if (tid == 0) state_integrate(L.space, nx, n, x, dx, alpha, xn);
+  __syncthreads();
+  for (int i = tid; i < nx; i += nthr) x[i] = xn[i];
+  double* v = a.vs + ((size_t)b * (N + 1) + k) * L.c;
+  const double* dv = a.dvs + ((size_t)b * (N + 1) + k) * L.c;
+  for (int i = tid; i < L.c; i += nthr) v[i] += alpha * dv[i];
+  double* lam = a.lams + ((size_t)b * (N + 1) + k) * n;
+  const double* dl = a.dlams + ((size_t)b * (N + 1) + k) * n;
+  for (int i = tid; i < n; i += nthr) lam[i] += alpha * dl[i];
+  if (k < N) {
+    double* u = a.us + ((size_t)b * N + k) * m;
+    const double* du = a.dus + ((size_t)b * N + k) * m;
+    for (int i = tid; i < m; i += nthr) u[i] += alpha * du[i];
+  }
+}
+
+// bookkeeping after a step.  grid B, block 1
+__global__ void k_after_step(SolverArgs a) {
+  InstState& st = a.inst[blockIdx.x];
+  if (st.done) return;
+  if (!st.skip_step) {
+    st.num_iters += 1;
+    if (st.num_iters >= a.opt.max_iters) st.done = 1;
+  }
+  if (!st.done) atomicExch(a.all_done, 0);
+}
+
+// start of run(): xs[0] = x0, tolerances of the BCL loop.  grid B, block 64
+__global__ void k_begin_run(SolverArgs a) {
+  const Layout& L = a.L;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  InstState& st = a.inst[b];
+  if (a.opt.force_initial_condition)
+    for (int i = tid; i < L.nx; i += blockDim.x) a.xs[(size_t)b * (L.N + 1) * L.nx + i] = a.x0[(size_t)b * L.nx + i];
+  if (tid == 0) {
+    st.num_iters = 0; st.al_iters = 0; st.converged = 0; st.done = 0; st.skip_step = 0; st.ls_step = 0; st.alpha = 0;
+    st.prim_tol = fmax(a.opt.prim_tol0 * pow(st.mu, a.opt.bcl_prim_alpha), a.opt.tol);
+    st.inner_tol = fmax(a.opt.inner_tol0 * pow(st.mu, a.opt.bcl_dual_alpha), a.opt.tol);
+  }
+}
+
+// warm-start shift on the device (fulldynamic_talos.py:532-534).  grid B, block 64
+__global__ void k_shift(SolverArgs a) {
+  const Layout& L = a.L;
+  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  double* xs = a.xs + (size_t)b * (L.N + 1) * L.nx;
+  double* us = a.us + (size_t)b * L.N * L.m;
+  // sequential over knots to stay in place; each element handled by one thread
+  for (int i = tid; i < L.nx; i += nthr) for (int k = 0; k < L.N; ++k) xs[k * L.nx + i] = xs[(k + 1) * L.nx + i];
+  for (int i = tid; i < L.m; i += nthr) for (int k = 0; k + 1 < L.N; ++k) us[k * L.m + i] = us[(k + 1) * L.m + i];
+}
