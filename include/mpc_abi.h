@@ -50,7 +50,7 @@ extern "C" {
 #define MPC_DYN_KINODYNAMICS_SEMIEULER 3         /* KinodynamicsFwdDynamics + IntegratorSemiImplEuler         kinodynamic_talos.py:108-111 */
 
 /* ---- residual ("term") types --------------------------------------------------------------- */
-#define MPC_TERM_STATE_ERROR 1          /* r = (x (-) x_ref)[i0 : i0+dim]      params: x_ref[nx]                         */
+#define MPC_TERM_STATE_ERROR 1          /* r = (x_ref (-) x)[i0 : i0+dim]      params: x_ref[nx]   (= space.difference(x, x_ref)) */
 #define MPC_TERM_CONTROL_ERROR 2        /* r = (u - u_ref)[i0 : i0+dim]        params: u_ref[nu]                         */
 #define MPC_TERM_FRAME_PLACEMENT 3      /* r = log6(Mref^-1 oMf)               iarg0=frame, params: R[9] p[3]            */
 #define MPC_TERM_FRAME_TRANSLATION 4    /* r = (oMf.t - p_ref)[i1:i1+dim]      iarg0=frame, params: p[3]                 */

@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(64) k_eval_vector(SolverArgs a, Layout KL, dou
     for (int i = tid; i < d; i += nthr) r[i] = 0.0;
     __syncthreads();
     if (tr.type == MPC_TERM_STATE_ERROR) {
-      for (int i = tid; i < d; i += nthr) { r[i] = x[tr.i0 + i] - tp[tr.i0 + i]; J[i * ldj + tr.i0 + i] = 1.0; }
+      for (int i = tid; i < d; i += nthr) { r[i] = tp[tr.i0 + i] - x[tr.i0 + i]; J[i * ldj + tr.i0 + i] = -1.0; }  // x_ref (-) x
     } else if (tr.type == MPC_TERM_CONTROL_ERROR) {
       for (int i = tid; i < d; i += nthr) { r[i] = u[tr.i0 + i] - tp[tr.i0 + i]; J[i * ldj + n + tr.i0 + i] = 1.0; }
     } else if (tr.type == MPC_TERM_CENTROIDAL_WRENCH_CONE) {

@@ -7,6 +7,8 @@
 // a dense KKT solve and the iteration against its own optimality conditions in tests/.
 #pragma once
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #ifdef _OPENMP
@@ -474,6 +476,7 @@ struct Solver {
       make_trial(in, alpha);
       evaluate(in, in.txs, in.tus, in.tknots, false);
       phi = merit(in, in.tknots, in.tvs, in.tlams);
+      if (std::getenv("MPC_ORACLE_DEBUG")) fprintf(stderr, "  ls: alpha %.4g phi %.10e phi0 %.10e dphi0 %.4e\n", alpha, phi, phi0, dphi0);
       if (phi <= phi0 + opt.ls_armijo_c1 * alpha * dphi0) break;
       if (step + 1 >= opt.ls_max_steps || 0.5 * alpha < opt.ls_alpha_min) break;
       alpha *= 0.5;

@@ -149,7 +149,7 @@ inline void eval_centroidal(const StageDesc& sd, int nx, int nu, const double* x
     const double* tp = P + t.poff;
     switch (t.type) {
       case MPC_TERM_STATE_ERROR:
-        for (int i = 0; i < d; ++i) { r[i] = x[t.i0 + i] - tp[t.i0 + i]; J[i * nz + t.i0 + i] = 1.0; }
+        for (int i = 0; i < d; ++i) { r[i] = tp[t.i0 + i] - x[t.i0 + i]; J[i * nz + t.i0 + i] = -1.0; }  // x_ref (-) x, see DESIGN.md
         break;
       case MPC_TERM_CONTROL_ERROR:
         for (int i = 0; i < d; ++i) { r[i] = u[t.i0 + i] - tp[t.i0 + i]; J[i * nz + n + t.i0 + i] = 1.0; }
@@ -277,12 +277,13 @@ void mb_functions(const Model& m, const StageDesc& sd, const State<T>& s, const 
     const double* tp = sd.params.data() + t.poff;
     switch (t.type) {
       case MPC_TERM_STATE_ERROR: {
-        // r = x (-) x_ref = [log6(Mref^-1 M); qa - qa_ref; v - v_ref], sliced
+        // r = x_ref (-) x = difference(x, x_ref) = [log6(M^-1 Mref); qa_ref - qa; v_ref - v], sliced
+        // (sign convention inferred from the flipped joint-limit bounds at fulldynamic_talos.py:209)
         std::vector<T> full(2 * m.nv);
         const State<double> ref = state_from_x(m, tp);
-        for (int i = 0; i < m.nv; ++i) { full[i] = s.qa[i] - T(ref.qa[i]); full[m.nv + i] = s.v[i] - T(ref.v[i]); }
+        for (int i = 0; i < m.nv; ++i) { full[i] = T(ref.qa[i]) - s.qa[i]; full[m.nv + i] = T(ref.v[i]) - s.v[i]; }
         if (m.has_freeflyer()) {
-          const Mot<T> e = log6(inverse(convert<T>(ref.base)) * s.base);
+          const Mot<T> e = log6(inverse(s.base) * convert<T>(ref.base));
           for (int i = 0; i < 3; ++i) { full[i] = e.lin[i]; full[3 + i] = e.ang[i]; }
         }
         for (int i = 0; i < t.dim; ++i) rt.push_back(full[t.i0 + i]);
