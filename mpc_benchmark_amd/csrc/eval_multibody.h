@@ -1,10 +1,847 @@
-// eval_multibody.h — per-knot evaluation of multibody stages (placeholder until the kernel lands).
+// eval_multibody.h — per-knot evaluation of whole-body stages on the GPU: the stage of fulldynamic_talos.py:100-232
+// (MultibodyConstraintFwdDynamics = pin.constraintDynamics + its derivatives, IntegratorSemiImplEuler, state /
+// control / centroidal-momentum / frame-placement / contact-force costs, torque & joint boxes, wrench cones).
+//
+// One workgroup (256 threads) per (knot, instance, linesearch candidate).  All rigid-body quantities are kept in
+// LDS in a WORLD-FRAME formulation (spatial vectors [lin; ang] taken at the world origin): after one pass over
+// the kinematic tree every entry of M, d tau/dq, d tau/dv, the contact Jacobians and their derivatives is a
+// 6-dimensional dot product of per-dof vectors, so the nv x nv blocks are filled by all lanes in parallel with
+// no further dependency on the tree (DESIGN.md §"Whole-body stage kernel" derives the formulas; they are
+// cross-checked against the AD-based oracle through tests/proto_multibody.py and the GPU parity tests).
 #pragma once
 #include <stdexcept>
 #include "eval_common.h"
 
-static inline void check_multibody_model(const int32_t*, int) {}
-static inline size_t multibody_work_doubles(const Layout&) { return 0; }
-static inline void launch_eval_multibody(hipStream_t, const SolverArgs&, const Layout&, double*, double*, size_t, bool) {
-  throw std::runtime_error("multibody stage evaluation kernel is not built into this library yet");
+// ---- 6-vectors --------------------------------------------------------------------------------------------
+struct S6 { double v[6]; };
+DEV S6 ld6(const double* p) { S6 r; for (int i = 0; i < 6; ++i) r.v[i] = p[i]; return r; }
+DEV void st6(double* p, const S6& a) { for (int i = 0; i < 6; ++i) p[i] = a.v[i]; }
+DEV S6 zero6() { S6 r; for (int i = 0; i < 6; ++i) r.v[i] = 0.0; return r; }
+DEV S6 add6(const S6& a, const S6& b) { S6 r; for (int i = 0; i < 6; ++i) r.v[i] = a.v[i] + b.v[i]; return r; }
+DEV S6 sub6(const S6& a, const S6& b) { S6 r; for (int i = 0; i < 6; ++i) r.v[i] = a.v[i] - b.v[i]; return r; }
+DEV S6 scale6(double s, const S6& a) { S6 r; for (int i = 0; i < 6; ++i) r.v[i] = s * a.v[i]; return r; }
+DEV double dot6(const S6& a, const S6& b) { double s = 0; for (int i = 0; i < 6; ++i) s += a.v[i] * b.v[i]; return s; }
+DEV V3 lin(const S6& a) { return v3(a.v[0], a.v[1], a.v[2]); }
+DEV V3 ang(const S6& a) { return v3(a.v[3], a.v[4], a.v[5]); }
+DEV S6 mk6(V3 l, V3 a) { S6 r; r.v[0] = l.x; r.v[1] = l.y; r.v[2] = l.z; r.v[3] = a.x; r.v[4] = a.y; r.v[5] = a.z; return r; }
+// motion x motion and motion x* force
+DEV S6 mcross(const S6& a, const S6& b) { return mk6(cross(ang(a), lin(b)) + cross(lin(a), ang(b)), cross(ang(a), ang(b))); }
+DEV S6 fcross(const S6& a, const S6& f) { return mk6(cross(ang(a), lin(f)), cross(ang(a), ang(f)) + cross(lin(a), lin(f))); }
+DEV S6 mat6_mul(const double* Y, const S6& x) { S6 r; for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < 6; ++j) s += Y[6 * i + j] * x.v[j]; r.v[i] = s; } return r; }
+DEV S6 mat6_tmul(const double* Y, const S6& x) { S6 r; for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < 6; ++j) s += Y[6 * j + i] * x.v[j]; r.v[i] = s; } return r; }
+DEV M3 ldm3(const double* p) { M3 r; for (int i = 0; i < 9; ++i) r.m[i] = p[i]; return r; }
+DEV V3 ldv3(const double* p) { return v3(p[0], p[1], p[2]); }
+// Ad(M)^-1 on a motion, M = (R, p)
+DEV S6 adinv(const M3& R, V3 p, const S6& m) { return mk6(tmul(R, lin(m) - cross(p, ang(m))), tmul(R, ang(m))); }
+
+// ---- SE(3) Jacobians (Barfoot's Q block; right Jacobians as used by Pinocchio's Jlog6 / Jexp6) ------------
+DEV void q_coeffs(double t2, double& a1, double& a2, double& a3) {
+  if (t2 < kSmall2) {
+    a1 = 1.0 / 6 - t2 * (1.0 / 120 - t2 * (1.0 / 5040 - t2 * (1.0 / 362880)));
+    a2 = 1.0 / 24 - t2 * (1.0 / 720 - t2 * (1.0 / 40320 - t2 * (1.0 / 3628800)));
+    a3 = 1.0 / 120 - t2 * (1.0 / 2520 - t2 * (1.0 / 120960 - t2 * (1.0 / 9979200)));
+  } else {
+    const double t = sqrt(t2), s = sin(t), c = cos(t);
+    a1 = (t - s) / (t2 * t); a2 = (t2 + 2 * c - 2) / (2 * t2 * t2); a3 = (2 * t - 3 * s + t * c) / (2 * t2 * t2 * t);
+  }
+}
+DEV M3 add3(const M3& A, const M3& B) { M3 C; for (int i = 0; i < 9; ++i) C.m[i] = A.m[i] + B.m[i]; return C; }
+DEV M3 scl3(double s, const M3& A) { M3 C; for (int i = 0; i < 9; ++i) C.m[i] = s * A.m[i]; return C; }
+DEV M3 Qmat(V3 v, V3 w) {
+  double a1, a2, a3;
+  q_coeffs(dot(w, w), a1, a2, a3);
+  const M3 P = skew_m(v), F = skew_m(w);
+  const M3 FP = mul(F, P), PF = mul(P, F), FPF = mul(FP, F), FF = mul(F, F);
+  M3 Q = scl3(0.5, P);
+  Q = add3(Q, scl3(a1, add3(add3(FP, PF), FPF)));
+  Q = add3(Q, scl3(a2, add3(add3(mul(FF, P), mul(P, FF)), scl3(-3.0, FPF))));
+  Q = add3(Q, scl3(a3, add3(mul(FPF, F), mul(F, FPF))));
+  return Q;
+}
+// out (6x6 row-major) = Jlog6 at M = (R, p)
+DEV void Jlog6(const M3& R, V3 p, double* out) {
+  V3 v, w;
+  log6(R, p, v, w);
+  const double t2 = dot(w, w);
+  double c;
+  if (t2 < kSmall2) c = 1.0 / 12 + t2 * (1.0 / 720 + t2 * (1.0 / 30240 + t2 * (1.0 / 1209600)));
+  else { const double t = sqrt(t2); c = (1.0 - t * cos(0.5 * t) / (2.0 * sin(0.5 * t))) / t2; }
+  const M3 K = skew_m(w), K2 = mul(K, K);
+  M3 Ji;
+  for (int i = 0; i < 9; ++i) Ji.m[i] = ((i % 4 == 0) ? 1.0 : 0.0) + 0.5 * K.m[i] + c * K2.m[i];
+  const M3 Q = Qmat(v3(-v.x, -v.y, -v.z), v3(-w.x, -w.y, -w.z));
+  const M3 B = mul(mul(Ji, Q), Ji);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    out[6 * i + j] = Ji.m[3 * i + j]; out[6 * (i + 3) + j + 3] = Ji.m[3 * i + j];
+    out[6 * i + j + 3] = -B.m[3 * i + j]; out[6 * (i + 3) + j] = 0.0;
+  }
+}
+DEV void Jexp6(V3 v, V3 w, double* out) {
+  double A, B, C;
+  so3_coeffs(dot(w, w), A, B, C);
+  const M3 K = skew_m(w), K2 = mul(K, K);
+  const M3 Q = Qmat(v3(-v.x, -v.y, -v.z), v3(-w.x, -w.y, -w.z));
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    const double jr = ((i == j) ? 1.0 : 0.0) - B * K.m[3 * i + j] + C * K2.m[3 * i + j];
+    out[6 * i + j] = jr; out[6 * (i + 3) + j + 3] = jr; out[6 * i + j + 3] = Q.m[3 * i + j]; out[6 * (i + 3) + j] = 0.0;
+  }
+}
+
+// ---- LDS carve-out ------------------------------------------------------------------------------------------
+struct MbLds {
+  int nj, nv, nq, nl_max, nK_max;
+  // body arrays
+  int oR, op, ov, oa, oh, of, Fc, Hc, oY, Yc, Bc;
+  // dof arrays
+  int J, U, Psd, Psdd, Phi, Bt, Tq, Tv, vlam;
+  // matrices / vectors
+  int M, Kinv, X, S, Jc, dr, gam, bias, rhs, a, lam, x, u, xn, cfr, small, red, total;
+  int anc_bytes_off, total_bytes;
+};
+
+static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu) {
+  MbLds s;
+  s.nj = nj; s.nv = nv; s.nq = nq; s.nl_max = 12; s.nK_max = nv + 12;
+  int o = 0;
+  auto take = [&](int c) { int r = o; o += (c + 1) & ~1; return r; };
+  s.oR = take(9 * nj); s.op = take(3 * nj); s.ov = take(6 * nj); s.oa = take(6 * nj); s.oh = take(6 * nj); s.of = take(6 * nj);
+  s.Fc = take(6 * nj); s.Hc = take(6 * nj); s.oY = take(36 * nj); s.Yc = take(36 * nj); s.Bc = take(36 * nj);
+  s.J = take(6 * nv); s.U = take(6 * nv); s.Psd = take(6 * nv); s.Psdd = take(6 * nv); s.Phi = take(6 * nv);
+  s.Bt = take(6 * nv); s.Tq = take(6 * nv); s.Tv = take(6 * nv); s.vlam = take(12 * nv);
+  s.M = take(nv * nv); s.Kinv = take(s.nK_max * s.nK_max); s.X = take(nv * 12); s.S = take(2 * 144); s.Jc = take(12 * nv);
+  s.dr = take(s.nK_max * 2 * nv);  // also hosts Minv (nv*nv) before the derivative rows are built
+  s.gam = take(12); s.bias = take(nv); s.rhs = take(s.nK_max); s.a = take(nv); s.lam = take(12);
+  s.x = take(nq + nv); s.u = take(nu > 0 ? nu : 1); s.xn = take(nq + nv);
+  s.cfr = take(2 * (12 + 36 + 6));  // per contact: R(9) p(3), Jlog6(c2Mc1) (36), spare(6)
+  s.small = take(6 * 36 + 64);      // integrator 6x6 blocks and scratch
+  s.red = take(2 * 256 + 8);
+  s.total = o;
+  s.anc_bytes_off = o * 8;
+  s.total_bytes = o * 8 + nj * 8 + nv * 4 + nj * 4 * 3 + 64;
+  return s;
+}
+
+static inline void check_multibody_model(const int32_t* itab, int n_i) {
+  const int nj = itab[0];
+  if (nj > 64) throw std::runtime_error("multibody kernel supports at most 64 bodies");
+  const int32_t* ip = itab + MPC_MODEL_HEADER_WORDS;
+  for (int i = 0; i < nj; ++i, ip += MPC_MODEL_JOINT_WORDS) {
+    if (ip[0] >= i) throw std::runtime_error("model joints must be topologically ordered");
+    if ((ip[1] == MPC_JOINT_FREEFLYER) != (i == 0)) throw std::runtime_error("the multibody kernel needs a free-flyer root followed by revolute joints");
+    if (i > 0 && ip[2] != ip[3] + 1) throw std::runtime_error("unexpected idx_q / idx_v layout");
+  }
+  (void)n_i;
+}
+
+// doubles of per-workgroup HBM scratch: dsol [nK x nz] (da ; dlam) and the term Jacobian / weighted Jacobian
+static inline size_t multibody_work_doubles(const Layout& L) {
+  const int nv = L.n / 2;
+  return (size_t)(nv + 12) * L.nz + 2 * (size_t)24 * L.nz + 64;
+}
+
+struct MbArgs {
+  MbLds lds;
+  double* scratch;        // per-workgroup HBM scratch
+  size_t scratch_stride;  // doubles
+};
+
+// ============================================================================================================
+template <int TRIAL>
+__global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL, double* records, MbArgs mb) {
+  const Layout& L = a.L;
+  const MbLds& S = mb.lds;
+  const int k = blockIdx.x, b = blockIdx.y, cand = blockIdx.z, tid = threadIdx.x, nthr = blockDim.x;
+  const InstState& st = a.inst[b];
+  if (st.done || (TRIAL && st.skip_step)) return;
+  const int n = L.n, N = L.N, nx = L.nx, nv = S.nv, nq = S.nq, nj = S.nj, nu = L.m;
+  const int slot = stage_slot(a, k);
+  const int32_t* desc = a.stage_desc + (size_t)slot * L.max_stage_ints;
+  const double* P = a.stage_params + (size_t)slot * L.max_stage_doubles;
+  const int dyn = desc[0];
+  const bool has_dyn = dyn == MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER;
+  const int m = has_dyn ? nu : 0, nz = n + m, nterms = desc[5], c = desc[6];
+  const int nk = has_dyn ? desc[1] : 0, nl = 6 * nk, nK = nv + nl;
+  const bool derivs = !TRIAL;
+  const double alpha = TRIAL ? ldexp(1.0, -cand) : 0.0;
+  const size_t wg = TRIAL ? (((size_t)b * L.n_alpha + cand) * (N + 1) + k) : ((size_t)b * (N + 1) + k);
+  double* kn = records + wg * KL.knot_stride;
+  double* scr = mb.scratch + (TRIAL ? 0 : wg) * mb.scratch_stride;  // value-only passes never touch it
+  double* dsol = scr;                         // [nK][nz]: rows < nv = da, rows >= nv = dlam
+  double* Jt = scr + (size_t)(nv + 12) * L.nz;  // [24][nz]
+  double* WJ = Jt + (size_t)24 * L.nz;
+
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  unsigned long long* anc = (unsigned long long*)((char*)sm + S.anc_bytes_off);
+  int* dof_body = (int*)(anc + nj);
+  int* parent = dof_body + nv;
+  int* jkind = parent + nj;
+  int* jidxv = jkind + nj;
+  double *oR = sm + S.oR, *op = sm + S.op, *ov = sm + S.ov, *oa = sm + S.oa, *oh = sm + S.oh, *of = sm + S.of, *Fc = sm + S.Fc, *Hc = sm + S.Hc;
+  double *oY = sm + S.oY, *Yc = sm + S.Yc, *Bc = sm + S.Bc;
+  double *J = sm + S.J, *U = sm + S.U, *Psd = sm + S.Psd, *Psdd = sm + S.Psdd, *Phi = sm + S.Phi, *Bt = sm + S.Bt, *Tq = sm + S.Tq, *Tv = sm + S.Tv, *vlam = sm + S.vlam;
+  double *M = sm + S.M, *Kinv = sm + S.Kinv, *X = sm + S.X, *Sm = sm + S.S, *Jc = sm + S.Jc, *dr = sm + S.dr, *Minv = sm + S.dr;
+  double *gam = sm + S.gam, *bias = sm + S.bias, *rhs = sm + S.rhs, *acc = sm + S.a, *lam = sm + S.lam;
+  double *x = sm + S.x, *u = sm + S.u, *xn = sm + S.xn, *cfr = sm + S.cfr, *small = sm + S.small, *red = sm + S.red;
+  __shared__ int iflag[2];
+  __shared__ double s_cost;
+
+  const int32_t* mi = a.model_i;
+  const double* md = a.model_d;
+  const int nframes = mi[3];
+  const int32_t* mj = mi + MPC_MODEL_HEADER_WORDS;
+  const int32_t* mframe = mj + MPC_MODEL_JOINT_WORDS * nj;
+  const int32_t* mcontact = mframe + nframes;
+  const double* jd = md + MPC_MODEL_HEADER_DOUBLES;
+  const double* fd = jd + MPC_MODEL_JOINT_DOUBLES * nj;
+  const double* cd = fd + MPC_MODEL_FRAME_DOUBLES * nframes;
+  const double grav[3] = {md[0], md[1], md[2]};
+  const double prox_mu = md[3];
+  const S6 a0 = mk6(v3(-grav[0], -grav[1], -grav[2]), v3(0, 0, 0));
+
+  // ---- P0: evaluation point, tree tables ---------------------------------------------------------------
+  {
+    const double* xs = a.xs + ((size_t)b * (N + 1) + k) * nx;
+    const double* dx = a.dxs + ((size_t)b * (N + 1) + k) * n;
+    if (TRIAL) {
+      if (tid == 0) state_integrate(MPC_SPACE_MULTIBODY, nx, n, xs, dx, alpha, x);
+      if (tid == 64 && k < N) state_integrate(MPC_SPACE_MULTIBODY, nx, n, xs + nx, dx + n, alpha, xn);
+    } else {
+      for (int i = tid; i < nx; i += nthr) { x[i] = xs[i]; if (k < N) xn[i] = xs[nx + i]; }
+    }
+    if (k < N) {
+      const double* us = a.us + ((size_t)b * N + k) * nu;
+      const double* du = a.dus + ((size_t)b * N + k) * nu;
+      for (int i = tid; i < nu; i += nthr) u[i] = us[i] + (TRIAL ? alpha * du[i] : 0.0);
+    }
+    for (int i = tid; i < nj; i += nthr) {
+      parent[i] = mj[4 * i]; jkind[i] = mj[4 * i + 1]; jidxv[i] = mj[4 * i + 3];
+      unsigned long long msk = 0ull;
+      for (int j = i; j >= 0; j = mj[4 * j]) msk |= 1ull << j;
+      anc[i] = msk;
+      const int ndof = (mj[4 * i + 1] == MPC_JOINT_FREEFLYER) ? 6 : 1;
+      for (int d = 0; d < ndof; ++d) dof_body[mj[4 * i + 3] + d] = i;
+    }
+    if (tid == 0) s_cost = 0.0;
+  }
+  __syncthreads();
+  clear_knot(KL, kn, nz, derivs, tid, nthr);
+  const double* q = x;
+  const double* v = x + nq;
+#define BELOW(kdof, body) ((anc[(body)] >> dof_body[(kdof)]) & 1ull)
+#define INSUB(j, i) ((anc[(j)] >> (i)) & 1ull)
+
+  // ---- P1: local joint transforms (stored in the Bc region), then world placements ----------------------
+  double* lR = Bc;
+  double* lp = Bc + 9 * nj;
+  for (int i = tid; i < nj; i += nthr) {
+    const M3 Rp = ldm3(jd + 25 * i);
+    const V3 pp = ldv3(jd + 25 * i + 9);
+    M3 Rj;
+    V3 pj = v3(0, 0, 0);
+    if (jkind[i] == MPC_JOINT_FREEFLYER) { Rj = quat_to_rot(q + 3); pj = v3(q[0], q[1], q[2]); }
+    else {
+      const double th = q[jidxv[i] + 1], cs = cos(th), sn = sin(th);
+      const int ax = jkind[i] - MPC_JOINT_RX, b1 = (ax + 1) % 3, b2 = (ax + 2) % 3;
+      for (int e = 0; e < 9; ++e) Rj.m[e] = (e % 4 == 0) ? 1.0 : 0.0;
+      Rj.m[3 * b1 + b1] = cs; Rj.m[3 * b1 + b2] = -sn; Rj.m[3 * b2 + b1] = sn; Rj.m[3 * b2 + b2] = cs;
+    }
+    const M3 Rl = mul(Rp, Rj);
+    const V3 pl = mul(Rp, pj) + pp;
+    for (int e = 0; e < 9; ++e) lR[9 * i + e] = Rl.m[e];
+    lp[3 * i] = pl.x; lp[3 * i + 1] = pl.y; lp[3 * i + 2] = pl.z;
+  }
+  __syncthreads();
+  for (int i = tid; i < nj; i += nthr) {
+    M3 R = ldm3(lR + 9 * i);
+    V3 p = ldv3(lp + 3 * i);
+    for (int j = parent[i]; j >= 0; j = parent[j]) {
+      const M3 Rj = ldm3(lR + 9 * j);
+      p = mul(Rj, p) + ldv3(lp + 3 * j);
+      R = mul(Rj, R);
+    }
+    for (int e = 0; e < 9; ++e) oR[9 * i + e] = R.m[e];
+    op[3 * i] = p.x; op[3 * i + 1] = p.y; op[3 * i + 2] = p.z;
+  }
+  __syncthreads();
+  // ---- P2: world-frame joint columns -------------------------------------------------------------------
+  for (int kd = tid; kd < nv; kd += nthr) {
+    const int i = dof_body[kd], loc = kd - jidxv[i];
+    const M3 R = ldm3(oR + 9 * i);
+    const V3 p = ldv3(op + 3 * i);
+    S6 col;
+    if (jkind[i] == MPC_JOINT_FREEFLYER && loc < 3) col = mk6(v3(R.m[loc], R.m[3 + loc], R.m[6 + loc]), v3(0, 0, 0));
+    else {
+      const int ax = (jkind[i] == MPC_JOINT_FREEFLYER) ? loc - 3 : jkind[i] - MPC_JOINT_RX;
+      const V3 w = v3(R.m[ax], R.m[3 + ax], R.m[6 + ax]);
+      col = mk6(cross(p, w), w);
+    }
+    st6(J + 6 * kd, col);
+  }
+  __syncthreads();
+  // ---- P3: body velocities ------------------------------------------------------------------------------
+  for (int idx = tid; idx < 6 * nj; idx += nthr) {
+    const int i = idx / 6, e = idx % 6;
+    double s = 0;
+    for (int kd = 0; kd < nv; ++kd) if (BELOW(kd, i)) s += J[6 * kd + e] * v[kd];
+    ov[idx] = s;
+  }
+  __syncthreads();
+  // ---- P4: bias accelerations (gravity field), spatial inertias, momenta --------------------------------
+  for (int i = tid; i < nj; i += nthr) {
+    S6 ai = a0;
+    for (int kd = 0; kd < nv; ++kd)
+      if (BELOW(kd, i)) ai = add6(ai, scale6(v[kd], mcross(ld6(ov + 6 * dof_body[kd]), ld6(J + 6 * kd))));
+    st6(oa + 6 * i, ai);
+    const M3 R = ldm3(oR + 9 * i);
+    const double mass = jd[25 * i + 12];
+    const V3 cw = mul(R, ldv3(jd + 25 * i + 13)) + ldv3(op + 3 * i);
+    const M3 RI = mul(R, ldm3(jd + 25 * i + 16));
+    M3 Iww;  // R I R^T
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Iww.m[3 * r + cc] = RI.m[3 * r] * R.m[3 * cc] + RI.m[3 * r + 1] * R.m[3 * cc + 1] + RI.m[3 * r + 2] * R.m[3 * cc + 2];
+    const M3 Sx = skew_m(cw), S2 = mul(Sx, Sx);
+    double* Y = oY + 36 * i;
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
+      Y[6 * r + cc] = (r == cc) ? mass : 0.0;
+      Y[6 * r + cc + 3] = -mass * Sx.m[3 * r + cc];
+      Y[6 * (r + 3) + cc] = mass * Sx.m[3 * r + cc];
+      Y[6 * (r + 3) + cc + 3] = Iww.m[3 * r + cc] - mass * S2.m[3 * r + cc];
+    }
+    st6(oh + 6 * i, mat6_mul(Y, ld6(ov + 6 * i)));
+  }
+  __syncthreads();
+  // ---- P5: composite inertias / momenta, bias forces ----------------------------------------------------
+  for (int idx = tid; idx < 36 * nj; idx += nthr) {
+    const int i = idx / 36, e = idx % 36;
+    double s = 0;
+    for (int j = i; j < nj; ++j) if (INSUB(j, i)) s += oY[36 * j + e];
+    Yc[idx] = s;
+  }
+  for (int idx = tid; idx < 6 * nj; idx += nthr) {
+    const int i = idx / 6, e = idx % 6;
+    double s = 0;
+    for (int j = i; j < nj; ++j) if (INSUB(j, i)) s += oh[6 * j + e];
+    Hc[idx] = s;
+  }
+  for (int i = tid; i < nj; i += nthr)
+    st6(of + 6 * i, add6(mat6_mul(oY + 36 * i, ld6(oa + 6 * i)), fcross(ld6(ov + 6 * i), ld6(oh + 6 * i))));
+  __syncthreads();
+  for (int idx = tid; idx < 6 * nj; idx += nthr) {
+    const int i = idx / 6, e = idx % 6;
+    double s = 0;
+    for (int j = i; j < nj; ++j) if (INSUB(j, i)) s += of[6 * j + e];
+    Fc[idx] = s;
+  }
+  for (int kd = tid; kd < nv; kd += nthr) st6(U + 6 * kd, mat6_mul(Yc + 36 * dof_body[kd], ld6(J + 6 * kd)));
+  __syncthreads();
+
+  if (has_dyn) {
+    const double dt = P[desc[4]];
+    // ---- P6: joint-space inertia, bias torques, contact frames -------------------------------------------
+    for (int idx = tid; idx < nv * nv; idx += nthr) {
+      const int r = idx / nv, cc = idx % nv;
+      double s = 0;
+      if (BELOW(cc, dof_body[r])) s = dot6(ld6(U + 6 * r), ld6(J + 6 * cc));
+      else if (BELOW(r, dof_body[cc])) s = dot6(ld6(U + 6 * cc), ld6(J + 6 * r));
+      M[idx] = s;
+    }
+    for (int kd = tid; kd < nv; kd += nthr) bias[kd] = dot6(ld6(J + 6 * kd), ld6(Fc + 6 * dof_body[kd]));
+    if (tid < nk) {
+      const int cid = desc[2 + tid], i = mcontact[cid];
+      const double* cm = cd + MPC_MODEL_CONTACT_DOUBLES * cid;
+      const M3 Ri = ldm3(oR + 9 * i);
+      const M3 Rc = mul(Ri, ldm3(cm));
+      const V3 pc = mul(Ri, ldv3(cm + 9)) + ldv3(op + 3 * i);
+      double* cf = cfr + 54 * tid;
+      for (int e = 0; e < 9; ++e) cf[e] = Rc.m[e];
+      cf[9] = pc.x; cf[10] = pc.y; cf[11] = pc.z;
+      const M3 R2 = ldm3(cm + 12);
+      const V3 p2 = ldv3(cm + 21);
+      V3 ev, ew;
+      log6(tmul(Rc, R2), tmul(Rc, p2 - pc), ev, ew);
+      const S6 e6 = mk6(ev, ew);
+      const S6 acb = adinv(Rc, pc, sub6(ld6(oa + 6 * i), a0));
+      const S6 vcb = adinv(Rc, pc, ld6(ov + 6 * i));
+      for (int r = 0; r < 6; ++r) gam[6 * tid + r] = acb.v[r] + cm[30 + r] * vcb.v[r] - cm[24 + r] * e6.v[r];
+      if (derivs) Jlog6(tmul(R2, Rc), tmul(R2, pc - p2), cf + 12);  // Jlog6(c2Mc1)
+    }
+    __syncthreads();
+    for (int idx = tid; idx < nk * nv; idx += nthr) {
+      const int cc = idx / nv, kd = idx % nv;
+      const int i = mcontact[desc[2 + cc]];
+      S6 col = zero6();
+      if (BELOW(kd, i)) col = adinv(ldm3(cfr + 54 * cc), ldv3(cfr + 54 * cc + 9), ld6(J + 6 * kd));
+      for (int r = 0; r < 6; ++r) Jc[(6 * cc + r) * nv + kd] = col.v[r];
+    }
+    for (int idx = tid; idx < nv * nv; idx += nthr) Minv[idx] = (idx / nv == idx % nv) ? 1.0 : 0.0;
+    __syncthreads();
+    // ---- P7: KKT inverse by blocks:  Minv, X = Minv Jc^T, S = Jc X + mu I, Kinv ---------------------------
+    if (!chol_block(M, nv, nv, tid, nthr, iflag)) { if (tid == 0) a.inst[b].done = 5; return; }
+    potrs_block(M, nv, nv, Minv, nv, nv, tid, nthr);
+    for (int idx = tid; idx < nv * nl; idx += nthr) {
+      const int r = idx / nl, cc = idx % nl;
+      double s = 0;
+      for (int l = 0; l < nv; ++l) s += Minv[r * nv + l] * Jc[cc * nv + l];
+      X[idx] = s;
+    }
+    __syncthreads();
+    double* Sinv = Sm + 144;
+    for (int idx = tid; idx < nl * nl; idx += nthr) {
+      const int r = idx / nl, cc = idx % nl;
+      double s = (r == cc) ? prox_mu : 0.0;
+      for (int l = 0; l < nv; ++l) s += Jc[r * nv + l] * X[l * nl + cc];
+      Sm[idx] = s;
+      Sinv[idx] = (r == cc) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (nl > 0) {
+      if (!chol_block(Sm, nl, nl, tid, nthr, iflag)) { if (tid == 0) a.inst[b].done = 6; return; }
+      potrs_block(Sm, nl, nl, Sinv, nl, nl, tid, nthr);
+    }
+    // XS = X Sinv  (stored in the Kinv 12-block first)
+    for (int idx = tid; idx < nv * nl; idx += nthr) {
+      const int r = idx / nl, cc = idx % nl;
+      double s = 0;
+      for (int l = 0; l < nl; ++l) s += X[r * nl + l] * Sinv[l * nl + cc];
+      Kinv[r * nK + nv + cc] = s;
+      Kinv[(nv + cc) * nK + r] = s;
+    }
+    for (int idx = tid; idx < nl * nl; idx += nthr) Kinv[(nv + idx / nl) * nK + nv + idx % nl] = -Sinv[idx];
+    __syncthreads();
+    for (int idx = tid; idx < nv * nv; idx += nthr) {
+      const int r = idx / nv, cc = idx % nv;
+      double s = Minv[idx];
+      for (int l = 0; l < nl; ++l) s -= Kinv[r * nK + nv + l] * X[cc * nl + l];
+      Kinv[r * nK + cc] = s;
+    }
+    for (int i = tid; i < nK; i += nthr) rhs[i] = (i < nv) ? (-bias[i] + (i >= nv - nu ? u[i - (nv - nu)] : 0.0)) : -gam[i - nv];
+    __syncthreads();
+    // ---- P8: solve, then accelerations / forces at the solution -------------------------------------------
+    for (int i = tid; i < nK; i += nthr) {
+      double s = 0;
+      for (int l = 0; l < nK; ++l) s += Kinv[i * nK + l] * rhs[l];
+      if (i < nv) acc[i] = s; else lam[i - nv] = -s;
+    }
+    __syncthreads();
+    if (derivs) {
+      for (int i = tid; i < n; i += nthr) kn[KL.oXD + i] = (i < nv) ? v[i] : acc[i - nv];
+      for (int i = tid; i < 12; i += nthr) kn[KL.oWR + i] = 0.0;
+      __syncthreads();
+      for (int i = tid; i < nl; i += nthr) kn[KL.oWR + 6 * desc[2 + i / 6] + i % 6] = lam[i];
+    }
+    for (int idx = tid; idx < 6 * nj; idx += nthr) {
+      const int i = idx / 6, e = idx % 6;
+      double s = oa[idx];
+      for (int kd = 0; kd < nv; ++kd) if (BELOW(kd, i)) s += J[6 * kd + e] * acc[kd];
+      oa[idx] = s;
+    }
+    __syncthreads();
+    if (derivs) {
+      for (int i = tid; i < nj; i += nthr) {
+        S6 f = add6(mat6_mul(oY + 36 * i, ld6(oa + 6 * i)), fcross(ld6(ov + 6 * i), ld6(oh + 6 * i)));
+        for (int cc = 0; cc < nk; ++cc) {
+          if (mcontact[desc[2 + cc]] != i) continue;
+          const M3 Rc = ldm3(cfr + 54 * cc);
+          const V3 pc = ldv3(cfr + 54 * cc + 9);
+          const V3 fl = mul(Rc, v3(lam[6 * cc], lam[6 * cc + 1], lam[6 * cc + 2]));
+          const V3 fa = mul(Rc, v3(lam[6 * cc + 3], lam[6 * cc + 4], lam[6 * cc + 5])) + cross(pc, fl);
+          f = sub6(f, mk6(fl, fa));
+        }
+        st6(of + 6 * i, f);
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 6 * nj; idx += nthr) {
+        const int i = idx / 6, e = idx % 6;
+        double s = 0;
+        for (int j = i; j < nj; ++j) if (INSUB(j, i)) s += of[6 * j + e];
+        Fc[idx] = s;
+      }
+    }
+    __syncthreads();
+    (void)dt;
+  }
+
+  // ---- P9: derivative building blocks (also needed by velocity-dependent residuals) ------------------------
+  for (int kd = tid; kd < nv; kd += nthr) {
+    const int pb = parent[dof_body[kd]];
+    const S6 vl = (pb >= 0) ? ld6(ov + 6 * pb) : zero6();
+    const S6 al = (pb >= 0) ? ld6(oa + 6 * pb) : a0;
+    st6(vlam + 12 * kd, vl);
+    st6(vlam + 12 * kd + 6, al);
+    const S6 Jk = ld6(J + 6 * kd);
+    const S6 psd = mcross(vl, Jk);
+    st6(Psd + 6 * kd, psd);
+    st6(Psdd + 6 * kd, add6(mcross(al, Jk), mcross(vl, psd)));
+    st6(Phi + 6 * kd, mcross(add6(ld6(ov + 6 * dof_body[kd]), vl), Jk));
+  }
+  __syncthreads();
+  if (derivs && has_dyn) {
+    // body-level "Coriolis" matrices B_i (overwrite oY), then their subtree sums
+    for (int i = tid; i < nj; i += nthr) {
+      double Yl[36], Bm[36];
+      for (int e = 0; e < 36; ++e) Yl[e] = oY[36 * i + e];
+      const S6 vi = ld6(ov + 6 * i), hi = ld6(oh + 6 * i);
+      for (int col = 0; col < 6; ++col) {
+        S6 e6 = zero6();
+        e6.v[col] = 1.0;
+        const S6 r = add6(add6(mat6_mul(Yl, mcross(e6, vi)), fcross(e6, hi)), fcross(vi, mat6_mul(Yl, e6)));
+        for (int row = 0; row < 6; ++row) Bm[6 * row + col] = r.v[row];
+      }
+      for (int e = 0; e < 36; ++e) oY[36 * i + e] = Bm[e];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 36 * nj; idx += nthr) {
+      const int i = idx / 36, e = idx % 36;
+      double s = 0;
+      for (int j = i; j < nj; ++j) if (INSUB(j, i)) s += oY[36 * j + e];
+      Bc[idx] = s;
+    }
+    __syncthreads();
+    for (int kd = tid; kd < nv; kd += nthr) {
+      const int bk = dof_body[kd];
+      const S6 Jk = ld6(J + 6 * kd);
+      st6(Bt + 6 * kd, mat6_tmul(Bc + 36 * bk, Jk));
+      st6(Tq + 6 * kd, add6(add6(mat6_mul(Yc + 36 * bk, ld6(Psdd + 6 * kd)), mat6_mul(Bc + 36 * bk, ld6(Psd + 6 * kd))), fcross(Jk, ld6(Fc + 6 * bk))));
+      st6(Tv + 6 * kd, add6(mat6_mul(Yc + 36 * bk, ld6(Phi + 6 * kd)), mat6_mul(Bc + 36 * bk, Jk)));
+    }
+    __syncthreads();
+    // ---- P10: rows of [d r1 ; d r2] w.r.t. (q, v)  (dr is nK x 2nv; Minv is dead from here on) -------------
+    const int n2 = 2 * nv;
+    for (int idx = tid; idx < nv * nv; idx += nthr) {
+      const int r = idx / nv, j = idx % nv;
+      const int br = dof_body[r], bj = dof_body[j];
+      double dq = 0, dv = 0;
+      if ((anc[br] >> bj) & 1ull) {
+        const S6 Ur = ld6(U + 6 * r), Btr = ld6(Bt + 6 * r);
+        dq = dot6(Ur, ld6(Psdd + 6 * j)) + dot6(Btr, ld6(Psd + 6 * j));
+        dv = dot6(Ur, ld6(Phi + 6 * j)) + dot6(Btr, ld6(J + 6 * j));
+      } else if ((anc[bj] >> br) & 1ull) {
+        const S6 Jr = ld6(J + 6 * r);
+        dq = dot6(Jr, ld6(Tq + 6 * j));
+        dv = dot6(Jr, ld6(Tv + 6 * j));
+      }
+      dr[r * n2 + j] = dq;
+      dr[r * n2 + nv + j] = dv;
+    }
+    for (int idx = tid; idx < nk * nv; idx += nthr) {
+      const int cc = idx / nv, j = idx % nv;
+      const int cid = desc[2 + cc], i = mcontact[cid];
+      const double* cm = cd + MPC_MODEL_CONTACT_DOUBLES * cid;
+      S6 rq = zero6(), rv = zero6();
+      if (BELOW(j, i)) {
+        const M3 Rc = ldm3(cfr + 54 * cc);
+        const V3 pc = ldv3(cfr + 54 * cc + 9);
+        const S6 Jj = ld6(J + 6 * j), vl = ld6(vlam + 12 * j), al = ld6(vlam + 12 * j + 6), psd = ld6(Psd + 6 * j);
+        const S6 w = sub6(ld6(ov + 6 * i), vl);
+        const S6 dacq = adinv(Rc, pc, add6(mcross(sub6(al, a0), Jj), mcross(psd, w)));
+        const S6 dacv = adinv(Rc, pc, add6(mcross(ld6(ov + 6 * dof_body[j]), Jj), mcross(Jj, w)));
+        const S6 apsd = adinv(Rc, pc, psd);
+        S6 Jcj;
+        for (int r = 0; r < 6; ++r) Jcj.v[r] = Jc[(6 * cc + r) * nv + j];
+        const S6 jl = mat6_mul(cfr + 54 * cc + 12, Jcj);
+        for (int r = 0; r < 6; ++r) {
+          rq.v[r] = dacq.v[r] + cm[30 + r] * apsd.v[r] + cm[24 + r] * jl.v[r];
+          rv.v[r] = dacv.v[r] + cm[30 + r] * Jcj.v[r];
+        }
+      }
+      for (int r = 0; r < 6; ++r) { dr[(nv + 6 * cc + r) * n2 + j] = rq.v[r]; dr[(nv + 6 * cc + r) * n2 + nv + j] = rv.v[r]; }
+    }
+    __syncthreads();
+    // ---- P11: implicit differentiation  d[a; -lam]/d(q,v) = -Kinv dr ;  d/du from the actuated columns -----
+    for (int idx = tid; idx < nK * nz; idx += nthr) {
+      const int r = idx / nz, z = idx % nz;
+      double s = 0;
+      if (z < n2) { for (int l = 0; l < nK; ++l) s += Kinv[r * nK + l] * dr[l * n2 + z]; s = (r < nv) ? -s : s; }
+      else { s = Kinv[r * nK + (nv - nu) + (z - n2)]; s = (r < nv) ? s : -s; }
+      dsol[(size_t)r * L.nz + z] = s;
+    }
+    __syncthreads();
+  }
+
+  // ---- P12: semi-implicit Euler, gap and its Jacobians ----------------------------------------------------
+  if (has_dyn) {
+    const double dt = P[desc[4]];
+    double* Jl6 = small;        // Jlog6(G)
+    double* Je6 = small + 36;   // Jexp6(delta)
+    double* Jq6 = small + 72;   // Ad(exp6(delta))^-1
+    if (tid == 0) {
+      const V3 dl = v3(dt * (v[0] + dt * acc[0]), dt * (v[1] + dt * acc[1]), dt * (v[2] + dt * acc[2]));
+      const V3 da_ = v3(dt * (v[3] + dt * acc[3]), dt * (v[4] + dt * acc[4]), dt * (v[5] + dt * acc[5]));
+      M3 dR; V3 dp;
+      exp6(dl, da_, dR, dp);
+      const M3 Rb = quat_to_rot(q + 3);
+      const M3 Rn = mul(Rb, dR);
+      const V3 pn = mul(Rb, dp) + v3(q[0], q[1], q[2]);
+      if (derivs) { kn[KL.oXN] = pn.x; kn[KL.oXN + 1] = pn.y; kn[KL.oXN + 2] = pn.z; rot_to_quat(Rn, kn + KL.oXN + 3); }
+      const M3 Rt = quat_to_rot(xn + 3);
+      const M3 GR = tmul(Rt, Rn);
+      const V3 Gp = tmul(Rt, pn - v3(xn[0], xn[1], xn[2]));
+      V3 gv, gw;
+      log6(GR, Gp, gv, gw);
+      kn[KL.oF] = gv.x; kn[KL.oF + 1] = gv.y; kn[KL.oF + 2] = gv.z; kn[KL.oF + 3] = gw.x; kn[KL.oF + 4] = gw.y; kn[KL.oF + 5] = gw.z;
+      if (derivs) {
+        Jlog6(GR, Gp, Jl6);
+        Jexp6(dl, da_, Je6);
+        // Ad(exp6(delta))^-1 = [[dR^T, -dR^T [dp]x],[0, dR^T]]
+        const M3 Sx = skew_m(dp);
+        const M3 RtS = tmul(dR, Sx);
+        for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
+          Jq6[6 * r + cc] = dR.m[3 * cc + r]; Jq6[6 * (r + 3) + cc + 3] = dR.m[3 * cc + r];
+          Jq6[6 * r + cc + 3] = -RtS.m[3 * r + cc]; Jq6[6 * (r + 3) + cc] = 0.0;
+        }
+        // E6 = -Jlog6(G^-1)
+        double E[36];
+        M3 Gi;
+        for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Gi.m[3 * r + cc] = GR.m[3 * cc + r];
+        const V3 gip = mul(Gi, v3(-Gp.x, -Gp.y, -Gp.z));
+        Jlog6(Gi, gip, E);
+        for (int e = 0; e < 36; ++e) kn[KL.oE6 + e] = -E[e];
+      }
+    }
+    for (int i = 6 + tid; i < n; i += nthr) {
+      if (i < nv) { const double vp = v[i] + dt * acc[i]; kn[KL.oF + i] = q[i + 1] + dt * vp - xn[i + 1]; if (derivs) kn[KL.oXN + i + 1] = q[i + 1] + dt * vp; }
+      else if (i >= nv) { const int j = i - nv; const double vp = v[j] + dt * acc[j]; kn[KL.oF + i] = vp - xn[nq + j]; if (derivs) kn[KL.oXN + nq + j] = vp; }
+    }
+    __syncthreads();
+    if (derivs) {
+      // dvp = dt * da + [0 I 0];  rows nv..n of AB = dvp; rows 6..nv = dt dvp + [I 0 0]; base rows below
+      for (int idx = tid; idx < nv * nz; idx += nthr) {
+        const int r = idx / nz, z = idx % nz;
+        const double dvp = dt * dsol[(size_t)r * L.nz + z] + ((z == nv + r) ? 1.0 : 0.0);
+        kn[KL.oAB + (size_t)(nv + r) * KL.nz + z] = dvp;
+        if (r >= 6) kn[KL.oAB + (size_t)r * KL.nz + z] = dt * dvp + ((z == r) ? 1.0 : 0.0);
+      }
+      __syncthreads();
+      // base rows: Jlog6(G) ( dt Jexp6 dvp[0:6] + [Jq6 0] )
+      for (int idx = tid; idx < 6 * nz; idx += nthr) {
+        const int r = idx / nz, z = idx % nz;
+        double s = (z < 6) ? Jq6[6 * r + z] : 0.0;
+        for (int l = 0; l < 6; ++l) s += dt * Je6[6 * r + l] * kn[KL.oAB + (size_t)(nv + l) * KL.nz + z];
+        Jt[idx] = s;  // temporary (6 x nz)
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 6 * nz; idx += nthr) {
+        const int r = idx / nz, z = idx % nz;
+        double s = 0;
+        for (int l = 0; l < 6; ++l) s += Jl6[6 * r + l] * Jt[l * nz + z];
+        kn[KL.oAB + (size_t)r * KL.nz + z] = s;
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- P13: cost stack and constraints -----------------------------------------------------------------------
+  // centre of mass and total momentum (body 0 is the root: its composite = whole robot)
+  double mtot = 0;
+  for (int i = 0; i < nj; ++i) mtot += jd[25 * i + 12];
+  // com = (1/m) * first moment; from the composite inertia of the root: Yc[0] lower-left block = m [c]x
+  const V3 com = v3(Yc[6 * 5 + 1] / mtot, Yc[6 * 3 + 2] / mtot, Yc[6 * 4 + 0] / mtot);
+  const S6 h0 = ld6(Hc);
+  int row = 0;
+  for (int t = 0; t < nterms; ++t) {
+    const TermRec tr = load_term(desc, t);
+    const double* tp = P + tr.poff;
+    const int d = tr.dim;
+    double* r = red + 2 * 256 - 64;  // 64 doubles of residual scratch at the tail of `red` (dim <= 56 only for state error, handled separately)
+    bool generic = true;
+    if (tr.type == MPC_TERM_STATE_ERROR) {
+      // r = x_ref (-) x ; J = -I except the base block -Jlog6(Mref^-1 M)
+      double* Jb = small + 108;  // 36
+      double* rfull = dr;        // reuse (n doubles) — dr is dead after P11
+      if (tid == 0) {
+        const M3 Rr = quat_to_rot(tp + 3), Rb = quat_to_rot(q + 3);
+        const V3 pr = v3(tp[0], tp[1], tp[2]), pb = v3(q[0], q[1], q[2]);
+        V3 ev, ew;
+        log6(tmul(Rb, Rr), tmul(Rb, pr - pb), ev, ew);
+        rfull[0] = ev.x; rfull[1] = ev.y; rfull[2] = ev.z; rfull[3] = ew.x; rfull[4] = ew.y; rfull[5] = ew.z;
+        if (derivs) { Jlog6(tmul(Rr, Rb), tmul(Rr, pb - pr), Jb); for (int e = 0; e < 36; ++e) Jb[e] = -Jb[e]; }
+      }
+      for (int i = 6 + tid; i < n; i += nthr) rfull[i] = (i < nv) ? (tp[i + 1] - q[i + 1]) : (tp[nq + i - nv] - v[i - nv]);
+      __syncthreads();
+      const double* W = P + tr.woff;
+      const bool diag = tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT;
+      if (tr.role == MPC_ROLE_COST && diag) {
+        generic = false;
+        if (tid == 0) { double cst = 0; for (int i = 0; i < d; ++i) cst += W[i] * rfull[tr.i0 + i] * rfull[tr.i0 + i]; s_cost += 0.5 * cst; }
+        if (derivs) {
+          // rows i0..i0+d of the full residual; row index ri = i0 + i
+          for (int z = tid; z < n; z += nthr) {
+            double g = 0;
+            if (z < 6) { for (int i = 0; i < d; ++i) { const int ri = tr.i0 + i; if (ri < 6) g += Jb[6 * ri + z] * W[i] * rfull[ri]; } }
+            else if (z >= tr.i0 && z < tr.i0 + d) g = -W[z - tr.i0] * rfull[z];
+            kn[KL.oG + z] += g;
+            if (z >= 6 && z >= tr.i0 && z < tr.i0 + d) kn[KL.oH + (size_t)z * KL.nz + z] += W[z - tr.i0];
+          }
+          for (int idx = tid; idx < 36; idx += nthr) {
+            const int za = idx / 6, zb = idx % 6;
+            double h = 0;
+            for (int i = 0; i < d; ++i) { const int ri = tr.i0 + i; if (ri < 6) h += Jb[6 * ri + za] * W[i] * Jb[6 * ri + zb]; }
+            kn[KL.oH + (size_t)za * KL.nz + zb] += h;
+          }
+        }
+        __syncthreads();
+      } else if (tr.role != MPC_ROLE_COST && tr.i0 >= 6) {
+        // joint-space selector rows (fulldynamic_talos.py:208-209): written straight into the knot record
+        generic = false;
+        for (int i = tid; i < d; i += nthr) {
+          kn[KL.oCV + row + i] = rfull[tr.i0 + i];
+          kn[KL.oCT + row + i] = (double)tr.role;
+          kn[KL.oLO + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + i] : 0.0;
+          kn[KL.oHI + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + d + i] : 0.0;
+        }
+        if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) kn[KL.oCD + (size_t)(row + idx / nz) * KL.nz + idx % nz] = ((idx % nz) == tr.i0 + idx / nz) ? -1.0 : 0.0;
+        __syncthreads();
+      } else {
+        // generic path (constraints on the base / dense weights, dim <= 24): materialise the sliced rows
+        for (int i = tid; i < d; i += nthr) r[i] = rfull[tr.i0 + i];
+        if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) {
+          const int i = idx / nz, z = idx % nz, ri = tr.i0 + i;
+          double jv = 0;
+          if (ri < 6) jv = (z < 6) ? Jb[6 * ri + z] : 0.0;
+          else jv = (z == ri) ? -1.0 : 0.0;
+          Jt[idx] = jv;
+        }
+        __syncthreads();
+      }
+    } else if (tr.type == MPC_TERM_CONTROL_ERROR) {
+      const double* W = P + tr.woff;
+      const bool diag = tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT;
+      if (tr.role == MPC_ROLE_COST && diag) {
+        generic = false;
+        if (tid == 0) { double cst = 0; for (int i = 0; i < d; ++i) { const double e = u[tr.i0 + i] - tp[tr.i0 + i]; cst += W[i] * e * e; } s_cost += 0.5 * cst; }
+        if (derivs) for (int i = tid; i < d; i += nthr) {
+          const int z = n + tr.i0 + i;
+          kn[KL.oG + z] += W[i] * (u[tr.i0 + i] - tp[tr.i0 + i]);
+          kn[KL.oH + (size_t)z * KL.nz + z] += W[i];
+        }
+        __syncthreads();
+      } else if (tr.role != MPC_ROLE_COST) {
+        // torque box (fulldynamic_talos.py:206-207): selector rows written straight into the knot record
+        generic = false;
+        for (int i = tid; i < d; i += nthr) {
+          kn[KL.oCV + row + i] = u[tr.i0 + i] - tp[tr.i0 + i];
+          kn[KL.oCT + row + i] = (double)tr.role;
+          kn[KL.oLO + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + i] : 0.0;
+          kn[KL.oHI + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + d + i] : 0.0;
+        }
+        if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) kn[KL.oCD + (size_t)(row + idx / nz) * KL.nz + idx % nz] = ((idx % nz) == n + tr.i0 + idx / nz) ? 1.0 : 0.0;
+        __syncthreads();
+      } else {
+        for (int i = tid; i < d; i += nthr) r[i] = u[tr.i0 + i] - tp[tr.i0 + i];
+        if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) Jt[idx] = ((idx % nz) == n + tr.i0 + idx / nz) ? 1.0 : 0.0;
+        __syncthreads();
+      }
+    } else {
+      if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) Jt[idx] = 0.0;
+      __syncthreads();
+      if (tr.type == MPC_TERM_FRAME_PLACEMENT || tr.type == MPC_TERM_FRAME_TRANSLATION || tr.type == MPC_TERM_FRAME_VELOCITY) {
+        const int fi = tr.i0, i = mframe[fi];
+        const M3 Ri = ldm3(oR + 9 * i);
+        const M3 Rf = mul(Ri, ldm3(fd + 12 * fi));
+        const V3 pf = mul(Ri, ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+        double* Jl = small + 108;
+        if (tr.type == MPC_TERM_FRAME_PLACEMENT) {
+          if (tid == 0) {
+            const M3 Rr = ldm3(tp);
+            const V3 pr = ldv3(tp + 9);
+            V3 ev, ew;
+            log6(tmul(Rr, Rf), tmul(Rr, pf - pr), ev, ew);
+            r[0] = ev.x; r[1] = ev.y; r[2] = ev.z; r[3] = ew.x; r[4] = ew.y; r[5] = ew.z;
+            if (derivs) Jlog6(tmul(Rr, Rf), tmul(Rr, pf - pr), Jl);
+          }
+          __syncthreads();
+          if (derivs) for (int j = tid; j < nv; j += nthr) if (BELOW(j, i)) {
+            const S6 col = mat6_mul(Jl, adinv(Rf, pf, ld6(J + 6 * j)));
+            for (int rr = 0; rr < 6; ++rr) Jt[rr * nz + j] = col.v[rr];
+          }
+        } else if (tr.type == MPC_TERM_FRAME_TRANSLATION) {
+          if (tid < d) { const double pfa[3] = {pf.x, pf.y, pf.z}; r[tid] = pfa[tr.i1 + tid] - tp[tr.i1 + tid]; }
+          if (derivs) for (int j = tid; j < nv; j += nthr) if (BELOW(j, i)) {
+            const S6 Jj = ld6(J + 6 * j);
+            const V3 lv = lin(Jj) + cross(ang(Jj), pf);
+            const double la[3] = {lv.x, lv.y, lv.z};
+            for (int rr = 0; rr < d; ++rr) Jt[rr * nz + j] = la[tr.i1 + rr];
+          }
+        } else {
+          if (tid == 0) { const S6 vf = adinv(Rf, pf, ld6(ov + 6 * i)); for (int rr = 0; rr < 6; ++rr) r[rr] = vf.v[rr] - tp[rr]; }
+          if (derivs) for (int j = tid; j < nv; j += nthr) if (BELOW(j, i)) {
+            const S6 cq = adinv(Rf, pf, ld6(Psd + 6 * j)), cv = adinv(Rf, pf, ld6(J + 6 * j));
+            for (int rr = 0; rr < 6; ++rr) { Jt[rr * nz + j] = cq.v[rr]; Jt[rr * nz + nv + j] = cv.v[rr]; }
+          }
+        }
+      } else if (tr.type == MPC_TERM_COM_TRANSLATION) {
+        if (tid < d) { const double ca[3] = {com.x, com.y, com.z}; r[tid] = ca[tr.i1 + tid] - tp[tr.i1 + tid]; }
+        if (derivs) for (int j = tid; j < nv; j += nthr) for (int rr = 0; rr < d; ++rr) Jt[rr * nz + j] = U[6 * j + tr.i1 + rr] / mtot;
+      } else if (tr.type == MPC_TERM_CENTROIDAL_MOMENTUM) {
+        if (tid == 0) {
+          const V3 hl = lin(h0), ha = ang(h0) - cross(com, lin(h0));
+          r[0] = hl.x - tp[0]; r[1] = hl.y - tp[1]; r[2] = hl.z - tp[2]; r[3] = ha.x - tp[3]; r[4] = ha.y - tp[4]; r[5] = ha.z - tp[5];
+        }
+        if (derivs) for (int j = tid; j < nv; j += nthr) {
+          const int bj = dof_body[j];
+          const S6 Uj = ld6(U + 6 * j);
+          const S6 D = add6(fcross(ld6(J + 6 * j), ld6(Hc + 6 * bj)), mat6_mul(Yc + 36 * bj, ld6(Psd + 6 * j)));
+          const V3 dc = (1.0 / mtot) * lin(Uj);
+          const V3 dql = lin(D), dqa = ang(D) - cross(dc, lin(h0)) - cross(com, lin(D));
+          const V3 dvl = lin(Uj), dva = ang(Uj) - cross(com, lin(Uj));
+          const double cq[6] = {dql.x, dql.y, dql.z, dqa.x, dqa.y, dqa.z}, cv[6] = {dvl.x, dvl.y, dvl.z, dva.x, dva.y, dva.z};
+          for (int rr = 0; rr < 6; ++rr) { Jt[rr * nz + j] = cq[rr]; Jt[rr * nz + nv + j] = cv[rr]; }
+        }
+      } else if (tr.type == MPC_TERM_CONTACT_FORCE) {
+        if (tid < 6) r[tid] = lam[6 * tr.i0 + tid] - tp[tid];
+        if (derivs) for (int idx = tid; idx < 6 * nz; idx += nthr) Jt[idx] = dsol[(size_t)(nv + 6 * tr.i0 + idx / nz) * L.nz + idx % nz];
+      } else if (tr.type == MPC_TERM_MB_WRENCH_CONE) {
+        for (int i = tid; i < d; i += nthr) { double s = 0; for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * lam[6 * tr.i0 + j]; r[i] = s; }
+        if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) {
+          const int i = idx / nz, z = idx % nz;
+          double s = 0;
+          for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * dsol[(size_t)(nv + 6 * tr.i0 + j) * L.nz + z];
+          Jt[idx] = s;
+        }
+      }
+      __syncthreads();
+    }
+    if (generic) {
+      if (tr.role == MPC_ROLE_COST) accumulate_cost(KL, kn, tr, P + tr.woff, r, Jt, nz, nz, red, WJ, derivs, s_cost, tid, nthr);
+      else { emit_constraint(KL, kn, tr, P, row, r, Jt, nz, nz, derivs, tid, nthr); }
+    }
+    if (tr.role != MPC_ROLE_COST) row += d;
+  }
+  if (derivs) for (int z = tid; z < nz; z += nthr) kn[KL.oH + (size_t)z * KL.nz + z] += a.opt.reg_init;
+  __syncthreads();
+
+  // ---- P14: projections, AL penalty, infeasibility ------------------------------------------------------------
+  const double mu = st.mu, mud = mu * a.opt.dyn_al_scale;
+  const size_t vo = ((size_t)b * (N + 1) + k) * L.c, lo = ((size_t)b * (N + 1) + k + 1) * n;
+  double pen = 0, prim = 0;
+  knot_merit(KL, kn, c, (k < N) ? kn + KL.oF : nullptr, a.vs + vo, TRIAL ? a.dvs + vo : nullptr, a.vs_e + vo,
+             a.lams + lo, TRIAL ? a.dlams + lo : nullptr, a.lams_e + lo, alpha, mu, mud, derivs, red, pen, prim, tid, nthr);
+  if (tid == 0) {
+    if (TRIAL) a.trial_phi[((size_t)b * L.n_alpha + cand) * (N + 1) + k] = s_cost + pen;
+    else {
+      double* ms = kn + KL.oMISC;
+      ms[MISC_COST] = s_cost; ms[MISC_PEN] = pen; ms[MISC_PRIM] = prim; ms[MISC_NC] = (double)c; ms[MISC_M] = (double)m;
+    }
+  }
+#undef BELOW
+#undef INSUB
+}
+
+static inline void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout& LT, double* records, double* scratch,
+                                         size_t scratch_stride, bool trial) {
+  const Layout& L = a.L;
+  MbArgs mb;
+  mb.lds = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m);
+  mb.scratch = scratch;
+  mb.scratch_stride = scratch_stride;
+  if (mb.lds.total_bytes > 160 * 1024) throw std::runtime_error("multibody model too large for the LDS budget of the stage kernel");
+  static int attr_bytes = -1;
+  if (attr_bytes != mb.lds.total_bytes) {
+    // the kernel also owns a few bytes of static LDS, so request exactly what the carve-out needs
+    hipError_t e1 = hipFuncSetAttribute((const void*)k_eval_multibody<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
+    hipError_t e2 = hipFuncSetAttribute((const void*)k_eval_multibody<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
+    if (e1 != hipSuccess || e2 != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(LDS) failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    attr_bytes = mb.lds.total_bytes;
+  }
+  if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(L.N + 1, L.B, 1), dim3(256), mb.lds.total_bytes, stream, a, L, records, mb);
+  else hipLaunchKernelGGL(k_eval_multibody<1>, dim3(L.N + 1, L.B, L.n_alpha), dim3(256), mb.lds.total_bytes, stream, a, LT, records, mb);
 }

@@ -255,7 +255,7 @@ int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double*
       check_multibody_model(itab, n_i);
       if (!s->d_mbwork) {
         s->mb_work_stride = multibody_work_doubles(s->L);
-        s->d_mbwork = s->alloc<double>((size_t)s->L.B * s->L.n_alpha * (s->L.N + 1) * 1 + 8);  // placeholder: kernel keeps its state in LDS
+        s->d_mbwork = s->alloc<double>((size_t)s->L.B * (s->L.N + 1) * s->mb_work_stride + 8);
       }
     }
     s->have_model = true;
