@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MPC solves/sec of the Talos full-dynamics OCP (fulldynamic_talos.py), horizon N=100.
+
+One "step" = one receding-horizon tick of an ensemble of B independent MPC instances on each GPU: stage
+cycling, warm-start shift, solver.setup and one ProxDDP iteration (max_iters = 1) — the timed region of
+fulldynamic_talos.py:538-541 — with all problem data resident in HBM.  Instances shard over GPUs with no
+data-path collective (weak scaling: B instances per GPU).  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured-achievable copy rate
+
+
+def _p50(v):
+    return float(np.percentile(np.asarray(v), 50))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="MPC instances per GPU (512 / 8 in the 8-GPU ensemble config)")
+    ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--model", choices=["complete", "reduced"], default="complete",
+                    help="complete = synthetic Talos nq=39 (32 actuated DoF, BASELINE.json); reduced = nq=29 as the scripts lock it")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from mpc_benchmark_amd import _capi
+    from mpc_benchmark_amd.ensemble import EnsembleMPC, gain_doubles, lq_knot_doubles
+    from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+
+    lib = _capi.load_hip_library()  # raises if the HIP library is missing: no CPU fallback
+    pd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
+    ens = EnsembleMPC(pd, batch=args.batch, library=lib, device=local_rank, seed=20250304 + rank)
+    ens.prepare_schedule(args.warmup + args.steps + 4)
+    cold = ens.cold_solve(max_iters=100)
+    for _ in range(args.warmup):
+        ens.step()
+
+    def sync_all():
+        ens.results(gains=False)  # stream sync of the solver (hipStreamSynchronize + tiny D2H)
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    ens.native.profile(2)
+    ens.native.profile(1)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ens.step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ens.native.profile(0)
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = ens.native.profile_read()
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    d = ens.dims
+    n, m = d.ndx, d.nu
+    # ---- roofline of the dominant kernel (HIP events on the solver's stream, over the timed region) ----
+    dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else None
+    roof = None
+    if dom is not None:
+        name, (launches, total_ms) = dom
+        # algorithmic bytes per launch = per-knot figure x knots per launch
+        cks = [int(t[0][6]) for t in ens.tables]
+        W = sum(lq_knot_doubles(n, m if k < d.horizon else 0, c) for k, c in enumerate(cks))
+        G = sum(gain_doubles(n, m if k < d.horizon else 0, c) for k, c in enumerate(cks))
+        io = (d.horizon + 1) * (d.nx + 2 * n) + d.horizon * m + sum(cks)
+        per_kernel = {
+            "k_eval_stage": 8.0 * (W + io),            # writes every LQ knot once, reads the iterate
+            "k_riccati_backward": 8.0 * (W + G),       # reads every LQ knot once, writes every gain record once
+            "k_eval_stage_trial": 8.0 * io * 8,        # value-only candidates: iterate in, merit partials out
+            "k_forward": 8.0 * (d.horizon * (m * n + m + n * n + n)),
+            "k_duals": 8.0 * (W + G) * 0.5,
+            "k_lagrangian": 8.0 * W * 0.5,
+        }
+        bytes_per_launch = per_kernel.get(name, 8.0 * (W + G)) * args.batch
+        avg_s = total_ms / launches * 1e-3
+        achieved = bytes_per_launch / avg_s / 1e9
+        roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_kernel_ms": round(total_ms / launches, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                "kernel_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+
+    # ---- batch = 1 latency (BASELINE.json config: batch=1 on one MI355X) ----
+    p50_ms = None
+    if not args.no_latency:
+        one = EnsembleMPC(pd, batch=1, library=lib, device=local_rank, perturb=False)
+        one.prepare_schedule(40)
+        one.cold_solve(max_iters=100)
+        lat = []
+        for i in range(30):
+            one.results(gains=False)
+            ts = time.perf_counter()
+            one.step()
+            one.results(gains=False)
+            if i >= 5:
+                lat.append((time.perf_counter() - ts) * 1e3)
+        p50_ms = round(_p50(lat), 4)
+        del one
+
+    # ---- CPU baseline: the oracle (a port, not Aligator) on this host's cores, bounded sample ----
+    cpu = None
+    if not args.no_cpu_baseline:
+        from tests import _oracle
+        cores = os.cpu_count() or 1
+        opd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
+        oens = EnsembleMPC(opd, batch=1, library=_oracle.load(), perturb=False)
+        oens.options.num_threads = cores
+        oens.prepare_schedule(40)
+        oens.cold_solve(max_iters=3)  # a few iterations are enough to get a warm start
+        oens.options.num_threads = cores
+        oens.native.set_options(oens.options)
+        oens.step()
+        ts = time.perf_counter()
+        nt = 0
+        while nt < 3 or (time.perf_counter() - ts < 10.0 and nt < 200):
+            oens.step()
+            nt += 1
+        dtc = time.perf_counter() - ts
+        cpu = {"value": round(nt / dtc, 3), "unit": "solves/s", "cores": cores, "kind": "port",
+               "sample": "%d warm-started MPC ticks (1 ProxDDP iteration each) of ONE instance of the same N=%d %s-model OCP, "
+                         "OpenMP over knots, %.1f s" % (nt, args.horizon, args.model, dtc)}
+
+    solves = args.batch * args.steps * world
+    out = {
+        "metric": "mpc_solves_per_sec", "value": round(solves / elapsed, 2), "unit": "solves/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "Talos full-dynamics MPC (fulldynamic_talos.py OCP), synthetic Talos %s model nq=%d nv=%d nu=%d, "
+                               "horizon N=%d, ensemble of %d instances per GPU, one ProxDDP iteration per solve (max_iters=1, warm start)"
+                               % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch),
+                   "horizon": args.horizon, "batch_per_gpu": args.batch, "model": "talos_synth_v1/" + args.model,
+                   "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
+        "p50_ms_per_solve_batch1": p50_ms,
+        "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

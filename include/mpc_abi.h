@@ -161,7 +161,9 @@ int mpc_update_stage_params(mpc_solver* s, int32_t k, int32_t offset, const doub
 /* replaceStageCircular + cycleAppend/cycleProblem: drop stage 0, shift, install the new stage at N-1. */
 int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params);
 
-/* problem.x0_init = x : x0[B][nx] */
+/* problem.x0_init = x : x0[B][nx].  x0 == NULL selects "perfect-model feedback": every later
+ * mpc_run_shifted takes the state the previous solution predicted for the next tick (xs[1]) as the new
+ * initial condition, so a closed receding-horizon loop runs without any host<->device traffic. */
 int mpc_set_x0(mpc_solver* s, const double* x0);
 /* solver.setup(problem): reset multipliers, penalty and tolerances (no re-allocation). */
 int mpc_setup(mpc_solver* s);
@@ -184,6 +186,14 @@ int mpc_get_stage_data(mpc_solver* s, int32_t k, double* xdot, double* wrenches)
 int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double* out, int32_t cap);
 /* Evaluate (value + derivatives) at the current iterate without stepping; fills the LQ knots. */
 int mpc_debug_evaluate(mpc_solver* s, const double* xs, const double* us);
+
+/* Per-kernel timing with device events on the solver's own stream (the reference only has wall-clock
+ * timers around run(): fulldynamic_talos.py:538-543).  mpc_profile(s, 1) starts recording, (s, 0) stops,
+ * (s, 2) clears.  mpc_profile_read returns the number of kernel slots; for slot i it fills the kernel
+ * name, the number of launches recorded and their summed duration in milliseconds.  The oracle reports
+ * zero slots. */
+int mpc_profile(mpc_solver* s, int32_t mode);
+int mpc_profile_read(mpc_solver* s, int32_t slot, char* name, int32_t name_cap, int32_t* launches, double* total_ms);
 
 #ifdef __cplusplus
 }

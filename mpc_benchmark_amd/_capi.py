@@ -86,6 +86,8 @@ _SIGNATURES = {
     "mpc_get_stage_data": (C.c_int, [C.c_void_p, C.c_int32, _DP, _DP]),
     "mpc_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, _DP, C.c_int32]),
     "mpc_debug_evaluate": (C.c_int, [C.c_void_p, _DP, _DP]),
+    "mpc_profile": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mpc_profile_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -179,6 +181,9 @@ class NativeSolver:
         self._check(self.lib.mpc_cycle(self._h, desc.ctypes.data_as(_IP), desc.size, _dp(params), params.size), "mpc_cycle")
 
     def set_x0(self, x0):
+        if x0 is None:  # perfect-model feedback (see mpc_abi.h)
+            self._check(self.lib.mpc_set_x0(self._h, None), "mpc_set_x0")
+            return
         x0 = _f64(x0)
         x0 = np.ascontiguousarray(np.broadcast_to(x0.reshape(-1, self.dims.nx), (self.dims.batch, self.dims.nx)))
         self._check(self.lib.mpc_set_x0(self._h, _dp(x0)), "mpc_set_x0")
@@ -226,6 +231,22 @@ class NativeSolver:
         wr = np.zeros((d.batch, 2, 6))
         self._check(self.lib.mpc_get_stage_data(self._h, k, _dp(xdot), _dp(wr)), "mpc_get_stage_data")
         return xdot, wr
+
+    # -- per-kernel timing ----------------------------------------------------------------------
+    def profile(self, mode):
+        self._check(self.lib.mpc_profile(self._h, int(mode)), "mpc_profile")
+
+    def profile_read(self):
+        """-> {kernel name: (launches, total_ms)}"""
+        out = {}
+        name = C.create_string_buffer(64)
+        cnt, ms = C.c_int32(0), C.c_double(0.0)
+        nslots = self._check(self.lib.mpc_profile_read(self._h, 0, name, 64, C.byref(cnt), C.byref(ms)), "mpc_profile_read")
+        for i in range(nslots):
+            self._check(self.lib.mpc_profile_read(self._h, i, name, 64, C.byref(cnt), C.byref(ms)), "mpc_profile_read")
+            if cnt.value:
+                out[name.value.decode()] = (cnt.value, ms.value)
+        return out
 
     # -- parity hooks ---------------------------------------------------------------------------
     def debug_evaluate(self, xs, us):

@@ -41,6 +41,32 @@ struct mpc_solver {
   std::vector<int> h_model_i;
   bool have_model = false;
   size_t mb_work_stride = 0;
+  bool perfect_feedback = false;
+  // per-kernel timing (mpc_profile): event pairs recorded around every launch while enabled
+  struct ProfSlot {
+    const char* name;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+  };
+  bool profiling = false;
+  std::vector<ProfSlot> prof;
+
+  template <class F> void timed(int slot, const char* name, F&& launch) {
+    if (!profiling) { launch(); return; }
+    if ((int)prof.size() <= slot) prof.resize(slot + 1);
+    ProfSlot& p = prof[slot];
+    p.name = name;
+    if (p.used == p.ev.size()) {
+      hipEvent_t e0, e1;
+      HIP_OK(hipEventCreate(&e0));
+      HIP_OK(hipEventCreate(&e1));
+      p.ev.emplace_back(e0, e1);
+    }
+    HIP_OK(hipEventRecord(p.ev[p.used].first, stream));
+    launch();
+    HIP_OK(hipEventRecord(p.ev[p.used].second, stream));
+    p.used++;
+  }
 
   template <class T> T* alloc(size_t count) {
     void* p = nullptr;
@@ -153,16 +179,16 @@ static void launch_pass(mpc_solver* s) {
   const Layout& L = s->L;
   SolverArgs a = s->args();
   HIP_OK(hipMemsetAsync(s->d_all_done, 0xff, sizeof(int), s->stream));  // all_done = -1 (true) unless cleared
-  launch_eval(s, false);
-  hipLaunchKernelGGL(k_lagrangian, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a);
-  hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(1), 0, s->stream, a);
-  hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);
-  hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(128), 2 * L.n * sizeof(double), s->stream, a);
-  hipLaunchKernelGGL(k_duals, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a);
-  launch_eval(s, true);
-  hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(1), 0, s->stream, a);
-  hipLaunchKernelGGL(k_accept, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a);
-  hipLaunchKernelGGL(k_after_step, dim3(L.B), dim3(1), 0, s->stream, a);
+  s->timed(0, "k_eval_stage", [&] { launch_eval(s, false); });
+  s->timed(1, "k_lagrangian", [&] { hipLaunchKernelGGL(k_lagrangian, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
+  s->timed(2, "k_decide", [&] { hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(1), 0, s->stream, a); });
+  s->timed(3, "k_riccati_backward", [&] { hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a); });
+  s->timed(4, "k_forward", [&] { hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(128), 2 * L.n * sizeof(double), s->stream, a); });
+  s->timed(5, "k_duals", [&] { hipLaunchKernelGGL(k_duals, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
+  s->timed(6, "k_eval_stage_trial", [&] { launch_eval(s, true); });
+  s->timed(7, "k_linesearch", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(1), 0, s->stream, a); });
+  s->timed(8, "k_accept", [&] { hipLaunchKernelGGL(k_accept, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
+  s->timed(9, "k_after_step", [&] { hipLaunchKernelGGL(k_after_step, dim3(L.B), dim3(1), 0, s->stream, a); });
   HIP_OK(hipGetLastError());
 }
 
@@ -221,6 +247,7 @@ int mpc_create(const mpc_dims* dims, mpc_solver** out) {
 void mpc_destroy(mpc_solver* s) {
   if (!s) return;
   (void)hipStreamSynchronize(s->stream);
+  for (auto& p : s->prof) for (auto& e : p.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (void* p : s->allocs) (void)hipFree(p);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -290,9 +317,42 @@ int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* 
 
 int mpc_set_x0(mpc_solver* s, const double* x0) {
   MPC_TRY(s, {
-    HIP_OK(hipMemcpyAsync(s->d_x0, x0, (size_t)s->L.B * s->L.nx * sizeof(double), hipMemcpyHostToDevice, s->stream));
-    HIP_OK(hipStreamSynchronize(s->stream));
+    s->perfect_feedback = (x0 == nullptr);
+    if (x0) {
+      HIP_OK(hipMemcpyAsync(s->d_x0, x0, (size_t)s->L.B * s->L.nx * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      HIP_OK(hipStreamSynchronize(s->stream));
+    }
   })
+}
+
+int mpc_profile(mpc_solver* s, int32_t mode) {
+  MPC_TRY(s, {
+    if (mode == 2) { for (auto& p : s->prof) p.used = 0; }
+    else s->profiling = (mode != 0);
+  })
+}
+
+int mpc_profile_read(mpc_solver* s, int32_t slot, char* name, int32_t name_cap, int32_t* launches, double* total_ms) {
+  if (!s) return -2;
+  try {
+    HIP_OK(hipStreamSynchronize(s->stream));
+    const int nslots = (int)s->prof.size();
+    if (slot < 0 || slot >= nslots) return nslots;
+    const mpc_solver::ProfSlot& p = s->prof[slot];
+    double tot = 0;
+    for (size_t i = 0; i < p.used; ++i) {
+      float ms = 0;
+      HIP_OK(hipEventElapsedTime(&ms, p.ev[i].first, p.ev[i].second));
+      tot += ms;
+    }
+    if (name && name_cap > 0) { std::strncpy(name, p.name ? p.name : "", name_cap - 1); name[name_cap - 1] = 0; }
+    if (launches) *launches = (int32_t)p.used;
+    if (total_ms) *total_ms = tot;
+    return nslots;
+  } catch (const std::exception& e) {
+    s->err = e.what();
+    return -1;
+  }
 }
 
 int mpc_setup(mpc_solver* s) {
@@ -322,7 +382,7 @@ int mpc_run(mpc_solver* s, const double* xs, const double* us, mpc_stats* stats)
 
 int mpc_run_shifted(mpc_solver* s, mpc_stats* stats) {
   MPC_TRY(s, {
-    hipLaunchKernelGGL(k_shift, dim3(s->L.B), dim3(64), 0, s->stream, s->args());
+    hipLaunchKernelGGL(k_shift, dim3(s->L.B), dim3(64), 0, s->stream, s->args(), s->perfect_feedback ? 1 : 0);
     run_impl(s, stats);
   })
 }

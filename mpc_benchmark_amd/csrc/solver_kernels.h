@@ -532,12 +532,15 @@ __global__ void k_begin_run(SolverArgs a) {
 }
 
 // warm-start shift on the device (fulldynamic_talos.py:532-534).  grid B, block 64
-__global__ void k_shift(SolverArgs a) {
+__global__ void k_shift(SolverArgs a, int perfect_feedback) {
   const Layout& L = a.L;
   const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   double* xs = a.xs + (size_t)b * (L.N + 1) * L.nx;
   double* us = a.us + (size_t)b * L.N * L.m;
   // sequential over knots to stay in place; each element handled by one thread
-  for (int i = tid; i < L.nx; i += nthr) for (int k = 0; k < L.N; ++k) xs[k * L.nx + i] = xs[(k + 1) * L.nx + i];
+  for (int i = tid; i < L.nx; i += nthr) {
+    for (int k = 0; k < L.N; ++k) xs[k * L.nx + i] = xs[(k + 1) * L.nx + i];
+    if (perfect_feedback) a.x0[(size_t)b * L.nx + i] = xs[i];  // the predicted next state is the new measurement
+  }
   for (int i = tid; i < L.m; i += nthr) for (int k = 0; k + 1 < L.N; ++k) us[k * L.m + i] = us[(k + 1) * L.m + i];
 }

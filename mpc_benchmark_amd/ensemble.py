@@ -1,0 +1,115 @@
+"""Ensemble receding-horizon driver: B independent Talos MPC instances (randomised initial states) advanced
+tick by tick on one GPU — the batched form of the loop body of fulldynamic_talos.py:438-550
+(replaceStageCircular -> warm-start shift -> setup -> run with max_iters = 1), with "perfect-model" feedback
+(the next measured state is the state the previous solution predicted) instead of the PyBullet simulator.
+Everything between ticks stays on the device: the stage ring buffer moves by one slot (``mpc_cycle``), the
+warm-start shift and the feedback happen in ``mpc_run_shifted``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _capi as K
+from .aligator import _core as core
+
+
+class EnsembleMPC:
+    def __init__(self, problem_def, batch=1, library=None, device=0, seed=20250304, perturb=True):
+        """``problem_def``: a FullDynamicsProblem / CentroidalProblem-like builder (``build``, ``stage_for_tick``,
+        ``make_solver``, ``initial_guess``)."""
+        self.pd = problem_def
+        self.batch = int(batch)
+        self.lib = library if library is not None else K.load_hip_library()
+        self.problem = problem_def.build(with_terminal_constraint=True) if hasattr(problem_def, "terminal_com_constraint") else problem_def.build()
+        self.ctx = core.LoweringContext()
+        N = self.problem.num_steps
+        first = self.problem.stages[0]
+        space = first.xspace
+        tables = [core.lower_stage(self.ctx, st.cost, st.dynamics, st.constraints) for st in self.problem.stages]
+        tables.append(core.lower_stage(self.ctx, self.problem.term_cost, None, self.problem.term_constraints))
+        # one lowered table per distinct stage of the schedule (contact pattern)
+        self._tick_tables = {}
+        d = K.MpcDims()
+        d.horizon, d.batch = N, self.batch
+        d.space = K.SPACE_MULTIBODY if hasattr(space, "model") else K.SPACE_VECTOR
+        d.nx, d.ndx, d.nu = space.nx, space.ndx, first.nu
+        d.nc_max = max(int(t[0][6]) for t in tables)
+        d.max_stage_ints = 8 + 8 * 24
+        d.max_stage_doubles = max(t[1].size for t in tables) + 64
+        d.device = int(device)
+        self.dims = d
+        self.native = K.NativeSolver(self.lib, d)
+        solver = problem_def.make_solver()
+        self.options = solver._options()
+        self.native.set_options(self.options)
+        if self.ctx.model is not None:
+            self.native.set_model(*self.ctx.model_tables())
+        for k, (desc, params) in enumerate(tables):
+            self.native.set_stage(k, desc, params)
+        self.tables = tables
+        # randomised initial states: joints ~ N(0, 0.02^2), joint velocities ~ N(0, 0.05^2)
+        rng = np.random.default_rng(seed)
+        x0 = np.asarray(self.problem.x0_init, dtype=float)
+        self.x0 = np.tile(x0, (self.batch, 1))
+        if perturb and hasattr(space, "model"):
+            nv = space.model.nv
+            for b in range(self.batch):
+                dq = np.zeros(2 * nv)
+                dq[6:nv] = 0.02 * rng.standard_normal(nv - 6)
+                dq[nv + 6:] = 0.05 * rng.standard_normal(nv - 6)
+                if b > 0:
+                    self.x0[b] = space.integrate(x0, dq)
+        self.tick = 0
+
+    # -- stage tables of the schedule ---------------------------------------------------------------
+    def _table_for_tick(self, t):
+        key = tuple(self.pd.contact_phases[t]) if hasattr(self.pd, "contact_phases") else t
+        if key not in self._tick_tables:
+            st = self.pd.stage_for_tick(t)
+            self._tick_tables[key] = core.lower_stage(self.ctx, st.cost, st.dynamics, st.constraints)
+            if self.ctx.changed:
+                self.native.set_model(*self.ctx.model_tables())
+                self.ctx.changed = False
+        return self._tick_tables[key]
+
+    def prepare_schedule(self, n_ticks):
+        for t in range(n_ticks):
+            self._table_for_tick(t % self.pd.t_mpc)
+
+    # -- solves -------------------------------------------------------------------------------------------
+    def cold_solve(self, max_iters=100):
+        xs, us = self.pd.initial_guess()
+        xs = np.tile(np.array(xs)[None], (self.batch, 1, 1))
+        xs[:, 0, :] = self.x0
+        us = np.tile(np.array(us)[None], (self.batch, 1, 1))
+        self.options.max_iters = int(max_iters)
+        self.native.set_options(self.options)
+        self.native.set_x0(self.x0)
+        self.native.setup()
+        stats = self.native.run(xs, us)
+        self.options.max_iters = 1
+        self.native.set_options(self.options)
+        self.native.set_x0(None)  # perfect-model feedback from here on
+        return stats
+
+    def step(self):
+        """One MPC tick for every instance of the ensemble (one ProxDDP iteration each)."""
+        desc, params = self._table_for_tick(self.tick % self.pd.t_mpc)
+        self.native.cycle(desc, params)
+        self.native.setup()
+        stats = self.native.run_shifted()
+        self.tick += 1
+        return stats
+
+    def results(self, **kw):
+        return self.native.get_results(**kw)
+
+
+def lq_knot_doubles(n, m, c):
+    """W_k of SURVEY.md §8d: Q,A (2 n^2), R (m^2), S,B (2 n m), q,f (2 n), r (m), [C D] (c (n + m)), d (c)."""
+    return 2 * n * n + m * m + 2 * n * m + 2 * n + m + c * (n + m) + c
+
+
+def gain_doubles(n, m, c):
+    """G_k of SURVEY.md §8d: K,k ; dual gains ; co-state gains ; P,p."""
+    return m * n + m + c * (n + 1) + n * (n + 1) + n * n + n

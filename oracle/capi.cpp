@@ -12,6 +12,7 @@ using namespace orc;
 struct mpc_solver {
   Solver s;
   std::string err;
+  bool perfect_feedback = false;
 };
 
 #define MPC_TRY(h, ...)                  \
@@ -79,9 +80,13 @@ int mpc_cycle(mpc_solver* h, const int32_t* desc, int32_t n_desc, const double* 
 int mpc_set_x0(mpc_solver* h, const double* x0) {
   MPC_TRY(h, {
     const int nx = h->s.dims.nx;
-    for (int b = 0; b < h->s.dims.batch; ++b) h->s.inst[b].x0.assign(x0 + b * nx, x0 + (b + 1) * nx);
+    h->perfect_feedback = (x0 == nullptr);
+    if (x0) for (int b = 0; b < h->s.dims.batch; ++b) h->s.inst[b].x0.assign(x0 + b * nx, x0 + (b + 1) * nx);
   })
 }
+
+int mpc_profile(mpc_solver*, int32_t) { return 0; }
+int mpc_profile_read(mpc_solver*, int32_t, char*, int32_t, int32_t*, double*) { return 0; }
 
 int mpc_setup(mpc_solver* h) { MPC_TRY(h, h->s.setup()) }
 
@@ -114,6 +119,7 @@ int mpc_run_shifted(mpc_solver* h, mpc_stats* stats) {
       Instance& in = s.inst[b];
       for (int k = 0; k < N; ++k) in.xs[k] = in.xs[k + 1];
       for (int k = 0; k + 1 < N; ++k) in.us[k] = in.us[k + 1];
+      if (h->perfect_feedback) in.x0 = in.xs[0];  // predicted next state becomes the measurement
       in.xs[0] = in.x0;
     }
     run_all(h, stats);
