@@ -147,12 +147,13 @@ struct MbArgs {
 
 // ============================================================================================================
 template <int TRIAL>
-__global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL, double* records, MbArgs mb) {
+__global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL, double* records, MbArgs mb, int cand0) {
   const Layout& L = a.L;
   const MbLds& S = mb.lds;
-  const int k = blockIdx.x, b = blockIdx.y, cand = blockIdx.z, tid = threadIdx.x, nthr = blockDim.x;
+  const int k = blockIdx.x, b = blockIdx.y, cand = blockIdx.z + cand0, tid = threadIdx.x, nthr = blockDim.x;
   const InstState& st = a.inst[b];
   if (st.done || (TRIAL && st.skip_step)) return;
+  if (TRIAL && cand > 0 && !st.ls_more) return;  // the full step was accepted: no backtracking candidates needed
   const int n = L.n, N = L.N, nx = L.nx, nv = S.nv, nq = S.nq, nj = S.nj, nu = L.m;
   const int slot = stage_slot(a, k);
   const int32_t* desc = a.stage_desc + (size_t)slot * L.max_stage_ints;
@@ -827,7 +828,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
 }
 
 static inline void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout& LT, double* records, double* scratch,
-                                         size_t scratch_stride, bool trial) {
+                                         size_t scratch_stride, bool trial, int cand0 = 0, int ncand = 1) {
   const Layout& L = a.L;
   MbArgs mb;
   mb.lds = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m);
@@ -842,6 +843,6 @@ static inline void launch_eval_multibody(hipStream_t stream, const SolverArgs& a
     if (e1 != hipSuccess || e2 != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(LDS) failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     attr_bytes = mb.lds.total_bytes;
   }
-  if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(L.N + 1, L.B, 1), dim3(256), mb.lds.total_bytes, stream, a, L, records, mb);
-  else hipLaunchKernelGGL(k_eval_multibody<1>, dim3(L.N + 1, L.B, L.n_alpha), dim3(256), mb.lds.total_bytes, stream, a, LT, records, mb);
+  if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(L.N + 1, L.B, 1), dim3(256), mb.lds.total_bytes, stream, a, L, records, mb, 0);
+  else hipLaunchKernelGGL(k_eval_multibody<1>, dim3(L.N + 1, L.B, ncand), dim3(256), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
 }

@@ -9,11 +9,12 @@
 // trial == 1: value only at (x (+) alpha dx, u + alpha du), candidate alpha = 2^-blockIdx.z; writes the
 //             merit partial of the knot to trial_phi.
 template <int TRIAL>
-__global__ void __launch_bounds__(64) k_eval_vector(SolverArgs a, Layout KL, double* records) {
+__global__ void __launch_bounds__(64) k_eval_vector(SolverArgs a, Layout KL, double* records, int cand0) {
   const Layout& L = a.L;
-  const int k = blockIdx.x, b = blockIdx.y, cand = blockIdx.z, tid = threadIdx.x, nthr = blockDim.x;
+  const int k = blockIdx.x, b = blockIdx.y, cand = blockIdx.z + cand0, tid = threadIdx.x, nthr = blockDim.x;
   const InstState& st = a.inst[b];
   if (st.done || (TRIAL && st.skip_step)) return;
+  if (TRIAL && cand > 0 && !st.ls_more) return;  // the full step was accepted: no backtracking candidates needed
   const int n = L.n, N = L.N, nx = L.nx, mfull = L.m;
   const int slot = stage_slot(a, k);
   const int32_t* desc = a.stage_desc + (size_t)slot * L.max_stage_ints;

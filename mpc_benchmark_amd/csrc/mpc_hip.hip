@@ -4,6 +4,7 @@
 // There is no CPU fallback in this file: any HIP failure is reported through the return code.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -11,6 +12,7 @@
 
 #include "eval_multibody.h"
 #include "eval_vector.h"
+#include "riccati_mfma.h"
 
 #define HIP_OK(expr)                                                                                  \
   do {                                                                                                \
@@ -42,6 +44,8 @@ struct mpc_solver {
   bool have_model = false;
   size_t mb_work_stride = 0;
   bool perfect_feedback = false;
+  RicLds ric{};
+  bool use_mfma_riccati = false;
   // per-kernel timing (mpc_profile): event pairs recorded around every launch while enabled
   struct ProfSlot {
     const char* name;
@@ -137,6 +141,10 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   o.max_iters = 100; o.max_al_iters = 100; o.force_initial_condition = 1; o.rollout_linear = 1; o.ls_max_steps = 8;
   o.num_threads = 1; o.riccati_legs = 1; o.reserved = 0;
   HIP_OK(hipFuncSetAttribute((const void*)k_riccati_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  s->ric = make_ric_lds(L.n, L.m, L.c);
+  s->use_mfma_riccati = s->ric.total_bytes <= 160 * 1024 && !getenv("MPC_HIP_GENERIC_RICCATI");
+  if (s->use_mfma_riccati)
+    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
   HIP_OK(hipStreamSynchronize(s->stream));
 }
 
@@ -162,14 +170,15 @@ static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_des
 static int slot_of(const mpc_solver* s, int k) { return k < s->L.N ? (s->head + k) % s->L.N : s->L.N; }
 
 // ---- kernel sequences -----------------------------------------------------------------------------
-static void launch_eval(mpc_solver* s, bool trial) {
+static void launch_eval(mpc_solver* s, bool trial, int cand0 = 0, int ncand = 1) {
   const Layout& L = s->L;
   SolverArgs a = s->args();
+  if (ncand <= 0) return;
   if (L.space == MPC_SPACE_VECTOR) {
-    if (!trial) hipLaunchKernelGGL(k_eval_vector<0>, dim3(L.N + 1, L.B, 1), dim3(64), 0, s->stream, a, s->L, s->d_knots);
-    else hipLaunchKernelGGL(k_eval_vector<1>, dim3(L.N + 1, L.B, L.n_alpha), dim3(64), 0, s->stream, a, s->LT, s->d_tknots);
+    if (!trial) hipLaunchKernelGGL(k_eval_vector<0>, dim3(L.N + 1, L.B, 1), dim3(64), 0, s->stream, a, s->L, s->d_knots, 0);
+    else hipLaunchKernelGGL(k_eval_vector<1>, dim3(L.N + 1, L.B, ncand), dim3(64), 0, s->stream, a, s->LT, s->d_tknots, cand0);
   } else {
-    launch_eval_multibody(s->stream, a, s->LT, trial ? s->d_tknots : s->d_knots, s->d_mbwork, s->mb_work_stride, trial);
+    launch_eval_multibody(s->stream, a, s->LT, trial ? s->d_tknots : s->d_knots, s->d_mbwork, s->mb_work_stride, trial, cand0, ncand);
   }
   HIP_OK(hipGetLastError());
 }
@@ -182,11 +191,18 @@ static void launch_pass(mpc_solver* s) {
   s->timed(0, "k_eval_stage", [&] { launch_eval(s, false); });
   s->timed(1, "k_lagrangian", [&] { hipLaunchKernelGGL(k_lagrangian, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   s->timed(2, "k_decide", [&] { hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(1), 0, s->stream, a); });
-  s->timed(3, "k_riccati_backward", [&] { hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a); });
-  s->timed(4, "k_forward", [&] { hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(128), 2 * L.n * sizeof(double), s->stream, a); });
+  s->timed(3, "k_riccati_backward", [&] {
+    if (s->use_mfma_riccati) hipLaunchKernelGGL(k_riccati_mfma, dim3(L.B), dim3(256), s->ric.total_bytes, s->stream, a, s->ric);
+    else hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);
+  });
+  s->timed(4, "k_forward", [&] { hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(256), (L.nz + 2 * L.n) * sizeof(double), s->stream, a); });
   s->timed(5, "k_duals", [&] { hipLaunchKernelGGL(k_duals, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
-  s->timed(6, "k_eval_stage_trial", [&] { launch_eval(s, true); });
-  s->timed(7, "k_linesearch", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(1), 0, s->stream, a); });
+  // linesearch: evaluate the full step first; the backtracking candidates alpha = 2^-i, i >= 1, are only
+  // evaluated for instances whose full step failed the Armijo test (their workgroups exit immediately otherwise)
+  s->timed(6, "k_eval_stage_trial", [&] { launch_eval(s, true, 0, 1); });
+  s->timed(7, "k_linesearch", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(1), 0, s->stream, a, 1); });
+  s->timed(10, "k_eval_stage_backtrack", [&] { launch_eval(s, true, 1, L.n_alpha - 1); });
+  s->timed(11, "k_linesearch_backtrack", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(1), 0, s->stream, a, 0); });
   s->timed(8, "k_accept", [&] { hipLaunchKernelGGL(k_accept, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   s->timed(9, "k_after_step", [&] { hipLaunchKernelGGL(k_after_step, dim3(L.B), dim3(1), 0, s->stream, a); });
   HIP_OK(hipGetLastError());

@@ -118,7 +118,6 @@ __global__ void k_decide(SolverArgs a) {
     st.al_iters += 1;
     if (st.al_iters >= o.max_al_iters) st.done = 1;
   }
-  if (!st.done) atomicExch(a.all_done, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -326,61 +325,70 @@ __global__ void __launch_bounds__(256) k_riccati_backward(SolverArgs a) {
       for (int i = 0; i < ca; ++i) t += Ct[i * nz + r] * V[i * nr + n];
       g[L.op + r] = t;
     }
-    // 6. closed-loop next-state map (uses AB, K, Lp, T6): Acl = Lam [A + B K | B k + ft - mud ph]
-    for (int idx = tid; idx < n * nr; idx += nthr) {
-      const int i = idx / nr, z = idx % nr;
-      double s = (z < n) ? AB[i * nz + z] : (ft[i] - mud * ph[i]);
-      for (int l = 0; l < m; ++l) s += AB[i * nz + n + l] * W[l * nr + z];
-      Acl[idx] = s;
-    }
+    // 6. what the forward sweep needs: x' = T Lam (A x + B u + ft - mud ph) with Lam = I - mud Pt
+    for (int idx = tid; idx < n * n; idx += nthr) g[L.oMx + idx] = Pt[idx];
+    for (int i = tid; i < n; i += nthr) g[L.omx + i] = ft[i] - mud * ph[i];
     __syncthreads();
     for (int idx = tid; idx < n * n; idx += nthr) {
       const int r = idx / n, s = idx % n;
       if (s > r) { const double t = 0.5 * (g[L.oP + idx] + g[L.oP + s * n + r]); g[L.oP + idx] = t; g[L.oP + s * n + r] = t; }
-    }
-    potrs_block(Lp, n, n, Acl, nr, nr, tid, nthr);
-    for (int idx = tid; idx < n * nr; idx += nthr) {
-      const int i = idx / nr, z = idx % nr;
-      double s;
-      if (ff && i < 6) { s = 0; for (int l = 0; l < 6; ++l) s += T6[i * 6 + l] * Acl[l * nr + z]; }
-      else s = Acl[idx];
-      if (z < n) g[L.oMx + i * n + z] = s; else g[L.omx + i] = s;
     }
     __syncthreads();
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// P7: dx_{k+1} = Mx dx_k + mx ; du_k = K dx_k + k.  grid B, block 128
+// P7: du_k = K dx_k + k ; y = A dx_k + B du_k + yv ; dx_{k+1} = T (y - mud Pt y).  grid B, block 256.
+// Every product is a wave-per-row dot product with coalesced row reads and a shuffle reduction.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_forward(SolverArgs a) {
+DEV double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return __shfl(v, 0, 64);
+}
+__global__ void __launch_bounds__(256) k_forward(SolverArgs a) {
   const Layout& L = a.L;
-  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
-  const int n = L.n, N = L.N, m = L.m;
+  const int n = L.n, N = L.N, m = L.m, nz = L.nz;
+  const double mud = st.mu * a.opt.dyn_al_scale;
+  const bool ff = L.space == MPC_SPACE_MULTIBODY;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* dx = lds;
-  double* dxn = lds + n;
-  for (int i = tid; i < n; i += nthr) { dx[i] = 0.0; a.dxs[(size_t)b * (N + 1) * n + i] = 0.0; }
+  double* dz = lds;           // [dx; du]  (nz)
+  double* y = lds + nz;       // n
+  double* z = y + n;          // n
+  for (int i = tid; i < n; i += blockDim.x) { dz[i] = 0.0; a.dxs[(size_t)b * (N + 1) * n + i] = 0.0; }
   __syncthreads();
   for (int k = 0; k < N; ++k) {
     const double* g = gain_ptr(a, b, k);
-    for (int i = tid; i < n + m; i += nthr) {
-      if (i < n) {
-        double s = g[L.omx + i];
-        for (int z = 0; z < n; ++z) s += g[L.oMx + i * n + z] * dx[z];
-        dxn[i] = s;
-        a.dxs[((size_t)b * (N + 1) + k + 1) * n + i] = s;
-      } else {
-        const int j = i - n;
-        double s = g[L.ok + j];
-        for (int z = 0; z < n; ++z) s += g[L.oK + j * n + z] * dx[z];
-        a.dus[((size_t)b * N + k) * m + j] = s;
-      }
+    const double* kn = knot_ptr(a, b, k);
+    for (int r = wv; r < m; r += nw) {
+      double s = 0;
+      for (int c0 = lane; c0 < n; c0 += 64) s += g[L.oK + r * n + c0] * dz[c0];
+      s = wave_sum(s);
+      if (lane == 0) { s += g[L.ok + r]; dz[n + r] = s; a.dus[((size_t)b * N + k) * m + r] = s; }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += nthr) dx[i] = dxn[i];
+    for (int r = wv; r < n; r += nw) {
+      double s = 0;
+      for (int c0 = lane; c0 < n + m; c0 += 64) s += kn[L.oAB + r * nz + c0] * dz[c0];
+      s = wave_sum(s);
+      if (lane == 0) y[r] = s + g[L.omx + r];
+    }
+    __syncthreads();
+    for (int r = wv; r < n; r += nw) {
+      double s = 0;
+      for (int c0 = lane; c0 < n; c0 += 64) s += g[L.oMx + r * n + c0] * y[c0];
+      s = wave_sum(s);
+      if (lane == 0) z[r] = y[r] - mud * s;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+      double s = z[i];
+      if (ff && i < 6) { s = 0; for (int l = 0; l < 6; ++l) s += g[L.oT6 + i * 6 + l] * z[l]; }
+      dz[i] = s;
+      a.dxs[((size_t)b * (N + 1) + k + 1) * n + i] = s;
+    }
     __syncthreads();
   }
 }
@@ -455,16 +463,30 @@ __global__ void k_duals(SolverArgs a) {
 // ------------------------------------------------------------------------------------------------
 // P8: Armijo backtracking over the pre-evaluated candidates alpha_i = 2^-i.  grid B, block 1
 // ------------------------------------------------------------------------------------------------
-__global__ void k_linesearch(SolverArgs a) {
+// first == 1: only the full step (candidate 0) has been evaluated; accept it if it passes Armijo, otherwise
+// raise ls_more so that the remaining candidates get evaluated.  first == 0: backtrack over all of them.
+__global__ void k_linesearch(SolverArgs a, int first) {
   const Layout& L = a.L;
   const int b = blockIdx.x;
   InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
+  if (!first && !st.ls_more) return;
   double d = 0;
   for (int k = 0; k <= L.N; ++k) d += knot_ptr(a, b, k)[L.oMISC + MISC_DMERIT];
   st.dphi0 = d;
   double alpha = 1.0;
   int step = 0;
+  if (first) {
+    double phi = 0;
+    const double* tp = a.trial_phi + ((size_t)b * L.n_alpha) * (L.N + 1);
+    for (int k = 0; k <= L.N; ++k) phi += tp[k];
+    const bool ok = phi <= st.phi0 + a.opt.ls_armijo_c1 * d;
+    const bool last = a.opt.ls_max_steps <= 1 || L.n_alpha <= 1 || 0.5 < a.opt.ls_alpha_min;
+    st.ls_more = (ok || last) ? 0 : 1;
+    st.alpha = 1.0;
+    st.ls_step = 0;
+    return;
+  }
   for (;; ++step) {
     double phi = 0;
     const double* tp = a.trial_phi + ((size_t)b * L.n_alpha + step) * (L.N + 1);

@@ -7,7 +7,7 @@ from mpc_benchmark_amd.problems.centroidal import CentroidalProblem
 pytestmark = pytest.mark.gpu
 
 PHASES = ["H", "grad", "AB", "f", "cval", "CD", "cost"]
-GAINS = ["P", "p", "K", "kff", "Knu", "knu", "Mx", "mx"]
+GAINS = ["P", "p", "K", "kff", "Knu", "knu"]
 STEPS = ["dx", "du", "dvs", "dlams"]
 
 
