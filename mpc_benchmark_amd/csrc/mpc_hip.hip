@@ -37,6 +37,7 @@ struct mpc_solver {
   double *d_knots = nullptr, *d_tknots = nullptr, *d_gains = nullptr, *d_work = nullptr, *d_trial_phi = nullptr, *d_mbwork = nullptr;
   InstState* d_inst = nullptr;
   int* d_all_done = nullptr;
+  double* d_prof = nullptr;
   std::vector<void*> allocs;
   // host mirrors of the stage tables (needed for ring-buffer bookkeeping and debug)
   std::vector<int32_t> h_desc;
@@ -86,7 +87,7 @@ struct mpc_solver {
     a.stage_desc = d_stage_desc; a.stage_params = d_stage_params; a.model_i = d_model_i; a.model_d = d_model_d;
     a.xs = d_xs; a.us = d_us; a.vs = d_vs; a.lams = d_lams; a.vs_e = d_vs_e; a.lams_e = d_lams_e; a.x0 = d_x0;
     a.dxs = d_dxs; a.dus = d_dus; a.dvs = d_dvs; a.dlams = d_dlams;
-    a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done;
+    a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = d_prof;
     return a;
   }
   size_t riccati_lds() const {
@@ -132,6 +133,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->d_trial_phi = s->alloc<double>(B * L.n_alpha * N1);
   s->d_inst = s->alloc<InstState>(B);
   s->d_all_done = s->alloc<int>(4);
+  s->d_prof = s->alloc<double>(B * 32);
   s->h_desc.assign(N1 * L.max_stage_ints, 0);
   // default options
   mpc_options& o = s->opt;
@@ -487,6 +489,7 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
     else if (nm == "knu") mat(g.data() + L.oknu, 1, c, c);
     else if (nm == "Mx") mat(g.data() + L.oMx, k < L.N ? n : 0, n, n);
     else if (nm == "mx") mat(g.data() + L.omx, 1, k < L.N ? n : 0, n);
+    else if (nm == "ric_prof") { dev_vec(s->d_prof + (size_t)b * 32, 32); HIP_OK(hipMemset(s->d_prof + (size_t)b * 32, 0, 32 * sizeof(double))); }
     else if (nm == "dx") dev_vec(s->d_dxs + ((size_t)b * (L.N + 1) + k) * n, n);
     else if (nm == "du") { if (k >= L.N) throw std::runtime_error("no du at the terminal knot"); dev_vec(s->d_dus + ((size_t)b * L.N + k) * L.m, L.m); }
     else if (nm == "dvs") dev_vec(s->d_dvs + ((size_t)b * (L.N + 1) + k) * L.c, L.c);

@@ -1,67 +1,98 @@
 // riccati_mfma.h — proximal Riccati backward sweep with every matrix operand
-// resident in LDS and the dense n x n / n x (n+m) products on the fp64 matrix cores
+// resident in LDS and the dense products / factorisations on the fp64 matrix cores
 // (v_mfma_f64_16x16x4_f64, one 16x16 output tile per wavefront instruction).
 //
 // One workgroup (256 threads = 4 wavefronts, one per SIMD) per MPC instance walks the horizon backwards:
 //   Ph = T^T P' T                         base-frame change of the co-state (6 x 6 block)
-//   L L^T = I + mu_d Ph                   Cholesky in LDS
-//   Pt = (I + mu_d Ph)^-1 Ph              blocked triangular solves, diagonal blocks pre-inverted -> pure MFMA
+//   L L^T = I + mu_d Ph                   blocked Cholesky: 16x16 diagonal blocks factored AND inverted in the
+//                                         registers of one wavefront (readlane broadcasts), panels and trailing
+//                                         updates on MFMA
+//   Pt = (I + mu_d Ph)^-1 Ph              blocked triangular solves with the pre-inverted diagonal blocks: pure
+//                                         MFMA, one column block per wavefront, no workgroup barrier inside
 //   G = Pt [A B] ; Hh = H + [A B]^T G     16-column panels: G panel in LDS, Hh panel to L2-resident scratch
-//   stage KKT (controls, then ACTIVE constraint rows), gains K, k, Knu, knu
+//   stage KKT (controls, then ACTIVE constraint rows), gains K, k, Knu, knu — same blocked routines
 //   P = Qh + Sh K + Ca^T Knu              MFMA, result stays in LDS as next knot's P'
 // dims are padded to multiples of 16 inside LDS (np, mp); u-columns start at column np.
 #pragma once
 #include "solver_kernels.h"
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+#define AB_ROWS 24  // register prefetch capacity: np <= 4 * AB_ROWS rows, nzp <= 128 columns
+
+// phase timing (shader clock) accumulated over the knots; read back with mpc_debug_get("ric_prof")
+#define RIC_PROF(slot) do { if (tid == 0 && a.prof) { const long long t1_ = clock64(); a.prof[(size_t)b * 32 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 struct RicLds {
-  int np, mp, nzp, ldl, nb, nbm, cap;  // padded dims, leading dim of L, #16-blocks of n and m, active-row capacity in LDS
+  int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
   int PT, R1, LP, LI, AB, GP, vec, iwork, total_bytes;
   // KKT / value-update workspace carved from R1 once AB is dead
-  int Lr, W, ST, CT, VX, Y, SC, lw;
+  int Lr, LIr, W, ST, CT, VX, Y, SC, LIs;
 };
 
 static inline RicLds make_ric_lds(int n, int m, int c) {
   RicLds s;
-  s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.ldl = s.np + 1; s.nb = s.np / 16; s.nbm = s.mp / 16;
-  s.cap = 16;
+  s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.ldl = s.np + 1; s.ldr = s.mp + 1;
+  s.nb = s.np / 16; s.nbm = s.mp / 16;
+  s.lw = s.np + 16;  // W = [K | pad | k | pad]: x-columns at 0..n-1, the feed-forward column at np
+  s.nwb = s.lw / 16;
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
-  s.PT = take(s.np * s.np);
+  s.PT = take(s.np * (s.np + 1));  // leading dimension np + 1: conflict-free row AND column access
   s.R1 = o;
-  // phase 1 view of R1
-  s.LP = take(s.np * s.ldl); s.LI = take(s.nb * 16 * 17);
+  s.LP = take(s.np * s.ldl); s.LI = take(s.nb * 272);             // phase 1 view of R1
   const int end1 = o;
-  // phase 2 view of R1 (overlaps phase 1)
   o = s.R1;
-  s.AB = take(s.np * s.nzp); s.GP = take(s.np * 16);
+  s.AB = take(s.np * s.nzp); s.GP = take(s.np * 16);               // phase 2 view (overlaps phase 1)
   const int end2 = o;
-  // phase 3 view of R1 (overlaps AB)
-  o = s.R1;
-  s.lw = s.np + 16;  // W = [K | pad | k | pad]: x-columns at 0..n-1, the feed-forward column at np
-  s.Lr = take(m * m); s.W = take(s.mp * s.lw); s.ST = take(s.mp * s.np);
-  s.CT = take(s.cap * s.np); s.VX = take(s.cap * s.np); s.Y = take(m * s.cap); s.SC = take(s.cap * s.cap);
+  o = s.R1;                                                         // phase 3 view (overlaps AB)
+  s.Lr = take(s.mp * s.ldr); s.LIr = take(s.nbm * 272); s.W = take(s.mp * s.lw); s.ST = take(s.mp * s.np);
+  s.CT = take(16 * s.lw); s.VX = take(16 * s.lw); s.Y = take(s.mp * 16); s.SC = take(16 * 17); s.LIs = take(272);
   const int end3 = o;
   o = end1 > end2 ? end1 : end2;
   if (end3 > o) o = end3;
   s.vec = take(8 * (s.nzp + c) + 64);
   s.iwork = o;
-  s.total_bytes = o * 8 + (c + 8) * 4;
+  s.total_bytes = o * 8 + (c + 72) * 4;
   return s;
 }
 
+// ---- MFMA tile primitives ---------------------------------------------------------------------------------
 // acc += sum_{k<K} A(i,k) * B(k,j) for one 16x16 tile; A(i,k) at A[i*a_is + k*a_ks], B(k,j) at B[k*b_ks + j*b_js].
 // Fragment layout of v_mfma_f64_16x16x4_f64: lane l supplies A(l&15, l>>4) and B(l>>4, l&15); result register r of
-// lane l is C((l>>4) + 4r, l&15).
+// lane l is C((l>>4) + 4r, l&15).  K must be a multiple of 4; groups of 16 are software-pipelined.
 template <bool NEG>
 DEV void mma_tile(d4_t& acc, const double* A, int a_is, int a_ks, const double* B, int b_ks, int b_js, int K, int lane) {
   const int i = lane & 15, kk = lane >> 4;
   const double* ap = A + i * a_is + kk * a_ks;
   const double* bp = B + kk * b_ks + i * b_js;
-  for (int k0 = 0; k0 < K; k0 += 4) {
+  int k0 = 0;
+  for (; k0 + 16 <= K; k0 += 16) {
+    double a0 = ap[k0 * a_ks], a1 = ap[(k0 + 4) * a_ks], a2 = ap[(k0 + 8) * a_ks], a3 = ap[(k0 + 12) * a_ks];
+    const double b0 = bp[k0 * b_ks], b1 = bp[(k0 + 4) * b_ks], b2 = bp[(k0 + 8) * b_ks], b3 = bp[(k0 + 12) * b_ks];
+    if (NEG) { a0 = -a0; a1 = -a1; a2 = -a2; a3 = -a3; }
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
+  }
+  for (; k0 < K; k0 += 4) {
     const double av = NEG ? -ap[k0 * a_ks] : ap[k0 * a_ks];
     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[k0 * b_ks], acc, 0, 0, 0);
+  }
+}
+// two output tiles sharing the B fragment (A0 / A1 differ): halves the LDS traffic of the B operand; K % 8 == 0
+DEV void mma_tile2(d4_t& acc0, d4_t& acc1, const double* A0, const double* A1, int a_is, int a_ks, const double* B, int b_ks, int b_js, int K, int lane) {
+  const int i = lane & 15, kk = lane >> 4;
+  const double* ap0 = A0 + i * a_is + kk * a_ks;
+  const double* ap1 = A1 + i * a_is + kk * a_ks;
+  const double* bp = B + kk * b_ks + i * b_js;
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    const double a00 = ap0[k0 * a_ks], a01 = ap0[(k0 + 4) * a_ks], a10 = ap1[k0 * a_ks], a11 = ap1[(k0 + 4) * a_ks];
+    const double b0 = bp[k0 * b_ks], b1 = bp[(k0 + 4) * b_ks];
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a10, b0, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, b1, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, b1, acc1, 0, 0, 0);
   }
 }
 DEV d4_t tile_load(const double* C, int ldc, int lane) {
@@ -75,21 +106,180 @@ DEV void tile_store(double* C, int ldc, const d4_t& v, int lane) {
   for (int q = 0; q < 4; ++q) C[(row + 4 * q) * ldc + col] = v[q];
 }
 
-__global__ void __launch_bounds__(256) k_riccati_mfma(SolverArgs a, RicLds S) {
+// value of `v` held by lane SRC (compile-time constant) broadcast to the whole wavefront
+template <int SRC> DEV double readlane_d(double v) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), SRC);
+  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), SRC);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int J, int C> struct CholCol {
+  static DEV void run(double (&d)[16], double l) { d[C] -= l * readlane_d<C>(l); CholCol<J, C + 1>::run(d, l); }
+};
+template <int J> struct CholCol<J, 16> { static DEV void run(double (&)[16], double) {} };
+template <int J> struct CholStep {
+  static DEV void run(double (&d)[16], double (&invd)[16], bool& ok) {
+    const double djj = readlane_d<J>(d[J]);
+    ok = ok && (djj > 0.0);
+    double inv = rsqrt(djj);
+    inv = inv * (1.5 - 0.5 * djj * inv * inv);  // one Newton step: 1/sqrt(djj) to full precision
+    invd[J] = inv;
+    const double l = d[J] * inv;  // lane J: sqrt(djj); lanes r > J: L[r][J]
+    d[J] = l;
+    CholCol<J, J + 1>::run(d, l);
+    CholStep<J + 1>::run(d, invd, ok);
+  }
+};
+template <> struct CholStep<16> { static DEV void run(double (&)[16], double (&)[16], bool&) {} };
+template <int R, int K> struct InvDot {
+  static DEV void run(const double (&d)[16], const double (&x)[16], double& acc) { acc -= readlane_d<R>(d[K]) * x[K]; InvDot<R, K + 1>::run(d, x, acc); }
+};
+template <int R> struct InvDot<R, R> { static DEV void run(const double (&)[16], const double (&)[16], double&) {} };
+template <int R> struct InvRow {
+  static DEV void run(const double (&d)[16], const double (&invd)[16], double (&x)[16], int lane) {
+    double acc = (lane == R) ? 1.0 : 0.0;
+    InvDot<R, 0>::run(d, x, acc);
+    x[R] = acc * invd[R];
+    InvRow<R + 1>::run(d, invd, x, lane);
+  }
+};
+template <> struct InvRow<16> { static DEV void run(const double (&)[16], const double (&)[16], double (&)[16], int) {} };
+
+// One wavefront: Cholesky of the 16x16 block D (lower triangle, leading dimension ld) entirely in registers —
+// lane r (< 16) holds row r — then its inverse.  Writes L back over D (lower part) and L^-1 to LIb (ld 17).
+DEV bool chol16_wave(double* D, int ld, double* LIb, int lane) {
+  double d[16], x[16], invd[16];
+  const int r = lane & 15;
+#pragma unroll
+  for (int cidx = 0; cidx < 16; ++cidx) d[cidx] = D[r * ld + cidx];
+  bool ok = true;
+  CholStep<0>::run(d, invd, ok);
+#pragma unroll
+  for (int cidx = 0; cidx < 16; ++cidx) x[cidx] = 0.0;
+  InvRow<0>::run(d, invd, x, lane);  // lane c (< 16) builds column c of L^-1
+  if (lane < 16) {
+#pragma unroll
+    for (int cidx = 0; cidx < 16; ++cidx) if (cidx <= r) D[r * ld + cidx] = d[cidx];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) LIb[rr * 17 + lane] = x[rr];
+  }
+  return ok;
+}
+
+// Blocked Cholesky of the (16 nb) x (16 nb) matrix A in LDS (lower triangle; pad rows/cols must be identity).
+// L overwrites the lower block triangle, LI[bi] (272 doubles each, ld 17) receives the inverse of diagonal block bi.
+DEV bool chol_blocked(double* A, int ld, int nb, double* LI, int tid, int* flag) {
+  const int lane = tid & 63, wv = tid >> 6, nw = 4;
+  if (tid == 0) *flag = 1;
+  __syncthreads();
+  for (int kb = 0; kb < nb; ++kb) {
+    if (wv == 0) { if (!chol16_wave(A + (kb * 16) * ld + kb * 16, ld, LI + kb * 272, lane) && lane == 0) *flag = 0; }
+    __syncthreads();
+    if (*flag == 0) return false;
+    // panel: L[ri][kb] = A[ri][kb] LI^T   (ri > kb)
+    for (int ri = kb + 1 + wv; ri < nb; ri += nw) {
+      d4_t acc = d4_t{0, 0, 0, 0};
+      mma_tile<false>(acc, A + (ri * 16) * ld + kb * 16, ld, 1, LI + kb * 272, 1, 17, 16, lane);
+      tile_store(A + (ri * 16) * ld + kb * 16, ld, acc, lane);
+    }
+    __syncthreads();
+    // trailing update of the lower block triangle: A[ri][cj] -= L[ri][kb] L[cj][kb]^T
+    const int rem = nb - kb - 1;
+    for (int t = wv; t < rem * (rem + 1) / 2; t += nw) {
+      int ri = 0, acc_t = 0;
+      while (acc_t + ri + 1 <= t) { acc_t += ri + 1; ++ri; }
+      const int cj = t - acc_t;
+      double* Ct = A + ((kb + 1 + ri) * 16) * ld + (kb + 1 + cj) * 16;
+      d4_t acc = tile_load(Ct, ld, lane);
+      mma_tile<true>(acc, A + ((kb + 1 + ri) * 16) * ld + kb * 16, ld, 1, A + ((kb + 1 + cj) * 16) * ld + kb * 16, 1, ld, 16, lane);
+      tile_store(Ct, ld, acc, lane);
+    }
+    __syncthreads();
+  }
+  return true;
+}
+
+// B <- L^-1 B (forward) for the column blocks owned by this wavefront; B is (16 nb) x (16 ncb), leading dim ldb.
+// Column blocks are independent, LDS operations of one wavefront execute in order: no workgroup barrier needed.
+DEV void trsm_fwd_blocked(const double* Lm, int ld, const double* LI, int nb, double* Bm, int ldb, int ncb, int wv, int nw, int lane) {
+  for (int cj = wv; cj < ncb; cj += nw) {
+    for (int bi = 0; bi < nb; ++bi) {
+      double* Bt = Bm + (bi * 16) * ldb + cj * 16;
+      d4_t acc = tile_load(Bt, ldb, lane);
+      mma_tile<true>(acc, Lm + (bi * 16) * ld, ld, 1, Bm + cj * 16, ldb, 1, bi * 16, lane);
+      tile_store(Bt, ldb, acc, lane);
+      d4_t acc2 = d4_t{0, 0, 0, 0};
+      mma_tile<false>(acc2, LI + bi * 272, 17, 1, Bt, ldb, 1, 16, lane);
+      tile_store(Bt, ldb, acc2, lane);
+    }
+  }
+}
+// B <- L^-T B (backward)
+DEV void trsm_bwd_blocked(const double* Lm, int ld, const double* LI, int nb, double* Bm, int ldb, int ncb, int wv, int nw, int lane) {
+  for (int cj = wv; cj < ncb; cj += nw) {
+    for (int bi = nb - 1; bi >= 0; --bi) {
+      double* Bt = Bm + (bi * 16) * ldb + cj * 16;
+      d4_t acc = tile_load(Bt, ldb, lane);
+      mma_tile<true>(acc, Lm + ((bi + 1) * 16) * ld + bi * 16, 1, ld, Bm + ((bi + 1) * 16) * ldb + cj * 16, ldb, 1, (nb - 1 - bi) * 16, lane);
+      tile_store(Bt, ldb, acc, lane);
+      d4_t acc2 = d4_t{0, 0, 0, 0};
+      mma_tile<false>(acc2, LI + bi * 272, 1, 17, Bt, ldb, 1, 16, lane);
+      tile_store(Bt, ldb, acc2, lane);
+    }
+  }
+}
+
+// 6x6 inverse by Gauss-Jordan without pivoting, fully unrolled so that the 6x12 tableau stays in registers
+// (-E6 = Jlog6 of the dynamics gap is a small perturbation of the identity: no pivoting needed).
+DEV void inv6_unrolled(const double* A, double* Ainv) {
+  double M[6][12];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { M[i][j] = A[i * 6 + j]; M[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double inv = 1.0 / M[k][k];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) M[k][j] *= inv;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i == k) continue;
+      const double l = M[i][k];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) M[i][j] -= l * M[k][j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Ainv[i * 6 + j] = M[i][6 + j];
+}
+
+DEV double wave_sum_r(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return __shfl(v, 0, 64);
+}
+
+// ============================================================================================================
+// one wavefront per SIMD (LDS-bound occupancy anyway): let the register allocator use the whole 512-entry file
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) k_riccati_mfma(SolverArgs a, RicLds S) {
   const Layout& L = a.L;
   const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nthr >> 6;
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
   const int n = L.n, nz = L.nz, N = L.N, nr = n + 1;
-  const int np = S.np, mp = S.mp, nzp = S.nzp, ldl = S.ldl, nb = S.nb, nzt = nzp / 16, lw = S.lw;
+  const int np = S.np, ldp = S.np + 1, mp = S.mp, nzp = S.nzp, ldl = S.ldl, ldr = S.ldr, nb = S.nb, nbm = S.nbm, nzt = nzp / 16, lw = S.lw, nwb = S.nwb;
   const double mu = st.mu, mud = mu * a.opt.dyn_al_scale;
   const bool ff = L.space == MPC_SPACE_MULTIBODY;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *PT = sm + S.PT, *LP = sm + S.LP, *LI = sm + S.LI, *AB = sm + S.AB, *GP = sm + S.GP, *vec = sm + S.vec;
-  double *Lr = sm + S.Lr, *W = sm + S.W, *ST = sm + S.ST, *CTl = sm + S.CT, *VXl = sm + S.VX, *Yl = sm + S.Y, *SCl = sm + S.SC;
+  double *Lr = sm + S.Lr, *LIr = sm + S.LIr, *W = sm + S.W, *ST = sm + S.ST, *CTl = sm + S.CT, *VXl = sm + S.VX, *Yl = sm + S.Y, *SCl = sm + S.SC, *LIs = sm + S.LIs;
   int* act_idx = (int*)(sm + S.iwork);
-  int* iflag = act_idx + L.c;
+  int* iflag = act_idx + L.c;  // [0] factorisation flag, [1] ca, [2..5] per-wave active counts
   double *ph = vec, *ft = vec + nzp, *vv = vec + 2 * nzp, *w = vec + 3 * nzp, *gh = vec + 4 * nzp, *pvec = vec + 5 * nzp, *dtl = vec + 6 * nzp;
+  double* kvc = dtl + L.c;
+  double* e6l = kvc + L.c;  // 36 doubles; vec reserves 8 (nzp + c) + 64
   double* wk = a.work + (size_t)b * L.work_stride;
   double* Hh = wk + L.wHh;  // nz x nz, leading dimension nz (L2-resident scratch)
 
@@ -103,15 +293,15 @@ __global__ void __launch_bounds__(256) k_riccati_mfma(SolverArgs a, RicLds S) {
       const int i = idx / n, z = idx % n;
       g[L.oKnu + idx] = (kn[L.oACT + i] != 0.0) ? kn[L.oCD + i * nz + z] / mu : 0.0;
     }
-    for (int idx = tid; idx < np * np; idx += nthr) PT[idx] = 0.0;
+    for (int idx = tid; idx < np * ldp; idx += nthr) PT[idx] = 0.0;
     __syncthreads();
-    for (int idx = tid; idx < n * n; idx += nthr) {
-      const int r = idx / n, s = idx % n;
-      double t = kn[L.oH + r * nz + s];
-      for (int i = 0; i < c; ++i) if (kn[L.oACT + i] != 0.0) t += kn[L.oCD + i * nz + r] * g[L.oKnu + i * n + s];
-      g[L.oP + idx] = t;
-      PT[r * np + s] = t;
-    }
+    for (int r = wv; r < n; r += nw)
+      for (int s = lane; s < n; s += 64) {
+        double t = kn[L.oH + r * nz + s];
+        for (int i = 0; i < c; ++i) if (kn[L.oACT + i] != 0.0) t += kn[L.oCD + i * nz + r] * g[L.oKnu + i * n + s];
+        g[L.oP + r * n + s] = t;
+        PT[r * ldp + s] = t;
+      }
     for (int r = tid; r < n; r += nthr) {
       double t = kn[L.oG + r];
       for (int i = 0; i < c; ++i) t += kn[L.oCD + i * nz + r] * g[L.oknu + i];
@@ -121,276 +311,342 @@ __global__ void __launch_bounds__(256) k_riccati_mfma(SolverArgs a, RicLds S) {
     __syncthreads();
   }
 
+  long long t0_ = clock64();
   for (int k = N - 1; k >= 0; --k) {
     const double* kn = knot_ptr(a, b, k);
     double* g = gain_ptr(a, b, k);
-    const int m = (int)kn[L.oMISC + MISC_M], c = (int)kn[L.oMISC + MISC_NC], nzk = n + m;
+    const int m = (int)kn[L.oMISC + MISC_M], c = (int)kn[L.oMISC + MISC_NC];
     const double* le = a.lams_e + ((size_t)b * (N + 1) + k + 1) * n;
-    // ---- 1. y = Ebar x' ----
-    if (tid == 0) {
-      if (ff) {
-        double Eb[36];
-        for (int i = 0; i < 36; ++i) Eb[i] = -kn[L.oE6 + i];
-        inv6_serial(Eb, g + L.oT6);
-      } else {
-        for (int i = 0; i < 36; ++i) g[L.oT6 + i] = (i % 7 == 0) ? 1.0 : 0.0;
+    // ---- 1. active rows (ballot prefix; wave q owns rows 64q .. 64q+63, c <= 256), T6 = (-E6)^-1 ----
+    const int arow = wv * 64 + lane;
+    const bool is_act = (arow < c) && (kn[L.oACT + arow] != 0.0);
+    const unsigned long long amask = __ballot(is_act);
+    if (lane == 0) iflag[2 + wv] = __popcll(amask);
+    if (tid < 36) e6l[tid] = -kn[L.oE6 + tid];
+    __syncthreads();
+    {
+      int off = 0;
+      for (int q = 0; q < wv; ++q) off += iflag[2 + q];
+      if (is_act) act_idx[off + __popcll(amask & ((1ull << lane) - 1ull))] = arow;
+      if (tid == 0) {
+        int ca_ = 0;
+        for (int q = 0; q < nw; ++q) ca_ += iflag[2 + q];
+        iflag[1] = ca_;
+        if (ff) inv6_unrolled(e6l, g + L.oT6);
+        else for (int i2 = 0; i2 < 36; ++i2) g[L.oT6 + i2] = (i2 % 7 == 0) ? 1.0 : 0.0;
       }
-      int ca = 0;
-      for (int i = 0; i < c; ++i) if (kn[L.oACT + i] != 0.0) act_idx[ca++] = i;
-      iflag[1] = ca;
     }
     __syncthreads();
+    RIC_PROF(0);
     const int ca = iflag[1];
     const double* T6 = g + L.oT6;
     if (ff) {
-      // columns < 6: tmp = P' T (stored in GP-free scratch: use w/gh region? need n x 6) -> use LP as scratch (dead here)
-      double* tmp = LP;  // n x 6
+      double* tmp = LP;  // scratch (LP is dead here)
       for (int idx = tid; idx < n * 6; idx += nthr) {
         const int i = idx / 6, j = idx % 6;
         double s = 0;
-        for (int l = 0; l < 6; ++l) s += PT[i * np + l] * T6[l * 6 + j];
+        for (int l = 0; l < 6; ++l) s += PT[i * ldp + l] * T6[l * 6 + j];
         tmp[idx] = s;
       }
       __syncthreads();
-      for (int idx = tid; idx < n * 6; idx += nthr) PT[(idx / 6) * np + idx % 6] = tmp[idx];
+      for (int idx = tid; idx < n * 6; idx += nthr) PT[(idx / 6) * ldp + idx % 6] = tmp[idx];
       __syncthreads();
-      // rows < 6: T^T (P' T)
-      for (int idx = tid; idx < 6 * n; idx += nthr) {
-        const int i = idx / n, j = idx % n;
-        double s = 0;
-        for (int l = 0; l < 6; ++l) s += T6[l * 6 + i] * PT[l * np + j];
-        tmp[idx] = s;
-      }
+      for (int i = wv; i < 6; i += nw)
+        for (int j = lane; j < n; j += 64) {
+          double s = 0;
+          for (int l = 0; l < 6; ++l) s += T6[l * 6 + i] * PT[l * ldp + j];
+          tmp[i * n + j] = s;
+        }
       if (tid < 6) { double s = 0; for (int l = 0; l < 6; ++l) s += T6[l * 6 + tid] * pvec[l]; ph[tid] = s; }
       __syncthreads();
-      for (int idx = tid; idx < 6 * n; idx += nthr) PT[(idx / n) * np + idx % n] = tmp[idx];
+      for (int i = wv; i < 6; i += nw) for (int j = lane; j < n; j += 64) PT[i * ldp + j] = tmp[i * n + j];
       for (int i = 6 + tid; i < n; i += nthr) ph[i] = pvec[i];
     } else {
       for (int i = tid; i < n; i += nthr) ph[i] = pvec[i];
     }
     for (int i = tid; i < n; i += nthr) ft[i] = kn[L.oF + i] + mud * le[i];
     __syncthreads();
-    // ---- 2. LP = I + mud sym(Ph) ; vv = Ph ft + ph ----
-    for (int idx = tid; idx < np * np; idx += nthr) {
-      const int i = idx / np, j = idx % np;
-      LP[i * ldl + j] = mud * 0.5 * (PT[idx] + PT[j * np + i]) + (i == j ? 1.0 : 0.0);
-    }
-    for (int i = tid; i < n; i += nthr) { double s = ph[i]; for (int j = 0; j < n; ++j) s += PT[i * np + j] * ft[j]; vv[i] = s; }
-    __syncthreads();
-    if (!chol_block(LP, n, ldl, tid, nthr, iflag)) { if (tid == 0) a.inst[b].done = 2; return; }
-    // inverses of the 16x16 diagonal blocks (pad rows/cols are identity)
-    for (int t = tid; t < nb * 16; t += nthr) {
-      const int bi = t / 16, cc = t % 16;
-      const double* D = LP + (bi * 16) * ldl + bi * 16;
-      double* X = LI + bi * 272;
-      double xcol[16];
-      for (int r = 0; r < 16; ++r) {
-        double s = (r == cc) ? 1.0 : 0.0;
-        for (int q = cc; q < r; ++q) s -= D[r * ldl + q] * xcol[q];
-        xcol[r] = (r < cc) ? 0.0 : s / D[r * ldl + r];
-      }
-      for (int r = 0; r < 16; ++r) X[r * 17 + cc] = xcol[r];
+    RIC_PROF(1);
+    // ---- 2. LP = I + mud Ph ; vv = Ph ft + ph ----
+    for (int i = wv; i < np; i += nw)
+      for (int j = lane; j < np; j += 64) LP[i * ldl + j] = mud * PT[i * ldp + j] + (i == j ? 1.0 : 0.0);
+    for (int i = wv; i < n; i += nw) {
+      double s = 0;
+      for (int j = lane; j < n; j += 64) s += PT[i * ldp + j] * ft[j];
+      s = wave_sum_r(s);
+      if (lane == 0) vv[i] = s + ph[i];
     }
     __syncthreads();
-    // ---- 3. PT <- (L L^T)^-1 PT, column block per wave ----
-    for (int bi = 0; bi < nb; ++bi) {
-      for (int cj0 = 0; cj0 < nb; cj0 += nw) {
-        const int cj = cj0 + wv;
-        d4_t acc;
-        if (cj < nb) {
-          acc = tile_load(PT + (bi * 16) * np + cj * 16, np, lane);
-          mma_tile<true>(acc, LP + (bi * 16) * ldl, ldl, 1, PT + cj * 16, np, 1, bi * 16, lane);
-        }
-        __syncthreads();
-        if (cj < nb) tile_store(PT + (bi * 16) * np + cj * 16, np, acc, lane);
-        __syncthreads();
-        if (cj < nb) {
-          acc = d4_t{0, 0, 0, 0};
-          mma_tile<false>(acc, LI + bi * 272, 17, 1, PT + (bi * 16) * np + cj * 16, np, 1, 16, lane);
-        }
-        __syncthreads();
-        if (cj < nb) tile_store(PT + (bi * 16) * np + cj * 16, np, acc, lane);
-        __syncthreads();
-      }
-    }
-    for (int bi = nb - 1; bi >= 0; --bi) {
-      for (int cj0 = 0; cj0 < nb; cj0 += nw) {
-        const int cj = cj0 + wv;
-        d4_t acc;
-        if (cj < nb) {
-          acc = tile_load(PT + (bi * 16) * np + cj * 16, np, lane);
-          // - sum_{bj > bi} L[bj][bi]^T X[bj][cj]
-          mma_tile<true>(acc, LP + ((bi + 1) * 16) * ldl + bi * 16, 1, ldl, PT + ((bi + 1) * 16) * np + cj * 16, np, 1, (nb - 1 - bi) * 16, lane);
-        }
-        __syncthreads();
-        if (cj < nb) tile_store(PT + (bi * 16) * np + cj * 16, np, acc, lane);
-        __syncthreads();
-        if (cj < nb) {
-          acc = d4_t{0, 0, 0, 0};
-          mma_tile<false>(acc, LI + bi * 272, 1, 17, PT + (bi * 16) * np + cj * 16, np, 1, 16, lane);
-        }
-        __syncthreads();
-        if (cj < nb) tile_store(PT + (bi * 16) * np + cj * 16, np, acc, lane);
-        __syncthreads();
-      }
-    }
-    // symmetrise Pt, w = vv - mud Pt vv
-    for (int idx = tid; idx < n * n; idx += nthr) {
-      const int i = idx / n, j = idx % n;
-      if (j > i) { const double s = 0.5 * (PT[i * np + j] + PT[j * np + i]); PT[i * np + j] = s; PT[j * np + i] = s; }
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += nthr) { double s = 0; for (int j = 0; j < n; ++j) s += PT[i * np + j] * vv[j]; w[i] = vv[i] - mud * s; }
-    for (int idx = tid; idx < n * n; idx += nthr) g[L.oMx + idx] = PT[(idx / n) * np + idx % n];
-    for (int i = tid; i < n; i += nthr) g[L.omx + i] = ft[i] - mud * ph[i];
-    // ---- 4. AB into LDS (zero padded; u-columns start at np) ----
-    for (int idx = tid; idx < np * nzp; idx += nthr) {
-      const int i = idx / nzp, zp = idx % nzp;
-      double v = 0.0;
+    RIC_PROF(2);
+    if (!chol_blocked(LP, ldl, nb, LI, tid, iflag)) { if (tid == 0) a.inst[b].done = 2; return; }
+    RIC_PROF(3);
+    // [A B] of this knot: issue the HBM loads here (the triangular solves below hide their latency), park them in
+    // registers, drop them into LDS in step 4
+    double abr[AB_ROWS][2];
+#pragma unroll
+    for (int q = 0; q < AB_ROWS; ++q) {
+      const int i = wv + nw * q;
+      abr[q][0] = 0.0; abr[q][1] = 0.0;
       if (i < n) {
-        if (zp < n) v = kn[L.oAB + i * nz + zp];
-        else if (zp >= np && zp - np < m) v = kn[L.oAB + i * nz + n + (zp - np)];
+        const double* src = kn + L.oAB + (size_t)i * nz;
+        const int z0 = lane, z1 = lane + 64;
+        if (z0 < n) abr[q][0] = src[z0]; else if (z0 >= np && z0 - np < m) abr[q][0] = src[n + z0 - np];
+        if (z1 < nzp) { if (z1 < n) abr[q][1] = src[z1]; else if (z1 >= np && z1 - np < m) abr[q][1] = src[n + z1 - np]; }
       }
-      AB[idx] = v;
+    }
+    // ---- 3. PT <- (L L^T)^-1 PT ----
+    trsm_fwd_blocked(LP, ldl, LI, nb, PT, ldp, nb, wv, nw, lane);
+    trsm_bwd_blocked(LP, ldl, LI, nb, PT, ldp, nb, wv, nw, lane);
+    __syncthreads();
+    RIC_PROF(5);
+    // w = vv - mud Pt vv, store Pt / yv for the forward sweep (Pt is symmetric up to rounding)
+    for (int i = wv; i < n; i += nw) {
+      double s = 0;
+      for (int j = lane; j < n; j += 64) { const double pv = PT[i * ldp + j]; s += pv * vv[j]; g[L.oMx + i * n + j] = pv; }
+      s = wave_sum_r(s);
+      if (lane == 0) w[i] = vv[i] - mud * s;
+    }
+    for (int i = tid; i < n; i += nthr) g[L.omx + i] = ft[i] - mud * ph[i];
+    RIC_PROF(6);
+    // ---- 4. AB into LDS (zero padded; u-columns start at np) ----
+#pragma unroll
+    for (int q = 0; q < AB_ROWS; ++q) {
+      const int i = wv + nw * q;
+      if (i < np) { if (lane < nzp) AB[i * nzp + lane] = abr[q][0]; if (lane + 64 < nzp) AB[i * nzp + lane + 64] = abr[q][1]; }
     }
     __syncthreads();
     for (int zp = tid; zp < nzp; zp += nthr) {
       const int z = (zp < n) ? zp : ((zp >= np && zp - np < m) ? n + zp - np : -1);
       if (z >= 0) { double s = kn[L.oG + z]; for (int i = 0; i < n; ++i) s += AB[i * nzp + zp] * w[i]; gh[z] = s; }
     }
+    RIC_PROF(7);
     // ---- 5. panels: G_j = Pt AB_j ; Hh[:, j] = H[:, j] + AB^T G_j ----
     for (int cj = 0; cj < nzt; ++cj) {
-      for (int ri0 = 0; ri0 < nb; ri0 += nw) {
-        const int ri = ri0 + wv;
-        if (ri < nb) {
-          d4_t acc = d4_t{0, 0, 0, 0};
-          mma_tile<false>(acc, PT + ri * 16, 1, np, AB + cj * 16, nzp, 1, np, lane);  // Pt symmetric: A(i,k) = Pt[k][i]
-          tile_store(GP + (ri * 16) * 16, 16, acc, lane);
+      for (int r0 = wv; r0 < nb; r0 += 2 * nw) {
+        const int r1 = r0 + nw;
+        d4_t acc0 = d4_t{0, 0, 0, 0}, acc1 = d4_t{0, 0, 0, 0};
+        if (r1 < nb) {
+          mma_tile2(acc0, acc1, PT + r0 * 16, PT + r1 * 16, 1, ldp, AB + cj * 16, nzp, 1, np, lane);  // Pt symmetric
+          tile_store(GP + (r1 * 16) * 16, 16, acc1, lane);
+        } else {
+          mma_tile<false>(acc0, PT + r0 * 16, 1, ldp, AB + cj * 16, nzp, 1, np, lane);
+        }
+        tile_store(GP + (r0 * 16) * 16, 16, acc0, lane);
+      }
+      __syncthreads();
+      const int col_p = cj * 16 + (lane & 15);
+      const int zc = (col_p < n) ? col_p : ((col_p >= np && col_p - np < m) ? n + col_p - np : -1);
+      for (int zi0 = wv; zi0 < nzt; zi0 += 2 * nw) {
+        const int zi1 = zi0 + nw;
+        d4_t acc0 = d4_t{0, 0, 0, 0}, acc1 = d4_t{0, 0, 0, 0};
+        int zr0[4], zr1[4];
+        double h0[4], h1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // H loads are in flight while the matrix cores work
+          const int rp0 = zi0 * 16 + (lane >> 4) + 4 * q, rp1 = zi1 * 16 + (lane >> 4) + 4 * q;
+          zr0[q] = (rp0 < n) ? rp0 : ((rp0 >= np && rp0 - np < m) ? n + rp0 - np : -1);
+          zr1[q] = (zi1 < nzt) ? ((rp1 < n) ? rp1 : ((rp1 >= np && rp1 - np < m) ? n + rp1 - np : -1)) : -1;
+          h0[q] = (zr0[q] >= 0 && zc >= 0) ? kn[L.oH + zr0[q] * nz + zc] : 0.0;
+          h1[q] = (zr1[q] >= 0 && zc >= 0) ? kn[L.oH + zr1[q] * nz + zc] : 0.0;
+        }
+        if (zi1 < nzt) mma_tile2(acc0, acc1, AB + zi0 * 16, AB + zi1 * 16, 1, nzp, GP, 16, 1, np, lane);
+        else mma_tile<false>(acc0, AB + zi0 * 16, 1, nzp, GP, 16, 1, np, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (zr0[q] >= 0 && zc >= 0) Hh[zr0[q] * nz + zc] = h0[q] + acc0[q];
+          if (zr1[q] >= 0 && zc >= 0) Hh[zr1[q] * nz + zc] = h1[q] + acc1[q];
         }
       }
       __syncthreads();
-      for (int zi0 = 0; zi0 < nzt; zi0 += nw) {
-        const int zi = zi0 + wv;
-        if (zi < nzt) {
+    }
+    RIC_PROF(8);
+    // ---- 6. stage KKT (AB is dead: R1 is reused) ----
+    const bool small_ca = ca <= 16;
+    // Lr = sym(Hh_uu) padded with identity ; W = -[Sh^T | rh] (mp x lw, zero padded) ; ST = Sh^T (mp x np)
+    for (int i = wv; i < mp; i += nw) {
+      for (int j = lane; j < mp; j += 64) Lr[i * ldr + j] = (i < m && j < m) ? 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]) : (i == j ? 1.0 : 0.0);
+      for (int z = lane; z < lw; z += 64) {
+        double sv = 0.0;
+        if (i < m) { if (z < n) sv = Hh[(n + i) * nz + z]; else if (z == np) sv = gh[n + i]; }
+        W[i * lw + z] = -sv;
+        if (z < np) ST[i * np + z] = (z < n) ? sv : 0.0;
+      }
+    }
+    if (small_ca) {
+      // CT = [Ca_x | . | dt | .] (16 x lw) ; Y = Da^T (mp x 16)
+      for (int i = wv; i < 16; i += nw)
+        for (int z = lane; z < lw; z += 64) {
+          double cv = 0.0;
+          if (i < ca) { if (z < n) cv = kn[L.oCD + act_idx[i] * nz + z]; else if (z == np) cv = kn[L.oDT + act_idx[i]]; }
+          CTl[i * lw + z] = cv;
+        }
+      for (int idx = tid; idx < mp * 16; idx += nthr) {
+        const int i = idx >> 4, j = idx & 15;
+        Yl[idx] = (i < m && j < ca) ? kn[L.oCD + act_idx[j] * nz + n + i] : 0.0;
+      }
+    }
+    __syncthreads();
+    RIC_PROF(9);
+    if (!chol_blocked(Lr, ldr, nbm, LIr, tid, iflag)) { if (tid == 0) a.inst[b].done = 3; return; }
+    RIC_PROF(10);
+    trsm_fwd_blocked(Lr, ldr, LIr, nbm, W, lw, nwb, wv, nw, lane);  // W = L^-1 T
+    if (ca > 0 && small_ca && wv == nw - 1) trsm_fwd_blocked(Lr, ldr, LIr, nbm, Yl, 16, 1, 0, 1, lane);  // Y = L^-1 Da^T
+    __syncthreads();
+    if (ca > 0) {
+      if (small_ca) {
+        // Sc = mu I + Y^T Y (pad identity) ; V = [Ca | dt] + Y^T W
+        if (wv == 0) {
           d4_t acc = d4_t{0, 0, 0, 0};
-          mma_tile<false>(acc, AB + zi * 16, 1, nzp, GP, 16, 1, np, lane);
-          // add H and write the valid entries to the scratch (leading dimension nz, compact z indexing)
-          const int col_p = cj * 16 + (lane & 15);
-          const int zc = (col_p < n) ? col_p : ((col_p >= np && col_p - np < m) ? n + col_p - np : -1);
+          mma_tile<false>(acc, Yl, 1, 16, Yl, 16, 1, mp, lane);
+          const int col = lane & 15;
           for (int q = 0; q < 4; ++q) {
-            const int row_p = zi * 16 + (lane >> 4) + 4 * q;
-            const int zr = (row_p < n) ? row_p : ((row_p >= np && row_p - np < m) ? n + row_p - np : -1);
-            if (zr >= 0 && zc >= 0) Hh[zr * nz + zc] = kn[L.oH + zr * nz + zc] + acc[q];
+            const int row = (lane >> 4) + 4 * q;
+            double v = acc[q];
+            if (row == col) v += (row < ca) ? mu : 1.0;
+            SCl[row * 17 + col] = v;
           }
         }
+        for (int cj = wv; cj < nwb; cj += nw) {
+          d4_t acc = tile_load(CTl + cj * 16, lw, lane);
+          mma_tile<false>(acc, Yl, 1, 16, W + cj * 16, lw, 1, mp, lane);
+          tile_store(VXl + cj * 16, lw, acc, lane);
+        }
+        __syncthreads();
+        if (tid == 0) iflag[0] = 1;
+        __syncthreads();
+        if (wv == 0) { if (!chol16_wave(SCl, 17, LIs, lane) && lane == 0) iflag[0] = 0; }
+        __syncthreads();
+        if (iflag[0] == 0) { if (tid == 0) a.inst[b].done = 4; return; }
+        trsm_fwd_blocked(SCl, 17, LIs, 1, VXl, lw, nwb, wv, nw, lane);
+        trsm_bwd_blocked(SCl, 17, LIs, 1, VXl, lw, nwb, wv, nw, lane);
+        __syncthreads();
+        // W -= Y V
+        for (int t = wv; t < nbm * nwb; t += nw) {
+          const int ri = t / nwb, cj = t % nwb;
+          double* Wt = W + (ri * 16) * lw + cj * 16;
+          d4_t acc = tile_load(Wt, lw, lane);
+          mma_tile<true>(acc, Yl + (ri * 16) * 16, 16, 1, VXl + cj * 16, lw, 1, 16, lane);
+          tile_store(Wt, lw, acc, lane);
+        }
+        __syncthreads();
+      } else {
+        // many active rows: unblocked path on the L2-resident scratch (rare: more than 16 active rows at one knot)
+        double *Ct = wk + L.wCt, *V = wk + L.wV, *Y = wk + L.wY, *Sc = wk + L.wSc;
+        for (int idx = tid; idx < ca * n; idx += nthr) Ct[(idx / n) * nz + idx % n] = kn[L.oCD + act_idx[idx / n] * nz + idx % n];
+        for (int idx = tid; idx < m * ca; idx += nthr) Y[idx] = kn[L.oCD + act_idx[idx % ca] * nz + n + idx / ca];
+        for (int i = tid; i < ca; i += nthr) dtl[i] = kn[L.oDT + act_idx[i]];
+        __syncthreads();
+        for (int j = tid; j < ca; j += nthr)
+          for (int i = 0; i < m; ++i) { double s = Y[i * ca + j]; for (int q = 0; q < i; ++q) s -= Lr[i * ldr + q] * Y[q * ca + j]; Y[i * ca + j] = s / Lr[i * ldr + i]; }
+        __syncthreads();
+        for (int idx = tid; idx < ca * ca; idx += nthr) {
+          const int i = idx / ca, j = idx % ca;
+          double s = (i == j) ? mu : 0.0;
+          for (int l = 0; l < m; ++l) s += Y[l * ca + i] * Y[l * ca + j];
+          Sc[idx] = s;
+        }
+        for (int idx = tid; idx < ca * nr; idx += nthr) {
+          const int i = idx / nr, z = idx % nr;
+          double s = (z < n) ? Ct[i * nz + z] : dtl[i];
+          for (int l = 0; l < m; ++l) s += Y[l * ca + i] * W[l * lw + ((z < n) ? z : np)];
+          V[i * nr + z] = s;
+        }
+        __syncthreads();
+        if (!chol_block(Sc, ca, ca, tid, nthr, iflag)) { if (tid == 0) a.inst[b].done = 4; return; }
+        potrs_block(Sc, ca, ca, V, nr, nr, tid, nthr);
+        for (int idx = tid; idx < m * nr; idx += nthr) {
+          const int l = idx / nr, z = idx % nr;
+          double s = 0;
+          for (int i = 0; i < ca; ++i) s += Y[l * ca + i] * V[i * nr + z];
+          W[l * lw + ((z < n) ? z : np)] -= s;
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
-    // ---- 6. stage KKT (AB is dead: R1 is reused) ----
-    const bool small_ca = ca <= S.cap;
-    double* Ct = small_ca ? CTl : (wk + L.wCt);   // ca x ldc
-    double* V = small_ca ? VXl : (wk + L.wV);     // ca x ldv
-    double* Y = small_ca ? Yl : (wk + L.wY);      // m x ca
-    double* Sc = small_ca ? SCl : (wk + L.wSc);   // ca x ca
-    const int ldc = small_ca ? np : nz, ldv = small_ca ? np : nr;
-    if (small_ca) for (int idx = tid; idx < S.cap * np; idx += nthr) { CTl[idx] = 0.0; VXl[idx] = 0.0; }
-    for (int idx = tid; idx < mp * np; idx += nthr) ST[idx] = 0.0;
-    for (int idx = tid; idx < mp * lw; idx += nthr) W[idx] = 0.0;
+    trsm_bwd_blocked(Lr, ldr, LIr, nbm, W, lw, nwb, wv, nw, lane);  // U = L^-T (W - Y V)
     __syncthreads();
-    for (int idx = tid; idx < m * m; idx += nthr) {
-      const int i = idx / m, j = idx % m;
-      Lr[idx] = 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]);
+    RIC_PROF(11);
+    // gains out: K, k, Knu, knu ; p = qh + Sh k + Ca^T kv
+    for (int i = wv; i < m; i += nw) {
+      for (int z = lane; z < n; z += 64) g[L.oK + i * n + z] = W[i * lw + z];
+      if (lane == 0) g[L.ok + i] = W[i * lw + np];
     }
-    for (int idx = tid; idx < m * nr; idx += nthr) {
-      const int i = idx / nr, z = idx % nr;
-      const double sv = (z < n) ? Hh[(n + i) * nz + z] : gh[n + i];
-      W[i * lw + ((z < n) ? z : np)] = -sv;
-      if (z < n) ST[i * np + z] = sv;
-    }
-    for (int idx = tid; idx < ca * n; idx += nthr) Ct[(idx / n) * ldc + idx % n] = kn[L.oCD + act_idx[idx / n] * nz + idx % n];
-    for (int idx = tid; idx < m * ca; idx += nthr) Y[(idx / ca) * ca + idx % ca] = kn[L.oCD + act_idx[idx % ca] * nz + n + idx / ca];
-    for (int i = tid; i < ca; i += nthr) dtl[i] = kn[L.oDT + act_idx[i]];
-    __syncthreads();
-    if (!chol_block(Lr, m, m, tid, nthr, iflag)) { if (tid == 0) a.inst[b].done = 3; return; }
-    trsm_lower_block(Lr, m, m, W, lw, lw, tid, nthr);
-    // V holds [Kv | kv]: columns 0..n-1 and a separate vector for the constant column
-    double* kvc = dtl + L.c;  // ca
-    if (ca > 0) {
-      trsm_lower_block(Lr, m, m, Y, ca, ca, tid, nthr);
-      for (int idx = tid; idx < ca * ca; idx += nthr) {
-        const int i = idx / ca, j = idx % ca;
-        double s = (i == j) ? mu : 0.0;
-        for (int l = 0; l < m; ++l) s += Y[l * ca + i] * Y[l * ca + j];
-        Sc[idx] = s;
-      }
-      for (int idx = tid; idx < ca * nr; idx += nthr) {
-        const int i = idx / nr, z = idx % nr;
-        double s = (z < n) ? Ct[i * ldc + z] : dtl[i];
-        for (int l = 0; l < m; ++l) s += Y[l * ca + i] * W[l * lw + ((z < n) ? z : np)];
-        if (z < n) V[i * ldv + z] = s; else kvc[i] = s;
-      }
-      __syncthreads();
-      if (!chol_block(Sc, ca, ca, tid, nthr, iflag)) { if (tid == 0) a.inst[b].done = 4; return; }
-      potrs_block(Sc, ca, ca, V, n, ldv, tid, nthr);
-      potrs_block(Sc, ca, ca, kvc, 1, 1, tid, nthr);
-      for (int idx = tid; idx < m * nr; idx += nthr) {
-        const int l = idx / nr, z = idx % nr;
-        double s = 0;
-        for (int i = 0; i < ca; ++i) s += Y[l * ca + i] * ((z < n) ? V[i * ldv + z] : kvc[i]);
-        W[l * lw + ((z < n) ? z : np)] -= s;
-      }
-      __syncthreads();
-    }
-    trsm_lower_t_block(Lr, m, m, W, lw, lw, tid, nthr);
-    for (int idx = tid; idx < m * n; idx += nthr) g[L.oK + idx] = W[(idx / n) * lw + idx % n];
-    for (int i = tid; i < m; i += nthr) g[L.ok + i] = W[i * lw + np];
     for (int idx = tid; idx < c * n; idx += nthr) g[L.oKnu + idx] = 0.0;
     for (int i = tid; i < c; i += nthr) g[L.oknu + i] = 0.0;
     __syncthreads();
-    for (int idx = tid; idx < ca * n; idx += nthr) g[L.oKnu + act_idx[idx / n] * n + idx % n] = V[(idx / n) * ldv + idx % n];
-    for (int i = tid; i < ca; i += nthr) g[L.oknu + act_idx[i]] = kvc[i];
-    // p = qh + Sh k + Ca^T kv
+    if (small_ca) {
+      for (int i = wv; i < ca; i += nw) {
+        for (int z = lane; z < n; z += 64) g[L.oKnu + act_idx[i] * n + z] = VXl[i * lw + z];
+        if (lane == 0) { g[L.oknu + act_idx[i]] = VXl[i * lw + np]; kvc[i] = VXl[i * lw + np]; }
+      }
+    } else {
+      const double* V = wk + L.wV;
+      for (int idx = tid; idx < ca * n; idx += nthr) g[L.oKnu + act_idx[idx / n] * n + idx % n] = V[(idx / n) * nr + idx % n];
+      for (int i = tid; i < ca; i += nthr) { g[L.oknu + act_idx[i]] = V[i * nr + n]; kvc[i] = V[i * nr + n]; }
+    }
+    __syncthreads();
     for (int r = tid; r < n; r += nthr) {
       double t = gh[r];
       for (int i = 0; i < m; ++i) t += ST[i * np + r] * W[i * lw + np];
-      for (int i = 0; i < ca; ++i) t += Ct[i * ldc + r] * kvc[i];
+      if (small_ca) { for (int i = 0; i < ca; ++i) t += CTl[i * lw + r] * kvc[i]; }
+      else { const double* Ct = wk + L.wCt; for (int i = 0; i < ca; ++i) t += Ct[i * nz + r] * kvc[i]; }
       g[L.op + r] = t;
       pvec[r] = t;
     }
-    __syncthreads();
-    // ---- 7. P = Qh + Sh K + Ca^T Kv  ->  PT (next knot's P') ----
+    // ---- 7. P = Qh + Sh K + Ca^T Kv  ->  PT (next knot's P'); only the upper block triangle is computed ----
     if (small_ca) {
       const int kc = (ca + 3) & ~3;
       for (int t = wv; t < nb * nb; t += nw) {
         const int ri = t / nb, cj = t % nb;
+        const int col = cj * 16 + (lane & 15);
+        double qh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; qh[q] = (row < n && col < n) ? Hh[row * nz + col] : 0.0; }
         d4_t acc = d4_t{0, 0, 0, 0};
         mma_tile<false>(acc, ST + ri * 16, 1, np, W + cj * 16, lw, 1, mp, lane);
-        if (kc > 0) mma_tile<false>(acc, CTl + ri * 16, 1, np, VXl + cj * 16, np, 1, kc, lane);
-        const int col = cj * 16 + (lane & 15);
+        if (kc > 0) mma_tile<false>(acc, CTl + ri * 16, 1, lw, VXl + cj * 16, lw, 1, kc, lane);
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int row = ri * 16 + (lane >> 4) + 4 * q;
-          PT[row * np + col] = (row < n && col < n) ? Hh[row * nz + col] + acc[q] : 0.0;
+          PT[row * ldp + col] = (row < n && col < n) ? qh[q] + acc[q] : 0.0;
         }
       }
     } else {
-      for (int idx = tid; idx < np * np; idx += nthr) {
-        const int r = idx / np, s = idx % np;
-        double t = 0.0;
-        if (r < n && s < n) {
-          t = Hh[r * nz + s];
-          for (int i = 0; i < m; ++i) t += ST[i * np + r] * W[i * lw + s];
-          for (int i = 0; i < ca; ++i) t += Ct[i * ldc + r] * V[i * ldv + s];
+      const double *Ct = wk + L.wCt, *V = wk + L.wV;
+      for (int r = wv; r < np; r += nw)
+        for (int s = lane; s < np; s += 64) {
+          double t = 0.0;
+          if (r < n && s < n) {
+            t = Hh[r * nz + s];
+            for (int i = 0; i < m; ++i) t += ST[i * np + r] * W[i * lw + s];
+            for (int i = 0; i < ca; ++i) t += Ct[i * nz + r] * V[i * nr + s];
+          }
+          PT[r * ldp + s] = t;
         }
-        PT[idx] = t;
+    }
+    __syncthreads();
+    // symmetrise in LDS (leading dimension np + 1: the transposed read is conflict-free), store the gain record
+    {
+      double sv[AB_ROWS][2];
+#pragma unroll
+      for (int q = 0; q < AB_ROWS; ++q) {
+        const int i = wv + nw * q;
+        if (i < n) {
+          if (lane < n) sv[q][0] = 0.5 * (PT[i * ldp + lane] + PT[lane * ldp + i]);
+          if (lane + 64 < n) sv[q][1] = 0.5 * (PT[i * ldp + lane + 64] + PT[(lane + 64) * ldp + i]);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < AB_ROWS; ++q) {
+        const int i = wv + nw * q;
+        if (i < n) {
+          if (lane < n) { PT[i * ldp + lane] = sv[q][0]; g[L.oP + i * n + lane] = sv[q][0]; }
+          if (lane + 64 < n) { PT[i * ldp + lane + 64] = sv[q][1]; g[L.oP + i * n + lane + 64] = sv[q][1]; }
+        }
       }
     }
     __syncthreads();
-    for (int idx = tid; idx < n * n; idx += nthr) {
-      const int i = idx / n, j = idx % n;
-      if (j >= i) { const double s = 0.5 * (PT[i * np + j] + PT[j * np + i]); g[L.oP + i * n + j] = s; g[L.oP + j * n + i] = s; }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < n * n; idx += nthr) PT[(idx / n) * np + idx % n] = g[L.oP + idx];
-    __syncthreads();
+    RIC_PROF(12);
   }
 }

@@ -26,6 +26,7 @@ struct SolverArgs {
   double *trial_phi;  // [B][n_alpha][N+1]
   InstState* inst;
   int* all_done;
+  double* prof;  // [B][32] phase cycle counters of the Riccati kernel (debug)
 };
 
 DEV double* knot_ptr(const SolverArgs& a, int b, int k) { return a.knots + ((size_t)b * (a.L.N + 1) + k) * a.L.knot_stride; }
