@@ -1,0 +1,106 @@
+"""Pins the oracle's proximal Riccati sweep and its iteration: the step of one ProxDDP iteration equals a dense,
+pivoted solve of the assembled KKT system (numpy), the cold solve drives the optimality conditions below the
+tolerance, and a converged solution is a fixed point."""
+import numpy as np
+import pytest
+
+from mpc_benchmark_amd import aligator
+from mpc_benchmark_amd.problems.centroidal import CentroidalProblem
+from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+from tests._dense_kkt import solve_dense_lq, stage_rows
+
+
+def _check_against_dense(solver, prob, N, n, m, multibody, tol):
+    nat = solver._native
+    rows = [stage_rows(*solver._node(prob, k)._lowered) for k in range(N + 1)]
+    ref = solve_dense_lq(nat, N, n, m, 1e-8, 1e-11, rows, multibody=multibody)
+    for k in range(N + 1):
+        dx = nat.debug_get("dx", k)
+        assert np.max(np.abs(dx - ref["dx"][k])) <= tol * max(1.0, np.max(np.abs(ref["dx"][k])))
+        if k < N:
+            du = nat.debug_get("du", k)
+            assert np.max(np.abs(du - ref["du"][k])) <= tol * max(1.0, np.max(np.abs(ref["du"][k])))
+        if k > 0:
+            lam = nat.debug_get("dlams", k)  # multipliers start at zero after setup: dlams = new co-states
+            assert np.max(np.abs(lam - ref["lam"][k])) <= 1e-5 * max(1.0, np.max(np.abs(ref["lam"][k])))
+
+
+def test_riccati_step_equals_dense_kkt_centroidal(oracle_lib):
+    cp = CentroidalProblem(horizon=12)
+    prob = cp.build()
+    for t in range(8):
+        prob.replaceStageCircular(cp.stage_for_tick(t + 15))  # brings single-support stages in
+    solver = cp.make_solver(_native_library=oracle_lib)
+    solver.max_iters = 1
+    solver.setup(prob)
+    xs, us = cp.initial_guess()
+    rng = np.random.default_rng(5)
+    xs = [x + 1e-2 * rng.standard_normal(9) for x in xs]
+    us = [u + 30.0 * rng.standard_normal(12) for u in us]
+    prob.x0_init = xs[0]
+    solver.run(prob, xs, us)
+    _check_against_dense(solver, prob, 12, 9, 12, False, 1e-8)
+
+
+def test_riccati_step_equals_dense_kkt_fulldynamics(oracle_lib):
+    fp = FullDynamicsProblem(horizon=4)
+    lf, rf = fp.robot.foot_placements
+    stages = [fp.create_stage(cs, lf.copy(), rf.copy()) for cs in ([True, True], [True, False], [False, True], [True, True])]
+    prob = aligator.TrajOptProblem(fp.x0, stages, fp.terminal_cost())
+    prob.addTerminalConstraint(fp.terminal_com_constraint(fp.robot.com0 + 0.01))
+    solver = fp.make_solver(_native_library=oracle_lib)
+    solver.max_iters = 1
+    solver.setup(prob)
+    rng = np.random.default_rng(2)
+    xs = [fp.space.integrate(fp.x0, 0.03 * rng.standard_normal(fp.space.ndx)) for _ in range(5)]
+    us = [15.0 * rng.standard_normal(fp.nu) for _ in range(4)]
+    prob.x0_init = xs[0]
+    solver.run(prob, xs, us)
+    _check_against_dense(solver, prob, 4, fp.space.ndx, fp.nu, True, 1e-7)
+
+
+@pytest.mark.parametrize("kind", ["centroidal", "fulldynamic"])
+def test_cold_solve_converges_to_tolerance(oracle_lib, kind):
+    pd = CentroidalProblem(horizon=50) if kind == "centroidal" else FullDynamicsProblem(horizon=8)
+    prob = pd.build()
+    solver = pd.make_solver(_native_library=oracle_lib)
+    solver.setup(prob)
+    xs, us = pd.initial_guess()
+    assert solver.run(prob, xs, us)
+    r = solver.results
+    assert r.conv and r.prim_infeas <= 1e-5 and r.dual_infeas <= 1e-5 and r.num_iters <= 20
+    # dynamics are satisfied along the solution and x[0] is the imposed initial state
+    assert np.allclose(r.xs[0], prob.x0_init)
+    # a converged solution is a fixed point: one more iteration from it does not move
+    solver.max_iters = 1
+    xs2, us2 = list(r.xs), list(r.us)
+    solver.setup(prob)
+    solver.run(prob, xs2, us2)
+    assert np.max(np.abs(np.array(solver.results.us) - np.array(us2))) < 1e-3 * max(1.0, np.max(np.abs(np.array(us2))))
+
+
+def test_centroidal_stage_jacobians_match_finite_differences(oracle_lib):
+    cp = CentroidalProblem(horizon=1)
+    prob = cp.build()
+    solver = cp.make_solver(_native_library=oracle_lib)
+    solver.setup(prob)
+    rng = np.random.default_rng(0)
+    x0, x1 = cp.x0 + 0.05 * rng.standard_normal(9), cp.x0 + 0.05 * rng.standard_normal(9)
+    u0 = cp.u0 + 20.0 * rng.standard_normal(12)
+    nat = solver._native
+
+    def ev(x, u):
+        nat.debug_evaluate(np.array([x, x1]), np.array([u]))
+        return nat.debug_get("f", 0), nat.debug_get("cval", 0), nat.debug_get("cost", 0)[0]
+
+    nat.debug_evaluate(np.array([x0, x1]), np.array([u0]))
+    AB, CD, grad = nat.debug_get("AB", 0).reshape(9, 21), nat.debug_get("CD", 0).reshape(-1, 21), nat.debug_get("grad", 0)
+    eps = 1e-6
+    for j in range(21):
+        d = np.zeros(21)
+        d[j] = eps
+        fp_, cp_, lp_ = ev(x0 + d[:9], u0 + d[9:])
+        fm_, cm_, lm_ = ev(x0 - d[:9], u0 - d[9:])
+        assert np.allclose((fp_ - fm_) / (2 * eps), AB[:, j], atol=1e-6)
+        assert np.allclose((cp_ - cm_) / (2 * eps), CD[:, j], atol=1e-6)
+        assert abs((lp_ - lm_) / (2 * eps) - grad[j]) < 1e-5 * max(1.0, abs(grad[j]))
