@@ -228,13 +228,52 @@ template <class T> Mot<T> elemwise(const double* k, const Mot<T>& m) {
   return Mot<T>{V3<T>(T(k[0]) * m.lin[0], T(k[1]) * m.lin[1], T(k[2]) * m.lin[2]), V3<T>(T(k[3]) * m.ang[0], T(k[4]) * m.ang[1], T(k[5]) * m.ang[2])};
 }
 
+// ---- kinodynamics (kinodynamic_talos.py:107-112): centroidal momentum balance closes the base acceleration ----
+// rate of the centroidal momentum d/dt hg (about the CoM, world axes) for joint accelerations `a`, no gravity
+template <class T>
+Frc<T> momentum_rate(const Model& m, const State<T>& s, const double* a, V3<T>& com) {
+  std::vector<T> aT(m.nv);
+  for (int i = 0; i < m.nv; ++i) aT[i] = T(a ? a[i] : 0.0);
+  Kin<T> k;
+  forward_pass(m, s, aT.data(), k, false);
+  Frc<T> f0;
+  V3<T> mc;
+  for (int i = 0; i < m.nj; ++i) {
+    const Inertia<T> Y = convert<T>(m.inertia[i]);
+    f0 = f0 + act(k.oMi[i], Y * k.a[i] + fcross(k.v[i], Y * k.v[i]));
+    mc = mc + Y.mass * (k.oMi[i].R * Y.c + k.oMi[i].p);
+  }
+  com = T(1.0 / m.total_mass) * mc;
+  return Frc<T>{f0.lin, f0.ang - cross(com, f0.lin)};
+}
+// momentum rate produced by the contact wrenches u = [f0 tau0 f1 tau1 ...] (world axes, applied at the sole
+// frame origins) and gravity:  [sum f + m g ; sum (p_i - c) x f_i + tau_i]
+template <class T>
+Frc<T> wrench_rate(const Model& m, const State<T>& s, const double* u, const double* grav, const int* states, const int* frames, int nk) {
+  Kin<T> k;
+  forward_pass<T>(m, s, nullptr, k, false);
+  V3<T> mc;
+  for (int i = 0; i < m.nj; ++i) { const Inertia<T> Y = convert<T>(m.inertia[i]); mc = mc + Y.mass * (k.oMi[i].R * Y.c + k.oMi[i].p); }
+  const V3<T> com = T(1.0 / m.total_mass) * mc;
+  Frc<T> h;
+  h.lin = V3<T>(T(m.total_mass * grav[0]), T(m.total_mass * grav[1]), T(m.total_mass * grav[2]));
+  for (int c = 0; c < nk; ++c) {
+    if (!states[c]) continue;
+    const SE3<T> oMf = k.oMi[m.frame_joint[frames[c]]] * convert<T>(m.frame_pl[frames[c]]);
+    const V3<T> f(T(u[6 * c]), T(u[6 * c + 1]), T(u[6 * c + 2])), tau(T(u[6 * c + 3]), T(u[6 * c + 4]), T(u[6 * c + 5]));
+    h.lin = h.lin + f;
+    h.ang = h.ang + cross(oMf.p - com, f) + tau;
+  }
+  return h;
+}
+
 // Everything that is a function of (q, v) only, given the solved (a, lambda) as constants:
 //   r1 = RNEA(q, v, a; fext = contact forces fixed in the contact frames)              (nv)
 //   r2 = contact-frame spatial acceleration + Kd*vel_err - Kp*log6(c1Mc2) per contact  (6 each)
 //   rt = stacked residuals of the (q,v)-only terms of the stage
 template <class T>
 void mb_functions(const Model& m, const StageDesc& sd, const State<T>& s, const double* a, const double* lam,
-                  std::vector<T>& r1, std::vector<T>& r2, std::vector<T>& rt) {
+                  std::vector<T>& r1, std::vector<T>& r2, std::vector<T>& rt, const double* u = nullptr) {
   const bool dyn = sd.dyn == MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER;
   const int nk = dyn ? sd.ncontact : 0;
   std::vector<T> aT(m.nv);
@@ -313,6 +352,15 @@ void mb_functions(const Model& m, const StageDesc& sd, const State<T>& s, const 
           for (int i = 0; i < 3; ++i) rt.push_back(hg.ang[i] - T(tp[3 + i]));
         }
       } break;
+      case MPC_TERM_CENTROIDAL_MOMENTUM_DER: {
+        // params: g[3], states[nk], frames[nk]
+        const int nkk = t.i0;
+        int states[4], frames[4];
+        for (int c = 0; c < nkk; ++c) { states[c] = tp[3 + c] != 0.0; frames[c] = (int)tp[3 + nkk + c]; }
+        const Frc<T> h = wrench_rate<T>(m, s, u, tp, states, frames, nkk);
+        for (int i = 0; i < 3; ++i) rt.push_back(h.lin[i]);
+        for (int i = 0; i < 3; ++i) rt.push_back(h.ang[i]);
+      } break;
       default: break;  // control / contact-force terms handled by the caller
     }
   }
@@ -320,7 +368,8 @@ void mb_functions(const Model& m, const StageDesc& sd, const State<T>& s, const 
 
 inline bool is_qv_term(int type) {
   return type == MPC_TERM_STATE_ERROR || type == MPC_TERM_FRAME_PLACEMENT || type == MPC_TERM_FRAME_TRANSLATION ||
-         type == MPC_TERM_FRAME_VELOCITY || type == MPC_TERM_COM_TRANSLATION || type == MPC_TERM_CENTROIDAL_MOMENTUM;
+         type == MPC_TERM_FRAME_VELOCITY || type == MPC_TERM_COM_TRANSLATION || type == MPC_TERM_CENTROIDAL_MOMENTUM ||
+         type == MPC_TERM_CENTROIDAL_MOMENTUM_DER;
 }
 
 // x' = x (+) dx on the multibody phase space (Pinocchio integrate on q, plain sum on v)
@@ -349,8 +398,9 @@ inline void eval_multibody(const Model& m, const StageDesc& sd, int nu, const do
                            Knot& kn, bool with_derivs) {
   const int nv = m.nv, n = 2 * nv, nx = m.nq + nv;
   const bool dyn = sd.dyn == MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER;
-  if (sd.dyn != MPC_DYN_NONE && !dyn) throw std::runtime_error("oracle: dynamics kind not implemented for multibody stages");
-  const int mm = dyn ? nu : 0, nz = n + mm;
+  const bool kino = sd.dyn == MPC_DYN_KINODYNAMICS_SEMIEULER;
+  if (sd.dyn != MPC_DYN_NONE && !dyn && !kino) throw std::runtime_error("oracle: dynamics kind not implemented for multibody stages");
+  const int mm = (dyn || kino) ? nu : 0, nz = n + mm;
   const int nk = dyn ? sd.ncontact : 0, nl = 6 * nk, nK = nv + nl;
   kn.resize(n, mm, sd.nc, nx);
   const double* P = sd.params.data();
@@ -405,19 +455,87 @@ inline void eval_multibody(const Model& m, const StageDesc& sd, int nu, const do
     for (int i = 0; i < nv; ++i) { kn.xdot[i] = s0.v[i]; kn.xdot[nv + i] = a[i]; }
   }
 
+  // ---------------- kinodynamics: a_joint = u[12:], base acceleration from the centroidal momentum balance ----------------
+  std::vector<double> da_kino;  // nv x nz
+  if (kino) {
+    const double* dp = P + sd.dyn_poff;
+    dt = dp[0];
+    const int nkk = sd.ncontact, nf = 6 * nkk;
+    int states[4], frames[4];
+    for (int c = 0; c < nkk; ++c) { states[c] = sd.cid[c]; frames[c] = (int)dp[4 + c]; }
+    dual_nd() = 0;
+    for (int i = 6; i < nv; ++i) a[i] = u[nf + i - 6];
+    // Ag columns: hg(q, e_k)
+    std::vector<double> Ag(6 * nv);
+    {
+      State<double> se = s0;
+      Kin<double> k;
+      for (int j = 0; j < nv; ++j) {
+        std::fill(se.v.begin(), se.v.end(), 0.0);
+        se.v[j] = 1.0;
+        forward_pass<double>(m, se, nullptr, k, false);
+        V3<double> c; Frc<double> hg;
+        centroidal(m, k, c, hg);
+        for (int i = 0; i < 3; ++i) { Ag[i * nv + j] = hg.lin[i]; Ag[(3 + i) * nv + j] = hg.ang[i]; }
+      }
+    }
+    V3<double> com;
+    std::vector<double> aj(a);
+    for (int i = 0; i < 6; ++i) aj[i] = 0.0;
+    const Frc<double> hd0 = momentum_rate<double>(m, s0, aj.data(), com);  // dAg v + Ag[:,6:] a_j
+    const Frc<double> hdes = wrench_rate<double>(m, s0, u, dp + 1, states, frames, nkk);
+    std::vector<double> Agb(36), rhs(6);
+    for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) Agb[i * 6 + j] = Ag[i * nv + j];
+    for (int i = 0; i < 3; ++i) { rhs[i] = hdes.lin[i] - hd0.lin[i]; rhs[3 + i] = hdes.ang[i] - hd0.ang[i]; }
+    std::vector<double> Agb_inv(36, 0.0);
+    for (int i = 0; i < 6; ++i) Agb_inv[i * 6 + i] = 1.0;
+    { std::vector<double> tmp(Agb); solve_dense(tmp, 6, Agb_inv, 6); }
+    for (int i = 0; i < 6; ++i) { double sacc = 0; for (int j = 0; j < 6; ++j) sacc += Agb_inv[i * 6 + j] * rhs[j]; a[i] = sacc; }
+    for (int i = 0; i < nv; ++i) { kn.xdot[i] = s0.v[i]; kn.xdot[nv + i] = a[i]; }
+    if (with_derivs) {
+      // r(q, v) = momentum_rate(q, v, a) - wrench_rate(q, u)   (6 rows), a and u held fixed
+      dual_nd() = n;
+      const State<Dual> sT = lift<Dual>(m, s0, 0);
+      V3<Dual> cT;
+      const Frc<Dual> hrT = momentum_rate<Dual>(m, sT, a.data(), cT);
+      const Frc<Dual> hwT = wrench_rate<Dual>(m, sT, u, dp + 1, states, frames, nkk);
+      std::vector<double> dr(6 * nz, 0.0);
+      for (int i = 0; i < 3; ++i) for (int k = 0; k < n; ++k) { dr[i * nz + k] = hrT.lin[i].d[k] - hwT.lin[i].d[k]; dr[(3 + i) * nz + k] = hrT.ang[i].d[k] - hwT.ang[i].d[k]; }
+      dual_nd() = 0;
+      // d r / d u: wrenches (- [I ; (p - c) x], - [0 ; I]) and joint accelerations (Ag columns)
+      Kin<double> k0;
+      forward_pass<double>(m, s0, nullptr, k0, false);
+      for (int c = 0; c < nkk; ++c) {
+        if (!states[c]) continue;
+        const SE3<double> oMf = k0.oMi[m.frame_joint[frames[c]]] * m.frame_pl[frames[c]];
+        const V3<double> r = oMf.p - com;
+        const M3<double> Rx = skew(r);
+        for (int i = 0; i < 3; ++i) {
+          dr[i * nz + n + 6 * c + i] -= 1.0;
+          dr[(3 + i) * nz + n + 6 * c + 3 + i] -= 1.0;
+          for (int j = 0; j < 3; ++j) dr[(3 + i) * nz + n + 6 * c + j] -= Rx(i, j);
+        }
+      }
+      for (int j = 6; j < nv; ++j) for (int i = 0; i < 6; ++i) dr[i * nz + n + nf + j - 6] += Ag[i * nv + j];
+      da_kino.assign(nv * nz, 0.0);
+      for (int i = 0; i < 6; ++i) for (int k = 0; k < nz; ++k) { double sacc = 0; for (int j = 0; j < 6; ++j) sacc += Agb_inv[i * 6 + j] * dr[j * nz + k]; da_kino[i * nz + k] = -sacc; }
+      for (int j = 6; j < nv; ++j) da_kino[j * nz + n + nf + j - 6] = 1.0;
+    }
+  }
+
   // ---------------- K2/K4: residual values and (q,v)-Jacobians by forward AD ----------------
   std::vector<double> r1v, r2v, rtv;
   std::vector<double> Jr1, Jr2, Jrt;  // (rows x 2nv)
   {
     dual_nd() = 0;
-    mb_functions<double>(m, sd, s0, a.data(), lam.data(), r1v, r2v, rtv);
+    mb_functions<double>(m, sd, s0, a.data(), lam.data(), r1v, r2v, rtv, u);
   }
   const int nrt = (int)rtv.size();
   if (with_derivs) {
     dual_nd() = n;
     std::vector<Dual> r1, r2, rt;
     const State<Dual> sT = lift<Dual>(m, s0, 0);
-    mb_functions<Dual>(m, sd, sT, a.data(), lam.data(), r1, r2, rt);
+    mb_functions<Dual>(m, sd, sT, a.data(), lam.data(), r1, r2, rt, u);
     Jr1.assign(nv * n, 0.0); Jr2.assign(nl * n, 0.0); Jrt.assign(nrt * n, 0.0);
     for (int i = 0; i < nv && dyn; ++i) for (int k = 0; k < n; ++k) Jr1[i * n + k] = r1[i].d[k];
     for (int i = 0; i < nl; ++i) for (int k = 0; k < n; ++k) Jr2[i * n + k] = r2[i].d[k];
@@ -443,8 +561,9 @@ inline void eval_multibody(const Model& m, const StageDesc& sd, int nu, const do
     }
   }
 
+  if (kino && with_derivs) da = da_kino;
   // ---------------- K3: semi-implicit Euler, dynamics gap and its Jacobians ----------------
-  if (dyn) {
+  if (dyn || kino) {
     // primal: v+ = v + dt a ; q+ = q (+) dt v+
     std::vector<double> dx(n);
     for (int i = 0; i < nv; ++i) { const double vp = s0.v[i] + dt * a[i]; dx[i] = dt * vp; dx[nv + i] = dt * a[i]; }
@@ -507,6 +626,28 @@ inline void eval_multibody(const Model& m, const StageDesc& sd, int nu, const do
         if (with_derivs) for (int k = 0; k < n; ++k) J[i * nz + k] = Jrt[(rtoff + i) * n + k];
       }
       rtoff += d;
+      if (t.type == MPC_TERM_CENTROIDAL_MOMENTUM_DER && with_derivs && mm > 0) {
+        // u-part: d/df = [I ; (p - c) x], d/dtau = [0 ; I] per active contact
+        const int nkk = t.i0;
+        Kin<double> k0;
+        dual_nd() = 0;
+        forward_pass<double>(m, s0, nullptr, k0, false);
+        V3<double> c0; Frc<double> hg0;
+        centroidal(m, k0, c0, hg0);
+        for (int c = 0; c < nkk; ++c) {
+          if (tp[3 + c] == 0.0) continue;
+          const int fr = (int)tp[3 + nkk + c];
+          const SE3<double> oMf = k0.oMi[m.frame_joint[fr]] * m.frame_pl[fr];
+          const M3<double> Rx = skew(oMf.p - c0);
+          for (int i = 0; i < 3; ++i) {
+            J[i * nz + n + 6 * c + i] = 1.0;
+            J[(3 + i) * nz + n + 6 * c + 3 + i] = 1.0;
+            for (int j = 0; j < 3; ++j) J[(3 + i) * nz + n + 6 * c + j] = Rx(i, j);
+          }
+        }
+      }
+    } else if (t.type == MPC_TERM_CENTROIDAL_WRENCH_CONE) {
+      for (int i = 0; i < d; ++i) for (int j = 0; j < 6; ++j) { r[i] += tp[i * 6 + j] * u[6 * t.i0 + j]; J[i * nz + n + 6 * t.i0 + j] = tp[i * 6 + j]; }
     } else if (t.type == MPC_TERM_CONTROL_ERROR) {
       for (int i = 0; i < d; ++i) { r[i] = u[t.i0 + i] - tp[t.i0 + i]; J[i * nz + n + t.i0 + i] = 1.0; }
     } else if (t.type == MPC_TERM_CONTACT_FORCE) {
