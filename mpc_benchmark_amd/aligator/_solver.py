@@ -198,7 +198,9 @@ class SolverProxDDP:
             d.horizon, d.batch = N, int(self.batch)
             d.space = K.SPACE_MULTIBODY if isinstance(space, _manifolds.MultibodyPhaseSpace) else K.SPACE_VECTOR
             d.nx, d.ndx, d.nu = space.nx, space.ndx, first.nu
-            d.nc_max = max(nc_max, 2 * 17 + 2 * first.nu + space.ndx)  # room for later stages with more rows
+            # every schedule of the reference starts in double support, which has the most constraint rows
+            # (fulldynamic_talos.py:371, kinodynamic_talos.py:274); a later stage with more rows is rejected by the library
+            d.nc_max = max(nc_max, 1)
             d.max_stage_ints = 8 + 8 * 24
             d.max_stage_doubles = max(nd._lowered[1].size for nd in nodes) + 1024
             d.device = 0

@@ -87,6 +87,32 @@ DEV void Jexp6(V3 v, V3 w, double* out) {
   }
 }
 
+// 6x6 inverse by Gauss-Jordan without pivoting, fully unrolled (registers only); used on M_bb (SPD)
+DEV void inv6_unrolled_mb(const double* A, double* Ainv) {
+  double M[6][12];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { M[i][j] = A[i * 6 + j]; M[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const double inv = 1.0 / M[k][k];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) M[k][j] *= inv;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      if (i == k) continue;
+      const double l = M[i][k];
+#pragma unroll
+      for (int j = 0; j < 12; ++j) M[i][j] -= l * M[k][j];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) Ainv[i * 6 + j] = M[i][6 + j];
+}
+
 // ---- LDS carve-out ------------------------------------------------------------------------------------------
 struct MbLds {
   int nj, nv, nq, nl_max, nK_max;
@@ -159,8 +185,9 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
   const int32_t* desc = a.stage_desc + (size_t)slot * L.max_stage_ints;
   const double* P = a.stage_params + (size_t)slot * L.max_stage_doubles;
   const int dyn = desc[0];
-  const bool has_dyn = dyn == MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER;
-  const int m = has_dyn ? nu : 0, nz = n + m, nterms = desc[5], c = desc[6];
+  const bool has_dyn = dyn == MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER;   // contact-constrained forward dynamics
+  const bool kino = dyn == MPC_DYN_KINODYNAMICS_SEMIEULER;               // kinodynamics: u = [wrenches ; joint accelerations]
+  const int m = (has_dyn || kino) ? nu : 0, nz = n + m, nterms = desc[5], c = desc[6];
   const int nk = has_dyn ? desc[1] : 0, nl = 6 * nk, nK = nv + nl;
   const bool derivs = !TRIAL;
   const double alpha = TRIAL ? ldexp(1.0, -cand) : 0.0;
@@ -197,7 +224,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
   const double* cd = fd + MPC_MODEL_FRAME_DOUBLES * nframes;
   const double grav[3] = {md[0], md[1], md[2]};
   const double prox_mu = md[3];
-  const S6 a0 = mk6(v3(-grav[0], -grav[1], -grav[2]), v3(0, 0, 0));
+  const S6 a0 = kino ? mk6(v3(0, 0, 0), v3(0, 0, 0)) : mk6(v3(-grav[0], -grav[1], -grav[2]), v3(0, 0, 0));
 
   // ---- P0: evaluation point, tree tables ---------------------------------------------------------------
   {
@@ -461,6 +488,69 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
     (void)dt;
   }
 
+  // ---- kinodynamics (kinodynamic_talos.py:107-112): a_joint = u[12:], base acceleration from the momentum balance
+  // about the world origin  sum_k U_k a_k + hdot(a = 0) = [sum f + m g ; sum p_i x f_i + tau_i + c x m g],
+  // projected on the base columns: (J_b^T U_b) a_b = J_b^T (...)  with J_b^T U_b = M_bb symmetric positive definite.
+  double mtot = 0;
+  for (int i = 0; i < nj; ++i) mtot += jd[25 * i + 12];
+  const V3 com = v3(Yc[6 * 5 + 1] / mtot, Yc[6 * 3 + 2] / mtot, Yc[6 * 4 + 0] / mtot);
+  if (kino) {
+    const double* dp = P + desc[4];
+    const int nkk = desc[1], nf = 6 * nkk;
+    const V3 mg = v3(mtot * dp[1], mtot * dp[2], mtot * dp[3]);
+    double* Minv6 = small + 144;  // 36
+    if (tid < nkk) {
+      const int fi = (int)dp[4 + tid], i = mframe[fi];
+      const V3 pf = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+      cfr[54 * tid + 9] = pf.x; cfr[54 * tid + 10] = pf.y; cfr[54 * tid + 11] = pf.z;
+      cfr[54 * tid] = (double)i;
+    }
+    for (int i = tid; i < nv; i += nthr) acc[i] = (i >= 6) ? u[nf + i - 6] : 0.0;
+    __syncthreads();
+    if (tid == 0) {
+      S6 r0 = mk6(mg, cross(com, mg));
+      for (int cc = 0; cc < nkk; ++cc) {
+        if (!desc[2 + cc]) continue;
+        const V3 pf = ldv3(cfr + 54 * cc + 9);
+        const V3 f = v3(u[6 * cc], u[6 * cc + 1], u[6 * cc + 2]), tq = v3(u[6 * cc + 3], u[6 * cc + 4], u[6 * cc + 5]);
+        r0 = add6(r0, mk6(f, cross(pf, f) + tq));
+      }
+      r0 = sub6(r0, ld6(Fc));  // hdot at a = 0 (true accelerations: a0 = 0 in this mode)
+      for (int j = 6; j < nv; ++j) r0 = sub6(r0, scale6(acc[j], ld6(U + 6 * j)));
+      double Mbb[36], rb[6];
+      for (int r = 0; r < 6; ++r) {
+        rb[r] = dot6(ld6(J + 6 * r), r0);
+        for (int cc = 0; cc < 6; ++cc) Mbb[6 * r + cc] = dot6(ld6(U + 6 * r), ld6(J + 6 * cc));
+      }
+      inv6_unrolled_mb(Mbb, Minv6);
+      for (int r = 0; r < 6; ++r) { double sacc = 0; for (int cc = 0; cc < 6; ++cc) sacc += Minv6[6 * r + cc] * rb[cc]; acc[r] = sacc; }
+    }
+    __syncthreads();
+    if (derivs) {
+      for (int i = tid; i < n; i += nthr) kn[KL.oXD + i] = (i < nv) ? v[i] : acc[i - nv];
+      for (int i = tid; i < 12; i += nthr) kn[KL.oWR + i] = 0.0;
+    }
+    // accelerations and body forces at the solution (needed by the derivative vectors)
+    for (int idx = tid; idx < 6 * nj; idx += nthr) {
+      const int i = idx / 6, e = idx % 6;
+      double sacc = oa[idx];
+      for (int kd = 0; kd < nv; ++kd) if (BELOW(kd, i)) sacc += J[6 * kd + e] * acc[kd];
+      oa[idx] = sacc;
+    }
+    __syncthreads();
+    if (derivs) {
+      for (int i = tid; i < nj; i += nthr) st6(of + 6 * i, add6(mat6_mul(oY + 36 * i, ld6(oa + 6 * i)), fcross(ld6(ov + 6 * i), ld6(oh + 6 * i))));
+      __syncthreads();
+      for (int idx = tid; idx < 6 * nj; idx += nthr) {
+        const int i = idx / 6, e = idx % 6;
+        double sacc = 0;
+        for (int j = i; j < nj; ++j) if (INSUB(j, i)) sacc += of[6 * j + e];
+        Fc[idx] = sacc;
+      }
+    }
+    __syncthreads();
+  }
+
   // ---- P9: derivative building blocks (also needed by velocity-dependent residuals) ------------------------
   for (int kd = tid; kd < nv; kd += nthr) {
     const int pb = parent[dof_body[kd]];
@@ -475,7 +565,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
     st6(Phi + 6 * kd, mcross(add6(ld6(ov + 6 * dof_body[kd]), vl), Jk));
   }
   __syncthreads();
-  if (derivs && has_dyn) {
+  if (derivs && (has_dyn || kino)) {
     // body-level "Coriolis" matrices B_i (overwrite oY), then their subtree sums
     for (int i = tid; i < nj; i += nthr) {
       double Yl[36], Bm[36];
@@ -505,8 +595,50 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
       st6(Tv + 6 * kd, add6(mat6_mul(Yc + 36 * bk, ld6(Phi + 6 * kd)), mat6_mul(Bc + 36 * bk, Jk)));
     }
     __syncthreads();
+    if (kino) {
+      // d r0 / d(q, v, u) (6 x nz, stored in dr), then  d a_b = -Mbb^-1 J_b^T d r0 ; joint accelerations are controls
+      const double* dp = P + desc[4];
+      const int nkk = desc[1], nf = 6 * nkk;
+      const V3 mg = v3(mtot * dp[1], mtot * dp[2], mtot * dp[3]);
+      const double* Minv6 = small + 144;
+      for (int z = tid; z < nz; z += nthr) {
+        S6 col = zero6();
+        if (z < nv) {
+          col = ld6(Tq + 6 * z);
+          V3 dang = cross((1.0 / mtot) * lin(ld6(U + 6 * z)), mg);
+          const S6 Jz = ld6(J + 6 * z);
+          for (int cc = 0; cc < nkk; ++cc) {
+            if (!desc[2 + cc] || !BELOW(z, (int)cfr[54 * cc])) continue;
+            const V3 pf = ldv3(cfr + 54 * cc + 9);
+            dang = dang + cross(lin(Jz) + cross(ang(Jz), pf), v3(u[6 * cc], u[6 * cc + 1], u[6 * cc + 2]));
+          }
+          col = sub6(col, mk6(v3(0, 0, 0), dang));
+        } else if (z < n) {
+          col = ld6(Tv + 6 * (z - nv));
+        } else if (z < n + nf) {
+          const int cc = (z - n) / 6, e = (z - n) % 6;
+          if (desc[2 + cc]) {
+            V3 ev = v3(e % 3 == 0 ? 1.0 : 0.0, e % 3 == 1 ? 1.0 : 0.0, e % 3 == 2 ? 1.0 : 0.0);
+            if (e < 3) col = mk6(v3(-ev.x, -ev.y, -ev.z), cross(ev, ldv3(cfr + 54 * cc + 9)));  // -[I ; p x]
+            else col = mk6(v3(0, 0, 0), v3(-ev.x, -ev.y, -ev.z));
+          }
+        } else {
+          col = ld6(U + 6 * (6 + z - n - nf));
+        }
+        double jb[6];
+        for (int r = 0; r < 6; ++r) jb[r] = dot6(ld6(J + 6 * r), col);
+        for (int r = 0; r < 6; ++r) {
+          double sacc = 0;
+          for (int cc = 0; cc < 6; ++cc) sacc += Minv6[6 * r + cc] * jb[cc];
+          dsol[(size_t)r * L.nz + z] = -sacc;
+        }
+        for (int r = 6; r < nv; ++r) dsol[(size_t)r * L.nz + z] = (z == n + nf + r - 6) ? 1.0 : 0.0;
+      }
+      __syncthreads();
+    }
     // ---- P10: rows of [d r1 ; d r2] w.r.t. (q, v)  (dr is nK x 2nv; Minv is dead from here on) -------------
     const int n2 = 2 * nv;
+    if (has_dyn) {
     for (int idx = tid; idx < nv * nv; idx += nthr) {
       const int r = idx / nv, j = idx % nv;
       const int br = dof_body[r], bj = dof_body[j];
@@ -556,10 +688,11 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
       dsol[(size_t)r * L.nz + z] = s;
     }
     __syncthreads();
+    }  // has_dyn
   }
 
   // ---- P12: semi-implicit Euler, gap and its Jacobians ----------------------------------------------------
-  if (has_dyn) {
+  if (has_dyn || kino) {
     const double dt = P[desc[4]];
     double* Jl6 = small;        // Jlog6(G)
     double* Je6 = small + 36;   // Jexp6(delta)
@@ -632,10 +765,6 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
 
   // ---- P13: cost stack and constraints -----------------------------------------------------------------------
   // centre of mass and total momentum (body 0 is the root: its composite = whole robot)
-  double mtot = 0;
-  for (int i = 0; i < nj; ++i) mtot += jd[25 * i + 12];
-  // com = (1/m) * first moment; from the composite inertia of the root: Yc[0] lower-left block = m [c]x
-  const V3 com = v3(Yc[6 * 5 + 1] / mtot, Yc[6 * 3 + 2] / mtot, Yc[6 * 4 + 0] / mtot);
   const S6 h0 = ld6(Hc);
   int row = 0;
   for (int t = 0; t < nterms; ++t) {
@@ -790,6 +919,50 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
       } else if (tr.type == MPC_TERM_CONTACT_FORCE) {
         if (tid < 6) r[tid] = lam[6 * tr.i0 + tid] - tp[tid];
         if (derivs) for (int idx = tid; idx < 6 * nz; idx += nthr) Jt[idx] = dsol[(size_t)(nv + 6 * tr.i0 + idx / nz) * L.nz + idx % nz];
+      } else if (tr.type == MPC_TERM_CENTROIDAL_WRENCH_CONE) {
+        for (int i = tid; i < d; i += nthr) { double sacc = 0; for (int j = 0; j < 6; ++j) sacc += tp[i * 6 + j] * u[6 * tr.i0 + j]; r[i] = sacc; }
+        if (derivs) for (int idx = tid; idx < d * 6; idx += nthr) Jt[(idx / 6) * nz + n + 6 * tr.i0 + idx % 6] = tp[idx];
+      } else if (tr.type == MPC_TERM_CENTROIDAL_MOMENTUM_DER) {
+        // r = [sum f + m g ; sum (p_i - c) x f_i + tau_i]   (kinodynamic_talos.py:125-127); params: g[3], states, frames
+        const int nkk = tr.i0;
+        if (tid == 0) {
+          V3 rl = v3(mtot * tp[0], mtot * tp[1], mtot * tp[2]), ra = v3(0, 0, 0);
+          for (int cc = 0; cc < nkk; ++cc) {
+            if (tp[3 + cc] == 0.0) continue;
+            const int fi = (int)tp[3 + nkk + cc], i = mframe[fi];
+            const V3 pf = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+            const V3 f = v3(u[6 * cc], u[6 * cc + 1], u[6 * cc + 2]);
+            rl = rl + f;
+            ra = ra + cross(pf - com, f) + v3(u[6 * cc + 3], u[6 * cc + 4], u[6 * cc + 5]);
+          }
+          r[0] = rl.x; r[1] = rl.y; r[2] = rl.z; r[3] = ra.x; r[4] = ra.y; r[5] = ra.z;
+        }
+        if (derivs) {
+          for (int j = tid; j < nv; j += nthr) {
+            V3 dang = v3(0, 0, 0);
+            const S6 Jj = ld6(J + 6 * j);
+            const V3 dc = (1.0 / mtot) * lin(ld6(U + 6 * j));
+            for (int cc = 0; cc < nkk; ++cc) {
+              if (tp[3 + cc] == 0.0) continue;
+              const int fi = (int)tp[3 + nkk + cc], i = mframe[fi];
+              const V3 pf = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+              V3 dp_ = v3(0, 0, 0);
+              if (BELOW(j, i)) dp_ = lin(Jj) + cross(ang(Jj), pf);
+              dang = dang + cross(dp_ - dc, v3(u[6 * cc], u[6 * cc + 1], u[6 * cc + 2]));
+            }
+            Jt[3 * nz + j] = dang.x; Jt[4 * nz + j] = dang.y; Jt[5 * nz + j] = dang.z;
+          }
+          if (tid < nkk && tp[3 + tid] != 0.0) {
+            const int cc = tid, fi = (int)tp[3 + nkk + cc], i = mframe[fi];
+            const V3 rr = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i) - com;
+            const M3 Rx = skew_m(rr);
+            for (int e = 0; e < 3; ++e) {
+              Jt[e * nz + n + 6 * cc + e] = 1.0;
+              Jt[(3 + e) * nz + n + 6 * cc + 3 + e] = 1.0;
+              for (int e2 = 0; e2 < 3; ++e2) Jt[(3 + e) * nz + n + 6 * cc + e2] = Rx.m[3 * e + e2];
+            }
+          }
+        }
       } else if (tr.type == MPC_TERM_MB_WRENCH_CONE) {
         for (int i = tid; i < d; i += nthr) { double s = 0; for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * lam[6 * tr.i0 + j]; r[i] = s; }
         if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) {

@@ -9,7 +9,7 @@
 
 namespace orc {
 
-constexpr int MAXD = 112;  // >= 2*nv + nu for the complete Talos (76 + 32)
+constexpr int MAXD = 128;  // >= 2*nv + nu: complete Talos full dynamics 76 + 32, kinodynamics 76 + 44
 
 // number of active tangent directions of the running AD sweep (per thread)
 inline int& dual_nd() {

@@ -570,6 +570,7 @@ inline void eval_multibody(const Model& m, const StageDesc& sd, int nu, const do
     mb_integrate(m, x, dx.data(), kn.xnext.data());
     const State<double> sn = state_from_x(m, xnext);
     if (with_derivs) {
+      if (nz > MAXD) throw std::runtime_error("oracle: n + m exceeds the AD tangent capacity");
       dual_nd() = nz;
       State<Dual> sT = lift<Dual>(m, s0, 0);
       std::vector<Dual> vp(nv);
