@@ -165,6 +165,8 @@ static inline size_t multibody_work_doubles(const Layout& L) {
   return (size_t)(nv + 12) * L.nz + 2 * (size_t)24 * L.nz + 64;
 }
 
+#define EV_PROF(slot) do { if (!TRIAL && tid == 0 && a.prof && k == 1) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + 32 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
+
 struct MbArgs {
   MbLds lds;
   double* scratch;        // per-workgroup HBM scratch
@@ -195,8 +197,8 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
   double* kn = records + wg * KL.knot_stride;
   double* scr = mb.scratch + (TRIAL ? 0 : wg) * mb.scratch_stride;  // value-only passes never touch it
   double* dsol = scr;                         // [nK][nz]: rows < nv = da, rows >= nv = dlam
-  double* Jt = scr + (size_t)(nv + 12) * L.nz;  // [24][nz]
-  double* WJ = Jt + (size_t)24 * L.nz;
+  double* JtG = scr + (size_t)(nv + 12) * L.nz;  // [24][nz] HBM fallback for dense (non-diagonal) weights
+  double* WJ = JtG + (size_t)24 * L.nz;
 
   extern __shared__ __attribute__((aligned(16))) double sm[];
   unsigned long long* anc = (unsigned long long*)((char*)sm + S.anc_bytes_off);
@@ -212,6 +214,11 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
   double *x = sm + S.x, *u = sm + S.u, *xn = sm + S.xn, *cfr = sm + S.cfr, *small = sm + S.small, *red = sm + S.red;
   __shared__ int iflag[2];
   __shared__ double s_cost;
+  // Jacobian staging in LDS, carved from the region M..dr that is dead once the dynamics derivatives are in HBM:
+  // JS = stacked rows sqrt(W) J of the cost terms (<= 32 rows), JL = rows of the constraint term being emitted
+  double* JS = sm + S.M;
+  double* JL = JS + 32 * nz;
+  double* wrs = red + 256;  // sqrt(W) r of the stacked rows
 
   const int32_t* mi = a.model_i;
   const double* md = a.model_d;
@@ -226,6 +233,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
   const double prox_mu = md[3];
   const S6 a0 = kino ? mk6(v3(0, 0, 0), v3(0, 0, 0)) : mk6(v3(-grav[0], -grav[1], -grav[2]), v3(0, 0, 0));
 
+  long long t0_ = clock64();
   // ---- P0: evaluation point, tree tables ---------------------------------------------------------------
   {
     const double* xs = a.xs + ((size_t)b * (N + 1) + k) * nx;
@@ -306,6 +314,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
     st6(J + 6 * kd, col);
   }
   __syncthreads();
+  EV_PROF(0);
   // ---- P3: body velocities ------------------------------------------------------------------------------
   for (int idx = tid; idx < 6 * nj; idx += nthr) {
     const int i = idx / 6, e = idx % 6;
@@ -362,6 +371,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
   for (int kd = tid; kd < nv; kd += nthr) st6(U + 6 * kd, mat6_mul(Yc + 36 * dof_body[kd], ld6(J + 6 * kd)));
   __syncthreads();
 
+  EV_PROF(1);
   if (has_dyn) {
     const double dt = P[desc[4]];
     // ---- P6: joint-space inertia, bias torques, contact frames -------------------------------------------
@@ -402,9 +412,12 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
     }
     for (int idx = tid; idx < nv * nv; idx += nthr) Minv[idx] = (idx / nv == idx % nv) ? 1.0 : 0.0;
     __syncthreads();
+    EV_PROF(2);
     // ---- P7: KKT inverse by blocks:  Minv, X = Minv Jc^T, S = Jc X + mu I, Kinv ---------------------------
     if (!chol_block(M, nv, nv, tid, nthr, iflag)) { if (tid == 0) a.inst[b].done = 5; return; }
+    EV_PROF(3);
     potrs_block(M, nv, nv, Minv, nv, nv, tid, nthr);
+    EV_PROF(4);
     for (int idx = tid; idx < nv * nl; idx += nthr) {
       const int r = idx / nl, cc = idx % nl;
       double s = 0;
@@ -443,6 +456,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
     }
     for (int i = tid; i < nK; i += nthr) rhs[i] = (i < nv) ? (-bias[i] + (i >= nv - nu ? u[i - (nv - nu)] : 0.0)) : -gam[i - nv];
     __syncthreads();
+    EV_PROF(5);
     // ---- P8: solve, then accelerations / forces at the solution -------------------------------------------
     for (int i = tid; i < nK; i += nthr) {
       double s = 0;
@@ -488,6 +502,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
     (void)dt;
   }
 
+  EV_PROF(6);
   // ---- kinodynamics (kinodynamic_talos.py:107-112): a_joint = u[12:], base acceleration from the momentum balance
   // about the world origin  sum_k U_k a_k + hdot(a = 0) = [sum f + m g ; sum p_i x f_i + tau_i + c x m g],
   // projected on the base columns: (J_b^T U_b) a_b = J_b^T (...)  with J_b^T U_b = M_bb symmetric positive definite.
@@ -636,6 +651,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
       }
       __syncthreads();
     }
+    EV_PROF(7);
     // ---- P10: rows of [d r1 ; d r2] w.r.t. (q, v)  (dr is nK x 2nv; Minv is dead from here on) -------------
     const int n2 = 2 * nv;
     if (has_dyn) {
@@ -679,6 +695,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
       for (int r = 0; r < 6; ++r) { dr[(nv + 6 * cc + r) * n2 + j] = rq.v[r]; dr[(nv + 6 * cc + r) * n2 + nv + j] = rv.v[r]; }
     }
     __syncthreads();
+    EV_PROF(8);
     // ---- P11: implicit differentiation  d[a; -lam]/d(q,v) = -Kinv dr ;  d/du from the actuated columns -----
     for (int idx = tid; idx < nK * nz; idx += nthr) {
       const int r = idx / nz, z = idx % nz;
@@ -691,6 +708,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
     }  // has_dyn
   }
 
+  EV_PROF(9);
   // ---- P12: semi-implicit Euler, gap and its Jacobians ----------------------------------------------------
   if (has_dyn || kino) {
     const double dt = P[desc[4]];
@@ -750,33 +768,56 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
         const int r = idx / nz, z = idx % nz;
         double s = (z < 6) ? Jq6[6 * r + z] : 0.0;
         for (int l = 0; l < 6; ++l) s += dt * Je6[6 * r + l] * kn[KL.oAB + (size_t)(nv + l) * KL.nz + z];
-        Jt[idx] = s;  // temporary (6 x nz)
+        JL[idx] = s;  // temporary (6 x nz)
       }
       __syncthreads();
       for (int idx = tid; idx < 6 * nz; idx += nthr) {
         const int r = idx / nz, z = idx % nz;
         double s = 0;
-        for (int l = 0; l < 6; ++l) s += Jl6[6 * r + l] * Jt[l * nz + z];
+        for (int l = 0; l < 6; ++l) s += Jl6[6 * r + l] * JL[l * nz + z];
         kn[KL.oAB + (size_t)r * KL.nz + z] = s;
       }
       __syncthreads();
     }
   }
 
+  EV_PROF(10);
   // ---- P13: cost stack and constraints -----------------------------------------------------------------------
   // centre of mass and total momentum (body 0 is the root: its composite = whole robot)
   const S6 h0 = ld6(Hc);
-  int row = 0;
+  int row = 0, rowc = 0;
+  // H += JS^T JS (upper triangle, mirrored), grad += JS^T wrs for the rows stacked so far
+  auto flush_stack = [&]() {
+    __syncthreads();
+    for (int z = tid; z < nz; z += nthr) {
+      double g = 0;
+      for (int i = 0; i < rowc; ++i) g += JS[i * nz + z] * wrs[i];
+      kn[KL.oG + z] += g;
+    }
+    const int lane_ = tid & 63, wv_ = tid >> 6, nw_ = nthr >> 6;
+    for (int za = wv_; za < nz; za += nw_)
+      for (int zb = za + lane_; zb < nz; zb += 64) {
+        double h = 0;
+        for (int i = 0; i < rowc; ++i) h += JS[i * nz + za] * JS[i * nz + zb];
+        kn[KL.oH + (size_t)za * KL.nz + zb] += h;
+        if (zb != za) kn[KL.oH + (size_t)zb * KL.nz + za] += h;
+      }
+    __syncthreads();
+    rowc = 0;
+  };
   for (int t = 0; t < nterms; ++t) {
     const TermRec tr = load_term(desc, t);
     const double* tp = P + tr.poff;
     const int d = tr.dim;
     double* r = red + 2 * 256 - 64;  // 64 doubles of residual scratch at the tail of `red` (dim <= 56 only for state error, handled separately)
     bool generic = true;
+    const bool is_cost = tr.role == MPC_ROLE_COST;
+    if (derivs && is_cost && rowc + d > 32 && d <= 24) flush_stack();
+    double* Jt = (is_cost && d <= 24) ? JS + rowc * nz : JL;  // staging rows of this term (LDS)
     if (tr.type == MPC_TERM_STATE_ERROR) {
       // r = x_ref (-) x ; J = -I except the base block -Jlog6(Mref^-1 M)
       double* Jb = small + 108;  // 36
-      double* rfull = dr;        // reuse (n doubles) — dr is dead after P11
+      double* rfull = Tq;        // n doubles of scratch — the derivative vectors are dead by now
       if (tid == 0) {
         const M3 Rr = quat_to_rot(tp + 3), Rb = quat_to_rot(q + 3);
         const V3 pr = v3(tp[0], tp[1], tp[2]), pb = v3(q[0], q[1], q[2]);
@@ -975,14 +1016,37 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
       __syncthreads();
     }
     if (generic) {
-      if (tr.role == MPC_ROLE_COST) accumulate_cost(KL, kn, tr, P + tr.woff, r, Jt, nz, nz, red, WJ, derivs, s_cost, tid, nthr);
-      else { emit_constraint(KL, kn, tr, P, row, r, Jt, nz, nz, derivs, tid, nthr); }
+      if (is_cost) {
+        const double* W = P + tr.woff;
+        bool wdiag = (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) != 0;
+        if (!wdiag) { wdiag = true; for (int e = 0; e < d * d; ++e) if ((e / d != e % d) && W[e] != 0.0) wdiag = false; }
+        if (wdiag && d <= 24) {
+          // 1/2 r^T W r with W = diag(w): stack sqrt(w_i) J_i and sqrt(w_i) r_i  (H += JS^T JS, grad += JS^T wrs)
+          const int wstride = (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) ? 1 : d + 1;
+          if (tid == 0) { double cst = 0; for (int i = 0; i < d; ++i) cst += W[i * wstride] * r[i] * r[i]; s_cost += 0.5 * cst; }
+          if (derivs) {
+            for (int i = tid; i < d; i += nthr) wrs[rowc + i] = sqrt(W[i * wstride]) * r[i];
+            for (int idx = tid; idx < d * nz; idx += nthr) Jt[idx] *= sqrt(W[(idx / nz) * wstride]);
+            rowc += d;
+          }
+          __syncthreads();
+        } else {
+          // dense weight: unfused path through the HBM scratch
+          if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) JtG[idx] = Jt[idx];
+          __syncthreads();
+          accumulate_cost(KL, kn, tr, W, r, JtG, nz, nz, red, WJ, derivs, s_cost, tid, nthr);
+        }
+      } else {
+        emit_constraint(KL, kn, tr, P, row, r, Jt, nz, nz, derivs, tid, nthr);
+      }
     }
     if (tr.role != MPC_ROLE_COST) row += d;
   }
+  if (derivs && rowc > 0) flush_stack();
   if (derivs) for (int z = tid; z < nz; z += nthr) kn[KL.oH + (size_t)z * KL.nz + z] += a.opt.reg_init;
   __syncthreads();
 
+  EV_PROF(11);
   // ---- P14: projections, AL penalty, infeasibility ------------------------------------------------------------
   const double mu = st.mu, mud = mu * a.opt.dyn_al_scale;
   const size_t vo = ((size_t)b * (N + 1) + k) * L.c, lo = ((size_t)b * (N + 1) + k + 1) * n;
@@ -996,6 +1060,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
       ms[MISC_COST] = s_cost; ms[MISC_PEN] = pen; ms[MISC_PRIM] = prim; ms[MISC_NC] = (double)c; ms[MISC_M] = (double)m;
     }
   }
+  EV_PROF(12);
 #undef BELOW
 #undef INSUB
 }

@@ -133,7 +133,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->d_trial_phi = s->alloc<double>(B * L.n_alpha * N1);
   s->d_inst = s->alloc<InstState>(B);
   s->d_all_done = s->alloc<int>(4);
-  s->d_prof = s->alloc<double>(B * 32);
+  s->d_prof = s->alloc<double>(B * 64);
   s->h_desc.assign(N1 * L.max_stage_ints, 0);
   // default options
   mpc_options& o = s->opt;
@@ -197,7 +197,7 @@ static void launch_pass(mpc_solver* s) {
     if (s->use_mfma_riccati) hipLaunchKernelGGL(k_riccati_mfma, dim3(L.B), dim3(256), s->ric.total_bytes, s->stream, a, s->ric);
     else hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);
   });
-  s->timed(4, "k_forward", [&] { hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(256), (L.nz + 2 * L.n) * sizeof(double), s->stream, a); });
+  s->timed(4, "k_forward", [&] { hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(1024), (L.nz + 2 * L.n) * sizeof(double), s->stream, a); });
   s->timed(5, "k_duals", [&] { hipLaunchKernelGGL(k_duals, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   // linesearch: evaluate the full step first; the backtracking candidates alpha = 2^-i, i >= 1, are only
   // evaluated for instances whose full step failed the Armijo test (their workgroups exit immediately otherwise)
@@ -489,7 +489,7 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
     else if (nm == "knu") mat(g.data() + L.oknu, 1, c, c);
     else if (nm == "Mx") mat(g.data() + L.oMx, k < L.N ? n : 0, n, n);
     else if (nm == "mx") mat(g.data() + L.omx, 1, k < L.N ? n : 0, n);
-    else if (nm == "ric_prof") { dev_vec(s->d_prof + (size_t)b * 32, 32); HIP_OK(hipMemset(s->d_prof + (size_t)b * 32, 0, 32 * sizeof(double))); }
+    else if (nm == "ric_prof") { dev_vec(s->d_prof + (size_t)b * 64, 64); HIP_OK(hipMemset(s->d_prof + (size_t)b * 64, 0, 64 * sizeof(double))); }
     else if (nm == "dx") dev_vec(s->d_dxs + ((size_t)b * (L.N + 1) + k) * n, n);
     else if (nm == "du") { if (k >= L.N) throw std::runtime_error("no du at the terminal knot"); dev_vec(s->d_dus + ((size_t)b * L.N + k) * L.m, L.m); }
     else if (nm == "dvs") dev_vec(s->d_dvs + ((size_t)b * (L.N + 1) + k) * L.c, L.c);

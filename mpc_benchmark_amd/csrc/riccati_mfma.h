@@ -20,7 +20,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 #define AB_ROWS 24  // register prefetch capacity: np <= 4 * AB_ROWS rows, nzp <= 128 columns
 
 // phase timing (shader clock) accumulated over the knots; read back with mpc_debug_get("ric_prof")
-#define RIC_PROF(slot) do { if (tid == 0 && a.prof) { const long long t1_ = clock64(); a.prof[(size_t)b * 32 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
+#define RIC_PROF(slot) do { if (tid == 0 && a.prof) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 struct RicLds {
   int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks

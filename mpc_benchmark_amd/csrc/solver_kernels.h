@@ -26,7 +26,7 @@ struct SolverArgs {
   double *trial_phi;  // [B][n_alpha][N+1]
   InstState* inst;
   int* all_done;
-  double* prof;  // [B][32] phase cycle counters of the Riccati kernel (debug)
+  double* prof;  // [B][64] phase cycle counters: 0..31 Riccati kernel, 32..63 whole-body stage kernel (knot 1)
 };
 
 DEV double* knot_ptr(const SolverArgs& a, int b, int k) { return a.knots + ((size_t)b * (a.L.N + 1) + k) * a.L.knot_stride; }
@@ -346,7 +346,8 @@ DEV double wave_sum(double v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return __shfl(v, 0, 64);
 }
-__global__ void __launch_bounds__(256) k_forward(SolverArgs a) {
+// 16 wavefronts per instance: the sweep is a chain of latency-bound mat-vecs, more waves = more HBM loads in flight
+__global__ void __launch_bounds__(1024) k_forward(SolverArgs a) {
   const Layout& L = a.L;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
   const InstState& st = a.inst[b];

@@ -13,6 +13,10 @@ ens.native.debug_get('ric_prof', 0)
 for _ in range(3): ens.step()
 p = ens.native.debug_get('ric_prof', 0)
 names = ['T6inv+actscan','T6 transform','LP build+vv','chol n','LI inv','trsm','sym,w,store Pt','AB load+gh','panels','KKT prep','chol m','KKT solve','value+store']
-tot = p.sum()
+tot = p[:32].sum()
 for n_, v in zip(names, p): print('%-18s %8.1f us/knot  %5.1f%%' % (n_, v/300/2400.0*1.0, 100*v/tot))
-print('total us/knot', tot/300/2400)
+print('total us/knot', p[:32].sum()/300/2400)
+ev = p[32:45]
+enames = ['load,FK,J','vel,inertia,composites,U','M,bias,contacts,Jc','chol M','Minv (potrs)','X,S,Kinv','solve,forces','deriv blocks','dr rows','dsol gemm','integrator,AB','terms','merit']
+for n_, v in zip(enames, ev): print('EVAL %-26s %8.1f us  %5.1f%%' % (n_, v/3/2400.0, 100*v/ev.sum()))
+print('EVAL total us per workgroup', ev.sum()/3/2400)
