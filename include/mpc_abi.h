@@ -172,6 +172,11 @@ int mpc_run(mpc_solver* s, const double* xs_init, const double* us_init, mpc_sta
 /* Re-run from the solver's own shifted solution: xs <- [xs[1:], xs[-1]], us likewise, xs[0] <- x0
  * (the warm-start shift of fulldynamic_talos.py:532-534 done on the device). */
 int mpc_run_shifted(mpc_solver* s, mpc_stats* stats);
+/* Asynchronous form for pipelining several handles (ensemble shards) on one device: enqueues the shift and the
+ * solver passes on the handle's stream and returns without waiting; mpc_wait blocks until the solve has finished
+ * (running further passes if an instance needed them) and fills stats[B] (may be NULL). */
+int mpc_run_shifted_async(mpc_solver* s);
+int mpc_wait(mpc_solver* s, mpc_stats* stats);
 
 /* results.xs / results.us / controlFeedbacks() / feed-forwards / multipliers. Any pointer may be NULL.
  * xs[B][N+1][nx] us[B][N][nu] K[B][N][nu][ndx] kff[B][N][nu] vs[B][N+1][nc_max] lams[B][N+1][ndx] */

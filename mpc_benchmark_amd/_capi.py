@@ -82,6 +82,8 @@ _SIGNATURES = {
     "mpc_setup": (C.c_int, [C.c_void_p]),
     "mpc_run": (C.c_int, [C.c_void_p, _DP, _DP, C.POINTER(MpcStats)]),
     "mpc_run_shifted": (C.c_int, [C.c_void_p, C.POINTER(MpcStats)]),
+    "mpc_run_shifted_async": (C.c_int, [C.c_void_p]),
+    "mpc_wait": (C.c_int, [C.c_void_p, C.POINTER(MpcStats)]),
     "mpc_get_results": (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP, _DP, _DP]),
     "mpc_get_stage_data": (C.c_int, [C.c_void_p, C.c_int32, _DP, _DP]),
     "mpc_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, _DP, C.c_int32]),
@@ -209,6 +211,14 @@ class NativeSolver:
     def run_shifted(self):
         stats = (MpcStats * self.dims.batch)()
         self._check(self.lib.mpc_run_shifted(self._h, stats), "mpc_run_shifted")
+        return list(stats)
+
+    def run_shifted_async(self):
+        self._check(self.lib.mpc_run_shifted_async(self._h), "mpc_run_shifted_async")
+
+    def wait(self):
+        stats = (MpcStats * self.dims.batch)()
+        self._check(self.lib.mpc_wait(self._h, stats), "mpc_wait")
         return list(stats)
 
     def get_results(self, gains=True, multipliers=False):

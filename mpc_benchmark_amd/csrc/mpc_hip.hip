@@ -45,6 +45,7 @@ struct mpc_solver {
   bool have_model = false;
   size_t mb_work_stride = 0;
   bool perfect_feedback = false;
+  int async_passes = 0;
   RicLds ric{};
   bool use_mfma_riccati = false;
   // per-kernel timing (mpc_profile): event pairs recorded around every launch while enabled
@@ -194,7 +195,7 @@ static void launch_pass(mpc_solver* s) {
   s->timed(1, "k_lagrangian", [&] { hipLaunchKernelGGL(k_lagrangian, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   s->timed(2, "k_decide", [&] { hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(1), 0, s->stream, a); });
   s->timed(3, "k_riccati_backward", [&] {
-    if (s->use_mfma_riccati) hipLaunchKernelGGL(k_riccati_mfma, dim3(L.B), dim3(256), s->ric.total_bytes, s->stream, a, s->ric);
+    if (s->use_mfma_riccati) hipLaunchKernelGGL(k_riccati_mfma, dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
     else hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);
   });
   s->timed(4, "k_forward", [&] { hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(1024), (L.nz + 2 * L.n) * sizeof(double), s->stream, a); });
@@ -210,13 +211,16 @@ static void launch_pass(mpc_solver* s) {
   HIP_OK(hipGetLastError());
 }
 
-static void run_impl(mpc_solver* s, mpc_stats* stats) {
+// passes_enqueued: passes already put on the stream by the asynchronous entry point (their completion flag is
+// checked first); the loop then continues synchronously until every instance is done.
+static void run_impl(mpc_solver* s, mpc_stats* stats, int passes_enqueued = 0) {
   const Layout& L = s->L;
   SolverArgs a = s->args();
-  hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, a);
+  if (passes_enqueued == 0) hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, a);
   const int max_passes = s->opt.max_iters + s->opt.max_al_iters + 1;
   for (int pass = 0; pass < max_passes; ++pass) {
-    launch_pass(s);
+    if (pass >= passes_enqueued) launch_pass(s);
+    else if (pass + 1 < passes_enqueued) continue;  // only the flag of the last enqueued pass is meaningful
     int done = 0;
     HIP_OK(hipMemcpyAsync(&done, s->d_all_done, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     HIP_OK(hipStreamSynchronize(s->stream));
@@ -402,6 +406,28 @@ int mpc_run_shifted(mpc_solver* s, mpc_stats* stats) {
   MPC_TRY(s, {
     hipLaunchKernelGGL(k_shift, dim3(s->L.B), dim3(64), 0, s->stream, s->args(), s->perfect_feedback ? 1 : 0);
     run_impl(s, stats);
+  })
+}
+
+int mpc_run_shifted_async(mpc_solver* s) {
+  MPC_TRY(s, {
+    const Layout& L = s->L;
+    hipLaunchKernelGGL(k_shift, dim3(L.B), dim3(64), 0, s->stream, s->args(), s->perfect_feedback ? 1 : 0);
+    hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, s->args());
+    // with max_iters = 1 one pass takes the step; the second one only acts for an instance whose first pass was a
+    // BCL update without a step (its workgroups exit immediately otherwise)
+    launch_pass(s);
+    launch_pass(s);
+    s->async_passes = 2;
+  })
+}
+
+int mpc_wait(mpc_solver* s, mpc_stats* stats) {
+  MPC_TRY(s, {
+    const int enq = s->async_passes;
+    s->async_passes = 0;
+    if (enq > 0) run_impl(s, stats, enq);
+    else HIP_OK(hipStreamSynchronize(s->stream));
   })
 }
 

@@ -17,7 +17,10 @@
 #include "solver_kernels.h"
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
-#define AB_ROWS 24  // register prefetch capacity: np <= 4 * AB_ROWS rows, nzp <= 128 columns
+#ifndef RIC_THREADS
+#define RIC_THREADS 512  // 8 wavefronts (2 per SIMD): the sweep is latency-bound, a second wave per SIMD hides LDS / MFMA latency
+#endif
+#define AB_ROWS (96 * 64 / RIC_THREADS)  // register prefetch capacity: np <= 96 rows, nzp <= 128 columns
 
 // phase timing (shader clock) accumulated over the knots; read back with mpc_debug_get("ric_prof")
 #define RIC_PROF(slot) do { if (tid == 0 && a.prof) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
@@ -169,7 +172,7 @@ DEV bool chol16_wave(double* D, int ld, double* LIb, int lane) {
 // Blocked Cholesky of the (16 nb) x (16 nb) matrix A in LDS (lower triangle; pad rows/cols must be identity).
 // L overwrites the lower block triangle, LI[bi] (272 doubles each, ld 17) receives the inverse of diagonal block bi.
 DEV bool chol_blocked(double* A, int ld, int nb, double* LI, int tid, int* flag) {
-  const int lane = tid & 63, wv = tid >> 6, nw = 4;
+  const int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
   if (tid == 0) *flag = 1;
   __syncthreads();
   for (int kb = 0; kb < nb; ++kb) {
@@ -263,7 +266,7 @@ DEV double wave_sum_r(double v) {
 
 // ============================================================================================================
 // one wavefront per SIMD (LDS-bound occupancy anyway): let the register allocator use the whole 512-entry file
-__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) k_riccati_mfma(SolverArgs a, RicLds S) {
+__global__ void __launch_bounds__(RIC_THREADS) k_riccati_mfma(SolverArgs a, RicLds S) {
   const Layout& L = a.L;
   const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nthr >> 6;
   const InstState& st = a.inst[b];

@@ -101,6 +101,17 @@ class EnsembleMPC:
         self.tick += 1
         return stats
 
+    def step_async(self):
+        """Enqueue one tick without waiting (several shards on different streams overlap on the device)."""
+        desc, params = self._table_for_tick(self.tick % self.pd.t_mpc)
+        self.native.cycle(desc, params)
+        self.native.setup()
+        self.native.run_shifted_async()
+        self.tick += 1
+
+    def wait(self):
+        return self.native.wait()
+
     def results(self, **kw):
         return self.native.get_results(**kw)
 

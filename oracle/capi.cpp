@@ -126,6 +126,11 @@ int mpc_run_shifted(mpc_solver* h, mpc_stats* stats) {
   })
 }
 
+int mpc_run_shifted_async(mpc_solver* h) { return mpc_run_shifted(h, nullptr); }
+int mpc_wait(mpc_solver* h, mpc_stats* stats) {
+  MPC_TRY(h, { if (stats) for (int b = 0; b < h->s.dims.batch; ++b) stats[b] = h->s.inst[b].stats; })
+}
+
 int mpc_get_results(mpc_solver* h, double* xs, double* us, double* K, double* kff, double* vs, double* lams) {
   MPC_TRY(h, {
     Solver& s = h->s;
