@@ -71,6 +71,9 @@ def main():
         cold = cold or c
 
     def step_all():
+        if nshard == 1:
+            shards[0].step()  # synchronous form: exactly one solver pass per tick
+            return
         for e in shards:
             e.step_async()
         for e in shards:
@@ -137,8 +140,19 @@ def main():
         bytes_per_launch = per_kernel.get(name, 8.0 * (W + G)) * args.batch / nshard  # one launch serves one shard
         avg_s = total_ms / launches * 1e-3
         achieved = bytes_per_launch / avg_s / 1e9
+        # HBM bytes per launch from the PMC passes of tools/gpu_profile_round.sh (FETCH_SIZE / WRITE_SIZE in separate
+        # rocprofv3 runs, calibrated on a streaming copy) — counters cannot be collected from inside this process
+        traffic = None
+        rocprof_name = {"k_riccati_backward": "k_riccati_mfma", "k_eval_stage": "void k_eval_multibody<0>",
+                        "k_eval_stage_trial": "void k_eval_multibody<1>"}.get(name, name)
+        tf = os.path.join(ROOT, "profiles", "traffic_b%d_n%d_%s.json" % (args.batch // nshard, args.horizon, args.model))
+        if os.path.exists(tf):
+            with open(tf) as fh:
+                ent = json.load(fh).get("kernels", {}).get(rocprof_name, {})
+            if "hbm_bytes" in ent:
+                traffic = int(ent["hbm_bytes"])
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_kernel_ms": round(total_ms / launches, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "kernel_ms_per_step_summed_over_shards": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
 

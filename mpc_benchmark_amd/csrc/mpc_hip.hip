@@ -193,7 +193,7 @@ static void launch_pass(mpc_solver* s) {
   HIP_OK(hipMemsetAsync(s->d_all_done, 0xff, sizeof(int), s->stream));  // all_done = -1 (true) unless cleared
   s->timed(0, "k_eval_stage", [&] { launch_eval(s, false); });
   s->timed(1, "k_lagrangian", [&] { hipLaunchKernelGGL(k_lagrangian, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
-  s->timed(2, "k_decide", [&] { hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(1), 0, s->stream, a); });
+  s->timed(2, "k_decide", [&] { hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(128), 0, s->stream, a); });
   s->timed(3, "k_riccati_backward", [&] {
     if (s->use_mfma_riccati) hipLaunchKernelGGL(k_riccati_mfma, dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
     else hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);

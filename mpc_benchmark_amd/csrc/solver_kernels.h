@@ -82,42 +82,64 @@ __global__ void k_lagrangian(SolverArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // P4 (cont.): per-instance reductions in fixed order + the BCL bookkeeping of SolverProxDDP::run.
-// grid B, block 1
+// grid B, block 128: the knot partials are gathered in parallel, summed in knot order by one thread
+// (deterministic), and the multiplier-estimate refresh of an accepted BCL step is a block-wide copy.
 // ------------------------------------------------------------------------------------------------
-__global__ void k_decide(SolverArgs a) {
+__global__ void __launch_bounds__(128) k_decide(SolverArgs a) {
   const Layout& L = a.L;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
   InstState& st = a.inst[b];
   if (st.done) return;
   const mpc_options& o = a.opt;
+  __shared__ double part[5][128];
+  __shared__ int refresh;
   double cost = 0, pen = 0, prim = 0, dual = 0, crit = 0;
-  for (int k = 0; k <= L.N; ++k) {
-    const double* ms = knot_ptr(a, b, k) + L.oMISC;
-    cost += ms[MISC_COST]; pen += ms[MISC_PEN];
-    prim = fmax(prim, ms[MISC_PRIM]); dual = fmax(dual, ms[MISC_DUAL]); crit = fmax(crit, ms[MISC_CRIT]);
-  }
-  crit = fmax(crit, dual);
-  st.cost = cost; st.phi0 = cost + pen; st.prim = prim; st.dual = dual; st.crit = crit;
-  st.skip_step = 0;
-  if (crit <= st.inner_tol) {
-    // inner problem solved: outer (BCL) update, no step this pass
-    st.skip_step = 1;
-    const size_t nv = (size_t)(L.N + 1) * L.c, nl = (size_t)(L.N + 1) * L.n;
-    if (prim <= st.prim_tol) {
-      st.prim_tol *= pow(st.mu, o.bcl_prim_beta);
-      st.inner_tol *= pow(st.mu, o.bcl_dual_beta);
-      for (size_t i = 0; i < nv; ++i) a.vs_e[b * nv + i] = a.vs[b * nv + i];
-      for (size_t i = 0; i < nl; ++i) a.lams_e[b * nl + i] = a.lams[b * nl + i];
-      if (fmax(prim, dual) <= o.tol) { st.converged = 1; st.done = 1; }
-    } else {
-      st.mu = fmax(st.mu * o.bcl_mu_update_factor, o.bcl_mu_lower_bound);
-      st.prim_tol = o.prim_tol0 * pow(st.mu, o.bcl_prim_alpha);
-      st.inner_tol = o.inner_tol0 * pow(st.mu, o.bcl_dual_alpha);
+  for (int k0 = 0; k0 <= L.N; k0 += nthr) {  // chunks of nthr knots, each summed in knot order
+    const int k = k0 + tid;
+    if (k <= L.N) {
+      const double* ms = knot_ptr(a, b, k) + L.oMISC;
+      part[0][tid] = ms[MISC_COST]; part[1][tid] = ms[MISC_PEN]; part[2][tid] = ms[MISC_PRIM];
+      part[3][tid] = ms[MISC_DUAL]; part[4][tid] = ms[MISC_CRIT];
     }
-    st.inner_tol = fmax(st.inner_tol, o.tol);
-    st.prim_tol = fmax(st.prim_tol, o.tol);
-    st.al_iters += 1;
-    if (st.al_iters >= o.max_al_iters) st.done = 1;
+    __syncthreads();
+    if (tid == 0) {
+      const int cnt = min(nthr, L.N + 1 - k0);
+      for (int i = 0; i < cnt; ++i) {
+        cost += part[0][i]; pen += part[1][i];
+        prim = fmax(prim, part[2][i]); dual = fmax(dual, part[3][i]); crit = fmax(crit, part[4][i]);
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    refresh = 0;
+    crit = fmax(crit, dual);
+    st.cost = cost; st.phi0 = cost + pen; st.prim = prim; st.dual = dual; st.crit = crit;
+    st.skip_step = 0;
+    if (crit <= st.inner_tol) {
+      // inner problem solved: outer (BCL) update, no step this pass
+      st.skip_step = 1;
+      if (prim <= st.prim_tol) {
+        st.prim_tol *= pow(st.mu, o.bcl_prim_beta);
+        st.inner_tol *= pow(st.mu, o.bcl_dual_beta);
+        refresh = 1;
+        if (fmax(prim, dual) <= o.tol) { st.converged = 1; st.done = 1; }
+      } else {
+        st.mu = fmax(st.mu * o.bcl_mu_update_factor, o.bcl_mu_lower_bound);
+        st.prim_tol = o.prim_tol0 * pow(st.mu, o.bcl_prim_alpha);
+        st.inner_tol = o.inner_tol0 * pow(st.mu, o.bcl_dual_alpha);
+      }
+      st.inner_tol = fmax(st.inner_tol, o.tol);
+      st.prim_tol = fmax(st.prim_tol, o.tol);
+      st.al_iters += 1;
+      if (st.al_iters >= o.max_al_iters) st.done = 1;
+    }
+  }
+  __syncthreads();
+  if (refresh) {
+    const size_t nv = (size_t)(L.N + 1) * L.c, nl = (size_t)(L.N + 1) * L.n;
+    for (size_t i = tid; i < nv; i += nthr) a.vs_e[b * nv + i] = a.vs[b * nv + i];
+    for (size_t i = tid; i < nl; i += nthr) a.lams_e[b * nl + i] = a.lams[b * nl + i];
   }
 }
 
