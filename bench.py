@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="the ensemble of one GPU is split into this many shards, each on its own handle/stream, so that the "
                          "sequential Riccati sweeps of one shard overlap the per-knot kernels of the others")
+    ap.add_argument("--lib", default=None, help="developer option: another build of the same HIP library (kernel tuning variants)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
@@ -58,7 +59,10 @@ def main():
     from mpc_benchmark_amd.ensemble import EnsembleMPC, gain_doubles, lq_knot_doubles
     from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
 
-    lib = _capi.load_hip_library()  # raises if the HIP library is missing: no CPU fallback
+    # raises if the HIP library is missing: no CPU fallback
+    lib = _capi.bind_library(args.lib) if args.lib else _capi.load_hip_library()
+    if lib.mpc_backend_name().decode() != "hip-gfx950":
+        raise RuntimeError("bench.py measures the HIP library only")
     pd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
     nshard = max(1, min(args.streams, args.batch))
     sizes = [args.batch // nshard + (1 if i < args.batch % nshard else 0) for i in range(nshard)]

@@ -11,6 +11,11 @@
 #pragma once
 #include <stdexcept>
 #include "eval_common.h"
+#include "mfma_blocks.h"
+
+#ifndef EVAL_THREADS
+#define EVAL_THREADS 256  // threads per stage workgroup
+#endif
 
 // ---- 6-vectors --------------------------------------------------------------------------------------------
 struct S6 { double v[6]; };
@@ -115,32 +120,50 @@ DEV void inv6_unrolled_mb(const double* A, double* Ainv) {
 
 // ---- LDS carve-out ------------------------------------------------------------------------------------------
 struct MbLds {
-  int nj, nv, nq, nl_max, nK_max;
+  int nj, nv, nq, nl_max;
+  int nvp, ldm, nbm, ldR, ncb;  // padded nv, leading dim / block count of the mass matrix, leading dim / column blocks of R
   // body arrays
   int oR, op, ov, oa, oh, of, Fc, Hc, oY, Yc, Bc;
   // dof arrays
   int J, U, Psd, Psdd, Phi, Bt, Tq, Tv, vlam;
   // matrices / vectors
-  int M, Kinv, X, S, Jc, dr, gam, bias, rhs, a, lam, x, u, xn, cfr, small, red, total;
+  int M, LIm, Y16, V16, Sp, LIs, R, Jc, gam, bias, a, lam, x, u, xn, cfr, small, red, total;
+  int stage_rows;  // rows of Jacobian staging (ld nz) that fit in the R region
   int anc_bytes_off, total_bytes;
 };
 
-static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu) {
+// The contact KKT system [[M, Jc^T], [Jc, -mu I]] is never inverted: M = L L^T (blocked Cholesky on the matrix
+// cores), Y = L^-1 Jc^T, S = Y^T Y + mu I = Ls Ls^T, and every right-hand side — the dynamics residual and the
+// nz columns of its derivatives, stacked in R = [R1 (nvp rows) ; R2 (16 rows)] — goes through
+//   W = L^-1 R1 ; Z2 = S^-1 (Y^T W - R2) ; Z1 = L^-T (W - Y Z2)
+// one 16-column block per wavefront.  R aliases the body-level inertia / Coriolis blocks (oY, Bc), dead by then,
+// and later hosts the Jacobian rows of the cost / constraint terms.
+static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz) {
   MbLds s;
-  s.nj = nj; s.nv = nv; s.nq = nq; s.nl_max = 12; s.nK_max = nv + 12;
+  s.nj = nj; s.nv = nv; s.nq = nq; s.nl_max = 12;
+  s.nvp = (nv + 15) & ~15; s.ldm = s.nvp + 1; s.nbm = s.nvp / 16;
+  s.ncb = (nz + 15) / 16; s.ldR = 16 * s.ncb + 1;
   int o = 0;
   auto take = [&](int c) { int r = o; o += (c + 1) & ~1; return r; };
   s.oR = take(9 * nj); s.op = take(3 * nj); s.ov = take(6 * nj); s.oa = take(6 * nj); s.oh = take(6 * nj); s.of = take(6 * nj);
-  s.Fc = take(6 * nj); s.Hc = take(6 * nj); s.oY = take(36 * nj); s.Yc = take(36 * nj); s.Bc = take(36 * nj);
+  s.Fc = take(6 * nj); s.Hc = take(6 * nj); s.Yc = take(36 * nj);
   s.J = take(6 * nv); s.U = take(6 * nv); s.Psd = take(6 * nv); s.Psdd = take(6 * nv); s.Phi = take(6 * nv);
   s.Bt = take(6 * nv); s.Tq = take(6 * nv); s.Tv = take(6 * nv); s.vlam = take(12 * nv);
-  s.M = take(nv * nv); s.Kinv = take(s.nK_max * s.nK_max); s.X = take(nv * 12); s.S = take(2 * 144); s.Jc = take(12 * nv);
-  s.dr = take(s.nK_max * 2 * nv);  // also hosts Minv (nv*nv) before the derivative rows are built
-  s.gam = take(12); s.bias = take(nv); s.rhs = take(s.nK_max); s.a = take(nv); s.lam = take(12);
+  s.M = take(s.nvp * s.ldm); s.LIm = take(s.nbm * 272); s.Y16 = take(s.nvp * 16); s.Sp = take(272); s.LIs = take(272); s.Jc = take(12 * nv);
+  s.gam = take(16); s.bias = take(nv); s.a = take(s.nvp); s.lam = take(16);
   s.x = take(nq + nv); s.u = take(nu > 0 ? nu : 1); s.xn = take(nq + nv);
   s.cfr = take(2 * (12 + 36 + 6));  // per contact: R(9) p(3), Jlog6(c2Mc1) (36), spare(6)
   s.small = take(6 * 36 + 64);      // integrator 6x6 blocks and scratch
-  s.red = take(2 * 256 + 8);
+  s.red = take(2 * EVAL_THREADS + 8);
+  // R region: oY | Bc | rest
+  s.oY = take(36 * nj); s.Bc = take(36 * nj);
+  s.R = s.oY;
+  int rsize = (s.nvp + 16) * s.ldR + 8;
+  if (rsize < 56 * nz + 8) rsize = 56 * nz + 8;  // 32 stacked cost rows + 24 rows of the constraint being emitted
+  if (s.R + rsize > o) o = (s.R + rsize + 1) & ~1;
+  if (o < s.Bc + 36 * nj + s.nvp * 16 + 4) o = (s.Bc + 36 * nj + s.nvp * 16 + 4 + 1) & ~1;  // V16 must not overlap oY / Bc
+  s.V16 = o - s.nvp * 16 - 2;  // tail of the R region: alive only between the two solves, while oY / Bc are in use
+  s.stage_rows = (o - s.R) / nz;
   s.total = o;
   s.anc_bytes_off = o * 8;
   s.total_bytes = o * 8 + nj * 8 + nv * 4 + nj * 4 * 3 + 64;
@@ -175,7 +198,7 @@ struct MbArgs {
 
 // ============================================================================================================
 template <int TRIAL>
-__global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL, double* records, MbArgs mb, int cand0) {
+__global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, Layout KL, double* records, MbArgs mb, int cand0) {
   const Layout& L = a.L;
   const MbLds& S = mb.lds;
   const int k = blockIdx.x, b = blockIdx.y, cand = blockIdx.z + cand0, tid = threadIdx.x, nthr = blockDim.x;
@@ -209,14 +232,16 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
   double *oR = sm + S.oR, *op = sm + S.op, *ov = sm + S.ov, *oa = sm + S.oa, *oh = sm + S.oh, *of = sm + S.of, *Fc = sm + S.Fc, *Hc = sm + S.Hc;
   double *oY = sm + S.oY, *Yc = sm + S.Yc, *Bc = sm + S.Bc;
   double *J = sm + S.J, *U = sm + S.U, *Psd = sm + S.Psd, *Psdd = sm + S.Psdd, *Phi = sm + S.Phi, *Bt = sm + S.Bt, *Tq = sm + S.Tq, *Tv = sm + S.Tv, *vlam = sm + S.vlam;
-  double *M = sm + S.M, *Kinv = sm + S.Kinv, *X = sm + S.X, *Sm = sm + S.S, *Jc = sm + S.Jc, *dr = sm + S.dr, *Minv = sm + S.dr;
-  double *gam = sm + S.gam, *bias = sm + S.bias, *rhs = sm + S.rhs, *acc = sm + S.a, *lam = sm + S.lam;
+  double *M = sm + S.M, *LIm = sm + S.LIm, *Y16 = sm + S.Y16, *V16 = sm + S.V16, *Sp = sm + S.Sp, *LIs = sm + S.LIs, *Rm = sm + S.R, *Jc = sm + S.Jc;
+  double *gam = sm + S.gam, *bias = sm + S.bias, *acc = sm + S.a, *lam = sm + S.lam;
+  const int nvp = S.nvp, ldm = S.ldm, nbm = S.nbm, ldR = S.ldR, ncb = S.ncb;
+  const int lane = tid & 63, wv = tid >> 6, nw = nthr >> 6;
   double *x = sm + S.x, *u = sm + S.u, *xn = sm + S.xn, *cfr = sm + S.cfr, *small = sm + S.small, *red = sm + S.red;
   __shared__ int iflag[2];
   __shared__ double s_cost;
-  // Jacobian staging in LDS, carved from the region M..dr that is dead once the dynamics derivatives are in HBM:
+  // Jacobian staging in LDS, in the R region that is dead once the dynamics derivatives are in HBM:
   // JS = stacked rows sqrt(W) J of the cost terms (<= 32 rows), JL = rows of the constraint term being emitted
-  double* JS = sm + S.M;
+  double* JS = Rm;
   double* JL = JS + 32 * nz;
   double* wrs = red + 256;  // sqrt(W) r of the stacked rows
 
@@ -375,12 +400,15 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
   if (has_dyn) {
     const double dt = P[desc[4]];
     // ---- P6: joint-space inertia, bias torques, contact frames -------------------------------------------
-    for (int idx = tid; idx < nv * nv; idx += nthr) {
-      const int r = idx / nv, cc = idx % nv;
-      double s = 0;
-      if (BELOW(cc, dof_body[r])) s = dot6(ld6(U + 6 * r), ld6(J + 6 * cc));
-      else if (BELOW(r, dof_body[cc])) s = dot6(ld6(U + 6 * cc), ld6(J + 6 * r));
-      M[idx] = s;
+    for (int idx = tid; idx < nvp * nvp; idx += nthr) {
+      const int r = idx / nvp, cc = idx % nvp;
+      double s = (r == cc) ? 1.0 : 0.0;  // identity padding
+      if (r < nv && cc < nv) {
+        s = 0;
+        if (BELOW(cc, dof_body[r])) s = dot6(ld6(U + 6 * r), ld6(J + 6 * cc));
+        else if (BELOW(r, dof_body[cc])) s = dot6(ld6(U + 6 * cc), ld6(J + 6 * r));
+      }
+      M[r * ldm + cc] = s;
     }
     for (int kd = tid; kd < nv; kd += nthr) bias[kd] = dot6(ld6(J + 6 * kd), ld6(Fc + 6 * dof_body[kd]));
     if (tid < nk) {
@@ -410,60 +438,66 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
       if (BELOW(kd, i)) col = adinv(ldm3(cfr + 54 * cc), ldv3(cfr + 54 * cc + 9), ld6(J + 6 * kd));
       for (int r = 0; r < 6; ++r) Jc[(6 * cc + r) * nv + kd] = col.v[r];
     }
-    for (int idx = tid; idx < nv * nv; idx += nthr) Minv[idx] = (idx / nv == idx % nv) ? 1.0 : 0.0;
+    __syncthreads();
+    // Y16 = [Jc^T | r1 | 0]  (nvp x 16): the contact columns and the dynamics right-hand side r1 = B u - bias
+    for (int idx = tid; idx < nvp * 16; idx += nthr) {
+      const int l = idx >> 4, j = idx & 15;
+      double s = 0.0;
+      if (l < nv) {
+        if (j < nl) s = Jc[j * nv + l];
+        else if (j == 12) s = -bias[l] + (l >= nv - nu ? u[l - (nv - nu)] : 0.0);
+      }
+      Y16[idx] = s;
+    }
     __syncthreads();
     EV_PROF(2);
-    // ---- P7: KKT inverse by blocks:  Minv, X = Minv Jc^T, S = Jc X + mu I, Kinv ---------------------------
-    if (!chol_block(M, nv, nv, tid, nthr, iflag)) { if (tid == 0) a.inst[b].done = 5; return; }
+    // ---- P7: M = L L^T ; Y = L^-1 [Jc^T | r1] ; S = Y^T Y + mu I = Ls Ls^T ; multipliers ; accelerations -------
+    if (tid == 0) iflag[1] = 1;
+    if (!chol_blocked(M, ldm, nbm, LIm, tid, iflag)) { if (tid == 0) a.inst[b].done = 5; return; }
     EV_PROF(3);
-    potrs_block(M, nv, nv, Minv, nv, nv, tid, nthr);
-    EV_PROF(4);
-    for (int idx = tid; idx < nv * nl; idx += nthr) {
-      const int r = idx / nl, cc = idx % nl;
-      double s = 0;
-      for (int l = 0; l < nv; ++l) s += Minv[r * nv + l] * Jc[cc * nv + l];
-      X[idx] = s;
+    if (wv == 0) {
+      trsm_fwd_blocked(M, ldm, LIm, nbm, Y16, 16, 1, 0, 1, lane);
+      d4_t g = d4_t{0, 0, 0, 0};
+      mma_tile<false>(g, Y16, 1, 16, Y16, 16, 1, nvp, lane);  // [Y w]^T [Y w]
+      const int col = lane & 15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = (lane >> 4) + 4 * q;
+        double sv = (row < nl && col < nl) ? g[q] : 0.0;
+        if (row == col) sv += (row < nl) ? prox_mu : 1.0;
+        Sp[row * 17 + col] = sv;
+        if (col == 12 && row < nl) small[row] = g[q] + gam[row];  // t = Y^T w - r2,  r2 = -gamma
+      }
+      if (!chol16_wave(Sp, 17, LIs, lane) && lane == 0) iflag[1] = 0;
+      // z2 = Ls^-T Ls^-1 t ; lambda = -z2
+      if (lane < 16) {
+        double y = 0;
+        for (int j = 0; j <= lane; ++j) y += LIs[lane * 17 + j] * ((j < nl) ? small[j] : 0.0);
+        small[16 + lane] = y;
+      }
+      if (lane < 16) {
+        double z = 0;
+        for (int j = lane; j < 16; ++j) z += LIs[j * 17 + lane] * small[16 + j];
+        small[32 + lane] = z;
+        if (lane < nl) lam[lane] = -z;
+      }
     }
     __syncthreads();
-    double* Sinv = Sm + 144;
-    for (int idx = tid; idx < nl * nl; idx += nthr) {
-      const int r = idx / nl, cc = idx % nl;
-      double s = (r == cc) ? prox_mu : 0.0;
-      for (int l = 0; l < nv; ++l) s += Jc[r * nv + l] * X[l * nl + cc];
-      Sm[idx] = s;
-      Sinv[idx] = (r == cc) ? 1.0 : 0.0;
+    if (iflag[1] == 0) { if (tid == 0) a.inst[b].done = 6; return; }
+    // V16 column 0 = w - Y z2, then accelerations = L^-T (.)
+    for (int idx = tid; idx < nvp * 16; idx += nthr) {
+      const int l = idx >> 4, j = idx & 15;
+      double s = 0.0;
+      if (j == 0) { s = Y16[l * 16 + 12]; for (int i = 0; i < nl; ++i) s -= Y16[l * 16 + i] * small[32 + i]; }
+      V16[idx] = s;
     }
     __syncthreads();
-    if (nl > 0) {
-      if (!chol_block(Sm, nl, nl, tid, nthr, iflag)) { if (tid == 0) a.inst[b].done = 6; return; }
-      potrs_block(Sm, nl, nl, Sinv, nl, nl, tid, nthr);
-    }
-    // XS = X Sinv  (stored in the Kinv 12-block first)
-    for (int idx = tid; idx < nv * nl; idx += nthr) {
-      const int r = idx / nl, cc = idx % nl;
-      double s = 0;
-      for (int l = 0; l < nl; ++l) s += X[r * nl + l] * Sinv[l * nl + cc];
-      Kinv[r * nK + nv + cc] = s;
-      Kinv[(nv + cc) * nK + r] = s;
-    }
-    for (int idx = tid; idx < nl * nl; idx += nthr) Kinv[(nv + idx / nl) * nK + nv + idx % nl] = -Sinv[idx];
+    if (wv == 0) trsm_bwd_blocked(M, ldm, LIm, nbm, V16, 16, 1, 0, 1, lane);
     __syncthreads();
-    for (int idx = tid; idx < nv * nv; idx += nthr) {
-      const int r = idx / nv, cc = idx % nv;
-      double s = Minv[idx];
-      for (int l = 0; l < nl; ++l) s -= Kinv[r * nK + nv + l] * X[cc * nl + l];
-      Kinv[r * nK + cc] = s;
-    }
-    for (int i = tid; i < nK; i += nthr) rhs[i] = (i < nv) ? (-bias[i] + (i >= nv - nu ? u[i - (nv - nu)] : 0.0)) : -gam[i - nv];
+    for (int i = tid; i < nv; i += nthr) acc[i] = V16[i * 16];
+    for (int l = tid; l < nvp; l += nthr) Y16[l * 16 + 12] = 0.0;  // from here on Y16 = Y (zero padded)
     __syncthreads();
     EV_PROF(5);
-    // ---- P8: solve, then accelerations / forces at the solution -------------------------------------------
-    for (int i = tid; i < nK; i += nthr) {
-      double s = 0;
-      for (int l = 0; l < nK; ++l) s += Kinv[i * nK + l] * rhs[l];
-      if (i < nv) acc[i] = s; else lam[i - nv] = -s;
-    }
-    __syncthreads();
     if (derivs) {
       for (int i = tid; i < n; i += nthr) kn[KL.oXD + i] = (i < nv) ? v[i] : acc[i - nv];
       for (int i = tid; i < 12; i += nthr) kn[KL.oWR + i] = 0.0;
@@ -652,9 +686,12 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
       __syncthreads();
     }
     EV_PROF(7);
-    // ---- P10: rows of [d r1 ; d r2] w.r.t. (q, v)  (dr is nK x 2nv; Minv is dead from here on) -------------
+    // ---- P10: R = [d r1 ; d r2] w.r.t. (q, v, u), zero padded (R overwrites the body-level blocks oY / Bc) ----
     const int n2 = 2 * nv;
     if (has_dyn) {
+    double* R2 = Rm + nvp * ldR;
+    for (int idx = tid; idx < (nvp + 16) * ldR; idx += nthr) Rm[idx] = 0.0;
+    __syncthreads();
     for (int idx = tid; idx < nv * nv; idx += nthr) {
       const int r = idx / nv, j = idx % nv;
       const int br = dof_body[r], bj = dof_body[j];
@@ -668,9 +705,10 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
         dq = dot6(Jr, ld6(Tq + 6 * j));
         dv = dot6(Jr, ld6(Tv + 6 * j));
       }
-      dr[r * n2 + j] = dq;
-      dr[r * n2 + nv + j] = dv;
+      Rm[r * ldR + j] = dq;
+      Rm[r * ldR + nv + j] = dv;
     }
+    for (int i = tid; i < nu; i += nthr) Rm[(nv - nu + i) * ldR + n2 + i] = -1.0;  // d r1 / du = -B
     for (int idx = tid; idx < nk * nv; idx += nthr) {
       const int cc = idx / nv, j = idx % nv;
       const int cid = desc[2 + cc], i = mcontact[cid];
@@ -692,17 +730,33 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
           rv.v[r] = dacv.v[r] + cm[30 + r] * Jcj.v[r];
         }
       }
-      for (int r = 0; r < 6; ++r) { dr[(nv + 6 * cc + r) * n2 + j] = rq.v[r]; dr[(nv + 6 * cc + r) * n2 + nv + j] = rv.v[r]; }
+      for (int r = 0; r < 6; ++r) { R2[(6 * cc + r) * ldR + j] = rq.v[r]; R2[(6 * cc + r) * ldR + nv + j] = rv.v[r]; }
     }
     __syncthreads();
     EV_PROF(8);
-    // ---- P11: implicit differentiation  d[a; -lam]/d(q,v) = -Kinv dr ;  d/du from the actuated columns -----
+    // ---- P11: implicit differentiation, one 16-column block per wavefront (no workgroup barrier inside):
+    //   W = L^-1 R1 ; T = Y^T W - R2 ; Z2 = S^-1 T ; Z1 = L^-T (W - Y Z2) ;  d a = -Z1 ,  d lambda = Z2
+    trsm_fwd_blocked(M, ldm, LIm, nbm, Rm, ldR, ncb, wv, nw, lane);
+    for (int cj = wv; cj < ncb; cj += nw) {
+      d4_t t = tile_load(R2 + cj * 16, ldR, lane);
+      t = -t;
+      mma_tile<false>(t, Y16, 1, 16, Rm + cj * 16, ldR, 1, nvp, lane);
+      tile_store(R2 + cj * 16, ldR, t, lane);
+    }
+    trsm_fwd_blocked(Sp, 17, LIs, 1, R2, ldR, ncb, wv, nw, lane);
+    trsm_bwd_blocked(Sp, 17, LIs, 1, R2, ldR, ncb, wv, nw, lane);
+    for (int cj = wv; cj < ncb; cj += nw)
+      for (int bi = 0; bi < nbm; ++bi) {
+        double* Wt = Rm + (bi * 16) * ldR + cj * 16;
+        d4_t w = tile_load(Wt, ldR, lane);
+        mma_tile<true>(w, Y16 + (bi * 16) * 16, 16, 1, R2 + cj * 16, ldR, 1, 16, lane);
+        tile_store(Wt, ldR, w, lane);
+      }
+    trsm_bwd_blocked(M, ldm, LIm, nbm, Rm, ldR, ncb, wv, nw, lane);
+    __syncthreads();
     for (int idx = tid; idx < nK * nz; idx += nthr) {
       const int r = idx / nz, z = idx % nz;
-      double s = 0;
-      if (z < n2) { for (int l = 0; l < nK; ++l) s += Kinv[r * nK + l] * dr[l * n2 + z]; s = (r < nv) ? -s : s; }
-      else { s = Kinv[r * nK + (nv - nu) + (z - n2)]; s = (r < nv) ? s : -s; }
-      dsol[(size_t)r * L.nz + z] = s;
+      dsol[(size_t)r * L.nz + z] = (r < nv) ? -Rm[r * ldR + z] : R2[(r - nv) * ldR + z];
     }
     __syncthreads();
     }  // has_dyn
@@ -788,22 +842,35 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
   int row = 0, rowc = 0;
   // H += JS^T JS (upper triangle, mirrored), grad += JS^T wrs for the rows stacked so far
   auto flush_stack = [&]() {
+    const int kc = (rowc + 3) & ~3;  // MFMA K granularity: zero rows up to a multiple of 4
+    for (int idx = tid; idx < (kc - rowc) * nz; idx += nthr) JS[rowc * nz + idx] = 0.0;
     __syncthreads();
     for (int z = tid; z < nz; z += nthr) {
       double g = 0;
       for (int i = 0; i < rowc; ++i) g += JS[i * nz + z] * wrs[i];
       kn[KL.oG + z] += g;
     }
-    const int lane_ = tid & 63, wv_ = tid >> 6, nw_ = nthr >> 6;
-    for (int za = wv_; za < nz; za += nw_)
-      for (int zb = za + lane_; zb < nz; zb += 64) {
-        double h = 0;
-        for (int i = 0; i < rowc; ++i) h += JS[i * nz + za] * JS[i * nz + zb];
-        kn[KL.oH + (size_t)za * KL.nz + zb] += h;
-        if (zb != za) kn[KL.oH + (size_t)zb * KL.nz + za] += h;
+    // H += JS^T JS on the matrix cores: upper block triangle of 16x16 tiles, mirrored on the way out
+    const int nzt = (nz + 15) >> 4;
+    for (int t = wv; t < nzt * (nzt + 1) / 2; t += nw) {
+      int ta = 0, rem = t;
+      while (rem >= nzt - ta) { rem -= nzt - ta; ++ta; }
+      const int tb = ta + rem;
+      d4_t h = d4_t{0, 0, 0, 0};
+      mma_tile<false>(h, JS + ta * 16, 1, nz, JS + tb * 16, nz, 1, kc, lane);
+      const int zb = tb * 16 + (lane & 15);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int za = ta * 16 + (lane >> 4) + 4 * q;
+        if (za < nz && zb < nz) {
+          kn[KL.oH + (size_t)za * KL.nz + zb] += h[q];
+          if (ta != tb) kn[KL.oH + (size_t)zb * KL.nz + za] += h[q];
+        }
       }
+    }
     __syncthreads();
     rowc = 0;
+    EV_PROF(27);
   };
   for (int t = 0; t < nterms; ++t) {
     const TermRec tr = load_term(desc, t);
@@ -1041,6 +1108,7 @@ __global__ void __launch_bounds__(256) k_eval_multibody(SolverArgs a, Layout KL,
       }
     }
     if (tr.role != MPC_ROLE_COST) row += d;
+    EV_PROF(13 + tr.type);
   }
   if (derivs && rowc > 0) flush_stack();
   if (derivs) for (int z = tid; z < nz; z += nthr) kn[KL.oH + (size_t)z * KL.nz + z] += a.opt.reg_init;
@@ -1069,7 +1137,7 @@ static inline void launch_eval_multibody(hipStream_t stream, const SolverArgs& a
                                          size_t scratch_stride, bool trial, int cand0 = 0, int ncand = 1) {
   const Layout& L = a.L;
   MbArgs mb;
-  mb.lds = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m);
+  mb.lds = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m, L.nz);
   mb.scratch = scratch;
   mb.scratch_stride = scratch_stride;
   if (mb.lds.total_bytes > 160 * 1024) throw std::runtime_error("multibody model too large for the LDS budget of the stage kernel");
@@ -1081,6 +1149,6 @@ static inline void launch_eval_multibody(hipStream_t stream, const SolverArgs& a
     if (e1 != hipSuccess || e2 != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(LDS) failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     attr_bytes = mb.lds.total_bytes;
   }
-  if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(L.N + 1, L.B, 1), dim3(256), mb.lds.total_bytes, stream, a, L, records, mb, 0);
-  else hipLaunchKernelGGL(k_eval_multibody<1>, dim3(L.N + 1, L.B, ncand), dim3(256), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
+  if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
+  else hipLaunchKernelGGL(k_eval_multibody<1>, dim3(L.N + 1, L.B, ncand), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
 }

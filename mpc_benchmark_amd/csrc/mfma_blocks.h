@@ -1,0 +1,182 @@
+// mfma_blocks.h — dense fp64 building blocks on the CDNA4 matrix cores, shared by the Riccati sweep and the
+// whole-body stage kernel: 16x16 MFMA tile products on LDS operands (v_mfma_f64_16x16x4_f64), a 16x16 Cholesky +
+// inverse held in the registers of one wavefront (readlane broadcasts), blocked Cholesky and blocked triangular
+// solves with pre-inverted diagonal blocks (pure MFMA, one column block per wavefront, no workgroup barrier).
+#pragma once
+#include "device_common.h"
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// ---- MFMA tile primitives ---------------------------------------------------------------------------------
+// acc += sum_{k<K} A(i,k) * B(k,j) for one 16x16 tile; A(i,k) at A[i*a_is + k*a_ks], B(k,j) at B[k*b_ks + j*b_js].
+// Fragment layout of v_mfma_f64_16x16x4_f64: lane l supplies A(l&15, l>>4) and B(l>>4, l&15); result register r of
+// lane l is C((l>>4) + 4r, l&15).  K must be a multiple of 4; groups of 16 are software-pipelined.
+template <bool NEG>
+DEV void mma_tile(d4_t& acc, const double* A, int a_is, int a_ks, const double* B, int b_ks, int b_js, int K, int lane) {
+  const int i = lane & 15, kk = lane >> 4;
+  const double* ap = A + i * a_is + kk * a_ks;
+  const double* bp = B + kk * b_ks + i * b_js;
+  int k0 = 0;
+  for (; k0 + 16 <= K; k0 += 16) {
+    double a0 = ap[k0 * a_ks], a1 = ap[(k0 + 4) * a_ks], a2 = ap[(k0 + 8) * a_ks], a3 = ap[(k0 + 12) * a_ks];
+    const double b0 = bp[k0 * b_ks], b1 = bp[(k0 + 4) * b_ks], b2 = bp[(k0 + 8) * b_ks], b3 = bp[(k0 + 12) * b_ks];
+    if (NEG) { a0 = -a0; a1 = -a1; a2 = -a2; a3 = -a3; }
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
+  }
+  for (; k0 < K; k0 += 4) {
+    const double av = NEG ? -ap[k0 * a_ks] : ap[k0 * a_ks];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bp[k0 * b_ks], acc, 0, 0, 0);
+  }
+}
+// two output tiles sharing the B fragment (A0 / A1 differ): halves the LDS traffic of the B operand; K % 8 == 0
+DEV void mma_tile2(d4_t& acc0, d4_t& acc1, const double* A0, const double* A1, int a_is, int a_ks, const double* B, int b_ks, int b_js, int K, int lane) {
+  const int i = lane & 15, kk = lane >> 4;
+  const double* ap0 = A0 + i * a_is + kk * a_ks;
+  const double* ap1 = A1 + i * a_is + kk * a_ks;
+  const double* bp = B + kk * b_ks + i * b_js;
+  for (int k0 = 0; k0 < K; k0 += 8) {
+    const double a00 = ap0[k0 * a_ks], a01 = ap0[(k0 + 4) * a_ks], a10 = ap1[k0 * a_ks], a11 = ap1[(k0 + 4) * a_ks];
+    const double b0 = bp[k0 * b_ks], b1 = bp[(k0 + 4) * b_ks];
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a00, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a10, b0, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a01, b1, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, b1, acc1, 0, 0, 0);
+  }
+}
+DEV d4_t tile_load(const double* C, int ldc, int lane) {
+  d4_t r;
+  const int row = lane >> 4, col = lane & 15;
+  for (int q = 0; q < 4; ++q) r[q] = C[(row + 4 * q) * ldc + col];
+  return r;
+}
+DEV void tile_store(double* C, int ldc, const d4_t& v, int lane) {
+  const int row = lane >> 4, col = lane & 15;
+  for (int q = 0; q < 4; ++q) C[(row + 4 * q) * ldc + col] = v[q];
+}
+
+// value of `v` held by lane SRC (compile-time constant) broadcast to the whole wavefront
+template <int SRC> DEV double readlane_d(double v) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), SRC);
+  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), SRC);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int J, int C> struct CholCol {
+  static DEV void run(double (&d)[16], double l) { d[C] -= l * readlane_d<C>(l); CholCol<J, C + 1>::run(d, l); }
+};
+template <int J> struct CholCol<J, 16> { static DEV void run(double (&)[16], double) {} };
+template <int J> struct CholStep {
+  static DEV void run(double (&d)[16], double (&invd)[16], bool& ok) {
+    const double djj = readlane_d<J>(d[J]);
+    ok = ok && (djj > 0.0);
+    double inv = rsqrt(djj);
+    inv = inv * (1.5 - 0.5 * djj * inv * inv);  // one Newton step: 1/sqrt(djj) to full precision
+    invd[J] = inv;
+    const double l = d[J] * inv;  // lane J: sqrt(djj); lanes r > J: L[r][J]
+    d[J] = l;
+    CholCol<J, J + 1>::run(d, l);
+    CholStep<J + 1>::run(d, invd, ok);
+  }
+};
+template <> struct CholStep<16> { static DEV void run(double (&)[16], double (&)[16], bool&) {} };
+template <int R, int K> struct InvDot {
+  static DEV void run(const double (&d)[16], const double (&x)[16], double& acc) { acc -= readlane_d<R>(d[K]) * x[K]; InvDot<R, K + 1>::run(d, x, acc); }
+};
+template <int R> struct InvDot<R, R> { static DEV void run(const double (&)[16], const double (&)[16], double&) {} };
+template <int R> struct InvRow {
+  static DEV void run(const double (&d)[16], const double (&invd)[16], double (&x)[16], int lane) {
+    double acc = (lane == R) ? 1.0 : 0.0;
+    InvDot<R, 0>::run(d, x, acc);
+    x[R] = acc * invd[R];
+    InvRow<R + 1>::run(d, invd, x, lane);
+  }
+};
+template <> struct InvRow<16> { static DEV void run(const double (&)[16], const double (&)[16], double (&)[16], int) {} };
+
+// One wavefront: Cholesky of the 16x16 block D (lower triangle, leading dimension ld) entirely in registers —
+// lane r (< 16) holds row r — then its inverse.  Writes L back over D (lower part) and L^-1 to LIb (ld 17).
+DEV bool chol16_wave(double* D, int ld, double* LIb, int lane) {
+  double d[16], x[16], invd[16];
+  const int r = lane & 15;
+#pragma unroll
+  for (int cidx = 0; cidx < 16; ++cidx) d[cidx] = D[r * ld + cidx];
+  bool ok = true;
+  CholStep<0>::run(d, invd, ok);
+#pragma unroll
+  for (int cidx = 0; cidx < 16; ++cidx) x[cidx] = 0.0;
+  InvRow<0>::run(d, invd, x, lane);  // lane c (< 16) builds column c of L^-1
+  if (lane < 16) {
+#pragma unroll
+    for (int cidx = 0; cidx < 16; ++cidx) if (cidx <= r) D[r * ld + cidx] = d[cidx];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) LIb[rr * 17 + lane] = x[rr];
+  }
+  return ok;
+}
+
+// Blocked Cholesky of the (16 nb) x (16 nb) matrix A in LDS (lower triangle; pad rows/cols must be identity).
+// L overwrites the lower block triangle, LI[bi] (272 doubles each, ld 17) receives the inverse of diagonal block bi.
+DEV bool chol_blocked(double* A, int ld, int nb, double* LI, int tid, int* flag) {
+  const int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+  if (tid == 0) *flag = 1;
+  __syncthreads();
+  for (int kb = 0; kb < nb; ++kb) {
+    if (wv == 0) { if (!chol16_wave(A + (kb * 16) * ld + kb * 16, ld, LI + kb * 272, lane) && lane == 0) *flag = 0; }
+    __syncthreads();
+    if (*flag == 0) return false;
+    // panel: L[ri][kb] = A[ri][kb] LI^T   (ri > kb)
+    for (int ri = kb + 1 + wv; ri < nb; ri += nw) {
+      d4_t acc = d4_t{0, 0, 0, 0};
+      mma_tile<false>(acc, A + (ri * 16) * ld + kb * 16, ld, 1, LI + kb * 272, 1, 17, 16, lane);
+      tile_store(A + (ri * 16) * ld + kb * 16, ld, acc, lane);
+    }
+    __syncthreads();
+    // trailing update of the lower block triangle: A[ri][cj] -= L[ri][kb] L[cj][kb]^T
+    const int rem = nb - kb - 1;
+    for (int t = wv; t < rem * (rem + 1) / 2; t += nw) {
+      int ri = 0, acc_t = 0;
+      while (acc_t + ri + 1 <= t) { acc_t += ri + 1; ++ri; }
+      const int cj = t - acc_t;
+      double* Ct = A + ((kb + 1 + ri) * 16) * ld + (kb + 1 + cj) * 16;
+      d4_t acc = tile_load(Ct, ld, lane);
+      mma_tile<true>(acc, A + ((kb + 1 + ri) * 16) * ld + kb * 16, ld, 1, A + ((kb + 1 + cj) * 16) * ld + kb * 16, 1, ld, 16, lane);
+      tile_store(Ct, ld, acc, lane);
+    }
+    __syncthreads();
+  }
+  return true;
+}
+
+// B <- L^-1 B (forward) for the column blocks owned by this wavefront; B is (16 nb) x (16 ncb), leading dim ldb.
+// Column blocks are independent, LDS operations of one wavefront execute in order: no workgroup barrier needed.
+DEV void trsm_fwd_blocked(const double* Lm, int ld, const double* LI, int nb, double* Bm, int ldb, int ncb, int wv, int nw, int lane) {
+  for (int cj = wv; cj < ncb; cj += nw) {
+    for (int bi = 0; bi < nb; ++bi) {
+      double* Bt = Bm + (bi * 16) * ldb + cj * 16;
+      d4_t acc = tile_load(Bt, ldb, lane);
+      mma_tile<true>(acc, Lm + (bi * 16) * ld, ld, 1, Bm + cj * 16, ldb, 1, bi * 16, lane);
+      tile_store(Bt, ldb, acc, lane);
+      d4_t acc2 = d4_t{0, 0, 0, 0};
+      mma_tile<false>(acc2, LI + bi * 272, 17, 1, Bt, ldb, 1, 16, lane);
+      tile_store(Bt, ldb, acc2, lane);
+    }
+  }
+}
+// B <- L^-T B (backward)
+DEV void trsm_bwd_blocked(const double* Lm, int ld, const double* LI, int nb, double* Bm, int ldb, int ncb, int wv, int nw, int lane) {
+  for (int cj = wv; cj < ncb; cj += nw) {
+    for (int bi = nb - 1; bi >= 0; --bi) {
+      double* Bt = Bm + (bi * 16) * ldb + cj * 16;
+      d4_t acc = tile_load(Bt, ldb, lane);
+      mma_tile<true>(acc, Lm + ((bi + 1) * 16) * ld + bi * 16, 1, ld, Bm + ((bi + 1) * 16) * ldb + cj * 16, ldb, 1, (nb - 1 - bi) * 16, lane);
+      tile_store(Bt, ldb, acc, lane);
+      d4_t acc2 = d4_t{0, 0, 0, 0};
+      mma_tile<false>(acc2, LI + bi * 272, 1, 17, Bt, ldb, 1, 16, lane);
+      tile_store(Bt, ldb, acc2, lane);
+    }
+  }
+}
+

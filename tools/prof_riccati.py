@@ -4,7 +4,7 @@ import numpy as np, time
 from mpc_benchmark_amd import _capi
 from mpc_benchmark_amd.ensemble import EnsembleMPC
 from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
-lib = _capi.load_hip_library()
+lib = _capi.bind_library(sys.argv[1]) if len(sys.argv) > 1 else _capi.load_hip_library()
 pd = FullDynamicsProblem(horizon=100, complete_model=True)
 ens = EnsembleMPC(pd, batch=4, library=lib)
 ens.prepare_schedule(10)
@@ -20,3 +20,8 @@ ev = p[32:45]
 enames = ['load,FK,J','vel,inertia,composites,U','M,bias,contacts,Jc','chol M','Minv (potrs)','X,S,Kinv','solve,forces','deriv blocks','dr rows','dsol gemm','integrator,AB','terms','merit']
 for n_, v in zip(enames, ev): print('EVAL %-26s %8.1f us  %5.1f%%' % (n_, v/3/2400.0, 100*v/ev.sum()))
 print('EVAL total us per workgroup', ev.sum()/3/2400)
+tn = ['', 'state_error', 'control_error', 'frame_placement', 'frame_translation', 'frame_velocity', 'com_translation', 'centroidal_momentum',
+      'contact_force', 'mb_wrench_cone', 'centroidal_wrench_cone', 'lin_acc', 'ang_acc', 'centroidal_momentum_der']
+for t in range(1, 14):
+    if p[32 + 13 + t] > 0: print('EVAL term %-24s %8.1f us' % (tn[t], p[32 + 13 + t] / 3 / 2400.0))
+print('EVAL flush_stack %8.1f us' % (p[32 + 27] / 3 / 2400.0))
