@@ -77,7 +77,7 @@ extern "C" {
  *       (multibody: indices into the model's contact table of the ACTIVE contacts;
  *        centroidal / kinodynamic: contact state flag of foot 0 / foot 1)
  *   [4] offset of the dynamics parameters in the stage's double table
- *       centroidal : mass, g[3], dt, p0[3], p1[3]     multibody: dt     kinodynamic: dt, g[3], mass, frame0, frame1
+ *       centroidal : mass, g[3], dt, p0[3], p1[3]     multibody: dt     kinodynamic: dt, g[3], frame0, frame1
  *   [5] number of terms T   [6] total constraint rows   [7] reserved
  *   then T records of MPC_TERM_WORDS words: type, role, dim, iarg0, iarg1, poff, woff, flags
  */

@@ -13,7 +13,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIBRARY_PATH = os.path.join(_HERE, "csrc", "libmpc_hip.so")
+# MPC_HIP_LIBRARY: developer override pointing at another build of the SAME HIP library (kernel tuning variants)
+HIP_LIBRARY_PATH = os.environ.get("MPC_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libmpc_hip.so")
 
 ABI_VERSION = 1
 

@@ -79,7 +79,9 @@ DEV void knot_merit(const Layout& L, double* kn, int c, const double* f, const d
                     const double* lam, const double* dlam, const double* lame, double alpha, double mu, double mud,
                     bool store_proj, double* red, double& pen_out, double& prim_out, int tid, int nthr) {
   double pen = 0, prim = 0;
-  for (int i = tid; i < c; i += nthr) {
+  const int nt = nthr < 256 ? nthr : 256;  // `red` holds 2 x 256 partials
+  if (tid < nt) {
+  for (int i = tid; i < c; i += nt) {
     bool act;
     const double pn = proj_normal((int)kn[L.oCT + i], kn[L.oCV + i] + mu * ve[i], kn[L.oLO + i], kn[L.oHI + i], act);
     if (store_proj) { kn[L.oDT + i] = pn; kn[L.oACT + i] = act ? 1.0 : 0.0; }
@@ -88,7 +90,7 @@ DEV void knot_merit(const Layout& L, double* kn, int c, const double* f, const d
     prim = fmax(prim, fabs(pn - mu * ve[i]));
   }
   if (f) {
-    for (int i = tid; i < L.n; i += nthr) {
+    for (int i = tid; i < L.n; i += nt) {
       const double lp = lame[i] + f[i] / mud, ll = lam[i] + (dlam ? alpha * dlam[i] : 0.0);
       pen += 0.5 * mud * lp * lp + 0.5 * mud * (lp - ll) * (lp - ll);
       prim = fmax(prim, fabs(f[i]));
@@ -96,11 +98,12 @@ DEV void knot_merit(const Layout& L, double* kn, int c, const double* f, const d
   }
   // deterministic reduction: fixed thread order
   red[tid] = pen;
-  red[nthr + tid] = prim;
+  red[nt + tid] = prim;
+  }
   __syncthreads();
   if (tid == 0) {
     double p = 0, q = 0;
-    for (int i = 0; i < nthr; ++i) { p += red[i]; q = fmax(q, red[nthr + i]); }
+    for (int i = 0; i < nt; ++i) { p += red[i]; q = fmax(q, red[nt + i]); }
     pen_out = p; prim_out = q;
   }
   __syncthreads();

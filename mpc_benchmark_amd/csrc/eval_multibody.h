@@ -14,8 +14,10 @@
 #include "mfma_blocks.h"
 
 #ifndef EVAL_THREADS
-#define EVAL_THREADS 256  // threads per stage workgroup
+#define EVAL_THREADS 512  // threads per stage workgroup (8 wavefronts: one 16-column block of the KKT solves each)
 #endif
+#define MB_SE3_SLOTS 8
+#define MB_STAGE_CONSTRAINT_ROWS 20  // LDS staging rows for the Jacobian of one constraint term (wrench cone: 17)
 
 // ---- 6-vectors --------------------------------------------------------------------------------------------
 struct S6 { double v[6]; };
@@ -127,7 +129,7 @@ struct MbLds {
   // dof arrays
   int J, U, Psd, Psdd, Phi, Bt, Tq, Tv, vlam;
   // matrices / vectors
-  int M, LIm, Y16, V16, Sp, LIs, R, Jc, gam, bias, a, lam, x, u, xn, cfr, small, red, total;
+  int M, LIm, Y16, V16, Sp, LIs, R, Jc, gam, bias, a, lam, x, u, xn, cfr, small, se3, red, total;
   int stage_rows;  // rows of Jacobian staging (ld nz) that fit in the R region
   int anc_bytes_off, total_bytes;
 };
@@ -154,25 +156,29 @@ static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz) {
   s.x = take(nq + nv); s.u = take(nu > 0 ? nu : 1); s.xn = take(nq + nv);
   s.cfr = take(2 * (12 + 36 + 6));  // per contact: R(9) p(3), Jlog6(c2Mc1) (36), spare(6)
   s.small = take(6 * 36 + 64);      // integrator 6x6 blocks and scratch
-  s.red = take(2 * EVAL_THREADS + 8);
+  s.se3 = take(MB_SE3_SLOTS * 48);  // per SE(3)-valued term: residual (6), Jacobian block (36 at +8)
+  s.red = take(2 * 256 + 8);
   // R region: oY | Bc | rest
   s.oY = take(36 * nj); s.Bc = take(36 * nj);
   s.R = s.oY;
-  int rsize = (s.nvp + 16) * s.ldR + 8;
-  if (rsize < 56 * nz + 8) rsize = 56 * nz + 8;  // 32 stacked cost rows + 24 rows of the constraint being emitted
+  // R = [R2 (16 rows: contact part, stays alive for the force terms) ; R1 (nvp rows)]; the Jacobian staging rows
+  // (32 stacked cost rows + MB_STAGE_CONSTRAINT_ROWS rows of the constraint being emitted, ld nz) reuse the R1 part
+  int r1size = s.nvp * s.ldR;
+  if (r1size < (32 + MB_STAGE_CONSTRAINT_ROWS) * nz) r1size = (32 + MB_STAGE_CONSTRAINT_ROWS) * nz;
+  const int rsize = 16 * s.ldR + r1size + 8;
   if (s.R + rsize > o) o = (s.R + rsize + 1) & ~1;
   if (o < s.Bc + 36 * nj + s.nvp * 16 + 4) o = (s.Bc + 36 * nj + s.nvp * 16 + 4 + 1) & ~1;  // V16 must not overlap oY / Bc
   s.V16 = o - s.nvp * 16 - 2;  // tail of the R region: alive only between the two solves, while oY / Bc are in use
   s.stage_rows = (o - s.R) / nz;
   s.total = o;
   s.anc_bytes_off = o * 8;
-  s.total_bytes = o * 8 + nj * 8 + nv * 4 + nj * 4 * 3 + 64;
+  s.total_bytes = o * 8 + 3 * nj * 8 + nv * 4 + nj * 4 * 3 + 64;
   return s;
 }
 
 static inline void check_multibody_model(const int32_t* itab, int n_i) {
   const int nj = itab[0];
-  if (nj > 64) throw std::runtime_error("multibody kernel supports at most 64 bodies");
+  if (nj > 64 || itab[2] > 64) throw std::runtime_error("multibody kernel supports at most 64 bodies / 64 velocity dofs (bitmask tree tables)");
   const int32_t* ip = itab + MPC_MODEL_HEADER_WORDS;
   for (int i = 0; i < nj; ++i, ip += MPC_MODEL_JOINT_WORDS) {
     if (ip[0] >= i) throw std::runtime_error("model joints must be topologically ordered");
@@ -225,7 +231,9 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
 
   extern __shared__ __attribute__((aligned(16))) double sm[];
   unsigned long long* anc = (unsigned long long*)((char*)sm + S.anc_bytes_off);
-  int* dof_body = (int*)(anc + nj);
+  unsigned long long* sub = anc + nj;    // bodies of the subtree rooted at i
+  unsigned long long* dmask = sub + nj;  // dofs of the joints on the path root .. i
+  int* dof_body = (int*)(dmask + nj);
   int* parent = dof_body + nv;
   int* jkind = parent + nj;
   int* jidxv = jkind + nj;
@@ -241,7 +249,10 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   __shared__ double s_cost;
   // Jacobian staging in LDS, in the R region that is dead once the dynamics derivatives are in HBM:
   // JS = stacked rows sqrt(W) J of the cost terms (<= 32 rows), JL = rows of the constraint term being emitted
-  double* JS = Rm;
+  double* R2 = Rm;                // contact rows of R / d lambda
+  double* R1 = Rm + 16 * ldR;     // joint rows of R / -d a
+  double* JS = R1;
+  double* se3 = sm + S.se3;
   double* JL = JS + 32 * nz;
   double* wrs = red + 256;  // sqrt(W) r of the stacked rows
 
@@ -285,6 +296,12 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     if (tid == 0) s_cost = 0.0;
   }
   __syncthreads();
+  for (int i = tid; i < nj; i += nthr) {
+    unsigned long long ms = 0ull, md_ = 0ull;
+    for (int j = i; j < nj; ++j) if ((anc[j] >> i) & 1ull) ms |= 1ull << j;
+    for (int kd = 0; kd < nv; ++kd) if ((anc[i] >> dof_body[kd]) & 1ull) md_ |= 1ull << kd;
+    sub[i] = ms; dmask[i] = md_;
+  }
   clear_knot(KL, kn, nz, derivs, tid, nthr);
   const double* q = x;
   const double* v = x + nq;
@@ -344,15 +361,17 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   for (int idx = tid; idx < 6 * nj; idx += nthr) {
     const int i = idx / 6, e = idx % 6;
     double s = 0;
-    for (int kd = 0; kd < nv; ++kd) if (BELOW(kd, i)) s += J[6 * kd + e] * v[kd];
+    for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); s += J[6 * kd + e] * v[kd]; }
     ov[idx] = s;
   }
   __syncthreads();
   // ---- P4: bias accelerations (gravity field), spatial inertias, momenta --------------------------------
   for (int i = tid; i < nj; i += nthr) {
     S6 ai = a0;
-    for (int kd = 0; kd < nv; ++kd)
-      if (BELOW(kd, i)) ai = add6(ai, scale6(v[kd], mcross(ld6(ov + 6 * dof_body[kd]), ld6(J + 6 * kd))));
+    for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) {
+      const int kd = __builtin_ctzll(mm);
+      ai = add6(ai, scale6(v[kd], mcross(ld6(ov + 6 * dof_body[kd]), ld6(J + 6 * kd))));
+    }
     st6(oa + 6 * i, ai);
     const M3 R = ldm3(oR + 9 * i);
     const double mass = jd[25 * i + 12];
@@ -375,13 +394,13 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   for (int idx = tid; idx < 36 * nj; idx += nthr) {
     const int i = idx / 36, e = idx % 36;
     double s = 0;
-    for (int j = i; j < nj; ++j) if (INSUB(j, i)) s += oY[36 * j + e];
+    for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += oY[36 * j + e]; }
     Yc[idx] = s;
   }
   for (int idx = tid; idx < 6 * nj; idx += nthr) {
     const int i = idx / 6, e = idx % 6;
     double s = 0;
-    for (int j = i; j < nj; ++j) if (INSUB(j, i)) s += oh[6 * j + e];
+    for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += oh[6 * j + e]; }
     Hc[idx] = s;
   }
   for (int i = tid; i < nj; i += nthr)
@@ -390,7 +409,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   for (int idx = tid; idx < 6 * nj; idx += nthr) {
     const int i = idx / 6, e = idx % 6;
     double s = 0;
-    for (int j = i; j < nj; ++j) if (INSUB(j, i)) s += of[6 * j + e];
+    for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += of[6 * j + e]; }
     Fc[idx] = s;
   }
   for (int kd = tid; kd < nv; kd += nthr) st6(U + 6 * kd, mat6_mul(Yc + 36 * dof_body[kd], ld6(J + 6 * kd)));
@@ -507,7 +526,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     for (int idx = tid; idx < 6 * nj; idx += nthr) {
       const int i = idx / 6, e = idx % 6;
       double s = oa[idx];
-      for (int kd = 0; kd < nv; ++kd) if (BELOW(kd, i)) s += J[6 * kd + e] * acc[kd];
+      for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); s += J[6 * kd + e] * acc[kd]; }
       oa[idx] = s;
     }
     __syncthreads();
@@ -528,7 +547,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
       for (int idx = tid; idx < 6 * nj; idx += nthr) {
         const int i = idx / 6, e = idx % 6;
         double s = 0;
-        for (int j = i; j < nj; ++j) if (INSUB(j, i)) s += of[6 * j + e];
+        for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += of[6 * j + e]; }
         Fc[idx] = s;
       }
     }
@@ -583,7 +602,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     for (int idx = tid; idx < 6 * nj; idx += nthr) {
       const int i = idx / 6, e = idx % 6;
       double sacc = oa[idx];
-      for (int kd = 0; kd < nv; ++kd) if (BELOW(kd, i)) sacc += J[6 * kd + e] * acc[kd];
+      for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); sacc += J[6 * kd + e] * acc[kd]; }
       oa[idx] = sacc;
     }
     __syncthreads();
@@ -593,7 +612,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
       for (int idx = tid; idx < 6 * nj; idx += nthr) {
         const int i = idx / 6, e = idx % 6;
         double sacc = 0;
-        for (int j = i; j < nj; ++j) if (INSUB(j, i)) sacc += of[6 * j + e];
+        for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); sacc += of[6 * j + e]; }
         Fc[idx] = sacc;
       }
     }
@@ -632,7 +651,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     for (int idx = tid; idx < 36 * nj; idx += nthr) {
       const int i = idx / 36, e = idx % 36;
       double s = 0;
-      for (int j = i; j < nj; ++j) if (INSUB(j, i)) s += oY[36 * j + e];
+      for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += oY[36 * j + e]; }
       Bc[idx] = s;
     }
     __syncthreads();
@@ -689,7 +708,6 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     // ---- P10: R = [d r1 ; d r2] w.r.t. (q, v, u), zero padded (R overwrites the body-level blocks oY / Bc) ----
     const int n2 = 2 * nv;
     if (has_dyn) {
-    double* R2 = Rm + nvp * ldR;
     for (int idx = tid; idx < (nvp + 16) * ldR; idx += nthr) Rm[idx] = 0.0;
     __syncthreads();
     for (int idx = tid; idx < nv * nv; idx += nthr) {
@@ -705,10 +723,10 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
         dq = dot6(Jr, ld6(Tq + 6 * j));
         dv = dot6(Jr, ld6(Tv + 6 * j));
       }
-      Rm[r * ldR + j] = dq;
-      Rm[r * ldR + nv + j] = dv;
+      R1[r * ldR + j] = dq;
+      R1[r * ldR + nv + j] = dv;
     }
-    for (int i = tid; i < nu; i += nthr) Rm[(nv - nu + i) * ldR + n2 + i] = -1.0;  // d r1 / du = -B
+    for (int i = tid; i < nu; i += nthr) R1[(nv - nu + i) * ldR + n2 + i] = -1.0;  // d r1 / du = -B
     for (int idx = tid; idx < nk * nv; idx += nthr) {
       const int cc = idx / nv, j = idx % nv;
       const int cid = desc[2 + cc], i = mcontact[cid];
@@ -736,40 +754,68 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     EV_PROF(8);
     // ---- P11: implicit differentiation, one 16-column block per wavefront (no workgroup barrier inside):
     //   W = L^-1 R1 ; T = Y^T W - R2 ; Z2 = S^-1 T ; Z1 = L^-T (W - Y Z2) ;  d a = -Z1 ,  d lambda = Z2
-    trsm_fwd_blocked(M, ldm, LIm, nbm, Rm, ldR, ncb, wv, nw, lane);
+    trsm_fwd_blocked(M, ldm, LIm, nbm, R1, ldR, ncb, wv, nw, lane);
     for (int cj = wv; cj < ncb; cj += nw) {
       d4_t t = tile_load(R2 + cj * 16, ldR, lane);
       t = -t;
-      mma_tile<false>(t, Y16, 1, 16, Rm + cj * 16, ldR, 1, nvp, lane);
+      mma_tile<false>(t, Y16, 1, 16, R1 + cj * 16, ldR, 1, nvp, lane);
       tile_store(R2 + cj * 16, ldR, t, lane);
     }
     trsm_fwd_blocked(Sp, 17, LIs, 1, R2, ldR, ncb, wv, nw, lane);
     trsm_bwd_blocked(Sp, 17, LIs, 1, R2, ldR, ncb, wv, nw, lane);
     for (int cj = wv; cj < ncb; cj += nw)
       for (int bi = 0; bi < nbm; ++bi) {
-        double* Wt = Rm + (bi * 16) * ldR + cj * 16;
+        double* Wt = R1 + (bi * 16) * ldR + cj * 16;
         d4_t w = tile_load(Wt, ldR, lane);
         mma_tile<true>(w, Y16 + (bi * 16) * 16, 16, 1, R2 + cj * 16, ldR, 1, 16, lane);
         tile_store(Wt, ldR, w, lane);
       }
-    trsm_bwd_blocked(M, ldm, LIm, nbm, Rm, ldR, ncb, wv, nw, lane);
-    __syncthreads();
-    for (int idx = tid; idx < nK * nz; idx += nthr) {
-      const int r = idx / nz, z = idx % nz;
-      dsol[(size_t)r * L.nz + z] = (r < nv) ? -Rm[r * ldR + z] : R2[(r - nv) * ldR + z];
-    }
-    __syncthreads();
+    trsm_bwd_blocked(M, ldm, LIm, nbm, R1, ldR, ncb, wv, nw, lane);
+    __syncthreads();  // d a = -R1, d lambda = R2 stay in LDS for the integrator and the force terms
     }  // has_dyn
   }
 
   EV_PROF(9);
+  // ---- SE(3)-valued terms: residual and Jacobian block, one term per wavefront lane 0 (waves 2..) ---------------
+  if (wv >= 2 && lane == 0) {
+    int slot = 0;
+    for (int t = 0; t < nterms; ++t) {
+      const TermRec tr = load_term(desc, t);
+      const bool se3_state = tr.type == MPC_TERM_STATE_ERROR && tr.i0 < 6;
+      if (!se3_state && tr.type != MPC_TERM_FRAME_PLACEMENT) continue;
+      const int my = slot++;
+      if (my >= MB_SE3_SLOTS || (my % (nw - 2)) != wv - 2) continue;
+      const double* tp = P + tr.poff;
+      double* sl = se3 + 48 * my;
+      V3 ev, ew;
+      if (se3_state) {
+        // r = x_ref (-) x on the base ; J = -Jlog6(Mref^-1 M)
+        const M3 Rr = quat_to_rot(tp + 3), Rb = quat_to_rot(q + 3);
+        const V3 pr = v3(tp[0], tp[1], tp[2]), pb = v3(q[0], q[1], q[2]);
+        log6(tmul(Rb, Rr), tmul(Rb, pr - pb), ev, ew);
+        if (derivs) { Jlog6(tmul(Rr, Rb), tmul(Rr, pb - pr), sl + 8); for (int e = 0; e < 36; ++e) sl[8 + e] = -sl[8 + e]; }
+      } else {
+        const int fi = tr.i0, i = mframe[fi];
+        const M3 Ri = ldm3(oR + 9 * i);
+        const M3 Rf = mul(Ri, ldm3(fd + 12 * fi));
+        const V3 pf = mul(Ri, ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+        const M3 Rr = ldm3(tp);
+        const V3 pr = ldv3(tp + 9);
+        log6(tmul(Rr, Rf), tmul(Rr, pf - pr), ev, ew);
+        if (derivs) Jlog6(tmul(Rr, Rf), tmul(Rr, pf - pr), sl + 8);
+      }
+      sl[0] = ev.x; sl[1] = ev.y; sl[2] = ev.z; sl[3] = ew.x; sl[4] = ew.y; sl[5] = ew.z;
+    }
+  }
   // ---- P12: semi-implicit Euler, gap and its Jacobians ----------------------------------------------------
   if (has_dyn || kino) {
     const double dt = P[desc[4]];
     double* Jl6 = small;        // Jlog6(G)
     double* Je6 = small + 36;   // Jexp6(delta)
     double* Jq6 = small + 72;   // Ad(exp6(delta))^-1
-    if (tid == 0) {
+    // The SE(3) pieces are single-lane work (log / exp maps and their Jacobians): spread them over the wavefronts
+    // — wave 0: step, gap, Jlog6(G) ; wave 1: Jexp6, Ad^-1, E6 ; waves 2..: the SE(3)-valued cost / constraint terms
+    if (tid == 0 || (tid == 64 && derivs)) {
       const V3 dl = v3(dt * (v[0] + dt * acc[0]), dt * (v[1] + dt * acc[1]), dt * (v[2] + dt * acc[2]));
       const V3 da_ = v3(dt * (v[3] + dt * acc[3]), dt * (v[4] + dt * acc[4]), dt * (v[5] + dt * acc[5]));
       M3 dR; V3 dp;
@@ -777,15 +823,16 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
       const M3 Rb = quat_to_rot(q + 3);
       const M3 Rn = mul(Rb, dR);
       const V3 pn = mul(Rb, dp) + v3(q[0], q[1], q[2]);
-      if (derivs) { kn[KL.oXN] = pn.x; kn[KL.oXN + 1] = pn.y; kn[KL.oXN + 2] = pn.z; rot_to_quat(Rn, kn + KL.oXN + 3); }
       const M3 Rt = quat_to_rot(xn + 3);
       const M3 GR = tmul(Rt, Rn);
       const V3 Gp = tmul(Rt, pn - v3(xn[0], xn[1], xn[2]));
-      V3 gv, gw;
-      log6(GR, Gp, gv, gw);
-      kn[KL.oF] = gv.x; kn[KL.oF + 1] = gv.y; kn[KL.oF + 2] = gv.z; kn[KL.oF + 3] = gw.x; kn[KL.oF + 4] = gw.y; kn[KL.oF + 5] = gw.z;
-      if (derivs) {
-        Jlog6(GR, Gp, Jl6);
+      if (tid == 0) {
+        if (derivs) { kn[KL.oXN] = pn.x; kn[KL.oXN + 1] = pn.y; kn[KL.oXN + 2] = pn.z; rot_to_quat(Rn, kn + KL.oXN + 3); }
+        V3 gv, gw;
+        log6(GR, Gp, gv, gw);
+        kn[KL.oF] = gv.x; kn[KL.oF + 1] = gv.y; kn[KL.oF + 2] = gv.z; kn[KL.oF + 3] = gw.x; kn[KL.oF + 4] = gw.y; kn[KL.oF + 5] = gw.z;
+        if (derivs) Jlog6(GR, Gp, Jl6);
+      } else {
         Jexp6(dl, da_, Je6);
         // Ad(exp6(delta))^-1 = [[dR^T, -dR^T [dp]x],[0, dR^T]]
         const M3 Sx = skew_m(dp);
@@ -812,16 +859,20 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
       // dvp = dt * da + [0 I 0];  rows nv..n of AB = dvp; rows 6..nv = dt dvp + [I 0 0]; base rows below
       for (int idx = tid; idx < nv * nz; idx += nthr) {
         const int r = idx / nz, z = idx % nz;
-        const double dvp = dt * dsol[(size_t)r * L.nz + z] + ((z == nv + r) ? 1.0 : 0.0);
+        const double da_rz = has_dyn ? -R1[r * ldR + z] : dsol[(size_t)r * L.nz + z];
+        const double dvp = dt * da_rz + ((z == nv + r) ? 1.0 : 0.0);
         kn[KL.oAB + (size_t)(nv + r) * KL.nz + z] = dvp;
         if (r >= 6) kn[KL.oAB + (size_t)r * KL.nz + z] = dt * dvp + ((z == r) ? 1.0 : 0.0);
       }
-      __syncthreads();
+      __syncthreads();  // JL aliases rows of R1
       // base rows: Jlog6(G) ( dt Jexp6 dvp[0:6] + [Jq6 0] )
       for (int idx = tid; idx < 6 * nz; idx += nthr) {
         const int r = idx / nz, z = idx % nz;
         double s = (z < 6) ? Jq6[6 * r + z] : 0.0;
-        for (int l = 0; l < 6; ++l) s += dt * Je6[6 * r + l] * kn[KL.oAB + (size_t)(nv + l) * KL.nz + z];
+        for (int l = 0; l < 6; ++l) {
+          const double da_lz = has_dyn ? -R1[l * ldR + z] : dsol[(size_t)l * L.nz + z];
+          s += dt * Je6[6 * r + l] * (dt * da_lz + ((z == nv + l) ? 1.0 : 0.0));
+        }
         JL[idx] = s;  // temporary (6 x nz)
       }
       __syncthreads();
@@ -835,11 +886,15 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     }
   }
 
+  else {
+    __syncthreads();  // the SE(3) table must be complete before the terms read it
+  }
+
   EV_PROF(10);
   // ---- P13: cost stack and constraints -----------------------------------------------------------------------
   // centre of mass and total momentum (body 0 is the root: its composite = whole robot)
   const S6 h0 = ld6(Hc);
-  int row = 0, rowc = 0;
+  int row = 0, rowc = 0, se3_next = 0;
   // H += JS^T JS (upper triangle, mirrored), grad += JS^T wrs for the rows stacked so far
   auto flush_stack = [&]() {
     const int kc = (rowc + 3) & ~3;  // MFMA K granularity: zero rows up to a multiple of 4
@@ -883,17 +938,11 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     double* Jt = (is_cost && d <= 24) ? JS + rowc * nz : JL;  // staging rows of this term (LDS)
     if (tr.type == MPC_TERM_STATE_ERROR) {
       // r = x_ref (-) x ; J = -I except the base block -Jlog6(Mref^-1 M)
-      double* Jb = small + 108;  // 36
-      double* rfull = Tq;        // n doubles of scratch — the derivative vectors are dead by now
-      if (tid == 0) {
-        const M3 Rr = quat_to_rot(tp + 3), Rb = quat_to_rot(q + 3);
-        const V3 pr = v3(tp[0], tp[1], tp[2]), pb = v3(q[0], q[1], q[2]);
-        V3 ev, ew;
-        log6(tmul(Rb, Rr), tmul(Rb, pr - pb), ev, ew);
-        rfull[0] = ev.x; rfull[1] = ev.y; rfull[2] = ev.z; rfull[3] = ew.x; rfull[4] = ew.y; rfull[5] = ew.z;
-        if (derivs) { Jlog6(tmul(Rr, Rb), tmul(Rr, pb - pr), Jb); for (int e = 0; e < 36; ++e) Jb[e] = -Jb[e]; }
-      }
-      for (int i = 6 + tid; i < n; i += nthr) rfull[i] = (i < nv) ? (tp[i + 1] - q[i + 1]) : (tp[nq + i - nv] - v[i - nv]);
+      // base rows: residual and -Jlog6 block from the SE(3) table (slices that start past the base never read them)
+      const double* sl = se3 + 48 * ((tr.i0 < 6) ? se3_next++ : 0);
+      const double* Jb = sl + 8;  // 36
+      double* rfull = Tq;         // n doubles of scratch — the derivative vectors are dead by now
+      for (int i = tid; i < n; i += nthr) rfull[i] = (i < 6) ? sl[i] : ((i < nv) ? (tp[i + 1] - q[i + 1]) : (tp[nq + i - nv] - v[i - nv]));
       __syncthreads();
       const double* W = P + tr.woff;
       const bool diag = tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT;
@@ -976,17 +1025,10 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
         const M3 Ri = ldm3(oR + 9 * i);
         const M3 Rf = mul(Ri, ldm3(fd + 12 * fi));
         const V3 pf = mul(Ri, ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
-        double* Jl = small + 108;
         if (tr.type == MPC_TERM_FRAME_PLACEMENT) {
-          if (tid == 0) {
-            const M3 Rr = ldm3(tp);
-            const V3 pr = ldv3(tp + 9);
-            V3 ev, ew;
-            log6(tmul(Rr, Rf), tmul(Rr, pf - pr), ev, ew);
-            r[0] = ev.x; r[1] = ev.y; r[2] = ev.z; r[3] = ew.x; r[4] = ew.y; r[5] = ew.z;
-            if (derivs) Jlog6(tmul(Rr, Rf), tmul(Rr, pf - pr), Jl);
-          }
-          __syncthreads();
+          const double* sl = se3 + 48 * se3_next++;
+          const double* Jl = sl + 8;
+          if (tid < 6) r[tid] = sl[tid];
           if (derivs) for (int j = tid; j < nv; j += nthr) if (BELOW(j, i)) {
             const S6 col = mat6_mul(Jl, adinv(Rf, pf, ld6(J + 6 * j)));
             for (int rr = 0; rr < 6; ++rr) Jt[rr * nz + j] = col.v[rr];
@@ -1026,7 +1068,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
         }
       } else if (tr.type == MPC_TERM_CONTACT_FORCE) {
         if (tid < 6) r[tid] = lam[6 * tr.i0 + tid] - tp[tid];
-        if (derivs) for (int idx = tid; idx < 6 * nz; idx += nthr) Jt[idx] = dsol[(size_t)(nv + 6 * tr.i0 + idx / nz) * L.nz + idx % nz];
+        if (derivs) for (int idx = tid; idx < 6 * nz; idx += nthr) Jt[idx] = R2[(6 * tr.i0 + idx / nz) * ldR + idx % nz];
       } else if (tr.type == MPC_TERM_CENTROIDAL_WRENCH_CONE) {
         for (int i = tid; i < d; i += nthr) { double sacc = 0; for (int j = 0; j < 6; ++j) sacc += tp[i * 6 + j] * u[6 * tr.i0 + j]; r[i] = sacc; }
         if (derivs) for (int idx = tid; idx < d * 6; idx += nthr) Jt[(idx / 6) * nz + n + 6 * tr.i0 + idx % 6] = tp[idx];
@@ -1076,7 +1118,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
         if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) {
           const int i = idx / nz, z = idx % nz;
           double s = 0;
-          for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * dsol[(size_t)(nv + 6 * tr.i0 + j) * L.nz + z];
+          for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * R2[(6 * tr.i0 + j) * ldR + z];
           Jt[idx] = s;
         }
       }

@@ -156,12 +156,21 @@ static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_des
   if (n_desc > L.max_stage_ints || n_params > L.max_stage_doubles) throw std::runtime_error("stage table exceeds the capacity given at mpc_create");
   if (n_desc < MPC_STAGE_HEADER_WORDS || n_desc < MPC_STAGE_HEADER_WORDS + MPC_TERM_WORDS * desc[5]) throw std::runtime_error("stage descriptor truncated");
   if (desc[6] > L.c) throw std::runtime_error("stage has more constraint rows than nc_max");
-  int nc = 0;
+  int nc = 0, nse3 = 0;
   for (int t = 0; t < desc[5]; ++t) {
     const int32_t* w = desc + MPC_STAGE_HEADER_WORDS + MPC_TERM_WORDS * t;
     if (w[1] != MPC_ROLE_COST) nc += w[2];
     if (w[2] > 24 && s->dims.space == MPC_SPACE_VECTOR) throw std::runtime_error("residual dimension too large for the vector-space kernel");
+    if (s->dims.space == MPC_SPACE_MULTIBODY) {
+      // whole-body kernel limits: LDS staging rows of a constraint term, slots of the SE(3) table
+      const bool selector = (w[0] == MPC_TERM_STATE_ERROR && w[3] >= 6) || w[0] == MPC_TERM_CONTROL_ERROR;
+      if (w[1] != MPC_ROLE_COST && !selector && w[2] > MB_STAGE_CONSTRAINT_ROWS) throw std::runtime_error("constraint term too large for the whole-body kernel's LDS staging rows");
+      const bool diag_sel = (w[0] == MPC_TERM_STATE_ERROR || w[0] == MPC_TERM_CONTROL_ERROR) && (w[7] & MPC_TERM_FLAG_DIAG_WEIGHT);
+      if (w[1] == MPC_ROLE_COST && !diag_sel && w[2] > 24) throw std::runtime_error("cost term too large for the whole-body kernel's LDS staging rows (dense weights: dim <= 24)");
+      if (w[0] == MPC_TERM_FRAME_PLACEMENT || (w[0] == MPC_TERM_STATE_ERROR && w[3] < 6)) ++nse3;
+    }
   }
+  if (nse3 > MB_SE3_SLOTS) throw std::runtime_error("too many SE(3)-valued terms in one stage for the whole-body kernel");
   if (nc != desc[6]) throw std::runtime_error("stage descriptor: constraint row count mismatch");
   std::memcpy(s->h_desc.data() + (size_t)slot * L.max_stage_ints, desc, n_desc * sizeof(int32_t));
   HIP_OK(hipMemcpyAsync(s->d_stage_desc + (size_t)slot * L.max_stage_ints, desc, n_desc * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
