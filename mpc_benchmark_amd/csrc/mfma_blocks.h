@@ -11,20 +11,32 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // acc += sum_{k<K} A(i,k) * B(k,j) for one 16x16 tile; A(i,k) at A[i*a_is + k*a_ks], B(k,j) at B[k*b_ks + j*b_js].
 // Fragment layout of v_mfma_f64_16x16x4_f64: lane l supplies A(l&15, l>>4) and B(l>>4, l&15); result register r of
 // lane l is C((l>>4) + 4r, l&15).  K must be a multiple of 4; groups of 16 are software-pipelined.
+// The k-loop is software-pipelined by hand: the eight operands of the next 16-deep group are requested from LDS
+// before the four (dependent) MFMAs of the current group issue, and the scheduler is fenced so that it cannot
+// sink those loads back below the MFMAs — with one or two wavefronts per SIMD nothing else hides the LDS latency.
 template <bool NEG>
 DEV void mma_tile(d4_t& acc, const double* A, int a_is, int a_ks, const double* B, int b_ks, int b_js, int K, int lane) {
   const int i = lane & 15, kk = lane >> 4;
   const double* ap = A + i * a_is + kk * a_ks;
   const double* bp = B + kk * b_ks + i * b_js;
+  const int Kmain = K & ~15;
   int k0 = 0;
-  for (; k0 + 16 <= K; k0 += 16) {
-    double a0 = ap[k0 * a_ks], a1 = ap[(k0 + 4) * a_ks], a2 = ap[(k0 + 8) * a_ks], a3 = ap[(k0 + 12) * a_ks];
-    const double b0 = bp[k0 * b_ks], b1 = bp[(k0 + 4) * b_ks], b2 = bp[(k0 + 8) * b_ks], b3 = bp[(k0 + 12) * b_ks];
-    if (NEG) { a0 = -a0; a1 = -a1; a2 = -a2; a3 = -a3; }
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
+  if (Kmain > 0) {
+    double a0 = ap[0], a1 = ap[4 * a_ks], a2 = ap[8 * a_ks], a3 = ap[12 * a_ks];
+    double b0 = bp[0], b1 = bp[4 * b_ks], b2 = bp[8 * b_ks], b3 = bp[12 * b_ks];
+    for (; k0 < Kmain; k0 += 16) {
+      const int kn = (k0 + 16 < Kmain) ? k0 + 16 : k0;  // the last group re-requests its own operands (unused)
+      const double na0 = ap[kn * a_ks], na1 = ap[(kn + 4) * a_ks], na2 = ap[(kn + 8) * a_ks], na3 = ap[(kn + 12) * a_ks];
+      const double nb0 = bp[kn * b_ks], nb1 = bp[(kn + 4) * b_ks], nb2 = bp[(kn + 8) * b_ks], nb3 = bp[(kn + 12) * b_ks];
+      __builtin_amdgcn_sched_barrier(0);
+      if (NEG) { a0 = -a0; a1 = -a1; a2 = -a2; a3 = -a3; }
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = na0; a1 = na1; a2 = na2; a3 = na3; b0 = nb0; b1 = nb1; b2 = nb2; b3 = nb3;
+    }
   }
   for (; k0 < K; k0 += 4) {
     const double av = NEG ? -ap[k0 * a_ks] : ap[k0 * a_ks];

@@ -144,7 +144,8 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   o.max_iters = 100; o.max_al_iters = 100; o.force_initial_condition = 1; o.rollout_linear = 1; o.ls_max_steps = 8;
   o.num_threads = 1; o.riccati_legs = 1; o.reserved = 0;
   HIP_OK(hipFuncSetAttribute((const void*)k_riccati_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  s->ric = make_ric_lds(L.n, L.m, L.c);
+  s->ric = make_ric_lds(L.n, L.m, L.c, 1);
+  if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0);  // panel-wise G when the whole G does not fit
   s->use_mfma_riccati = s->ric.total_bytes <= 160 * 1024 && !getenv("MPC_HIP_GENERIC_RICCATI");
   if (s->use_mfma_riccati)
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));

@@ -20,20 +20,24 @@
 #ifndef RIC_THREADS
 #define RIC_THREADS 512  // 8 wavefronts (2 per SIMD): the sweep is latency-bound, a second wave per SIMD hides LDS / MFMA latency
 #endif
+#define RIC_MAX_SERIES 8
+#define RIC_SERIES_TILES ((21 * 64 + RIC_THREADS - 1) / RIC_THREADS)  // lower-triangle output tiles per wavefront: nb <= 6  // Neumann terms before falling back to the factorisation of I + mu_d Ph
+#define RIC_G_TILES ((48 * 64 + RIC_THREADS - 1) / RIC_THREADS)  // tiles of G per wavefront: nb <= 6, nzt <= 8
 #define AB_ROWS (96 * 64 / RIC_THREADS)  // register prefetch capacity: np <= 96 rows, nzp <= 128 columns
 
 // phase timing (shader clock) accumulated over the knots; read back with mpc_debug_get("ric_prof")
 #define RIC_PROF(slot) do { if (tid == 0 && a.prof) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 struct RicLds {
-  int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
+  int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb, gfull;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
   int PT, R1, LP, LI, AB, GP, vec, iwork, total_bytes;
   // KKT / value-update workspace carved from R1 once AB is dead
   int Lr, LIr, W, ST, CT, VX, Y, SC, LIs;
 };
 
-static inline RicLds make_ric_lds(int n, int m, int c) {
+static inline RicLds make_ric_lds(int n, int m, int c, int gfull = 1) {
   RicLds s;
+  s.gfull = gfull;  // 1: G = Pt [A B] kept whole (x part over PT, u part in GP) — needs np x mp doubles for GP instead of np x 16
   s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.ldl = s.np + 1; s.ldr = s.mp + 1;
   s.nb = s.np / 16; s.nbm = s.mp / 16;
   s.lw = s.np + 16;  // W = [K | pad | k | pad]: x-columns at 0..n-1, the feed-forward column at np
@@ -45,7 +49,7 @@ static inline RicLds make_ric_lds(int n, int m, int c) {
   s.LP = take(s.np * s.ldl); s.LI = take(s.nb * 272);             // phase 1 view of R1
   const int end1 = o;
   o = s.R1;
-  s.AB = take(s.np * s.nzp); s.GP = take(s.np * 16);               // phase 2 view (overlaps phase 1)
+  s.AB = take(s.np * s.nzp); s.GP = take(s.np * (gfull ? s.mp : 16));               // phase 2 view (overlaps phase 1)
   const int end2 = o;
   o = s.R1;                                                         // phase 3 view (overlaps AB)
   s.Lr = take(s.mp * s.ldr); s.LIr = take(s.nbm * 272); s.W = take(s.mp * s.lw); s.ST = take(s.mp * s.np);
@@ -110,6 +114,7 @@ __global__ void __launch_bounds__(RIC_THREADS) k_riccati_mfma(SolverArgs a, RicL
   double *ph = vec, *ft = vec + nzp, *vv = vec + 2 * nzp, *w = vec + 3 * nzp, *gh = vec + 4 * nzp, *pvec = vec + 5 * nzp, *dtl = vec + 6 * nzp;
   double* kvc = dtl + L.c;
   double* e6l = kvc + L.c;  // 36 doubles; vec reserves 8 (nzp + c) + 64
+  double* wred = e6l + 40;  // per-wavefront partial sums (<= 16)
   double* wk = a.work + (size_t)b * L.work_stride;
   double* Hh = wk + L.wHh;  // nz x nz, leading dimension nz (L2-resident scratch)
 
@@ -197,9 +202,14 @@ __global__ void __launch_bounds__(RIC_THREADS) k_riccati_mfma(SolverArgs a, RicL
     for (int i = tid; i < n; i += nthr) ft[i] = kn[L.oF + i] + mud * le[i];
     __syncthreads();
     RIC_PROF(1);
-    // ---- 2. LP = I + mud Ph ; vv = Ph ft + ph ----
-    for (int i = wv; i < np; i += nw)
-      for (int j = lane; j < np; j += 64) LP[i * ldl + j] = mud * PT[i * ldp + j] + (i == j ? 1.0 : 0.0);
+    // ---- 2. LP = Ph, ||Ph||_F ; vv = Ph ft + ph ----
+    {
+      double ss = 0;
+      for (int i = wv; i < np; i += nw)
+        for (int j = lane; j < np; j += 64) { const double pv = PT[i * ldp + j]; LP[i * ldl + j] = pv; ss += pv * pv; }
+      ss = wave_sum_r(ss);
+      if (lane == 0) wred[wv] = ss;
+    }
     for (int i = wv; i < n; i += nw) {
       double s = 0;
       for (int j = lane; j < n; j += 64) s += PT[i * ldp + j] * ft[j];
@@ -208,9 +218,74 @@ __global__ void __launch_bounds__(RIC_THREADS) k_riccati_mfma(SolverArgs a, RicL
     }
     __syncthreads();
     RIC_PROF(2);
-    if (!chol_blocked(LP, ldl, nb, LI, tid, iflag)) { if (tid == 0) a.inst[b].done = 2; return; }
-    RIC_PROF(3);
-    // [A B] of this knot: issue the HBM loads here (the triangular solves below hide their latency), park them in
+    // Pt = (I + X)^-1 Ph with X = mu_d Ph, ||X||_2 <= rho = mu_d ||Ph||_F.  mu_d = dyn_al_scale * mu is tiny, so the
+    // Neumann series Ph (I - X + X^2 - ...) reaches double precision after a few terms (remainder <= rho^(nser+1)):
+    // nser in-place Horner steps T <- Ph - mu_d T Ph on the matrix cores replace the n x n factorisation and the
+    // two triangular solves.  Larger rho falls back to the Cholesky path.
+    int nser = 0;
+    {
+      double fro = 0;
+      for (int q = 0; q < nw; ++q) fro += wred[q];
+      const double rho = mud * sqrt(fro);
+      double rem = rho;
+      while (rem > 1e-16 && nser < RIC_MAX_SERIES) { rem *= rho; ++nser; }
+      if (rem > 1e-16) nser = -1;
+      if (tid == 0 && a.prof) {
+        double* pr = a.prof + (size_t)b * 64;
+        pr[20] = fmax(pr[20], rho); pr[21] += (nser >= 0) ? nser : 0; pr[22] += (nser < 0) ? 1.0 : 0.0;
+      }
+    }
+    RIC_PROF(13);
+    if (nser >= 0) {
+      // ---- 3a. series: every iterate is a polynomial in the symmetric Ph, hence symmetric — only the lower block
+      // triangle of 16x16 tiles is computed (dealt round-robin to the wavefronts) and mirrored on the way out;
+      // products first, barrier, then the in-place update of PT
+      const int ntile = nb * (nb + 1) / 2;
+      for (int it = 0; it < nser; ++it) {
+        d4_t res[RIC_SERIES_TILES];
+        int tri[RIC_SERIES_TILES], tcj[RIC_SERIES_TILES];
+#pragma unroll
+        for (int sidx = 0; sidx < RIC_SERIES_TILES; ++sidx) {
+          const int t = wv + sidx * nw;
+          res[sidx] = d4_t{0, 0, 0, 0};
+          int ri = 0, rem = t;
+          while (rem > ri) { rem -= ri + 1; ++ri; }  // t = ri (ri + 1) / 2 + cj, cj <= ri
+          tri[sidx] = ri; tcj[sidx] = rem;
+          if (t < ntile) mma_tile<false>(res[sidx], PT + (ri * 16) * ldp, ldp, 1, LP + rem * 16, ldl, 1, np, lane);
+        }
+        RIC_PROF(14);
+        __syncthreads();
+        RIC_PROF(15);
+#pragma unroll
+        for (int sidx = 0; sidx < RIC_SERIES_TILES; ++sidx) {
+          const int t = wv + sidx * nw;
+          if (t < ntile) {
+            const int r0 = tri[sidx] * 16 + (lane >> 4), c0 = tcj[sidx] * 16 + (lane & 15);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const double v = LP[(r0 + 4 * q) * ldl + c0] - mud * res[sidx][q];
+              PT[(r0 + 4 * q) * ldp + c0] = v;
+              if (tri[sidx] != tcj[sidx]) PT[c0 * ldp + r0 + 4 * q] = v;
+            }
+          }
+        }
+        __syncthreads();
+        RIC_PROF(16);
+      }
+      RIC_PROF(3);
+    } else {
+      // ---- 3b. LP <- I + mud Ph = L L^T ; PT <- (L L^T)^-1 PT ----
+      for (int i = wv; i < np; i += nw)
+        for (int j = lane; j < np; j += 64) LP[i * ldl + j] = mud * LP[i * ldl + j] + (i == j ? 1.0 : 0.0);
+      __syncthreads();
+      if (!chol_blocked(LP, ldl, nb, LI, tid, iflag)) { if (tid == 0) a.inst[b].done = 2; return; }
+      RIC_PROF(3);
+      trsm_fwd_blocked(LP, ldl, LI, nb, PT, ldp, nb, wv, nw, lane);
+      trsm_bwd_blocked(LP, ldl, LI, nb, PT, ldp, nb, wv, nw, lane);
+      __syncthreads();
+    }
+    RIC_PROF(5);
+    // [A B] of this knot: issue the HBM loads here (the vector work below hides part of their latency), park them in
     // registers, drop them into LDS in step 4
     double abr[AB_ROWS][2];
 #pragma unroll
@@ -224,11 +299,6 @@ __global__ void __launch_bounds__(RIC_THREADS) k_riccati_mfma(SolverArgs a, RicL
         if (z1 < nzp) { if (z1 < n) abr[q][1] = src[z1]; else if (z1 >= np && z1 - np < m) abr[q][1] = src[n + z1 - np]; }
       }
     }
-    // ---- 3. PT <- (L L^T)^-1 PT ----
-    trsm_fwd_blocked(LP, ldl, LI, nb, PT, ldp, nb, wv, nw, lane);
-    trsm_bwd_blocked(LP, ldl, LI, nb, PT, ldp, nb, wv, nw, lane);
-    __syncthreads();
-    RIC_PROF(5);
     // w = vv - mud Pt vv, store Pt / yv for the forward sweep (Pt is symmetric up to rounding)
     for (int i = wv; i < n; i += nw) {
       double s = 0;
@@ -250,6 +320,54 @@ __global__ void __launch_bounds__(RIC_THREADS) k_riccati_mfma(SolverArgs a, RicL
       if (z >= 0) { double s = kn[L.oG + z]; for (int i = 0; i < n; ++i) s += AB[i * nzp + zp] * w[i]; gh[z] = s; }
     }
     RIC_PROF(7);
+    if (S.gfull) {
+    // ---- 5. G = Pt [A B] : every 16x16 tile dealt round-robin to the wavefronts, kept in registers until all of
+    // them are done (barrier), then G_x overwrites PT (Pt itself is no longer needed: it went to the gain record
+    // above) and G_u goes to GP ; Hh = H + [A B]^T G on the lower block triangle only (Hh is symmetric) ----
+    {
+      const int ngt = nb * nzt;
+      d4_t gres[RIC_G_TILES];
+#pragma unroll
+      for (int sidx = 0; sidx < RIC_G_TILES; ++sidx) {
+        const int t = wv + sidx * nw;
+        gres[sidx] = d4_t{0, 0, 0, 0};
+        if (t < ngt) mma_tile<false>(gres[sidx], PT + (t / nzt) * 16, 1, ldp, AB + (t % nzt) * 16, nzp, 1, np, lane);  // Pt symmetric
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sidx = 0; sidx < RIC_G_TILES; ++sidx) {
+        const int t = wv + sidx * nw;
+        if (t < ngt) {
+          const int ri = t / nzt, cj = t % nzt;
+          if (cj < nb) tile_store(PT + (ri * 16) * ldp + cj * 16, ldp, gres[sidx], lane);
+          else tile_store(GP + (ri * 16) * mp + (cj - nb) * 16, mp, gres[sidx], lane);
+        }
+      }
+      __syncthreads();
+      const int nht = nzt * (nzt + 1) / 2;
+      for (int t = wv; t < nht; t += nw) {
+        int zi = 0, cj = t;
+        while (cj > zi) { cj -= zi + 1; ++zi; }  // t = zi (zi + 1) / 2 + cj, cj <= zi
+        const int col_p = cj * 16 + (lane & 15);
+        const int zc = (col_p < n) ? col_p : ((col_p >= np && col_p - np < m) ? n + col_p - np : -1);
+        int zr[4];
+        double h[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // H loads are in flight while the matrix cores work
+          const int rp = zi * 16 + (lane >> 4) + 4 * q;
+          zr[q] = (rp < n) ? rp : ((rp >= np && rp - np < m) ? n + rp - np : -1);
+          h[q] = (zr[q] >= 0 && zc >= 0) ? kn[L.oH + zr[q] * nz + zc] : 0.0;
+        }
+        d4_t acc = d4_t{0, 0, 0, 0};
+        if (cj < nb) mma_tile<false>(acc, AB + zi * 16, 1, nzp, PT + cj * 16, ldp, 1, np, lane);
+        else mma_tile<false>(acc, AB + zi * 16, 1, nzp, GP + (cj - nb) * 16, mp, 1, np, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (zr[q] >= 0 && zc >= 0) Hh[zr[q] * nz + zc] = h[q] + acc[q];
+      }
+      __syncthreads();
+    }
+    } else {
     // ---- 5. panels: G_j = Pt AB_j ; Hh[:, j] = H[:, j] + AB^T G_j ----
     for (int cj = 0; cj < nzt; ++cj) {
       for (int r0 = wv; r0 < nb; r0 += 2 * nw) {
@@ -289,12 +407,13 @@ __global__ void __launch_bounds__(RIC_THREADS) k_riccati_mfma(SolverArgs a, RicL
       }
       __syncthreads();
     }
+    }
     RIC_PROF(8);
     // ---- 6. stage KKT (AB is dead: R1 is reused) ----
     const bool small_ca = ca <= 16;
     // Lr = sym(Hh_uu) padded with identity ; W = -[Sh^T | rh] (mp x lw, zero padded) ; ST = Sh^T (mp x np)
     for (int i = wv; i < mp; i += nw) {
-      for (int j = lane; j < mp; j += 64) Lr[i * ldr + j] = (i < m && j < m) ? 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]) : (i == j ? 1.0 : 0.0);
+      for (int j = lane; j < mp; j += 64) Lr[i * ldr + j] = (i < m && j < m) ? Hh[(n + (i > j ? i : j)) * nz + n + (i > j ? j : i)] : (i == j ? 1.0 : 0.0);  // lower triangle of Hh_uu
       for (int z = lane; z < lw; z += 64) {
         double sv = 0.0;
         if (i < m) { if (z < n) sv = Hh[(n + i) * nz + z]; else if (z == np) sv = gh[n + i]; }
@@ -431,7 +550,7 @@ __global__ void __launch_bounds__(RIC_THREADS) k_riccati_mfma(SolverArgs a, RicL
         const int col = cj * 16 + (lane & 15);
         double qh[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; qh[q] = (row < n && col < n) ? Hh[row * nz + col] : 0.0; }
+        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; qh[q] = (row < n && col < n) ? (ri >= cj ? Hh[row * nz + col] : Hh[col * nz + row]) : 0.0; }  // Hh: lower block triangle only
         d4_t acc = d4_t{0, 0, 0, 0};
         mma_tile<false>(acc, ST + ri * 16, 1, np, W + cj * 16, lw, 1, mp, lane);
         if (kc > 0) mma_tile<false>(acc, CTl + ri * 16, 1, lw, VXl + cj * 16, lw, 1, kc, lane);
@@ -447,7 +566,7 @@ __global__ void __launch_bounds__(RIC_THREADS) k_riccati_mfma(SolverArgs a, RicL
         for (int s = lane; s < np; s += 64) {
           double t = 0.0;
           if (r < n && s < n) {
-            t = Hh[r * nz + s];
+            t = Hh[(r >= s ? r : s) * nz + (r >= s ? s : r)];  // lower triangle of Hh
             for (int i = 0; i < m; ++i) t += ST[i * np + r] * W[i * lw + s];
             for (int i = 0; i < ca; ++i) t += Ct[i * nz + r] * V[i * nr + s];
           }

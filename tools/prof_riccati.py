@@ -25,3 +25,6 @@ tn = ['', 'state_error', 'control_error', 'frame_placement', 'frame_translation'
 for t in range(1, 14):
     if p[32 + 13 + t] > 0: print('EVAL term %-24s %8.1f us' % (tn[t], p[32 + 13 + t] / 3 / 2400.0))
 print('EVAL flush_stack %8.1f us' % (p[32 + 27] / 3 / 2400.0))
+print('RIC series: max rho %.3e, mean terms %.2f, chol fallbacks/knot %.3f' % (p[20], p[21] / 300, p[22] / 300))
+for i_, n_ in ((13, 'norm+abr issue'), (14, 'series mma (wave 0)'), (15, 'series barrier wait'), (16, 'series store+barrier')):
+    print('RIC fine %-24s %8.1f us/knot' % (n_, p[i_] / 300 / 2400.0))
