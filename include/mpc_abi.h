@@ -194,7 +194,8 @@ int mpc_debug_evaluate(mpc_solver* s, const double* xs, const double* us);
 
 /* Per-kernel timing with device events on the solver's own stream (the reference only has wall-clock
  * timers around run(): fulldynamic_talos.py:538-543).  mpc_profile(s, 1) starts recording, (s, 0) stops,
- * (s, 2) clears.  mpc_profile_read returns the number of kernel slots; for slot i it fills the kernel
+ * (s, 2) clears; (s, 3) / (s, 4) switch the in-kernel phase timers (shader-clock counters of the Riccati and stage
+ * kernels, read with mpc_debug_get("ric_prof")) on / off — developer tooling, off by default.  mpc_profile_read returns the number of kernel slots; for slot i it fills the kernel
  * name, the number of launches recorded and their summed duration in milliseconds.  The oracle reports
  * zero slots. */
 int mpc_profile(mpc_solver* s, int32_t mode);

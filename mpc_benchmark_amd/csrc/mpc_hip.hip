@@ -38,6 +38,7 @@ struct mpc_solver {
   InstState* d_inst = nullptr;
   int* d_all_done = nullptr;
   double* d_prof = nullptr;
+  bool phase_timers = false;
   std::vector<void*> allocs;
   // host mirrors of the stage tables (needed for ring-buffer bookkeeping and debug)
   std::vector<int32_t> h_desc;
@@ -88,7 +89,7 @@ struct mpc_solver {
     a.stage_desc = d_stage_desc; a.stage_params = d_stage_params; a.model_i = d_model_i; a.model_d = d_model_d;
     a.xs = d_xs; a.us = d_us; a.vs = d_vs; a.lams = d_lams; a.vs_e = d_vs_e; a.lams_e = d_lams_e; a.x0 = d_x0;
     a.dxs = d_dxs; a.dus = d_dus; a.dvs = d_dvs; a.dlams = d_dlams;
-    a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = d_prof;
+    a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = phase_timers ? d_prof : nullptr;
     return a;
   }
   size_t riccati_lds() const {
@@ -360,6 +361,7 @@ int mpc_set_x0(mpc_solver* s, const double* x0) {
 int mpc_profile(mpc_solver* s, int32_t mode) {
   MPC_TRY(s, {
     if (mode == 2) { for (auto& p : s->prof) p.used = 0; }
+    else if (mode == 3 || mode == 4) s->phase_timers = (mode == 3);  // in-kernel phase timers (developer tooling, perturbs timing)
     else s->profiling = (mode != 0);
   })
 }

@@ -20,13 +20,23 @@
 #ifndef RIC_THREADS
 #define RIC_THREADS 512  // 8 wavefronts (2 per SIMD): the sweep is latency-bound, a second wave per SIMD hides LDS / MFMA latency
 #endif
+#if RIC_THREADS <= 256
+#define RIC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))  // one wavefront per SIMD: the whole 512-entry register file
+#else
+#define RIC_WAVES_ATTR
+#endif
 #define RIC_MAX_SERIES 8
 #define RIC_SERIES_TILES ((21 * 64 + RIC_THREADS - 1) / RIC_THREADS)  // lower-triangle output tiles per wavefront: nb <= 6  // Neumann terms before falling back to the factorisation of I + mu_d Ph
 #define RIC_G_TILES ((48 * 64 + RIC_THREADS - 1) / RIC_THREADS)  // tiles of G per wavefront: nb <= 6, nzt <= 8
 #define AB_ROWS (96 * 64 / RIC_THREADS)  // register prefetch capacity: np <= 96 rows, nzp <= 128 columns
 
 // phase timing (shader clock) accumulated over the knots; read back with mpc_debug_get("ric_prof")
-#define RIC_PROF(slot) do { if (tid == 0 && a.prof) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
+// The sweep is one long loop over the knots with ~15 phases per knot; left alone, the compiler hoists every per-lane
+// index expression of every phase out of the knot loop and then spills those ~300 loop invariants to scratch, and
+// each reload (s_waitcnt vmcnt(0)) also drains the global loads in flight.  Passing the lane ids through an empty
+// asm at each phase boundary makes all index arithmetic phase-local: recomputed (a few integer ops), never spilled.
+#define RIC_LAUNDER() do { asm volatile("" : "+v"(tid), "+v"(lane)); wv = __builtin_amdgcn_readfirstlane(tid >> 6); } while (0)
+#define RIC_PROF(slot) do { RIC_LAUNDER(); if (tid == 0 && a.prof) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 struct RicLds {
   int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb, gfull;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
@@ -97,9 +107,10 @@ DEV double wave_sum_r(double v) {
 
 // ============================================================================================================
 // one wavefront per SIMD (LDS-bound occupancy anyway): let the register allocator use the whole 512-entry file
-__global__ void __launch_bounds__(RIC_THREADS) k_riccati_mfma(SolverArgs a, RicLds S) {
+__global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(SolverArgs a, RicLds S) {
   const Layout& L = a.L;
-  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nthr >> 6;
+  const int b = blockIdx.x, nthr = blockDim.x, nw = nthr >> 6;
+  int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // re-derived at every phase boundary (RIC_LAUNDER)
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
   const int n = L.n, nz = L.nz, N = L.N, nr = n + 1;
@@ -288,15 +299,20 @@ __global__ void __launch_bounds__(RIC_THREADS) k_riccati_mfma(SolverArgs a, RicL
     // [A B] of this knot: issue the HBM loads here (the vector work below hides part of their latency), park them in
     // registers, drop them into LDS in step 4
     double abr[AB_ROWS][2];
+    {
+      // column of [A B] behind padded column zp (x columns 0..n-1, u columns np..np+m-1), clamped to a valid one so
+      // that every load is unconditional (straight-line code: the loads of all rows are in flight together)
+      const int z0 = lane, z1 = lane + 64;
+      const bool ok0 = z0 < n || (z0 >= np && z0 - np < m), ok1 = z1 < n || (z1 >= np && z1 - np < m);
+      const int c0 = ok0 ? (z0 < n ? z0 : n + z0 - np) : 0, c1 = ok1 ? (z1 < n ? z1 : n + z1 - np) : 0;
+      const double* ab0 = kn + L.oAB;
 #pragma unroll
-    for (int q = 0; q < AB_ROWS; ++q) {
-      const int i = wv + nw * q;
-      abr[q][0] = 0.0; abr[q][1] = 0.0;
-      if (i < n) {
-        const double* src = kn + L.oAB + (size_t)i * nz;
-        const int z0 = lane, z1 = lane + 64;
-        if (z0 < n) abr[q][0] = src[z0]; else if (z0 >= np && z0 - np < m) abr[q][0] = src[n + z0 - np];
-        if (z1 < nzp) { if (z1 < n) abr[q][1] = src[z1]; else if (z1 >= np && z1 - np < m) abr[q][1] = src[n + z1 - np]; }
+      for (int q = 0; q < AB_ROWS; ++q) {
+        const int i = wv + nw * q;  // wave-uniform row
+        const double* src = ab0 + (size_t)(i < n ? i : 0) * nz;
+        const double v0 = src[c0], v1 = src[c1];
+        abr[q][0] = (ok0 && i < n) ? v0 : 0.0;
+        abr[q][1] = (ok1 && i < n) ? v1 : 0.0;
       }
     }
     // w = vv - mud Pt vv, store Pt / yv for the forward sweep (Pt is symmetric up to rounding)

@@ -9,6 +9,7 @@ pd = FullDynamicsProblem(horizon=100, complete_model=True)
 ens = EnsembleMPC(pd, batch=4, library=lib)
 ens.prepare_schedule(10)
 ens.cold_solve(100)
+ens.native.profile(3)  # in-kernel phase timers on
 ens.native.debug_get('ric_prof', 0)
 for _ in range(3): ens.step()
 p = ens.native.debug_get('ric_prof', 0)
