@@ -194,7 +194,10 @@ static inline size_t multibody_work_doubles(const Layout& L) {
   return (size_t)(nv + 12) * L.nz + 2 * (size_t)24 * L.nz + 64;
 }
 
-#define EV_PROF(slot) do { if (!TRIAL && tid == 0 && a.prof && k == 1) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + 32 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
+// lane ids pass through an empty asm at every phase boundary: index arithmetic stays phase-local instead of being
+// kept live (and spilled) across the whole kernel — see RIC_LAUNDER in riccati_mfma.h
+#define EV_LAUNDER() do { asm volatile("" : "+v"(tid)); lane = tid & 63; wv = __builtin_amdgcn_readfirstlane(tid >> 6); } while (0)
+#define EV_PROF(slot) do { EV_LAUNDER(); if (!TRIAL && tid == 0 && a.prof && k == 1) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + 32 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 struct MbArgs {
   MbLds lds;
@@ -207,7 +210,8 @@ template <int TRIAL>
 __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, Layout KL, double* records, MbArgs mb, int cand0) {
   const Layout& L = a.L;
   const MbLds& S = mb.lds;
-  const int k = blockIdx.x, b = blockIdx.y, cand = blockIdx.z + cand0, tid = threadIdx.x, nthr = blockDim.x;
+  const int k = blockIdx.x, b = blockIdx.y, cand = blockIdx.z + cand0, nthr = blockDim.x;
+  int tid = threadIdx.x;
   const InstState& st = a.inst[b];
   if (st.done || (TRIAL && st.skip_step)) return;
   if (TRIAL && cand > 0 && !st.ls_more) return;  // the full step was accepted: no backtracking candidates needed
@@ -243,7 +247,8 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   double *M = sm + S.M, *LIm = sm + S.LIm, *Y16 = sm + S.Y16, *V16 = sm + S.V16, *Sp = sm + S.Sp, *LIs = sm + S.LIs, *Rm = sm + S.R, *Jc = sm + S.Jc;
   double *gam = sm + S.gam, *bias = sm + S.bias, *acc = sm + S.a, *lam = sm + S.lam;
   const int nvp = S.nvp, ldm = S.ldm, nbm = S.nbm, ldR = S.ldR, ncb = S.ncb;
-  const int lane = tid & 63, wv = tid >> 6, nw = nthr >> 6;
+  int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = nthr >> 6;
   double *x = sm + S.x, *u = sm + S.u, *xn = sm + S.xn, *cfr = sm + S.cfr, *small = sm + S.small, *red = sm + S.red;
   __shared__ int iflag[2];
   __shared__ double s_cost;
