@@ -209,7 +209,13 @@ static void launch_pass(mpc_solver* s) {
     if (s->use_mfma_riccati) hipLaunchKernelGGL(k_riccati_mfma, dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
     else hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);
   });
-  s->timed(4, "k_forward", [&] { hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(1024), (L.nz + 2 * L.n) * sizeof(double), s->stream, a); });
+  s->timed(4, "k_forward", [&] {
+    const size_t fw_lds = (L.nz + 2 * L.n) * sizeof(double);
+    const bool fits = L.nz <= 128 && L.n + L.m <= L.nz;
+    if (fits && L.n <= 80 && L.m <= 32) hipLaunchKernelGGL((k_forward_prefetch<4, 10>), dim3(L.B), dim3(512), fw_lds, s->stream, a);
+    else if (fits && L.n <= 80 && L.m <= 48) hipLaunchKernelGGL((k_forward_prefetch<6, 10>), dim3(L.B), dim3(512), fw_lds, s->stream, a);
+    else hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(1024), fw_lds, s->stream, a);
+  });
   s->timed(5, "k_duals", [&] { hipLaunchKernelGGL(k_duals, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   // linesearch: evaluate the full step first; the backtracking candidates alpha = 2^-i, i >= 1, are only
   // evaluated for instances whose full step failed the Armijo test (their workgroups exit immediately otherwise)

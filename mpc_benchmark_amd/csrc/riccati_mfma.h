@@ -100,10 +100,7 @@ DEV void inv6_unrolled(const double* A, double* Ainv) {
     for (int j = 0; j < 6; ++j) Ainv[i * 6 + j] = M[i][6 + j];
 }
 
-DEV double wave_sum_r(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return __shfl(v, 0, 64);
-}
+DEV double wave_sum_r(double v) { return wave_sum(v); }  // DPP reduction of solver_kernels.h
 
 // ============================================================================================================
 // one wavefront per SIMD (LDS-bound occupancy anyway): let the register allocator use the whole 512-entry file

@@ -364,9 +364,25 @@ __global__ void __launch_bounds__(256) k_riccati_backward(SolverArgs a) {
 // P7: du_k = K dx_k + k ; y = A dx_k + B du_k + yv ; dx_{k+1} = T (y - mud Pt y).  grid B, block 256.
 // Every product is a wave-per-row dot product with coalesced row reads and a shuffle reduction.
 // ------------------------------------------------------------------------------------------------
+// Sum over the 64 lanes on the DPP network (row shifts inside 16-lane rows, then the two row broadcasts of gfx9) — no
+// LDS permutes (ds_bpermute, what __shfl_down compiles to, costs an LDS round trip per step); result broadcast from lane 63.
+template <int CTRL, int ROW_MASK>
+DEV double dpp_add(double v) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xffffffffll), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, ROW_MASK, 0xf, true);
+  return v + __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 DEV double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return __shfl(v, 0, 64);
+  v = dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of every row holds the row sum
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // 16 wavefronts per instance: the sweep is a chain of latency-bound mat-vecs, more waves = more HBM loads in flight
 __global__ void __launch_bounds__(1024) k_forward(SolverArgs a) {
@@ -414,6 +430,109 @@ __global__ void __launch_bounds__(1024) k_forward(SolverArgs a) {
       a.dxs[((size_t)b * (N + 1) + k + 1) * n + i] = s;
     }
     __syncthreads();
+  }
+}
+
+// Same sweep with the operands of knot k+1 (rows of K, [A B], Pt and the small vectors) requested from HBM while
+// knot k computes: the matrices do not depend on the recursion, only the vectors do, so every wavefront keeps "its"
+// rows of the next knot in registers (<= 3 rows of K, 6 of [A B] and Pt, two columns per lane) and the chain of
+// mat-vecs never waits on memory.  The barrier is a bare s_barrier behind the LDS counter, so that the loads in
+// flight are not drained.  FW_KR / FW_NR = rows of K / of [A B] and Pt per wavefront (8 wavefronts, up to 256 registers each): m <= 8 FW_KR,
+// n <= 8 FW_NR, n + m <= 128.
+#define FW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <int FW_KR, int FW_NR>
+__global__ void __launch_bounds__(512) k_forward_prefetch(SolverArgs a) {
+  const Layout& L = a.L;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row addresses are SGPR base + lane offset
+  const InstState& st = a.inst[b];
+  if (st.done || st.skip_step) return;
+  const int n = L.n, N = L.N, m = L.m, nz = L.nz;
+  const double mud = st.mu * a.opt.dyn_al_scale;
+  const bool ff = L.space == MPC_SPACE_MULTIBODY;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* dz = lds;           // [dx; du]  (nz)
+  double* y = lds + nz;       // n
+  double* z = y + n;          // n
+  double Kr[FW_KR][2], kf[FW_KR], ABr[FW_NR][2], mxv[FW_NR], Mr[FW_NR][2], t6[6];
+  const int c0 = lane, c1 = lane + 64;
+  const int cn0 = c0 < n ? c0 : n - 1, cn1 = c1 < n ? c1 : n - 1, cz0 = c0 < n + m ? c0 : n + m - 1, cz1 = c1 < n + m ? c1 : n + m - 1;
+  auto load_K = [&](int k) {
+    const double* g = gain_ptr(a, b, k);
+#pragma unroll
+    for (int q = 0; q < FW_KR; ++q) {
+      const int r = wv + nw * q, rr = r < m ? r : 0;
+      Kr[q][0] = g[L.oK + rr * n + cn0]; Kr[q][1] = g[L.oK + rr * n + cn1]; kf[q] = g[L.ok + rr];
+    }
+  };
+  auto load_AB = [&](int k) {
+    const double* g = gain_ptr(a, b, k);
+    const double* kn = knot_ptr(a, b, k);
+#pragma unroll
+    for (int q = 0; q < FW_NR; ++q) {
+      const int r = wv + nw * q, rr = r < n ? r : 0;
+      ABr[q][0] = kn[L.oAB + rr * nz + cz0]; ABr[q][1] = kn[L.oAB + rr * nz + cz1]; mxv[q] = g[L.omx + rr];
+    }
+  };
+  auto load_M = [&](int k) {
+    const double* g = gain_ptr(a, b, k);
+#pragma unroll
+    for (int q = 0; q < FW_NR; ++q) {
+      const int r = wv + nw * q, rr = r < n ? r : 0;
+      Mr[q][0] = g[L.oMx + rr * n + cn0]; Mr[q][1] = g[L.oMx + rr * n + cn1];
+    }
+  };
+  auto load_T6 = [&](int k) {
+    const double* g = gain_ptr(a, b, k);
+#pragma unroll
+    for (int l = 0; l < 6; ++l) t6[l] = g[L.oT6 + (tid < 6 ? tid : 0) * 6 + l];
+  };
+  load_K(0); load_AB(0); load_M(0); load_T6(0);
+  for (int i = tid; i < n; i += blockDim.x) { dz[i] = 0.0; a.dxs[(size_t)b * (N + 1) * n + i] = 0.0; }
+  FW_BARRIER();
+  for (int k = 0; k < N; ++k) {
+    const bool more = k + 1 < N;
+#pragma unroll
+    for (int q = 0; q < FW_KR; ++q) {
+      const int r = wv + nw * q;
+      if (r < m) {
+        double s = (c0 < n ? Kr[q][0] * dz[c0] : 0.0) + (c1 < n ? Kr[q][1] * dz[c1] : 0.0);
+        s = wave_sum(s);
+        if (lane == 0) { s += kf[q]; dz[n + r] = s; a.dus[((size_t)b * N + k) * m + r] = s; }
+      }
+    }
+    if (more) load_K(k + 1);
+    FW_BARRIER();
+#pragma unroll
+    for (int q = 0; q < FW_NR; ++q) {
+      const int r = wv + nw * q;
+      if (r < n) {
+        double s = (c0 < n + m ? ABr[q][0] * dz[c0] : 0.0) + (c1 < n + m ? ABr[q][1] * dz[c1] : 0.0);
+        s = wave_sum(s);
+        if (lane == 0) y[r] = s + mxv[q];
+      }
+    }
+    if (more) load_AB(k + 1);
+    FW_BARRIER();
+#pragma unroll
+    for (int q = 0; q < FW_NR; ++q) {
+      const int r = wv + nw * q;
+      if (r < n) {
+        double s = (c0 < n ? Mr[q][0] * y[c0] : 0.0) + (c1 < n ? Mr[q][1] * y[c1] : 0.0);
+        s = wave_sum(s);
+        if (lane == 0) z[r] = y[r] - mud * s;
+      }
+    }
+    if (more) load_M(k + 1);
+    FW_BARRIER();
+    if (tid < n) {
+      double s = z[tid];
+      if (ff && tid < 6) { s = 0; for (int l = 0; l < 6; ++l) s += t6[l] * z[l]; }
+      dz[tid] = s;
+      a.dxs[((size_t)b * (N + 1) + k + 1) * n + tid] = s;
+    }
+    if (more) load_T6(k + 1);
+    FW_BARRIER();
   }
 }
 
