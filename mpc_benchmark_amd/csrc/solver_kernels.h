@@ -538,11 +538,11 @@ __global__ void __launch_bounds__(512) k_forward_prefetch(SolverArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // P7 (cont.): multiplier steps and the merit directional derivative, parallel over knots.
-// grid (N+1, B), block 64
+// grid (N+1, B), block 256, LDS (nz + 3 n + 16) doubles
 // ------------------------------------------------------------------------------------------------
-__global__ void k_duals(SolverArgs a) {
+__global__ void __launch_bounds__(256) k_duals(SolverArgs a) {
   const Layout& L = a.L;
-  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nthr >> 6;
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
   const int n = L.n, nz = L.nz, N = L.N;
@@ -551,56 +551,72 @@ __global__ void k_duals(SolverArgs a) {
   const int c = (int)kn[L.oMISC + MISC_NC], m = (int)kn[L.oMISC + MISC_M];
   const double mu = st.mu, mud = mu * a.opt.dyn_al_scale;
   const bool ff = L.space == MPC_SPACE_MULTIBODY;
-  const double* dx = a.dxs + ((size_t)b * (N + 1) + k) * n;
-  const double* du = a.dus + ((size_t)b * N + k) * L.m;
   const double* v = a.vs + ((size_t)b * (N + 1) + k) * L.c;
   double* dv = a.dvs + ((size_t)b * (N + 1) + k) * L.c;
-  __shared__ double red[64];
-  __shared__ double lnew[128];
-  double acc = 0.0;
-  // cost gradient part
-  for (int z = tid; z < n + m; z += nthr) acc += kn[L.oG + z] * (z < n ? dx[z] : du[z - n]);
+  // one matrix row per wavefront, lanes across the columns (coalesced), DPP reductions; the step [dx; du] in LDS
+  extern __shared__ __attribute__((aligned(16))) double sh[];
+  double* dz = sh;            // nz
+  double* dxn = dz + nz;      // n
+  double* lnew = dxn + n;     // n
+  double* jdl = lnew + n;     // n
+  double* part = jdl + n;     // nw + 1 partial sums of the directional derivative
+  for (int z = tid; z < n + m; z += nthr) dz[z] = (z < n) ? a.dxs[((size_t)b * (N + 1) + k) * n + z] : a.dus[((size_t)b * N + k) * L.m + z - n];
+  if (k < N) for (int z = tid; z < n; z += nthr) dxn[z] = a.dxs[((size_t)b * (N + 1) + k + 1) * n + z];
+  __syncthreads();
+  double acc = 0.0;  // lane 0 of every wavefront accumulates the rows of that wavefront
+  if (wv == 0) {     // cost gradient part
+    double s = 0;
+    for (int z = lane; z < n + m; z += 64) s += kn[L.oG + z] * dz[z];
+    acc += wave_sum(s);
+  }
   // constraints
-  for (int i = tid; i < L.c; i += nthr) {
-    if (i >= c) { dv[i] = 0.0; continue; }
-    double s = g[L.oknu + i];
-    for (int z = 0; z < n; ++z) s += g[L.oKnu + i * n + z] * dx[z];
+  for (int i = wv; i < L.c; i += nw) {
+    if (i >= c) { if (lane == 0) dv[i] = 0.0; continue; }
+    double s = 0, jd = 0;
+    for (int z = lane; z < n; z += 64) s += g[L.oKnu + i * n + z] * dz[z];
+    for (int z = lane; z < n + m; z += 64) jd += kn[L.oCD + i * nz + z] * dz[z];
+    s = wave_sum(s) + g[L.oknu + i];
+    jd = wave_sum(jd);
     const double dvi = s - v[i];
-    dv[i] = dvi;
+    if (lane == 0) dv[i] = dvi;
     const double vp = kn[L.oDT + i] / mu;
-    double jd = 0;
-    for (int z = 0; z < n + m; ++z) jd += kn[L.oCD + i * nz + z] * (z < n ? dx[z] : du[z - n]);
     acc += (vp + (kn[L.oACT + i] != 0.0 ? (vp - v[i]) : 0.0)) * jd - mu * (vp - v[i]) * dvi;
   }
   if (k == 0) for (int i = tid; i < n; i += nthr) a.dlams[(size_t)b * (N + 1) * n + i] = 0.0;
   if (k < N) {
     const double* gn = gain_ptr(a, b, k + 1);
-    const double* dxn = a.dxs + ((size_t)b * (N + 1) + k + 1) * n;
+    for (int i = wv; i < n; i += nw) {
+      double s = 0, jd = 0;
+      for (int z = lane; z < n; z += 64) s += gn[L.oP + i * n + z] * dxn[z];
+      for (int z = lane; z < n + m; z += 64) jd += kn[L.oAB + i * nz + z] * dz[z];
+      s = wave_sum(s);
+      jd = wave_sum(jd);
+      if (lane == 0) { lnew[i] = s + gn[L.op + i]; jdl[i] = jd; }
+    }
+  }
+  if (lane == 0) part[wv] = acc;
+  __syncthreads();
+  if (k < N && wv == 0) {
     const double* lam = a.lams + ((size_t)b * (N + 1) + k + 1) * n;
     const double* le = a.lams_e + ((size_t)b * (N + 1) + k + 1) * n;
     double* dl = a.dlams + ((size_t)b * (N + 1) + k + 1) * n;
-    for (int i = tid; i < n; i += nthr) {
-      double s = gn[L.op + i];
-      for (int z = 0; z < n; ++z) s += gn[L.oP + i * n + z] * dxn[z];
-      lnew[i] = s;
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += nthr) {
+    double s = 0;
+    for (int i = lane; i < n; i += 64) {
       double ln = lnew[i];
       if (ff && i < 6) { ln = 0; for (int l = 0; l < 6; ++l) ln += g[L.oT6 + l * 6 + i] * lnew[l]; }
       const double dli = ln - lam[i];
       dl[i] = dli;
       const double lp = le[i] + kn[L.oF + i] / mud;
-      double jd = 0;
-      for (int z = 0; z < n + m; ++z) jd += kn[L.oAB + i * nz + z] * (z < n ? dx[z] : du[z - n]);
+      double jd = jdl[i];
       if (ff && i < 6) { for (int l = 0; l < 6; ++l) jd += kn[L.oE6 + i * 6 + l] * dxn[l]; }
       else jd -= dxn[i];
-      acc += (2.0 * lp - lam[i]) * jd - mud * (lp - lam[i]) * dli;
+      s += (2.0 * lp - lam[i]) * jd - mud * (lp - lam[i]) * dli;
     }
+    s = wave_sum(s);
+    if (lane == 0) part[nw] = s;
   }
-  red[tid] = acc;
   __syncthreads();
-  if (tid == 0) { double r = 0; for (int i = 0; i < nthr; ++i) r += red[i]; kn[L.oMISC + MISC_DMERIT] = r; }
+  if (tid == 0) { double r = 0; for (int i = 0; i < nw; ++i) r += part[i]; if (k < N) r += part[nw]; kn[L.oMISC + MISC_DMERIT] = r; }
 }
 
 // ------------------------------------------------------------------------------------------------
