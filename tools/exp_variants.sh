@@ -13,5 +13,5 @@ for l in sys.stdin:
         j = json.loads(l); print(j['value'], 'solves/s', j['ms_per_step'], 'ms/step', j['roofline']['kernel_ms_per_step_summed_over_shards'])
     else: print(l, end='')
 "
-  python3 tools/prof_riccati.py $lib 2>&1 | grep -E "EVAL|total" 
+  python3 tools/phase_timers.py $lib 2>&1 | grep -E "EVAL|total" 
 done

@@ -1,0 +1,44 @@
+"""Developer tool: in-kernel phase timers (shader clock, ~2.4 GHz assumed) of the Riccati sweep and of the whole-body
+stage kernel on the default bench workload.  usage: python tools/phase_timers.py [path/to/libmpc_hip.so]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mpc_benchmark_amd import _capi
+from mpc_benchmark_amd.ensemble import EnsembleMPC
+from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+
+lib = _capi.bind_library(sys.argv[1]) if len(sys.argv) > 1 else _capi.load_hip_library()
+pd = FullDynamicsProblem(horizon=100, complete_model=True)
+ens = EnsembleMPC(pd, batch=4, library=lib)
+ens.prepare_schedule(10)
+ens.cold_solve(100)
+ens.native.profile(3)  # in-kernel phase timers on
+ens.native.debug_get('ric_prof', 0)  # read + clear
+TICKS = 3
+for _ in range(TICKS):
+    ens.step()
+p = ens.native.debug_get('ric_prof', 0)
+GHZ = 2.4
+ric = {0: 'T6 inverse, active-row scan', 1: 'T6 similarity transform of P', 2: 'Ph copy, Frobenius norm, vv', 13: 'series length',
+       14: 'series: tile products', 15: 'series: barrier wait', 16: 'series: in-place update', 3: 'chol n (fallback only)',
+       5: 'triangular solves (fallback only)', 6: 'AB prefetch issue, w, store Pt', 7: 'AB to LDS, gh', 8: 'G = Pt [A B], Hh = H + [A B]^T G',
+       9: 'KKT operands', 10: 'chol m', 11: 'KKT solve (active rows), gains', 12: 'value function, store gain record'}
+knots = 100 * TICKS
+tot = sum(p[i] for i in ric)
+for i, name in ric.items():
+    print('RIC  %-40s %7.1f us/knot %5.1f%%' % (name, p[i] / knots / (GHZ * 1e3), 100 * p[i] / tot))
+print('RIC  total %.1f us/knot ; series: max rho %.3e, mean terms %.2f, Cholesky fallbacks per knot %.3f' % (
+    tot / knots / (GHZ * 1e3), p[20], p[21] / knots, p[22] / knots))
+ev = {0: 'load, FK, joint columns', 1: 'velocities, inertias, composites, U', 2: 'M, bias, contact frames, Jc, Y16', 3: 'chol M (blocked, MFMA)',
+      5: 'Y, S, multipliers, accelerations', 6: 'forces at the solution', 7: 'derivative building blocks', 8: 'right-hand sides R1, R2',
+      9: 'implicit differentiation (blocked solves)', 10: 'SE(3) pre-pass, integrator, [A B]', 12: 'merit, projections'}
+terms = {1: 'state_error', 2: 'control_error', 3: 'frame_placement', 4: 'frame_translation', 5: 'frame_velocity', 6: 'com_translation',
+         7: 'centroidal_momentum', 8: 'contact_force', 9: 'mb_wrench_cone', 10: 'centroidal_wrench_cone', 13: 'centroidal_momentum_der'}
+e = p[32:]
+etot = sum(e[i] for i in ev) + sum(e[13 + t] for t in terms) + e[27]
+for i, name in ev.items():
+    print('EVAL %-40s %7.1f us %5.1f%%' % (name, e[i] / TICKS / (GHZ * 1e3), 100 * e[i] / etot))
+for t, name in terms.items():
+    if e[13 + t] > 0:
+        print('EVAL term %-35s %7.1f us %5.1f%%' % (name, e[13 + t] / TICKS / (GHZ * 1e3), 100 * e[13 + t] / etot))
+print('EVAL %-40s %7.1f us %5.1f%%' % ('Gauss-Newton Hessian flush (MFMA)', e[27] / TICKS / (GHZ * 1e3), 100 * e[27] / etot))
+print('EVAL total %.1f us per workgroup (knot 1 of instance 0)' % (etot / TICKS / (GHZ * 1e3)))

@@ -7,8 +7,8 @@ Each *_DIR holds the ``*counter_collection.csv`` of ONE pass (FETCH_SIZE and WRI
 gfx950, MI355X_MICROARCH.md §rocprofv3 PMC slots).  The calibration passes ran tools/pmc/pmc_calib (a streaming
 8 B/lane copy of CALIB_BYTES in and CALIB_BYTES out per launch): bytes-per-counter-unit is derived from it, which
 subsumes the guide's "double FETCH_SIZE" correction for this access width.  Early-exit launches of a kernel
-(passes enqueued after convergence return immediately) are dropped: only launches whose counter is >= 10 % of that
-kernel's maximum count.
+(passes enqueued after convergence return immediately) and the launches of the cold-solve tail (most instances
+already finished) are dropped: only launches whose counter is >= 90 % of that kernel's maximum count.
 """
 import csv
 import glob
@@ -33,7 +33,7 @@ def mean_real(v):
     if not v:
         return None, 0
     mx = max(v)
-    keep = [x for x in v if x >= 0.1 * mx]
+    keep = [x for x in v if x >= 0.9 * mx]  # the full-ensemble launches (the cold-solve tail runs with most instances finished)
     return sum(keep) / len(keep), len(keep)
 
 
