@@ -790,6 +790,8 @@ def _lower_weight(term_type, dim, W, space):
         if np.count_nonzero(W - np.diag(np.diag(W))):
             raise NotImplementedError("state/control cost weights must be diagonal")
         return np.diag(W).copy(), K.TERM_FLAG_DIAG_WEIGHT
+    if not np.count_nonzero(W - np.diag(np.diag(W))):
+        return np.diag(W).copy(), K.TERM_FLAG_DIAG_WEIGHT  # diagonal weights travel as their diagonal
     return W.reshape(-1).copy(), 0
 
 

@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     for (int kd = 0; kd < nv; ++kd) if ((anc[i] >> dof_body[kd]) & 1ull) md_ |= 1ull << kd;
     sub[i] = ms; dmask[i] = md_;
   }
-  clear_knot(KL, kn, nz, derivs, tid, nthr);
+  __syncthreads();
   const double* q = x;
   const double* v = x + nq;
 #define BELOW(kdof, body) ((anc[(body)] >> dof_body[(kdof)]) & 1ull)
@@ -897,268 +897,312 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
 
   EV_PROF(10);
   // ---- P13: cost stack and constraints -----------------------------------------------------------------------
-  // centre of mass and total momentum (body 0 is the root: its composite = whole robot)
+  // Cost terms with diagonal weights are evaluated CONCURRENTLY, one term per wavefront, straight into their rows of
+  // the LDS stack JS = sqrt(W) J (<= 32 rows per chunk); the Gauss-Newton Hessian JS^T JS (+ the diagonal / base-block
+  // contributions of the state and control error terms, accumulated in LDS) is written ONCE per knot by MFMA tiles —
+  // no clear, no read-modify-write of the nz x nz block in HBM.  Constraints and the diagonal state / control costs
+  // run through the whole workgroup term by term.
   const S6 h0 = ld6(Hc);
-  int row = 0, rowc = 0, se3_next = 0;
-  // H += JS^T JS (upper triangle, mirrored), grad += JS^T wrs for the rows stacked so far
-  auto flush_stack = [&]() {
-    const int kc = (rowc + 3) & ~3;  // MFMA K granularity: zero rows up to a multiple of 4
-    for (int idx = tid; idx < (kc - rowc) * nz; idx += nthr) JS[rowc * nz + idx] = 0.0;
-    __syncthreads();
-    for (int z = tid; z < nz; z += nthr) {
-      double g = 0;
-      for (int i = 0; i < rowc; ++i) g += JS[i * nz + z] * wrs[i];
-      kn[KL.oG + z] += g;
+  double* gacc = Bt;     // nz: gradient accumulator        (the derivative vectors Bt, Tv, Phi, Tq are dead by now)
+  double* hdg = Tv;      // nz: additions to diag(H)
+  double* hbb = Phi;     // 36: additions to the base 6x6 block of H
+  double* tcost = small; // per-term cost, summed in term order at the end (deterministic)
+  int* tkind = (int*)(small + 32);  // 0 workgroup pass, 1 stacked cost (wave pass), 2 dense-weight cost (HBM pass)
+  int* trow = tkind + 24;           // first stack row of a stacked term
+  int* tse3 = tkind + 48;           // slot in the SE(3) table
+  int* tchunk = tkind + 72;         // stack chunk (32 rows each)
+  int* tmeta = tkind + 96;          // [0] number of chunks, [1] any dense-weight cost
+  for (int z = tid; z < nz; z += nthr) { gacc[z] = 0.0; hdg[z] = a.opt.reg_init; }
+  for (int i = tid; i < 36; i += nthr) hbb[i] = 0.0;
+  for (int i = tid; i < 24; i += nthr) tcost[i] = 0.0;
+  if (tid == 0) {
+    int rows = 0, chunk = 0, se3n = 0, dense = 0, nst = 0;
+    for (int t = 0; t < nterms; ++t) {
+      const TermRec tr = load_term(desc, t);
+      const bool se3t = tr.type == MPC_TERM_FRAME_PLACEMENT || (tr.type == MPC_TERM_STATE_ERROR && tr.i0 < 6);
+      tse3[t] = se3t ? se3n++ : 0;
+      const bool diag_sel = (tr.type == MPC_TERM_STATE_ERROR || tr.type == MPC_TERM_CONTROL_ERROR) && (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT);
+      int kind = 0;
+      if (tr.role == MPC_ROLE_COST && !diag_sel) {
+        bool wdiag = (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) != 0;
+        if (!wdiag) { const double* W = P + tr.woff; wdiag = true; for (int e = 0; e < tr.dim * tr.dim; ++e) if ((e / tr.dim != e % tr.dim) && W[e] != 0.0) wdiag = false; }
+        if (wdiag && tr.dim <= 24) {
+          kind = 1;
+          if (rows + tr.dim > 32) { ++chunk; rows = 0; }
+          trow[t] = rows; tchunk[t] = chunk; rows += tr.dim; ++nst;
+        } else { kind = 2; dense = 1; }
+      }
+      tkind[t] = kind;
     }
-    // H += JS^T JS on the matrix cores: upper block triangle of 16x16 tiles, mirrored on the way out
-    const int nzt = (nz + 15) >> 4;
-    for (int t = wv; t < nzt * (nzt + 1) / 2; t += nw) {
-      int ta = 0, rem = t;
-      while (rem >= nzt - ta) { rem -= nzt - ta; ++ta; }
-      const int tb = ta + rem;
-      d4_t h = d4_t{0, 0, 0, 0};
-      mma_tile<false>(h, JS + ta * 16, 1, nz, JS + tb * 16, nz, 1, kc, lane);
-      const int zb = tb * 16 + (lane & 15);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int za = ta * 16 + (lane >> 4) + 4 * q;
-        if (za < nz && zb < nz) {
-          kn[KL.oH + (size_t)za * KL.nz + zb] += h[q];
-          if (ta != tb) kn[KL.oH + (size_t)zb * KL.nz + za] += h[q];
+    tmeta[0] = nst ? chunk + 1 : 0; tmeta[1] = dense;
+  }
+  __syncthreads();
+
+  // residual entry ri of x_ref (-) x : base rows from the SE(3) table, joint rows in closed form
+  auto state_res = [&](const double* tp, const double* sl, int ri) -> double {
+    return (ri < 6) ? sl[ri] : ((ri < nv) ? (tp[ri + 1] - q[ri + 1]) : (tp[nq + ri - nv] - v[ri - nv]));
+  };
+  // r (dim) and, with derivatives, the Jacobian rows Jt (dim x nz, ld nz) of one term, by the threads t0 (of nt): the
+  // whole workgroup (wg, barriers) or one wavefront (LDS operations of a wavefront execute in order: no barrier)
+  auto term_rows = [&](const TermRec& tr, const double* tp, const double* sl, double* r, double* Jt, int t0, int nt, bool wg) {
+    const int d = tr.dim;
+    if (derivs) for (int idx = t0; idx < d * nz; idx += nt) Jt[idx] = 0.0;
+    if (wg) __syncthreads();
+    if (tr.type == MPC_TERM_STATE_ERROR) {
+      const double* Jb = sl + 8;  // -Jlog6 block of the base rows
+      for (int i = t0; i < d; i += nt) r[i] = state_res(tp, sl, tr.i0 + i);
+      if (derivs) for (int i = t0; i < d; i += nt) {
+        const int ri = tr.i0 + i;
+        if (ri < 6) { for (int z = 0; z < 6; ++z) Jt[i * nz + z] = Jb[6 * ri + z]; }
+        else Jt[i * nz + ri] = -1.0;
+      }
+    } else if (tr.type == MPC_TERM_CONTROL_ERROR) {
+      for (int i = t0; i < d; i += nt) { r[i] = u[tr.i0 + i] - tp[tr.i0 + i]; if (derivs) Jt[i * nz + n + tr.i0 + i] = 1.0; }
+    } else if (tr.type == MPC_TERM_FRAME_PLACEMENT || tr.type == MPC_TERM_FRAME_TRANSLATION || tr.type == MPC_TERM_FRAME_VELOCITY) {
+      const int fi = tr.i0, i = mframe[fi];
+      const M3 Ri = ldm3(oR + 9 * i);
+      const M3 Rf = mul(Ri, ldm3(fd + 12 * fi));
+      const V3 pf = mul(Ri, ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+      if (tr.type == MPC_TERM_FRAME_PLACEMENT) {
+        const double* Jl = sl + 8;
+        if (t0 < 6) r[t0] = sl[t0];
+        if (derivs) for (int j = t0; j < nv; j += nt) if (BELOW(j, i)) {
+          const S6 col = mat6_mul(Jl, adinv(Rf, pf, ld6(J + 6 * j)));
+          for (int rr = 0; rr < 6; ++rr) Jt[rr * nz + j] = col.v[rr];
+        }
+      } else if (tr.type == MPC_TERM_FRAME_TRANSLATION) {
+        if (t0 < d) { const double pfa[3] = {pf.x, pf.y, pf.z}; r[t0] = pfa[tr.i1 + t0] - tp[tr.i1 + t0]; }
+        if (derivs) for (int j = t0; j < nv; j += nt) if (BELOW(j, i)) {
+          const S6 Jj = ld6(J + 6 * j);
+          const V3 lv = lin(Jj) + cross(ang(Jj), pf);
+          const double la[3] = {lv.x, lv.y, lv.z};
+          for (int rr = 0; rr < d; ++rr) Jt[rr * nz + j] = la[tr.i1 + rr];
+        }
+      } else {
+        if (t0 == 0) { const S6 vf = adinv(Rf, pf, ld6(ov + 6 * i)); for (int rr = 0; rr < 6; ++rr) r[rr] = vf.v[rr] - tp[rr]; }
+        if (derivs) for (int j = t0; j < nv; j += nt) if (BELOW(j, i)) {
+          const S6 cq = adinv(Rf, pf, ld6(Psd + 6 * j)), cv = adinv(Rf, pf, ld6(J + 6 * j));
+          for (int rr = 0; rr < 6; ++rr) { Jt[rr * nz + j] = cq.v[rr]; Jt[rr * nz + nv + j] = cv.v[rr]; }
         }
       }
+    } else if (tr.type == MPC_TERM_COM_TRANSLATION) {
+      if (t0 < d) { const double ca[3] = {com.x, com.y, com.z}; r[t0] = ca[tr.i1 + t0] - tp[tr.i1 + t0]; }
+      if (derivs) for (int j = t0; j < nv; j += nt) for (int rr = 0; rr < d; ++rr) Jt[rr * nz + j] = U[6 * j + tr.i1 + rr] / mtot;
+    } else if (tr.type == MPC_TERM_CENTROIDAL_MOMENTUM) {
+      if (t0 == 0) {
+        const V3 hl = lin(h0), ha = ang(h0) - cross(com, lin(h0));
+        r[0] = hl.x - tp[0]; r[1] = hl.y - tp[1]; r[2] = hl.z - tp[2]; r[3] = ha.x - tp[3]; r[4] = ha.y - tp[4]; r[5] = ha.z - tp[5];
+      }
+      if (derivs) for (int j = t0; j < nv; j += nt) {
+        const int bj = dof_body[j];
+        const S6 Uj = ld6(U + 6 * j);
+        const S6 D = add6(fcross(ld6(J + 6 * j), ld6(Hc + 6 * bj)), mat6_mul(Yc + 36 * bj, ld6(Psd + 6 * j)));
+        const V3 dc = (1.0 / mtot) * lin(Uj);
+        const V3 dql = lin(D), dqa = ang(D) - cross(dc, lin(h0)) - cross(com, lin(D));
+        const V3 dvl = lin(Uj), dva = ang(Uj) - cross(com, lin(Uj));
+        const double cq[6] = {dql.x, dql.y, dql.z, dqa.x, dqa.y, dqa.z}, cv[6] = {dvl.x, dvl.y, dvl.z, dva.x, dva.y, dva.z};
+        for (int rr = 0; rr < 6; ++rr) { Jt[rr * nz + j] = cq[rr]; Jt[rr * nz + nv + j] = cv[rr]; }
+      }
+    } else if (tr.type == MPC_TERM_CONTACT_FORCE) {
+      if (t0 < 6) r[t0] = lam[6 * tr.i0 + t0] - tp[t0];
+      if (derivs) for (int idx = t0; idx < 6 * nz; idx += nt) Jt[idx] = R2[(6 * tr.i0 + idx / nz) * ldR + idx % nz];
+    } else if (tr.type == MPC_TERM_CENTROIDAL_WRENCH_CONE) {
+      for (int i = t0; i < d; i += nt) { double sacc = 0; for (int j = 0; j < 6; ++j) sacc += tp[i * 6 + j] * u[6 * tr.i0 + j]; r[i] = sacc; }
+      if (derivs) for (int idx = t0; idx < d * 6; idx += nt) Jt[(idx / 6) * nz + n + 6 * tr.i0 + idx % 6] = tp[idx];
+    } else if (tr.type == MPC_TERM_CENTROIDAL_MOMENTUM_DER) {
+      // r = [sum f + m g ; sum (p_i - c) x f_i + tau_i]   (kinodynamic_talos.py:125-127); params: g[3], states, frames
+      const int nkk = tr.i0;
+      if (t0 == 0) {
+        V3 rl = v3(mtot * tp[0], mtot * tp[1], mtot * tp[2]), ra = v3(0, 0, 0);
+        for (int cc = 0; cc < nkk; ++cc) {
+          if (tp[3 + cc] == 0.0) continue;
+          const int fi = (int)tp[3 + nkk + cc], i = mframe[fi];
+          const V3 pf = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+          const V3 f = v3(u[6 * cc], u[6 * cc + 1], u[6 * cc + 2]);
+          rl = rl + f;
+          ra = ra + cross(pf - com, f) + v3(u[6 * cc + 3], u[6 * cc + 4], u[6 * cc + 5]);
+        }
+        r[0] = rl.x; r[1] = rl.y; r[2] = rl.z; r[3] = ra.x; r[4] = ra.y; r[5] = ra.z;
+      }
+      if (derivs) {
+        for (int j = t0; j < nv; j += nt) {
+          V3 dang = v3(0, 0, 0);
+          const S6 Jj = ld6(J + 6 * j);
+          const V3 dc = (1.0 / mtot) * lin(ld6(U + 6 * j));
+          for (int cc = 0; cc < nkk; ++cc) {
+            if (tp[3 + cc] == 0.0) continue;
+            const int fi = (int)tp[3 + nkk + cc], i = mframe[fi];
+            const V3 pf = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+            V3 dp_ = v3(0, 0, 0);
+            if (BELOW(j, i)) dp_ = lin(Jj) + cross(ang(Jj), pf);
+            dang = dang + cross(dp_ - dc, v3(u[6 * cc], u[6 * cc + 1], u[6 * cc + 2]));
+          }
+          Jt[3 * nz + j] = dang.x; Jt[4 * nz + j] = dang.y; Jt[5 * nz + j] = dang.z;
+        }
+        if (t0 < nkk && tp[3 + t0] != 0.0) {
+          const int cc = t0, fi = (int)tp[3 + nkk + cc], i = mframe[fi];
+          const V3 rr = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i) - com;
+          const M3 Rx = skew_m(rr);
+          for (int e = 0; e < 3; ++e) {
+            Jt[e * nz + n + 6 * cc + e] = 1.0;
+            Jt[(3 + e) * nz + n + 6 * cc + 3 + e] = 1.0;
+            for (int e2 = 0; e2 < 3; ++e2) Jt[(3 + e) * nz + n + 6 * cc + e2] = Rx.m[3 * e + e2];
+          }
+        }
+      }
+    } else if (tr.type == MPC_TERM_MB_WRENCH_CONE) {
+      for (int i = t0; i < d; i += nt) { double s = 0; for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * lam[6 * tr.i0 + j]; r[i] = s; }
+      if (derivs) for (int idx = t0; idx < d * nz; idx += nt) {
+        const int i = idx / nz, z = idx % nz;
+        double s = 0;
+        for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * R2[(6 * tr.i0 + j) * ldR + z];
+        Jt[idx] = s;
+      }
     }
-    __syncthreads();
-    rowc = 0;
-    EV_PROF(27);
+    if (wg) __syncthreads();
   };
-  for (int t = 0; t < nterms; ++t) {
-    const TermRec tr = load_term(desc, t);
-    const double* tp = P + tr.poff;
-    const int d = tr.dim;
-    double* r = red + 2 * 256 - 64;  // 64 doubles of residual scratch at the tail of `red` (dim <= 56 only for state error, handled separately)
-    bool generic = true;
-    const bool is_cost = tr.role == MPC_ROLE_COST;
-    if (derivs && is_cost && rowc + d > 32 && d <= 24) flush_stack();
-    double* Jt = (is_cost && d <= 24) ? JS + rowc * nz : JL;  // staging rows of this term (LDS)
-    if (tr.type == MPC_TERM_STATE_ERROR) {
-      // r = x_ref (-) x ; J = -I except the base block -Jlog6(Mref^-1 M)
-      // base rows: residual and -Jlog6 block from the SE(3) table (slices that start past the base never read them)
-      const double* sl = se3 + 48 * ((tr.i0 < 6) ? se3_next++ : 0);
-      const double* Jb = sl + 8;  // 36
-      double* rfull = Tq;         // n doubles of scratch — the derivative vectors are dead by now
-      for (int i = tid; i < n; i += nthr) rfull[i] = (i < 6) ? sl[i] : ((i < nv) ? (tp[i + 1] - q[i + 1]) : (tp[nq + i - nv] - v[i - nv]));
-      __syncthreads();
-      const double* W = P + tr.woff;
-      const bool diag = tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT;
-      if (tr.role == MPC_ROLE_COST && diag) {
-        generic = false;
-        if (tid == 0) { double cst = 0; for (int i = 0; i < d; ++i) cst += W[i] * rfull[tr.i0 + i] * rfull[tr.i0 + i]; s_cost += 0.5 * cst; }
+
+  // ---- pass B: constraints and the diagonal state / control costs, term by term through the whole workgroup ----
+  {
+    int row = 0;
+    double* r = red + 2 * 256 - 64;
+    for (int t = 0; t < nterms; ++t) {
+      const TermRec tr = load_term(desc, t);
+      if (tkind[t] != 0) continue;
+      const double* tp = P + tr.poff;
+      const double* sl = se3 + 48 * tse3[t];
+      const int d = tr.dim;
+      const bool is_cost = tr.role == MPC_ROLE_COST;
+      if (tr.type == MPC_TERM_STATE_ERROR && is_cost) {
+        const double* W = P + tr.woff;
+        const double* Jb = sl + 8;
+        if (tid == 0) { double cst = 0; for (int i = 0; i < d; ++i) { const double e = state_res(tp, sl, tr.i0 + i); cst += W[i] * e * e; } tcost[t] = 0.5 * cst; }
         if (derivs) {
-          // rows i0..i0+d of the full residual; row index ri = i0 + i
           for (int z = tid; z < n; z += nthr) {
             double g = 0;
-            if (z < 6) { for (int i = 0; i < d; ++i) { const int ri = tr.i0 + i; if (ri < 6) g += Jb[6 * ri + z] * W[i] * rfull[ri]; } }
-            else if (z >= tr.i0 && z < tr.i0 + d) g = -W[z - tr.i0] * rfull[z];
-            kn[KL.oG + z] += g;
-            if (z >= 6 && z >= tr.i0 && z < tr.i0 + d) kn[KL.oH + (size_t)z * KL.nz + z] += W[z - tr.i0];
+            if (z < 6) { for (int i = 0; i < d; ++i) { const int ri = tr.i0 + i; if (ri < 6) g += Jb[6 * ri + z] * W[i] * sl[ri]; } }
+            else if (z >= tr.i0 && z < tr.i0 + d) { g = -W[z - tr.i0] * state_res(tp, sl, z); hdg[z] += W[z - tr.i0]; }
+            gacc[z] += g;
           }
           for (int idx = tid; idx < 36; idx += nthr) {
             const int za = idx / 6, zb = idx % 6;
             double h = 0;
             for (int i = 0; i < d; ++i) { const int ri = tr.i0 + i; if (ri < 6) h += Jb[6 * ri + za] * W[i] * Jb[6 * ri + zb]; }
-            kn[KL.oH + (size_t)za * KL.nz + zb] += h;
+            hbb[idx] += h;
           }
         }
         __syncthreads();
-      } else if (tr.role != MPC_ROLE_COST && tr.i0 >= 6) {
-        // joint-space selector rows (fulldynamic_talos.py:208-209): written straight into the knot record
-        generic = false;
-        for (int i = tid; i < d; i += nthr) {
-          kn[KL.oCV + row + i] = rfull[tr.i0 + i];
-          kn[KL.oCT + row + i] = (double)tr.role;
-          kn[KL.oLO + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + i] : 0.0;
-          kn[KL.oHI + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + d + i] : 0.0;
-        }
-        if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) kn[KL.oCD + (size_t)(row + idx / nz) * KL.nz + idx % nz] = ((idx % nz) == tr.i0 + idx / nz) ? -1.0 : 0.0;
-        __syncthreads();
-      } else {
-        // generic path (constraints on the base / dense weights, dim <= 24): materialise the sliced rows
-        for (int i = tid; i < d; i += nthr) r[i] = rfull[tr.i0 + i];
-        if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) {
-          const int i = idx / nz, z = idx % nz, ri = tr.i0 + i;
-          double jv = 0;
-          if (ri < 6) jv = (z < 6) ? Jb[6 * ri + z] : 0.0;
-          else jv = (z == ri) ? -1.0 : 0.0;
-          Jt[idx] = jv;
-        }
-        __syncthreads();
-      }
-    } else if (tr.type == MPC_TERM_CONTROL_ERROR) {
-      const double* W = P + tr.woff;
-      const bool diag = tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT;
-      if (tr.role == MPC_ROLE_COST && diag) {
-        generic = false;
-        if (tid == 0) { double cst = 0; for (int i = 0; i < d; ++i) { const double e = u[tr.i0 + i] - tp[tr.i0 + i]; cst += W[i] * e * e; } s_cost += 0.5 * cst; }
+      } else if (tr.type == MPC_TERM_CONTROL_ERROR && is_cost) {
+        const double* W = P + tr.woff;
+        if (tid == 0) { double cst = 0; for (int i = 0; i < d; ++i) { const double e = u[tr.i0 + i] - tp[tr.i0 + i]; cst += W[i] * e * e; } tcost[t] = 0.5 * cst; }
         if (derivs) for (int i = tid; i < d; i += nthr) {
           const int z = n + tr.i0 + i;
-          kn[KL.oG + z] += W[i] * (u[tr.i0 + i] - tp[tr.i0 + i]);
-          kn[KL.oH + (size_t)z * KL.nz + z] += W[i];
+          gacc[z] += W[i] * (u[tr.i0 + i] - tp[tr.i0 + i]);
+          hdg[z] += W[i];
         }
         __syncthreads();
-      } else if (tr.role != MPC_ROLE_COST) {
-        // torque box (fulldynamic_talos.py:206-207): selector rows written straight into the knot record
-        generic = false;
+      } else if ((tr.type == MPC_TERM_STATE_ERROR && tr.i0 >= 6) || tr.type == MPC_TERM_CONTROL_ERROR) {
+        // selector constraints (joint limits fulldynamic_talos.py:208-209, torque box :206-207): straight into the record
+        const bool st_ = tr.type == MPC_TERM_STATE_ERROR;
         for (int i = tid; i < d; i += nthr) {
-          kn[KL.oCV + row + i] = u[tr.i0 + i] - tp[tr.i0 + i];
+          kn[KL.oCV + row + i] = st_ ? state_res(tp, sl, tr.i0 + i) : (u[tr.i0 + i] - tp[tr.i0 + i]);
           kn[KL.oCT + row + i] = (double)tr.role;
           kn[KL.oLO + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + i] : 0.0;
           kn[KL.oHI + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + d + i] : 0.0;
         }
-        if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) kn[KL.oCD + (size_t)(row + idx / nz) * KL.nz + idx % nz] = ((idx % nz) == n + tr.i0 + idx / nz) ? 1.0 : 0.0;
-        __syncthreads();
+        const int zc0 = st_ ? tr.i0 : n + tr.i0;
+        const double sgn = st_ ? -1.0 : 1.0;
+        if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) kn[KL.oCD + (size_t)(row + idx / nz) * KL.nz + idx % nz] = ((idx % nz) == zc0 + idx / nz) ? sgn : 0.0;
       } else {
-        for (int i = tid; i < d; i += nthr) r[i] = u[tr.i0 + i] - tp[tr.i0 + i];
-        if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) Jt[idx] = ((idx % nz) == n + tr.i0 + idx / nz) ? 1.0 : 0.0;
-        __syncthreads();
+        term_rows(tr, tp, sl, r, JL, tid, nthr, true);
+        emit_constraint(KL, kn, tr, P, row, r, JL, nz, nz, derivs, tid, nthr);
       }
-    } else {
-      if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) Jt[idx] = 0.0;
-      __syncthreads();
-      if (tr.type == MPC_TERM_FRAME_PLACEMENT || tr.type == MPC_TERM_FRAME_TRANSLATION || tr.type == MPC_TERM_FRAME_VELOCITY) {
-        const int fi = tr.i0, i = mframe[fi];
-        const M3 Ri = ldm3(oR + 9 * i);
-        const M3 Rf = mul(Ri, ldm3(fd + 12 * fi));
-        const V3 pf = mul(Ri, ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
-        if (tr.type == MPC_TERM_FRAME_PLACEMENT) {
-          const double* sl = se3 + 48 * se3_next++;
-          const double* Jl = sl + 8;
-          if (tid < 6) r[tid] = sl[tid];
-          if (derivs) for (int j = tid; j < nv; j += nthr) if (BELOW(j, i)) {
-            const S6 col = mat6_mul(Jl, adinv(Rf, pf, ld6(J + 6 * j)));
-            for (int rr = 0; rr < 6; ++rr) Jt[rr * nz + j] = col.v[rr];
-          }
-        } else if (tr.type == MPC_TERM_FRAME_TRANSLATION) {
-          if (tid < d) { const double pfa[3] = {pf.x, pf.y, pf.z}; r[tid] = pfa[tr.i1 + tid] - tp[tr.i1 + tid]; }
-          if (derivs) for (int j = tid; j < nv; j += nthr) if (BELOW(j, i)) {
-            const S6 Jj = ld6(J + 6 * j);
-            const V3 lv = lin(Jj) + cross(ang(Jj), pf);
-            const double la[3] = {lv.x, lv.y, lv.z};
-            for (int rr = 0; rr < d; ++rr) Jt[rr * nz + j] = la[tr.i1 + rr];
-          }
-        } else {
-          if (tid == 0) { const S6 vf = adinv(Rf, pf, ld6(ov + 6 * i)); for (int rr = 0; rr < 6; ++rr) r[rr] = vf.v[rr] - tp[rr]; }
-          if (derivs) for (int j = tid; j < nv; j += nthr) if (BELOW(j, i)) {
-            const S6 cq = adinv(Rf, pf, ld6(Psd + 6 * j)), cv = adinv(Rf, pf, ld6(J + 6 * j));
-            for (int rr = 0; rr < 6; ++rr) { Jt[rr * nz + j] = cq.v[rr]; Jt[rr * nz + nv + j] = cv.v[rr]; }
-          }
-        }
-      } else if (tr.type == MPC_TERM_COM_TRANSLATION) {
-        if (tid < d) { const double ca[3] = {com.x, com.y, com.z}; r[tid] = ca[tr.i1 + tid] - tp[tr.i1 + tid]; }
-        if (derivs) for (int j = tid; j < nv; j += nthr) for (int rr = 0; rr < d; ++rr) Jt[rr * nz + j] = U[6 * j + tr.i1 + rr] / mtot;
-      } else if (tr.type == MPC_TERM_CENTROIDAL_MOMENTUM) {
-        if (tid == 0) {
-          const V3 hl = lin(h0), ha = ang(h0) - cross(com, lin(h0));
-          r[0] = hl.x - tp[0]; r[1] = hl.y - tp[1]; r[2] = hl.z - tp[2]; r[3] = ha.x - tp[3]; r[4] = ha.y - tp[4]; r[5] = ha.z - tp[5];
-        }
-        if (derivs) for (int j = tid; j < nv; j += nthr) {
-          const int bj = dof_body[j];
-          const S6 Uj = ld6(U + 6 * j);
-          const S6 D = add6(fcross(ld6(J + 6 * j), ld6(Hc + 6 * bj)), mat6_mul(Yc + 36 * bj, ld6(Psd + 6 * j)));
-          const V3 dc = (1.0 / mtot) * lin(Uj);
-          const V3 dql = lin(D), dqa = ang(D) - cross(dc, lin(h0)) - cross(com, lin(D));
-          const V3 dvl = lin(Uj), dva = ang(Uj) - cross(com, lin(Uj));
-          const double cq[6] = {dql.x, dql.y, dql.z, dqa.x, dqa.y, dqa.z}, cv[6] = {dvl.x, dvl.y, dvl.z, dva.x, dva.y, dva.z};
-          for (int rr = 0; rr < 6; ++rr) { Jt[rr * nz + j] = cq[rr]; Jt[rr * nz + nv + j] = cv[rr]; }
-        }
-      } else if (tr.type == MPC_TERM_CONTACT_FORCE) {
-        if (tid < 6) r[tid] = lam[6 * tr.i0 + tid] - tp[tid];
-        if (derivs) for (int idx = tid; idx < 6 * nz; idx += nthr) Jt[idx] = R2[(6 * tr.i0 + idx / nz) * ldR + idx % nz];
-      } else if (tr.type == MPC_TERM_CENTROIDAL_WRENCH_CONE) {
-        for (int i = tid; i < d; i += nthr) { double sacc = 0; for (int j = 0; j < 6; ++j) sacc += tp[i * 6 + j] * u[6 * tr.i0 + j]; r[i] = sacc; }
-        if (derivs) for (int idx = tid; idx < d * 6; idx += nthr) Jt[(idx / 6) * nz + n + 6 * tr.i0 + idx % 6] = tp[idx];
-      } else if (tr.type == MPC_TERM_CENTROIDAL_MOMENTUM_DER) {
-        // r = [sum f + m g ; sum (p_i - c) x f_i + tau_i]   (kinodynamic_talos.py:125-127); params: g[3], states, frames
-        const int nkk = tr.i0;
-        if (tid == 0) {
-          V3 rl = v3(mtot * tp[0], mtot * tp[1], mtot * tp[2]), ra = v3(0, 0, 0);
-          for (int cc = 0; cc < nkk; ++cc) {
-            if (tp[3 + cc] == 0.0) continue;
-            const int fi = (int)tp[3 + nkk + cc], i = mframe[fi];
-            const V3 pf = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
-            const V3 f = v3(u[6 * cc], u[6 * cc + 1], u[6 * cc + 2]);
-            rl = rl + f;
-            ra = ra + cross(pf - com, f) + v3(u[6 * cc + 3], u[6 * cc + 4], u[6 * cc + 5]);
-          }
-          r[0] = rl.x; r[1] = rl.y; r[2] = rl.z; r[3] = ra.x; r[4] = ra.y; r[5] = ra.z;
-        }
-        if (derivs) {
-          for (int j = tid; j < nv; j += nthr) {
-            V3 dang = v3(0, 0, 0);
-            const S6 Jj = ld6(J + 6 * j);
-            const V3 dc = (1.0 / mtot) * lin(ld6(U + 6 * j));
-            for (int cc = 0; cc < nkk; ++cc) {
-              if (tp[3 + cc] == 0.0) continue;
-              const int fi = (int)tp[3 + nkk + cc], i = mframe[fi];
-              const V3 pf = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
-              V3 dp_ = v3(0, 0, 0);
-              if (BELOW(j, i)) dp_ = lin(Jj) + cross(ang(Jj), pf);
-              dang = dang + cross(dp_ - dc, v3(u[6 * cc], u[6 * cc + 1], u[6 * cc + 2]));
-            }
-            Jt[3 * nz + j] = dang.x; Jt[4 * nz + j] = dang.y; Jt[5 * nz + j] = dang.z;
-          }
-          if (tid < nkk && tp[3 + tid] != 0.0) {
-            const int cc = tid, fi = (int)tp[3 + nkk + cc], i = mframe[fi];
-            const V3 rr = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i) - com;
-            const M3 Rx = skew_m(rr);
-            for (int e = 0; e < 3; ++e) {
-              Jt[e * nz + n + 6 * cc + e] = 1.0;
-              Jt[(3 + e) * nz + n + 6 * cc + 3 + e] = 1.0;
-              for (int e2 = 0; e2 < 3; ++e2) Jt[(3 + e) * nz + n + 6 * cc + e2] = Rx.m[3 * e + e2];
-            }
-          }
-        }
-      } else if (tr.type == MPC_TERM_MB_WRENCH_CONE) {
-        for (int i = tid; i < d; i += nthr) { double s = 0; for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * lam[6 * tr.i0 + j]; r[i] = s; }
-        if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) {
-          const int i = idx / nz, z = idx % nz;
-          double s = 0;
-          for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * R2[(6 * tr.i0 + j) * ldR + z];
-          Jt[idx] = s;
-        }
-      }
-      __syncthreads();
+      if (!is_cost) row += d;
+      EV_PROF(13 + tr.type);
     }
-    if (generic) {
-      if (is_cost) {
-        const double* W = P + tr.woff;
-        bool wdiag = (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) != 0;
-        if (!wdiag) { wdiag = true; for (int e = 0; e < d * d; ++e) if ((e / d != e % d) && W[e] != 0.0) wdiag = false; }
-        if (wdiag && d <= 24) {
-          // 1/2 r^T W r with W = diag(w): stack sqrt(w_i) J_i and sqrt(w_i) r_i  (H += JS^T JS, grad += JS^T wrs)
-          const int wstride = (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) ? 1 : d + 1;
-          if (tid == 0) { double cst = 0; for (int i = 0; i < d; ++i) cst += W[i * wstride] * r[i] * r[i]; s_cost += 0.5 * cst; }
-          if (derivs) {
-            for (int i = tid; i < d; i += nthr) wrs[rowc + i] = sqrt(W[i * wstride]) * r[i];
-            for (int idx = tid; idx < d * nz; idx += nthr) Jt[idx] *= sqrt(W[(idx / nz) * wstride]);
-            rowc += d;
-          }
-          __syncthreads();
-        } else {
-          // dense weight: unfused path through the HBM scratch
-          if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) JtG[idx] = Jt[idx];
-          __syncthreads();
-          accumulate_cost(KL, kn, tr, W, r, JtG, nz, nz, red, WJ, derivs, s_cost, tid, nthr);
-        }
-      } else {
-        emit_constraint(KL, kn, tr, P, row, r, Jt, nz, nz, derivs, tid, nthr);
-      }
-    }
-    if (tr.role != MPC_ROLE_COST) row += d;
-    EV_PROF(13 + tr.type);
   }
-  if (derivs && rowc > 0) flush_stack();
-  if (derivs) for (int z = tid; z < nz; z += nthr) kn[KL.oH + (size_t)z * KL.nz + z] += a.opt.reg_init;
+  __syncthreads();
+
+  // ---- pass A: stacked cost terms, one per wavefront; then H = JS^T JS (+ diagonal / base additions) on the MFMA ----
+  const int nchunks = tmeta[0];
+  for (int ch = 0; ch < (nchunks > 0 ? nchunks : 1); ++ch) {
+    int rowc = 0, ord = 0;
+    for (int t = 0; t < nterms; ++t) {
+      if (tkind[t] != 1 || tchunk[t] != ch) continue;
+      const TermRec tr = load_term(desc, t);
+      const int d = tr.dim;
+      if (trow[t] + d > rowc) rowc = trow[t] + d;
+      if ((ord++ % nw) != wv) continue;
+      double* r = red + 288 + 24 * wv;  // private residual scratch of this wavefront
+      double* Jt = JS + trow[t] * nz;
+      term_rows(tr, P + tr.poff, se3 + 48 * tse3[t], r, Jt, lane, 64, false);
+      const double* W = P + tr.woff;
+      const int wstride = (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) ? 1 : d + 1;
+      if (lane == 0) { double cst = 0; for (int i = 0; i < d; ++i) cst += W[i * wstride] * r[i] * r[i]; tcost[t] = 0.5 * cst; }
+      if (derivs) {
+        if (lane < d) wrs[trow[t] + lane] = sqrt(W[lane * wstride]) * r[lane];
+        for (int idx = lane; idx < d * nz; idx += 64) Jt[idx] *= sqrt(W[(idx / nz) * wstride]);
+      }
+    }
+    EV_PROF(28);
+    if (derivs) {
+      const int kc = (rowc + 3) & ~3;  // MFMA K granularity: zero rows up to a multiple of 4
+      __syncthreads();
+      for (int idx = tid; idx < (kc - rowc) * nz; idx += nthr) JS[rowc * nz + idx] = 0.0;
+      __syncthreads();
+      for (int z = tid; z < nz; z += nthr) {
+        double g = 0;
+        for (int i = 0; i < rowc; ++i) g += JS[i * nz + z] * wrs[i];
+        gacc[z] += g;
+      }
+      // upper block triangle of 16x16 tiles, mirrored on the way out; the first chunk writes, later ones accumulate
+      const int nzt = (nz + 15) >> 4;
+      for (int t = wv; t < nzt * (nzt + 1) / 2; t += nw) {
+        int ta = 0, rem = t;
+        while (rem >= nzt - ta) { rem -= nzt - ta; ++ta; }
+        const int tb = ta + rem;
+        d4_t h = d4_t{0, 0, 0, 0};
+        mma_tile<false>(h, JS + ta * 16, 1, nz, JS + tb * 16, nz, 1, kc, lane);
+        const int zb = tb * 16 + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int za = ta * 16 + (lane >> 4) + 4 * q;
+          if (za < nz && zb < nz) {
+            double hv = h[q];
+            if (ch == 0) {
+              if (za == zb) hv += hdg[za];
+              if (za < 6 && zb < 6) hv += hbb[6 * za + zb];
+              kn[KL.oH + (size_t)za * KL.nz + zb] = hv;
+              if (ta != tb) kn[KL.oH + (size_t)zb * KL.nz + za] = hv;
+            } else {
+              kn[KL.oH + (size_t)za * KL.nz + zb] += hv;
+              if (ta != tb) kn[KL.oH + (size_t)zb * KL.nz + za] += hv;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    EV_PROF(27);
+  }
+  if (derivs) for (int z = tid; z < nz; z += nthr) kn[KL.oG + z] = gacc[z];
+  // ---- pass C: cost terms with dense weights (none in the three Talos problems): HBM read-modify-write path ----
+  if (tmeta[1]) {
+    __syncthreads();
+    double* r = red + 2 * 256 - 64;
+    for (int t = 0; t < nterms; ++t) {
+      if (tkind[t] != 2) continue;
+      const TermRec tr = load_term(desc, t);
+      term_rows(tr, P + tr.poff, se3 + 48 * tse3[t], r, JS, tid, nthr, true);
+      if (derivs) for (int idx = tid; idx < tr.dim * nz; idx += nthr) JtG[idx] = JS[idx];
+      __syncthreads();
+      double cst = 0.0;
+      accumulate_cost(KL, kn, tr, P + tr.woff, r, JtG, nz, nz, red, WJ, derivs, cst, tid, nthr);
+      if (tid == 0) tcost[t] = cst;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { double sc = 0; for (int t = 0; t < nterms; ++t) sc += tcost[t]; s_cost = sc; }
   __syncthreads();
 
   EV_PROF(11);

@@ -34,11 +34,12 @@ ev = {0: 'load, FK, joint columns', 1: 'velocities, inertias, composites, U', 2:
 terms = {1: 'state_error', 2: 'control_error', 3: 'frame_placement', 4: 'frame_translation', 5: 'frame_velocity', 6: 'com_translation',
          7: 'centroidal_momentum', 8: 'contact_force', 9: 'mb_wrench_cone', 10: 'centroidal_wrench_cone', 13: 'centroidal_momentum_der'}
 e = p[32:]
-etot = sum(e[i] for i in ev) + sum(e[13 + t] for t in terms) + e[27]
+etot = sum(e[i] for i in ev) + sum(e[13 + t] for t in terms) + e[27] + e[28]
 for i, name in ev.items():
     print('EVAL %-40s %7.1f us %5.1f%%' % (name, e[i] / TICKS / (GHZ * 1e3), 100 * e[i] / etot))
 for t, name in terms.items():
     if e[13 + t] > 0:
         print('EVAL term %-35s %7.1f us %5.1f%%' % (name, e[13 + t] / TICKS / (GHZ * 1e3), 100 * e[13 + t] / etot))
+print('EVAL %-40s %7.1f us %5.1f%%' % ('stacked cost terms (one per wavefront)', e[28] / TICKS / (GHZ * 1e3), 100 * e[28] / etot))
 print('EVAL %-40s %7.1f us %5.1f%%' % ('Gauss-Newton Hessian flush (MFMA)', e[27] / TICKS / (GHZ * 1e3), 100 * e[27] / etot))
 print('EVAL total %.1f us per workgroup (knot 1 of instance 0)' % (etot / TICKS / (GHZ * 1e3)))
