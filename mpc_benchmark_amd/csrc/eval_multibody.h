@@ -290,22 +290,15 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
       const double* du = a.dus + ((size_t)b * N + k) * nu;
       for (int i = tid; i < nu; i += nthr) u[i] = us[i] + (TRIAL ? alpha * du[i] : 0.0);
     }
+    // tree tables; the bit masks (model constants) were built on the host by mpc_set_model
+    const unsigned long long* gmask = (const unsigned long long*)(a.model_i + L.model_mask_off);
     for (int i = tid; i < nj; i += nthr) {
       parent[i] = mj[4 * i]; jkind[i] = mj[4 * i + 1]; jidxv[i] = mj[4 * i + 3];
-      unsigned long long msk = 0ull;
-      for (int j = i; j >= 0; j = mj[4 * j]) msk |= 1ull << j;
-      anc[i] = msk;
+      anc[i] = gmask[i]; sub[i] = gmask[nj + i]; dmask[i] = gmask[2 * nj + i];
       const int ndof = (mj[4 * i + 1] == MPC_JOINT_FREEFLYER) ? 6 : 1;
       for (int d = 0; d < ndof; ++d) dof_body[mj[4 * i + 3] + d] = i;
     }
     if (tid == 0) s_cost = 0.0;
-  }
-  __syncthreads();
-  for (int i = tid; i < nj; i += nthr) {
-    unsigned long long ms = 0ull, md_ = 0ull;
-    for (int j = i; j < nj; ++j) if ((anc[j] >> i) & 1ull) ms |= 1ull << j;
-    for (int kd = 0; kd < nv; ++kd) if ((anc[i] >> dof_body[kd]) & 1ull) md_ |= 1ull << kd;
-    sub[i] = ms; dmask[i] = md_;
   }
   __syncthreads();
   const double* q = x;
@@ -624,8 +617,8 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     __syncthreads();
   }
 
-  // ---- P9: derivative building blocks (also needed by velocity-dependent residuals) ------------------------
-  for (int kd = tid; kd < nv; kd += nthr) {
+  // ---- P9: derivative building blocks (Jacobians only: the value-only pass skips them) ----------------------
+  if (derivs) for (int kd = tid; kd < nv; kd += nthr) {
     const int pb = parent[dof_body[kd]];
     const S6 vl = (pb >= 0) ? ld6(ov + 6 * pb) : zero6();
     const S6 al = (pb >= 0) ? ld6(oa + 6 * pb) : a0;

@@ -310,12 +310,34 @@ int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double*
         n_d < MPC_MODEL_HEADER_DOUBLES + MPC_MODEL_JOINT_DOUBLES * nj + MPC_MODEL_FRAME_DOUBLES * nf + MPC_MODEL_CONTACT_DOUBLES * ncn)
       throw std::runtime_error("model table size mismatch");
     HIP_OK(hipStreamSynchronize(s->stream));
-    s->d_model_i = s->alloc<int32_t>(n_i);
+    // device copy of the int table = the caller's table followed by the 64-bit tree masks the whole-body kernel walks
+    // (ancestors of a body, bodies of its subtree, dofs on its root path), two int32 words each
+    const int nvm = itab[2];
+    std::vector<int32_t> ext(itab, itab + n_i);
+    if (s->dims.space == MPC_SPACE_MULTIBODY) {
+      const int32_t* mj = itab + MPC_MODEL_HEADER_WORDS;
+      std::vector<unsigned long long> anc(nj, 0ull), sub(nj, 0ull), dm(nj, 0ull);
+      std::vector<int> dof_body(nvm, 0);
+      for (int i = 0; i < nj; ++i) {
+        for (int j = i; j >= 0; j = mj[4 * j]) anc[i] |= 1ull << j;
+        const int ndof = (mj[4 * i + 1] == MPC_JOINT_FREEFLYER) ? 6 : 1;
+        for (int d = 0; d < ndof; ++d) dof_body[mj[4 * i + 3] + d] = i;
+      }
+      for (int i = 0; i < nj; ++i) {
+        for (int j = i; j < nj; ++j) if ((anc[j] >> i) & 1ull) sub[i] |= 1ull << j;
+        for (int kd = 0; kd < nvm; ++kd) if ((anc[i] >> dof_body[kd]) & 1ull) dm[i] |= 1ull << kd;
+      }
+      if (ext.size() & 1) ext.push_back(0);  // 8-byte alignment of the mask block
+      s->L.model_mask_off = (int)ext.size();
+      for (const auto* v : {&anc, &sub, &dm})
+        for (int i = 0; i < nj; ++i) { ext.push_back((int32_t)((*v)[i] & 0xffffffffull)); ext.push_back((int32_t)((*v)[i] >> 32)); }
+    }
+    s->d_model_i = s->alloc<int32_t>(ext.size());
     s->d_model_d = s->alloc<double>(n_d);
-    HIP_OK(hipMemcpy(s->d_model_i, itab, n_i * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(s->d_model_i, ext.data(), ext.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(s->d_model_d, dtab, n_d * sizeof(double), hipMemcpyHostToDevice));
     s->h_model_i.assign(itab, itab + n_i);
-    s->L.nj = nj; s->LT.nj = nj;
+    s->L.nj = nj; s->LT.nj = nj; s->LT.model_mask_off = s->L.model_mask_off;
     if (s->dims.space == MPC_SPACE_MULTIBODY) {
       if (itab[2] * 2 != s->L.n || itab[1] + itab[2] != s->L.nx) throw std::runtime_error("model dimensions do not match the state space");
       check_multibody_model(itab, n_i);
