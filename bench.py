@@ -74,17 +74,31 @@ def main():
         c = e.cold_solve(max_iters=100)
         cold = cold or c
 
-    def step_all():
+    def run_ticks(count):
+        """`count` MPC ticks of every shard.  Shards are independent ensembles: each one is driven by its own host
+        thread (ctypes releases the GIL), so that they run out of phase on the device instead of in lock step."""
         if nshard == 1:
-            shards[0].step()  # synchronous form: exactly one solver pass per tick
+            for _ in range(count):
+                shards[0].step()  # synchronous form: exactly one solver pass per tick
             return
-        for e in shards:
-            e.step_async()
-        for e in shards:
-            e.wait()
+        import threading
+        errs = []
 
-    for _ in range(args.warmup):
-        step_all()
+        def drive(e):
+            try:
+                for _ in range(count):
+                    e.step()
+            except Exception as ex:  # noqa: BLE001 - re-raised on the main thread
+                errs.append(ex)
+        th = [threading.Thread(target=drive, args=(e,)) for e in shards]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+
+    run_ticks(args.warmup)
 
     def sync_all():
         for e in shards:
@@ -99,8 +113,7 @@ def main():
         e.native.profile(1)
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step_all()
+    run_ticks(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
     for e in shards:

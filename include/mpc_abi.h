@@ -158,6 +158,11 @@ int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double*
 int mpc_set_stage(mpc_solver* s, int32_t k, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params);
 /* setReference / contact_poses[i] = ... : overwrite n doubles of stage k's parameter table. */
 int mpc_update_stage_params(mpc_solver* s, int32_t k, int32_t offset, const double* vals, int32_t n);
+/* The per-tick form of the above (fulldynamic_talos.py:461-463 calls setReference on two residuals of every stage of
+ * the horizon): `count` updates in one call — update i overwrites lens[i] doubles at offsets[i] of stage ks[i]; `vals`
+ * holds the new values back to back. */
+int mpc_update_stage_params_batch(mpc_solver* s, int32_t count, const int32_t* ks, const int32_t* offsets, const int32_t* lens,
+                                  const double* vals);
 /* replaceStageCircular + cycleAppend/cycleProblem: drop stage 0, shift, install the new stage at N-1. */
 int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params);
 

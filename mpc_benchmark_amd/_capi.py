@@ -78,6 +78,7 @@ _SIGNATURES = {
     "mpc_set_model": (C.c_int, [C.c_void_p, _IP, C.c_int32, _DP, C.c_int32]),
     "mpc_set_stage": (C.c_int, [C.c_void_p, C.c_int32, _IP, C.c_int32, _DP, C.c_int32]),
     "mpc_update_stage_params": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _DP, C.c_int32]),
+    "mpc_update_stage_params_batch": (C.c_int, [C.c_void_p, C.c_int32, _IP, _IP, _IP, _DP]),
     "mpc_cycle": (C.c_int, [C.c_void_p, _IP, C.c_int32, _DP, C.c_int32]),
     "mpc_set_x0": (C.c_int, [C.c_void_p, _DP]),
     "mpc_setup": (C.c_int, [C.c_void_p]),
@@ -178,6 +179,19 @@ class NativeSolver:
     def update_stage_params(self, k, offset, vals):
         vals = _f64(vals).ravel()
         self._check(self.lib.mpc_update_stage_params(self._h, k, offset, _dp(vals), vals.size), "mpc_update_stage_params")
+
+    def update_stage_params_batch(self, updates):
+        """``updates``: iterable of (k, offset, values) — one library call, one stream synchronisation."""
+        updates = list(updates)
+        if not updates:
+            return
+        ks = _i32([u[0] for u in updates])
+        offs = _i32([u[1] for u in updates])
+        chunks = [_f64(u[2]).ravel() for u in updates]
+        lens = _i32([c.size for c in chunks])
+        vals = _f64(np.concatenate(chunks))
+        self._check(self.lib.mpc_update_stage_params_batch(self._h, len(updates), ks.ctypes.data_as(_IP), offs.ctypes.data_as(_IP),
+                                                           lens.ctypes.data_as(_IP), _dp(vals)), "mpc_update_stage_params_batch")
 
     def cycle(self, desc, params):
         desc, params = _i32(desc), _f64(params)

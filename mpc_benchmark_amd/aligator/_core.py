@@ -48,6 +48,34 @@ class _Owned:
             child._owner = self
         return child
 
+    def _ref_flat(self):
+        """The reference as it sits in the stage's parameter table (what ``_lower`` returns as its last element)."""
+        return np.asarray(self._ref, dtype=float).reshape(-1)
+
+    def _owner_node(self):
+        o = self
+        while o is not None:
+            if isinstance(o, (StageModel, _TerminalNode)):
+                return o
+            o = getattr(o, "_owner", None)
+        return None
+
+    def _reference_changed(self, flat):
+        """A reference / target value changed.  Fast path (what the MPC loops do 2 N times per tick, fulldynamic_talos.py:
+        461-463): the stage is lowered and structurally unchanged, so the new values are written straight into its
+        parameter table at the slot recorded by ``lower_stage`` and only those doubles travel to the device.
+        Anything else falls back to re-lowering the whole stage."""
+        slot = getattr(self, "_slot", None)
+        if slot is not None:
+            node, off, size = slot
+            flat = np.asarray(flat, dtype=float).reshape(-1)
+            if (node._lowered is not None and not node._dirty and flat.size == size and self._owner_node() is node
+                    and off + size <= node._lowered[1].size):
+                node._lowered[1][off:off + size] = flat
+                node._patches.append((off, size))
+                return
+        self._touch()
+
 
 # ------------------------------------------------------------------------------------------------
 # constraint sets (aligator.constraints)
@@ -181,9 +209,12 @@ class FramePlacementResidual(_FrameFunction):
         self.pin_model, self.frame_id = model, int(frame_id)
         self._ref = ref.copy()
 
+    def _ref_flat(self):
+        return _se3_flat(self._ref)
+
     def setReference(self, ref):
         self._ref = ref.copy()
-        self._touch()
+        self._reference_changed(self._ref_flat())
 
     def getReference(self):
         return self._ref
@@ -202,7 +233,7 @@ class FrameTranslationResidual(_FrameFunction):
 
     def setReference(self, ref):
         self._ref = _vec(ref, 3)
-        self._touch()
+        self._reference_changed(self._ref_flat())
 
     def getReference(self):
         return self._ref
@@ -223,7 +254,7 @@ class FrameVelocityResidual(_FrameFunction):
 
     def setReference(self, ref):
         self._ref = _vec(getattr(ref, "np", ref), 6)
-        self._touch()
+        self._reference_changed(self._ref_flat())
 
     def getReference(self):
         return self._ref
@@ -242,7 +273,7 @@ class CenterOfMassTranslationResidual(StageFunction):
 
     def setReference(self, ref):
         self._ref = _vec(ref, 3)
-        self._touch()
+        self._reference_changed(self._ref_flat())
 
     def getReference(self):
         return self._ref
@@ -261,7 +292,7 @@ class CentroidalMomentumResidual(StageFunction):
 
     def setReference(self, ref):
         self._ref = _vec(ref, 6)
-        self._touch()
+        self._reference_changed(self._ref_flat())
 
     def getReference(self):
         return self._ref
@@ -292,7 +323,7 @@ class ContactForceResidual(StageFunction):
 
     def setReference(self, ref):
         self._ref = _vec(ref, 6)
-        self._touch()
+        self._reference_changed(self._ref_flat())
 
     def getReference(self):
         return self._ref
@@ -425,15 +456,18 @@ class _CentroidalSlice(StageFunction):
 
     def setReference(self, ref):
         self._ref = _vec(ref, 3)
-        self._touch()
+        self._reference_changed(self._ref_flat())
 
     def getReference(self):
         return self._ref
 
-    def _lower(self, ctx):
+    def _ref_flat(self):
         full = np.zeros(self.ndx)
         full[self._start:self._start + 3] = self._ref
-        return K.TERM_STATE_ERROR, 3, self._start, 0, full
+        return full
+
+    def _lower(self, ctx):
+        return K.TERM_STATE_ERROR, 3, self._start, 0, self._ref_flat()
 
 
 class CentroidalCoMResidual(_CentroidalSlice):
@@ -795,8 +829,9 @@ def _lower_weight(term_type, dim, W, space):
     return W.reshape(-1).copy(), 0
 
 
-def lower_stage(ctx, cost, dynamics, constraints):
-    """-> (desc int32[], params float64[]) for one stage (``dynamics`` is None on the terminal node)."""
+def lower_stage(ctx, cost, dynamics, constraints, slots=None):
+    """-> (desc int32[], params float64[]) for one stage (``dynamics`` is None on the terminal node).  ``slots`` (a list)
+    receives (residual, offset, size) for every term: where its reference sits in the parameter table."""
     params = []
     off = [0]
 
@@ -850,7 +885,11 @@ def lower_stage(ctx, cost, dynamics, constraints):
             ctx.set_model(c.residual.pin_model)
         t, dim, i0, i1, p = c.residual._lower(ctx)
         Wf, flags = _lower_weight(t, dim, c.weights * w, c.space)
-        records.append([t, K.ROLE_COST, dim, i0, i1, push(p), push(Wf), flags])
+        poff = push(p)
+        if slots is not None:
+            res = c.residual.func if isinstance(c.residual, FunctionSlice) else c.residual
+            slots.append((res, poff, int(np.asarray(p).size)))
+        records.append([t, K.ROLE_COST, dim, i0, i1, poff, push(Wf), flags])
     for f, s in zip(constraints.funcs, constraints.sets):
         if hasattr(f, "pin_model"):
             ctx.set_model(f.pin_model)
@@ -859,6 +898,8 @@ def lower_stage(ctx, cost, dynamics, constraints):
             ctx.set_model(inner.space.model)
         t, dim, i0, i1, p = f._lower(ctx)
         poff = push(p)
+        if slots is not None:
+            slots.append((inner, poff, int(np.asarray(p).size)))
         woff = 0
         if s._role == K.ROLE_BOX:
             if s.lower_limit.size != dim or s.upper_limit.size != dim:

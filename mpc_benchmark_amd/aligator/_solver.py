@@ -158,8 +158,13 @@ class SolverProxDDP:
     # -- lowering / device sync -----------------------------------------------------------------
     def _lower_node(self, node, cost, dynamics, constraints):
         if node._dirty or node._lowered is None:
-            node._lowered = core.lower_stage(self._ctx, cost, dynamics, constraints)
+            slots = []
+            node._lowered = core.lower_stage(self._ctx, cost, dynamics, constraints, slots)
             node._dirty = False
+            node._patches = []
+            for res, off, size in slots:
+                if hasattr(res, "_ref"):
+                    res._slot = (node, off, size)  # setReference writes here from now on (see _Owned._reference_changed)
             return True
         return False
 
@@ -235,16 +240,24 @@ class SolverProxDDP:
         if self._ctx.changed:
             nat.set_model(*self._ctx.model_tables())
             self._ctx.changed = False
+        batch = []
         for k in range(N + 1):
-            desc, params = self._node(problem, k)._lowered
+            node = self._node(problem, k)
+            desc, params = node._lowered
             up = self._uploaded[k]
             if up is not None and up[0] is desc and up[1] is params:
+                # unchanged structure: only the reference slots patched in place since the last upload travel
+                for off, size in node._patches:
+                    batch.append((k, off, params[off:off + size]))
+                node._patches = []
                 continue
+            node._patches = []
             if up is not None and np.array_equal(up[0], desc) and up[1].size == params.size:
                 nat.update_stage_params(k, 0, params)
             else:
                 nat.set_stage(k, desc, params)
             self._uploaded[k] = (desc, params)
+        nat.update_stage_params_batch(batch)
 
     def cycleProblem(self, problem, stage_data=None):
         """kinodynamic_talos.py:488 / centroidal_talos.py:460 — the rotation itself was recorded by

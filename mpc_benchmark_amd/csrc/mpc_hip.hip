@@ -100,7 +100,16 @@ struct mpc_solver {
 static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->dims = d;
   HIP_OK(hipSetDevice(d.device));
-  HIP_OK(hipStreamCreate(&s->stream));
+  {
+    // Ensemble shards on one GPU (several handles) are given alternating stream priorities: the dispatcher then runs the
+    // shards out of phase — the sequential Riccati sweep of one shard (B workgroups) overlaps the wide per-knot kernels
+    // of the other instead of both shards executing the same kernel type side by side.
+    static int created = 0;
+    int lo = 0, hi = 0;
+    HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const int prio = (created++ % 2 == 0) ? hi : lo;
+    HIP_OK(hipStreamCreateWithPriority(&s->stream, hipStreamDefault, prio));
+  }
   Layout& L = s->L;
   L.N = d.horizon; L.B = d.batch; L.space = d.space; L.nx = d.nx; L.n = d.ndx; L.m = d.nu; L.c = d.nc_max > 0 ? d.nc_max : 1;
   L.nj = 0;
@@ -355,6 +364,21 @@ int mpc_set_stage(mpc_solver* s, int32_t k, const int32_t* desc, int32_t n_desc,
   MPC_TRY(s, {
     if (k < 0 || k > s->L.N) throw std::runtime_error("stage index out of range");
     upload_stage(s, slot_of(s, k), desc, n_desc, params, n_params);
+  })
+}
+
+int mpc_update_stage_params_batch(mpc_solver* s, int32_t count, const int32_t* ks, const int32_t* offsets, const int32_t* lens,
+                                  const double* vals) {
+  MPC_TRY(s, {
+    size_t pos = 0;
+    for (int i = 0; i < count; ++i) {
+      if (ks[i] < 0 || ks[i] > s->L.N) throw std::runtime_error("stage index out of range");
+      if (offsets[i] < 0 || lens[i] < 0 || offsets[i] + lens[i] > s->L.max_stage_doubles) throw std::runtime_error("parameter update out of range");
+      HIP_OK(hipMemcpyAsync(s->d_stage_params + (size_t)slot_of(s, ks[i]) * s->L.max_stage_doubles + offsets[i], vals + pos,
+                            lens[i] * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      pos += lens[i];
+    }
+    HIP_OK(hipStreamSynchronize(s->stream));  // host buffers are not retained past the call
   })
 }
 

@@ -67,6 +67,20 @@ int mpc_update_stage_params(mpc_solver* h, int32_t k, int32_t offset, const doub
   })
 }
 
+int mpc_update_stage_params_batch(mpc_solver* h, int32_t count, const int32_t* ks, const int32_t* offsets, const int32_t* lens,
+                                  const double* vals) {
+  MPC_TRY(h, {
+    size_t pos = 0;
+    for (int i = 0; i < count; ++i) {
+      if (ks[i] < 0 || ks[i] > h->s.N()) throw std::runtime_error("stage index out of range");
+      auto& p = h->s.stages[ks[i]].params;
+      if (offsets[i] < 0 || lens[i] < 0 || offsets[i] + lens[i] > (int)p.size()) throw std::runtime_error("parameter update out of range");
+      std::memcpy(p.data() + offsets[i], vals + pos, lens[i] * sizeof(double));
+      pos += lens[i];
+    }
+  })
+}
+
 int mpc_cycle(mpc_solver* h, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params) {
   MPC_TRY(h, {
     const int N = h->s.N();
