@@ -123,6 +123,8 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
   double* kvc = dtl + L.c;
   double* e6l = kvc + L.c;  // 36 doubles; vec reserves 8 (nzp + c) + 64
   double* wred = e6l + 40;  // per-wavefront partial sums (<= 16)
+  double* t6l = e6l + 56;   // T6 = (-E6)^-1 (36)
+  double* gpre = e6l + 92;  // gradient of the knot (nz); vec holds 7 nzp + 2 c + 92 <= 8 (nzp + c) + 64 doubles
   double* wk = a.work + (size_t)b * L.work_stride;
   double* Hh = wk + L.wHh;  // nz x nz, leading dimension nz (L2-resident scratch)
 
@@ -154,18 +156,35 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
     __syncthreads();
   }
 
+  // The small per-knot vectors (row counts, active flags, E6, gap, multiplier estimate, gradient) of knot k - 1 are
+  // requested from HBM in the middle of knot k and sit in registers until the next iteration starts: one value per
+  // thread each, so no phase of a knot begins by waiting on a scattered HBM load.
+  double pre_m, pre_c, pre_act, pre_e6, pre_f, pre_le, pre_g;
+  auto prefetch_small = [&](int kk) {
+    const double* kp = knot_ptr(a, b, kk);
+    const int row = wv * 64 + lane;
+    pre_m = kp[L.oMISC + MISC_M]; pre_c = kp[L.oMISC + MISC_NC];
+    pre_act = kp[L.oACT + (row < L.c ? row : 0)];
+    pre_e6 = kp[L.oE6 + (tid < 36 ? tid : 0)];
+    pre_f = kp[L.oF + (tid < n ? tid : 0)];
+    pre_le = a.lams_e[((size_t)b * (N + 1) + kk + 1) * n + (tid < n ? tid : 0)];
+    pre_g = kp[L.oG + (tid < nz ? tid : 0)];
+  };
+  prefetch_small(N - 1);
+
   long long t0_ = clock64();
   for (int k = N - 1; k >= 0; --k) {
     const double* kn = knot_ptr(a, b, k);
     double* g = gain_ptr(a, b, k);
-    const int m = (int)kn[L.oMISC + MISC_M], c = (int)kn[L.oMISC + MISC_NC];
-    const double* le = a.lams_e + ((size_t)b * (N + 1) + k + 1) * n;
+    const int m = (int)pre_m, c = (int)pre_c;
     // ---- 1. active rows (ballot prefix; wave q owns rows 64q .. 64q+63, c <= 256), T6 = (-E6)^-1 ----
     const int arow = wv * 64 + lane;
-    const bool is_act = (arow < c) && (kn[L.oACT + arow] != 0.0);
+    const bool is_act = (arow < c) && (pre_act != 0.0);
     const unsigned long long amask = __ballot(is_act);
     if (lane == 0) iflag[2 + wv] = __popcll(amask);
-    if (tid < 36) e6l[tid] = -kn[L.oE6 + tid];
+    if (tid < 36) e6l[tid] = -pre_e6;
+    if (tid < n) ft[tid] = pre_f + mud * pre_le;
+    if (tid < nz) gpre[tid] = pre_g;
     __syncthreads();
     {
       int off = 0;
@@ -175,14 +194,15 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
         int ca_ = 0;
         for (int q = 0; q < nw; ++q) ca_ += iflag[2 + q];
         iflag[1] = ca_;
-        if (ff) inv6_unrolled(e6l, g + L.oT6);
-        else for (int i2 = 0; i2 < 36; ++i2) g[L.oT6 + i2] = (i2 % 7 == 0) ? 1.0 : 0.0;
+        if (ff) inv6_unrolled(e6l, t6l);
+        else for (int i2 = 0; i2 < 36; ++i2) t6l[i2] = (i2 % 7 == 0) ? 1.0 : 0.0;
       }
     }
     __syncthreads();
     RIC_PROF(0);
     const int ca = iflag[1];
-    const double* T6 = g + L.oT6;
+    const double* T6 = t6l;  // LDS copy; the gain record gets it below
+    if (tid < 36) g[L.oT6 + tid] = t6l[tid];
     if (ff) {
       double* tmp = LP;  // scratch (LP is dead here)
       for (int idx = tid; idx < n * 6; idx += nthr) {
@@ -207,7 +227,6 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
     } else {
       for (int i = tid; i < n; i += nthr) ph[i] = pvec[i];
     }
-    for (int i = tid; i < n; i += nthr) ft[i] = kn[L.oF + i] + mud * le[i];
     __syncthreads();
     RIC_PROF(1);
     // ---- 2. LP = Ph, ||Ph||_F ; vv = Ph ft + ph ----
@@ -243,6 +262,7 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
         pr[20] = fmax(pr[20], rho); pr[21] += (nser >= 0) ? nser : 0; pr[22] += (nser < 0) ? 1.0 : 0.0;
       }
     }
+    if (k > 0) prefetch_small(k - 1);  // consumed at the top of the next iteration
     RIC_PROF(13);
     if (nser >= 0) {
       // ---- 3a. series: every iterate is a polynomial in the symmetric Ph, hence symmetric — only the lower block
@@ -312,25 +332,35 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
         abr[q][1] = (ok1 && i < n) ? v1 : 0.0;
       }
     }
-    // w = vv - mud Pt vv, store Pt / yv for the forward sweep (Pt is symmetric up to rounding)
-    for (int i = wv; i < n; i += nw) {
-      double s = 0;
-      for (int j = lane; j < n; j += 64) { const double pv = PT[i * ldp + j]; s += pv * vv[j]; g[L.oMx + i * n + j] = pv; }
-      s = wave_sum_r(s);
-      if (lane == 0) w[i] = vv[i] - mud * s;
+    // w = vv - mud Pt vv, store Pt / yv for the forward sweep (Pt is symmetric up to rounding).  The wavefront that owns
+    // row i of Pt also holds row i of [A B] in registers: its share of gh = grad + [A B]^T w accumulates on the fly.
+    double gp0 = 0.0, gp1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < AB_ROWS; ++q) {
+      const int i = wv + nw * q;
+      if (i < n) {
+        double s = 0;
+        for (int j = lane; j < n; j += 64) { const double pv = PT[i * ldp + j]; s += pv * vv[j]; g[L.oMx + i * n + j] = pv; }
+        s = wave_sum_r(s);
+        const double wi = vv[i] - mud * s;
+        if (lane == 0) w[i] = wi;
+        gp0 += abr[q][0] * wi; gp1 += abr[q][1] * wi;
+      }
     }
     for (int i = tid; i < n; i += nthr) g[L.omx + i] = ft[i] - mud * ph[i];
     RIC_PROF(6);
-    // ---- 4. AB into LDS (zero padded; u-columns start at np) ----
+    // ---- 4. AB into LDS (zero padded; u-columns start at np) ; gh from the per-wavefront partial sums (GP is free) ----
 #pragma unroll
     for (int q = 0; q < AB_ROWS; ++q) {
       const int i = wv + nw * q;
       if (i < np) { if (lane < nzp) AB[i * nzp + lane] = abr[q][0]; if (lane + 64 < nzp) AB[i * nzp + lane + 64] = abr[q][1]; }
     }
+    if (lane < nzp) GP[wv * nzp + lane] = gp0;
+    if (lane + 64 < nzp) GP[wv * nzp + lane + 64] = gp1;
     __syncthreads();
     for (int zp = tid; zp < nzp; zp += nthr) {
       const int z = (zp < n) ? zp : ((zp >= np && zp - np < m) ? n + zp - np : -1);
-      if (z >= 0) { double s = kn[L.oG + z]; for (int i = 0; i < n; ++i) s += AB[i * nzp + zp] * w[i]; gh[z] = s; }
+      if (z >= 0) { double s = gpre[z]; for (int q = 0; q < nw; ++q) s += GP[q * nzp + zp]; gh[z] = s; }
     }
     RIC_PROF(7);
     if (S.gfull) {
