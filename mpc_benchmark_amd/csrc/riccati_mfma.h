@@ -262,6 +262,25 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
         pr[20] = fmax(pr[20], rho); pr[21] += (nser >= 0) ? nser : 0; pr[22] += (nser < 0) ? 1.0 : 0.0;
       }
     }
+    // [A B] of this knot: issue the HBM loads here (the series below hides their latency), park them in
+    // registers, drop them into LDS in step 4
+    double abr[AB_ROWS][2];
+    {
+      // column of [A B] behind padded column zp (x columns 0..n-1, u columns np..np+m-1), clamped to a valid one so
+      // that every load is unconditional (straight-line code: the loads of all rows are in flight together)
+      const int z0 = lane, z1 = lane + 64;
+      const bool ok0 = z0 < n || (z0 >= np && z0 - np < m), ok1 = z1 < n || (z1 >= np && z1 - np < m);
+      const int c0 = ok0 ? (z0 < n ? z0 : n + z0 - np) : 0, c1 = ok1 ? (z1 < n ? z1 : n + z1 - np) : 0;
+      const double* ab0 = kn + L.oAB;
+#pragma unroll
+      for (int q = 0; q < AB_ROWS; ++q) {
+        const int i = wv + nw * q;  // wave-uniform row
+        const double* src = ab0 + (size_t)(i < n ? i : 0) * nz;
+        const double v0 = src[c0], v1 = src[c1];
+        abr[q][0] = (ok0 && i < n) ? v0 : 0.0;
+        abr[q][1] = (ok1 && i < n) ? v1 : 0.0;
+      }
+    }
     if (k > 0) prefetch_small(k - 1);  // consumed at the top of the next iteration
     RIC_PROF(13);
     if (nser >= 0) {
@@ -313,25 +332,6 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
       __syncthreads();
     }
     RIC_PROF(5);
-    // [A B] of this knot: issue the HBM loads here (the vector work below hides part of their latency), park them in
-    // registers, drop them into LDS in step 4
-    double abr[AB_ROWS][2];
-    {
-      // column of [A B] behind padded column zp (x columns 0..n-1, u columns np..np+m-1), clamped to a valid one so
-      // that every load is unconditional (straight-line code: the loads of all rows are in flight together)
-      const int z0 = lane, z1 = lane + 64;
-      const bool ok0 = z0 < n || (z0 >= np && z0 - np < m), ok1 = z1 < n || (z1 >= np && z1 - np < m);
-      const int c0 = ok0 ? (z0 < n ? z0 : n + z0 - np) : 0, c1 = ok1 ? (z1 < n ? z1 : n + z1 - np) : 0;
-      const double* ab0 = kn + L.oAB;
-#pragma unroll
-      for (int q = 0; q < AB_ROWS; ++q) {
-        const int i = wv + nw * q;  // wave-uniform row
-        const double* src = ab0 + (size_t)(i < n ? i : 0) * nz;
-        const double v0 = src[c0], v1 = src[c1];
-        abr[q][0] = (ok0 && i < n) ? v0 : 0.0;
-        abr[q][1] = (ok1 && i < n) ? v1 : 0.0;
-      }
-    }
     // w = vv - mud Pt vv, store Pt / yv for the forward sweep (Pt is symmetric up to rounding).  The wavefront that owns
     // row i of Pt also holds row i of [A B] in registers: its share of gh = grad + [A B]^T w accumulates on the fly.
     double gp0 = 0.0, gp1 = 0.0;
