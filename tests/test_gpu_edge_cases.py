@@ -1,0 +1,120 @@
+"""GPU parity and invariants on the edges of the problem space: shortest horizons, stages without constraints or
+without contacts, the full-size benchmark workload (N = 100, complete model), ensembles vs single instances,
+run-to-run determinism.  The reference ships no tests; these are the cases its scripts can produce."""
+import numpy as np
+import pytest
+
+from mpc_benchmark_amd import aligator
+from mpc_benchmark_amd.ensemble import EnsembleMPC
+from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b))))) if a.size else 0.0
+
+
+def _solve(lib, prob, fp, xs, us, max_iters):
+    solver = fp.make_solver(_native_library=lib)
+    solver.max_iters = max_iters
+    solver.setup(prob)
+    prob.x0_init = xs[0]
+    solver.run(prob, xs, us)
+    return solver
+
+
+def _perturbed(fp, n, seed=3, sx=0.02, su=5.0):
+    rng = np.random.default_rng(seed)
+    xs = [fp.space.integrate(fp.x0, sx * rng.standard_normal(fp.space.ndx)) for _ in range(n + 1)]
+    us = [su * rng.standard_normal(fp.nu) for _ in range(n)]
+    return xs, us
+
+
+@pytest.mark.parametrize("horizon", [1, 2])
+def test_shortest_horizons(hip_lib, oracle_lib, horizon):
+    out = {}
+    for name, lib in (("hip", hip_lib), ("ref", oracle_lib)):
+        fp = FullDynamicsProblem(horizon=horizon)
+        prob = fp.build(with_terminal_constraint=True)
+        xs, us = _perturbed(fp, horizon)
+        s = _solve(lib, prob, fp, xs, us, 3)
+        out[name] = (np.array(s.results.xs), np.array(s.results.us), np.array(s.results.controlFeedbacks()))
+    assert _rel(out["hip"][0], out["ref"][0]) < 1e-7 and _rel(out["hip"][1], out["ref"][1]) < 1e-6
+    assert _rel(out["hip"][2], out["ref"][2]) < 1e-6
+
+
+def _stage(fp, cs, with_constraints):
+    lf, rf = fp.robot.foot_placements
+    st = fp.create_stage(cs, lf.copy(), rf.copy())
+    if with_constraints:
+        return st
+    return aligator.StageModel(st.cost, st.dynamics)  # same cost and dynamics, empty constraint stack
+
+
+def test_unconstrained_and_flight_stages(hip_lib, oracle_lib):
+    """Stages with no constraint at all, and stages with no contact (free flight: no KKT block, no force terms)."""
+    pattern = [([True, True], False), ([True, False], False), ([False, False], False), ([False, False], True), ([True, True], True)]
+    out = {}
+    for name, lib in (("hip", hip_lib), ("ref", oracle_lib)):
+        fp = FullDynamicsProblem(horizon=len(pattern))
+        stages = [_stage(fp, cs, wc) for cs, wc in pattern]
+        prob = aligator.TrajOptProblem(fp.x0, stages, fp.terminal_cost())
+        xs, us = _perturbed(fp, len(pattern), seed=5)
+        s = _solve(lib, prob, fp, xs, us, 1)
+        dumps = {q: [s._native.debug_get(q, k) for k in range(len(pattern))] for q in ("cost", "f", "H", "AB", "grad", "K", "kff", "dx", "du")}
+        out[name] = (np.array(s.results.xs), np.array(s.results.us), dumps)
+    for q, tol in (("cost", 1e-9), ("f", 1e-9), ("H", 1e-9), ("AB", 1e-9), ("grad", 1e-9), ("K", 1e-7), ("kff", 1e-7), ("dx", 1e-7), ("du", 1e-7)):
+        for a, b in zip(out["hip"][2][q], out["ref"][2][q]):
+            assert _rel(a, b) < tol, q
+    assert _rel(out["hip"][0], out["ref"][0]) < 1e-8 and _rel(out["hip"][1], out["ref"][1]) < 1e-7
+
+
+def test_full_size_workload_one_iteration(hip_lib, oracle_lib):
+    """The benchmark's own sizes: N = 100, complete model (nq = 39), double support with cones, limits and the terminal
+    CoM constraint — one iteration from a perturbed trajectory, every knot of the LQ problem and the step compared."""
+    N = 100
+    out = {}
+    for name, lib in (("hip", hip_lib), ("ref", oracle_lib)):
+        fp = FullDynamicsProblem(horizon=N, complete_model=True)
+        prob = fp.build(with_terminal_constraint=True)
+        xs, us = _perturbed(fp, N, seed=9, sx=0.01, su=2.0)
+        s = _solve(lib, prob, fp, xs, us, 1)
+        ks = [0, 1, 37, 98, 99]
+        dumps = {q: [s._native.debug_get(q, k) for k in ks] for q in ("cost", "f", "H", "AB", "CD", "grad", "P", "K", "kff")}
+        out[name] = (np.array(s.results.xs), np.array(s.results.us), dumps, s.results.traj_cost, s.results.prim_infeas, s.results.dual_infeas)
+    for q, tol in (("cost", 1e-9), ("f", 1e-9), ("H", 1e-9), ("AB", 1e-9), ("CD", 1e-9), ("grad", 1e-9), ("P", 1e-6), ("K", 1e-6), ("kff", 1e-6)):
+        for a, b in zip(out["hip"][2][q], out["ref"][2][q]):
+            assert _rel(a, b) < tol, q
+    assert _rel(out["hip"][0], out["ref"][0]) < 1e-6 and _rel(out["hip"][1], out["ref"][1]) < 1e-6   # BASELINE tolerance
+    assert abs(out["hip"][3] - out["ref"][3]) < 1e-8 * max(1.0, abs(out["ref"][3]))
+    assert abs(out["hip"][4] - out["ref"][4]) < 1e-7 * max(1.0, out["ref"][4])
+
+
+def test_ensemble_instance_equals_single_instance_and_is_deterministic(hip_lib):
+    """Instances of an ensemble never interact: instance b of a batch of 5 is bitwise the batch-of-1 solve of the same
+    initial state, and a repeated run reproduces every bit (fixed reduction orders, no atomics)."""
+    pd = FullDynamicsProblem(horizon=30, complete_model=False)
+
+    def run(batch, seed):
+        ens = EnsembleMPC(pd, batch=batch, library=hip_lib, seed=seed)
+        ens.prepare_schedule(8)
+        ens.cold_solve(max_iters=20)
+        for _ in range(4):
+            ens.step()
+        return ens, ens.results(gains=True)
+    ens5, r5 = run(5, 123)
+    _, r5b = run(5, 123)
+    for key in r5:
+        assert np.array_equal(r5[key], r5b[key]), key
+    # rebuild instance 3 alone: same x0, same schedule
+    one = EnsembleMPC(pd, batch=1, library=hip_lib, perturb=False)
+    one.x0[0] = ens5.x0[3]
+    one.prepare_schedule(8)
+    one.cold_solve(max_iters=20)
+    for _ in range(4):
+        one.step()
+    r1 = one.results(gains=True)
+    for key in r5:
+        assert np.array_equal(r5[key][3], r1[key][0]), key
