@@ -585,24 +585,36 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
       g[L.op + r] = t;
       pvec[r] = t;
     }
-    // ---- 7. P = Qh + Sh K + Ca^T Kv  ->  PT (next knot's P'); only the upper block triangle is computed ----
+    // ---- 7. P = Qh + Sh K + Ca^T Kv  ->  PT (next knot's P'): lower block triangle on the MFMA, mirrored into the upper
+    // one (P is symmetric); diagonal tiles are symmetrised in place by the wavefront that produced them ----
     if (small_ca) {
       const int kc = (ca + 3) & ~3;
-      for (int t = wv; t < nb * nb; t += nw) {
-        const int ri = t / nb, cj = t % nb;
+      for (int t = wv; t < nb * (nb + 1) / 2; t += nw) {
+        int ri = 0, cj = t;
+        while (cj > ri) { cj -= ri + 1; ++ri; }  // t = ri (ri + 1) / 2 + cj, cj <= ri
         const int col = cj * 16 + (lane & 15);
         double qh[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; qh[q] = (row < n && col < n) ? (ri >= cj ? Hh[row * nz + col] : Hh[col * nz + row]) : 0.0; }  // Hh: lower block triangle only
+        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; qh[q] = (row < n && col < n) ? Hh[row * nz + col] : 0.0; }  // Hh: lower block triangle
         d4_t acc = d4_t{0, 0, 0, 0};
         mma_tile<false>(acc, ST + ri * 16, 1, np, W + cj * 16, lw, 1, mp, lane);
         if (kc > 0) mma_tile<false>(acc, CTl + ri * 16, 1, lw, VXl + cj * 16, lw, 1, kc, lane);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int row = ri * 16 + (lane >> 4) + 4 * q;
-          PT[row * ldp + col] = (row < n && col < n) ? qh[q] + acc[q] : 0.0;
+          const double pv = (row < n && col < n) ? qh[q] + acc[q] : 0.0;
+          PT[row * ldp + col] = pv;
+          if (ri != cj) PT[col * ldp + row] = pv;
+        }
+        if (ri == cj) {
+          double tv[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; tv[q] = 0.5 * (PT[row * ldp + col] + PT[col * ldp + row]); }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; PT[row * ldp + col] = tv[q]; }
         }
       }
+      __syncthreads();
     } else {
       const double *Ct = wk + L.wCt, *V = wk + L.wV;
       for (int r = wv; r < np; r += nw)
@@ -615,10 +627,8 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
           }
           PT[r * ldp + s] = t;
         }
-    }
-    __syncthreads();
-    // symmetrise in LDS (leading dimension np + 1: the transposed read is conflict-free), store the gain record
-    {
+      __syncthreads();
+      // symmetrise in LDS (leading dimension np + 1: the transposed read is conflict-free)
       double sv[AB_ROWS][2];
 #pragma unroll
       for (int q = 0; q < AB_ROWS; ++q) {
@@ -633,11 +643,15 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
       for (int q = 0; q < AB_ROWS; ++q) {
         const int i = wv + nw * q;
         if (i < n) {
-          if (lane < n) { PT[i * ldp + lane] = sv[q][0]; g[L.oP + i * n + lane] = sv[q][0]; }
-          if (lane + 64 < n) { PT[i * ldp + lane + 64] = sv[q][1]; g[L.oP + i * n + lane + 64] = sv[q][1]; }
+          if (lane < n) PT[i * ldp + lane] = sv[q][0];
+          if (lane + 64 < n) PT[i * ldp + lane + 64] = sv[q][1];
         }
       }
+      __syncthreads();
     }
+    // gain record: P of this knot, row by row (coalesced)
+    for (int i = wv; i < n; i += nw)
+      for (int j = lane; j < n; j += 64) g[L.oP + i * n + j] = PT[i * ldp + j];
     __syncthreads();
     RIC_PROF(12);
   }
