@@ -27,7 +27,7 @@ enum { MISC_COST = 0, MISC_PEN = 1, MISC_PRIM = 2, MISC_NC = 3, MISC_M = 4, MISC
 struct InstState {
   double mu, inner_tol, prim_tol;
   double phi0, dphi0, alpha, cost, prim, dual, crit;
-  int32_t num_iters, al_iters, converged, done, skip_step, ls_step, ls_more, pad1;
+  int32_t num_iters, al_iters, converged, done, skip_step, ls_step, ls_more, stalled;
 };
 
 static inline int align2(int x) { return (x + 1) & ~1; }

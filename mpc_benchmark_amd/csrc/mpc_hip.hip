@@ -155,8 +155,9 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   o.num_threads = 1; o.riccati_legs = 1; o.reserved = 0;
   HIP_OK(hipFuncSetAttribute((const void*)k_riccati_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   s->ric = make_ric_lds(L.n, L.m, L.c, 1);
-  if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0);  // panel-wise G when the whole G does not fit
-  s->use_mfma_riccati = s->ric.total_bytes <= 160 * 1024 && !getenv("MPC_HIP_GENERIC_RICCATI");
+  if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0);     // panel-wise G when the whole G does not fit
+  if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0, 0);  // large m: Sh^T out of LDS as well
+  s->use_mfma_riccati = s->ric.total_bytes <= 160 * 1024 && (s->ric.st_lds || s->ric.mp * s->ric.np <= L.n * L.nz) && !getenv("MPC_HIP_GENERIC_RICCATI");
   if (s->use_mfma_riccati)
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
   HIP_OK(hipStreamSynchronize(s->stream));
@@ -250,6 +251,15 @@ static void run_impl(mpc_solver* s, mpc_stats* stats, int passes_enqueued = 0) {
     int done = 0;
     HIP_OK(hipMemcpyAsync(&done, s->d_all_done, sizeof(int), hipMemcpyDeviceToHost, s->stream));
     HIP_OK(hipStreamSynchronize(s->stream));
+    if (const char* tr = getenv("MPC_HIP_TRACE")) {  // developer aid: per-pass solver state of one instance
+      const int tb = atoi(tr);
+      if (tb >= 0 && tb < L.B) {
+        InstState t;
+        HIP_OK(hipMemcpy(&t, s->d_inst + tb, sizeof(InstState), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[trace b=%d pass %d] it %d al %d mu %.1e phi0 %.10e dphi0 %.3e alpha %.4g ls %d prim %.3e dual %.3e crit %.3e inner_tol %.1e prim_tol %.1e skip %d stalled %d done %d\n",
+                tb, pass, t.num_iters, t.al_iters, t.mu, t.phi0, t.dphi0, t.alpha, t.ls_step, t.prim, t.dual, t.crit, t.inner_tol, t.prim_tol, t.skip_step, t.stalled, t.done);
+      }
+    }
     if (done != 0) break;
   }
   std::vector<InstState> st(L.B);

@@ -39,14 +39,15 @@
 #define RIC_PROF(slot) do { RIC_LAUNDER(); if (tid == 0 && a.prof) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 struct RicLds {
-  int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb, gfull;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
+  int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb, gfull, st_lds;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
   int PT, R1, LP, LI, AB, GP, vec, iwork, total_bytes;
   // KKT / value-update workspace carved from R1 once AB is dead
   int Lr, LIr, W, ST, CT, VX, Y, SC, LIs;
 };
 
-static inline RicLds make_ric_lds(int n, int m, int c, int gfull = 1) {
+static inline RicLds make_ric_lds(int n, int m, int c, int gfull = 1, int st_lds = 1) {
   RicLds s;
+  s.st_lds = st_lds;  // 0: Sh^T (mp x np) lives in the L2-resident per-instance scratch instead of LDS (large m)
   s.gfull = gfull;  // 1: G = Pt [A B] kept whole (x part over PT, u part in GP) — needs np x mp doubles for GP instead of np x 16
   s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.ldl = s.np + 1; s.ldr = s.mp + 1;
   s.nb = s.np / 16; s.nbm = s.mp / 16;
@@ -62,12 +63,12 @@ static inline RicLds make_ric_lds(int n, int m, int c, int gfull = 1) {
   s.AB = take(s.np * s.nzp); s.GP = take(s.np * (gfull ? s.mp : 16));               // phase 2 view (overlaps phase 1)
   const int end2 = o;
   o = s.R1;                                                         // phase 3 view (overlaps AB)
-  s.Lr = take(s.mp * s.ldr); s.LIr = take(s.nbm * 272); s.W = take(s.mp * s.lw); s.ST = take(s.mp * s.np);
+  s.Lr = take(s.mp * s.ldr); s.LIr = take(s.nbm * 272); s.W = take(s.mp * s.lw); s.ST = take(st_lds ? s.mp * s.np : 0);
   s.CT = take(16 * s.lw); s.VX = take(16 * s.lw); s.Y = take(s.mp * 16); s.SC = take(16 * 17); s.LIs = take(272);
   const int end3 = o;
   o = end1 > end2 ? end1 : end2;
   if (end3 > o) o = end3;
-  s.vec = take(8 * (s.nzp + c) + 64);
+  s.vec = take(7 * s.nzp + 2 * c + 96);  // ph ft vv w gh pvec (6 nzp) | dtl kvc (2 c) | e6l wred t6l (92) | gpre (nzp)
   s.iwork = o;
   s.total_bytes = o * 8 + (c + 72) * 4;
   return s;
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
   const bool ff = L.space == MPC_SPACE_MULTIBODY;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *PT = sm + S.PT, *LP = sm + S.LP, *LI = sm + S.LI, *AB = sm + S.AB, *GP = sm + S.GP, *vec = sm + S.vec;
-  double *Lr = sm + S.Lr, *LIr = sm + S.LIr, *W = sm + S.W, *ST = sm + S.ST, *CTl = sm + S.CT, *VXl = sm + S.VX, *Yl = sm + S.Y, *SCl = sm + S.SC, *LIs = sm + S.LIs;
+  double *Lr = sm + S.Lr, *LIr = sm + S.LIr, *W = sm + S.W, *CTl = sm + S.CT, *VXl = sm + S.VX, *Yl = sm + S.Y, *SCl = sm + S.SC, *LIs = sm + S.LIs;
   int* act_idx = (int*)(sm + S.iwork);
   int* iflag = act_idx + L.c;  // [0] factorisation flag, [1] ca, [2..5] per-wave active counts
   double *ph = vec, *ft = vec + nzp, *vv = vec + 2 * nzp, *w = vec + 3 * nzp, *gh = vec + 4 * nzp, *pvec = vec + 5 * nzp, *dtl = vec + 6 * nzp;
@@ -127,6 +128,7 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
   double* gpre = e6l + 92;  // gradient of the knot (nz); vec holds 7 nzp + 2 c + 92 <= 8 (nzp + c) + 64 doubles
   double* wk = a.work + (size_t)b * L.work_stride;
   double* Hh = wk + L.wHh;  // nz x nz, leading dimension nz (L2-resident scratch)
+  double* ST = S.st_lds ? sm + S.ST : wk + L.wG;  // Sh^T (mp x np)
 
   // ---- terminal node: P_N = H + Ca^T Ca / mu ; p_N = grad + Ca^T dt / mu ----
   {

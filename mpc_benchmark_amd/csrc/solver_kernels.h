@@ -10,6 +10,9 @@
 #pragma once
 #include "device_common.h"
 
+// |dphi0| <= MPC_STALL_TOL (1 + |phi0|): no descent left in the inner problem (shared with oracle/solver.hpp)
+#define MPC_STALL_TOL 1e-13
+
 struct SolverArgs {
   Layout L;
   mpc_options opt;
@@ -116,8 +119,10 @@ __global__ void __launch_bounds__(128) k_decide(SolverArgs a) {
     crit = fmax(crit, dual);
     st.cost = cost; st.phi0 = cost + pen; st.prim = prim; st.dual = dual; st.crit = crit;
     st.skip_step = 0;
-    if (crit <= st.inner_tol) {
+    const bool via_stall = (st.stalled & 1) != 0;  // bit 0: the previous pass found no descent left; bits 8..: consecutive stalls
+    if (crit <= st.inner_tol || via_stall) {
       // inner problem solved: outer (BCL) update, no step this pass
+      st.stalled &= ~1;
       st.skip_step = 1;
       if (prim <= st.prim_tol) {
         st.prim_tol *= pow(st.mu, o.bcl_prim_beta);
@@ -133,6 +138,7 @@ __global__ void __launch_bounds__(128) k_decide(SolverArgs a) {
       st.prim_tol = fmax(st.prim_tol, o.tol);
       st.al_iters += 1;
       if (st.al_iters >= o.max_al_iters) st.done = 1;
+      if (via_stall && (st.stalled >> 8) >= 4) st.done = 1;  // four stalls with no step in between (two full BCL cycles): nothing left to gain
     }
   }
   __syncthreads();
@@ -635,6 +641,12 @@ __global__ void k_linesearch(SolverArgs a, int first) {
   st.dphi0 = d;
   double alpha = 1.0;
   int step = 0;
+  if (first && fabs(d) <= MPC_STALL_TOL * (1.0 + fabs(st.phi0))) {
+    // the Newton step cannot decrease the merit any further (round-off floor of the 1/mu-conditioned system): the inner
+    // problem counts as solved — no step, no iteration counted, the next pass takes the BCL branch
+    st.stalled = (((st.stalled >> 8) + 1) << 8) | 1; st.ls_more = 0; st.alpha = 0.0; st.ls_step = 0;
+    return;
+  }
   if (first) {
     double phi = 0;
     const double* tp = a.trial_phi + ((size_t)b * L.n_alpha) * (L.N + 1);
@@ -665,7 +677,7 @@ __global__ void k_accept(SolverArgs a) {
   const Layout& L = a.L;
   const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
   InstState& st = a.inst[b];
-  if (st.done || st.skip_step) return;
+  if (st.done || st.skip_step || (st.stalled & 1)) return;
   const int n = L.n, N = L.N, nx = L.nx, m = L.m;
   const double alpha = st.alpha;
   double* x = a.xs + ((size_t)b * (N + 1) + k) * nx;
@@ -691,7 +703,8 @@ __global__ void k_accept(SolverArgs a) {
 __global__ void k_after_step(SolverArgs a) {
   InstState& st = a.inst[blockIdx.x];
   if (st.done) return;
-  if (!st.skip_step) {
+  if (!st.skip_step && !(st.stalled & 1)) {
+    st.stalled = 0;
     st.num_iters += 1;
     if (st.num_iters >= a.opt.max_iters) st.done = 1;
   }

@@ -14,7 +14,7 @@ from .aligator import _core as core
 
 
 class EnsembleMPC:
-    def __init__(self, problem_def, batch=1, library=None, device=0, seed=20250304, perturb=True):
+    def __init__(self, problem_def, batch=1, library=None, device=0, seed=20250304, perturb=True, sigma_q=0.02, sigma_v=0.05, perturb_dofs=None):
         """``problem_def``: a FullDynamicsProblem / CentroidalProblem-like builder (``build``, ``stage_for_tick``,
         ``make_solver``, ``initial_guess``)."""
         self.pd = problem_def
@@ -47,7 +47,7 @@ class EnsembleMPC:
         for k, (desc, params) in enumerate(tables):
             self.native.set_stage(k, desc, params)
         self.tables = tables
-        # randomised initial states: joints ~ N(0, 0.02^2), joint velocities ~ N(0, 0.05^2)
+        # randomised initial states: joints ~ N(0, sigma_q^2), joint velocities ~ N(0, sigma_v^2)
         rng = np.random.default_rng(seed)
         x0 = np.asarray(self.problem.x0_init, dtype=float)
         self.x0 = np.tile(x0, (self.batch, 1))
@@ -55,15 +55,32 @@ class EnsembleMPC:
             nv = space.model.nv
             for b in range(self.batch):
                 dq = np.zeros(2 * nv)
-                dq[6:nv] = 0.02 * rng.standard_normal(nv - 6)
-                dq[nv + 6:] = 0.05 * rng.standard_normal(nv - 6)
+                dq[6:nv] = sigma_q * rng.standard_normal(nv - 6)
+                dq[nv + 6:] = sigma_v * rng.standard_normal(nv - 6)
+                if perturb_dofs is not None:  # e.g. upper body only: feet that must stay at rest are not disturbed
+                    keep = np.zeros(nv, dtype=bool)
+                    keep[np.asarray(perturb_dofs, dtype=int)] = True
+                    dq[:nv][~keep] = 0.0
+                    dq[nv:][~keep] = 0.0
                 if b > 0:
-                    self.x0[b] = space.integrate(x0, dq)
+                    xb = space.integrate(x0, dq)
+                    # keep the measured configuration inside the joint limits: the initial state is fixed
+                    # (force_initial_condition), so a violated limit at knot 0 is an infeasible constraint that no
+                    # iteration can repair (two joints of the nominal posture sit exactly on a limit)
+                    mdl = space.model
+                    if hasattr(mdl, "lowerPositionLimit"):
+                        xb[7:mdl.nq] = np.clip(xb[7:mdl.nq], mdl.lowerPositionLimit[7:], mdl.upperPositionLimit[7:])
+                    self.x0[b] = xb
         self.tick = 0
 
     # -- stage tables of the schedule ---------------------------------------------------------------
     def _table_for_tick(self, t):
-        key = tuple(self.pd.contact_phases[t]) if hasattr(self.pd, "contact_phases") else t
+        # stages of one contact pattern share a table unless the problem says its stages differ tick by tick
+        # (kinodynamic: a force reference per tick)
+        if hasattr(self.pd, "stage_key"):
+            key = self.pd.stage_key(t)
+        else:
+            key = tuple(self.pd.contact_phases[t]) if hasattr(self.pd, "contact_phases") else t
         if key not in self._tick_tables:
             st = self.pd.stage_for_tick(t)
             self._tick_tables[key] = core.lower_stage(self.ctx, st.cost, st.dynamics, st.constraints)

@@ -99,6 +99,9 @@ class KinodynamicProblem:
         fn = aligator.CenterOfMassTranslationResidual(self.space.ndx, self.nu, self.robot.model, com_target)
         return aligator.StageConstraint(fn, constraints.EqualityConstraintSet())
 
+    def stage_key(self, t):
+        return int(t)  # every tick has its own force reference (kinodynamic_talos.py:200-237)
+
     def stage_for_tick(self, t):
         lf, rf = self.robot.foot_placements
         return self.create_stage(self.contact_phases[t], lf.copy(), rf.copy(), self.urefs[t])

@@ -459,17 +459,20 @@ struct Solver {
     }
   }
 
-  // one inner iteration; returns true if the inner criterion was already met (no step taken)
-  bool iterate(Instance& in) {
+  // one inner iteration; returns 0 after a step, 1 if the inner criterion was already met, 2 if no descent is left (no step)
+  int iterate(Instance& in) {
     evaluate(in, in.xs, in.us, in.knots, true);
     double cost, prim, dual, crit;
     const double phi0 = merit(in, in.knots, in.vs, in.lams, &cost, &prim);
     lagrangian_residuals(in, dual, crit);
     in.stats.traj_cost = cost; in.stats.merit = phi0; in.stats.prim_infeas = prim; in.stats.dual_infeas = dual; in.stats.mu = in.mu;
-    if (crit <= in.inner_tol) return true;
+    if (crit <= in.inner_tol) return 1;
     backward(in);
     forward(in);
     const double dphi0 = dmerit(in);
+    // no descent left in the inner problem (round-off floor of the 1/mu-conditioned system): counts as solved, no step
+    // (MPC_STALL_TOL of csrc/solver_kernels.h)
+    if (std::fabs(dphi0) <= 1e-13 * (1.0 + std::fabs(phi0))) return 2;
     double alpha = 1.0, phi = 0.0;
     int step = 0;
     for (;; ++step) {
@@ -483,7 +486,7 @@ struct Solver {
     }
     in.xs.swap(in.txs); in.us.swap(in.tus); in.vs.swap(in.tvs); in.lams.swap(in.tlams);
     in.stats.alpha = alpha; in.stats.ls_steps = step; in.stats.num_iters += 1;
-    return false;
+    return 0;
   }
 
   // SolverProxDDP::run for one instance (xs/us already installed)
@@ -492,10 +495,15 @@ struct Solver {
     in.stats.num_iters = 0; in.stats.converged = 0; in.stats.al_iters = 0;
     update_tols_on_failure(in);
     in.inner_tol = std::max(in.inner_tol, opt.tol); in.prim_tol = std::max(in.prim_tol, opt.tol);
+    int stalls = 0;
     while (in.stats.al_iters < opt.max_al_iters && in.stats.num_iters < opt.max_iters) {
-      bool inner_conv = false;
+      bool inner_conv = false, via_stall = false;
       while (in.stats.num_iters < opt.max_iters) {
-        if (iterate(in)) { inner_conv = true; break; }
+        const int r = iterate(in);
+        if (r == 0) { stalls = 0; continue; }
+        inner_conv = true;
+        if (r == 2) { via_stall = true; ++stalls; }
+        break;
       }
       if (!inner_conv) break;
       if (in.stats.prim_infeas <= in.prim_tol) {
@@ -508,6 +516,7 @@ struct Solver {
       }
       in.inner_tol = std::max(in.inner_tol, opt.tol); in.prim_tol = std::max(in.prim_tol, opt.tol);
       in.stats.al_iters += 1;
+      if (via_stall && stalls >= 4) break;  // four stalls with no step in between (two full BCL cycles): nothing left to gain
     }
     in.stats.mu = in.mu;
   }

@@ -118,3 +118,30 @@ def test_ensemble_instance_equals_single_instance_and_is_deterministic(hip_lib):
     r1 = one.results(gains=True)
     for key in r5:
         assert np.array_equal(r5[key][3], r1[key][0]), key
+
+
+def test_kinodynamic_ensemble_config3_sizes(hip_lib, oracle_lib):
+    """BASELINE.json config 3: kinodynamic OCP, N = 150, 64 instances on one GPU (complete model).  Instance 0 (the
+    unperturbed initial state) is compared with the oracle after the cold solve and three MPC ticks; the cold start of this
+    OCP takes tens of iterations whose linesearch decisions differ at round-off level (tests/test_gpu_kinodynamic.py), so the
+    comparison is on converged solutions; every instance must converge and stay feasible."""
+    from mpc_benchmark_amd.problems.kinodynamic import KinodynamicProblem
+    kp = KinodynamicProblem(horizon=150, complete_model=True)
+    # randomised upper body (torso, arms, head: dofs 18..): the kinodynamic stages pin the contact feet with equality
+    # constraints from knot 0 on, so a disturbed leg state would be an infeasible initial condition
+    ens = EnsembleMPC(kp, batch=64, library=hip_lib, seed=7, perturb_dofs=range(18, kp.nv))
+    ens.prepare_schedule(4)
+    stats = ens.cold_solve(max_iters=100)
+    assert sum(bool(s.converged) for s in stats) >= 60 and max(s.prim_infeas for s in stats) < 1e-3
+    ref = EnsembleMPC(KinodynamicProblem(horizon=150, complete_model=True), batch=1, library=oracle_lib, perturb=False)
+    ref.prepare_schedule(4)
+    rstats = ref.cold_solve(max_iters=100)
+    assert rstats[0].converged
+    a, b = ens.results(gains=False), ref.results(gains=False)
+    assert _rel(a["xs"][0], b["xs"][0]) < 1e-4 and _rel(a["us"][0], b["us"][0]) < 1e-3
+    for _ in range(3):
+        st = ens.step()
+        ref.step()
+    a, b = ens.results(gains=False), ref.results(gains=False)
+    assert _rel(a["xs"][0], b["xs"][0]) < 1e-4 and _rel(a["us"][0], b["us"][0]) < 2e-3
+    assert all(np.isfinite(s.traj_cost) and s.prim_infeas < 1e-2 for s in st)
