@@ -80,7 +80,7 @@ def main():
         thread (ctypes releases the GIL), so that they run out of phase on the device instead of in lock step."""
         if nshard == 1:
             for _ in range(count):
-                shards[0].step()  # synchronous form: exactly one solver pass per tick
+                shards[0].step(rescue=True)  # synchronous form: exactly one solver pass per tick
             return
         import threading
         errs = []
@@ -88,7 +88,7 @@ def main():
         def drive(e):
             try:
                 for _ in range(count):
-                    e.step()
+                    e.step(rescue=True)
             except Exception as ex:  # noqa: BLE001 - re-raised on the main thread
                 errs.append(ex)
         th = [threading.Thread(target=drive, args=(e,)) for e in shards]
@@ -227,6 +227,7 @@ def main():
         "p50_ms_per_solve_batch1": p50_ms,
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
         "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; the others are within 1e-4 of feasibility)" % (n_conv, args.batch),
+        "diverged_instance_rescues": sum(getattr(e, "rescues", 0) for e in shards),
         "roofline": roof, "cpu_baseline": cpu,
     }
     print(json.dumps(out))

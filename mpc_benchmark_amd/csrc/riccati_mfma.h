@@ -481,7 +481,25 @@ __global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(Sol
     }
     __syncthreads();
     RIC_PROF(9);
-    if (!chol_blocked(Lr, ldr, nbm, LIr, tid, iflag)) { if (tid == 0) a.inst[b].done = 3; return; }
+    // An indefinite reduced control Hessian (far from the solution the Gauss-Newton + penalty model can lose definiteness
+    // through the AL terms) is regularised: Ruu + rho I with rho = max(1e-8, 1e-6 max|diag|) x 10^t until the Cholesky
+    // succeeds (same rule in oracle/solver.hpp) — the damped Newton step of ProxDDP's inertia correction.
+    for (int attempt = 1; !chol_blocked(Lr, ldr, nbm, LIr, tid, iflag); ++attempt) {
+      if (attempt > 10) { if (tid == 0) a.inst[b].done = 3; return; }
+      if (tid == 0) {
+        double dmax = 0.0;
+        for (int i = 0; i < m; ++i) dmax = fmax(dmax, fabs(Hh[(n + i) * nz + n + i]));
+        double rho = fmax(1e-8, 1e-6 * dmax);
+        for (int t = 1; t < attempt; ++t) rho *= 10.0;
+        wred[0] = rho;
+      }
+      __syncthreads();
+      const double rho = wred[0];
+      for (int i = wv; i < mp; i += nw)
+        for (int j = lane; j < mp; j += 64)
+          Lr[i * ldr + j] = (i < m && j < m) ? Hh[(n + (i > j ? i : j)) * nz + n + (i > j ? j : i)] + (i == j ? rho : 0.0) : (i == j ? 1.0 : 0.0);
+      __syncthreads();
+    }
     RIC_PROF(10);
     trsm_fwd_blocked(Lr, ldr, LIr, nbm, W, lw, nwb, wv, nw, lane);  // W = L^-1 T
     if (ca > 0 && small_ca && wv == nw - 1) trsm_fwd_blocked(Lr, ldr, LIr, nbm, Yl, 16, 1, 0, 1, lane);  // Y = L^-1 Da^T

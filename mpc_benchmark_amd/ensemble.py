@@ -109,14 +109,22 @@ class EnsembleMPC:
         self.native.set_x0(None)  # perfect-model feedback from here on
         return stats
 
-    def step(self):
-        """One MPC tick for every instance of the ensemble (one ProxDDP iteration each)."""
+    def step(self, rescue=False):
+        """One MPC tick for every instance of the ensemble (one ProxDDP iteration each).  ``rescue``: an instance whose
+        trajectory has diverged (the library reports a failed factorisation) does not abort a long-running ensemble — the
+        ensemble is re-solved from its initial states (counted in ``self.rescues``; the time of the re-solve stays inside
+        whatever region the caller is timing)."""
         desc, params = self._table_for_tick(self.tick % self.pd.t_mpc)
         self.native.cycle(desc, params)
         self.native.setup()
-        stats = self.native.run_shifted()
         self.tick += 1
-        return stats
+        try:
+            return self.native.run_shifted()
+        except RuntimeError as e:
+            if not rescue or "factorisation failed" not in str(e):
+                raise
+            self.rescues = getattr(self, "rescues", 0) + 1
+            return self.cold_solve(max_iters=20)
 
     def step_async(self):
         """Enqueue one tick without waiting (several shards on different streams overlap on the device)."""

@@ -303,7 +303,16 @@ struct Solver {
       // 4. stage KKT  [[R, D^T],[D, -mu I]] [U; V] = -[[S^T r],[C d]]
       std::vector<double> Lr(m * m), Ct(c * nz, 0.0), dt_(c, 0.0);
       for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Lr[i * m + j] = 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]);
-      if (!chol_lower(Lr.data(), m)) throw std::runtime_error("Riccati: reduced control Hessian not positive definite");
+      for (int attempt = 1; !chol_lower(Lr.data(), m); ++attempt) {
+        // inertia correction (same rule as csrc/riccati_mfma.h): Ruu + rho I, rho = max(1e-8, 1e-6 max|diag|) x 10^t
+        if (attempt > 10) throw std::runtime_error("Riccati: reduced control Hessian not positive definite");
+        double dmax = 0.0;
+        for (int i = 0; i < m; ++i) dmax = std::max(dmax, std::fabs(Hh[(n + i) * nz + n + i]));
+        double rho = std::max(1e-8, 1e-6 * dmax);
+        for (int t = 1; t < attempt; ++t) rho *= 10.0;
+        for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j)
+          Lr[i * m + j] = 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]) + (i == j ? rho : 0.0);
+      }
       for (int i = 0; i < c; ++i) {
         bool act;
         dt_[i] = proj_normal(kn.ctype[i], kn.cval[i] + mu * in.vs_e[k][i], kn.lo[i], kn.hi[i], act);
