@@ -12,7 +12,7 @@ struct Layout {
   // offsets inside one knot record (doubles)
   int oH, oG, oAB, oF, oE6, oCV, oCD, oLO, oHI, oDT, oACT, oCT, oMISC, oXD, oWR, oXN, knot_stride;
   // offsets inside one gain record
-  int oP, op, oK, ok, oKnu, oknu, oMx, omx, oT6, gain_stride;
+  int oP, op, oK, ok, oKnu, oknu, oMx, omx, oT6, oPhi, ophi, gain_stride;
   // backward-sweep scratch per instance
   int wPh, wPt, wLp, wG, wHh, wgh, wCt, wW, wY, wSc, wV, wAcl, wvec, work_stride;
   int max_stage_ints, max_stage_doubles;
@@ -43,6 +43,7 @@ static inline void make_layout(Layout& L) {
   o = 0;
   L.oP = take(n * n); L.op = take(n); L.oK = take(m * n); L.ok = take(m); L.oKnu = take(c * n); L.oknu = take(c);
   L.oMx = take(n * n); L.omx = take(n); L.oT6 = take(36);
+  L.oPhi = take(n * n); L.ophi = take(n);  // closed-loop transition dx' = Phi dx + phi (closed_loop.h)
   L.gain_stride = o;
   o = 0;
   const int nr = n + 1;

@@ -13,6 +13,7 @@
 #include "eval_multibody.h"
 #include "eval_vector.h"
 #include "riccati_mfma.h"
+#include "closed_loop.h"
 
 #define HIP_OK(expr)                                                                                  \
   do {                                                                                                \
@@ -48,6 +49,7 @@ struct mpc_solver {
   bool perfect_feedback = false;
   int async_passes = 0;
   RicLds ric{};
+  ClLds cl{};
   bool use_mfma_riccati = false;
   // per-kernel timing (mpc_profile): event pairs recorded around every launch while enabled
   struct ProfSlot {
@@ -157,6 +159,9 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->ric = make_ric_lds(L.n, L.m, L.c, 1);
   if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0);     // panel-wise G when the whole G does not fit
   if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0, 0);  // large m: Sh^T out of LDS as well
+  s->cl = make_cl_lds(L.n, L.m);
+  if (s->cl.total_bytes <= 160 * 1024)
+    HIP_OK(hipFuncSetAttribute((const void*)k_closed_loop, hipFuncAttributeMaxDynamicSharedMemorySize, s->cl.total_bytes));
   s->use_mfma_riccati = s->ric.total_bytes <= 160 * 1024 && (s->ric.st_lds || s->ric.mp * s->ric.np <= L.n * L.nz) && !getenv("MPC_HIP_GENERIC_RICCATI");
   if (s->use_mfma_riccati)
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
@@ -219,13 +224,23 @@ static void launch_pass(mpc_solver* s) {
     if (s->use_mfma_riccati) hipLaunchKernelGGL(k_riccati_mfma, dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
     else hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);
   });
-  s->timed(4, "k_forward", [&] {
-    const size_t fw_lds = (L.nz + 2 * L.n) * sizeof(double);
-    const bool fits = L.nz <= 128 && L.n + L.m <= L.nz;
-    if (fits && L.n <= 80 && L.m <= 32) hipLaunchKernelGGL((k_forward_prefetch<4, 10>), dim3(L.B), dim3(512), fw_lds, s->stream, a);
-    else if (fits && L.n <= 80 && L.m <= 48) hipLaunchKernelGGL((k_forward_prefetch<6, 10>), dim3(L.B), dim3(512), fw_lds, s->stream, a);
-    else hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(1024), fw_lds, s->stream, a);
-  });
+  // forward sweep: closed-loop transitions Phi / phi for all knots in parallel, then one mat-vec per knot (closed_loop.h);
+  // the three-mat-vec sweep remains for dimensions whose operands do not fit the LDS of k_closed_loop
+  // The knot-parallel kernel costs (N x B) workgroups: it pays when the GPU is mostly idle during the sweep (small
+  // ensembles, latency-bound: 0.95 -> 0.53 ms at batch 1), not when the ensemble already fills it (B = 64: 0.97 -> 1.3 ms)
+  const bool fw_phi = s->cl.total_bytes <= 160 * 1024 && L.n <= 80 && L.m <= 32 && L.B * L.N <= 2048;
+  if (fw_phi) {
+    s->timed(12, "k_closed_loop", [&] { hipLaunchKernelGGL(k_closed_loop, dim3(L.N, L.B), dim3(CL_THREADS), s->cl.total_bytes, s->stream, a, s->cl); });
+    s->timed(4, "k_forward", [&] { hipLaunchKernelGGL((k_forward_phi<4, 10>), dim3(L.B), dim3(512), 2 * L.n * sizeof(double), s->stream, a); });
+  } else {
+    s->timed(4, "k_forward", [&] {
+      const size_t fw_lds = (L.nz + 2 * L.n) * sizeof(double);
+      const bool fits = L.nz <= 128 && L.n + L.m <= L.nz;
+      if (fits && L.n <= 80 && L.m <= 32) hipLaunchKernelGGL((k_forward_prefetch<4, 10>), dim3(L.B), dim3(512), fw_lds, s->stream, a);
+      else if (fits && L.n <= 80 && L.m <= 48) hipLaunchKernelGGL((k_forward_prefetch<6, 10>), dim3(L.B), dim3(512), fw_lds, s->stream, a);
+      else hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(1024), fw_lds, s->stream, a);
+    });
+  }
   s->timed(5, "k_duals", [&] { hipLaunchKernelGGL(k_duals, dim3(L.N + 1, L.B), dim3(256), (L.nz + 3 * L.n + 16) * sizeof(double), s->stream, a); });
   // linesearch: evaluate the full step first; the backtracking candidates alpha = 2^-i, i >= 1, are only
   // evaluated for instances whose full step failed the Armijo test (their workgroups exit immediately otherwise)
