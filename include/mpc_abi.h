@@ -125,7 +125,7 @@ typedef struct mpc_options {
   int32_t rollout_linear;  /* ROLLOUT_LINEAR = 1 (only mode implemented)               */
   int32_t ls_max_steps;    /* number of backtracking candidates alpha = 2^-i           */
   int32_t num_threads;     /* oracle: OpenMP threads ; HIP: ignored                    */
-  int32_t riccati_legs;    /* HIP: legs of the parallel-in-time Riccati (LQ_SOLVER_PARALLEL) ; 1 = serial */
+  int32_t riccati_legs;    /* linear_solver_choice = LQ_SOLVER_PARALLEL + setNumThreads (fulldynamic_talos.py:376,385): accepted, the sweep is serial per instance */
   int32_t reserved;
 } mpc_options;
 
@@ -147,14 +147,20 @@ typedef struct mpc_solver mpc_solver;
 int mpc_abi_version(void);
 const char* mpc_backend_name(void); /* "hip-gfx950" or "oracle-cpu" */
 
+/* aligator.SolverProxDDP(TOL, mu_init, ...) (fulldynamic_talos.py:374) for an ensemble of dims->batch independent copies
+ * of one problem structure; allocates every device buffer once. */
 int mpc_create(const mpc_dims* dims, mpc_solver** out);
 void mpc_destroy(mpc_solver* s);
 const char* mpc_last_error(mpc_solver* s);
 
+/* solver.rollout_type / .max_iters / .force_initial_condition ... (fulldynamic_talos.py:375-386) */
 int mpc_set_options(mpc_solver* s, const mpc_options* opt);
+/* the pin.Model the residuals and dynamics were built on (talos_utils.py:31-41 loadTalos), its frames and the
+ * RigidConstraintModels of fulldynamic_talos.py:79-98, lowered to the model table documented above */
 int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double* dtab, int32_t n_d);
 
-/* TrajOptProblem(x0, stages, term_cost): k in [0, N]; k == N is the terminal node (cost + terminal constraints). */
+/* TrajOptProblem(x0, stages, term_cost) (fulldynamic_talos.py:153-232 createStage, :372): k in [0, N]; k == N is the
+ * terminal node (cost + terminal constraints, :234-245, :499-506). */
 int mpc_set_stage(mpc_solver* s, int32_t k, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params);
 /* setReference / contact_poses[i] = ... : overwrite n doubles of stage k's parameter table. */
 int mpc_update_stage_params(mpc_solver* s, int32_t k, int32_t offset, const double* vals, int32_t n);
@@ -163,16 +169,17 @@ int mpc_update_stage_params(mpc_solver* s, int32_t k, int32_t offset, const doub
  * holds the new values back to back. */
 int mpc_update_stage_params_batch(mpc_solver* s, int32_t count, const int32_t* ks, const int32_t* offsets, const int32_t* lens,
                                   const double* vals);
-/* replaceStageCircular + cycleAppend/cycleProblem: drop stage 0, shift, install the new stage at N-1. */
+/* replaceStageCircular + cycleAppend/cycleProblem (fulldynamic_talos.py:496-497, kinodynamic_talos.py:487-488): drop stage 0,
+ * shift, install the new stage at N-1. */
 int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params);
 
-/* problem.x0_init = x : x0[B][nx].  x0 == NULL selects "perfect-model feedback": every later
+/* problem.x0_init = x (fulldynamic_talos.py:536): x0[B][nx].  x0 == NULL selects "perfect-model feedback": every later
  * mpc_run_shifted takes the state the previous solution predicted for the next tick (xs[1]) as the new
  * initial condition, so a closed receding-horizon loop runs without any host<->device traffic. */
 int mpc_set_x0(mpc_solver* s, const double* x0);
-/* solver.setup(problem): reset multipliers, penalty and tolerances (no re-allocation). */
+/* solver.setup(problem) (fulldynamic_talos.py:539): reset multipliers, penalty and tolerances (no re-allocation). */
 int mpc_setup(mpc_solver* s);
-/* solver.run(problem, xs, us): xs[B][N+1][nx], us[B][N][nu]; stats[B] (may be NULL). */
+/* solver.run(problem, xs, us) (fulldynamic_talos.py:540): xs[B][N+1][nx], us[B][N][nu]; stats[B] (may be NULL). */
 int mpc_run(mpc_solver* s, const double* xs_init, const double* us_init, mpc_stats* stats);
 /* Re-run from the solver's own shifted solution: xs <- [xs[1:], xs[-1]], us likewise, xs[0] <- x0
  * (the warm-start shift of fulldynamic_talos.py:532-534 done on the device). */
@@ -183,10 +190,11 @@ int mpc_run_shifted(mpc_solver* s, mpc_stats* stats);
 int mpc_run_shifted_async(mpc_solver* s);
 int mpc_wait(mpc_solver* s, mpc_stats* stats);
 
-/* results.xs / results.us / controlFeedbacks() / feed-forwards / multipliers. Any pointer may be NULL.
+/* results.xs / results.us / controlFeedbacks() (fulldynamic_talos.py:398-400, :524) / feed-forwards / multipliers. Any pointer may be NULL.
  * xs[B][N+1][nx] us[B][N][nu] K[B][N][nu][ndx] kff[B][N][nu] vs[B][N+1][nc_max] lams[B][N+1][ndx] */
 int mpc_get_results(mpc_solver* s, double* xs, double* us, double* K, double* kff, double* vs, double* lams);
 /* workspace.problem_data.stage_data[k].dynamics_data.continuous_data.{xdot, constraint_datas[i].contact_force}
+ * (fulldynamic_talos.py:465-480, kinodynamic_talos.py:432)
  * xdot[B][ndx], wrenches[B][2][6] (inactive contacts zero). */
 int mpc_get_stage_data(mpc_solver* s, int32_t k, double* xdot, double* wrenches);
 
