@@ -125,7 +125,7 @@ typedef struct mpc_options {
   int32_t rollout_linear;  /* ROLLOUT_LINEAR = 1 (only mode implemented)               */
   int32_t ls_max_steps;    /* number of backtracking candidates alpha = 2^-i           */
   int32_t num_threads;     /* oracle: OpenMP threads ; HIP: ignored                    */
-  int32_t riccati_legs;    /* linear_solver_choice = LQ_SOLVER_PARALLEL + setNumThreads (fulldynamic_talos.py:376,385): accepted, the sweep is serial per instance */
+  int32_t riccati_legs;    /* linear_solver_choice = LQ_SOLVER_PARALLEL + setNumThreads (fulldynamic_talos.py:383,385): accepted, the sweep is serial per instance */
   int32_t reserved;
 } mpc_options;
 
@@ -147,20 +147,20 @@ typedef struct mpc_solver mpc_solver;
 int mpc_abi_version(void);
 const char* mpc_backend_name(void); /* "hip-gfx950" or "oracle-cpu" */
 
-/* aligator.SolverProxDDP(TOL, mu_init, ...) (fulldynamic_talos.py:374) for an ensemble of dims->batch independent copies
+/* aligator.SolverProxDDP(TOL, mu_init, ...) (fulldynamic_talos.py:379) for an ensemble of dims->batch independent copies
  * of one problem structure; allocates every device buffer once. */
 int mpc_create(const mpc_dims* dims, mpc_solver** out);
 void mpc_destroy(mpc_solver* s);
 const char* mpc_last_error(mpc_solver* s);
 
-/* solver.rollout_type / .max_iters / .force_initial_condition ... (fulldynamic_talos.py:375-386) */
+/* solver.rollout_type / .max_iters / .force_initial_condition ... (fulldynamic_talos.py:380-386) */
 int mpc_set_options(mpc_solver* s, const mpc_options* opt);
 /* the pin.Model the residuals and dynamics were built on (talos_utils.py:31-41 loadTalos), its frames and the
- * RigidConstraintModels of fulldynamic_talos.py:79-98, lowered to the model table documented above */
+ * RigidConstraintModels of fulldynamic_talos.py:84-98, lowered to the model table documented above */
 int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double* dtab, int32_t n_d);
 
 /* TrajOptProblem(x0, stages, term_cost) (fulldynamic_talos.py:153-232 createStage, :372): k in [0, N]; k == N is the
- * terminal node (cost + terminal constraints, :234-245, :499-506). */
+ * terminal node (cost + terminal constraints, :234-245, :499-507). */
 int mpc_set_stage(mpc_solver* s, int32_t k, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params);
 /* setReference / contact_poses[i] = ... : overwrite n doubles of stage k's parameter table. */
 int mpc_update_stage_params(mpc_solver* s, int32_t k, int32_t offset, const double* vals, int32_t n);
@@ -169,7 +169,7 @@ int mpc_update_stage_params(mpc_solver* s, int32_t k, int32_t offset, const doub
  * holds the new values back to back. */
 int mpc_update_stage_params_batch(mpc_solver* s, int32_t count, const int32_t* ks, const int32_t* offsets, const int32_t* lens,
                                   const double* vals);
-/* replaceStageCircular + cycleAppend/cycleProblem (fulldynamic_talos.py:496-497, kinodynamic_talos.py:487-488): drop stage 0,
+/* replaceStageCircular + cycleAppend/cycleProblem (fulldynamic_talos.py:496-497, kinodynamic_talos.py:395, :488): drop stage 0,
  * shift, install the new stage at N-1. */
 int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params);
 
@@ -190,7 +190,7 @@ int mpc_run_shifted(mpc_solver* s, mpc_stats* stats);
 int mpc_run_shifted_async(mpc_solver* s);
 int mpc_wait(mpc_solver* s, mpc_stats* stats);
 
-/* results.xs / results.us / controlFeedbacks() (fulldynamic_talos.py:398-400, :524) / feed-forwards / multipliers. Any pointer may be NULL.
+/* results.xs / results.us / controlFeedbacks() (fulldynamic_talos.py:403-405, :522, :548-550) / feed-forwards / multipliers. Any pointer may be NULL.
  * xs[B][N+1][nx] us[B][N][nu] K[B][N][nu][ndx] kff[B][N][nu] vs[B][N+1][nc_max] lams[B][N+1][ndx] */
 int mpc_get_results(mpc_solver* s, double* xs, double* us, double* K, double* kff, double* vs, double* lams);
 /* workspace.problem_data.stage_data[k].dynamics_data.continuous_data.{xdot, constraint_datas[i].contact_force}
