@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="the ensemble of one GPU is split into this many shards, each on its own handle/stream, so that the "
                          "sequential Riccati sweeps of one shard overlap the per-knot kernels of the others")
+    ap.add_argument("--closed-loop", action="store_true",
+                    help="measured states from the simulation stand-in (10 x 1 ms of knot 0's dynamics under the feedback law, N2) "
+                         "instead of perfect-model feedback; the simulation runs inside the timed region")
     ap.add_argument("--lib", default=None, help="developer option: another build of the same HIP library (kernel tuning variants)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -66,7 +69,8 @@ def main():
     pd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
     nshard = max(1, min(args.streams, args.batch))
     sizes = [args.batch // nshard + (1 if i < args.batch % nshard else 0) for i in range(nshard)]
-    shards = [EnsembleMPC(pd, batch=sz, library=lib, device=local_rank, seed=20250304 + 1000 * rank + i) for i, sz in enumerate(sizes)]
+    shards = [EnsembleMPC(pd, batch=sz, library=lib, device=local_rank, seed=20250304 + 1000 * rank + i,
+                          closed_loop=((10, pd.dt / 10) if args.closed_loop else None)) for i, sz in enumerate(sizes)]
     ens = shards[0]
     cold = None
     for e in shards:
@@ -222,7 +226,7 @@ def main():
         "config": {"workload": "Talos full-dynamics MPC (fulldynamic_talos.py OCP), synthetic Talos %s model nq=%d nv=%d nu=%d, "
                                "horizon N=%d, ensemble of %d instances per GPU, one ProxDDP iteration per solve (max_iters=1, warm start)"
                                % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch),
-                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "model": "talos_synth_v1/" + args.model,
+                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "model": "talos_synth_v1/" + args.model,
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
         "p50_ms_per_solve_batch1": p50_ms,
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),

@@ -177,6 +177,14 @@ int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* 
  * mpc_run_shifted takes the state the previous solution predicted for the next tick (xs[1]) as the new
  * initial condition, so a closed receding-horizon loop runs without any host<->device traffic. */
 int mpc_set_x0(mpc_solver* s, const double* x0);
+/* "Next" row N2 — closed-loop stand-in for the 1 kHz low-level loop + simulator of fulldynamic_talos.py:512-530
+ * (bullet_robot.py:138-145, 172-196): starting from xs[0], knot 0's contact dynamics are integrated `substeps` times with
+ * step `dt` (semi-implicit Euler, the scheme of the stage dynamics) under the state-feedback law
+ *     u = us[0] - controlFeedbacks()[0] * difference(x, xs[0]) ;
+ * the final state becomes the measured state x0 of every instance (as if set by mpc_set_x0), so the next mpc_run_shifted
+ * starts from it.  Whole-body contact dynamics only.  mpc_get_x0 reads the measured states back: x0[B][nx]. */
+int mpc_simulate(mpc_solver* s, int32_t substeps, double dt);
+int mpc_get_x0(mpc_solver* s, double* x0);
 /* solver.setup(problem) (fulldynamic_talos.py:539): reset multipliers, penalty and tolerances (no re-allocation). */
 int mpc_setup(mpc_solver* s);
 /* solver.run(problem, xs, us) (fulldynamic_talos.py:540): xs[B][N+1][nx], us[B][N][nu]; stats[B] (may be NULL). */

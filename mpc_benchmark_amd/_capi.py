@@ -81,6 +81,8 @@ _SIGNATURES = {
     "mpc_update_stage_params_batch": (C.c_int, [C.c_void_p, C.c_int32, _IP, _IP, _IP, _DP]),
     "mpc_cycle": (C.c_int, [C.c_void_p, _IP, C.c_int32, _DP, C.c_int32]),
     "mpc_set_x0": (C.c_int, [C.c_void_p, _DP]),
+    "mpc_simulate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    "mpc_get_x0": (C.c_int, [C.c_void_p, _DP]),
     "mpc_setup": (C.c_int, [C.c_void_p]),
     "mpc_run": (C.c_int, [C.c_void_p, _DP, _DP, C.POINTER(MpcStats)]),
     "mpc_run_shifted": (C.c_int, [C.c_void_p, C.POINTER(MpcStats)]),
@@ -204,6 +206,15 @@ class NativeSolver:
         x0 = _f64(x0)
         x0 = np.ascontiguousarray(np.broadcast_to(x0.reshape(-1, self.dims.nx), (self.dims.batch, self.dims.nx)))
         self._check(self.lib.mpc_set_x0(self._h, _dp(x0)), "mpc_set_x0")
+
+    def simulate(self, substeps, dt):
+        """N2: integrate knot 0's dynamics under u = us[0] - K0 difference(x, xs[0]); the result is the next measured state."""
+        self._check(self.lib.mpc_simulate(self._h, int(substeps), float(dt)), "mpc_simulate")
+
+    def get_x0(self):
+        x0 = np.zeros((self.dims.batch, self.dims.nx))
+        self._check(self.lib.mpc_get_x0(self._h, _dp(x0)), "mpc_get_x0")
+        return x0
 
     def setup(self):
         self._check(self.lib.mpc_setup(self._h), "mpc_setup")

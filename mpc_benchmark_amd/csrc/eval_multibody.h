@@ -203,6 +203,8 @@ struct MbArgs {
   MbLds lds;
   double* scratch;        // per-workgroup HBM scratch
   size_t scratch_stride;  // doubles
+  int sim_substeps;       // TRIAL == 2 (closed-loop simulation stand-in): integration steps ...
+  double sim_dt;          // ... of this length
 };
 
 // ============================================================================================================
@@ -213,8 +215,10 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   const int k = blockIdx.x, b = blockIdx.y, cand = blockIdx.z + cand0, nthr = blockDim.x;
   int tid = threadIdx.x;
   const InstState& st = a.inst[b];
-  if (st.done || (TRIAL && st.skip_step)) return;
-  if (TRIAL && cand > 0 && !st.ls_more) return;  // the full step was accepted: no backtracking candidates needed
+  // TRIAL: 0 full evaluation, 1 value-only linesearch candidate, 2 closed-loop simulation stand-in (N2): knot 0's contact
+  // dynamics integrated mb.sim_substeps times under u = us[0] - K0 difference(x, xs[0]) (fulldynamic_talos.py:512-530)
+  if (TRIAL != 2 && (st.done || (TRIAL && st.skip_step))) return;
+  if (TRIAL == 1 && cand > 0 && !st.ls_more) return;  // the full step was accepted: no backtracking candidates needed
   const int n = L.n, N = L.N, nx = L.nx, nv = S.nv, nq = S.nq, nj = S.nj, nu = L.m;
   const int slot = stage_slot(a, k);
   const int32_t* desc = a.stage_desc + (size_t)slot * L.max_stage_ints;
@@ -279,13 +283,15 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   {
     const double* xs = a.xs + ((size_t)b * (N + 1) + k) * nx;
     const double* dx = a.dxs + ((size_t)b * (N + 1) + k) * n;
-    if (TRIAL) {
+    if (TRIAL == 2) {
+      for (int i = tid; i < nx; i += nthr) { x[i] = xs[i]; xn[i] = xs[i]; }  // simulated state ; xn = xs[0], the feedback reference
+    } else if (TRIAL) {
       if (tid == 0) state_integrate(MPC_SPACE_MULTIBODY, nx, n, xs, dx, alpha, x);
       if (tid == 64 && k < N) state_integrate(MPC_SPACE_MULTIBODY, nx, n, xs + nx, dx + n, alpha, xn);
     } else {
       for (int i = tid; i < nx; i += nthr) { x[i] = xs[i]; if (k < N) xn[i] = xs[nx + i]; }
     }
-    if (k < N) {
+    if (k < N && TRIAL != 2) {
       const double* us = a.us + ((size_t)b * N + k) * nu;
       const double* du = a.dus + ((size_t)b * N + k) * nu;
       for (int i = tid; i < nu; i += nthr) u[i] = us[i] + (TRIAL ? alpha * du[i] : 0.0);
@@ -303,6 +309,30 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   __syncthreads();
   const double* q = x;
   const double* v = x + nq;
+  int sim_sub = 0;
+sim_loop:
+  if (TRIAL == 2) {
+    // feedback law of the low-level loop: u = us[0] - K0 difference(x, xs[0]),  difference(a, b) = b (-) a
+    if (!has_dyn) return;
+    double* dd = Tq;
+    if (tid == 0) {
+      const M3 Rx = quat_to_rot(x + 3), R0 = quat_to_rot(xn + 3);
+      V3 ev, ew;
+      log6(tmul(Rx, R0), tmul(Rx, v3(xn[0] - x[0], xn[1] - x[1], xn[2] - x[2])), ev, ew);
+      dd[0] = ev.x; dd[1] = ev.y; dd[2] = ev.z; dd[3] = ew.x; dd[4] = ew.y; dd[5] = ew.z;
+    }
+    for (int i = 6 + tid; i < nv; i += nthr) dd[i] = xn[i + 1] - x[i + 1];
+    for (int i = tid; i < nv; i += nthr) dd[nv + i] = xn[nq + i] - x[nq + i];
+    __syncthreads();
+    const double* K0 = gain_ptr(a, b, 0) + L.oK;
+    const double* us0 = a.us + (size_t)b * N * nu;
+    for (int i = tid; i < nu; i += nthr) {
+      double su = us0[i];
+      for (int j = 0; j < n; ++j) su -= K0[i * n + j] * dd[j];
+      u[i] = su;
+    }
+    __syncthreads();
+  }
 #define BELOW(kdof, body) ((anc[(body)] >> dof_body[(kdof)]) & 1ull)
 #define INSUB(j, i) ((anc[(j)] >> (i)) & 1ull)
 
@@ -554,6 +584,33 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   }
 
   EV_PROF(6);
+  if (TRIAL == 2) {
+    // semi-implicit Euler step of length sim_dt (same scheme as the stage dynamics), then the next sub-step
+    const double dts = mb.sim_dt;
+    double* xnew = Tv;
+    if (tid == 0) {
+      const V3 dl = v3(dts * (v[0] + dts * acc[0]), dts * (v[1] + dts * acc[1]), dts * (v[2] + dts * acc[2]));
+      const V3 da_ = v3(dts * (v[3] + dts * acc[3]), dts * (v[4] + dts * acc[4]), dts * (v[5] + dts * acc[5]));
+      M3 dR; V3 dp;
+      exp6(dl, da_, dR, dp);
+      const M3 Rb = quat_to_rot(q + 3);
+      const M3 Rn = mul(Rb, dR);
+      const V3 pn = mul(Rb, dp) + v3(q[0], q[1], q[2]);
+      xnew[0] = pn.x; xnew[1] = pn.y; xnew[2] = pn.z;
+      rot_to_quat(Rn, xnew + 3);
+    }
+    for (int i = tid; i < nv; i += nthr) {
+      const double vp = v[i] + dts * acc[i];
+      xnew[nq + i] = vp;
+      if (i >= 6) xnew[i + 1] = q[i + 1] + dts * vp;
+    }
+    __syncthreads();
+    for (int i = tid; i < nx; i += nthr) x[i] = xnew[i];
+    __syncthreads();
+    if (++sim_sub < mb.sim_substeps) goto sim_loop;
+    for (int i = tid; i < nx; i += nthr) a.x0[(size_t)b * nx + i] = x[i];  // the measured state of the next tick
+    return;
+  }
   // ---- kinodynamics (kinodynamic_talos.py:107-112): a_joint = u[12:], base acceleration from the momentum balance
   // about the world origin  sum_k U_k a_k + hdot(a = 0) = [sum f + m g ; sum p_i x f_i + tau_i + c x m g],
   // projected on the base columns: (J_b^T U_b) a_b = J_b^T (...)  with J_b^T U_b = M_bb symmetric positive definite.
@@ -1218,21 +1275,24 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
 }
 
 static inline void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout& LT, double* records, double* scratch,
-                                         size_t scratch_stride, bool trial, int cand0 = 0, int ncand = 1) {
+                                         size_t scratch_stride, bool trial, int cand0 = 0, int ncand = 1, int sim_substeps = 0, double sim_dt = 0.0) {
   const Layout& L = a.L;
   MbArgs mb;
   mb.lds = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m, L.nz);
   mb.scratch = scratch;
   mb.scratch_stride = scratch_stride;
+  mb.sim_substeps = sim_substeps; mb.sim_dt = sim_dt;
   if (mb.lds.total_bytes > 160 * 1024) throw std::runtime_error("multibody model too large for the LDS budget of the stage kernel");
   static int attr_bytes = -1;
   if (attr_bytes != mb.lds.total_bytes) {
     // the kernel also owns a few bytes of static LDS, so request exactly what the carve-out needs
     hipError_t e1 = hipFuncSetAttribute((const void*)k_eval_multibody<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
     hipError_t e2 = hipFuncSetAttribute((const void*)k_eval_multibody<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
+    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)k_eval_multibody<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
     if (e1 != hipSuccess || e2 != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(LDS) failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     attr_bytes = mb.lds.total_bytes;
   }
-  if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
+  if (sim_substeps > 0) hipLaunchKernelGGL(k_eval_multibody<2>, dim3(1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, 0);
+  else if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
   else hipLaunchKernelGGL(k_eval_multibody<1>, dim3(L.N + 1, L.B, ncand), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
 }

@@ -466,6 +466,24 @@ int mpc_profile_read(mpc_solver* s, int32_t slot, char* name, int32_t name_cap, 
   }
 }
 
+int mpc_simulate(mpc_solver* s, int32_t substeps, double dt) {
+  MPC_TRY(s, {
+    if (substeps <= 0 || !(dt > 0.0)) throw std::runtime_error("simulate: substeps and dt must be positive");
+    if (s->L.space != MPC_SPACE_MULTIBODY || s->h_desc[(size_t)slot_of(s, 0) * s->L.max_stage_ints] != MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER)
+      throw std::runtime_error("simulate: only contact-constrained whole-body dynamics are supported");
+    launch_eval_multibody(s->stream, s->args(), s->LT, s->d_tknots, s->d_mbwork, s->mb_work_stride, true, 0, 1, substeps, dt);
+    HIP_OK(hipGetLastError());
+    s->perfect_feedback = false;
+  })
+}
+
+int mpc_get_x0(mpc_solver* s, double* x0) {
+  MPC_TRY(s, {
+    HIP_OK(hipMemcpyAsync(x0, s->d_x0, (size_t)s->L.B * s->L.nx * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+  })
+}
+
 int mpc_setup(mpc_solver* s) {
   MPC_TRY(s, {
     const Layout& L = s->L;

@@ -14,7 +14,8 @@ from .aligator import _core as core
 
 
 class EnsembleMPC:
-    def __init__(self, problem_def, batch=1, library=None, device=0, seed=20250304, perturb=True, sigma_q=0.02, sigma_v=0.05, perturb_dofs=None):
+    def __init__(self, problem_def, batch=1, library=None, device=0, seed=20250304, perturb=True, sigma_q=0.02, sigma_v=0.05, perturb_dofs=None,
+                 closed_loop=None):
         """``problem_def``: a FullDynamicsProblem / CentroidalProblem-like builder (``build``, ``stage_for_tick``,
         ``make_solver``, ``initial_guess``)."""
         self.pd = problem_def
@@ -71,6 +72,9 @@ class EnsembleMPC:
                     if hasattr(mdl, "lowerPositionLimit"):
                         xb[7:mdl.nq] = np.clip(xb[7:mdl.nq], mdl.lowerPositionLimit[7:], mdl.upperPositionLimit[7:])
                     self.x0[b] = xb
+        # closed_loop = (substeps, dt): the measured state of every tick comes from the simulation stand-in (N2: knot 0's dynamics
+        # integrated under the feedback law of the low-level loop) instead of the model's own prediction xs[1]
+        self.closed_loop = closed_loop
         self.tick = 0
 
     # -- stage tables of the schedule ---------------------------------------------------------------
@@ -114,6 +118,8 @@ class EnsembleMPC:
         trajectory has diverged (the library reports a failed factorisation) does not abort a long-running ensemble — the
         ensemble is re-solved from its initial states (counted in ``self.rescues``; the time of the re-solve stays inside
         whatever region the caller is timing)."""
+        if self.closed_loop:
+            self.native.simulate(*self.closed_loop)  # apply us[0] + feedback for one MPC period, measure
         desc, params = self._table_for_tick(self.tick % self.pd.t_mpc)
         self.native.cycle(desc, params)
         self.native.setup()

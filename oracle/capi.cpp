@@ -99,6 +99,20 @@ int mpc_set_x0(mpc_solver* h, const double* x0) {
   })
 }
 
+int mpc_simulate(mpc_solver* h, int32_t substeps, double dt) {
+  MPC_TRY(h, {
+    if (substeps <= 0 || !(dt > 0.0)) throw std::runtime_error("simulate: substeps and dt must be positive");
+    for (int b = 0; b < h->s.dims.batch; ++b) h->s.simulate(h->s.inst[b], substeps, dt);
+    h->perfect_feedback = false;
+  })
+}
+int mpc_get_x0(mpc_solver* h, double* x0) {
+  MPC_TRY(h, {
+    const int nx = h->s.dims.nx;
+    for (int b = 0; b < h->s.dims.batch; ++b) std::memcpy(x0 + (size_t)b * nx, h->s.inst[b].x0.data(), nx * sizeof(double));
+  })
+}
+
 int mpc_profile(mpc_solver*, int32_t) { return 0; }
 int mpc_profile_read(mpc_solver*, int32_t, char*, int32_t, int32_t*, double*) { return 0; }
 

@@ -498,6 +498,32 @@ struct Solver {
     return 0;
   }
 
+  // N2: closed-loop simulation stand-in — knot 0's contact dynamics integrated `substeps` times with step
+  // `dt` under the feedback law of the low-level loop u = us[0] - K0 difference(x, xs[0]) (fulldynamic_talos.py:512-530);
+  // the result becomes the measured state x0 of the next tick.
+  void simulate(Instance& in, int substeps, double dt) const {
+    if (dims.space != MPC_SPACE_MULTIBODY || stages[0].dyn != MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER)
+      throw std::runtime_error("simulate: only contact-constrained whole-body dynamics are supported");
+    const int n = dims.ndx, nu = dims.nu, nx = dims.nx;
+    StageDesc sd = stages[0];
+    sd.params[sd.dyn_poff] = dt;  // the stage's time step is the first dynamics parameter
+    sd.terms.clear(); sd.nc = 0;  // dynamics only
+    std::vector<double> x = in.xs[0], d(n), u(nu);
+    Knot kn;
+    kn.resize(n, nu, 0, nx);
+    for (int sstep = 0; sstep < substeps; ++sstep) {
+      mb_difference(model, x.data(), in.xs[0].data(), d.data());
+      for (int i = 0; i < nu; ++i) {
+        double su = in.us[0][i];
+        for (int j = 0; j < n; ++j) su -= in.gains[0].K[i * n + j] * d[j];
+        u[i] = su;
+      }
+      eval_multibody(model, sd, nu, x.data(), u.data(), x.data(), kn, false);
+      x = kn.xnext;
+    }
+    in.x0 = x;
+  }
+
   // SolverProxDDP::run for one instance (xs/us already installed)
   void run_instance(Instance& in) {
     if (opt.force_initial_condition) in.xs[0] = in.x0;
