@@ -720,6 +720,7 @@ __global__ void k_begin_run(SolverArgs a) {
     for (int i = tid; i < L.nx; i += blockDim.x) a.xs[(size_t)b * (L.N + 1) * L.nx + i] = a.x0[(size_t)b * L.nx + i];
   if (tid == 0) {
     st.num_iters = 0; st.al_iters = 0; st.converged = 0; st.done = 0; st.skip_step = 0; st.ls_step = 0; st.alpha = 0;
+    st.stalled = 0; st.ls_more = 0;
     st.prim_tol = fmax(a.opt.prim_tol0 * pow(st.mu, a.opt.bcl_prim_alpha), a.opt.tol);
     st.inner_tol = fmax(a.opt.inner_tol0 * pow(st.mu, a.opt.bcl_dual_alpha), a.opt.tol);
   }
