@@ -178,6 +178,19 @@ def main():
                 "avg_kernel_ms": round(total_ms / launches, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "kernel_ms_per_step_summed_over_shards": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
 
+    mfma = None
+    if roof is not None and roof["kernel"] == "k_riccati_backward":
+        cks = [int(t[0][6]) for t in ens.tables]
+        fl = 0.0
+        for k_, c_ in enumerate(cks[:-1]):
+            nz_ = n + m
+            # Pt = (I + mu_d Ph)^-1 Ph (one n^3/3 factorisation + 2 n^3 of solves), G = Pt [A B], H + [A B]^T G (symmetric), stage KKT, P update
+            fl += n ** 3 / 3.0 + 2.0 * n ** 3 + 2.0 * n * n * nz_ + n * nz_ * nz_ + m ** 3 / 3.0 + 2.0 * m * m * (n + 1) + 2.0 * n * n * m
+        fl *= args.batch / nshard
+        ach = fl / (roof["avg_kernel_ms"] * 1e-3) / 1e12
+        mfma = {"bound": "mfma", "kernel": roof["kernel"], "achieved": round(ach, 3), "peak": 78.6, "unit": "TFLOP/s", "frac": round(ach / 78.6, 5),
+                "busy_cus": min(256, args.batch // nshard), "frac_of_busy_cus": round(ach / (78.6 * min(256, args.batch // nshard) / 256.0), 5)}
+
     # ---- batch = 1 latency (BASELINE.json config: batch=1 on one MI355X) ----
     p50_ms = None
     if not args.no_latency:
@@ -233,6 +246,9 @@ def main():
         "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; the others are within 1e-4 of feasibility)" % (n_conv, args.batch),
         "diverged_instance_rescues": sum(getattr(e, "rescues", 0) for e in shards),
         "roofline": roof, "cpu_baseline": cpu,
+        # supplementary: the same kernel against the fp64 matrix-core peak (the sweep is a chain of dependent dense steps on ONE CU
+        # per instance, not a streaming kernel — DESIGN.md §5); flops = textbook count of the recursion on the unpadded dimensions
+        "roofline_mfma": mfma,
     }
     print(json.dumps(out))
     if dist is not None:
