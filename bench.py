@@ -31,15 +31,18 @@ def _p50(v):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="MPC instances per GPU (512 / 8 in the 8-GPU ensemble config)")
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--model", choices=["complete", "reduced"], default="complete",
                     help="complete = synthetic Talos nq=39 (32 actuated DoF, BASELINE.json); reduced = nq=29 as the scripts lock it")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=4,
                     help="the ensemble of one GPU is split into this many shards, each on its own handle/stream, so that the "
                          "sequential Riccati sweeps of one shard overlap the per-knot kernels of the others")
+    ap.add_argument("--phase-offset-ms", type=float, default=-1.0,
+                    help="with --streams S: shard i starts its ticks i x this many ms late (inside the timed region); "
+                         "negative = automatic (0.8 x one lock-step tick of the warm-up / S)")
     ap.add_argument("--closed-loop", action="store_true",
                     help="measured states from the simulation stand-in (10 x 1 ms of knot 0's dynamics under the feedback law, N2) "
                          "instead of perfect-model feedback; the simulation runs inside the timed region")
@@ -79,31 +82,55 @@ def main():
         n_conv = locals().get("n_conv", 0) + sum(bool(st.converged) for st in c)
         cold = cold or c
 
+    stagger = {"ms": args.phase_offset_ms}
+
     def run_ticks(count):
-        """`count` MPC ticks of every shard.  Shards are independent ensembles: each one is driven by its own host
-        thread (ctypes releases the GIL), so that they run out of phase on the device instead of in lock step."""
+        """`count` MPC ticks of every shard (independent ensembles, each on its own handle / stream)."""
         if nshard == 1:
             for _ in range(count):
                 shards[0].step(rescue=True)  # synchronous form: exactly one solver pass per tick
             return
-        import threading
-        errs = []
+        # One host thread drives all shards round-robin: a tick is enqueued on the shard's stream without waiting, and
+        # completed (stream sync + status read-back) just before that shard's next tick is enqueued.  Shard i starts
+        # i x phase-offset late, so that the sequential Riccati sweep of one shard (few busy CUs) runs beside the per-knot
+        # kernels of the others instead of beside their sweeps.  Automatic offset: the first call (warm-up) times one
+        # lock-step tick T and uses 0.8 T / shards from then on.
+        done_ticks = 0
+        if stagger["ms"] < 0:
+            t_ = time.perf_counter()
+            for e in shards:
+                e.step_async()
+            for e in shards:
+                e.wait(rescue=True)
+            stagger["ms"] = 0.8 * (time.perf_counter() - t_) * 1e3 / nshard  # staggered ticks are ~0.8 of a lock-step one
+            done_ticks = 1
+        if count - done_ticks <= 0:
+            return
+        for i, e in enumerate(shards):
+            if i and stagger["ms"] > 0:
+                time.sleep(stagger["ms"] * 1e-3)
+            e.step_async()
+        for _ in range(count - done_ticks - 1):
+            for e in shards:
+                e.wait(rescue=True)
+                e.step_async()
+        for e in shards:
+            e.wait(rescue=True)
 
-        def drive(e):
-            try:
-                for _ in range(count):
-                    e.step(rescue=True)
-            except Exception as ex:  # noqa: BLE001 - re-raised on the main thread
-                errs.append(ex)
-        th = [threading.Thread(target=drive, args=(e,)) for e in shards]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errs:
-            raise errs[0]
-
+    # warm-up: every kernel is timed (HIP events on the solver's stream) to find the dominant one and the per-kernel
+    # split; the timed region below then only brackets the dominant kernel, because an event pair between two kernels
+    # costs stream time (the next launch is not dispatched back to back)
+    for e in shards:
+        e.native.profile(2)
+        e.native.profile(1)
     run_ticks(args.warmup)
+    warm = {}
+    for e in shards:
+        e.native.profile(0)
+        for kname, (cnt, ms, slot) in e.native.profile_read(slots=True).items():
+            c0, m0, _ = warm.get(kname, (0, 0.0, slot))
+            warm[kname] = (c0 + cnt, m0 + ms, slot)
+    dom_slot = max(warm.values(), key=lambda v: v[1])[2] if warm else 0
 
     def sync_all():
         for e in shards:
@@ -115,7 +142,7 @@ def main():
 
     for e in shards:
         e.native.profile(2)
-        e.native.profile(1)
+        e.native.profile(16 * (1 << dom_slot))
     sync_all()
     t0 = time.perf_counter()
     run_ticks(args.steps)
@@ -170,13 +197,15 @@ def main():
         tf = os.path.join(ROOT, "profiles", "traffic_b%d_n%d_%s.json" % (args.batch // nshard, args.horizon, args.model))
         if os.path.exists(tf):
             with open(tf) as fh:
-                ent = json.load(fh).get("kernels", {}).get(rocprof_name, {})
+                kk = json.load(fh).get("kernels", {})
+            ent = kk.get(rocprof_name) or kk.get("void %s<512>" % rocprof_name) or {}
             if "hbm_bytes" in ent:
                 traffic = int(ent["hbm_bytes"])
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_kernel_ms": round(total_ms / launches, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                "kernel_ms_per_step_summed_over_shards": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1][1])}}
+                "shards_in_flight": nshard,  # one launch serves one shard; the shards' launches overlap on the device
+                "warmup_kernel_ms_per_step_summed_over_shards": {k: round(v[1] / max(1, args.warmup), 4) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])}}
 
     mfma = None
     if roof is not None and roof["kernel"] == "k_riccati_backward":
@@ -239,7 +268,7 @@ def main():
         "config": {"workload": "Talos full-dynamics MPC (fulldynamic_talos.py OCP), synthetic Talos %s model nq=%d nv=%d nu=%d, "
                                "horizon N=%d, ensemble of %d instances per GPU, one ProxDDP iteration per solve (max_iters=1, warm start)"
                                % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch),
-                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "model": "talos_synth_v1/" + args.model,
+                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "model": "talos_synth_v1/" + args.model,
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
         "p50_ms_per_solve_batch1": p50_ms,
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),

@@ -215,7 +215,9 @@ int mpc_debug_evaluate(mpc_solver* s, const double* xs, const double* us);
 
 /* Per-kernel timing with device events on the solver's own stream (the reference only has wall-clock
  * timers around run(): fulldynamic_talos.py:538-543).  mpc_profile(s, 1) starts recording, (s, 0) stops,
- * (s, 2) clears; (s, 3) / (s, 4) switch the in-kernel phase timers (shader-clock counters of the Riccati and stage
+ * (s, 2) clears; (s, 16 * mask), mask != 0, records only the kernel slots whose bit is set in mask (an event pair between two
+ * kernels costs stream time: a timed region that wants one kernel's duration should not pay for all of them);
+ * (s, 3) / (s, 4) switch the in-kernel phase timers (shader-clock counters of the Riccati and stage
  * kernels, read with mpc_debug_get("ric_prof")) on / off — developer tooling, off by default.  mpc_profile_read returns the number of kernel slots; for slot i it fills the kernel
  * name, the number of launches recorded and their summed duration in milliseconds.  The oracle reports
  * zero slots. */

@@ -272,8 +272,9 @@ class NativeSolver:
     def profile(self, mode):
         self._check(self.lib.mpc_profile(self._h, int(mode)), "mpc_profile")
 
-    def profile_read(self):
-        """-> {kernel name: (launches, total_ms)}"""
+    def profile_read(self, slots=False):
+        """-> {kernel name: (launches, total_ms)}  (``slots=True``: (launches, total_ms, slot index) — the index is the bit
+        of ``profile(16 * mask)``)"""
         out = {}
         name = C.create_string_buffer(64)
         cnt, ms = C.c_int32(0), C.c_double(0.0)
@@ -281,7 +282,7 @@ class NativeSolver:
         for i in range(nslots):
             self._check(self.lib.mpc_profile_read(self._h, i, name, 64, C.byref(cnt), C.byref(ms)), "mpc_profile_read")
             if cnt.value:
-                out[name.value.decode()] = (cnt.value, ms.value)
+                out[name.value.decode()] = (cnt.value, ms.value, i) if slots else (cnt.value, ms.value)
         return out
 
     # -- parity hooks ---------------------------------------------------------------------------

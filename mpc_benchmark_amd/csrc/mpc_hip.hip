@@ -43,6 +43,8 @@ struct mpc_solver {
   std::vector<void*> allocs;
   // host mirrors of the stage tables (needed for ring-buffer bookkeeping and debug)
   std::vector<int32_t> h_desc;
+  std::vector<double> h_params;            // host mirror of the stage parameters (an unchanged stage is not uploaded again)
+  std::vector<int32_t> h_len;              // per slot: n_desc, n_params of the mirror (0, 0 = nothing uploaded yet)
   std::vector<int> h_model_i;
   bool have_model = false;
   size_t mb_work_stride = 0;
@@ -58,10 +60,11 @@ struct mpc_solver {
     size_t used = 0;
   };
   bool profiling = false;
+  unsigned prof_mask = ~0u;  // kernel slots that get event pairs while profiling (an event pair costs stream time)
   std::vector<ProfSlot> prof;
 
   template <class F> void timed(int slot, const char* name, F&& launch) {
-    if (!profiling) { launch(); return; }
+    if (!profiling || !((prof_mask >> slot) & 1u)) { launch(); return; }
     if ((int)prof.size() <= slot) prof.resize(slot + 1);
     ProfSlot& p = prof[slot];
     p.name = name;
@@ -99,19 +102,20 @@ struct mpc_solver {
   }
 };
 
+// Blocking copy on the handle's own stream.  (A plain hipMemcpy goes through the null stream, which waits for the work of
+// every other handle on the device: shards of one GPU would then run in lock step.)
+static void copy_sync(mpc_solver* s, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+  HIP_OK(hipMemcpyAsync(dst, src, bytes, kind, s->stream));
+  HIP_OK(hipStreamSynchronize(s->stream));
+}
+
 static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->dims = d;
   HIP_OK(hipSetDevice(d.device));
-  {
-    // Ensemble shards on one GPU (several handles) are given alternating stream priorities: the dispatcher then runs the
-    // shards out of phase — the sequential Riccati sweep of one shard (B workgroups) overlaps the wide per-knot kernels
-    // of the other instead of both shards executing the same kernel type side by side.
-    static int created = 0;
-    int lo = 0, hi = 0;
-    HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    const int prio = (created++ % 2 == 0) ? hi : lo;
-    HIP_OK(hipStreamCreateWithPriority(&s->stream, hipStreamDefault, prio));
-  }
+  // Own non-blocking stream per handle: the shards of an ensemble on one GPU (several handles) run out of phase, the
+  // sequential Riccati sweep of one shard (B workgroups) beside the wide per-knot kernels of the others.  Equal priorities:
+  // alternating high / low priorities starved the low-priority shards (their tick took 16 - 21 ms against 14.5 ms).
+  HIP_OK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
   Layout& L = s->L;
   L.N = d.horizon; L.B = d.batch; L.space = d.space; L.nx = d.nx; L.n = d.ndx; L.m = d.nu; L.c = d.nc_max > 0 ? d.nc_max : 1;
   L.nj = 0;
@@ -148,6 +152,8 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->d_all_done = s->alloc<int>(4);
   s->d_prof = s->alloc<double>(B * 64);
   s->h_desc.assign(N1 * L.max_stage_ints, 0);
+  s->h_params.assign(N1 * (size_t)L.max_stage_doubles, 0.0);
+  s->h_len.assign(2 * N1, 0);
   // default options
   mpc_options& o = s->opt;
   o.tol = 1e-5; o.mu_init = 1e-8; o.dyn_al_scale = 1e-3; o.reg_init = 1e-9; o.ls_armijo_c1 = 1e-4; o.ls_alpha_min = 1e-7;
@@ -164,7 +170,10 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
     HIP_OK(hipFuncSetAttribute((const void*)k_closed_loop, hipFuncAttributeMaxDynamicSharedMemorySize, s->cl.total_bytes));
   s->use_mfma_riccati = s->ric.total_bytes <= 160 * 1024 && (s->ric.st_lds || s->ric.mp * s->ric.np <= L.n * L.nz) && !getenv("MPC_HIP_GENERIC_RICCATI");
   if (s->use_mfma_riccati)
-    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+  {
+    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+  }
   HIP_OK(hipStreamSynchronize(s->stream));
 }
 
@@ -189,7 +198,16 @@ static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_des
   }
   if (nse3 > MB_SE3_SLOTS) throw std::runtime_error("too many SE(3)-valued terms in one stage for the whole-body kernel");
   if (nc != desc[6]) throw std::runtime_error("stage descriptor: constraint row count mismatch");
-  std::memcpy(s->h_desc.data() + (size_t)slot * L.max_stage_ints, desc, n_desc * sizeof(int32_t));
+  // receding horizon: the stage that enters the ring usually equals the one that left the slot (same contact phase,
+  // same references) — nothing to move then
+  int32_t* hd = s->h_desc.data() + (size_t)slot * L.max_stage_ints;
+  double* hp = s->h_params.data() + (size_t)slot * L.max_stage_doubles;
+  if (s->h_len[2 * slot] == n_desc && s->h_len[2 * slot + 1] == n_params && std::memcmp(hd, desc, n_desc * sizeof(int32_t)) == 0 &&
+      (n_params == 0 || std::memcmp(hp, params, n_params * sizeof(double)) == 0))
+    return;
+  std::memcpy(hd, desc, n_desc * sizeof(int32_t));
+  if (n_params > 0) std::memcpy(hp, params, n_params * sizeof(double));
+  s->h_len[2 * slot] = n_desc; s->h_len[2 * slot + 1] = n_params;
   HIP_OK(hipMemcpyAsync(s->d_stage_desc + (size_t)slot * L.max_stage_ints, desc, n_desc * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
   if (n_params > 0)
     HIP_OK(hipMemcpyAsync(s->d_stage_params + (size_t)slot * L.max_stage_doubles, params, n_params * sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -221,7 +239,9 @@ static void launch_pass(mpc_solver* s) {
   s->timed(1, "k_lagrangian", [&] { hipLaunchKernelGGL(k_lagrangian, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   s->timed(2, "k_decide", [&] { hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(128), 0, s->stream, a); });
   s->timed(3, "k_riccati_backward", [&] {
-    if (s->use_mfma_riccati) hipLaunchKernelGGL(k_riccati_mfma, dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
+    if (s->use_mfma_riccati && s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_SMALL_THREADS, 16>), dim3(L.B), dim3(RIC_SMALL_THREADS), s->ric.total_bytes, s->stream, a, s->ric);  // small problems: one wavefront
+    else if (s->use_mfma_riccati) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 96>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
     else hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);
   });
   // forward sweep: closed-loop transitions Phi / phi for all knots in parallel, then one mat-vec per knot (closed_loop.h);
@@ -260,25 +280,24 @@ static void run_impl(mpc_solver* s, mpc_stats* stats, int passes_enqueued = 0) {
   SolverArgs a = s->args();
   if (passes_enqueued == 0) hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, a);
   const int max_passes = s->opt.max_iters + s->opt.max_al_iters + 1;
+  std::vector<InstState> st(L.B);
   for (int pass = 0; pass < max_passes; ++pass) {
     if (pass >= passes_enqueued) launch_pass(s);
     else if (pass + 1 < passes_enqueued) continue;  // only the flag of the last enqueued pass is meaningful
-    int done = 0;
-    HIP_OK(hipMemcpyAsync(&done, s->d_all_done, sizeof(int), hipMemcpyDeviceToHost, s->stream));
-    HIP_OK(hipStreamSynchronize(s->stream));
+    // one read-back per pass: the per-instance status (the device-side all_done flag says the same as "every done != 0")
+    copy_sync(s, st.data(), s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost);
+    int done = 1;
+    for (int b = 0; b < L.B; ++b) if (!st[b].done) done = 0;
     if (const char* tr = getenv("MPC_HIP_TRACE")) {  // developer aid: per-pass solver state of one instance
       const int tb = atoi(tr);
       if (tb >= 0 && tb < L.B) {
-        InstState t;
-        HIP_OK(hipMemcpy(&t, s->d_inst + tb, sizeof(InstState), hipMemcpyDeviceToHost));
+        const InstState& t = st[tb];
         fprintf(stderr, "[trace b=%d pass %d] it %d al %d mu %.1e phi0 %.10e dphi0 %.3e alpha %.4g ls %d prim %.3e dual %.3e crit %.3e inner_tol %.1e prim_tol %.1e skip %d stalled %d done %d\n",
                 tb, pass, t.num_iters, t.al_iters, t.mu, t.phi0, t.dphi0, t.alpha, t.ls_step, t.prim, t.dual, t.crit, t.inner_tol, t.prim_tol, t.skip_step, t.stalled, t.done);
       }
     }
     if (done != 0) break;
   }
-  std::vector<InstState> st(L.B);
-  HIP_OK(hipMemcpy(st.data(), s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost));
   for (int b = 0; b < L.B; ++b) {
     if (st[b].done >= 2) throw std::runtime_error("Riccati factorisation failed on instance " + std::to_string(b) + " (code " + std::to_string(st[b].done) + ")");
     if (!stats) continue;
@@ -368,8 +387,8 @@ int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double*
     }
     s->d_model_i = s->alloc<int32_t>(ext.size());
     s->d_model_d = s->alloc<double>(n_d);
-    HIP_OK(hipMemcpy(s->d_model_i, ext.data(), ext.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(s->d_model_d, dtab, n_d * sizeof(double), hipMemcpyHostToDevice));
+    copy_sync(s, s->d_model_i, ext.data(), ext.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    copy_sync(s, s->d_model_d, dtab, n_d * sizeof(double), hipMemcpyHostToDevice);
     s->h_model_i.assign(itab, itab + n_i);
     s->L.nj = nj; s->LT.nj = nj; s->LT.model_mask_off = s->L.model_mask_off;
     if (s->dims.space == MPC_SPACE_MULTIBODY) {
@@ -399,6 +418,7 @@ int mpc_update_stage_params_batch(mpc_solver* s, int32_t count, const int32_t* k
     for (int i = 0; i < count; ++i) {
       if (ks[i] < 0 || ks[i] > s->L.N) throw std::runtime_error("stage index out of range");
       if (offsets[i] < 0 || lens[i] < 0 || offsets[i] + lens[i] > s->L.max_stage_doubles) throw std::runtime_error("parameter update out of range");
+      std::memcpy(s->h_params.data() + (size_t)slot_of(s, ks[i]) * s->L.max_stage_doubles + offsets[i], vals + pos, lens[i] * sizeof(double));
       HIP_OK(hipMemcpyAsync(s->d_stage_params + (size_t)slot_of(s, ks[i]) * s->L.max_stage_doubles + offsets[i], vals + pos,
                             lens[i] * sizeof(double), hipMemcpyHostToDevice, s->stream));
       pos += lens[i];
@@ -411,6 +431,7 @@ int mpc_update_stage_params(mpc_solver* s, int32_t k, int32_t offset, const doub
   MPC_TRY(s, {
     if (k < 0 || k > s->L.N) throw std::runtime_error("stage index out of range");
     if (offset < 0 || offset + n > s->L.max_stage_doubles) throw std::runtime_error("parameter update out of range");
+    std::memcpy(s->h_params.data() + (size_t)slot_of(s, k) * s->L.max_stage_doubles + offset, vals, n * sizeof(double));
     HIP_OK(hipMemcpyAsync(s->d_stage_params + (size_t)slot_of(s, k) * s->L.max_stage_doubles + offset, vals, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipStreamSynchronize(s->stream));
   })
@@ -439,7 +460,8 @@ int mpc_profile(mpc_solver* s, int32_t mode) {
   MPC_TRY(s, {
     if (mode == 2) { for (auto& p : s->prof) p.used = 0; }
     else if (mode == 3 || mode == 4) s->phase_timers = (mode == 3);  // in-kernel phase timers (developer tooling, perturbs timing)
-    else s->profiling = (mode != 0);
+    else if (mode >= 16) { s->profiling = true; s->prof_mask = (unsigned)mode >> 4; }
+    else { s->profiling = (mode != 0); s->prof_mask = ~0u; }
   })
 }
 
@@ -521,11 +543,10 @@ int mpc_run_shifted_async(mpc_solver* s) {
     const Layout& L = s->L;
     hipLaunchKernelGGL(k_shift, dim3(L.B), dim3(64), 0, s->stream, s->args(), s->perfect_feedback ? 1 : 0);
     hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, s->args());
-    // with max_iters = 1 one pass takes the step; the second one only acts for an instance whose first pass was a
-    // BCL update without a step (its workgroups exit immediately otherwise)
+    // with max_iters = 1 one pass takes the step; mpc_wait runs further passes for the rare instance whose first pass
+    // was a BCL update without a step
     launch_pass(s);
-    launch_pass(s);
-    s->async_passes = 2;
+    s->async_passes = 1;
   })
 }
 
@@ -543,19 +564,20 @@ int mpc_get_results(mpc_solver* s, double* xs, double* us, double* K, double* kf
     const Layout& L = s->L;
     const size_t B = L.B, N1 = L.N + 1, N = L.N;
     HIP_OK(hipStreamSynchronize(s->stream));
-    if (xs) HIP_OK(hipMemcpy(xs, s->d_xs, B * N1 * L.nx * sizeof(double), hipMemcpyDeviceToHost));
-    if (us) HIP_OK(hipMemcpy(us, s->d_us, B * N * L.m * sizeof(double), hipMemcpyDeviceToHost));
-    if (vs) HIP_OK(hipMemcpy(vs, s->d_vs, B * N1 * L.c * sizeof(double), hipMemcpyDeviceToHost));
-    if (lams) HIP_OK(hipMemcpy(lams, s->d_lams, B * N1 * L.n * sizeof(double), hipMemcpyDeviceToHost));
+    if (xs) copy_sync(s, xs, s->d_xs, B * N1 * L.nx * sizeof(double), hipMemcpyDeviceToHost);
+    if (us) copy_sync(s, us, s->d_us, B * N * L.m * sizeof(double), hipMemcpyDeviceToHost);
+    if (vs) copy_sync(s, vs, s->d_vs, B * N1 * L.c * sizeof(double), hipMemcpyDeviceToHost);
+    if (lams) copy_sync(s, lams, s->d_lams, B * N1 * L.n * sizeof(double), hipMemcpyDeviceToHost);
     if (K || kff) {
       // gains live inside the gain records: strided 2-D copies
       for (size_t b = 0; b < B; ++b) {
         const double* g0 = s->d_gains + b * N1 * L.gain_stride;
-        if (K) HIP_OK(hipMemcpy2D(K + b * N * L.m * L.n, (size_t)L.m * L.n * sizeof(double), g0 + L.oK, (size_t)L.gain_stride * sizeof(double),
-                                  (size_t)L.m * L.n * sizeof(double), N, hipMemcpyDeviceToHost));
-        if (kff) HIP_OK(hipMemcpy2D(kff + b * N * L.m, (size_t)L.m * sizeof(double), g0 + L.ok, (size_t)L.gain_stride * sizeof(double),
-                                    (size_t)L.m * sizeof(double), N, hipMemcpyDeviceToHost));
+        if (K) HIP_OK(hipMemcpy2DAsync(K + b * N * L.m * L.n, (size_t)L.m * L.n * sizeof(double), g0 + L.oK, (size_t)L.gain_stride * sizeof(double),
+                                       (size_t)L.m * L.n * sizeof(double), N, hipMemcpyDeviceToHost, s->stream));
+        if (kff) HIP_OK(hipMemcpy2DAsync(kff + b * N * L.m, (size_t)L.m * sizeof(double), g0 + L.ok, (size_t)L.gain_stride * sizeof(double),
+                                         (size_t)L.m * sizeof(double), N, hipMemcpyDeviceToHost, s->stream));
       }
+      HIP_OK(hipStreamSynchronize(s->stream));
     }
   })
 }
@@ -567,8 +589,8 @@ int mpc_get_stage_data(mpc_solver* s, int32_t k, double* xdot, double* wrenches)
     HIP_OK(hipStreamSynchronize(s->stream));
     for (int b = 0; b < L.B; ++b) {
       const double* kn = s->d_knots + ((size_t)b * (L.N + 1) + k) * L.knot_stride;
-      if (xdot) HIP_OK(hipMemcpy(xdot + (size_t)b * L.n, kn + L.oXD, L.n * sizeof(double), hipMemcpyDeviceToHost));
-      if (wrenches) HIP_OK(hipMemcpy(wrenches + (size_t)b * 12, kn + L.oWR, 12 * sizeof(double), hipMemcpyDeviceToHost));
+      if (xdot) copy_sync(s, xdot + (size_t)b * L.n, kn + L.oXD, L.n * sizeof(double), hipMemcpyDeviceToHost);
+      if (wrenches) copy_sync(s, wrenches + (size_t)b * 12, kn + L.oWR, 12 * sizeof(double), hipMemcpyDeviceToHost);
     }
   })
 }
@@ -596,13 +618,13 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
     if (b < 0 || b >= L.B || k < 0 || k > L.N) throw std::runtime_error("debug_get: index out of range");
     HIP_OK(hipStreamSynchronize(s->stream));
     std::vector<double> kn(L.knot_stride), g(L.gain_stride);
-    HIP_OK(hipMemcpy(kn.data(), s->d_knots + ((size_t)b * (L.N + 1) + k) * L.knot_stride, L.knot_stride * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_OK(hipMemcpy(g.data(), s->d_gains + ((size_t)b * (L.N + 1) + k) * L.gain_stride, L.gain_stride * sizeof(double), hipMemcpyDeviceToHost));
+    copy_sync(s, kn.data(), s->d_knots + ((size_t)b * (L.N + 1) + k) * L.knot_stride, L.knot_stride * sizeof(double), hipMemcpyDeviceToHost);
+    copy_sync(s, g.data(), s->d_gains + ((size_t)b * (L.N + 1) + k) * L.gain_stride, L.gain_stride * sizeof(double), hipMemcpyDeviceToHost);
     const int n = L.n, nz = L.nz, c = (int)kn[L.oMISC + MISC_NC], m = (int)kn[L.oMISC + MISC_M], nzk = n + m;
     const std::string nm(name);
     std::vector<double> v;
     auto mat = [&](const double* src, int rows, int cols, int ld) { v.resize((size_t)rows * cols); for (int i = 0; i < rows; ++i) for (int j = 0; j < cols; ++j) v[(size_t)i * cols + j] = src[(size_t)i * ld + j]; };
-    auto dev_vec = [&](const double* d_ptr, int len) { v.resize(len); HIP_OK(hipMemcpy(v.data(), d_ptr, len * sizeof(double), hipMemcpyDeviceToHost)); };
+    auto dev_vec = [&](const double* d_ptr, int len) { v.resize(len); copy_sync(s, v.data(), d_ptr, len * sizeof(double), hipMemcpyDeviceToHost); };
     if (nm == "H") mat(kn.data() + L.oH, nzk, nzk, nz);
     else if (nm == "grad") mat(kn.data() + L.oG, 1, nzk, nz);
     else if (nm == "AB") mat(kn.data() + L.oAB, k < L.N ? n : 0, nzk, nz);
@@ -622,7 +644,7 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
     else if (nm == "knu") mat(g.data() + L.oknu, 1, c, c);
     else if (nm == "Mx") mat(g.data() + L.oMx, k < L.N ? n : 0, n, n);
     else if (nm == "mx") mat(g.data() + L.omx, 1, k < L.N ? n : 0, n);
-    else if (nm == "ric_prof") { dev_vec(s->d_prof + (size_t)b * 64, 64); HIP_OK(hipMemset(s->d_prof + (size_t)b * 64, 0, 64 * sizeof(double))); }
+    else if (nm == "ric_prof") { dev_vec(s->d_prof + (size_t)b * 64, 64); HIP_OK(hipMemsetAsync(s->d_prof + (size_t)b * 64, 0, 64 * sizeof(double), s->stream)); HIP_OK(hipStreamSynchronize(s->stream)); }
     else if (nm == "dx") dev_vec(s->d_dxs + ((size_t)b * (L.N + 1) + k) * n, n);
     else if (nm == "du") { if (k >= L.N) throw std::runtime_error("no du at the terminal knot"); dev_vec(s->d_dus + ((size_t)b * L.N + k) * L.m, L.m); }
     else if (nm == "dvs") dev_vec(s->d_dvs + ((size_t)b * (L.N + 1) + k) * L.c, L.c);

@@ -18,6 +18,9 @@
 #include "mfma_blocks.h"
 
 #ifndef RIC_THREADS
+#ifndef RIC_SMALL_THREADS
+#define RIC_SMALL_THREADS 128  // workgroup of the small-problem instantiation (np = mp = 16)
+#endif
 #define RIC_THREADS 512  // 8 wavefronts (2 per SIMD): the sweep is latency-bound, a second wave per SIMD hides LDS / MFMA latency
 #endif
 #if RIC_THREADS <= 256
@@ -26,9 +29,6 @@
 #define RIC_WAVES_ATTR
 #endif
 #define RIC_MAX_SERIES 8
-#define RIC_SERIES_TILES ((21 * 64 + RIC_THREADS - 1) / RIC_THREADS)  // lower-triangle output tiles per wavefront: nb <= 6  // Neumann terms before falling back to the factorisation of I + mu_d Ph
-#define RIC_G_TILES ((48 * 64 + RIC_THREADS - 1) / RIC_THREADS)  // tiles of G per wavefront: nb <= 6, nzt <= 8
-#define AB_ROWS (96 * 64 / RIC_THREADS)  // register prefetch capacity: np <= 96 rows, nzp <= 128 columns
 
 // phase timing (shader clock) accumulated over the knots; read back with mpc_debug_get("ric_prof")
 // The sweep is one long loop over the knots with ~15 phases per knot; left alone, the compiler hoists every per-lane
@@ -105,7 +105,15 @@ DEV double wave_sum_r(double v) { return wave_sum(v); }  // DPP reduction of sol
 
 // ============================================================================================================
 // one wavefront per SIMD (LDS-bound occupancy anyway): let the register allocator use the whole 512-entry file
-__global__ void __launch_bounds__(RIC_THREADS) RIC_WAVES_ATTR k_riccati_mfma(SolverArgs a, RicLds S) {
+// RT = threads per workgroup.  RT = RIC_THREADS (8 wavefronts) is the general kernel (np <= 96, nzp <= 128); RT = 64 is the
+// small-problem variant (np = mp = 16, at most 64 constraint rows: the centroidal OCP): a single wavefront walks the same
+// code, so every workgroup barrier degenerates and no wavefront waits on another.
+template <int RT, int NPMAX>
+__global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
+  constexpr int NWV = RT / 64, NBMAX = NPMAX / 16, NZTMAX = NPMAX > 16 ? 8 : 2;
+  constexpr int AB_ROWS = (NPMAX + NWV - 1) / NWV;                                // register prefetch capacity: rows of [A B] per wavefront
+  constexpr int RIC_SERIES_TILES = (NBMAX * (NBMAX + 1) / 2 + NWV - 1) / NWV;     // lower-triangle output tiles per wavefront
+  constexpr int RIC_G_TILES = (NBMAX * NZTMAX + NWV - 1) / NWV;                   // tiles of G per wavefront
   const Layout& L = a.L;
   const int b = blockIdx.x, nthr = blockDim.x, nw = nthr >> 6;
   int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // re-derived at every phase boundary (RIC_LAUNDER)

@@ -133,15 +133,25 @@ class EnsembleMPC:
             return self.cold_solve(max_iters=20)
 
     def step_async(self):
-        """Enqueue one tick without waiting (several shards on different streams overlap on the device)."""
+        """Enqueue one tick without waiting (several shards on different streams overlap on the device); ``wait``
+        completes it."""
+        if self.closed_loop:
+            self.native.simulate(*self.closed_loop)
         desc, params = self._table_for_tick(self.tick % self.pd.t_mpc)
         self.native.cycle(desc, params)
         self.native.setup()
         self.native.run_shifted_async()
         self.tick += 1
 
-    def wait(self):
-        return self.native.wait()
+    def wait(self, rescue=False):
+        """Complete the tick enqueued by ``step_async`` (``rescue`` as in ``step``)."""
+        try:
+            return self.native.wait()
+        except RuntimeError as e:
+            if not rescue or "factorisation failed" not in str(e):
+                raise
+            self.rescues = getattr(self, "rescues", 0) + 1
+            return self.cold_solve(max_iters=20)
 
     def results(self, **kw):
         return self.native.get_results(**kw)

@@ -10,7 +10,7 @@ for v in "$@"; do
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
-        j = json.loads(l); print(j['value'], 'solves/s', j['ms_per_step'], 'ms/step', j['roofline']['kernel_ms_per_step_summed_over_shards'])
+        j = json.loads(l); print(j['value'], 'solves/s', j['ms_per_step'], 'ms/step', j['roofline']['warmup_kernel_ms_per_step_summed_over_shards'])
     else: print(l, end='')
 "
   python3 tools/phase_timers.py $lib 2>&1 | grep -E "EVAL|total" 

@@ -1,13 +1,17 @@
 """Developer tool: in-kernel phase timers (shader clock, ~2.4 GHz assumed) of the Riccati sweep and of the whole-body
-stage kernel on the default bench workload.  usage: python tools/phase_timers.py [path/to/libmpc_hip.so]"""
+stage kernel on the default bench workload.  usage: python tools/phase_timers.py [path/to/libmpc_hip.so] [centroidal]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpc_benchmark_amd import _capi
 from mpc_benchmark_amd.ensemble import EnsembleMPC
 from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
 
-lib = _capi.bind_library(sys.argv[1]) if len(sys.argv) > 1 else _capi.load_hip_library()
-pd = FullDynamicsProblem(horizon=100, complete_model=True)
+lib = _capi.bind_library(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].endswith(".so") else _capi.load_hip_library()
+if "centroidal" in sys.argv[1:]:
+    from mpc_benchmark_amd.problems.centroidal import CentroidalProblem
+    pd = CentroidalProblem(horizon=100)
+else:
+    pd = FullDynamicsProblem(horizon=100, complete_model=True)
 ens = EnsembleMPC(pd, batch=4, library=lib)
 ens.prepare_schedule(10)
 ens.cold_solve(100)
