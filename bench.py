@@ -73,7 +73,8 @@ def main():
     nshard = max(1, min(args.streams, args.batch))
     sizes = [args.batch // nshard + (1 if i < args.batch % nshard else 0) for i in range(nshard)]
     shards = [EnsembleMPC(pd, batch=sz, library=lib, device=local_rank, seed=20250304 + 1000 * rank + i,
-                          closed_loop=((10, pd.dt / 10) if args.closed_loop else None)) for i, sz in enumerate(sizes)]
+                          closed_loop=((10, pd.dt / 10) if args.closed_loop else None), forward_mode=(1 if nshard > 1 else 0))
+              for i, sz in enumerate(sizes)]
     ens = shards[0]
     cold = None
     for e in shards:

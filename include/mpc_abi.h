@@ -126,7 +126,9 @@ typedef struct mpc_options {
   int32_t ls_max_steps;    /* number of backtracking candidates alpha = 2^-i           */
   int32_t num_threads;     /* oracle: OpenMP threads ; HIP: ignored                    */
   int32_t riccati_legs;    /* linear_solver_choice = LQ_SOLVER_PARALLEL + setNumThreads (fulldynamic_talos.py:383,385): accepted, the sweep is serial per instance */
-  int32_t reserved;
+  int32_t forward_mode;    /* HIP forward sweep: 0 = automatic, 1 = one workgroup per instance walks the knots (least CU time: ensembles
+                            * sharded over several handles of one GPU), 2 = knot-parallel closed-loop transitions first (shortest latency:
+                            * a single small ensemble) ; oracle: ignored                */
 } mpc_options;
 
 typedef struct mpc_stats {

@@ -160,7 +160,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   o.bcl_prim_alpha = 0.1; o.bcl_prim_beta = 0.9; o.bcl_dual_alpha = 1.0; o.bcl_dual_beta = 1.0;
   o.bcl_mu_update_factor = 0.01; o.bcl_mu_lower_bound = 1e-8; o.inner_tol0 = 1.0; o.prim_tol0 = 1.0;
   o.max_iters = 100; o.max_al_iters = 100; o.force_initial_condition = 1; o.rollout_linear = 1; o.ls_max_steps = 8;
-  o.num_threads = 1; o.riccati_legs = 1; o.reserved = 0;
+  o.num_threads = 1; o.riccati_legs = 1; o.forward_mode = 0;
   HIP_OK(hipFuncSetAttribute((const void*)k_riccati_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   s->ric = make_ric_lds(L.n, L.m, L.c, 1);
   if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0);     // panel-wise G when the whole G does not fit
@@ -234,7 +234,6 @@ static void launch_eval(mpc_solver* s, bool trial, int cand0 = 0, int ncand = 1)
 static void launch_pass(mpc_solver* s) {
   const Layout& L = s->L;
   SolverArgs a = s->args();
-  HIP_OK(hipMemsetAsync(s->d_all_done, 0xff, sizeof(int), s->stream));  // all_done = -1 (true) unless cleared
   s->timed(0, "k_eval_stage", [&] { launch_eval(s, false); });
   s->timed(1, "k_lagrangian", [&] { hipLaunchKernelGGL(k_lagrangian, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   s->timed(2, "k_decide", [&] { hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(128), 0, s->stream, a); });
@@ -248,7 +247,9 @@ static void launch_pass(mpc_solver* s) {
   // the three-mat-vec sweep remains for dimensions whose operands do not fit the LDS of k_closed_loop
   // The knot-parallel kernel costs (N x B) workgroups: it pays when the GPU is mostly idle during the sweep (small
   // ensembles, latency-bound: 0.95 -> 0.53 ms at batch 1), not when the ensemble already fills it (B = 64: 0.97 -> 1.3 ms)
-  const bool fw_phi = s->cl.total_bytes <= 160 * 1024 && L.n <= 80 && L.m <= 32 && L.B * L.N <= 2048;
+  // (options.forward_mode overrides: a handle cannot see the other handles that share its GPU — with 4 shards of 16 instances the
+  // sweep gives 4714 solves/s against 4551)
+  const bool fw_phi = s->cl.total_bytes <= 160 * 1024 && L.n <= 80 && L.m <= 32 && (s->opt.forward_mode == 0 ? L.B * L.N <= 2048 : s->opt.forward_mode == 2);
   if (fw_phi) {
     s->timed(12, "k_closed_loop", [&] { hipLaunchKernelGGL(k_closed_loop, dim3(L.N, L.B), dim3(CL_THREADS), s->cl.total_bytes, s->stream, a, s->cl); });
     s->timed(4, "k_forward", [&] { hipLaunchKernelGGL((k_forward_phi<4, 10>), dim3(L.B), dim3(512), 2 * L.n * sizeof(double), s->stream, a); });
@@ -509,16 +510,8 @@ int mpc_get_x0(mpc_solver* s, double* x0) {
 int mpc_setup(mpc_solver* s) {
   MPC_TRY(s, {
     const Layout& L = s->L;
-    const size_t B = L.B, N1 = L.N + 1;
-    HIP_OK(hipMemsetAsync(s->d_vs, 0, B * N1 * L.c * sizeof(double), s->stream));
-    HIP_OK(hipMemsetAsync(s->d_vs_e, 0, B * N1 * L.c * sizeof(double), s->stream));
-    HIP_OK(hipMemsetAsync(s->d_lams, 0, B * (N1 + 1) * L.n * sizeof(double), s->stream));
-    HIP_OK(hipMemsetAsync(s->d_lams_e, 0, B * (N1 + 1) * L.n * sizeof(double), s->stream));
-    std::vector<InstState> st(B);
-    std::memset(st.data(), 0, B * sizeof(InstState));
-    for (auto& i : st) i.mu = s->opt.mu_init;
-    HIP_OK(hipMemcpyAsync(s->d_inst, st.data(), B * sizeof(InstState), hipMemcpyHostToDevice, s->stream));
-    HIP_OK(hipStreamSynchronize(s->stream));
+    hipLaunchKernelGGL(k_setup, dim3(L.N + 2, L.B), dim3(256), 0, s->stream, s->args());  // asynchronous: the MPC loop calls it every tick
+    HIP_OK(hipGetLastError());
   })
 }
 

@@ -19,7 +19,7 @@
 
 #ifndef RIC_THREADS
 #ifndef RIC_SMALL_THREADS
-#define RIC_SMALL_THREADS 128  // workgroup of the small-problem instantiation (np = mp = 16)
+#define RIC_SMALL_THREADS 256  // workgroup of the small-problem instantiation (np = mp = 16): 20.5 us / knot (128: 26, 64: 38, 512: 21)
 #endif
 #define RIC_THREADS 512  // 8 wavefronts (2 per SIMD): the sweep is latency-bound, a second wave per SIMD hides LDS / MFMA latency
 #endif
@@ -105,9 +105,8 @@ DEV double wave_sum_r(double v) { return wave_sum(v); }  // DPP reduction of sol
 
 // ============================================================================================================
 // one wavefront per SIMD (LDS-bound occupancy anyway): let the register allocator use the whole 512-entry file
-// RT = threads per workgroup.  RT = RIC_THREADS (8 wavefronts) is the general kernel (np <= 96, nzp <= 128); RT = 64 is the
-// small-problem variant (np = mp = 16, at most 64 constraint rows: the centroidal OCP): a single wavefront walks the same
-// code, so every workgroup barrier degenerates and no wavefront waits on another.
+// RT = threads per workgroup.  RT = RIC_THREADS (8 wavefronts) is the general kernel (np <= 96, nzp <= 128); RT = RIC_SMALL_THREADS is the
+// small-problem variant (np = mp = 16, at most RT constraint rows: the centroidal OCP) — the same code with fewer wavefronts.
 template <int RT, int NPMAX>
 __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   constexpr int NWV = RT / 64, NBMAX = NPMAX / 16, NZTMAX = NPMAX > 16 ? 8 : 2;

@@ -28,7 +28,7 @@ struct SolverArgs {
   double *knots, *gains, *work;
   double *trial_phi;  // [B][n_alpha][N+1]
   InstState* inst;
-  int* all_done;
+  int* all_done;  // unused: the host reads the per-instance status instead
   double* prof;  // [B][64] phase cycle counters: 0..31 Riccati kernel, 32..63 whole-body stage kernel (knot 1)
 };
 
@@ -708,7 +708,25 @@ __global__ void k_after_step(SolverArgs a) {
     st.num_iters += 1;
     if (st.num_iters >= a.opt.max_iters) st.done = 1;
   }
-  if (!st.done) atomicExch(a.all_done, 0);
+}
+
+// setup(): multipliers and their estimates to zero, fresh per-instance solver state (mu = mu_init).  One launch instead
+// of four fills, an upload and a stream sync: the MPC loop calls setup every tick.  grid (N + 2, B), block 256
+__global__ void k_setup(SolverArgs a) {
+  const Layout& L = a.L;
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const size_t lrow = ((size_t)b * (L.N + 2) + k) * L.n;
+  for (int i = tid; i < L.n; i += blockDim.x) { a.lams[lrow + i] = 0.0; a.lams_e[lrow + i] = 0.0; }
+  if (k <= L.N) {
+    const size_t vrow = ((size_t)b * (L.N + 1) + k) * L.c;
+    for (int i = tid; i < L.c; i += blockDim.x) { a.vs[vrow + i] = 0.0; a.vs_e[vrow + i] = 0.0; }
+  }
+  if (k == 0 && tid == 0) {
+    InstState z;
+    memset(&z, 0, sizeof(z));
+    z.mu = a.opt.mu_init;
+    a.inst[b] = z;
+  }
 }
 
 // start of run(): xs[0] = x0, tolerances of the BCL loop.  grid B, block 64

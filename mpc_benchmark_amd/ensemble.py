@@ -15,9 +15,9 @@ from .aligator import _core as core
 
 class EnsembleMPC:
     def __init__(self, problem_def, batch=1, library=None, device=0, seed=20250304, perturb=True, sigma_q=0.02, sigma_v=0.05, perturb_dofs=None,
-                 closed_loop=None):
+                 closed_loop=None, forward_mode=0):
         """``problem_def``: a FullDynamicsProblem / CentroidalProblem-like builder (``build``, ``stage_for_tick``,
-        ``make_solver``, ``initial_guess``)."""
+        ``make_solver``, ``initial_guess``).  ``forward_mode``: mpc_options.forward_mode (1 for shards that share a GPU)."""
         self.pd = problem_def
         self.batch = int(batch)
         self.lib = library if library is not None else K.load_hip_library()
@@ -42,6 +42,7 @@ class EnsembleMPC:
         self.native = K.NativeSolver(self.lib, d)
         solver = problem_def.make_solver()
         self.options = solver._options()
+        self.options.forward_mode = int(forward_mode)
         self.native.set_options(self.options)
         if self.ctx.model is not None:
             self.native.set_model(*self.ctx.model_tables())
