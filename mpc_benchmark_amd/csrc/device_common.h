@@ -194,6 +194,26 @@ DEV void log6(const M3& R, V3 p, V3& v, V3& w) {
 }
 
 // x (+) alpha*dx for either state space.  Multibody: q = [p, quat(xyzw), joints], free-flyer at the root.
+// the same by a group of threads (t0 of nt): the elementwise part in parallel, the free-flyer pose by thread 0
+DEV void state_integrate_group(int space, int nx, int n, const double* x, const double* dx, double alpha, double* out, int t0, int nt) {
+  if (space == MPC_SPACE_VECTOR) {
+    for (int i = t0; i < nx; i += nt) out[i] = x[i] + alpha * dx[i];
+    return;
+  }
+  const int nv = n / 2, nq = nx - nv;
+  for (int i = 6 + t0; i < nv; i += nt) out[i + 1] = x[i + 1] + alpha * dx[i];
+  for (int i = t0; i < nv; i += nt) out[nq + i] = x[nq + i] + alpha * dx[nv + i];
+  if (t0 == 0) {
+    const M3 R = quat_to_rot(x + 3);
+    M3 dR;
+    V3 dp;
+    exp6(v3(alpha * dx[0], alpha * dx[1], alpha * dx[2]), v3(alpha * dx[3], alpha * dx[4], alpha * dx[5]), dR, dp);
+    const V3 p = v3(x[0], x[1], x[2]) + mul(R, dp);
+    out[0] = p.x; out[1] = p.y; out[2] = p.z;
+    rot_to_quat(mul(R, dR), out + 3);
+  }
+}
+
 DEV void state_integrate(int space, int nx, int n, const double* x, const double* dx, double alpha, double* out) {
   if (space == MPC_SPACE_VECTOR) {
     for (int i = 0; i < nx; ++i) out[i] = x[i] + alpha * dx[i];

@@ -13,6 +13,13 @@ DEV TermRec load_term(const int32_t* desc, int t) {
   return r;
 }
 
+DEV TermRec lds_term(const int* w0, int t) {  // the same record from an LDS copy of the term table
+  const int* w = w0 + MPC_TERM_WORDS * t;
+  TermRec r;
+  r.type = w[0]; r.role = w[1]; r.dim = w[2]; r.i0 = w[3]; r.i1 = w[4]; r.poff = w[5]; r.woff = w[6]; r.flags = w[7];
+  return r;
+}
+
 // Add 1/2 r^T W r (and, when derivs, J^T W r and J^T W J) of one cost term.  r[dim], J[dim][ldj] in LDS,
 // Wr/WJ are LDS scratch (dim and dim*ldj doubles).  `cost` is accumulated by thread 0 only.
 DEV void accumulate_cost(const Layout& L, double* kn, const TermRec& t, const double* W, const double* r, const double* J, int ldj,
@@ -58,8 +65,11 @@ DEV void emit_constraint(const Layout& L, double* kn, const TermRec& t, const do
     kn[L.oLO + row0 + i] = (t.role == MPC_ROLE_BOX) ? params[t.woff + i] : 0.0;
     kn[L.oHI + row0 + i] = (t.role == MPC_ROLE_BOX) ? params[t.woff + t.dim + i] : 0.0;
   }
-  if (derivs)
-    for (int idx = tid; idx < t.dim * nzk; idx += nthr) kn[L.oCD + (row0 + idx / nzk) * L.nz + idx % nzk] = J[(idx / nzk) * ldj + idx % nzk];
+  if (derivs) {
+    const int lane = tid & 63, wv = tid >> 6, nw = nthr >> 6;  // a row per wavefront: coalesced, no index divisions
+    if (nw > 0) { for (int i = wv; i < t.dim; i += nw) for (int z = lane; z < nzk; z += 64) kn[L.oCD + (size_t)(row0 + i) * L.nz + z] = J[i * ldj + z]; }
+    else for (int idx = tid; idx < t.dim * nzk; idx += nthr) kn[L.oCD + (row0 + idx / nzk) * L.nz + idx % nzk] = J[(idx / nzk) * ldj + idx % nzk];
+  }
   __syncthreads();
 }
 
@@ -96,14 +106,15 @@ DEV void knot_merit(const Layout& L, double* kn, int c, const double* f, const d
       prim = fmax(prim, fabs(f[i]));
     }
   }
-  // deterministic reduction: fixed thread order
-  red[tid] = pen;
-  red[nt + tid] = prim;
+  // deterministic reduction: DPP tree inside each wavefront, then the (at most 4) wavefront partials in order
+  pen = wave_sum(pen);
+  prim = wave_max_nonneg(prim);
+  if ((tid & 63) == 0) { red[tid >> 6] = pen; red[8 + (tid >> 6)] = prim; }
   }
   __syncthreads();
   if (tid == 0) {
     double p = 0, q = 0;
-    for (int i = 0; i < nt; ++i) { p += red[i]; q = fmax(q, red[nt + i]); }
+    for (int i = 0; i < (nt >> 6); ++i) { p += red[i]; q = fmax(q, red[8 + i]); }
     pen_out = p; prim_out = q;
   }
   __syncthreads();

@@ -264,6 +264,8 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   double* se3 = sm + S.se3;
   double* JL = JS + 32 * nz;
   double* wrs = red + 256;  // sqrt(W) r of the stacked rows
+  int* lterm = (int*)(small + 184);  // term records of the stage (24 x MPC_TERM_WORDS ints): read once, coalesced, instead of
+                                     // a chain of dependent global loads in every term loop
 
   const int32_t* mi = a.model_i;
   const double* md = a.model_d;
@@ -286,8 +288,8 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     if (TRIAL == 2) {
       for (int i = tid; i < nx; i += nthr) { x[i] = xs[i]; xn[i] = xs[i]; }  // simulated state ; xn = xs[0], the feedback reference
     } else if (TRIAL) {
-      if (tid == 0) state_integrate(MPC_SPACE_MULTIBODY, nx, n, xs, dx, alpha, x);
-      if (tid == 64 && k < N) state_integrate(MPC_SPACE_MULTIBODY, nx, n, xs + nx, dx + n, alpha, xn);
+      if (wv == 0) state_integrate_group(MPC_SPACE_MULTIBODY, nx, n, xs, dx, alpha, x, lane, 64);
+      if (wv == 1 && k < N) state_integrate_group(MPC_SPACE_MULTIBODY, nx, n, xs + nx, dx + n, alpha, xn, lane, 64);
     } else {
       for (int i = tid; i < nx; i += nthr) { x[i] = xs[i]; if (k < N) xn[i] = xs[nx + i]; }
     }
@@ -296,6 +298,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
       const double* du = a.dus + ((size_t)b * N + k) * nu;
       for (int i = tid; i < nu; i += nthr) u[i] = us[i] + (TRIAL ? alpha * du[i] : 0.0);
     }
+    for (int i = tid; i < nterms * MPC_TERM_WORDS; i += nthr) lterm[i] = desc[MPC_STAGE_HEADER_WORDS + i];
     // tree tables; the bit masks (model constants) were built on the host by mpc_set_model
     const unsigned long long* gmask = (const unsigned long long*)(a.model_i + L.model_mask_off);
     for (int i = tid; i < nj; i += nthr) {
@@ -835,7 +838,7 @@ sim_loop:
   if (wv >= 2 && lane == 0) {
     int slot = 0;
     for (int t = 0; t < nterms; ++t) {
-      const TermRec tr = load_term(desc, t);
+      const TermRec tr = lds_term(lterm, t);
       const bool se3_state = tr.type == MPC_TERM_STATE_ERROR && tr.i0 < 6;
       if (!se3_state && tr.type != MPC_TERM_FRAME_PLACEMENT) continue;
       const int my = slot++;
@@ -968,7 +971,7 @@ sim_loop:
   if (tid == 0) {
     int rows = 0, chunk = 0, se3n = 0, dense = 0, nst = 0;
     for (int t = 0; t < nterms; ++t) {
-      const TermRec tr = load_term(desc, t);
+      const TermRec tr = lds_term(lterm, t);
       const bool se3t = tr.type == MPC_TERM_FRAME_PLACEMENT || (tr.type == MPC_TERM_STATE_ERROR && tr.i0 < 6);
       tse3[t] = se3t ? se3n++ : 0;
       const bool diag_sel = (tr.type == MPC_TERM_STATE_ERROR || tr.type == MPC_TERM_CONTROL_ERROR) && (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT);
@@ -987,6 +990,7 @@ sim_loop:
     tmeta[0] = nst ? chunk + 1 : 0; tmeta[1] = dense;
   }
   __syncthreads();
+  EV_PROF(29);
 
   // residual entry ri of x_ref (-) x : base rows from the SE(3) table, joint rows in closed form
   auto state_res = [&](const double* tp, const double* sl, int ri) -> double {
@@ -1117,7 +1121,7 @@ sim_loop:
     int row = 0;
     double* r = red + 2 * 256 - 64;
     for (int t = 0; t < nterms; ++t) {
-      const TermRec tr = load_term(desc, t);
+      const TermRec tr = lds_term(lterm, t);
       if (tkind[t] != 0) continue;
       const double* tp = P + tr.poff;
       const double* sl = se3 + 48 * tse3[t];
@@ -1126,7 +1130,12 @@ sim_loop:
       if (tr.type == MPC_TERM_STATE_ERROR && is_cost) {
         const double* W = P + tr.woff;
         const double* Jb = sl + 8;
-        if (tid == 0) { double cst = 0; for (int i = 0; i < d; ++i) { const double e = state_res(tp, sl, tr.i0 + i); cst += W[i] * e * e; } tcost[t] = 0.5 * cst; }
+        if (wv == 0) {  // cost value: one wavefront, DPP reduction (a single thread walking d residuals costs ~15 us)
+          double cst = 0;
+          for (int i = lane; i < d; i += 64) { const double e = state_res(tp, sl, tr.i0 + i); cst += W[i] * e * e; }
+          cst = wave_sum(cst);
+          if (lane == 0) tcost[t] = 0.5 * cst;
+        }
         if (derivs) {
           for (int z = tid; z < n; z += nthr) {
             double g = 0;
@@ -1144,7 +1153,12 @@ sim_loop:
         __syncthreads();
       } else if (tr.type == MPC_TERM_CONTROL_ERROR && is_cost) {
         const double* W = P + tr.woff;
-        if (tid == 0) { double cst = 0; for (int i = 0; i < d; ++i) { const double e = u[tr.i0 + i] - tp[tr.i0 + i]; cst += W[i] * e * e; } tcost[t] = 0.5 * cst; }
+        if (wv == nw - 1) {
+          double cst = 0;
+          for (int i = lane; i < d; i += 64) { const double e = u[tr.i0 + i] - tp[tr.i0 + i]; cst += W[i] * e * e; }
+          cst = wave_sum(cst);
+          if (lane == 0) tcost[t] = 0.5 * cst;
+        }
         if (derivs) for (int i = tid; i < d; i += nthr) {
           const int z = n + tr.i0 + i;
           gacc[z] += W[i] * (u[tr.i0 + i] - tp[tr.i0 + i]);
@@ -1162,7 +1176,7 @@ sim_loop:
         }
         const int zc0 = st_ ? tr.i0 : n + tr.i0;
         const double sgn = st_ ? -1.0 : 1.0;
-        if (derivs) for (int idx = tid; idx < d * nz; idx += nthr) kn[KL.oCD + (size_t)(row + idx / nz) * KL.nz + idx % nz] = ((idx % nz) == zc0 + idx / nz) ? sgn : 0.0;
+        if (derivs) for (int i = wv; i < d; i += nw) for (int z = lane; z < nz; z += 64) kn[KL.oCD + (size_t)(row + i) * KL.nz + z] = (z == zc0 + i) ? sgn : 0.0;
       } else {
         term_rows(tr, tp, sl, r, JL, tid, nthr, true);
         emit_constraint(KL, kn, tr, P, row, r, JL, nz, nz, derivs, tid, nthr);
@@ -1179,7 +1193,7 @@ sim_loop:
     int rowc = 0, ord = 0;
     for (int t = 0; t < nterms; ++t) {
       if (tkind[t] != 1 || tchunk[t] != ch) continue;
-      const TermRec tr = load_term(desc, t);
+      const TermRec tr = lds_term(lterm, t);
       const int d = tr.dim;
       if (trow[t] + d > rowc) rowc = trow[t] + d;
       if ((ord++ % nw) != wv) continue;
@@ -1188,7 +1202,11 @@ sim_loop:
       term_rows(tr, P + tr.poff, se3 + 48 * tse3[t], r, Jt, lane, 64, false);
       const double* W = P + tr.woff;
       const int wstride = (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) ? 1 : d + 1;
-      if (lane == 0) { double cst = 0; for (int i = 0; i < d; ++i) cst += W[i * wstride] * r[i] * r[i]; tcost[t] = 0.5 * cst; }
+      {
+        double cst = (lane < d) ? W[lane * wstride] * r[lane] * r[lane] : 0.0;  // d <= 24
+        cst = wave_sum(cst);
+        if (lane == 0) tcost[t] = 0.5 * cst;
+      }
       if (derivs) {
         if (lane < d) wrs[trow[t] + lane] = sqrt(W[lane * wstride]) * r[lane];
         for (int idx = lane; idx < d * nz; idx += 64) Jt[idx] *= sqrt(W[(idx / nz) * wstride]);
@@ -1242,7 +1260,7 @@ sim_loop:
     double* r = red + 2 * 256 - 64;
     for (int t = 0; t < nterms; ++t) {
       if (tkind[t] != 2) continue;
-      const TermRec tr = load_term(desc, t);
+      const TermRec tr = lds_term(lterm, t);
       term_rows(tr, P + tr.poff, se3 + 48 * tse3[t], r, JS, tid, nthr, true);
       if (derivs) for (int idx = tid; idx < tr.dim * nz; idx += nthr) JtG[idx] = JS[idx];
       __syncthreads();

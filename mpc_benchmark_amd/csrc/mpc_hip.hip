@@ -183,6 +183,7 @@ static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_des
   if (n_desc < MPC_STAGE_HEADER_WORDS || n_desc < MPC_STAGE_HEADER_WORDS + MPC_TERM_WORDS * desc[5]) throw std::runtime_error("stage descriptor truncated");
   if (desc[6] > L.c) throw std::runtime_error("stage has more constraint rows than nc_max");
   int nc = 0, nse3 = 0;
+  if (s->dims.space == MPC_SPACE_MULTIBODY && desc[5] > 24) throw std::runtime_error("more than 24 terms in one stage (whole-body kernel's LDS term table)");
   for (int t = 0; t < desc[5]; ++t) {
     const int32_t* w = desc + MPC_STAGE_HEADER_WORDS + MPC_TERM_WORDS * t;
     if (w[1] != MPC_ROLE_COST) nc += w[2];

@@ -390,6 +390,24 @@ DEV double wave_sum(double v) {
   const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+template <int CTRL, int ROW_MASK>
+DEV double dpp_max(double v) {  // v >= 0 (infeasibility measures): lanes without a source read 0
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(bits & 0xffffffffll), CTRL, ROW_MASK, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(bits >> 32), CTRL, ROW_MASK, 0xf, true);
+  return fmax(v, __longlong_as_double(((long long)hi << 32) | (unsigned int)lo));
+}
+DEV double wave_max_nonneg(double v) {
+  v = dpp_max<0x111, 0xf>(v);
+  v = dpp_max<0x112, 0xf>(v);
+  v = dpp_max<0x114, 0xf>(v);
+  v = dpp_max<0x118, 0xf>(v);
+  v = dpp_max<0x142, 0xa>(v);
+  v = dpp_max<0x143, 0xc>(v);
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(bits >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 // 16 wavefronts per instance: the sweep is a chain of latency-bound mat-vecs, more waves = more HBM loads in flight
 __global__ void __launch_bounds__(1024) k_forward(SolverArgs a) {
   const Layout& L = a.L;
@@ -683,7 +701,7 @@ __global__ void k_accept(SolverArgs a) {
   double* x = a.xs + ((size_t)b * (N + 1) + k) * nx;
   const double* dx = a.dxs + ((size_t)b * (N + 1) + k) * n;
   __shared__ double xn[160];
-  if (tid == 0) state_integrate(L.space, nx, n, x, dx, alpha, xn);
+  state_integrate_group(L.space, nx, n, x, dx, alpha, xn, tid, nthr);
   __syncthreads();
   for (int i = tid; i < nx; i += nthr) x[i] = xn[i];
   double* v = a.vs + ((size_t)b * (N + 1) + k) * L.c;

@@ -34,7 +34,8 @@ print('RIC  total %.1f us/knot ; series: max rho %.3e, mean terms %.2f, Cholesky
     tot / knots / (GHZ * 1e3), p[20], p[21] / knots, p[22] / knots))
 ev = {0: 'load, FK, joint columns', 1: 'velocities, inertias, composites, U', 2: 'M, bias, contact frames, Jc, Y16', 3: 'chol M (blocked, MFMA)',
       5: 'Y, S, multipliers, accelerations', 6: 'forces at the solution', 7: 'derivative building blocks', 8: 'right-hand sides R1, R2',
-      9: 'implicit differentiation (blocked solves)', 10: 'SE(3) pre-pass, integrator, [A B]', 12: 'merit, projections'}
+      9: 'implicit differentiation (blocked solves)', 10: 'SE(3) pre-pass, integrator, [A B]', 29: 'term table: classification, accumulator reset',
+      11: 'dense-weight terms, cost sum', 12: 'merit, projections'}
 terms = {1: 'state_error', 2: 'control_error', 3: 'frame_placement', 4: 'frame_translation', 5: 'frame_velocity', 6: 'com_translation',
          7: 'centroidal_momentum', 8: 'contact_force', 9: 'mb_wrench_cone', 10: 'centroidal_wrench_cone', 13: 'centroidal_momentum_der'}
 e = p[32:]
