@@ -29,6 +29,7 @@
 #define RIC_WAVES_ATTR
 #endif
 #define RIC_MAX_SERIES 8
+#define RIC_SERIES_TOL 1e-14  // truncation of the series relative to Pt (the products themselves round at ~n eps)
 
 // phase timing (shader clock) accumulated over the knots; read back with mpc_debug_get("ric_prof")
 // The sweep is one long loop over the knots with ~15 phases per knot; left alone, the compiler hoists every per-lane
@@ -113,6 +114,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   constexpr int AB_ROWS = (NPMAX + NWV - 1) / NWV;                                // register prefetch capacity: rows of [A B] per wavefront
   constexpr int RIC_SERIES_TILES = (NBMAX * (NBMAX + 1) / 2 + NWV - 1) / NWV;     // lower-triangle output tiles per wavefront
   constexpr int RIC_G_TILES = (NBMAX * NZTMAX + NWV - 1) / NWV;                   // tiles of G per wavefront
+  constexpr int RIC_U_TILES = NPMAX > 16 ? 2 : 1;  // lower-triangle tiles of the u rows of Hh a wavefront can keep in registers
   const Layout& L = a.L;
   const int b = blockIdx.x, nthr = blockDim.x, nw = nthr >> 6;
   int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // re-derived at every phase boundary (RIC_LAUNDER)
@@ -122,6 +124,8 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   const int np = S.np, ldp = S.np + 1, mp = S.mp, nzp = S.nzp, ldl = S.ldl, ldr = S.ldr, nb = S.nb, nbm = S.nbm, nzt = nzp / 16, lw = S.lw, nwb = S.nwb;
   const double mu = st.mu, mud = mu * a.opt.dyn_al_scale;
   const bool ff = L.space == MPC_SPACE_MULTIBODY;
+  // u rows of Hh straight from registers into the KKT operands (step 5 / 6) when every wavefront can hold its share
+  const bool ureg = S.gfull && (nzt * (nzt + 1) / 2 - nb * (nb + 1) / 2) <= RIC_U_TILES * nw;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *PT = sm + S.PT, *LP = sm + S.LP, *LI = sm + S.LI, *AB = sm + S.AB, *GP = sm + S.GP, *vec = sm + S.vec;
   double *Lr = sm + S.Lr, *LIr = sm + S.LIr, *W = sm + S.W, *CTl = sm + S.CT, *VXl = sm + S.VX, *Yl = sm + S.Y, *SCl = sm + S.SC, *LIs = sm + S.LIs;
@@ -238,11 +242,11 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     }
     __syncthreads();
     RIC_PROF(1);
-    // ---- 2. LP = Ph, ||Ph||_F ; vv = Ph ft + ph ----
+    // ---- 2. ||Ph||_F ; vv = Ph ft + ph ----
     {
       double ss = 0;
       for (int i = wv; i < np; i += nw)
-        for (int j = lane; j < np; j += 64) { const double pv = PT[i * ldp + j]; LP[i * ldl + j] = pv; ss += pv * pv; }
+        for (int j = lane; j < np; j += 64) { const double pv = PT[i * ldp + j]; ss += pv * pv; }
       ss = wave_sum_r(ss);
       if (lane == 0) wred[wv] = ss;
     }
@@ -264,8 +268,8 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       for (int q = 0; q < nw; ++q) fro += wred[q];
       const double rho = mud * sqrt(fro);
       double rem = rho;
-      while (rem > 1e-16 && nser < RIC_MAX_SERIES) { rem *= rho; ++nser; }
-      if (rem > 1e-16) nser = -1;
+      while (rem > RIC_SERIES_TOL && nser < RIC_MAX_SERIES) { rem *= rho; ++nser; }
+      if (rem > RIC_SERIES_TOL) nser = -1;
       if (tid == 0 && a.prof) {
         double* pr = a.prof + (size_t)b * 64;
         pr[20] = fmax(pr[20], rho); pr[21] += (nser >= 0) ? nser : 0; pr[22] += (nser < 0) ? 1.0 : 0.0;
@@ -273,6 +277,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     }
     // [A B] of this knot: issue the HBM loads here (the series below hides their latency), park them in
     // registers, drop them into LDS in step 4
+    RIC_PROF(17);
     double abr[AB_ROWS][2];
     {
       // column of [A B] behind padded column zp (x columns 0..n-1, u columns np..np+m-1), clamped to a valid one so
@@ -285,18 +290,98 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       for (int q = 0; q < AB_ROWS; ++q) {
         const int i = wv + nw * q;  // wave-uniform row
         const double* src = ab0 + (size_t)(i < n ? i : 0) * nz;
+        // mask by multiplication: with a select the compiler makes the load itself conditional (branch + s_waitcnt
+        // vmcnt(0) per row: the 12 rows of a wavefront were fetched one after the other, 4 us per knot)
         const double v0 = src[c0], v1 = src[c1];
-        abr[q][0] = (ok0 && i < n) ? v0 : 0.0;
-        abr[q][1] = (ok1 && i < n) ? v1 : 0.0;
+        abr[q][0] = v0 * ((ok0 && i < n) ? 1.0 : 0.0);
+        abr[q][1] = v1 * ((ok1 && i < n) ? 1.0 : 0.0);
       }
     }
+    RIC_PROF(18);
     if (k > 0) prefetch_small(k - 1);  // consumed at the top of the next iteration
     RIC_PROF(13);
-    if (nser >= 0) {
-      // ---- 3a. series: every iterate is a polynomial in the symmetric Ph, hence symmetric — only the lower block
-      // triangle of 16x16 tiles is computed (dealt round-robin to the wavefronts) and mirrored on the way out;
+    if (nser >= 0 && nser <= 7) {
+      // ---- 3a. series sum_{i <= nser} (-X)^i Ph, X = mu_d Ph, as a product of factors instead of nser Horner steps:
+      //   nser <= 1:  Pt = Ph - mu_d Q,  Q = Ph^2                                  1 product
+      //   nser <= 3:  T = Ph - mu_d Q ;  Pt = T + mu_d^2 T Q                       2 products  (I - X)(I + X^2)
+      //   nser <= 7:  ... ;              Pt = Pt + mu_d^4 Pt Q^2                   4 products  (I - X)(I + X^2)(I + X^4)
+      // Every factor is a polynomial in the symmetric Ph: only the lower block triangle of 16x16 tiles is computed
+      // (dealt round-robin to the wavefronts) and mirrored on the way out.  Q, then Q^2, live in LP; Ph is never copied.
+      const int ntile = nb * (nb + 1) / 2;
+      d4_t res[RIC_SERIES_TILES];
+      int tri[RIC_SERIES_TILES], tcj[RIC_SERIES_TILES];
+#pragma unroll
+      for (int sidx = 0; sidx < RIC_SERIES_TILES; ++sidx) {
+        const int t = wv + sidx * nw;
+        int ri = 0, rem = t;
+        while (rem > ri) { rem -= ri + 1; ++ri; }  // t = ri (ri + 1) / 2 + cj, cj <= ri
+        tri[sidx] = ri; tcj[sidx] = rem;
+      }
+      auto products = [&](const double* Am, const double* Bm) {  // both with leading dimension np + 1
+#pragma unroll
+        for (int sidx = 0; sidx < RIC_SERIES_TILES; ++sidx) {
+          res[sidx] = d4_t{0, 0, 0, 0};
+          if (wv + sidx * nw < ntile) mma_tile<false>(res[sidx], Am + (tri[sidx] * 16) * ldp, ldp, 1, Bm + tcj[sidx] * 16, ldp, 1, np, lane);
+        }
+      };
+      // PT <- PT + sc * res (pt) ; LP <- res (lp): own tile and its mirror image
+      auto update = [&](bool pt, double sc, bool lp) {
+#pragma unroll
+        for (int sidx = 0; sidx < RIC_SERIES_TILES; ++sidx) {
+          if (wv + sidx * nw < ntile) {
+            const int r0 = tri[sidx] * 16 + (lane >> 4), c0 = tcj[sidx] * 16 + (lane & 15);
+            const bool offd = tri[sidx] != tcj[sidx];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int r = r0 + 4 * q;
+              const double rv = res[sidx][q];
+              if (lp) { LP[r * ldp + c0] = rv; if (offd) LP[c0 * ldp + r] = rv; }
+              if (pt) { const double v = PT[r * ldp + c0] + sc * rv; PT[r * ldp + c0] = v; if (offd) PT[c0 * ldp + r] = v; }
+            }
+          }
+        }
+      };
+      if (nser >= 1) {
+        products(PT, PT);  // Q = Ph Ph
+        RIC_PROF(14);
+        __syncthreads();   // PT is overwritten below: every wavefront must be done reading it
+        RIC_PROF(15);
+        update(true, -mud, nser >= 2);   // PT <- Ph - mu_d Q ; LP <- Q
+        __syncthreads();
+        RIC_PROF(16);
+      }
+      if (nser >= 2) {
+        products(PT, LP);  // T Q
+        RIC_PROF(14);
+        __syncthreads();
+        RIC_PROF(15);
+        update(true, mud * mud, false);
+        __syncthreads();
+        RIC_PROF(16);
+      }
+      if (nser >= 4) {
+        products(LP, LP);  // Q^2
+        RIC_PROF(14);
+        __syncthreads();
+        RIC_PROF(15);
+        update(false, 0.0, true);
+        __syncthreads();
+        RIC_PROF(16);
+        products(PT, LP);
+        RIC_PROF(14);
+        __syncthreads();
+        RIC_PROF(15);
+        update(true, mud * mud * mud * mud, false);
+        __syncthreads();
+        RIC_PROF(16);
+      }
+      RIC_PROF(3);
+    } else if (nser >= 0) {
+      // ---- 3a'. longer series: Horner steps T <- Ph - mu_d T Ph on the lower block triangle;
       // products first, barrier, then the in-place update of PT
       const int ntile = nb * (nb + 1) / 2;
+      for (int i = wv; i < np; i += nw) for (int j = lane; j < np; j += 64) LP[i * ldl + j] = PT[i * ldp + j];
+      __syncthreads();
       for (int it = 0; it < nser; ++it) {
         d4_t res[RIC_SERIES_TILES];
         int tri[RIC_SERIES_TILES], tcj[RIC_SERIES_TILES];
@@ -332,7 +417,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     } else {
       // ---- 3b. LP <- I + mud Ph = L L^T ; PT <- (L L^T)^-1 PT ----
       for (int i = wv; i < np; i += nw)
-        for (int j = lane; j < np; j += 64) LP[i * ldl + j] = mud * LP[i * ldl + j] + (i == j ? 1.0 : 0.0);
+        for (int j = lane; j < np; j += 64) LP[i * ldl + j] = mud * PT[i * ldp + j] + (i == j ? 1.0 : 0.0);
       __syncthreads();
       if (!chol_blocked(LP, ldl, nb, LI, tid, iflag)) { if (tid == 0) a.inst[b].done = 2; return; }
       RIC_PROF(3);
@@ -396,13 +481,13 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         }
       }
       __syncthreads();
-      const int nht = nzt * (nzt + 1) / 2;
-      for (int t = wv; t < nht; t += nw) {
+      const int nht = nzt * (nzt + 1) / 2, nxt = nb * (nb + 1) / 2;
+      // one lower-triangle tile (zi, cj) of Hh = H + [A B]^T G
+      auto hh_tile = [&](int t, d4_t& out, int (&zr)[4], int& zc) {
         int zi = 0, cj = t;
         while (cj > zi) { cj -= zi + 1; ++zi; }  // t = zi (zi + 1) / 2 + cj, cj <= zi
         const int col_p = cj * 16 + (lane & 15);
-        const int zc = (col_p < n) ? col_p : ((col_p >= np && col_p - np < m) ? n + col_p - np : -1);
-        int zr[4];
+        zc = (col_p < n) ? col_p : ((col_p >= np && col_p - np < m) ? n + col_p - np : -1);
         double h[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {  // H loads are in flight while the matrix cores work
@@ -414,10 +499,54 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         if (cj < nb) mma_tile<false>(acc, AB + zi * 16, 1, nzp, PT + cj * 16, ldp, 1, np, lane);
         else mma_tile<false>(acc, AB + zi * 16, 1, nzp, GP + (cj - nb) * 16, mp, 1, np, lane);
 #pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = h[q] + acc[q];
+      };
+      // x rows (tiles 0 .. nxt-1): only the value update of step 7 reads them — to the L2-resident scratch
+      for (int t = wv; t < (ureg ? nxt : nht); t += nw) {
+        d4_t hv; int zr[4], zc;
+        hh_tile(t, hv, zr, zc);
+#pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (zr[q] >= 0 && zc >= 0) Hh[zr[q] * nz + zc] = h[q] + acc[q];
+          if (zr[q] >= 0 && zc >= 0) Hh[zr[q] * nz + zc] = hv[q];
+      }
+      // u rows (Sh^T, Ruu): the operands of the stage KKT system.  They stay in registers until [A B] is dead and then go
+      // straight to their LDS places (Lr, W, ST) — reading them back from the scratch cost a chain of L2 round trips.
+      d4_t ures[RIC_U_TILES];
+#pragma unroll
+      for (int sidx = 0; sidx < RIC_U_TILES; ++sidx) {
+        const int t = nxt + wv + sidx * nw;
+        ures[sidx] = d4_t{0, 0, 0, 0};
+        if (ureg && t < nht) {
+          int zr[4], zc;
+          hh_tile(t, ures[sidx], zr, zc);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (zr[q] >= 0 && zc >= 0) Hh[zr[q] * nz + zc] = ures[sidx][q];  // kept for the inertia-correction path
+        }
       }
       __syncthreads();
+      // ---- 6. stage KKT (AB is dead: R1 is reused): Lr = Ruu (lower block triangle, identity padding) ;
+      // W = -[Sh^T | rh] (mp x lw, zero padded) ; ST = Sh^T (mp x np)
+#pragma unroll
+      for (int sidx = 0; sidx < RIC_U_TILES; ++sidx) {
+        const int t = nxt + wv + sidx * nw;
+        if (ureg && t < nht) {
+          int zi = 0, cj = t;
+          while (cj > zi) { cj -= zi + 1; ++zi; }
+          const int col = lane & 15;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = (zi - nb) * 16 + (lane >> 4) + 4 * q;  // u row (padded index)
+            const double v = ures[sidx][q];
+            if (cj < nb) { W[i * lw + cj * 16 + col] = -v; ST[i * np + cj * 16 + col] = v; }
+            else { const int j = (cj - nb) * 16 + col; Lr[i * ldr + j] = (i == j && i >= m) ? 1.0 : v; }
+          }
+        }
+      }
+      if (ureg) for (int idx = tid; idx < mp * 16; idx += nthr) {  // feed-forward column of W and its padding
+        const int i = idx >> 4, cc = idx & 15;
+        W[i * lw + np + cc] = (cc == 0 && i < m) ? -gh[n + i] : 0.0;
+      }
     }
     } else {
     // ---- 5. panels: G_j = Pt AB_j ; Hh[:, j] = H[:, j] + AB^T G_j ----
@@ -463,8 +592,8 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     RIC_PROF(8);
     // ---- 6. stage KKT (AB is dead: R1 is reused) ----
     const bool small_ca = ca <= 16;
-    // Lr = sym(Hh_uu) padded with identity ; W = -[Sh^T | rh] (mp x lw, zero padded) ; ST = Sh^T (mp x np)
-    for (int i = wv; i < mp; i += nw) {
+    // panel path / many u tiles: Lr = sym(Hh_uu) padded with identity ; W = -[Sh^T | rh] (mp x lw, zero padded) ; ST = Sh^T (mp x np)
+    if (!ureg) for (int i = wv; i < mp; i += nw) {
       for (int j = lane; j < mp; j += 64) Lr[i * ldr + j] = (i < m && j < m) ? Hh[(n + (i > j ? i : j)) * nz + n + (i > j ? j : i)] : (i == j ? 1.0 : 0.0);  // lower triangle of Hh_uu
       for (int z = lane; z < lw; z += 64) {
         double sv = 0.0;
@@ -477,13 +606,16 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       // CT = [Ca_x | . | dt | .] (16 x lw) ; Y = Da^T (mp x 16)
       for (int i = wv; i < 16; i += nw)
         for (int z = lane; z < lw; z += 64) {
-          double cv = 0.0;
-          if (i < ca) { if (z < n) cv = kn[L.oCD + act_idx[i] * nz + z]; else if (z == np) cv = kn[L.oDT + act_idx[i]]; }
-          CTl[i * lw + z] = cv;
+          // clamped address, mask by multiplication: the loads of all rows are in flight together (see step 3)
+          const int ai = (i < ca) ? act_idx[i] : 0;
+          const bool isx = z < n, isd = z == np;
+          const double cv = kn[isd ? L.oDT + ai : L.oCD + ai * nz + (isx ? z : 0)];
+          CTl[i * lw + z] = cv * ((i < ca && (isx || isd)) ? 1.0 : 0.0);
         }
       for (int idx = tid; idx < mp * 16; idx += nthr) {
         const int i = idx >> 4, j = idx & 15;
-        Yl[idx] = (i < m && j < ca) ? kn[L.oCD + act_idx[j] * nz + n + i] : 0.0;
+        const int aj = (j < ca) ? act_idx[j] : 0;
+        Yl[idx] = kn[L.oCD + aj * nz + n + (i < m ? i : 0)] * ((i < m && j < ca) ? 1.0 : 0.0);
       }
     }
     __syncthreads();

@@ -22,7 +22,7 @@ for _ in range(TICKS):
     ens.step()
 p = ens.native.debug_get('ric_prof', 0)
 GHZ = 2.4
-ric = {0: 'T6 inverse, active-row scan', 1: 'T6 similarity transform of P', 2: 'Ph copy, Frobenius norm, vv', 13: 'series length',
+ric = {0: 'T6 inverse, active-row scan', 1: 'T6 similarity transform of P', 2: 'Ph copy, Frobenius norm, vv', 17: 'series length', 18: '[A B] prefetch issue', 13: 'small-vector prefetch issue',
        14: 'series: tile products', 15: 'series: barrier wait', 16: 'series: in-place update', 3: 'chol n (fallback only)',
        5: 'triangular solves (fallback only)', 6: 'AB prefetch issue, w, store Pt', 7: 'AB to LDS, gh', 8: 'G = Pt [A B], Hh = H + [A B]^T G',
        9: 'KKT operands', 10: 'chol m', 11: 'KKT solve (active rows), gains', 12: 'value function, store gain record'}
