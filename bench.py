@@ -199,7 +199,7 @@ def main():
         if os.path.exists(tf):
             with open(tf) as fh:
                 kk = json.load(fh).get("kernels", {})
-            ent = kk.get(rocprof_name) or kk.get("void %s<512>" % rocprof_name) or {}
+            ent = kk.get(rocprof_name) or next((v for k_, v in kk.items() if rocprof_name in k_), {})  # template kernels: "void name<...>"
             if "hbm_bytes" in ent:
                 traffic = int(ent["hbm_bytes"])
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -17,6 +17,12 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -o cf -- tools/
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -o cw -- tools/pmc/pmc_calib > $OUT/cal_write.log 2>&1
 python3 tools/pmc/summarize.py $OUT/traffic.json $OUT/pmc_fetch $OUT/pmc_write $OUT/cal_fetch $OUT/cal_write 1073741824 > $OUT/traffic.log 2>&1
 tail -n 60 $OUT/traffic.log
+python3 tools/overlap_report.py $(find $OUT/stats -name '*kernel_trace.csv' | head -1) 0.08 > $OUT/overlap_report.txt 2>&1
+python3 tools/overlap_report.py $(find $OUT/stats -name '*kernel_trace.csv' | head -1) 0.08 chain | tail -20 >> $OUT/overlap_report.txt 2>&1
+python3 bench.py --streams 1 --no-cpu-baseline > $OUT/bench_streams1.log 2>&1
+python3 bench.py --batch 256 --no-cpu-baseline --no-latency > $OUT/bench_batch256.log 2>&1
+python3 tools/phase_timers.py > $OUT/phase_timers.txt 2>&1
+tools/pmc/sq_counters.sh $OUT/sq > $OUT/sq_counters.txt 2>&1
 # the raw per-dispatch CSVs are large: keep only the summaries
 find $OUT -name '*counter_collection.csv' -size +2M -delete
 find $OUT -name '*kernel_trace.csv' -size +8M -delete
