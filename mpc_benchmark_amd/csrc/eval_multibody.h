@@ -1139,14 +1139,14 @@ sim_loop:
         if (derivs) {
           for (int z = tid; z < n; z += nthr) {
             double g = 0;
-            if (z < 6) { for (int i = 0; i < d; ++i) { const int ri = tr.i0 + i; if (ri < 6) g += Jb[6 * ri + z] * W[i] * sl[ri]; } }
+            if (z < 6) { for (int i = 0; i < d && tr.i0 + i < 6; ++i) { const int ri = tr.i0 + i; g += Jb[6 * ri + z] * W[i] * sl[ri]; } }  // base rows only
             else if (z >= tr.i0 && z < tr.i0 + d) { g = -W[z - tr.i0] * state_res(tp, sl, z); hdg[z] += W[z - tr.i0]; }
             gacc[z] += g;
           }
           for (int idx = tid; idx < 36; idx += nthr) {
             const int za = idx / 6, zb = idx % 6;
             double h = 0;
-            for (int i = 0; i < d; ++i) { const int ri = tr.i0 + i; if (ri < 6) h += Jb[6 * ri + za] * W[i] * Jb[6 * ri + zb]; }
+            for (int i = 0; i < d && tr.i0 + i < 6; ++i) { const int ri = tr.i0 + i; h += Jb[6 * ri + za] * W[i] * Jb[6 * ri + zb]; }
             hbb[idx] += h;
           }
         }
