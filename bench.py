@@ -206,6 +206,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_kernel_ms": round(total_ms / launches, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "shards_in_flight": nshard,  # one launch serves one shard; the shards' launches overlap on the device
+                # supplementary, per GPU: the algorithmic bytes of ALL launches of this kernel in the timed region over the
+                # length of the region (what the kernel moves per second of wall time, shards and other kernels included)
+                "achieved_over_timed_region": round(bytes_per_launch * launches / (elapsed * 1e9), 2),
                 "warmup_kernel_ms_per_step_summed_over_shards": {k: round(v[1] / max(1, args.warmup), 4) for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])}}
 
     mfma = None
