@@ -1,0 +1,75 @@
+/*
+ * mpc_qp_abi.h — C-ABI of the batched dense QP solver ("next" row N3 of SURVEY.md §8f).
+ *
+ * What this replaces on the reference side: `proxsuite.proxqp.dense.QP` as QP_utils.py uses it (PrimalDualLDLT backend)
+ *     qp = proxsuite.proxqp.dense.QP(n, neq, nin, box, ...); qp.settings.eps_abs / max_iter / max_iter_in      QP_utils.py:500-507, 651-658
+ *     qp.init(H, g, A, b, C, l, u[, l_box, u_box])                                                              QP_utils.py:508, 659
+ *     qp.update(A=..., b=..., C=..., l=...[, H=..., g=...]); qp.solve(); qp.results.x                          QP_utils.py:556-567, 736-752
+ * for the whole-body inverse-dynamics QPs of the 1 kHz loop (IDSolver_ulim :437-575, IKIDSolver_f6 :584-762):
+ *     min 1/2 x^T H x + g^T x   s.t.  A x = b,   l <= C x <= u,   l_box <= x <= u_box
+ * with n = 2 nv - 6 + 6 nk (62 for the 28-dof model), neq = nv + 6 nk (40), nin = 9 nk (18).
+ *
+ * One handle solves B independent QPs of the same shape per call (B robots, one QP each): plain pointers and sizes, every
+ * array with a leading batch dimension, row-major float64.  Exported by the same two libraries as mpc_abi.h
+ * (libmpc_hip.so: one workgroup per QP on the GPU; libmpc_oracle.so: CPU restatement, test infrastructure only).
+ *
+ * Algorithm (both libraries): proximal augmented Lagrangian in the ProxQP family — outer bound-constrained-Lagrangian loop
+ * on (mu_eq, mu_in) with proximal weight rho on x; the inner problem (convex, piecewise quadratic, C^1) by semismooth
+ * Newton on the active inequality rows with an exact line search; every Newton system
+ *     [ H + rho I + C_I^T C_I / mu_in (+ active box rows / mu_in)    A^T      ] [dx]
+ *     [ A                                                          -mu_eq I  ] [y+]
+ * by Cholesky of the primal block and of the Schur complement on the equality rows.
+ */
+#ifndef MPC_QP_ABI_H
+#define MPC_QP_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpc_qp_solver mpc_qp_solver; /* opaque */
+
+typedef struct mpc_qp_dims {
+  int32_t batch, n, neq, nin;
+  int32_t box;     /* 1: l_box <= x <= u_box present (QP(n, neq, nin, True)) */
+  int32_t device;  /* HIP device ordinal (oracle: ignored) */
+} mpc_qp_dims;
+
+typedef struct mpc_qp_settings {
+  double eps_abs;           /* qp.settings.eps_abs (1e-3 in QP_utils.py)                                   */
+  double rho;               /* proximal weight on x              (proxsuite default 1e-6)                  */
+  double mu_eq, mu_in;      /* initial penalty parameters        (proxsuite defaults 1e-3, 1e-1)           */
+  double mu_min_eq, mu_min_in; /* lower bounds of the BCL updates (1e-9, 1e-8)                             */
+  double mu_update_factor;  /* 0.1                                                                          */
+  double alpha_bcl, beta_bcl; /* 0.1, 0.9                                                                   */
+  int32_t max_iter;         /* outer iterations  (qp.settings.max_iter)                                     */
+  int32_t max_iter_in;      /* Newton iterations per outer iteration (qp.settings.max_iter_in)              */
+  int32_t warm_start;       /* 1: start from the handle's previous solution, 0: from zero                   */
+  int32_t reserved;
+} mpc_qp_settings;
+
+typedef struct mpc_qp_info {
+  double prim_res, dual_res;  /* inf-norms at the returned point */
+  double mu_eq, mu_in;
+  int32_t iters, iters_in;    /* outer iterations, Newton steps in total */
+  int32_t status;             /* 0 solved to eps_abs, 1 iteration limit, 2 factorisation failed */
+  int32_t n_active;           /* active inequality + box rows at the solution */
+} mpc_qp_info;
+
+int mpc_qp_create(const mpc_qp_dims* dims, mpc_qp_solver** out);
+void mpc_qp_destroy(mpc_qp_solver* s);
+const char* mpc_qp_last_error(mpc_qp_solver* s);
+void mpc_qp_default_settings(mpc_qp_settings* out);
+/* Solve B QPs.  H[B][n][n] (symmetric), g[B][n], A[B][neq][n], b[B][neq], C[B][nin][n], l[B][nin], u[B][nin],
+ * l_box / u_box [B][n] (ignored unless dims.box).  Outputs x[B][n], y[B][neq], z[B][nin], z_box[B][n] (may be NULL),
+ * info[B].  Sign convention of the multipliers: H x + g + A^T y + C^T z + z_box = 0, z_i > 0 on an active upper bound. */
+int mpc_qp_solve(mpc_qp_solver* s, const mpc_qp_settings* settings, const double* H, const double* g, const double* A, const double* b,
+                 const double* C, const double* l, const double* u, const double* l_box, const double* u_box,
+                 double* x, double* y, double* z, double* z_box, mpc_qp_info* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
