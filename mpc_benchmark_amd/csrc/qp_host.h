@@ -1,0 +1,108 @@
+// qp_host.h — host side of the batched QP solver (include/mpc_qp_abi.h) for the HIP library; included by mpc_hip.hip.
+#pragma once
+#include "qp_kernel.h"
+
+struct mpc_qp_solver {
+  mpc_qp_dims d{};
+  hipStream_t stream = nullptr;
+  QpLds lds{};
+  double *dH = nullptr, *dg = nullptr, *dA = nullptr, *db = nullptr, *dC = nullptr, *dl = nullptr, *du = nullptr, *dlb = nullptr, *dub = nullptr;
+  double *dx = nullptr, *dy = nullptr, *dz = nullptr;
+  mpc_qp_info* dinfo = nullptr;
+  std::vector<void*> allocs;
+  std::string err;
+  template <class T> T* alloc(size_t count) {
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, (count ? count : 1) * sizeof(T)));
+    HIP_OK(hipMemsetAsync(p, 0, (count ? count : 1) * sizeof(T), stream));
+    allocs.push_back(p);
+    return (T*)p;
+  }
+};
+
+extern "C" {
+
+int mpc_qp_create(const mpc_qp_dims* dims, mpc_qp_solver** out) {
+  if (!dims || !out) return -2;
+  if (dims->batch <= 0 || dims->n <= 0 || dims->neq < 0 || dims->nin < 0) return -2;
+  mpc_qp_solver* s = new mpc_qp_solver();
+  try {
+    s->d = *dims;
+    HIP_OK(hipSetDevice(dims->device));
+    HIP_OK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    const size_t B = dims->batch, n = dims->n, neq = dims->neq, nin = dims->nin, m = nin + (dims->box ? n : 0);
+    s->lds = make_qp_lds(dims->n, dims->neq, (int)m);
+    if (s->lds.total_bytes > 160 * 1024) throw std::runtime_error("QP too large for the LDS of one workgroup (n (n + 1) + n neq + neq (neq + 1) doubles)");
+    s->dH = s->alloc<double>(B * n * n); s->dg = s->alloc<double>(B * n); s->dA = s->alloc<double>(B * neq * n); s->db = s->alloc<double>(B * neq);
+    s->dC = s->alloc<double>(B * nin * n); s->dl = s->alloc<double>(B * nin); s->du = s->alloc<double>(B * nin);
+    s->dlb = s->alloc<double>(B * n); s->dub = s->alloc<double>(B * n);
+    s->dx = s->alloc<double>(B * n); s->dy = s->alloc<double>(B * neq); s->dz = s->alloc<double>(B * m);
+    s->dinfo = s->alloc<mpc_qp_info>(B);
+    HIP_OK(hipFuncSetAttribute((const void*)k_qp_solve, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds.total_bytes));
+    HIP_OK(hipStreamSynchronize(s->stream));
+  } catch (const std::exception& e) {
+    fprintf(stderr, "mpc_qp_create: %s\n", e.what());
+    for (void* p : s->allocs) (void)hipFree(p);
+    delete s;
+    return -1;
+  }
+  *out = s;
+  return 0;
+}
+
+void mpc_qp_destroy(mpc_qp_solver* s) {
+  if (!s) return;
+  (void)hipStreamSynchronize(s->stream);
+  for (void* p : s->allocs) (void)hipFree(p);
+  (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+const char* mpc_qp_last_error(mpc_qp_solver* s) { return s ? s->err.c_str() : "null handle"; }
+void mpc_qp_default_settings(mpc_qp_settings* o) {
+  o->eps_abs = 1e-5; o->rho = 1e-6; o->mu_eq = 1e-3; o->mu_in = 1e-1; o->mu_min_eq = 1e-9; o->mu_min_in = 1e-8;
+  o->mu_update_factor = 0.1; o->alpha_bcl = 0.1; o->beta_bcl = 0.9; o->max_iter = 10000; o->max_iter_in = 1500; o->warm_start = 0; o->reserved = 0;
+}
+
+int mpc_qp_solve(mpc_qp_solver* s, const mpc_qp_settings* S, const double* H, const double* g, const double* A, const double* b,
+                 const double* C, const double* l, const double* u, const double* l_box, const double* u_box,
+                 double* x, double* y, double* z, double* z_box, mpc_qp_info* info) {
+  if (!s) return -2;
+  try {
+    if (!S || !H || !g || !x || !info) throw std::runtime_error("qp_solve: null argument");
+    const mpc_qp_dims& d = s->d;
+    if (d.box && (!l_box || !u_box)) throw std::runtime_error("qp_solve: box bounds missing");
+    if ((d.neq && (!A || !b)) || (d.nin && (!C || !l || !u))) throw std::runtime_error("qp_solve: constraint data missing");
+    const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin, m = nin + (d.box ? n : 0);
+    auto up = [&](double* dst, const double* src, size_t cnt) { if (cnt) HIP_OK(hipMemcpyAsync(dst, src, cnt * sizeof(double), hipMemcpyHostToDevice, s->stream)); };
+    up(s->dH, H, B * n * n); up(s->dg, g, B * n); up(s->dA, A, B * neq * n); up(s->db, b, B * neq);
+    up(s->dC, C, B * nin * n); up(s->dl, l, B * nin); up(s->du, u, B * nin);
+    if (d.box) { up(s->dlb, l_box, B * n); up(s->dub, u_box, B * n); }
+    if (!S->warm_start) {
+      HIP_OK(hipMemsetAsync(s->dx, 0, B * n * sizeof(double), s->stream));
+      if (neq) HIP_OK(hipMemsetAsync(s->dy, 0, B * neq * sizeof(double), s->stream));
+      if (m) HIP_OK(hipMemsetAsync(s->dz, 0, B * m * sizeof(double), s->stream));
+    }
+    QpArgs a;
+    a.d = d; a.S = *S;
+    a.H = s->dH; a.g = s->dg; a.A = s->dA; a.b = s->db; a.C = s->dC; a.l = s->dl; a.u = s->du; a.lb = s->dlb; a.ub = s->dub;
+    a.x = s->dx; a.y = s->dy; a.z = s->dz; a.info = s->dinfo; a.lds = s->lds;
+    hipLaunchKernelGGL(k_qp_solve, dim3(d.batch), dim3(QP_THREADS), s->lds.total_bytes, s->stream, a);
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipMemcpyAsync(x, s->dx, B * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (y && neq) HIP_OK(hipMemcpyAsync(y, s->dy, B * neq * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    std::vector<double> zh(B * m);
+    if (m) HIP_OK(hipMemcpyAsync(zh.data(), s->dz, B * m * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipMemcpyAsync(info, s->dinfo, B * sizeof(mpc_qp_info), hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    for (size_t bi = 0; bi < B; ++bi) {
+      if (z && nin) std::memcpy(z + bi * nin, zh.data() + bi * m, nin * sizeof(double));
+      if (z_box && d.box) std::memcpy(z_box + bi * n, zh.data() + bi * m + nin, n * sizeof(double));
+    }
+    return 0;
+  } catch (const std::exception& e) {
+    s->err = e.what();
+    return -1;
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,127 @@
+"""Rigid-body quantities the whole-body QPs of the reference read from Pinocchio (QP_utils.py:517-535: ``data.nle``, the
+joint-space inertia ``M``, ``getFrameJacobian`` / ``getFrameJacobianTimeVariation`` / ``getFrameVelocity`` in the LOCAL
+frame), on the duck-typed model of ``minipin`` in plain numpy.  Host-side glue for the N3 row: the hot path computes the same
+quantities inside the stage kernel; this file exists so that the QP classes can be driven and tested without Pinocchio.
+
+World-frame formulation: the motion subspace column of dof k is ``S_k = Ad(oMi) s_k`` at the world origin, velocities and
+accelerations accumulate down the tree, forces back up (recursive Newton-Euler); ``[lin; ang]`` ordering throughout.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import minipin as pin
+
+
+def _crm(v):
+    """motion cross product matrix: (v x) m"""
+    X = np.zeros((6, 6))
+    w, l = pin.skew(v[3:]), pin.skew(v[:3])
+    X[:3, :3] = w; X[:3, 3:] = l; X[3:, 3:] = w
+    return X
+
+
+def _crf(v):
+    """force cross product matrix: v x* f = -(v x)^T f"""
+    return -_crm(v).T
+
+
+def _local_columns(jm):
+    k = jm.shortname()
+    if k == "JointModelFreeFlyer":
+        return np.eye(6)
+    c = np.zeros((6, 1))
+    c[3 + {"JointModelRX": 0, "JointModelRY": 1, "JointModelRZ": 2}[k], 0] = 1.0
+    return c
+
+
+def compute_all_terms(model, data, q, v):
+    """Fills ``data``: oMi / oMf, ``S`` (6 x nv world columns), ``v_w`` / ``a0_w`` (spatial velocity and the velocity-product
+    acceleration of every joint, world frame), ``M`` (nv x nv), ``nle`` (Coriolis + gravity), ``Yw`` (world spatial inertias)."""
+    q = np.asarray(q, dtype=float); v = np.asarray(v, dtype=float)
+    pin.framesForwardKinematics(model, data, q)
+    nj, nv = model.njoints, model.nv
+    S = np.zeros((6, nv))
+    Yw = [np.zeros((6, 6)) for _ in range(nj)]
+    vw = [np.zeros(6) for _ in range(nj)]
+    a0 = [np.zeros(6) for _ in range(nj)]
+    for i in range(1, nj):
+        jm = model.joints[i]
+        Ad = data.oMi[i].action()
+        cols = Ad @ _local_columns(jm)
+        S[:, jm.idx_v:jm.idx_v + jm.nv] = cols
+        Ainv = np.linalg.inv(Ad)
+        Yw[i] = Ainv.T @ model.inertias[i].matrix() @ Ainv
+        p = model.parents[i]
+        vj = cols @ v[jm.idx_v:jm.idx_v + jm.nv]
+        vw[i] = vw[p] + vj
+        a0[i] = a0[p] + _crm(vw[i]) @ vj
+    data.S, data.Yw, data.v_w, data.a0_w = S, Yw, vw, a0
+
+    def rnea(acc, with_velocity, gravity):
+        a = [np.zeros(6) for _ in range(nj)]
+        f = [np.zeros(6) for _ in range(nj)]
+        base = np.zeros(6)
+        if gravity:
+            base[:3] = -np.asarray(model.gravity.linear)
+        for i in range(1, nj):
+            jm = model.joints[i]
+            p = model.parents[i]
+            a[i] = (a[p] if p else base) + S[:, jm.idx_v:jm.idx_v + jm.nv] @ acc[jm.idx_v:jm.idx_v + jm.nv]
+            if with_velocity:
+                a[i] = a[i] + (a0[i] - a0[p])
+            f[i] = Yw[i] @ a[i]
+            if with_velocity:
+                f[i] = f[i] + _crf(vw[i]) @ (Yw[i] @ vw[i])
+        tau = np.zeros(nv)
+        for i in range(nj - 1, 0, -1):
+            jm = model.joints[i]
+            tau[jm.idx_v:jm.idx_v + jm.nv] = S[:, jm.idx_v:jm.idx_v + jm.nv].T @ f[i]
+            p = model.parents[i]
+            if p:
+                f[p] = f[p] + f[i]
+        return tau
+
+    data.nle = rnea(np.zeros(nv), True, True)
+    M = np.zeros((nv, nv))
+    for k in range(nv):
+        e = np.zeros(nv); e[k] = 1.0
+        M[:, k] = rnea(e, False, False)
+    data.M = 0.5 * (M + M.T)
+    return data
+
+
+def _supports(model, joint, dof_joint):
+    """True if ``dof_joint`` is ``joint`` or one of its ancestors."""
+    i = joint
+    while i:
+        if i == dof_joint:
+            return True
+        i = model.parents[i]
+    return False
+
+
+def frame_jacobian_local(model, data, frame_id):
+    """6 x nv Jacobian of the frame velocity expressed in the frame (pin.getFrameJacobian(..., pin.LOCAL))."""
+    f = model.frames[frame_id]
+    Ainv = np.linalg.inv(data.oMf[frame_id].action())
+    J = np.zeros((6, model.nv))
+    for i in range(1, model.njoints):
+        if _supports(model, f.parentJoint, i):
+            jm = model.joints[i]
+            J[:, jm.idx_v:jm.idx_v + jm.nv] = Ainv @ data.S[:, jm.idx_v:jm.idx_v + jm.nv]
+    return J
+
+
+def frame_velocity_local(model, data, frame_id):
+    """pin.getFrameVelocity(model, data, id) (LOCAL): Motion with .linear / .angular"""
+    f = model.frames[frame_id]
+    vl = np.linalg.inv(data.oMf[frame_id].action()) @ data.v_w[f.parentJoint]
+    return pin.Motion(vl[:3], vl[3:])
+
+
+def frame_jdot_v_local(model, data, frame_id):
+    """(dJ/dt) v of the LOCAL frame Jacobian = spatial acceleration of the frame at zero joint acceleration, expressed in the
+    frame (what QP_utils.py multiplies out as ``getFrameJacobianTimeVariation(...) @ v``)."""
+    f = model.frames[frame_id]
+    return np.linalg.inv(data.oMf[frame_id].action()) @ data.a0_w[f.parentJoint]

@@ -90,8 +90,6 @@ static inline void solve_one(const Problem& P, const mpc_qp_settings& S, double*
     if (outer == S.max_iter) break;
     info.iters = outer + 1;
     for (int j = 0; j < n; ++j) xk[j] = x[j];
-    double gprev = 1e300;
-    int stall = 0;
     for (int it = 0; it < S.max_iter_in; ++it) {
       eval(x);
       double gnorm = 0;
@@ -106,10 +104,6 @@ static inline void solve_one(const Problem& P, const mpc_qp_settings& S, double*
         gnorm = std::max(gnorm, std::fabs(t));
       }
       if (gnorm <= inner_tol) break;
-      // round-off floor of the gradient (multipliers of size 1/mu): three steps without halving it end the inner loop
-      stall = (gnorm > 0.5 * gprev) ? stall + 1 : 0;
-      gprev = gnorm;
-      if (stall >= 3) break;
       info.iters_in += 1;
       // primal block
       for (int j = 0; j < n; ++j) for (int k = 0; k <= j; ++k) {
@@ -160,7 +154,9 @@ static inline void solve_one(const Problem& P, const mpc_qp_settings& S, double*
         if (std::fabs(an - alpha) <= 1e-15 * alpha) { alpha = an; break; }
         alpha = an;
       }
-      for (int j = 0; j < n; ++j) x[j] += alpha * dx[j];
+      double stepn = 0, xn = 1.0;
+      for (int j = 0; j < n; ++j) { stepn = std::max(stepn, std::fabs(alpha * dx[j])); xn = std::max(xn, std::fabs(x[j])); x[j] += alpha * dx[j]; }
+      if (stepn <= 1e-14 * xn) break;  // round-off floor (multiplier estimates carry an error of size eps / mu): no further progress
     }
     eval(x);
     double rp_eq = 0, rp_in = 0;

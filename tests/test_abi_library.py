@@ -13,8 +13,8 @@ from mpc_benchmark_amd import _capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "mpc_abi.h")).read()
+def _declared_functions(header="mpc_abi.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(mpc_[a-z0-9_]+)\s*\(", text)))
 
@@ -52,3 +52,15 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_capi.MpcDims) == 10 * 4
     assert ctypes.sizeof(_capi.MpcOptions) == 14 * 8 + 8 * 4
     assert ctypes.sizeof(_capi.MpcStats) == 4 * 4 + 6 * 8
+
+
+def test_qp_abi_is_exported_by_both_libraries(oracle_lib):
+    """include/mpc_qp_abi.h (batched dense QP, N3): same symbols in the product library and in the checker."""
+    from mpc_benchmark_amd import _qp_capi
+    names = _declared_functions("mpc_qp_abi.h")
+    assert names == ["mpc_qp_create", "mpc_qp_default_settings", "mpc_qp_destroy", "mpc_qp_last_error", "mpc_qp_solve"]
+    lib = ctypes.CDLL(_capi.HIP_LIBRARY_PATH)
+    for name in names:
+        assert hasattr(lib, name), "libmpc_hip.so does not export %s" % name
+        assert hasattr(oracle_lib, name)
+    assert ctypes.sizeof(_qp_capi.QpDims) == 6 * 4 and ctypes.sizeof(_qp_capi.QpSettings) == 9 * 8 + 4 * 4 and ctypes.sizeof(_qp_capi.QpInfo) == 4 * 8 + 4 * 4

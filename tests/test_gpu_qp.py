@@ -1,0 +1,75 @@
+"""N3 on the GPU: the batched dense QP kernel through the C-ABI against the oracle on the same problems (inverse-dynamics
+structure of QP_utils.py:437-575, with and without the torque box) and against the KKT conditions directly."""
+import numpy as np
+import pytest
+
+from tests import _oracle, _qp_cases as cases
+from mpc_benchmark_amd import _capi
+from mpc_benchmark_amd._qp_capi import BatchedQP
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(lib, qs, box, eps, max_iter=60, max_iter_in=40):
+    n, neq, nin = qs[0]["H"].shape[0], qs[0]["A"].shape[0], qs[0]["C"].shape[0]
+    qp = BatchedQP(len(qs), n, neq, nin, box=box, library=lib)
+    qp.settings.eps_abs, qp.settings.max_iter, qp.settings.max_iter_in = eps, max_iter, max_iter_in
+    st = lambda k: np.stack([q[k] for q in qs])
+    args = [st(k) for k in ("H", "g", "A", "b", "C", "l", "u")] + ([st("l_box"), st("u_box")] if box else [])
+    return qp.solve(*args)
+
+
+@pytest.mark.parametrize("box", [False, True])
+def test_qp_matches_oracle_and_kkt(box):
+    rng = np.random.default_rng(21)
+    contacts = [(True, True), (True, False), (False, True)]
+    qs = [cases.id_qp(rng, contact=contacts[i % 3], torque_limit=(45.0 if box else None)) for i in range(12)]
+    xh, yh, zh, zbh, ih = _solve(_capi.load_hip_library(), qs, box, 1e-6)
+    xr, yr, zr, zbr, ir = _solve(_oracle.load(), qs, box, 1e-6)
+    for i, q in enumerate(qs):
+        assert ih[i].status == 0 and ir[i].status == 0
+        stat, prim, comp = cases.kkt_residuals(q, xh[i], yh[i], zh[i], zbh[i] if box else None)
+        assert stat < 2e-6 and prim < 2e-6
+        scale = max(1.0, float(np.max(np.abs(xr[i]))))
+        assert np.max(np.abs(xh[i] - xr[i])) / scale < 1e-6  # same algorithm, same path: agreement far below eps_abs
+        assert ih[i].n_active == ir[i].n_active  # (iteration counts may differ by round-off when a pass ends at the tolerance)
+
+
+def test_complete_model_size_and_reference_settings():
+    """nv = 38 (n = 82, neq = 50) with eps_abs = 1e-3, max_iter = 10, max_iter_in = 10 (QP_utils.py:502-507)."""
+    rng = np.random.default_rng(4)
+    qs = [cases.id_qp(rng, nv=38) for _ in range(8)]
+    xh, yh, zh, _, ih = _solve(_capi.load_hip_library(), qs, False, 1e-3, 10, 10)
+    for i, q in enumerate(qs):
+        assert ih[i].status == 0 and ih[i].iters <= 10
+        stat, prim, comp = cases.kkt_residuals(q, xh[i], yh[i], zh[i])
+        assert stat < 2e-3 and prim < 2e-3
+
+
+def test_id_solver_mirror_hip_equals_oracle():
+    """The IDSolver_ulim mirror (QP_utils.py:437-575) on the synthetic Talos: HIP and oracle give the same accelerations,
+    forces and torques; a batch of robots in one launch."""
+    from mpc_benchmark_amd import qp_utils
+    from mpc_benchmark_amd.robot import dynamics as dyn, minipin as pin
+    from mpc_benchmark_amd.robot.talos_synth import load_talos
+    _, model, _, q0 = load_talos()
+    rng = np.random.default_rng(6)
+    ids = [model.getFrameId("left_sole_link"), model.getFrameId("right_sole_link")]
+    w = 9.81 * pin.computeTotalMass(model)
+    items = []
+    for i in range(4):
+        v = rng.normal(size=model.nv) * 0.05
+        q = pin.integrate(model, q0, np.concatenate((np.zeros(6), rng.normal(size=model.nv - 6) * 0.02)))
+        data = dyn.compute_all_terms(model, model.createData(), q, v)
+        a = rng.normal(size=model.nv) * 0.2
+        forces = np.array([5, -3, 0.55 * w, 1, -2, 0, -4, 2, 0.45 * w, 0, 1, 0], dtype=float)
+        items.append((data, [True, True], v, a, forces, data.M))
+    out = {}
+    for name, lib in (("hip", _capi.load_hip_library()), ("ref", _oracle.load())):
+        solver = qp_utils.IDSolver_ulim(model, [1.0, 1e-3], 2, 0.8, 0.1, 0.075, ids, 6, False, library=lib, batch=4)
+        solver.qp.settings.eps_abs, solver.qp.settings.max_iter, solver.qp.settings.max_iter_in = 1e-6, 60, 40
+        out[name] = solver.solve_batch(items)
+        assert all(i.status == 0 for i in solver.last_info)
+    for h, r in zip(out["hip"], out["ref"]):
+        for xh, xr in zip(h, r):
+            assert np.max(np.abs(xh - xr)) / max(1.0, np.max(np.abs(xr))) < 1e-6
