@@ -92,3 +92,70 @@ class IDSolver_ulim:
             _, _, _, a, forces, _ = it
             res.append((a + x[i, :nv], forces + x[i, nv:nv + fs * nk], x[i, nv + fs * nk:].copy()))
         return res
+
+
+class IKIDSolver_f6:
+    """Inverse kinematics + inverse dynamics in one QP (QP_utils.py:584-762, used at centroidal_talos.py:326, 435): unknowns
+    ``x = (a, df, tau)``; tasks in the cost — posture (w0), foot accelerations (w1), centroidal momentum rate (w2), base and
+    torso angular accelerations (w3), force increments (w4), each with PD gains ``K_gains[k] = (Kp, Kd)`` on the task errors —
+    dynamics and contact-acceleration equalities, wrench-cone inequalities and the torque box ``|tau| <= effortLimit``.
+    eps_abs = 1e-3, max_iter = max_iter_in = 100 as in the reference."""
+
+    def __init__(self, model, weights, K_gains, nk, mu, L, W, contact_ids, base_id, torso_id, force_size, verbose=False, library=None, batch=1):
+        self.model, self.weights, self.K_gains, self.nk = model, list(weights), K_gains, nk
+        self.contact_ids, self.base_id, self.torso_id = list(contact_ids), base_id, torso_id
+        self.mu, self.L, self.W, self.force_size = mu, L, W, force_size
+        nv, fs = model.nv, force_size
+        self.n, self.neq, self.nin = 2 * nv - 6 + fs * nk, nv + fs * nk, 9 * nk
+        self.S = np.zeros((nv, nv - 6)); self.S[6:] = np.eye(nv - 6)
+        self.Cmin = wrench_cone_rows(mu, L, W, fs)
+        self.l_box = np.full(self.n, -1e5); self.u_box = np.full(self.n, 1e5)
+        self.l_box[nv + fs * nk:] = -np.asarray(model.effortLimit)[6:]
+        self.u_box[nv + fs * nk:] = np.asarray(model.effortLimit)[6:]
+        self.u = np.full(self.nin, 1e5)
+        self.batch = int(batch)
+        self.qp = BatchedQP(self.batch, self.n, self.neq, self.nin, box=True, library=library)
+        self.qp.settings.eps_abs, self.qp.settings.max_iter, self.qp.settings.max_iter_in = 1e-3, 100, 100
+        self.last_info = None
+
+    def computeMatrice(self, data, cs, v, q_diff, dq_diff, LF_diff, dLF_diff, RF_diff, dRF_diff, base_diff, dbase_diff, torso_diff, dtorso_diff,
+                       forces, dH, M):
+        """-> H, g, A, b, C, l of one robot."""
+        m, nv, fs, nk, w, K = self.model, self.model.nv, self.force_size, self.nk, self.weights, self.K_gains
+        J = [dyn.frame_jacobian_local(m, data, fid) for fid in self.contact_ids]
+        dJv = [dyn.frame_jdot_v_local(m, data, fid) for fid in self.contact_ids]
+        Jb, Jt = dyn.frame_jacobian_local(m, data, self.base_id)[3:], dyn.frame_jacobian_local(m, data, self.torso_id)[3:]
+        dJbv, dJtv = dyn.frame_jdot_v_local(m, data, self.base_id)[3:], dyn.frame_jdot_v_local(m, data, self.torso_id)[3:]
+        H = np.zeros((self.n, self.n)); g = np.zeros(self.n)
+        Haa = w[0] * np.eye(nv) + w[1] * (J[0].T @ J[0] + J[1].T @ J[1]) + w[2] * data.Ag.T @ data.Ag + w[3] * (Jb.T @ Jb + Jt.T @ Jt)
+        H[:nv, :nv] = Haa
+        H[nv:nv + fs * nk, nv:nv + fs * nk] = np.eye(fs * nk) * w[4]
+        ga = w[0] * (-K[0][0] @ q_diff - K[0][1] @ dq_diff)
+        ga = ga + w[1] * (dJv[0] - K[1][0] @ LF_diff - K[1][1] @ dLF_diff) @ J[0]
+        ga = ga + w[1] * (dJv[1] - K[1][0] @ RF_diff - K[1][1] @ dRF_diff) @ J[1]
+        ga = ga - w[2] * (dH - data.dAg_v) @ data.Ag
+        ga = ga + w[3] * (dJbv - K[3][0] @ base_diff - K[3][1] @ dbase_diff) @ Jb
+        ga = ga + w[3] * (dJtv - K[3][0] @ torso_diff - K[3][1] @ dtorso_diff) @ Jt
+        g[:nv] = ga
+        A = np.zeros((self.neq, self.n)); b = np.zeros(self.neq)
+        A[:nv, :nv] = M; A[:nv, nv + fs * nk:] = -self.S
+        b[:nv] = -data.nle
+        C = np.zeros((self.nin, self.n)); l = np.zeros(self.nin)
+        for i in range(nk):
+            if cs[i]:
+                A[:nv, nv + fs * i:nv + fs * (i + 1)] = -J[i].T
+                A[nv + fs * i:nv + fs * (i + 1), :nv] = J[i]
+                b[:nv] += J[i].T @ forces[fs * i:fs * (i + 1)]
+                b[nv + fs * i:nv + fs * (i + 1)] = -dJv[i]
+                l[9 * i:9 * (i + 1)] = -self.Cmin @ forces[fs * i:fs * (i + 1)]
+                C[9 * i:9 * (i + 1), nv + fs * i:nv + fs * (i + 1)] = self.Cmin
+        return H, g, A, b, C, l
+
+    def solve(self, data, cs, v, q_diff, dq_diff, LF_diff, dLF_diff, RF_diff, dRF_diff, base_diff, dbase_diff, torso_diff, dtorso_diff, forces, dH, M):
+        """-> (a_new, new_forces, torque) as QP_utils.py:736-762 (the acceleration itself is an unknown here)."""
+        mats = self.computeMatrice(data, cs, v, q_diff, dq_diff, LF_diff, dLF_diff, RF_diff, dRF_diff, base_diff, dbase_diff, torso_diff, dtorso_diff,
+                                   forces, dH, M)
+        x, y, z, zb, info = self.qp.solve(*[np.broadcast_to(a, (self.batch,) + a.shape) for a in mats], self.u, self.l_box, self.u_box)
+        self.last_info = info
+        nv, fs, nk = self.model.nv, self.force_size, self.nk
+        return x[0, :nv].copy(), forces + x[0, nv:nv + fs * nk], x[0, nv + fs * nk:].copy()

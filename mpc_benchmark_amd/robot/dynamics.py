@@ -37,7 +37,8 @@ def _local_columns(jm):
 
 def compute_all_terms(model, data, q, v):
     """Fills ``data``: oMi / oMf, ``S`` (6 x nv world columns), ``v_w`` / ``a0_w`` (spatial velocity and the velocity-product
-    acceleration of every joint, world frame), ``M`` (nv x nv), ``nle`` (Coriolis + gravity), ``Yw`` (world spatial inertias)."""
+    acceleration of every joint, world frame), ``M`` (nv x nv), ``nle`` (Coriolis + gravity), ``Yw`` (world spatial inertias),
+    ``Ag`` / ``dAg_v`` (centroidal momentum matrix and (dAg/dt) v)."""
     q = np.asarray(q, dtype=float); v = np.asarray(v, dtype=float)
     pin.framesForwardKinematics(model, data, q)
     nj, nv = model.njoints, model.nv
@@ -83,6 +84,23 @@ def compute_all_terms(model, data, q, v):
         return tau
 
     data.nle = rnea(np.zeros(nv), True, True)
+    # centroidal momentum matrix Ag (6 x nv, [lin; ang] about the CoM, world axes) and its drift (dAg/dt) v: momentum of the
+    # subtree below each dof at the world origin, moved to the CoM; drift = net force of the zero-acceleration motion
+    mtot = sum(Y.mass for Y in model.inertias[1:])
+    com = sum(Y.mass * data.oMi[i].act(Y.lever) for i, Y in enumerate(model.inertias) if i) / mtot
+    Yc = [Y.copy() for Y in Yw]
+    for i in range(nj - 1, 0, -1):
+        if model.parents[i]:
+            Yc[model.parents[i]] = Yc[model.parents[i]] + Yc[i]
+    Ao = np.zeros((6, nv)); fo = np.zeros(6)
+    for i in range(1, nj):
+        jm = model.joints[i]
+        Ao[:, jm.idx_v:jm.idx_v + jm.nv] = Yc[i] @ S[:, jm.idx_v:jm.idx_v + jm.nv]
+        fo += Yw[i] @ a0[i] + _crf(vw[i]) @ (Yw[i] @ vw[i])
+    cx = pin.skew(com)
+    data.Ag = np.vstack((Ao[:3], Ao[3:] - cx @ Ao[:3]))
+    data.dAg_v = np.concatenate((fo[:3], fo[3:] - cx @ fo[:3]))
+    data.com[0] = com
     M = np.zeros((nv, nv))
     for k in range(nv):
         e = np.zeros(nv); e[k] = 1.0

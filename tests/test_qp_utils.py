@@ -72,3 +72,41 @@ def test_id_solver_end_to_end_on_the_oracle():
     forces1 = np.array([0, 0, w, 0, 0, 0, 0, 0, 0, 0, 0, 0], dtype=float)
     a1, f1, tau1 = solver.solve(data, [True, False], v, a, forces1, data.M)
     assert solver.last_info[0].status == 0 and np.allclose(f1[6:], 0.0, atol=1e-6)
+
+
+def test_centroidal_momentum_matrix_and_drift():
+    model, q0 = _model()
+    rng = np.random.default_rng(3)
+    v = rng.normal(size=model.nv) * 0.3
+    d = dyn.compute_all_terms(model, model.createData(), q0, v)
+    e = 1e-6
+    d2 = dyn.compute_all_terms(model, model.createData(), pin.integrate(model, q0, v * e), v)
+    assert np.allclose((d.Ag @ v)[:3], pin.computeTotalMass(model) * (d2.com[0] - d.com[0]) / e, atol=1e-4)  # linear momentum = m c'
+    assert np.allclose((d2.Ag @ v - d.Ag @ v) / e, d.dAg_v, atol=1e-4)                                       # (dAg/dt) v
+
+
+def test_ikid_solver_end_to_end_on_the_oracle():
+    model, q0 = _model()
+    rng = np.random.default_rng(4)
+    v = rng.normal(size=model.nv) * 0.02
+    data = dyn.compute_all_terms(model, model.createData(), q0, v)
+    ids = [model.getFrameId("left_sole_link"), model.getFrameId("right_sole_link")]
+    nv = model.nv
+    Kp, Kd = 100.0, 20.0
+    gains = [(np.eye(nv) * Kp, np.eye(nv) * Kd), (np.eye(6) * Kp, np.eye(6) * Kd), None, (np.eye(3) * Kp, np.eye(3) * Kd)]
+    solver = qp_utils.IKIDSolver_f6(model, [1.0, 100.0, 1.0, 10.0, 1e-3], gains, 2, 0.8, 0.1, 0.075, ids, model.getFrameId("base_link"),
+                                    model.getFrameId("torso_2_link"), 6, False, library=_oracle.load())
+    w = 9.81 * pin.computeTotalMass(model)
+    forces = np.array([0, 0, 0.5 * w, 0, 0, 0, 0, 0, 0.5 * w, 0, 0, 0], dtype=float)
+    z3, z6, zn = np.zeros(3), np.zeros(6), np.zeros(nv)
+    q_diff = np.concatenate((np.zeros(6), rng.normal(size=nv - 6) * 0.01))
+    a, f, tau = solver.solve(data, [True, True], v, q_diff, zn, z6, z6, z6, z6, z3, z3, z3, z3, forces, np.zeros(6), data.M)
+    assert solver.last_info[0].status == 0
+    Jc = np.vstack([dyn.frame_jacobian_local(model, data, i) for i in ids])
+    S = np.zeros((nv, nv - 6)); S[6:] = np.eye(nv - 6)
+    assert np.max(np.abs(data.M @ a + data.nle - S @ tau - Jc.T @ f)) < 5e-3                   # dynamics
+    drift = np.concatenate([dyn.frame_jdot_v_local(model, data, i) for i in ids])
+    assert np.max(np.abs(Jc @ a + drift)) < 5e-3                                                # feet do not accelerate
+    for i in range(2):
+        assert np.min(solver.Cmin @ f[6 * i:6 * i + 6]) > -5e-3                                 # wrench cone
+    assert np.all(np.abs(tau) <= np.asarray(model.effortLimit)[6:] + 5e-3)                      # torque box
