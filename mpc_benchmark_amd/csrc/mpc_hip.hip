@@ -163,6 +163,10 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   o.num_threads = 1; o.riccati_legs = 1; o.forward_mode = 0;
   HIP_OK(hipFuncSetAttribute((const void*)k_riccati_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   s->ric = make_ric_lds(L.n, L.m, L.c, 1);
+  if (s->ric.total_bytes > 160 * 1024 && ((L.n + 15) & ~15) * ((L.m + 15) & ~15) <= L.n * L.n) {
+    s->ric = make_ric_lds(L.n, L.m, L.c, 2);                                         // whole G, its u part in the L2 scratch (large m)
+    if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 2, 0);
+  }
   if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0);     // panel-wise G when the whole G does not fit
   if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0, 0);  // large m: Sh^T out of LDS as well
   s->cl = make_cl_lds(L.n, L.m);

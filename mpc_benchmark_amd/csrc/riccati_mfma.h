@@ -49,7 +49,8 @@ struct RicLds {
 static inline RicLds make_ric_lds(int n, int m, int c, int gfull = 1, int st_lds = 1) {
   RicLds s;
   s.st_lds = st_lds;  // 0: Sh^T (mp x np) lives in the L2-resident per-instance scratch instead of LDS (large m)
-  s.gfull = gfull;  // 1: G = Pt [A B] kept whole (x part over PT, u part in GP) — needs np x mp doubles for GP instead of np x 16
+  s.gfull = gfull;  // 1: G = Pt [A B] kept whole (x part over PT, u part in GP) — needs np x mp doubles for GP instead of np x 16 ;
+                    // 2: whole G with its u part in the L2-resident scratch (large m: only the few Ruu tiles read it back)
   s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.ldl = s.np + 1; s.ldr = s.mp + 1;
   s.nb = s.np / 16; s.nbm = s.mp / 16;
   s.lw = s.np + 16;  // W = [K | pad | k | pad]: x-columns at 0..n-1, the feed-forward column at np
@@ -61,7 +62,7 @@ static inline RicLds make_ric_lds(int n, int m, int c, int gfull = 1, int st_lds
   s.LP = take(s.np * s.ldl); s.LI = take(s.nb * 272);             // phase 1 view of R1
   const int end1 = o;
   o = s.R1;
-  s.AB = take(s.np * s.nzp); s.GP = take(s.np * (gfull ? s.mp : 16));               // phase 2 view (overlaps phase 1)
+  s.AB = take(s.np * s.nzp); s.GP = take(gfull == 1 ? s.np * s.mp : (s.np * 16 > 8 * s.nzp ? s.np * 16 : 8 * s.nzp));               // phase 2 view (overlaps phase 1)
   const int end2 = o;
   o = s.R1;                                                         // phase 3 view (overlaps AB)
   s.Lr = take(s.mp * s.ldr); s.LIr = take(s.nbm * 272); s.W = take(s.mp * s.lw); s.ST = take(st_lds ? s.mp * s.np : 0);
@@ -140,6 +141,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   double* wk = a.work + (size_t)b * L.work_stride;
   double* Hh = wk + L.wHh;  // nz x nz, leading dimension nz (L2-resident scratch)
   double* ST = S.st_lds ? sm + S.ST : wk + L.wG;  // Sh^T (mp x np)
+  double* GU = (S.gfull == 2) ? wk + L.wPt : GP;   // G_u (np x mp)
 
   // ---- terminal node: P_N = H + Ca^T Ca / mu ; p_N = grad + Ca^T dt / mu ----
   {
@@ -477,7 +479,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         if (t < ngt) {
           const int ri = t / nzt, cj = t % nzt;
           if (cj < nb) tile_store(PT + (ri * 16) * ldp + cj * 16, ldp, gres[sidx], lane);
-          else tile_store(GP + (ri * 16) * mp + (cj - nb) * 16, mp, gres[sidx], lane);
+          else tile_store(GU + (ri * 16) * mp + (cj - nb) * 16, mp, gres[sidx], lane);
         }
       }
       __syncthreads();
@@ -497,7 +499,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         }
         d4_t acc = d4_t{0, 0, 0, 0};
         if (cj < nb) mma_tile<false>(acc, AB + zi * 16, 1, nzp, PT + cj * 16, ldp, 1, np, lane);
-        else mma_tile<false>(acc, AB + zi * 16, 1, nzp, GP + (cj - nb) * 16, mp, 1, np, lane);
+        else mma_tile<false>(acc, AB + zi * 16, 1, nzp, GU + (cj - nb) * 16, mp, 1, np, lane);
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[q] = h[q] + acc[q];
       };
