@@ -638,7 +638,7 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
     else if (nm == "p") mat(g.data() + L.op, 1, n, n);
     else if (nm == "K") mat(g.data() + L.oK, m, n, n);
     else if (nm == "kff") mat(g.data() + L.ok, 1, m, m);
-    else if (nm == "Knu") mat(g.data() + L.oKnu, c, n, n);
+    else if (nm == "Knu") { for (int i = 0; i < c; ++i) if (kn[L.oACT + i] == 0.0) for (int z = 0; z < n; ++z) g[L.oKnu + i * n + z] = 0.0; mat(g.data() + L.oKnu, c, n, n); }  // inactive rows are not written by the sweep
     else if (nm == "knu") mat(g.data() + L.oknu, 1, c, c);
     else if (nm == "Mx") mat(g.data() + L.oMx, k < L.N ? n : 0, n, n);
     else if (nm == "mx") mat(g.data() + L.omx, 1, k < L.N ? n : 0, n);

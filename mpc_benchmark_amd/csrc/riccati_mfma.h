@@ -724,7 +724,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       for (int z = lane; z < n; z += 64) g[L.oK + i * n + z] = W[i * lw + z];
       if (lane == 0) g[L.ok + i] = W[i * lw + np];
     }
-    for (int idx = tid; idx < c * n; idx += nthr) g[L.oKnu + idx] = 0.0;
+    // rows of Knu of inactive constraints are left as they are: k_duals reads Knu only where the knot's active flag is set
     for (int i = tid; i < c; i += nthr) g[L.oknu + i] = 0.0;
     __syncthreads();
     if (small_ca) {

@@ -597,7 +597,8 @@ __global__ void __launch_bounds__(256) k_duals(SolverArgs a) {
   for (int i = wv; i < L.c; i += nw) {
     if (i >= c) { if (lane == 0) dv[i] = 0.0; continue; }
     double s = 0, jd = 0;
-    for (int z = lane; z < n; z += 64) s += g[L.oKnu + i * n + z] * dz[z];
+    if (kn[L.oACT + i] != 0.0)  // the sweep writes the dual gains of active rows only (inactive: dv = -v)
+      for (int z = lane; z < n; z += 64) s += g[L.oKnu + i * n + z] * dz[z];
     for (int z = lane; z < n + m; z += 64) jd += kn[L.oCD + i * nz + z] * dz[z];
     s = wave_sum(s) + g[L.oknu + i];
     jd = wave_sum(jd);

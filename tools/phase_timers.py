@@ -7,12 +7,15 @@ from mpc_benchmark_amd.ensemble import EnsembleMPC
 from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
 
 lib = _capi.bind_library(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].endswith(".so") else _capi.load_hip_library()
-if "centroidal" in sys.argv[1:]:
+if "kino" in sys.argv[1:]:
+    from mpc_benchmark_amd.problems.kinodynamic import KinodynamicProblem
+    pd = KinodynamicProblem(horizon=100, complete_model=True)
+elif "centroidal" in sys.argv[1:]:
     from mpc_benchmark_amd.problems.centroidal import CentroidalProblem
     pd = CentroidalProblem(horizon=100)
 else:
     pd = FullDynamicsProblem(horizon=100, complete_model=True)
-ens = EnsembleMPC(pd, batch=4, library=lib)
+ens = EnsembleMPC(pd, batch=4, library=lib, **({'perturb_dofs': range(18, pd.nv), 'seed': 7} if 'kino' in sys.argv[1:] else {}))
 ens.prepare_schedule(10)
 ens.cold_solve(100)
 ens.native.profile(3)  # in-kernel phase timers on
