@@ -11,13 +11,17 @@
 
 #define QP_THREADS 256
 
-struct QpLds { int P, Y, S, vec, total_bytes; };
-static inline QpLds make_qp_lds(int n, int neq, int m) {
+struct QpLds { int P, Y, S, vec, H, A, C, mats, total_bytes; };  // mats = 1: H, A, C are staged in LDS too
+static inline QpLds make_qp_lds(int n, int neq, int nin, int m, bool want_mats = true) {
   QpLds s;
   int o = 0;
   auto take = [&](int c) { int r = o; o += (c + 1) & ~1; return r; };
   s.P = take(n * (n + 1)); s.Y = take(n * (neq + 1)); s.S = take(neq * (neq + 1));
   s.vec = take(9 * n + 6 * neq + 4 * m + 64);
+  const int base = o;
+  s.H = take(n * n); s.A = take(neq * n); s.C = take(nin * n);
+  s.mats = (want_mats && o * 8 <= 160 * 1024) ? 1 : 0;
+  if (!s.mats) o = base;
   s.total_bytes = o * 8;
   return s;
 }
@@ -95,18 +99,29 @@ DEV bool qp_chol(double* M, int n, int ld, int* flag, int tid) {
   return true;
 }
 
+template <bool MATS>
 __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
   const int bi = blockIdx.x, tid = threadIdx.x, nthr = QP_THREADS;
   const int n = a.d.n, neq = a.d.neq, nin = a.d.nin, box = a.d.box, m = nin + (box ? n : 0);
   const mpc_qp_settings& S = a.S;
-  const double* H = a.H + (size_t)bi * n * n; const double* g = a.g + (size_t)bi * n;
-  const double* A = a.A + (size_t)bi * neq * n; const double* b = a.b + (size_t)bi * neq;
-  const double* C = a.C + (size_t)bi * nin * n; const double* l = a.l + (size_t)bi * nin; const double* u = a.u + (size_t)bi * nin;
+  const double* Hg = a.H + (size_t)bi * n * n; const double* g = a.g + (size_t)bi * n;
+  const double* Ag = a.A + (size_t)bi * neq * n; const double* b = a.b + (size_t)bi * neq;
+  const double* Cg = a.C + (size_t)bi * nin * n; const double* l = a.l + (size_t)bi * nin; const double* u = a.u + (size_t)bi * nin;
   const double* lb = box ? a.lb + (size_t)bi * n : nullptr; const double* ub = box ? a.ub + (size_t)bi * n : nullptr;
   double* xg = a.x + (size_t)bi * n; double* yg = a.y + (size_t)bi * neq; double* zg = a.z + (size_t)bi * m;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int ldp = n + 1, lds_ = neq + 1, ldy = neq + 1;
   double *Pm = sm + a.lds.P, *Y = sm + a.lds.Y, *Sm = sm + a.lds.S, *v = sm + a.lds.vec;
+  // H, A, C: LDS copies when they fit (MATS; every mat-vec below then runs on LDS), else the global arrays (H through its
+  // symmetric image so that neighbouring threads read neighbouring addresses)
+  const double* H = MATS ? sm + a.lds.H : Hg;
+  const double* A = MATS ? sm + a.lds.A : Ag;
+  const double* C = MATS ? sm + a.lds.C : Cg;
+  if (MATS) {
+    for (int i = tid; i < n * n; i += nthr) sm[a.lds.H + i] = Hg[i];
+    for (int i = tid; i < neq * n; i += nthr) sm[a.lds.A + i] = Ag[i];
+    for (int i = tid; i < nin * n; i += nthr) sm[a.lds.C + i] = Cg[i];
+  }
   double *x = v, *xk = x + n, *grad = xk + n, *r1 = grad + n, *dx = r1 + n, *w = dx + n, *hx = w + n, *hd = hx + n, *tmpn = hd + n;
   double *y = tmpn + n, *ye = y + neq, *yplus = ye + neq, *Ax = yplus + neq, *Ad = Ax + neq, *tmpe = Ad + neq;
   double *z = tmpe + neq, *zp = z + m, *s = zp + m, *ds = s + m;
@@ -139,7 +154,7 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
     for (int r = tid; r < m; r += nthr) { const double sr = row_dot(r, x); rp = fmax(rp, fmax(sr - hi(r), lo(r) - sr)); }
     for (int j = tid; j < n; j += nthr) {
       double t = g[j];
-      for (int k = 0; k < n; ++k) t += H[j * n + k] * x[k];
+      for (int k = 0; k < n; ++k) t += H[k * n + j] * x[k];
       for (int i = 0; i < neq; ++i) t += A[i * n + j] * y[i];
       for (int r = 0; r < nin; ++r) t += C[r * n + j] * z[r];
       if (box) t += z[nin + j];
@@ -158,7 +173,7 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
       double gn = 0;
       for (int j = tid; j < n; j += nthr) {
         double t = g[j] + S.rho * (x[j] - xk[j]);
-        for (int k = 0; k < n; ++k) t += H[j * n + k] * x[k];
+        for (int k = 0; k < n; ++k) t += H[k * n + j] * x[k];
         hx[j] = t;  // H x + g + rho (x - xk): reused by the line search
         for (int r = 0; r < nin; ++r) t += C[r * n + j] * zp[r];
         if (box) t += zp[nin + j];
@@ -215,27 +230,33 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
       double pa0 = 0, pa1 = 0, pe0 = 0, pe1 = 0;
       for (int j = tid; j < n; j += nthr) {
         double t = S.rho * dx[j];
-        for (int k = 0; k < n; ++k) t += H[j * n + k] * dx[k];
+        for (int k = 0; k < n; ++k) t += H[k * n + j] * dx[k];
         pa0 += dx[j] * hx[j]; pa1 += dx[j] * t;
       }
       for (int i = tid; i < neq; i += nthr) { double t = 0; for (int j = 0; j < n; ++j) t += A[i * n + j] * dx[j]; pe0 += t * ye[i]; pe1 += t * t / mu_eq; }
       const double lin = qp_block_sum(pa0 + pe0, red, tid), quad = qp_block_sum(pa1 + pe1, red, tid);
-      double alpha = 1.0, lo_a = 0.0, hi_a = -1.0;
-      for (int ls = 0; ls < 40; ++ls) {
-        double pf = 0, pc = 0;
-        for (int r = tid; r < m; r += nthr) {
-          const double zr = qp_zplus(z[r], s[r] + alpha * ds[r], lo(r), hi(r), mu_in);
-          if (zr != 0.0) { pf += ds[r] * zr; pc += ds[r] * ds[r] / mu_in; }
+      // root of the increasing piecewise-linear phi' by ONE wavefront (safeguarded Newton; no workgroup barrier per trial)
+      if (tid < 64) {
+        double alpha = 1.0, lo_a = 0.0, hi_a = -1.0;
+        for (int ls = 0; ls < 40; ++ls) {
+          double pf = 0, pc = 0;
+          for (int r = tid; r < m; r += 64) {
+            const double zr = qp_zplus(z[r], s[r] + alpha * ds[r], lo(r), hi(r), mu_in);
+            if (zr != 0.0) { pf += ds[r] * zr; pc += ds[r] * ds[r] / mu_in; }
+          }
+          const double f = lin + alpha * quad + wave_sum(pf);
+          const double curv = quad + wave_sum(pc);
+          if (fabs(f) <= 1e-13 * (fabs(lin) + 1.0)) break;
+          if (f < 0) lo_a = alpha; else hi_a = alpha;
+          double an = alpha - f / curv;
+          if (an <= lo_a || (hi_a > 0 && an >= hi_a)) an = (hi_a > 0) ? 0.5 * (lo_a + hi_a) : 2.0 * alpha;
+          if (fabs(an - alpha) <= 1e-15 * alpha) { alpha = an; break; }
+          alpha = an;
         }
-        const double f = lin + alpha * quad + qp_block_sum(pf, red, tid);
-        const double curv = quad + qp_block_sum(pc, red, tid);
-        if (fabs(f) <= 1e-13 * (fabs(lin) + 1.0)) break;
-        if (f < 0) lo_a = alpha; else hi_a = alpha;
-        double an = alpha - f / curv;
-        if (an <= lo_a || (hi_a > 0 && an >= hi_a)) an = (hi_a > 0) ? 0.5 * (lo_a + hi_a) : 2.0 * alpha;
-        if (fabs(an - alpha) <= 1e-15 * alpha) { alpha = an; break; }
-        alpha = an;
+        if (tid == 0) red[15] = alpha;
       }
+      __syncthreads();
+      const double alpha = red[15];
       double stepn = 0, xn = 1.0;
       for (int j = tid; j < n; j += nthr) { stepn = fmax(stepn, fabs(alpha * dx[j])); xn = fmax(xn, fabs(x[j])); x[j] += alpha * dx[j]; }
       stepn = qp_block_max(stepn, red, tid);
