@@ -92,7 +92,7 @@ def main():
                 shards[0].step(rescue=True)  # synchronous form: exactly one solver pass per tick
             return
         # One host thread drives all shards round-robin: a tick is enqueued on the shard's stream without waiting, and
-        # completed (stream sync + status read-back) just before that shard's next tick is enqueued.  Shard i starts
+        # completed (event on an asynchronous status read-back) right AFTER that shard's next tick has been enqueued.  Shard i starts
         # i x phase-offset late, so that the sequential Riccati sweep of one shard (few busy CUs) runs beside the per-knot
         # kernels of the others instead of beside their sweeps.  Automatic offset: the first call (warm-up) times one
         # lock-step tick T and uses 0.8 T / shards from then on.
@@ -113,8 +113,8 @@ def main():
             e.step_async()
         for _ in range(count - done_ticks - 1):
             for e in shards:
-                e.wait(rescue=True)
-                e.step_async()
+                e.step_async()         # tick t + 1 goes on the stream first ...
+                e.wait(rescue=True)    # ... then the host looks at tick t: the stream never runs dry
         for e in shards:
             e.wait(rescue=True)
 

@@ -194,9 +194,12 @@ int mpc_run(mpc_solver* s, const double* xs_init, const double* us_init, mpc_sta
 /* Re-run from the solver's own shifted solution: xs <- [xs[1:], xs[-1]], us likewise, xs[0] <- x0
  * (the warm-start shift of fulldynamic_talos.py:532-534 done on the device). */
 int mpc_run_shifted(mpc_solver* s, mpc_stats* stats);
-/* Asynchronous form for pipelining several handles (ensemble shards) on one device: enqueues the shift and the
- * solver passes on the handle's stream and returns without waiting; mpc_wait blocks until the solve has finished
- * (running further passes if an instance needed them) and fills stats[B] (may be NULL). */
+/* Asynchronous form for pipelining several handles (ensemble shards) on one device: enqueues the shift, one solver pass
+ * (max_iters = 1) and an asynchronous status read-back on the handle's stream and returns without waiting.  Up to TWO
+ * ticks may be in flight per handle (enqueue tick t + 1, then wait for tick t: the stream never runs dry).  mpc_wait
+ * completes the OLDEST tick in flight and fills stats[B] (may be NULL); when no younger tick is queued behind it, an
+ * instance whose pass was a BCL update without a step gets its further passes then (as mpc_run_shifted does), otherwise
+ * it carries on in the next tick.  The oracle runs the tick inside mpc_run_shifted_async. */
 int mpc_run_shifted_async(mpc_solver* s);
 int mpc_wait(mpc_solver* s, mpc_stats* stats);
 

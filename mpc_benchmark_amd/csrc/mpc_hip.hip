@@ -50,6 +50,12 @@ struct mpc_solver {
   size_t mb_work_stride = 0;
   bool perfect_feedback = false;
   int async_passes = 0;
+  // asynchronous ticks (mpc_run_shifted_async / mpc_wait): status snapshots in pinned host memory, one event each; up to
+  // ASYNC_DEPTH ticks may be in flight, so that the next tick is already queued while the host looks at the previous one
+  static constexpr int ASYNC_DEPTH = 2;
+  InstState* h_status[ASYNC_DEPTH] = {nullptr, nullptr};
+  hipEvent_t status_ev[ASYNC_DEPTH] = {nullptr, nullptr};
+  int async_head = 0, async_pending = 0;
   RicLds ric{};
   ClLds cl{};
   bool use_mfma_riccati = false;
@@ -281,6 +287,16 @@ static void launch_pass(mpc_solver* s) {
 
 // passes_enqueued: passes already put on the stream by the asynchronous entry point (their completion flag is
 // checked first); the loop then continues synchronously until every instance is done.
+static void report_status(int B, const InstState* st, mpc_stats* stats) {
+  for (int b = 0; b < B; ++b) {
+    if (st[b].done >= 2) throw std::runtime_error("Riccati factorisation failed on instance " + std::to_string(b) + " (code " + std::to_string(st[b].done) + ")");
+    if (!stats) continue;
+    mpc_stats& o = stats[b];
+    o.num_iters = st[b].num_iters; o.converged = st[b].converged; o.al_iters = st[b].al_iters; o.ls_steps = st[b].ls_step;
+    o.traj_cost = st[b].cost; o.merit = st[b].phi0; o.prim_infeas = st[b].prim; o.dual_infeas = st[b].dual; o.mu = st[b].mu; o.alpha = st[b].alpha;
+  }
+}
+
 static void run_impl(mpc_solver* s, mpc_stats* stats, int passes_enqueued = 0) {
   const Layout& L = s->L;
   SolverArgs a = s->args();
@@ -304,13 +320,7 @@ static void run_impl(mpc_solver* s, mpc_stats* stats, int passes_enqueued = 0) {
     }
     if (done != 0) break;
   }
-  for (int b = 0; b < L.B; ++b) {
-    if (st[b].done >= 2) throw std::runtime_error("Riccati factorisation failed on instance " + std::to_string(b) + " (code " + std::to_string(st[b].done) + ")");
-    if (!stats) continue;
-    mpc_stats& o = stats[b];
-    o.num_iters = st[b].num_iters; o.converged = st[b].converged; o.al_iters = st[b].al_iters; o.ls_steps = st[b].ls_step;
-    o.traj_cost = st[b].cost; o.merit = st[b].phi0; o.prim_infeas = st[b].prim; o.dual_infeas = st[b].dual; o.mu = st[b].mu; o.alpha = st[b].alpha;
-  }
+  report_status(L.B, st.data(), stats);
 }
 
 #define MPC_TRY(h, ...)                 \
@@ -346,6 +356,7 @@ void mpc_destroy(mpc_solver* s) {
   if (!s) return;
   (void)hipStreamSynchronize(s->stream);
   for (auto& p : s->prof) for (auto& e : p.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  for (int i = 0; i < mpc_solver::ASYNC_DEPTH; ++i) { if (s->h_status[i]) (void)hipHostFree(s->h_status[i]); if (s->status_ev[i]) (void)hipEventDestroy(s->status_ev[i]); }
   for (void* p : s->allocs) (void)hipFree(p);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -539,21 +550,38 @@ int mpc_run_shifted(mpc_solver* s, mpc_stats* stats) {
 int mpc_run_shifted_async(mpc_solver* s) {
   MPC_TRY(s, {
     const Layout& L = s->L;
+    if (s->async_pending >= mpc_solver::ASYNC_DEPTH) throw std::runtime_error("run_shifted_async: too many ticks in flight (call mpc_wait first)");
+    const int slot = (s->async_head + s->async_pending) % mpc_solver::ASYNC_DEPTH;
+    if (!s->h_status[slot]) {
+      HIP_OK(hipHostMalloc((void**)&s->h_status[slot], L.B * sizeof(InstState), hipHostMallocDefault));
+      HIP_OK(hipEventCreateWithFlags(&s->status_ev[slot], hipEventDisableTiming));
+    }
     hipLaunchKernelGGL(k_shift, dim3(L.B), dim3(64), 0, s->stream, s->args(), s->perfect_feedback ? 1 : 0);
     hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, s->args());
-    // with max_iters = 1 one pass takes the step; mpc_wait runs further passes for the rare instance whose first pass
-    // was a BCL update without a step
+    // with max_iters = 1 one pass takes the step
     launch_pass(s);
-    s->async_passes = 1;
+    HIP_OK(hipMemcpyAsync(s->h_status[slot], s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipEventRecord(s->status_ev[slot], s->stream));
+    s->async_pending += 1;
   })
 }
 
+// Completes the OLDEST tick in flight.  If it is also the only one, an instance whose pass was a BCL update without a
+// step gets its further passes now (as mpc_run_shifted does); with a younger tick already queued behind it the instance
+// simply carries on in that tick.
 int mpc_wait(mpc_solver* s, mpc_stats* stats) {
   MPC_TRY(s, {
-    const int enq = s->async_passes;
-    s->async_passes = 0;
-    if (enq > 0) run_impl(s, stats, enq);
-    else HIP_OK(hipStreamSynchronize(s->stream));
+    const Layout& L = s->L;
+    if (s->async_pending == 0) { HIP_OK(hipStreamSynchronize(s->stream)); return 0; }
+    const int slot = s->async_head;
+    s->async_head = (s->async_head + 1) % mpc_solver::ASYNC_DEPTH;
+    s->async_pending -= 1;
+    HIP_OK(hipEventSynchronize(s->status_ev[slot]));
+    const InstState* st = s->h_status[slot];
+    bool done = true;
+    for (int b = 0; b < L.B; ++b) if (!st[b].done) done = false;
+    if (!done && s->async_pending == 0) run_impl(s, stats, 1);  // continues from pass 1: the enqueued pass 0 is complete
+    else report_status(L.B, st, stats);
   })
 }
 

@@ -135,7 +135,7 @@ class EnsembleMPC:
 
     def step_async(self):
         """Enqueue one tick without waiting (several shards on different streams overlap on the device); ``wait``
-        completes it."""
+        completes the oldest tick in flight.  Two ticks may be in flight: enqueue tick t + 1, then wait for tick t."""
         if self.closed_loop:
             self.native.simulate(*self.closed_loop)
         desc, params = self._table_for_tick(self.tick % self.pd.t_mpc)
@@ -152,6 +152,10 @@ class EnsembleMPC:
             if not rescue or "factorisation failed" not in str(e):
                 raise
             self.rescues = getattr(self, "rescues", 0) + 1
+            try:  # a younger tick may already be queued behind the failed one: let it drain
+                self.native.wait()
+            except RuntimeError:
+                pass
             return self.cold_solve(max_iters=20)
 
     def results(self, **kw):

@@ -32,8 +32,8 @@ def _run(lib, mode, ticks=8, forward_mode=0):
             e.step_async()
         for _ in range(ticks - 1):
             for e in shards:
+                e.step_async()  # two ticks in flight
                 e.wait()
-                e.step_async()
         for e in shards:
             e.wait()
     return np.concatenate([np.concatenate([np.ravel(e.results(gains=False)["xs"]), np.ravel(e.results(gains=False)["us"])]) for e in shards])
