@@ -131,6 +131,27 @@ DEV bool chol16_wave(double* D, int ld, double* LIb, int lane) {
 
 // Blocked Cholesky of the (16 nb) x (16 nb) matrix A in LDS (lower triangle; pad rows/cols must be identity).
 // L overwrites the lower block triangle, LI[bi] (272 doubles each, ld 17) receives the inverse of diagonal block bi.
+// the whole blocked factorisation by ONE wavefront (nb <= 3): its LDS operations execute in order, no workgroup barrier
+DEV bool chol_blocked_wave(double* A, int ld, int nb, double* LI, int lane) {
+  bool ok = true;
+  for (int kb = 0; kb < nb && ok; ++kb) {
+    ok = chol16_wave(A + (kb * 16) * ld + kb * 16, ld, LI + kb * 272, lane);
+    for (int ri = kb + 1; ri < nb; ++ri) {
+      d4_t acc = d4_t{0, 0, 0, 0};
+      mma_tile<false>(acc, A + (ri * 16) * ld + kb * 16, ld, 1, LI + kb * 272, 1, 17, 16, lane);
+      tile_store(A + (ri * 16) * ld + kb * 16, ld, acc, lane);
+    }
+    for (int ri = kb + 1; ri < nb; ++ri)
+      for (int cj = kb + 1; cj <= ri; ++cj) {
+        double* Ct = A + (ri * 16) * ld + cj * 16;
+        d4_t acc = tile_load(Ct, ld, lane);
+        mma_tile<true>(acc, A + (ri * 16) * ld + kb * 16, ld, 1, A + (cj * 16) * ld + kb * 16, 1, ld, 16, lane);
+        tile_store(Ct, ld, acc, lane);
+      }
+  }
+  return ok;
+}
+
 DEV bool chol_blocked(double* A, int ld, int nb, double* LI, int tid, int* flag) {
   const int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
   if (tid == 0) *flag = 1;
@@ -139,22 +160,7 @@ DEV bool chol_blocked(double* A, int ld, int nb, double* LI, int tid, int* flag)
     // small matrices: ONE wavefront runs the whole factorisation — its LDS operations execute in order, so the
     // 3 nb - 1 workgroup barriers (and the idle time around the serial 16x16 steps) of the cooperative form go away
     if (wv == 0) {
-      bool ok = true;
-      for (int kb = 0; kb < nb && ok; ++kb) {
-        ok = chol16_wave(A + (kb * 16) * ld + kb * 16, ld, LI + kb * 272, lane);
-        for (int ri = kb + 1; ri < nb; ++ri) {
-          d4_t acc = d4_t{0, 0, 0, 0};
-          mma_tile<false>(acc, A + (ri * 16) * ld + kb * 16, ld, 1, LI + kb * 272, 1, 17, 16, lane);
-          tile_store(A + (ri * 16) * ld + kb * 16, ld, acc, lane);
-        }
-        for (int ri = kb + 1; ri < nb; ++ri)
-          for (int cj = kb + 1; cj <= ri; ++cj) {
-            double* Ct = A + (ri * 16) * ld + cj * 16;
-            d4_t acc = tile_load(Ct, ld, lane);
-            mma_tile<true>(acc, A + (ri * 16) * ld + kb * 16, ld, 1, A + (cj * 16) * ld + kb * 16, 1, ld, 16, lane);
-            tile_store(Ct, ld, acc, lane);
-          }
-      }
+      const bool ok = chol_blocked_wave(A, ld, nb, LI, lane);
       if (!ok && lane == 0) *flag = 0;
     }
     __syncthreads();

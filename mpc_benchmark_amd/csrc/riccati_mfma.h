@@ -40,7 +40,7 @@
 #define RIC_PROF(slot) do { RIC_LAUNDER(); if (tid == 0 && a.prof) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 struct RicLds {
-  int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb, gfull, st_lds;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
+  int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb, gfull, st_lds, ovl;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
   int PT, R1, LP, LI, AB, GP, vec, iwork, total_bytes;
   // KKT / value-update workspace carved from R1 once AB is dead
   int Lr, LIr, W, ST, CT, VX, Y, SC, LIs;
@@ -67,7 +67,24 @@ static inline RicLds make_ric_lds(int n, int m, int c, int gfull = 1, int st_lds
   o = s.R1;                                                         // phase 3 view (overlaps AB)
   s.Lr = take(s.mp * s.ldr); s.LIr = take(s.nbm * 272); s.W = take(s.mp * s.lw); s.ST = take(st_lds ? s.mp * s.np : 0);
   s.CT = take(16 * s.lw); s.VX = take(16 * s.lw); s.Y = take(s.mp * 16); s.SC = take(16 * 17); s.LIs = take(272);
-  const int end3 = o;
+  int end3 = o;
+  // Overlap layout: Lr / LIr in the G_u region (dead once the Ruu tiles are done) instead of on top of [A B] — the one-wavefront
+  // factorisation of Ruu then runs while the other wavefronts still multiply [A B]^T G_x for the x rows of Hh.  The other
+  // phase-3 operands are written after those tiles and may lie over [A B] and the head of G_u.
+  s.ovl = 0;
+  if (gfull == 1 && s.nbm <= 3) {
+    const int need = ((s.mp * s.ldr + 1) & ~1) + ((s.nbm * 272 + 1) & ~1);
+    const int lr = s.GP + ((s.np * s.mp - need) & ~1), lir = lr + ((s.mp * s.ldr + 1) & ~1);  // at the end of the G_u region
+    int cur = s.R1;
+    auto place = [&](int cnt) { const int r = cur; cur += (cnt + 1) & ~1; return r; };
+    const int w_ = place(s.mp * s.lw), st_ = place(st_lds ? s.mp * s.np : 0), ct_ = place(16 * s.lw), vx_ = place(16 * s.lw), y_ = place(s.mp * 16),
+              sc_ = place(16 * 17), lis_ = place(272);
+    if (need <= s.np * s.mp && cur <= lr) {  // everything else fits in front of it: no growth of the carve-out
+      s.ovl = 1;
+      s.Lr = lr; s.LIr = lir; s.W = w_; s.ST = st_; s.CT = ct_; s.VX = vx_; s.Y = y_; s.SC = sc_; s.LIs = lis_;
+      end3 = s.GP + s.np * s.mp;
+    }
+  }
   o = end1 > end2 ? end1 : end2;
   if (end3 > o) o = end3;
   s.vec = take(7 * s.nzp + 2 * c + 96);  // ph ft vv w gh pvec (6 nzp) | dtl kvc (2 c) | e6l wred t6l (92) | gpre (nzp)
@@ -127,6 +144,8 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   const bool ff = L.space == MPC_SPACE_MULTIBODY;
   // u rows of Hh straight from registers into the KKT operands (step 5 / 6) when every wavefront can hold its share
   const bool ureg = S.gfull && (nzt * (nzt + 1) / 2 - nb * (nb + 1) / 2) <= RIC_U_TILES * nw;
+  // Ruu factorised by wavefront 0 while the others finish the x rows of Hh (needs the overlap layout of make_ric_lds)
+  const bool ovl = S.ovl && ureg && nw >= 2;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *PT = sm + S.PT, *LP = sm + S.LP, *LI = sm + S.LI, *AB = sm + S.AB, *GP = sm + S.GP, *vec = sm + S.vec;
   double *Lr = sm + S.Lr, *LIr = sm + S.LIr, *W = sm + S.W, *CTl = sm + S.CT, *VXl = sm + S.VX, *Yl = sm + S.Y, *SCl = sm + S.SC, *LIs = sm + S.LIs;
@@ -503,14 +522,14 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[q] = h[q] + acc[q];
       };
-      // x rows (tiles 0 .. nxt-1): only the value update of step 7 reads them — to the L2-resident scratch
-      for (int t = wv; t < (ureg ? nxt : nht); t += nw) {
+      auto x_tile = [&](int t) {  // x rows: only the value update of step 7 reads them — to the L2-resident scratch
         d4_t hv; int zr[4], zc;
         hh_tile(t, hv, zr, zc);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (zr[q] >= 0 && zc >= 0) Hh[zr[q] * nz + zc] = hv[q];
-      }
+      };
+      if (!ovl) for (int t = wv; t < (ureg ? nxt : nht); t += nw) x_tile(t);
       // u rows (Sh^T, Ruu): the operands of the stage KKT system.  They stay in registers until [A B] is dead and then go
       // straight to their LDS places (Lr, W, ST) — reading them back from the scratch cost a chain of L2 round trips.
       d4_t ures[RIC_U_TILES];
@@ -527,23 +546,35 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         }
       }
       __syncthreads();
-      // ---- 6. stage KKT (AB is dead: R1 is reused): Lr = Ruu (lower block triangle, identity padding) ;
-      // W = -[Sh^T | rh] (mp x lw, zero padded) ; ST = Sh^T (mp x np)
+      // ---- 6. stage KKT: Lr = Ruu (lower block triangle, identity padding) ; W = -[Sh^T | rh] (mp x lw, zero padded) ;
+      // ST = Sh^T (mp x np).  uu: tiles of Ruu -> Lr ; ux: tiles of Sh^T -> W, ST (these lie over [A B]: only once it is dead)
+      auto scatter = [&](bool uu, bool ux) {
 #pragma unroll
-      for (int sidx = 0; sidx < RIC_U_TILES; ++sidx) {
-        const int t = nxt + wv + sidx * nw;
-        if (ureg && t < nht) {
-          int zi = 0, cj = t;
-          while (cj > zi) { cj -= zi + 1; ++zi; }
-          const int col = lane & 15;
+        for (int sidx = 0; sidx < RIC_U_TILES; ++sidx) {
+          const int t = nxt + wv + sidx * nw;
+          if (ureg && t < nht) {
+            int zi = 0, cj = t;
+            while (cj > zi) { cj -= zi + 1; ++zi; }
+            const int col = lane & 15;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int i = (zi - nb) * 16 + (lane >> 4) + 4 * q;  // u row (padded index)
-            const double v = ures[sidx][q];
-            if (cj < nb) { W[i * lw + cj * 16 + col] = -v; ST[i * np + cj * 16 + col] = v; }
-            else { const int j = (cj - nb) * 16 + col; Lr[i * ldr + j] = (i == j && i >= m) ? 1.0 : v; }
+            for (int q = 0; q < 4; ++q) {
+              const int i = (zi - nb) * 16 + (lane >> 4) + 4 * q;  // u row (padded index)
+              const double v = ures[sidx][q];
+              if (cj < nb) { if (ux) { W[i * lw + cj * 16 + col] = -v; ST[i * np + cj * 16 + col] = v; } }
+              else if (uu) { const int j = (cj - nb) * 16 + col; Lr[i * ldr + j] = (i == j && i >= m) ? 1.0 : v; }
+            }
           }
         }
+      };
+      if (ovl) {
+        scatter(true, false);  // Lr lives in the (now dead) G_u region
+        __syncthreads();
+        if (wv == 0) { const bool ok = chol_blocked_wave(Lr, ldr, nbm, LIr, lane); if (lane == 0) iflag[0] = ok ? 1 : 0; }
+        else for (int t = wv - 1; t < nxt; t += nw - 1) x_tile(t);
+        __syncthreads();       // [A B] is dead from here on
+        scatter(false, true);
+      } else {
+        scatter(true, true);
       }
       if (ureg) for (int idx = tid; idx < mp * 16; idx += nthr) {  // feed-forward column of W and its padding
         const int i = idx >> 4, cc = idx & 15;
@@ -625,7 +656,8 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     // An indefinite reduced control Hessian (far from the solution the Gauss-Newton + penalty model can lose definiteness
     // through the AL terms) is regularised: Ruu + rho I with rho = max(1e-8, 1e-6 max|diag|) x 10^t until the Cholesky
     // succeeds (same rule in oracle/solver.hpp) — the damped Newton step of ProxDDP's inertia correction.
-    for (int attempt = 1; !chol_blocked(Lr, ldr, nbm, LIr, tid, iflag); ++attempt) {
+    bool chol_ok = ovl ? (iflag[0] != 0) : chol_blocked(Lr, ldr, nbm, LIr, tid, iflag);  // ovl: wavefront 0 did it during step 5
+    for (int attempt = 1; !chol_ok; ++attempt) {
       if (attempt > 10) { if (tid == 0) a.inst[b].done = 3; return; }
       if (tid == 0) {
         double dmax = 0.0;
@@ -640,6 +672,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         for (int j = lane; j < mp; j += 64)
           Lr[i * ldr + j] = (i < m && j < m) ? Hh[(n + (i > j ? i : j)) * nz + n + (i > j ? j : i)] + (i == j ? rho : 0.0) : (i == j ? 1.0 : 0.0);
       __syncthreads();
+      chol_ok = chol_blocked(Lr, ldr, nbm, LIr, tid, iflag);
     }
     RIC_PROF(10);
     trsm_fwd_blocked(Lr, ldr, LIr, nbm, W, lw, nwb, wv, nw, lane);  // W = L^-1 T
