@@ -182,6 +182,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   if (s->use_mfma_riccati)
   {
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
   }
   HIP_OK(hipStreamSynchronize(s->stream));
@@ -251,6 +252,7 @@ static void launch_pass(mpc_solver* s) {
   s->timed(3, "k_riccati_backward", [&] {
     if (s->use_mfma_riccati && s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_SMALL_THREADS, 16>), dim3(L.B), dim3(RIC_SMALL_THREADS), s->ric.total_bytes, s->stream, a, s->ric);  // small problems: one wavefront
+    else if (s->use_mfma_riccati && s->ric.np <= 80) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);  // fewer tiles per wavefront: lower register pressure
     else if (s->use_mfma_riccati) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 96>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
     else hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);
   });
