@@ -132,7 +132,9 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   constexpr int AB_ROWS = (NPMAX + NWV - 1) / NWV;                                // register prefetch capacity: rows of [A B] per wavefront
   constexpr int RIC_SERIES_TILES = (NBMAX * (NBMAX + 1) / 2 + NWV - 1) / NWV;     // lower-triangle output tiles per wavefront
   constexpr int RIC_G_TILES = (NBMAX * NZTMAX + NWV - 1) / NWV;                   // tiles of G per wavefront
-  constexpr int RIC_U_TILES = NPMAX > 16 ? 2 : 1;  // lower-triangle tiles of the u rows of Hh a wavefront can keep in registers
+  constexpr int RIC_U_TILES = NPMAX > 16 ? 2 : 1;
+  constexpr bool CT_PREFETCH = NPMAX <= 80;  // the largest instantiation has no registers to spare for it
+  constexpr int CT_ROWS = 16 / NWV, Y_ELEMS = (NPMAX > 16 ? 48 : 16) * 16 / RT + ((NPMAX > 16 ? 48 : 16) * 16 % RT ? 1 : 0);  // per-thread shares of CT (16 rows) and Y (mp x 16)  // lower-triangle tiles of the u rows of Hh a wavefront can keep in registers
   const Layout& L = a.L;
   const int b = blockIdx.x, nthr = blockDim.x, nw = nthr >> 6;
   int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // re-derived at every phase boundary (RIC_LAUNDER)
@@ -235,6 +237,28 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     __syncthreads();
     RIC_PROF(0);
     const int ca = iflag[1];
+    // rows of the active constraints ([Ca_x | dt], Da^T) for the stage KKT system of step 6: requested here, in registers
+    // until then (an L2 round trip that nothing waits for)
+    double pf_ct[CT_ROWS][2], pf_y[Y_ELEMS];
+    if (CT_PREFETCH && ca <= 16) {
+#pragma unroll
+      for (int ii = 0; ii < CT_ROWS; ++ii) {
+        const int i = wv + ii * nw;
+        const int ai = (i < ca) ? act_idx[i] : 0;
+#pragma unroll
+        for (int zz = 0; zz < 2; ++zz) {
+          const int z = lane + 64 * zz;
+          const bool isx = z < n, isd = z == np;
+          pf_ct[ii][zz] = kn[isd ? L.oDT + ai : L.oCD + ai * nz + (isx ? z : 0)];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < Y_ELEMS; ++e) {
+        const int idx = tid + e * nthr, i = idx >> 4, j = idx & 15;
+        const int aj = (j < ca) ? act_idx[j] : 0;
+        pf_y[e] = kn[L.oCD + aj * nz + n + ((idx < mp * 16 && i < m) ? i : 0)];
+      }
+    }
     const double* T6 = t6l;  // LDS copy; the gain record gets it below
     if (tid < 36) g[L.oT6 + tid] = t6l[tid];
     if (ff) {
@@ -636,6 +660,23 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       }
     }
     if (small_ca) {
+      if (CT_PREFETCH) {
+      // CT = [Ca_x | . | dt | .] (16 x lw) ; Y = Da^T (mp x 16): from the registers filled at the top of the knot
+#pragma unroll
+      for (int ii = 0; ii < CT_ROWS; ++ii) {
+        const int i = wv + ii * nw;
+#pragma unroll
+        for (int zz = 0; zz < 2; ++zz) {
+          const int z = lane + 64 * zz;
+          if (i < 16 && z < lw) CTl[i * lw + z] = (i < ca && (z < n || z == np)) ? pf_ct[ii][zz] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < Y_ELEMS; ++e) {
+        const int idx = tid + e * nthr, i = idx >> 4, j = idx & 15;
+        if (idx < mp * 16) Yl[idx] = (i < m && j < ca) ? pf_y[e] : 0.0;
+      }
+      } else {
       // CT = [Ca_x | . | dt | .] (16 x lw) ; Y = Da^T (mp x 16)
       for (int i = wv; i < 16; i += nw)
         for (int z = lane; z < lw; z += 64) {
@@ -649,6 +690,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         const int i = idx >> 4, j = idx & 15;
         const int aj = (j < ca) ? act_idx[j] : 0;
         Yl[idx] = kn[L.oCD + aj * nz + n + (i < m ? i : 0)] * ((i < m && j < ca) ? 1.0 : 0.0);
+      }
       }
     }
     __syncthreads();
