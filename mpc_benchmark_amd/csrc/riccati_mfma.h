@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   // u rows of Hh straight from registers into the KKT operands (step 5 / 6) when every wavefront can hold its share
   const bool ureg = S.gfull && (nzt * (nzt + 1) / 2 - nb * (nb + 1) / 2) <= RIC_U_TILES * nw;
   // Ruu factorised by wavefront 0 while the others finish the x rows of Hh (needs the overlap layout of make_ric_lds)
-  const bool ovl = S.ovl && ureg && nw >= 2;
+  const bool ovl = S.ovl && ureg && nw >= 2 && nbm * (nbm + 1) / 2 <= nw && nbm * nb <= RIC_U_TILES * (nw - 1);
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *PT = sm + S.PT, *LP = sm + S.LP, *LI = sm + S.LI, *AB = sm + S.AB, *GP = sm + S.GP, *vec = sm + S.vec;
   double *Lr = sm + S.Lr, *LIr = sm + S.LIr, *W = sm + S.W, *CTl = sm + S.CT, *VXl = sm + S.VX, *Yl = sm + S.Y, *SCl = sm + S.SC, *LIs = sm + S.LIs;
@@ -558,9 +558,65 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       // straight to their LDS places (Lr, W, ST) — reading them back from the scratch cost a chain of L2 round trips.
       d4_t ures[RIC_U_TILES];
 #pragma unroll
+      for (int sidx = 0; sidx < RIC_U_TILES; ++sidx) ures[sidx] = d4_t{0, 0, 0, 0};
+      if (ovl) {
+        // Overlap: the serial part of a knot is the factorisation of Ruu (16x16 Cholesky steps in the registers of ONE
+        // wavefront, ~9 us).  Only its own tiles come first (one per wavefront), Lr sits at the end of the then dead G_u
+        // region, and wavefront 0 factorises it WHILE the others multiply the Sh^T and x-row tiles of Hh.
+        const int nuu = nbm * (nbm + 1) / 2, nux = nbm * nb, nwx = nw - 1;
+        d4_t uu = d4_t{0, 0, 0, 0};
+        int ubi = 0, ubj = wv;  // lower block (ubi, ubj) of Ruu
+        while (ubj > ubi) { ubj -= ubi + 1; ++ubi; }
+        if (wv < nuu) {
+          int zr[4], zc;
+          hh_tile((nb + ubi) * (nb + ubi + 1) / 2 + nb + ubj, uu, zr, zc);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (zr[q] >= 0 && zc >= 0) Hh[zr[q] * nz + zc] = uu[q];  // kept for the inertia-correction path
+        }
+        __syncthreads();  // G_u is dead
+        if (wv < nuu) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = ubi * 16 + (lane >> 4) + 4 * q, j = ubj * 16 + (lane & 15);
+            Lr[i * ldr + j] = (i == j && i >= m) ? 1.0 : uu[q];
+          }
+        }
+        __syncthreads();
+        if (wv == 0) { const bool ok = chol_blocked_wave(Lr, ldr, nbm, LIr, lane); if (lane == 0) iflag[0] = ok ? 1 : 0; }
+        else {
+#pragma unroll
+          for (int sidx = 0; sidx < RIC_U_TILES; ++sidx) {
+            const int e = wv - 1 + sidx * nwx;
+            if (e < nux) {
+              const int zi = nb + e / nb, cj = e % nb;
+              int zr[4], zc;
+              hh_tile(zi * (zi + 1) / 2 + cj, ures[sidx], zr, zc);
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (zr[q] >= 0 && zc >= 0) Hh[zr[q] * nz + zc] = ures[sidx][q];
+            }
+          }
+          for (int t = wv - 1; t < nxt; t += nwx) x_tile(t);
+        }
+        __syncthreads();  // [A B] is dead from here on: W = -[Sh^T | rh], ST = Sh^T lie over it
+        if (wv > 0) {
+#pragma unroll
+          for (int sidx = 0; sidx < RIC_U_TILES; ++sidx) {
+            const int e = wv - 1 + sidx * nwx;
+            if (e < nux) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int i = (e / nb) * 16 + (lane >> 4) + 4 * q, cp = (e % nb) * 16 + (lane & 15);
+                W[i * lw + cp] = -ures[sidx][q]; ST[i * np + cp] = ures[sidx][q];
+              }
+            }
+          }
+        }
+      } else {
+#pragma unroll
       for (int sidx = 0; sidx < RIC_U_TILES; ++sidx) {
         const int t = nxt + wv + sidx * nw;
-        ures[sidx] = d4_t{0, 0, 0, 0};
         if (ureg && t < nht) {
           int zr[4], zc;
           hh_tile(t, ures[sidx], zr, zc);
@@ -571,34 +627,23 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       }
       __syncthreads();
       // ---- 6. stage KKT: Lr = Ruu (lower block triangle, identity padding) ; W = -[Sh^T | rh] (mp x lw, zero padded) ;
-      // ST = Sh^T (mp x np).  uu: tiles of Ruu -> Lr ; ux: tiles of Sh^T -> W, ST (these lie over [A B]: only once it is dead)
-      auto scatter = [&](bool uu, bool ux) {
+      // ST = Sh^T (mp x np)
 #pragma unroll
-        for (int sidx = 0; sidx < RIC_U_TILES; ++sidx) {
-          const int t = nxt + wv + sidx * nw;
-          if (ureg && t < nht) {
-            int zi = 0, cj = t;
-            while (cj > zi) { cj -= zi + 1; ++zi; }
-            const int col = lane & 15;
+      for (int sidx = 0; sidx < RIC_U_TILES; ++sidx) {
+        const int t = nxt + wv + sidx * nw;
+        if (ureg && t < nht) {
+          int zi = 0, cj = t;
+          while (cj > zi) { cj -= zi + 1; ++zi; }
+          const int col = lane & 15;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int i = (zi - nb) * 16 + (lane >> 4) + 4 * q;  // u row (padded index)
-              const double v = ures[sidx][q];
-              if (cj < nb) { if (ux) { W[i * lw + cj * 16 + col] = -v; ST[i * np + cj * 16 + col] = v; } }
-              else if (uu) { const int j = (cj - nb) * 16 + col; Lr[i * ldr + j] = (i == j && i >= m) ? 1.0 : v; }
-            }
+          for (int q = 0; q < 4; ++q) {
+            const int i = (zi - nb) * 16 + (lane >> 4) + 4 * q;  // u row (padded index)
+            const double v = ures[sidx][q];
+            if (cj < nb) { W[i * lw + cj * 16 + col] = -v; ST[i * np + cj * 16 + col] = v; }
+            else { const int j = (cj - nb) * 16 + col; Lr[i * ldr + j] = (i == j && i >= m) ? 1.0 : v; }
           }
         }
-      };
-      if (ovl) {
-        scatter(true, false);  // Lr lives in the (now dead) G_u region
-        __syncthreads();
-        if (wv == 0) { const bool ok = chol_blocked_wave(Lr, ldr, nbm, LIr, lane); if (lane == 0) iflag[0] = ok ? 1 : 0; }
-        else for (int t = wv - 1; t < nxt; t += nw - 1) x_tile(t);
-        __syncthreads();       // [A B] is dead from here on
-        scatter(false, true);
-      } else {
-        scatter(true, true);
+      }
       }
       if (ureg) for (int idx = tid; idx < mp * 16; idx += nthr) {  // feed-forward column of W and its padding
         const int i = idx >> 4, cc = idx & 15;
