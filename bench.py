@@ -43,6 +43,9 @@ def main():
     ap.add_argument("--phase-offset-ms", type=float, default=-1.0,
                     help="with --streams S: shard i starts its ticks i x this many ms late (inside the timed region); "
                          "negative = automatic (0.8 x one lock-step tick of the warm-up / S)")
+    ap.add_argument("--episode", type=int, default=100,
+                    help="ticks after which a shard goes back to its cold-solved start (one extra warm iteration, inside the timed "
+                         "region): the synthetic walk with frozen foot references is replayed in episodes, see DESIGN.md section 5")
     ap.add_argument("--closed-loop", action="store_true",
                     help="measured states from the simulation stand-in (10 x 1 ms of knot 0's dynamics under the feedback law, N2) "
                          "instead of perfect-model feedback; the simulation runs inside the timed region")
@@ -82,6 +85,7 @@ def main():
         c = e.cold_solve(max_iters=100)
         n_conv = locals().get("n_conv", 0) + sum(bool(st.converged) for st in c)
         cold = cold or c
+        e.save_episode()
 
     stagger = {"ms": args.phase_offset_ms}
 
@@ -89,6 +93,8 @@ def main():
         """`count` MPC ticks of every shard (independent ensembles, each on its own handle / stream)."""
         if nshard == 1:
             for _ in range(count):
+                if shards[0].tick >= args.episode:
+                    shards[0].restart_episode()
                 shards[0].step(rescue=True)  # synchronous form: exactly one solver pass per tick
             return
         # One host thread drives all shards round-robin: a tick is enqueued on the shard's stream without waiting, and
@@ -113,6 +119,11 @@ def main():
             e.step_async()
         for _ in range(count - done_ticks - 1):
             for e in shards:
+                if e.tick >= args.episode:  # end of an episode: drain, back to the start, refill the pipeline
+                    e.wait(rescue=True)
+                    e.restart_episode()
+                    e.step_async()
+                    continue
                 e.step_async()         # tick t + 1 goes on the stream first ...
                 e.wait(rescue=True)    # ... then the host looks at tick t: the stream never runs dry
         for e in shards:
@@ -278,6 +289,7 @@ def main():
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
         "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; the others are within 1e-4 of feasibility)" % (n_conv, args.batch),
         "diverged_instance_rescues": sum(getattr(e, "rescues", 0) for e in shards),
+        "episode_ticks": args.episode, "episode_restarts": sum(getattr(e, "episodes", 0) for e in shards),
         "roofline": roof, "cpu_baseline": cpu,
         # supplementary: the same kernel against the fp64 matrix-core peak (the sweep is a chain of dependent dense steps on ONE CU
         # per instance, not a streaming kernel — DESIGN.md §5); flops = textbook count of the recursion on the unpadded dimensions

@@ -114,6 +114,26 @@ class EnsembleMPC:
         self.native.set_x0(None)  # perfect-model feedback from here on
         return stats
 
+    def save_episode(self):
+        """Remember the current iterate (normally the cold-solved start) as the beginning of an episode."""
+        r = self.results(gains=False)
+        self._episode = (r["xs"].copy(), r["us"].copy(), self.tick)
+
+    def restart_episode(self):
+        """Back to the saved start: stage tables of the first tick, initial states, one iteration from the saved iterate.
+        The synthetic scenario (frozen foot references, perfect-model feedback, randomised states) is not meant to be replayed
+        far past the first single-support phase; long runs walk it in episodes instead."""
+        xs, us, tick0 = self._episode
+        for k, (desc, params) in enumerate(self.tables):
+            self.native.set_stage(k, desc, params)
+        self.tick = tick0
+        self.native.set_x0(self.x0)
+        self.native.setup()
+        stats = self.native.run(xs, us)  # max_iters = 1: one warm iteration, as a tick
+        self.native.set_x0(None)
+        self.episodes = getattr(self, "episodes", 0) + 1
+        return stats
+
     def step(self, rescue=False):
         """One MPC tick for every instance of the ensemble (one ProxDDP iteration each).  ``rescue``: an instance whose
         trajectory has diverged (the library reports a failed factorisation) does not abort a long-running ensemble — the

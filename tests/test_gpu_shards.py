@@ -75,3 +75,26 @@ def test_profile_mask_times_only_selected_kernels():
     ens.native.profile(0)
     only = ens.native.profile_read()
     assert list(only) == ["k_riccati_backward"] and only["k_riccati_backward"][0] == 2
+
+
+def test_episode_restart_replays_the_walk():
+    """``restart_episode``: stage ring, initial states and iterate go back to the cold-solved start; the ticks that follow
+    repeat the first episode up to the extra warm iteration taken at the restart (the cold solve stops at its tolerance, so one more
+    iteration still moves the iterate a little)."""
+    hip = _capi.load_hip_library()
+    pd = FullDynamicsProblem(horizon=12)
+    ens = EnsembleMPC(pd, batch=3, library=hip, seed=21, sigma_q=0.005, sigma_v=0.01)
+    ens.prepare_schedule(40)
+    ens.cold_solve(max_iters=60)
+    ens.save_episode()
+    first = []
+    for _ in range(5):
+        ens.step()
+        first.append(ens.results(gains=False)["xs"].copy())
+    for _ in range(20):  # far enough for the contact pattern at the head of the ring to have changed
+        ens.step()
+    ens.restart_episode()
+    assert ens.tick == 0 and ens.episodes == 1
+    for t in range(5):
+        ens.step()
+        assert _rel(ens.results(gains=False)["xs"], first[t]) < 1e-2
