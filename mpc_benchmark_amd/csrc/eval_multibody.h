@@ -554,13 +554,15 @@ sim_loop:
       __syncthreads();
       for (int i = tid; i < nl; i += nthr) kn[KL.oWR + 6 * desc[2 + i / 6] + i % 6] = lam[i];
     }
-    for (int idx = tid; idx < 6 * nj; idx += nthr) {
-      const int i = idx / 6, e = idx % 6;
-      double s = oa[idx];
-      for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); s += J[6 * kd + e] * acc[kd]; }
-      oa[idx] = s;
+    if (derivs) {  // body accelerations at the solution: only the derivative blocks read them
+      for (int idx = tid; idx < 6 * nj; idx += nthr) {
+        const int i = idx / 6, e = idx % 6;
+        double s = oa[idx];
+        for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); s += J[6 * kd + e] * acc[kd]; }
+        oa[idx] = s;
+      }
+      __syncthreads();
     }
-    __syncthreads();
     if (derivs) {
       for (int i = tid; i < nj; i += nthr) {
         S6 f = add6(mat6_mul(oY + 36 * i, ld6(oa + 6 * i)), fcross(ld6(ov + 6 * i), ld6(oh + 6 * i)));
