@@ -30,7 +30,10 @@ def wrench_cone_rows(mu, L, W, force_size=6):
 
 
 class IDSolver_ulim:
-    def __init__(self, model, weights, nk, mu, L, W, contact_ids, force_size, verbose=False, library=None, batch=1):
+    def __init__(self, model, weights, nk, mu, L, W, contact_ids, force_size, verbose=False, library=None, batch=1, warm_start=False):
+        """``warm_start``: from the second solve on, start from the previous solution (the 1 kHz loop solves a slowly
+        varying sequence of QPs; ProxQP's own default is a cold equality-constrained start)."""
+        self.warm_start = bool(warm_start)
         self.model, self.nk, self.contact_ids, self.mu, self.L, self.W, self.force_size = model, nk, list(contact_ids), mu, L, W, force_size
         self.baum_Kd = np.eye(3)  # velocity damping of the contact point (kd = 1)
         nv, fs = model.nv, force_size
@@ -83,6 +86,8 @@ class IDSolver_ulim:
         A = np.stack([m[0] for m in mats]); b = np.stack([m[1] for m in mats]); C = np.stack([m[2] for m in mats]); l = np.stack([m[3] for m in mats])
         x, y, z, _, info = self.qp.solve(self.H, self.g, A, b, C, l, self.u)
         self.last_info = info
+        if self.warm_start:
+            self.qp.settings.warm_start = 1
         nv, fs, nk = self.model.nv, self.force_size, self.nk
         res = []
         for i, it in enumerate(items):

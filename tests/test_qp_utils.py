@@ -110,3 +110,21 @@ def test_ikid_solver_end_to_end_on_the_oracle():
     for i in range(2):
         assert np.min(solver.Cmin @ f[6 * i:6 * i + 6]) > -5e-3                                 # wrench cone
     assert np.all(np.abs(tau) <= np.asarray(model.effortLimit)[6:] + 5e-3)                      # torque box
+
+
+def test_warm_start_saves_newton_steps():
+    model, q0 = _model()
+    rng = np.random.default_rng(7)
+    ids = [model.getFrameId("left_sole_link"), model.getFrameId("right_sole_link")]
+    solver = qp_utils.IDSolver_ulim(model, [1.0, 1e-3], 2, 0.8, 0.1, 0.075, ids, 6, False, library=_oracle.load(), warm_start=True)
+    w = 9.81 * pin.computeTotalMass(model)
+    forces = np.array([0.45 * w, 0, 0.5 * w, 0, 0, 0, -0.45 * w, 0, 0.5 * w, 0, 0, 0], dtype=float)  # outside the friction cone: it binds
+    steps = []
+    v = rng.normal(size=model.nv) * 0.05
+    a = rng.normal(size=model.nv) * 0.2
+    for k in range(3):  # a slowly varying sequence, as consecutive 1 ms ticks
+        data = dyn.compute_all_terms(model, model.createData(), q0, v * (1.0 + 0.01 * k))
+        solver.solve(data, [True, True], v, a * (1.0 + 0.01 * k), forces, data.M)
+        assert solver.last_info[0].status == 0
+        steps.append(solver.last_info[0].iters_in)
+    assert steps[0] >= 2 and steps[1] < steps[0] and steps[2] < steps[0]
