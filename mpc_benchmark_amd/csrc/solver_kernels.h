@@ -56,8 +56,8 @@ __global__ void k_lagrangian(SolverArgs a) {
   double dual = 0.0, crit = 0.0;
   for (int z = tid; z < nzk; z += nthr) {
     double s = kn[L.oG + z];
-    for (int i = 0; i < c; ++i) s += kn[L.oCD + i * nz + z] * v[i];
-    if (k < N) for (int i = 0; i < n; ++i) s += kn[L.oAB + i * nz + z] * lamn[i];
+    for (int i = 0; i < c; ++i) if (v[i] != 0.0) s += kn[L.oCD + i * nz + z] * v[i];  // rows with a zero multiplier are not read (all of them right after setup)
+    if (k < N) for (int i = 0; i < n; ++i) if (lamn[i] != 0.0) s += kn[L.oAB + i * nz + z] * lamn[i];
     if (k > 0 && z < n) {
       if (L.space == MPC_SPACE_MULTIBODY && z < 6) {
         const double* E6 = knot_ptr(a, b, k - 1) + L.oE6;
@@ -597,15 +597,18 @@ __global__ void __launch_bounds__(256) k_duals(SolverArgs a) {
   for (int i = wv; i < L.c; i += nw) {
     if (i >= c) { if (lane == 0) dv[i] = 0.0; continue; }
     double s = 0, jd = 0;
-    if (kn[L.oACT + i] != 0.0)  // the sweep writes the dual gains of active rows only (inactive: dv = -v)
+    const bool act = kn[L.oACT + i] != 0.0;
+    const double vp = kn[L.oDT + i] / mu;
+    const double wj = vp + (act ? (vp - v[i]) : 0.0);  // weight of the row's directional derivative in the merit slope
+    if (act)  // the sweep writes the dual gains of active rows only (inactive: dv = -v)
       for (int z = lane; z < n; z += 64) s += g[L.oKnu + i * n + z] * dz[z];
-    for (int z = lane; z < n + m; z += 64) jd += kn[L.oCD + i * nz + z] * dz[z];
+    if (wj != 0.0)  // an inactive row with a zero projection does not enter the slope: its Jacobian row is not read
+      for (int z = lane; z < n + m; z += 64) jd += kn[L.oCD + i * nz + z] * dz[z];
     s = wave_sum(s) + g[L.oknu + i];
     jd = wave_sum(jd);
     const double dvi = s - v[i];
     if (lane == 0) dv[i] = dvi;
-    const double vp = kn[L.oDT + i] / mu;
-    acc += (vp + (kn[L.oACT + i] != 0.0 ? (vp - v[i]) : 0.0)) * jd - mu * (vp - v[i]) * dvi;
+    acc += wj * jd - mu * (vp - v[i]) * dvi;
   }
   if (k == 0) for (int i = tid; i < n; i += nthr) a.dlams[(size_t)b * (N + 1) * n + i] = 0.0;
   if (k < N) {
