@@ -34,7 +34,7 @@ struct mpc_solver {
   int32_t* d_model_i = nullptr;
   double* d_model_d = nullptr;
   double *d_xs = nullptr, *d_us = nullptr, *d_vs = nullptr, *d_lams = nullptr, *d_vs_e = nullptr, *d_lams_e = nullptr, *d_x0 = nullptr;
-  double *d_dxs = nullptr, *d_dus = nullptr, *d_dvs = nullptr, *d_dlams = nullptr;
+  double *d_dxs = nullptr, *d_dus = nullptr, *d_dvs = nullptr, *d_dlams = nullptr, *d_abdz = nullptr;
   double *d_knots = nullptr, *d_tknots = nullptr, *d_gains = nullptr, *d_work = nullptr, *d_trial_phi = nullptr, *d_mbwork = nullptr;
   InstState* d_inst = nullptr;
   int* d_all_done = nullptr;
@@ -99,7 +99,7 @@ struct mpc_solver {
     a.L = L; a.opt = opt; a.head = head;
     a.stage_desc = d_stage_desc; a.stage_params = d_stage_params; a.model_i = d_model_i; a.model_d = d_model_d;
     a.xs = d_xs; a.us = d_us; a.vs = d_vs; a.lams = d_lams; a.vs_e = d_vs_e; a.lams_e = d_lams_e; a.x0 = d_x0;
-    a.dxs = d_dxs; a.dus = d_dus; a.dvs = d_dvs; a.dlams = d_dlams;
+    a.dxs = d_dxs; a.dus = d_dus; a.dvs = d_dvs; a.dlams = d_dlams; a.abdz = nullptr;
     a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = phase_timers ? d_prof : nullptr;
     return a;
   }
@@ -148,7 +148,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->d_vs_e = s->alloc<double>(B * N1 * L.c); s->d_lams_e = s->alloc<double>(B * (N1 + 1) * L.n);
   s->d_x0 = s->alloc<double>(B * L.nx);
   s->d_dxs = s->alloc<double>(B * (N1 + 1) * L.n); s->d_dus = s->alloc<double>(B * N * L.m + 1);
-  s->d_dvs = s->alloc<double>(B * N1 * L.c); s->d_dlams = s->alloc<double>(B * (N1 + 1) * L.n);
+  s->d_dvs = s->alloc<double>(B * N1 * L.c); s->d_dlams = s->alloc<double>(B * (N1 + 1) * L.n); s->d_abdz = s->alloc<double>(B * N1 * L.n);
   s->d_knots = s->alloc<double>(B * N1 * L.knot_stride);
   s->d_tknots = s->alloc<double>(B * L.n_alpha * N1 * T.knot_stride);
   s->d_gains = s->alloc<double>(B * N1 * L.gain_stride);
@@ -262,6 +262,7 @@ static void launch_pass(mpc_solver* s) {
   // ensembles, latency-bound: 0.95 -> 0.53 ms at batch 1), not when the ensemble already fills it (B = 64: 0.97 -> 1.3 ms)
   // (options.forward_mode overrides: a handle cannot see the other handles that share its GPU — with 4 shards of 16 instances the
   // sweep gives 4714 solves/s against 4551)
+  a.abdz = nullptr;
   const bool fw_phi = s->cl.total_bytes <= 160 * 1024 && L.n <= 80 && L.m <= 32 && (s->opt.forward_mode == 0 ? L.B * L.N <= 2048 : s->opt.forward_mode == 2);
   if (fw_phi) {
     s->timed(12, "k_closed_loop", [&] { hipLaunchKernelGGL(k_closed_loop, dim3(L.N, L.B), dim3(CL_THREADS), s->cl.total_bytes, s->stream, a, s->cl); });
@@ -270,6 +271,7 @@ static void launch_pass(mpc_solver* s) {
     s->timed(4, "k_forward", [&] {
       const size_t fw_lds = (L.nz + 2 * L.n) * sizeof(double);
       const bool fits = L.nz <= 128 && L.n + L.m <= L.nz;
+      if (fits && L.n <= 80 && L.m <= 48) a.abdz = s->d_abdz;  // the register-prefetch sweeps leave [A B] [dx; du] of every knot for k_duals
       if (fits && L.n <= 80 && L.m <= 32) hipLaunchKernelGGL((k_forward_prefetch<4, 10>), dim3(L.B), dim3(512), fw_lds, s->stream, a);
       else if (fits && L.n <= 80 && L.m <= 48) hipLaunchKernelGGL((k_forward_prefetch<6, 10>), dim3(L.B), dim3(512), fw_lds, s->stream, a);
       else hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(1024), fw_lds, s->stream, a);

@@ -25,6 +25,7 @@ struct SolverArgs {
   // iterate
   double *xs, *us, *vs, *lams, *vs_e, *lams_e, *x0;
   double *dxs, *dus, *dvs, *dlams;
+  double* abdz;  // [B][N][n]: [A B] [dx; du] per knot, written by the forward sweep for k_duals (nullptr: k_duals forms it itself)
   double *knots, *gains, *work;
   double *trial_phi;  // [B][n_alpha][N+1]
   InstState* inst;
@@ -533,7 +534,7 @@ __global__ void __launch_bounds__(512) k_forward_prefetch(SolverArgs a) {
       if (r < n) {
         double s = (c0 < n + m ? ABr[q][0] * dz[c0] : 0.0) + (c1 < n + m ? ABr[q][1] * dz[c1] : 0.0);
         s = wave_sum(s);
-        if (lane == 0) y[r] = s + mxv[q];
+        if (lane == 0) { y[r] = s + mxv[q]; if (a.abdz) a.abdz[((size_t)b * N + k) * n + r] = s; }
       }
     }
     if (more) load_AB(k + 1);
@@ -616,9 +617,10 @@ __global__ void __launch_bounds__(256) k_duals(SolverArgs a) {
     for (int i = wv; i < n; i += nw) {
       double s = 0, jd = 0;
       for (int z = lane; z < n; z += 64) s += gn[L.oP + i * n + z] * dxn[z];
-      for (int z = lane; z < n + m; z += 64) jd += kn[L.oAB + i * nz + z] * dz[z];
+      const bool have = a.abdz != nullptr;  // the forward sweep already formed [A B] [dx; du]: 66 KB per knot not read again
+      if (!have) for (int z = lane; z < n + m; z += 64) jd += kn[L.oAB + i * nz + z] * dz[z];
       s = wave_sum(s);
-      jd = wave_sum(jd);
+      jd = have ? a.abdz[((size_t)b * N + k) * n + i] : wave_sum(jd);
       if (lane == 0) { lnew[i] = s + gn[L.op + i]; jdl[i] = jd; }
     }
   }
