@@ -43,9 +43,20 @@ def main():
     ap.add_argument("--phase-offset-ms", type=float, default=-1.0,
                     help="with --streams S: shard i starts its ticks i x this many ms late (inside the timed region); "
                          "negative = automatic (0.8 x one lock-step tick of the warm-up / S)")
+    ap.add_argument("--period-ms", type=float, default=-1.0,
+                    help="with --streams S: pace every shard at this tick period (shard i released i / S of a period after shard 0). "
+                         "Free-running shards drift into lock step (their heavy kernels share the chip and finish together), which "
+                         "costs 10-20 %%; negative = adaptive (starts from the lock-step tick and shortens the period while every tick "
+                         "is finished when the next one is released), 0 = free-running")
+    ap.add_argument("--calibration-ticks", type=int, default=20,
+                    help="untimed ticks BEFORE the warm-up in which the adaptive shard pacer finds its period (sharded runs only; "
+                         "like the cold solves they are set-up, not part of --warmup / --steps)")
     ap.add_argument("--episode", type=int, default=100,
                     help="ticks after which a shard goes back to its cold-solved start (one extra warm iteration, inside the timed "
                          "region): the synthetic walk with frozen foot references is replayed in episodes, see DESIGN.md section 5")
+    ap.add_argument("--no-tick-reuse", action="store_true",
+                    help="evaluate every knot afresh each tick (by default the accepted full step is evaluated with derivatives and "
+                         "its records serve the next tick: bit-identical results, see mpc_set_tick_reuse in include/mpc_abi.h)")
     ap.add_argument("--closed-loop", action="store_true",
                     help="measured states from the simulation stand-in (10 x 1 ms of knot 0's dynamics under the feedback law, N2) "
                          "instead of perfect-model feedback; the simulation runs inside the timed region")
@@ -76,18 +87,20 @@ def main():
     nshard = max(1, min(args.streams, args.batch))
     sizes = [args.batch // nshard + (1 if i < args.batch % nshard else 0) for i in range(nshard)]
     shards = [EnsembleMPC(pd, batch=sz, library=lib, device=local_rank, seed=20250304 + 1000 * rank + i,
-                          closed_loop=((10, pd.dt / 10) if args.closed_loop else None), forward_mode=(1 if nshard > 1 else 0))
+                          closed_loop=((10, pd.dt / 10) if args.closed_loop else None), forward_mode=(1 if nshard > 1 else 0),
+                          tick_reuse=not args.no_tick_reuse)
               for i, sz in enumerate(sizes)]
     ens = shards[0]
     cold = None
     for e in shards:
-        e.prepare_schedule(args.warmup + args.steps + 4)
+        e.prepare_schedule(args.warmup + args.steps + args.calibration_ticks + 4)
         c = e.cold_solve(max_iters=100)
         n_conv = locals().get("n_conv", 0) + sum(bool(st.converged) for st in c)
         cold = cold or c
         e.save_episode()
 
     stagger = {"ms": args.phase_offset_ms}
+    pace = {"period": 0.0, "fast": True, "late": 0}  # state of the shard pacer (kept from the warm-up into the timed region)
 
     def run_ticks(count):
         """`count` MPC ticks of every shard (independent ensembles, each on its own handle / stream)."""
@@ -113,25 +126,57 @@ def main():
             done_ticks = 1
         if count - done_ticks <= 0:
             return
-        for i, e in enumerate(shards):
-            if i and stagger["ms"] > 0:
-                time.sleep(stagger["ms"] * 1e-3)
+        remaining = count - done_ticks
+        depth = min(2, remaining)  # ticks in flight per shard: while the host looks at tick t, t + 1 runs and t + 2 may wait behind it
+        if args.period_ms > 0:
+            pace["period"] = args.period_ms * 1e-3
+        elif args.period_ms < 0 and pace["period"] <= 0:
+            pace["period"] = stagger["ms"] * 1e-3 * nshard / 0.8  # the lock-step tick measured above: safe, the pacer shortens it
+        period0 = pace["period"]
+        t_next = [time.perf_counter() + i * (period0 / nshard if period0 > 0 else 0.0) for i in range(nshard)]
+
+        def paced(i, e):
+            """Metronome: shard i's ticks are released one period apart, 1 / S of a period after shard i - 1's.  Adaptive
+            period (AIMD): a release that finds the shard's previous tick still running means the device does not keep up
+            (period up 1-3 %); otherwise the period shrinks — 1 % per release until the first late one, 0.1 % afterwards."""
+            if pace["period"] > 0:
+                dt_ = t_next[i] - time.perf_counter()
+                if dt_ > 0:
+                    time.sleep(dt_)
+                if args.period_ms < 0:
+                    in_flight, completed = e.native.poll()
+                    if in_flight > completed:  # the newest tick is still on the device
+                        pace["period"] *= 1.03 if pace["fast"] else 1.01
+                        pace["fast"] = False
+                        pace["late"] += 1
+                    else:
+                        pace["period"] *= 0.99 if pace["fast"] else 0.999
+                t_next[i] = max(t_next[i], time.perf_counter() - pace["period"]) + pace["period"]
             e.step_async()
-        for _ in range(count - done_ticks - 1):
-            for e in shards:
+        for i, e in enumerate(shards):
+            if pace["period"] <= 0 and i and stagger["ms"] > 0:
+                time.sleep(stagger["ms"] * 1e-3)
+            paced(i, e)
+        for _ in range(depth - 1):
+            for i, e in enumerate(shards):
+                paced(i, e)
+        for _ in range(remaining - depth):
+            for i, e in enumerate(shards):
+                e.wait(rescue=True)        # the oldest tick of this shard
                 if e.tick >= args.episode:  # end of an episode: drain, back to the start, refill the pipeline
                     e.wait(rescue=True)
                     e.restart_episode()
                     e.step_async()
-                    continue
-                e.step_async()         # tick t + 1 goes on the stream first ...
-                e.wait(rescue=True)    # ... then the host looks at tick t: the stream never runs dry
-        for e in shards:
-            e.wait(rescue=True)
+                paced(i, e)
+        for _ in range(depth):
+            for e in shards:
+                e.wait(rescue=True)
 
     # warm-up: every kernel is timed (HIP events on the solver's stream) to find the dominant one and the per-kernel
     # split; the timed region below then only brackets the dominant kernel, because an event pair between two kernels
     # costs stream time (the next launch is not dispatched back to back)
+    if nshard > 1 and args.period_ms < 0 and args.calibration_ticks > 0:
+        run_ticks(args.calibration_ticks)  # the pacer converges here; its state carries over
     for e in shards:
         e.native.profile(2)
         e.native.profile(1)
@@ -238,7 +283,7 @@ def main():
     # ---- batch = 1 latency (BASELINE.json config: batch=1 on one MI355X) ----
     p50_ms = None
     if not args.no_latency:
-        one = EnsembleMPC(pd, batch=1, library=lib, device=local_rank, perturb=False)
+        one = EnsembleMPC(pd, batch=1, library=lib, device=local_rank, perturb=False, tick_reuse=not args.no_tick_reuse)
         one.prepare_schedule(40)
         one.cold_solve(max_iters=100)
         lat = []
@@ -283,7 +328,7 @@ def main():
         "config": {"workload": "Talos full-dynamics MPC (fulldynamic_talos.py OCP), synthetic Talos %s model nq=%d nv=%d nu=%d, "
                                "horizon N=%d, ensemble of %d instances per GPU, one ProxDDP iteration per solve (max_iters=1, warm start)"
                                % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch),
-                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
+                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "tick_reuse": not args.no_tick_reuse, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
         "p50_ms_per_solve_batch1": p50_ms,
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),

@@ -201,7 +201,15 @@ int mpc_run_shifted(mpc_solver* s, mpc_stats* stats);
  * instance whose pass was a BCL update without a step gets its further passes then (as mpc_run_shifted does), otherwise
  * it carries on in the next tick.  The oracle runs the tick inside mpc_run_shifted_async. */
 int mpc_run_shifted_async(mpc_solver* s);
+/* Tick reuse for MPC ticks with max_iters = 1 on whole-body problems (HIP; the oracle accepts and ignores it): the full step
+ * of a tick is evaluated WITH derivatives into the knot records; when it is accepted, mpc_run_shifted of the next tick finds
+ * the records of its knots 0 .. N-2 in place (one knot on) and only refreshes the multiplier-dependent part.  Results are
+ * bit-identical to the plain path.  Parameter updates, set_stage, set_options and mpc_run invalidate the kept records. */
+int mpc_set_tick_reuse(mpc_solver* s, int32_t on);
 int mpc_wait(mpc_solver* s, mpc_stats* stats);
+/* Non-blocking look at the asynchronous ticks: *in_flight = ticks enqueued and not yet collected by mpc_wait, *completed = how
+ * many of those have already finished on the device (a host-side pacer uses it to tell whether the device keeps up). */
+int mpc_poll(mpc_solver* s, int32_t* in_flight, int32_t* completed);
 
 /* results.xs / results.us / controlFeedbacks() (fulldynamic_talos.py:403-405, :522, :548-550) / feed-forwards / multipliers. Any pointer may be NULL.
  * xs[B][N+1][nx] us[B][N][nu] K[B][N][nu][ndx] kff[B][N][nu] vs[B][N+1][nc_max] lams[B][N+1][ndx] */

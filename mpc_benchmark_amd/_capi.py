@@ -82,6 +82,8 @@ _SIGNATURES = {
     "mpc_cycle": (C.c_int, [C.c_void_p, _IP, C.c_int32, _DP, C.c_int32]),
     "mpc_set_x0": (C.c_int, [C.c_void_p, _DP]),
     "mpc_simulate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    "mpc_set_tick_reuse": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mpc_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mpc_get_x0": (C.c_int, [C.c_void_p, _DP]),
     "mpc_setup": (C.c_int, [C.c_void_p]),
     "mpc_run": (C.c_int, [C.c_void_p, _DP, _DP, C.POINTER(MpcStats)]),
@@ -206,6 +208,16 @@ class NativeSolver:
         x0 = _f64(x0)
         x0 = np.ascontiguousarray(np.broadcast_to(x0.reshape(-1, self.dims.nx), (self.dims.batch, self.dims.nx)))
         self._check(self.lib.mpc_set_x0(self._h, _dp(x0)), "mpc_set_x0")
+
+    def poll(self):
+        """-> (ticks in flight, how many of them have finished on the device); does not block."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._check(self.lib.mpc_poll(self._h, C.byref(a), C.byref(b)), "mpc_poll")
+        return a.value, b.value
+
+    def set_tick_reuse(self, on):
+        """MPC ticks: keep the records of the accepted full step for the next tick (see mpc_abi.h)."""
+        self._check(self.lib.mpc_set_tick_reuse(self._h, int(bool(on))), "mpc_set_tick_reuse")
 
     def simulate(self, substeps, dt):
         """N2: integrate knot 0's dynamics under u = us[0] - K0 difference(x, xs[0]); the result is the next measured state."""

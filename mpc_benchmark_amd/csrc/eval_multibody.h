@@ -197,12 +197,13 @@ static inline size_t multibody_work_doubles(const Layout& L) {
 // lane ids pass through an empty asm at every phase boundary: index arithmetic stays phase-local instead of being
 // kept live (and spilled) across the whole kernel — see RIC_LAUNDER in riccati_mfma.h
 #define EV_LAUNDER() do { asm volatile("" : "+v"(tid)); lane = tid & 63; wv = __builtin_amdgcn_readfirstlane(tid >> 6); } while (0)
-#define EV_PROF(slot) do { EV_LAUNDER(); if (!TRIAL && tid == 0 && a.prof && k == 1) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + 32 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
+#define EV_PROF(slot) do { EV_LAUNDER(); if (TRIAL == 0 && tid == 0 && a.prof && k == 1) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + 32 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 struct MbArgs {
   MbLds lds;
   double* scratch;        // per-workgroup HBM scratch
   size_t scratch_stride;  // doubles
+  int ncand_loop;         // TRIAL == 1: > 0 = the workgroup walks this many candidates itself (grid z = 1)
   int sim_substeps;       // TRIAL == 2 (closed-loop simulation stand-in): integration steps ...
   double sim_dt;          // ... of this length
 };
@@ -212,13 +213,18 @@ template <int TRIAL>
 __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, Layout KL, double* records, MbArgs mb, int cand0) {
   const Layout& L = a.L;
   const MbLds& S = mb.lds;
-  const int k = blockIdx.x, b = blockIdx.y, cand = blockIdx.z + cand0, nthr = blockDim.x;
+  const int k = blockIdx.x, b = blockIdx.y, nthr = blockDim.x;
+  int cand = blockIdx.z + cand0;
   int tid = threadIdx.x;
   const InstState& st = a.inst[b];
-  // TRIAL: 0 full evaluation, 1 value-only linesearch candidate, 2 closed-loop simulation stand-in (N2): knot 0's contact
+  // TRIAL: 0 full evaluation, 1 value-only linesearch candidate, 3 the alpha = 1 candidate WITH derivatives, written into the knot
+  // records themselves (tick reuse: if the full step is accepted these are the records of the next tick, one knot on),
+  // 2 closed-loop simulation stand-in (N2): knot 0's contact
   // dynamics integrated mb.sim_substeps times under u = us[0] - K0 difference(x, xs[0]) (fulldynamic_talos.py:512-530)
-  if (TRIAL != 2 && (st.done || (TRIAL && st.skip_step))) return;
+  constexpr bool CAND = (TRIAL == 1 || TRIAL == 3);  // evaluated at the candidate point x (+) alpha dx
+  if (TRIAL != 2 && (st.done || (CAND && st.skip_step))) return;
   if (TRIAL == 1 && cand > 0 && !st.ls_more) return;  // the full step was accepted: no backtracking candidates needed
+  if (TRIAL == 0 && knot_reused(a, b, k)) return;     // tick reuse: the record is there already (k_reproject refreshes its projections)
   const int n = L.n, N = L.N, nx = L.nx, nv = S.nv, nq = S.nq, nj = S.nj, nu = L.m;
   const int slot = stage_slot(a, k);
   const int32_t* desc = a.stage_desc + (size_t)slot * L.max_stage_ints;
@@ -228,11 +234,12 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   const bool kino = dyn == MPC_DYN_KINODYNAMICS_SEMIEULER;               // kinodynamics: u = [wrenches ; joint accelerations]
   const int m = (has_dyn || kino) ? nu : 0, nz = n + m, nterms = desc[5], c = desc[6];
   const int nk = has_dyn ? desc[1] : 0, nl = 6 * nk, nK = nv + nl;
-  const bool derivs = !TRIAL;
-  const double alpha = TRIAL ? ldexp(1.0, -cand) : 0.0;
-  const size_t wg = TRIAL ? (((size_t)b * L.n_alpha + cand) * (N + 1) + k) : ((size_t)b * (N + 1) + k);
+  const bool derivs = (TRIAL == 0 || TRIAL == 3);
+cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of the same knot)
+  const double alpha = CAND ? ldexp(1.0, -cand) : 0.0;
+  const size_t wg = (TRIAL == 1) ? (((size_t)b * L.n_alpha + cand) * (N + 1) + k) : ((size_t)b * (N + 1) + knot_slot(a, k));
   double* kn = records + wg * KL.knot_stride;
-  double* scr = mb.scratch + (TRIAL ? 0 : wg) * mb.scratch_stride;  // value-only passes never touch it
+  double* scr = mb.scratch + (derivs ? wg : 0) * mb.scratch_stride;  // value-only passes never touch it
   double* dsol = scr;                         // [nK][nz]: rows < nv = da, rows >= nv = dlam
   double* JtG = scr + (size_t)(nv + 12) * L.nz;  // [24][nz] HBM fallback for dense (non-diagonal) weights
   double* WJ = JtG + (size_t)24 * L.nz;
@@ -287,7 +294,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     const double* dx = a.dxs + ((size_t)b * (N + 1) + k) * n;
     if (TRIAL == 2) {
       for (int i = tid; i < nx; i += nthr) { x[i] = xs[i]; xn[i] = xs[i]; }  // simulated state ; xn = xs[0], the feedback reference
-    } else if (TRIAL) {
+    } else if (CAND) {
       if (wv == 0) state_integrate_group(MPC_SPACE_MULTIBODY, nx, n, xs, dx, alpha, x, lane, 64);
       if (wv == 1 && k < N) state_integrate_group(MPC_SPACE_MULTIBODY, nx, n, xs + nx, dx + n, alpha, xn, lane, 64);
     } else {
@@ -296,7 +303,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
     if (k < N && TRIAL != 2) {
       const double* us = a.us + ((size_t)b * N + k) * nu;
       const double* du = a.dus + ((size_t)b * N + k) * nu;
-      for (int i = tid; i < nu; i += nthr) u[i] = us[i] + (TRIAL ? alpha * du[i] : 0.0);
+      for (int i = tid; i < nu; i += nthr) u[i] = us[i] + (CAND ? alpha * du[i] : 0.0);
     }
     for (int i = tid; i < nterms * MPC_TERM_WORDS; i += nthr) lterm[i] = desc[MPC_STAGE_HEADER_WORDS + i];
     // tree tables; the bit masks (model constants) were built on the host by mpc_set_model
@@ -1280,28 +1287,33 @@ sim_loop:
   const double mu = st.mu, mud = mu * a.opt.dyn_al_scale;
   const size_t vo = ((size_t)b * (N + 1) + k) * L.c, lo = ((size_t)b * (N + 1) + k + 1) * n;
   double pen = 0, prim = 0;
-  knot_merit(KL, kn, c, (k < N) ? kn + KL.oF : nullptr, a.vs + vo, TRIAL ? a.dvs + vo : nullptr, a.vs_e + vo,
-             a.lams + lo, TRIAL ? a.dlams + lo : nullptr, a.lams_e + lo, alpha, mu, mud, derivs, red, pen, prim, tid, nthr);
+  knot_merit(KL, kn, c, (k < N) ? kn + KL.oF : nullptr, a.vs + vo, CAND ? a.dvs + vo : nullptr, a.vs_e + vo,
+             a.lams + lo, CAND ? a.dlams + lo : nullptr, a.lams_e + lo, alpha, mu, mud, derivs, red, pen, prim, tid, nthr);
   if (tid == 0) {
-    if (TRIAL) a.trial_phi[((size_t)b * L.n_alpha + cand) * (N + 1) + k] = s_cost + pen;
-    else {
+    if (CAND) a.trial_phi[((size_t)b * L.n_alpha + cand) * (N + 1) + k] = s_cost + pen;
+    if (TRIAL == 0 || TRIAL == 3) {
       double* ms = kn + KL.oMISC;
       ms[MISC_COST] = s_cost; ms[MISC_PEN] = pen; ms[MISC_PRIM] = prim; ms[MISC_NC] = (double)c; ms[MISC_M] = (double)m;
     }
   }
   EV_PROF(12);
+  // Backtracking candidates one after the other in the same workgroup: a launch with one workgroup per candidate costs
+  // 7 (N + 1) B dispatches that each need the whole LDS of a CU just to find out that the full step was accepted.
+  if (TRIAL == 1 && mb.ncand_loop > 0 && cand + 1 < cand0 + mb.ncand_loop) { ++cand; __syncthreads(); goto cand_loop; }
 #undef BELOW
 #undef INSUB
 }
 
 static inline void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout& LT, double* records, double* scratch,
-                                         size_t scratch_stride, bool trial, int cand0 = 0, int ncand = 1, int sim_substeps = 0, double sim_dt = 0.0) {
+                                         size_t scratch_stride, bool trial, int cand0 = 0, int ncand = 1, int sim_substeps = 0, double sim_dt = 0.0,
+                                         bool with_derivs = false) {
   const Layout& L = a.L;
   MbArgs mb;
   mb.lds = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m, L.nz);
   mb.scratch = scratch;
   mb.scratch_stride = scratch_stride;
   mb.sim_substeps = sim_substeps; mb.sim_dt = sim_dt;
+  mb.ncand_loop = (trial && !with_derivs && ncand > 1) ? ncand : 0;
   if (mb.lds.total_bytes > 160 * 1024) throw std::runtime_error("multibody model too large for the LDS budget of the stage kernel");
   static int attr_bytes = -1;
   if (attr_bytes != mb.lds.total_bytes) {
@@ -1309,10 +1321,12 @@ static inline void launch_eval_multibody(hipStream_t stream, const SolverArgs& a
     hipError_t e1 = hipFuncSetAttribute((const void*)k_eval_multibody<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
     hipError_t e2 = hipFuncSetAttribute((const void*)k_eval_multibody<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
     if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)k_eval_multibody<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
+    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)k_eval_multibody<3>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
     if (e1 != hipSuccess || e2 != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(LDS) failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     attr_bytes = mb.lds.total_bytes;
   }
   if (sim_substeps > 0) hipLaunchKernelGGL(k_eval_multibody<2>, dim3(1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, 0);
+  else if (trial && with_derivs) hipLaunchKernelGGL(k_eval_multibody<3>, dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);  // records = the knot records
   else if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
-  else hipLaunchKernelGGL(k_eval_multibody<1>, dim3(L.N + 1, L.B, ncand), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
+  else hipLaunchKernelGGL(k_eval_multibody<1>, dim3(L.N + 1, L.B, mb.ncand_loop > 0 ? 1 : ncand), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
 }

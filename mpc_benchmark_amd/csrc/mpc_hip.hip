@@ -50,6 +50,10 @@ struct mpc_solver {
   size_t mb_work_stride = 0;
   bool perfect_feedback = false;
   int async_passes = 0;
+  // tick reuse (mpc_set_tick_reuse): see SolverArgs
+  bool tick_reuse = false, reuse_this_pass = false;
+  int khead = 0;
+  int* d_spec = nullptr;
   // asynchronous ticks (mpc_run_shifted_async / mpc_wait): status snapshots in pinned host memory, one event each; up to
   // ASYNC_DEPTH ticks may be in flight, so that the next tick is already queued while the host looks at the previous one
   static constexpr int ASYNC_DEPTH = 2;
@@ -100,6 +104,10 @@ struct mpc_solver {
     a.stage_desc = d_stage_desc; a.stage_params = d_stage_params; a.model_i = d_model_i; a.model_d = d_model_d;
     a.xs = d_xs; a.us = d_us; a.vs = d_vs; a.lams = d_lams; a.vs_e = d_vs_e; a.lams_e = d_lams_e; a.x0 = d_x0;
     a.dxs = d_dxs; a.dus = d_dus; a.dvs = d_dvs; a.dlams = d_dlams; a.abdz = nullptr;
+    a.khead = khead; a.spec = d_spec;
+    a.spec_on = (tick_reuse && opt.max_iters == 1 && L.space == MPC_SPACE_MULTIBODY) ? 1 : 0;
+    a.reuse_on = (a.spec_on && reuse_this_pass) ? 1 : 0;
+    a.reuse_k0 = perfect_feedback ? 1 : 0;
     a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = phase_timers ? d_prof : nullptr;
     return a;
   }
@@ -121,7 +129,21 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   // Own non-blocking stream per handle: the shards of an ensemble on one GPU (several handles) run out of phase, the
   // sequential Riccati sweep of one shard (B workgroups) beside the wide per-knot kernels of the others.  Equal priorities:
   // alternating high / low priorities starved the low-priority shards (their tick took 16 - 21 ms against 14.5 ms).
-  HIP_OK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  {
+    // developer experiment: MPC_HIP_STREAM_PRIO=1 gives the handles of a process descending stream priorities
+    static int created = 0;
+    const char* pe = getenv("MPC_HIP_STREAM_PRIO");
+    if (pe && atoi(pe) > 0) {
+      int lo = 0, hi = 0;
+      HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));  // lo = least priority (largest number)
+      const int levels = lo - hi + 1;
+      const int prio = hi + (created++ % levels);
+      HIP_OK(hipStreamCreateWithPriority(&s->stream, hipStreamNonBlocking, prio));
+      if (atoi(pe) > 1) fprintf(stderr, "[mpc] stream priority %d (range %d..%d)\n", prio, hi, lo);
+    } else {
+      HIP_OK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    }
+  }
   Layout& L = s->L;
   L.N = d.horizon; L.B = d.batch; L.space = d.space; L.nx = d.nx; L.n = d.ndx; L.m = d.nu; L.c = d.nc_max > 0 ? d.nc_max : 1;
   L.nj = 0;
@@ -156,6 +178,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->d_trial_phi = s->alloc<double>(B * L.n_alpha * N1);
   s->d_inst = s->alloc<InstState>(B);
   s->d_all_done = s->alloc<int>(4);
+  s->d_spec = s->alloc<int>(B);
   s->d_prof = s->alloc<double>(B * 64);
   s->h_desc.assign(N1 * L.max_stage_ints, 0);
   s->h_params.assign(N1 * (size_t)L.max_stage_doubles, 0.0);
@@ -226,10 +249,13 @@ static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_des
   HIP_OK(hipStreamSynchronize(s->stream));  // host buffers are not retained past the call
 }
 
+// tick reuse: whatever changes the problem or the iterate behind the solver's back invalidates the kept records
+static void spec_clear(mpc_solver* s) { if (s->d_spec) HIP_OK(hipMemsetAsync(s->d_spec, 0, s->L.B * sizeof(int), s->stream)); }
+
 static int slot_of(const mpc_solver* s, int k) { return k < s->L.N ? (s->head + k) % s->L.N : s->L.N; }
 
 // ---- kernel sequences -----------------------------------------------------------------------------
-static void launch_eval(mpc_solver* s, bool trial, int cand0 = 0, int ncand = 1) {
+static void launch_eval(mpc_solver* s, bool trial, int cand0 = 0, int ncand = 1, bool with_derivs = false) {
   const Layout& L = s->L;
   SolverArgs a = s->args();
   if (ncand <= 0) return;
@@ -237,7 +263,7 @@ static void launch_eval(mpc_solver* s, bool trial, int cand0 = 0, int ncand = 1)
     if (!trial) hipLaunchKernelGGL(k_eval_vector<0>, dim3(L.N + 1, L.B, 1), dim3(64), 0, s->stream, a, s->L, s->d_knots, 0);
     else hipLaunchKernelGGL(k_eval_vector<1>, dim3(L.N + 1, L.B, ncand), dim3(64), 0, s->stream, a, s->LT, s->d_tknots, cand0);
   } else {
-    launch_eval_multibody(s->stream, a, s->LT, trial ? s->d_tknots : s->d_knots, s->d_mbwork, s->mb_work_stride, trial, cand0, ncand);
+    launch_eval_multibody(s->stream, a, s->LT, (trial && !with_derivs) ? s->d_tknots : s->d_knots, s->d_mbwork, s->mb_work_stride, trial, cand0, ncand, 0, 0.0, with_derivs);
   }
   HIP_OK(hipGetLastError());
 }
@@ -247,6 +273,8 @@ static void launch_pass(mpc_solver* s) {
   const Layout& L = s->L;
   SolverArgs a = s->args();
   s->timed(0, "k_eval_stage", [&] { launch_eval(s, false); });
+  if (a.reuse_on) hipLaunchKernelGGL(k_reproject, dim3(L.N + 1, L.B), dim3(256), 0, s->stream, a);  // records kept from the last tick: fresh projections
+  s->reuse_this_pass = false;  // further passes of the same run evaluate everything
   s->timed(1, "k_lagrangian", [&] { hipLaunchKernelGGL(k_lagrangian, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   s->timed(2, "k_decide", [&] { hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(128), 0, s->stream, a); });
   s->timed(3, "k_riccati_backward", [&] {
@@ -280,7 +308,7 @@ static void launch_pass(mpc_solver* s) {
   s->timed(5, "k_duals", [&] { hipLaunchKernelGGL(k_duals, dim3(L.N + 1, L.B), dim3(256), (L.nz + 3 * L.n + 16) * sizeof(double), s->stream, a); });
   // linesearch: evaluate the full step first; the backtracking candidates alpha = 2^-i, i >= 1, are only
   // evaluated for instances whose full step failed the Armijo test (their workgroups exit immediately otherwise)
-  s->timed(6, "k_eval_stage_trial", [&] { launch_eval(s, true, 0, 1); });
+  s->timed(6, "k_eval_stage_trial", [&] { launch_eval(s, true, 0, 1, a.spec_on != 0); });
   s->timed(7, "k_linesearch", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(1), 0, s->stream, a, 1); });
   s->timed(10, "k_eval_stage_backtrack", [&] { launch_eval(s, true, 1, L.n_alpha - 1); });
   s->timed(11, "k_linesearch_backtrack", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(1), 0, s->stream, a, 0); });
@@ -370,6 +398,7 @@ const char* mpc_last_error(mpc_solver* s) { return s ? s->err.c_str() : "null ha
 
 int mpc_set_options(mpc_solver* s, const mpc_options* opt) {
   MPC_TRY(s, {
+    spec_clear(s);
     if (!opt->rollout_linear || !opt->force_initial_condition) throw std::runtime_error("only ROLLOUT_LINEAR with force_initial_condition is implemented");
     s->opt = *opt;
     if (s->opt.ls_max_steps > s->L.n_alpha) s->opt.ls_max_steps = s->L.n_alpha;
@@ -427,6 +456,7 @@ int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double*
 
 int mpc_set_stage(mpc_solver* s, int32_t k, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params) {
   MPC_TRY(s, {
+    spec_clear(s);
     if (k < 0 || k > s->L.N) throw std::runtime_error("stage index out of range");
     upload_stage(s, slot_of(s, k), desc, n_desc, params, n_params);
   })
@@ -435,6 +465,7 @@ int mpc_set_stage(mpc_solver* s, int32_t k, const int32_t* desc, int32_t n_desc,
 int mpc_update_stage_params_batch(mpc_solver* s, int32_t count, const int32_t* ks, const int32_t* offsets, const int32_t* lens,
                                   const double* vals) {
   MPC_TRY(s, {
+    spec_clear(s);
     size_t pos = 0;
     for (int i = 0; i < count; ++i) {
       if (ks[i] < 0 || ks[i] > s->L.N) throw std::runtime_error("stage index out of range");
@@ -450,6 +481,7 @@ int mpc_update_stage_params_batch(mpc_solver* s, int32_t count, const int32_t* k
 
 int mpc_update_stage_params(mpc_solver* s, int32_t k, int32_t offset, const double* vals, int32_t n) {
   MPC_TRY(s, {
+    spec_clear(s);
     if (k < 0 || k > s->L.N) throw std::runtime_error("stage index out of range");
     if (offset < 0 || offset + n > s->L.max_stage_doubles) throw std::runtime_error("parameter update out of range");
     std::memcpy(s->h_params.data() + (size_t)slot_of(s, k) * s->L.max_stage_doubles + offset, vals, n * sizeof(double));
@@ -474,6 +506,14 @@ int mpc_set_x0(mpc_solver* s, const double* x0) {
       HIP_OK(hipMemcpyAsync(s->d_x0, x0, (size_t)s->L.B * s->L.nx * sizeof(double), hipMemcpyHostToDevice, s->stream));
       HIP_OK(hipStreamSynchronize(s->stream));
     }
+  })
+}
+
+int mpc_set_tick_reuse(mpc_solver* s, int32_t on) {
+  MPC_TRY(s, {
+    s->tick_reuse = on != 0;
+    s->reuse_this_pass = false;
+    spec_clear(s);
   })
 }
 
@@ -537,6 +577,8 @@ int mpc_setup(mpc_solver* s) {
 
 int mpc_run(mpc_solver* s, const double* xs, const double* us, mpc_stats* stats) {
   MPC_TRY(s, {
+    spec_clear(s);
+    s->reuse_this_pass = false;
     const Layout& L = s->L;
     HIP_OK(hipMemcpyAsync(s->d_xs, xs, (size_t)L.B * (L.N + 1) * L.nx * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipMemcpyAsync(s->d_us, us, (size_t)L.B * L.N * L.m * sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -546,6 +588,7 @@ int mpc_run(mpc_solver* s, const double* xs, const double* us, mpc_stats* stats)
 
 int mpc_run_shifted(mpc_solver* s, mpc_stats* stats) {
   MPC_TRY(s, {
+    if (s->tick_reuse) { s->khead = (s->khead + 1) % s->L.N; s->reuse_this_pass = true; }  // the records move one knot on with the iterate
     hipLaunchKernelGGL(k_shift, dim3(s->L.B), dim3(64), 0, s->stream, s->args(), s->perfect_feedback ? 1 : 0);
     run_impl(s, stats);
   })
@@ -560,6 +603,7 @@ int mpc_run_shifted_async(mpc_solver* s) {
       HIP_OK(hipHostMalloc((void**)&s->h_status[slot], L.B * sizeof(InstState), hipHostMallocDefault));
       HIP_OK(hipEventCreateWithFlags(&s->status_ev[slot], hipEventDisableTiming));
     }
+    if (s->tick_reuse) { s->khead = (s->khead + 1) % L.N; s->reuse_this_pass = true; }
     hipLaunchKernelGGL(k_shift, dim3(L.B), dim3(64), 0, s->stream, s->args(), s->perfect_feedback ? 1 : 0);
     hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, s->args());
     // with max_iters = 1 one pass takes the step
@@ -586,6 +630,19 @@ int mpc_wait(mpc_solver* s, mpc_stats* stats) {
     for (int b = 0; b < L.B; ++b) if (!st[b].done) done = false;
     if (!done && s->async_pending == 0) run_impl(s, stats, 1);  // continues from pass 1: the enqueued pass 0 is complete
     else report_status(L.B, st, stats);
+  })
+}
+
+int mpc_poll(mpc_solver* s, int32_t* in_flight, int32_t* completed) {
+  MPC_TRY(s, {
+    int done = 0;
+    for (int i = 0; i < s->async_pending; ++i) {
+      const hipError_t q = hipEventQuery(s->status_ev[(s->async_head + i) % mpc_solver::ASYNC_DEPTH]);
+      if (q == hipSuccess) ++done;
+      else if (q != hipErrorNotReady) HIP_OK(q);
+    }
+    if (in_flight) *in_flight = s->async_pending;
+    if (completed) *completed = done;
   })
 }
 
@@ -618,7 +675,7 @@ int mpc_get_stage_data(mpc_solver* s, int32_t k, double* xdot, double* wrenches)
     if (k < 0 || k >= L.N) throw std::runtime_error("stage index out of range");
     HIP_OK(hipStreamSynchronize(s->stream));
     for (int b = 0; b < L.B; ++b) {
-      const double* kn = s->d_knots + ((size_t)b * (L.N + 1) + k) * L.knot_stride;
+      const double* kn = s->d_knots + ((size_t)b * (L.N + 1) + (k < L.N ? (s->khead + k) % L.N : L.N)) * L.knot_stride;
       if (xdot) copy_sync(s, xdot + (size_t)b * L.n, kn + L.oXD, L.n * sizeof(double), hipMemcpyDeviceToHost);
       if (wrenches) copy_sync(s, wrenches + (size_t)b * 12, kn + L.oWR, 12 * sizeof(double), hipMemcpyDeviceToHost);
     }
@@ -648,7 +705,7 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
     if (b < 0 || b >= L.B || k < 0 || k > L.N) throw std::runtime_error("debug_get: index out of range");
     HIP_OK(hipStreamSynchronize(s->stream));
     std::vector<double> kn(L.knot_stride), g(L.gain_stride);
-    copy_sync(s, kn.data(), s->d_knots + ((size_t)b * (L.N + 1) + k) * L.knot_stride, L.knot_stride * sizeof(double), hipMemcpyDeviceToHost);
+    copy_sync(s, kn.data(), s->d_knots + ((size_t)b * (L.N + 1) + (k < L.N ? (s->khead + k) % L.N : L.N)) * L.knot_stride, L.knot_stride * sizeof(double), hipMemcpyDeviceToHost);
     copy_sync(s, g.data(), s->d_gains + ((size_t)b * (L.N + 1) + k) * L.gain_stride, L.gain_stride * sizeof(double), hipMemcpyDeviceToHost);
     const int n = L.n, nz = L.nz, c = (int)kn[L.oMISC + MISC_NC], m = (int)kn[L.oMISC + MISC_M], nzk = n + m;
     const std::string nm(name);

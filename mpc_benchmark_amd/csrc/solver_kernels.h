@@ -25,6 +25,14 @@ struct SolverArgs {
   // iterate
   double *xs, *us, *vs, *lams, *vs_e, *lams_e, *x0;
   double *dxs, *dus, *dvs, *dlams;
+  // Tick reuse (MPC ticks with max_iters = 1): the full step of tick t is evaluated WITH derivatives straight into the knot
+  // records, which are ring-indexed like the stage tables; when it is accepted, tick t + 1 finds the records of its knots
+  // 0 .. N-2 already there and only re-projects the constraint values under the fresh multipliers.
+  int khead;      // ring head of the N running knot records (the terminal record has its own slot)
+  int spec_on;    // the alpha = 1 candidate of this pass writes full records (k_eval_multibody<3>)
+  int reuse_on;   // this tick may reuse records marked valid in spec[]
+  int reuse_k0;   // ... knot 0 included (perfect-model feedback: the measured state is the predicted one)
+  int* spec;      // [B] 1: the records of instance b hold the evaluation of its current iterate shifted by one knot
   double* abdz;  // [B][N][n]: [A B] [dx; du] per knot, written by the forward sweep for k_duals (nullptr: k_duals forms it itself)
   double *knots, *gains, *work;
   double *trial_phi;  // [B][n_alpha][N+1]
@@ -33,7 +41,10 @@ struct SolverArgs {
   double* prof;  // [B][64] phase cycle counters: 0..31 Riccati kernel, 32..63 whole-body stage kernel (knot 1)
 };
 
-DEV double* knot_ptr(const SolverArgs& a, int b, int k) { return a.knots + ((size_t)b * (a.L.N + 1) + k) * a.L.knot_stride; }
+DEV int knot_slot(const SolverArgs& a, int k) { return k < a.L.N ? (a.khead + k) % a.L.N : a.L.N; }
+DEV double* knot_ptr(const SolverArgs& a, int b, int k) { return a.knots + ((size_t)b * (a.L.N + 1) + knot_slot(a, k)) * a.L.knot_stride; }
+// true if tick reuse applies to knot k of instance b: its record is already the evaluation of the current iterate
+DEV bool knot_reused(const SolverArgs& a, int b, int k) { return a.reuse_on && a.spec[b] && k < a.L.N - 1 && (k > 0 || a.reuse_k0); }
 DEV double* gain_ptr(const SolverArgs& a, int b, int k) { return a.gains + ((size_t)b * (a.L.N + 1) + k) * a.L.gain_stride; }
 DEV int stage_slot(const SolverArgs& a, int k) { return k < a.L.N ? (a.head + k) % a.L.N : a.L.N; }
 
@@ -727,11 +738,14 @@ __global__ void k_accept(SolverArgs a) {
 __global__ void k_after_step(SolverArgs a) {
   InstState& st = a.inst[blockIdx.x];
   if (st.done) return;
-  if (!st.skip_step && !(st.stalled & 1)) {
+  const bool stepped = !st.skip_step && !(st.stalled & 1);
+  if (stepped) {
     st.stalled = 0;
     st.num_iters += 1;
     if (st.num_iters >= a.opt.max_iters) st.done = 1;
   }
+  // the records now hold the evaluation of the accepted iterate iff the full step (the one evaluated with derivatives) was taken
+  if (a.spec) a.spec[blockIdx.x] = (a.spec_on && stepped && st.alpha == 1.0) ? 1 : 0;
 }
 
 // setup(): multipliers and their estimates to zero, fresh per-instance solver state (mu = mu_init).  One launch instead

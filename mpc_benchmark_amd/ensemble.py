@@ -15,7 +15,7 @@ from .aligator import _core as core
 
 class EnsembleMPC:
     def __init__(self, problem_def, batch=1, library=None, device=0, seed=20250304, perturb=True, sigma_q=0.02, sigma_v=0.05, perturb_dofs=None,
-                 closed_loop=None, forward_mode=0):
+                 closed_loop=None, forward_mode=0, tick_reuse=False):
         """``problem_def``: a FullDynamicsProblem / CentroidalProblem-like builder (``build``, ``stage_for_tick``,
         ``make_solver``, ``initial_guess``).  ``forward_mode``: mpc_options.forward_mode (1 for shards that share a GPU)."""
         self.pd = problem_def
@@ -44,6 +44,8 @@ class EnsembleMPC:
         self.options = solver._options()
         self.options.forward_mode = int(forward_mode)
         self.native.set_options(self.options)
+        if tick_reuse:  # the accepted full step's evaluation serves the next tick (bit-identical results, see mpc_abi.h)
+            self.native.set_tick_reuse(True)
         if self.ctx.model is not None:
             self.native.set_model(*self.ctx.model_tables())
         for k, (desc, params) in enumerate(tables):

@@ -155,6 +155,8 @@ int mpc_run_shifted(mpc_solver* h, mpc_stats* stats) {
 }
 
 int mpc_run_shifted_async(mpc_solver* h) { return mpc_run_shifted(h, nullptr); }
+int mpc_set_tick_reuse(mpc_solver*, int32_t) { return 0; }
+int mpc_poll(mpc_solver*, int32_t* in_flight, int32_t* completed) { if (in_flight) *in_flight = 0; if (completed) *completed = 0; return 0; }  // ticks run inside the call  // an optimisation of the HIP library only
 int mpc_wait(mpc_solver* h, mpc_stats* stats) {
   MPC_TRY(h, { if (stats) for (int b = 0; b < h->s.dims.batch; ++b) stats[b] = h->s.inst[b].stats; })
 }

@@ -98,3 +98,29 @@ def test_episode_restart_replays_the_walk():
     for t in range(5):
         ens.step()
         assert _rel(ens.results(gains=False)["xs"], first[t]) < 1e-2
+
+
+@pytest.mark.parametrize("horizon,ticks", [(12, 30), (40, 12)])
+def test_tick_reuse_is_bit_identical(horizon, ticks):
+    """mpc_set_tick_reuse: the accepted full step's evaluation (with derivatives) becomes the next tick's knot records.  Same
+    arithmetic on the same points: trajectories, controls and gains equal the plain path bit for bit — across contact switches
+    of the schedule, ticks with backtracking (the kept records are dropped then) and the asynchronous two-deep drive."""
+    hip = _capi.load_hip_library()
+    out = {}
+    for reuse in (False, True):
+        pd = FullDynamicsProblem(horizon=horizon)
+        ens = EnsembleMPC(pd, batch=4, library=hip, seed=31, tick_reuse=reuse)
+        ens.prepare_schedule(ticks + 2)
+        ens.cold_solve(max_iters=60)
+        hist, alphas = [], []
+        ens.step_async()
+        for _ in range(ticks - 1):
+            ens.step_async()
+            st = ens.wait()
+            alphas.append([s.alpha for s in st])
+        ens.wait()
+        r = ens.results(gains=True)
+        out[reuse] = (r["xs"].copy(), r["us"].copy(), r["K"].copy(), np.array(alphas))
+    assert np.array_equal(out[False][3], out[True][3])
+    for a, b in zip(out[False][:3], out[True][:3]):
+        assert np.array_equal(a, b)
