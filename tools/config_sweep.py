@@ -17,7 +17,7 @@ lib = _capi.load_hip_library()
 
 
 def run(name, pd, batch, ticks, warm, **kw):
-    ens = EnsembleMPC(pd, batch=batch, library=lib, **kw)
+    ens = EnsembleMPC(pd, batch=batch, library=lib, tick_reuse=True, **kw)  # (whole-body problems only; ignored for the centroidal one)
     ens.prepare_schedule(ticks + warm + 4)
     st = ens.cold_solve(max_iters=100)
     for _ in range(warm):

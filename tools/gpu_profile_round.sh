@@ -11,8 +11,8 @@ python3 bench.py > $OUT/bench.log 2> $OUT/bench.err
 tail -c 3000 $OUT/bench.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o st -- python3 bench.py $BENCH_ARGS > $OUT/bench_under_rocprof.log 2>&1
 python3 tools/trace_summary.py $(find $OUT/stats -name '*kernel_trace.csv' | head -1) $OUT/kernel_trace_summary.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pf -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pw -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-latency > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pf -- python3 bench.py --steps 3 --warmup 1 --calibration-ticks 4 --no-cpu-baseline --no-latency > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pw -- python3 bench.py --steps 3 --warmup 1 --calibration-ticks 4 --no-cpu-baseline --no-latency > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -o cf -- tools/pmc/pmc_calib > $OUT/cal_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -o cw -- tools/pmc/pmc_calib > $OUT/cal_write.log 2>&1
 python3 tools/pmc/summarize.py $OUT/traffic.json $OUT/pmc_fetch $OUT/pmc_write $OUT/cal_fetch $OUT/cal_write 1073741824 > $OUT/traffic.log 2>&1
