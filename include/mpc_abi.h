@@ -204,7 +204,8 @@ int mpc_run_shifted_async(mpc_solver* s);
 /* Tick reuse for MPC ticks with max_iters = 1 on whole-body problems (HIP; the oracle accepts and ignores it): the full step
  * of a tick is evaluated WITH derivatives into the knot records; when it is accepted, mpc_run_shifted of the next tick finds
  * the records of its knots 0 .. N-2 in place (one knot on) and only refreshes the multiplier-dependent part.  Results are
- * bit-identical to the plain path.  Parameter updates, set_stage, set_options and mpc_run invalidate the kept records. */
+ * bit-identical to the plain path.  Parameter updates, set_stage, set_options and mpc_run invalidate the kept records.
+ * A no-op on vector-space problems (centroidal): accepted, nothing changes. */
 int mpc_set_tick_reuse(mpc_solver* s, int32_t on);
 int mpc_wait(mpc_solver* s, mpc_stats* stats);
 /* Non-blocking look at the asynchronous ticks: *in_flight = ticks enqueued and not yet collected by mpc_wait, *completed = how

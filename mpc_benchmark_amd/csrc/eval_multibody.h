@@ -949,11 +949,20 @@ sim_loop:
         for (int l = 0; l < 6; ++l) s += Jl6[6 * r + l] * JL[l * nz + z];
         kn[KL.oAB + (size_t)r * KL.nz + z] = s;
       }
+      // the same rows in factored form (layout.h, oD12): D1_b = Jlog6(G) Jq6, Dd_b = dt Jlog6(G) Jexp6
+      if (tid < 72) {
+        const int e = tid % 36, r = e / 6, cc = e % 6;
+        const double* Rm = (tid < 36) ? Jq6 : Je6;
+        double s = 0;
+        for (int l = 0; l < 6; ++l) s += Jl6[6 * r + l] * Rm[6 * l + cc];
+        kn[KL.oD12 + tid] = (tid < 36) ? s : dt * s;
+      } else if (tid == 72) { kn[KL.oD12 + 72] = dt; kn[KL.oD12 + 73] = 1.0; }
       __syncthreads();
     }
   }
 
   else {
+    if (derivs && tid == 0) kn[KL.oD12 + 73] = 0.0;  // no dynamics rows: nothing to factor
     __syncthreads();  // the SE(3) table must be complete before the terms read it
   }
 

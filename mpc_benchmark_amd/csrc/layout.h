@@ -10,7 +10,7 @@ struct Layout {
   int nj;  // moving joints of the multibody model (0 for vector spaces)
   int model_mask_off;  // int32 offset of the 64-bit tree masks (ancestors | subtree | path dofs, nj each) in the device model table
   // offsets inside one knot record (doubles)
-  int oH, oG, oAB, oF, oE6, oCV, oCD, oLO, oHI, oDT, oACT, oCT, oMISC, oXD, oWR, oXN, knot_stride;
+  int oH, oG, oAB, oF, oE6, oD12, oCV, oCD, oLO, oHI, oDT, oACT, oCT, oMISC, oXD, oWR, oXN, knot_stride;
   // offsets inside one gain record
   int oP, op, oK, ok, oKnu, oknu, oMx, omx, oT6, oPhi, ophi, gain_stride;
   // backward-sweep scratch per instance
@@ -37,6 +37,9 @@ static inline void make_layout(Layout& L) {
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += align2(cnt); return r; };
   L.oH = take(nz * nz); L.oG = take(nz); L.oAB = take(n * nz); L.oF = take(n); L.oE6 = take(36);
+  // structure of the semi-implicit Euler rows: [A B]_q = D1 [I 0 0] + Dd [A B]_v with D1, Dd = identity, dt on the joints and 6x6 on the
+  // base: D1_b (36) | Dd_b (36) | dt | valid flag — the Riccati sweep then multiplies with the v rows of [A B] only
+  L.oD12 = take(74);
   L.oCV = take(c); L.oCD = take(c * nz); L.oLO = take(c); L.oHI = take(c); L.oDT = take(c); L.oACT = take(c); L.oCT = take(c);
   L.oMISC = take(MISC_COUNT); L.oXD = take(n); L.oWR = take(12); L.oXN = take(L.nx);
   L.knot_stride = o;

@@ -158,7 +158,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
     auto take = [&](int cnt) { int r = o; o += align2(cnt); return r; };
     T.oCV = take(L.c); T.oCT = take(L.c); T.oLO = take(L.c); T.oHI = take(L.c); T.oDT = take(L.c); T.oACT = take(L.c);
     T.oF = take(L.n); T.oMISC = take(MISC_COUNT);
-    T.oH = T.oG = T.oAB = T.oE6 = T.oCD = T.oXD = T.oWR = T.oXN = 0;  // never written in value-only mode
+    T.oH = T.oG = T.oAB = T.oE6 = T.oD12 = T.oCD = T.oXD = T.oWR = T.oXN = 0;  // never written in value-only mode
     T.knot_stride = o;
   }
   if (s->riccati_lds() > 160 * 1024) throw std::runtime_error("problem dimensions exceed the LDS budget of the Riccati kernel");
@@ -198,6 +198,8 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   }
   if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0);     // panel-wise G when the whole G does not fit
   if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0, 0);  // large m: Sh^T out of LDS as well
+  // whole-body dynamics rows come in factored form (layout.h, oD12): the sweep multiplies with the v rows of [A B] only
+  if (L.space == MPC_SPACE_MULTIBODY && s->ric.gfull && L.n % 2 == 0 && L.n >= 24 && !getenv("MPC_HIP_DENSE_AB")) { s->ric.sq = 1; s->ric.nv = L.n / 2; }
   s->cl = make_cl_lds(L.n, L.m);
   if (s->cl.total_bytes <= 160 * 1024)
     HIP_OK(hipFuncSetAttribute((const void*)k_closed_loop, hipFuncAttributeMaxDynamicSharedMemorySize, s->cl.total_bytes));
@@ -206,6 +208,8 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   {
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 96, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
   }
   HIP_OK(hipStreamSynchronize(s->stream));
@@ -280,6 +284,8 @@ static void launch_pass(mpc_solver* s) {
   s->timed(3, "k_riccati_backward", [&] {
     if (s->use_mfma_riccati && s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_SMALL_THREADS, 16>), dim3(L.B), dim3(RIC_SMALL_THREADS), s->ric.total_bytes, s->stream, a, s->ric);  // small problems: one wavefront
+    else if (s->use_mfma_riccati && s->ric.sq && s->ric.np <= 80) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
+    else if (s->use_mfma_riccati && s->ric.sq) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 96, true>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
     else if (s->use_mfma_riccati && s->ric.np <= 80) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);  // fewer tiles per wavefront: lower register pressure
     else if (s->use_mfma_riccati) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 96>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
     else hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);
@@ -511,7 +517,9 @@ int mpc_set_x0(mpc_solver* s, const double* x0) {
 
 int mpc_set_tick_reuse(mpc_solver* s, int32_t on) {
   MPC_TRY(s, {
-    s->tick_reuse = on != 0;
+    // whole-body problems only: the vector-space stage kernel keeps its records in knot order (no ring), so the ring head must not move
+    s->tick_reuse = on != 0 && s->L.space == MPC_SPACE_MULTIBODY;
+    if (!s->tick_reuse) s->khead = 0;  // records go back to knot order; they are rewritten by the next pass (spec cleared below)
     s->reuse_this_pass = false;
     spec_clear(s);
   })

@@ -37,10 +37,13 @@
 // each reload (s_waitcnt vmcnt(0)) also drains the global loads in flight.  Passing the lane ids through an empty
 // asm at each phase boundary makes all index arithmetic phase-local: recomputed (a few integer ops), never spilled.
 #define RIC_LAUNDER() do { asm volatile("" : "+v"(tid), "+v"(lane)); wv = __builtin_amdgcn_readfirstlane(tid >> 6); } while (0)
+// nv, ks, Ke of the structured products, derived inside the phase that uses them (as scalars living across the whole knot loop they
+// push the SGPR spills past what the spill VGPRs hold, and every reload of those drains the loads in flight)
+#define RIC_SQ_DIMS() int n_l_ = n; asm volatile("" : "+s"(n_l_)); const int nv = SQ ? (n_l_ >> 1) : 0, ks = SQ ? (nv & ~3) : 0, Ke = SQ ? ((n_l_ + 3) & ~3) - ks : np; (void)nv; (void)ks; (void)Ke
 #define RIC_PROF(slot) do { RIC_LAUNDER(); if (tid == 0 && a.prof) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 struct RicLds {
-  int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb, gfull, st_lds, ovl;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
+  int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb, gfull, st_lds, ovl, sq, nv;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
   int PT, R1, LP, LI, AB, GP, vec, iwork, total_bytes;
   // KKT / value-update workspace carved from R1 once AB is dead
   int Lr, LIr, W, ST, CT, VX, Y, SC, LIs;
@@ -87,7 +90,8 @@ static inline RicLds make_ric_lds(int n, int m, int c, int gfull = 1, int st_lds
   }
   o = end1 > end2 ? end1 : end2;
   if (end3 > o) o = end3;
-  s.vec = take(7 * s.nzp + 2 * c + 96);  // ph ft vv w gh pvec (6 nzp) | dtl kvc (2 c) | e6l wred t6l (92) | gpre (nzp)
+  s.vec = take(7 * s.nzp + 2 * c + 96 + 80);  // ph ft vv w gh pvec (6 nzp) | dtl kvc (2 c) | e6l wred t6l (92) | gpre (nzp) | d12l (74)
+  s.sq = 0; s.nv = 0;  // structured [A B] (set by the caller for whole-body problems, see step 5)
   s.iwork = o;
   s.total_bytes = o * 8 + (c + 72) * 4;
   return s;
@@ -126,10 +130,12 @@ DEV double wave_sum_r(double v) { return wave_sum(v); }  // DPP reduction of sol
 // one wavefront per SIMD (LDS-bound occupancy anyway): let the register allocator use the whole 512-entry file
 // RT = threads per workgroup.  RT = RIC_THREADS (8 wavefronts) is the general kernel (np <= 96, nzp <= 128); RT = RIC_SMALL_THREADS is the
 // small-problem variant (np = mp = 16, at most RT constraint rows: the centroidal OCP) — the same code with fewer wavefronts.
-template <int RT, int NPMAX>
+// SQ: structured dynamics rows (whole-body problems, layout.h oD12): only the v rows of [A B] are loaded and multiplied
+template <int RT, int NPMAX, bool SQ = false>
 __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   constexpr int NWV = RT / 64, NBMAX = NPMAX / 16, NZTMAX = NPMAX > 16 ? 8 : 2;
-  constexpr int AB_ROWS = (NPMAX + NWV - 1) / NWV;                                // register prefetch capacity: rows of [A B] per wavefront
+  constexpr int PT_ROWS = (NPMAX + NWV - 1) / NWV;                                // rows of Pt per wavefront
+  constexpr int AB_ROWS = SQ ? (NPMAX / 2 + NWV - 1) / NWV : PT_ROWS;             // register prefetch capacity: rows of [A B] per wavefront (SQ: v rows only)
   constexpr int RIC_SERIES_TILES = (NBMAX * (NBMAX + 1) / 2 + NWV - 1) / NWV;     // lower-triangle output tiles per wavefront
   constexpr int RIC_G_TILES = (NBMAX * NZTMAX + NWV - 1) / NWV;                   // tiles of G per wavefront
   constexpr int RIC_U_TILES = NPMAX > 16 ? 2 : 1;
@@ -159,6 +165,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   double* wred = e6l + 40;  // per-wavefront partial sums (<= 16)
   double* t6l = e6l + 56;   // T6 = (-E6)^-1 (36)
   double* gpre = e6l + 92;  // gradient of the knot (nz); vec holds 7 nzp + 2 c + 92 <= 8 (nzp + c) + 64 doubles
+  double* d12l = gpre + nzp;  // D1_b (36) | Dd_b (36) | dt | valid (layout.h, oD12)
   double* wk = a.work + (size_t)b * L.work_stride;
   double* Hh = wk + L.wHh;  // nz x nz, leading dimension nz (L2-resident scratch)
   double* ST = S.st_lds ? sm + S.ST : wk + L.wG;  // Sh^T (mp x np)
@@ -213,6 +220,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     const double* kn = knot_ptr(a, b, k);
     double* g = gain_ptr(a, b, k);
     const int m = (int)pre_m, c = (int)pre_c;
+    const double dreg = SQ ? kn[L.oD12 + (tid < 74 ? tid : 0)] : 0.0;  // in flight during step 1
     // ---- 1. active rows (ballot prefix; wave q owns rows 64q .. 64q+63, c <= 256), T6 = (-E6)^-1 ----
     const int arow = wv * 64 + lane;
     const bool is_act = (arow < c) && (pre_act != 0.0);
@@ -261,6 +269,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     }
     const double* T6 = t6l;  // LDS copy; the gain record gets it below
     if (tid < 36) g[L.oT6 + tid] = t6l[tid];
+    if (SQ && tid < 74) d12l[tid] = dreg;
     if (ff) {
       double* tmp = LP;  // scratch (LP is dead here)
       for (int idx = tid; idx < n * 6; idx += nthr) {
@@ -286,6 +295,9 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       for (int i = tid; i < n; i += nthr) ph[i] = pvec[i];
     }
     __syncthreads();
+    // Structured knot: [A B]_q = D1 [I 0 0] + Dd [A B]_v (semi-implicit Euler), so Pt [A B] and [A B]^T G need the v rows of [A B]
+    // only: K = nv instead of n in both products of step 5 (ks .. ks + Ke: the v rows, aligned down to the MFMA depth of 4)
+    constexpr bool sq = SQ;  // every stage knot of a whole-body problem has dynamics rows (valid flag d12l[73] = 1)
     RIC_PROF(1);
     // ---- 2. ||Ph||_F ; vv = Ph ft + ph ----
     {
@@ -327,13 +339,14 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     {
       // column of [A B] behind padded column zp (x columns 0..n-1, u columns np..np+m-1), clamped to a valid one so
       // that every load is unconditional (straight-line code: the loads of all rows are in flight together)
+      RIC_SQ_DIMS();
       const int z0 = lane, z1 = lane + 64;
       const bool ok0 = z0 < n || (z0 >= np && z0 - np < m), ok1 = z1 < n || (z1 >= np && z1 - np < m);
       const int c0 = ok0 ? (z0 < n ? z0 : n + z0 - np) : 0, c1 = ok1 ? (z1 < n ? z1 : n + z1 - np) : 0;
       const double* ab0 = kn + L.oAB;
 #pragma unroll
       for (int q = 0; q < AB_ROWS; ++q) {
-        const int i = wv + nw * q;  // wave-uniform row
+        const int i = (SQ ? nv : 0) + wv + nw * q;  // wave-uniform row
         const double* src = ab0 + (size_t)(i < n ? i : 0) * nz;
         // mask by multiplication: with a select the compiler makes the load itself conditional (branch + s_waitcnt
         // vmcnt(0) per row: the 12 rows of a wavefront were fetched one after the other, 4 us per knot)
@@ -475,7 +488,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     // row i of Pt also holds row i of [A B] in registers: its share of gh = grad + [A B]^T w accumulates on the fly.
     double gp0 = 0.0, gp1 = 0.0;
 #pragma unroll
-    for (int q = 0; q < AB_ROWS; ++q) {
+    for (int q = 0; q < PT_ROWS; ++q) {
       const int i = wv + nw * q;
       if (i < n) {
         double s = 0;
@@ -483,12 +496,84 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         s = wave_sum_r(s);
         const double wi = vv[i] - mud * s;
         if (lane == 0) w[i] = wi;
-        gp0 += abr[q][0] * wi; gp1 += abr[q][1] * wi;
+        if constexpr (!SQ) { gp0 += abr[q][0] * wi; gp1 += abr[q][1] * wi; }
       }
     }
     for (int i = tid; i < n; i += nthr) g[L.omx + i] = ft[i] - mud * ph[i];
+    if (sq) {
+      // v rows of PT, each by the wavefront that has just stored it (the q rows stay as they are): row nv + jq <- row jq of
+      // Pe^T = Dd^T Pt[q rows] + Pt[v rows], then its v columns <- (. Dd + .) so that the v rows of the product of step 5 are
+      // Ge = Dd^T G_q + G_v, what Hh needs, directly
+      RIC_SQ_DIMS();
+      const double dts = d12l[72];
+      const int i0 = nv + ((wv - nv) & (nw - 1));
+      // all reads of a pass first, then its writes: the rows of a wavefront are independent, but through the one pointer the compiler
+      // would keep them in order (a dependent LDS round trip per row and column half)
+      double t0[AB_ROWS], t1[AB_ROWS];
+#pragma unroll
+      for (int q = 0; q < AB_ROWS; ++q) {
+        const int i = i0 + nw * q, jq = i - nv;
+        t0[q] = t1[q] = 0.0;
+        if (i < n) {
+          const int j0 = lane, j1 = (lane + 64 < n) ? lane + 64 : lane;
+          t0[q] = PT[i * ldp + j0]; t1[q] = PT[i * ldp + j1];
+          if (jq >= 6) { t0[q] += dts * PT[jq * ldp + j0]; t1[q] += dts * PT[jq * ldp + j1]; }
+          else for (int l = 0; l < 6; ++l) { const double dl = d12l[36 + l * 6 + jq]; t0[q] += dl * PT[l * ldp + j0]; t1[q] += dl * PT[l * ldp + j1]; }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < AB_ROWS; ++q) {
+        const int i = i0 + nw * q;
+        if (i < n) { PT[i * ldp + lane] = t0[q]; if (lane + 64 < n) PT[i * ldp + lane + 64] = t1[q]; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int lq = (lane < nv) ? lane : 0;
+#pragma unroll
+      for (int q = 0; q < AB_ROWS; ++q) {
+        const int i = i0 + nw * q;
+        t0[q] = 0.0;
+        if (i < n) {
+          t0[q] = PT[i * ldp + nv + lq];
+          if (lq >= 6) t0[q] += dts * PT[i * ldp + lq];
+          else for (int l = 0; l < 6; ++l) t0[q] += d12l[36 + l * 6 + lq] * PT[i * ldp + l];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < AB_ROWS; ++q) {
+        const int i = i0 + nw * q;
+        if (i < n && lane < nv) PT[i * ldp + nv + lane] = t0[q];
+      }
+    }
     RIC_PROF(6);
     // ---- 4. AB into LDS (zero padded; u-columns start at np) ; gh from the per-wavefront partial sums (GP is free) ----
+    if constexpr (SQ) {
+      RIC_SQ_DIMS();
+#pragma unroll
+      for (int q = 0; q < AB_ROWS; ++q) {
+        const int i = nv + wv + nw * q;
+        if (i < np) { if (lane < nzp) AB[i * nzp + lane] = abr[q][0]; if (lane + 64 < nzp) AB[i * nzp + lane + 64] = abr[q][1]; }
+      }
+      for (int idx = tid; idx < (nv - ks) * nzp; idx += nthr) AB[ks * nzp + idx] = 0.0;  // q rows inside the first MFMA group
+      __syncthreads();
+      // gh = grad + [A B]^T w = grad + [I 0 0]^T D1^T w_q + [A B]_v^T (Dd^T w_q + w_v), by the last two wavefronts (they have the fewest tiles below)
+      const int zp = tid - (nthr - 128);
+      if (zp >= 0 && zp < nzp) {
+        const int z = (zp < n) ? zp : ((zp >= np && zp - np < m) ? n + zp - np : -1);
+        if (z >= 0) {
+          const double dts = d12l[72];
+          double sacc = gpre[z];
+          if (zp < 6) { for (int l = 0; l < 6; ++l) sacc += d12l[l * 6 + zp] * w[l]; }
+          else if (zp < nv) sacc += w[zp];
+          for (int kq = 0; kq < 6; ++kq) {
+            double we = w[nv + kq];
+            for (int l = 0; l < 6; ++l) we += d12l[36 + l * 6 + kq] * w[l];
+            sacc += AB[(nv + kq) * nzp + zp] * we;
+          }
+          for (int kq = 6; kq < nv; ++kq) sacc += AB[(nv + kq) * nzp + zp] * (w[nv + kq] + dts * w[kq]);
+          gh[z] = sacc;
+        }
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < AB_ROWS; ++q) {
       const int i = wv + nw * q;
@@ -501,19 +586,21 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       const int z = (zp < n) ? zp : ((zp >= np && zp - np < m) ? n + zp - np : -1);
       if (z >= 0) { double s = gpre[z]; for (int q = 0; q < nw; ++q) s += GP[q * nzp + zp]; gh[z] = s; }
     }
+    }
     RIC_PROF(7);
     if (S.gfull) {
     // ---- 5. G = Pt [A B] : every 16x16 tile dealt round-robin to the wavefronts, kept in registers until all of
     // them are done (barrier), then G_x overwrites PT (Pt itself is no longer needed: it went to the gain record
     // above) and G_u goes to GP ; Hh = H + [A B]^T G on the lower block triangle only (Hh is symmetric) ----
     {
+      RIC_SQ_DIMS();
       const int ngt = nb * nzt;
       d4_t gres[RIC_G_TILES];
 #pragma unroll
       for (int sidx = 0; sidx < RIC_G_TILES; ++sidx) {
         const int t = wv + sidx * nw;
         gres[sidx] = d4_t{0, 0, 0, 0};
-        if (t < ngt) mma_tile<false>(gres[sidx], PT + (t / nzt) * 16, 1, ldp, AB + (t % nzt) * 16, nzp, 1, np, lane);  // Pt symmetric
+        if (t < ngt) mma_tile<false>(gres[sidx], PT + ks * ldp + (t / nzt) * 16, 1, ldp, AB + ks * nzp + (t % nzt) * 16, nzp, 1, Ke, lane);  // Pt symmetric
       }
       __syncthreads();
 #pragma unroll
@@ -521,6 +608,17 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         const int t = wv + sidx * nw;
         if (t < ngt) {
           const int ri = t / nzt, cj = t % nzt;
+          if (sq && cj * 16 < nv) {  // + Pt_q D1 on the q columns, read at the tile's own place in PT before G_x overwrites it (rows nv.. hold
+            const int col = cj * 16 + (lane & 15);  // Pe^T there: the v rows of the product are Ge = Dd^T G_q + G_v, what Hh needs)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int row = ri * 16 + (lane >> 4) + 4 * q;
+              double ad = 0.0;
+              if (col >= 6) ad = (col < nv) ? PT[row * ldp + col] : 0.0;
+              else for (int l = 0; l < 6; ++l) ad += PT[row * ldp + l] * d12l[l * 6 + col];
+              gres[sidx][q] += ad;
+            }
+          }
           if (cj < nb) tile_store(PT + (ri * 16) * ldp + cj * 16, ldp, gres[sidx], lane);
           else tile_store(GU + (ri * 16) * mp + (cj - nb) * 16, mp, gres[sidx], lane);
         }
@@ -541,8 +639,19 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
           h[q] = (zr[q] >= 0 && zc >= 0) ? kn[L.oH + zr[q] * nz + zc] : 0.0;
         }
         d4_t acc = d4_t{0, 0, 0, 0};
-        if (cj < nb) mma_tile<false>(acc, AB + zi * 16, 1, nzp, PT + cj * 16, ldp, 1, np, lane);
-        else mma_tile<false>(acc, AB + zi * 16, 1, nzp, GU + (cj - nb) * 16, mp, 1, np, lane);
+        if (cj < nb) mma_tile<false>(acc, AB + ks * nzp + zi * 16, 1, nzp, PT + ks * ldp + cj * 16, ldp, 1, Ke, lane);
+        else mma_tile<false>(acc, AB + ks * nzp + zi * 16, 1, nzp, GU + ks * mp + (cj - nb) * 16, mp, 1, Ke, lane);
+        if (sq && zi * 16 < nv) {  // + [I 0 0]^T D1^T G_q on the q rows (x tiles only: cj <= zi < nb)
+          const int col = cj * 16 + (lane & 15);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int rp = zi * 16 + (lane >> 4) + 4 * q;
+            double ad = 0.0;
+            if (rp >= 6) ad = (rp < nv) ? PT[rp * ldp + col] : 0.0;
+            else for (int l = 0; l < 6; ++l) ad += d12l[l * 6 + rp] * PT[l * ldp + col];
+            acc[q] += ad;
+          }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[q] = h[q] + acc[q];
       };

@@ -124,3 +124,22 @@ def test_tick_reuse_is_bit_identical(horizon, ticks):
     assert np.array_equal(out[False][3], out[True][3])
     for a, b in zip(out[False][:3], out[True][:3]):
         assert np.array_equal(a, b)
+
+
+def test_tick_reuse_is_inert_on_vector_space_problems():
+    """The centroidal problem keeps its knot records in knot order (no ring): mpc_set_tick_reuse is accepted and changes
+    nothing, tick after tick."""
+    from mpc_benchmark_amd.problems.centroidal import CentroidalProblem
+    hip = _capi.load_hip_library()
+    out = {}
+    for reuse in (False, True):
+        pd = CentroidalProblem(horizon=20)
+        ens = EnsembleMPC(pd, batch=2, library=hip, seed=5, perturb=False, tick_reuse=reuse)
+        ens.prepare_schedule(10)
+        ens.cold_solve(max_iters=40)
+        for _ in range(8):
+            ens.step()
+        r = ens.results(gains=True)
+        out[reuse] = (r["xs"].copy(), r["us"].copy(), r["K"].copy())
+    for a, b in zip(out[False], out[True]):
+        assert np.array_equal(a, b)
