@@ -725,6 +725,7 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
     else if (nm == "AB") mat(kn.data() + L.oAB, k < L.N ? n : 0, nzk, nz);
     else if (nm == "f") mat(kn.data() + L.oF, 1, k < L.N ? n : 0, n);
     else if (nm == "E6") mat(kn.data() + L.oE6, 6, 6, 6);
+    else if (nm == "D12") mat(kn.data() + L.oD12, 1, 74, 74);  // D1_b (36) | Dd_b (36) | dt | valid (layout.h)
     else if (nm == "cval") mat(kn.data() + L.oCV, 1, c, c);
     else if (nm == "CD") mat(kn.data() + L.oCD, c, nzk, nz);
     else if (nm == "cost") mat(kn.data() + L.oMISC + MISC_COST, 1, 1, 1);

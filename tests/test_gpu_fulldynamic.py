@@ -120,3 +120,23 @@ def test_mpc_ticks_with_cycling_and_references(hip_lib, oracle_lib):
             hist.append(np.concatenate([np.ravel(xs), np.ravel(us)]))
         traj[name] = np.array(hist)
     assert _rel(traj["hip"], traj["ref"]) < 1e-6
+
+
+@pytest.mark.parametrize("complete_model", [False, True])
+def test_dynamics_rows_factored_form(hip_lib, complete_model):
+    """The stage kernel also writes the semi-implicit Euler rows in factored form, [A B]_q = D1 [I 0 0] + Dd [A B]_v with
+    D1 = I, Dd = dt I on the joints and 6x6 blocks on the base (layout.h, oD12) — what the structured Riccati sweep multiplies
+    with.  The factored form must reproduce the full rows of the same knot record (which the oracle parity above pins)."""
+    fp, sh = _run_one_iteration(hip_lib, complete_model)
+    nv = fp.space.ndx // 2
+    for k in range(len(PATTERN)):
+        AB = sh._native.debug_get("AB", k).reshape(2 * nv, -1)
+        d = sh._native.debug_get("D12", k).ravel()
+        assert d[73] == 1.0
+        D1 = np.eye(nv)
+        D1[:6, :6] = d[:36].reshape(6, 6)
+        Dd = d[72] * np.eye(nv)
+        Dd[:6, :6] = d[36:72].reshape(6, 6)
+        E = np.zeros((nv, AB.shape[1]))
+        E[:, :nv] = np.eye(nv)
+        assert _rel(D1 @ E + Dd @ AB[nv:], AB[:nv]) < 1e-13
