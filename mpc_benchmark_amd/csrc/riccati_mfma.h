@@ -300,18 +300,16 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     constexpr bool sq = SQ;  // every stage knot of a whole-body problem has dynamics rows (valid flag d12l[73] = 1)
     RIC_PROF(1);
     // ---- 2. ||Ph||_F ; vv = Ph ft + ph ----
-    {
+    {  // one pass over the rows of Ph for both (its padding rows and columns are zero)
       double ss = 0;
-      for (int i = wv; i < np; i += nw)
-        for (int j = lane; j < np; j += 64) { const double pv = PT[i * ldp + j]; ss += pv * pv; }
+      for (int i = wv; i < n; i += nw) {
+        double s = 0;
+        for (int j = lane; j < n; j += 64) { const double pv = PT[i * ldp + j]; ss += pv * pv; s += pv * ft[j]; }
+        s = wave_sum_r(s);
+        if (lane == 0) vv[i] = s + ph[i];
+      }
       ss = wave_sum_r(ss);
       if (lane == 0) wred[wv] = ss;
-    }
-    for (int i = wv; i < n; i += nw) {
-      double s = 0;
-      for (int j = lane; j < n; j += 64) s += PT[i * ldp + j] * ft[j];
-      s = wave_sum_r(s);
-      if (lane == 0) vv[i] = s + ph[i];
     }
     __syncthreads();
     RIC_PROF(2);
