@@ -242,6 +242,11 @@ int mpc_debug_get(mpc_solver* h, const char* name, int32_t b, int32_t k, double*
     else if (nm == "kff") v = &g.kff;
     else if (nm == "Knu") v = &g.Knu;
     else if (nm == "knu") v = &g.knu;
+    else if (nm == "Kexact") v = &g.Kexact;
+    else if (nm == "Lm") v = &g.Lm;
+    else if (nm == "Sg") v = &g.Sg;
+    else if (nm == "sg") v = &g.sg;
+    else if (nm == "Kth") v = &g.Kth;
     else if (nm == "Mx") v = &g.Mx;
     else if (nm == "mx") v = &g.mx;
     else if (nm == "dx") v = &in.dxs[k];

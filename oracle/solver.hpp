@@ -76,6 +76,10 @@ inline double proj_normal(int role, double z, double lo, double hi, bool& active
 struct Gains {
   std::vector<double> P, p, K, kff, Knu, knu, Mx, mx;
   double T6[36];  // Ebar^{-1} base block (Ebar = -E6)
+  // parallel-in-time legs (riccati_legs > 1), knots of a leg whose end co-state theta is a parameter:
+  // Lm = dp/dtheta (n x n), Kth = dk/dtheta (m x n), Knuth = dknu/dtheta (c x n), Mth = d dx'/dtheta (n x n),
+  // Sg, sg: dx_cut = Lm^T dx + Sg theta + sg (condensed leg from this knot to its end)
+  std::vector<double> Lm, Kth, Knuth, Mth, Sg, sg, Kexact;
 };
 
 struct Instance {
@@ -232,148 +236,340 @@ struct Solver {
 
   // P6: proximal Riccati backward sweep, unpivoted quasi-definite elimination
   // (controls first, then constraint multipliers).
-  void backward(Instance& in) const {
+  void backward_terminal(Instance& in) const {
     const int N = dims.horizon, n = dims.ndx;
-    const double mu = in.mu, mud = mu_dyn(in);
-    const bool ff = dims.space == MPC_SPACE_MULTIBODY && model.has_freeflyer();
-    // terminal node
-    {
-      const Knot& kn = in.knots[N];
-      Gains& g = in.gains[N];
-      g.P.assign(kn.H.begin(), kn.H.end()); g.p.assign(kn.grad.begin(), kn.grad.end());
-      g.Knu.assign(kn.c * n, 0.0); g.knu.assign(kn.c, 0.0);
-      for (int i = 0; i < kn.c; ++i) {
-        bool act;
-        const double pn = proj_normal(kn.ctype[i], kn.cval[i] + mu * in.vs_e[N][i], kn.lo[i], kn.hi[i], act);
-        g.knu[i] = pn / mu;
-        if (!act) continue;
-        for (int a = 0; a < n; ++a) g.Knu[i * n + a] = kn.CD[i * n + a] / mu;
-        for (int a = 0; a < n; ++a) {
-          g.p[a] += kn.CD[i * n + a] * g.knu[i];
-          for (int b = 0; b < n; ++b) g.P[a * n + b] += kn.CD[i * n + a] * g.Knu[i * n + b];
-        }
+    const double mu = in.mu;
+    const Knot& kn = in.knots[N];
+    Gains& g = in.gains[N];
+    g.P.assign(kn.H.begin(), kn.H.end()); g.p.assign(kn.grad.begin(), kn.grad.end());
+    g.Knu.assign(kn.c * n, 0.0); g.knu.assign(kn.c, 0.0);
+    g.Lm.clear(); g.Kth.clear(); g.Knuth.clear(); g.Mth.clear(); g.Sg.clear(); g.sg.clear();
+    for (int i = 0; i < kn.c; ++i) {
+      bool act;
+      const double pn = proj_normal(kn.ctype[i], kn.cval[i] + mu * in.vs_e[N][i], kn.lo[i], kn.hi[i], act);
+      g.knu[i] = pn / mu;
+      if (!act) continue;
+      for (int a = 0; a < n; ++a) g.Knu[i * n + a] = kn.CD[i * n + a] / mu;
+      for (int a = 0; a < n; ++a) {
+        g.p[a] += kn.CD[i * n + a] * g.knu[i];
+        for (int b = 0; b < n; ++b) g.P[a * n + b] += kn.CD[i * n + a] * g.Knu[i * n + b];
       }
     }
-    for (int k = N - 1; k >= 0; --k) {
-      const Knot& kn = in.knots[k];
-      const Gains& gn = in.gains[k + 1];
-      Gains& g = in.gains[k];
-      const int m = kn.m, c = kn.c, nz = n + m;
-      // 1. change of variable y = Ebar x'
-      for (int i = 0; i < 36; ++i) g.T6[i] = (i % 7 == 0) ? 1.0 : 0.0;
-      std::vector<double> Ph(gn.P), ph(gn.p);
-      if (ff) {
-        double Eb[36];
-        for (int i = 0; i < 36; ++i) Eb[i] = -kn.E6[i];
-        inv6(Eb, g.T6);
-        // Ph = T^T P T, ph = T^T p with T = blockdiag(T6, I)
-        std::vector<double> tmp(n * n);
-        for (int i = 0; i < n; ++i)
-          for (int j = 0; j < n; ++j) {
-            if (j < 6) { double s = 0; for (int l = 0; l < 6; ++l) s += gn.P[i * n + l] * g.T6[l * 6 + j]; tmp[i * n + j] = s; }
-            else tmp[i * n + j] = gn.P[i * n + j];
-          }
-        for (int i = 0; i < n; ++i)
-          for (int j = 0; j < n; ++j) {
-            if (i < 6) { double s = 0; for (int l = 0; l < 6; ++l) s += g.T6[l * 6 + i] * tmp[l * n + j]; Ph[i * n + j] = s; }
-            else Ph[i * n + j] = tmp[i * n + j];
-          }
-        for (int i = 0; i < 6; ++i) { double s = 0; for (int l = 0; l < 6; ++l) s += g.T6[l * 6 + i] * gn.p[l]; ph[i] = s; }
-      }
-      // 2. Lam = (I + mud Ph)^-1 ; Pt = Lam Ph ; pt = Lam (Ph ft + ph)
-      std::vector<double> Lp(n * n);
-      for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Lp[i * n + j] = mud * 0.5 * (Ph[i * n + j] + Ph[j * n + i]) + (i == j ? 1.0 : 0.0);
-      if (!chol_lower(Lp.data(), n)) throw std::runtime_error("Riccati: I + mu_dyn P not positive definite");
-      std::vector<double> Pt(Ph), ft(n), w(n);
-      for (int i = 0; i < n; ++i) ft[i] = kn.f[i] + mud * in.lams_e[k + 1][i];
-      for (int i = 0; i < n; ++i) { double s = ph[i]; for (int j = 0; j < n; ++j) s += Ph[i * n + j] * ft[j]; w[i] = s; }
-      trsm_lower(Lp.data(), n, Pt.data(), n); trsm_lower_t(Lp.data(), n, Pt.data(), n);
-      trsm_lower(Lp.data(), n, w.data(), 1); trsm_lower_t(Lp.data(), n, w.data(), 1);
-      for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) { const double s = 0.5 * (Pt[i * n + j] + Pt[j * n + i]); Pt[i * n + j] = Pt[j * n + i] = s; }
-      // 3. Hh = H + AB^T Pt AB ; gh = grad + AB^T pt
-      std::vector<double> G(n * nz, 0.0), Hh(kn.H), gh(kn.grad);
-      for (int i = 0; i < n; ++i) for (int l = 0; l < n; ++l) { const double pv = Pt[i * n + l]; if (pv != 0.0) for (int a = 0; a < nz; ++a) G[i * nz + a] += pv * kn.AB[l * nz + a]; }
+  }
+
+  // One backward step at knot k < N from the value function of knot k + 1,
+  //   V'(x', theta) = 1/2 x'^T Pn x' + x'^T (pn + Lmn theta) + 1/2 theta^T Sgn theta + sgn^T theta .
+  // Lmn == nullptr: the plain recursion (no parameter).  With a parameter (the co-state at the end of a leg of the
+  // parallel-in-time solver) every affine quantity gains n columns: Kth, Knuth, Lm = dp/dtheta, Mth = d dx'/dtheta, and the
+  // envelope theorem gives Sg = Sgn + Lmn^T Mth, sg = sgn + Lmn^T mx.
+  void knot_backward(const Instance& in, int k, const std::vector<double>& Pn, const std::vector<double>& pn,
+                     const std::vector<double>* Lmn, const std::vector<double>* Sgn, const std::vector<double>* sgn, Gains& g) const {
+    const int n = dims.ndx;
+    const double mu = in.mu, mud = mu_dyn(in);
+    const bool ff = dims.space == MPC_SPACE_MULTIBODY && model.has_freeflyer();
+    const Knot& kn = in.knots[k];
+    const int m = kn.m, c = kn.c, nz = n + m;
+    const int np = Lmn ? n : 0;
+    // 1. change of variable y = Ebar x'
+    for (int i = 0; i < 36; ++i) g.T6[i] = (i % 7 == 0) ? 1.0 : 0.0;
+    std::vector<double> Ph(Pn), ph(pn), phM;
+    if (np) phM = *Lmn;
+    if (ff) {
+      double Eb[36];
+      for (int i = 0; i < 36; ++i) Eb[i] = -kn.E6[i];
+      inv6(Eb, g.T6);
+      // Ph = T^T P T, ph = T^T p with T = blockdiag(T6, I)
+      std::vector<double> tmp(n * n);
       for (int i = 0; i < n; ++i)
-        for (int a = 0; a < nz; ++a) {
-          const double ab = kn.AB[i * nz + a];
-          if (ab == 0.0) continue;
-          gh[a] += ab * w[i];
-          for (int b = 0; b < nz; ++b) Hh[a * nz + b] += ab * G[i * nz + b];
+        for (int j = 0; j < n; ++j) {
+          if (j < 6) { double s = 0; for (int l = 0; l < 6; ++l) s += Pn[i * n + l] * g.T6[l * 6 + j]; tmp[i * n + j] = s; }
+          else tmp[i * n + j] = Pn[i * n + j];
         }
-      // 4. stage KKT  [[R, D^T],[D, -mu I]] [U; V] = -[[S^T r],[C d]]
-      std::vector<double> Lr(m * m), Ct(c * nz, 0.0), dt_(c, 0.0);
-      for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Lr[i * m + j] = 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]);
-      for (int attempt = 1; !chol_lower(Lr.data(), m); ++attempt) {
-        // inertia correction (same rule as csrc/riccati_mfma.h): Ruu + rho I, rho = max(1e-8, 1e-6 max|diag|) x 10^t
-        if (attempt > 10) throw std::runtime_error("Riccati: reduced control Hessian not positive definite");
-        double dmax = 0.0;
-        for (int i = 0; i < m; ++i) dmax = std::max(dmax, std::fabs(Hh[(n + i) * nz + n + i]));
-        double rho = std::max(1e-8, 1e-6 * dmax);
-        for (int t = 1; t < attempt; ++t) rho *= 10.0;
-        for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j)
-          Lr[i * m + j] = 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]) + (i == j ? rho : 0.0);
-      }
-      for (int i = 0; i < c; ++i) {
-        bool act;
-        dt_[i] = proj_normal(kn.ctype[i], kn.cval[i] + mu * in.vs_e[k][i], kn.lo[i], kn.hi[i], act);
-        if (act) for (int a = 0; a < nz; ++a) Ct[i * nz + a] = kn.CD[i * nz + a];
-      }
-      const int nr = n + 1;
-      std::vector<double> W(m * nr), Y(m * (c > 0 ? c : 1), 0.0);
-      for (int i = 0; i < m; ++i) { for (int a = 0; a < n; ++a) W[i * nr + a] = -Hh[(n + i) * nz + a]; W[i * nr + n] = -gh[n + i]; }
-      trsm_lower(Lr.data(), m, W.data(), nr);  // W = L^-1 T
-      std::vector<double> V(c * nr > 0 ? c * nr : 1, 0.0);
-      if (c > 0) {
-        for (int i = 0; i < m; ++i) for (int j = 0; j < c; ++j) Y[i * c + j] = Ct[j * nz + n + i];
-        trsm_lower(Lr.data(), m, Y.data(), c);  // Y = L^-1 D^T
-        std::vector<double> Sc(c * c, 0.0);
-        for (int i = 0; i < c; ++i) for (int j = 0; j < c; ++j) { double s = (i == j) ? mu : 0.0; for (int l = 0; l < m; ++l) s += Y[l * c + i] * Y[l * c + j]; Sc[i * c + j] = s; }
-        if (!chol_lower(Sc.data(), c)) throw std::runtime_error("Riccati: constraint Schur complement not positive definite");
-        // V = Sc^-1 (Y^T W - Bt),  Bt = -[C d]
-        for (int i = 0; i < c; ++i)
-          for (int a = 0; a < nr; ++a) {
-            double s = (a < n) ? Ct[i * nz + a] : dt_[i];
-            for (int l = 0; l < m; ++l) s += Y[l * c + i] * W[l * nr + a];
-            V[i * nr + a] = s;
-          }
-        trsm_lower(Sc.data(), c, V.data(), nr); trsm_lower_t(Sc.data(), c, V.data(), nr);
-        for (int l = 0; l < m; ++l) for (int a = 0; a < nr; ++a) { double s = 0; for (int i = 0; i < c; ++i) s += Y[l * c + i] * V[i * nr + a]; W[l * nr + a] -= s; }
-      }
-      trsm_lower_t(Lr.data(), m, W.data(), nr);  // U = L^-T (W - Y V)
-      g.K.assign(m * n, 0.0); g.kff.assign(m, 0.0); g.Knu.assign(c * n, 0.0); g.knu.assign(c, 0.0);
-      for (int i = 0; i < m; ++i) { for (int a = 0; a < n; ++a) g.K[i * n + a] = W[i * nr + a]; g.kff[i] = W[i * nr + n]; }
-      for (int i = 0; i < c; ++i) { for (int a = 0; a < n; ++a) g.Knu[i * n + a] = V[i * nr + a]; g.knu[i] = V[i * nr + n]; }
-      // 5. value function  P = Qh + Sh K + C^T Knu ,  p = qh + Sh k + C^T knu
-      g.P.assign(n * n, 0.0); g.p.assign(n, 0.0);
-      for (int a = 0; a < n; ++a) {
-        double s = gh[a];
-        for (int i = 0; i < m; ++i) s += Hh[a * nz + n + i] * g.kff[i];
-        for (int i = 0; i < c; ++i) s += Ct[i * nz + a] * g.knu[i];
-        g.p[a] = s;
-        for (int b = 0; b < n; ++b) {
-          double t = Hh[a * nz + b];
-          for (int i = 0; i < m; ++i) t += Hh[a * nz + n + i] * g.K[i * n + b];
-          for (int i = 0; i < c; ++i) t += Ct[i * nz + a] * g.Knu[i * n + b];
-          g.P[a * n + b] = t;
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+          if (i < 6) { double s = 0; for (int l = 0; l < 6; ++l) s += g.T6[l * 6 + i] * tmp[l * n + j]; Ph[i * n + j] = s; }
+          else Ph[i * n + j] = tmp[i * n + j];
         }
+      for (int i = 0; i < 6; ++i) { double s = 0; for (int l = 0; l < 6; ++l) s += g.T6[l * 6 + i] * pn[l]; ph[i] = s; }
+      for (int j = 0; j < np; ++j) for (int i = 0; i < 6; ++i) { double s = 0; for (int l = 0; l < 6; ++l) s += g.T6[l * 6 + i] * (*Lmn)[l * np + j]; phM[i * np + j] = s; }
+    }
+    // 2. Lam = (I + mud Ph)^-1 ; Pt = Lam Ph ; pt = Lam (Ph ft + ph)
+    std::vector<double> Lp(n * n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Lp[i * n + j] = mud * 0.5 * (Ph[i * n + j] + Ph[j * n + i]) + (i == j ? 1.0 : 0.0);
+    if (!chol_lower(Lp.data(), n)) throw std::runtime_error("Riccati: I + mu_dyn P not positive definite");
+    std::vector<double> Pt(Ph), ft(n), w(n), wM(phM);
+    for (int i = 0; i < n; ++i) ft[i] = kn.f[i] + mud * in.lams_e[k + 1][i];
+    for (int i = 0; i < n; ++i) { double s = ph[i]; for (int j = 0; j < n; ++j) s += Ph[i * n + j] * ft[j]; w[i] = s; }
+    trsm_lower(Lp.data(), n, Pt.data(), n); trsm_lower_t(Lp.data(), n, Pt.data(), n);
+    trsm_lower(Lp.data(), n, w.data(), 1); trsm_lower_t(Lp.data(), n, w.data(), 1);
+    if (np) { trsm_lower(Lp.data(), n, wM.data(), np); trsm_lower_t(Lp.data(), n, wM.data(), np); }
+    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) { const double s = 0.5 * (Pt[i * n + j] + Pt[j * n + i]); Pt[i * n + j] = Pt[j * n + i] = s; }
+    // 3. Hh = H + AB^T Pt AB ; gh = grad + AB^T pt
+    std::vector<double> G(n * nz, 0.0), Hh(kn.H), gh(kn.grad), ghM((size_t)nz * np, 0.0);
+    for (int i = 0; i < n; ++i) for (int l = 0; l < n; ++l) { const double pv = Pt[i * n + l]; if (pv != 0.0) for (int a = 0; a < nz; ++a) G[i * nz + a] += pv * kn.AB[l * nz + a]; }
+    for (int i = 0; i < n; ++i)
+      for (int a = 0; a < nz; ++a) {
+        const double ab = kn.AB[i * nz + a];
+        if (ab == 0.0) continue;
+        gh[a] += ab * w[i];
+        for (int b = 0; b < nz; ++b) Hh[a * nz + b] += ab * G[i * nz + b];
+        for (int j = 0; j < np; ++j) ghM[a * np + j] += ab * wM[i * np + j];
       }
-      for (int a = 0; a < n; ++a) for (int b = a + 1; b < n; ++b) { const double s = 0.5 * (g.P[a * n + b] + g.P[b * n + a]); g.P[a * n + b] = g.P[b * n + a] = s; }
-      // 6. closed-loop next-state map  x' = T Lam (A x + B u + ft - mud ph)  =  Mx x + mx
-      std::vector<double> Acl((size_t)n * nr, 0.0);
+    // 4. stage KKT  [[R, D^T],[D, -mu I]] [U; V] = -[[S^T r],[C d]]
+    std::vector<double> Lr(m * m), Ct(c * nz, 0.0), dt_(c, 0.0);
+    for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Lr[i * m + j] = 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]);
+    for (int attempt = 1; !chol_lower(Lr.data(), m); ++attempt) {
+      // inertia correction (same rule as csrc/riccati_mfma.h): Ruu + rho I, rho = max(1e-8, 1e-6 max|diag|) x 10^t
+      if (attempt > 10) throw std::runtime_error("Riccati: reduced control Hessian not positive definite");
+      double dmax = 0.0;
+      for (int i = 0; i < m; ++i) dmax = std::max(dmax, std::fabs(Hh[(n + i) * nz + n + i]));
+      double rho = std::max(1e-8, 1e-6 * dmax);
+      for (int t = 1; t < attempt; ++t) rho *= 10.0;
+      for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j)
+        Lr[i * m + j] = 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]) + (i == j ? rho : 0.0);
+    }
+    for (int i = 0; i < c; ++i) {
+      bool act;
+      dt_[i] = proj_normal(kn.ctype[i], kn.cval[i] + mu * in.vs_e[k][i], kn.lo[i], kn.hi[i], act);
+      if (act) for (int a = 0; a < nz; ++a) Ct[i * nz + a] = kn.CD[i * nz + a];
+    }
+    const int nr = n + 1 + np;  // columns: feedback on dx | feed-forward | feedback on theta
+    std::vector<double> W((size_t)m * nr), Y(m * (c > 0 ? c : 1), 0.0);
+    for (int i = 0; i < m; ++i) {
+      for (int a = 0; a < n; ++a) W[i * nr + a] = -Hh[(n + i) * nz + a];
+      W[i * nr + n] = -gh[n + i];
+      for (int j = 0; j < np; ++j) W[i * nr + n + 1 + j] = -ghM[(n + i) * np + j];
+    }
+    trsm_lower(Lr.data(), m, W.data(), nr);  // W = L^-1 T
+    std::vector<double> V((size_t)c * nr > 0 ? (size_t)c * nr : 1, 0.0);
+    if (c > 0) {
+      for (int i = 0; i < m; ++i) for (int j = 0; j < c; ++j) Y[i * c + j] = Ct[j * nz + n + i];
+      trsm_lower(Lr.data(), m, Y.data(), c);  // Y = L^-1 D^T
+      std::vector<double> Sc(c * c, 0.0);
+      for (int i = 0; i < c; ++i) for (int j = 0; j < c; ++j) { double s = (i == j) ? mu : 0.0; for (int l = 0; l < m; ++l) s += Y[l * c + i] * Y[l * c + j]; Sc[i * c + j] = s; }
+      if (!chol_lower(Sc.data(), c)) throw std::runtime_error("Riccati: constraint Schur complement not positive definite");
+      // V = Sc^-1 (Y^T W - Bt),  Bt = -[C d 0]
+      for (int i = 0; i < c; ++i)
+        for (int a = 0; a < nr; ++a) {
+          double s = (a < n) ? Ct[i * nz + a] : (a == n ? dt_[i] : 0.0);
+          for (int l = 0; l < m; ++l) s += Y[l * c + i] * W[l * nr + a];
+          V[i * nr + a] = s;
+        }
+      trsm_lower(Sc.data(), c, V.data(), nr); trsm_lower_t(Sc.data(), c, V.data(), nr);
+      for (int l = 0; l < m; ++l) for (int a = 0; a < nr; ++a) { double s = 0; for (int i = 0; i < c; ++i) s += Y[l * c + i] * V[i * nr + a]; W[l * nr + a] -= s; }
+    }
+    trsm_lower_t(Lr.data(), m, W.data(), nr);  // U = L^-T (W - Y V)
+    g.K.assign(m * n, 0.0); g.kff.assign(m, 0.0); g.Knu.assign(c * n, 0.0); g.knu.assign(c, 0.0);
+    g.Kth.assign((size_t)m * np, 0.0); g.Knuth.assign((size_t)c * np, 0.0);
+    for (int i = 0; i < m; ++i) { for (int a = 0; a < n; ++a) g.K[i * n + a] = W[i * nr + a]; g.kff[i] = W[i * nr + n]; for (int j = 0; j < np; ++j) g.Kth[i * np + j] = W[i * nr + n + 1 + j]; }
+    for (int i = 0; i < c; ++i) { for (int a = 0; a < n; ++a) g.Knu[i * n + a] = V[i * nr + a]; g.knu[i] = V[i * nr + n]; for (int j = 0; j < np; ++j) g.Knuth[i * np + j] = V[i * nr + n + 1 + j]; }
+    // 5. value function  P = Qh + Sh K + C^T Knu ,  p = qh + Sh k + C^T knu
+    g.P.assign(n * n, 0.0); g.p.assign(n, 0.0); g.Lm.assign((size_t)n * np, 0.0);
+    for (int a = 0; a < n; ++a) {
+      double s = gh[a];
+      for (int i = 0; i < m; ++i) s += Hh[a * nz + n + i] * g.kff[i];
+      for (int i = 0; i < c; ++i) s += Ct[i * nz + a] * g.knu[i];
+      g.p[a] = s;
+      for (int b = 0; b < n; ++b) {
+        double t = Hh[a * nz + b];
+        for (int i = 0; i < m; ++i) t += Hh[a * nz + n + i] * g.K[i * n + b];
+        for (int i = 0; i < c; ++i) t += Ct[i * nz + a] * g.Knu[i * n + b];
+        g.P[a * n + b] = t;
+      }
+      for (int j = 0; j < np; ++j) {
+        double t = ghM[a * np + j];
+        for (int i = 0; i < m; ++i) t += Hh[a * nz + n + i] * g.Kth[i * np + j];
+        for (int i = 0; i < c; ++i) t += Ct[i * nz + a] * g.Knuth[i * np + j];
+        g.Lm[a * np + j] = t;
+      }
+    }
+    for (int a = 0; a < n; ++a) for (int b = a + 1; b < n; ++b) { const double s = 0.5 * (g.P[a * n + b] + g.P[b * n + a]); g.P[a * n + b] = g.P[b * n + a] = s; }
+    // 6. closed-loop next-state map  x' = T Lam (A x + B u + ft - mud ph)  =  Mx x + mx + Mth theta
+    std::vector<double> Acl((size_t)n * nr, 0.0);
+    for (int i = 0; i < n; ++i) {
+      for (int a = 0; a < n; ++a) { double s = kn.AB[i * nz + a]; for (int l = 0; l < m; ++l) s += kn.AB[i * nz + n + l] * g.K[l * n + a]; Acl[i * nr + a] = s; }
+      double s = ft[i] - mud * ph[i];
+      for (int l = 0; l < m; ++l) s += kn.AB[i * nz + n + l] * g.kff[l];
+      Acl[i * nr + n] = s;
+      for (int j = 0; j < np; ++j) {
+        double t = -mud * phM[i * np + j];
+        for (int l = 0; l < m; ++l) t += kn.AB[i * nz + n + l] * g.Kth[l * np + j];
+        Acl[i * nr + n + 1 + j] = t;
+      }
+    }
+    trsm_lower(Lp.data(), n, Acl.data(), nr); trsm_lower_t(Lp.data(), n, Acl.data(), nr);
+    if (ff) {
+      std::vector<double> top(6 * nr);
+      for (int i = 0; i < 6; ++i) for (int a = 0; a < nr; ++a) { double s2 = 0; for (int l = 0; l < 6; ++l) s2 += g.T6[i * 6 + l] * Acl[l * nr + a]; top[i * nr + a] = s2; }
+      std::memcpy(Acl.data(), top.data(), 6 * nr * sizeof(double));
+    }
+    g.Mx.assign(n * n, 0.0); g.mx.assign(n, 0.0); g.Mth.assign((size_t)n * np, 0.0);
+    for (int i = 0; i < n; ++i) { for (int a = 0; a < n; ++a) g.Mx[i * n + a] = Acl[i * nr + a]; g.mx[i] = Acl[i * nr + n]; for (int j = 0; j < np; ++j) g.Mth[i * np + j] = Acl[i * nr + n + 1 + j]; }
+    // 7. condensed leg: dx_cut = Lm^T dx + Sg theta + sg
+    g.Sg.clear(); g.sg.clear();
+    if (np) {
+      g.Sg = *Sgn; g.sg = *sgn;
+      for (int l = 0; l < n; ++l)
+        for (int a = 0; a < np; ++a) {
+          const double lv = (*Lmn)[l * np + a];
+          if (lv == 0.0) continue;
+          g.sg[a] += lv * g.mx[l];
+          for (int b = 0; b < np; ++b) g.Sg[a * np + b] += lv * g.Mth[l * np + b];
+        }
+      for (int a = 0; a < np; ++a) for (int b = a + 1; b < np; ++b) { const double s = 0.5 * (g.Sg[a * np + b] + g.Sg[b * np + a]); g.Sg[a * np + b] = g.Sg[b * np + a] = s; }
+    }
+  }
+
+  void backward(Instance& in) const {
+    const int N = dims.horizon;
+    backward_terminal(in);
+    for (int k = N - 1; k >= 0; --k) knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, nullptr, nullptr, nullptr, in.gains[k]);
+  }
+
+  // ---- parallel-in-time Riccati: linear_solver_choice = LQ_SOLVER_PARALLEL + setNumThreads (fulldynamic_talos.py:383-385) ----
+  // The horizon is cut into `legs` legs.  Leg j < legs - 1 runs the recursion from a zero value function at its end with the
+  // co-state theta_{j+1} of the cut state as a parameter (Jallet et al., "Parallel and proximal constrained LQ", 2024);
+  // all legs are independent of one another.  A serial pass over the cuts (consensus) then fixes the cut states and co-states,
+  // and the forward sweeps of the legs are independent again.  Same KKT system as the serial sweep: identical results up to
+  // round-off.
+  int nlegs() const { int L = opt.riccati_legs; if (L > dims.horizon) L = dims.horizon; if (L < 1) L = 1; return L; }
+  int leg_start(int j) const { return (int)((long long)j * dims.horizon / nlegs()); }  // first knot of leg j (leg nlegs()-1 ends with the terminal knot)
+
+  // consensus data of leg j < legs-1: cut state dx_{j+1} = Zx dx_j + zc, co-state theta_{j+1} = calP dx_{j+1} + calp
+  // ((calP, calp) = exact value function at the start of leg j+1)
+  struct LegLink { std::vector<double> Zx, zc, calP, calp; };
+
+  // a parametric knot and the exact value function (calP, calp) at the end of its leg:
+  // x_cut = Lm^T x + Sg theta + sg, theta = calP x_cut + calp  ->  x_cut = (I - Sg calP)^-1 (Lm^T x + Sg calp + sg) = Zx x + zc
+  void leg_link(const Gains& g, const std::vector<double>& calP, const std::vector<double>& calp, std::vector<double>& Zx, std::vector<double>* zc) const {
+    const int n = dims.ndx;
+    std::vector<double> Mt((size_t)n * n), R((size_t)n * (n + 1));
+    for (int i = 0; i < n; ++i) {
+      for (int j = 0; j < n; ++j) { double s = (i == j) ? 1.0 : 0.0; for (int l = 0; l < n; ++l) s -= g.Sg[i * n + l] * calP[l * n + j]; Mt[i * n + j] = s; }
+      for (int j = 0; j < n; ++j) R[i * (n + 1) + j] = g.Lm[j * n + i];
+      double s = g.sg[i]; for (int l = 0; l < n; ++l) s += g.Sg[i * n + l] * calp[l];
+      R[i * (n + 1) + n] = s;
+    }
+    solve_dense(Mt, n, R, n + 1);
+    Zx.assign((size_t)n * n, 0.0);
+    if (zc) zc->assign(n, 0.0);
+    for (int i = 0; i < n; ++i) {
+      for (int j = 0; j < n; ++j) Zx[i * n + j] = R[i * (n + 1) + j];
+      if (zc) (*zc)[i] = R[i * (n + 1) + n];
+    }
+  }
+
+  void backward_legs(Instance& in, std::vector<LegLink>& links) const {
+    const int N = dims.horizon, n = dims.ndx, J = nlegs();
+    backward_terminal(in);
+    std::vector<double> zeroP((size_t)n * n, 0.0), zerop(n, 0.0), eye((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) eye[i * n + i] = 1.0;
+    // the legs are independent of one another
+#pragma omp parallel for schedule(dynamic) num_threads(opt.num_threads > 0 ? opt.num_threads : 1)
+    for (int j = 0; j < J; ++j) {
+      const int s = leg_start(j), e = (j + 1 < J) ? leg_start(j + 1) - 1 : N - 1;
+      for (int k = e; k >= s; --k) {
+        if (j + 1 == J) knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, nullptr, nullptr, nullptr, in.gains[k]);
+        else if (k == e) knot_backward(in, k, zeroP, zerop, &eye, &zeroP, &zerop, in.gains[k]);
+        else knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, &in.gains[k + 1].Lm, &in.gains[k + 1].Sg, &in.gains[k + 1].sg, in.gains[k]);
+      }
+    }
+    // consensus over the cuts, last to first: true value function (calP, calp) at the start of each leg
+    links.assign(J, LegLink());
+    std::vector<double> calP = in.gains[leg_start(J - 1)].P, calp = in.gains[leg_start(J - 1)].p;
+    for (int j = J - 2; j >= 0; --j) {
+      const int s = leg_start(j), e = leg_start(j + 1) - 1;
+      // exact feedback gains of every knot of the leg (checker only: the product corrects knot 0): K + Kth dtheta/dx, dtheta/dx = calP Zx
+      for (int k = s; k <= e; ++k) {
+        Gains& g = in.gains[k];
+        std::vector<double> Zk, Dk((size_t)n * n, 0.0);
+        leg_link(g, calP, calp, Zk, nullptr);
+        for (int i = 0; i < n; ++i) for (int a = 0; a < n; ++a) { double t = 0; for (int l = 0; l < n; ++l) t += calP[i * n + l] * Zk[l * n + a]; Dk[i * n + a] = t; }
+        const int m = in.knots[k].m;
+        g.Kexact = g.K;
+        for (int i = 0; i < m; ++i) for (int a = 0; a < n; ++a) { double t = 0; for (int l = 0; l < n; ++l) t += g.Kth[i * n + l] * Dk[l * n + a]; g.Kexact[i * n + a] += t; }
+      }
+      const Gains& g = in.gains[s];
+      LegLink& lk = links[j];
+      leg_link(g, calP, calp, lk.Zx, &lk.zc);
+      lk.calP = calP; lk.calp = calp;
+      // value function at the start of leg j: theta = D x + e with D = calP Zx, e = calP zc + calp
+      std::vector<double> D((size_t)n * n), ev(n), nP(g.P), np_(g.p);
       for (int i = 0; i < n; ++i) {
-        for (int a = 0; a < n; ++a) { double s = kn.AB[i * nz + a]; for (int l = 0; l < m; ++l) s += kn.AB[i * nz + n + l] * g.K[l * n + a]; Acl[i * nr + a] = s; }
-        double s = ft[i] - mud * ph[i];
-        for (int l = 0; l < m; ++l) s += kn.AB[i * nz + n + l] * g.kff[l];
-        Acl[i * nr + n] = s;
+        for (int a = 0; a < n; ++a) { double t = 0; for (int l = 0; l < n; ++l) t += calP[i * n + l] * lk.Zx[l * n + a]; D[i * n + a] = t; }
+        double t = calp[i]; for (int l = 0; l < n; ++l) t += calP[i * n + l] * lk.zc[l];
+        ev[i] = t;
       }
-      trsm_lower(Lp.data(), n, Acl.data(), nr); trsm_lower_t(Lp.data(), n, Acl.data(), nr);
-      if (ff) {
-        std::vector<double> top(6 * nr);
-        for (int i = 0; i < 6; ++i) for (int a = 0; a < nr; ++a) { double s2 = 0; for (int l = 0; l < 6; ++l) s2 += g.T6[i * 6 + l] * Acl[l * nr + a]; top[i * nr + a] = s2; }
-        std::memcpy(Acl.data(), top.data(), 6 * nr * sizeof(double));
+      for (int a = 0; a < n; ++a) {
+        for (int b = 0; b < n; ++b) { double t = 0; for (int l = 0; l < n; ++l) t += g.Lm[a * n + l] * D[l * n + b]; nP[a * n + b] += t; }
+        double t = 0; for (int l = 0; l < n; ++l) t += g.Lm[a * n + l] * ev[l];
+        np_[a] += t;
       }
-      g.Mx.assign(n * n, 0.0); g.mx.assign(n, 0.0);
-      for (int i = 0; i < n; ++i) { for (int a = 0; a < n; ++a) g.Mx[i * n + a] = Acl[i * nr + a]; g.mx[i] = Acl[i * nr + n]; }
+      for (int a = 0; a < n; ++a) for (int b = a + 1; b < n; ++b) { const double t = 0.5 * (nP[a * n + b] + nP[b * n + a]); nP[a * n + b] = nP[b * n + a] = t; }
+      calP.swap(nP); calp.swap(np_);
+    }
+    for (int k = leg_start(J - 1); k < N; ++k) in.gains[k].Kexact = in.gains[k].K;
+    // controlFeedbacks()[0] is what the scripts read (fulldynamic_talos.py:522): knot 0 carries the exact gain
+    if (J > 1) in.gains[0].K = in.gains[0].Kexact;
+  }
+
+  void forward_legs(Instance& in, const std::vector<LegLink>& links) const {
+    const int N = dims.horizon, n = dims.ndx, J = nlegs();
+    const bool ff = dims.space == MPC_SPACE_MULTIBODY && model.has_freeflyer();
+    std::fill(in.dxs[0].begin(), in.dxs[0].end(), 0.0);  // force_initial_condition
+    std::fill(in.dlams[0].begin(), in.dlams[0].end(), 0.0);
+    for (int j = 0; j < J; ++j) {
+      const bool par = j + 1 < J;
+      const int s = leg_start(j), e = par ? leg_start(j + 1) - 1 : N;
+      // consensus: the cut state and its co-state come from the SAME solve (theta = calP x_cut + calp holds to round-off of that
+      // product), so the stationarity condition of the cut state is met as accurately as that of any other knot; what is left
+      // of the round-off of the leg's own forward sweep is a dynamics gap of the order of 1e-12 at the cut
+      std::vector<double> th(n, 0.0), xcut(n, 0.0);
+      if (par) {
+        const LegLink& lk = links[j];
+        for (int i = 0; i < n; ++i) { double t = lk.zc[i]; for (int a = 0; a < n; ++a) t += lk.Zx[i * n + a] * in.dxs[s][a]; xcut[i] = t; }
+        for (int i = 0; i < n; ++i) { double t = lk.calp[i]; for (int a = 0; a < n; ++a) t += lk.calP[i * n + a] * xcut[a]; th[i] = t; }
+      }
+      for (int k = s; k <= e; ++k) {
+        const Gains& g = in.gains[k];
+        const Knot& kn = in.knots[k];
+        const double* dx = in.dxs[k].data();
+        for (int i = 0; i < kn.c; ++i) {
+          double t = g.knu[i];
+          for (int a = 0; a < n; ++a) t += g.Knu[i * n + a] * dx[a];
+          if (par) for (int a = 0; a < n; ++a) t += g.Knuth[i * n + a] * th[a];
+          in.dvs[k][i] = t - in.vs[k][i];
+        }
+        for (int i = kn.c; i < dims.nc_max; ++i) in.dvs[k][i] = 0.0;
+        if (k == N) break;
+        for (int i = 0; i < kn.m; ++i) {
+          double t = g.kff[i];
+          for (int a = 0; a < n; ++a) t += g.K[i * n + a] * dx[a];  // knot 0 holds the exact gain; dx_0 = 0 (force_initial_condition)
+          if (par) for (int a = 0; a < n; ++a) t += g.Kth[i * n + a] * th[a];
+          in.dus[k][i] = t;
+        }
+        double* dxn = in.dxs[k + 1].data();
+        for (int i = 0; i < n; ++i) {
+          double t = g.mx[i];
+          for (int a = 0; a < n; ++a) t += g.Mx[i * n + a] * dx[a];
+          if (par) for (int a = 0; a < n; ++a) t += g.Mth[i * n + a] * th[a];
+          dxn[i] = t;
+        }
+        if (par && k == e) for (int i = 0; i < n; ++i) dxn[i] = xcut[i];
+        std::vector<double> l(n);
+        if (par && k == e) l = th;  // the co-state of the cut is the parameter itself
+        else {
+          const Gains& gn = in.gains[k + 1];
+          for (int i = 0; i < n; ++i) {
+            double t = gn.p[i];
+            for (int a = 0; a < n; ++a) t += gn.P[i * n + a] * dxn[a];
+            if (par) for (int a = 0; a < n; ++a) t += gn.Lm[i * n + a] * th[a];
+            l[i] = t;
+          }
+        }
+        if (ff) { double t[6]; for (int i = 0; i < 6; ++i) { double s2 = 0; for (int a = 0; a < 6; ++a) s2 += g.T6[a * 6 + i] * l[a]; t[i] = s2; } for (int i = 0; i < 6; ++i) l[i] = t[i]; }
+        for (int i = 0; i < n; ++i) in.dlams[k + 1][i] = l[i] - in.lams[k + 1][i];
+      }
     }
   }
 
@@ -475,9 +671,16 @@ struct Solver {
     const double phi0 = merit(in, in.knots, in.vs, in.lams, &cost, &prim);
     lagrangian_residuals(in, dual, crit);
     in.stats.traj_cost = cost; in.stats.merit = phi0; in.stats.prim_infeas = prim; in.stats.dual_infeas = dual; in.stats.mu = in.mu;
+    if (std::getenv("MPC_ORACLE_DEBUG")) fprintf(stderr, "it %d: cost %.10e merit %.10e prim %.3e dual %.3e crit %.3e (inner_tol %.3e) mu %.1e\n", in.stats.num_iters, cost, phi0, prim, dual, crit, in.inner_tol, in.mu);
     if (crit <= in.inner_tol) return 1;
-    backward(in);
-    forward(in);
+    if (nlegs() > 1) {
+      std::vector<LegLink> links;
+      backward_legs(in, links);
+      forward_legs(in, links);
+    } else {
+      backward(in);
+      forward(in);
+    }
     const double dphi0 = dmerit(in);
     // no descent left in the inner problem (round-off floor of the 1/mu-conditioned system): counts as solved, no step
     // (MPC_STALL_TOL of csrc/solver_kernels.h)
