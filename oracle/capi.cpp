@@ -247,6 +247,15 @@ int mpc_debug_get(mpc_solver* h, const char* name, int32_t b, int32_t k, double*
     else if (nm == "Sg") v = &g.Sg;
     else if (nm == "sg") v = &g.sg;
     else if (nm == "Kth") v = &g.Kth;
+    else if (nm == "Knuth") v = &g.Knuth;
+    else if (nm == "Mth") v = &g.Mth;
+    else if (nm == "Pt") v = &g.Pt;
+    else if (nm == "mx0") v = &g.mx0;
+    else if (nm == "p0") v = &g.p0;
+    else if (nm == "kff0") v = &g.kff0;
+    else if (nm == "Mu") v = &g.Mu;
+    else if (nm == "Znu") v = &g.Znu;
+    else if (nm == "T6") { tmp.assign(g.T6, g.T6 + 36); v = &tmp; }
     else if (nm == "Mx") v = &g.Mx;
     else if (nm == "mx") v = &g.mx;
     else if (nm == "dx") v = &in.dxs[k];

@@ -80,6 +80,8 @@ struct Gains {
   // Lm = dp/dtheta (n x n), Kth = dk/dtheta (m x n), Knuth = dknu/dtheta (c x n), Mth = d dx'/dtheta (n x n),
   // Sg, sg: dx_cut = Lm^T dx + Sg theta + sg (condensed leg from this knot to its end)
   std::vector<double> Lm, Kth, Knuth, Mth, Sg, sg, Kexact;
+  std::vector<double> mx0, p0, kff0;  // affine terms of a parametric knot before the co-state of its leg is applied
+  std::vector<double> Pt, Mu, Znu;  // parametric knots only: Pt, and the (u,u) / (nu,u) blocks of the inverse stage KKT matrix (what csrc/legs.h builds Gamma, Ku, Knup from)
 };
 
 struct Instance {
@@ -359,6 +361,23 @@ struct Solver {
       for (int l = 0; l < m; ++l) for (int a = 0; a < nr; ++a) { double s = 0; for (int i = 0; i < c; ++i) s += Y[l * c + i] * V[i * nr + a]; W[l * nr + a] -= s; }
     }
     trsm_lower_t(Lr.data(), m, W.data(), nr);  // U = L^-T (W - Y V)
+    g.Pt.clear(); g.Mu.clear(); g.Znu.clear();
+    if (np) {  // inverse stage KKT matrix applied to [I; 0]: Mu = (Ruu + Da^T Da / mu)^-1, Znu = Sc^-1 Y^T L^-1
+      g.Pt = Pt;
+      std::vector<double> W2((size_t)m * m, 0.0), V2((size_t)(c > 0 ? c : 1) * m, 0.0);
+      for (int i = 0; i < m; ++i) W2[i * m + i] = 1.0;
+      trsm_lower(Lr.data(), m, W2.data(), m);
+      if (c > 0) {
+        std::vector<double> Sc2(c * c, 0.0);
+        for (int i = 0; i < c; ++i) for (int j = 0; j < c; ++j) { double s2 = (i == j) ? mu : 0.0; for (int l = 0; l < m; ++l) s2 += Y[l * c + i] * Y[l * c + j]; Sc2[i * c + j] = s2; }
+        chol_lower(Sc2.data(), c);
+        for (int i = 0; i < c; ++i) for (int a = 0; a < m; ++a) { double s2 = 0; for (int l = 0; l < m; ++l) s2 += Y[l * c + i] * W2[l * m + a]; V2[i * m + a] = s2; }
+        trsm_lower(Sc2.data(), c, V2.data(), m); trsm_lower_t(Sc2.data(), c, V2.data(), m);
+        for (int l = 0; l < m; ++l) for (int a = 0; a < m; ++a) { double s2 = 0; for (int i = 0; i < c; ++i) s2 += Y[l * c + i] * V2[i * m + a]; W2[l * m + a] -= s2; }
+      }
+      trsm_lower_t(Lr.data(), m, W2.data(), m);
+      g.Mu = W2; g.Znu.assign(V2.begin(), V2.begin() + (size_t)c * m);
+    }
     g.K.assign(m * n, 0.0); g.kff.assign(m, 0.0); g.Knu.assign(c * n, 0.0); g.knu.assign(c, 0.0);
     g.Kth.assign((size_t)m * np, 0.0); g.Knuth.assign((size_t)c * np, 0.0);
     for (int i = 0; i < m; ++i) { for (int a = 0; a < n; ++a) g.K[i * n + a] = W[i * nr + a]; g.kff[i] = W[i * nr + n]; for (int j = 0; j < np; ++j) g.Kth[i * np + j] = W[i * nr + n + 1 + j]; }
@@ -406,8 +425,9 @@ struct Solver {
     g.Mx.assign(n * n, 0.0); g.mx.assign(n, 0.0); g.Mth.assign((size_t)n * np, 0.0);
     for (int i = 0; i < n; ++i) { for (int a = 0; a < n; ++a) g.Mx[i * n + a] = Acl[i * nr + a]; g.mx[i] = Acl[i * nr + n]; for (int j = 0; j < np; ++j) g.Mth[i * np + j] = Acl[i * nr + n + 1 + j]; }
     // 7. condensed leg: dx_cut = Lm^T dx + Sg theta + sg
-    g.Sg.clear(); g.sg.clear();
+    g.Sg.clear(); g.sg.clear(); g.mx0.clear(); g.p0.clear(); g.kff0.clear();
     if (np) {
+      g.mx0 = g.mx; g.p0 = g.p; g.kff0 = g.kff;
       g.Sg = *Sgn; g.sg = *sgn;
       for (int l = 0; l < n; ++l)
         for (int a = 0; a < np; ++a) {
@@ -518,18 +538,32 @@ struct Solver {
     const bool ff = dims.space == MPC_SPACE_MULTIBODY && model.has_freeflyer();
     std::fill(in.dxs[0].begin(), in.dxs[0].end(), 0.0);  // force_initial_condition
     std::fill(in.dlams[0].begin(), in.dlams[0].end(), 0.0);
+    // consensus, first cut to last (csrc/legs.h k_leg_consensus): the cut state and its co-state come from the SAME solve
+    // (theta = calP x_cut + calp holds to round-off of that product), so the stationarity condition of the cut state is met as
+    // accurately as that of any other knot; what is left of the round-off of the leg's own forward sweep is a dynamics gap of
+    // the order of 1e-12 at the cut
+    std::vector<std::vector<double>> ths(J, std::vector<double>(n, 0.0));
+    for (int j = 0; j + 1 < J; ++j) {
+      const LegLink& lk = links[j];
+      const int s = leg_start(j), c = leg_start(j + 1);
+      for (int i = 0; i < n; ++i) { double t = lk.zc[i]; for (int a = 0; a < n; ++a) t += lk.Zx[i * n + a] * in.dxs[s][a]; in.dxs[c][i] = t; }
+      for (int i = 0; i < n; ++i) { double t = lk.calp[i]; for (int a = 0; a < n; ++a) t += lk.calP[i * n + a] * in.dxs[c][a]; ths[j][i] = t; }
+    }
+    // apply (csrc/legs.h k_leg_apply): with theta known, the affine terms of the leg's knots take their final values
+    //   p += Lm theta, k += Kth theta, knu += Knuth theta, mx += Mth theta ; the sweeps below are then the plain ones
+    for (int j = 0; j + 1 < J; ++j) {
+      const std::vector<double>& th = ths[j];
+      for (int k = leg_start(j); k < leg_start(j + 1); ++k) {
+        Gains& g = in.gains[k];
+        const Knot& kn = in.knots[k];
+        for (int i = 0; i < n; ++i) { double t = 0, t2 = 0; for (int a = 0; a < n; ++a) { t += g.Lm[i * n + a] * th[a]; t2 += g.Mth[i * n + a] * th[a]; } g.p[i] += t; g.mx[i] += t2; }
+        for (int i = 0; i < kn.m; ++i) { double t = 0; for (int a = 0; a < n; ++a) t += g.Kth[i * n + a] * th[a]; g.kff[i] += t; }
+        for (int i = 0; i < kn.c; ++i) { double t = 0; for (int a = 0; a < n; ++a) t += g.Knuth[i * n + a] * th[a]; g.knu[i] += t; }
+      }
+    }
     for (int j = 0; j < J; ++j) {
       const bool par = j + 1 < J;
       const int s = leg_start(j), e = par ? leg_start(j + 1) - 1 : N;
-      // consensus: the cut state and its co-state come from the SAME solve (theta = calP x_cut + calp holds to round-off of that
-      // product), so the stationarity condition of the cut state is met as accurately as that of any other knot; what is left
-      // of the round-off of the leg's own forward sweep is a dynamics gap of the order of 1e-12 at the cut
-      std::vector<double> th(n, 0.0), xcut(n, 0.0);
-      if (par) {
-        const LegLink& lk = links[j];
-        for (int i = 0; i < n; ++i) { double t = lk.zc[i]; for (int a = 0; a < n; ++a) t += lk.Zx[i * n + a] * in.dxs[s][a]; xcut[i] = t; }
-        for (int i = 0; i < n; ++i) { double t = lk.calp[i]; for (int a = 0; a < n; ++a) t += lk.calP[i * n + a] * xcut[a]; th[i] = t; }
-      }
       for (int k = s; k <= e; ++k) {
         const Gains& g = in.gains[k];
         const Knot& kn = in.knots[k];
@@ -537,7 +571,6 @@ struct Solver {
         for (int i = 0; i < kn.c; ++i) {
           double t = g.knu[i];
           for (int a = 0; a < n; ++a) t += g.Knu[i * n + a] * dx[a];
-          if (par) for (int a = 0; a < n; ++a) t += g.Knuth[i * n + a] * th[a];
           in.dvs[k][i] = t - in.vs[k][i];
         }
         for (int i = kn.c; i < dims.nc_max; ++i) in.dvs[k][i] = 0.0;
@@ -545,25 +578,22 @@ struct Solver {
         for (int i = 0; i < kn.m; ++i) {
           double t = g.kff[i];
           for (int a = 0; a < n; ++a) t += g.K[i * n + a] * dx[a];  // knot 0 holds the exact gain; dx_0 = 0 (force_initial_condition)
-          if (par) for (int a = 0; a < n; ++a) t += g.Kth[i * n + a] * th[a];
           in.dus[k][i] = t;
         }
         double* dxn = in.dxs[k + 1].data();
-        for (int i = 0; i < n; ++i) {
-          double t = g.mx[i];
-          for (int a = 0; a < n; ++a) t += g.Mx[i * n + a] * dx[a];
-          if (par) for (int a = 0; a < n; ++a) t += g.Mth[i * n + a] * th[a];
-          dxn[i] = t;
-        }
-        if (par && k == e) for (int i = 0; i < n; ++i) dxn[i] = xcut[i];
+        if (!(par && k == e))  // the cut state is the consensus value
+          for (int i = 0; i < n; ++i) {
+            double t = g.mx[i];
+            for (int a = 0; a < n; ++a) t += g.Mx[i * n + a] * dx[a];
+            dxn[i] = t;
+          }
+        // co-state of knot k + 1: T^T (P' dx' + p') with the final p' — at a cut this is theta itself up to round-off (consensus)
         std::vector<double> l(n);
-        if (par && k == e) l = th;  // the co-state of the cut is the parameter itself
-        else {
+        {
           const Gains& gn = in.gains[k + 1];
           for (int i = 0; i < n; ++i) {
             double t = gn.p[i];
             for (int a = 0; a < n; ++a) t += gn.P[i * n + a] * dxn[a];
-            if (par) for (int a = 0; a < n; ++a) t += gn.Lm[i * n + a] * th[a];
             l[i] = t;
           }
         }

@@ -79,3 +79,45 @@ def test_cold_solve_and_ticks_with_legs_equal_serial(oracle_lib, kind, N, legs):
     for a, b in zip(res[1], res[legs]):
         assert _rel(b[0], a[0]) < 1e-8 and _rel(b[1], a[1]) < 1e-7
         assert b[4] <= 2.0 * a[4] + 1e-9   # the dual residual floor of the legs is that of the serial sweep
+
+
+def test_condensed_form_identities(oracle_lib):
+    """The factored form the HIP kernels use (csrc/legs.h) against the oracle's direct parametric columns: with
+    Bc = T (I - mu_d Pt) B, Ku = -Mu Bc^T, Knup = -Znu Bc^T, Gamma = Bc Ku - mu_d T (I - mu_d Pt) T^T (per knot, independent of
+    the recursion) the leg recursion is Kth = Ku Lm', Knuth = Knup Lm', Mth = Gamma Lm', Lm = Mx^T Lm',
+    Sg = Sg' + Lm'^T Gamma Lm', sg = sg' + Lm'^T mx (Lm' = I, Sg' = 0, sg' = 0 at the end of a leg)."""
+    N, legs = 9, 3
+    pd = FullDynamicsProblem(horizon=N)
+    prob = pd.build()
+    solver = _solver(pd, oracle_lib, legs, 1)
+    solver.setup(prob)
+    xs, us = pd.initial_guess()
+    rng = np.random.default_rng(7)
+    xs = [pd.space.integrate(x, 0.01 * rng.standard_normal(pd.space.ndx)) for x in xs]
+    us = [u + 5.0 * rng.standard_normal(u.size) for u in us]
+    prob.x0_init = xs[0]
+    solver.run(prob, xs, us)
+    nat = solver._native
+    n, m = pd.space.ndx, pd.nu
+    mud = 1e-8 * 1e-3
+    starts = [j * N // legs for j in range(legs)]
+    for j in range(legs - 1):
+        s, e = starts[j], starts[j + 1] - 1
+        Lmn, Sgn, sgn = np.eye(n), np.zeros((n, n)), np.zeros(n)
+        for k in range(e, s - 1, -1):
+            get = lambda name, shape: nat.debug_get(name, k).reshape(shape)
+            AB = get("AB", (n, n + m)); B = AB[:, n:]
+            Pt, Mu = get("Pt", (n, n)), get("Mu", (m, m))
+            c = nat.debug_get("cval", k).size
+            Znu = get("Znu", (c, m))
+            T = np.eye(n); T[:6, :6] = get("T6", (6, 6))
+            Lam = np.eye(n) - mud * Pt
+            Bc = T @ Lam @ B
+            Ku, Knup = -Mu @ Bc.T, -Znu @ Bc.T
+            Gam = Bc @ Ku - mud * T @ Lam @ T.T
+            Mx, mx0 = get("Mx", (n, n)), nat.debug_get("mx0", k)
+            for name, shape, val in (("Kth", (m, n), Ku @ Lmn), ("Knuth", (c, n), Knup @ Lmn), ("Mth", (n, n), Gam @ Lmn),
+                                     ("Lm", (n, n), Mx.T @ Lmn), ("Sg", (n, n), Sgn + Lmn.T @ Gam @ Lmn), ("sg", (n,), sgn + Lmn.T @ mx0)):
+                ref = get(name, shape)
+                assert np.max(np.abs(val - ref)) <= 1e-9 * max(1.0, np.max(np.abs(ref))) + 1e-12, (name, k)
+            Lmn, Sgn, sgn = get("Lm", (n, n)), get("Sg", (n, n)), nat.debug_get("sg", k)
