@@ -148,14 +148,19 @@ __global__ void __launch_bounds__(CL_THREADS) k_closed_loop(SolverArgs a, ClLds 
 // knot k + 1 are pulled into registers while knot k computes (FW_PR rows of Phi, FW_KR rows of K per wavefront, two
 // columns per lane: n <= 128).  One barrier per knot.  (A second register set to look two knots ahead does not fit the
 // 256 registers of an 8-wavefront workgroup without spilling, and 16 wavefronts spill as well: measured slower.)
+// Parallel-in-time legs (legs.h): the grid is B x nlegs, workgroup (b, leg) sweeps the knots of its leg from the cut state the
+// consensus kernel left in dxs (leg 0: dx_0 = 0); the state at the next cut is NOT written (it is the consensus value).  nlegs = 1 is
+// the sweep over the whole horizon.
 template <int FW_KR, int FW_PR>
 __global__ void __launch_bounds__(512) k_forward_phi(SolverArgs a) {
   const Layout& L = a.L;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
+  const int b = blockIdx.x % L.B, leg = blockIdx.x / L.B, tid = threadIdx.x, lane = tid & 63, nw = blockDim.x >> 6;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
   const int n = L.n, N = L.N, m = L.m;
+  const bool cut_end = leg + 1 < a.nlegs;
+  const int k0 = leg_start(a, leg), k1 = cut_end ? leg_start(a, leg + 1) : N;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* dx0 = lds;       // dx of the current knot (n)
   double* dx1 = lds + n;   // dx of the next knot (n): ping-pong, so a single barrier per knot suffices
@@ -175,12 +180,16 @@ __global__ void __launch_bounds__(512) k_forward_phi(SolverArgs a) {
       Pr[q][0] = g[L.oPhi + rr * n + cn0]; Pr[q][1] = g[L.oPhi + rr * n + cn1]; pf[q] = g[L.ophi + rr];
     }
   };
-  load_rows(0);
-  for (int i = tid; i < n; i += blockDim.x) { dx0[i] = 0.0; a.dxs[(size_t)b * (N + 1) * n + i] = 0.0; }
+  load_rows(k0);
+  for (int i = tid; i < n; i += blockDim.x) {
+    if (leg == 0) { dx0[i] = 0.0; a.dxs[(size_t)b * (N + 1) * n + i] = 0.0; }
+    else dx0[i] = a.dxs[((size_t)b * (N + 1) + k0) * n + i];
+  }
   FW_BARRIER();
-  for (int k = 0; k < N; ++k) {
-    const double* cur = (k & 1) ? dx1 : dx0;
-    double* nxt = (k & 1) ? dx0 : dx1;
+  for (int k = k0; k < k1; ++k) {
+    const double* cur = ((k - k0) & 1) ? dx1 : dx0;
+    double* nxt = ((k - k0) & 1) ? dx0 : dx1;
+    const bool keep = !(cut_end && k + 1 == k1);
     const double d0 = c0 < n ? cur[c0] : 0.0, d1 = c1 < n ? cur[c1] : 0.0;
 #pragma unroll
     for (int q = 0; q < FW_PR; ++q) {
@@ -188,7 +197,7 @@ __global__ void __launch_bounds__(512) k_forward_phi(SolverArgs a) {
       if (r < n) {
         double s = Pr[q][0] * d0 + Pr[q][1] * d1;
         s = wave_sum(s);
-        if (lane == 0) { s += pf[q]; nxt[r] = s; a.dxs[((size_t)b * (N + 1) + k + 1) * n + r] = s; }
+        if (lane == 0) { s += pf[q]; nxt[r] = s; if (keep) a.dxs[((size_t)b * (N + 1) + k + 1) * n + r] = s; }
       }
     }
 #pragma unroll
@@ -200,7 +209,7 @@ __global__ void __launch_bounds__(512) k_forward_phi(SolverArgs a) {
         if (lane == 0) a.dus[((size_t)b * N + k) * m + r] = s + kf[q];
       }
     }
-    if (k + 1 < N) load_rows(k + 1);
+    if (k + 1 < k1) load_rows(k + 1);
     FW_BARRIER();
   }
 }

@@ -13,6 +13,12 @@ struct Layout {
   int oH, oG, oAB, oF, oE6, oD12, oCV, oCD, oLO, oHI, oDT, oACT, oCT, oMISC, oXD, oWR, oXN, knot_stride;
   // offsets inside one gain record
   int oP, op, oK, ok, oKnu, oknu, oMx, omx, oT6, oPhi, ophi, gain_stride;
+  // parallel-in-time legs (legs.h), knots of a parametric leg: (u,u) and (nu,u) blocks of the inverse stage KKT matrix (Riccati sweep),
+  // Gamma = d dx'/dp', Ku = dk/dp', Knup = dknu/dp' (k_leg_knot), Lm = dp/dtheta (k_leg_condense)
+  int oMu, oZnu, oGam, oKu, oKnup, oLm, mpad;
+  // per (instance, parametric leg j) record: Sg (n x n) | sg | Zx (n x n) | zc | calP (n x n: exact value-function Hessian at the start of
+  // leg j + 1 — kept across passes: the terminal cost of leg j in the next pass) | calp | theta | dP (n x n: calP minus the guess the leg carried)
+  int lSg, lsg, lZx, lzc, lcP, lcp, lth, ldP, leg_stride;
   // backward-sweep scratch per instance
   int wPh, wPt, wLp, wG, wHh, wgh, wCt, wW, wY, wSc, wV, wAcl, wvec, work_stride;
   int max_stage_ints, max_stage_doubles;
@@ -29,6 +35,8 @@ struct InstState {
   double phi0, dphi0, alpha, cost, prim, dual, crit;
   int32_t num_iters, al_iters, converged, done, skip_step, ls_step, ls_more, stalled;
 };
+
+#define MPC_MAX_LEGS 16  // riccati_legs is clamped to this (and to the horizon)
 
 static inline int align2(int x) { return (x + 1) & ~1; }
 
@@ -47,7 +55,12 @@ static inline void make_layout(Layout& L) {
   L.oP = take(n * n); L.op = take(n); L.oK = take(m * n); L.ok = take(m); L.oKnu = take(c * n); L.oknu = take(c);
   L.oMx = take(n * n); L.omx = take(n); L.oT6 = take(36);
   L.oPhi = take(n * n); L.ophi = take(n);  // closed-loop transition dx' = Phi dx + phi (closed_loop.h)
+  L.mpad = (m + 15) & ~15;
+  L.oMu = take(L.mpad * L.mpad); L.oZnu = take(c * L.mpad); L.oGam = take(n * n); L.oKu = take(m * n); L.oKnup = take(c * n); L.oLm = take(n * n);
   L.gain_stride = o;
+  o = 0;
+  L.lSg = take(n * n); L.lsg = take(n); L.lZx = take(n * n); L.lzc = take(n); L.lcP = take(n * n); L.lcp = take(n); L.lth = take(n); L.ldP = take(n * n);
+  L.leg_stride = o;
   o = 0;
   const int nr = n + 1;
   L.wPh = take(n * n); L.wPt = take(n * n); L.wLp = take(n * n); L.wG = take(n * nz); L.wHh = take(nz * nz); L.wgh = take(nz);

@@ -1,0 +1,684 @@
+// legs.h — parallel-in-time proximal Riccati: linear_solver_choice = LQ_SOLVER_PARALLEL + setNumThreads(n) of the reference scripts
+// (fulldynamic_talos.py:383-385) mapped on the GPU.  The horizon is cut into `nlegs` legs; workgroup (instance, leg) of the
+// Riccati kernel (riccati_mfma.h, LEGS) sweeps its own leg, a leg other than the last from a ZERO value function at its end with
+// the co-state theta of the cut state as a parameter (Jallet et al., "Parallel and proximal constrained LQ", 2024).  The
+// parametric part is factored so that the sequential kernels stay small (algebra pinned in tests/test_oracle_legs.py):
+//
+//   per knot, independent of the recursion (k_leg_knot, one workgroup per knot):
+//     Bc = T (I - mu_d Pt) B ;  Phi = T (I - mu_d Pt)(A + B K) ;  phi = T (I - mu_d Pt)(B k + mx)
+//     Ku = -Mu Bc^T = dk/dp' ;  Knup = -Znu Bc^T = dknu/dp' ;  Gamma = Bc Ku - mu_d T (I - mu_d Pt) T^T = d dx'/dp'
+//     (Mu, Znu: (u,u) and (nu,u) blocks of the inverse stage KKT matrix, left by the Riccati kernel)
+//   per leg, backwards over its knots (k_leg_condense):  Lm = dp/dtheta,  dx_cut = Lm^T dx + Sg theta + sg
+//     Lm_k = Phi_k^T Lm' ;  Sg += Lm'^T Gamma_k Lm' ;  sg += Lm'^T phi_k        (Lm' = I, Sg = 0, sg = 0 at the end of the leg)
+//   per instance, over the cuts (k_leg_consensus): exact value function (calP, calp) at every cut, last to first,
+//     x_cut = (I - Sg dP)^-1 (Lm^T x + Sg calp + sg) = Zx x + zc ;  then first to last: cut states and theta = dP x_cut + calp
+//     (both from the same solve: the stationarity condition at a cut is met like at any other knot) ; exact gain K_0.
+//     dP = calP - Pg, Pg = the terminal Hessian the leg carried: with Pg = 0, I - Sg calP mixes the stiffest directions of calP
+//     (constraint penalties, 1/mu) with the most controllable ones of the leg and the cut states lose up to ten digits; with
+//     Pg = calP of the previous pass / MPC tick the consensus solves for a small correction.  The first pass of a handle has no
+//     guess: it sweeps twice (mpc_hip.hip)
+//   per knot (k_leg_apply): the affine terms take their final values,  p += Lm theta, k += Ku p', knu += Knup p', phi += Gamma p'
+//     with p' = Lm' theta ; the forward sweeps of the legs (closed_loop.h k_forward_phi) and k_duals are then the plain ones.
+// Same KKT system as the serial sweep: identical results up to round-off (tests/test_gpu_legs.py).
+#pragma once
+#include "mfma_blocks.h"
+#include "solver_kernels.h"
+
+#define LK_THREADS 512
+#define LK_U 20      // global loads in flight per thread in the LDS fills
+#define LK_PT 13     // matrix elements per thread parked in registers (np <= 80: 6400 / 512)
+#define LK_TILES 5   // output tiles per wavefront: nb (nb + nbm) <= 35 on 8 wavefronts
+
+struct LkLds {
+  int np, mp, nzp, ldp, ldm, nb, nbm;
+  int AB, PT, KM, MU, ZN, vec, total_bytes;
+};
+static inline LkLds make_lk_lds(int n, int m) {
+  LkLds s;
+  s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.ldp = s.np + 1; s.ldm = s.mp + 1;
+  s.nb = s.np / 16; s.nbm = s.mp / 16;
+  int o = 0;
+  auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
+  s.AB = take(s.np * s.nzp); s.PT = take(s.np * s.ldp);
+  const int km = s.mp * s.np > 6 * s.nzp + 6 * s.np ? s.mp * s.np : 6 * s.nzp + 6 * s.np;
+  s.KM = take(km); s.MU = take(s.mp * s.ldm); s.ZN = take(16 * s.ldm); s.vec = take(s.mp + 2 * s.np + 80);
+  s.total_bytes = o * 8;
+  return s;
+}
+
+// grid (N, B): knot k of instance b.  Reads K, k, Pt, mx, T6, Mu, Znu (gain record) and [A B] (knot record); writes Phi, phi for every
+// knot and Gamma, Ku, Knup for the knots of parametric legs.
+__global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) {
+  const Layout& L = a.L;
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const InstState& st = a.inst[b];
+  if (st.done || st.skip_step) return;
+  const int n = L.n, nz = L.nz, np = S.np, mp = S.mp, nzp = S.nzp, ldp = S.ldp, ldm = S.ldm, nb = S.nb, nbm = S.nbm;
+  const double* kn = knot_ptr(a, b, k);
+  double* g = gain_ptr(a, b, k);
+  const int m = (int)kn[L.oMISC + MISC_M], c = (int)kn[L.oMISC + MISC_NC];
+  const double mud = st.mu * a.opt.dyn_al_scale;
+  const bool par = leg_of_knot(a, k) + 1 < a.nlegs;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *AB = sm + S.AB, *PT = sm + S.PT, *KM = sm + S.KM, *MU = sm + S.MU, *ZN = sm + S.ZN, *vec = sm + S.vec;
+  double *kf = vec, *y0 = vec + mp, *z0 = y0 + np, *t6 = z0 + np, *g6 = t6 + 36;  // k (mp), B k + mx (np), (I - mu_d Pt) y0 (np), T6, T6 T6^T
+  double *TMP = KM, *TMP2 = KM + 6 * nzp;  // rows 0..5 of [M | Bl] (6 x nzp) ; Pt T^T columns 0..5 (np x 6) — K is dead by then
+
+  // ---- stage 1: [A B] and K into LDS (zero padded; u-columns of [A B] start at np) ; A_cl = A + B K in place ; y0 = B k + mx ----
+  for (int base = tid; base < np * nzp; base += nthr * LK_U) {
+    double v[LK_U];
+#pragma unroll
+    for (int u = 0; u < LK_U; ++u) {
+      const int idx = base + u * nthr, i = idx / nzp, zp = idx % nzp;
+      const int z = (zp < n) ? zp : ((zp >= np && zp - np < m) ? n + zp - np : -1);
+      v[u] = (idx < np * nzp && i < n && z >= 0) ? kn[L.oAB + (size_t)i * nz + z] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < LK_U; ++u) { const int idx = base + u * nthr; if (idx < np * nzp) AB[idx] = v[u]; }
+  }
+  for (int base = tid; base < mp * np; base += nthr * LK_U) {
+    double v[LK_U];
+#pragma unroll
+    for (int u = 0; u < LK_U; ++u) {
+      const int idx = base + u * nthr, l = idx / np, j = idx % np;
+      v[u] = (idx < mp * np && l < m && j < n) ? g[L.oK + l * n + j] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < LK_U; ++u) { const int idx = base + u * nthr; if (idx < mp * np) KM[idx] = v[u]; }
+  }
+  for (int l = tid; l < mp; l += nthr) kf[l] = (l < m) ? g[L.ok + l] : 0.0;
+  if (tid < 36) t6[tid] = g[L.oT6 + tid];
+  // Pt is requested now and parked in registers: its HBM latency hides behind stage 1
+  double ptv[LK_PT];
+#pragma unroll
+  for (int u = 0; u < LK_PT; ++u) {
+    const int idx = tid + u * nthr, i = idx / np, j = idx % np;
+    ptv[u] = (idx < np * np && i < n && j < n) ? g[L.oMx + i * n + j] : 0.0;
+  }
+  __syncthreads();
+  for (int t = wv; t < nb * nb; t += nw) {
+    const int ri = t / nb, cj = t % nb;
+    double* At = AB + (ri * 16) * nzp + cj * 16;
+    d4_t acc = tile_load(At, nzp, lane);                                                           // A tile
+    mma_tile<false>(acc, AB + (ri * 16) * nzp + np, nzp, 1, KM + cj * 16, np, 1, mp, lane);        // + B K (own tile only: in place)
+    tile_store(At, nzp, acc, lane);
+  }
+  for (int i = tid; i < np; i += nthr) {
+    double s = (i < n) ? g[L.omx + i] : 0.0;
+    for (int l = 0; l < m; ++l) s += AB[i * nzp + np + l] * kf[l];
+    y0[i] = s;
+  }
+  if (tid < 36) { const int i = tid / 6, j = tid % 6; double s = 0; for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * t6[j * 6 + l]; g6[tid] = s; }
+  // ---- stage 2: Pt into LDS ; [M | Bl] = (I - mu_d Pt) [A_cl | B] (products to registers, then in place) ; z0 = y0 - mu_d Pt y0 ----
+#pragma unroll
+  for (int u = 0; u < LK_PT; ++u) { const int idx = tid + u * nthr; if (idx < np * np) PT[(idx / np) * ldp + idx % np] = ptv[u]; }
+  __syncthreads();
+  const int nct = par ? nb + nbm : nb;  // the u columns are only needed for the parametric quantities
+  d4_t res[LK_TILES];
+#pragma unroll
+  for (int sidx = 0; sidx < LK_TILES; ++sidx) {
+    const int t = wv + sidx * nw;
+    res[sidx] = d4_t{0, 0, 0, 0};
+    if (t < nb * nct) mma_tile<false>(res[sidx], PT + ((t / nct) * 16) * ldp, ldp, 1, AB + (t % nct) * 16, nzp, 1, np, lane);
+  }
+  for (int i = wv; i < n; i += nw) {
+    double s = 0;
+    for (int j = lane; j < n; j += 64) s += PT[i * ldp + j] * y0[j];
+    s = wave_sum(s);
+    if (lane == 0) z0[i] = y0[i] - mud * s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int sidx = 0; sidx < LK_TILES; ++sidx) {
+    const int t = wv + sidx * nw;
+    if (t < nb * nct) {
+      double* At = AB + ((t / nct) * 16) * nzp + (t % nct) * 16;
+      const int row = lane >> 4, col = lane & 15;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) At[(row + 4 * q) * nzp + col] -= mud * res[sidx][q];
+    }
+  }
+  __syncthreads();
+  // ---- stage 3: base rows through T6 (rows 0..5 of [M | Bl] -> [Phi | Bc]) ; Phi, phi out ; Pt <- T Pt T^T for Gamma ----
+  for (int idx = tid; idx < 6 * nzp; idx += nthr) TMP[idx] = AB[idx];
+  if (par) for (int idx = tid; idx < np * 6; idx += nthr) {  // (Pt T^T)[i][j] = sum_l Pt[i][l] T6[j][l]
+    const int i = idx / 6, j = idx % 6;
+    double s = 0;
+    for (int l = 0; l < 6; ++l) s += PT[i * ldp + l] * t6[j * 6 + l];
+    TMP2[idx] = s;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < 6 * nzp; idx += nthr) {
+    const int i = idx / nzp, z = idx % nzp;
+    double s = 0;
+    for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * TMP[l * nzp + z];
+    AB[idx] = s;
+  }
+  if (par) for (int idx = tid; idx < np * 6; idx += nthr) PT[(idx / 6) * ldp + idx % 6] = TMP2[idx];
+  __syncthreads();
+  for (int i = wv; i < n; i += nw)
+    for (int j = lane; j < n; j += 64) g[L.oPhi + i * n + j] = AB[i * nzp + j];
+  for (int i = tid; i < n; i += nthr) {
+    double s = z0[i];
+    if (i < 6) { s = 0; for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * z0[l]; }
+    g[L.ophi + i] = s;
+  }
+  if (!par) return;
+  // rows 0..5 of T (Pt T^T): into TMP2 first (the rows are read by all)
+  for (int idx = tid; idx < 6 * np; idx += nthr) {
+    const int i = idx / np, j = idx % np;
+    double s = 0;
+    for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * PT[l * ldp + j];
+    TMP2[idx] = s;
+  }
+  // ---- stage 4: Mu, Znu into LDS ; U1 = Mu Bc^T (-> Ku = -U1, kept in KM for stage 5) ; V1 = Znu Bc^T (-> Knup = -V1) ----
+  const int ca = __syncthreads_count(tid < c && kn[L.oACT + (tid < c ? tid : 0)] != 0.0);  // c <= LK_THREADS (checked by the host)
+  for (int idx = tid; idx < mp * mp; idx += nthr) MU[(idx / mp) * ldm + idx % mp] = g[L.oMu + idx];
+  for (int idx = tid; idx < 16 * mp; idx += nthr) ZN[(idx / mp) * ldm + idx % mp] = (idx / mp < ca && ca <= 16) ? g[L.oZnu + idx] : 0.0;
+  __syncthreads();
+  for (int idx = tid; idx < 6 * np; idx += nthr) PT[(idx / np) * ldp + idx % np] = TMP2[idx];
+  __syncthreads();  // TMP / TMP2 (inside KM) are dead: KM receives U1
+  d4_t ures[2];
+#pragma unroll
+  for (int sidx = 0; sidx < 2; ++sidx) {
+    const int t = wv + sidx * nw;
+    ures[sidx] = d4_t{0, 0, 0, 0};
+    if (t < nbm * nb) mma_tile<false>(ures[sidx], MU + ((t / nb) * 16) * ldm, ldm, 1, AB + ((t % nb) * 16) * nzp + np, 1, nzp, mp, lane);
+  }
+  if (ca <= 16) {
+    for (int cj = wv; cj < nb; cj += nw) {
+      d4_t acc = d4_t{0, 0, 0, 0};
+      mma_tile<false>(acc, ZN, ldm, 1, AB + (cj * 16) * nzp + np, 1, nzp, mp, lane);
+      const int col = cj * 16 + (lane & 15);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int row = (lane >> 4) + 4 * q; if (row < ca && col < n) g[L.oKnup + row * n + col] = -acc[q]; }
+    }
+  } else {
+    for (int idx = tid; idx < ca * n; idx += nthr) {
+      const int i = idx / n, j = idx % n;
+      double s = 0;
+      for (int l = 0; l < m; ++l) s += g[L.oZnu + i * mp + l] * AB[j * nzp + np + l];
+      g[L.oKnup + idx] = -s;
+    }
+  }
+#pragma unroll
+  for (int sidx = 0; sidx < 2; ++sidx) {
+    const int t = wv + sidx * nw;
+    if (t < nbm * nb) {
+      const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = ri * 16 + (lane >> 4) + 4 * q;
+        KM[row * np + col] = ures[sidx][q];
+        if (row < m && col < n) g[L.oKu + row * n + col] = -ures[sidx][q];
+      }
+    }
+  }
+  __syncthreads();
+  // ---- stage 5: Gamma = -Bc U1 - mu_d (T T^T - mu_d T Pt T^T) ----
+  for (int t = wv; t < nb * nb; t += nw) {
+    const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+    d4_t acc = d4_t{0, 0, 0, 0};
+    mma_tile<false>(acc, AB + (ri * 16) * nzp + np, nzp, 1, KM + cj * 16, np, 1, mp, lane);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = ri * 16 + (lane >> 4) + 4 * q;
+      if (row < n && col < n) {
+        const double tt = (row < 6 && col < 6) ? g6[row * 6 + col] : (row == col ? 1.0 : 0.0);
+        g[L.oGam + row * n + col] = -acc[q] - mud * (tt - mud * PT[row * ldp + col]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_leg_condense: grid (nlegs - 1, B), leg j of instance b, backwards over its knots.  Lm (this knot's dp/dtheta) stays in LDS, Sg in the
+// accumulator registers of the matrix cores over the whole leg; Phi and Gamma of the next knot are requested while this one computes.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LcLds { int np, ldp, nb; int LM, BA, BB, vec, total_bytes; };
+static inline LcLds make_lc_lds(int n) {
+  LcLds s;
+  s.np = (n + 15) & ~15; s.ldp = s.np + 1; s.nb = s.np / 16;
+  int o = 0;
+  auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
+  s.LM = take(s.np * s.ldp); s.BA = take(s.np * s.ldp); s.BB = take(s.np * s.ldp); s.vec = take(3 * s.np + 16);
+  s.total_bytes = o * 8;
+  return s;
+}
+#define LC_TILES 4   // nb^2 <= 25 output tiles on 8 wavefronts
+#define LC_STILES 2  // nb (nb + 1) / 2 <= 15 lower-triangle tiles of Sg
+
+// (per-lane index expressions are kept phase-local by passing the lane ids through an empty asm, as in riccati_mfma.h: hoisted out of
+// the knot loop they would be spilled)
+#define LEG_LAUNDER() do { asm volatile("" : "+v"(tid), "+v"(lane)); wv = __builtin_amdgcn_readfirstlane(tid >> 6); } while (0)
+__global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds S) {
+  const Layout& L = a.L;
+  const int j = blockIdx.x, b = blockIdx.y, nthr = blockDim.x, nw = nthr >> 6;
+  int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const InstState& st = a.inst[b];
+  if (st.done || st.skip_step) return;
+  const int n = L.n, np = S.np, ldp = S.ldp, nb = S.nb;
+  const int ks = leg_start(a, j), ke = leg_start(a, j + 1) - 1;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *LM = sm + S.LM, *BA = sm + S.BA, *BB = sm + S.BB, *sg = sm + S.vec, *phi = sg + np;
+  for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; LM[idx] = (i == c0 && i < n) ? 1.0 : 0.0; }
+  for (int i = tid; i < np; i += nthr) sg[i] = 0.0;
+  d4_t sacc[LC_STILES];
+  int tri[LC_STILES], tcj[LC_STILES];
+#pragma unroll
+  for (int sidx = 0; sidx < LC_STILES; ++sidx) {
+    sacc[sidx] = d4_t{0, 0, 0, 0};
+    int ri = 0, rem = wv + sidx * nw;
+    while (rem > ri) { rem -= ri + 1; ++ri; }  // t = ri (ri + 1) / 2 + cj, cj <= ri
+    tri[sidx] = ri; tcj[sidx] = rem;
+  }
+  const int nst = nb * (nb + 1) / 2;
+  double pa[LK_PT], pb[LK_PT], pphi;
+  auto prefetch = [&](int kk) {
+    const double* gk = gain_ptr(a, b, kk);
+#pragma unroll
+    for (int u = 0; u < LK_PT; ++u) {
+      const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
+      const bool ok = idx < np * np && i < n && c0 < n;
+      const int src = ok ? i * n + c0 : 0;
+      pa[u] = gk[L.oPhi + src] * (ok ? 1.0 : 0.0);
+      pb[u] = gk[L.oGam + src] * (ok ? 1.0 : 0.0);
+    }
+    pphi = gk[L.ophi + (tid < n ? tid : 0)];
+  };
+  prefetch(ke);
+  for (int k = ke; k >= ks; --k) {
+    LEG_LAUNDER();
+#pragma unroll
+    for (int u = 0; u < LK_PT; ++u) {
+      const int idx = tid + u * nthr;
+      if (idx < np * np) { BA[(idx / np) * ldp + idx % np] = pa[u]; BB[(idx / np) * ldp + idx % np] = pb[u]; }
+    }
+    if (tid < np) phi[tid] = (tid < n) ? pphi : 0.0;
+    __syncthreads();
+    LEG_LAUNDER();
+    if (k > ks) prefetch(k - 1);
+    LEG_LAUNDER();
+    // Lm_k = Phi^T Lm' ; Z = Gamma Lm' (both to registers) ; sg += Lm'^T phi
+    d4_t lres[LC_TILES], zres[LC_TILES];
+#pragma unroll
+    for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      lres[sidx] = d4_t{0, 0, 0, 0}; zres[sidx] = d4_t{0, 0, 0, 0};
+      if (t < nb * nb) {
+        mma_tile<false>(lres[sidx], BA + (t / nb) * 16, 1, ldp, LM + (t % nb) * 16, ldp, 1, np, lane);
+        mma_tile<false>(zres[sidx], BB + ((t / nb) * 16) * ldp, ldp, 1, LM + (t % nb) * 16, ldp, 1, np, lane);
+      }
+    }
+    if (tid < n) { double s = 0; for (int l = 0; l < n; ++l) s += LM[l * ldp + tid] * phi[l]; sg[tid] += s; }
+    __syncthreads();
+    LEG_LAUNDER();
+#pragma unroll
+    for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      if (t < nb * nb) tile_store(BB + ((t / nb) * 16) * ldp + (t % nb) * 16, ldp, zres[sidx], lane);
+    }
+    __syncthreads();
+    LEG_LAUNDER();
+    // Sg += Lm'^T Z on the lower block triangle
+#pragma unroll
+    for (int sidx = 0; sidx < LC_STILES; ++sidx)
+      if (wv + sidx * nw < nst) mma_tile<false>(sacc[sidx], LM + tri[sidx] * 16, 1, ldp, BB + tcj[sidx] * 16, ldp, 1, np, lane);
+    __syncthreads();
+    LEG_LAUNDER();
+    double* gk = gain_ptr(a, b, k);
+#pragma unroll
+    for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      if (t < nb * nb) {
+        const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+        tile_store(LM + (ri * 16) * ldp + cj * 16, ldp, lres[sidx], lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; if (row < n && col < n) gk[L.oLm + row * n + col] = lres[sidx][q]; }
+      }
+    }
+    __syncthreads();
+  }
+  double* lr = leg_ptr(a, b, j);
+#pragma unroll
+  for (int sidx = 0; sidx < LC_STILES; ++sidx)
+    if (wv + sidx * nw < nst) {
+      const int col = tcj[sidx] * 16 + (lane & 15);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = tri[sidx] * 16 + (lane >> 4) + 4 * q;
+        if (row < n && col < n) {
+          if (tri[sidx] != tcj[sidx]) { lr[L.lSg + row * n + col] = sacc[sidx][q]; lr[L.lSg + col * n + row] = sacc[sidx][q]; }
+          else if (col <= row) { lr[L.lSg + row * n + col] = sacc[sidx][q]; lr[L.lSg + col * n + row] = sacc[sidx][q]; }  // diagonal tile: its lower triangle, mirrored
+        }
+      }
+    }
+  for (int i = tid; i < n; i += nthr) lr[L.lsg + i] = sg[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_leg_consensus: grid B.  Backward over the cuts: exact value function at the start of every leg and the linear map of the cut
+// state, x_{j+1} = Zx_j x_j + zc_j (Gauss-Jordan with partial pivoting on I - Sg calP, implicit row permutation); then forward over
+// the cuts: cut states (straight into dxs) and co-states theta ; last, the exact feedback gain of knot 0 (controlFeedbacks()[0]).
+// ---------------------------------------------------------------------------------------------------------------------
+struct LxLds { int np, mp, ldp, nb, nbm; int PC, MA, RB, vec, iw, total_bytes; };
+static inline LxLds make_lx_lds(int n, int m) {
+  LxLds s;
+  s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.ldp = s.np + 1; s.nb = s.np / 16; s.nbm = s.mp / 16;
+  int o = 0;
+  auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
+  s.PC = take(s.np * s.ldp); s.MA = take(s.np * s.ldp); s.RB = take(s.np * s.ldp); s.vec = take(8 * s.np + 16);
+  s.iw = o;
+  s.total_bytes = o * 8 + (2 * s.np + 8) * 4;
+  return s;
+}
+
+__global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLds S) {
+  const Layout& L = a.L;
+  const int b = blockIdx.x, nthr = blockDim.x, nw = nthr >> 6;
+  int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const InstState& st = a.inst[b];
+  if (st.done || st.skip_step) return;
+  const int n = L.n, N = L.N, np = S.np, mp = S.mp, ldp = S.ldp, nb = S.nb, nbm = S.nbm, J = a.nlegs;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *PC = sm + S.PC, *MA = sm + S.MA, *RB = sm + S.RB, *vec = sm + S.vec;
+  double *pc = vec, *rv = vec + np, *ev = vec + 2 * np, *prow_rv = vec + 3 * np, *fcol = vec + 4 * np, *xv = vec + 5 * np, *prowA = vec + 6 * np, *prowB = vec + 7 * np;
+  int* perm = (int*)(sm + S.iw);  // perm[col] = row that was the pivot of column col
+  int* used = perm + np;          // used[row] != 0: row already served as a pivot
+  int* ipiv = used + np;
+  d4_t res[LC_TILES];
+  // value function at the start of the last leg
+  {
+    const double* gl = gain_ptr(a, b, leg_start(a, J - 1));
+    for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; PC[idx] = (i < n && c0 < n) ? gl[L.oP + i * n + c0] : 0.0; }
+    for (int i = tid; i < np; i += nthr) pc[i] = (i < n) ? gl[L.op + i] : 0.0;
+  }
+  __syncthreads();
+  for (int j = J - 2; j >= 0; --j) {
+    LEG_LAUNDER();
+    double* lr = leg_ptr(a, b, j);
+    double* gs = gain_ptr(a, b, leg_start(a, j));
+    // calP_{j+1} out (the next pass starts leg j from it) ; PC <- dP = calP_{j+1} - (the guess leg j carried in this pass): the leg's
+    // terminal gradient is Pg x + theta, so theta = dP x_cut + calp ; dP, calp out (the forward part computes theta from them) ;
+    // MA <- Sg ; RB <- Lm^T
+    for (int i = wv; i < n; i += nw)
+      for (int c0 = lane; c0 < n; c0 += 64) {
+        const double pnew = PC[i * ldp + c0], pold = a.leg_guess ? lr[L.lcP + i * n + c0] : 0.0, d = pnew - pold;
+        lr[L.lcP + i * n + c0] = pnew; lr[L.ldP + i * n + c0] = d; PC[i * ldp + c0] = d;
+      }
+    for (int i = tid; i < n; i += nthr) lr[L.lcp + i] = pc[i];
+    for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; MA[idx] = (i < n && c0 < n) ? lr[L.lSg + i * n + c0] : 0.0; }
+    for (int idx = tid; idx < np * np; idx += nthr) { const int r = idx / np, c0 = idx % np; RB[c0 * ldp + r] = (r < n && c0 < n) ? gs[L.oLm + r * n + c0] : 0.0; }  // coalesced read, transposed write (odd ld: no conflicts)
+    __syncthreads();
+    // rv = Sg calp + sg ; Mt = I - Sg calP (to registers, then over Sg)
+    for (int i = wv; i < np; i += nw) {
+      double s = 0;
+      for (int c0 = lane; c0 < n; c0 += 64) s += MA[i * ldp + c0] * pc[c0];
+      s = wave_sum(s);
+      if (lane == 0) rv[i] = (i < n) ? s + lr[L.lsg + i] : 0.0;
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      res[sidx] = d4_t{0, 0, 0, 0};
+      if (t < nb * nb) mma_tile<true>(res[sidx], MA + ((t / nb) * 16) * ldp, ldp, 1, PC + (t % nb) * 16, ldp, 1, np, lane);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      if (t < nb * nb) {
+        const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; MA[row * ldp + col] = res[sidx][q] + (row == col ? 1.0 : 0.0); }  // pad rows: identity
+      }
+    }
+    for (int i = tid; i < np; i += nthr) used[i] = 0;
+    __syncthreads();
+    // Gauss-Jordan on [MA | RB | rv], pivot = largest entry of the column among the rows not used yet
+    for (int col = 0; col < n; ++col) {
+      LEG_LAUNDER();
+      if (wv == 0) {
+        double best = -1.0;
+        int bi = 0;
+        for (int r = lane; r < n; r += 64) { const double v = used[r] ? -1.0 : fabs(MA[r * ldp + col]); if (v > best) { best = v; bi = r; } }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+          const double ob = __shfl_xor(best, off);
+          const int oi = __shfl_xor(bi, off);
+          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) { ipiv[0] = bi; perm[col] = bi; used[bi] = 1; }
+      }
+      __syncthreads();
+      const int p = ipiv[0];
+      {
+        const double inv = 1.0 / MA[p * ldp + col];
+        for (int z = tid; z < 2 * np + 1; z += nthr) {
+          if (z < np) prowA[z] = MA[p * ldp + z] * inv;
+          else if (z < 2 * np) prowB[z - np] = RB[p * ldp + z - np] * inv;
+          else prow_rv[0] = rv[p] * inv;
+        }
+        for (int r = tid; r < n; r += nthr) fcol[r] = MA[r * ldp + col];
+      }
+      __syncthreads();
+      // rows r != p: row_r -= fcol[r] * prow ; row p = prow.  Columns of MA up to col are unit vectors already (not touched, except col itself)
+      const int za = col, wa = n - za;  // MA columns za .. n-1
+      for (int idx = tid; idx < n * (wa + n); idx += nthr) {
+        const int r = idx / (wa + n), zz = idx % (wa + n);
+        if (zz < wa) { const int z = za + zz; MA[r * ldp + z] = (r == p) ? prowA[z] : MA[r * ldp + z] - fcol[r] * prowA[z]; }
+        else { const int z = zz - wa; RB[r * ldp + z] = (r == p) ? prowB[z] : RB[r * ldp + z] - fcol[r] * prowB[z]; }
+      }
+      for (int r = tid; r < n; r += nthr) rv[r] = (r == p) ? prow_rv[0] : rv[r] - fcol[r] * prow_rv[0];
+      __syncthreads();
+    }
+    LEG_LAUNDER();
+    // unknown `col` sits in row perm[col]: Zx, zc out in natural order ; then bring RB into natural order in LDS (through registers)
+    {
+      double zr[LK_PT];
+#pragma unroll
+      for (int u = 0; u < LK_PT; ++u) {
+        const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
+        zr[u] = (idx < np * np && i < n && c0 < n) ? RB[perm[i] * ldp + c0] : 0.0;
+      }
+      for (int i = tid; i < n; i += nthr) ev[i] = rv[perm[i]];
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < LK_PT; ++u) {
+        const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
+        if (idx < np * np) { RB[i * ldp + c0] = zr[u]; if (i < n && c0 < n) lr[L.lZx + i * n + c0] = zr[u]; }
+      }
+      for (int i = tid; i < np; i += nthr) { rv[i] = (i < n) ? ev[i] : 0.0; if (i < n) lr[L.lzc + i] = ev[i]; }
+      __syncthreads();
+    }
+    LEG_LAUNDER();
+    // D = calP Zx (to registers, then into MA) ; ev = calP zc + calp
+#pragma unroll
+    for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      res[sidx] = d4_t{0, 0, 0, 0};
+      if (t < nb * nb) mma_tile<false>(res[sidx], PC + ((t / nb) * 16) * ldp, ldp, 1, RB + (t % nb) * 16, ldp, 1, np, lane);
+    }
+    for (int i = wv; i < np; i += nw) {
+      double s = 0;
+      for (int c0 = lane; c0 < n; c0 += 64) s += PC[i * ldp + c0] * rv[c0];
+      s = wave_sum(s);
+      if (lane == 0) ev[i] = (i < n) ? s + pc[i] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      if (t < nb * nb) tile_store(MA + ((t / nb) * 16) * ldp + (t % nb) * 16, ldp, res[sidx], lane);
+    }
+    LEG_LAUNDER();
+    if (j > 0) {
+      // calP_j = P_j + Lm_j D ; calp_j = p_j + Lm_j ev   (RB <- Lm_j)
+      for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; RB[idx] = (i < n && c0 < n) ? gs[L.oLm + i * n + c0] : 0.0; }
+      __syncthreads();
+      const int nst = nb * (nb + 1) / 2;
+      d4_t pres[LC_STILES];
+#pragma unroll
+      for (int sidx = 0; sidx < LC_STILES; ++sidx) {
+        const int t = wv + sidx * nw;
+        pres[sidx] = d4_t{0, 0, 0, 0};
+        if (t < nst) {
+          int ri = 0, rem = t;
+          while (rem > ri) { rem -= ri + 1; ++ri; }
+          mma_tile<false>(pres[sidx], RB + (ri * 16) * ldp, ldp, 1, MA + rem * 16, ldp, 1, np, lane);
+        }
+      }
+      for (int i = wv; i < np; i += nw) {
+        double s = 0;
+        for (int c0 = lane; c0 < n; c0 += 64) s += RB[i * ldp + c0] * ev[c0];
+        s = wave_sum(s);
+        if (lane == 0) pc[i] = (i < n) ? s + gs[L.op + i] : 0.0;
+      }
+      __syncthreads();
+      // lower block triangle + P_j, mirrored; diagonal tiles symmetrised (0.5 (a + a^T)) through LDS
+#pragma unroll
+      for (int sidx = 0; sidx < LC_STILES; ++sidx) {
+        const int t = wv + sidx * nw;
+        if (t < nst) {
+          int ri = 0, rem = t;
+          while (rem > ri) { rem -= ri + 1; ++ri; }
+          const int col = rem * 16 + (lane & 15);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = ri * 16 + (lane >> 4) + 4 * q;
+            const double v = (row < n && col < n) ? pres[sidx][q] + gs[L.oP + row * n + col] : 0.0;
+            PC[row * ldp + col] = v;
+            if (ri != rem) PC[col * ldp + row] = v;
+          }
+          if (ri == rem) {
+            double tv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; tv[q] = 0.5 * (PC[row * ldp + col] + PC[col * ldp + row]); }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; PC[row * ldp + col] = tv[q]; }
+          }
+        }
+      }
+      __syncthreads();
+    } else {
+      // exact K_0 = K_0 + Kth_0 D_0 with Kth_0 = Ku_0 Lm_1 (Lm_1 = I when leg 0 is a single knot) ; MA = D_0
+      double* g0 = gain_ptr(a, b, 0);
+      const bool single = leg_start(a, 1) == 1;
+      const double* g1 = gain_ptr(a, b, 1);
+      __syncthreads();
+      for (int idx = tid; idx < mp * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; RB[idx] = (i < L.m && c0 < n) ? g0[L.oKu + i * n + c0] : 0.0; }
+      for (int idx = tid; idx < np * ldp; idx += nthr) {
+        const int i = idx / ldp, c0 = idx % ldp;
+        PC[idx] = (i < n && c0 < n) ? (single ? (i == c0 ? 1.0 : 0.0) : g1[L.oLm + i * n + c0]) : 0.0;
+      }
+      __syncthreads();
+      d4_t kres[2];
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const int t = wv + sidx * nw;
+        kres[sidx] = d4_t{0, 0, 0, 0};
+        if (t < nbm * nb) mma_tile<false>(kres[sidx], RB + ((t / nb) * 16) * ldp, ldp, 1, PC + (t % nb) * 16, ldp, 1, np, lane);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const int t = wv + sidx * nw;
+        if (t < nbm * nb) tile_store(RB + ((t / nb) * 16) * ldp + (t % nb) * 16, ldp, kres[sidx], lane);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const int t = wv + sidx * nw;
+        if (t < nbm * nb) {
+          d4_t acc = d4_t{0, 0, 0, 0};
+          mma_tile<false>(acc, RB + ((t / nb) * 16) * ldp, ldp, 1, MA + (t % nb) * 16, ldp, 1, np, lane);
+          const int col = (t % nb) * 16 + (lane & 15);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int row = (t / nb) * 16 + (lane >> 4) + 4 * q; if (row < L.m && col < n) g0[L.oK + row * n + col] += acc[q]; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // forward over the cuts: x_{j+1} = Zx_j x_j + zc_j (x_0 = 0: forced initial condition) ; theta_{j+1} = calP_{j+1} x_{j+1} + calp_{j+1}
+  for (int i = tid; i < np; i += nthr) xv[i] = 0.0;
+  __syncthreads();
+  for (int j = 0; j + 1 < J; ++j) {
+    double* lr = leg_ptr(a, b, j);
+    const int cut = leg_start(a, j + 1);
+    for (int i = wv; i < n; i += nw) {
+      double s = 0;
+      for (int c0 = lane; c0 < n; c0 += 64) s += lr[L.lZx + i * n + c0] * xv[c0];
+      s = wave_sum(s);
+      if (lane == 0) { ev[i] = s + lr[L.lzc + i]; a.dxs[((size_t)b * (N + 1) + cut) * n + i] = ev[i]; }
+    }
+    __syncthreads();
+    for (int i = wv; i < n; i += nw) {
+      double s = 0;
+      for (int c0 = lane; c0 < n; c0 += 64) s += lr[L.ldP + i * n + c0] * ev[c0];
+      s = wave_sum(s);
+      if (lane == 0) lr[L.lth + i] = s + lr[L.lcp + i];
+    }
+    for (int i = tid; i < n; i += nthr) xv[i] = ev[i];
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_leg_apply: grid (N, B), block 256.  Knot k of a parametric leg with end co-state theta: p' = Lm_{k+1} theta (theta itself at
+// the last knot of the leg) ; p += Lm_k theta ; k += Ku p' ; knu[active] += Knup p' ; phi += Gamma p'.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_leg_apply(SolverArgs a) {
+  const Layout& L = a.L;
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nthr >> 6;
+  const InstState& st = a.inst[b];
+  if (st.done || st.skip_step) return;
+  const int j = leg_of_knot(a, k);
+  if (j + 1 >= a.nlegs) return;
+  const int n = L.n, ke = leg_start(a, j + 1) - 1;
+  const double* kn = knot_ptr(a, b, k);
+  double* g = gain_ptr(a, b, k);
+  const int m = (int)kn[L.oMISC + MISC_M], c = (int)kn[L.oMISC + MISC_NC];
+  const double* th_g = leg_ptr(a, b, j) + L.lth;
+  __shared__ double th[128], pn[128];
+  __shared__ int act_idx[256];
+  __shared__ int wcnt[4];
+  for (int i = tid; i < n; i += nthr) th[i] = th_g[i];
+  // active rows in order (ballot prefix; c <= 256 = block size, checked by the host)
+  const bool is_act = tid < c && kn[L.oACT + (tid < c ? tid : 0)] != 0.0;
+  const unsigned long long amask = __ballot(is_act);
+  if (lane == 0) wcnt[wv] = __popcll(amask);
+  __syncthreads();
+  int ca = 0;
+  {
+    int off = 0;
+    for (int q = 0; q < nw; ++q) { if (q < wv) off += wcnt[q]; ca += wcnt[q]; }
+    if (is_act) act_idx[off + __popcll(amask & ((1ull << lane) - 1ull))] = tid;
+  }
+  if (k == ke) { for (int i = tid; i < n; i += nthr) pn[i] = th[i]; }
+  else {
+    const double* gn = gain_ptr(a, b, k + 1);
+    for (int i = wv; i < n; i += nw) {
+      double s = 0;
+      for (int c0 = lane; c0 < n; c0 += 64) s += gn[L.oLm + i * n + c0] * th[c0];
+      s = wave_sum(s);
+      if (lane == 0) pn[i] = s;
+    }
+  }
+  __syncthreads();
+  for (int r = wv; r < 2 * n + m + ca; r += nw) {
+    // rows: [0, n) p += Lm_k theta ; [n, 2n) phi += Gamma p' ; [2n, 2n + m) k += Ku p' ; then the active constraint rows
+    const double* row;
+    const double* x;
+    double* dst;
+    if (r < n) { row = g + L.oLm + r * n; x = th; dst = g + L.op + r; }
+    else if (r < 2 * n) { row = g + L.oGam + (r - n) * n; x = pn; dst = g + L.ophi + (r - n); }
+    else if (r < 2 * n + m) { row = g + L.oKu + (r - 2 * n) * n; x = pn; dst = g + L.ok + (r - 2 * n); }
+    else { row = g + L.oKnup + (r - 2 * n - m) * n; x = pn; dst = g + L.oknu + act_idx[r - 2 * n - m]; }
+    double s = 0;
+    for (int c0 = lane; c0 < n; c0 += 64) s += row[c0] * x[c0];
+    s = wave_sum(s);
+    if (lane == 0) *dst += s;
+  }
+}

@@ -14,6 +14,7 @@
 #include "eval_vector.h"
 #include "riccati_mfma.h"
 #include "closed_loop.h"
+#include "legs.h"
 
 #define HIP_OK(expr)                                                                                  \
   do {                                                                                                \
@@ -63,6 +64,21 @@ struct mpc_solver {
   RicLds ric{};
   ClLds cl{};
   bool use_mfma_riccati = false;
+  // parallel-in-time legs (legs.h)
+  LkLds lk{};
+  LcLds lc{};
+  LxLds lx{};
+  bool legs_ok = false;  // the dimensions fit the leg kernels (np <= 80, mp <= 32, LDS carve-outs)
+  double* d_legbuf = nullptr;
+  bool leg_guess_valid = false;  // the leg records hold the cut Hessians of an earlier pass (terminal costs of the legs)
+  int leg_guess_now = 0;
+  int eff_legs() const {
+    if (!legs_ok) return 1;
+    int J = opt.riccati_legs;
+    if (J > MPC_MAX_LEGS) J = MPC_MAX_LEGS;
+    if (J > L.N) J = L.N;
+    return J < 1 ? 1 : J;
+  }
   // per-kernel timing (mpc_profile): event pairs recorded around every launch while enabled
   struct ProfSlot {
     const char* name;
@@ -108,6 +124,7 @@ struct mpc_solver {
     a.spec_on = (tick_reuse && opt.max_iters == 1 && L.space == MPC_SPACE_MULTIBODY) ? 1 : 0;
     a.reuse_on = (a.spec_on && reuse_this_pass) ? 1 : 0;
     a.reuse_k0 = perfect_feedback ? 1 : 0;
+    a.nlegs = eff_legs(); a.legbuf = d_legbuf; a.leg_guess = leg_guess_now;
     a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = phase_timers ? d_prof : nullptr;
     return a;
   }
@@ -174,7 +191,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->d_knots = s->alloc<double>(B * N1 * L.knot_stride);
   s->d_tknots = s->alloc<double>(B * L.n_alpha * N1 * T.knot_stride);
   s->d_gains = s->alloc<double>(B * N1 * L.gain_stride);
-  s->d_work = s->alloc<double>(B * L.work_stride);
+  s->d_work = s->alloc<double>(B * MPC_MAX_LEGS * (size_t)L.work_stride);  // per (leg, instance): the legs of one instance run side by side
   s->d_trial_phi = s->alloc<double>(B * L.n_alpha * N1);
   s->d_inst = s->alloc<InstState>(B);
   s->d_all_done = s->alloc<int>(4);
@@ -211,6 +228,19 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 96, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+  }
+  // parallel-in-time legs: every kernel of legs.h keeps three n x n operands (or [A B] + Pt) in LDS
+  s->lk = make_lk_lds(L.n, L.m); s->lc = make_lc_lds(L.n); s->lx = make_lx_lds(L.n, L.m);
+  s->legs_ok = s->use_mfma_riccati && s->ric.np <= 80 && s->ric.mp <= 32 && L.c <= 256 && s->ric.gfull == 1 && s->lk.total_bytes <= 160 * 1024 &&
+               s->lc.total_bytes <= 160 * 1024 && s->lx.total_bytes <= 160 * 1024 && !getenv("MPC_HIP_NO_LEGS");
+  if (s->legs_ok) {
+    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    s->d_legbuf = s->alloc<double>(B * (MPC_MAX_LEGS - 1) * (size_t)L.leg_stride);
   }
   HIP_OK(hipStreamSynchronize(s->stream));
 }
@@ -281,15 +311,6 @@ static void launch_pass(mpc_solver* s) {
   s->reuse_this_pass = false;  // further passes of the same run evaluate everything
   s->timed(1, "k_lagrangian", [&] { hipLaunchKernelGGL(k_lagrangian, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   s->timed(2, "k_decide", [&] { hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(128), 0, s->stream, a); });
-  s->timed(3, "k_riccati_backward", [&] {
-    if (s->use_mfma_riccati && s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_SMALL_THREADS, 16>), dim3(L.B), dim3(RIC_SMALL_THREADS), s->ric.total_bytes, s->stream, a, s->ric);  // small problems: one wavefront
-    else if (s->use_mfma_riccati && s->ric.sq && s->ric.np <= 80) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
-    else if (s->use_mfma_riccati && s->ric.sq) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 96, true>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
-    else if (s->use_mfma_riccati && s->ric.np <= 80) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);  // fewer tiles per wavefront: lower register pressure
-    else if (s->use_mfma_riccati) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 96>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
-    else hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);
-  });
   // forward sweep: closed-loop transitions Phi / phi for all knots in parallel, then one mat-vec per knot (closed_loop.h);
   // the three-mat-vec sweep remains for dimensions whose operands do not fit the LDS of k_closed_loop
   // The knot-parallel kernel costs (N x B) workgroups: it pays when the GPU is mostly idle during the sweep (small
@@ -297,6 +318,45 @@ static void launch_pass(mpc_solver* s) {
   // (options.forward_mode overrides: a handle cannot see the other handles that share its GPU — with 4 shards of 16 instances the
   // sweep gives 4714 solves/s against 4551)
   a.abdz = nullptr;
+  const int J = a.nlegs;
+  // legs without a value-function guess at the cuts (first pass of the handle): two sweeps, the second from the Hessians the first
+  // one found (legs.h) ; MPC_LEGS_PLAIN=1: always one sweep from zero (intermediates comparable with the oracle's)
+  const char* plain_env = getenv("MPC_LEGS_PLAIN");
+  const bool plain = plain_env && atoi(plain_env) > 0;
+  const int sweeps = (J > 1 && !plain && !s->leg_guess_valid) ? 2 : 1;
+  for (int sweep = 0; sweep < sweeps; ++sweep) {
+  s->leg_guess_now = (J > 1 && !plain && (s->leg_guess_valid || sweep > 0)) ? 1 : 0;
+  a = s->args();
+  a.abdz = nullptr;
+  s->timed(3, "k_riccati_backward", [&] {
+    if (J > 1) {
+      // parallel-in-time: workgroup (instance, leg), the last leg first
+      if (s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>), dim3(L.B * J), dim3(RIC_SMALL_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
+      else if (s->ric.sq) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true, true>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, false, true>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
+    }
+    else if (s->use_mfma_riccati && s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_SMALL_THREADS, 16>), dim3(L.B), dim3(RIC_SMALL_THREADS), s->ric.total_bytes, s->stream, a, s->ric);  // small problems: one wavefront
+    else if (s->use_mfma_riccati && s->ric.sq && s->ric.np <= 80) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
+    else if (s->use_mfma_riccati && s->ric.sq) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 96, true>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
+    else if (s->use_mfma_riccati && s->ric.np <= 80) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);  // fewer tiles per wavefront: lower register pressure
+    else if (s->use_mfma_riccati) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 96>), dim3(L.B), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
+    else hipLaunchKernelGGL(k_riccati_backward, dim3(L.B), dim3(256), s->riccati_lds(), s->stream, a);
+  });
+  if (J > 1) {
+    // legs: per-knot closed-loop transitions and parametric terms, condensation of every leg, consensus over the cuts, final
+    // affine terms, then the forward sweeps of the legs side by side
+    s->timed(12, "k_closed_loop", [&] { hipLaunchKernelGGL(k_leg_knot, dim3(L.N, L.B), dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk); });
+    s->timed(13, "k_leg_condense", [&] { hipLaunchKernelGGL(k_leg_condense, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc); });
+    s->timed(14, "k_leg_consensus", [&] { hipLaunchKernelGGL(k_leg_consensus, dim3(L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx); });
+  }
+  }
+  if (J > 1) {
+    s->leg_guess_valid = true;
+    s->timed(15, "k_leg_apply", [&] { hipLaunchKernelGGL(k_leg_apply, dim3(L.N, L.B), dim3(256), 0, s->stream, a); });
+    s->timed(4, "k_forward", [&] { hipLaunchKernelGGL((k_forward_phi<4, 10>), dim3(L.B * J), dim3(512), 2 * L.n * sizeof(double), s->stream, a); });
+  } else {
   const bool fw_phi = s->cl.total_bytes <= 160 * 1024 && L.n <= 80 && L.m <= 32 && (s->opt.forward_mode == 0 ? L.B * L.N <= 2048 : s->opt.forward_mode == 2);
   if (fw_phi) {
     s->timed(12, "k_closed_loop", [&] { hipLaunchKernelGGL(k_closed_loop, dim3(L.N, L.B), dim3(CL_THREADS), s->cl.total_bytes, s->stream, a, s->cl); });
@@ -310,6 +370,7 @@ static void launch_pass(mpc_solver* s) {
       else if (fits && L.n <= 80 && L.m <= 48) hipLaunchKernelGGL((k_forward_prefetch<6, 10>), dim3(L.B), dim3(512), fw_lds, s->stream, a);
       else hipLaunchKernelGGL(k_forward, dim3(L.B), dim3(1024), fw_lds, s->stream, a);
     });
+  }
   }
   s->timed(5, "k_duals", [&] { hipLaunchKernelGGL(k_duals, dim3(L.N + 1, L.B), dim3(256), (L.nz + 3 * L.n + 16) * sizeof(double), s->stream, a); });
   // linesearch: evaluate the full step first; the backtracking candidates alpha = 2^-i, i >= 1, are only
@@ -325,8 +386,9 @@ static void launch_pass(mpc_solver* s) {
 
 // passes_enqueued: passes already put on the stream by the asynchronous entry point (their completion flag is
 // checked first); the loop then continues synchronously until every instance is done.
-static void report_status(int B, const InstState* st, mpc_stats* stats) {
+static void report_status(mpc_solver* s, int B, const InstState* st, mpc_stats* stats) {
   for (int b = 0; b < B; ++b) {
+    if (st[b].done >= 2) s->leg_guess_valid = false;  // do not start the legs of the next pass from what a failed sweep left
     if (st[b].done >= 2) throw std::runtime_error("Riccati factorisation failed on instance " + std::to_string(b) + " (code " + std::to_string(st[b].done) + ")");
     if (!stats) continue;
     mpc_stats& o = stats[b];
@@ -358,7 +420,7 @@ static void run_impl(mpc_solver* s, mpc_stats* stats, int passes_enqueued = 0) {
     }
     if (done != 0) break;
   }
-  report_status(L.B, st.data(), stats);
+  report_status(s, L.B, st.data(), stats);
 }
 
 #define MPC_TRY(h, ...)                 \
@@ -406,8 +468,10 @@ int mpc_set_options(mpc_solver* s, const mpc_options* opt) {
   MPC_TRY(s, {
     spec_clear(s);
     if (!opt->rollout_linear || !opt->force_initial_condition) throw std::runtime_error("only ROLLOUT_LINEAR with force_initial_condition is implemented");
+    const int legs_before = s->eff_legs();
     s->opt = *opt;
     if (s->opt.ls_max_steps > s->L.n_alpha) s->opt.ls_max_steps = s->L.n_alpha;
+    if (s->eff_legs() != legs_before) s->leg_guess_valid = false;  // the cuts moved: the kept Hessians belong to other knots
   })
 }
 
@@ -637,7 +701,7 @@ int mpc_wait(mpc_solver* s, mpc_stats* stats) {
     bool done = true;
     for (int b = 0; b < L.B; ++b) if (!st[b].done) done = false;
     if (!done && s->async_pending == 0) run_impl(s, stats, 1);  // continues from pass 1: the enqueued pass 0 is complete
-    else report_status(L.B, st, stats);
+    else report_status(s, L.B, st, stats);
   })
 }
 
@@ -740,6 +804,28 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
     else if (nm == "knu") mat(g.data() + L.oknu, 1, c, c);
     else if (nm == "Mx") mat(g.data() + L.oMx, k < L.N ? n : 0, n, n);
     else if (nm == "mx") mat(g.data() + L.omx, 1, k < L.N ? n : 0, n);
+    else if (nm == "Phi") mat(g.data() + L.oPhi, k < L.N ? n : 0, n, n);
+    else if (nm == "phi") mat(g.data() + L.ophi, 1, k < L.N ? n : 0, n);
+    else if (nm == "Gam") mat(g.data() + L.oGam, n, n, n);
+    else if (nm == "Ku") mat(g.data() + L.oKu, m, n, n);
+    else if (nm == "Lm") mat(g.data() + L.oLm, n, n, n);
+    else if (nm == "Mu") mat(g.data() + L.oMu, m, m, L.mpad);
+    else if (nm == "Znu" || nm == "Knup") {  // rows of the ACTIVE constraints, scattered to their row numbers like the oracle's (inactive rows zero)
+      const bool zn = nm == "Znu";
+      const int cols = zn ? m : n, ld = zn ? L.mpad : n;
+      v.assign((size_t)c * cols, 0.0);
+      int ai = 0;
+      for (int i = 0; i < c; ++i) if (kn[L.oACT + i] != 0.0) { for (int j = 0; j < cols; ++j) v[(size_t)i * cols + j] = g[(zn ? L.oZnu : L.oKnup) + ai * ld + j]; ++ai; }
+    }
+    else if (nm == "Sg" || nm == "sg" || nm == "Zx" || nm == "zc" || nm == "calP" || nm == "calp" || nm == "theta") {
+      // records of parametric leg k (k = leg index here)
+      if (!s->d_legbuf || k >= MPC_MAX_LEGS - 1) throw std::runtime_error("debug_get: no such leg record");
+      const double* lr = s->d_legbuf + ((size_t)b * (MPC_MAX_LEGS - 1) + k) * L.leg_stride;
+      if (nm == "Sg") dev_vec(lr + L.lSg, n * n); else if (nm == "sg") dev_vec(lr + L.lsg, n); else if (nm == "Zx") dev_vec(lr + L.lZx, n * n);
+      else if (nm == "zc") dev_vec(lr + L.lzc, n); else if (nm == "calP") dev_vec(lr + L.ldP, n * n);  // what the consensus worked on (the oracle's "calP")
+      else if (nm == "calp") dev_vec(lr + L.lcp, n);
+      else dev_vec(lr + L.lth, n);
+    }
     else if (nm == "ric_prof") { dev_vec(s->d_prof + (size_t)b * 64, 64); HIP_OK(hipMemsetAsync(s->d_prof + (size_t)b * 64, 0, 64 * sizeof(double), s->stream)); HIP_OK(hipStreamSynchronize(s->stream)); }
     else if (nm == "dx") dev_vec(s->d_dxs + ((size_t)b * (L.N + 1) + k) * n, n);
     else if (nm == "du") { if (k >= L.N) throw std::runtime_error("no du at the terminal knot"); dev_vec(s->d_dus + ((size_t)b * L.N + k) * L.m, L.m); }

@@ -40,13 +40,14 @@
 // nv, ks, Ke of the structured products, derived inside the phase that uses them (as scalars living across the whole knot loop they
 // push the SGPR spills past what the spill VGPRs hold, and every reload of those drains the loads in flight)
 #define RIC_SQ_DIMS() int n_l_ = n; asm volatile("" : "+s"(n_l_)); const int nv = SQ ? (n_l_ >> 1) : 0, ks = SQ ? (nv & ~3) : 0, Ke = SQ ? ((n_l_ + 3) & ~3) - ks : np; (void)nv; (void)ks; (void)Ke
-#define RIC_PROF(slot) do { RIC_LAUNDER(); if (tid == 0 && a.prof) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
+#define RIC_PROF(slot) do { RIC_LAUNDER(); if (tid == 0 && a.prof && !par) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 struct RicLds {
   int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb, gfull, st_lds, ovl, sq, nv;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
   int PT, R1, LP, LI, AB, GP, vec, iwork, total_bytes;
   // KKT / value-update workspace carved from R1 once AB is dead
   int Lr, LIr, W, ST, CT, VX, Y, SC, LIs;
+  int K2;  // legs: W2 (mp x (mp+1)) | VX2 (16 x (mp+1)) of the [I; 0] solve — inside the PT region when it fits (dead during step 6)
 };
 
 static inline RicLds make_ric_lds(int n, int m, int c, int gfull = 1, int st_lds = 1) {
@@ -90,6 +91,8 @@ static inline RicLds make_ric_lds(int n, int m, int c, int gfull = 1, int st_lds
   }
   o = end1 > end2 ? end1 : end2;
   if (end3 > o) o = end3;
+  s.K2 = s.PT;
+  if (s.np * (s.np + 1) < (s.mp + 16) * (s.mp + 1)) s.K2 = take((s.mp + 16) * (s.mp + 1));  // small problems: own space
   s.vec = take(7 * s.nzp + 2 * c + 96 + 80);  // ph ft vv w gh pvec (6 nzp) | dtl kvc (2 c) | e6l wred t6l (92) | gpre (nzp) | d12l (74)
   s.sq = 0; s.nv = 0;  // structured [A B] (set by the caller for whole-body problems, see step 5)
   s.iwork = o;
@@ -131,7 +134,11 @@ DEV double wave_sum_r(double v) { return wave_sum(v); }  // DPP reduction of sol
 // RT = threads per workgroup.  RT = RIC_THREADS (8 wavefronts) is the general kernel (np <= 96, nzp <= 128); RT = RIC_SMALL_THREADS is the
 // small-problem variant (np = mp = 16, at most RT constraint rows: the centroidal OCP) — the same code with fewer wavefronts.
 // SQ: structured dynamics rows (whole-body problems, layout.h oD12): only the v rows of [A B] are loaded and multiplied
-template <int RT, int NPMAX, bool SQ = false>
+// LEGS: parallel-in-time sweep (legs.h).  The grid is B x nlegs workgroups; workgroup (b, leg) walks the knots of its leg only.  A
+// leg other than the last starts from a ZERO value function at its end (its end co-state is a parameter handled by
+// k_leg_condense / k_leg_consensus) and additionally leaves, per knot, the (u,u) and (nu,u) blocks of the inverse stage KKT
+// matrix (Mu, Znu: the solve with the right-hand side [I; 0] rides along in otherwise idle wavefronts).
+template <int RT, int NPMAX, bool SQ = false, bool LEGS = false>
 __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   constexpr int NWV = RT / 64, NBMAX = NPMAX / 16, NZTMAX = NPMAX > 16 ? 8 : 2;
   constexpr int PT_ROWS = (NPMAX + NWV - 1) / NWV;                                // rows of Pt per wavefront
@@ -142,11 +149,15 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   constexpr bool CT_PREFETCH = NPMAX <= 80;  // the largest instantiation has no registers to spare for it
   constexpr int CT_ROWS = 16 / NWV, Y_ELEMS = (NPMAX > 16 ? 48 : 16) * 16 / RT + ((NPMAX > 16 ? 48 : 16) * 16 % RT ? 1 : 0);  // per-thread shares of CT (16 rows) and Y (mp x 16)  // lower-triangle tiles of the u rows of Hh a wavefront can keep in registers
   const Layout& L = a.L;
-  const int b = blockIdx.x, nthr = blockDim.x, nw = nthr >> 6;
+  const int nthr = blockDim.x, nw = nthr >> 6;
+  // legs: the last leg (the only one with the terminal node, never shorter than the others) is dispatched first
+  const int b = LEGS ? (int)(blockIdx.x % L.B) : (int)blockIdx.x, leg = LEGS ? a.nlegs - 1 - (int)(blockIdx.x / L.B) : 0;
+  const bool par = LEGS && leg + 1 < a.nlegs;  // parametric leg: zero value function at its end
   int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // re-derived at every phase boundary (RIC_LAUNDER)
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
   const int n = L.n, nz = L.nz, N = L.N, nr = n + 1;
+  const int k_top = par ? leg_start(a, leg + 1) - 1 : N - 1, k_bot = LEGS ? leg_start(a, leg) : 0;
   const int np = S.np, ldp = S.np + 1, mp = S.mp, nzp = S.nzp, ldl = S.ldl, ldr = S.ldr, nb = S.nb, nbm = S.nbm, nzt = nzp / 16, lw = S.lw, nwb = S.nwb;
   const double mu = st.mu, mud = mu * a.opt.dyn_al_scale;
   const bool ff = L.space == MPC_SPACE_MULTIBODY;
@@ -166,13 +177,20 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   double* t6l = e6l + 56;   // T6 = (-E6)^-1 (36)
   double* gpre = e6l + 92;  // gradient of the knot (nz); vec holds 7 nzp + 2 c + 92 <= 8 (nzp + c) + 64 doubles
   double* d12l = gpre + nzp;  // D1_b (36) | Dd_b (36) | dt | valid (layout.h, oD12)
-  double* wk = a.work + (size_t)b * L.work_stride;
+  double* wk = a.work + ((size_t)b + (size_t)leg * L.B) * L.work_stride;  // legs: the scratch of (instance, leg) — the legs of an instance run side by side
   double* Hh = wk + L.wHh;  // nz x nz, leading dimension nz (L2-resident scratch)
   double* ST = S.st_lds ? sm + S.ST : wk + L.wG;  // Sh^T (mp x np)
   double* GU = (S.gfull == 2) ? wk + L.wPt : GP;   // G_u (np x mp)
 
   // ---- terminal node: P_N = H + Ca^T Ca / mu ; p_N = grad + Ca^T dt / mu ----
-  {
+  if (par) {
+    // the leg's terminal cost: 1/2 x^T Pg x with Pg = the exact Hessian the consensus found at this cut in the previous pass / tick
+    // (legs.h: the consensus then solves for the difference only), or zero
+    const double* pg = leg_ptr(a, b, leg) + L.lcP;
+    for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; PT[idx] = (a.leg_guess && i < n && c0 < n) ? pg[i * n + c0] : 0.0; }
+    for (int r = tid; r < nzp; r += nthr) pvec[r] = 0.0;
+    __syncthreads();
+  } else {
     const double* kn = knot_ptr(a, b, N);
     double* g = gain_ptr(a, b, N);
     const int c = (int)kn[L.oMISC + MISC_NC];
@@ -213,10 +231,10 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     pre_le = a.lams_e[((size_t)b * (N + 1) + kk + 1) * n + (tid < n ? tid : 0)];
     pre_g = kp[L.oG + (tid < nz ? tid : 0)];
   };
-  prefetch_small(N - 1);
+  prefetch_small(k_top);
 
   long long t0_ = clock64();
-  for (int k = N - 1; k >= 0; --k) {
+  for (int k = k_top; k >= k_bot; --k) {
     const double* kn = knot_ptr(a, b, k);
     double* g = gain_ptr(a, b, k);
     const int m = (int)pre_m, c = (int)pre_c;
@@ -354,7 +372,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       }
     }
     RIC_PROF(18);
-    if (k > 0) prefetch_small(k - 1);  // consumed at the top of the next iteration
+    if (k > k_bot) prefetch_small(k - 1);  // consumed at the top of the next iteration
     RIC_PROF(13);
     if (nser >= 0 && nser <= 7) {
       // ---- 3a. series sum_{i <= nser} (-X)^i Ph, X = mu_d Ph, as a product of factors instead of nser Horner steps:
@@ -869,6 +887,18 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       chol_ok = chol_blocked(Lr, ldr, nbm, LIr, tid, iflag);
     }
     RIC_PROF(10);
+    // legs: the inverse stage KKT matrix applied to [I; 0] -> Mu (m x m), Znu (ca x m).  Column block j2 of the identity is one more
+    // column block next to those of W, solved by wavefront (nwb + j2) % nw from start to end; its operands W2 (mp x mp), VX2 (16 x mp)
+    // live in the PT region, which is dead between step 5 (G_x consumed) and step 7 (next P)
+    double *W2 = sm + S.K2, *VX2 = W2 + mp * (mp + 1);
+    const int ldw2 = mp + 1;
+    const bool kkt2 = par && small_ca;
+    if (LEGS && kkt2)
+      for (int j2 = 0; j2 < nbm; ++j2)
+        if (wv == (nwb + j2) % nw) {
+          for (int idx = lane; idx < mp * 16; idx += 64) { const int i = idx >> 4, cc = j2 * 16 + (idx & 15); W2[i * ldw2 + cc] = (i == cc && i < m) ? 1.0 : 0.0; }
+          trsm_fwd_blocked(Lr, ldr, LIr, nbm, W2 + j2 * 16, ldw2, 1, 0, 1, lane);
+        }
     trsm_fwd_blocked(Lr, ldr, LIr, nbm, W, lw, nwb, wv, nw, lane);  // W = L^-1 T
     if (ca > 0 && small_ca && wv == nw - 1) trsm_fwd_blocked(Lr, ldr, LIr, nbm, Yl, 16, 1, 0, 1, lane);  // Y = L^-1 Da^T
     __syncthreads();
@@ -891,6 +921,13 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
           mma_tile<false>(acc, Yl, 1, 16, W + cj * 16, lw, 1, mp, lane);
           tile_store(VXl + cj * 16, lw, acc, lane);
         }
+        if (LEGS && kkt2)
+          for (int j2 = 0; j2 < nbm; ++j2)
+            if (wv == (nwb + j2) % nw) {
+              d4_t acc = d4_t{0, 0, 0, 0};
+              mma_tile<false>(acc, Yl, 1, 16, W2 + j2 * 16, ldw2, 1, mp, lane);
+              tile_store(VX2 + j2 * 16, ldw2, acc, lane);
+            }
         __syncthreads();
         if (tid == 0) iflag[0] = 1;
         __syncthreads();
@@ -899,6 +936,18 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         if (iflag[0] == 0) { if (tid == 0) a.inst[b].done = 4; return; }
         trsm_fwd_blocked(SCl, 17, LIs, 1, VXl, lw, nwb, wv, nw, lane);
         trsm_bwd_blocked(SCl, 17, LIs, 1, VXl, lw, nwb, wv, nw, lane);
+        if (LEGS && kkt2)
+          for (int j2 = 0; j2 < nbm; ++j2)
+            if (wv == (nwb + j2) % nw) {
+              trsm_fwd_blocked(SCl, 17, LIs, 1, VX2 + j2 * 16, ldw2, 1, 0, 1, lane);
+              trsm_bwd_blocked(SCl, 17, LIs, 1, VX2 + j2 * 16, ldw2, 1, 0, 1, lane);
+              for (int ri = 0; ri < nbm; ++ri) {  // W2 -= Y VX2 (own column block: in order within the wavefront)
+                double* Wt = W2 + (ri * 16) * ldw2 + j2 * 16;
+                d4_t acc = tile_load(Wt, ldw2, lane);
+                mma_tile<true>(acc, Yl + (ri * 16) * 16, 16, 1, VX2 + j2 * 16, ldw2, 1, 16, lane);
+                tile_store(Wt, ldw2, acc, lane);
+              }
+            }
         __syncthreads();
         // W -= Y V
         for (int t = wv; t < nbm * nwb; t += nw) {
@@ -944,7 +993,46 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       }
     }
     trsm_bwd_blocked(Lr, ldr, LIr, nbm, W, lw, nwb, wv, nw, lane);  // U = L^-T (W - Y V)
+    if (LEGS && kkt2)
+      for (int j2 = 0; j2 < nbm; ++j2)
+        if (wv == (nwb + j2) % nw) trsm_bwd_blocked(Lr, ldr, LIr, nbm, W2 + j2 * 16, ldw2, 1, 0, 1, lane);
     __syncthreads();
+    if (LEGS && par) {
+      const int mpd = L.mpad;  // == mp
+      if (small_ca) {
+        for (int idx = tid; idx < mp * mp; idx += nthr) g[L.oMu + idx] = W2[(idx / mp) * ldw2 + idx % mp];
+        for (int idx = tid; idx < ca * mp; idx += nthr) g[L.oZnu + idx] = VX2[(idx / mp) * ldw2 + idx % mp];
+      } else {
+        // many active rows (rare): the same solve by the unblocked routines on the L2-resident scratch
+        double *W2s = wk + L.wAcl, *V2s = wk + L.wLp;  // m x m, ca x m (both free in this kernel)
+        const double *Y = wk + L.wY, *Sc = wk + L.wSc;
+        for (int idx = tid; idx < m * m; idx += nthr) W2s[idx] = (idx / m == idx % m) ? 1.0 : 0.0;
+        __syncthreads();
+        for (int j = tid; j < m; j += nthr)
+          for (int i = 0; i < m; ++i) { double s2 = W2s[i * m + j]; for (int q = 0; q < i; ++q) s2 -= Lr[i * ldr + q] * W2s[q * m + j]; W2s[i * m + j] = s2 / Lr[i * ldr + i]; }
+        __syncthreads();
+        for (int idx = tid; idx < ca * m; idx += nthr) {
+          const int i = idx / m, z = idx % m;
+          double s2 = 0;
+          for (int l = 0; l < m; ++l) s2 += Y[l * ca + i] * W2s[l * m + z];
+          V2s[idx] = s2;
+        }
+        __syncthreads();
+        potrs_block(Sc, ca, ca, V2s, m, m, tid, nthr);
+        for (int idx = tid; idx < m * m; idx += nthr) {
+          const int l = idx / m, z = idx % m;
+          double s2 = 0;
+          for (int i = 0; i < ca; ++i) s2 += Y[l * ca + i] * V2s[i * m + z];
+          W2s[idx] -= s2;
+        }
+        __syncthreads();
+        for (int j = tid; j < m; j += nthr)
+          for (int i = m - 1; i >= 0; --i) { double s2 = W2s[i * m + j]; for (int q = i + 1; q < m; ++q) s2 -= Lr[q * ldr + i] * W2s[q * m + j]; W2s[i * m + j] = s2 / Lr[i * ldr + i]; }
+        __syncthreads();
+        for (int idx = tid; idx < mpd * mpd; idx += nthr) { const int i = idx / mpd, j = idx % mpd; g[L.oMu + idx] = (i < m && j < m) ? W2s[i * m + j] : 0.0; }
+        for (int idx = tid; idx < ca * mpd; idx += nthr) { const int i = idx / mpd, j = idx % mpd; g[L.oZnu + idx] = (j < m) ? V2s[i * m + j] : 0.0; }
+      }
+    }
     RIC_PROF(11);
     // gains out: K, k, Knu, knu ; p = qh + Sh k + Ca^T kv
     for (int i = wv; i < m; i += nw) {

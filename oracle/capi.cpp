@@ -258,6 +258,11 @@ int mpc_debug_get(mpc_solver* h, const char* name, int32_t b, int32_t k, double*
     else if (nm == "T6") { tmp.assign(g.T6, g.T6 + 36); v = &tmp; }
     else if (nm == "Mx") v = &g.Mx;
     else if (nm == "mx") v = &g.mx;
+    else if (nm == "Zx" || nm == "zc" || nm == "calP" || nm == "calp" || nm == "theta") {  // k = index of the parametric leg
+      const auto& src = nm == "Zx" ? in.leg_Zx : nm == "zc" ? in.leg_zc : nm == "calP" ? in.leg_calP : nm == "calp" ? in.leg_calp : in.leg_theta;
+      if (k >= (int)src.size()) throw std::runtime_error("debug_get: no such leg record");
+      v = &src[k];
+    }
     else if (nm == "dx") v = &in.dxs[k];
     else if (nm == "du") { if (k >= s.N()) throw std::runtime_error("no du at the terminal knot"); v = &in.dus[k]; }
     else if (nm == "dvs") v = &in.dvs[k];

@@ -93,6 +93,8 @@ struct Instance {
   std::vector<Gains> gains;
   double mu = 0, inner_tol = 0, prim_tol = 0;
   mpc_stats stats{};
+  // parallel-in-time legs, per parametric leg (debug dumps): Zx | zc | calP | calp | theta
+  std::vector<std::vector<double>> leg_Zx, leg_zc, leg_calP, leg_calp, leg_theta;
 };
 
 struct Solver {
@@ -452,7 +454,7 @@ struct Solver {
   // all legs are independent of one another.  A serial pass over the cuts (consensus) then fixes the cut states and co-states,
   // and the forward sweeps of the legs are independent again.  Same KKT system as the serial sweep: identical results up to
   // round-off.
-  int nlegs() const { int L = opt.riccati_legs; if (L > dims.horizon) L = dims.horizon; if (L < 1) L = 1; return L; }
+  int nlegs() const { int L = opt.riccati_legs; if (L > 16) L = 16; if (L > dims.horizon) L = dims.horizon; if (L < 1) L = 1; return L; }  // 16 = MPC_MAX_LEGS of csrc/layout.h
   int leg_start(int j) const { return (int)((long long)j * dims.horizon / nlegs()); }  // first knot of leg j (leg nlegs()-1 ends with the terminal knot)
 
   // consensus data of leg j < legs-1: cut state dx_{j+1} = Zx dx_j + zc, co-state theta_{j+1} = calP dx_{j+1} + calp
@@ -479,8 +481,11 @@ struct Solver {
     }
   }
 
-  void backward_legs(Instance& in, std::vector<LegLink>& links) const {
+  // ptil[j] (n x n, or empty = zero): guess of the value-function Hessian at the START of leg j (j >= 1), used as the quadratic
+  // terminal cost of leg j - 1; the consensus then only solves for the correction calP - ptil.  calP_out[j] = exact Hessian found.
+  void backward_legs(Instance& in, std::vector<LegLink>& links, const std::vector<std::vector<double>>& ptil, std::vector<std::vector<double>>& calP_out) const {
     const int N = dims.horizon, n = dims.ndx, J = nlegs();
+    calP_out.assign(J, {});
     backward_terminal(in);
     std::vector<double> zeroP((size_t)n * n, 0.0), zerop(n, 0.0), eye((size_t)n * n, 0.0);
     for (int i = 0; i < n; ++i) eye[i * n + i] = 1.0;
@@ -490,7 +495,7 @@ struct Solver {
       const int s = leg_start(j), e = (j + 1 < J) ? leg_start(j + 1) - 1 : N - 1;
       for (int k = e; k >= s; --k) {
         if (j + 1 == J) knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, nullptr, nullptr, nullptr, in.gains[k]);
-        else if (k == e) knot_backward(in, k, zeroP, zerop, &eye, &zeroP, &zerop, in.gains[k]);
+        else if (k == e) knot_backward(in, k, (j + 1 < (int)ptil.size() && !ptil[j + 1].empty()) ? ptil[j + 1] : zeroP, zerop, &eye, &zeroP, &zerop, in.gains[k]);
         else knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, &in.gains[k + 1].Lm, &in.gains[k + 1].Sg, &in.gains[k + 1].sg, in.gains[k]);
       }
     }
@@ -499,6 +504,9 @@ struct Solver {
     std::vector<double> calP = in.gains[leg_start(J - 1)].P, calp = in.gains[leg_start(J - 1)].p;
     for (int j = J - 2; j >= 0; --j) {
       const int s = leg_start(j), e = leg_start(j + 1) - 1;
+      calP_out[j + 1] = calP;
+      // the leg carries ptil[j + 1] itself: the consensus works on the difference (theta = (calP - ptil) x_cut + calp)
+      if (j + 1 < (int)ptil.size() && !ptil[j + 1].empty()) for (size_t i = 0; i < calP.size(); ++i) calP[i] -= ptil[j + 1][i];
       // exact feedback gains of every knot of the leg (checker only: the product corrects knot 0): K + Kth dtheta/dx, dtheta/dx = calP Zx
       for (int k = s; k <= e; ++k) {
         Gains& g = in.gains[k];
@@ -543,11 +551,13 @@ struct Solver {
     // accurately as that of any other knot; what is left of the round-off of the leg's own forward sweep is a dynamics gap of
     // the order of 1e-12 at the cut
     std::vector<std::vector<double>> ths(J, std::vector<double>(n, 0.0));
+    in.leg_Zx.assign(J, {}); in.leg_zc.assign(J, {}); in.leg_calP.assign(J, {}); in.leg_calp.assign(J, {}); in.leg_theta.assign(J, {});
     for (int j = 0; j + 1 < J; ++j) {
       const LegLink& lk = links[j];
       const int s = leg_start(j), c = leg_start(j + 1);
       for (int i = 0; i < n; ++i) { double t = lk.zc[i]; for (int a = 0; a < n; ++a) t += lk.Zx[i * n + a] * in.dxs[s][a]; in.dxs[c][i] = t; }
       for (int i = 0; i < n; ++i) { double t = lk.calp[i]; for (int a = 0; a < n; ++a) t += lk.calP[i * n + a] * in.dxs[c][a]; ths[j][i] = t; }
+      in.leg_Zx[j] = lk.Zx; in.leg_zc[j] = lk.zc; in.leg_calP[j] = lk.calP; in.leg_calp[j] = lk.calp; in.leg_theta[j] = ths[j];
     }
     // apply (csrc/legs.h k_leg_apply): with theta known, the affine terms of the leg's knots take their final values
     //   p += Lm theta, k += Kth theta, knu += Knuth theta, mx += Mth theta ; the sweeps below are then the plain ones
@@ -705,7 +715,16 @@ struct Solver {
     if (crit <= in.inner_tol) return 1;
     if (nlegs() > 1) {
       std::vector<LegLink> links;
-      backward_legs(in, links);
+      std::vector<std::vector<double>> ptil, calP;
+      // Two sweeps: the first from a zero value function at the leg ends, the second with the Hessians the consensus of the first
+      // found at the cuts as terminal costs of the legs.  The consensus then only solves for a small correction: with a zero
+      // guess I - Sg calP mixes the stiffest directions of calP (constraint penalties, 1/mu) with the most controllable ones of
+      // the leg and the cut states lose up to ten digits (complete Talos model, far from the solution).  The HIP library takes
+      // the guess from its previous pass / MPC tick instead (csrc/legs.h).  MPC_LEGS_PLAIN=1: one sweep from zero (both
+      // libraries: the intermediates of the leg kernels are then comparable one to one).
+      const char* ep = std::getenv("MPC_LEGS_PLAIN");
+      const int passes = (ep && std::atoi(ep) > 0) ? 1 : 2;
+      for (int pass = 0; pass < passes; ++pass) { backward_legs(in, links, ptil, calP); ptil = calP; }
       forward_legs(in, links);
     } else {
       backward(in);

@@ -2,6 +2,8 @@
 import numpy as np
 import pytest
 
+from mpc_benchmark_amd import aligator
+
 from mpc_benchmark_amd.problems.centroidal import CentroidalProblem
 
 pytestmark = pytest.mark.gpu
@@ -15,6 +17,8 @@ def _make(lib, horizon, tick=0, max_iters=1):
     cp = CentroidalProblem(horizon=horizon)
     prob = cp.build()
     solver = cp.make_solver(_native_library=lib)
+    if max_iters == 1:
+        solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL  # per-phase parity of the SERIAL sweep: the raw gains of a parallel-in-time leg depend on its guess of the cut Hessian (tests/test_gpu_legs.py covers the legs)
     solver.max_iters = max_iters
     for t in range(tick):
         prob.replaceStageCircular(cp.stage_for_tick(t))

@@ -16,8 +16,10 @@ def _rel(a, b):
     return float(np.max(np.abs(a - b)) / max(1.0, float(np.max(np.abs(b))))) if a.size else 0.0
 
 
-def _solve(lib, prob, fp, xs, us, max_iters):
+def _solve(lib, prob, fp, xs, us, max_iters, serial=True):
     solver = fp.make_solver(_native_library=lib)
+    if serial:
+        solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL  # per-phase parity of the SERIAL sweep: the raw gains of a parallel-in-time leg depend on its guess of the cut Hessian (tests/test_gpu_legs.py covers the legs)
     solver.max_iters = max_iters
     solver.setup(prob)
     prob.x0_init = xs[0]

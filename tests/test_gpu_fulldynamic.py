@@ -33,6 +33,7 @@ def _run_one_iteration(lib, complete_model=False, seed=11):
     fp = FullDynamicsProblem(horizon=len(PATTERN), complete_model=complete_model)
     prob = _mixed_problem(fp)
     solver = fp.make_solver(_native_library=lib)
+    solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL  # per-phase parity of the SERIAL sweep: the raw gains of a parallel-in-time leg depend on its guess of the cut Hessian (tests/test_gpu_legs.py covers the legs)
     solver.max_iters = 1
     solver.setup(prob)
     rng = np.random.default_rng(seed)

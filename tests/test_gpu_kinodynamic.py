@@ -24,6 +24,7 @@ def _run_one_iteration(lib, complete_model, seed=3):
     prob = aligator.TrajOptProblem(kp.x0, stages, aligator.CostStack(kp.space, kp.nu))
     prob.addTerminalConstraint(kp.terminal_com_constraint(kp.robot.com0 + np.array([0.01, 0.0, 0.0])))
     solver = kp.make_solver(_native_library=lib)
+    solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL  # per-phase parity of the SERIAL sweep: the raw gains of a parallel-in-time leg depend on its guess of the cut Hessian (tests/test_gpu_legs.py covers the legs)
     solver.max_iters = 1
     solver.setup(prob)
     rng = np.random.default_rng(seed)
