@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--closed-loop", action="store_true",
                     help="measured states from the simulation stand-in (10 x 1 ms of knot 0's dynamics under the feedback law, N2) "
                          "instead of perfect-model feedback; the simulation runs inside the timed region")
+    ap.add_argument("--legs", type=int, default=-1,
+                    help="legs of the parallel-in-time Riccati sweep (mpc_options.riccati_legs); negative = what the reference script "
+                         "configures: linear_solver_choice = LQ_SOLVER_PARALLEL with setNumThreads(8) (fulldynamic_talos.py:383-385); 1 = serial sweep")
     ap.add_argument("--lib", default=None, help="developer option: another build of the same HIP library (kernel tuning variants)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -90,7 +93,12 @@ def main():
                           closed_loop=((10, pd.dt / 10) if args.closed_loop else None), forward_mode=(1 if nshard > 1 else 0),
                           tick_reuse=not args.no_tick_reuse)
               for i, sz in enumerate(sizes)]
+    if args.legs > 0:
+        for e in shards:
+            e.options.riccati_legs = args.legs
+            e.native.set_options(e.options)
     ens = shards[0]
+    legs = int(ens.options.riccati_legs)
     cold = None
     for e in shards:
         e.prepare_schedule(args.warmup + args.steps + args.calibration_ticks + 4)
@@ -98,6 +106,13 @@ def main():
         n_conv = locals().get("n_conv", 0) + sum(bool(st.converged) for st in c)
         cold = cold or c
         e.save_episode()
+
+    # instances whose tick was a BCL update / stall without a ProxDDP step (num_iters == 0 in the status of the tick): not a solve
+    nostep = {"n": 0, "on": False}
+
+    def tally(stats):
+        if nostep["on"] and stats:
+            nostep["n"] += sum(1 for st in stats if st.num_iters == 0)
 
     stagger = {"ms": args.phase_offset_ms}
     pace = {"period": 0.0, "fast": True, "late": 0}  # state of the shard pacer (kept from the warm-up into the timed region)
@@ -108,7 +123,7 @@ def main():
             for _ in range(count):
                 if shards[0].tick >= args.episode:
                     shards[0].restart_episode()
-                shards[0].step(rescue=True)  # synchronous form: exactly one solver pass per tick
+                tally(shards[0].step(rescue=True))  # synchronous form: every instance steps (further passes inside the call)
             return
         # One host thread drives all shards round-robin: a tick is enqueued on the shard's stream without waiting, and
         # completed (event on an asynchronous status read-back) right AFTER that shard's next tick has been enqueued.  Shard i starts
@@ -162,7 +177,7 @@ def main():
                 paced(i, e)
         for _ in range(remaining - depth):
             for i, e in enumerate(shards):
-                e.wait(rescue=True)        # the oldest tick of this shard
+                tally(e.wait(rescue=True))  # the oldest tick of this shard
                 if e.tick >= args.episode:  # end of an episode: drain, back to the start, refill the pipeline
                     e.wait(rescue=True)
                     e.restart_episode()
@@ -170,7 +185,7 @@ def main():
                 paced(i, e)
         for _ in range(depth):
             for e in shards:
-                e.wait(rescue=True)
+                tally(e.wait(rescue=True))
 
     # warm-up: every kernel is timed (HIP events on the solver's stream) to find the dominant one and the per-kernel
     # split; the timed region below then only brackets the dominant kernel, because an event pair between two kernels
@@ -201,10 +216,12 @@ def main():
         e.native.profile(2)
         e.native.profile(16 * (1 << dom_slot))
     sync_all()
+    nostep["on"] = True
     t0 = time.perf_counter()
     run_ticks(args.steps)
     sync_all()
     elapsed = time.perf_counter() - t0
+    nostep["on"] = False
     for e in shards:
         e.native.profile(0)
     if dist is not None:
@@ -278,12 +295,15 @@ def main():
         fl *= args.batch / nshard
         ach = fl / (roof["avg_kernel_ms"] * 1e-3) / 1e12
         mfma = {"bound": "mfma", "kernel": roof["kernel"], "achieved": round(ach, 3), "peak": 78.6, "unit": "TFLOP/s", "frac": round(ach / 78.6, 5),
-                "busy_cus": min(256, args.batch // nshard), "frac_of_busy_cus": round(ach / (78.6 * min(256, args.batch // nshard) / 256.0), 5)}
+                "busy_cus": min(256, args.batch // nshard * legs), "frac_of_busy_cus": round(ach / (78.6 * min(256, args.batch // nshard * legs) / 256.0), 5)}
 
     # ---- batch = 1 latency (BASELINE.json config: batch=1 on one MI355X) ----
     p50_ms = None
     if not args.no_latency:
         one = EnsembleMPC(pd, batch=1, library=lib, device=local_rank, perturb=False, tick_reuse=not args.no_tick_reuse)
+        if args.legs > 0:
+            one.options.riccati_legs = args.legs
+            one.native.set_options(one.options)
         one.prepare_schedule(40)
         one.cold_solve(max_iters=100)
         lat = []
@@ -320,7 +340,9 @@ def main():
                "sample": "%d warm-started MPC ticks (1 ProxDDP iteration each) of ONE instance of the same N=%d %s-model OCP, "
                          "OpenMP over knots, %.1f s" % (nt, args.horizon, args.model, dtc)}
 
-    solves = args.batch * args.steps * world
+    # With two ticks in flight per shard an instance whose pass was a BCL update without a step carries on in the next tick instead
+    # of getting further passes at once: such instance-ticks are not solves (rank 0's count, the shards of the other ranks are alike)
+    solves = (args.batch * args.steps - nostep["n"]) * world
     out = {
         "metric": "mpc_solves_per_sec", "value": round(solves / elapsed, 2), "unit": "solves/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -328,12 +350,12 @@ def main():
         "config": {"workload": "Talos full-dynamics MPC (fulldynamic_talos.py OCP), synthetic Talos %s model nq=%d nv=%d nu=%d, "
                                "horizon N=%d, ensemble of %d instances per GPU, one ProxDDP iteration per solve (max_iters=1, warm start)"
                                % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch),
-                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "tick_reuse": not args.no_tick_reuse, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
+                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "riccati_legs": legs, "tick_reuse": not args.no_tick_reuse, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
         "p50_ms_per_solve_batch1": p50_ms,
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
         "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; the others are within 1e-4 of feasibility)" % (n_conv, args.batch),
-        "diverged_instance_rescues": sum(getattr(e, "rescues", 0) for e in shards),
+        "instance_ticks_without_step": nostep["n"] * world, "diverged_instance_rescues": sum(getattr(e, "rescues", 0) for e in shards),
         "episode_ticks": args.episode, "episode_restarts": sum(getattr(e, "episodes", 0) for e in shards),
         "roofline": roof, "cpu_baseline": cpu,
         # supplementary: the same kernel against the fp64 matrix-core peak (the sweep is a chain of dependent dense steps on ONE CU

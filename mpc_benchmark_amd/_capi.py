@@ -267,7 +267,7 @@ class NativeSolver:
             out["K"] = np.zeros((B, N, d.nu, d.ndx))
             out["kff"] = np.zeros((B, N, d.nu))
         if multipliers:
-            out["vs"] = np.zeros((B, N + 1, d.nc_max))
+            out["vs"] = np.zeros((B, N + 1, max(int(d.nc_max), 1)))  # the library keeps (and copies) at least one row per knot
             out["lams"] = np.zeros((B, N + 1, d.ndx))
         self._check(self.lib.mpc_get_results(self._h, _dp(out["xs"]), _dp(out["us"]), _dp(out.get("K")), _dp(out.get("kff")),
                                              _dp(out.get("vs")), _dp(out.get("lams"))), "mpc_get_results")

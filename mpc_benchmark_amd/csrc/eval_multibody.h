@@ -9,6 +9,7 @@
 // no further dependency on the tree (DESIGN.md §"Whole-body stage kernel" derives the formulas; they are
 // cross-checked against the AD-based oracle through tests/proto_multibody.py and the GPU parity tests).
 #pragma once
+#include <atomic>
 #include <stdexcept>
 #include "eval_common.h"
 #include "mfma_blocks.h"
@@ -1324,15 +1325,20 @@ static inline void launch_eval_multibody(hipStream_t stream, const SolverArgs& a
   mb.sim_substeps = sim_substeps; mb.sim_dt = sim_dt;
   mb.ncand_loop = (trial && !with_derivs && ncand > 1) ? ncand : 0;
   if (mb.lds.total_bytes > 160 * 1024) throw std::runtime_error("multibody model too large for the LDS budget of the stage kernel");
-  static int attr_bytes = -1;
-  if (attr_bytes != mb.lds.total_bytes) {
+  // hipFuncSetAttribute is a per-device setting: remember what was requested on every device (a process may hold handles on several
+  // devices, driven from different threads)
+  static std::atomic<int> attr_bytes_dev[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<int>& attr_bytes = attr_bytes_dev[dev & 63];
+  if (attr_bytes.load() != mb.lds.total_bytes + 1) {
     // the kernel also owns a few bytes of static LDS, so request exactly what the carve-out needs
     hipError_t e1 = hipFuncSetAttribute((const void*)k_eval_multibody<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
     hipError_t e2 = hipFuncSetAttribute((const void*)k_eval_multibody<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
     if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)k_eval_multibody<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
     if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)k_eval_multibody<3>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
     if (e1 != hipSuccess || e2 != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(LDS) failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-    attr_bytes = mb.lds.total_bytes;
+    attr_bytes.store(mb.lds.total_bytes + 1);  // + 1: the zero-initialised slots mean "not set"
   }
   if (sim_substeps > 0) hipLaunchKernelGGL(k_eval_multibody<2>, dim3(1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, 0);
   else if (trial && with_derivs) hipLaunchKernelGGL(k_eval_multibody<3>, dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);  // records = the knot records

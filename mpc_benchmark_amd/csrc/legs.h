@@ -374,6 +374,37 @@ static inline LxLds make_lx_lds(int n, int m) {
   return s;
 }
 
+// n x n matrix (row-major, leading dimension n) from global memory into an LDS buffer (np x np used, leading dimension ldp, zero padded),
+// optionally transposed; every load of a thread is in flight before the first LDS write (a plain strided loop waits per element).
+// `add`: an LDS matrix of the same shape added on the way (dst = src + add) — may be dst itself.
+template <bool TR>
+DEV void leg_load_mat(double* dst, int ldp, int np, const double* src, int n, int tid, int nthr) {
+  double v[LK_PT];
+#pragma unroll
+  for (int u = 0; u < LK_PT; ++u) {
+    const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
+    const bool ok = idx < np * np && i < n && c0 < n;
+    v[u] = src[ok ? i * n + c0 : 0] * (ok ? 1.0 : 0.0);  // clamped address, mask by multiplication: unconditional loads
+  }
+#pragma unroll
+  for (int u = 0; u < LK_PT; ++u) {
+    const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
+    if (idx < np * np) dst[TR ? c0 * ldp + i : i * ldp + c0] = v[u];
+  }
+}
+
+// broadcast of a double from a wave-uniform lane (v_readlane with a scalar lane index)
+DEV double readlane_dyn(double v, int src_lane) {
+  const long long bits = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(bits & 0xffffffffll), src_lane);
+  const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), src_lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// phase timers of the consensus kernel (developer tooling, mpc_profile(3)): slots 23..29 of the instance's counter block
+#define LEG_PROF(slot) do { LEG_LAUNDER(); if (tid == 0 && a.prof) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
+// NP: padded state dimension (S.np), a template parameter so that the rows of the elimination are unrolled without guards
+template <int NP>
 __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLds S) {
   const Layout& L = a.L;
   const int b = blockIdx.x, nthr = blockDim.x, nw = nthr >> 6;
@@ -388,10 +419,11 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
   int* used = perm + np;          // used[row] != 0: row already served as a pivot
   int* ipiv = used + np;
   d4_t res[LC_TILES];
+  long long t0_ = clock64();
   // value function at the start of the last leg
   {
     const double* gl = gain_ptr(a, b, leg_start(a, J - 1));
-    for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; PC[idx] = (i < n && c0 < n) ? gl[L.oP + i * n + c0] : 0.0; }
+    leg_load_mat<false>(PC, ldp, np, gl + L.oP, n, tid, nthr);
     for (int i = tid; i < np; i += nthr) pc[i] = (i < n) ? gl[L.op + i] : 0.0;
   }
   __syncthreads();
@@ -402,15 +434,28 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
     // calP_{j+1} out (the next pass starts leg j from it) ; PC <- dP = calP_{j+1} - (the guess leg j carried in this pass): the leg's
     // terminal gradient is Pg x + theta, so theta = dP x_cut + calp ; dP, calp out (the forward part computes theta from them) ;
     // MA <- Sg ; RB <- Lm^T
-    for (int i = wv; i < n; i += nw)
-      for (int c0 = lane; c0 < n; c0 += 64) {
-        const double pnew = PC[i * ldp + c0], pold = a.leg_guess ? lr[L.lcP + i * n + c0] : 0.0, d = pnew - pold;
-        lr[L.lcP + i * n + c0] = pnew; lr[L.ldP + i * n + c0] = d; PC[i * ldp + c0] = d;
+    {
+      double po[LK_PT];
+#pragma unroll
+      for (int u = 0; u < LK_PT; ++u) {
+        const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
+        const bool ok = a.leg_guess && idx < np * np && i < n && c0 < n;
+        po[u] = lr[L.lcP + (ok ? i * n + c0 : 0)] * (ok ? 1.0 : 0.0);
       }
+      leg_load_mat<false>(MA, ldp, np, lr + L.lSg, n, tid, nthr);
+      leg_load_mat<true>(RB, ldp, np, gs + L.oLm, n, tid, nthr);  // coalesced read, transposed write (odd ld: no conflicts)
+#pragma unroll
+      for (int u = 0; u < LK_PT; ++u) {
+        const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
+        if (idx < np * np && i < n && c0 < n) {
+          const double pnew = PC[i * ldp + c0], d = pnew - po[u];
+          lr[L.lcP + i * n + c0] = pnew; lr[L.ldP + i * n + c0] = d; PC[i * ldp + c0] = d;
+        }
+      }
+    }
     for (int i = tid; i < n; i += nthr) lr[L.lcp + i] = pc[i];
-    for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; MA[idx] = (i < n && c0 < n) ? lr[L.lSg + i * n + c0] : 0.0; }
-    for (int idx = tid; idx < np * np; idx += nthr) { const int r = idx / np, c0 = idx % np; RB[c0 * ldp + r] = (r < n && c0 < n) ? gs[L.oLm + r * n + c0] : 0.0; }  // coalesced read, transposed write (odd ld: no conflicts)
     __syncthreads();
+    LEG_PROF(23);
     // rv = Sg calp + sg ; Mt = I - Sg calP (to registers, then over Sg)
     for (int i = wv; i < np; i += nw) {
       double s = 0;
@@ -436,63 +481,155 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
     }
     for (int i = tid; i < np; i += nthr) used[i] = 0;
     __syncthreads();
-    // Gauss-Jordan on [MA | RB | rv], pivot = largest entry of the column among the rows not used yet
+    LEG_PROF(24);
+    // Gauss-Jordan on [Mt | R | rv] with partial pivoting, the whole tableau in REGISTERS (through LDS the elimination is bound by
+    // LDS bandwidth: every column rewrites the tableau).  Wavefront w owns rows w, w + 8, ... (GJ_ROWS = NP / 8: all of them exist,
+    // padding rows are identity / zero), lane l the columns l and l + 64 of Mt and of [R | rv] (rv is column n of the right-hand
+    // block).  Per column: every wavefront reads its rows' entries of the column with v_readlane (they double as the elimination
+    // factors), the best unused row of each wavefront goes to LDS, barrier, every wavefront picks the global pivot, its owner puts the
+    // pivot row into LDS, barrier, rank-one update in registers.  Implicit row permutation, the pivot row is not scaled: at the end
+    // unknown `col` sits in row perm[col], scaled by dinv[col].  Dead columns (<= col) keep round-off residues: never read again.
+    constexpr int GJ_ROWS = NP / 8;
+    double* dinv = fcol;                 // 1 / pivot of every column
+    double* prow = MA;                   // pivot row: Mt part [0, 128), right-hand part [128, 256), 1 / pivot at 256 — MA and RB are dead while the
+                                         // tableau is in registers (the first write comes after the first barrier of the loop: every load is done)
+    double* cand = ev;                   // per wavefront: best |entry| and its row
+    int* iperm = used;                   // iperm[row] = unknown that row holds
+    double ga[GJ_ROWS][2], gb[GJ_ROWS][2];
+#pragma unroll
+    for (int i = 0; i < GJ_ROWS; ++i) {
+      const int r = wv + i * nw;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int z = lane + 64 * h;
+        ga[i][h] = (z < np) ? MA[r * ldp + z] : 0.0;
+        gb[i][h] = (z < n) ? RB[r * ldp + z] : ((z == n) ? rv[r] : 0.0);
+      }
+    }
+    // Diagonal dominance of Mt = I - Sg dP (rows: sum of the off-diagonal magnitudes against the diagonal): with a good guess of the
+    // cut Hessian dP is small and Mt is close to the identity — Gauss-Jordan then needs no pivot search (one barrier per column,
+    // the column entries by v_readlane); otherwise (first sweep of a handle, a contact switch at the cut) partial pivoting.
+    double domw = 0.0;
+#pragma unroll
+    for (int i = 0; i < GJ_ROWS; ++i) {
+      const int r = wv + i * nw;
+      const double o0 = (lane == r) ? 0.0 : fabs(ga[i][0]), o1 = (lane + 64 == r) ? 0.0 : fabs(ga[i][1]);
+      const double off = wave_sum(o0 + o1);
+      const double dg = fabs(readlane_dyn((r >> 6) ? ga[i][1] : ga[i][0], r & 63));
+      domw = fmax(domw, (r < n) ? off / dg : 0.0);  // a zero diagonal gives inf (or nan -> compare false below): pivoting
+    }
+    if (lane == 0) cand[wv] = domw;
+    __syncthreads();
+    bool dominant = true;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dominant = dominant && (cand[q] < 0.5);
+    if (tid == 0 && a.prof) { double dm = 0.0; for (int q = 0; q < 8; ++q) dm = fmax(dm, cand[q]); a.prof[(size_t)b * 64 + 30] = fmax(a.prof[(size_t)b * 64 + 30], dm); a.prof[(size_t)b * 64 + 31] += dominant ? 0.0 : 1.0; }
+    __syncthreads();
+    if (dominant) {
+      for (int col = 0; col < n; ++col) {
+        const int cl = col & 63, ch = col >> 6, pw = col & 7, pi = col >> 3;  // nw == 8: row col belongs to wavefront pw, its pi-th row
+        double* buf = MA + (col & 1) * 264;  // pivot row (Mt part [0,128), right-hand part [128,256), 1 / pivot at 256), double-buffered
+        double fc[GJ_ROWS];
+#pragma unroll
+        for (int i = 0; i < GJ_ROWS; ++i) fc[i] = readlane_dyn(ch ? ga[i][1] : ga[i][0], cl);
+        if (wv == pw) {
+#pragma unroll
+          for (int i = 0; i < GJ_ROWS; ++i)
+            if (i == pi) {
+              buf[lane] = ga[i][0]; buf[lane + 64] = ga[i][1]; buf[128 + lane] = gb[i][0]; buf[192 + lane] = gb[i][1];
+              if (lane == 0) { const double dd = 1.0 / fc[i]; buf[256] = dd; perm[col] = col; iperm[col] = col; dinv[col] = dd; }
+            }
+        }
+        __syncthreads();
+        const double inv = buf[256];
+        const double pa0 = buf[lane], pa1 = buf[lane + 64], pb0 = buf[128 + lane], pb1 = buf[192 + lane];
+#pragma unroll
+        for (int i = 0; i < GJ_ROWS; ++i) {
+          const int r = wv + i * nw;
+          const double f = (r == col) ? 0.0 : fc[i] * inv;  // padding rows: their column entries are zero
+          ga[i][0] -= f * pa0; ga[i][1] -= f * pa1; gb[i][0] -= f * pb0; gb[i][1] -= f * pb1;
+        }
+      }
+    } else {
+    unsigned usedmask = 0;  // bit i: row wv + 8 i already served as a pivot (kept identically by every lane of the wavefront)
+    double* fcw = MA + 528;  // [8][GJ_ROWS]: entries of the current column, per wavefront (the elimination factors before scaling)
     for (int col = 0; col < n; ++col) {
-      LEG_LAUNDER();
-      if (wv == 0) {
+      const int cl = col & 63, ch = col >> 6;
+      // lane cl of every wavefront holds column col of its rows: it finds the best unused row of the wavefront (branch-free) and puts
+      // the entries (they are the elimination factors, wanted by every lane after the barrier) and the candidate into LDS
+      {
         double best = -1.0;
         int bi = 0;
-        for (int r = lane; r < n; r += 64) { const double v = used[r] ? -1.0 : fabs(MA[r * ldp + col]); if (v > best) { best = v; bi = r; } }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-          const double ob = __shfl_xor(best, off);
-          const int oi = __shfl_xor(bi, off);
-          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        for (int i = 0; i < GJ_ROWS; ++i) {
+          const double e = ch ? ga[i][1] : ga[i][0];
+          const int r = wv + i * nw;
+          const double v = (r < n && !((usedmask >> i) & 1u)) ? fabs(e) : -1.0;
+          const bool better = v > best;
+          best = better ? v : best; bi = better ? i : bi;
+          if (lane == cl) fcw[wv * GJ_ROWS + i] = e;
         }
-        if (lane == 0) { ipiv[0] = bi; perm[col] = bi; used[bi] = 1; }
+        if (lane == cl) { cand[2 * wv] = best; cand[2 * wv + 1] = (double)(wv + bi * nw); }
       }
       __syncthreads();
-      const int p = ipiv[0];
-      {
-        const double inv = 1.0 / MA[p * ldp + col];
-        for (int z = tid; z < 2 * np + 1; z += nthr) {
-          if (z < np) prowA[z] = MA[p * ldp + z] * inv;
-          else if (z < 2 * np) prowB[z - np] = RB[p * ldp + z - np] * inv;
-          else prow_rv[0] = rv[p] * inv;
+      // global pivot: largest candidate, ties to the smaller row (branch-free; identical in every lane)
+      double cvv[8];
+      int crr[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { cvv[q] = cand[2 * q]; crr[q] = (int)cand[2 * q + 1]; }  // 8 wavefronts (LK_THREADS)
+      double gbest = cvv[0];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) gbest = fmax(gbest, cvv[q]);
+      int p = 1 << 30;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { const int c2 = (cvv[q] == gbest) ? crr[q] : (1 << 30); p = c2 < p ? c2 : p; }
+      p = __builtin_amdgcn_readfirstlane(p);
+      const int pw = p & 7, pi = p >> 3;  // nw == 8
+      if (wv == pw) {
+        usedmask |= 1u << pi;
+#pragma unroll
+        for (int i = 0; i < GJ_ROWS; ++i)
+          if (i == pi) {
+            prow[lane] = ga[i][0]; prow[lane + 64] = ga[i][1]; prow[128 + lane] = gb[i][0]; prow[192 + lane] = gb[i][1];
+            if (lane == cl) { const double dd = 1.0 / (ch ? ga[i][1] : ga[i][0]); prow[256] = dd; perm[col] = p; iperm[p] = col; dinv[col] = dd; }
+          }
+      }
+      __syncthreads();
+      const double inv = prow[256];
+      const double pa0 = prow[lane], pa1 = prow[lane + 64], pb0 = prow[128 + lane], pb1 = prow[192 + lane];
+      double fc[GJ_ROWS];
+#pragma unroll
+      for (int i = 0; i < GJ_ROWS; ++i) fc[i] = fcw[wv * GJ_ROWS + i];
+#pragma unroll
+      for (int i = 0; i < GJ_ROWS; ++i) {
+        const int r = wv + i * nw;
+        const double f = (r == p || r >= n) ? 0.0 : fc[i] * inv;
+        ga[i][0] -= f * pa0; ga[i][1] -= f * pa1; gb[i][0] -= f * pb0; gb[i][1] -= f * pb1;
+      }
+    }
+    }
+    __syncthreads();
+    // solution in natural order back into RB (rows of the unknowns) and rv
+#pragma unroll
+    for (int i = 0; i < GJ_ROWS; ++i) {
+      const int r = wv + i * nw;
+      if (r < n) {
+        const int u = iperm[r];
+        const double sc = dinv[u];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int z = lane + 64 * h;
+          if (z < n) RB[u * ldp + z] = gb[i][h] * sc;
+          else if (z == n) rv[u] = gb[i][h] * sc;
         }
-        for (int r = tid; r < n; r += nthr) fcol[r] = MA[r * ldp + col];
       }
-      __syncthreads();
-      // rows r != p: row_r -= fcol[r] * prow ; row p = prow.  Columns of MA up to col are unit vectors already (not touched, except col itself)
-      const int za = col, wa = n - za;  // MA columns za .. n-1
-      for (int idx = tid; idx < n * (wa + n); idx += nthr) {
-        const int r = idx / (wa + n), zz = idx % (wa + n);
-        if (zz < wa) { const int z = za + zz; MA[r * ldp + z] = (r == p) ? prowA[z] : MA[r * ldp + z] - fcol[r] * prowA[z]; }
-        else { const int z = zz - wa; RB[r * ldp + z] = (r == p) ? prowB[z] : RB[r * ldp + z] - fcol[r] * prowB[z]; }
-      }
-      for (int r = tid; r < n; r += nthr) rv[r] = (r == p) ? prow_rv[0] : rv[r] - fcol[r] * prow_rv[0];
-      __syncthreads();
     }
-    LEG_LAUNDER();
-    // unknown `col` sits in row perm[col]: Zx, zc out in natural order ; then bring RB into natural order in LDS (through registers)
-    {
-      double zr[LK_PT];
-#pragma unroll
-      for (int u = 0; u < LK_PT; ++u) {
-        const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
-        zr[u] = (idx < np * np && i < n && c0 < n) ? RB[perm[i] * ldp + c0] : 0.0;
-      }
-      for (int i = tid; i < n; i += nthr) ev[i] = rv[perm[i]];
-      __syncthreads();
-#pragma unroll
-      for (int u = 0; u < LK_PT; ++u) {
-        const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
-        if (idx < np * np) { RB[i * ldp + c0] = zr[u]; if (i < n && c0 < n) lr[L.lZx + i * n + c0] = zr[u]; }
-      }
-      for (int i = tid; i < np; i += nthr) { rv[i] = (i < n) ? ev[i] : 0.0; if (i < n) lr[L.lzc + i] = ev[i]; }
-      __syncthreads();
-    }
-    LEG_LAUNDER();
+    __syncthreads();
+    LEG_PROF(25);
+    // Zx, zc out (the forward part and the exact K_0 read them) ; padding of RB / rv stays zero
+    for (int i = wv; i < n; i += nw) for (int c0 = lane; c0 < n; c0 += 64) lr[L.lZx + i * n + c0] = RB[i * ldp + c0];
+    for (int i = tid; i < n; i += nthr) lr[L.lzc + i] = rv[i];
+    LEG_PROF(26);
     // D = calP Zx (to registers, then into MA) ; ev = calP zc + calp
 #pragma unroll
     for (int sidx = 0; sidx < LC_TILES; ++sidx) {
@@ -512,10 +649,10 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       const int t = wv + sidx * nw;
       if (t < nb * nb) tile_store(MA + ((t / nb) * 16) * ldp + (t % nb) * 16, ldp, res[sidx], lane);
     }
-    LEG_LAUNDER();
+    LEG_PROF(27);
     if (j > 0) {
       // calP_j = P_j + Lm_j D ; calp_j = p_j + Lm_j ev   (RB <- Lm_j)
-      for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; RB[idx] = (i < n && c0 < n) ? gs[L.oLm + i * n + c0] : 0.0; }
+      leg_load_mat<false>(RB, ldp, np, gs + L.oLm, n, tid, nthr);
       __syncthreads();
       const int nst = nb * (nb + 1) / 2;
       d4_t pres[LC_STILES];
@@ -526,6 +663,12 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
         if (t < nst) {
           int ri = 0, rem = t;
           while (rem > ri) { rem -= ri + 1; ++ri; }
+          const int col = rem * 16 + (lane & 15);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {  // P_j tile: in flight while the matrix cores work
+            const int row = ri * 16 + (lane >> 4) + 4 * q;
+            pres[sidx][q] = (row < n && col < n) ? gs[L.oP + row * n + col] : 0.0;
+          }
           mma_tile<false>(pres[sidx], RB + (ri * 16) * ldp, ldp, 1, MA + rem * 16, ldp, 1, np, lane);
         }
       }
@@ -547,7 +690,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int row = ri * 16 + (lane >> 4) + 4 * q;
-            const double v = (row < n && col < n) ? pres[sidx][q] + gs[L.oP + row * n + col] : 0.0;
+            const double v = (row < n && col < n) ? pres[sidx][q] : 0.0;
             PC[row * ldp + col] = v;
             if (ri != rem) PC[col * ldp + row] = v;
           }
@@ -568,10 +711,8 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       const double* g1 = gain_ptr(a, b, 1);
       __syncthreads();
       for (int idx = tid; idx < mp * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; RB[idx] = (i < L.m && c0 < n) ? g0[L.oKu + i * n + c0] : 0.0; }
-      for (int idx = tid; idx < np * ldp; idx += nthr) {
-        const int i = idx / ldp, c0 = idx % ldp;
-        PC[idx] = (i < n && c0 < n) ? (single ? (i == c0 ? 1.0 : 0.0) : g1[L.oLm + i * n + c0]) : 0.0;
-      }
+      if (single) { for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; PC[idx] = (i == c0 && i < n) ? 1.0 : 0.0; } }
+      else leg_load_mat<false>(PC, ldp, np, g1 + L.oLm, n, tid, nthr);
       __syncthreads();
       d4_t kres[2];
 #pragma unroll
@@ -601,6 +742,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       __syncthreads();
     }
   }
+  LEG_PROF(28);
   // forward over the cuts: x_{j+1} = Zx_j x_j + zc_j (x_0 = 0: forced initial condition) ; theta_{j+1} = calP_{j+1} x_{j+1} + calp_{j+1}
   for (int i = tid; i < np; i += nthr) xv[i] = 0.0;
   __syncthreads();
@@ -623,6 +765,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
     for (int i = tid; i < n; i += nthr) xv[i] = ev[i];
     __syncthreads();
   }
+  LEG_PROF(29);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -61,6 +61,12 @@ struct mpc_solver {
   InstState* h_status[ASYNC_DEPTH] = {nullptr, nullptr};
   hipEvent_t status_ev[ASYNC_DEPTH] = {nullptr, nullptr};
   int async_head = 0, async_pending = 0;
+  // pinned staging ring for stage-table uploads: the copy is stream-ordered and the host does not wait for the ticks in flight
+  // (a stage that differs from its slot's mirror arrives at every contact-phase switch)
+  static constexpr int STAGE_RING = 8;
+  char* stage_pin[STAGE_RING] = {};
+  hipEvent_t stage_ev[STAGE_RING] = {};
+  int stage_next = 0;
   RicLds ric{};
   ClLds cl{};
   bool use_mfma_riccati = false;
@@ -239,7 +245,11 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<64>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     s->d_legbuf = s->alloc<double>(B * (MPC_MAX_LEGS - 1) * (size_t)L.leg_stride);
   }
   HIP_OK(hipStreamSynchronize(s->stream));
@@ -277,10 +287,25 @@ static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_des
   std::memcpy(hd, desc, n_desc * sizeof(int32_t));
   if (n_params > 0) std::memcpy(hp, params, n_params * sizeof(double));
   s->h_len[2 * slot] = n_desc; s->h_len[2 * slot + 1] = n_params;
-  HIP_OK(hipMemcpyAsync(s->d_stage_desc + (size_t)slot * L.max_stage_ints, desc, n_desc * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+  // through a pinned ring slot (the caller's buffers are not retained past the call): waits only if the copy that used this slot
+  // STAGE_RING uploads ago has not run yet
+  const int rs = s->stage_next;
+  s->stage_next = (s->stage_next + 1) % mpc_solver::STAGE_RING;
+  const size_t ints_bytes = (size_t)L.max_stage_ints * sizeof(int32_t), dbl_bytes = (size_t)L.max_stage_doubles * sizeof(double);
+  if (!s->stage_pin[rs]) {
+    HIP_OK(hipHostMalloc((void**)&s->stage_pin[rs], ints_bytes + dbl_bytes + 16, hipHostMallocDefault));
+    HIP_OK(hipEventCreateWithFlags(&s->stage_ev[rs], hipEventDisableTiming));
+  } else {
+    HIP_OK(hipEventSynchronize(s->stage_ev[rs]));
+  }
+  char* pin = s->stage_pin[rs];
+  char* pin_d = pin + ((ints_bytes + 15) & ~(size_t)15);
+  std::memcpy(pin, desc, n_desc * sizeof(int32_t));
+  if (n_params > 0) std::memcpy(pin_d, params, n_params * sizeof(double));
+  HIP_OK(hipMemcpyAsync(s->d_stage_desc + (size_t)slot * L.max_stage_ints, pin, n_desc * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
   if (n_params > 0)
-    HIP_OK(hipMemcpyAsync(s->d_stage_params + (size_t)slot * L.max_stage_doubles, params, n_params * sizeof(double), hipMemcpyHostToDevice, s->stream));
-  HIP_OK(hipStreamSynchronize(s->stream));  // host buffers are not retained past the call
+    HIP_OK(hipMemcpyAsync(s->d_stage_params + (size_t)slot * L.max_stage_doubles, pin_d, n_params * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  HIP_OK(hipEventRecord(s->stage_ev[rs], s->stream));
 }
 
 // tick reuse: whatever changes the problem or the iterate behind the solver's back invalidates the kept records
@@ -349,7 +374,15 @@ static void launch_pass(mpc_solver* s) {
     // affine terms, then the forward sweeps of the legs side by side
     s->timed(12, "k_closed_loop", [&] { hipLaunchKernelGGL(k_leg_knot, dim3(L.N, L.B), dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk); });
     s->timed(13, "k_leg_condense", [&] { hipLaunchKernelGGL(k_leg_condense, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc); });
-    s->timed(14, "k_leg_consensus", [&] { hipLaunchKernelGGL(k_leg_consensus, dim3(L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx); });
+    s->timed(14, "k_leg_consensus", [&] {
+      switch (s->lx.np) {
+        case 16: hipLaunchKernelGGL(k_leg_consensus<16>, dim3(L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx); break;
+        case 32: hipLaunchKernelGGL(k_leg_consensus<32>, dim3(L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx); break;
+        case 48: hipLaunchKernelGGL(k_leg_consensus<48>, dim3(L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx); break;
+        case 64: hipLaunchKernelGGL(k_leg_consensus<64>, dim3(L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx); break;
+        default: hipLaunchKernelGGL(k_leg_consensus<80>, dim3(L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx); break;
+      }
+    });
   }
   }
   if (J > 1) {
@@ -423,8 +456,10 @@ static void run_impl(mpc_solver* s, mpc_stats* stats, int passes_enqueued = 0) {
   report_status(s, L.B, st.data(), stats);
 }
 
+// every entry point runs on the handle's own device (several handles of one process may live on different devices)
 #define MPC_TRY(h, ...)                 \
   try {                                 \
+    if (h) HIP_OK(hipSetDevice((h)->dims.device)); \
     __VA_ARGS__;                        \
     return 0;                           \
   } catch (const std::exception& e) {   \
@@ -457,6 +492,7 @@ void mpc_destroy(mpc_solver* s) {
   (void)hipStreamSynchronize(s->stream);
   for (auto& p : s->prof) for (auto& e : p.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (int i = 0; i < mpc_solver::ASYNC_DEPTH; ++i) { if (s->h_status[i]) (void)hipHostFree(s->h_status[i]); if (s->status_ev[i]) (void)hipEventDestroy(s->status_ev[i]); }
+  for (int i = 0; i < mpc_solver::STAGE_RING; ++i) { if (s->stage_pin[i]) (void)hipHostFree(s->stage_pin[i]); if (s->stage_ev[i]) (void)hipEventDestroy(s->stage_ev[i]); }
   for (void* p : s->allocs) (void)hipFree(p);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -505,8 +541,16 @@ int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double*
       for (const auto* v : {&anc, &sub, &dm})
         for (int i = 0; i < nj; ++i) { ext.push_back((int32_t)((*v)[i] & 0xffffffffull)); ext.push_back((int32_t)((*v)[i] >> 32)); }
     }
+    // a model may be set again (a new contact frame lowered later): the old tables are released, not leaked until destroy
+    for (void* old : {(void*)s->d_model_i, (void*)s->d_model_d})
+      if (old) {
+        for (auto it = s->allocs.begin(); it != s->allocs.end(); ++it) if (*it == old) { s->allocs.erase(it); break; }
+        HIP_OK(hipFree(old));
+      }
     s->d_model_i = s->alloc<int32_t>(ext.size());
     s->d_model_d = s->alloc<double>(n_d);
+    spec_clear(s);  // records kept for tick reuse were evaluated on the old model
+    s->reuse_this_pass = false;
     copy_sync(s, s->d_model_i, ext.data(), ext.size() * sizeof(int32_t), hipMemcpyHostToDevice);
     copy_sync(s, s->d_model_d, dtab, n_d * sizeof(double), hipMemcpyHostToDevice);
     s->h_model_i.assign(itab, itab + n_i);
@@ -601,6 +645,7 @@ int mpc_profile(mpc_solver* s, int32_t mode) {
 int mpc_profile_read(mpc_solver* s, int32_t slot, char* name, int32_t name_cap, int32_t* launches, double* total_ms) {
   if (!s) return -2;
   try {
+    HIP_OK(hipSetDevice(s->dims.device));
     HIP_OK(hipStreamSynchronize(s->stream));
     const int nslots = (int)s->prof.size();
     if (slot < 0 || slot >= nslots) return nslots;
@@ -775,6 +820,7 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
   try {
     const Layout& L = s->L;
     if (b < 0 || b >= L.B || k < 0 || k > L.N) throw std::runtime_error("debug_get: index out of range");
+    HIP_OK(hipSetDevice(s->dims.device));
     HIP_OK(hipStreamSynchronize(s->stream));
     std::vector<double> kn(L.knot_stride), g(L.gain_stride);
     copy_sync(s, kn.data(), s->d_knots + ((size_t)b * (L.N + 1) + (k < L.N ? (s->khead + k) % L.N : L.N)) * L.knot_stride, L.knot_stride * sizeof(double), hipMemcpyDeviceToHost);

@@ -34,7 +34,7 @@ class EnsembleMPC:
         d.horizon, d.batch = N, self.batch
         d.space = K.SPACE_MULTIBODY if hasattr(space, "model") else K.SPACE_VECTOR
         d.nx, d.ndx, d.nu = space.nx, space.ndx, first.nu
-        d.nc_max = max(int(t[0][6]) for t in tables)
+        d.nc_max = max(1, max(int(t[0][6]) for t in tables))  # the library keeps at least one row (an unconstrained problem has nc_max = 0)
         d.max_stage_ints = 8 + 8 * 24
         d.max_stage_doubles = max(t[1].size for t in tables) + 64
         d.device = int(device)

@@ -100,6 +100,12 @@ class SE3:
     """Rigid placement (rotation, translation) — mirrors the part of ``pin.SE3`` the scripts touch."""
 
     def __init__(self, rotation=None, translation=None):
+        # pin.SE3(R, p) ; pin.SE3(other) ; pin.SE3(H) with a 4 x 4 homogeneous matrix (plot.py:138-144 rebuilds poses that way)
+        if translation is None and isinstance(rotation, SE3):
+            rotation, translation = rotation.rotation, rotation.translation
+        elif translation is None and rotation is not None and np.shape(rotation) == (4, 4):
+            H = np.array(rotation, dtype=float)
+            rotation, translation = H[:3, :3], H[:3, 3]
         self.rotation = np.eye(3) if rotation is None else np.array(rotation, dtype=float)
         self.translation = np.zeros(3) if translation is None else np.array(translation, dtype=float)
 

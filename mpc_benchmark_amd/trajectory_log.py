@@ -67,9 +67,22 @@ class TrajectoryLog:
 
     def append(self, x, u, com, wrenches, LF_pose, RF_pose, LF_ref, RF_ref, L_measured=None, t=None):
         """``wrenches``: (2, 6) contact wrenches of knot 0, [left, right] x [force(3), torque(3)] in the sole frames
-        (``mpc_get_stage_data``); poses as SE3-like objects or 3-vectors (their translation is stored, as the scripts do)."""
+        (``mpc_get_stage_data``); poses as SE3-like objects (``.rotation`` / ``.translation``), 4 x 4 homogeneous matrices or bare
+        3-vectors (identity rotation).  The scripts store the SE3 objects themselves (``rdata.oMf[LF_id].copy()``,
+        fulldynamic_talos.py:487-490) and plot.py rebuilds ``pin.SE3(LF_pose[i])`` to read ``.translation`` and, in computeCoP,
+        ``.rotation`` (plot.py:138-144): a 4 x 4 homogeneous matrix per tick is what ``pin.SE3(...)`` accepts without Pinocchio
+        objects in the pickle."""
         def trans(p):
-            return np.array(p.translation if hasattr(p, "translation") else p, dtype=float).copy()
+            H = np.eye(4)
+            if hasattr(p, "translation"):
+                H[:3, :3] = np.asarray(p.rotation, dtype=float); H[:3, 3] = np.asarray(p.translation, dtype=float)
+            else:
+                a = np.asarray(p, dtype=float)
+                if a.shape == (4, 4):
+                    H = a.copy()
+                else:
+                    H[:3, 3] = a.reshape(3)
+            return H
         w = np.asarray(wrenches, dtype=float).reshape(2, 6)
         r = self.rows
         r["xs"].append(np.array(x, dtype=float)); r["us"].append(np.array(u, dtype=float)); r["com"].append(np.array(com, dtype=float))

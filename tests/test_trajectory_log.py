@@ -8,15 +8,23 @@ from mpc_benchmark_amd.robot import minipin as pin
 def test_archive_round_trip_has_the_reference_fields(tmp_path):
     log = tl.TrajectoryLog()
     rng = np.random.default_rng(0)
+    yawed = np.array([[np.cos(0.2), -np.sin(0.2), 0.0], [np.sin(0.2), np.cos(0.2), 0.0], [0.0, 0.0, 1.0]])
     for t in range(5):
-        lf = pin.SE3(np.eye(3), np.array([0.0, 0.09, 0.0]))
+        lf = pin.SE3(yawed, np.array([0.0, 0.09, 0.0]))
         rf = pin.SE3(np.eye(3), np.array([0.0, -0.09, 0.0]))
         log.append(rng.normal(size=77), rng.normal(size=32), rng.normal(size=3), rng.normal(size=(2, 6)), lf, rf, lf, rf, t=0.01 * t)
     path = log.save("run", str(tmp_path))
     d = tl.load_data(path)
     assert set(d) == set(tl.FIELDS)  # exactly what plot.py indexes
     assert np.array(d["xs"]).shape == (5, 77) and np.array(d["us"]).shape == (5, 32)
-    assert np.allclose(np.array(d["LF_pose"])[:, 1], 0.09) and np.allclose(np.array(d["time"]), 0.01 * np.arange(5))
+    assert np.allclose(np.array(d["time"]), 0.01 * np.arange(5))
+    # plot.py's access pattern (plot.py:138-144): pin.SE3(pose[i]).translation, and .rotation inside computeCoP
+    for i in range(5):
+        lf_se3, rf_se3 = pin.SE3(d["LF_pose"][i]), pin.SE3(d["RF_pose"][i])
+        assert np.allclose(lf_se3.translation, [0.0, 0.09, 0.0]) and np.allclose(lf_se3.rotation, yawed)
+        assert np.allclose(pin.SE3(d["RF_pose_ref"][i]).translation, [0.0, -0.09, 0.0])
+        cop = tl.computeCoP(lf_se3, rf_se3, d["LF_force"][i], d["LF_torque"][i], d["RF_force"][i], d["RF_torque"][i])
+        assert cop.shape == (3,)
     # the raw container is the one the reference writes: a pickled dict under "data"
     with np.load(path, allow_pickle=True) as z:
         assert list(z.keys()) == ["data"]

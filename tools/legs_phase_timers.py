@@ -1,0 +1,30 @@
+"""Developer tool: in-kernel phase timers of k_leg_consensus (shader clock, 2.4 GHz assumed; ratios are what counts)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mpc_benchmark_amd import _capi
+from mpc_benchmark_amd.ensemble import EnsembleMPC
+from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+
+legs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+lib = _capi.load_hip_library()
+pd = FullDynamicsProblem(horizon=100, complete_model=True)
+ens = EnsembleMPC(pd, batch=4, library=lib)
+ens.options.riccati_legs = legs
+ens.native.set_options(ens.options)
+ens.prepare_schedule(10)
+ens.cold_solve(100)
+ens.native.profile(3)
+ens.native.debug_get('ric_prof', 0)
+TICKS = 3
+for _ in range(TICKS):
+    ens.step()
+p = ens.native.debug_get('ric_prof', 0)
+GHZ = 2.4
+names = {23: 'loads (Sg, Lm^T, old calP), dP', 24: 'rv, Mt = I - Sg dP', 25: 'Gauss-Jordan', 26: 'reorder, Zx / zc out', 27: 'D = dP Zx, ev',
+         28: 'calP_j = P_j + Lm_j D (or K0)', 29: 'forward over the cuts'}
+cuts = (legs - 1) * TICKS
+tot = sum(p[i] for i in names)
+for i, nm in names.items():
+    print('CONS %-40s %7.1f us/cut %5.1f%%' % (nm, p[i] / cuts / (GHZ * 1e3), 100 * p[i] / tot))
+print('CONS total %.1f us per cut' % (tot / cuts / (GHZ * 1e3)))
+print('CONS diagonal dominance measure of Mt (max over cuts and ticks) %.3e ; cuts solved with pivoting: %d of %d' % (p[30], int(p[31]), cuts))
