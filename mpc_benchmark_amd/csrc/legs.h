@@ -24,22 +24,26 @@
 #include "mfma_blocks.h"
 #include "solver_kernels.h"
 
+// workgroup barrier that waits for the LDS traffic only: a __syncthreads() also drains the global loads in flight (the prefetch of the
+// next knot) and waits for every global store to be acknowledged.  Used wherever the data exchanged lives in LDS.
+#define LEG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 #define LK_THREADS 512
 #define LK_U 20      // global loads in flight per thread in the LDS fills
 #define LK_PT 13     // matrix elements per thread parked in registers (np <= 80: 6400 / 512)
 #define LK_TILES 5   // output tiles per wavefront: nb (nb + nbm) <= 35 on 8 wavefronts
 
 struct LkLds {
-  int np, mp, nzp, ldp, ldm, nb, nbm;
+  int np, mp, nzp, lda, ldp, ldm, nb, nbm;  // lda: leading dimension of the [A B] buffer (odd: rows AND columns are read with a lane stride)
   int AB, PT, KM, MU, ZN, vec, total_bytes;
 };
 static inline LkLds make_lk_lds(int n, int m) {
   LkLds s;
-  s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.ldp = s.np + 1; s.ldm = s.mp + 1;
+  s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.lda = s.nzp + 1; s.ldp = s.np + 1; s.ldm = s.mp + 1;
   s.nb = s.np / 16; s.nbm = s.mp / 16;
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
-  s.AB = take(s.np * s.nzp); s.PT = take(s.np * s.ldp);
+  s.AB = take(s.np * s.lda); s.PT = take(s.np * s.ldp);
   const int km = s.mp * s.np > 6 * s.nzp + 6 * s.np ? s.mp * s.np : 6 * s.nzp + 6 * s.np;
   s.KM = take(km); s.MU = take(s.mp * s.ldm); s.ZN = take(16 * s.ldm); s.vec = take(s.mp + 2 * s.np + 80);
   s.total_bytes = o * 8;
@@ -54,7 +58,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
-  const int n = L.n, nz = L.nz, np = S.np, mp = S.mp, nzp = S.nzp, ldp = S.ldp, ldm = S.ldm, nb = S.nb, nbm = S.nbm;
+  const int n = L.n, nz = L.nz, np = S.np, mp = S.mp, nzp = S.nzp, lda = S.lda, ldp = S.ldp, ldm = S.ldm, nb = S.nb, nbm = S.nbm;
   const double* kn = knot_ptr(a, b, k);
   double* g = gain_ptr(a, b, k);
   const int m = (int)kn[L.oMISC + MISC_M], c = (int)kn[L.oMISC + MISC_NC];
@@ -64,6 +68,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
   double *AB = sm + S.AB, *PT = sm + S.PT, *KM = sm + S.KM, *MU = sm + S.MU, *ZN = sm + S.ZN, *vec = sm + S.vec;
   double *kf = vec, *y0 = vec + mp, *z0 = y0 + np, *t6 = z0 + np, *g6 = t6 + 36;  // k (mp), B k + mx (np), (I - mu_d Pt) y0 (np), T6, T6 T6^T
   double *TMP = KM, *TMP2 = KM + 6 * nzp;  // rows 0..5 of [M | Bl] (6 x nzp) ; Pt T^T columns 0..5 (np x 6) — K is dead by then
+  // developer phase timers (mpc_profile(3)): workgroup (knot 1, instance 1) -> slots 32.. of instance 1's counter block
+  long long tk0_ = clock64();
+#define LK_PROF(slot) do { if (a.prof && k == 1 && b == 1 && tid == 0) { const long long t1_ = clock64(); a.prof[64 + 32 + (slot)] += (double)(t1_ - tk0_); tk0_ = t1_; } } while (0)
 
   // ---- stage 1: [A B] and K into LDS (zero padded; u-columns of [A B] start at np) ; A_cl = A + B K in place ; y0 = B k + mx ----
   for (int base = tid; base < np * nzp; base += nthr * LK_U) {
@@ -75,7 +82,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
       v[u] = (idx < np * nzp && i < n && z >= 0) ? kn[L.oAB + (size_t)i * nz + z] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < LK_U; ++u) { const int idx = base + u * nthr; if (idx < np * nzp) AB[idx] = v[u]; }
+    for (int u = 0; u < LK_U; ++u) { const int idx = base + u * nthr; if (idx < np * nzp) AB[(idx / nzp) * lda + idx % nzp] = v[u]; }
   }
   for (int base = tid; base < mp * np; base += nthr * LK_U) {
     double v[LK_U];
@@ -96,31 +103,33 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
     const int idx = tid + u * nthr, i = idx / np, j = idx % np;
     ptv[u] = (idx < np * np && i < n && j < n) ? g[L.oMx + i * n + j] : 0.0;
   }
-  __syncthreads();
+  LEG_BARRIER();
+  LK_PROF(0);
   for (int t = wv; t < nb * nb; t += nw) {
     const int ri = t / nb, cj = t % nb;
-    double* At = AB + (ri * 16) * nzp + cj * 16;
-    d4_t acc = tile_load(At, nzp, lane);                                                           // A tile
-    mma_tile<false>(acc, AB + (ri * 16) * nzp + np, nzp, 1, KM + cj * 16, np, 1, mp, lane);        // + B K (own tile only: in place)
-    tile_store(At, nzp, acc, lane);
+    double* At = AB + (ri * 16) * lda + cj * 16;
+    d4_t acc = tile_load(At, lda, lane);                                                           // A tile
+    mma_tile<false>(acc, AB + (ri * 16) * lda + np, lda, 1, KM + cj * 16, np, 1, mp, lane);        // + B K (own tile only: in place)
+    tile_store(At, lda, acc, lane);
   }
-  for (int i = tid; i < np; i += nthr) {
-    double s = (i < n) ? g[L.omx + i] : 0.0;
-    for (int l = 0; l < m; ++l) s += AB[i * nzp + np + l] * kf[l];
-    y0[i] = s;
+  for (int i = wv; i < np; i += nw) {  // one row per wavefront, lanes over the controls
+    double s = (lane < m) ? AB[i * lda + np + lane] * kf[lane] : 0.0;
+    s = wave_sum(s);
+    if (lane == 0) y0[i] = s + ((i < n) ? g[L.omx + i] : 0.0);
   }
   if (tid < 36) { const int i = tid / 6, j = tid % 6; double s = 0; for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * t6[j * 6 + l]; g6[tid] = s; }
   // ---- stage 2: Pt into LDS ; [M | Bl] = (I - mu_d Pt) [A_cl | B] (products to registers, then in place) ; z0 = y0 - mu_d Pt y0 ----
 #pragma unroll
   for (int u = 0; u < LK_PT; ++u) { const int idx = tid + u * nthr; if (idx < np * np) PT[(idx / np) * ldp + idx % np] = ptv[u]; }
-  __syncthreads();
+  LEG_BARRIER();
+  LK_PROF(1);
   const int nct = par ? nb + nbm : nb;  // the u columns are only needed for the parametric quantities
   d4_t res[LK_TILES];
 #pragma unroll
   for (int sidx = 0; sidx < LK_TILES; ++sidx) {
     const int t = wv + sidx * nw;
     res[sidx] = d4_t{0, 0, 0, 0};
-    if (t < nb * nct) mma_tile<false>(res[sidx], PT + ((t / nct) * 16) * ldp, ldp, 1, AB + (t % nct) * 16, nzp, 1, np, lane);
+    if (t < nb * nct) mma_tile<false>(res[sidx], PT + ((t / nct) * 16) * ldp, ldp, 1, AB + (t % nct) * 16, lda, 1, np, lane);
   }
   for (int i = wv; i < n; i += nw) {
     double s = 0;
@@ -128,42 +137,44 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
     s = wave_sum(s);
     if (lane == 0) z0[i] = y0[i] - mud * s;
   }
-  __syncthreads();
+  LEG_BARRIER();
 #pragma unroll
   for (int sidx = 0; sidx < LK_TILES; ++sidx) {
     const int t = wv + sidx * nw;
     if (t < nb * nct) {
-      double* At = AB + ((t / nct) * 16) * nzp + (t % nct) * 16;
+      double* At = AB + ((t / nct) * 16) * lda + (t % nct) * 16;
       const int row = lane >> 4, col = lane & 15;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) At[(row + 4 * q) * nzp + col] -= mud * res[sidx][q];
+      for (int q = 0; q < 4; ++q) At[(row + 4 * q) * lda + col] -= mud * res[sidx][q];
     }
   }
-  __syncthreads();
+  LEG_BARRIER();
+  LK_PROF(2);
   // ---- stage 3: base rows through T6 (rows 0..5 of [M | Bl] -> [Phi | Bc]) ; Phi, phi out ; Pt <- T Pt T^T for Gamma ----
-  for (int idx = tid; idx < 6 * nzp; idx += nthr) TMP[idx] = AB[idx];
+  for (int idx = tid; idx < 6 * nzp; idx += nthr) TMP[idx] = AB[(idx / nzp) * lda + idx % nzp];
   if (par) for (int idx = tid; idx < np * 6; idx += nthr) {  // (Pt T^T)[i][j] = sum_l Pt[i][l] T6[j][l]
     const int i = idx / 6, j = idx % 6;
     double s = 0;
     for (int l = 0; l < 6; ++l) s += PT[i * ldp + l] * t6[j * 6 + l];
     TMP2[idx] = s;
   }
-  __syncthreads();
+  LEG_BARRIER();
   for (int idx = tid; idx < 6 * nzp; idx += nthr) {
     const int i = idx / nzp, z = idx % nzp;
     double s = 0;
     for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * TMP[l * nzp + z];
-    AB[idx] = s;
+    AB[i * lda + z] = s;
   }
   if (par) for (int idx = tid; idx < np * 6; idx += nthr) PT[(idx / 6) * ldp + idx % 6] = TMP2[idx];
-  __syncthreads();
+  LEG_BARRIER();
   for (int i = wv; i < n; i += nw)
-    for (int j = lane; j < n; j += 64) g[L.oPhi + i * n + j] = AB[i * nzp + j];
+    for (int j = lane; j < n; j += 64) g[L.oPhi + i * n + j] = AB[i * lda + j];
   for (int i = tid; i < n; i += nthr) {
     double s = z0[i];
     if (i < 6) { s = 0; for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * z0[l]; }
     g[L.ophi + i] = s;
   }
+  LK_PROF(3);
   if (!par) return;
   // rows 0..5 of T (Pt T^T): into TMP2 first (the rows are read by all)
   for (int idx = tid; idx < 6 * np; idx += nthr) {
@@ -176,20 +187,21 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
   const int ca = __syncthreads_count(tid < c && kn[L.oACT + (tid < c ? tid : 0)] != 0.0);  // c <= LK_THREADS (checked by the host)
   for (int idx = tid; idx < mp * mp; idx += nthr) MU[(idx / mp) * ldm + idx % mp] = g[L.oMu + idx];
   for (int idx = tid; idx < 16 * mp; idx += nthr) ZN[(idx / mp) * ldm + idx % mp] = (idx / mp < ca && ca <= 16) ? g[L.oZnu + idx] : 0.0;
-  __syncthreads();
+  LEG_BARRIER();
   for (int idx = tid; idx < 6 * np; idx += nthr) PT[(idx / np) * ldp + idx % np] = TMP2[idx];
-  __syncthreads();  // TMP / TMP2 (inside KM) are dead: KM receives U1
+  LEG_BARRIER();  // TMP / TMP2 (inside KM) are dead: KM receives U1
+  LK_PROF(4);
   d4_t ures[2];
 #pragma unroll
   for (int sidx = 0; sidx < 2; ++sidx) {
     const int t = wv + sidx * nw;
     ures[sidx] = d4_t{0, 0, 0, 0};
-    if (t < nbm * nb) mma_tile<false>(ures[sidx], MU + ((t / nb) * 16) * ldm, ldm, 1, AB + ((t % nb) * 16) * nzp + np, 1, nzp, mp, lane);
+    if (t < nbm * nb) mma_tile<false>(ures[sidx], MU + ((t / nb) * 16) * ldm, ldm, 1, AB + ((t % nb) * 16) * lda + np, 1, lda, mp, lane);
   }
   if (ca <= 16) {
     for (int cj = wv; cj < nb; cj += nw) {
       d4_t acc = d4_t{0, 0, 0, 0};
-      mma_tile<false>(acc, ZN, ldm, 1, AB + (cj * 16) * nzp + np, 1, nzp, mp, lane);
+      mma_tile<false>(acc, ZN, ldm, 1, AB + (cj * 16) * lda + np, 1, lda, mp, lane);
       const int col = cj * 16 + (lane & 15);
 #pragma unroll
       for (int q = 0; q < 4; ++q) { const int row = (lane >> 4) + 4 * q; if (row < ca && col < n) g[L.oKnup + row * n + col] = -acc[q]; }
@@ -198,7 +210,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
     for (int idx = tid; idx < ca * n; idx += nthr) {
       const int i = idx / n, j = idx % n;
       double s = 0;
-      for (int l = 0; l < m; ++l) s += g[L.oZnu + i * mp + l] * AB[j * nzp + np + l];
+      for (int l = 0; l < m; ++l) s += g[L.oZnu + i * mp + l] * AB[j * lda + np + l];
       g[L.oKnup + idx] = -s;
     }
   }
@@ -215,12 +227,13 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
       }
     }
   }
-  __syncthreads();
+  LEG_BARRIER();
+  LK_PROF(5);
   // ---- stage 5: Gamma = -Bc U1 - mu_d (T T^T - mu_d T Pt T^T) ----
   for (int t = wv; t < nb * nb; t += nw) {
     const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
     d4_t acc = d4_t{0, 0, 0, 0};
-    mma_tile<false>(acc, AB + (ri * 16) * nzp + np, nzp, 1, KM + cj * 16, np, 1, mp, lane);
+    mma_tile<false>(acc, AB + (ri * 16) * lda + np, lda, 1, KM + cj * 16, np, 1, mp, lane);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = ri * 16 + (lane >> 4) + 4 * q;
@@ -230,6 +243,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
       }
     }
   }
+  LK_PROF(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -288,6 +302,8 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds
     pphi = gk[L.ophi + (tid < n ? tid : 0)];
   };
   prefetch(ke);
+  long long tc0_ = clock64();
+#define LC_PROF(slot) do { if (a.prof && j == 0 && b == 2 && tid == 0) { const long long t1_ = clock64(); a.prof[128 + 32 + (slot)] += (double)(t1_ - tc0_); tc0_ = t1_; } } while (0)
   for (int k = ke; k >= ks; --k) {
     LEG_LAUNDER();
 #pragma unroll
@@ -296,7 +312,8 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds
       if (idx < np * np) { BA[(idx / np) * ldp + idx % np] = pa[u]; BB[(idx / np) * ldp + idx % np] = pb[u]; }
     }
     if (tid < np) phi[tid] = (tid < n) ? pphi : 0.0;
-    __syncthreads();
+    LEG_BARRIER();
+    LC_PROF(0);
     LEG_LAUNDER();
     if (k > ks) prefetch(k - 1);
     LEG_LAUNDER();
@@ -311,21 +328,27 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds
         mma_tile<false>(zres[sidx], BB + ((t / nb) * 16) * ldp, ldp, 1, LM + (t % nb) * 16, ldp, 1, np, lane);
       }
     }
+    LC_PROF(1);
     if (tid < n) { double s = 0; for (int l = 0; l < n; ++l) s += LM[l * ldp + tid] * phi[l]; sg[tid] += s; }
-    __syncthreads();
+    LC_PROF(2);
+    LEG_BARRIER();
+    LC_PROF(3);
     LEG_LAUNDER();
 #pragma unroll
     for (int sidx = 0; sidx < LC_TILES; ++sidx) {
       const int t = wv + sidx * nw;
       if (t < nb * nb) tile_store(BB + ((t / nb) * 16) * ldp + (t % nb) * 16, ldp, zres[sidx], lane);
     }
-    __syncthreads();
+    LEG_BARRIER();
+    LC_PROF(4);
     LEG_LAUNDER();
     // Sg += Lm'^T Z on the lower block triangle
 #pragma unroll
     for (int sidx = 0; sidx < LC_STILES; ++sidx)
       if (wv + sidx * nw < nst) mma_tile<false>(sacc[sidx], LM + tri[sidx] * 16, 1, ldp, BB + tcj[sidx] * 16, ldp, 1, np, lane);
-    __syncthreads();
+    LC_PROF(5);
+    LEG_BARRIER();
+    LC_PROF(6);
     LEG_LAUNDER();
     double* gk = gain_ptr(a, b, k);
 #pragma unroll
@@ -338,7 +361,8 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds
         for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; if (row < n && col < n) gk[L.oLm + row * n + col] = lres[sidx][q]; }
       }
     }
-    __syncthreads();
+    LEG_BARRIER();
+    LC_PROF(7);
   }
   double* lr = leg_ptr(a, b, j);
 #pragma unroll
@@ -426,7 +450,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
     leg_load_mat<false>(PC, ldp, np, gl + L.oP, n, tid, nthr);
     for (int i = tid; i < np; i += nthr) pc[i] = (i < n) ? gl[L.op + i] : 0.0;
   }
-  __syncthreads();
+  LEG_BARRIER();
   for (int j = J - 2; j >= 0; --j) {
     LEG_LAUNDER();
     double* lr = leg_ptr(a, b, j);
@@ -454,7 +478,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       }
     }
     for (int i = tid; i < n; i += nthr) lr[L.lcp + i] = pc[i];
-    __syncthreads();
+    LEG_BARRIER();
     LEG_PROF(23);
     // rv = Sg calp + sg ; Mt = I - Sg calP (to registers, then over Sg)
     for (int i = wv; i < np; i += nw) {
@@ -469,7 +493,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       res[sidx] = d4_t{0, 0, 0, 0};
       if (t < nb * nb) mma_tile<true>(res[sidx], MA + ((t / nb) * 16) * ldp, ldp, 1, PC + (t % nb) * 16, ldp, 1, np, lane);
     }
-    __syncthreads();
+    LEG_BARRIER();
 #pragma unroll
     for (int sidx = 0; sidx < LC_TILES; ++sidx) {
       const int t = wv + sidx * nw;
@@ -480,7 +504,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       }
     }
     for (int i = tid; i < np; i += nthr) used[i] = 0;
-    __syncthreads();
+    LEG_BARRIER();
     LEG_PROF(24);
     // Gauss-Jordan on [Mt | R | rv] with partial pivoting, the whole tableau in REGISTERS (through LDS the elimination is bound by
     // LDS bandwidth: every column rewrites the tableau).  Wavefront w owns rows w, w + 8, ... (GJ_ROWS = NP / 8: all of them exist,
@@ -519,12 +543,12 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       domw = fmax(domw, (r < n) ? off / dg : 0.0);  // a zero diagonal gives inf (or nan -> compare false below): pivoting
     }
     if (lane == 0) cand[wv] = domw;
-    __syncthreads();
+    LEG_BARRIER();
     bool dominant = true;
 #pragma unroll
     for (int q = 0; q < 8; ++q) dominant = dominant && (cand[q] < 0.5);
     if (tid == 0 && a.prof) { double dm = 0.0; for (int q = 0; q < 8; ++q) dm = fmax(dm, cand[q]); a.prof[(size_t)b * 64 + 30] = fmax(a.prof[(size_t)b * 64 + 30], dm); a.prof[(size_t)b * 64 + 31] += dominant ? 0.0 : 1.0; }
-    __syncthreads();
+    LEG_BARRIER();
     if (dominant) {
       for (int col = 0; col < n; ++col) {
         const int cl = col & 63, ch = col >> 6, pw = col & 7, pi = col >> 3;  // nw == 8: row col belongs to wavefront pw, its pi-th row
@@ -540,7 +564,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
               if (lane == 0) { const double dd = 1.0 / fc[i]; buf[256] = dd; perm[col] = col; iperm[col] = col; dinv[col] = dd; }
             }
         }
-        __syncthreads();
+        LEG_BARRIER();
         const double inv = buf[256];
         const double pa0 = buf[lane], pa1 = buf[lane + 64], pb0 = buf[128 + lane], pb1 = buf[192 + lane];
 #pragma unroll
@@ -571,7 +595,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
         }
         if (lane == cl) { cand[2 * wv] = best; cand[2 * wv + 1] = (double)(wv + bi * nw); }
       }
-      __syncthreads();
+      LEG_BARRIER();
       // global pivot: largest candidate, ties to the smaller row (branch-free; identical in every lane)
       double cvv[8];
       int crr[8];
@@ -594,7 +618,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
             if (lane == cl) { const double dd = 1.0 / (ch ? ga[i][1] : ga[i][0]); prow[256] = dd; perm[col] = p; iperm[p] = col; dinv[col] = dd; }
           }
       }
-      __syncthreads();
+      LEG_BARRIER();
       const double inv = prow[256];
       const double pa0 = prow[lane], pa1 = prow[lane + 64], pb0 = prow[128 + lane], pb1 = prow[192 + lane];
       double fc[GJ_ROWS];
@@ -608,7 +632,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       }
     }
     }
-    __syncthreads();
+    LEG_BARRIER();
     // solution in natural order back into RB (rows of the unknowns) and rv
 #pragma unroll
     for (int i = 0; i < GJ_ROWS; ++i) {
@@ -624,7 +648,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
         }
       }
     }
-    __syncthreads();
+    LEG_BARRIER();
     LEG_PROF(25);
     // Zx, zc out (the forward part and the exact K_0 read them) ; padding of RB / rv stays zero
     for (int i = wv; i < n; i += nw) for (int c0 = lane; c0 < n; c0 += 64) lr[L.lZx + i * n + c0] = RB[i * ldp + c0];
@@ -643,7 +667,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       s = wave_sum(s);
       if (lane == 0) ev[i] = (i < n) ? s + pc[i] : 0.0;
     }
-    __syncthreads();
+    LEG_BARRIER();
 #pragma unroll
     for (int sidx = 0; sidx < LC_TILES; ++sidx) {
       const int t = wv + sidx * nw;
@@ -653,7 +677,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
     if (j > 0) {
       // calP_j = P_j + Lm_j D ; calp_j = p_j + Lm_j ev   (RB <- Lm_j)
       leg_load_mat<false>(RB, ldp, np, gs + L.oLm, n, tid, nthr);
-      __syncthreads();
+      LEG_BARRIER();
       const int nst = nb * (nb + 1) / 2;
       d4_t pres[LC_STILES];
 #pragma unroll
@@ -678,7 +702,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
         s = wave_sum(s);
         if (lane == 0) pc[i] = (i < n) ? s + gs[L.op + i] : 0.0;
       }
-      __syncthreads();
+      LEG_BARRIER();
       // lower block triangle + P_j, mirrored; diagonal tiles symmetrised (0.5 (a + a^T)) through LDS
 #pragma unroll
       for (int sidx = 0; sidx < LC_STILES; ++sidx) {
@@ -703,17 +727,17 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
           }
         }
       }
-      __syncthreads();
+      LEG_BARRIER();
     } else {
       // exact K_0 = K_0 + Kth_0 D_0 with Kth_0 = Ku_0 Lm_1 (Lm_1 = I when leg 0 is a single knot) ; MA = D_0
       double* g0 = gain_ptr(a, b, 0);
       const bool single = leg_start(a, 1) == 1;
       const double* g1 = gain_ptr(a, b, 1);
-      __syncthreads();
+      LEG_BARRIER();
       for (int idx = tid; idx < mp * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; RB[idx] = (i < L.m && c0 < n) ? g0[L.oKu + i * n + c0] : 0.0; }
       if (single) { for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; PC[idx] = (i == c0 && i < n) ? 1.0 : 0.0; } }
       else leg_load_mat<false>(PC, ldp, np, g1 + L.oLm, n, tid, nthr);
-      __syncthreads();
+      LEG_BARRIER();
       d4_t kres[2];
 #pragma unroll
       for (int sidx = 0; sidx < 2; ++sidx) {
@@ -721,13 +745,13 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
         kres[sidx] = d4_t{0, 0, 0, 0};
         if (t < nbm * nb) mma_tile<false>(kres[sidx], RB + ((t / nb) * 16) * ldp, ldp, 1, PC + (t % nb) * 16, ldp, 1, np, lane);
       }
-      __syncthreads();
+      LEG_BARRIER();
 #pragma unroll
       for (int sidx = 0; sidx < 2; ++sidx) {
         const int t = wv + sidx * nw;
         if (t < nbm * nb) tile_store(RB + ((t / nb) * 16) * ldp + (t % nb) * 16, ldp, kres[sidx], lane);
       }
-      __syncthreads();
+      LEG_BARRIER();
 #pragma unroll
       for (int sidx = 0; sidx < 2; ++sidx) {
         const int t = wv + sidx * nw;
@@ -739,13 +763,14 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
           for (int q = 0; q < 4; ++q) { const int row = (t / nb) * 16 + (lane >> 4) + 4 * q; if (row < L.m && col < n) g0[L.oK + row * n + col] += acc[q]; }
         }
       }
-      __syncthreads();
+      LEG_BARRIER();
     }
   }
+  __syncthreads();  // full barrier: Zx, zc, dP, calp of every cut were written to global memory by other threads
   LEG_PROF(28);
   // forward over the cuts: x_{j+1} = Zx_j x_j + zc_j (x_0 = 0: forced initial condition) ; theta_{j+1} = calP_{j+1} x_{j+1} + calp_{j+1}
   for (int i = tid; i < np; i += nthr) xv[i] = 0.0;
-  __syncthreads();
+  LEG_BARRIER();
   for (int j = 0; j + 1 < J; ++j) {
     double* lr = leg_ptr(a, b, j);
     const int cut = leg_start(a, j + 1);
@@ -755,7 +780,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       s = wave_sum(s);
       if (lane == 0) { ev[i] = s + lr[L.lzc + i]; a.dxs[((size_t)b * (N + 1) + cut) * n + i] = ev[i]; }
     }
-    __syncthreads();
+    LEG_BARRIER();
     for (int i = wv; i < n; i += nw) {
       double s = 0;
       for (int c0 = lane; c0 < n; c0 += 64) s += lr[L.ldP + i * n + c0] * ev[c0];
@@ -763,7 +788,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       if (lane == 0) lr[L.lth + i] = s + lr[L.lcp + i];
     }
     for (int i = tid; i < n; i += nthr) xv[i] = ev[i];
-    __syncthreads();
+    LEG_BARRIER();
   }
   LEG_PROF(29);
 }
