@@ -64,6 +64,8 @@ def main():
                     help="legs of the parallel-in-time Riccati sweep (mpc_options.riccati_legs: linear_solver_choice = LQ_SOLVER_PARALLEL of "
                          "fulldynamic_talos.py:383; the script's setNumThreads(8) is a CPU thread count — 64 instances x 4 legs fill the 256 CUs); "
                          "1 = serial sweep, negative = the script's 8")
+    ap.add_argument("--latency-legs", type=int, default=8,
+                    help="legs of the batch-1 latency measurement (a single instance leaves the chip idle: more, shorter legs pay)")
     ap.add_argument("--lib", default=None, help="developer option: another build of the same HIP library (kernel tuning variants)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
@@ -316,9 +318,8 @@ def main():
     p50_ms = None
     if not args.no_latency:
         one = EnsembleMPC(pd, batch=1, library=lib, device=local_rank, perturb=False, tick_reuse=not args.no_tick_reuse)
-        if args.legs > 0:
-            one.options.riccati_legs = args.legs
-            one.native.set_options(one.options)
+        one.options.riccati_legs = args.latency_legs if args.legs != 1 else 1
+        one.native.set_options(one.options)
         one.prepare_schedule(40)
         one.cold_solve(max_iters=100)
         lat = []
@@ -340,9 +341,11 @@ def main():
         opd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
         oens = EnsembleMPC(opd, batch=1, library=_oracle.load(), perturb=False)
         oens.options.num_threads = cores
+        oens.options.riccati_legs = 1  # on the host the serial sweep is the faster one (3.3 against 1.7 solves/s with the 8 legs of the script)
         oens.prepare_schedule(40)
         oens.cold_solve(max_iters=3)  # a few iterations are enough to get a warm start
         oens.options.num_threads = cores
+        oens.options.riccati_legs = 1
         oens.native.set_options(oens.options)
         oens.step()
         ts = time.perf_counter()
@@ -353,7 +356,7 @@ def main():
         dtc = time.perf_counter() - ts
         cpu = {"value": round(nt / dtc, 3), "unit": "solves/s", "cores": cores, "kind": "port",
                "sample": "%d warm-started MPC ticks (1 ProxDDP iteration each) of ONE instance of the same N=%d %s-model OCP, "
-                         "OpenMP over knots, %.1f s" % (nt, args.horizon, args.model, dtc)}
+                         "OpenMP over knots (serial Riccati sweep: faster on the host than the 8 legs of the script), %.1f s" % (nt, args.horizon, args.model, dtc)}
 
     # With two ticks in flight per shard an instance whose pass was a BCL update without a step carries on in the next tick instead
     # of getting further passes at once: such instance-ticks are not solves (rank 0's count, the shards of the other ranks are alike)
@@ -367,7 +370,7 @@ def main():
                                % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch),
                    "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "riccati_legs": legs, "tick_reuse": not args.no_tick_reuse, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
-        "p50_ms_per_solve_batch1": p50_ms,
+        "p50_ms_per_solve_batch1": p50_ms, "p50_riccati_legs": (args.latency_legs if args.legs != 1 else 1),
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
         "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; the others are within 1e-4 of feasibility)" % (n_conv, args.batch),
         "instance_ticks_without_step": nostep["n"] * world, "diverged_instance_rescues": sum(getattr(e, "rescues", 0) for e in shards),

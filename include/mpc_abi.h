@@ -129,7 +129,7 @@ typedef struct mpc_options {
                             * into this many legs (clamped to 16 and to the horizon; leg j starts at knot floor(j N / legs)) whose Riccati
                             * sweeps run side by side — parallel-in-time, same KKT system, results equal to the serial sweep (1) up to
                             * round-off.  controlFeedbacks()[0] is the exact gain; the gains of later knots are those of their leg.  HIP:
-                            * problems with more than 80 tangent dimensions or 32 controls (kinodynamic) keep the serial sweep */
+                            * problems with more than 80 tangent dimensions or 48 controls keep the serial sweep */
   int32_t forward_mode;    /* HIP forward sweep: 0 = automatic, 1 = one workgroup per instance walks the knots (least CU time: ensembles
                             * sharded over several handles of one GPU), 2 = knot-parallel closed-loop transitions first (shortest latency:
                             * a single small ensemble) ; oracle: ignored                */

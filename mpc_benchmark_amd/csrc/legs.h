@@ -35,17 +35,18 @@
 
 struct LkLds {
   int np, mp, nzp, lda, ldp, ldm, nb, nbm;  // lda: leading dimension of the [A B] buffer (odd: rows AND columns are read with a lane stride)
-  int AB, PT, KM, MU, ZN, vec, total_bytes;
+  int AB, PR, TM, ZN, vec, total_bytes;
 };
+// LDS plan (np = 80, mp = 48: 153 KB; mp = 32: 140 KB).  PR is one n x n region with three lives: K (stage 1), Pt (stages 2-3),
+// U1 = Mu Bc^T next to Mu (stages 4-5).  TM: rows 0..5 of [M | Bl] (6 x nzp) | columns 0..5 of Pt T^T (np x 6) | 6 x 6 corner of T Pt T^T.
 static inline LkLds make_lk_lds(int n, int m) {
   LkLds s;
   s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.lda = s.nzp + 1; s.ldp = s.np + 1; s.ldm = s.mp + 1;
   s.nb = s.np / 16; s.nbm = s.mp / 16;
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
-  s.AB = take(s.np * s.lda); s.PT = take(s.np * s.ldp);
-  const int km = s.mp * s.np > 6 * s.nzp + 6 * s.np ? s.mp * s.np : 6 * s.nzp + 6 * s.np;
-  s.KM = take(km); s.MU = take(s.mp * s.ldm); s.ZN = take(16 * s.ldm); s.vec = take(s.mp + 2 * s.np + 80);
+  const int pr = s.np * s.ldp > s.mp * s.np + s.mp * s.ldm ? s.np * s.ldp : s.mp * s.np + s.mp * s.ldm;
+  s.AB = take(s.np * s.lda); s.PR = take(pr); s.TM = take(6 * s.nzp + 6 * s.np + 40); s.ZN = take(16 * s.ldm); s.vec = take(s.mp + 2 * s.np + 80);
   s.total_bytes = o * 8;
   return s;
 }
@@ -65,9 +66,10 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
   const double mud = st.mu * a.opt.dyn_al_scale;
   const bool par = leg_of_knot(a, k) + 1 < a.nlegs;
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double *AB = sm + S.AB, *PT = sm + S.PT, *KM = sm + S.KM, *MU = sm + S.MU, *ZN = sm + S.ZN, *vec = sm + S.vec;
+  double *AB = sm + S.AB, *PR = sm + S.PR, *ZN = sm + S.ZN, *vec = sm + S.vec;
+  double *KM = PR, *PT = PR, *U1 = PR, *MU = PR + mp * np;  // the three lives of PR
+  double *TMP = sm + S.TM, *PT6 = TMP + 6 * nzp, *c6 = PT6 + 6 * np;
   double *kf = vec, *y0 = vec + mp, *z0 = y0 + np, *t6 = z0 + np, *g6 = t6 + 36;  // k (mp), B k + mx (np), (I - mu_d Pt) y0 (np), T6, T6 T6^T
-  double *TMP = KM, *TMP2 = KM + 6 * nzp;  // rows 0..5 of [M | Bl] (6 x nzp) ; Pt T^T columns 0..5 (np x 6) — K is dead by then
   // developer phase timers (mpc_profile(3)): workgroup (knot 1, instance 1) -> slots 32.. of instance 1's counter block
   long long tk0_ = clock64();
 #define LK_PROF(slot) do { if (a.prof && k == 1 && b == 1 && tid == 0) { const long long t1_ = clock64(); a.prof[64 + 32 + (slot)] += (double)(t1_ - tk0_); tk0_ = t1_; } } while (0)
@@ -118,6 +120,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
     if (lane == 0) y0[i] = s + ((i < n) ? g[L.omx + i] : 0.0);
   }
   if (tid < 36) { const int i = tid / 6, j = tid % 6; double s = 0; for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * t6[j * 6 + l]; g6[tid] = s; }
+  LEG_BARRIER();  // K is dead: Pt takes its place
   // ---- stage 2: Pt into LDS ; [M | Bl] = (I - mu_d Pt) [A_cl | B] (products to registers, then in place) ; z0 = y0 - mu_d Pt y0 ----
 #pragma unroll
   for (int u = 0; u < LK_PT; ++u) { const int idx = tid + u * nthr; if (idx < np * np) PT[(idx / np) * ldp + idx % np] = ptv[u]; }
@@ -150,13 +153,13 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
   }
   LEG_BARRIER();
   LK_PROF(2);
-  // ---- stage 3: base rows through T6 (rows 0..5 of [M | Bl] -> [Phi | Bc]) ; Phi, phi out ; Pt <- T Pt T^T for Gamma ----
+  // ---- stage 3: base rows through T6 (rows 0..5 of [M | Bl] -> [Phi | Bc]) ; Phi, phi out ; columns 0..5 of Pt T^T kept for Gamma ----
   for (int idx = tid; idx < 6 * nzp; idx += nthr) TMP[idx] = AB[(idx / nzp) * lda + idx % nzp];
   if (par) for (int idx = tid; idx < np * 6; idx += nthr) {  // (Pt T^T)[i][j] = sum_l Pt[i][l] T6[j][l]
     const int i = idx / 6, j = idx % 6;
     double s = 0;
     for (int l = 0; l < 6; ++l) s += PT[i * ldp + l] * t6[j * 6 + l];
-    TMP2[idx] = s;
+    PT6[idx] = s;
   }
   LEG_BARRIER();
   for (int idx = tid; idx < 6 * nzp; idx += nthr) {
@@ -165,7 +168,12 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
     for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * TMP[l * nzp + z];
     AB[i * lda + z] = s;
   }
-  if (par) for (int idx = tid; idx < np * 6; idx += nthr) PT[(idx / 6) * ldp + idx % 6] = TMP2[idx];
+  if (par && tid < 36) {  // 6 x 6 corner of T (Pt T^T)
+    const int i = tid / 6, j = tid % 6;
+    double s = 0;
+    for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * PT6[l * 6 + j];
+    c6[tid] = s;
+  }
   LEG_BARRIER();
   for (int i = wv; i < n; i += nw)
     for (int j = lane; j < n; j += 64) g[L.oPhi + i * n + j] = AB[i * lda + j];
@@ -176,20 +184,11 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
   }
   LK_PROF(3);
   if (!par) return;
-  // rows 0..5 of T (Pt T^T): into TMP2 first (the rows are read by all)
-  for (int idx = tid; idx < 6 * np; idx += nthr) {
-    const int i = idx / np, j = idx % np;
-    double s = 0;
-    for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * PT[l * ldp + j];
-    TMP2[idx] = s;
-  }
-  // ---- stage 4: Mu, Znu into LDS ; U1 = Mu Bc^T (-> Ku = -U1, kept in KM for stage 5) ; V1 = Znu Bc^T (-> Knup = -V1) ----
-  const int ca = __syncthreads_count(tid < c && kn[L.oACT + (tid < c ? tid : 0)] != 0.0);  // c <= LK_THREADS (checked by the host)
+  // ---- stage 4: Mu (into PR behind the place of U1: Pt is dead), Znu ; U1 = Mu Bc^T (-> Ku = -U1, kept for stage 5) ; V1 = Znu Bc^T (-> Knup = -V1) ----
+  const int ca = __syncthreads_count(tid < c && kn[L.oACT + (tid < c ? tid : 0)] != 0.0);  // c <= LK_THREADS (checked by the host) ; a barrier: Pt is dead
   for (int idx = tid; idx < mp * mp; idx += nthr) MU[(idx / mp) * ldm + idx % mp] = g[L.oMu + idx];
   for (int idx = tid; idx < 16 * mp; idx += nthr) ZN[(idx / mp) * ldm + idx % mp] = (idx / mp < ca && ca <= 16) ? g[L.oZnu + idx] : 0.0;
   LEG_BARRIER();
-  for (int idx = tid; idx < 6 * np; idx += nthr) PT[(idx / np) * ldp + idx % np] = TMP2[idx];
-  LEG_BARRIER();  // TMP / TMP2 (inside KM) are dead: KM receives U1
   LK_PROF(4);
   d4_t ures[2];
 #pragma unroll
@@ -222,24 +221,33 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) 
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = ri * 16 + (lane >> 4) + 4 * q;
-        KM[row * np + col] = ures[sidx][q];
+        U1[row * np + col] = ures[sidx][q];  // beside Mu (other wavefronts may still read it), not over it
         if (row < m && col < n) g[L.oKu + row * n + col] = -ures[sidx][q];
       }
     }
   }
   LEG_BARRIER();
   LK_PROF(5);
-  // ---- stage 5: Gamma = -Bc U1 - mu_d (T T^T - mu_d T Pt T^T) ----
+  // ---- stage 5: Gamma = -Bc U1 - mu_d (T T^T - mu_d T Pt T^T) ; T Pt T^T: rows / columns 0..5 from PT6 / c6 (symmetric), the rest is Pt
+  // itself, read again from the gain record (L2) while the matrix cores work ----
   for (int t = wv; t < nb * nb; t += nw) {
     const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+    double ptt[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = ri * 16 + (lane >> 4) + 4 * q;
+      const bool in = row < n && col < n;
+      ptt[q] = (in && row >= 6 && col >= 6) ? g[L.oMx + row * n + col] : 0.0;
+    }
     d4_t acc = d4_t{0, 0, 0, 0};
-    mma_tile<false>(acc, AB + (ri * 16) * lda + np, lda, 1, KM + cj * 16, np, 1, mp, lane);
+    mma_tile<false>(acc, AB + (ri * 16) * lda + np, lda, 1, U1 + cj * 16, np, 1, mp, lane);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int row = ri * 16 + (lane >> 4) + 4 * q;
       if (row < n && col < n) {
         const double tt = (row < 6 && col < 6) ? g6[row * 6 + col] : (row == col ? 1.0 : 0.0);
-        g[L.oGam + row * n + col] = -acc[q] - mud * (tt - mud * PT[row * ldp + col]);
+        const double tp = (row < 6 && col < 6) ? c6[row * 6 + col] : (col < 6 ? PT6[row * 6 + col] : (row < 6 ? PT6[col * 6 + row] : ptt[q]));
+        g[L.oGam + row * n + col] = -acc[q] - mud * (tt - mud * tp);
       }
     }
   }

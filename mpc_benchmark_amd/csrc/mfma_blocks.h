@@ -76,37 +76,51 @@ template <int SRC> DEV double readlane_d(double v) {
   const int hi = __builtin_amdgcn_readlane((int)(bits >> 32), SRC);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+// acc += (value of `src` held by lane C of the lane's own row of 16 lanes) * mul — ONE fp64 VALU instruction: the DPP form of
+// v_fmac_f64 with row_newbcast (the only DPP control 64-bit operands take on CDNA3/4).  The 16x16 factorisation below keeps identical
+// copies of the block in the four 16-lane rows of the wavefront, so "lane C of the row" is "lane C".  Replaces two v_readlane_b32
+// (through SGPRs) + a v_fma_f64 per term: 5 us -> ~2 us per 16x16 block.  (s_nop 1: a VALU write of a VGPR that a DPP instruction
+// reads needs two wait states, and the hazard recogniser does not look inside inline asm.)
+template <int C> DEV void fmac_bcast(double& acc, double src, double mul) {
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul), "n"(C));
+}
+template <int C> DEV double bcast_row(double src) {
+  double r;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(src), "n"(C));
+  return r;
+}
 template <int J, int C> struct CholCol {
-  static DEV void run(double (&d)[16], double l) { d[C] -= l * readlane_d<C>(l); CholCol<J, C + 1>::run(d, l); }
+  static DEV void run(double (&d)[16], double l, double nl) { fmac_bcast<C>(d[C], l, nl); CholCol<J, C + 1>::run(d, l, nl); }  // d[C] -= l * l_C
 };
-template <int J> struct CholCol<J, 16> { static DEV void run(double (&)[16], double) {} };
+template <int J> struct CholCol<J, 16> { static DEV void run(double (&)[16], double, double) {} };
 template <int J> struct CholStep {
   static DEV void run(double (&d)[16], double (&invd)[16], bool& ok) {
-    const double djj = readlane_d<J>(d[J]);
+    const double djj = bcast_row<J>(d[J]);
     ok = ok && (djj > 0.0);
     double inv = rsqrt(djj);
     inv = inv * (1.5 - 0.5 * djj * inv * inv);  // one Newton step: 1/sqrt(djj) to full precision
     invd[J] = inv;
     const double l = d[J] * inv;  // lane J: sqrt(djj); lanes r > J: L[r][J]
     d[J] = l;
-    CholCol<J, J + 1>::run(d, l);
+    CholCol<J, J + 1>::run(d, l, -l);
     CholStep<J + 1>::run(d, invd, ok);
   }
 };
 template <> struct CholStep<16> { static DEV void run(double (&)[16], double (&)[16], bool&) {} };
 template <int R, int K> struct InvDot {
-  static DEV void run(const double (&d)[16], const double (&x)[16], double& acc) { acc -= readlane_d<R>(d[K]) * x[K]; InvDot<R, K + 1>::run(d, x, acc); }
+  static DEV void run(const double (&d)[16], const double (&nx)[16], double& acc) { fmac_bcast<R>(acc, d[K], nx[K]); InvDot<R, K + 1>::run(d, nx, acc); }  // acc -= L[R][K] x[K]
 };
 template <int R> struct InvDot<R, R> { static DEV void run(const double (&)[16], const double (&)[16], double&) {} };
 template <int R> struct InvRow {
-  static DEV void run(const double (&d)[16], const double (&invd)[16], double (&x)[16], int lane) {
-    double acc = (lane == R) ? 1.0 : 0.0;
-    InvDot<R, 0>::run(d, x, acc);
+  static DEV void run(const double (&d)[16], const double (&invd)[16], double (&x)[16], double (&nx)[16], int lane) {
+    double acc = ((lane & 15) == R) ? 1.0 : 0.0;
+    InvDot<R, 0>::run(d, nx, acc);
     x[R] = acc * invd[R];
-    InvRow<R + 1>::run(d, invd, x, lane);
+    nx[R] = -x[R];
+    InvRow<R + 1>::run(d, invd, x, nx, lane);
   }
 };
-template <> struct InvRow<16> { static DEV void run(const double (&)[16], const double (&)[16], double (&)[16], int) {} };
+template <> struct InvRow<16> { static DEV void run(const double (&)[16], const double (&)[16], double (&)[16], double (&)[16], int) {} };
 
 // One wavefront: Cholesky of the 16x16 block D (lower triangle, leading dimension ld) entirely in registers —
 // lane r (< 16) holds row r — then its inverse.  Writes L back over D (lower part) and L^-1 to LIb (ld 17).
@@ -117,9 +131,10 @@ DEV bool chol16_wave(double* D, int ld, double* LIb, int lane) {
   for (int cidx = 0; cidx < 16; ++cidx) d[cidx] = D[r * ld + cidx];
   bool ok = true;
   CholStep<0>::run(d, invd, ok);
+  double nx[16];
 #pragma unroll
-  for (int cidx = 0; cidx < 16; ++cidx) x[cidx] = 0.0;
-  InvRow<0>::run(d, invd, x, lane);  // lane c (< 16) builds column c of L^-1
+  for (int cidx = 0; cidx < 16; ++cidx) { x[cidx] = 0.0; nx[cidx] = 0.0; }
+  InvRow<0>::run(d, invd, x, nx, lane);  // lane c of every 16-lane row builds column c of L^-1
   if (lane < 16) {
 #pragma unroll
     for (int cidx = 0; cidx < 16; ++cidx) if (cidx <= r) D[r * ld + cidx] = d[cidx];

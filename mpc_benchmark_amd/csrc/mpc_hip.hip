@@ -237,7 +237,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   }
   // parallel-in-time legs: every kernel of legs.h keeps three n x n operands (or [A B] + Pt) in LDS
   s->lk = make_lk_lds(L.n, L.m); s->lc = make_lc_lds(L.n); s->lx = make_lx_lds(L.n, L.m);
-  s->legs_ok = s->use_mfma_riccati && s->ric.np <= 80 && s->ric.mp <= 32 && L.c <= 256 && s->ric.gfull == 1 && s->lk.total_bytes <= 160 * 1024 &&
+  s->legs_ok = s->use_mfma_riccati && s->ric.np <= 80 && s->ric.mp <= 48 && L.c <= 256 && s->ric.gfull >= 1 && s->lk.total_bytes <= 160 * 1024 &&
                s->lc.total_bytes <= 160 * 1024 && s->lx.total_bytes <= 160 * 1024 && !getenv("MPC_HIP_NO_LEGS");
   if (s->legs_ok) {
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
@@ -388,7 +388,10 @@ static void launch_pass(mpc_solver* s) {
   if (J > 1) {
     s->leg_guess_valid = true;
     s->timed(15, "k_leg_apply", [&] { hipLaunchKernelGGL(k_leg_apply, dim3(L.N, L.B), dim3(256), 0, s->stream, a); });
-    s->timed(4, "k_forward", [&] { hipLaunchKernelGGL((k_forward_phi<4, 10>), dim3(L.B * J), dim3(512), 2 * L.n * sizeof(double), s->stream, a); });
+    s->timed(4, "k_forward", [&] {
+      if (L.m <= 32) hipLaunchKernelGGL((k_forward_phi<4, 10>), dim3(L.B * J), dim3(512), 2 * L.n * sizeof(double), s->stream, a);
+      else hipLaunchKernelGGL((k_forward_phi<6, 10>), dim3(L.B * J), dim3(512), 2 * L.n * sizeof(double), s->stream, a);
+    });
   } else {
   const bool fw_phi = s->cl.total_bytes <= 160 * 1024 && L.n <= 80 && L.m <= 32 && (s->opt.forward_mode == 0 ? L.B * L.N <= 2048 : s->opt.forward_mode == 2);
   if (fw_phi) {

@@ -47,8 +47,9 @@ for legs in (1, 4, 8):
     run("config 3: full dynamics N=100 batch 1 (nq=29)", FullDynamicsProblem(horizon=100, complete_model=False), 1, 100, 20, legs=legs, perturb=False)
 for legs in (1, 4):
     run("full dynamics N=100 batch 64 (nq=29)", FullDynamicsProblem(horizon=100, complete_model=False), 64, 40, 5, legs=legs)
-# kinodynamic: nu = nv + 6 > 32 controls: the leg kernels do not take it (csrc/legs.h), serial sweep
-kp = KinodynamicProblem(horizon=150, complete_model=True)
-run("config 4: kinodynamic N=150 batch 64 (nq=39)", kp, 64, 20, 3, seed=7, perturb_dofs=range(18, kp.nv))
-kr = KinodynamicProblem(horizon=150, complete_model=False)
-run("config 4: kinodynamic N=150 batch 64 (nq=29)", kr, 64, 20, 3, seed=7, perturb_dofs=range(18, kr.nv))
+for legs in (1, 4):
+    kp = KinodynamicProblem(horizon=150, complete_model=True)
+    run("config 4: kinodynamic N=150 batch 64 (nq=39)", kp, 64, 20, 3, legs=legs, seed=7, perturb_dofs=range(18, kp.nv))
+for legs in (1, 4):
+    kr = KinodynamicProblem(horizon=150, complete_model=False)
+    run("config 4: kinodynamic N=150 batch 64 (nq=29)", kr, 64, 20, 3, legs=legs, seed=7, perturb_dofs=range(18, kr.nv))
