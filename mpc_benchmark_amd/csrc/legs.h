@@ -511,148 +511,84 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
         for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; MA[row * ldp + col] = res[sidx][q] + (row == col ? 1.0 : 0.0); }  // pad rows: identity
       }
     }
-    for (int i = tid; i < np; i += nthr) used[i] = 0;
     LEG_BARRIER();
     LEG_PROF(24);
-    // Gauss-Jordan on [Mt | R | rv] with partial pivoting, the whole tableau in REGISTERS (through LDS the elimination is bound by
-    // LDS bandwidth: every column rewrites the tableau).  Wavefront w owns rows w, w + 8, ... (GJ_ROWS = NP / 8: all of them exist,
-    // padding rows are identity / zero), lane l the columns l and l + 64 of Mt and of [R | rv] (rv is column n of the right-hand
-    // block).  Per column: every wavefront reads its rows' entries of the column with v_readlane (they double as the elimination
-    // factors), the best unused row of each wavefront goes to LDS, barrier, every wavefront picks the global pivot, its owner puts the
-    // pivot row into LDS, barrier, rank-one update in registers.  Implicit row permutation, the pivot row is not scaled: at the end
-    // unknown `col` sits in row perm[col], scaled by dinv[col].  Dead columns (<= col) keep round-off residues: never read again.
-    constexpr int GJ_ROWS = NP / 8;
-    double* dinv = fcol;                 // 1 / pivot of every column
-    double* prow = MA;                   // pivot row: Mt part [0, 128), right-hand part [128, 256), 1 / pivot at 256 — MA and RB are dead while the
-                                         // tableau is in registers (the first write comes after the first barrier of the loop: every load is done)
-    double* cand = ev;                   // per wavefront: best |entry| and its row
-    int* iperm = used;                   // iperm[row] = unknown that row holds
-    double ga[GJ_ROWS][2], gb[GJ_ROWS][2];
+    // Gauss-Jordan on T = [Mt | R | rv] (n rows, 2 n + 1 columns) with partial pivoting, the whole tableau in REGISTERS (through LDS
+    // the elimination is bound by LDS bandwidth: every column rewrites the tableau).  A lane is a ROW (lane l: rows l and l + 64), a
+    // wavefront owns every 8th COLUMN (wavefront w: columns w, w + 8, ...: GJ_SLOTS of them).  Per pivot column: its owner finds the
+    // pivot with a DPP max + ballot over its own lanes, scales the column to the elimination factors and leaves them (one per row)
+    // and the pivot row index in LDS; ONE barrier; every wavefront fetches its factor(s) and broadcasts the pivot row's entries of its
+    // own columns with v_readlane (lane p), rank-one update in registers.  Implicit row permutation, the pivot row is not scaled: at
+    // the end unknown `col` sits in row perm[col], scaled by dinv[col].  Dead columns keep round-off residues: never read again.
+    // (An earlier layout — wavefronts own rows, lanes own columns — needed the column entries of ten rows per wavefront, a search
+    // through LDS and two barriers per column: 165 us per cut against this one's, see DESIGN.md.)
+    constexpr int GJ_SLOTS = (2 * NP + 1 + 7) / 8;
+    double* dinv = fcol;        // 1 / pivot of every column
+    int* iperm = used;          // iperm[row] = unknown that row holds
+    double* fbuf = MA;          // [2][128] elimination factors of the current column, double-buffered ; MA and RB are dead while the
+    int* pbuf = (int*)(MA + 256);  // tableau is in registers (first written after every wavefront has loaded its share: barrier below)
+    double tq[2][GJ_SLOTS];
 #pragma unroll
-    for (int i = 0; i < GJ_ROWS; ++i) {
-      const int r = wv + i * nw;
+    for (int sl = 0; sl < GJ_SLOTS; ++sl) {
+      const int cc = 8 * sl + wv;  // column of the tableau: [0, n) Mt, [n, 2 n) R, 2 n: rv
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int z = lane + 64 * h;
-        ga[i][h] = (z < np) ? MA[r * ldp + z] : 0.0;
-        gb[i][h] = (z < n) ? RB[r * ldp + z] : ((z == n) ? rv[r] : 0.0);
+        const int r = lane + 64 * h;
+        double v = 0.0;
+        if (r < NP) v = (cc < n) ? MA[r * ldp + cc] : ((cc < 2 * n) ? RB[r * ldp + (cc - n)] : ((cc == 2 * n) ? rv[r] : 0.0));
+        tq[h][sl] = v;
       }
     }
-    // Diagonal dominance of Mt = I - Sg dP (rows: sum of the off-diagonal magnitudes against the diagonal): with a good guess of the
-    // cut Hessian dP is small and Mt is close to the identity — Gauss-Jordan then needs no pivot search (one barrier per column,
-    // the column entries by v_readlane); otherwise (first sweep of a handle, a contact switch at the cut) partial pivoting.
-    double domw = 0.0;
-#pragma unroll
-    for (int i = 0; i < GJ_ROWS; ++i) {
-      const int r = wv + i * nw;
-      const double o0 = (lane == r) ? 0.0 : fabs(ga[i][0]), o1 = (lane + 64 == r) ? 0.0 : fabs(ga[i][1]);
-      const double off = wave_sum(o0 + o1);
-      const double dg = fabs(readlane_dyn((r >> 6) ? ga[i][1] : ga[i][0], r & 63));
-      domw = fmax(domw, (r < n) ? off / dg : 0.0);  // a zero diagonal gives inf (or nan -> compare false below): pivoting
-    }
-    if (lane == 0) cand[wv] = domw;
+    bool used0 = false, used1 = false;  // rows lane, lane + 64 already served as pivots (every wavefront keeps the same flags)
     LEG_BARRIER();
-    bool dominant = true;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) dominant = dominant && (cand[q] < 0.5);
-    if (tid == 0 && a.prof) { double dm = 0.0; for (int q = 0; q < 8; ++q) dm = fmax(dm, cand[q]); a.prof[(size_t)b * 64 + 30] = fmax(a.prof[(size_t)b * 64 + 30], dm); a.prof[(size_t)b * 64 + 31] += dominant ? 0.0 : 1.0; }
-    LEG_BARRIER();
-    if (dominant) {
-      for (int col = 0; col < n; ++col) {
-        const int cl = col & 63, ch = col >> 6, pw = col & 7, pi = col >> 3;  // nw == 8: row col belongs to wavefront pw, its pi-th row
-        double* buf = MA + (col & 1) * 264;  // pivot row (Mt part [0,128), right-hand part [128,256), 1 / pivot at 256), double-buffered
-        double fc[GJ_ROWS];
-#pragma unroll
-        for (int i = 0; i < GJ_ROWS; ++i) fc[i] = readlane_dyn(ch ? ga[i][1] : ga[i][0], cl);
-        if (wv == pw) {
-#pragma unroll
-          for (int i = 0; i < GJ_ROWS; ++i)
-            if (i == pi) {
-              buf[lane] = ga[i][0]; buf[lane + 64] = ga[i][1]; buf[128 + lane] = gb[i][0]; buf[192 + lane] = gb[i][1];
-              if (lane == 0) { const double dd = 1.0 / fc[i]; buf[256] = dd; perm[col] = col; iperm[col] = col; dinv[col] = dd; }
-            }
+    for (int so = 0; so < NP / 8; ++so) {
+      for (int ow = 0; ow < 8; ++ow) {  // nw == 8
+        const int col = 8 * so + ow;
+        if (col >= n) break;
+        double* fb = fbuf + (col & 1) * 128;
+        if (wv == ow) {
+          const double e0 = tq[0][so], e1 = tq[1][so];
+          const double v0 = (lane < n && !used0) ? fabs(e0) : -1.0, v1 = (lane + 64 < n && !used1) ? fabs(e1) : -1.0;
+          const bool second = v1 > v0;
+          const double vl = second ? v1 : v0;
+          const double vmax = wave_max_nonneg(fmax(vl, 0.0));
+          const unsigned long long mk = __ballot(vl == vmax);
+          const int src = __builtin_amdgcn_readfirstlane(mk ? __ffsll((long long)mk) - 1 : 0);
+          const int ph = __builtin_amdgcn_readlane(second ? 1 : 0, src);
+          const int p = src + 64 * ph;
+          const double piv = readlane_dyn(ph ? e1 : e0, src);
+          const double inv = 1.0 / piv;
+          fb[lane] = (lane == p || lane >= n) ? 0.0 : e0 * inv;
+          fb[lane + 64] = (lane + 64 == p || lane + 64 >= n) ? 0.0 : e1 * inv;
+          if (lane == 0) { pbuf[col & 1] = p; perm[col] = p; iperm[p] = col; dinv[col] = inv; }
         }
         LEG_BARRIER();
-        const double inv = buf[256];
-        const double pa0 = buf[lane], pa1 = buf[lane + 64], pb0 = buf[128 + lane], pb1 = buf[192 + lane];
+        const int p = __builtin_amdgcn_readfirstlane(pbuf[col & 1]);
+        const double f0 = fb[lane], f1 = fb[lane + 64];
+        if (lane == (p & 63)) { if (p >> 6) used1 = true; else used0 = true; }
+        // slots below `so` hold columns of Mt that are dead already (all their columns are < col): skipped
+        if (p < 64) {
 #pragma unroll
-        for (int i = 0; i < GJ_ROWS; ++i) {
-          const int r = wv + i * nw;
-          const double f = (r == col) ? 0.0 : fc[i] * inv;  // padding rows: their column entries are zero
-          ga[i][0] -= f * pa0; ga[i][1] -= f * pa1; gb[i][0] -= f * pb0; gb[i][1] -= f * pb1;
+          for (int sl = so; sl < GJ_SLOTS; ++sl) { const double pr = readlane_dyn(tq[0][sl], p); tq[0][sl] -= f0 * pr; tq[1][sl] -= f1 * pr; }
+        } else {
+#pragma unroll
+          for (int sl = so; sl < GJ_SLOTS; ++sl) { const double pr = readlane_dyn(tq[1][sl], p - 64); tq[0][sl] -= f0 * pr; tq[1][sl] -= f1 * pr; }
         }
       }
-    } else {
-    unsigned usedmask = 0;  // bit i: row wv + 8 i already served as a pivot (kept identically by every lane of the wavefront)
-    double* fcw = MA + 528;  // [8][GJ_ROWS]: entries of the current column, per wavefront (the elimination factors before scaling)
-    for (int col = 0; col < n; ++col) {
-      const int cl = col & 63, ch = col >> 6;
-      // lane cl of every wavefront holds column col of its rows: it finds the best unused row of the wavefront (branch-free) and puts
-      // the entries (they are the elimination factors, wanted by every lane after the barrier) and the candidate into LDS
-      {
-        double best = -1.0;
-        int bi = 0;
-#pragma unroll
-        for (int i = 0; i < GJ_ROWS; ++i) {
-          const double e = ch ? ga[i][1] : ga[i][0];
-          const int r = wv + i * nw;
-          const double v = (r < n && !((usedmask >> i) & 1u)) ? fabs(e) : -1.0;
-          const bool better = v > best;
-          best = better ? v : best; bi = better ? i : bi;
-          if (lane == cl) fcw[wv * GJ_ROWS + i] = e;
-        }
-        if (lane == cl) { cand[2 * wv] = best; cand[2 * wv + 1] = (double)(wv + bi * nw); }
-      }
-      LEG_BARRIER();
-      // global pivot: largest candidate, ties to the smaller row (branch-free; identical in every lane)
-      double cvv[8];
-      int crr[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { cvv[q] = cand[2 * q]; crr[q] = (int)cand[2 * q + 1]; }  // 8 wavefronts (LK_THREADS)
-      double gbest = cvv[0];
-#pragma unroll
-      for (int q = 1; q < 8; ++q) gbest = fmax(gbest, cvv[q]);
-      int p = 1 << 30;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) { const int c2 = (cvv[q] == gbest) ? crr[q] : (1 << 30); p = c2 < p ? c2 : p; }
-      p = __builtin_amdgcn_readfirstlane(p);
-      const int pw = p & 7, pi = p >> 3;  // nw == 8
-      if (wv == pw) {
-        usedmask |= 1u << pi;
-#pragma unroll
-        for (int i = 0; i < GJ_ROWS; ++i)
-          if (i == pi) {
-            prow[lane] = ga[i][0]; prow[lane + 64] = ga[i][1]; prow[128 + lane] = gb[i][0]; prow[192 + lane] = gb[i][1];
-            if (lane == cl) { const double dd = 1.0 / (ch ? ga[i][1] : ga[i][0]); prow[256] = dd; perm[col] = p; iperm[p] = col; dinv[col] = dd; }
-          }
-      }
-      LEG_BARRIER();
-      const double inv = prow[256];
-      const double pa0 = prow[lane], pa1 = prow[lane + 64], pb0 = prow[128 + lane], pb1 = prow[192 + lane];
-      double fc[GJ_ROWS];
-#pragma unroll
-      for (int i = 0; i < GJ_ROWS; ++i) fc[i] = fcw[wv * GJ_ROWS + i];
-#pragma unroll
-      for (int i = 0; i < GJ_ROWS; ++i) {
-        const int r = wv + i * nw;
-        const double f = (r == p || r >= n) ? 0.0 : fc[i] * inv;
-        ga[i][0] -= f * pa0; ga[i][1] -= f * pa1; gb[i][0] -= f * pb0; gb[i][1] -= f * pb1;
-      }
-    }
     }
     LEG_BARRIER();
     // solution in natural order back into RB (rows of the unknowns) and rv
 #pragma unroll
-    for (int i = 0; i < GJ_ROWS; ++i) {
-      const int r = wv + i * nw;
-      if (r < n) {
-        const int u = iperm[r];
-        const double sc = dinv[u];
+    for (int sl = 0; sl < GJ_SLOTS; ++sl) {
+      const int cc = 8 * sl + wv;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int z = lane + 64 * h;
-          if (z < n) RB[u * ldp + z] = gb[i][h] * sc;
-          else if (z == n) rv[u] = gb[i][h] * sc;
+      for (int h = 0; h < 2; ++h) {
+        const int r = lane + 64 * h;
+        if (r < n && cc >= n && cc <= 2 * n) {
+          const int u = iperm[r];
+          const double v = tq[h][sl] * dinv[u];
+          if (cc < 2 * n) RB[u * ldp + (cc - n)] = v; else rv[u] = v;
         }
       }
     }
@@ -779,21 +715,32 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
   // forward over the cuts: x_{j+1} = Zx_j x_j + zc_j (x_0 = 0: forced initial condition) ; theta_{j+1} = calP_{j+1} x_{j+1} + calp_{j+1}
   for (int i = tid; i < np; i += nthr) xv[i] = 0.0;
   LEG_BARRIER();
+  constexpr int FW_ROWS = NP / 8;  // rows of a mat-vec per wavefront: all their loads in flight before the reductions
   for (int j = 0; j + 1 < J; ++j) {
     double* lr = leg_ptr(a, b, j);
     const int cut = leg_start(a, j + 1);
-    for (int i = wv; i < n; i += nw) {
-      double s = 0;
-      for (int c0 = lane; c0 < n; c0 += 64) s += lr[L.lZx + i * n + c0] * xv[c0];
-      s = wave_sum(s);
-      if (lane == 0) { ev[i] = s + lr[L.lzc + i]; a.dxs[((size_t)b * (N + 1) + cut) * n + i] = ev[i]; }
+    const int c0 = lane < n ? lane : 0, c1 = lane + 64 < n ? lane + 64 : 0;
+    const double m0 = lane < n ? 1.0 : 0.0, m1 = lane + 64 < n ? 1.0 : 0.0;
+    double va[FW_ROWS][2];
+    if (j > 0) {  // x_0 = 0: the first cut state is zc_0
+#pragma unroll
+      for (int i = 0; i < FW_ROWS; ++i) { const int r = wv + i * nw, rr = r < n ? r : 0; va[i][0] = lr[L.lZx + rr * n + c0] * m0; va[i][1] = lr[L.lZx + rr * n + c1] * m1; }
     }
+#pragma unroll
+    for (int i = 0; i < FW_ROWS; ++i) {
+      const int r = wv + i * nw;
+      double sx = 0.0;
+      if (j > 0) sx = wave_sum(va[i][0] * xv[c0] + va[i][1] * xv[c1]);
+      if (lane == 0 && r < n) { ev[r] = sx + lr[L.lzc + r]; a.dxs[((size_t)b * (N + 1) + cut) * n + r] = ev[r]; }
+    }
+#pragma unroll
+    for (int i = 0; i < FW_ROWS; ++i) { const int r = wv + i * nw, rr = r < n ? r : 0; va[i][0] = lr[L.ldP + rr * n + c0] * m0; va[i][1] = lr[L.ldP + rr * n + c1] * m1; }
     LEG_BARRIER();
-    for (int i = wv; i < n; i += nw) {
-      double s = 0;
-      for (int c0 = lane; c0 < n; c0 += 64) s += lr[L.ldP + i * n + c0] * ev[c0];
-      s = wave_sum(s);
-      if (lane == 0) lr[L.lth + i] = s + lr[L.lcp + i];
+#pragma unroll
+    for (int i = 0; i < FW_ROWS; ++i) {
+      const int r = wv + i * nw;
+      const double sx = wave_sum(va[i][0] * ev[c0] + va[i][1] * ev[c1]);
+      if (lane == 0 && r < n) lr[L.lth + r] = sx + lr[L.lcp + r];
     }
     for (int i = tid; i < n; i += nthr) xv[i] = ev[i];
     LEG_BARRIER();

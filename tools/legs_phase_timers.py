@@ -29,7 +29,6 @@ tot = sum(p[i] for i in names)
 for i, nm in names.items():
     print('CONS %-40s %7.1f us/cut %5.1f%%' % (nm, p[i] / cuts / (GHZ * 1e3), 100 * p[i] / tot))
 print('CONS total %.1f us per cut' % (tot / cuts / (GHZ * 1e3)))
-print('CONS diagonal dominance measure of Mt (max over cuts and ticks) %.3e ; cuts solved with pivoting: %d of %d' % (p[30], int(p[31]), cuts))
 
 q = ens.native.debug_get('ric_prof', 0, b=1)[32:] if False else None
 
