@@ -331,10 +331,8 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds
     for (int sidx = 0; sidx < LC_TILES; ++sidx) {
       const int t = wv + sidx * nw;
       lres[sidx] = d4_t{0, 0, 0, 0}; zres[sidx] = d4_t{0, 0, 0, 0};
-      if (t < nb * nb) {
-        mma_tile<false>(lres[sidx], BA + (t / nb) * 16, 1, ldp, LM + (t % nb) * 16, ldp, 1, np, lane);
-        mma_tile<false>(zres[sidx], BB + ((t / nb) * 16) * ldp, ldp, 1, LM + (t % nb) * 16, ldp, 1, np, lane);
-      }
+      if (t < nb * nb)  // both products read the same columns of Lm': one pass, two accumulator chains
+        mma_tile_2a(lres[sidx], zres[sidx], BA + (t / nb) * 16, 1, ldp, BB + ((t / nb) * 16) * ldp, ldp, 1, LM + (t % nb) * 16, ldp, 1, np, lane);
     }
     LC_PROF(1);
     if (tid < n) { double s = 0; for (int l = 0; l < n; ++l) s += LM[l * ldp + tid] * phi[l]; sg[tid] += s; }

@@ -58,6 +58,45 @@ DEV void mma_tile2(d4_t& acc0, d4_t& acc1, const double* A0, const double* A1, i
     acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a11, b1, acc1, 0, 0, 0);
   }
 }
+// two output tiles sharing the B fragment, with independent strides of the two A operands (acc0 += A0 B, acc1 += A1 B): one LDS
+// read of B serves both, and the two accumulator chains interleave on the matrix core.  K % 4 == 0; groups of 16 software-pipelined
+// like mma_tile.
+DEV void mma_tile_2a(d4_t& acc0, d4_t& acc1, const double* A0, int a0_is, int a0_ks, const double* A1, int a1_is, int a1_ks,
+                     const double* B, int b_ks, int b_js, int K, int lane) {
+  const int i = lane & 15, kk = lane >> 4;
+  const double* ap0 = A0 + i * a0_is + kk * a0_ks;
+  const double* ap1 = A1 + i * a1_is + kk * a1_ks;
+  const double* bp = B + kk * b_ks + i * b_js;
+  const int Kmain = K & ~15;
+  int k0 = 0;
+  if (Kmain > 0) {
+    double x0 = ap0[0], x1 = ap0[4 * a0_ks], x2 = ap0[8 * a0_ks], x3 = ap0[12 * a0_ks];
+    double y0 = ap1[0], y1 = ap1[4 * a1_ks], y2 = ap1[8 * a1_ks], y3 = ap1[12 * a1_ks];
+    double b0 = bp[0], b1 = bp[4 * b_ks], b2 = bp[8 * b_ks], b3 = bp[12 * b_ks];
+    for (; k0 < Kmain; k0 += 16) {
+      const int kn = (k0 + 16 < Kmain) ? k0 + 16 : k0;  // the last group re-requests its own operands (unused)
+      const double nx0 = ap0[kn * a0_ks], nx1 = ap0[(kn + 4) * a0_ks], nx2 = ap0[(kn + 8) * a0_ks], nx3 = ap0[(kn + 12) * a0_ks];
+      const double ny0 = ap1[kn * a1_ks], ny1 = ap1[(kn + 4) * a1_ks], ny2 = ap1[(kn + 8) * a1_ks], ny3 = ap1[(kn + 12) * a1_ks];
+      const double nb0 = bp[kn * b_ks], nb1 = bp[(kn + 4) * b_ks], nb2 = bp[(kn + 8) * b_ks], nb3 = bp[(kn + 12) * b_ks];
+      __builtin_amdgcn_sched_barrier(0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y0, b0, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, b1, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y1, b1, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x2, b2, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y2, b2, acc1, 0, 0, 0);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x3, b3, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y3, b3, acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      x0 = nx0; x1 = nx1; x2 = nx2; x3 = nx3; y0 = ny0; y1 = ny1; y2 = ny2; y3 = ny3; b0 = nb0; b1 = nb1; b2 = nb2; b3 = nb3;
+    }
+  }
+  for (; k0 < K; k0 += 4) {
+    const double bv = bp[k0 * b_ks];
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap0[k0 * a0_ks], bv, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ap1[k0 * a1_ks], bv, acc1, 0, 0, 0);
+  }
+}
 DEV d4_t tile_load(const double* C, int ldc, int lane) {
   d4_t r;
   const int row = lane >> 4, col = lane & 15;
