@@ -16,6 +16,8 @@ elif "centroidal" in sys.argv[1:]:
 else:
     pd = FullDynamicsProblem(horizon=100, complete_model=True)
 ens = EnsembleMPC(pd, batch=4, library=lib, **({'perturb_dofs': range(18, pd.nv), 'seed': 7} if 'kino' in sys.argv[1:] else {}))
+ens.options.riccati_legs = 1  # the serial sweep: one workgroup walks all knots (tools/legs_phase_timers.py times the leg kernels)
+ens.native.set_options(ens.options)
 ens.prepare_schedule(10)
 ens.cold_solve(100)
 ens.native.profile(3)  # in-kernel phase timers on
