@@ -637,10 +637,12 @@ __global__ void __launch_bounds__(256) k_duals(SolverArgs a) {
     for (int i = wv; i < n; i += nw) {
       double s = 0, jd = 0;
       for (int z = lane; z < n; z += 64) s += gn[L.oP + i * n + z] * dxn[z];
-      const bool have = a.abdz != nullptr;  // the forward sweep already formed [A B] [dx; du]: 66 KB per knot not read again
-      if (!have) for (int z = lane; z < n + m; z += 64) jd += kn[L.oAB + i * nz + z] * dz[z];
+      // [A B] [dx; du]: left by the three-mat-vec forward sweep (abdz) ; without it (closed-loop / leg sweeps) the linearised
+      // dynamics residual comes from the multiplier update the LQ step satisfies, A dx + B du + E dx' = mu_d (lambda' - lambda_e) - f
+      // (below): the 66 KB of [A B] per knot are not read again
+      const bool have = a.abdz != nullptr;
       s = wave_sum(s);
-      jd = have ? a.abdz[((size_t)b * N + k) * n + i] : wave_sum(jd);
+      jd = have ? a.abdz[((size_t)b * N + k) * n + i] : 0.0;
       if (lane == 0) { lnew[i] = s + gn[L.op + i]; jdl[i] = jd; }
     }
   }
@@ -658,7 +660,8 @@ __global__ void __launch_bounds__(256) k_duals(SolverArgs a) {
       dl[i] = dli;
       const double lp = le[i] + kn[L.oF + i] / mud;
       double jd = jdl[i];
-      if (ff && i < 6) { for (int l = 0; l < 6; ++l) jd += kn[L.oE6 + i * 6 + l] * dxn[l]; }
+      if (a.abdz == nullptr) jd = mud * (ln - le[i]) - kn[L.oF + i];
+      else if (ff && i < 6) { for (int l = 0; l < 6; ++l) jd += kn[L.oE6 + i * 6 + l] * dxn[l]; }
       else jd -= dxn[i];
       s += (2.0 * lp - lam[i]) * jd - mud * (lp - lam[i]) * dli;
     }
