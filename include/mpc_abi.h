@@ -226,7 +226,10 @@ int mpc_get_stage_data(mpc_solver* s, int32_t k, double* xdot, double* wrenches)
 
 /* Phase dumps for parity tests: copies the named per-knot quantity of instance b, knot k into out
  * (capacity cap doubles) and returns the number of doubles written (<0 on error).  Names:
- * "H" "grad" "AB" "f" "E6" "cval" "CD" "cost" "P" "p" "K" "kff" "Knu" "knu" "dx" "du" "dvs" "dlams" "xnext". */
+ * "H" "grad" "AB" "f" "E6" "cval" "CD" "cost" "P" "p" "K" "kff" "Knu" "knu" "dx" "du" "dvs" "dlams" "xnext".
+ * Parallel-in-time sweep (riccati_legs > 1), knots of a leg other than the last: "Mu" "Znu" "Lm" and, HIP, "Phi" "phi" "Gam" "Ku" "Knup" /
+ * oracle, "Mx" "Mth" "Kth" "Knuth" "Kexact" (same quantities: Phi = Mx everywhere, Gam = Mth, Ku = Kth, Knup = Knuth at the last knot of a leg) ;
+ * with k = index of the leg instead of a knot: "Sg" "sg" (HIP; the oracle keeps them per knot) "Zx" "zc" "calP" "calp" "theta". */
 int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double* out, int32_t cap);
 /* Evaluate (value + derivatives) at the current iterate without stepping; fills the LQ knots. */
 int mpc_debug_evaluate(mpc_solver* s, const double* xs, const double* us);

@@ -444,10 +444,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
   const int n = L.n, N = L.N, np = S.np, mp = S.mp, ldp = S.ldp, nb = S.nb, nbm = S.nbm, J = a.nlegs;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *PC = sm + S.PC, *MA = sm + S.MA, *RB = sm + S.RB, *vec = sm + S.vec;
-  double *pc = vec, *rv = vec + np, *ev = vec + 2 * np, *prow_rv = vec + 3 * np, *fcol = vec + 4 * np, *xv = vec + 5 * np, *prowA = vec + 6 * np, *prowB = vec + 7 * np;
+  double *pc = vec, *rv = vec + np, *ev = vec + 2 * np, *fcol = vec + 4 * np, *xv = vec + 5 * np;  // calp | right-hand side / zc | scratch | 1 / pivots | cut state
   int* perm = (int*)(sm + S.iw);  // perm[col] = row that was the pivot of column col
   int* used = perm + np;          // used[row] != 0: row already served as a pivot
-  int* ipiv = used + np;
   d4_t res[LC_TILES];
   long long t0_ = clock64();
   // value function at the start of the last leg

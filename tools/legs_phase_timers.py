@@ -8,7 +8,7 @@ from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
 legs = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 lib = _capi.load_hip_library()
 pd = FullDynamicsProblem(horizon=100, complete_model=True)
-ens = EnsembleMPC(pd, batch=4, library=lib)
+ens = EnsembleMPC(pd, batch=int(sys.argv[2]) if len(sys.argv) > 2 else 4, library=lib)
 ens.options.riccati_legs = legs
 ens.native.set_options(ens.options)
 ens.prepare_schedule(10)
