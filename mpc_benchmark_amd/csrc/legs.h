@@ -776,29 +776,43 @@ __global__ void __launch_bounds__(256) k_leg_apply(SolverArgs a) {
     for (int q = 0; q < nw; ++q) { if (q < wv) off += wcnt[q]; ca += wcnt[q]; }
     if (is_act) act_idx[off + __popcll(amask & ((1ull << lane) - 1ull))] = tid;
   }
+  // mat-vecs: a wavefront takes four rows at a time, all their loads in flight before the four reductions
+  const int c0 = lane < n ? lane : 0, c1 = lane + 64 < n ? lane + 64 : 0;
+  const double m0 = lane < n ? 1.0 : 0.0, m1 = lane + 64 < n ? 1.0 : 0.0;
   if (k == ke) { for (int i = tid; i < n; i += nthr) pn[i] = th[i]; }
   else {
-    const double* gn = gain_ptr(a, b, k + 1);
-    for (int i = wv; i < n; i += nw) {
-      double s = 0;
-      for (int c0 = lane; c0 < n; c0 += 64) s += gn[L.oLm + i * n + c0] * th[c0];
-      s = wave_sum(s);
-      if (lane == 0) pn[i] = s;
+    const double* gn = gain_ptr(a, b, k + 1) + L.oLm;
+    const double t0 = th[c0] * m0, t1 = th[c1] * m1;
+    for (int r0 = 4 * wv; r0 < n; r0 += 4 * nw) {
+      double v[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int r = r0 + q < n ? r0 + q : 0; v[q][0] = gn[r * n + c0]; v[q][1] = gn[r * n + c1]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const double sx = wave_sum(v[q][0] * t0 + v[q][1] * t1); if (lane == 0 && r0 + q < n) pn[r0 + q] = sx; }
     }
   }
   __syncthreads();
-  for (int r = wv; r < 2 * n + m + ca; r += nw) {
-    // rows: [0, n) p += Lm_k theta ; [n, 2n) phi += Gamma p' ; [2n, 2n + m) k += Ku p' ; then the active constraint rows
-    const double* row;
-    const double* x;
-    double* dst;
-    if (r < n) { row = g + L.oLm + r * n; x = th; dst = g + L.op + r; }
-    else if (r < 2 * n) { row = g + L.oGam + (r - n) * n; x = pn; dst = g + L.ophi + (r - n); }
-    else if (r < 2 * n + m) { row = g + L.oKu + (r - 2 * n) * n; x = pn; dst = g + L.ok + (r - 2 * n); }
-    else { row = g + L.oKnup + (r - 2 * n - m) * n; x = pn; dst = g + L.oknu + act_idx[r - 2 * n - m]; }
-    double s = 0;
-    for (int c0 = lane; c0 < n; c0 += 64) s += row[c0] * x[c0];
-    s = wave_sum(s);
-    if (lane == 0) *dst += s;
+  // rows: [0, n) p += Lm_k theta ; [n, 2n) phi += Gamma p' ; [2n, 2n + m) k += Ku p' ; then the active constraint rows: knu += Knup p'
+  const double t0 = th[c0] * m0, t1 = th[c1] * m1, q0 = pn[c0] * m0, q1 = pn[c1] * m1;
+  const int total = 2 * n + m + ca;
+  for (int r0 = 4 * wv; r0 < total; r0 += 4 * nw) {
+    double v[4][2];
+    double* dst[4];
+    bool use_th[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = r0 + q < total ? r0 + q : 0;
+      const double* row;
+      if (r < n) { row = g + L.oLm + r * n; dst[q] = g + L.op + r; use_th[q] = true; }
+      else if (r < 2 * n) { row = g + L.oGam + (r - n) * n; dst[q] = g + L.ophi + (r - n); use_th[q] = false; }
+      else if (r < 2 * n + m) { row = g + L.oKu + (r - 2 * n) * n; dst[q] = g + L.ok + (r - 2 * n); use_th[q] = false; }
+      else { row = g + L.oKnup + (r - 2 * n - m) * n; dst[q] = g + L.oknu + act_idx[r - 2 * n - m]; use_th[q] = false; }
+      v[q][0] = row[c0]; v[q][1] = row[c1];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double sx = wave_sum(use_th[q] ? v[q][0] * t0 + v[q][1] * t1 : v[q][0] * q0 + v[q][1] * q1);
+      if (lane == 0 && r0 + q < total) *dst[q] += sx;
+    }
   }
 }

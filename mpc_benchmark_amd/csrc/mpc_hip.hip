@@ -8,6 +8,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "eval_multibody.h"
@@ -36,6 +37,7 @@ struct mpc_solver {
   double* d_model_d = nullptr;
   double *d_xs = nullptr, *d_us = nullptr, *d_vs = nullptr, *d_lams = nullptr, *d_vs_e = nullptr, *d_lams_e = nullptr, *d_x0 = nullptr;
   double *d_dxs = nullptr, *d_dus = nullptr, *d_dvs = nullptr, *d_dlams = nullptr, *d_abdz = nullptr;
+  double *d_xs_alt = nullptr, *d_us_alt = nullptr;  // second pair of iterate buffers: the warm-start shift writes out of place, then the pairs swap
   double *d_knots = nullptr, *d_tknots = nullptr, *d_gains = nullptr, *d_work = nullptr, *d_trial_phi = nullptr, *d_mbwork = nullptr;
   InstState* d_inst = nullptr;
   int* d_all_done = nullptr;
@@ -189,6 +191,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->d_stage_desc = s->alloc<int32_t>(N1 * L.max_stage_ints);
   s->d_stage_params = s->alloc<double>(N1 * L.max_stage_doubles);
   s->d_xs = s->alloc<double>(B * N1 * L.nx); s->d_us = s->alloc<double>(B * N * L.m + 1);
+  s->d_xs_alt = s->alloc<double>(B * N1 * L.nx); s->d_us_alt = s->alloc<double>(B * N * L.m + 1);
   s->d_vs = s->alloc<double>(B * N1 * L.c); s->d_lams = s->alloc<double>(B * (N1 + 1) * L.n);
   s->d_vs_e = s->alloc<double>(B * N1 * L.c); s->d_lams_e = s->alloc<double>(B * (N1 + 1) * L.n);
   s->d_x0 = s->alloc<double>(B * L.nx);
@@ -311,6 +314,14 @@ static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_des
 // tick reuse: whatever changes the problem or the iterate behind the solver's back invalidates the kept records
 static void spec_clear(mpc_solver* s) { if (s->d_spec) HIP_OK(hipMemsetAsync(s->d_spec, 0, s->L.B * sizeof(int), s->stream)); }
 
+// warm-start shift of the iterate (k_shift): from the current pair of buffers into the other one, which becomes the current pair
+static void launch_shift(mpc_solver* s) {
+  const double *xin = s->d_xs, *uin = s->d_us;
+  std::swap(s->d_xs, s->d_xs_alt);
+  std::swap(s->d_us, s->d_us_alt);
+  hipLaunchKernelGGL(k_shift, dim3(s->L.N + 1, s->L.B), dim3(64), 0, s->stream, s->args(), xin, uin, s->perfect_feedback ? 1 : 0);
+}
+
 static int slot_of(const mpc_solver* s, int k) { return k < s->L.N ? (s->head + k) % s->L.N : s->L.N; }
 
 // ---- kernel sequences -----------------------------------------------------------------------------
@@ -412,9 +423,9 @@ static void launch_pass(mpc_solver* s) {
   // linesearch: evaluate the full step first; the backtracking candidates alpha = 2^-i, i >= 1, are only
   // evaluated for instances whose full step failed the Armijo test (their workgroups exit immediately otherwise)
   s->timed(6, "k_eval_stage_trial", [&] { launch_eval(s, true, 0, 1, a.spec_on != 0); });
-  s->timed(7, "k_linesearch", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(1), 0, s->stream, a, 1); });
+  s->timed(7, "k_linesearch", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(64), 0, s->stream, a, 1); });
   s->timed(10, "k_eval_stage_backtrack", [&] { launch_eval(s, true, 1, L.n_alpha - 1); });
-  s->timed(11, "k_linesearch_backtrack", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(1), 0, s->stream, a, 0); });
+  s->timed(11, "k_linesearch_backtrack", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(64), 0, s->stream, a, 0); });
   s->timed(8, "k_accept", [&] { hipLaunchKernelGGL(k_accept, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   s->timed(9, "k_after_step", [&] { hipLaunchKernelGGL(k_after_step, dim3(L.B), dim3(1), 0, s->stream, a); });
   HIP_OK(hipGetLastError());
@@ -709,7 +720,7 @@ int mpc_run(mpc_solver* s, const double* xs, const double* us, mpc_stats* stats)
 int mpc_run_shifted(mpc_solver* s, mpc_stats* stats) {
   MPC_TRY(s, {
     if (s->tick_reuse) { s->khead = (s->khead + 1) % s->L.N; s->reuse_this_pass = true; }  // the records move one knot on with the iterate
-    hipLaunchKernelGGL(k_shift, dim3(s->L.B), dim3(64), 0, s->stream, s->args(), s->perfect_feedback ? 1 : 0);
+    launch_shift(s);
     run_impl(s, stats);
   })
 }
@@ -724,7 +735,7 @@ int mpc_run_shifted_async(mpc_solver* s) {
       HIP_OK(hipEventCreateWithFlags(&s->status_ev[slot], hipEventDisableTiming));
     }
     if (s->tick_reuse) { s->khead = (s->khead + 1) % L.N; s->reuse_this_pass = true; }
-    hipLaunchKernelGGL(k_shift, dim3(L.B), dim3(64), 0, s->stream, s->args(), s->perfect_feedback ? 1 : 0);
+    launch_shift(s);
     hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, s->args());
     // with max_iters = 1 one pass takes the step
     launch_pass(s);

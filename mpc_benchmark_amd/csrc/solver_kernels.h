@@ -634,16 +634,31 @@ __global__ void __launch_bounds__(256) k_duals(SolverArgs a) {
   if (k == 0) for (int i = tid; i < n; i += nthr) a.dlams[(size_t)b * (N + 1) * n + i] = 0.0;
   if (k < N) {
     const double* gn = gain_ptr(a, b, k + 1);
-    for (int i = wv; i < n; i += nw) {
-      double s = 0, jd = 0;
-      for (int z = lane; z < n; z += 64) s += gn[L.oP + i * n + z] * dxn[z];
-      // [A B] [dx; du]: left by the three-mat-vec forward sweep (abdz) ; without it (closed-loop / leg sweeps) the linearised
-      // dynamics residual comes from the multiplier update the LQ step satisfies, A dx + B du + E dx' = mu_d (lambda' - lambda_e) - f
-      // (below): the 66 KB of [A B] per knot are not read again
-      const bool have = a.abdz != nullptr;
-      s = wave_sum(s);
-      jd = have ? a.abdz[((size_t)b * N + k) * n + i] : 0.0;
-      if (lane == 0) { lnew[i] = s + gn[L.op + i]; jdl[i] = jd; }
+    // [A B] [dx; du]: left by the three-mat-vec forward sweep (abdz) ; without it (closed-loop / leg sweeps) the linearised
+    // dynamics residual comes from the multiplier update the LQ step satisfies, A dx + B du + E dx' = mu_d (lambda' - lambda_e) - f
+    // (below): the 66 KB of [A B] per knot are not read again
+    const bool have = a.abdz != nullptr;
+    // lambda' = P' dx' + p': a wavefront takes four rows of P' at a time, all their loads in flight before the reductions (n <= 128)
+    const int c0 = lane < n ? lane : 0, c1 = lane + 64 < n ? lane + 64 : 0;
+    const double d0 = lane < n ? dxn[c0] : 0.0, d1 = lane + 64 < n ? dxn[c1] : 0.0;
+    if (n > 128) {  // general form (no kernel of the whole-body / centroidal problems gets here)
+      for (int i = wv; i < n; i += nw) {
+        double s = 0;
+        for (int z = lane; z < n; z += 64) s += gn[L.oP + i * n + z] * dxn[z];
+        s = wave_sum(s);
+        if (lane == 0) { lnew[i] = s + gn[L.op + i]; jdl[i] = have ? a.abdz[((size_t)b * N + k) * n + i] : 0.0; }
+      }
+    } else
+    for (int r0 = 4 * wv; r0 < n; r0 += 4 * nw) {
+      double pv[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int r = r0 + q < n ? r0 + q : 0; pv[q][0] = gn[L.oP + r * n + c0]; pv[q][1] = gn[L.oP + r * n + c1]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = r0 + q;
+        const double s = wave_sum(pv[q][0] * d0 + pv[q][1] * d1);
+        if (lane == 0 && i < n) { lnew[i] = s + gn[L.op + i]; jdl[i] = have ? a.abdz[((size_t)b * N + k) * n + i] : 0.0; }
+      }
     }
   }
   if (lane == 0) part[wv] = acc;
@@ -673,48 +688,48 @@ __global__ void __launch_bounds__(256) k_duals(SolverArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// P8: Armijo backtracking over the pre-evaluated candidates alpha_i = 2^-i.  grid B, block 1
+// P8: Armijo backtracking over the pre-evaluated candidates alpha_i = 2^-i.  grid B, block 64
 // ------------------------------------------------------------------------------------------------
 // first == 1: only the full step (candidate 0) has been evaluated; accept it if it passes Armijo, otherwise
 // raise ls_more so that the remaining candidates get evaluated.  first == 0: backtrack over all of them.
-__global__ void k_linesearch(SolverArgs a, int first) {
+// one wavefront per instance: the sums over the knots are taken by the lanes (two knots per lane, then the fixed DPP tree of wave_sum:
+// deterministic), not by one thread walking 101 records
+__global__ void __launch_bounds__(64) k_linesearch(SolverArgs a, int first) {
   const Layout& L = a.L;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, lane = threadIdx.x;
   InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
   if (!first && !st.ls_more) return;
-  double d = 0;
-  for (int k = 0; k <= L.N; ++k) d += knot_ptr(a, b, k)[L.oMISC + MISC_DMERIT];
-  st.dphi0 = d;
+  auto knot_sum = [&](auto&& value_of) {  // sum over k = 0 .. N of value_of(k)
+    double s = 0.0;
+    for (int k = lane; k <= L.N; k += 64) s += value_of(k);
+    return wave_sum(s);
+  };
+  const double d = knot_sum([&](int k) { return knot_ptr(a, b, k)[L.oMISC + MISC_DMERIT]; });
   double alpha = 1.0;
   int step = 0;
   if (first && fabs(d) <= MPC_STALL_TOL * (1.0 + fabs(st.phi0))) {
     // the Newton step cannot decrease the merit any further (round-off floor of the 1/mu-conditioned system): the inner
     // problem counts as solved — no step, no iteration counted, the next pass takes the BCL branch
-    st.stalled = (((st.stalled >> 8) + 1) << 8) | 1; st.ls_more = 0; st.alpha = 0.0; st.ls_step = 0;
+    if (lane == 0) { st.dphi0 = d; st.stalled = (((st.stalled >> 8) + 1) << 8) | 1; st.ls_more = 0; st.alpha = 0.0; st.ls_step = 0; }
     return;
   }
   if (first) {
-    double phi = 0;
     const double* tp = a.trial_phi + ((size_t)b * L.n_alpha) * (L.N + 1);
-    for (int k = 0; k <= L.N; ++k) phi += tp[k];
+    const double phi = knot_sum([&](int k) { return tp[k]; });
     const bool ok = phi <= st.phi0 + a.opt.ls_armijo_c1 * d;
     const bool last = a.opt.ls_max_steps <= 1 || L.n_alpha <= 1 || 0.5 < a.opt.ls_alpha_min;
-    st.ls_more = (ok || last) ? 0 : 1;
-    st.alpha = 1.0;
-    st.ls_step = 0;
+    if (lane == 0) { st.dphi0 = d; st.ls_more = (ok || last) ? 0 : 1; st.alpha = 1.0; st.ls_step = 0; }
     return;
   }
   for (;; ++step) {
-    double phi = 0;
     const double* tp = a.trial_phi + ((size_t)b * L.n_alpha + step) * (L.N + 1);
-    for (int k = 0; k <= L.N; ++k) phi += tp[k];
+    const double phi = knot_sum([&](int k) { return tp[k]; });
     if (phi <= st.phi0 + a.opt.ls_armijo_c1 * alpha * d) break;
     if (step + 1 >= a.opt.ls_max_steps || step + 1 >= L.n_alpha || 0.5 * alpha < a.opt.ls_alpha_min) break;
     alpha *= 0.5;
   }
-  st.alpha = alpha;
-  st.ls_step = step;
+  if (lane == 0) { st.dphi0 = d; st.alpha = alpha; st.ls_step = step; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -794,16 +809,21 @@ __global__ void k_begin_run(SolverArgs a) {
   }
 }
 
-// warm-start shift on the device (fulldynamic_talos.py:532-534).  grid B, block 64
-__global__ void k_shift(SolverArgs a, int perfect_feedback) {
+// warm-start shift on the device (fulldynamic_talos.py:532-534): xs <- [xs[1:], xs[-1]], us <- [us[1:], us[-1]], out of place (the
+// host swaps the two buffer pairs), one workgroup per knot.  grid (N + 1, B), block 64
+__global__ void k_shift(SolverArgs a, const double* xs_in, const double* us_in, int perfect_feedback) {
   const Layout& L = a.L;
-  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
-  double* xs = a.xs + (size_t)b * (L.N + 1) * L.nx;
-  double* us = a.us + (size_t)b * L.N * L.m;
-  // sequential over knots to stay in place; each element handled by one thread
+  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x;
+  const double* xi = xs_in + ((size_t)b * (L.N + 1) + (k < L.N ? k + 1 : L.N)) * L.nx;
+  double* xo = a.xs + ((size_t)b * (L.N + 1) + k) * L.nx;
   for (int i = tid; i < L.nx; i += nthr) {
-    for (int k = 0; k < L.N; ++k) xs[k * L.nx + i] = xs[(k + 1) * L.nx + i];
-    if (perfect_feedback) a.x0[(size_t)b * L.nx + i] = xs[i];  // the predicted next state is the new measurement
+    const double v = xi[i];
+    xo[i] = v;
+    if (k == 0 && perfect_feedback) a.x0[(size_t)b * L.nx + i] = v;  // the predicted next state is the new measurement
   }
-  for (int i = tid; i < L.m; i += nthr) for (int k = 0; k + 1 < L.N; ++k) us[k * L.m + i] = us[(k + 1) * L.m + i];
+  if (k < L.N) {
+    const double* ui = us_in + ((size_t)b * L.N + (k + 1 < L.N ? k + 1 : L.N - 1)) * L.m;
+    double* uo = a.us + ((size_t)b * L.N + k) * L.m;
+    for (int i = tid; i < L.m; i += nthr) uo[i] = ui[i];
+  }
 }
