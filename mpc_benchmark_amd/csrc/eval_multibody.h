@@ -133,6 +133,7 @@ struct MbLds {
   int M, LIm, Y16, V16, Sp, LIs, R, Jc, gam, bias, a, lam, x, u, xn, cfr, small, se3, red, total;
   int stage_rows;  // rows of Jacobian staging (ld nz) that fit in the R region
   int anc_bytes_off, total_bytes;
+  unsigned mg_nv, mg_nvp, mg_nz, mg_n;  // magic_div (device_common.h) of the run-time divisors nv, nvp, n + nu, n of the per-element loops
 };
 
 // The contact KKT system [[M, Jc^T], [Jc, -mu I]] is never inverted: M = L L^T (blocked Cholesky on the matrix
@@ -174,6 +175,7 @@ static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz) {
   s.total = o;
   s.anc_bytes_off = o * 8;
   s.total_bytes = o * 8 + 3 * nj * 8 + nv * 4 + nj * 4 * 3 + 64;
+  s.mg_nv = magic_div(nv); s.mg_nvp = magic_div(s.nvp); s.mg_nz = magic_div(nz); s.mg_n = magic_div(2 * nv);
   return s;
 }
 
@@ -235,6 +237,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   const bool kino = dyn == MPC_DYN_KINODYNAMICS_SEMIEULER;               // kinodynamics: u = [wrenches ; joint accelerations]
   const int m = (has_dyn || kino) ? nu : 0, nz = n + m, nterms = desc[5], c = desc[6];
   const int nk = has_dyn ? desc[1] : 0, nl = 6 * nk, nK = nv + nl;
+  const unsigned mg_nz = m ? S.mg_nz : S.mg_n;  // nz = n + nu on a stage with dynamics, n on the terminal knot
   const bool derivs = (TRIAL == 0 || TRIAL == 3);
 cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of the same knot)
   const double alpha = CAND ? ldexp(1.0, -cand) : 0.0;
@@ -459,7 +462,7 @@ sim_loop:
     const double dt = P[desc[4]];
     // ---- P6: joint-space inertia, bias torques, contact frames -------------------------------------------
     for (int idx = tid; idx < nvp * nvp; idx += nthr) {
-      const int r = idx / nvp, cc = idx % nvp;
+      const int r = qdiv(idx, S.mg_nvp), cc = (idx - qdiv(idx, S.mg_nvp) * nvp);
       double s = (r == cc) ? 1.0 : 0.0;  // identity padding
       if (r < nv && cc < nv) {
         s = 0;
@@ -490,7 +493,7 @@ sim_loop:
     }
     __syncthreads();
     for (int idx = tid; idx < nk * nv; idx += nthr) {
-      const int cc = idx / nv, kd = idx % nv;
+      const int cc = qdiv(idx, S.mg_nv), kd = (idx - qdiv(idx, S.mg_nv) * nv);
       const int i = mcontact[desc[2 + cc]];
       S6 col = zero6();
       if (BELOW(kd, i)) col = adinv(ldm3(cfr + 54 * cc), ldv3(cfr + 54 * cc + 9), ld6(J + 6 * kd));
@@ -779,7 +782,7 @@ sim_loop:
     for (int idx = tid; idx < (nvp + 16) * ldR; idx += nthr) Rm[idx] = 0.0;
     __syncthreads();
     for (int idx = tid; idx < nv * nv; idx += nthr) {
-      const int r = idx / nv, j = idx % nv;
+      const int r = qdiv(idx, S.mg_nv), j = (idx - qdiv(idx, S.mg_nv) * nv);
       const int br = dof_body[r], bj = dof_body[j];
       double dq = 0, dv = 0;
       if ((anc[br] >> bj) & 1ull) {
@@ -796,7 +799,7 @@ sim_loop:
     }
     for (int i = tid; i < nu; i += nthr) R1[(nv - nu + i) * ldR + n2 + i] = -1.0;  // d r1 / du = -B
     for (int idx = tid; idx < nk * nv; idx += nthr) {
-      const int cc = idx / nv, j = idx % nv;
+      const int cc = qdiv(idx, S.mg_nv), j = (idx - qdiv(idx, S.mg_nv) * nv);
       const int cid = desc[2 + cc], i = mcontact[cid];
       const double* cm = cd + MPC_MODEL_CONTACT_DOUBLES * cid;
       S6 rq = zero6(), rv = zero6();
@@ -926,7 +929,7 @@ sim_loop:
     if (derivs) {
       // dvp = dt * da + [0 I 0];  rows nv..n of AB = dvp; rows 6..nv = dt dvp + [I 0 0]; base rows below
       for (int idx = tid; idx < nv * nz; idx += nthr) {
-        const int r = idx / nz, z = idx % nz;
+        const int r = qdiv(idx, mg_nz), z = (idx - qdiv(idx, mg_nz) * nz);
         const double da_rz = has_dyn ? -R1[r * ldR + z] : dsol[(size_t)r * L.nz + z];
         const double dvp = dt * da_rz + ((z == nv + r) ? 1.0 : 0.0);
         kn[KL.oAB + (size_t)(nv + r) * KL.nz + z] = dvp;
@@ -935,7 +938,7 @@ sim_loop:
       __syncthreads();  // JL aliases rows of R1
       // base rows: Jlog6(G) ( dt Jexp6 dvp[0:6] + [Jq6 0] )
       for (int idx = tid; idx < 6 * nz; idx += nthr) {
-        const int r = idx / nz, z = idx % nz;
+        const int r = qdiv(idx, mg_nz), z = (idx - qdiv(idx, mg_nz) * nz);
         double s = (z < 6) ? Jq6[6 * r + z] : 0.0;
         for (int l = 0; l < 6; ++l) {
           const double da_lz = has_dyn ? -R1[l * ldR + z] : dsol[(size_t)l * L.nz + z];
@@ -945,7 +948,7 @@ sim_loop:
       }
       __syncthreads();
       for (int idx = tid; idx < 6 * nz; idx += nthr) {
-        const int r = idx / nz, z = idx % nz;
+        const int r = qdiv(idx, mg_nz), z = (idx - qdiv(idx, mg_nz) * nz);
         double s = 0;
         for (int l = 0; l < 6; ++l) s += Jl6[6 * r + l] * JL[l * nz + z];
         kn[KL.oAB + (size_t)r * KL.nz + z] = s;
@@ -1078,7 +1081,7 @@ sim_loop:
       }
     } else if (tr.type == MPC_TERM_CONTACT_FORCE) {
       if (t0 < 6) r[t0] = lam[6 * tr.i0 + t0] - tp[t0];
-      if (derivs) for (int idx = t0; idx < 6 * nz; idx += nt) Jt[idx] = R2[(6 * tr.i0 + idx / nz) * ldR + idx % nz];
+      if (derivs) for (int idx = t0; idx < 6 * nz; idx += nt) Jt[idx] = R2[(6 * tr.i0 + qdiv(idx, mg_nz)) * ldR + (idx - qdiv(idx, mg_nz) * nz)];
     } else if (tr.type == MPC_TERM_CENTROIDAL_WRENCH_CONE) {
       for (int i = t0; i < d; i += nt) { double sacc = 0; for (int j = 0; j < 6; ++j) sacc += tp[i * 6 + j] * u[6 * tr.i0 + j]; r[i] = sacc; }
       if (derivs) for (int idx = t0; idx < d * 6; idx += nt) Jt[(idx / 6) * nz + n + 6 * tr.i0 + idx % 6] = tp[idx];
@@ -1126,7 +1129,7 @@ sim_loop:
     } else if (tr.type == MPC_TERM_MB_WRENCH_CONE) {
       for (int i = t0; i < d; i += nt) { double s = 0; for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * lam[6 * tr.i0 + j]; r[i] = s; }
       if (derivs) for (int idx = t0; idx < d * nz; idx += nt) {
-        const int i = idx / nz, z = idx % nz;
+        const int i = qdiv(idx, mg_nz), z = (idx - qdiv(idx, mg_nz) * nz);
         double s = 0;
         for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * R2[(6 * tr.i0 + j) * ldR + z];
         Jt[idx] = s;
@@ -1228,7 +1231,7 @@ sim_loop:
       }
       if (derivs) {
         if (lane < d) wrs[trow[t] + lane] = sqrt(W[lane * wstride]) * r[lane];
-        for (int idx = lane; idx < d * nz; idx += 64) Jt[idx] *= sqrt(W[(idx / nz) * wstride]);
+        for (int idx = lane; idx < d * nz; idx += 64) Jt[idx] *= sqrt(W[(qdiv(idx, mg_nz)) * wstride]);
       }
     }
     EV_PROF(28);

@@ -28,6 +28,10 @@
 // next knot) and waits for every global store to be acknowledged.  Used wherever the data exchanged lives in LDS.
 #define LEG_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// (per-lane index expressions are kept phase-local by passing the lane ids through an empty asm, as in riccati_mfma.h: hoisted out of
+// the knot loop they would be spilled)
+#define LEG_LAUNDER() do { asm volatile("" : "+v"(tid), "+v"(lane)); wv = __builtin_amdgcn_readfirstlane(tid >> 6); } while (0)
+
 #define LK_THREADS 512
 #define LK_U 20      // global loads in flight per thread in the LDS fills
 #define LK_PT 13     // matrix elements per thread parked in registers (np <= 80: 6400 / 512)
@@ -36,6 +40,7 @@
 struct LkLds {
   int np, mp, nzp, lda, ldp, ldm, nb, nbm;  // lda: leading dimension of the [A B] buffer (odd: rows AND columns are read with a lane stride)
   int AB, PR, TM, ZN, vec, total_bytes;
+  unsigned mg_nzp, mg_np, mg_mp;  // magic_div of the run-time divisors of the fills
 };
 // LDS plan (np = 80, mp = 48: 153 KB; mp = 32: 140 KB).  PR is one n x n region with three lives: K (stage 1), Pt (stages 2-3),
 // U1 = Mu Bc^T next to Mu (stages 4-5).  TM: rows 0..5 of [M | Bl] (6 x nzp) | columns 0..5 of Pt T^T (np x 6) | 6 x 6 corner of T Pt T^T.
@@ -43,225 +48,278 @@ static inline LkLds make_lk_lds(int n, int m) {
   LkLds s;
   s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.lda = s.nzp + 1; s.ldp = s.np + 1; s.ldm = s.mp + 1;
   s.nb = s.np / 16; s.nbm = s.mp / 16;
+  s.mg_nzp = magic_div(s.nzp); s.mg_np = magic_div(s.np); s.mg_mp = magic_div(s.mp);
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
   const int pr = s.np * s.ldp > s.mp * s.np + s.mp * s.ldm ? s.np * s.ldp : s.mp * s.np + s.mp * s.ldm;
-  s.AB = take(s.np * s.lda); s.PR = take(pr); s.TM = take(6 * s.nzp + 6 * s.np + 40); s.ZN = take(16 * s.ldm); s.vec = take(s.mp + 2 * s.np + 80);
+  s.AB = take(s.np * s.lda); s.PR = take(pr); s.TM = take(6 * s.nzp + 6 * s.np + 40); s.ZN = take(16 * s.ldm); s.vec = take(s.mp + 3 * s.np + 80 + 8);
   s.total_bytes = o * 8;
   return s;
 }
 
-// grid (N, B): knot k of instance b.  Reads K, k, Pt, mx, T6, Mu, Znu (gain record) and [A B] (knot record); writes Phi, phi for every
-// knot and Gamma, Ku, Knup for the knots of parametric legs.
-__global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S) {
+// grid (ceil(N / chunk), B): workgroup (ck, b) walks knots ck * chunk .. of instance b.  Reads K, k, Pt, mx, T6, Mu, Znu (gain record) and
+// [A B] (knot record); writes Phi, phi for every knot and Gamma, Ku, Knup for the knots of parametric legs.  Everything the NEXT knot of
+// the chunk needs is requested into registers while this one computes (a workgroup owns its CU: 140 - 153 KB of LDS), so only the first
+// knot of a chunk waits for HBM.  MP: padded control dimension (sizes the prefetch registers).
+template <int MP>
+__global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S, int chunk) {
+  constexpr int NAB = (80 * (80 + MP) + LK_THREADS - 1) / LK_THREADS, NK = (MP * 80 + LK_THREADS - 1) / LK_THREADS;
+  constexpr int NMU = (MP * MP + LK_THREADS - 1) / LK_THREADS, NZN = (16 * MP + LK_THREADS - 1) / LK_THREADS;
   const Layout& L = a.L;
-  const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, nw = nthr >> 6;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  int tid = threadIdx.x, lane = tid & 63;
+  constexpr int nthr = LK_THREADS, nw = LK_THREADS / 64;
+  int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
   const int n = L.n, nz = L.nz, np = S.np, mp = S.mp, nzp = S.nzp, lda = S.lda, ldp = S.ldp, ldm = S.ldm, nb = S.nb, nbm = S.nbm;
-  const double* kn = knot_ptr(a, b, k);
-  double* g = gain_ptr(a, b, k);
-  const int m = (int)kn[L.oMISC + MISC_M], c = (int)kn[L.oMISC + MISC_NC];
+  const int kbeg = blockIdx.x * chunk, kend = (kbeg + chunk < L.N) ? kbeg + chunk : L.N;
   const double mud = st.mu * a.opt.dyn_al_scale;
-  const bool par = leg_of_knot(a, k) + 1 < a.nlegs;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *AB = sm + S.AB, *PR = sm + S.PR, *ZN = sm + S.ZN, *vec = sm + S.vec;
   double *KM = PR, *PT = PR, *U1 = PR, *MU = PR + mp * np;  // the three lives of PR
   double *TMP = sm + S.TM, *PT6 = TMP + 6 * nzp, *c6 = PT6 + 6 * np;
-  double *kf = vec, *y0 = vec + mp, *z0 = y0 + np, *t6 = z0 + np, *g6 = t6 + 36;  // k (mp), B k + mx (np), (I - mu_d Pt) y0 (np), T6, T6 T6^T
-  // developer phase timers (mpc_profile(3)): workgroup (knot 1, instance 1) -> slots 32.. of instance 1's counter block
+  double *kf = vec, *y0 = vec + mp, *z0 = y0 + np, *t6 = z0 + np, *g6 = t6 + 36, *mxs = g6 + 36;  // k (mp), B k + mx (np), (I - mu_d Pt) y0 (np), T6, T6 T6^T, mx (np)
+  int* cnt = (int*)(mxs + np);  // active rows counted per wavefront (nw ints)
+  // developer phase timers (mpc_profile(3)): the workgroup of (knot 1, instance 1) -> slots 32.. of instance 1's counter block
   long long tk0_ = clock64();
 #define LK_PROF(slot) do { if (a.prof && k == 1 && b == 1 && tid == 0) { const long long t1_ = clock64(); a.prof[64 + 32 + (slot)] += (double)(t1_ - tk0_); tk0_ = t1_; } } while (0)
 
-  // ---- stage 1: [A B] and K into LDS (zero padded; u-columns of [A B] start at np) ; A_cl = A + B K in place ; y0 = B k + mx ----
-  for (int base = tid; base < np * nzp; base += nthr * LK_U) {
-    double v[LK_U];
+  // ---- the operands of a knot, as the registers of the prefetch hold them ----
+  double pab[NAB], pkm[NK], ptv[LK_PT], pmu[NMU], pzn[NZN], psm = 0.0, pact = 0.0;  // psm: k / T6 / mx element of this thread
+  auto request_ab = [&](int k) {  // [A B], K, the small vectors, the active-row flags
+    const double* kn = knot_ptr(a, b, k);
+    const double* g = gain_ptr(a, b, k);
+    const int m = (int)kn[L.oMISC + MISC_M], c = (int)kn[L.oMISC + MISC_NC];
 #pragma unroll
-    for (int u = 0; u < LK_U; ++u) {
-      const int idx = base + u * nthr, i = idx / nzp, zp = idx % nzp;
+    for (int u = 0; u < NAB; ++u) {
+      const int idx = tid + u * nthr, i = qdiv(idx, S.mg_nzp), zp = (idx - qdiv(idx, S.mg_nzp) * nzp);
       const int z = (zp < n) ? zp : ((zp >= np && zp - np < m) ? n + zp - np : -1);
-      v[u] = (idx < np * nzp && i < n && z >= 0) ? kn[L.oAB + (size_t)i * nz + z] : 0.0;
+      pab[u] = (idx < np * nzp && i < n && z >= 0) ? kn[L.oAB + (size_t)i * nz + z] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < LK_U; ++u) { const int idx = base + u * nthr; if (idx < np * nzp) AB[(idx / nzp) * lda + idx % nzp] = v[u]; }
-  }
-  for (int base = tid; base < mp * np; base += nthr * LK_U) {
-    double v[LK_U];
-#pragma unroll
-    for (int u = 0; u < LK_U; ++u) {
-      const int idx = base + u * nthr, l = idx / np, j = idx % np;
-      v[u] = (idx < mp * np && l < m && j < n) ? g[L.oK + l * n + j] : 0.0;
+    for (int u = 0; u < NK; ++u) {
+      const int idx = tid + u * nthr, l = qdiv(idx, S.mg_np), j = (idx - qdiv(idx, S.mg_np) * np);
+      pkm[u] = (idx < mp * np && l < m && j < n) ? g[L.oK + l * n + j] : 0.0;
     }
+    // threads 0..mp-1: k ; 64..99: T6 ; 128..128+np-1: mx
+    psm = (tid < mp) ? ((tid < m) ? g[L.ok + tid] : 0.0) : ((tid >= 64 && tid < 100) ? g[L.oT6 + tid - 64] : ((tid >= 128 && tid < 128 + n) ? g[L.omx + tid - 128] : 0.0));
+    pact = (tid < c) ? kn[L.oACT + tid] : 0.0;  // c <= LK_THREADS (checked by the host)
+  };
+  auto request_pt = [&](int k) {  // Pt, Mu, Znu
+    const double* g = gain_ptr(a, b, k);
 #pragma unroll
-    for (int u = 0; u < LK_U; ++u) { const int idx = base + u * nthr; if (idx < mp * np) KM[idx] = v[u]; }
-  }
-  for (int l = tid; l < mp; l += nthr) kf[l] = (l < m) ? g[L.ok + l] : 0.0;
-  if (tid < 36) t6[tid] = g[L.oT6 + tid];
-  // Pt is requested now and parked in registers: its HBM latency hides behind stage 1
-  double ptv[LK_PT];
-#pragma unroll
-  for (int u = 0; u < LK_PT; ++u) {
-    const int idx = tid + u * nthr, i = idx / np, j = idx % np;
-    ptv[u] = (idx < np * np && i < n && j < n) ? g[L.oMx + i * n + j] : 0.0;
-  }
-  LEG_BARRIER();
-  LK_PROF(0);
-  for (int t = wv; t < nb * nb; t += nw) {
-    const int ri = t / nb, cj = t % nb;
-    double* At = AB + (ri * 16) * lda + cj * 16;
-    d4_t acc = tile_load(At, lda, lane);                                                           // A tile
-    mma_tile<false>(acc, AB + (ri * 16) * lda + np, lda, 1, KM + cj * 16, np, 1, mp, lane);        // + B K (own tile only: in place)
-    tile_store(At, lda, acc, lane);
-  }
-  for (int i = wv; i < np; i += nw) {  // one row per wavefront, lanes over the controls
-    double s = (lane < m) ? AB[i * lda + np + lane] * kf[lane] : 0.0;
-    s = wave_sum(s);
-    if (lane == 0) y0[i] = s + ((i < n) ? g[L.omx + i] : 0.0);
-  }
-  if (tid < 36) { const int i = tid / 6, j = tid % 6; double s = 0; for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * t6[j * 6 + l]; g6[tid] = s; }
-  LEG_BARRIER();  // K is dead: Pt takes its place
-  // ---- stage 2: Pt into LDS ; [M | Bl] = (I - mu_d Pt) [A_cl | B] (products to registers, then in place) ; z0 = y0 - mu_d Pt y0 ----
-#pragma unroll
-  for (int u = 0; u < LK_PT; ++u) { const int idx = tid + u * nthr; if (idx < np * np) PT[(idx / np) * ldp + idx % np] = ptv[u]; }
-  LEG_BARRIER();
-  LK_PROF(1);
-  const int nct = par ? nb + nbm : nb;  // the u columns are only needed for the parametric quantities
-  d4_t res[LK_TILES];
-#pragma unroll
-  for (int sidx = 0; sidx < LK_TILES; ++sidx) {
-    const int t = wv + sidx * nw;
-    res[sidx] = d4_t{0, 0, 0, 0};
-    if (t < nb * nct) mma_tile<false>(res[sidx], PT + ((t / nct) * 16) * ldp, ldp, 1, AB + (t % nct) * 16, lda, 1, np, lane);
-  }
-  for (int i = wv; i < n; i += nw) {
-    double s = 0;
-    for (int j = lane; j < n; j += 64) s += PT[i * ldp + j] * y0[j];
-    s = wave_sum(s);
-    if (lane == 0) z0[i] = y0[i] - mud * s;
-  }
-  LEG_BARRIER();
-#pragma unroll
-  for (int sidx = 0; sidx < LK_TILES; ++sidx) {
-    const int t = wv + sidx * nw;
-    if (t < nb * nct) {
-      double* At = AB + ((t / nct) * 16) * lda + (t % nct) * 16;
-      const int row = lane >> 4, col = lane & 15;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) At[(row + 4 * q) * lda + col] -= mud * res[sidx][q];
+    for (int u = 0; u < LK_PT; ++u) {
+      const int idx = tid + u * nthr, i = qdiv(idx, S.mg_np), j = (idx - qdiv(idx, S.mg_np) * np);
+      ptv[u] = (idx < np * np && i < n && j < n) ? g[L.oMx + i * n + j] : 0.0;
     }
-  }
-  LEG_BARRIER();
-  LK_PROF(2);
-  // ---- stage 3: base rows through T6 (rows 0..5 of [M | Bl] -> [Phi | Bc]) ; Phi, phi out ; columns 0..5 of Pt T^T kept for Gamma ----
-  for (int idx = tid; idx < 6 * nzp; idx += nthr) TMP[idx] = AB[(idx / nzp) * lda + idx % nzp];
-  if (par) for (int idx = tid; idx < np * 6; idx += nthr) {  // (Pt T^T)[i][j] = sum_l Pt[i][l] T6[j][l]
-    const int i = idx / 6, j = idx % 6;
-    double s = 0;
-    for (int l = 0; l < 6; ++l) s += PT[i * ldp + l] * t6[j * 6 + l];
-    PT6[idx] = s;
-  }
-  LEG_BARRIER();
-  for (int idx = tid; idx < 6 * nzp; idx += nthr) {
-    const int i = idx / nzp, z = idx % nzp;
-    double s = 0;
-    for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * TMP[l * nzp + z];
-    AB[i * lda + z] = s;
-  }
-  if (par && tid < 36) {  // 6 x 6 corner of T (Pt T^T)
-    const int i = tid / 6, j = tid % 6;
-    double s = 0;
-    for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * PT6[l * 6 + j];
-    c6[tid] = s;
-  }
-  LEG_BARRIER();
-  for (int i = wv; i < n; i += nw)
-    for (int j = lane; j < n; j += 64) g[L.oPhi + i * n + j] = AB[i * lda + j];
-  for (int i = tid; i < n; i += nthr) {
-    double s = z0[i];
-    if (i < 6) { s = 0; for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * z0[l]; }
-    g[L.ophi + i] = s;
-  }
-  LK_PROF(3);
-  if (!par) return;
-  // ---- stage 4: Mu (into PR behind the place of U1: Pt is dead), Znu ; U1 = Mu Bc^T (-> Ku = -U1, kept for stage 5) ; V1 = Znu Bc^T (-> Knup = -V1) ----
-  const int ca = __syncthreads_count(tid < c && kn[L.oACT + (tid < c ? tid : 0)] != 0.0);  // c <= LK_THREADS (checked by the host) ; a barrier: Pt is dead
-  for (int idx = tid; idx < mp * mp; idx += nthr) MU[(idx / mp) * ldm + idx % mp] = g[L.oMu + idx];
-  for (int idx = tid; idx < 16 * mp; idx += nthr) ZN[(idx / mp) * ldm + idx % mp] = (idx / mp < ca && ca <= 16) ? g[L.oZnu + idx] : 0.0;
-  LEG_BARRIER();
-  LK_PROF(4);
-  d4_t ures[2];
+  };
+  auto request_mu = [&](int k) {
+    const double* g = gain_ptr(a, b, k);
 #pragma unroll
-  for (int sidx = 0; sidx < 2; ++sidx) {
-    const int t = wv + sidx * nw;
-    ures[sidx] = d4_t{0, 0, 0, 0};
-    if (t < nbm * nb) mma_tile<false>(ures[sidx], MU + ((t / nb) * 16) * ldm, ldm, 1, AB + ((t % nb) * 16) * lda + np, 1, lda, mp, lane);
-  }
-  if (ca <= 16) {
-    for (int cj = wv; cj < nb; cj += nw) {
-      d4_t acc = d4_t{0, 0, 0, 0};
-      mma_tile<false>(acc, ZN, ldm, 1, AB + (cj * 16) * lda + np, 1, lda, mp, lane);
-      const int col = cj * 16 + (lane & 15);
+    for (int u = 0; u < NMU; ++u) { const int idx = tid + u * nthr; pmu[u] = (idx < mp * mp) ? g[L.oMu + idx] : 0.0; }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const int row = (lane >> 4) + 4 * q; if (row < ca && col < n) g[L.oKnup + row * n + col] = -acc[q]; }
+    for (int u = 0; u < NZN; ++u) { const int idx = tid + u * nthr; pzn[u] = (idx < 16 * mp) ? g[L.oZnu + idx] : 0.0; }
+  };
+
+  request_ab(kbeg);
+  request_pt(kbeg);
+  if (leg_of_knot(a, kbeg) + 1 < a.nlegs) request_mu(kbeg);
+  for (int k = kbeg; k < kend; ++k) {
+    const double* kn = knot_ptr(a, b, k);
+    double* g = gain_ptr(a, b, k);
+    const int m = (int)kn[L.oMISC + MISC_M];
+    const bool par = leg_of_knot(a, k) + 1 < a.nlegs;
+    const bool more = k + 1 < kend, par_next = more && leg_of_knot(a, k + 1) + 1 < a.nlegs;
+    LEG_BARRIER();  // the previous knot of the chunk is done with every buffer
+    LEG_LAUNDER();
+    if (a.prof) tk0_ = clock64();
+    // ---- stage 1: [A B] and K into LDS (zero padded; u-columns of [A B] start at np) ; A_cl = A + B K in place ; y0 = B k + mx ----
+#pragma unroll
+    for (int u = 0; u < NAB; ++u) { const int idx = tid + u * nthr; if (idx < np * nzp) AB[(qdiv(idx, S.mg_nzp)) * lda + (idx - qdiv(idx, S.mg_nzp) * nzp)] = pab[u]; }
+#pragma unroll
+    for (int u = 0; u < NK; ++u) { const int idx = tid + u * nthr; if (idx < mp * np) KM[idx] = pkm[u]; }
+    if (tid < mp) kf[tid] = psm;
+    else if (tid >= 64 && tid < 100) t6[tid - 64] = psm;
+    else if (tid >= 128 && tid < 128 + np) mxs[tid - 128] = psm;
+    int ca = 0;
+    if (par) {
+      const unsigned long long act = __ballot(pact != 0.0);
+      if (lane == 0) cnt[wv] = __popcll(act);
     }
-  } else {
-    for (int idx = tid; idx < ca * n; idx += nthr) {
-      const int i = idx / n, j = idx % n;
+    LEG_BARRIER();
+    if (par) for (int w = 0; w < nw; ++w) ca += cnt[w];
+    LEG_LAUNDER();
+    if (more) request_ab(k + 1);  // lands behind stages 1 - 5
+    LEG_LAUNDER();
+    LK_PROF(0);
+    for (int t = wv; t < nb * nb; t += nw) {
+      const int ri = t / nb, cj = t % nb;
+      double* At = AB + (ri * 16) * lda + cj * 16;
+      d4_t acc = tile_load(At, lda, lane);                                                           // A tile
+      mma_tile<false>(acc, AB + (ri * 16) * lda + np, lda, 1, KM + cj * 16, np, 1, mp, lane);        // + B K (own tile only: in place)
+      tile_store(At, lda, acc, lane);
+    }
+    for (int i = wv; i < np; i += nw) {  // one row per wavefront, lanes over the controls
+      double s = (lane < m) ? AB[i * lda + np + lane] * kf[lane] : 0.0;
+      s = wave_sum(s);
+      if (lane == 0) y0[i] = s + mxs[i];
+    }
+    if (tid < 36) { const int i = tid / 6, j = tid % 6; double s = 0; for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * t6[j * 6 + l]; g6[tid] = s; }
+    LEG_BARRIER();  // K is dead: Pt takes its place
+    LEG_LAUNDER();
+    // ---- stage 2: Pt into LDS ; [M | Bl] = (I - mu_d Pt) [A_cl | B] (products to registers, then in place) ; z0 = y0 - mu_d Pt y0 ----
+#pragma unroll
+    for (int u = 0; u < LK_PT; ++u) { const int idx = tid + u * nthr; if (idx < np * np) PT[(qdiv(idx, S.mg_np)) * ldp + (idx - qdiv(idx, S.mg_np) * np)] = ptv[u]; }
+    LEG_BARRIER();
+    LEG_LAUNDER();
+    if (more) request_pt(k + 1);
+    LEG_LAUNDER();
+    LK_PROF(1);
+    const int nct = par ? nb + nbm : nb;  // the u columns are only needed for the parametric quantities
+    d4_t res[LK_TILES];
+#pragma unroll
+    for (int sidx = 0; sidx < LK_TILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      res[sidx] = d4_t{0, 0, 0, 0};
+      if (t < nb * nct) mma_tile<false>(res[sidx], PT + ((t / nct) * 16) * ldp, ldp, 1, AB + (t % nct) * 16, lda, 1, np, lane);
+    }
+    for (int i = wv; i < n; i += nw) {
       double s = 0;
-      for (int l = 0; l < m; ++l) s += g[L.oZnu + i * mp + l] * AB[j * lda + np + l];
-      g[L.oKnup + idx] = -s;
+      for (int j = lane; j < n; j += 64) s += PT[i * ldp + j] * y0[j];
+      s = wave_sum(s);
+      if (lane == 0) z0[i] = y0[i] - mud * s;
     }
-  }
+    LEG_BARRIER();
 #pragma unroll
-  for (int sidx = 0; sidx < 2; ++sidx) {
-    const int t = wv + sidx * nw;
-    if (t < nbm * nb) {
-      const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+    for (int sidx = 0; sidx < LK_TILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      if (t < nb * nct) {
+        double* At = AB + ((t / nct) * 16) * lda + (t % nct) * 16;
+        const int row = lane >> 4, col = lane & 15;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = ri * 16 + (lane >> 4) + 4 * q;
-        U1[row * np + col] = ures[sidx][q];  // beside Mu (other wavefronts may still read it), not over it
-        if (row < m && col < n) g[L.oKu + row * n + col] = -ures[sidx][q];
+        for (int q = 0; q < 4; ++q) At[(row + 4 * q) * lda + col] -= mud * res[sidx][q];
       }
     }
-  }
-  LEG_BARRIER();
-  LK_PROF(5);
-  // ---- stage 5: Gamma = -Bc U1 - mu_d (T T^T - mu_d T Pt T^T) ; T Pt T^T: rows / columns 0..5 from PT6 / c6 (symmetric), the rest is Pt
-  // itself, read again from the gain record (L2) while the matrix cores work ----
-  for (int t = wv; t < nb * nb; t += nw) {
-    const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
-    double ptt[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = ri * 16 + (lane >> 4) + 4 * q;
-      const bool in = row < n && col < n;
-      ptt[q] = (in && row >= 6 && col >= 6) ? g[L.oMx + row * n + col] : 0.0;
+    LEG_BARRIER();
+    LK_PROF(2);
+    // ---- stage 3: base rows through T6 (rows 0..5 of [M | Bl] -> [Phi | Bc]) ; Phi, phi out ; columns 0..5 of Pt T^T kept for Gamma ----
+    for (int idx = tid; idx < 6 * nzp; idx += nthr) TMP[idx] = AB[(qdiv(idx, S.mg_nzp)) * lda + (idx - qdiv(idx, S.mg_nzp) * nzp)];
+    if (par) for (int idx = tid; idx < np * 6; idx += nthr) {  // (Pt T^T)[i][j] = sum_l Pt[i][l] T6[j][l]
+      const int i = idx / 6, j = idx % 6;
+      double s = 0;
+      for (int l = 0; l < 6; ++l) s += PT[i * ldp + l] * t6[j * 6 + l];
+      PT6[idx] = s;
     }
-    d4_t acc = d4_t{0, 0, 0, 0};
-    mma_tile<false>(acc, AB + (ri * 16) * lda + np, lda, 1, U1 + cj * 16, np, 1, mp, lane);
+    LEG_BARRIER();
+    for (int idx = tid; idx < 6 * nzp; idx += nthr) {
+      const int i = qdiv(idx, S.mg_nzp), z = (idx - qdiv(idx, S.mg_nzp) * nzp);
+      double s = 0;
+      for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * TMP[l * nzp + z];
+      AB[i * lda + z] = s;
+    }
+    if (par && tid < 36) {  // 6 x 6 corner of T (Pt T^T)
+      const int i = tid / 6, j = tid % 6;
+      double s = 0;
+      for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * PT6[l * 6 + j];
+      c6[tid] = s;
+    }
+    LEG_BARRIER();
+    for (int i = wv; i < n; i += nw)
+      for (int j = lane; j < n; j += 64) g[L.oPhi + i * n + j] = AB[i * lda + j];
+    for (int i = tid; i < n; i += nthr) {
+      double s = z0[i];
+      if (i < 6) { s = 0; for (int l = 0; l < 6; ++l) s += t6[i * 6 + l] * z0[l]; }
+      g[L.ophi + i] = s;
+    }
+    LK_PROF(3);
+    LEG_LAUNDER();
+    if (par) {
+      // ---- stage 4: Mu (into PR behind the place of U1: Pt is dead), Znu ; U1 = Mu Bc^T (-> Ku = -U1, kept for stage 5) ; V1 = Znu Bc^T (-> Knup = -V1) ----
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int row = ri * 16 + (lane >> 4) + 4 * q;
-      if (row < n && col < n) {
-        const double tt = (row < 6 && col < 6) ? g6[row * 6 + col] : (row == col ? 1.0 : 0.0);
-        const double tp = (row < 6 && col < 6) ? c6[row * 6 + col] : (col < 6 ? PT6[row * 6 + col] : (row < 6 ? PT6[col * 6 + row] : ptt[q]));
-        g[L.oGam + row * n + col] = -acc[q] - mud * (tt - mud * tp);
+      for (int u = 0; u < NMU; ++u) { const int idx = tid + u * nthr; if (idx < mp * mp) MU[(qdiv(idx, S.mg_mp)) * ldm + (idx - qdiv(idx, S.mg_mp) * mp)] = pmu[u]; }
+#pragma unroll
+      for (int u = 0; u < NZN; ++u) { const int idx = tid + u * nthr; if (idx < 16 * mp) ZN[(qdiv(idx, S.mg_mp)) * ldm + (idx - qdiv(idx, S.mg_mp) * mp)] = (qdiv(idx, S.mg_mp) < ca && ca <= 16) ? pzn[u] : 0.0; }
+      LEG_BARRIER();
+      LEG_LAUNDER();
+      if (par_next) request_mu(k + 1);
+      LEG_LAUNDER();
+      LK_PROF(4);
+      d4_t ures[2];
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const int t = wv + sidx * nw;
+        ures[sidx] = d4_t{0, 0, 0, 0};
+        if (t < nbm * nb) mma_tile<false>(ures[sidx], MU + ((t / nb) * 16) * ldm, ldm, 1, AB + ((t % nb) * 16) * lda + np, 1, lda, mp, lane);
       }
-    }
+      if (ca <= 16) {
+        for (int cj = wv; cj < nb; cj += nw) {
+          d4_t acc = d4_t{0, 0, 0, 0};
+          mma_tile<false>(acc, ZN, ldm, 1, AB + (cj * 16) * lda + np, 1, lda, mp, lane);
+          const int col = cj * 16 + (lane & 15);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int row = (lane >> 4) + 4 * q; if (row < ca && col < n) g[L.oKnup + row * n + col] = -acc[q]; }
+        }
+      } else {
+        for (int idx = tid; idx < ca * n; idx += nthr) {
+          const int i = idx / n, j = idx % n;
+          double s = 0;
+          for (int l = 0; l < m; ++l) s += g[L.oZnu + i * mp + l] * AB[j * lda + np + l];
+          g[L.oKnup + idx] = -s;
+        }
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 2; ++sidx) {
+        const int t = wv + sidx * nw;
+        if (t < nbm * nb) {
+          const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int row = ri * 16 + (lane >> 4) + 4 * q;
+            U1[row * np + col] = ures[sidx][q];  // beside Mu (other wavefronts may still read it), not over it
+            if (row < m && col < n) g[L.oKu + row * n + col] = -ures[sidx][q];
+          }
+        }
+      }
+      LEG_BARRIER();
+      LK_PROF(5);
+      // ---- stage 5: Gamma = -Bc U1 - mu_d (T T^T - mu_d T Pt T^T) ; T Pt T^T: rows / columns 0..5 from PT6 / c6 (symmetric), the rest is Pt
+      // itself, read again from the gain record (L2) while the matrix cores work ----
+      for (int t = wv; t < nb * nb; t += nw) {
+        const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+        double ptt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = ri * 16 + (lane >> 4) + 4 * q;
+          const bool in = row < n && col < n;
+          ptt[q] = (in && row >= 6 && col >= 6) ? g[L.oMx + row * n + col] : 0.0;
+        }
+        d4_t acc = d4_t{0, 0, 0, 0};
+        mma_tile<false>(acc, AB + (ri * 16) * lda + np, lda, 1, U1 + cj * 16, np, 1, mp, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = ri * 16 + (lane >> 4) + 4 * q;
+          if (row < n && col < n) {
+            const double tt = (row < 6 && col < 6) ? g6[row * 6 + col] : (row == col ? 1.0 : 0.0);
+            const double tp = (row < 6 && col < 6) ? c6[row * 6 + col] : (col < 6 ? PT6[row * 6 + col] : (row < 6 ? PT6[col * 6 + row] : ptt[q]));
+            g[L.oGam + row * n + col] = -acc[q] - mud * (tt - mud * tp);
+          }
+        }
+      }
+      LK_PROF(6);
+    } else if (par_next) request_mu(k + 1);
   }
-  LK_PROF(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_leg_condense: grid (nlegs - 1, B), leg j of instance b, backwards over its knots.  Lm (this knot's dp/dtheta) stays in LDS, Sg in the
 // accumulator registers of the matrix cores over the whole leg; Phi and Gamma of the next knot are requested while this one computes.
 // ---------------------------------------------------------------------------------------------------------------------
-struct LcLds { int np, ldp, nb; int LM, BA, BB, vec, total_bytes; };
+struct LcLds { int np, ldp, nb; int LM, BA, BB, vec, total_bytes; unsigned mg_np, mg_ldp; };
 static inline LcLds make_lc_lds(int n) {
   LcLds s;
   s.np = (n + 15) & ~15; s.ldp = s.np + 1; s.nb = s.np / 16;
+  s.mg_np = magic_div(s.np); s.mg_ldp = magic_div(s.ldp);
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
   s.LM = take(s.np * s.ldp); s.BA = take(s.np * s.ldp); s.BB = take(s.np * s.ldp); s.vec = take(3 * s.np + 16);
@@ -271,9 +329,6 @@ static inline LcLds make_lc_lds(int n) {
 #define LC_TILES 4   // nb^2 <= 25 output tiles on 8 wavefronts
 #define LC_STILES 2  // nb (nb + 1) / 2 <= 15 lower-triangle tiles of Sg
 
-// (per-lane index expressions are kept phase-local by passing the lane ids through an empty asm, as in riccati_mfma.h: hoisted out of
-// the knot loop they would be spilled)
-#define LEG_LAUNDER() do { asm volatile("" : "+v"(tid), "+v"(lane)); wv = __builtin_amdgcn_readfirstlane(tid >> 6); } while (0)
 __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds S) {
   const Layout& L = a.L;
   const int j = blockIdx.x, b = blockIdx.y, nthr = blockDim.x, nw = nthr >> 6;
@@ -284,7 +339,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds
   const int ks = leg_start(a, j), ke = leg_start(a, j + 1) - 1;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *LM = sm + S.LM, *BA = sm + S.BA, *BB = sm + S.BB, *sg = sm + S.vec, *phi = sg + np;
-  for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; LM[idx] = (i == c0 && i < n) ? 1.0 : 0.0; }
+  for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = qdiv(idx, S.mg_ldp), c0 = (idx - qdiv(idx, S.mg_ldp) * ldp); LM[idx] = (i == c0 && i < n) ? 1.0 : 0.0; }
   for (int i = tid; i < np; i += nthr) sg[i] = 0.0;
   d4_t sacc[LC_STILES];
   int tri[LC_STILES], tcj[LC_STILES];
@@ -301,7 +356,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds
     const double* gk = gain_ptr(a, b, kk);
 #pragma unroll
     for (int u = 0; u < LK_PT; ++u) {
-      const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
+      const int idx = tid + u * nthr, i = qdiv(idx, S.mg_np), c0 = (idx - qdiv(idx, S.mg_np) * np);
       const bool ok = idx < np * np && i < n && c0 < n;
       const int src = ok ? i * n + c0 : 0;
       pa[u] = gk[L.oPhi + src] * (ok ? 1.0 : 0.0);
@@ -317,7 +372,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds
 #pragma unroll
     for (int u = 0; u < LK_PT; ++u) {
       const int idx = tid + u * nthr;
-      if (idx < np * np) { BA[(idx / np) * ldp + idx % np] = pa[u]; BB[(idx / np) * ldp + idx % np] = pb[u]; }
+      if (idx < np * np) { BA[(qdiv(idx, S.mg_np)) * ldp + (idx - qdiv(idx, S.mg_np) * np)] = pa[u]; BB[(qdiv(idx, S.mg_np)) * ldp + (idx - qdiv(idx, S.mg_np) * np)] = pb[u]; }
     }
     if (tid < np) phi[tid] = (tid < n) ? pphi : 0.0;
     LEG_BARRIER();
@@ -392,10 +447,11 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds
 // state, x_{j+1} = Zx_j x_j + zc_j (Gauss-Jordan with partial pivoting on I - Sg calP, implicit row permutation); then forward over
 // the cuts: cut states (straight into dxs) and co-states theta ; last, the exact feedback gain of knot 0 (controlFeedbacks()[0]).
 // ---------------------------------------------------------------------------------------------------------------------
-struct LxLds { int np, mp, ldp, nb, nbm; int PC, MA, RB, vec, iw, total_bytes; };
+struct LxLds { int np, mp, ldp, nb, nbm; int PC, MA, RB, vec, iw, total_bytes; unsigned mg_np, mg_ldp; };
 static inline LxLds make_lx_lds(int n, int m) {
   LxLds s;
   s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.ldp = s.np + 1; s.nb = s.np / 16; s.nbm = s.mp / 16;
+  s.mg_np = magic_div(s.np); s.mg_ldp = magic_div(s.ldp);
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
   s.PC = take(s.np * s.ldp); s.MA = take(s.np * s.ldp); s.RB = take(s.np * s.ldp); s.vec = take(8 * s.np + 16);
@@ -408,17 +464,18 @@ static inline LxLds make_lx_lds(int n, int m) {
 // optionally transposed; every load of a thread is in flight before the first LDS write (a plain strided loop waits per element).
 // `add`: an LDS matrix of the same shape added on the way (dst = src + add) — may be dst itself.
 template <bool TR>
-DEV void leg_load_mat(double* dst, int ldp, int np, const double* src, int n, int tid, int nthr) {
+DEV void leg_load_mat(double* dst, int ldp, int np, const double* src, int n, int tid, int nthr, unsigned mg_np) {
+  const struct { unsigned mg_np; } S = {mg_np};
   double v[LK_PT];
 #pragma unroll
   for (int u = 0; u < LK_PT; ++u) {
-    const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
+    const int idx = tid + u * nthr, i = qdiv(idx, S.mg_np), c0 = (idx - qdiv(idx, S.mg_np) * np);
     const bool ok = idx < np * np && i < n && c0 < n;
     v[u] = src[ok ? i * n + c0 : 0] * (ok ? 1.0 : 0.0);  // clamped address, mask by multiplication: unconditional loads
   }
 #pragma unroll
   for (int u = 0; u < LK_PT; ++u) {
-    const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
+    const int idx = tid + u * nthr, i = qdiv(idx, S.mg_np), c0 = (idx - qdiv(idx, S.mg_np) * np);
     if (idx < np * np) dst[TR ? c0 * ldp + i : i * ldp + c0] = v[u];
   }
 }
@@ -452,7 +509,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
   // value function at the start of the last leg
   {
     const double* gl = gain_ptr(a, b, leg_start(a, J - 1));
-    leg_load_mat<false>(PC, ldp, np, gl + L.oP, n, tid, nthr);
+    leg_load_mat<false>(PC, ldp, np, gl + L.oP, n, tid, nthr, S.mg_np);
     for (int i = tid; i < np; i += nthr) pc[i] = (i < n) ? gl[L.op + i] : 0.0;
   }
   LEG_BARRIER();
@@ -467,15 +524,15 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       double po[LK_PT];
 #pragma unroll
       for (int u = 0; u < LK_PT; ++u) {
-        const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
+        const int idx = tid + u * nthr, i = qdiv(idx, S.mg_np), c0 = (idx - qdiv(idx, S.mg_np) * np);
         const bool ok = a.leg_guess && idx < np * np && i < n && c0 < n;
         po[u] = lr[L.lcP + (ok ? i * n + c0 : 0)] * (ok ? 1.0 : 0.0);
       }
-      leg_load_mat<false>(MA, ldp, np, lr + L.lSg, n, tid, nthr);
-      leg_load_mat<true>(RB, ldp, np, gs + L.oLm, n, tid, nthr);  // coalesced read, transposed write (odd ld: no conflicts)
+      leg_load_mat<false>(MA, ldp, np, lr + L.lSg, n, tid, nthr, S.mg_np);
+      leg_load_mat<true>(RB, ldp, np, gs + L.oLm, n, tid, nthr, S.mg_np);  // coalesced read, transposed write (odd ld: no conflicts)
 #pragma unroll
       for (int u = 0; u < LK_PT; ++u) {
-        const int idx = tid + u * nthr, i = idx / np, c0 = idx % np;
+        const int idx = tid + u * nthr, i = qdiv(idx, S.mg_np), c0 = (idx - qdiv(idx, S.mg_np) * np);
         if (idx < np * np && i < n && c0 < n) {
           const double pnew = PC[i * ldp + c0], d = pnew - po[u];
           lr[L.lcP + i * n + c0] = pnew; lr[L.ldP + i * n + c0] = d; PC[i * ldp + c0] = d;
@@ -617,7 +674,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
     LEG_PROF(27);
     if (j > 0) {
       // calP_j = P_j + Lm_j D ; calp_j = p_j + Lm_j ev   (RB <- Lm_j)
-      leg_load_mat<false>(RB, ldp, np, gs + L.oLm, n, tid, nthr);
+      leg_load_mat<false>(RB, ldp, np, gs + L.oLm, n, tid, nthr, S.mg_np);
       LEG_BARRIER();
       const int nst = nb * (nb + 1) / 2;
       d4_t pres[LC_STILES];
@@ -675,9 +732,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
       const bool single = leg_start(a, 1) == 1;
       const double* g1 = gain_ptr(a, b, 1);
       LEG_BARRIER();
-      for (int idx = tid; idx < mp * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; RB[idx] = (i < L.m && c0 < n) ? g0[L.oKu + i * n + c0] : 0.0; }
-      if (single) { for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = idx / ldp, c0 = idx % ldp; PC[idx] = (i == c0 && i < n) ? 1.0 : 0.0; } }
-      else leg_load_mat<false>(PC, ldp, np, g1 + L.oLm, n, tid, nthr);
+      for (int idx = tid; idx < mp * ldp; idx += nthr) { const int i = qdiv(idx, S.mg_ldp), c0 = (idx - qdiv(idx, S.mg_ldp) * ldp); RB[idx] = (i < L.m && c0 < n) ? g0[L.oKu + i * n + c0] : 0.0; }
+      if (single) { for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = qdiv(idx, S.mg_ldp), c0 = (idx - qdiv(idx, S.mg_ldp) * ldp); PC[idx] = (i == c0 && i < n) ? 1.0 : 0.0; } }
+      else leg_load_mat<false>(PC, ldp, np, g1 + L.oLm, n, tid, nthr, S.mg_np);
       LEG_BARRIER();
       d4_t kres[2];
 #pragma unroll

@@ -246,7 +246,9 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
@@ -383,7 +385,16 @@ static void launch_pass(mpc_solver* s) {
   if (J > 1) {
     // legs: per-knot closed-loop transitions and parametric terms, condensation of every leg, consensus over the cuts, final
     // affine terms, then the forward sweeps of the legs side by side
-    s->timed(12, "k_closed_loop", [&] { hipLaunchKernelGGL(k_leg_knot, dim3(L.N, L.B), dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk); });
+    s->timed(12, "k_closed_loop", [&] {
+      // knots per workgroup: 1 (measured: with the operands of the next knot prefetched, chunks of 4 .. 25 knots take the same time per
+      // knot — the kernel is bound by its own instruction stream, not by the loads; MPC_LEG_KNOT_CHUNK for experiments)
+      static const int chunk_env = getenv("MPC_LEG_KNOT_CHUNK") ? atoi(getenv("MPC_LEG_KNOT_CHUNK")) : 0;
+      const int chunk = chunk_env > 0 ? chunk_env : 1;
+      const dim3 grid((L.N + chunk - 1) / chunk, L.B);
+      if (s->lk.mp <= 16) hipLaunchKernelGGL(k_leg_knot<16>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
+      else if (s->lk.mp <= 32) hipLaunchKernelGGL(k_leg_knot<32>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
+      else hipLaunchKernelGGL(k_leg_knot<48>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
+    });
     s->timed(13, "k_leg_condense", [&] { hipLaunchKernelGGL(k_leg_condense, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc); });
     s->timed(14, "k_leg_consensus", [&] {
       switch (s->lx.np) {

@@ -47,6 +47,7 @@ struct RicLds {
   int PT, R1, LP, LI, AB, GP, vec, iwork, total_bytes;
   // KKT / value-update workspace carved from R1 once AB is dead
   int Lr, LIr, W, ST, CT, VX, Y, SC, LIs;
+  unsigned mg_mp;  // magic_div(mp)
   int K2;  // legs: W2 (mp x (mp+1)) | VX2 (16 x (mp+1)) of the [I; 0] solve — inside the PT region when it fits (dead during step 6)
 };
 
@@ -94,6 +95,7 @@ static inline RicLds make_ric_lds(int n, int m, int c, int gfull = 1, int st_lds
   s.K2 = s.PT;
   if (s.np * (s.np + 1) < (s.mp + 16) * (s.mp + 1)) s.K2 = take((s.mp + 16) * (s.mp + 1));  // small problems: own space
   s.vec = take(7 * s.nzp + 2 * c + 96 + 80);  // ph ft vv w gh pvec (6 nzp) | dtl kvc (2 c) | e6l wred t6l (92) | gpre (nzp) | d12l (74)
+  s.mg_mp = magic_div(s.mp);
   s.sq = 0; s.nv = 0;  // structured [A B] (set by the caller for whole-body problems, see step 5)
   s.iwork = o;
   s.total_bytes = o * 8 + (c + 72) * 4;
@@ -1000,8 +1002,8 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     if (LEGS && par) {
       const int mpd = L.mpad;  // == mp
       if (small_ca) {
-        for (int idx = tid; idx < mp * mp; idx += nthr) g[L.oMu + idx] = W2[(idx / mp) * ldw2 + idx % mp];
-        for (int idx = tid; idx < ca * mp; idx += nthr) g[L.oZnu + idx] = VX2[(idx / mp) * ldw2 + idx % mp];
+        for (int idx = tid; idx < mp * mp; idx += nthr) { const int i = qdiv(idx, S.mg_mp); g[L.oMu + idx] = W2[i * ldw2 + idx - i * mp]; }
+        for (int idx = tid; idx < ca * mp; idx += nthr) { const int i = qdiv(idx, S.mg_mp); g[L.oZnu + idx] = VX2[i * ldw2 + idx - i * mp]; }
       } else {
         // many active rows (rare): the same solve by the unblocked routines on the L2-resident scratch
         double *W2s = wk + L.wAcl, *V2s = wk + L.wLp;  // m x m, ca x m (both free in this kernel)

@@ -17,17 +17,20 @@ import csv, glob, sys, os
 from collections import defaultdict
 out = sys.argv[1]
 acc = defaultdict(lambda: defaultdict(list))
+grid = defaultdict(list)
 for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f, newline="")):
-        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        kname = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        acc[kname][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        grid[kname].append(float(r["Grid_Size"]) / max(1.0, float(r["Workgroup_Size"])))
 for k in sorted(acc):
-    if not any(s in k for s in ("riccati", "eval_multibody")):
+    if not any(s in k for s in ("riccati", "eval_multibody", "k_leg", "k_duals", "k_forward", "k_lagrangian")):
         continue
-    print(k)
+    print(k, " workgroups per full launch:", int(max(grid[k])))
     for c in sorted(acc[k]):
         v = acc[k][c]
         mx = max(v)
         keep = [x for x in v if x >= 0.9 * mx]
-        print("   %-32s %16.0f  (mean of %d full launches)" % (c, sum(keep) / len(keep), len(keep)))
+        print("   %-32s %16.0f  (mean of %d full launches)  %12.0f per workgroup" % (c, sum(keep) / len(keep), len(keep), sum(keep) / len(keep) / max(grid[k])))
 PY
 find $OUT -name '*counter_collection.csv' -size +1M -delete
