@@ -244,6 +244,11 @@ int mpc_debug_evaluate(mpc_solver* s, const double* xs, const double* us);
  * zero slots. */
 int mpc_profile(mpc_solver* s, int32_t mode);
 int mpc_profile_read(mpc_solver* s, int32_t slot, char* name, int32_t name_cap, int32_t* launches, double* total_ms);
+/* Occupancy table of the kernels one pass of this handle launches (the "LDS / wave occupancy study" of BASELINE.json's kinodynamic
+ * configuration: tools/occupancy_report.py).  Entry idx: info[8] = {threads per workgroup, VGPRs, scratch bytes per lane, static LDS bytes,
+ * dynamic LDS bytes, workgroups one CU can hold (the runtime's occupancy calculator), workgroups per launch, wavefronts per SIMD at
+ * that residency}.  Returns the number of entries (for any idx, also one out of range); the oracle reports zero. */
+int mpc_kernel_info(mpc_solver* s, int32_t idx, char* name, int32_t name_cap, int32_t* info);
 
 #ifdef __cplusplus
 }

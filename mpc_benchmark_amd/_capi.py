@@ -96,6 +96,7 @@ _SIGNATURES = {
     "mpc_debug_evaluate": (C.c_int, [C.c_void_p, _DP, _DP]),
     "mpc_profile": (C.c_int, [C.c_void_p, C.c_int32]),
     "mpc_profile_read": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "mpc_kernel_info": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
@@ -295,6 +296,19 @@ class NativeSolver:
             self._check(self.lib.mpc_profile_read(self._h, i, name, 64, C.byref(cnt), C.byref(ms)), "mpc_profile_read")
             if cnt.value:
                 out[name.value.decode()] = (cnt.value, ms.value, i) if slots else (cnt.value, ms.value)
+        return out
+
+    def kernel_info(self):
+        """-> [(kernel, {threads, vgprs, scratch_bytes, static_lds, dynamic_lds, workgroups_per_cu, workgroups_per_launch,
+        waves_per_simd})] for the kernels one pass of this handle launches (mpc_abi.h, mpc_kernel_info)."""
+        keys = ("threads", "vgprs", "scratch_bytes", "static_lds", "dynamic_lds", "workgroups_per_cu", "workgroups_per_launch", "waves_per_simd")
+        name = C.create_string_buffer(96)
+        info = (C.c_int32 * 8)()
+        n = self._check(self.lib.mpc_kernel_info(self._h, -1, name, 96, info), "mpc_kernel_info")
+        out = []
+        for i in range(n):
+            self._check(self.lib.mpc_kernel_info(self._h, i, name, 96, info), "mpc_kernel_info")
+            out.append((name.value.decode(), dict(zip(keys, [int(v) for v in info]))))
         return out
 
     # -- parity hooks ---------------------------------------------------------------------------

@@ -667,6 +667,60 @@ int mpc_profile(mpc_solver* s, int32_t mode) {
   })
 }
 
+// Occupancy table of the kernels one pass of this handle launches (developer tooling: tools/occupancy_report.py).  For entry idx:
+// info = {threads per workgroup, VGPRs, scratch bytes per lane, static LDS, dynamic LDS, workgroups a CU can hold (the runtime's
+// occupancy calculator for this block size and LDS request), workgroups per launch, wavefronts per SIMD at that residency}.
+// Returns the number of entries.
+int mpc_kernel_info(mpc_solver* s, int32_t idx, char* name, int32_t name_cap, int32_t* info) {
+  if (!s) return -2;
+  try {
+    HIP_OK(hipSetDevice(s->dims.device));
+    const Layout& L = s->L;
+    struct Ent { const char* name; const void* fn; int block; int dyn; long long grid; };
+    std::vector<Ent> e;
+    const int J = s->eff_legs();
+    if (L.space == MPC_SPACE_VECTOR) {
+      e.push_back({"k_eval_vector<0> (stage kernel, value + derivatives)", (const void*)k_eval_vector<0>, 64, 0, (long long)(L.N + 1) * L.B});
+      e.push_back({"k_eval_vector<1> (linesearch candidate)", (const void*)k_eval_vector<1>, 64, 0, (long long)(L.N + 1) * L.B});
+    } else {
+      const MbLds ml = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m, L.nz);
+      e.push_back({"k_eval_multibody<0> (stage kernel, value + derivatives)", (const void*)k_eval_multibody<0>, EVAL_THREADS, ml.total_bytes, (long long)(L.N + 1) * L.B});
+      e.push_back({"k_eval_multibody<3> (alpha = 1 candidate with derivatives)", (const void*)k_eval_multibody<3>, EVAL_THREADS, ml.total_bytes, (long long)(L.N + 1) * L.B});
+      e.push_back({"k_eval_multibody<1> (backtracking candidates, values only)", (const void*)k_eval_multibody<1>, EVAL_THREADS, ml.total_bytes, (long long)(L.N + 1) * L.B});
+    }
+    const bool small = s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS;
+    if (J > 1) {
+      if (small) e.push_back({"k_riccati_mfma<256,16,false,true> (sweep, legs)", (const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>, RIC_SMALL_THREADS, s->ric.total_bytes, (long long)L.B * J});
+      else if (s->ric.sq) e.push_back({"k_riccati_mfma<512,80,true,true> (sweep, legs)", (const void*)k_riccati_mfma<RIC_THREADS, 80, true, true>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
+      else e.push_back({"k_riccati_mfma<512,80,false,true> (sweep, legs)", (const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
+      const void* lk = s->lk.mp <= 16 ? (const void*)k_leg_knot<16> : (s->lk.mp <= 32 ? (const void*)k_leg_knot<32> : (const void*)k_leg_knot<48>);
+      e.push_back({"k_leg_knot", lk, LK_THREADS, s->lk.total_bytes, (long long)L.N * L.B});
+      e.push_back({"k_leg_condense", (const void*)k_leg_condense, LK_THREADS, s->lc.total_bytes, (long long)(J - 1) * L.B});
+      const void* lx = s->lx.np == 16 ? (const void*)k_leg_consensus<16> : s->lx.np == 32 ? (const void*)k_leg_consensus<32> : s->lx.np == 48 ? (const void*)k_leg_consensus<48>
+                     : s->lx.np == 64 ? (const void*)k_leg_consensus<64> : (const void*)k_leg_consensus<80>;
+      e.push_back({"k_leg_consensus", lx, LK_THREADS, s->lx.total_bytes, (long long)L.B});
+      e.push_back({"k_leg_apply", (const void*)k_leg_apply, 256, 0, (long long)L.N * L.B});
+      e.push_back({"k_forward_phi (forward sweeps of the legs)", L.m <= 32 ? (const void*)k_forward_phi<4, 10> : (const void*)k_forward_phi<6, 10>, 512, (int)(2 * L.n * sizeof(double)), (long long)L.B * J});
+    } else if (s->use_mfma_riccati) {
+      const void* fn = small ? (const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16> : (s->ric.sq && s->ric.np <= 80) ? (const void*)k_riccati_mfma<RIC_THREADS, 80, true>
+                     : s->ric.sq ? (const void*)k_riccati_mfma<RIC_THREADS, 96, true> : s->ric.np <= 80 ? (const void*)k_riccati_mfma<RIC_THREADS, 80> : (const void*)k_riccati_mfma<RIC_THREADS, 96>;
+      e.push_back({"k_riccati_mfma (serial sweep)", fn, small ? RIC_SMALL_THREADS : RIC_THREADS, s->ric.total_bytes, (long long)L.B});
+    } else e.push_back({"k_riccati_backward (serial sweep, no matrix cores)", (const void*)k_riccati_backward, 256, (int)s->riccati_lds(), (long long)L.B});
+    e.push_back({"k_duals", (const void*)k_duals, 256, (int)((L.nz + 3 * L.n + 16) * sizeof(double)), (long long)(L.N + 1) * L.B});
+    e.push_back({"k_lagrangian", (const void*)k_lagrangian, 64, 0, (long long)(L.N + 1) * L.B});
+    if (idx < 0 || idx >= (int)e.size()) return (int)e.size();
+    const Ent& k = e[idx];
+    hipFuncAttributes at;
+    HIP_OK(hipFuncGetAttributes(&at, k.fn));
+    int nb = 0;
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k.fn, k.block, (size_t)k.dyn));
+    if (name && name_cap > 0) { strncpy(name, k.name, name_cap - 1); name[name_cap - 1] = 0; }
+    info[0] = k.block; info[1] = at.numRegs; info[2] = (int)at.localSizeBytes; info[3] = (int)at.sharedSizeBytes; info[4] = k.dyn; info[5] = nb;
+    info[6] = (int)k.grid; info[7] = nb * ((k.block + 63) / 64) / 4;
+    return (int)e.size();
+  } catch (const std::exception& ex) { s->err = ex.what(); return -1; }
+}
+
 int mpc_profile_read(mpc_solver* s, int32_t slot, char* name, int32_t name_cap, int32_t* launches, double* total_ms) {
   if (!s) return -2;
   try {

@@ -17,10 +17,10 @@
 #include "solver_kernels.h"
 #include "mfma_blocks.h"
 
-#ifndef RIC_THREADS
 #ifndef RIC_SMALL_THREADS
 #define RIC_SMALL_THREADS 256  // workgroup of the small-problem instantiation (np = mp = 16): 20.5 us / knot (128: 26, 64: 38, 512: 21)
 #endif
+#ifndef RIC_THREADS
 #define RIC_THREADS 512  // 8 wavefronts (2 per SIMD): the sweep is latency-bound, a second wave per SIMD hides LDS / MFMA latency
 #endif
 #if RIC_THREADS <= 256

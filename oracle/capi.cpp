@@ -115,6 +115,7 @@ int mpc_get_x0(mpc_solver* h, double* x0) {
 
 int mpc_profile(mpc_solver*, int32_t) { return 0; }
 int mpc_profile_read(mpc_solver*, int32_t, char*, int32_t, int32_t*, double*) { return 0; }
+int mpc_kernel_info(mpc_solver*, int32_t, char*, int32_t, int32_t*) { return 0; }
 
 int mpc_setup(mpc_solver* h) { MPC_TRY(h, h->s.setup()) }
 
