@@ -40,7 +40,7 @@
 // nv, ks, Ke of the structured products, derived inside the phase that uses them (as scalars living across the whole knot loop they
 // push the SGPR spills past what the spill VGPRs hold, and every reload of those drains the loads in flight)
 #define RIC_SQ_DIMS() int n_l_ = n; asm volatile("" : "+s"(n_l_)); const int nv = SQ ? (n_l_ >> 1) : 0, ks = SQ ? (nv & ~3) : 0, Ke = SQ ? ((n_l_ + 3) & ~3) - ks : np; (void)nv; (void)ks; (void)Ke
-#define RIC_PROF(slot) do { RIC_LAUNDER(); if (tid == 0 && a.prof && !par) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
+#define RIC_PROF(slot) do { RIC_LAUNDER(); if (tid == 0 && a.prof && leg == 0) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 struct RicLds {
   int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb, gfull, st_lds, ovl, sq, nv;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
@@ -613,6 +613,27 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     {
       RIC_SQ_DIMS();
       const int ngt = nb * nzt;
+      // overlap path: the H values of this wavefront's Ruu tile and of its first Sh^T tile are requested now, behind the G products
+      // (both tiles are otherwise the first thing a wavefront does after a barrier: their HBM latency was in the open)
+      double hp_uu[4] = {0, 0, 0, 0}, hp_ux[4] = {0, 0, 0, 0};
+      auto h_request = [&](int zi, int cj, double (&h)[4]) {
+        const int col_p = cj * 16 + (lane & 15);
+        const int zc = (col_p < n) ? col_p : ((col_p >= np && col_p - np < m) ? n + col_p - np : -1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rp = zi * 16 + (lane >> 4) + 4 * q;
+          const int zr = (rp < n) ? rp : ((rp >= np && rp - np < m) ? n + rp - np : -1);
+          h[q] = (zr >= 0 && zc >= 0) ? kn[L.oH + zr * nz + zc] : 0.0;
+        }
+      };
+      if (ovl) {
+        if (wv < nbm * (nbm + 1) / 2) {
+          int ubi = 0, ubj = wv;
+          while (ubj > ubi) { ubj -= ubi + 1; ++ubi; }
+          h_request(nb + ubi, nb + ubj, hp_uu);
+        }
+        if (wv >= 1 && wv - 1 < nbm * nb) h_request(nb + (wv - 1) / nb, (wv - 1) % nb, hp_ux);
+      }
       d4_t gres[RIC_G_TILES];
 #pragma unroll
       for (int sidx = 0; sidx < RIC_G_TILES; ++sidx) {
@@ -644,9 +665,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       __syncthreads();
       const int nht = nzt * (nzt + 1) / 2, nxt = nb * (nb + 1) / 2;
       // one lower-triangle tile (zi, cj) of Hh = H + [A B]^T G
-      auto hh_tile = [&](int t, d4_t& out, int (&zr)[4], int& zc) {
-        int zi = 0, cj = t;
-        while (cj > zi) { cj -= zi + 1; ++zi; }  // t = zi (zi + 1) / 2 + cj, cj <= zi
+      auto hh_tile_at = [&](int zi, int cj, d4_t& out, int (&zr)[4], int& zc, const double* hp) {  // hp: the tile's H values, requested earlier (or null)
         const int col_p = cj * 16 + (lane & 15);
         zc = (col_p < n) ? col_p : ((col_p >= np && col_p - np < m) ? n + col_p - np : -1);
         double h[4];
@@ -654,7 +673,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         for (int q = 0; q < 4; ++q) {  // H loads are in flight while the matrix cores work
           const int rp = zi * 16 + (lane >> 4) + 4 * q;
           zr[q] = (rp < n) ? rp : ((rp >= np && rp - np < m) ? n + rp - np : -1);
-          h[q] = (zr[q] >= 0 && zc >= 0) ? kn[L.oH + zr[q] * nz + zc] : 0.0;
+          h[q] = hp ? hp[q] : ((zr[q] >= 0 && zc >= 0) ? kn[L.oH + zr[q] * nz + zc] : 0.0);
         }
         d4_t acc = d4_t{0, 0, 0, 0};
         if (cj < nb) mma_tile<false>(acc, AB + ks * nzp + zi * 16, 1, nzp, PT + ks * ldp + cj * 16, ldp, 1, Ke, lane);
@@ -673,9 +692,16 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[q] = h[q] + acc[q];
       };
-      auto x_tile = [&](int t) {  // x rows: only the value update of step 7 reads them — to the L2-resident scratch
+      auto hh_tile = [&](int t, d4_t& out, int (&zr)[4], int& zc) {
+        int zi = 0, cj = t;
+        while (cj > zi) { cj -= zi + 1; ++zi; }  // t = zi (zi + 1) / 2 + cj, cj <= zi
+        hh_tile_at(zi, cj, out, zr, zc, nullptr);
+      };
+      auto x_tile = [&](int t, const double* hp = nullptr) {  // x rows: only the value update of step 7 reads them — to the L2-resident scratch
         d4_t hv; int zr[4], zc;
-        hh_tile(t, hv, zr, zc);
+        int zi = 0, cj = t;
+        while (cj > zi) { cj -= zi + 1; ++zi; }
+        hh_tile_at(zi, cj, hv, zr, zc, hp);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (zr[q] >= 0 && zc >= 0) Hh[zr[q] * nz + zc] = hv[q];
@@ -691,12 +717,13 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         // wavefront, ~9 us).  Only its own tiles come first (one per wavefront), Lr sits at the end of the then dead G_u
         // region, and wavefront 0 factorises it WHILE the others multiply the Sh^T and x-row tiles of Hh.
         const int nuu = nbm * (nbm + 1) / 2, nux = nbm * nb, nwx = nw - 1;
+        const int xt0 = (wv - 1 + nwx - nux % nwx) % nwx;  // the x tiles continue the round-robin of the Sh^T tiles: 25 tiles on 7 wavefronts are 4 rounds, not 5
         d4_t uu = d4_t{0, 0, 0, 0};
         int ubi = 0, ubj = wv;  // lower block (ubi, ubj) of Ruu
         while (ubj > ubi) { ubj -= ubi + 1; ++ubi; }
         if (wv < nuu) {
           int zr[4], zc;
-          hh_tile((nb + ubi) * (nb + ubi + 1) / 2 + nb + ubj, uu, zr, zc);
+          hh_tile_at(nb + ubi, nb + ubj, uu, zr, zc, hp_uu);
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             if (zr[q] >= 0 && zc >= 0) Hh[zr[q] * nz + zc] = uu[q];  // kept for the inertia-correction path
@@ -718,13 +745,13 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
             if (e < nux) {
               const int zi = nb + e / nb, cj = e % nb;
               int zr[4], zc;
-              hh_tile(zi * (zi + 1) / 2 + cj, ures[sidx], zr, zc);
+              hh_tile_at(zi, cj, ures[sidx], zr, zc, sidx == 0 ? hp_ux : nullptr);
 #pragma unroll
               for (int q = 0; q < 4; ++q)
                 if (zr[q] >= 0 && zc >= 0) Hh[zr[q] * nz + zc] = ures[sidx][q];
             }
           }
-          for (int t = wv - 1; t < nxt; t += nwx) x_tile(t);
+          for (int t = xt0; t < nxt; t += nwx) x_tile(t);
         }
         __syncthreads();  // [A B] is dead from here on: W = -[Sh^T | rh], ST = Sh^T lie over it
         if (wv > 0) {

@@ -15,8 +15,10 @@ elif "centroidal" in sys.argv[1:]:
     pd = CentroidalProblem(horizon=100)
 else:
     pd = FullDynamicsProblem(horizon=100, complete_model=True)
-ens = EnsembleMPC(pd, batch=4, library=lib, **({'perturb_dofs': range(18, pd.nv), 'seed': 7} if 'kino' in sys.argv[1:] else {}))
-ens.options.riccati_legs = 1  # the serial sweep: one workgroup walks all knots (tools/legs_phase_timers.py times the leg kernels)
+LEGS = int(os.environ.get("PHASE_LEGS", "1"))  # > 1: the workgroup of leg 0 is timed (a parametric leg: N / legs knots per sweep)
+BATCH = int(os.environ.get("PHASE_BATCH", "4"))
+ens = EnsembleMPC(pd, batch=BATCH, library=lib, **({'perturb_dofs': range(18, pd.nv), 'seed': 7} if 'kino' in sys.argv[1:] else {}))
+ens.options.riccati_legs = LEGS  # 1: the serial sweep, one workgroup walks all knots (tools/legs_phase_timers.py times the other leg kernels)
 ens.native.set_options(ens.options)
 ens.prepare_schedule(10)
 ens.cold_solve(100)
@@ -31,7 +33,7 @@ ric = {0: 'T6 inverse, active-row scan', 1: 'T6 similarity transform of P', 2: '
        14: 'series: tile products', 15: 'series: barrier wait', 16: 'series: in-place update', 3: 'chol n (fallback only)',
        5: 'triangular solves (fallback only)', 6: 'AB prefetch issue, w, store Pt', 7: 'AB to LDS, gh', 8: 'G = Pt [A B], Hh = H + [A B]^T G',
        9: 'KKT operands', 10: 'chol m', 11: 'KKT solve (active rows), gains', 12: 'value function, store gain record'}
-knots = 100 * TICKS
+knots = (100 // LEGS) * TICKS
 tot = sum(p[i] for i in ric)
 for i, name in ric.items():
     print('RIC  %-40s %7.1f us/knot %5.1f%%' % (name, p[i] / knots / (GHZ * 1e3), 100 * p[i] / tot))
