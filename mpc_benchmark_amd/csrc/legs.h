@@ -612,7 +612,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_consensus(SolverArgs a, LxLd
           const int ph = __builtin_amdgcn_readlane(second ? 1 : 0, src);
           const int p = src + 64 * ph;
           const double piv = readlane_dyn(ph ? e1 : e0, src);
-          const double inv = 1.0 / piv;
+          double inv = __builtin_amdgcn_rcp(piv);  // v_rcp_f64 + two Newton steps: the IEEE division is ~40 dependent instructions on the critical path of every column
+          inv = inv * (2.0 - piv * inv);
+          inv = inv * (2.0 - piv * inv);
           fb[lane] = (lane == p || lane >= n) ? 0.0 : e0 * inv;
           fb[lane + 64] = (lane + 64 == p || lane + 64 >= n) ? 0.0 : e1 * inv;
           if (lane == 0) { pbuf[col & 1] = p; perm[col] = p; iperm[p] = col; dinv[col] = inv; }

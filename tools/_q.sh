@@ -1,4 +1,4 @@
-python -m pytest tests/test_gpu_legs.py tests/test_gpu_fulldynamic.py -x -q -m gpu 2>&1 | tail -2
+python -m pytest tests -x -q -m gpu 2>&1 | tail -2
 python bench.py --steps 30 --warmup 3 --no-cpu-baseline > /tmp/b.json 2>/dev/null; tail -1 /tmp/b.json | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
