@@ -19,6 +19,9 @@ struct Layout {
   // per (instance, parametric leg j) record: Sg (n x n) | sg | Zx (n x n) | zc | calP (n x n: exact value-function Hessian at the start of
   // leg j + 1 — kept across passes: the terminal cost of leg j in the next pass) | calp | theta | dP (n x n: calP minus the guess the leg carried)
   int lSg, lsg, lZx, lzc, lcP, lcp, lth, ldP, leg_stride;
+  // tree over the cuts (legs_tree.h), per (instance, inner node): condensed form P | Lm | Sg | p | sg of the legs it covers and the maps of
+  // the down-sweep Zx | Zt | F | E | zc | u
+  int tP, tLm, tSg, tZx, tZt, tF, tE, tp, tsg, tzc, tu, tree_stride;
   // backward-sweep scratch per instance
   int wPh, wPt, wLp, wG, wHh, wgh, wCt, wW, wY, wSc, wV, wAcl, wvec, work_stride;
   int max_stage_ints, max_stage_doubles;
@@ -61,6 +64,10 @@ static inline void make_layout(Layout& L) {
   o = 0;
   L.lSg = take(n * n); L.lsg = take(n); L.lZx = take(n * n); L.lzc = take(n); L.lcP = take(n * n); L.lcp = take(n); L.lth = take(n); L.ldP = take(n * n);
   L.leg_stride = o;
+  o = 0;
+  L.tP = take(n * n); L.tLm = take(n * n); L.tSg = take(n * n); L.tZx = take(n * n); L.tZt = take(n * n); L.tF = take(n * n); L.tE = take(n * n);
+  L.tp = take(n); L.tsg = take(n); L.tzc = take(n); L.tu = take(n);
+  L.tree_stride = o;
   o = 0;
   const int nr = n + 1;
   L.wPh = take(n * n); L.wPt = take(n * n); L.wLp = take(n * n); L.wG = take(n * nz); L.wHh = take(nz * nz); L.wgh = take(nz);

@@ -1,0 +1,514 @@
+// legs_tree.h — a TREE over the cuts of the parallel-in-time sweep instead of the chain of k_leg_consensus (legs.h).
+// The chain solves one n x n system per cut, one after the other: with J legs the sweep takes N / J knots and the consensus J - 1
+// solves, which is what bounds the latency of a single instance (batch 1: 8 legs, 0.9 ms of sweep + 0.9 ms of consensus).  Here the
+// condensed forms of adjacent (groups of) legs are composed pairwise, all pairs of a level side by side on their own CUs:
+// ceil(log2 J) rounds.  A node covering legs lo..hi is, like a leg,
+//     lambda_in = P x_in + Lm theta_out + p ,   x_out = Lm^T x_in + Sg theta_out + sg      (theta_out: co-state parameter at its end)
+// and a followed by b, with D = P_b - Pg (Pg = the terminal Hessian the last leg of a carried), W = (I - Sg_a D)^-1:
+//     T1 = W Lm_a^T, T2 = W Sg_a, t3 = W (Sg_a p_b + sg_a)                     (one Gauss-Jordan with 2 n + 1 right-hand sides)
+//     Zt = T2 Lm_b ;  Lm_ab = T1^T Lm_b ;  Sg_ab = Sg_b + Lm_b^T Zt ;  sg_ab = sg_b + Lm_b^T t3
+//     F = D T1 ;  E = D Zt + Lm_b ;  u = D t3 + p_b ;  P_ab = P_a + Lm_a F ;  p_ab = p_a + Lm_a u
+//     x_mid = T1 x_in + Zt theta_out + t3 ;  theta_mid = F x_in + E theta_out + u          (down-sweep: k_leg_tree_down)
+// Same KKT system as the chain and the serial sweep: identical steps up to round-off (oracle/solver.hpp backward_legs_tree,
+// tests/test_oracle_legs.py, tests/test_gpu_legs.py).  The guess of the value-function Hessian at a cut (kept in the leg record for the
+// next pass) is the Hessian of the node that STARTS there, given its own end guess: exact for the nodes that hold the last leg, the
+// others catch up one level per pass (a handle's first pass sweeps depth + 1 times).  The exact feedback gain of knot 0 follows the
+// leftmost path of the tree: d theta / d x_0 = F + E (d theta_out / d x_0).
+#pragma once
+#include "legs.h"
+
+#define MPC_TREE_MAX_NODES (2 * MPC_MAX_LEGS - 1)
+#define MPC_TREE_MAX_LEVELS 6
+struct TreeDesc {
+  int J, nnodes, nlev;
+  int lo[MPC_TREE_MAX_NODES], hi[MPC_TREE_MAX_NODES], left[MPC_TREE_MAX_NODES], right[MPC_TREE_MAX_NODES];
+  int lev_first[MPC_TREE_MAX_LEVELS], lev_cnt[MPC_TREE_MAX_LEVELS];  // inner nodes created by level l: lev_first[l] .. + lev_cnt[l]
+};
+// leaves 0 .. J-1 (the legs), then the inner nodes level by level: adjacent nodes paired, an odd one carried up (oracle: backward_legs_tree)
+static inline TreeDesc make_tree_desc(int J) {
+  TreeDesc T;
+  T.J = J; T.nnodes = J; T.nlev = 0;
+  int level[MPC_MAX_LEGS], cnt = J;
+  for (int j = 0; j < J; ++j) { T.lo[j] = T.hi[j] = j; T.left[j] = T.right[j] = -1; level[j] = j; }
+  while (cnt > 1) {
+    int next[MPC_MAX_LEGS], nn = 0;
+    T.lev_first[T.nlev] = T.nnodes;
+    for (int i = 0; i + 1 < cnt; i += 2) {
+      const int id = T.nnodes++;
+      T.left[id] = level[i]; T.right[id] = level[i + 1]; T.lo[id] = T.lo[level[i]]; T.hi[id] = T.hi[level[i + 1]];
+      next[nn++] = id;
+    }
+    T.lev_cnt[T.nlev] = T.nnodes - T.lev_first[T.nlev];
+    ++T.nlev;
+    if (cnt % 2) next[nn++] = level[cnt - 1];
+    for (int i = 0; i < nn; ++i) level[i] = next[i];
+    cnt = nn;
+  }
+  return T;
+}
+
+DEV double* tree_node_ptr(const SolverArgs& a, int b, int inner) { return a.treebuf + ((size_t)b * (MPC_MAX_LEGS - 1) + inner) * a.L.tree_stride; }
+// condensed form of a node; Lm == nullptr: the node holds the last leg (no end parameter: Lm = Sg = 0, sg = 0)
+struct NodeRef { const double *P, *p, *Lm, *Sg, *sg; };
+DEV NodeRef tree_node_ref(const SolverArgs& a, const TreeDesc& T, int b, int node) {
+  const Layout& L = a.L;
+  NodeRef r;
+  const bool last = T.hi[node] + 1 == T.J;
+  if (node < T.J) {
+    const double* g = gain_ptr(a, b, leg_start(a, node));
+    r.P = g + L.oP; r.p = g + L.op;
+    r.Lm = last ? nullptr : g + L.oLm;
+    const double* lr = last ? nullptr : leg_ptr(a, b, node);
+    r.Sg = last ? nullptr : lr + L.lSg; r.sg = last ? nullptr : lr + L.lsg;
+  } else {
+    const double* t = tree_node_ptr(a, b, node - T.J);
+    r.P = t + L.tP; r.p = t + L.tp;
+    r.Lm = last ? nullptr : t + L.tLm; r.Sg = last ? nullptr : t + L.tSg; r.sg = last ? nullptr : t + L.tsg;
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_leg_compose: grid (nodes of the level, B).  LDS: the three n x n buffers of the consensus kernel (X, Y, Z below).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds S, TreeDesc T, int level) {
+  const Layout& L = a.L;
+  const int b = blockIdx.y, nthr = blockDim.x, nw = nthr >> 6;
+  int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const InstState& st = a.inst[b];
+  if (st.done || st.skip_step) return;
+  const int n = L.n, np = S.np, ldp = S.ldp, nb = S.nb;
+  const int node = T.lev_first[level] + blockIdx.x;
+  const NodeRef A = tree_node_ref(a, T, b, T.left[node]), Bn = tree_node_ref(a, T, b, T.right[node]);
+  double* out = tree_node_ptr(a, b, node - T.J);
+  double* lrc = leg_ptr(a, b, T.hi[T.left[node]]);  // the leg that ends at the cut: its record keeps the guess (lcP) and D (ldP)
+  const bool bpar = Bn.Lm != nullptr;              // b has an end parameter (it does not hold the last leg)
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *X = sm + S.PC, *Y = sm + S.MA, *Z = sm + S.RB, *vec = sm + S.vec;
+  double *pb = vec, *rv = vec + np, *uu = vec + 2 * np, *fcol = vec + 4 * np;  // p_b | right-hand side / t3 | u | 1 / pivots
+  int* perm = (int*)(sm + S.iw);
+  int* used = perm + np;
+  d4_t res[LC_TILES];
+  // ---- X <- Sg_a ; Y <- D = P_b - Pg ; the guess of the next pass (lcP) <- P_b ; ldP <- D ----
+  {
+    double pv[LK_PT], po[LK_PT];
+#pragma unroll
+    for (int u = 0; u < LK_PT; ++u) {
+      const int idx = tid + u * nthr, i = qdiv(idx, S.mg_np), c0 = idx - i * np;
+      const bool ok = idx < np * np && i < n && c0 < n;
+      pv[u] = Bn.P[ok ? i * n + c0 : 0] * (ok ? 1.0 : 0.0);
+      const double pg = lrc[L.lcP + (ok ? i * n + c0 : 0)];
+      po[u] = (ok && a.leg_guess) ? pg : 0.0;
+    }
+    leg_load_mat<false>(X, ldp, np, A.Sg, n, tid, nthr, S.mg_np);
+#pragma unroll
+    for (int u = 0; u < LK_PT; ++u) {
+      const int idx = tid + u * nthr, i = qdiv(idx, S.mg_np), c0 = idx - i * np;
+      if (idx < np * np) {
+        const double d = pv[u] - po[u];
+        Y[i * ldp + c0] = d;
+        if (i < n && c0 < n) { lrc[L.lcP + i * n + c0] = pv[u]; lrc[L.ldP + i * n + c0] = d; }
+      }
+    }
+  }
+  for (int i = tid; i < np; i += nthr) pb[i] = (i < n) ? Bn.p[i] : 0.0;
+  LEG_BARRIER();
+  // ---- rv = Sg_a p_b + sg_a ; Mt = I - Sg_a D (to registers, then into Z) ----
+  for (int i = wv; i < np; i += nw) {
+    double s = 0;
+    for (int c0 = lane; c0 < n; c0 += 64) s += X[i * ldp + c0] * pb[c0];
+    s = wave_sum(s);
+    if (lane == 0) rv[i] = (i < n) ? s + A.sg[i] : 0.0;
+  }
+#pragma unroll
+  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+    const int t = wv + sidx * nw;
+    res[sidx] = d4_t{0, 0, 0, 0};
+    if (t < nb * nb) mma_tile<true>(res[sidx], X + ((t / nb) * 16) * ldp, ldp, 1, Y + (t % nb) * 16, ldp, 1, np, lane);
+  }
+#pragma unroll
+  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+    const int t = wv + sidx * nw;
+    if (t < nb * nb) {
+      const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; Z[row * ldp + col] = res[sidx][q] + (row == col ? 1.0 : 0.0); }  // pad rows: identity
+    }
+  }
+  LEG_BARRIER();  // D in Y is dead
+  LEG_LAUNDER();
+  leg_load_mat<true>(Y, ldp, np, A.Lm, n, tid, nthr, S.mg_np);  // Y <- Lm_a^T
+  LEG_BARRIER();
+  // ---- Gauss-Jordan on [Mt | Lm_a^T | Sg_a | rv] (n rows, 3 n + 1 columns), tableau in registers: as in k_leg_consensus (a lane is a
+  // row, a wavefront owns every 8th column, the owner of the pivot column leaves the elimination factors in LDS, one barrier) ----
+  {
+    constexpr int GJ_SLOTS = (3 * NP + 1 + 7) / 8;
+    double* dinv = fcol;
+    int* iperm = used;
+    double* fbuf = Y;                 // [2][128], double-buffered (Y, Z, X are dead while the tableau is in registers)
+    int* pbuf = (int*)(Y + 256);
+    double tq[2][GJ_SLOTS];
+#pragma unroll
+    for (int sl = 0; sl < GJ_SLOTS; ++sl) {
+      const int cc = 8 * sl + wv;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = lane + 64 * h;
+        double v = 0.0;
+        if (r < NP) v = (cc < n) ? Z[r * ldp + cc] : ((cc < 2 * n) ? Y[r * ldp + (cc - n)] : ((cc < 3 * n) ? X[r * ldp + (cc - 2 * n)] : ((cc == 3 * n) ? rv[r] : 0.0)));
+        tq[h][sl] = v;
+      }
+    }
+    bool used0 = false, used1 = false;
+    LEG_BARRIER();
+#pragma unroll
+    for (int so = 0; so < NP / 8; ++so) {
+      for (int ow = 0; ow < 8; ++ow) {  // nw == 8
+        const int col = 8 * so + ow;
+        if (col >= n) break;
+        double* fb = fbuf + (col & 1) * 128;
+        if (wv == ow) {
+          const double e0 = tq[0][so], e1 = tq[1][so];
+          const double v0 = (lane < n && !used0) ? fabs(e0) : -1.0, v1 = (lane + 64 < n && !used1) ? fabs(e1) : -1.0;
+          const bool second = v1 > v0;
+          const double vl = second ? v1 : v0;
+          const double vmax = wave_max_nonneg(fmax(vl, 0.0));
+          const unsigned long long mk = __ballot(vl == vmax);
+          const int src = __builtin_amdgcn_readfirstlane(mk ? __ffsll((long long)mk) - 1 : 0);
+          const int ph = __builtin_amdgcn_readlane(second ? 1 : 0, src);
+          const int p = src + 64 * ph;
+          const double piv = readlane_dyn(ph ? e1 : e0, src);
+          double inv = __builtin_amdgcn_rcp(piv);
+          inv = inv * (2.0 - piv * inv);
+          inv = inv * (2.0 - piv * inv);
+          fb[lane] = (lane == p || lane >= n) ? 0.0 : e0 * inv;
+          fb[lane + 64] = (lane + 64 == p || lane + 64 >= n) ? 0.0 : e1 * inv;
+          if (lane == 0) { pbuf[col & 1] = p; perm[col] = p; iperm[p] = col; dinv[col] = inv; }
+        }
+        LEG_BARRIER();
+        const int p = __builtin_amdgcn_readfirstlane(pbuf[col & 1]);
+        const double f0 = fb[lane], f1 = fb[lane + 64];
+        if (lane == (p & 63)) { if (p >> 6) used1 = true; else used0 = true; }
+        if (p < 64) {
+#pragma unroll
+          for (int sl = so; sl < GJ_SLOTS; ++sl) { const double pr = readlane_dyn(tq[0][sl], p); tq[0][sl] -= f0 * pr; tq[1][sl] -= f1 * pr; }
+        } else {
+#pragma unroll
+          for (int sl = so; sl < GJ_SLOTS; ++sl) { const double pr = readlane_dyn(tq[1][sl], p - 64); tq[0][sl] -= f0 * pr; tq[1][sl] -= f1 * pr; }
+        }
+      }
+    }
+    LEG_BARRIER();
+    // solution in natural order: T1 -> Y, T2 -> X, t3 -> rv (padding of Y / X keeps what it had in rows / columns >= n: cleared first)
+    for (int idx = tid; idx < np * ldp; idx += nthr) { Y[idx] = 0.0; X[idx] = 0.0; }
+    for (int i = tid; i < np; i += nthr) rv[i] = 0.0;
+    LEG_BARRIER();
+#pragma unroll
+    for (int sl = 0; sl < GJ_SLOTS; ++sl) {
+      const int cc = 8 * sl + wv;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = lane + 64 * h;
+        if (r < n && cc >= n && cc <= 3 * n) {
+          const int u = iperm[r];
+          const double v = tq[h][sl] * dinv[u];
+          if (cc < 2 * n) Y[u * ldp + (cc - n)] = v; else if (cc < 3 * n) X[u * ldp + (cc - 2 * n)] = v; else rv[u] = v;
+        }
+      }
+    }
+    LEG_BARRIER();
+  }
+  LEG_LAUNDER();
+  // T1 (= Zx of the down-sweep), t3 out
+  for (int i = wv; i < n; i += nw) for (int c0 = lane; c0 < n; c0 += 64) out[L.tZx + i * n + c0] = Y[i * ldp + c0];
+  for (int i = tid; i < n; i += nthr) out[L.tzc + i] = rv[i];
+  // ---- Z <- Lm_b ; Zt = T2 Lm_b (out, then over T2 in X) ; Lm_ab = T1^T Lm_b (out) ----
+  if (bpar) leg_load_mat<false>(Z, ldp, np, Bn.Lm, n, tid, nthr, S.mg_np);
+  else for (int idx = tid; idx < np * ldp; idx += nthr) Z[idx] = 0.0;
+  LEG_BARRIER();
+  d4_t res2[LC_TILES];
+#pragma unroll
+  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+    const int t = wv + sidx * nw;
+    res[sidx] = d4_t{0, 0, 0, 0}; res2[sidx] = d4_t{0, 0, 0, 0};
+    if (bpar && t < nb * nb) {
+      mma_tile<false>(res[sidx], X + ((t / nb) * 16) * ldp, ldp, 1, Z + (t % nb) * 16, ldp, 1, np, lane);
+      mma_tile<false>(res2[sidx], Y + (t / nb) * 16, 1, ldp, Z + (t % nb) * 16, ldp, 1, np, lane);  // T1^T: rows of the product are columns of Y
+    }
+  }
+  LEG_BARRIER();
+#pragma unroll
+  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+    const int t = wv + sidx * nw;
+    if (t < nb * nb) {
+      const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+      tile_store(X + (ri * 16) * ldp + cj * 16, ldp, res[sidx], lane);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = ri * 16 + (lane >> 4) + 4 * q;
+        if (row < n && col < n) { out[L.tZt + row * n + col] = res[sidx][q]; out[L.tLm + row * n + col] = res2[sidx][q]; }
+      }
+    }
+  }
+  LEG_BARRIER();
+  // ---- Sg_ab = Sg_b + Lm_b^T Zt (lower block triangle, mirrored) ; sg_ab = sg_b + Lm_b^T t3 ----
+  {
+    const int nst = nb * (nb + 1) / 2;
+#pragma unroll
+    for (int sidx = 0; sidx < LC_STILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      if (t < nst) {
+        int ri = 0, rem = t;
+        while (rem > ri) { rem -= ri + 1; ++ri; }
+        const int col = rem * 16 + (lane & 15);
+        d4_t acc = d4_t{0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; acc[q] = (bpar && row < n && col < n) ? Bn.Sg[row * n + col] : 0.0; }
+        if (bpar) mma_tile<false>(acc, Z + ri * 16, 1, ldp, X + rem * 16, ldp, 1, np, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = ri * 16 + (lane >> 4) + 4 * q;
+          if (row < n && col < n) { out[L.tSg + row * n + col] = acc[q]; if (ri != rem) out[L.tSg + col * n + row] = acc[q]; }
+        }
+      }
+    }
+    for (int i = wv; i < n; i += nw) {  // (Lm_b^T t3)_i = sum_l Lm_b[l][i] t3[l]: lanes over l
+      double s = 0;
+      for (int l = lane; l < n; l += 64) s += Z[l * ldp + i] * rv[l];
+      s = wave_sum(s);
+      if (lane == 0) out[L.tsg + i] = s + (bpar ? Bn.sg[i] : 0.0);
+    }
+  }
+  __syncthreads();  // ldP (written above by other threads) is read back below ; Z, rows of X / Y: all reads done
+  LEG_LAUNDER();
+  // ---- Z <- D ; F = D T1 (out, then over T1 in Y) ; E = D Zt + Lm_b (out) ; u = D t3 + p_b ----
+  leg_load_mat<false>(Z, ldp, np, lrc + L.ldP, n, tid, nthr, S.mg_np);
+  LEG_BARRIER();
+#pragma unroll
+  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+    const int t = wv + sidx * nw;
+    res[sidx] = d4_t{0, 0, 0, 0}; res2[sidx] = d4_t{0, 0, 0, 0};
+    if (t < nb * nb) {
+      const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; res2[sidx][q] = (bpar && row < n && col < n) ? Bn.Lm[row * n + col] : 0.0; }
+      mma_tile<false>(res[sidx], Z + (ri * 16) * ldp, ldp, 1, Y + cj * 16, ldp, 1, np, lane);
+      if (bpar) mma_tile<false>(res2[sidx], Z + (ri * 16) * ldp, ldp, 1, X + cj * 16, ldp, 1, np, lane);
+    }
+  }
+  for (int i = wv; i < np; i += nw) {
+    double s = 0;
+    for (int c0 = lane; c0 < n; c0 += 64) s += Z[i * ldp + c0] * rv[c0];
+    s = wave_sum(s);
+    if (lane == 0) { uu[i] = (i < n) ? s + pb[i] : 0.0; if (i < n) out[L.tu + i] = uu[i]; }
+  }
+  LEG_BARRIER();
+#pragma unroll
+  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+    const int t = wv + sidx * nw;
+    if (t < nb * nb) {
+      const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+      tile_store(Y + (ri * 16) * ldp + cj * 16, ldp, res[sidx], lane);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = ri * 16 + (lane >> 4) + 4 * q;
+        if (row < n && col < n) { out[L.tF + row * n + col] = res[sidx][q]; out[L.tE + row * n + col] = res2[sidx][q]; }
+      }
+    }
+  }
+  LEG_LAUNDER();
+  // ---- Z <- Lm_a ; P_ab = P_a + Lm_a F (lower block triangle, mirrored, diagonal tiles symmetrised through X) ; p_ab = p_a + Lm_a u ----
+  leg_load_mat<false>(Z, ldp, np, A.Lm, n, tid, nthr, S.mg_np);
+  LEG_BARRIER();
+  {
+    const int nst = nb * (nb + 1) / 2;
+    d4_t pres[LC_STILES];
+#pragma unroll
+    for (int sidx = 0; sidx < LC_STILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      pres[sidx] = d4_t{0, 0, 0, 0};
+      if (t < nst) {
+        int ri = 0, rem = t;
+        while (rem > ri) { rem -= ri + 1; ++ri; }
+        const int col = rem * 16 + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; pres[sidx][q] = (row < n && col < n) ? A.P[row * n + col] : 0.0; }
+        mma_tile<false>(pres[sidx], Z + (ri * 16) * ldp, ldp, 1, Y + rem * 16, ldp, 1, np, lane);
+      }
+    }
+    for (int i = wv; i < n; i += nw) {
+      double s = 0;
+      for (int c0 = lane; c0 < n; c0 += 64) s += Z[i * ldp + c0] * uu[c0];
+      s = wave_sum(s);
+      if (lane == 0) out[L.tp + i] = s + A.p[i];
+    }
+#pragma unroll
+    for (int sidx = 0; sidx < LC_STILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      if (t < nst) {
+        int ri = 0, rem = t;
+        while (rem > ri) { rem -= ri + 1; ++ri; }
+        const int col = rem * 16 + (lane & 15);
+        if (ri == rem) {  // diagonal tile: 0.5 (a + a^T) through its own place in X (X is dead: every tile writes and reads its own block only)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; X[row * ldp + col] = pres[sidx][q]; }
+          __builtin_amdgcn_wave_barrier();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; pres[sidx][q] = 0.5 * (pres[sidx][q] + X[col * ldp + row]); }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int row = ri * 16 + (lane >> 4) + 4 * q;
+          if (row < n && col < n) { out[L.tP + row * n + col] = pres[sidx][q]; if (ri != rem) out[L.tP + col * n + row] = pres[sidx][q]; }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_leg_tree_down: grid B.  Top-down over the inner nodes (a parent has a higher index than its children): state at the cut between the
+// children and the co-state parameter of the left child, x_mid = Zx x_in + Zt theta_out + zc, theta_mid = F x_in + E theta_out + u —
+// four mat-vecs of one phase, the rows dealt to the wavefronts with all their loads in flight.  Cut states go straight into dxs, theta
+// into the leg records (what k_leg_apply and the forward sweeps of the legs read).  Then the exact feedback gain of knot 0 along the
+// leftmost path: S = d theta_out / d x_0 of the left child = F + E S_parent ; K_0 += Ku_0 Lm_1 S (as k_leg_consensus).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ void __launch_bounds__(LK_THREADS) k_leg_tree_down(SolverArgs a, LxLds S, TreeDesc T) {
+  const Layout& L = a.L;
+  const int b = blockIdx.x, nthr = blockDim.x, nw = nthr >> 6;
+  int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const InstState& st = a.inst[b];
+  if (st.done || st.skip_step) return;
+  const int n = L.n, N = L.N, np = S.np, mp = S.mp, ldp = S.ldp, nb = S.nb, nbm = S.nbm;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double *PC = sm + S.PC, *MA = sm + S.MA, *RB = sm + S.RB;
+  // per INNER node: state at its start, co-state parameter at its end (2 x 15 x np doubles over the three contiguous matrix buffers)
+  double* XIN = PC;
+  double* THO = PC + (MPC_MAX_LEGS - 1) * np;
+  const int root = T.nnodes - 1, J = T.J;
+  for (int i = tid; i < np; i += nthr) { XIN[(root - J) * np + i] = 0.0; THO[(root - J) * np + i] = 0.0; }  // x_0 = 0 (forced initial condition) ; no end parameter
+  LEG_BARRIER();
+  constexpr int FW_ROWS = NP / 8;
+  const int c0 = lane < n ? lane : 0, c1 = lane + 64 < n ? lane + 64 : 0;
+  const double m0 = lane < n ? 1.0 : 0.0, m1 = lane + 64 < n ? 1.0 : 0.0;
+  for (int node = root; node >= T.J; --node) {
+    LEG_LAUNDER();
+    const double* t = tree_node_ptr(a, b, node - T.J);
+    const int lc = T.left[node], rc = T.right[node], cutleg = T.lo[rc];
+    const double* xin = XIN + (node - J) * np;
+    const double* tho = THO + (node - J) * np;
+    const bool has_x = T.lo[node] > 0;            // x_in = 0 on the leftmost path
+    const bool has_t = T.hi[node] + 1 < T.J;      // no end parameter on the rightmost path
+    const double x0 = xin[c0] * m0, x1 = xin[c1] * m1, t0 = tho[c0] * m0, t1 = tho[c1] * m1;
+    double xm[FW_ROWS], tm[FW_ROWS];
+    double va[FW_ROWS][2], vb[FW_ROWS][2];
+    // x part: Zx x_in, F x_in
+#pragma unroll
+    for (int i = 0; i < FW_ROWS; ++i) { xm[i] = 0.0; tm[i] = 0.0; }
+    if (has_x) {
+#pragma unroll
+      for (int i = 0; i < FW_ROWS; ++i) {
+        const int r = wv + i * nw, rr = r < n ? r : 0;
+        va[i][0] = t[L.tZx + rr * n + c0]; va[i][1] = t[L.tZx + rr * n + c1]; vb[i][0] = t[L.tF + rr * n + c0]; vb[i][1] = t[L.tF + rr * n + c1];
+      }
+#pragma unroll
+      for (int i = 0; i < FW_ROWS; ++i) { xm[i] += wave_sum(va[i][0] * x0 + va[i][1] * x1); tm[i] += wave_sum(vb[i][0] * x0 + vb[i][1] * x1); }
+    }
+    if (has_t) {
+#pragma unroll
+      for (int i = 0; i < FW_ROWS; ++i) {
+        const int r = wv + i * nw, rr = r < n ? r : 0;
+        va[i][0] = t[L.tZt + rr * n + c0]; va[i][1] = t[L.tZt + rr * n + c1]; vb[i][0] = t[L.tE + rr * n + c0]; vb[i][1] = t[L.tE + rr * n + c1];
+      }
+#pragma unroll
+      for (int i = 0; i < FW_ROWS; ++i) { xm[i] += wave_sum(va[i][0] * t0 + va[i][1] * t1); tm[i] += wave_sum(vb[i][0] * t0 + vb[i][1] * t1); }
+    }
+    double* lr = leg_ptr(a, b, cutleg - 1);
+    const int cut = leg_start(a, cutleg);
+#pragma unroll
+    for (int i = 0; i < FW_ROWS; ++i) {
+      const int r = wv + i * nw;
+      if (lane == 0 && r < n) {
+        const double xv = xm[i] + t[L.tzc + r], tv = tm[i] + t[L.tu + r];
+        a.dxs[((size_t)b * (N + 1) + cut) * n + r] = xv;
+        lr[L.lth + r] = tv;
+        if (rc >= J) { XIN[(rc - J) * np + r] = xv; THO[(rc - J) * np + r] = tho[r]; }
+        if (lc >= J) { XIN[(lc - J) * np + r] = xin[r]; THO[(lc - J) * np + r] = tv; }
+      }
+    }
+    LEG_BARRIER();
+  }
+  // ---- exact K_0: S = d theta_1 / d x_0 along the leftmost path (PC <- S), then K_0 += (Ku_0 Lm_1) S ----
+  LEG_LAUNDER();
+  d4_t res[LC_TILES];
+  bool first = true;
+  for (int node = root; node >= T.J; node = T.left[node]) {
+    const double* t = tree_node_ptr(a, b, node - T.J);
+    if (first) {  // S_parent = 0: S = F
+      LEG_BARRIER();
+      leg_load_mat<false>(PC, ldp, np, t + L.tF, n, tid, nthr, S.mg_np);
+      LEG_BARRIER();
+      first = false;
+    } else {      // S = F + E S_parent
+      leg_load_mat<false>(MA, ldp, np, t + L.tE, n, tid, nthr, S.mg_np);
+      LEG_BARRIER();
+#pragma unroll
+      for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+        const int tt = wv + sidx * nw;
+        res[sidx] = d4_t{0, 0, 0, 0};
+        if (tt < nb * nb) {
+          const int ri = tt / nb, cj = tt % nb, col = cj * 16 + (lane & 15);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; res[sidx][q] = (row < n && col < n) ? t[L.tF + row * n + col] : 0.0; }
+          mma_tile<false>(res[sidx], MA + (ri * 16) * ldp, ldp, 1, PC + cj * 16, ldp, 1, np, lane);
+        }
+      }
+      LEG_BARRIER();
+#pragma unroll
+      for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+        const int tt = wv + sidx * nw;
+        if (tt < nb * nb) tile_store(PC + ((tt / nb) * 16) * ldp + (tt % nb) * 16, ldp, res[sidx], lane);
+      }
+      LEG_BARRIER();
+    }
+    if (T.left[node] < T.J) break;  // the left child is leg 0: S is d theta_1 / d x_0
+  }
+  {
+    double* g0 = gain_ptr(a, b, 0);
+    const bool single = leg_start(a, 1) == 1;
+    const double* g1 = gain_ptr(a, b, 1);
+    LEG_BARRIER();
+    for (int idx = tid; idx < mp * ldp; idx += nthr) { const int i = qdiv(idx, S.mg_ldp), cc = idx - i * ldp; RB[idx] = (i < L.m && cc < n) ? g0[L.oKu + i * n + cc] : 0.0; }
+    if (single) { for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = qdiv(idx, S.mg_ldp), cc = idx - i * ldp; MA[idx] = (i == cc && i < n) ? 1.0 : 0.0; } }
+    else leg_load_mat<false>(MA, ldp, np, g1 + L.oLm, n, tid, nthr, S.mg_np);
+    LEG_BARRIER();
+    d4_t kres[2];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const int tt = wv + sidx * nw;
+      kres[sidx] = d4_t{0, 0, 0, 0};
+      if (tt < nbm * nb) mma_tile<false>(kres[sidx], RB + ((tt / nb) * 16) * ldp, ldp, 1, MA + (tt % nb) * 16, ldp, 1, np, lane);
+    }
+    LEG_BARRIER();
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const int tt = wv + sidx * nw;
+      if (tt < nbm * nb) tile_store(RB + ((tt / nb) * 16) * ldp + (tt % nb) * 16, ldp, kres[sidx], lane);
+    }
+    LEG_BARRIER();
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const int tt = wv + sidx * nw;
+      if (tt < nbm * nb) {
+        d4_t acc = d4_t{0, 0, 0, 0};
+        mma_tile<false>(acc, RB + ((tt / nb) * 16) * ldp, ldp, 1, PC + (tt % nb) * 16, ldp, 1, np, lane);
+        const int col = (tt % nb) * 16 + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = (tt / nb) * 16 + (lane >> 4) + 4 * q; if (row < L.m && col < n) g0[L.oK + row * n + col] += acc[q]; }
+      }
+    }
+  }
+}

@@ -16,6 +16,7 @@
 #include "riccati_mfma.h"
 #include "closed_loop.h"
 #include "legs.h"
+#include "legs_tree.h"
 
 #define HIP_OK(expr)                                                                                  \
   do {                                                                                                \
@@ -78,6 +79,16 @@ struct mpc_solver {
   LxLds lx{};
   bool legs_ok = false;  // the dimensions fit the leg kernels (np <= 80, mp <= 32, LDS carve-outs)
   double* d_legbuf = nullptr;
+  double* d_treebuf = nullptr;
+  TreeDesc tree{};       // tree over the cuts for the current number of legs (legs_tree.h)
+  // more than 8 legs: the cuts are resolved by a tree of pairwise compositions instead of the chain of k_leg_consensus (legs_tree.h;
+  // the oracle follows the same rule) ; MPC_LEGS_TREE=1 forces the tree for any number of legs (tests)
+  bool use_tree() const {
+    const char* fe = getenv("MPC_LEGS_TREE");
+    const bool force = fe && atoi(fe) > 0;
+    const int J = eff_legs();
+    return J > 1 && d_treebuf != nullptr && (J > 8 || force);
+  }
   bool leg_guess_valid = false;  // the leg records hold the cut Hessians of an earlier pass (terminal costs of the legs)
   int leg_guess_now = 0;
   int eff_legs() const {
@@ -132,7 +143,7 @@ struct mpc_solver {
     a.spec_on = (tick_reuse && opt.max_iters == 1 && L.space == MPC_SPACE_MULTIBODY) ? 1 : 0;
     a.reuse_on = (a.spec_on && reuse_this_pass) ? 1 : 0;
     a.reuse_k0 = perfect_feedback ? 1 : 0;
-    a.nlegs = eff_legs(); a.legbuf = d_legbuf; a.leg_guess = leg_guess_now;
+    a.nlegs = eff_legs(); a.legbuf = d_legbuf; a.treebuf = d_treebuf; a.leg_guess = leg_guess_now;
     a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = phase_timers ? d_prof : nullptr;
     return a;
   }
@@ -256,6 +267,17 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<64>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     s->d_legbuf = s->alloc<double>(B * (MPC_MAX_LEGS - 1) * (size_t)L.leg_stride);
+    s->d_treebuf = s->alloc<double>(B * (MPC_MAX_LEGS - 1) * (size_t)L.tree_stride);
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<64>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<64>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
   }
   HIP_OK(hipStreamSynchronize(s->stream));
 }
@@ -361,7 +383,10 @@ static void launch_pass(mpc_solver* s) {
   // one found (legs.h) ; MPC_LEGS_PLAIN=1: always one sweep from zero (intermediates comparable with the oracle's)
   const char* plain_env = getenv("MPC_LEGS_PLAIN");
   const bool plain = plain_env && atoi(plain_env) > 0;
-  const int sweeps = (J > 1 && !plain && !s->leg_guess_valid) ? 2 : 1;
+  const bool tree = s->use_tree();
+  if (tree && s->tree.J != J) s->tree = make_tree_desc(J);
+  // (the tree refreshes the guess of a cut from the node that starts there: every cut has seen the true terminal cost after one sweep per level)
+  const int sweeps = (J > 1 && !plain && !s->leg_guess_valid) ? (tree ? s->tree.nlev + 1 : 2) : 1;
   for (int sweep = 0; sweep < sweeps; ++sweep) {
   s->leg_guess_now = (J > 1 && !plain && (s->leg_guess_valid || sweep > 0)) ? 1 : 0;
   a = s->args();
@@ -396,7 +421,21 @@ static void launch_pass(mpc_solver* s) {
       else hipLaunchKernelGGL(k_leg_knot<48>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
     });
     s->timed(13, "k_leg_condense", [&] { hipLaunchKernelGGL(k_leg_condense, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc); });
-    s->timed(14, "k_leg_consensus", [&] {
+    if (tree) s->timed(14, "k_leg_consensus", [&] {
+      const TreeDesc& T = s->tree;
+#define MPC_TREE_LAUNCH(NPV) do { \
+        for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL(k_leg_compose<NPV>, dim3(T.lev_cnt[lev], L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); \
+        if (sweep + 1 == sweeps) hipLaunchKernelGGL(k_leg_tree_down<NPV>, dim3(L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); } while (0)
+      switch (s->lx.np) {
+        case 16: MPC_TREE_LAUNCH(16); break;
+        case 32: MPC_TREE_LAUNCH(32); break;
+        case 48: MPC_TREE_LAUNCH(48); break;
+        case 64: MPC_TREE_LAUNCH(64); break;
+        default: MPC_TREE_LAUNCH(80); break;
+      }
+#undef MPC_TREE_LAUNCH
+    });
+    else s->timed(14, "k_leg_consensus", [&] {
       switch (s->lx.np) {
         case 16: hipLaunchKernelGGL(k_leg_consensus<16>, dim3(L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx); break;
         case 32: hipLaunchKernelGGL(k_leg_consensus<32>, dim3(L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx); break;

@@ -43,6 +43,7 @@ struct SolverArgs {
   int nlegs;
   int leg_guess;   // 1: leg j starts from the Hessian calP_{j+1} its record holds from the previous pass / tick (0: from zero)
   double* legbuf;  // [B][MPC_MAX_LEGS - 1][leg_stride]
+  double* treebuf; // [B][MPC_MAX_LEGS - 1][tree_stride]: inner nodes of the tree over the cuts (legs_tree.h)
 };
 
 // first knot of leg j (leg nlegs - 1 ends with the terminal knot) — the rule of oracle/solver.hpp leg_start

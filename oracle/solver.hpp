@@ -84,6 +84,11 @@ struct Gains {
   std::vector<double> Pt, Mu, Znu;  // parametric knots only: Pt, and the (u,u) / (nu,u) blocks of the inverse stage KKT matrix (what csrc/legs.h builds Gamma, Ku, Knup from)
 };
 
+// node of the tree over the legs (legs lo..hi composed): its condensed form (P, p: value function at its first knot given the guess at its
+// end; Lm, Sg, sg: p = p0 + Lm theta, x_end = Lm^T x + Sg theta + sg) and, for an inner node, what recovers the state and co-state
+// parameter at the cut between its children: x_mid = Zx x_in + Zt theta_out + zc, theta_mid = D x_mid + Lm_right theta_out + p_right
+struct TreeNode { int lo = 0, hi = 0, left = -1, right = -1; std::vector<double> P, p, Lm, Sg, sg, Zx, Zt, zc, D; };
+
 struct Instance {
   std::vector<double> x0;
   std::vector<std::vector<double>> xs, us, vs, lams, vs_e, lams_e;
@@ -95,6 +100,10 @@ struct Instance {
   mpc_stats stats{};
   // parallel-in-time legs, per parametric leg (debug dumps): Zx | zc | calP | calp | theta
   std::vector<std::vector<double>> leg_Zx, leg_zc, leg_calP, leg_calp, leg_theta;
+  // tree consensus (riccati_legs > 8): nodes of the last pass, and the value-function guesses at the cuts kept from pass to pass
+  std::vector<struct TreeNode> tree;
+  std::vector<std::vector<double>> tree_guess;
+  bool tree_guess_valid = false;
 };
 
 struct Solver {
@@ -541,6 +550,143 @@ struct Solver {
     if (J > 1) in.gains[0].K = in.gains[0].Kexact;
   }
 
+  // ---- tree over the cuts (csrc/legs.h, riccati_legs > 8): the chain of backward_legs costs one solve per cut, one after the other;
+  // composing the condensed forms of adjacent (groups of) legs pairwise takes ceil(log2 J) rounds of independent solves.  Same KKT
+  // system: identical steps up to round-off.  The guess of the value-function Hessian at a cut is the Hessian of the node that
+  // starts there, given ITS end guess (exact for the nodes that hold the last leg; the others catch up one tree level per pass).
+  bool use_tree() const { const char* e = std::getenv("MPC_LEGS_TREE"); return nlegs() > 8 || (e && std::atoi(e) > 0 && nlegs() > 1); }
+  static void mm(const std::vector<double>& A, const std::vector<double>& B, std::vector<double>& C, int n, bool ta = false) {  // C = A B (or A^T B)
+    C.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) for (int l = 0; l < n; ++l) { const double a = ta ? A[l * n + i] : A[i * n + l]; if (a == 0.0) continue; for (int j = 0; j < n; ++j) C[i * n + j] += a * B[l * n + j]; }
+  }
+  static void mv(const std::vector<double>& A, const std::vector<double>& x, std::vector<double>& y, int n, bool ta = false) {
+    y.assign(n, 0.0);
+    for (int i = 0; i < n; ++i) for (int l = 0; l < n; ++l) y[i] += (ta ? A[l * n + i] : A[i * n + l]) * x[l];
+  }
+  // a followed by b; pg = the Hessian the last leg of a carried as its terminal cost (or null = zero)
+  void tree_compose(const TreeNode& a, const TreeNode& b, const std::vector<double>* pg, TreeNode& ab) const {
+    const int n = dims.ndx;
+    ab.lo = a.lo; ab.hi = b.hi;
+    ab.D = b.P;
+    if (pg && !pg->empty()) for (size_t i = 0; i < ab.D.size(); ++i) ab.D[i] -= (*pg)[i];
+    // W [Lm_a^T | Sg_a | Sg_a p_b + sg_a],  W = (I - Sg_a D)^-1
+    std::vector<double> Mt, R((size_t)n * (2 * n + 1)), t;
+    mm(a.Sg, ab.D, Mt, n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Mt[i * n + j] = ((i == j) ? 1.0 : 0.0) - Mt[i * n + j];
+    mv(a.Sg, b.p, t, n);
+    for (int i = 0; i < n; ++i) {
+      for (int j = 0; j < n; ++j) { R[i * (2 * n + 1) + j] = a.Lm[j * n + i]; R[i * (2 * n + 1) + n + j] = a.Sg[i * n + j]; }
+      R[i * (2 * n + 1) + 2 * n] = t[i] + a.sg[i];
+    }
+    solve_dense(Mt, n, R, 2 * n + 1);
+    std::vector<double> T1((size_t)n * n), T2((size_t)n * n), t3(n);
+    for (int i = 0; i < n; ++i) { for (int j = 0; j < n; ++j) { T1[i * n + j] = R[i * (2 * n + 1) + j]; T2[i * n + j] = R[i * (2 * n + 1) + n + j]; } t3[i] = R[i * (2 * n + 1) + 2 * n]; }
+    ab.Zx = T1; ab.zc = t3;
+    mm(T2, b.Lm, ab.Zt, n);                                   // Zt = W Sg_a Lm_b
+    std::vector<double> X, Y, u, w;
+    mm(b.Lm, ab.Zt, X, n, true);                              // Sg_ab = Sg_b + Lm_b^T Zt
+    ab.Sg = b.Sg; for (size_t i = 0; i < X.size(); ++i) ab.Sg[i] += X[i];
+    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) { const double v = 0.5 * (ab.Sg[i * n + j] + ab.Sg[j * n + i]); ab.Sg[i * n + j] = ab.Sg[j * n + i] = v; }
+    mv(b.Lm, t3, u, n, true);                                 // sg_ab = sg_b + Lm_b^T t3
+    ab.sg = b.sg; for (int i = 0; i < n; ++i) ab.sg[i] += u[i];
+    mm(T1, b.Lm, ab.Lm, n, true);                             // Lm_ab = T1^T Lm_b  (= Lm_a (I - D Sg_a)^-1 Lm_b)
+    mm(ab.D, T1, X, n); mm(a.Lm, X, Y, n);                    // P_ab = P_a + Lm_a D T1
+    ab.P = a.P; for (size_t i = 0; i < Y.size(); ++i) ab.P[i] += Y[i];
+    for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) { const double v = 0.5 * (ab.P[i * n + j] + ab.P[j * n + i]); ab.P[i * n + j] = ab.P[j * n + i] = v; }
+    mv(ab.D, t3, u, n); for (int i = 0; i < n; ++i) u[i] += b.p[i];  // p_ab = p_a + Lm_a (D t3 + p_b)
+    mv(a.Lm, u, w, n);
+    ab.p = a.p; for (int i = 0; i < n; ++i) ab.p[i] += w[i];
+  }
+  // the sweeps of the legs (as backward_legs), then the tree; the new guesses go to in.tree_guess
+  void backward_legs_tree(Instance& in) const {
+    const int N = dims.horizon, n = dims.ndx, J = nlegs();
+    backward_terminal(in);
+    std::vector<double> zeroP((size_t)n * n, 0.0), zerop(n, 0.0), eye((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) eye[i * n + i] = 1.0;
+    const std::vector<std::vector<double>>& ptil = in.tree_guess;
+#pragma omp parallel for schedule(dynamic) num_threads(opt.num_threads > 0 ? opt.num_threads : 1)
+    for (int j = 0; j < J; ++j) {
+      const int s = leg_start(j), e = (j + 1 < J) ? leg_start(j + 1) - 1 : N - 1;
+      for (int k = e; k >= s; --k) {
+        if (j + 1 == J) knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, nullptr, nullptr, nullptr, in.gains[k]);
+        else if (k == e) knot_backward(in, k, (j + 1 < (int)ptil.size() && !ptil[j + 1].empty()) ? ptil[j + 1] : zeroP, zerop, &eye, &zeroP, &zerop, in.gains[k]);
+        else knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, &in.gains[k + 1].Lm, &in.gains[k + 1].Sg, &in.gains[k + 1].sg, in.gains[k]);
+      }
+    }
+    std::vector<TreeNode>& T = in.tree;
+    T.clear();
+    std::vector<int> level;
+    for (int j = 0; j < J; ++j) {
+      const Gains& g = in.gains[leg_start(j)];
+      TreeNode nd; nd.lo = nd.hi = j; nd.P = g.P; nd.p = g.p;
+      if (j + 1 < J) { nd.Lm = g.Lm; nd.Sg = g.Sg; nd.sg = g.sg; } else { nd.Lm = zeroP; nd.Sg = zeroP; nd.sg = zerop; }
+      T.push_back(nd); level.push_back(j);
+    }
+    while (level.size() > 1) {
+      std::vector<int> next;
+      for (size_t i = 0; i + 1 < level.size(); i += 2) {
+        TreeNode ab;
+        const int cut = T[level[i + 1]].lo;
+        tree_compose(T[level[i]], T[level[i + 1]], cut < (int)ptil.size() ? &ptil[cut] : nullptr, ab);
+        ab.left = level[i]; ab.right = level[i + 1];
+        T.push_back(ab); next.push_back((int)T.size() - 1);
+      }
+      if (level.size() % 2) next.push_back(level.back());
+      level.swap(next);
+    }
+    // guesses of the next pass: the Hessian of the node that starts at the cut
+    std::vector<std::vector<double>> ng(J);
+    for (const TreeNode& nd : T) if (nd.right >= 0) ng[T[nd.right].lo] = T[nd.right].P;
+    in.tree_guess.swap(ng);
+    for (int k = 0; k < N; ++k) in.gains[k].Kexact = in.gains[k].K;
+  }
+  // cut states and co-state parameters by the down-sweep, the exact gain of knot 0 along the leftmost path; then as forward_legs
+  void forward_legs_tree(Instance& in) const {
+    const int n = dims.ndx, J = nlegs();
+    std::fill(in.dxs[0].begin(), in.dxs[0].end(), 0.0);
+    std::fill(in.dlams[0].begin(), in.dlams[0].end(), 0.0);
+    std::vector<std::vector<double>> ths(J, std::vector<double>(n, 0.0));
+    const std::vector<TreeNode>& T = in.tree;
+    struct Item { int node; std::vector<double> xin, thout; };
+    std::vector<Item> stack;
+    stack.push_back({(int)T.size() - 1, in.dxs[0], std::vector<double>(n, 0.0)});
+    while (!stack.empty()) {
+      Item it = stack.back(); stack.pop_back();
+      const TreeNode& nd = T[it.node];
+      if (nd.right < 0) continue;
+      const TreeNode& b = T[nd.right];
+      std::vector<double> xm(nd.zc), thm(b.p), t;
+      mv(nd.Zx, it.xin, t, n); for (int i = 0; i < n; ++i) xm[i] += t[i];
+      mv(nd.Zt, it.thout, t, n); for (int i = 0; i < n; ++i) xm[i] += t[i];
+      mv(nd.D, xm, t, n); for (int i = 0; i < n; ++i) thm[i] += t[i];
+      mv(b.Lm, it.thout, t, n); for (int i = 0; i < n; ++i) thm[i] += t[i];
+      in.dxs[leg_start(b.lo)] = xm; ths[b.lo - 1] = thm;
+      stack.push_back({nd.left, it.xin, thm});
+      stack.push_back({nd.right, xm, it.thout});
+    }
+    // exact K_0 = K_0 + Kth_0 d theta_1 / d x_0: sensitivities along the leftmost path (theta_out of the root is absent)
+    {
+      std::vector<double> S((size_t)n * n, 0.0), X, Y, Z;  // S = d theta_out / d x_0 of the current node
+      int node = (int)T.size() - 1;
+      while (T[node].right >= 0) {
+        const TreeNode& nd = T[node];
+        const TreeNode& b = T[nd.right];
+        mm(nd.Zt, S, X, n); for (size_t i = 0; i < X.size(); ++i) X[i] += nd.Zx[i];     // d x_mid / d x_0
+        mm(nd.D, X, Y, n); mm(b.Lm, S, Z, n); for (size_t i = 0; i < Y.size(); ++i) Y[i] += Z[i];  // d theta_mid / d x_0
+        S.swap(Y);
+        node = nd.left;
+      }
+      Gains& g0 = in.gains[0];
+      const int m = in.knots[0].m;
+      g0.Kexact = g0.K;
+      for (int i = 0; i < m; ++i) for (int a = 0; a < n; ++a) { double t = 0; for (int l = 0; l < n; ++l) t += g0.Kth[i * n + l] * S[l * n + a]; g0.Kexact[i * n + a] += t; }
+      g0.K = g0.Kexact;
+    }
+    in.leg_Zx.assign(J, {}); in.leg_zc.assign(J, {}); in.leg_calP.assign(J, {}); in.leg_calp.assign(J, {}); in.leg_theta.assign(J, {});
+    for (int j = 0; j + 1 < J; ++j) in.leg_theta[j] = ths[j];
+    forward_legs_apply(in, ths);
+  }
+
   void forward_legs(Instance& in, const std::vector<LegLink>& links) const {
     const int N = dims.horizon, n = dims.ndx, J = nlegs();
     const bool ff = dims.space == MPC_SPACE_MULTIBODY && model.has_freeflyer();
@@ -559,6 +705,12 @@ struct Solver {
       for (int i = 0; i < n; ++i) { double t = lk.calp[i]; for (int a = 0; a < n; ++a) t += lk.calP[i * n + a] * in.dxs[c][a]; ths[j][i] = t; }
       in.leg_Zx[j] = lk.Zx; in.leg_zc[j] = lk.zc; in.leg_calP[j] = lk.calP; in.leg_calp[j] = lk.calp; in.leg_theta[j] = ths[j];
     }
+    forward_legs_apply(in, ths);
+  }
+
+  void forward_legs_apply(Instance& in, const std::vector<std::vector<double>>& ths) const {
+    const int N = dims.horizon, n = dims.ndx, J = nlegs();
+    const bool ff = dims.space == MPC_SPACE_MULTIBODY && model.has_freeflyer();
     // apply (csrc/legs.h k_leg_apply): with theta known, the affine terms of the leg's knots take their final values
     //   p += Lm theta, k += Kth theta, knu += Knuth theta, mx += Mth theta ; the sweeps below are then the plain ones
     for (int j = 0; j + 1 < J; ++j) {
@@ -724,8 +876,19 @@ struct Solver {
       // libraries: the intermediates of the leg kernels are then comparable one to one).
       const char* ep = std::getenv("MPC_LEGS_PLAIN");
       const int passes = (ep && std::atoi(ep) > 0) ? 1 : 2;
+      if (use_tree()) {
+        // the guesses live from pass to pass (as in the HIP library); a pass without any sweeps once per level of the tree so that
+        // every cut has seen a guess derived from the true terminal cost
+        int depth = 0; for (int w = 1; w < nlegs(); w *= 2) ++depth;
+        const int sweeps = (ep && std::atoi(ep) > 0) ? 1 : (in.tree_guess_valid ? 1 : depth + 1);
+        if (ep && std::atoi(ep) > 0) in.tree_guess.clear();
+        for (int pass = 0; pass < sweeps; ++pass) backward_legs_tree(in);
+        in.tree_guess_valid = true;
+        forward_legs_tree(in);
+      } else {
       for (int pass = 0; pass < passes; ++pass) { backward_legs(in, links, ptil, calP); ptil = calP; }
       forward_legs(in, links);
+      }
     } else {
       backward(in);
       forward(in);

@@ -91,9 +91,13 @@ def test_leg_kernels_against_oracle(hip_lib, oracle_lib, kind, N, legs, complete
 
 
 @pytest.mark.parametrize("kind,N,legs,complete", [("fulldynamic", 12, 3, False), ("fulldynamic", 16, 4, True), ("fulldynamic", 10, 10, False),
-                                                  ("centroidal", 30, 7, False), ("kinodynamic", 12, 3, False), ("kinodynamic", 12, 4, True)])
+                                                  ("centroidal", 30, 7, False), ("kinodynamic", 12, 3, False), ("kinodynamic", 12, 4, True),
+                                                  # more than 8 legs: the cuts are resolved by the tree of csrc/legs_tree.h
+                                                  ("fulldynamic", 24, 12, False), ("fulldynamic", 32, 16, True), ("centroidal", 40, 13, False),
+                                                  ("kinodynamic", 20, 10, True)])
 def test_hip_legs_equal_hip_serial(hip_lib, oracle_lib, kind, N, legs, complete):
-    """Default mode (cut-Hessian guess; the first pass of a handle sweeps twice): one iteration from a point far from the solution."""
+    """Default mode (cut-Hessian guess; the first pass of a handle sweeps twice — once per tree level + 1 with more than 8 legs): one
+    iteration from a point far from the solution."""
     _, s1 = _one_iteration(hip_lib, kind, N, 1, complete)
     _, sl = _one_iteration(hip_lib, kind, N, legs, complete)
     _, so = _one_iteration(oracle_lib, kind, N, 1, complete)
@@ -108,10 +112,33 @@ def test_hip_legs_equal_hip_serial(hip_lib, oracle_lib, kind, N, legs, complete)
     assert _rel(np.array(sl.results.us), np.array(s1.results.us)) < 1e-7
 
 
-def test_cold_solve_and_mpc_ticks_with_legs(hip_lib, oracle_lib):
-    """Cold solve + warm-started ticks of the N = 24 full-dynamics OCP with 4 legs: HIP legs vs HIP serial vs the oracle (legs)."""
+@pytest.mark.parametrize("tree_forced", [False, True])
+@pytest.mark.parametrize("kind,N,legs", [("fulldynamic", 15, 3), ("fulldynamic", 14, 5), ("centroidal", 21, 7), ("fulldynamic", 16, 8)])
+def test_tree_over_the_cuts_for_any_number_of_legs(hip_lib, oracle_lib, kind, N, legs, tree_forced, monkeypatch):
+    """MPC_LEGS_TREE=1 resolves the cuts by the tree for any number of legs (odd counts: a node is carried up a level unpaired): same
+    step as the chain consensus and as the serial sweep."""
+    if tree_forced:
+        monkeypatch.setenv("MPC_LEGS_TREE", "1")
+    _, s1 = _one_iteration(hip_lib, kind, N, 1)
+    _, sl = _one_iteration(hip_lib, kind, N, legs)
+    _, so = _one_iteration(oracle_lib, kind, N, legs)  # the oracle follows the same rule (oracle/solver.hpp use_tree)
+    for name in ("dx", "du", "dlams"):
+        for k in range(N + (0 if name == "du" else 1)):
+            tol = 1e-5 if name == "dlams" else 1e-7
+            assert _rel(sl._native.debug_get(name, k), s1._native.debug_get(name, k)) < tol, (name, k)
+            assert _rel(sl._native.debug_get(name, k), so._native.debug_get(name, k)) < tol, (name, k, "oracle")
+    starts = [j * N // legs for j in range(legs)]
+    for j in range(legs - 1):  # co-state parameter at the end of every parametric leg
+        assert _rel(sl._native.debug_get("theta", j), so._native.debug_get("theta", j)) < 1e-6, j
+    assert _rel(sl.results.controlFeedbacks()[0], s1.results.controlFeedbacks()[0]) < 1e-8
+
+
+@pytest.mark.parametrize("legs", [4, 12])
+def test_cold_solve_and_mpc_ticks_with_legs(hip_lib, oracle_lib, legs):
+    """Cold solve + warm-started ticks of the N = 24 full-dynamics OCP with 4 legs (chain over the cuts) and 12 legs (tree): HIP legs vs
+    HIP serial vs the oracle (legs)."""
     out = {}
-    for tag, lib, legs in (("hip_legs", hip_lib, 4), ("hip_serial", hip_lib, 1), ("oracle_legs", oracle_lib, 4)):
+    for tag, lib, legs in (("hip_legs", hip_lib, legs), ("hip_serial", hip_lib, 1), ("oracle_legs", oracle_lib, legs)):
         fp = FullDynamicsProblem(horizon=24)
         prob = fp.build()
         solver = fp.make_solver(_native_library=lib)
@@ -139,16 +166,19 @@ def test_cold_solve_and_mpc_ticks_with_legs(hip_lib, oracle_lib):
             assert _rel(a[0], b[0]) < 1e-6 and _rel(a[1], b[1]) < 1e-6, other
 
 
-def test_full_size_workload_with_legs(hip_lib, oracle_lib):
-    """The benchmark's sizes (N = 100, complete model, 8 legs as the scripts ask: setNumThreads(8)): one iteration from a perturbed
-    trajectory against the serial sweep of the oracle and of the HIP library."""
+@pytest.mark.parametrize("nlegs", [8, 16])
+def test_full_size_workload_with_legs(hip_lib, oracle_lib, nlegs):
+    """The benchmark's sizes (N = 100, complete model, 8 legs as the scripts ask: setNumThreads(8) ; 16 legs: the tree over the cuts):
+    one iteration from a perturbed trajectory against the serial sweep of the oracle and of the HIP library."""
     res = {}
-    for tag, lib, legs in (("hip_legs", hip_lib, 8), ("hip_serial", hip_lib, 1), ("oracle_serial", oracle_lib, 1)):
+    for tag, lib, legs in (("hip_legs", hip_lib, nlegs), ("hip_serial", hip_lib, 1), ("oracle_serial", oracle_lib, 1)):
         fp = FullDynamicsProblem(horizon=100, complete_model=True)
         prob = fp.build(with_terminal_constraint=True)
         solver = fp.make_solver(_native_library=lib)
         if legs == 1:
             solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL
+        else:
+            solver.setNumThreads(legs)
         solver.max_iters = 1
         solver.setup(prob)
         rng = np.random.default_rng(9)
