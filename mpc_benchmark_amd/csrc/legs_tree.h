@@ -69,7 +69,11 @@ DEV NodeRef tree_node_ref(const SolverArgs& a, const TreeDesc& T, int b, int nod
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_leg_compose: grid (nodes of the level, B).  LDS: the three n x n buffers of the consensus kernel (X, Y, Z below).
+// k_leg_compose: grid (nodes of the level, B, 2).  LDS: the three n x n buffers of the consensus kernel (X, Y, Z below).
+// The composition splits into two halves that share nothing but their inputs, one workgroup each (blockIdx.z):
+//   role 0: Gauss-Jordan on [Mt | Lm_a^T | rv] -> T1, t3 ;  Zx, zc, Lm_ab, sg_ab, F, u, P_ab, p_ab
+//   role 1: Gauss-Jordan on [Mt | Sg_a]        -> T2     ;  Zt, Sg_ab, E            (nothing to do when b holds the last leg)
+// (both eliminate the same Mt: the elimination is two thirds of a composition, and its cost is the number of columns a wavefront owns)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NP>
 __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds S, TreeDesc T, int level) {
@@ -84,6 +88,10 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
   double* out = tree_node_ptr(a, b, node - T.J);
   double* lrc = leg_ptr(a, b, T.hi[T.left[node]]);  // the leg that ends at the cut: its record keeps the guess (lcP) and D (ldP)
   const bool bpar = Bn.Lm != nullptr;              // b has an end parameter (it does not hold the last leg)
+  const int role = blockIdx.z;
+  if (role == 1 && !bpar) {  // Zt = 0, Sg_ab = 0, E = 0: never read (the node has no end parameter either)
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *X = sm + S.PC, *Y = sm + S.MA, *Z = sm + S.RB, *vec = sm + S.vec;
   double *pb = vec, *rv = vec + np, *uu = vec + 2 * np, *fcol = vec + 4 * np;  // p_b | right-hand side / t3 | u | 1 / pivots
@@ -108,7 +116,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
       if (idx < np * np) {
         const double d = pv[u] - po[u];
         Y[i * ldp + c0] = d;
-        if (i < n && c0 < n) { lrc[L.lcP + i * n + c0] = pv[u]; lrc[L.ldP + i * n + c0] = d; }
+        if (role == 0 && i < n && c0 < n) { lrc[L.lcP + i * n + c0] = pv[u]; lrc[L.ldP + i * n + c0] = d; }
       }
     }
   }
@@ -136,18 +144,20 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
       for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; Z[row * ldp + col] = res[sidx][q] + (row == col ? 1.0 : 0.0); }  // pad rows: identity
     }
   }
-  LEG_BARRIER();  // D in Y is dead
+  LEG_BARRIER();  // role 0: D in Y is dead (it reads D back from the leg record later) ; role 1 keeps D in Y
   LEG_LAUNDER();
-  leg_load_mat<true>(Y, ldp, np, A.Lm, n, tid, nthr, S.mg_np);  // Y <- Lm_a^T
+  if (role == 0) leg_load_mat<true>(Y, ldp, np, A.Lm, n, tid, nthr, S.mg_np);  // Y <- Lm_a^T
   LEG_BARRIER();
-  // ---- Gauss-Jordan on [Mt | Lm_a^T | Sg_a | rv] (n rows, 3 n + 1 columns), tableau in registers: as in k_leg_consensus (a lane is a
-  // row, a wavefront owns every 8th column, the owner of the pivot column leaves the elimination factors in LDS, one barrier) ----
+  // ---- Gauss-Jordan on [Mt | R | rv] (n rows, 2 n + 1 columns; role 0: R = Lm_a^T in Y, role 1: R = Sg_a in X, no rv), tableau in
+  // registers: as in k_leg_consensus (a lane is a row, a wavefront owns every 8th column, the owner of the pivot column leaves the
+  // elimination factors in LDS, one barrier per column) ----
   {
-    constexpr int GJ_SLOTS = (3 * NP + 1 + 7) / 8;
+    constexpr int GJ_SLOTS = (2 * NP + 1 + 7) / 8;
     double* dinv = fcol;
     int* iperm = used;
-    double* fbuf = Y;                 // [2][128], double-buffered (Y, Z, X are dead while the tableau is in registers)
-    int* pbuf = (int*)(Y + 256);
+    double* fbuf = Z;                 // [2][128], double-buffered: Mt is dead once the tableau is in registers (Y keeps D for role 1)
+    int* pbuf = (int*)(Z + 256);
+    const double* R = role == 0 ? Y : X;
     double tq[2][GJ_SLOTS];
 #pragma unroll
     for (int sl = 0; sl < GJ_SLOTS; ++sl) {
@@ -156,7 +166,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
       for (int h = 0; h < 2; ++h) {
         const int r = lane + 64 * h;
         double v = 0.0;
-        if (r < NP) v = (cc < n) ? Z[r * ldp + cc] : ((cc < 2 * n) ? Y[r * ldp + (cc - n)] : ((cc < 3 * n) ? X[r * ldp + (cc - 2 * n)] : ((cc == 3 * n) ? rv[r] : 0.0)));
+        if (r < NP) v = (cc < n) ? Z[r * ldp + cc] : ((cc < 2 * n) ? R[r * ldp + (cc - n)] : ((cc == 2 * n && role == 0) ? rv[r] : 0.0));
         tq[h][sl] = v;
       }
     }
@@ -200,8 +210,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
       }
     }
     LEG_BARRIER();
-    // solution in natural order: T1 -> Y, T2 -> X, t3 -> rv (padding of Y / X keeps what it had in rows / columns >= n: cleared first)
-    for (int idx = tid; idx < np * ldp; idx += nthr) { Y[idx] = 0.0; X[idx] = 0.0; }
+    // solution in natural order over R (role 0: T1 -> Y, t3 -> rv ; role 1: T2 -> X): rows / columns >= n of the buffer cleared first
+    double* Rw = role == 0 ? Y : X;
+    for (int idx = tid; idx < np * ldp; idx += nthr) Rw[idx] = 0.0;
     for (int i = tid; i < np; i += nthr) rv[i] = 0.0;
     LEG_BARRIER();
 #pragma unroll
@@ -210,53 +221,43 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int r = lane + 64 * h;
-        if (r < n && cc >= n && cc <= 3 * n) {
+        if (r < n && cc >= n && cc <= 2 * n) {
           const int u = iperm[r];
           const double v = tq[h][sl] * dinv[u];
-          if (cc < 2 * n) Y[u * ldp + (cc - n)] = v; else if (cc < 3 * n) X[u * ldp + (cc - 2 * n)] = v; else rv[u] = v;
+          if (cc < 2 * n) Rw[u * ldp + (cc - n)] = v; else if (role == 0) rv[u] = v;
         }
       }
     }
     LEG_BARRIER();
   }
   LEG_LAUNDER();
-  // T1 (= Zx of the down-sweep), t3 out
-  for (int i = wv; i < n; i += nw) for (int c0 = lane; c0 < n; c0 += 64) out[L.tZx + i * n + c0] = Y[i * ldp + c0];
-  for (int i = tid; i < n; i += nthr) out[L.tzc + i] = rv[i];
-  // ---- Z <- Lm_b ; Zt = T2 Lm_b (out, then over T2 in X) ; Lm_ab = T1^T Lm_b (out) ----
+  // Z <- Lm_b (both roles)
   if (bpar) leg_load_mat<false>(Z, ldp, np, Bn.Lm, n, tid, nthr, S.mg_np);
   else for (int idx = tid; idx < np * ldp; idx += nthr) Z[idx] = 0.0;
-  LEG_BARRIER();
-  d4_t res2[LC_TILES];
+  if (role == 1) {
+    // ======== role 1: X = T2, Y = D, Z = Lm_b ;  Zt = T2 Lm_b (out, then over T2) ; Sg_ab = Sg_b + Lm_b^T Zt ; E = D Zt + Lm_b ========
+    LEG_BARRIER();
 #pragma unroll
-  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
-    const int t = wv + sidx * nw;
-    res[sidx] = d4_t{0, 0, 0, 0}; res2[sidx] = d4_t{0, 0, 0, 0};
-    if (bpar && t < nb * nb) {
-      mma_tile<false>(res[sidx], X + ((t / nb) * 16) * ldp, ldp, 1, Z + (t % nb) * 16, ldp, 1, np, lane);
-      mma_tile<false>(res2[sidx], Y + (t / nb) * 16, 1, ldp, Z + (t % nb) * 16, ldp, 1, np, lane);  // T1^T: rows of the product are columns of Y
+    for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      res[sidx] = d4_t{0, 0, 0, 0};
+      if (t < nb * nb) mma_tile<false>(res[sidx], X + ((t / nb) * 16) * ldp, ldp, 1, Z + (t % nb) * 16, ldp, 1, np, lane);
     }
-  }
-  LEG_BARRIER();
+    LEG_BARRIER();
 #pragma unroll
-  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
-    const int t = wv + sidx * nw;
-    if (t < nb * nb) {
-      const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
-      tile_store(X + (ri * 16) * ldp + cj * 16, ldp, res[sidx], lane);
+    for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+      const int t = wv + sidx * nw;
+      if (t < nb * nb) {
+        const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+        tile_store(X + (ri * 16) * ldp + cj * 16, ldp, res[sidx], lane);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = ri * 16 + (lane >> 4) + 4 * q;
-        if (row < n && col < n) { out[L.tZt + row * n + col] = res[sidx][q]; out[L.tLm + row * n + col] = res2[sidx][q]; }
+        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; if (row < n && col < n) out[L.tZt + row * n + col] = res[sidx][q]; }
       }
     }
-  }
-  LEG_BARRIER();
-  // ---- Sg_ab = Sg_b + Lm_b^T Zt (lower block triangle, mirrored) ; sg_ab = sg_b + Lm_b^T t3 ----
-  {
+    LEG_BARRIER();
     const int nst = nb * (nb + 1) / 2;
 #pragma unroll
-    for (int sidx = 0; sidx < LC_STILES; ++sidx) {
+    for (int sidx = 0; sidx < LC_STILES; ++sidx) {  // Sg_ab: lower block triangle, mirrored
       const int t = wv + sidx * nw;
       if (t < nst) {
         int ri = 0, rem = t;
@@ -264,8 +265,8 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
         const int col = rem * 16 + (lane & 15);
         d4_t acc = d4_t{0, 0, 0, 0};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; acc[q] = (bpar && row < n && col < n) ? Bn.Sg[row * n + col] : 0.0; }
-        if (bpar) mma_tile<false>(acc, Z + ri * 16, 1, ldp, X + rem * 16, ldp, 1, np, lane);
+        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; acc[q] = (row < n && col < n) ? Bn.Sg[row * n + col] : 0.0; }
+        mma_tile<false>(acc, Z + ri * 16, 1, ldp, X + rem * 16, ldp, 1, np, lane);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int row = ri * 16 + (lane >> 4) + 4 * q;
@@ -273,29 +274,54 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
         }
       }
     }
-    for (int i = wv; i < n; i += nw) {  // (Lm_b^T t3)_i = sum_l Lm_b[l][i] t3[l]: lanes over l
-      double s = 0;
-      for (int l = lane; l < n; l += 64) s += Z[l * ldp + i] * rv[l];
-      s = wave_sum(s);
-      if (lane == 0) out[L.tsg + i] = s + (bpar ? Bn.sg[i] : 0.0);
+#pragma unroll
+    for (int sidx = 0; sidx < LC_TILES; ++sidx) {  // E = Lm_b + D Zt
+      const int t = wv + sidx * nw;
+      if (t < nb * nb) {
+        const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+        d4_t acc = d4_t{0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; acc[q] = (row < n && col < n) ? Bn.Lm[row * n + col] : 0.0; }
+        mma_tile<false>(acc, Y + (ri * 16) * ldp, ldp, 1, X + cj * 16, ldp, 1, np, lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; if (row < n && col < n) out[L.tE + row * n + col] = acc[q]; }
+      }
+    }
+    return;
+  }
+  // ======== role 0: Y = T1, rv = t3, Z = Lm_b ========
+  // T1 (= Zx of the down-sweep), t3 out
+  for (int i = wv; i < n; i += nw) for (int c0 = lane; c0 < n; c0 += 64) out[L.tZx + i * n + c0] = Y[i * ldp + c0];
+  for (int i = tid; i < n; i += nthr) out[L.tzc + i] = rv[i];
+  LEG_BARRIER();
+  // Lm_ab = T1^T Lm_b (out) ; sg_ab = sg_b + Lm_b^T t3
+#pragma unroll
+  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+    const int t = wv + sidx * nw;
+    if (t < nb * nb) {
+      const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+      d4_t acc = d4_t{0, 0, 0, 0};
+      if (bpar) mma_tile<false>(acc, Y + ri * 16, 1, ldp, Z + cj * 16, ldp, 1, np, lane);  // T1^T: rows of the product are columns of Y
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; if (row < n && col < n) out[L.tLm + row * n + col] = acc[q]; }
     }
   }
-  __syncthreads();  // ldP (written above by other threads) is read back below ; Z, rows of X / Y: all reads done
+  for (int i = wv; i < n; i += nw) {  // (Lm_b^T t3)_i = sum_l Lm_b[l][i] t3[l]: lanes over l
+    double s = 0;
+    for (int l = lane; l < n; l += 64) s += Z[l * ldp + i] * rv[l];
+    s = wave_sum(s);
+    if (lane == 0) out[L.tsg + i] = s + (bpar ? Bn.sg[i] : 0.0);
+  }
+  __syncthreads();  // ldP (written at the top by other threads of this workgroup) is read back below ; all reads of Z done
   LEG_LAUNDER();
-  // ---- Z <- D ; F = D T1 (out, then over T1 in Y) ; E = D Zt + Lm_b (out) ; u = D t3 + p_b ----
+  // ---- Z <- D ; F = D T1 (out, then over T1 in Y) ; u = D t3 + p_b ----
   leg_load_mat<false>(Z, ldp, np, lrc + L.ldP, n, tid, nthr, S.mg_np);
   LEG_BARRIER();
 #pragma unroll
   for (int sidx = 0; sidx < LC_TILES; ++sidx) {
     const int t = wv + sidx * nw;
-    res[sidx] = d4_t{0, 0, 0, 0}; res2[sidx] = d4_t{0, 0, 0, 0};
-    if (t < nb * nb) {
-      const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; res2[sidx][q] = (bpar && row < n && col < n) ? Bn.Lm[row * n + col] : 0.0; }
-      mma_tile<false>(res[sidx], Z + (ri * 16) * ldp, ldp, 1, Y + cj * 16, ldp, 1, np, lane);
-      if (bpar) mma_tile<false>(res2[sidx], Z + (ri * 16) * ldp, ldp, 1, X + cj * 16, ldp, 1, np, lane);
-    }
+    res[sidx] = d4_t{0, 0, 0, 0};
+    if (t < nb * nb) mma_tile<false>(res[sidx], Z + ((t / nb) * 16) * ldp, ldp, 1, Y + (t % nb) * 16, ldp, 1, np, lane);
   }
   for (int i = wv; i < np; i += nw) {
     double s = 0;
@@ -311,10 +337,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
       const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
       tile_store(Y + (ri * 16) * ldp + cj * 16, ldp, res[sidx], lane);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = ri * 16 + (lane >> 4) + 4 * q;
-        if (row < n && col < n) { out[L.tF + row * n + col] = res[sidx][q]; out[L.tE + row * n + col] = res2[sidx][q]; }
-      }
+      for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; if (row < n && col < n) out[L.tF + row * n + col] = res[sidx][q]; }
     }
   }
   LEG_LAUNDER();
@@ -369,11 +392,11 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_leg_tree_down: grid B.  Top-down over the inner nodes (a parent has a higher index than its children): state at the cut between the
+// k_leg_tree_down: grid (B, 2).  Workgroup 0 of an instance: top-down over the inner nodes (a parent has a higher index than its children): state at the cut between the
 // children and the co-state parameter of the left child, x_mid = Zx x_in + Zt theta_out + zc, theta_mid = F x_in + E theta_out + u —
 // four mat-vecs of one phase, the rows dealt to the wavefronts with all their loads in flight.  Cut states go straight into dxs, theta
-// into the leg records (what k_leg_apply and the forward sweeps of the legs read).  Then the exact feedback gain of knot 0 along the
-// leftmost path: S = d theta_out / d x_0 of the left child = F + E S_parent ; K_0 += Ku_0 Lm_1 S (as k_leg_consensus).
+// into the leg records (what k_leg_apply and the forward sweeps of the legs read).  Workgroup 1, beside it: the exact feedback gain of knot 0
+// along the leftmost path: S = d theta_out / d x_0 of the left child = F + E S_parent ; K_0 += Ku_0 Lm_1 S (as k_leg_consensus).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NP>
 __global__ void __launch_bounds__(LK_THREADS) k_leg_tree_down(SolverArgs a, LxLds S, TreeDesc T) {
@@ -389,6 +412,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_tree_down(SolverArgs a, LxLd
   double* XIN = PC;
   double* THO = PC + (MPC_MAX_LEGS - 1) * np;
   const int root = T.nnodes - 1, J = T.J;
+  if (blockIdx.y == 0) {  // ======== workgroup 0 of the instance: cut states and co-state parameters ========
   for (int i = tid; i < np; i += nthr) { XIN[(root - J) * np + i] = 0.0; THO[(root - J) * np + i] = 0.0; }  // x_0 = 0 (forced initial condition) ; no end parameter
   LEG_BARRIER();
   constexpr int FW_ROWS = NP / 8;
@@ -441,7 +465,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_tree_down(SolverArgs a, LxLd
     }
     LEG_BARRIER();
   }
-  // ---- exact K_0: S = d theta_1 / d x_0 along the leftmost path (PC <- S), then K_0 += (Ku_0 Lm_1) S ----
+  return;
+  }
+  // ======== workgroup 1 of the instance: exact K_0: S = d theta_1 / d x_0 along the leftmost path (PC <- S), then K_0 += (Ku_0 Lm_1) S ========
   LEG_LAUNDER();
   d4_t res[LC_TILES];
   bool first = true;

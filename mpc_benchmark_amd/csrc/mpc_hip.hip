@@ -424,8 +424,7 @@ static void launch_pass(mpc_solver* s) {
     if (tree) s->timed(14, "k_leg_consensus", [&] {
       const TreeDesc& T = s->tree;
 #define MPC_TREE_LAUNCH(NPV) do { \
-        for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL(k_leg_compose<NPV>, dim3(T.lev_cnt[lev], L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); \
-        if (sweep + 1 == sweeps) hipLaunchKernelGGL(k_leg_tree_down<NPV>, dim3(L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); } while (0)
+        for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL(k_leg_compose<NPV>, dim3(T.lev_cnt[lev], L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); } while (0)
       switch (s->lx.np) {
         case 16: MPC_TREE_LAUNCH(16); break;
         case 32: MPC_TREE_LAUNCH(32); break;
@@ -434,6 +433,16 @@ static void launch_pass(mpc_solver* s) {
         default: MPC_TREE_LAUNCH(80); break;
       }
 #undef MPC_TREE_LAUNCH
+    });
+    if (tree && sweep + 1 == sweeps) s->timed(16, "k_leg_tree_down", [&] {
+      const TreeDesc& T = s->tree;
+      switch (s->lx.np) {
+        case 16: hipLaunchKernelGGL(k_leg_tree_down<16>, dim3(L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); break;
+        case 32: hipLaunchKernelGGL(k_leg_tree_down<32>, dim3(L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); break;
+        case 48: hipLaunchKernelGGL(k_leg_tree_down<48>, dim3(L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); break;
+        case 64: hipLaunchKernelGGL(k_leg_tree_down<64>, dim3(L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); break;
+        default: hipLaunchKernelGGL(k_leg_tree_down<80>, dim3(L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); break;
+      }
     });
     else s->timed(14, "k_leg_consensus", [&] {
       switch (s->lx.np) {
