@@ -435,7 +435,7 @@ static void launch_pass(mpc_solver* s) {
 #undef MPC_TREE_LAUNCH
     });
     if (tree && sweep + 1 == sweeps) s->timed(16, "k_leg_tree_down", [&] {
-      const TreeDesc& T = s->tree;
+      const TreeDesc& T = s->tree;  // (the node vectors of the down-sweep, 2 (MPC_MAX_LEGS - 1) np doubles, lie over the three matrix buffers: make_lx_lds)
       switch (s->lx.np) {
         case 16: hipLaunchKernelGGL(k_leg_tree_down<16>, dim3(L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); break;
         case 32: hipLaunchKernelGGL(k_leg_tree_down<32>, dim3(L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); break;

@@ -94,7 +94,7 @@ def test_leg_kernels_against_oracle(hip_lib, oracle_lib, kind, N, legs, complete
                                                   ("centroidal", 30, 7, False), ("kinodynamic", 12, 3, False), ("kinodynamic", 12, 4, True),
                                                   # more than 8 legs: the cuts are resolved by the tree of csrc/legs_tree.h
                                                   ("fulldynamic", 24, 12, False), ("fulldynamic", 32, 16, True), ("centroidal", 40, 13, False),
-                                                  ("kinodynamic", 20, 10, True)])
+                                                  ("kinodynamic", 20, 10, True), ("fulldynamic", 45, 15, False), ("centroidal", 64, 16, False)])
 def test_hip_legs_equal_hip_serial(hip_lib, oracle_lib, kind, N, legs, complete):
     """Default mode (cut-Hessian guess; the first pass of a handle sweeps twice — once per tree level + 1 with more than 8 legs): one
     iteration from a point far from the solution."""
