@@ -21,7 +21,7 @@ struct Layout {
   int lSg, lsg, lZx, lzc, lcP, lcp, lth, ldP, leg_stride;
   // tree over the cuts (legs_tree.h), per (instance, inner node): condensed form P | Lm | Sg | p | sg of the legs it covers and the maps of
   // the down-sweep Zx | Zt | F | E | zc | u
-  int tP, tLm, tSg, tZx, tZt, tF, tE, tp, tsg, tzc, tu, tree_stride;
+  int tP, tLm, tSg, tZx, tZt, tF, tE, tp, tsg, tzc, tu, txin, ttho, tree_stride;  // (txin, ttho: state at the node's start, parameter at its end)
   // backward-sweep scratch per instance
   int wPh, wPt, wLp, wG, wHh, wgh, wCt, wW, wY, wSc, wV, wAcl, wvec, work_stride;
   int max_stage_ints, max_stage_doubles;
@@ -66,7 +66,7 @@ static inline void make_layout(Layout& L) {
   L.leg_stride = o;
   o = 0;
   L.tP = take(n * n); L.tLm = take(n * n); L.tSg = take(n * n); L.tZx = take(n * n); L.tZt = take(n * n); L.tF = take(n * n); L.tE = take(n * n);
-  L.tp = take(n); L.tsg = take(n); L.tzc = take(n); L.tu = take(n);
+  L.tp = take(n); L.tsg = take(n); L.tzc = take(n); L.tu = take(n); L.txin = take(n); L.ttho = take(n);
   L.tree_stride = o;
   o = 0;
   const int nr = n + 1;

@@ -47,7 +47,71 @@ static inline TreeDesc make_tree_desc(int J) {
   return T;
 }
 
-DEV double* tree_node_ptr(const SolverArgs& a, int b, int inner) { return a.treebuf + ((size_t)b * (MPC_MAX_LEGS - 1) + inner) * a.L.tree_stride; }
+DEV double* tree_node_ptr(const SolverArgs& a, int b, int inner) { return a.treebuf + ((size_t)b * MPC_MAX_LEGS + inner) * a.L.tree_stride; }
+DEV double* tree_scratch_ptr(const SolverArgs& a, int b) { return tree_node_ptr(a, b, MPC_MAX_LEGS - 1); }  // G of the K_0 path (mp x n)
+
+// Exact K_0 = K_0 + Ku_0 Lm_1 d theta_1 / d x_0, d theta_1 / d x_0 = S_1, S_i = F_i + E_i S_{i+1} along the leftmost path (node 1: the
+// parent of leg 0 ... the root), evaluated from the left with the thin matrix G (m x n):  G_1 = Ku_0 Lm_1 ;  K_0 += G_i F_i ;
+// G_{i+1} = G_i E_i.  One step per launch of the up-sweep, by a workgroup of its own beside the compositions (node i is complete when
+// level i + 1 starts), the root's step beside the first level of the down-sweep: nothing of it is on the critical path.
+// node < 0: G_1 only.
+template <int NP>
+DEV void tree_k0_step(const SolverArgs& a, const LxLds& S, const TreeDesc& T, int b, int node, double* sm, int tid, int nthr) {
+  const Layout& L = a.L;
+  const int n = L.n, np = S.np, mp = S.mp, ldp = S.ldp, nb = S.nb, nbm = S.nbm, nw = nthr >> 6, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  double *PC = sm + S.PC, *MA = sm + S.MA, *RB = sm + S.RB;
+  double* G = tree_scratch_ptr(a, b);
+  double* g0 = gain_ptr(a, b, 0);
+  d4_t r0[2], r1[2];
+  if (node < 0) {  // G_1 = Ku_0 Lm_1 (Lm_1 = I when leg 0 is a single knot)
+    const bool single = leg_start(a, 1) == 1;
+    const double* g1 = gain_ptr(a, b, 1);
+    for (int idx = tid; idx < mp * ldp; idx += nthr) { const int i = qdiv(idx, S.mg_ldp), cc = idx - i * ldp; RB[idx] = (i < L.m && cc < n) ? g0[L.oKu + i * n + cc] : 0.0; }
+    if (single) { for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = qdiv(idx, S.mg_ldp), cc = idx - i * ldp; MA[idx] = (i == cc && i < n) ? 1.0 : 0.0; } }
+    else leg_load_mat<false>(MA, ldp, np, g1 + L.oLm, n, tid, nthr, S.mg_np);
+    LEG_BARRIER();
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+      const int tt = wv + sidx * nw;
+      if (tt < nbm * nb) {
+        d4_t acc = d4_t{0, 0, 0, 0};
+        mma_tile<false>(acc, RB + ((tt / nb) * 16) * ldp, ldp, 1, MA + (tt % nb) * 16, ldp, 1, np, lane);
+        const int col = (tt % nb) * 16 + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = (tt / nb) * 16 + (lane >> 4) + 4 * q; if (row < L.m && col < n) G[row * n + col] = acc[q]; }
+      }
+    }
+    return;
+  }
+  const double* t = tree_node_ptr(a, b, node - T.J);
+  const bool has_t = T.hi[node] + 1 < T.J;
+  for (int idx = tid; idx < mp * ldp; idx += nthr) { const int i = qdiv(idx, S.mg_ldp), cc = idx - i * ldp; RB[idx] = (i < L.m && cc < n) ? G[i * n + cc] : 0.0; }
+  leg_load_mat<false>(PC, ldp, np, t + L.tF, n, tid, nthr, S.mg_np);
+  if (has_t) leg_load_mat<false>(MA, ldp, np, t + L.tE, n, tid, nthr, S.mg_np);
+  LEG_BARRIER();
+#pragma unroll
+  for (int sidx = 0; sidx < 2; ++sidx) {
+    const int tt = wv + sidx * nw;
+    r0[sidx] = d4_t{0, 0, 0, 0}; r1[sidx] = d4_t{0, 0, 0, 0};
+    if (tt < nbm * nb) {
+      mma_tile<false>(r0[sidx], RB + ((tt / nb) * 16) * ldp, ldp, 1, PC + (tt % nb) * 16, ldp, 1, np, lane);
+      if (has_t) mma_tile<false>(r1[sidx], RB + ((tt / nb) * 16) * ldp, ldp, 1, MA + (tt % nb) * 16, ldp, 1, np, lane);
+    }
+  }
+#pragma unroll
+  for (int sidx = 0; sidx < 2; ++sidx) {
+    const int tt = wv + sidx * nw;
+    if (tt < nbm * nb) {
+      const int col = (tt % nb) * 16 + (lane & 15);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = (tt / nb) * 16 + (lane >> 4) + 4 * q;
+        if (row < L.m && col < n) { g0[L.oK + row * n + col] += r0[sidx][q]; if (has_t) G[row * n + col] = r1[sidx][q]; }  // (G was read into LDS by everybody: barrier above)
+      }
+    }
+  }
+}
 // condensed form of a node; Lm == nullptr: the node holds the last leg (no end parameter: Lm = Sg = 0, sg = 0)
 struct NodeRef { const double *P, *p, *Lm, *Sg, *sg; };
 DEV NodeRef tree_node_ref(const SolverArgs& a, const TreeDesc& T, int b, int node) {
@@ -69,7 +133,7 @@ DEV NodeRef tree_node_ref(const SolverArgs& a, const TreeDesc& T, int b, int nod
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_leg_compose: grid (nodes of the level, B, 2).  LDS: the three n x n buffers of the consensus kernel (X, Y, Z below).
+// k_leg_compose: grid (nodes of the level + 1, B, 2) — the extra workgroup (z = 0) takes a step of the K_0 path.  LDS: the three n x n buffers of the consensus kernel (X, Y, Z below).
 // The composition splits into two halves that share nothing but their inputs, one workgroup each (blockIdx.z):
 //   role 0: Gauss-Jordan on [Mt | Lm_a^T | rv] -> T1, t3 ;  Zx, zc, Lm_ab, sg_ab, F, u, P_ab, p_ab
 //   role 1: Gauss-Jordan on [Mt | Sg_a]        -> T2     ;  Zt, Sg_ab, E            (nothing to do when b holds the last leg)
@@ -83,6 +147,11 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
   const int n = L.n, np = S.np, ldp = S.ldp, nb = S.nb;
+  if ((int)blockIdx.x == T.lev_cnt[level]) {  // the workgroup of the K_0 path (tree_k0_step): the leftmost node of the level below
+    extern __shared__ __attribute__((aligned(16))) double smk[];
+    if (blockIdx.z == 0) tree_k0_step<NP>(a, S, T, b, level == 0 ? -1 : T.lev_first[level - 1], smk, tid, nthr);
+    return;
+  }
   const int node = T.lev_first[level] + blockIdx.x;
   const NodeRef A = tree_node_ref(a, T, b, T.left[node]), Bn = tree_node_ref(a, T, b, T.right[node]);
   double* out = tree_node_ptr(a, b, node - T.J);
@@ -392,149 +461,67 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_leg_tree_down: grid (B, 2).  Workgroup 0 of an instance: top-down over the inner nodes (a parent has a higher index than its children): state at the cut between the
-// children and the co-state parameter of the left child, x_mid = Zx x_in + Zt theta_out + zc, theta_mid = F x_in + E theta_out + u —
-// four mat-vecs of one phase, the rows dealt to the wavefronts with all their loads in flight.  Cut states go straight into dxs, theta
-// into the leg records (what k_leg_apply and the forward sweeps of the legs read).  Workgroup 1, beside it: the exact feedback gain of knot 0
-// along the leftmost path: S = d theta_out / d x_0 of the left child = F + E S_parent ; K_0 += Ku_0 Lm_1 S (as k_leg_consensus).
+// k_leg_tree_down: one launch per level, top-down (a node is created at a lower level than its parent): grid (nodes of the level, B),
+// plus one workgroup for the last step of the K_0 path in the first launch.  A node: state at the cut between its children and the
+// co-state parameter of the left child, x_mid = Zx x_in + Zt theta_out + zc, theta_mid = F x_in + E theta_out + u — four mat-vecs, the
+// rows dealt to the wavefronts with all their loads in flight.  Cut states go straight into dxs, theta into the leg records (what
+// k_leg_apply and the forward sweeps of the legs read), x_in / theta_out of the children into their records.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ void __launch_bounds__(LK_THREADS) k_leg_tree_down(SolverArgs a, LxLds S, TreeDesc T) {
+__global__ void __launch_bounds__(LK_THREADS) k_leg_tree_down(SolverArgs a, LxLds S, TreeDesc T, int level) {
   const Layout& L = a.L;
-  const int b = blockIdx.x, nthr = blockDim.x, nw = nthr >> 6;
+  const int b = blockIdx.y, nthr = blockDim.x, nw = nthr >> 6;
   int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
-  const int n = L.n, N = L.N, np = S.np, mp = S.mp, ldp = S.ldp, nb = S.nb, nbm = S.nbm;
+  const int n = L.n, N = L.N, J = T.J;
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double *PC = sm + S.PC, *MA = sm + S.MA, *RB = sm + S.RB;
-  // per INNER node: state at its start, co-state parameter at its end (2 x 15 x np doubles over the three contiguous matrix buffers)
-  double* XIN = PC;
-  double* THO = PC + (MPC_MAX_LEGS - 1) * np;
-  const int root = T.nnodes - 1, J = T.J;
-  if (blockIdx.y == 0) {  // ======== workgroup 0 of the instance: cut states and co-state parameters ========
-  for (int i = tid; i < np; i += nthr) { XIN[(root - J) * np + i] = 0.0; THO[(root - J) * np + i] = 0.0; }  // x_0 = 0 (forced initial condition) ; no end parameter
-  LEG_BARRIER();
+  if ((int)blockIdx.x == T.lev_cnt[level]) { tree_k0_step<NP>(a, S, T, b, T.lev_first[level], sm, tid, nthr); return; }  // (first launch only: the root)
+  const int node = T.lev_first[level] + blockIdx.x;
+  double* t = tree_node_ptr(a, b, node - J);
+  const int lc = T.left[node], rc = T.right[node], cutleg = T.lo[rc];
+  const bool has_x = T.lo[node] > 0;            // x_in = 0 on the leftmost path (forced initial condition)
+  const bool has_t = T.hi[node] + 1 < J;        // no end parameter on the rightmost path
   constexpr int FW_ROWS = NP / 8;
   const int c0 = lane < n ? lane : 0, c1 = lane + 64 < n ? lane + 64 : 0;
   const double m0 = lane < n ? 1.0 : 0.0, m1 = lane + 64 < n ? 1.0 : 0.0;
-  for (int node = root; node >= T.J; --node) {
-    LEG_LAUNDER();
-    const double* t = tree_node_ptr(a, b, node - T.J);
-    const int lc = T.left[node], rc = T.right[node], cutleg = T.lo[rc];
-    const double* xin = XIN + (node - J) * np;
-    const double* tho = THO + (node - J) * np;
-    const bool has_x = T.lo[node] > 0;            // x_in = 0 on the leftmost path
-    const bool has_t = T.hi[node] + 1 < T.J;      // no end parameter on the rightmost path
-    const double x0 = xin[c0] * m0, x1 = xin[c1] * m1, t0 = tho[c0] * m0, t1 = tho[c1] * m1;
-    double xm[FW_ROWS], tm[FW_ROWS];
-    double va[FW_ROWS][2], vb[FW_ROWS][2];
-    // x part: Zx x_in, F x_in
+  double x0 = 0, x1 = 0, t0 = 0, t1 = 0;
+  if (has_x) { x0 = t[L.txin + c0] * m0; x1 = t[L.txin + c1] * m1; }
+  if (has_t) { t0 = t[L.ttho + c0] * m0; t1 = t[L.ttho + c1] * m1; }
+  double xm[FW_ROWS], tm[FW_ROWS], va[FW_ROWS][2], vb[FW_ROWS][2];
 #pragma unroll
-    for (int i = 0; i < FW_ROWS; ++i) { xm[i] = 0.0; tm[i] = 0.0; }
-    if (has_x) {
-#pragma unroll
-      for (int i = 0; i < FW_ROWS; ++i) {
-        const int r = wv + i * nw, rr = r < n ? r : 0;
-        va[i][0] = t[L.tZx + rr * n + c0]; va[i][1] = t[L.tZx + rr * n + c1]; vb[i][0] = t[L.tF + rr * n + c0]; vb[i][1] = t[L.tF + rr * n + c1];
-      }
-#pragma unroll
-      for (int i = 0; i < FW_ROWS; ++i) { xm[i] += wave_sum(va[i][0] * x0 + va[i][1] * x1); tm[i] += wave_sum(vb[i][0] * x0 + vb[i][1] * x1); }
-    }
-    if (has_t) {
-#pragma unroll
-      for (int i = 0; i < FW_ROWS; ++i) {
-        const int r = wv + i * nw, rr = r < n ? r : 0;
-        va[i][0] = t[L.tZt + rr * n + c0]; va[i][1] = t[L.tZt + rr * n + c1]; vb[i][0] = t[L.tE + rr * n + c0]; vb[i][1] = t[L.tE + rr * n + c1];
-      }
-#pragma unroll
-      for (int i = 0; i < FW_ROWS; ++i) { xm[i] += wave_sum(va[i][0] * t0 + va[i][1] * t1); tm[i] += wave_sum(vb[i][0] * t0 + vb[i][1] * t1); }
-    }
-    double* lr = leg_ptr(a, b, cutleg - 1);
-    const int cut = leg_start(a, cutleg);
+  for (int i = 0; i < FW_ROWS; ++i) { xm[i] = 0.0; tm[i] = 0.0; }
+  if (has_x) {
 #pragma unroll
     for (int i = 0; i < FW_ROWS; ++i) {
-      const int r = wv + i * nw;
-      if (lane == 0 && r < n) {
-        const double xv = xm[i] + t[L.tzc + r], tv = tm[i] + t[L.tu + r];
-        a.dxs[((size_t)b * (N + 1) + cut) * n + r] = xv;
-        lr[L.lth + r] = tv;
-        if (rc >= J) { XIN[(rc - J) * np + r] = xv; THO[(rc - J) * np + r] = tho[r]; }
-        if (lc >= J) { XIN[(lc - J) * np + r] = xin[r]; THO[(lc - J) * np + r] = tv; }
-      }
+      const int r = wv + i * nw, rr = r < n ? r : 0;
+      va[i][0] = t[L.tZx + rr * n + c0]; va[i][1] = t[L.tZx + rr * n + c1]; vb[i][0] = t[L.tF + rr * n + c0]; vb[i][1] = t[L.tF + rr * n + c1];
     }
-    LEG_BARRIER();
+#pragma unroll
+    for (int i = 0; i < FW_ROWS; ++i) { xm[i] += wave_sum(va[i][0] * x0 + va[i][1] * x1); tm[i] += wave_sum(vb[i][0] * x0 + vb[i][1] * x1); }
   }
-  return;
+  if (has_t) {
+#pragma unroll
+    for (int i = 0; i < FW_ROWS; ++i) {
+      const int r = wv + i * nw, rr = r < n ? r : 0;
+      va[i][0] = t[L.tZt + rr * n + c0]; va[i][1] = t[L.tZt + rr * n + c1]; vb[i][0] = t[L.tE + rr * n + c0]; vb[i][1] = t[L.tE + rr * n + c1];
+    }
+#pragma unroll
+    for (int i = 0; i < FW_ROWS; ++i) { xm[i] += wave_sum(va[i][0] * t0 + va[i][1] * t1); tm[i] += wave_sum(vb[i][0] * t0 + vb[i][1] * t1); }
   }
-  // ======== workgroup 1 of the instance: exact K_0: S = d theta_1 / d x_0 along the leftmost path (PC <- S), then K_0 += (Ku_0 Lm_1) S ========
-  LEG_LAUNDER();
-  d4_t res[LC_TILES];
-  bool first = true;
-  for (int node = root; node >= T.J; node = T.left[node]) {
-    const double* t = tree_node_ptr(a, b, node - T.J);
-    if (first) {  // S_parent = 0: S = F
-      LEG_BARRIER();
-      leg_load_mat<false>(PC, ldp, np, t + L.tF, n, tid, nthr, S.mg_np);
-      LEG_BARRIER();
-      first = false;
-    } else {      // S = F + E S_parent
-      leg_load_mat<false>(MA, ldp, np, t + L.tE, n, tid, nthr, S.mg_np);
-      LEG_BARRIER();
+  double* lr = leg_ptr(a, b, cutleg - 1);
+  const int cut = leg_start(a, cutleg);
+  double* tl = lc >= J ? tree_node_ptr(a, b, lc - J) : nullptr;
+  double* tr = rc >= J ? tree_node_ptr(a, b, rc - J) : nullptr;
 #pragma unroll
-      for (int sidx = 0; sidx < LC_TILES; ++sidx) {
-        const int tt = wv + sidx * nw;
-        res[sidx] = d4_t{0, 0, 0, 0};
-        if (tt < nb * nb) {
-          const int ri = tt / nb, cj = tt % nb, col = cj * 16 + (lane & 15);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; res[sidx][q] = (row < n && col < n) ? t[L.tF + row * n + col] : 0.0; }
-          mma_tile<false>(res[sidx], MA + (ri * 16) * ldp, ldp, 1, PC + cj * 16, ldp, 1, np, lane);
-        }
-      }
-      LEG_BARRIER();
-#pragma unroll
-      for (int sidx = 0; sidx < LC_TILES; ++sidx) {
-        const int tt = wv + sidx * nw;
-        if (tt < nb * nb) tile_store(PC + ((tt / nb) * 16) * ldp + (tt % nb) * 16, ldp, res[sidx], lane);
-      }
-      LEG_BARRIER();
-    }
-    if (T.left[node] < T.J) break;  // the left child is leg 0: S is d theta_1 / d x_0
-  }
-  {
-    double* g0 = gain_ptr(a, b, 0);
-    const bool single = leg_start(a, 1) == 1;
-    const double* g1 = gain_ptr(a, b, 1);
-    LEG_BARRIER();
-    for (int idx = tid; idx < mp * ldp; idx += nthr) { const int i = qdiv(idx, S.mg_ldp), cc = idx - i * ldp; RB[idx] = (i < L.m && cc < n) ? g0[L.oKu + i * n + cc] : 0.0; }
-    if (single) { for (int idx = tid; idx < np * ldp; idx += nthr) { const int i = qdiv(idx, S.mg_ldp), cc = idx - i * ldp; MA[idx] = (i == cc && i < n) ? 1.0 : 0.0; } }
-    else leg_load_mat<false>(MA, ldp, np, g1 + L.oLm, n, tid, nthr, S.mg_np);
-    LEG_BARRIER();
-    d4_t kres[2];
-#pragma unroll
-    for (int sidx = 0; sidx < 2; ++sidx) {
-      const int tt = wv + sidx * nw;
-      kres[sidx] = d4_t{0, 0, 0, 0};
-      if (tt < nbm * nb) mma_tile<false>(kres[sidx], RB + ((tt / nb) * 16) * ldp, ldp, 1, MA + (tt % nb) * 16, ldp, 1, np, lane);
-    }
-    LEG_BARRIER();
-#pragma unroll
-    for (int sidx = 0; sidx < 2; ++sidx) {
-      const int tt = wv + sidx * nw;
-      if (tt < nbm * nb) tile_store(RB + ((tt / nb) * 16) * ldp + (tt % nb) * 16, ldp, kres[sidx], lane);
-    }
-    LEG_BARRIER();
-#pragma unroll
-    for (int sidx = 0; sidx < 2; ++sidx) {
-      const int tt = wv + sidx * nw;
-      if (tt < nbm * nb) {
-        d4_t acc = d4_t{0, 0, 0, 0};
-        mma_tile<false>(acc, RB + ((tt / nb) * 16) * ldp, ldp, 1, PC + (tt % nb) * 16, ldp, 1, np, lane);
-        const int col = (tt % nb) * 16 + (lane & 15);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const int row = (tt / nb) * 16 + (lane >> 4) + 4 * q; if (row < L.m && col < n) g0[L.oK + row * n + col] += acc[q]; }
-      }
+  for (int i = 0; i < FW_ROWS; ++i) {
+    const int r = wv + i * nw;
+    if (lane == 0 && r < n) {
+      const double xv = xm[i] + t[L.tzc + r], tv = tm[i] + t[L.tu + r];
+      a.dxs[((size_t)b * (N + 1) + cut) * n + r] = xv;
+      lr[L.lth + r] = tv;
+      if (tr) { tr[L.txin + r] = xv; if (has_t) tr[L.ttho + r] = t[L.ttho + r]; }
+      if (tl) { tl[L.ttho + r] = tv; if (has_x) tl[L.txin + r] = t[L.txin + r]; }
     }
   }
 }

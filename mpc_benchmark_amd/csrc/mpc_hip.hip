@@ -267,7 +267,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<64>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     s->d_legbuf = s->alloc<double>(B * (MPC_MAX_LEGS - 1) * (size_t)L.leg_stride);
-    s->d_treebuf = s->alloc<double>(B * (MPC_MAX_LEGS - 1) * (size_t)L.tree_stride);
+    s->d_treebuf = s->alloc<double>(B * MPC_MAX_LEGS * (size_t)L.tree_stride);  // inner nodes + one scratch record per instance
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
@@ -424,7 +424,7 @@ static void launch_pass(mpc_solver* s) {
     if (tree) s->timed(14, "k_leg_consensus", [&] {
       const TreeDesc& T = s->tree;
 #define MPC_TREE_LAUNCH(NPV) do { \
-        for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL(k_leg_compose<NPV>, dim3(T.lev_cnt[lev], L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); } while (0)
+        for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL(k_leg_compose<NPV>, dim3(T.lev_cnt[lev] + 1, L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); } while (0)
       switch (s->lx.np) {
         case 16: MPC_TREE_LAUNCH(16); break;
         case 32: MPC_TREE_LAUNCH(32); break;
@@ -437,11 +437,11 @@ static void launch_pass(mpc_solver* s) {
     if (tree && sweep + 1 == sweeps) s->timed(16, "k_leg_tree_down", [&] {
       const TreeDesc& T = s->tree;  // (the node vectors of the down-sweep, 2 (MPC_MAX_LEGS - 1) np doubles, lie over the three matrix buffers: make_lx_lds)
       switch (s->lx.np) {
-        case 16: hipLaunchKernelGGL(k_leg_tree_down<16>, dim3(L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); break;
-        case 32: hipLaunchKernelGGL(k_leg_tree_down<32>, dim3(L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); break;
-        case 48: hipLaunchKernelGGL(k_leg_tree_down<48>, dim3(L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); break;
-        case 64: hipLaunchKernelGGL(k_leg_tree_down<64>, dim3(L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); break;
-        default: hipLaunchKernelGGL(k_leg_tree_down<80>, dim3(L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T); break;
+        case 16: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<16>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;
+        case 32: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<32>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;
+        case 48: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<48>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;
+        case 64: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<64>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;
+        default: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<80>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;
       }
     });
     else s->timed(14, "k_leg_consensus", [&] {
