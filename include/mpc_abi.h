@@ -128,8 +128,8 @@ typedef struct mpc_options {
   int32_t riccati_legs;    /* linear_solver_choice = LQ_SOLVER_PARALLEL + setNumThreads(n) (fulldynamic_talos.py:383,385): the horizon is cut
                             * into this many legs (clamped to 16 and to the horizon; leg j starts at knot floor(j N / legs)) whose Riccati
                             * sweeps run side by side — parallel-in-time, same KKT system, results equal to the serial sweep (1) up to
-                            * round-off.  Up to 8 legs the cuts are resolved one after the other (a chain of legs - 1 solves), with more
-                            * by a tree of pairwise compositions (ceil(log2 legs) rounds: the latency-bound single instance).
+                            * round-off.  The cuts are resolved by a tree of pairwise compositions (ceil(log2 legs) rounds of independent
+                            * solves; MPC_LEGS_CHAIN=1: one after the other, a chain of legs - 1 solves — the first form, kept for tests).
                             * controlFeedbacks()[0] is the exact gain; the gains of later knots are those of their leg.  HIP:
                             * problems with more than 80 tangent dimensions or 48 controls keep the serial sweep */
   int32_t forward_mode;    /* HIP forward sweep: 0 = automatic, 1 = one workgroup per instance walks the knots (least CU time: ensembles

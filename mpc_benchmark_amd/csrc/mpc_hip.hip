@@ -81,13 +81,12 @@ struct mpc_solver {
   double* d_legbuf = nullptr;
   double* d_treebuf = nullptr;
   TreeDesc tree{};       // tree over the cuts for the current number of legs (legs_tree.h)
-  // more than 8 legs: the cuts are resolved by a tree of pairwise compositions instead of the chain of k_leg_consensus (legs_tree.h;
-  // the oracle follows the same rule) ; MPC_LEGS_TREE=1 forces the tree for any number of legs (tests)
+  // three legs or more: the cuts are resolved by a tree of pairwise compositions (legs_tree.h) instead of the chain of k_leg_consensus
+  // (fewer solves in a row, and the compositions of a level run side by side: 64 x 4 legs 0.38 -> 0.27 ms, batch 1 with 16 legs is only
+  // worth it this way) ; MPC_LEGS_CHAIN=1 keeps the chain (tests: its intermediates are compared with the oracle's one to one)
   bool use_tree() const {
-    const char* fe = getenv("MPC_LEGS_TREE");
-    const bool force = fe && atoi(fe) > 0;
-    const int J = eff_legs();
-    return J > 1 && d_treebuf != nullptr && (J > 8 || force);
+    const char* fe = getenv("MPC_LEGS_CHAIN");
+    return eff_legs() >= 3 && d_treebuf != nullptr && !(fe && atoi(fe) > 0);
   }
   bool leg_guess_valid = false;  // the leg records hold the cut Hessians of an earlier pass (terminal costs of the legs)
   int leg_guess_now = 0;

@@ -100,7 +100,7 @@ struct Instance {
   mpc_stats stats{};
   // parallel-in-time legs, per parametric leg (debug dumps): Zx | zc | calP | calp | theta
   std::vector<std::vector<double>> leg_Zx, leg_zc, leg_calP, leg_calp, leg_theta;
-  // tree consensus (riccati_legs > 8): nodes of the last pass, and the value-function guesses at the cuts kept from pass to pass
+  // tree over the cuts (three legs or more): nodes of the last pass, and the value-function guesses at the cuts kept from pass to pass
   std::vector<struct TreeNode> tree;
   std::vector<std::vector<double>> tree_guess;
   bool tree_guess_valid = false;
@@ -550,11 +550,11 @@ struct Solver {
     if (J > 1) in.gains[0].K = in.gains[0].Kexact;
   }
 
-  // ---- tree over the cuts (csrc/legs.h, riccati_legs > 8): the chain of backward_legs costs one solve per cut, one after the other;
+  // ---- tree over the cuts (csrc/legs_tree.h, three legs or more unless MPC_LEGS_CHAIN=1): the chain of backward_legs costs one solve per cut, one after the other;
   // composing the condensed forms of adjacent (groups of) legs pairwise takes ceil(log2 J) rounds of independent solves.  Same KKT
   // system: identical steps up to round-off.  The guess of the value-function Hessian at a cut is the Hessian of the node that
   // starts there, given ITS end guess (exact for the nodes that hold the last leg; the others catch up one tree level per pass).
-  bool use_tree() const { const char* e = std::getenv("MPC_LEGS_TREE"); return nlegs() > 8 || (e && std::atoi(e) > 0 && nlegs() > 1); }
+  bool use_tree() const { const char* e = std::getenv("MPC_LEGS_CHAIN"); return nlegs() >= 3 && !(e && std::atoi(e) > 0); }  // (the rule of csrc/mpc_hip.hip)
   static void mm(const std::vector<double>& A, const std::vector<double>& B, std::vector<double>& C, int n, bool ta = false) {  // C = A B (or A^T B)
     C.assign((size_t)n * n, 0.0);
     for (int i = 0; i < n; ++i) for (int l = 0; l < n; ++l) { const double a = ta ? A[l * n + i] : A[i * n + l]; if (a == 0.0) continue; for (int j = 0; j < n; ++j) C[i * n + j] += a * B[l * n + j]; }

@@ -47,6 +47,7 @@ def test_leg_kernels_against_oracle(hip_lib, oracle_lib, kind, N, legs, complete
     the solution (cut states to ~1e-5: the reason for the cut-Hessian guess of the default mode) — its outputs are
     compared at 1e-4 there, everything before it at 1e-8."""
     monkeypatch.setenv("MPC_LEGS_PLAIN", "1")
+    monkeypatch.setenv("MPC_LEGS_CHAIN", "1")  # the chain over the cuts (k_leg_consensus): Zx, zc, calP, calp per cut ; the tree: next test
     # (kinodynamic: the last knot of a leg has a zero value function behind it, its control Hessian is the bare, weakly
     # curved cost Hessian: the feed-forward there is compared at 1e-4 as well)
     loose = 1e-4 if (complete or kind == "kinodynamic") else 1e-7
@@ -92,7 +93,7 @@ def test_leg_kernels_against_oracle(hip_lib, oracle_lib, kind, N, legs, complete
 
 @pytest.mark.parametrize("kind,N,legs,complete", [("fulldynamic", 12, 3, False), ("fulldynamic", 16, 4, True), ("fulldynamic", 10, 10, False),
                                                   ("centroidal", 30, 7, False), ("kinodynamic", 12, 3, False), ("kinodynamic", 12, 4, True),
-                                                  # more than 8 legs: the cuts are resolved by the tree of csrc/legs_tree.h
+                                                  # ten legs and more (the latency configuration of the bench: 16)
                                                   ("fulldynamic", 24, 12, False), ("fulldynamic", 32, 16, True), ("centroidal", 40, 13, False),
                                                   ("kinodynamic", 20, 10, True), ("fulldynamic", 45, 15, False), ("centroidal", 64, 16, False)])
 def test_hip_legs_equal_hip_serial(hip_lib, oracle_lib, kind, N, legs, complete):
@@ -112,13 +113,13 @@ def test_hip_legs_equal_hip_serial(hip_lib, oracle_lib, kind, N, legs, complete)
     assert _rel(np.array(sl.results.us), np.array(s1.results.us)) < 1e-7
 
 
-@pytest.mark.parametrize("tree_forced", [False, True])
+@pytest.mark.parametrize("chain", [False, True])
 @pytest.mark.parametrize("kind,N,legs", [("fulldynamic", 15, 3), ("fulldynamic", 14, 5), ("centroidal", 21, 7), ("fulldynamic", 16, 8)])
-def test_tree_over_the_cuts_for_any_number_of_legs(hip_lib, oracle_lib, kind, N, legs, tree_forced, monkeypatch):
-    """MPC_LEGS_TREE=1 resolves the cuts by the tree for any number of legs (odd counts: a node is carried up a level unpaired): same
-    step as the chain consensus and as the serial sweep."""
-    if tree_forced:
-        monkeypatch.setenv("MPC_LEGS_TREE", "1")
+def test_tree_and_chain_over_the_cuts(hip_lib, oracle_lib, kind, N, legs, chain, monkeypatch):
+    """The cuts resolved by the tree (default from three legs; odd counts: a node is carried up a level unpaired) and by the chain of
+    k_leg_consensus (MPC_LEGS_CHAIN=1): same step as the serial sweep."""
+    if chain:
+        monkeypatch.setenv("MPC_LEGS_CHAIN", "1")
     _, s1 = _one_iteration(hip_lib, kind, N, 1)
     _, sl = _one_iteration(hip_lib, kind, N, legs)
     _, so = _one_iteration(oracle_lib, kind, N, legs)  # the oracle follows the same rule (oracle/solver.hpp use_tree)

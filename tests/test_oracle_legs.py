@@ -23,15 +23,15 @@ def _solver(pd, lib, legs, iters):
     return solver
 
 
-@pytest.mark.parametrize("kind,N,legs,force_tree", [("fulldynamic", 12, 3, False), ("fulldynamic", 9, 9, False), ("kinodynamic", 10, 4, False),
-                                                    ("centroidal", 30, 7, False),
-                                                    # tree over the cuts (more than 8 legs, or MPC_LEGS_TREE=1): oracle/solver.hpp backward_legs_tree
-                                                    ("fulldynamic", 24, 12, False), ("centroidal", 48, 16, False), ("fulldynamic", 12, 3, True),
-                                                    ("centroidal", 30, 7, True), ("kinodynamic", 10, 5, True)])
-def test_one_iteration_with_legs_equals_serial(oracle_lib, kind, N, legs, force_tree, monkeypatch):
-    if force_tree:
-        monkeypatch.setenv("MPC_LEGS_TREE", "1")
-    tree = force_tree or legs > 8
+@pytest.mark.parametrize("kind,N,legs,chain", [("fulldynamic", 12, 3, True), ("fulldynamic", 9, 9, True), ("kinodynamic", 10, 4, True),
+                                                ("centroidal", 30, 7, True), ("centroidal", 30, 2, False),
+                                                # tree over the cuts (three legs or more; MPC_LEGS_CHAIN=1: the chain): oracle/solver.hpp backward_legs_tree
+                                                ("fulldynamic", 24, 12, False), ("centroidal", 48, 16, False), ("fulldynamic", 12, 3, False),
+                                                ("centroidal", 30, 7, False), ("kinodynamic", 10, 5, False)])
+def test_one_iteration_with_legs_equals_serial(oracle_lib, kind, N, legs, chain, monkeypatch):
+    if chain:
+        monkeypatch.setenv("MPC_LEGS_CHAIN", "1")
+    tree = legs >= 3 and not chain
     res = {}
     for L in (1, legs):
         pd = {"fulldynamic": FullDynamicsProblem, "kinodynamic": KinodynamicProblem, "centroidal": CentroidalProblem}[kind](horizon=N)

@@ -2,6 +2,7 @@
 product of their condensed forms), cut states by a down-sweep — against the oracle's chain consensus on the same leg records."""
 import os, sys
 os.environ["MPC_LEGS_PLAIN"] = "1"
+os.environ["MPC_LEGS_CHAIN"] = "1"  # the oracle resolves the cuts by its chain: the reference for the numpy tree below
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
