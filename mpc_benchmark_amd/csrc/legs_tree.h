@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
   int* perm = (int*)(sm + S.iw);
   int* used = perm + np;
   d4_t res[LC_TILES];
-  // ---- X <- Sg_a ; Y <- D = P_b - Pg ; the guess of the next pass (lcP) <- P_b ; ldP <- D ----
+  // ---- X <- Sg_a ; Y <- D = P_b - Pg (Pg: lcP of the leg that ends at the cut, read by both roles) ; ldP <- D ----
   {
     double pv[LK_PT], po[LK_PT];
 #pragma unroll
@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
       if (idx < np * np) {
         const double d = pv[u] - po[u];
         Y[i * ldp + c0] = d;
-        if (role == 0 && i < n && c0 < n) { lrc[L.lcP + i * n + c0] = pv[u]; lrc[L.ldP + i * n + c0] = d; }
+        if (role == 0 && i < n && c0 < n) lrc[L.ldP + i * n + c0] = d;  // (the guess itself is refreshed by k_leg_tree_down: the other role reads it too)
       }
     }
   }
@@ -465,7 +465,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
 // plus one workgroup for the last step of the K_0 path in the first launch.  A node: state at the cut between its children and the
 // co-state parameter of the left child, x_mid = Zx x_in + Zt theta_out + zc, theta_mid = F x_in + E theta_out + u — four mat-vecs, the
 // rows dealt to the wavefronts with all their loads in flight.  Cut states go straight into dxs, theta into the leg records (what
-// k_leg_apply and the forward sweeps of the legs read), x_in / theta_out of the children into their records.
+// k_leg_apply and the forward sweeps of the legs read), x_in / theta_out of the children into their records ; last, the guess of the
+// value-function Hessian at the cut for the next pass (the leg record's lcP).  Launched after every sweep (the guesses), also the ones
+// whose cut states are not used (first pass of a handle).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int NP>
 __global__ void __launch_bounds__(LK_THREADS) k_leg_tree_down(SolverArgs a, LxLds S, TreeDesc T, int level) {
@@ -524,4 +526,8 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_tree_down(SolverArgs a, LxLd
       if (tl) { tl[L.ttho + r] = tv; if (has_x) tl[L.txin + r] = t[L.txin + r]; }
     }
   }
+  // the guess of the next pass at this cut: the Hessian of the node that starts there (not in k_leg_compose: both workgroups of a
+  // composition read the old guess, at their own pace)
+  const double* Pr = tree_node_ref(a, T, b, rc).P;
+  for (int idx = tid; idx < n * n; idx += nthr) lr[L.lcP + idx] = Pr[idx];
 }

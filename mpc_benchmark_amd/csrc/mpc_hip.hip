@@ -385,7 +385,8 @@ static void launch_pass(mpc_solver* s) {
   const bool tree = s->use_tree();
   if (tree && s->tree.J != J) s->tree = make_tree_desc(J);
   // (the tree refreshes the guess of a cut from the node that starts there: every cut has seen the true terminal cost after one sweep per level)
-  const int sweeps = (J > 1 && !plain && !s->leg_guess_valid) ? (tree ? s->tree.nlev + 1 : 2) : 1;
+  int sweeps = (J > 1 && !plain && !s->leg_guess_valid) ? (tree ? s->tree.nlev + 1 : 2) : 1;
+  if (const char* se = getenv("MPC_TREE_SWEEPS")) { if (tree && !plain && atoi(se) > sweeps) sweeps = atoi(se); }  // developer knob: sweeps per pass
   for (int sweep = 0; sweep < sweeps; ++sweep) {
   s->leg_guess_now = (J > 1 && !plain && (s->leg_guess_valid || sweep > 0)) ? 1 : 0;
   a = s->args();
@@ -433,7 +434,7 @@ static void launch_pass(mpc_solver* s) {
       }
 #undef MPC_TREE_LAUNCH
     });
-    if (tree && sweep + 1 == sweeps) s->timed(16, "k_leg_tree_down", [&] {
+    if (tree) s->timed(16, "k_leg_tree_down", [&] {
       const TreeDesc& T = s->tree;  // (the node vectors of the down-sweep, 2 (MPC_MAX_LEGS - 1) np doubles, lie over the three matrix buffers: make_lx_lds)
       switch (s->lx.np) {
         case 16: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<16>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;

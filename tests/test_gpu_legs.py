@@ -265,3 +265,29 @@ def test_ensemble_with_legs_is_deterministic_and_instancewise(hip_lib):
     b = run(3, 11)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_tree_with_more_workgroups_than_cus(hip_lib):
+    """An ensemble whose compositions do not all start together (48 instances x 8 legs: 480 workgroups at the first level of the tree,
+    256 CUs): the two workgroups of a composition run at different times, so neither may change what the other still reads (the guess
+    of the cut's value function: refreshed by the down-sweep, not by the composition).  The same cold solve (serial sweep) for both
+    runs, then warm ticks with the legs under test against ticks with the serial sweep."""
+    from mpc_benchmark_amd.ensemble import EnsembleMPC
+    out = {}
+    for legs in (1, 8):
+        pd = FullDynamicsProblem(horizon=24, complete_model=False)
+        ens = EnsembleMPC(pd, batch=48, library=hip_lib, seed=11, sigma_q=0.01, sigma_v=0.02)
+        ens.options.riccati_legs = 1
+        ens.native.set_options(ens.options)
+        ens.prepare_schedule(12)
+        ens.cold_solve(max_iters=60)
+        ens.options.riccati_legs = legs
+        ens.native.set_options(ens.options)
+        rec = []
+        for _ in range(6):
+            ens.step()
+            r = ens.results()
+            rec.append((r["xs"].copy(), r["us"].copy(), r["K"][:, 0].copy()))
+        out[legs] = rec
+    for a, b in zip(out[8], out[1]):
+        assert _rel(a[0], b[0]) < 1e-8 and _rel(a[1], b[1]) < 1e-8 and _rel(a[2], b[2]) < 1e-8
