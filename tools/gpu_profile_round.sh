@@ -34,11 +34,13 @@ python3 bench.py --legs 1 --streams 4 --no-cpu-baseline > $OUT/bench_serial_swee
 python3 bench.py --legs 8 --no-cpu-baseline > $OUT/bench_legs8.log 2>&1
 python3 bench.py --batch 256 --legs 1 --streams 1 --no-cpu-baseline --no-latency > $OUT/bench_batch256.log 2>&1
 python3 tools/phase_timers.py > $OUT/phase_timers.txt 2>&1
-python3 tools/legs_phase_timers.py 4 > $OUT/legs_phase_timers.txt 2>&1
+MPC_LEGS_CHAIN=1 python3 tools/legs_phase_timers.py 4 > $OUT/legs_phase_timers.txt 2>&1  # (the chain over the cuts: its kernel carries the phase timers of the elimination)
 python3 tools/config_sweep.py > $OUT/other_configs.txt 2>&1
 python3 tools/shim_tick_time.py 2>&1 | grep -E 'p50' > $OUT/drop_in_tick.txt
 python3 tools/latency_vs_legs.py > $OUT/latency_vs_legs.txt 2>&1
-python3 tools/batch1_kernel_times.py 8 > $OUT/batch1_kernel_times.txt 2>&1
+python3 tools/batch1_kernel_times.py 16 > $OUT/batch1_kernel_times.txt 2>&1
+python3 tools/occupancy_report.py > $OUT/occupancy_kinodynamic.txt 2>&1
+python3 tools/occupancy_report.py --problem full --batches 16,64,256 > $OUT/occupancy_fulldynamic.txt 2>&1
 # the raw per-dispatch CSVs are large: keep only the summaries
 find $OUT -name '*counter_collection.csv' -size +2M -delete
 find $OUT -name '*kernel_trace.csv' -size +8M -delete
