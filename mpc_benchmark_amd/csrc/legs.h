@@ -455,7 +455,6 @@ static inline LxLds make_lx_lds(int n, int m) {
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
   s.PC = take(s.np * s.ldp); s.MA = take(s.np * s.ldp); s.RB = take(s.np * s.ldp);
-  if (o < 2 * (MPC_MAX_LEGS - 1) * s.np) o = (2 * (MPC_MAX_LEGS - 1) * s.np + 1) & ~1;  // small np: room for the node vectors of k_leg_tree_down over the matrix buffers
   s.vec = take(8 * s.np + 16);
   s.iw = o;
   s.total_bytes = o * 8 + (2 * s.np + 8) * 4;

@@ -435,7 +435,7 @@ static void launch_pass(mpc_solver* s) {
 #undef MPC_TREE_LAUNCH
     });
     if (tree) s->timed(16, "k_leg_tree_down", [&] {
-      const TreeDesc& T = s->tree;  // (the node vectors of the down-sweep, 2 (MPC_MAX_LEGS - 1) np doubles, lie over the three matrix buffers: make_lx_lds)
+      const TreeDesc& T = s->tree;
       switch (s->lx.np) {
         case 16: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<16>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;
         case 32: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<32>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;

@@ -291,3 +291,24 @@ def test_tree_with_more_workgroups_than_cus(hip_lib):
         out[legs] = rec
     for a, b in zip(out[8], out[1]):
         assert _rel(a[0], b[0]) < 1e-8 and _rel(a[1], b[1]) < 1e-8 and _rel(a[2], b[2]) < 1e-8
+
+
+def test_ensemble_cold_solve_with_the_tree(hip_lib):
+    """Cold solves of a perturbed ensemble with 6 legs (tree over the cuts, odd level sizes): instances converge at different iterations
+    (their workgroups then leave every kernel at once) — the instances whose solve took as many iterations as with the serial sweep end
+    at the same point.  (Some instances of this ensemble stop at the round-off floor of the inner problem with a dual infeasibility
+    within 50 % of the tolerance — with the serial sweep too; which ones is decided at round-off level.)"""
+    from mpc_benchmark_amd.ensemble import EnsembleMPC
+    out = {}
+    for legs in (1, 6):
+        pd = FullDynamicsProblem(horizon=18, complete_model=False)
+        ens = EnsembleMPC(pd, batch=6, library=hip_lib, seed=3, sigma_q=0.01, sigma_v=0.02)
+        ens.options.riccati_legs = legs
+        ens.native.set_options(ens.options)
+        ens.prepare_schedule(4)
+        st = ens.cold_solve(max_iters=80)
+        r = ens.results()
+        out[legs] = (r["xs"].copy(), r["us"].copy(), [int(s.num_iters) for s in st], [bool(s.converged) for s in st])
+    same = [i for i in range(6) if out[1][2][i] == out[6][2][i] and out[1][3][i] == out[6][3][i]]
+    assert len(same) >= 3 and sum(out[6][3]) >= 4, (out[1][2], out[6][2], out[1][3], out[6][3])
+    assert _rel(out[6][0][same], out[1][0][same]) < 1e-7 and _rel(out[6][1][same], out[1][1][same]) < 1e-7
