@@ -383,6 +383,7 @@ def main():
                    "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "riccati_legs": legs, "tick_reuse": not args.no_tick_reuse, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
         "p50_ms_per_solve_batch1": p50_ms, "p50_riccati_legs": (args.latency_legs if args.legs != 1 else 1),
+        "riccati_cuts": ("chain (MPC_LEGS_CHAIN)" if os.environ.get("MPC_LEGS_CHAIN", "0") not in ("", "0") else "tree of pairwise compositions (csrc/legs_tree.h) from three legs on"),
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
         "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; the others are within 1e-4 of feasibility)" % (n_conv, args.batch),
         "instance_ticks_without_step": nostep["n"] * world, "diverged_instance_rescues": sum(getattr(e, "rescues", 0) for e in shards),

@@ -744,9 +744,19 @@ int mpc_kernel_info(mpc_solver* s, int32_t idx, char* name, int32_t name_cap, in
       const void* lk = s->lk.mp <= 16 ? (const void*)k_leg_knot<16> : (s->lk.mp <= 32 ? (const void*)k_leg_knot<32> : (const void*)k_leg_knot<48>);
       e.push_back({"k_leg_knot", lk, LK_THREADS, s->lk.total_bytes, (long long)L.N * L.B});
       e.push_back({"k_leg_condense", (const void*)k_leg_condense, LK_THREADS, s->lc.total_bytes, (long long)(J - 1) * L.B});
+      if (s->use_tree()) {
+        const TreeDesc T = make_tree_desc(J);
+        const void* lc = s->lx.np == 16 ? (const void*)k_leg_compose<16> : s->lx.np == 32 ? (const void*)k_leg_compose<32> : s->lx.np == 48 ? (const void*)k_leg_compose<48>
+                       : s->lx.np == 64 ? (const void*)k_leg_compose<64> : (const void*)k_leg_compose<80>;
+        const void* ld = s->lx.np == 16 ? (const void*)k_leg_tree_down<16> : s->lx.np == 32 ? (const void*)k_leg_tree_down<32> : s->lx.np == 48 ? (const void*)k_leg_tree_down<48>
+                       : s->lx.np == 64 ? (const void*)k_leg_tree_down<64> : (const void*)k_leg_tree_down<80>;
+        e.push_back({"k_leg_compose (first level of the tree over the cuts)", lc, LK_THREADS, s->lx.total_bytes, (long long)(T.lev_cnt[0] + 1) * L.B * 2});
+        e.push_back({"k_leg_tree_down (last level)", ld, LK_THREADS, s->lx.total_bytes, (long long)T.lev_cnt[0] * L.B});
+      } else {
       const void* lx = s->lx.np == 16 ? (const void*)k_leg_consensus<16> : s->lx.np == 32 ? (const void*)k_leg_consensus<32> : s->lx.np == 48 ? (const void*)k_leg_consensus<48>
                      : s->lx.np == 64 ? (const void*)k_leg_consensus<64> : (const void*)k_leg_consensus<80>;
       e.push_back({"k_leg_consensus", lx, LK_THREADS, s->lx.total_bytes, (long long)L.B});
+      }
       e.push_back({"k_leg_apply", (const void*)k_leg_apply, 256, 0, (long long)L.N * L.B});
       e.push_back({"k_forward_phi (forward sweeps of the legs)", L.m <= 32 ? (const void*)k_forward_phi<4, 10> : (const void*)k_forward_phi<6, 10>, 512, (int)(2 * L.n * sizeof(double)), (long long)L.B * J});
     } else if (s->use_mfma_riccati) {
