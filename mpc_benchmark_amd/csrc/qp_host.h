@@ -32,15 +32,17 @@ int mpc_qp_create(const mpc_qp_dims* dims, mpc_qp_solver** out) {
     HIP_OK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
     const size_t B = dims->batch, n = dims->n, neq = dims->neq, nin = dims->nin, m = nin + (dims->box ? n : 0);
     // matrices in LDS shorten one QP's dependent chain but halve the workgroups a CU can hold: only while every QP has a CU to itself
-    s->lds = make_qp_lds(dims->n, dims->neq, dims->nin, (int)m, dims->batch <= 256);
+    s->lds = make_qp_lds(dims->n, dims->neq, dims->nin, (int)m, dims->batch <= 256, getenv("MPC_QP_NO_MFMA") == nullptr);  // (MPC_QP_NO_MFMA: the column-by-column form, developer switch)
+    if (dims->n > 128) throw std::runtime_error("QP too large: more than 128 unknowns (the H mat-vec of the kernel takes two columns per lane)");
     if (s->lds.total_bytes > 160 * 1024) throw std::runtime_error("QP too large for the LDS of one workgroup (n (n + 1) + n neq + neq (neq + 1) doubles)");
     s->dH = s->alloc<double>(B * n * n); s->dg = s->alloc<double>(B * n); s->dA = s->alloc<double>(B * neq * n); s->db = s->alloc<double>(B * neq);
     s->dC = s->alloc<double>(B * nin * n); s->dl = s->alloc<double>(B * nin); s->du = s->alloc<double>(B * nin);
     s->dlb = s->alloc<double>(B * n); s->dub = s->alloc<double>(B * n);
     s->dx = s->alloc<double>(B * n); s->dy = s->alloc<double>(B * neq); s->dz = s->alloc<double>(B * m);
     s->dinfo = s->alloc<mpc_qp_info>(B);
-    HIP_OK(hipFuncSetAttribute((const void*)k_qp_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_OK(hipFuncSetAttribute((const void*)k_qp_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (const void* fn : {(const void*)k_qp_solve<0, false>, (const void*)k_qp_solve<1, false>, (const void*)k_qp_solve<0, true>, (const void*)k_qp_solve<1, true>,
+                           (const void*)k_qp_solve<2, true>})
+      HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds.total_bytes));  // (the kernels keep a static int beside the dynamic carve-out)
     HIP_OK(hipStreamSynchronize(s->stream));
   } catch (const std::exception& e) {
     fprintf(stderr, "mpc_qp_create: %s\n", e.what());
@@ -88,8 +90,12 @@ int mpc_qp_solve(mpc_qp_solver* s, const mpc_qp_settings* S, const double* H, co
     a.d = d; a.S = *S;
     a.H = s->dH; a.g = s->dg; a.A = s->dA; a.b = s->db; a.C = s->dC; a.l = s->dl; a.u = s->du; a.lb = s->dlb; a.ub = s->dub;
     a.x = s->dx; a.y = s->dy; a.z = s->dz; a.info = s->dinfo; a.lds = s->lds;
-    if (s->lds.mats) hipLaunchKernelGGL(k_qp_solve<true>, dim3(d.batch), dim3(QP_THREADS), s->lds.total_bytes, s->stream, a);
-    else hipLaunchKernelGGL(k_qp_solve<false>, dim3(d.batch), dim3(QP_THREADS), s->lds.total_bytes, s->stream, a);
+    const dim3 grid(d.batch), blk(QP_THREADS);
+    if (s->lds.mf && s->lds.mats == 1) hipLaunchKernelGGL((k_qp_solve<1, true>), grid, blk, s->lds.total_bytes, s->stream, a);
+    else if (s->lds.mf && s->lds.mats == 2) hipLaunchKernelGGL((k_qp_solve<2, true>), grid, blk, s->lds.total_bytes, s->stream, a);
+    else if (s->lds.mf) hipLaunchKernelGGL((k_qp_solve<0, true>), grid, blk, s->lds.total_bytes, s->stream, a);
+    else if (s->lds.mats) hipLaunchKernelGGL((k_qp_solve<1, false>), grid, blk, s->lds.total_bytes, s->stream, a);
+    else hipLaunchKernelGGL((k_qp_solve<0, false>), grid, blk, s->lds.total_bytes, s->stream, a);
     HIP_OK(hipGetLastError());
     HIP_OK(hipMemcpyAsync(x, s->dx, B * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     if (y && neq) HIP_OK(hipMemcpyAsync(y, s->dy, B * neq * sizeof(double), hipMemcpyDeviceToHost, s->stream));

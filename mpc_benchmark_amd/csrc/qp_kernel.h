@@ -2,27 +2,53 @@
 // 584-762): one workgroup per QP, the Newton matrices in LDS.  Same algorithm as oracle/qp.hpp (include/mpc_qp_abi.h):
 // proximal augmented Lagrangian with a bound-constrained-Lagrangian outer loop, semismooth Newton on the active rows with an
 // exact line search, Cholesky of the primal block P = H + rho I + C_I^T C_I / mu_in and of the equality Schur complement
-// S = mu_eq I + A P^-1 A^T.  First version: plain parallel loops (no MFMA) — the QPs of the 1 kHz loop are small (n = 62,
-// neq = 40, nin = 18) and the batch is the parallel dimension.
+// S = mu_eq I + A P^-1 A^T.  Two forms of the linear algebra of a Newton step: MF (problems whose padded matrices fit the LDS: the
+// reference's n = 62, neq = 40) — blocked Cholesky with pre-inverted 16 x 16 diagonal blocks, blocked triangular solves and the
+// Schur complement as tile products on the fp64 matrix cores (mfma_blocks.h, the building blocks of the Riccati sweep) — and the
+// first version's column-by-column VALU loops (two workgroup barriers per column) for everything larger.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/mpc_qp_abi.h"
 #include "solver_kernels.h"  // wave_sum, wave_max_nonneg
+#include "mfma_blocks.h"    // blocked Cholesky / triangular solves on the matrix cores
 
 #define QP_THREADS 256
 
-struct QpLds { int P, Y, S, vec, H, A, C, mats, total_bytes; };  // mats = 1: H, A, C are staged in LDS too
-static inline QpLds make_qp_lds(int n, int neq, int nin, int m, bool want_mats = true) {
+struct QpLds {
+  int P, Y, S, vec, H, A, C, mats, total_bytes;  // mats: 1 = H, A, C are staged in LDS too, 2 = A and C only
+  // MF form: padded dimensions (np, ep: multiples of 16 ; ncb: 16-column blocks of [A^T | r1]), leading dimensions, inverted diagonal blocks
+  int mf, np, ep, ncb, ldp, ldy, lds, LIp, LIs, ZD;
+};
+static inline QpLds make_qp_lds(int n, int neq, int nin, int m, bool want_mats = true, bool allow_mf = true) {
   QpLds s;
-  int o = 0;
-  auto take = [&](int c) { int r = o; o += (c + 1) & ~1; return r; };
-  s.P = take(n * (n + 1)); s.Y = take(n * (neq + 1)); s.S = take(neq * (neq + 1));
-  s.vec = take(9 * n + 6 * neq + 4 * m + 64);
-  const int base = o;
-  s.H = take(n * n); s.A = take(neq * n); s.C = take(nin * n);
-  s.mats = (want_mats && o * 8 <= 160 * 1024) ? 1 : 0;
-  if (!s.mats) o = base;
-  s.total_bytes = o * 8;
+  auto layout = [&](bool mf, int mats) {
+    int o = 0;
+    auto take = [&](int c) { int r = o; o += (c + 1) & ~1; return r; };
+    s.mf = mf ? 1 : 0;
+    s.np = (n + 15) & ~15; s.ep = (neq + 15) & ~15; s.ncb = (neq + 1 + 15) / 16;
+    if (mf) {
+      s.ldp = s.np + 1; s.ldy = 16 * s.ncb + 1; s.lds = 16 * s.ncb + 1;
+      s.P = take(s.np * s.ldp); s.LIp = take((s.np / 16) * 272); s.Y = take(s.np * s.ldy);
+      s.S = take(16 * s.ncb * s.lds); s.LIs = take((s.ep / 16) * 272); s.ZD = take((s.np > s.ep ? s.np : s.ep) * 17);
+    } else {
+      s.ldp = n + 1; s.ldy = neq + 1; s.lds = neq + 1; s.LIp = s.LIs = s.ZD = 0;
+      s.P = take(n * (n + 1)); s.Y = take(n * (neq + 1)); s.S = take(neq * (neq + 1));
+    }
+    s.vec = take(11 * n + 6 * neq + 4 * m + nin + 64);
+    s.H = s.A = s.C = 0;
+    if (mats == 1) s.H = take(n * n);
+    if (mats >= 1) { s.A = take(neq * n); s.C = take(nin * n); }
+    s.mats = mats;
+    s.total_bytes = o * 8;
+    return o * 8 + 64 <= 160 * 1024;
+  };
+  // preference: matrix-core form with all / some / none of the problem matrices in LDS, then the column-by-column form
+  const bool can_mf = allow_mf && neq > 0 && n >= 16;
+  if (can_mf && want_mats && layout(true, 1)) return s;
+  if (can_mf && want_mats && layout(true, 2)) return s;
+  if (can_mf && layout(true, 0)) return s;
+  if (want_mats && layout(false, 1)) return s;
+  layout(false, 0);
   return s;
 }
 
@@ -99,7 +125,8 @@ DEV bool qp_chol(double* M, int n, int ld, int* flag, int tid) {
   return true;
 }
 
-template <bool MATS>
+// MATS: 0 = H, A, C read from global memory, 1 = all three staged in LDS, 2 = A and C only ; MF: matrix-core linear algebra
+template <int MATS, bool MF>
 __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
   const int bi = blockIdx.x, tid = threadIdx.x, nthr = QP_THREADS;
   const int n = a.d.n, neq = a.d.neq, nin = a.d.nin, box = a.d.box, m = nin + (box ? n : 0);
@@ -110,15 +137,17 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
   const double* lb = box ? a.lb + (size_t)bi * n : nullptr; const double* ub = box ? a.ub + (size_t)bi * n : nullptr;
   double* xg = a.x + (size_t)bi * n; double* yg = a.y + (size_t)bi * neq; double* zg = a.z + (size_t)bi * m;
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int ldp = n + 1, lds_ = neq + 1, ldy = neq + 1;
+  const int ldp = a.lds.ldp, lds_ = a.lds.lds, ldy = a.lds.ldy;
   double *Pm = sm + a.lds.P, *Y = sm + a.lds.Y, *Sm = sm + a.lds.S, *v = sm + a.lds.vec;
+  const int np = a.lds.np, ep = a.lds.ep, ncb = a.lds.ncb, lane = tid & 63, wv = tid >> 6, nw = QP_THREADS >> 6;
+  double *LIp = sm + a.lds.LIp, *LIs = sm + a.lds.LIs, *ZD = sm + a.lds.ZD;
   // H, A, C: LDS copies when they fit (MATS; every mat-vec below then runs on LDS), else the global arrays (H through its
   // symmetric image so that neighbouring threads read neighbouring addresses)
-  const double* H = MATS ? sm + a.lds.H : Hg;
+  const double* H = MATS == 1 ? sm + a.lds.H : Hg;
   const double* A = MATS ? sm + a.lds.A : Ag;
   const double* C = MATS ? sm + a.lds.C : Cg;
+  if (MATS == 1) for (int i = tid; i < n * n; i += nthr) sm[a.lds.H + i] = Hg[i];
   if (MATS) {
-    for (int i = tid; i < n * n; i += nthr) sm[a.lds.H + i] = Hg[i];
     for (int i = tid; i < neq * n; i += nthr) sm[a.lds.A + i] = Ag[i];
     for (int i = tid; i < nin * n; i += nthr) sm[a.lds.C + i] = Cg[i];
   }
@@ -126,6 +155,9 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
   double *y = tmpn + n, *ye = y + neq, *yplus = ye + neq, *Ax = yplus + neq, *Ad = Ax + neq, *tmpe = Ad + neq;
   double *z = tmpe + neq, *zp = z + m, *s = zp + m, *ds = s + m;
   double* red = ds + m;  // 16
+  double* hx0 = red + 16;   // H x, kept up to date (H x += alpha H dx): H is read for ONE mat-vec per Newton step (global memory unless MATS == 1)
+  double* hdx = hx0 + n;    // H dx of the current step
+  int* actl = (int*)(hdx + n);  // active inequality rows of the current Newton step (nin ints)
   __shared__ int flag;
   auto lo = [&](int r) { return r < nin ? l[r] : lb[r - nin]; };
   auto hi = [&](int r) { return r < nin ? u[r] : ub[r - nin]; };
@@ -133,9 +165,22 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
     if (r >= nin) return xx[r - nin];
     double t = 0; for (int j = 0; j < n; ++j) t += C[r * n + j] * xx[j]; return t;
   };
+  auto h_times = [&](const double* vv, double* out) {  // out = H vv  (n <= 128)
+    const int c0 = lane < n ? lane : 0, c1 = lane + 64 < n ? lane + 64 : 0;
+    const double v0 = lane < n ? vv[c0] : 0.0, v1 = lane + 64 < n ? vv[c1] : 0.0;
+    for (int r0 = 4 * wv; r0 < n; r0 += 4 * nw) {
+      double hv[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const int r = r0 + q < n ? r0 + q : 0; hv[q][0] = H[r * n + c0]; hv[q][1] = H[r * n + c1]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const double sres = wave_sum(hv[q][0] * v0 + hv[q][1] * v1); if (lane == 0 && r0 + q < n) out[r0 + q] = sres; }
+    }
+  };
   for (int j = tid; j < n; j += nthr) x[j] = xg[j];
   for (int i = tid; i < neq; i += nthr) y[i] = yg[i];
   for (int r = tid; r < m; r += nthr) z[r] = zg[r];
+  __syncthreads();
+  h_times(x, hx0);
   __syncthreads();
   double mu_eq = S.mu_eq, mu_in = S.mu_in;
   double prim_tol = pow(0.1, S.alpha_bcl), inner_tol = 1.0;
@@ -153,8 +198,7 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
     for (int i = tid; i < neq; i += nthr) { double t = -b[i]; for (int j = 0; j < n; ++j) t += A[i * n + j] * x[j]; rp = fmax(rp, fabs(t)); }
     for (int r = tid; r < m; r += nthr) { const double sr = row_dot(r, x); rp = fmax(rp, fmax(sr - hi(r), lo(r) - sr)); }
     for (int j = tid; j < n; j += nthr) {
-      double t = g[j];
-      for (int k = 0; k < n; ++k) t += H[k * n + j] * x[k];
+      double t = g[j] + hx0[j];
       for (int i = 0; i < neq; ++i) t += A[i * n + j] * y[i];
       for (int r = 0; r < nin; ++r) t += C[r * n + j] * z[r];
       if (box) t += z[nin + j];
@@ -172,8 +216,7 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
       eval();
       double gn = 0;
       for (int j = tid; j < n; j += nthr) {
-        double t = g[j] + S.rho * (x[j] - xk[j]);
-        for (int k = 0; k < n; ++k) t += H[k * n + j] * x[k];
+        double t = g[j] + S.rho * (x[j] - xk[j]) + hx0[j];
         hx[j] = t;  // H x + g + rho (x - xk): reused by the line search
         for (int r = 0; r < nin; ++r) t += C[r * n + j] * zp[r];
         if (box) t += zp[nin + j];
@@ -185,6 +228,73 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
       gn = qp_block_max(gn, red, tid);
       if (gn <= inner_tol) break;
       iters_in += 1;
+      if constexpr (MF) {
+        // ---- matrix-core form.  P (np x np, symmetric, identity padding) ; Y = [A^T | r1 | 0] (np x 16 ncb, zero padding) ----
+        if (tid == 0) { int na_ = 0; for (int r = 0; r < nin; ++r) if (zp[r] != 0.0) actl[na_++] = r; flag = na_; }  // active inequality rows (few)
+        __syncthreads();
+        const int nact = flag;
+        for (int idx = tid; idx < np * np; idx += nthr) {
+          const int j = idx / np, k = idx % np;
+          double t = (j == k) ? 1.0 : 0.0;
+          if (j < n && k < n) {
+            t = H[j * n + k] + (j == k ? S.rho : 0.0);
+            for (int q = 0; q < nact; ++q) { const int r = actl[q]; t += C[r * n + j] * C[r * n + k] / mu_in; }
+            if (box && j == k && zp[nin + j] != 0.0) t += 1.0 / mu_in;
+          }
+          Pm[j * ldp + k] = t;
+        }
+        for (int idx = tid; idx < 16 * ncb * np; idx += nthr) {  // j fastest: A is read along its rows
+          const int i = idx / np, j = idx % np;
+          Y[j * ldy + i] = (j < n) ? ((i < neq) ? A[i * n + j] : (i == neq ? r1[j] : 0.0)) : 0.0;
+        }
+        __syncthreads();
+        if (!chol_blocked(Pm, ldp, np / 16, LIp, tid, &flag)) { status = 2; goto done; }
+        trsm_fwd_blocked(Pm, ldp, LIp, np / 16, Y, ldy, ncb, wv, nw, lane);   // [Y | w] <- L^-1 [A^T | r1]
+        __syncthreads();
+        for (int j = tid; j < n; j += nthr) w[j] = Y[j * ldy + neq];
+        // G = [Y | w]^T [Y | w] (lower block triangle): S = mu_eq I + G[:neq, :neq], Y^T w = G[neq, :neq]
+        {
+          const int nst = ncb * (ncb + 1) / 2;
+          for (int t = wv; t < nst; t += nw) {
+            int ri = 0, rem = t;
+            while (rem > ri) { rem -= ri + 1; ++ri; }
+            d4_t acc = d4_t{0, 0, 0, 0};
+            mma_tile<false>(acc, Y + ri * 16, 1, ldy, Y + rem * 16, ldy, 1, np, lane);
+            tile_store(Sm + (ri * 16) * lds_ + rem * 16, lds_, acc, lane);
+          }
+        }
+        __syncthreads();
+        for (int i = tid; i < neq; i += nthr) yplus[i] = Sm[neq * lds_ + i] + Ax[i] + mu_eq * y[i];  // row neq of G (lower triangle: column index i <= neq)
+        __syncthreads();
+        for (int idx = tid; idx < ep * ep; idx += nthr) {  // S proper: mu_eq on the diagonal, identity padding, symmetric image
+          const int i = idx / ep, k = idx % ep;
+          if (k <= i) {
+            const double t = (i < neq) ? Sm[i * lds_ + k] + (i == k ? mu_eq : 0.0) : (i == k ? 1.0 : 0.0);
+            Sm[i * lds_ + k] = t;
+          }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < ep * ep; idx += nthr) { const int i = idx / ep, k = idx % ep; if (k > i) Sm[i * lds_ + k] = Sm[k * lds_ + i]; }
+        for (int idx = tid; idx < ep * 16; idx += nthr) { const int i = idx >> 4, c = idx & 15; ZD[i * 17 + c] = (c == 0 && i < neq) ? yplus[i] : 0.0; }
+        __syncthreads();
+        if (!chol_blocked(Sm, lds_, ep / 16, LIs, tid, &flag)) { status = 2; goto done; }
+        trsm_fwd_blocked(Sm, lds_, LIs, ep / 16, ZD, 17, 1, wv, nw, lane);
+        trsm_bwd_blocked(Sm, lds_, LIs, ep / 16, ZD, 17, 1, wv, nw, lane);   // (one column block: wavefront 0, its LDS operations in order)
+        __syncthreads();
+        for (int i = tid; i < neq; i += nthr) yplus[i] = ZD[i * 17];
+        __syncthreads();
+        for (int idx = tid; idx < np * 16; idx += nthr) {
+          const int j = idx >> 4, c = idx & 15;
+          double t = 0.0;
+          if (c == 0 && j < n) { t = w[j]; for (int i = 0; i < neq; ++i) t -= Y[j * ldy + i] * yplus[i]; }
+          ZD[j * 17 + c] = t;
+        }
+        __syncthreads();
+        trsm_bwd_blocked(Pm, ldp, LIp, np / 16, ZD, 17, 1, wv, nw, lane);    // dx = L^-T (w - Y yplus)
+        __syncthreads();
+        for (int j = tid; j < n; j += nthr) dx[j] = ZD[j * 17];
+        __syncthreads();
+      } else {
       // ---- primal block P = H + rho I + active rows / mu_in (lower triangle), Y = A^T ----
       for (int idx = tid; idx < n * n; idx += nthr) {
         const int j = idx / n, k = idx % n;
@@ -225,14 +335,13 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
       __syncthreads();
       if (tid < 64) qp_bwd_wave(Pm, n, ldp, dx, tid);
       __syncthreads();
+      }
       // ---- exact line search along dx ----
       for (int r = tid; r < m; r += nthr) ds[r] = row_dot(r, dx);
+      h_times(dx, hdx);
+      __syncthreads();
       double pa0 = 0, pa1 = 0, pe0 = 0, pe1 = 0;
-      for (int j = tid; j < n; j += nthr) {
-        double t = S.rho * dx[j];
-        for (int k = 0; k < n; ++k) t += H[k * n + j] * dx[k];
-        pa0 += dx[j] * hx[j]; pa1 += dx[j] * t;
-      }
+      for (int j = tid; j < n; j += nthr) { pa0 += dx[j] * hx[j]; pa1 += dx[j] * (S.rho * dx[j] + hdx[j]); }
       for (int i = tid; i < neq; i += nthr) { double t = 0; for (int j = 0; j < n; ++j) t += A[i * n + j] * dx[j]; pe0 += t * ye[i]; pe1 += t * t / mu_eq; }
       const double lin = qp_block_sum(pa0 + pe0, red, tid), quad = qp_block_sum(pa1 + pe1, red, tid);
       // root of the increasing piecewise-linear phi' by ONE wavefront (safeguarded Newton; no workgroup barrier per trial)
@@ -258,7 +367,7 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
       __syncthreads();
       const double alpha = red[15];
       double stepn = 0, xn = 1.0;
-      for (int j = tid; j < n; j += nthr) { stepn = fmax(stepn, fabs(alpha * dx[j])); xn = fmax(xn, fabs(x[j])); x[j] += alpha * dx[j]; }
+      for (int j = tid; j < n; j += nthr) { stepn = fmax(stepn, fabs(alpha * dx[j])); xn = fmax(xn, fabs(x[j])); x[j] += alpha * dx[j]; hx0[j] += alpha * hdx[j]; }
       stepn = qp_block_max(stepn, red, tid);
       xn = qp_block_max(xn, red, tid);
       __syncthreads();
