@@ -478,7 +478,7 @@ static void launch_pass(mpc_solver* s) {
     });
   }
   }
-  s->timed(5, "k_duals", [&] { hipLaunchKernelGGL(k_duals, dim3(L.N + 1, L.B), dim3(256), (L.nz + 3 * L.n + 16) * sizeof(double), s->stream, a); });
+  s->timed(5, "k_duals", [&] { hipLaunchKernelGGL(k_duals, dim3(L.N + 1, L.B), dim3(256), (L.nz + 3 * L.n + 16 + 3 * L.c) * sizeof(double), s->stream, a); });
   // linesearch: evaluate the full step first; the backtracking candidates alpha = 2^-i, i >= 1, are only
   // evaluated for instances whose full step failed the Armijo test (their workgroups exit immediately otherwise)
   s->timed(6, "k_eval_stage_trial", [&] { launch_eval(s, true, 0, 1, a.spec_on != 0); });
@@ -764,7 +764,7 @@ int mpc_kernel_info(mpc_solver* s, int32_t idx, char* name, int32_t name_cap, in
                      : s->ric.sq ? (const void*)k_riccati_mfma<RIC_THREADS, 96, true> : s->ric.np <= 80 ? (const void*)k_riccati_mfma<RIC_THREADS, 80> : (const void*)k_riccati_mfma<RIC_THREADS, 96>;
       e.push_back({"k_riccati_mfma (serial sweep)", fn, small ? RIC_SMALL_THREADS : RIC_THREADS, s->ric.total_bytes, (long long)L.B});
     } else e.push_back({"k_riccati_backward (serial sweep, no matrix cores)", (const void*)k_riccati_backward, 256, (int)s->riccati_lds(), (long long)L.B});
-    e.push_back({"k_duals", (const void*)k_duals, 256, (int)((L.nz + 3 * L.n + 16) * sizeof(double)), (long long)(L.N + 1) * L.B});
+    e.push_back({"k_duals", (const void*)k_duals, 256, (int)((L.nz + 3 * L.n + 16 + 3 * L.c) * sizeof(double)), (long long)(L.N + 1) * L.B});
     e.push_back({"k_lagrangian", (const void*)k_lagrangian, 64, 0, (long long)(L.N + 1) * L.B});
     if (idx < 0 || idx >= (int)e.size()) return (int)e.size();
     const Ent& k = e[idx];

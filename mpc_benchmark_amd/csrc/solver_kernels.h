@@ -584,7 +584,7 @@ __global__ void __launch_bounds__(512) k_forward_prefetch(SolverArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // P7 (cont.): multiplier steps and the merit directional derivative, parallel over knots.
-// grid (N+1, B), block 256, LDS (nz + 3 n + 16) doubles
+// grid (N+1, B), block 256, LDS (nz + 3 n + 16 + 3 c) doubles
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_duals(SolverArgs a) {
   const Layout& L = a.L;
@@ -609,6 +609,14 @@ __global__ void __launch_bounds__(256) k_duals(SolverArgs a) {
   for (int z = tid; z < n + m; z += nthr) dz[z] = (z < n) ? a.dxs[((size_t)b * (N + 1) + k) * n + z] : a.dus[((size_t)b * N + k) * L.m + z - n];
   if (k < N) for (int z = tid; z < n; z += nthr) dxn[z] = a.dxs[((size_t)b * (N + 1) + k + 1) * n + z];
   __syncthreads();
+  // per-row scalars of the constraint block (active flag, shifted value / mu, multiplier): one coalesced load per thread up front — read
+  // row by row from global memory they are three dependent round trips per row, and most rows are inactive (nothing else to do)
+  double* rsc = part + nw + 2;  // [3][L.c]
+  for (int i = tid; i < L.c; i += nthr) {
+    const bool in = i < c;
+    rsc[i] = in ? kn[L.oACT + i] : 0.0; rsc[L.c + i] = in ? kn[L.oDT + i] / mu : 0.0; rsc[2 * L.c + i] = in ? v[i] : 0.0;
+  }
+  __syncthreads();
   double acc = 0.0;  // lane 0 of every wavefront accumulates the rows of that wavefront
   if (wv == 0) {     // cost gradient part
     double s = 0;
@@ -619,18 +627,18 @@ __global__ void __launch_bounds__(256) k_duals(SolverArgs a) {
   for (int i = wv; i < L.c; i += nw) {
     if (i >= c) { if (lane == 0) dv[i] = 0.0; continue; }
     double s = 0, jd = 0;
-    const bool act = kn[L.oACT + i] != 0.0;
-    const double vp = kn[L.oDT + i] / mu;
-    const double wj = vp + (act ? (vp - v[i]) : 0.0);  // weight of the row's directional derivative in the merit slope
+    const bool act = rsc[i] != 0.0;
+    const double vp = rsc[L.c + i], vi = rsc[2 * L.c + i];
+    const double wj = vp + (act ? (vp - vi) : 0.0);  // weight of the row's directional derivative in the merit slope
     if (act)  // the sweep writes the dual gains of active rows only (inactive: dv = -v)
       for (int z = lane; z < n; z += 64) s += g[L.oKnu + i * n + z] * dz[z];
     if (wj != 0.0)  // an inactive row with a zero projection does not enter the slope: its Jacobian row is not read
       for (int z = lane; z < n + m; z += 64) jd += kn[L.oCD + i * nz + z] * dz[z];
     s = wave_sum(s) + g[L.oknu + i];
     jd = wave_sum(jd);
-    const double dvi = s - v[i];
+    const double dvi = s - vi;
     if (lane == 0) dv[i] = dvi;
-    acc += wj * jd - mu * (vp - v[i]) * dvi;
+    acc += wj * jd - mu * (vp - vi) * dvi;
   }
   if (k == 0) for (int i = tid; i < n; i += nthr) a.dlams[(size_t)b * (N + 1) * n + i] = 0.0;
   if (k < N) {
