@@ -9,6 +9,8 @@ pd = FullDynamicsProblem(horizon=100, complete_model=True)
 sq, sv = float(sys.argv[1]), float(sys.argv[2])
 ens = EnsembleMPC(pd, batch=64, library=lib, seed=20250304, sigma_q=sq, sigma_v=sv, perturb_dofs=(range(18, pd.nv) if len(sys.argv) > 3 and sys.argv[3] == 'upper' else None),
                   closed_loop=((10, pd.dt / 10) if 'closed' in sys.argv else None))
+if os.environ.get("LEGS"):
+    ens.options.riccati_legs = int(os.environ["LEGS"]); ens.native.set_options(ens.options)
 ens.prepare_schedule(400)
 st = ens.cold_solve(max_iters=100)
 print("sigma", sq, sv, "cold converged", sum(bool(s.converged) for s in st), "cost med %.1f max %.1f" % (np.median([s.traj_cost for s in st]), max(s.traj_cost for s in st)))
