@@ -347,7 +347,7 @@ def main():
 
     # ---- CPU baseline: the oracle (a port, not Aligator) on this host's cores, bounded sample ----
     cpu = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: the multi-GPU runs of the same session would time the same host cores again)
         from tests import _oracle
         cores = os.cpu_count() or 1
         opd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
