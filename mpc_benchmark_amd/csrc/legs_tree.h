@@ -139,8 +139,12 @@ DEV NodeRef tree_node_ref(const SolverArgs& a, const TreeDesc& T, int b, int nod
 //   role 1: Gauss-Jordan on [Mt | Sg_a]        -> T2     ;  Zt, Sg_ab, E            (nothing to do when b holds the last leg)
 // (both eliminate the same Mt: the elimination is two thirds of a composition, and its cost is the number of columns a wavefront owns)
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef LCMP_THREADS
+#define LCMP_THREADS 512  // 8 wavefronts (measured with 1024 — every 16th column, 11 slots per wavefront, 128 VGPRs: 128 B of spills, dearer barriers: 0.502 against 0.507 ms for four levels, the centroidal problem slower)
+#endif
 template <int NP>
-__global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds S, TreeDesc T, int level) {
+__global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLds S, TreeDesc T, int level) {
+  constexpr int NWC = LCMP_THREADS / 64, LCT = (25 + NWC - 1) / NWC, LCS = (15 + NWC - 1) / NWC;  // wavefronts ; tiles / lower-triangle tiles per wavefront (nb <= 5)
   const Layout& L = a.L;
   const int b = blockIdx.y, nthr = blockDim.x, nw = nthr >> 6;
   int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,7 +170,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
   double *pb = vec, *rv = vec + np, *uu = vec + 2 * np, *fcol = vec + 4 * np;  // p_b | right-hand side / t3 | u | 1 / pivots
   int* perm = (int*)(sm + S.iw);
   int* used = perm + np;
-  d4_t res[LC_TILES];
+  d4_t res[LCT];
   // ---- X <- Sg_a ; Y <- D = P_b - Pg (Pg: lcP of the leg that ends at the cut, read by both roles) ; ldP <- D ----
   {
     double pv[LK_PT], po[LK_PT];
@@ -199,13 +203,13 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
     if (lane == 0) rv[i] = (i < n) ? s + A.sg[i] : 0.0;
   }
 #pragma unroll
-  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+  for (int sidx = 0; sidx < LCT; ++sidx) {
     const int t = wv + sidx * nw;
     res[sidx] = d4_t{0, 0, 0, 0};
     if (t < nb * nb) mma_tile<true>(res[sidx], X + ((t / nb) * 16) * ldp, ldp, 1, Y + (t % nb) * 16, ldp, 1, np, lane);
   }
 #pragma unroll
-  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+  for (int sidx = 0; sidx < LCT; ++sidx) {
     const int t = wv + sidx * nw;
     if (t < nb * nb) {
       const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
   // registers: as in k_leg_consensus (a lane is a row, a wavefront owns every 8th column, the owner of the pivot column leaves the
   // elimination factors in LDS, one barrier per column) ----
   {
-    constexpr int GJ_SLOTS = (2 * NP + 1 + 7) / 8;
+    constexpr int GJ_SLOTS = (2 * NP + 1 + NWC - 1) / NWC;
     double* dinv = fcol;
     int* iperm = used;
     double* fbuf = Z;                 // [2][128], double-buffered: Mt is dead once the tableau is in registers (Y keeps D for role 1)
@@ -230,7 +234,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
     double tq[2][GJ_SLOTS];
 #pragma unroll
     for (int sl = 0; sl < GJ_SLOTS; ++sl) {
-      const int cc = 8 * sl + wv;
+      const int cc = NWC * sl + wv;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int r = lane + 64 * h;
@@ -242,9 +246,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
     bool used0 = false, used1 = false;
     LEG_BARRIER();
 #pragma unroll
-    for (int so = 0; so < NP / 8; ++so) {
-      for (int ow = 0; ow < 8; ++ow) {  // nw == 8
-        const int col = 8 * so + ow;
+    for (int so = 0; so < (NP + NWC - 1) / NWC; ++so) {
+      for (int ow = 0; ow < NWC; ++ow) {  // nw == NWC
+        const int col = NWC * so + ow;
         if (col >= n) break;
         double* fb = fbuf + (col & 1) * 128;
         if (wv == ow) {
@@ -286,7 +290,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
     LEG_BARRIER();
 #pragma unroll
     for (int sl = 0; sl < GJ_SLOTS; ++sl) {
-      const int cc = 8 * sl + wv;
+      const int cc = NWC * sl + wv;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int r = lane + 64 * h;
@@ -307,14 +311,14 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
     // ======== role 1: X = T2, Y = D, Z = Lm_b ;  Zt = T2 Lm_b (out, then over T2) ; Sg_ab = Sg_b + Lm_b^T Zt ; E = D Zt + Lm_b ========
     LEG_BARRIER();
 #pragma unroll
-    for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+    for (int sidx = 0; sidx < LCT; ++sidx) {
       const int t = wv + sidx * nw;
       res[sidx] = d4_t{0, 0, 0, 0};
       if (t < nb * nb) mma_tile<false>(res[sidx], X + ((t / nb) * 16) * ldp, ldp, 1, Z + (t % nb) * 16, ldp, 1, np, lane);
     }
     LEG_BARRIER();
 #pragma unroll
-    for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+    for (int sidx = 0; sidx < LCT; ++sidx) {
       const int t = wv + sidx * nw;
       if (t < nb * nb) {
         const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
@@ -326,7 +330,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
     LEG_BARRIER();
     const int nst = nb * (nb + 1) / 2;
 #pragma unroll
-    for (int sidx = 0; sidx < LC_STILES; ++sidx) {  // Sg_ab: lower block triangle, mirrored
+    for (int sidx = 0; sidx < LCS; ++sidx) {  // Sg_ab: lower block triangle, mirrored
       const int t = wv + sidx * nw;
       if (t < nst) {
         int ri = 0, rem = t;
@@ -344,7 +348,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
       }
     }
 #pragma unroll
-    for (int sidx = 0; sidx < LC_TILES; ++sidx) {  // E = Lm_b + D Zt
+    for (int sidx = 0; sidx < LCT; ++sidx) {  // E = Lm_b + D Zt
       const int t = wv + sidx * nw;
       if (t < nb * nb) {
         const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
@@ -365,7 +369,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
   LEG_BARRIER();
   // Lm_ab = T1^T Lm_b (out) ; sg_ab = sg_b + Lm_b^T t3
 #pragma unroll
-  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+  for (int sidx = 0; sidx < LCT; ++sidx) {
     const int t = wv + sidx * nw;
     if (t < nb * nb) {
       const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
@@ -387,7 +391,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
   leg_load_mat<false>(Z, ldp, np, lrc + L.ldP, n, tid, nthr, S.mg_np);
   LEG_BARRIER();
 #pragma unroll
-  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+  for (int sidx = 0; sidx < LCT; ++sidx) {
     const int t = wv + sidx * nw;
     res[sidx] = d4_t{0, 0, 0, 0};
     if (t < nb * nb) mma_tile<false>(res[sidx], Z + ((t / nb) * 16) * ldp, ldp, 1, Y + (t % nb) * 16, ldp, 1, np, lane);
@@ -400,7 +404,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
   }
   LEG_BARRIER();
 #pragma unroll
-  for (int sidx = 0; sidx < LC_TILES; ++sidx) {
+  for (int sidx = 0; sidx < LCT; ++sidx) {
     const int t = wv + sidx * nw;
     if (t < nb * nb) {
       const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
@@ -415,9 +419,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
   LEG_BARRIER();
   {
     const int nst = nb * (nb + 1) / 2;
-    d4_t pres[LC_STILES];
+    d4_t pres[LCS];
 #pragma unroll
-    for (int sidx = 0; sidx < LC_STILES; ++sidx) {
+    for (int sidx = 0; sidx < LCS; ++sidx) {
       const int t = wv + sidx * nw;
       pres[sidx] = d4_t{0, 0, 0, 0};
       if (t < nst) {
@@ -436,7 +440,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_compose(SolverArgs a, LxLds 
       if (lane == 0) out[L.tp + i] = s + A.p[i];
     }
 #pragma unroll
-    for (int sidx = 0; sidx < LC_STILES; ++sidx) {
+    for (int sidx = 0; sidx < LCS; ++sidx) {
       const int t = wv + sidx * nw;
       if (t < nst) {
         int ri = 0, rem = t;

@@ -424,7 +424,7 @@ static void launch_pass(mpc_solver* s) {
     if (tree) s->timed(14, "k_leg_consensus", [&] {
       const TreeDesc& T = s->tree;
 #define MPC_TREE_LAUNCH(NPV) do { \
-        for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL(k_leg_compose<NPV>, dim3(T.lev_cnt[lev] + 1, L.B, 2), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); } while (0)
+        for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL(k_leg_compose<NPV>, dim3(T.lev_cnt[lev] + 1, L.B, 2), dim3(LCMP_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); } while (0)
       switch (s->lx.np) {
         case 16: MPC_TREE_LAUNCH(16); break;
         case 32: MPC_TREE_LAUNCH(32); break;
@@ -750,7 +750,7 @@ int mpc_kernel_info(mpc_solver* s, int32_t idx, char* name, int32_t name_cap, in
                        : s->lx.np == 64 ? (const void*)k_leg_compose<64> : (const void*)k_leg_compose<80>;
         const void* ld = s->lx.np == 16 ? (const void*)k_leg_tree_down<16> : s->lx.np == 32 ? (const void*)k_leg_tree_down<32> : s->lx.np == 48 ? (const void*)k_leg_tree_down<48>
                        : s->lx.np == 64 ? (const void*)k_leg_tree_down<64> : (const void*)k_leg_tree_down<80>;
-        e.push_back({"k_leg_compose (first level of the tree over the cuts)", lc, LK_THREADS, s->lx.total_bytes, (long long)(T.lev_cnt[0] + 1) * L.B * 2});
+        e.push_back({"k_leg_compose (first level of the tree over the cuts)", lc, LCMP_THREADS, s->lx.total_bytes, (long long)(T.lev_cnt[0] + 1) * L.B * 2});
         e.push_back({"k_leg_tree_down (last level)", ld, LK_THREADS, s->lx.total_bytes, (long long)T.lev_cnt[0] * L.B});
       } else {
       const void* lx = s->lx.np == 16 ? (const void*)k_leg_consensus<16> : s->lx.np == 32 ? (const void*)k_leg_consensus<32> : s->lx.np == 48 ? (const void*)k_leg_consensus<48>
