@@ -120,6 +120,17 @@ DEV void knot_merit(const Layout& L, double* kn, int c, const double* f, const d
   __syncthreads();
 }
 
+// Tick reuse, appended knot: its record is the speculative one of the previous tick — from the spare slot to its place in the ring
+// (the slot knot 0 has just left).  grid (32, B), block 256: 32 workgroups share the 220 KB of a record
+__global__ void __launch_bounds__(256) k_copy_spec(SolverArgs a) {
+  const Layout& L = a.L;
+  const int b = blockIdx.y;
+  if (a.inst[b].done || !knot_reused(a, b, L.N - 1)) return;
+  const double* sp = a.spec_knot + (size_t)b * L.knot_stride;
+  double* kn = knot_ptr(a, b, L.N - 1);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < L.knot_stride; i += 32 * 256) kn[i] = sp[i];
+}
+
 // Tick reuse: the record of a reused knot holds the evaluation of the current point already (written by the full-step
 // candidate of the previous tick); only what depends on the multipliers — projections, active flags, penalty,
 // infeasibility — is refreshed here, exactly as the tail of the stage kernel does.  grid (N+1, B), block 256

@@ -216,7 +216,13 @@ template <int TRIAL>
 __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, Layout KL, double* records, MbArgs mb, int cand0) {
   const Layout& L = a.L;
   const MbLds& S = mb.lds;
-  const int k = blockIdx.x, b = blockIdx.y, nthr = blockDim.x;
+  // TRIAL == 3 with one workgroup more per instance (blockIdx.x == N + 1): the SPECULATIVE evaluation of the knot the next tick appends —
+  // the accepted terminal state as a running stage with the table of the current last stage and the last control (what the warm-start
+  // shift makes of it).  Its record goes to a spare slot (a.spec_knot) ; if the table of the appended stage turns out to be that one
+  // (mpc_cycle compares), the next tick takes it as knot N - 1 instead of evaluating it (k_reproject, knot_reused).
+  const bool specw = TRIAL == 3 && (int)blockIdx.x == a.L.N + 1;
+  const int k = specw ? a.L.N - 1 : (int)blockIdx.x;  // stage table, control, multipliers
+  const int b = blockIdx.y, nthr = blockDim.x;
   int cand = blockIdx.z + cand0;
   int tid = threadIdx.x;
   const InstState& st = a.inst[b];
@@ -241,9 +247,9 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   const bool derivs = (TRIAL == 0 || TRIAL == 3);
 cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of the same knot)
   const double alpha = CAND ? ldexp(1.0, -cand) : 0.0;
-  const size_t wg = (TRIAL == 1) ? (((size_t)b * L.n_alpha + cand) * (N + 1) + k) : ((size_t)b * (N + 1) + knot_slot(a, k));
-  double* kn = records + wg * KL.knot_stride;
-  double* scr = mb.scratch + (derivs ? wg : 0) * mb.scratch_stride;  // value-only passes never touch it
+  const size_t wg = (TRIAL == 1) ? (((size_t)b * L.n_alpha + cand) * (N + 1) + k) : (specw ? (size_t)L.B * (N + 1) + b : ((size_t)b * (N + 1) + knot_slot(a, k)));
+  double* kn = specw ? a.spec_knot + (size_t)b * KL.knot_stride : records + wg * KL.knot_stride;
+  double* scr = mb.scratch + (derivs ? wg : 0) * mb.scratch_stride;  // value-only passes never touch it (B (N + 1) + B slots)
   double* dsol = scr;                         // [nK][nz]: rows < nv = da, rows >= nv = dlam
   double* JtG = scr + (size_t)(nv + 12) * L.nz;  // [24][nz] HBM fallback for dense (non-diagonal) weights
   double* WJ = JtG + (size_t)24 * L.nz;
@@ -294,13 +300,14 @@ cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of th
   long long t0_ = clock64();
   // ---- P0: evaluation point, tree tables ---------------------------------------------------------------
   {
-    const double* xs = a.xs + ((size_t)b * (N + 1) + k) * nx;
-    const double* dx = a.dxs + ((size_t)b * (N + 1) + k) * n;
+    const int kx = specw ? N : k;  // state (the speculative knot: the terminal state, which the shift duplicates: its next state is the same one)
+    const double* xs = a.xs + ((size_t)b * (N + 1) + kx) * nx;
+    const double* dx = a.dxs + ((size_t)b * (N + 1) + kx) * n;
     if (TRIAL == 2) {
       for (int i = tid; i < nx; i += nthr) { x[i] = xs[i]; xn[i] = xs[i]; }  // simulated state ; xn = xs[0], the feedback reference
     } else if (CAND) {
       if (wv == 0) state_integrate_group(MPC_SPACE_MULTIBODY, nx, n, xs, dx, alpha, x, lane, 64);
-      if (wv == 1 && k < N) state_integrate_group(MPC_SPACE_MULTIBODY, nx, n, xs + nx, dx + n, alpha, xn, lane, 64);
+      if (wv == 1 && k < N) state_integrate_group(MPC_SPACE_MULTIBODY, nx, n, specw ? xs : xs + nx, specw ? dx : dx + n, alpha, xn, lane, 64);
     } else {
       for (int i = tid; i < nx; i += nthr) { x[i] = xs[i]; if (k < N) xn[i] = xs[nx + i]; }
     }
@@ -1303,7 +1310,7 @@ sim_loop:
   knot_merit(KL, kn, c, (k < N) ? kn + KL.oF : nullptr, a.vs + vo, CAND ? a.dvs + vo : nullptr, a.vs_e + vo,
              a.lams + lo, CAND ? a.dlams + lo : nullptr, a.lams_e + lo, alpha, mu, mud, derivs, red, pen, prim, tid, nthr);
   if (tid == 0) {
-    if (CAND) a.trial_phi[((size_t)b * L.n_alpha + cand) * (N + 1) + k] = s_cost + pen;
+    if (CAND && !specw) a.trial_phi[((size_t)b * L.n_alpha + cand) * (N + 1) + k] = s_cost + pen;
     if (TRIAL == 0 || TRIAL == 3) {
       double* ms = kn + KL.oMISC;
       ms[MISC_COST] = s_cost; ms[MISC_PEN] = pen; ms[MISC_PRIM] = prim; ms[MISC_NC] = (double)c; ms[MISC_M] = (double)m;
@@ -1344,7 +1351,7 @@ static inline void launch_eval_multibody(hipStream_t stream, const SolverArgs& a
     attr_bytes.store(mb.lds.total_bytes + 1);  // + 1: the zero-initialised slots mean "not set"
   }
   if (sim_substeps > 0) hipLaunchKernelGGL(k_eval_multibody<2>, dim3(1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, 0);
-  else if (trial && with_derivs) hipLaunchKernelGGL(k_eval_multibody<3>, dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);  // records = the knot records
+  else if (trial && with_derivs) hipLaunchKernelGGL(k_eval_multibody<3>, dim3(L.N + 1 + (a.spec_knot ? 1 : 0), L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);  // records = the knot records (+ the speculative knot)
   else if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
   else hipLaunchKernelGGL(k_eval_multibody<1>, dim3(L.N + 1, L.B, mb.ncand_loop > 0 ? 1 : ncand), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
 }

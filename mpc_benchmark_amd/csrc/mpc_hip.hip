@@ -56,6 +56,10 @@ struct mpc_solver {
   int async_passes = 0;
   // tick reuse (mpc_set_tick_reuse): see SolverArgs
   bool tick_reuse = false, reuse_this_pass = false;
+  // speculative evaluation of the appended knot (eval_multibody.h): the spare records hold one made with the table of the then last
+  // stage (spec_rec_valid) ; the stage appended since is that table (spec_next_pending, set by mpc_cycle) ; this pass may use it
+  double* d_spec_knot = nullptr;
+  bool spec_rec_valid = false, spec_next_pending = false, spec_next_now = false;
   int khead = 0;
   int* d_spec = nullptr;
   // asynchronous ticks (mpc_run_shifted_async / mpc_wait): status snapshots in pinned host memory, one event each; up to
@@ -142,6 +146,7 @@ struct mpc_solver {
     a.spec_on = (tick_reuse && opt.max_iters == 1 && L.space == MPC_SPACE_MULTIBODY) ? 1 : 0;
     a.reuse_on = (a.spec_on && reuse_this_pass) ? 1 : 0;
     a.reuse_k0 = perfect_feedback ? 1 : 0;
+    a.spec_knot = a.spec_on ? d_spec_knot : nullptr; a.spec_next = (a.reuse_on && spec_next_now) ? 1 : 0;
     a.nlegs = eff_legs(); a.legbuf = d_legbuf; a.treebuf = d_treebuf; a.leg_guess = leg_guess_now;
     a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = phase_timers ? d_prof : nullptr;
     return a;
@@ -335,7 +340,10 @@ static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_des
 }
 
 // tick reuse: whatever changes the problem or the iterate behind the solver's back invalidates the kept records
-static void spec_clear(mpc_solver* s) { if (s->d_spec) HIP_OK(hipMemsetAsync(s->d_spec, 0, s->L.B * sizeof(int), s->stream)); }
+static void spec_clear(mpc_solver* s) {
+  if (s->d_spec) HIP_OK(hipMemsetAsync(s->d_spec, 0, s->L.B * sizeof(int), s->stream));
+  s->spec_rec_valid = s->spec_next_pending = s->spec_next_now = false;
+}
 
 // warm-start shift of the iterate (k_shift): from the current pair of buffers into the other one, which becomes the current pair
 static void launch_shift(mpc_solver* s) {
@@ -365,9 +373,11 @@ static void launch_eval(mpc_solver* s, bool trial, int cand0 = 0, int ncand = 1,
 static void launch_pass(mpc_solver* s) {
   const Layout& L = s->L;
   SolverArgs a = s->args();
+  if (a.spec_next) hipLaunchKernelGGL(k_copy_spec, dim3(32, L.B), dim3(256), 0, s->stream, a);  // the appended knot: evaluated speculatively by the previous tick
   s->timed(0, "k_eval_stage", [&] { launch_eval(s, false); });
   if (a.reuse_on) hipLaunchKernelGGL(k_reproject, dim3(L.N + 1, L.B), dim3(256), 0, s->stream, a);  // records kept from the last tick: fresh projections
   s->reuse_this_pass = false;  // further passes of the same run evaluate everything
+  s->spec_next_now = false;
   s->timed(1, "k_lagrangian", [&] { hipLaunchKernelGGL(k_lagrangian, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   s->timed(2, "k_decide", [&] { hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(128), 0, s->stream, a); });
   // forward sweep: closed-loop transitions Phi / phi for all knots in parallel, then one mat-vec per knot (closed_loop.h);
@@ -482,6 +492,7 @@ static void launch_pass(mpc_solver* s) {
   // linesearch: evaluate the full step first; the backtracking candidates alpha = 2^-i, i >= 1, are only
   // evaluated for instances whose full step failed the Armijo test (their workgroups exit immediately otherwise)
   s->timed(6, "k_eval_stage_trial", [&] { launch_eval(s, true, 0, 1, a.spec_on != 0); });
+  s->spec_rec_valid = a.spec_on != 0 && a.spec_knot != nullptr;  // (per instance it counts only if the full step is accepted: a.spec[b])
   s->timed(7, "k_linesearch", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(64), 0, s->stream, a, 1); });
   s->timed(10, "k_eval_stage_backtrack", [&] { launch_eval(s, true, 1, L.n_alpha - 1); });
   s->timed(11, "k_linesearch_backtrack", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(64), 0, s->stream, a, 0); });
@@ -633,7 +644,8 @@ int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double*
       check_multibody_model(itab, n_i);
       if (!s->d_mbwork) {
         s->mb_work_stride = multibody_work_doubles(s->L);
-        s->d_mbwork = s->alloc<double>((size_t)s->L.B * (s->L.N + 1) * s->mb_work_stride + 8);
+        s->d_mbwork = s->alloc<double>((size_t)s->L.B * (s->L.N + 2) * s->mb_work_stride + 8);  // one slot more per instance: the speculative knot
+        s->d_spec_knot = s->alloc<double>((size_t)s->L.B * s->L.knot_stride);
       }
     }
     s->have_model = true;
@@ -681,6 +693,15 @@ int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* 
   MPC_TRY(s, {
     // the slot of stage 0 is recycled for the new last stage: no data movement, only the ring head moves
     const int slot = s->head;
+    {  // does the appended stage have the table of the current last stage (what the speculative evaluation assumed)?
+      const Layout& L = s->L;
+      const int last = (s->head + L.N - 1) % L.N;
+      const int32_t* hd = s->h_desc.data() + (size_t)last * L.max_stage_ints;
+      const double* hp = s->h_params.data() + (size_t)last * L.max_stage_doubles;
+      const bool same = s->h_len[2 * last] == n_desc && s->h_len[2 * last + 1] == n_params && std::memcmp(hd, desc, n_desc * sizeof(int32_t)) == 0 &&
+                        (n_params == 0 || std::memcmp(hp, params, n_params * sizeof(double)) == 0);
+      s->spec_next_pending = same && s->spec_rec_valid;
+    }
     upload_stage(s, slot, desc, n_desc, params, n_params);
     s->head = (s->head + 1) % s->L.N;
   })
@@ -842,7 +863,8 @@ int mpc_run(mpc_solver* s, const double* xs, const double* us, mpc_stats* stats)
 
 int mpc_run_shifted(mpc_solver* s, mpc_stats* stats) {
   MPC_TRY(s, {
-    if (s->tick_reuse) { s->khead = (s->khead + 1) % s->L.N; s->reuse_this_pass = true; }  // the records move one knot on with the iterate
+    if (s->tick_reuse) { s->khead = (s->khead + 1) % s->L.N; s->reuse_this_pass = true; s->spec_next_now = s->spec_next_pending; }  // the records move one knot on with the iterate
+    s->spec_next_pending = false;
     launch_shift(s);
     run_impl(s, stats);
   })
@@ -857,7 +879,8 @@ int mpc_run_shifted_async(mpc_solver* s) {
       HIP_OK(hipHostMalloc((void**)&s->h_status[slot], L.B * sizeof(InstState), hipHostMallocDefault));
       HIP_OK(hipEventCreateWithFlags(&s->status_ev[slot], hipEventDisableTiming));
     }
-    if (s->tick_reuse) { s->khead = (s->khead + 1) % L.N; s->reuse_this_pass = true; }
+    if (s->tick_reuse) { s->khead = (s->khead + 1) % L.N; s->reuse_this_pass = true; s->spec_next_now = s->spec_next_pending; }
+    s->spec_next_pending = false;
     launch_shift(s);
     hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, s->args());
     // with max_iters = 1 one pass takes the step

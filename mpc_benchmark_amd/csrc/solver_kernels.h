@@ -44,6 +44,10 @@ struct SolverArgs {
   int leg_guess;   // 1: leg j starts from the Hessian calP_{j+1} its record holds from the previous pass / tick (0: from zero)
   double* legbuf;  // [B][MPC_MAX_LEGS - 1][leg_stride]
   double* treebuf; // [B][MPC_MAX_LEGS - 1][tree_stride]: inner nodes of the tree over the cuts (legs_tree.h)
+  // tick reuse: spare knot record per instance for the speculative evaluation of the knot the next tick appends (eval_multibody.h) ;
+  // spec_next: this tick's appended stage has the table the speculation assumed (knots N - 1 and N are reused too)
+  double* spec_knot;
+  int spec_next;
 };
 
 // first knot of leg j (leg nlegs - 1 ends with the terminal knot) — the rule of oracle/solver.hpp leg_start
@@ -54,7 +58,13 @@ DEV double* leg_ptr(const SolverArgs& a, int b, int j) { return a.legbuf + ((siz
 DEV int knot_slot(const SolverArgs& a, int k) { return k < a.L.N ? (a.khead + k) % a.L.N : a.L.N; }
 DEV double* knot_ptr(const SolverArgs& a, int b, int k) { return a.knots + ((size_t)b * (a.L.N + 1) + knot_slot(a, k)) * a.L.knot_stride; }
 // true if tick reuse applies to knot k of instance b: its record is already the evaluation of the current iterate
-DEV bool knot_reused(const SolverArgs& a, int b, int k) { return a.reuse_on && a.spec[b] && k < a.L.N - 1 && (k > 0 || a.reuse_k0); }
+// (knot N - 1, the appended one: if the previous tick evaluated it speculatively with the table that was then appended — spec_next ;
+// knot N: the terminal state and its table are those of the previous tick)
+DEV bool knot_reused(const SolverArgs& a, int b, int k) {
+  if (!(a.reuse_on && a.spec[b])) return false;
+  if (k < a.L.N - 1) return k > 0 || a.reuse_k0;
+  return a.spec_next != 0;
+}
 DEV double* gain_ptr(const SolverArgs& a, int b, int k) { return a.gains + ((size_t)b * (a.L.N + 1) + k) * a.L.gain_stride; }
 DEV int stage_slot(const SolverArgs& a, int k) { return k < a.L.N ? (a.head + k) % a.L.N : a.L.N; }
 
