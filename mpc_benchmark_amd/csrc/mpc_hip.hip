@@ -60,6 +60,7 @@ struct mpc_solver {
   // stage (spec_rec_valid) ; the stage appended since is that table (spec_next_pending, set by mpc_cycle) ; this pass may use it
   double* d_spec_knot = nullptr;
   bool spec_rec_valid = false, spec_next_pending = false, spec_next_now = false;
+  int cycles_since_run = 0;  // the speculation assumes ONE mpc_cycle per tick (replaceStageCircular + cycleAppend of the scripts)
   int khead = 0;
   int* d_spec = nullptr;
   // asynchronous ticks (mpc_run_shifted_async / mpc_wait): status snapshots in pinned host memory, one event each; up to
@@ -343,6 +344,7 @@ static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_des
 static void spec_clear(mpc_solver* s) {
   if (s->d_spec) HIP_OK(hipMemsetAsync(s->d_spec, 0, s->L.B * sizeof(int), s->stream));
   s->spec_rec_valid = s->spec_next_pending = s->spec_next_now = false;
+  s->cycles_since_run = 0;
 }
 
 // warm-start shift of the iterate (k_shift): from the current pair of buffers into the other one, which becomes the current pair
@@ -700,7 +702,8 @@ int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* 
       const double* hp = s->h_params.data() + (size_t)last * L.max_stage_doubles;
       const bool same = s->h_len[2 * last] == n_desc && s->h_len[2 * last + 1] == n_params && std::memcmp(hd, desc, n_desc * sizeof(int32_t)) == 0 &&
                         (n_params == 0 || std::memcmp(hp, params, n_params * sizeof(double)) == 0);
-      s->spec_next_pending = same && s->spec_rec_valid;
+      s->cycles_since_run += 1;
+      s->spec_next_pending = same && s->spec_rec_valid && s->cycles_since_run == 1;
     }
     upload_stage(s, slot, desc, n_desc, params, n_params);
     s->head = (s->head + 1) % s->L.N;
@@ -864,7 +867,7 @@ int mpc_run(mpc_solver* s, const double* xs, const double* us, mpc_stats* stats)
 int mpc_run_shifted(mpc_solver* s, mpc_stats* stats) {
   MPC_TRY(s, {
     if (s->tick_reuse) { s->khead = (s->khead + 1) % s->L.N; s->reuse_this_pass = true; s->spec_next_now = s->spec_next_pending; }  // the records move one knot on with the iterate
-    s->spec_next_pending = false;
+    s->spec_next_pending = false; s->cycles_since_run = 0;
     launch_shift(s);
     run_impl(s, stats);
   })
@@ -880,7 +883,7 @@ int mpc_run_shifted_async(mpc_solver* s) {
       HIP_OK(hipEventCreateWithFlags(&s->status_ev[slot], hipEventDisableTiming));
     }
     if (s->tick_reuse) { s->khead = (s->khead + 1) % L.N; s->reuse_this_pass = true; s->spec_next_now = s->spec_next_pending; }
-    s->spec_next_pending = false;
+    s->spec_next_pending = false; s->cycles_since_run = 0;
     launch_shift(s);
     hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, s->args());
     // with max_iters = 1 one pass takes the step

@@ -126,6 +126,32 @@ def test_tick_reuse_is_bit_identical(horizon, ticks):
         assert np.array_equal(a, b)
 
 
+def test_tick_reuse_with_irregular_cycling_is_bit_identical():
+    """The speculative evaluation of the appended knot assumes one mpc_cycle per tick with the table of the then last stage: two cycles
+    before a run, a run without a cycle and a changed table must all fall back to the plain evaluation (same results bit for bit)."""
+    hip = _capi.load_hip_library()
+    out = {}
+    for reuse in (False, True):
+        pd = FullDynamicsProblem(horizon=12)
+        ens = EnsembleMPC(pd, batch=3, library=hip, seed=17, tick_reuse=reuse)
+        ens.prepare_schedule(40)
+        ens.cold_solve(max_iters=60)
+        for i in range(18):
+            desc, params = ens._table_for_tick(ens.tick % pd.t_mpc)
+            if i % 5 != 4:                       # (every fifth tick: no cycle at all)
+                ens.native.cycle(desc, params)
+            if i % 3 == 0:                       # (every third: a second cycle, with the table of a later tick)
+                d2, p2 = ens._table_for_tick((ens.tick + 7) % pd.t_mpc)
+                ens.native.cycle(d2, p2)
+            ens.native.setup()
+            ens.tick += 1
+            ens.native.run_shifted()
+        r = ens.results(gains=True)
+        out[reuse] = (r["xs"].copy(), r["us"].copy(), r["K"].copy())
+    for a, b in zip(out[False], out[True]):
+        assert np.array_equal(a, b)
+
+
 def test_tick_reuse_is_inert_on_vector_space_problems():
     """The centroidal problem keeps its knot records in knot order (no ring): mpc_set_tick_reuse is accepted and changes
     nothing, tick after tick."""
