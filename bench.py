@@ -66,7 +66,7 @@ def main():
                     help="legs of the parallel-in-time Riccati sweep (mpc_options.riccati_legs: linear_solver_choice = LQ_SOLVER_PARALLEL of "
                          "fulldynamic_talos.py:383; the script's setNumThreads(8) is a CPU thread count — 64 instances x 4 legs fill the 256 CUs); "
                          "1 = serial sweep, negative = the script's 8")
-    ap.add_argument("--latency-legs", type=int, default=16,
+    ap.add_argument("--latency-legs", type=int, default=32,
                     help="legs of the batch-1 latency measurement (a single instance leaves the chip idle: more, shorter legs pay; with more "
                          "than 8 the cuts are resolved by a tree of pairwise compositions, csrc/legs_tree.h)")
     ap.add_argument("--lib", default=None, help="developer option: another build of the same HIP library (kernel tuning variants)")

@@ -126,7 +126,7 @@ typedef struct mpc_options {
   int32_t ls_max_steps;    /* number of backtracking candidates alpha = 2^-i           */
   int32_t num_threads;     /* oracle: OpenMP threads ; HIP: ignored                    */
   int32_t riccati_legs;    /* linear_solver_choice = LQ_SOLVER_PARALLEL + setNumThreads(n) (fulldynamic_talos.py:383,385): the horizon is cut
-                            * into this many legs (clamped to 16 and to the horizon; leg j starts at knot floor(j N / legs)) whose Riccati
+                            * into this many legs (clamped to 32 and to the horizon; leg j starts at knot floor(j N / legs)) whose Riccati
                             * sweeps run side by side — parallel-in-time, same KKT system, results equal to the serial sweep (1) up to
                             * round-off.  The cuts are resolved by a tree of pairwise compositions (ceil(log2 legs) rounds of independent
                             * solves; MPC_LEGS_CHAIN=1: one after the other, a chain of legs - 1 solves — the first form, kept for tests).

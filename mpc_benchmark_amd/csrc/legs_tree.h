@@ -18,7 +18,7 @@
 #include "legs.h"
 
 #define MPC_TREE_MAX_NODES (2 * MPC_MAX_LEGS - 1)
-#define MPC_TREE_MAX_LEVELS 6
+#define MPC_TREE_MAX_LEVELS 8
 struct TreeDesc {
   int J, nnodes, nlev;
   int lo[MPC_TREE_MAX_NODES], hi[MPC_TREE_MAX_NODES], left[MPC_TREE_MAX_NODES], right[MPC_TREE_MAX_NODES];

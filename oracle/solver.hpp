@@ -463,7 +463,7 @@ struct Solver {
   // all legs are independent of one another.  A serial pass over the cuts (consensus) then fixes the cut states and co-states,
   // and the forward sweeps of the legs are independent again.  Same KKT system as the serial sweep: identical results up to
   // round-off.
-  int nlegs() const { int L = opt.riccati_legs; if (L > 16) L = 16; if (L > dims.horizon) L = dims.horizon; if (L < 1) L = 1; return L; }  // 16 = MPC_MAX_LEGS of csrc/layout.h
+  int nlegs() const { int L = opt.riccati_legs; if (L > 32) L = 32; if (L > dims.horizon) L = dims.horizon; if (L < 1) L = 1; return L; }  // 32 = MPC_MAX_LEGS of csrc/layout.h
   int leg_start(int j) const { return (int)((long long)j * dims.horizon / nlegs()); }  // first knot of leg j (leg nlegs()-1 ends with the terminal knot)
 
   // consensus data of leg j < legs-1: cut state dx_{j+1} = Zx dx_j + zc, co-state theta_{j+1} = calP dx_{j+1} + calp

@@ -95,7 +95,8 @@ def test_leg_kernels_against_oracle(hip_lib, oracle_lib, kind, N, legs, complete
                                                   ("centroidal", 30, 7, False), ("kinodynamic", 12, 3, False), ("kinodynamic", 12, 4, True),
                                                   # ten legs and more (the latency configuration of the bench: 16)
                                                   ("fulldynamic", 24, 12, False), ("fulldynamic", 32, 16, True), ("centroidal", 40, 13, False),
-                                                  ("kinodynamic", 20, 10, True), ("fulldynamic", 45, 15, False), ("centroidal", 64, 16, False)])
+                                                  ("kinodynamic", 20, 10, True), ("fulldynamic", 45, 15, False), ("centroidal", 64, 16, False),
+                                                  ("fulldynamic", 50, 25, False), ("centroidal", 64, 32, False)])
 def test_hip_legs_equal_hip_serial(hip_lib, oracle_lib, kind, N, legs, complete):
     """Default mode (cut-Hessian guess; the first pass of a handle sweeps twice — once per tree level + 1 with more than 8 legs): one
     iteration from a point far from the solution."""
@@ -167,7 +168,7 @@ def test_cold_solve_and_mpc_ticks_with_legs(hip_lib, oracle_lib, legs):
             assert _rel(a[0], b[0]) < 1e-6 and _rel(a[1], b[1]) < 1e-6, other
 
 
-@pytest.mark.parametrize("nlegs", [8, 16])
+@pytest.mark.parametrize("nlegs", [8, 16, 32])
 def test_full_size_workload_with_legs(hip_lib, oracle_lib, nlegs):
     """The benchmark's sizes (N = 100, complete model, 8 legs as the scripts ask: setNumThreads(8) ; 16 legs: the tree over the cuts):
     one iteration from a perturbed trajectory against the serial sweep of the oracle and of the HIP library."""

@@ -38,12 +38,12 @@ def run(name, pd, batch, ticks, warm, legs=1, **kw):
     sys.stdout.flush()
 
 
-for legs in (1, 4, 8, 16):
+for legs in (1, 4, 8, 16, 32):
     run("config 2: centroidal N=100 batch 1", CentroidalProblem(horizon=100), 1, 180, 20, legs=legs, perturb=False)
 run("config 2': centroidal N=100 batch 64", CentroidalProblem(horizon=100), 64, 60, 10, legs=4, perturb=False)
-for legs in (1, 4, 8, 16):
+for legs in (1, 4, 8, 16, 32):
     run("config 3: full dynamics N=100 batch 1 (nq=39)", FullDynamicsProblem(horizon=100, complete_model=True), 1, 100, 20, legs=legs, perturb=False)
-for legs in (1, 4, 8, 16):
+for legs in (1, 4, 8, 16, 32):
     run("config 3: full dynamics N=100 batch 1 (nq=29)", FullDynamicsProblem(horizon=100, complete_model=False), 1, 100, 20, legs=legs, perturb=False)
 for legs in (1, 4):
     run("full dynamics N=100 batch 64 (nq=29)", FullDynamicsProblem(horizon=100, complete_model=False), 64, 40, 5, legs=legs)

@@ -6,7 +6,7 @@ from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
 from mpc_benchmark_amd.problems.centroidal import CentroidalProblem
 lib = _capi.load_hip_library()
 for name, pdf in (("full dynamics nq=39", lambda: FullDynamicsProblem(horizon=100, complete_model=True)), ("centroidal", lambda: CentroidalProblem(horizon=100))):
-    for legs in (4, 6, 8, 10, 12, 16):
+    for legs in (4, 8, 12, 16, 24, 32):
         pd = pdf()
         one = EnsembleMPC(pd, batch=1, library=lib, perturb=False, tick_reuse=True)
         one.options.riccati_legs = legs
