@@ -12,7 +12,7 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 110
 rel = lambda a, b: float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b))))
 MARKS = sorted({t for t in (1, 5, 20, 55) if t < T} | {T})
 runs = {}
-for legs in (1, 4, 16):
+for legs in (1, 4, 32):
     pd = FullDynamicsProblem(horizon=100, complete_model=True)
     ens = EnsembleMPC(pd, batch=B, library=lib, seed=20250304, tick_reuse=True)
     ens.options.riccati_legs = legs
@@ -25,9 +25,9 @@ for legs in (1, 4, 16):
         if t in MARKS:
             rec.append((ens.results(gains=False)["xs"].copy(), np.array([s.traj_cost for s in st]), np.array([s.prim_infeas for s in st]), min(s.alpha for s in st)))
     runs[legs] = rec
-same = [i for i in range(B) if runs[1][0][1][i] == runs[4][0][1][i] == runs[16][0][1][i]]
+same = [i for i in range(B) if runs[1][0][1][i] == runs[4][0][1][i] == runs[32][0][1][i]]
 print("instances whose cold solves took the same number of iterations in all three runs: %d of %d" % (len(same), B))
-for legs in (4, 16):
+for legs in (4, 32):
     print("legs %2d vs serial:" % legs)
     for (ta, a), b in zip(zip(MARKS, runs[legs][1:]), runs[1][1:]):
         print("   tick %3d: xs rel err %.2e | cost med %.3f vs %.3f | prim max %.2e vs %.2e | alpha min %.3g vs %.3g" % (
