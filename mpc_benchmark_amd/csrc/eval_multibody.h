@@ -9,16 +9,9 @@
 // no further dependency on the tree (DESIGN.md §"Whole-body stage kernel" derives the formulas; they are
 // cross-checked against the AD-based oracle through tests/proto_multibody.py and the GPU parity tests).
 #pragma once
-#include <atomic>
-#include <stdexcept>
 #include "eval_common.h"
 #include "mfma_blocks.h"
-
-#ifndef EVAL_THREADS
-#define EVAL_THREADS 512  // threads per stage workgroup (8 wavefronts: one 16-column block of the KKT solves each)
-#endif
-#define MB_SE3_SLOTS 8
-#define MB_STAGE_CONSTRAINT_ROWS 20  // LDS staging rows for the Jacobian of one constraint term (wrench cone: 17)
+#include "eval_multibody_host.h"
 
 // ---- 6-vectors --------------------------------------------------------------------------------------------
 struct S6 { double v[6]; };
@@ -121,99 +114,74 @@ DEV void inv6_unrolled_mb(const double* A, double* Ainv) {
     for (int j = 0; j < 6; ++j) Ainv[i * 6 + j] = M[i][6 + j];
 }
 
-// ---- LDS carve-out ------------------------------------------------------------------------------------------
-struct MbLds {
-  int nj, nv, nq, nl_max;
-  int nvp, ldm, nbm, ldR, ncb;  // padded nv, leading dim / block count of the mass matrix, leading dim / column blocks of R
-  // body arrays
-  int oR, op, ov, oa, oh, of, Fc, Hc, oY, Yc, Bc;
-  // dof arrays
-  int J, U, Psd, Psdd, Phi, Bt, Tq, Tv, vlam;
-  // matrices / vectors
-  int M, LIm, Y16, V16, Sp, LIs, R, Jc, gam, bias, a, lam, x, u, xn, cfr, small, se3, red, total;
-  int stage_rows;  // rows of Jacobian staging (ld nz) that fit in the R region
-  int anc_bytes_off, total_bytes;
-  unsigned mg_nv, mg_nvp, mg_nz, mg_n;  // magic_div (device_common.h) of the run-time divisors nv, nvp, n + nu, n of the per-element loops
-};
-
-// The contact KKT system [[M, Jc^T], [Jc, -mu I]] is never inverted: M = L L^T (blocked Cholesky on the matrix
-// cores), Y = L^-1 Jc^T, S = Y^T Y + mu I = Ls Ls^T, and every right-hand side — the dynamics residual and the
-// nz columns of its derivatives, stacked in R = [R1 (nvp rows) ; R2 (16 rows)] — goes through
-//   W = L^-1 R1 ; Z2 = S^-1 (Y^T W - R2) ; Z1 = L^-T (W - Y Z2)
-// one 16-column block per wavefront.  R aliases the body-level inertia / Coriolis blocks (oY, Bc), dead by then,
-// and later hosts the Jacobian rows of the cost / constraint terms.
-static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz) {
-  MbLds s;
-  s.nj = nj; s.nv = nv; s.nq = nq; s.nl_max = 12;
-  s.nvp = (nv + 15) & ~15; s.ldm = s.nvp + 1; s.nbm = s.nvp / 16;
-  s.ncb = (nz + 15) / 16; s.ldR = 16 * s.ncb + 1;
-  int o = 0;
-  auto take = [&](int c) { int r = o; o += (c + 1) & ~1; return r; };
-  s.oR = take(9 * nj); s.op = take(3 * nj); s.ov = take(6 * nj); s.oa = take(6 * nj); s.oh = take(6 * nj); s.of = take(6 * nj);
-  s.Fc = take(6 * nj); s.Hc = take(6 * nj); s.Yc = take(36 * nj);
-  s.J = take(6 * nv); s.U = take(6 * nv); s.Psd = take(6 * nv); s.Psdd = take(6 * nv); s.Phi = take(6 * nv);
-  s.Bt = take(6 * nv); s.Tq = take(6 * nv); s.Tv = take(6 * nv); s.vlam = take(12 * nv);
-  s.M = take(s.nvp * s.ldm); s.LIm = take(s.nbm * 272); s.Y16 = take(s.nvp * 16); s.Sp = take(272); s.LIs = take(272); s.Jc = take(12 * nv);
-  s.gam = take(16); s.bias = take(nv); s.a = take(s.nvp); s.lam = take(16);
-  s.x = take(nq + nv); s.u = take(nu > 0 ? nu : 1); s.xn = take(nq + nv);
-  s.cfr = take(2 * (12 + 36 + 6));  // per contact: R(9) p(3), Jlog6(c2Mc1) (36), spare(6)
-  s.small = take(6 * 36 + 64);      // integrator 6x6 blocks and scratch
-  s.se3 = take(MB_SE3_SLOTS * 48);  // per SE(3)-valued term: residual (6), Jacobian block (36 at +8)
-  s.red = take(2 * 256 + 8);
-  // R region: oY | Bc | rest
-  s.oY = take(36 * nj); s.Bc = take(36 * nj);
-  s.R = s.oY;
-  // R = [R2 (16 rows: contact part, stays alive for the force terms) ; R1 (nvp rows)]; the Jacobian staging rows
-  // (32 stacked cost rows + MB_STAGE_CONSTRAINT_ROWS rows of the constraint being emitted, ld nz) reuse the R1 part
-  int r1size = s.nvp * s.ldR;
-  if (r1size < (32 + MB_STAGE_CONSTRAINT_ROWS) * nz) r1size = (32 + MB_STAGE_CONSTRAINT_ROWS) * nz;
-  const int rsize = 16 * s.ldR + r1size + 8;
-  if (s.R + rsize > o) o = (s.R + rsize + 1) & ~1;
-  if (o < s.Bc + 36 * nj + s.nvp * 16 + 4) o = (s.Bc + 36 * nj + s.nvp * 16 + 4 + 1) & ~1;  // V16 must not overlap oY / Bc
-  s.V16 = o - s.nvp * 16 - 2;  // tail of the R region: alive only between the two solves, while oY / Bc are in use
-  s.stage_rows = (o - s.R) / nz;
-  s.total = o;
-  s.anc_bytes_off = o * 8;
-  s.total_bytes = o * 8 + 3 * nj * 8 + nv * 4 + nj * 4 * 3 + 64;
-  s.mg_nv = magic_div(nv); s.mg_nvp = magic_div(s.nvp); s.mg_nz = magic_div(nz); s.mg_n = magic_div(2 * nv);
-  return s;
-}
-
-static inline void check_multibody_model(const int32_t* itab, int n_i) {
-  const int nj = itab[0];
-  if (nj > 64 || itab[2] > 64) throw std::runtime_error("multibody kernel supports at most 64 bodies / 64 velocity dofs (bitmask tree tables)");
-  const int32_t* ip = itab + MPC_MODEL_HEADER_WORDS;
-  for (int i = 0; i < nj; ++i, ip += MPC_MODEL_JOINT_WORDS) {
-    if (ip[0] >= i) throw std::runtime_error("model joints must be topologically ordered");
-    if ((ip[1] == MPC_JOINT_FREEFLYER) != (i == 0)) throw std::runtime_error("the multibody kernel needs a free-flyer root followed by revolute joints");
-    if (i > 0 && ip[2] != ip[3] + 1) throw std::runtime_error("unexpected idx_q / idx_v layout");
+// ---- structure-of-arrays accessors (component e of element i at A[e * ld + i]) -------------------------------
+DEV S6 ldc6(const double* A, int ld, int i) { S6 r; for (int e = 0; e < 6; ++e) r.v[e] = A[e * ld + i]; return r; }
+DEV void stc6(double* A, int ld, int i, const S6& a) { for (int e = 0; e < 6; ++e) A[e * ld + i] = a.v[e]; }
+DEV M3 ldcm3(const double* A, int ld, int i) { M3 r; for (int e = 0; e < 9; ++e) r.m[e] = A[e * ld + i]; return r; }
+DEV V3 ldcv3(const double* A, int ld, int i) { return v3(A[i], A[ld + i], A[2 * ld + i]); }
+// symmetric 6x6 blocks are stored packed: entry (r, c), r <= c, at row sym6(r, c) of the 21-row array
+DEV constexpr int sym6(int r, int c) { return r <= c ? (r * (13 - r)) / 2 + (c - r) : (c * (13 - c)) / 2 + (r - c); }
+struct Y21 { double y[21]; };
+DEV Y21 ldy21(const double* A, int ld, int i) { Y21 r; for (int e = 0; e < 21; ++e) r.y[e] = A[e * ld + i]; return r; }
+DEV S6 sym_mul(const Y21& Y, const S6& x) {
+  S6 r;
+#pragma unroll
+  for (int a = 0; a < 6; ++a) {
+    double s = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) s += Y.y[sym6(a, b)] * x.v[b];
+    r.v[a] = s;
   }
-  (void)n_i;
+  return r;
 }
-
-// doubles of per-workgroup HBM scratch: dsol [nK x nz] (da ; dlam) and the term Jacobian / weighted Jacobian
-static inline size_t multibody_work_doubles(const Layout& L) {
-  const int nv = L.n / 2;
-  return (size_t)(nv + 12) * L.nz + 2 * (size_t)24 * L.nz + 64;
-}
+struct G36 { double g[36]; };
+DEV G36 ldg36(const double* A, int ld, int i) { G36 r; for (int e = 0; e < 36; ++e) r.g[e] = A[e * ld + i]; return r; }
 
 // lane ids pass through an empty asm at every phase boundary: index arithmetic stays phase-local instead of being
 // kept live (and spilled) across the whole kernel — see RIC_LAUNDER in riccati_mfma.h
 #define EV_LAUNDER() do { asm volatile("" : "+v"(tid)); lane = tid & 63; wv = __builtin_amdgcn_readfirstlane(tid >> 6); } while (0)
 #define EV_PROF(slot) do { EV_LAUNDER(); if (TRIAL == 0 && tid == 0 && a.prof && k == 1) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + 32 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
-struct MbArgs {
-  MbLds lds;
-  double* scratch;        // per-workgroup HBM scratch
-  size_t scratch_stride;  // doubles
-  int ncand_loop;         // TRIAL == 1: > 0 = the workgroup walks this many candidates itself (grid z = 1)
-  int sim_substeps;       // TRIAL == 2 (closed-loop simulation stand-in): integration steps ...
-  double sim_dt;          // ... of this length
-};
+#ifndef EVAL_MIN_WAVES
+#define EVAL_MIN_WAVES (EVAL_THREADS / 128)  // waves per SIMD the register budget must allow: two workgroups per CU
+#endif
+static_assert(EVAL_THREADS >= 128 && EVAL_THREADS <= 512 && EVAL_THREADS % 64 == 0, "stage workgroup: 2 to 8 wavefronts");
+
+// ---- implicit differentiation of the contact dynamics for ONE 16-column block, entirely in registers -----------------
+//   W = L^-1 R1 ; T = Y^T W - R2 ; Z2 = S^-1 T ; Z1 = L^-T (W - Y Z2) ;  d a = -Z1 ,  d lambda = Z2
+// w[bi] = the 16 x 16 tiles of R1 (fragment layout of an MFMA result), t = R2 (rows >= 12 zero).  Mt: tile-packed L with the inverses
+// of the diagonal blocks in place, Y16 = L^-1 Jc^T (nvp x 16, zero padded), LIs = inverse Cholesky factor of S = Y^T Y + mu I.
+DEV void implicit_diff_block(d4_t (&w)[4], d4_t& t, const double* Mt, const double* Y16, const double* LIs, int nbm, int lane) {
+#pragma unroll
+  for (int bi = 0; bi < 4; ++bi) if (bi < nbm) {
+    d4_t acc = w[bi];
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj) if (bj < bi) mma_tile_rb<true>(acc, ctile(Mt, bi, bj), 17, 1, w[bj], lane);
+    w[bi] = d4_t{0, 0, 0, 0};
+    mma_tile_rb<false>(w[bi], ctile(Mt, bi, bi), 17, 1, acc, lane);
+  }
+  t = -t;
+#pragma unroll
+  for (int bi = 0; bi < 4; ++bi) if (bi < nbm) mma_tile_rb<false>(t, Y16 + (bi * 16) * 16, 1, 16, w[bi], lane);
+  d4_t u = d4_t{0, 0, 0, 0};
+  mma_tile_rb<false>(u, LIs, 17, 1, t, lane);
+  t = d4_t{0, 0, 0, 0};
+  mma_tile_rb<false>(t, LIs, 1, 17, u, lane);
+#pragma unroll
+  for (int bi = 0; bi < 4; ++bi) if (bi < nbm) mma_tile_rb<true>(w[bi], Y16 + (bi * 16) * 16, 16, 1, t, lane);
+#pragma unroll
+  for (int bi = 3; bi >= 0; --bi) if (bi < nbm) {
+    d4_t acc = w[bi];
+#pragma unroll
+    for (int bj = 0; bj < 4; ++bj) if (bj > bi && bj < nbm) mma_tile_rb<true>(acc, ctile(Mt, bj, bi), 1, 17, w[bj], lane);
+    w[bi] = d4_t{0, 0, 0, 0};
+    mma_tile_rb<false>(w[bi], ctile(Mt, bi, bi), 1, 17, acc, lane);
+  }
+}
 
 // ============================================================================================================
 template <int TRIAL>
-__global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, Layout KL, double* records, MbArgs mb, int cand0) {
+__global__ void __launch_bounds__(EVAL_THREADS, EVAL_MIN_WAVES) k_eval_multibody(SolverArgs a, Layout KL, double* records, MbArgs mb, int cand0) {
   const Layout& L = a.L;
   const MbLds& S = mb.lds;
   // TRIAL == 3 with one workgroup more per instance (blockIdx.x == N + 1): the SPECULATIVE evaluation of the knot the next tick appends —
@@ -242,7 +210,7 @@ __global__ void __launch_bounds__(EVAL_THREADS) k_eval_multibody(SolverArgs a, L
   const bool has_dyn = dyn == MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER;   // contact-constrained forward dynamics
   const bool kino = dyn == MPC_DYN_KINODYNAMICS_SEMIEULER;               // kinodynamics: u = [wrenches ; joint accelerations]
   const int m = (has_dyn || kino) ? nu : 0, nz = n + m, nterms = desc[5], c = desc[6];
-  const int nk = has_dyn ? desc[1] : 0, nl = 6 * nk, nK = nv + nl;
+  const int nk = has_dyn ? desc[1] : 0, nl = 6 * nk;
   const unsigned mg_nz = m ? S.mg_nz : S.mg_n;  // nz = n + nu on a stage with dynamics, n on the terminal knot
   const bool derivs = (TRIAL == 0 || TRIAL == 3);
 cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of the same knot)
@@ -250,7 +218,7 @@ cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of th
   const size_t wg = (TRIAL == 1) ? (((size_t)b * L.n_alpha + cand) * (N + 1) + k) : (specw ? (size_t)L.B * (N + 1) + b : ((size_t)b * (N + 1) + knot_slot(a, k)));
   double* kn = specw ? a.spec_knot + (size_t)b * KL.knot_stride : records + wg * KL.knot_stride;
   double* scr = mb.scratch + (derivs ? wg : 0) * mb.scratch_stride;  // value-only passes never touch it (B (N + 1) + B slots)
-  double* dsol = scr;                         // [nK][nz]: rows < nv = da, rows >= nv = dlam
+  double* dsol = scr;                         // [nv][nz]: d a w.r.t. (q, v, u) — written by the implicit differentiation, read by the integrator
   double* JtG = scr + (size_t)(nv + 12) * L.nz;  // [24][nz] HBM fallback for dense (non-diagonal) weights
   double* WJ = JtG + (size_t)24 * L.nz;
 
@@ -258,29 +226,30 @@ cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of th
   unsigned long long* anc = (unsigned long long*)((char*)sm + S.anc_bytes_off);
   unsigned long long* sub = anc + nj;    // bodies of the subtree rooted at i
   unsigned long long* dmask = sub + nj;  // dofs of the joints on the path root .. i
-  int* dof_body = (int*)(dmask + nj);
+  unsigned long long* below = dmask + nj;  // dofs of the joints strictly inside the subtree of i
+  int* dof_body = (int*)(below + nj);
   int* parent = dof_body + nv;
   int* jkind = parent + nj;
   int* jidxv = jkind + nj;
   double *oR = sm + S.oR, *op = sm + S.op, *ov = sm + S.ov, *oa = sm + S.oa, *oh = sm + S.oh, *of = sm + S.of, *Fc = sm + S.Fc, *Hc = sm + S.Hc;
   double *oY = sm + S.oY, *Yc = sm + S.Yc, *Bc = sm + S.Bc;
-  double *J = sm + S.J, *U = sm + S.U, *Psd = sm + S.Psd, *Psdd = sm + S.Psdd, *Phi = sm + S.Phi, *Bt = sm + S.Bt, *Tq = sm + S.Tq, *Tv = sm + S.Tv, *vlam = sm + S.vlam;
-  double *M = sm + S.M, *LIm = sm + S.LIm, *Y16 = sm + S.Y16, *V16 = sm + S.V16, *Sp = sm + S.Sp, *LIs = sm + S.LIs, *Rm = sm + S.R, *Jc = sm + S.Jc;
+  double *J = sm + S.J, *U = sm + S.U, *Psd = sm + S.Psd, *Psdd = sm + S.Psdd, *Phi = sm + S.Phi, *Bt = sm + S.Bt, *Tq = sm + S.Tq, *Tv = sm + S.Tv;
+  double *BcPsd = sm + S.BcPsd, *YcPsd = sm + S.YcPsd;
+  double *Mt = sm + S.Mt, *Y16 = sm + S.Y16, *V16 = sm + S.V16, *Sp = sm + S.Sp, *LIs = sm + S.LIs, *DL = sm + S.DL;
   double *gam = sm + S.gam, *bias = sm + S.bias, *acc = sm + S.a, *lam = sm + S.lam;
-  const int nvp = S.nvp, ldm = S.ldm, nbm = S.nbm, ldR = S.ldR, ncb = S.ncb;
+  const int nvp = S.nvp, nbm = S.nbm, ncb = S.ncb, ldl = S.ldl;
   int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = nthr >> 6;
   double *x = sm + S.x, *u = sm + S.u, *xn = sm + S.xn, *cfr = sm + S.cfr, *small = sm + S.small, *red = sm + S.red;
   __shared__ int iflag[2];
   __shared__ double s_cost;
-  // Jacobian staging in LDS, in the R region that is dead once the dynamics derivatives are in HBM:
-  // JS = stacked rows sqrt(W) J of the cost terms (<= 32 rows), JL = rows of the constraint term being emitted
-  double* R2 = Rm;                // contact rows of R / d lambda
-  double* R1 = Rm + 16 * ldR;     // joint rows of R / -d a
-  double* JS = R1;
+  // Jacobian staging in LDS, in the region that is dead once the dynamics derivatives are out (Yc, then the factor of M):
+  // JS = stacked rows sqrt(W) J of the cost terms (<= 32 rows) ; JL = rows of the constraint term being emitted — the constraints are
+  // emitted before the cost rows are stacked, so the two share the region
+  double* JS = sm + S.JS;
   double* se3 = sm + S.se3;
-  double* JL = JS + 32 * nz;
-  double* wrs = red + 256;  // sqrt(W) r of the stacked rows
+  double* JL = JS;
+  double* wrs = red + 16;  // sqrt(W) r of the stacked rows
   int* lterm = (int*)(small + 184);  // term records of the stage (24 x MPC_TERM_WORDS ints): read once, coalesced, instead of
                                      // a chain of dependent global loads in every term loop
 
@@ -324,6 +293,12 @@ cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of th
       anc[i] = gmask[i]; sub[i] = gmask[nj + i]; dmask[i] = gmask[2 * nj + i];
       const int ndof = (mj[4 * i + 1] == MPC_JOINT_FREEFLYER) ? 6 : 1;
       for (int d = 0; d < ndof; ++d) dof_body[mj[4 * i + 3] + d] = i;
+      unsigned long long bm = 0;
+      for (unsigned long long mm = gmask[nj + i] & ~(1ull << i); mm; mm &= mm - 1) {
+        const int j = __builtin_ctzll(mm);
+        bm |= ((mj[4 * j + 1] == MPC_JOINT_FREEFLYER) ? 63ull : 1ull) << mj[4 * j + 3];
+      }
+      below[i] = bm;
     }
     if (tid == 0) s_cost = 0.0;
   }
@@ -355,7 +330,6 @@ sim_loop:
     __syncthreads();
   }
 #define BELOW(kdof, body) ((anc[(body)] >> dof_body[(kdof)]) & 1ull)
-#define INSUB(j, i) ((anc[(j)] >> (i)) & 1ull)
 
   // ---- P1: local joint transforms (stored in the Bc region), then world placements ----------------------
   double* lR = Bc;
@@ -374,27 +348,27 @@ sim_loop:
     }
     const M3 Rl = mul(Rp, Rj);
     const V3 pl = mul(Rp, pj) + pp;
-    for (int e = 0; e < 9; ++e) lR[9 * i + e] = Rl.m[e];
-    lp[3 * i] = pl.x; lp[3 * i + 1] = pl.y; lp[3 * i + 2] = pl.z;
+    for (int e = 0; e < 9; ++e) lR[e * nj + i] = Rl.m[e];
+    lp[i] = pl.x; lp[nj + i] = pl.y; lp[2 * nj + i] = pl.z;
   }
   __syncthreads();
   for (int i = tid; i < nj; i += nthr) {
-    M3 R = ldm3(lR + 9 * i);
-    V3 p = ldv3(lp + 3 * i);
+    M3 R = ldcm3(lR, nj, i);
+    V3 p = ldcv3(lp, nj, i);
     for (int j = parent[i]; j >= 0; j = parent[j]) {
-      const M3 Rj = ldm3(lR + 9 * j);
-      p = mul(Rj, p) + ldv3(lp + 3 * j);
+      const M3 Rj = ldcm3(lR, nj, j);
+      p = mul(Rj, p) + ldcv3(lp, nj, j);
       R = mul(Rj, R);
     }
-    for (int e = 0; e < 9; ++e) oR[9 * i + e] = R.m[e];
-    op[3 * i] = p.x; op[3 * i + 1] = p.y; op[3 * i + 2] = p.z;
+    for (int e = 0; e < 9; ++e) oR[e * nj + i] = R.m[e];
+    op[i] = p.x; op[nj + i] = p.y; op[2 * nj + i] = p.z;
   }
   __syncthreads();
   // ---- P2: world-frame joint columns -------------------------------------------------------------------
   for (int kd = tid; kd < nv; kd += nthr) {
     const int i = dof_body[kd], loc = kd - jidxv[i];
-    const M3 R = ldm3(oR + 9 * i);
-    const V3 p = ldv3(op + 3 * i);
+    const M3 R = ldcm3(oR, nj, i);
+    const V3 p = ldcv3(op, nj, i);
     S6 col;
     if (jkind[i] == MPC_JOINT_FREEFLYER && loc < 3) col = mk6(v3(R.m[loc], R.m[3 + loc], R.m[6 + loc]), v3(0, 0, 0));
     else {
@@ -402,89 +376,146 @@ sim_loop:
       const V3 w = v3(R.m[ax], R.m[3 + ax], R.m[6 + ax]);
       col = mk6(cross(p, w), w);
     }
-    st6(J + 6 * kd, col);
+    stc6(J, nv, kd, col);
   }
   __syncthreads();
   EV_PROF(0);
   // ---- P3: body velocities ------------------------------------------------------------------------------
   for (int idx = tid; idx < 6 * nj; idx += nthr) {
-    const int i = idx / 6, e = idx % 6;
+    const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
     double s = 0;
-    for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); s += J[6 * kd + e] * v[kd]; }
+    for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); s += J[e * nv + kd] * v[kd]; }
     ov[idx] = s;
   }
   __syncthreads();
-  // ---- P4: bias accelerations (gravity field), spatial inertias, momenta --------------------------------
+  // ---- P4: bias accelerations (gravity field), spatial inertias (packed symmetric), momenta ---------------
   for (int i = tid; i < nj; i += nthr) {
     S6 ai = a0;
     for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) {
       const int kd = __builtin_ctzll(mm);
-      ai = add6(ai, scale6(v[kd], mcross(ld6(ov + 6 * dof_body[kd]), ld6(J + 6 * kd))));
+      ai = add6(ai, scale6(v[kd], mcross(ldc6(ov, nj, dof_body[kd]), ldc6(J, nv, kd))));
     }
-    st6(oa + 6 * i, ai);
-    const M3 R = ldm3(oR + 9 * i);
+    stc6(oa, nj, i, ai);
+    const M3 R = ldcm3(oR, nj, i);
     const double mass = jd[25 * i + 12];
-    const V3 cw = mul(R, ldv3(jd + 25 * i + 13)) + ldv3(op + 3 * i);
+    const V3 cw = mul(R, ldv3(jd + 25 * i + 13)) + ldcv3(op, nj, i);
     const M3 RI = mul(R, ldm3(jd + 25 * i + 16));
     M3 Iww;  // R I R^T
     for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Iww.m[3 * r + cc] = RI.m[3 * r] * R.m[3 * cc] + RI.m[3 * r + 1] * R.m[3 * cc + 1] + RI.m[3 * r + 2] * R.m[3 * cc + 2];
     const M3 Sx = skew_m(cw), S2 = mul(Sx, Sx);
-    double* Y = oY + 36 * i;
+    double Y[36];
     for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
       Y[6 * r + cc] = (r == cc) ? mass : 0.0;
       Y[6 * r + cc + 3] = -mass * Sx.m[3 * r + cc];
       Y[6 * (r + 3) + cc] = mass * Sx.m[3 * r + cc];
       Y[6 * (r + 3) + cc + 3] = Iww.m[3 * r + cc] - mass * S2.m[3 * r + cc];
     }
-    st6(oh + 6 * i, mat6_mul(Y, ld6(ov + 6 * i)));
+#pragma unroll
+    for (int r = 0; r < 6; ++r)
+#pragma unroll
+      for (int cc = r; cc < 6; ++cc) oY[sym6(r, cc) * nj + i] = Y[6 * r + cc];
+    stc6(oh, nj, i, mat6_mul(Y, ldc6(ov, nj, i)));
   }
   __syncthreads();
   // ---- P5: composite inertias / momenta, bias forces ----------------------------------------------------
-  for (int idx = tid; idx < 36 * nj; idx += nthr) {
-    const int i = idx / 36, e = idx % 36;
+  for (int idx = tid; idx < 21 * nj; idx += nthr) {
+    const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
     double s = 0;
-    for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += oY[36 * j + e]; }
+    for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += oY[e * nj + j]; }
     Yc[idx] = s;
   }
   for (int idx = tid; idx < 6 * nj; idx += nthr) {
-    const int i = idx / 6, e = idx % 6;
+    const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
     double s = 0;
-    for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += oh[6 * j + e]; }
+    for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += oh[e * nj + j]; }
     Hc[idx] = s;
   }
   for (int i = tid; i < nj; i += nthr)
-    st6(of + 6 * i, add6(mat6_mul(oY + 36 * i, ld6(oa + 6 * i)), fcross(ld6(ov + 6 * i), ld6(oh + 6 * i))));
+    stc6(of, nj, i, add6(sym_mul(ldy21(oY, nj, i), ldc6(oa, nj, i)), fcross(ldc6(ov, nj, i), ldc6(oh, nj, i))));
   __syncthreads();
   for (int idx = tid; idx < 6 * nj; idx += nthr) {
-    const int i = idx / 6, e = idx % 6;
+    const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
     double s = 0;
-    for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += of[6 * j + e]; }
+    for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += of[e * nj + j]; }
     Fc[idx] = s;
   }
-  for (int kd = tid; kd < nv; kd += nthr) st6(U + 6 * kd, mat6_mul(Yc + 36 * dof_body[kd], ld6(J + 6 * kd)));
+  for (int kd = tid; kd < nv; kd += nthr) stc6(U, nv, kd, sym_mul(ldy21(Yc, nj, dof_body[kd]), ldc6(J, nv, kd)));
+  // total mass and centre of mass from the composite inertia of the root (Yc is recycled before the terms read them)
+  const double mtot = Yc[0];
+  const V3 com = v3(Yc[sym6(1, 5) * nj] / mtot, Yc[sym6(2, 3) * nj] / mtot, Yc[sym6(0, 4) * nj] / mtot);
   __syncthreads();
-
   EV_PROF(1);
+
+  // ---- P6: derivative blocks that depend on (q, v) only — formed BEFORE the factorisation, so that the body-level 6 x 6 blocks are
+  // dead when M is built (they share one LDS region): Psd, Phi, the body-level "Coriolis" matrices B_i (over Y_i) and their subtree
+  // sums, Bt = Bc^T J, Tv, and the products Bc Psd / Yc Psd that the torque derivative and the momentum term need later
+  if (derivs) {
+    for (int kd = tid; kd < nv; kd += nthr) {
+      const int bk = dof_body[kd], pb = parent[bk];
+      const S6 vl = (pb >= 0) ? ldc6(ov, nj, pb) : zero6();
+      const S6 Jk = ldc6(J, nv, kd);
+      const S6 psd = mcross(vl, Jk);
+      stc6(Psd, nv, kd, psd);
+      stc6(Phi, nv, kd, mcross(add6(ldc6(ov, nj, bk), vl), Jk));
+      stc6(YcPsd, nv, kd, sym_mul(ldy21(Yc, nj, bk), psd));
+    }
+    if (has_dyn || kino) {
+      for (int i = tid; i < nj; i += nthr) {
+        const Y21 Yl = ldy21(oY, nj, i);
+        const S6 vi = ldc6(ov, nj, i), hi = ldc6(oh, nj, i);
+#pragma unroll
+        for (int col = 0; col < 6; ++col) {
+          S6 e6 = zero6();
+          e6.v[col] = 1.0;
+          const S6 r = add6(add6(sym_mul(Yl, mcross(e6, vi)), fcross(e6, hi)), fcross(vi, sym_mul(Yl, e6)));
+#pragma unroll
+          for (int row = 0; row < 6; ++row) oY[(6 * row + col) * nj + i] = r.v[row];
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 36 * nj; idx += nthr) {
+        const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
+        double s = 0;
+        for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += oY[e * nj + j]; }
+        Bc[idx] = s;
+      }
+      __syncthreads();
+      for (int kd = tid; kd < nv; kd += nthr) {
+        const int bk = dof_body[kd];
+        const S6 Jk = ldc6(J, nv, kd);
+        const G36 Bm = ldg36(Bc, nj, bk);
+        stc6(Bt, nv, kd, mat6_tmul(Bm.g, Jk));
+        stc6(Tv, nv, kd, add6(sym_mul(ldy21(Yc, nj, bk), ldc6(Phi, nv, kd)), mat6_mul(Bm.g, Jk)));
+        stc6(BcPsd, nv, kd, mat6_mul(Bm.g, ldc6(Psd, nv, kd)));
+      }
+    }
+    __syncthreads();
+  }
+  EV_PROF(7);
+
   if (has_dyn) {
-    const double dt = P[desc[4]];
-    // ---- P6: joint-space inertia, bias torques, contact frames -------------------------------------------
-    for (int idx = tid; idx < nvp * nvp; idx += nthr) {
-      const int r = qdiv(idx, S.mg_nvp), cc = (idx - qdiv(idx, S.mg_nvp) * nvp);
+    // ---- P7: joint-space inertia (lower block triangle, tile-packed), bias torques, contact frames ---------------
+    const int ntile = nbm * (nbm + 1) / 2;
+    for (int idx = tid; idx < ntile * 256; idx += nthr) {
+      const int t = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
+      int bi = 0;
+      while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+      const int bj = t - bi * (bi + 1) / 2, r = 16 * bi + i, cc = 16 * bj + j;
       double s = (r == cc) ? 1.0 : 0.0;  // identity padding
       if (r < nv && cc < nv) {
         s = 0;
-        if (BELOW(cc, dof_body[r])) s = dot6(ld6(U + 6 * r), ld6(J + 6 * cc));
-        else if (BELOW(r, dof_body[cc])) s = dot6(ld6(U + 6 * cc), ld6(J + 6 * r));
+        if (BELOW(cc, dof_body[r])) s = dot6(ldc6(U, nv, r), ldc6(J, nv, cc));
+        else if (BELOW(r, dof_body[cc])) s = dot6(ldc6(U, nv, cc), ldc6(J, nv, r));
       }
-      M[r * ldm + cc] = s;
+      Mt[t * 272 + i * 17 + j] = s;
     }
-    for (int kd = tid; kd < nv; kd += nthr) bias[kd] = dot6(ld6(J + 6 * kd), ld6(Fc + 6 * dof_body[kd]));
+    for (int kd = tid; kd < nv; kd += nthr) bias[kd] = dot6(ldc6(J, nv, kd), ldc6(Fc, nj, dof_body[kd]));
     if (tid < nk) {
       const int cid = desc[2 + tid], i = mcontact[cid];
       const double* cm = cd + MPC_MODEL_CONTACT_DOUBLES * cid;
-      const M3 Ri = ldm3(oR + 9 * i);
+      const M3 Ri = ldcm3(oR, nj, i);
       const M3 Rc = mul(Ri, ldm3(cm));
-      const V3 pc = mul(Ri, ldv3(cm + 9)) + ldv3(op + 3 * i);
+      const V3 pc = mul(Ri, ldv3(cm + 9)) + ldcv3(op, nj, i);
       double* cf = cfr + 54 * tid;
       for (int e = 0; e < 9; ++e) cf[e] = Rc.m[e];
       cf[9] = pc.x; cf[10] = pc.y; cf[11] = pc.z;
@@ -493,117 +524,87 @@ sim_loop:
       V3 ev, ew;
       log6(tmul(Rc, R2), tmul(Rc, p2 - pc), ev, ew);
       const S6 e6 = mk6(ev, ew);
-      const S6 acb = adinv(Rc, pc, sub6(ld6(oa + 6 * i), a0));
-      const S6 vcb = adinv(Rc, pc, ld6(ov + 6 * i));
+      const S6 acb = adinv(Rc, pc, sub6(ldc6(oa, nj, i), a0));
+      const S6 vcb = adinv(Rc, pc, ldc6(ov, nj, i));
       for (int r = 0; r < 6; ++r) gam[6 * tid + r] = acb.v[r] + cm[30 + r] * vcb.v[r] - cm[24 + r] * e6.v[r];
       if (derivs) Jlog6(tmul(R2, Rc), tmul(R2, pc - p2), cf + 12);  // Jlog6(c2Mc1)
     }
     __syncthreads();
-    for (int idx = tid; idx < nk * nv; idx += nthr) {
-      const int cc = qdiv(idx, S.mg_nv), kd = (idx - qdiv(idx, S.mg_nv) * nv);
-      const int i = mcontact[desc[2 + cc]];
-      S6 col = zero6();
-      if (BELOW(kd, i)) col = adinv(ldm3(cfr + 54 * cc), ldv3(cfr + 54 * cc + 9), ld6(J + 6 * kd));
-      for (int r = 0; r < 6; ++r) Jc[(6 * cc + r) * nv + kd] = col.v[r];
-    }
-    __syncthreads();
-    // Y16 = [Jc^T | r1 | 0]  (nvp x 16): the contact columns and the dynamics right-hand side r1 = B u - bias
+    // Y16 = [Jc^T | r1 | 0]  (nvp x 16): the contact columns (LOCAL frame: Ad(M_c)^-1 J) and the dynamics right-hand side r1 = B u - bias
     for (int idx = tid; idx < nvp * 16; idx += nthr) {
       const int l = idx >> 4, j = idx & 15;
       double s = 0.0;
       if (l < nv) {
-        if (j < nl) s = Jc[j * nv + l];
-        else if (j == 12) s = -bias[l] + (l >= nv - nu ? u[l - (nv - nu)] : 0.0);
+        if (j < nl) {
+          const int cc = j / 6;
+          if (BELOW(l, mcontact[desc[2 + cc]])) s = adinv(ldm3(cfr + 54 * cc), ldv3(cfr + 54 * cc + 9), ldc6(J, nv, l)).v[j - 6 * cc];
+        } else if (j == 12) s = -bias[l] + (l >= nv - nu ? u[l - (nv - nu)] : 0.0);
       }
       Y16[idx] = s;
     }
+    if (tid == 0) { iflag[0] = 1; iflag[1] = 1; }
     __syncthreads();
     EV_PROF(2);
-    // ---- P7: M = L L^T ; Y = L^-1 [Jc^T | r1] ; S = Y^T Y + mu I = Ls Ls^T ; multipliers ; accelerations -------
-    if (tid == 0) iflag[1] = 1;
-    if (!chol_blocked(M, ldm, nbm, LIm, tid, iflag)) { if (tid == 0) a.inst[b].done = 5; return; }
-    EV_PROF(3);
+    // ---- P8: M = L L^T ; Y = L^-1 [Jc^T | r1] ; S = Y^T Y + mu I = Ls Ls^T ; multipliers — ONE wavefront, no barrier inside (its LDS
+    // operations execute in order) ; then the accelerations
     if (wv == 0) {
-      trsm_fwd_blocked(M, ldm, LIm, nbm, Y16, 16, 1, 0, 1, lane);
-      d4_t g = d4_t{0, 0, 0, 0};
-      mma_tile<false>(g, Y16, 1, 16, Y16, 16, 1, nvp, lane);  // [Y w]^T [Y w]
-      const int col = lane & 15;
+      if (!chol_tiles_wave(Mt, nbm, lane)) { if (lane == 0) iflag[0] = 0; }
+      else {
+        trsm_fwd_tiles(Mt, nbm, Y16, 16, 1, 0, 1, lane);
+        d4_t g = d4_t{0, 0, 0, 0};
+        mma_tile<false>(g, Y16, 1, 16, Y16, 16, 1, nvp, lane);  // [Y w]^T [Y w]
+        const int col = lane & 15;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int row = (lane >> 4) + 4 * q;
-        double sv = (row < nl && col < nl) ? g[q] : 0.0;
-        if (row == col) sv += (row < nl) ? prox_mu : 1.0;
-        Sp[row * 17 + col] = sv;
-        if (col == 12 && row < nl) small[row] = g[q] + gam[row];  // t = Y^T w - r2,  r2 = -gamma
-      }
-      if (!chol16_wave(Sp, 17, LIs, lane) && lane == 0) iflag[1] = 0;
-      // z2 = Ls^-T Ls^-1 t ; lambda = -z2
-      if (lane < 16) {
-        double y = 0;
-        for (int j = 0; j <= lane; ++j) y += LIs[lane * 17 + j] * ((j < nl) ? small[j] : 0.0);
-        small[16 + lane] = y;
-      }
-      if (lane < 16) {
-        double z = 0;
-        for (int j = lane; j < 16; ++j) z += LIs[j * 17 + lane] * small[16 + j];
-        small[32 + lane] = z;
-        if (lane < nl) lam[lane] = -z;
+        for (int qq = 0; qq < 4; ++qq) {
+          const int row = (lane >> 4) + 4 * qq;
+          double sv = (row < nl && col < nl) ? g[qq] : 0.0;
+          if (row == col) sv += (row < nl) ? prox_mu : 1.0;
+          Sp[row * 17 + col] = sv;
+          if (col == 12 && row < nl) small[row] = g[qq] + gam[row];  // t = Y^T w - r2,  r2 = -gamma
+        }
+        if (!chol16_wave(Sp, 17, LIs, lane) && lane == 0) iflag[1] = 0;
+        // z2 = Ls^-T Ls^-1 t ; lambda = -z2
+        if (lane < 16) {
+          double y = 0;
+          for (int j = 0; j <= lane; ++j) y += LIs[lane * 17 + j] * ((j < nl) ? small[j] : 0.0);
+          small[16 + lane] = y;
+        }
+        if (lane < 16) {
+          double z = 0;
+          for (int j = lane; j < 16; ++j) z += LIs[j * 17 + lane] * small[16 + j];
+          small[32 + lane] = z;
+          if (lane < nl) lam[lane] = -z;
+        }
+        // V16 column 0 = w - Y z2, then accelerations = L^-T (.)
+        for (int idx = lane; idx < nvp * 16; idx += 64) {
+          const int l = idx >> 4, j = idx & 15;
+          double s = 0.0;
+          if (j == 0) { s = Y16[l * 16 + 12]; for (int i = 0; i < nl; ++i) s -= Y16[l * 16 + i] * small[32 + i]; }
+          V16[idx] = s;
+        }
+        trsm_bwd_tiles(Mt, nbm, V16, 16, 1, 0, 1, lane);
+        for (int i = lane; i < nvp; i += 64) { acc[i] = V16[i * 16]; Y16[i * 16 + 12] = 0.0; }  // from here on Y16 = Y (zero padded)
       }
     }
     __syncthreads();
-    if (iflag[1] == 0) { if (tid == 0) a.inst[b].done = 6; return; }
-    // V16 column 0 = w - Y z2, then accelerations = L^-T (.)
-    for (int idx = tid; idx < nvp * 16; idx += nthr) {
-      const int l = idx >> 4, j = idx & 15;
-      double s = 0.0;
-      if (j == 0) { s = Y16[l * 16 + 12]; for (int i = 0; i < nl; ++i) s -= Y16[l * 16 + i] * small[32 + i]; }
-      V16[idx] = s;
-    }
-    __syncthreads();
-    if (wv == 0) trsm_bwd_blocked(M, ldm, LIm, nbm, V16, 16, 1, 0, 1, lane);
-    __syncthreads();
-    for (int i = tid; i < nv; i += nthr) acc[i] = V16[i * 16];
-    for (int l = tid; l < nvp; l += nthr) Y16[l * 16 + 12] = 0.0;  // from here on Y16 = Y (zero padded)
-    __syncthreads();
+    if (iflag[0] == 0 || iflag[1] == 0) { if (tid == 0) a.inst[b].done = iflag[0] == 0 ? 5 : 6; return; }
     EV_PROF(5);
     if (derivs) {
       for (int i = tid; i < n; i += nthr) kn[KL.oXD + i] = (i < nv) ? v[i] : acc[i - nv];
-      for (int i = tid; i < 12; i += nthr) kn[KL.oWR + i] = 0.0;
-      __syncthreads();
-      for (int i = tid; i < nl; i += nthr) kn[KL.oWR + 6 * desc[2 + i / 6] + i % 6] = lam[i];
-    }
-    if (derivs) {  // body accelerations at the solution: only the derivative blocks read them
-      for (int idx = tid; idx < 6 * nj; idx += nthr) {
-        const int i = idx / 6, e = idx % 6;
-        double s = oa[idx];
-        for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); s += J[6 * kd + e] * acc[kd]; }
-        oa[idx] = s;
+      for (int i = tid; i < 12; i += nthr) {
+        double wr = 0.0;
+        for (int cc = 0; cc < nk; ++cc) if (desc[2 + cc] == i / 6) wr = lam[6 * cc + i % 6];
+        kn[KL.oWR + i] = wr;
       }
-      __syncthreads();
-    }
-    if (derivs) {
-      for (int i = tid; i < nj; i += nthr) {
-        S6 f = add6(mat6_mul(oY + 36 * i, ld6(oa + 6 * i)), fcross(ld6(ov + 6 * i), ld6(oh + 6 * i)));
-        for (int cc = 0; cc < nk; ++cc) {
-          if (mcontact[desc[2 + cc]] != i) continue;
-          const M3 Rc = ldm3(cfr + 54 * cc);
-          const V3 pc = ldv3(cfr + 54 * cc + 9);
-          const V3 fl = mul(Rc, v3(lam[6 * cc], lam[6 * cc + 1], lam[6 * cc + 2]));
-          const V3 fa = mul(Rc, v3(lam[6 * cc + 3], lam[6 * cc + 4], lam[6 * cc + 5])) + cross(pc, fl);
-          f = sub6(f, mk6(fl, fa));
-        }
-        st6(of + 6 * i, f);
-      }
-      __syncthreads();
-      for (int idx = tid; idx < 6 * nj; idx += nthr) {
-        const int i = idx / 6, e = idx % 6;
-        double s = 0;
-        for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += of[6 * j + e]; }
-        Fc[idx] = s;
+      // world-frame wrench of every contact (at the origin), for the forces at the solution
+      if (tid < nk) {
+        const M3 Rc = ldm3(cfr + 54 * tid);
+        const V3 pc = ldv3(cfr + 54 * tid + 9);
+        const V3 fl = mul(Rc, v3(lam[6 * tid], lam[6 * tid + 1], lam[6 * tid + 2]));
+        const V3 fa = mul(Rc, v3(lam[6 * tid + 3], lam[6 * tid + 4], lam[6 * tid + 5])) + cross(pc, fl);
+        st6(cfr + 54 * tid + 48, mk6(fl, fa));
       }
     }
-    __syncthreads();
-    (void)dt;
   }
 
   EV_PROF(6);
@@ -637,9 +638,6 @@ sim_loop:
   // ---- kinodynamics (kinodynamic_talos.py:107-112): a_joint = u[12:], base acceleration from the momentum balance
   // about the world origin  sum_k U_k a_k + hdot(a = 0) = [sum f + m g ; sum p_i x f_i + tau_i + c x m g],
   // projected on the base columns: (J_b^T U_b) a_b = J_b^T (...)  with J_b^T U_b = M_bb symmetric positive definite.
-  double mtot = 0;
-  for (int i = 0; i < nj; ++i) mtot += jd[25 * i + 12];
-  const V3 com = v3(Yc[6 * 5 + 1] / mtot, Yc[6 * 3 + 2] / mtot, Yc[6 * 4 + 0] / mtot);
   if (kino) {
     const double* dp = P + desc[4];
     const int nkk = desc[1], nf = 6 * nkk;
@@ -647,7 +645,7 @@ sim_loop:
     double* Minv6 = small + 144;  // 36
     if (tid < nkk) {
       const int fi = (int)dp[4 + tid], i = mframe[fi];
-      const V3 pf = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+      const V3 pf = mul(ldcm3(oR, nj, i), ldv3(fd + 12 * fi + 9)) + ldcv3(op, nj, i);
       cfr[54 * tid + 9] = pf.x; cfr[54 * tid + 10] = pf.y; cfr[54 * tid + 11] = pf.z;
       cfr[54 * tid] = (double)i;
     }
@@ -661,12 +659,12 @@ sim_loop:
         const V3 f = v3(u[6 * cc], u[6 * cc + 1], u[6 * cc + 2]), tq = v3(u[6 * cc + 3], u[6 * cc + 4], u[6 * cc + 5]);
         r0 = add6(r0, mk6(f, cross(pf, f) + tq));
       }
-      r0 = sub6(r0, ld6(Fc));  // hdot at a = 0 (true accelerations: a0 = 0 in this mode)
-      for (int j = 6; j < nv; ++j) r0 = sub6(r0, scale6(acc[j], ld6(U + 6 * j)));
+      r0 = sub6(r0, ldc6(Fc, nj, 0));  // hdot at a = 0 (true accelerations: a0 = 0 in this mode)
+      for (int j = 6; j < nv; ++j) r0 = sub6(r0, scale6(acc[j], ldc6(U, nv, j)));
       double Mbb[36], rb[6];
       for (int r = 0; r < 6; ++r) {
-        rb[r] = dot6(ld6(J + 6 * r), r0);
-        for (int cc = 0; cc < 6; ++cc) Mbb[6 * r + cc] = dot6(ld6(U + 6 * r), ld6(J + 6 * cc));
+        rb[r] = dot6(ldc6(J, nv, r), r0);
+        for (int cc = 0; cc < 6; ++cc) Mbb[6 * r + cc] = dot6(ldc6(U, nv, r), ldc6(J, nv, cc));
       }
       inv6_unrolled_mb(Mbb, Minv6);
       for (int r = 0; r < 6; ++r) { double sacc = 0; for (int cc = 0; cc < 6; ++cc) sacc += Minv6[6 * r + cc] * rb[cc]; acc[r] = sacc; }
@@ -676,73 +674,44 @@ sim_loop:
       for (int i = tid; i < n; i += nthr) kn[KL.oXD + i] = (i < nv) ? v[i] : acc[i - nv];
       for (int i = tid; i < 12; i += nthr) kn[KL.oWR + i] = 0.0;
     }
-    // accelerations and body forces at the solution (needed by the derivative vectors)
-    for (int idx = tid; idx < 6 * nj; idx += nthr) {
-      const int i = idx / 6, e = idx % 6;
-      double sacc = oa[idx];
-      for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); sacc += J[6 * kd + e] * acc[kd]; }
-      oa[idx] = sacc;
-    }
-    __syncthreads();
-    if (derivs) {
-      for (int i = tid; i < nj; i += nthr) st6(of + 6 * i, add6(mat6_mul(oY + 36 * i, ld6(oa + 6 * i)), fcross(ld6(ov + 6 * i), ld6(oh + 6 * i))));
-      __syncthreads();
-      for (int idx = tid; idx < 6 * nj; idx += nthr) {
-        const int i = idx / 6, e = idx % 6;
-        double sacc = 0;
-        for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); sacc += of[6 * j + e]; }
-        Fc[idx] = sacc;
-      }
-    }
-    __syncthreads();
   }
 
-  // ---- P9: derivative building blocks (Jacobians only: the value-only pass skips them) ----------------------
-  if (derivs) for (int kd = tid; kd < nv; kd += nthr) {
-    const int pb = parent[dof_body[kd]];
-    const S6 vl = (pb >= 0) ? ld6(ov + 6 * pb) : zero6();
-    const S6 al = (pb >= 0) ? ld6(oa + 6 * pb) : a0;
-    st6(vlam + 12 * kd, vl);
-    st6(vlam + 12 * kd + 6, al);
-    const S6 Jk = ld6(J + 6 * kd);
-    const S6 psd = mcross(vl, Jk);
-    st6(Psd + 6 * kd, psd);
-    st6(Psdd + 6 * kd, add6(mcross(al, Jk), mcross(vl, psd)));
-    st6(Phi + 6 * kd, mcross(add6(ld6(ov + 6 * dof_body[kd]), vl), Jk));
-  }
-  __syncthreads();
+  // ---- P9: body accelerations and subtree forces AT THE SOLUTION (only the derivative blocks read them):
+  //   da_i = sum_{k on the path to i} J_k acc_k ;  Fc_i += Yc_i da_i + sum_{k strictly below i} U_k acc_k - (wrenches of the contacts below i)
+  // (sum over the subtree of Y_j da_j, regrouped by dof: the composite inertias and U = Yc J are at hand, the body inertias are not)
   if (derivs && (has_dyn || kino)) {
-    // body-level "Coriolis" matrices B_i (overwrite oY), then their subtree sums
-    for (int i = tid; i < nj; i += nthr) {
-      double Yl[36], Bm[36];
-      for (int e = 0; e < 36; ++e) Yl[e] = oY[36 * i + e];
-      const S6 vi = ld6(ov + 6 * i), hi = ld6(oh + 6 * i);
-      for (int col = 0; col < 6; ++col) {
-        S6 e6 = zero6();
-        e6.v[col] = 1.0;
-        const S6 r = add6(add6(mat6_mul(Yl, mcross(e6, vi)), fcross(e6, hi)), fcross(vi, mat6_mul(Yl, e6)));
-        for (int row = 0; row < 6; ++row) Bm[6 * row + col] = r.v[row];
-      }
-      for (int e = 0; e < 36; ++e) oY[36 * i + e] = Bm[e];
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 36 * nj; idx += nthr) {
-      const int i = idx / 36, e = idx % 36;
+    double* da = Tq;  // scratch [6][nj] (Tq is formed afterwards)
+    for (int idx = tid; idx < 6 * nj; idx += nthr) {
+      const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
       double s = 0;
-      for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += oY[36 * j + e]; }
-      Bc[idx] = s;
+      for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); s += J[e * nv + kd] * acc[kd]; }
+      da[idx] = s;
     }
     __syncthreads();
+    for (int idx = tid; idx < 6 * nj; idx += nthr) {
+      const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
+      double s = Fc[idx];
+#pragma unroll
+      for (int bb = 0; bb < 6; ++bb) s += Yc[sym6(e, bb) * nj + i] * da[bb * nj + i];
+      for (unsigned long long mm = below[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); s += U[e * nv + kd] * acc[kd]; }
+      for (int cc = 0; cc < nk; ++cc) if ((anc[mcontact[desc[2 + cc]]] >> i) & 1ull) s -= cfr[54 * cc + 48 + e];
+      Fc[idx] = s;
+      oa[idx] += da[idx];
+    }
+    __syncthreads();
+    // Psdd (needs the parents' accelerations at the solution) and Tq = Yc Psdd + Bc Psd + J x* Fc
     for (int kd = tid; kd < nv; kd += nthr) {
-      const int bk = dof_body[kd];
-      const S6 Jk = ld6(J + 6 * kd);
-      st6(Bt + 6 * kd, mat6_tmul(Bc + 36 * bk, Jk));
-      st6(Tq + 6 * kd, add6(add6(mat6_mul(Yc + 36 * bk, ld6(Psdd + 6 * kd)), mat6_mul(Bc + 36 * bk, ld6(Psd + 6 * kd))), fcross(Jk, ld6(Fc + 6 * bk))));
-      st6(Tv + 6 * kd, add6(mat6_mul(Yc + 36 * bk, ld6(Phi + 6 * kd)), mat6_mul(Bc + 36 * bk, Jk)));
+      const int bk = dof_body[kd], pb = parent[bk];
+      const S6 vl = (pb >= 0) ? ldc6(ov, nj, pb) : zero6();
+      const S6 al = (pb >= 0) ? ldc6(oa, nj, pb) : a0;
+      const S6 Jk = ldc6(J, nv, kd);
+      const S6 psdd = add6(mcross(al, Jk), mcross(vl, ldc6(Psd, nv, kd)));
+      stc6(Psdd, nv, kd, psdd);
+      stc6(Tq, nv, kd, add6(add6(sym_mul(ldy21(Yc, nj, bk), psdd), ldc6(BcPsd, nv, kd)), fcross(Jk, ldc6(Fc, nj, bk))));
     }
     __syncthreads();
     if (kino) {
-      // d r0 / d(q, v, u) (6 x nz, stored in dr), then  d a_b = -Mbb^-1 J_b^T d r0 ; joint accelerations are controls
+      // d r0 / d(q, v, u) (6 x nz), then  d a_b = -Mbb^-1 J_b^T d r0 ; joint accelerations are controls
       const double* dp = P + desc[4];
       const int nkk = desc[1], nf = 6 * nkk;
       const V3 mg = v3(mtot * dp[1], mtot * dp[2], mtot * dp[3]);
@@ -750,9 +719,9 @@ sim_loop:
       for (int z = tid; z < nz; z += nthr) {
         S6 col = zero6();
         if (z < nv) {
-          col = ld6(Tq + 6 * z);
-          V3 dang = cross((1.0 / mtot) * lin(ld6(U + 6 * z)), mg);
-          const S6 Jz = ld6(J + 6 * z);
+          col = ldc6(Tq, nv, z);
+          V3 dang = cross((1.0 / mtot) * lin(ldc6(U, nv, z)), mg);
+          const S6 Jz = ldc6(J, nv, z);
           for (int cc = 0; cc < nkk; ++cc) {
             if (!desc[2 + cc] || !BELOW(z, (int)cfr[54 * cc])) continue;
             const V3 pf = ldv3(cfr + 54 * cc + 9);
@@ -760,7 +729,7 @@ sim_loop:
           }
           col = sub6(col, mk6(v3(0, 0, 0), dang));
         } else if (z < n) {
-          col = ld6(Tv + 6 * (z - nv));
+          col = ldc6(Tv, nv, z - nv);
         } else if (z < n + nf) {
           const int cc = (z - n) / 6, e = (z - n) % 6;
           if (desc[2 + cc]) {
@@ -769,10 +738,10 @@ sim_loop:
             else col = mk6(v3(0, 0, 0), v3(-ev.x, -ev.y, -ev.z));
           }
         } else {
-          col = ld6(U + 6 * (6 + z - n - nf));
+          col = ldc6(U, nv, 6 + z - n - nf);
         }
         double jb[6];
-        for (int r = 0; r < 6; ++r) jb[r] = dot6(ld6(J + 6 * r), col);
+        for (int r = 0; r < 6; ++r) jb[r] = dot6(ldc6(J, nv, r), col);
         for (int r = 0; r < 6; ++r) {
           double sacc = 0;
           for (int cc = 0; cc < 6; ++cc) sacc += Minv6[6 * r + cc] * jb[cc];
@@ -782,107 +751,113 @@ sim_loop:
       }
       __syncthreads();
     }
-    EV_PROF(7);
-    // ---- P10: R = [d r1 ; d r2] w.r.t. (q, v, u), zero padded (R overwrites the body-level blocks oY / Bc) ----
-    const int n2 = 2 * nv;
+    EV_PROF(8);
     if (has_dyn) {
-    for (int idx = tid; idx < (nvp + 16) * ldR; idx += nthr) Rm[idx] = 0.0;
-    __syncthreads();
-    for (int idx = tid; idx < nv * nv; idx += nthr) {
-      const int r = qdiv(idx, S.mg_nv), j = (idx - qdiv(idx, S.mg_nv) * nv);
-      const int br = dof_body[r], bj = dof_body[j];
-      double dq = 0, dv = 0;
-      if ((anc[br] >> bj) & 1ull) {
-        const S6 Ur = ld6(U + 6 * r), Btr = ld6(Bt + 6 * r);
-        dq = dot6(Ur, ld6(Psdd + 6 * j)) + dot6(Btr, ld6(Psd + 6 * j));
-        dv = dot6(Ur, ld6(Phi + 6 * j)) + dot6(Btr, ld6(J + 6 * j));
-      } else if ((anc[bj] >> br) & 1ull) {
-        const S6 Jr = ld6(J + 6 * r);
-        dq = dot6(Jr, ld6(Tq + 6 * j));
-        dv = dot6(Jr, ld6(Tv + 6 * j));
-      }
-      R1[r * ldR + j] = dq;
-      R1[r * ldR + nv + j] = dv;
-    }
-    for (int i = tid; i < nu; i += nthr) R1[(nv - nu + i) * ldR + n2 + i] = -1.0;  // d r1 / du = -B
-    for (int idx = tid; idx < nk * nv; idx += nthr) {
-      const int cc = qdiv(idx, S.mg_nv), j = (idx - qdiv(idx, S.mg_nv) * nv);
-      const int cid = desc[2 + cc], i = mcontact[cid];
-      const double* cm = cd + MPC_MODEL_CONTACT_DOUBLES * cid;
-      S6 rq = zero6(), rv = zero6();
-      if (BELOW(j, i)) {
+      // ---- P10: contact rows R2 = d r2 / d(q, v) into DL (zero padded ; d r2 / du = 0) -------------------------------------
+      for (int idx = tid; idx < 12 * ldl; idx += nthr) DL[idx] = 0.0;
+      __syncthreads();
+      for (int idx = tid; idx < nk * nv; idx += nthr) {
+        const int cc = qdiv(idx, S.mg_nv), j = (idx - qdiv(idx, S.mg_nv) * nv);
+        const int cid = desc[2 + cc], i = mcontact[cid];
+        if (!BELOW(j, i)) continue;
+        const double* cm = cd + MPC_MODEL_CONTACT_DOUBLES * cid;
         const M3 Rc = ldm3(cfr + 54 * cc);
         const V3 pc = ldv3(cfr + 54 * cc + 9);
-        const S6 Jj = ld6(J + 6 * j), vl = ld6(vlam + 12 * j), al = ld6(vlam + 12 * j + 6), psd = ld6(Psd + 6 * j);
-        const S6 w = sub6(ld6(ov + 6 * i), vl);
+        const int pb = parent[dof_body[j]];
+        const S6 vl = (pb >= 0) ? ldc6(ov, nj, pb) : zero6();
+        const S6 al = (pb >= 0) ? ldc6(oa, nj, pb) : a0;
+        const S6 Jj = ldc6(J, nv, j), psd = ldc6(Psd, nv, j);
+        const S6 w = sub6(ldc6(ov, nj, i), vl);
         const S6 dacq = adinv(Rc, pc, add6(mcross(sub6(al, a0), Jj), mcross(psd, w)));
-        const S6 dacv = adinv(Rc, pc, add6(mcross(ld6(ov + 6 * dof_body[j]), Jj), mcross(Jj, w)));
+        const S6 dacv = adinv(Rc, pc, add6(mcross(ldc6(ov, nj, dof_body[j]), Jj), mcross(Jj, w)));
         const S6 apsd = adinv(Rc, pc, psd);
-        S6 Jcj;
-        for (int r = 0; r < 6; ++r) Jcj.v[r] = Jc[(6 * cc + r) * nv + j];
+        const S6 Jcj = adinv(Rc, pc, Jj);
         const S6 jl = mat6_mul(cfr + 54 * cc + 12, Jcj);
         for (int r = 0; r < 6; ++r) {
-          rq.v[r] = dacq.v[r] + cm[30 + r] * apsd.v[r] + cm[24 + r] * jl.v[r];
-          rv.v[r] = dacv.v[r] + cm[30 + r] * Jcj.v[r];
+          DL[(6 * cc + r) * ldl + j] = dacq.v[r] + cm[30 + r] * apsd.v[r] + cm[24 + r] * jl.v[r];
+          DL[(6 * cc + r) * ldl + nv + j] = dacv.v[r] + cm[30 + r] * Jcj.v[r];
         }
       }
-      for (int r = 0; r < 6; ++r) { R2[(6 * cc + r) * ldR + j] = rq.v[r]; R2[(6 * cc + r) * ldR + nv + j] = rv.v[r]; }
-    }
-    __syncthreads();
-    EV_PROF(8);
-    // ---- P11: implicit differentiation, one 16-column block per wavefront (no workgroup barrier inside):
-    //   W = L^-1 R1 ; T = Y^T W - R2 ; Z2 = S^-1 T ; Z1 = L^-T (W - Y Z2) ;  d a = -Z1 ,  d lambda = Z2
-    trsm_fwd_blocked(M, ldm, LIm, nbm, R1, ldR, ncb, wv, nw, lane);
-    for (int cj = wv; cj < ncb; cj += nw) {
-      d4_t t = tile_load(R2 + cj * 16, ldR, lane);
-      t = -t;
-      mma_tile<false>(t, Y16, 1, 16, R1 + cj * 16, ldR, 1, nvp, lane);
-      tile_store(R2 + cj * 16, ldR, t, lane);
-    }
-    trsm_fwd_blocked(Sp, 17, LIs, 1, R2, ldR, ncb, wv, nw, lane);
-    trsm_bwd_blocked(Sp, 17, LIs, 1, R2, ldR, ncb, wv, nw, lane);
-    for (int cj = wv; cj < ncb; cj += nw)
-      for (int bi = 0; bi < nbm; ++bi) {
-        double* Wt = R1 + (bi * 16) * ldR + cj * 16;
-        d4_t w = tile_load(Wt, ldR, lane);
-        mma_tile<true>(w, Y16 + (bi * 16) * 16, 16, 1, R2 + cj * 16, ldR, 1, 16, lane);
-        tile_store(Wt, ldR, w, lane);
+      __syncthreads();
+      // ---- P11: R1 = d r1 / d(q, v, u) built in registers, one 16-column block per wavefront at a time, and the whole chain of
+      // blocked solves on it without touching LDS for the intermediate results (implicit_diff_block)
+      const int n2 = 2 * nv;
+      for (int cj = wv; cj < ncb; cj += nw) {
+        const int z = 16 * cj + (lane & 15), rq = lane >> 4;
+        const int kind = z < nv ? 0 : (z < n2 ? 1 : (z < n2 + nu ? 2 : 3));
+        const int j = kind == 0 ? z : (kind == 1 ? z - nv : 0);
+        const int bj = dof_body[j];
+        const S6 c1 = ldc6(kind ? Phi : Psdd, nv, j), c2 = ldc6(kind ? J : Psd, nv, j), c3 = ldc6(kind ? Tv : Tq, nv, j);
+        d4_t w[4], t;
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi) {
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int r = 16 * bi + rq + 4 * qq;
+            double val = 0.0;
+            if (bi < nbm && r < nv) {
+              if (kind < 2) {
+                const int br = dof_body[r];
+                if ((anc[br] >> bj) & 1ull) val = dot6(ldc6(U, nv, r), c1) + dot6(ldc6(Bt, nv, r), c2);
+                else if ((anc[bj] >> br) & 1ull) val = dot6(ldc6(J, nv, r), c3);
+              } else if (kind == 2 && r == nv - nu + (z - n2)) val = -1.0;  // d r1 / du = -B
+            }
+            w[bi][qq] = val;
+          }
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) t[qq] = (qq < 3) ? DL[(rq + 4 * qq) * ldl + 16 * cj + (lane & 15)] : 0.0;
+        implicit_diff_block(w, t, Mt, Y16, LIs, nbm, lane);
+        // d a = -Z1 to the HBM scratch (read back by the integrator through L2), d lambda = Z2 stays in LDS for the force terms
+        if (z < nz) {
+#pragma unroll
+          for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+              const int r = 16 * bi + rq + 4 * qq;
+              if (bi < nbm && r < nv) dsol[(size_t)r * L.nz + z] = -w[bi][qq];
+            }
+        }
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) DL[(rq + 4 * qq) * ldl + 16 * cj + (lane & 15)] = t[qq];
       }
-    trsm_bwd_blocked(M, ldm, LIm, nbm, R1, ldR, ncb, wv, nw, lane);
-    __syncthreads();  // d a = -R1, d lambda = R2 stay in LDS for the integrator and the force terms
-    }  // has_dyn
+      __syncthreads();
+    }
   }
 
   EV_PROF(9);
-  // ---- SE(3)-valued terms: residual and Jacobian block, one term per wavefront lane 0 (waves 2..) ---------------
-  if (wv >= 2 && lane == 0) {
-    int slot = 0;
-    for (int t = 0; t < nterms; ++t) {
-      const TermRec tr = lds_term(lterm, t);
-      const bool se3_state = tr.type == MPC_TERM_STATE_ERROR && tr.i0 < 6;
-      if (!se3_state && tr.type != MPC_TERM_FRAME_PLACEMENT) continue;
-      const int my = slot++;
-      if (my >= MB_SE3_SLOTS || (my % (nw - 2)) != wv - 2) continue;
-      const double* tp = P + tr.poff;
-      double* sl = se3 + 48 * my;
-      V3 ev, ew;
-      if (se3_state) {
-        // r = x_ref (-) x on the base ; J = -Jlog6(Mref^-1 M)
-        const M3 Rr = quat_to_rot(tp + 3), Rb = quat_to_rot(q + 3);
-        const V3 pr = v3(tp[0], tp[1], tp[2]), pb = v3(q[0], q[1], q[2]);
-        log6(tmul(Rb, Rr), tmul(Rb, pr - pb), ev, ew);
-        if (derivs) { Jlog6(tmul(Rr, Rb), tmul(Rr, pb - pr), sl + 8); for (int e = 0; e < 36; ++e) sl[8 + e] = -sl[8 + e]; }
-      } else {
-        const int fi = tr.i0, i = mframe[fi];
-        const M3 Ri = ldm3(oR + 9 * i);
-        const M3 Rf = mul(Ri, ldm3(fd + 12 * fi));
-        const V3 pf = mul(Ri, ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
-        const M3 Rr = ldm3(tp);
-        const V3 pr = ldv3(tp + 9);
-        log6(tmul(Rr, Rf), tmul(Rr, pf - pr), ev, ew);
-        if (derivs) Jlog6(tmul(Rr, Rf), tmul(Rr, pf - pr), sl + 8);
+  // ---- SE(3)-valued terms: residual and Jacobian block, one term per wavefront lane 0 (waves 2.. ; 1.. when there are only two) ----
+  {
+    const int w0 = nw > 2 ? 2 : nw - 1, nws = nw - w0;
+    if (wv >= w0 && lane == 0) {
+      int slot_ = 0;
+      for (int t = 0; t < nterms; ++t) {
+        const TermRec tr = lds_term(lterm, t);
+        const bool se3_state = tr.type == MPC_TERM_STATE_ERROR && tr.i0 < 6;
+        if (!se3_state && tr.type != MPC_TERM_FRAME_PLACEMENT) continue;
+        const int my = slot_++;
+        if (my >= MB_SE3_SLOTS || (my % nws) != wv - w0) continue;
+        const double* tp = P + tr.poff;
+        double* sl = se3 + 48 * my;
+        V3 ev, ew;
+        if (se3_state) {
+          // r = x_ref (-) x on the base ; J = -Jlog6(Mref^-1 M)
+          const M3 Rr = quat_to_rot(tp + 3), Rb = quat_to_rot(q + 3);
+          const V3 pr = v3(tp[0], tp[1], tp[2]), pb = v3(q[0], q[1], q[2]);
+          log6(tmul(Rb, Rr), tmul(Rb, pr - pb), ev, ew);
+          if (derivs) { Jlog6(tmul(Rr, Rb), tmul(Rr, pb - pr), sl + 8); for (int e = 0; e < 36; ++e) sl[8 + e] = -sl[8 + e]; }
+        } else {
+          const int fi = tr.i0, i = mframe[fi];
+          const M3 Ri = ldcm3(oR, nj, i);
+          const M3 Rf = mul(Ri, ldm3(fd + 12 * fi));
+          const V3 pf = mul(Ri, ldv3(fd + 12 * fi + 9)) + ldcv3(op, nj, i);
+          const M3 Rr = ldm3(tp);
+          const V3 pr = ldv3(tp + 9);
+          log6(tmul(Rr, Rf), tmul(Rr, pf - pr), ev, ew);
+          if (derivs) Jlog6(tmul(Rr, Rf), tmul(Rr, pf - pr), sl + 8);
+        }
+        sl[0] = ev.x; sl[1] = ev.y; sl[2] = ev.z; sl[3] = ew.x; sl[4] = ew.y; sl[5] = ew.z;
       }
-      sl[0] = ev.x; sl[1] = ev.y; sl[2] = ev.z; sl[3] = ew.x; sl[4] = ew.y; sl[5] = ew.z;
     }
   }
   // ---- P12: semi-implicit Euler, gap and its Jacobians ----------------------------------------------------
@@ -891,6 +866,7 @@ sim_loop:
     double* Jl6 = small;        // Jlog6(G)
     double* Je6 = small + 36;   // Jexp6(delta)
     double* Jq6 = small + 72;   // Ad(exp6(delta))^-1
+    double* D12 = small + 108;  // D1_b = Jlog6(G) Jq6 (36) | Dd_b = dt Jlog6(G) Jexp6 (36)   (layout.h, oD12)
     // The SE(3) pieces are single-lane work (log / exp maps and their Jacobians): spread them over the wavefronts
     // — wave 0: step, gap, Jlog6(G) ; wave 1: Jexp6, Ad^-1, E6 ; waves 2..: the SE(3)-valued cost / constraint terms
     if (tid == 0 || (tid == 64 && derivs)) {
@@ -934,40 +910,31 @@ sim_loop:
     }
     __syncthreads();
     if (derivs) {
-      // dvp = dt * da + [0 I 0];  rows nv..n of AB = dvp; rows 6..nv = dt dvp + [I 0 0]; base rows below
+      // base rows in factored form (layout.h, oD12): D1_b = Jlog6(G) Jq6, Dd_b = dt Jlog6(G) Jexp6
+      if (tid < 72) {
+        const int e = tid % 36, r = e / 6, cc = e % 6;
+        const double* Rm_ = (tid < 36) ? Jq6 : Je6;
+        double s = 0;
+        for (int l = 0; l < 6; ++l) s += Jl6[6 * r + l] * Rm_[6 * l + cc];
+        s = (tid < 36) ? s : dt * s;
+        D12[tid] = s;
+        kn[KL.oD12 + tid] = s;
+      } else if (tid == 72) { kn[KL.oD12 + 72] = dt; kn[KL.oD12 + 73] = 1.0; }
+      // dvp = dt * da + [0 I 0];  rows nv..n of AB = dvp; rows 6..nv = dt dvp + [I 0 0]
       for (int idx = tid; idx < nv * nz; idx += nthr) {
         const int r = qdiv(idx, mg_nz), z = (idx - qdiv(idx, mg_nz) * nz);
-        const double da_rz = has_dyn ? -R1[r * ldR + z] : dsol[(size_t)r * L.nz + z];
-        const double dvp = dt * da_rz + ((z == nv + r) ? 1.0 : 0.0);
+        const double dvp = dt * dsol[(size_t)r * L.nz + z] + ((z == nv + r) ? 1.0 : 0.0);
         kn[KL.oAB + (size_t)(nv + r) * KL.nz + z] = dvp;
         if (r >= 6) kn[KL.oAB + (size_t)r * KL.nz + z] = dt * dvp + ((z == r) ? 1.0 : 0.0);
       }
-      __syncthreads();  // JL aliases rows of R1
-      // base rows: Jlog6(G) ( dt Jexp6 dvp[0:6] + [Jq6 0] )
-      for (int idx = tid; idx < 6 * nz; idx += nthr) {
-        const int r = qdiv(idx, mg_nz), z = (idx - qdiv(idx, mg_nz) * nz);
-        double s = (z < 6) ? Jq6[6 * r + z] : 0.0;
-        for (int l = 0; l < 6; ++l) {
-          const double da_lz = has_dyn ? -R1[l * ldR + z] : dsol[(size_t)l * L.nz + z];
-          s += dt * Je6[6 * r + l] * (dt * da_lz + ((z == nv + l) ? 1.0 : 0.0));
-        }
-        JL[idx] = s;  // temporary (6 x nz)
-      }
       __syncthreads();
+      // base rows: D1_b [I 0 0] + Dd_b dvp[0:6]
       for (int idx = tid; idx < 6 * nz; idx += nthr) {
         const int r = qdiv(idx, mg_nz), z = (idx - qdiv(idx, mg_nz) * nz);
-        double s = 0;
-        for (int l = 0; l < 6; ++l) s += Jl6[6 * r + l] * JL[l * nz + z];
+        double s = (z < 6) ? D12[6 * r + z] : 0.0;
+        for (int l = 0; l < 6; ++l) s += D12[36 + 6 * r + l] * (dt * dsol[(size_t)l * L.nz + z] + ((z == nv + l) ? 1.0 : 0.0));
         kn[KL.oAB + (size_t)r * KL.nz + z] = s;
       }
-      // the same rows in factored form (layout.h, oD12): D1_b = Jlog6(G) Jq6, Dd_b = dt Jlog6(G) Jexp6
-      if (tid < 72) {
-        const int e = tid % 36, r = e / 6, cc = e % 6;
-        const double* Rm = (tid < 36) ? Jq6 : Je6;
-        double s = 0;
-        for (int l = 0; l < 6; ++l) s += Jl6[6 * r + l] * Rm[6 * l + cc];
-        kn[KL.oD12 + tid] = (tid < 36) ? s : dt * s;
-      } else if (tid == 72) { kn[KL.oD12 + 72] = dt; kn[KL.oD12 + 73] = 1.0; }
       __syncthreads();
     }
   }
@@ -984,8 +951,8 @@ sim_loop:
   // contributions of the state and control error terms, accumulated in LDS) is written ONCE per knot by MFMA tiles —
   // no clear, no read-modify-write of the nz x nz block in HBM.  Constraints and the diagonal state / control costs
   // run through the whole workgroup term by term.
-  const S6 h0 = ld6(Hc);
-  double* gacc = Bt;     // nz: gradient accumulator        (the derivative vectors Bt, Tv, Phi, Tq are dead by now)
+  const S6 h0 = ldc6(Hc, nj, 0);
+  double* gacc = Bt;     // nz: gradient accumulator        (the derivative vectors Bt, Tv, Phi are dead by now)
   double* hdg = Tv;      // nz: additions to diag(H)
   double* hbb = Phi;     // 36: additions to the base 6x6 block of H
   double* tcost = small; // per-term cost, summed in term order at the end (deterministic)
@@ -1043,34 +1010,34 @@ sim_loop:
       for (int i = t0; i < d; i += nt) { r[i] = u[tr.i0 + i] - tp[tr.i0 + i]; if (derivs) Jt[i * nz + n + tr.i0 + i] = 1.0; }
     } else if (tr.type == MPC_TERM_FRAME_PLACEMENT || tr.type == MPC_TERM_FRAME_TRANSLATION || tr.type == MPC_TERM_FRAME_VELOCITY) {
       const int fi = tr.i0, i = mframe[fi];
-      const M3 Ri = ldm3(oR + 9 * i);
+      const M3 Ri = ldcm3(oR, nj, i);
       const M3 Rf = mul(Ri, ldm3(fd + 12 * fi));
-      const V3 pf = mul(Ri, ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+      const V3 pf = mul(Ri, ldv3(fd + 12 * fi + 9)) + ldcv3(op, nj, i);
       if (tr.type == MPC_TERM_FRAME_PLACEMENT) {
         const double* Jl = sl + 8;
         if (t0 < 6) r[t0] = sl[t0];
         if (derivs) for (int j = t0; j < nv; j += nt) if (BELOW(j, i)) {
-          const S6 col = mat6_mul(Jl, adinv(Rf, pf, ld6(J + 6 * j)));
+          const S6 col = mat6_mul(Jl, adinv(Rf, pf, ldc6(J, nv, j)));
           for (int rr = 0; rr < 6; ++rr) Jt[rr * nz + j] = col.v[rr];
         }
       } else if (tr.type == MPC_TERM_FRAME_TRANSLATION) {
         if (t0 < d) { const double pfa[3] = {pf.x, pf.y, pf.z}; r[t0] = pfa[tr.i1 + t0] - tp[tr.i1 + t0]; }
         if (derivs) for (int j = t0; j < nv; j += nt) if (BELOW(j, i)) {
-          const S6 Jj = ld6(J + 6 * j);
+          const S6 Jj = ldc6(J, nv, j);
           const V3 lv = lin(Jj) + cross(ang(Jj), pf);
           const double la[3] = {lv.x, lv.y, lv.z};
           for (int rr = 0; rr < d; ++rr) Jt[rr * nz + j] = la[tr.i1 + rr];
         }
       } else {
-        if (t0 == 0) { const S6 vf = adinv(Rf, pf, ld6(ov + 6 * i)); for (int rr = 0; rr < 6; ++rr) r[rr] = vf.v[rr] - tp[rr]; }
+        if (t0 == 0) { const S6 vf = adinv(Rf, pf, ldc6(ov, nj, i)); for (int rr = 0; rr < 6; ++rr) r[rr] = vf.v[rr] - tp[rr]; }
         if (derivs) for (int j = t0; j < nv; j += nt) if (BELOW(j, i)) {
-          const S6 cq = adinv(Rf, pf, ld6(Psd + 6 * j)), cv = adinv(Rf, pf, ld6(J + 6 * j));
+          const S6 cq = adinv(Rf, pf, ldc6(Psd, nv, j)), cv = adinv(Rf, pf, ldc6(J, nv, j));
           for (int rr = 0; rr < 6; ++rr) { Jt[rr * nz + j] = cq.v[rr]; Jt[rr * nz + nv + j] = cv.v[rr]; }
         }
       }
     } else if (tr.type == MPC_TERM_COM_TRANSLATION) {
       if (t0 < d) { const double ca[3] = {com.x, com.y, com.z}; r[t0] = ca[tr.i1 + t0] - tp[tr.i1 + t0]; }
-      if (derivs) for (int j = t0; j < nv; j += nt) for (int rr = 0; rr < d; ++rr) Jt[rr * nz + j] = U[6 * j + tr.i1 + rr] / mtot;
+      if (derivs) for (int j = t0; j < nv; j += nt) for (int rr = 0; rr < d; ++rr) Jt[rr * nz + j] = U[(tr.i1 + rr) * nv + j] / mtot;
     } else if (tr.type == MPC_TERM_CENTROIDAL_MOMENTUM) {
       if (t0 == 0) {
         const V3 hl = lin(h0), ha = ang(h0) - cross(com, lin(h0));
@@ -1078,8 +1045,8 @@ sim_loop:
       }
       if (derivs) for (int j = t0; j < nv; j += nt) {
         const int bj = dof_body[j];
-        const S6 Uj = ld6(U + 6 * j);
-        const S6 D = add6(fcross(ld6(J + 6 * j), ld6(Hc + 6 * bj)), mat6_mul(Yc + 36 * bj, ld6(Psd + 6 * j)));
+        const S6 Uj = ldc6(U, nv, j);
+        const S6 D = add6(fcross(ldc6(J, nv, j), ldc6(Hc, nj, bj)), ldc6(YcPsd, nv, j));
         const V3 dc = (1.0 / mtot) * lin(Uj);
         const V3 dql = lin(D), dqa = ang(D) - cross(dc, lin(h0)) - cross(com, lin(D));
         const V3 dvl = lin(Uj), dva = ang(Uj) - cross(com, lin(Uj));
@@ -1088,7 +1055,7 @@ sim_loop:
       }
     } else if (tr.type == MPC_TERM_CONTACT_FORCE) {
       if (t0 < 6) r[t0] = lam[6 * tr.i0 + t0] - tp[t0];
-      if (derivs) for (int idx = t0; idx < 6 * nz; idx += nt) Jt[idx] = R2[(6 * tr.i0 + qdiv(idx, mg_nz)) * ldR + (idx - qdiv(idx, mg_nz) * nz)];
+      if (derivs) for (int idx = t0; idx < 6 * nz; idx += nt) Jt[idx] = DL[(6 * tr.i0 + qdiv(idx, mg_nz)) * ldl + (idx - qdiv(idx, mg_nz) * nz)];
     } else if (tr.type == MPC_TERM_CENTROIDAL_WRENCH_CONE) {
       for (int i = t0; i < d; i += nt) { double sacc = 0; for (int j = 0; j < 6; ++j) sacc += tp[i * 6 + j] * u[6 * tr.i0 + j]; r[i] = sacc; }
       if (derivs) for (int idx = t0; idx < d * 6; idx += nt) Jt[(idx / 6) * nz + n + 6 * tr.i0 + idx % 6] = tp[idx];
@@ -1100,7 +1067,7 @@ sim_loop:
         for (int cc = 0; cc < nkk; ++cc) {
           if (tp[3 + cc] == 0.0) continue;
           const int fi = (int)tp[3 + nkk + cc], i = mframe[fi];
-          const V3 pf = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+          const V3 pf = mul(ldcm3(oR, nj, i), ldv3(fd + 12 * fi + 9)) + ldcv3(op, nj, i);
           const V3 f = v3(u[6 * cc], u[6 * cc + 1], u[6 * cc + 2]);
           rl = rl + f;
           ra = ra + cross(pf - com, f) + v3(u[6 * cc + 3], u[6 * cc + 4], u[6 * cc + 5]);
@@ -1110,12 +1077,12 @@ sim_loop:
       if (derivs) {
         for (int j = t0; j < nv; j += nt) {
           V3 dang = v3(0, 0, 0);
-          const S6 Jj = ld6(J + 6 * j);
-          const V3 dc = (1.0 / mtot) * lin(ld6(U + 6 * j));
+          const S6 Jj = ldc6(J, nv, j);
+          const V3 dc = (1.0 / mtot) * lin(ldc6(U, nv, j));
           for (int cc = 0; cc < nkk; ++cc) {
             if (tp[3 + cc] == 0.0) continue;
             const int fi = (int)tp[3 + nkk + cc], i = mframe[fi];
-            const V3 pf = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+            const V3 pf = mul(ldcm3(oR, nj, i), ldv3(fd + 12 * fi + 9)) + ldcv3(op, nj, i);
             V3 dp_ = v3(0, 0, 0);
             if (BELOW(j, i)) dp_ = lin(Jj) + cross(ang(Jj), pf);
             dang = dang + cross(dp_ - dc, v3(u[6 * cc], u[6 * cc + 1], u[6 * cc + 2]));
@@ -1124,7 +1091,7 @@ sim_loop:
         }
         if (t0 < nkk && tp[3 + t0] != 0.0) {
           const int cc = t0, fi = (int)tp[3 + nkk + cc], i = mframe[fi];
-          const V3 rr = mul(ldm3(oR + 9 * i), ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i) - com;
+          const V3 rr = mul(ldcm3(oR, nj, i), ldv3(fd + 12 * fi + 9)) + ldcv3(op, nj, i) - com;
           const M3 Rx = skew_m(rr);
           for (int e = 0; e < 3; ++e) {
             Jt[e * nz + n + 6 * cc + e] = 1.0;
@@ -1138,7 +1105,7 @@ sim_loop:
       if (derivs) for (int idx = t0; idx < d * nz; idx += nt) {
         const int i = qdiv(idx, mg_nz), z = (idx - qdiv(idx, mg_nz) * nz);
         double s = 0;
-        for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * R2[(6 * tr.i0 + j) * ldR + z];
+        for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * DL[(6 * tr.i0 + j) * ldl + z];
         Jt[idx] = s;
       }
     }
@@ -1148,7 +1115,7 @@ sim_loop:
   // ---- pass B: constraints and the diagonal state / control costs, term by term through the whole workgroup ----
   {
     int row = 0;
-    double* r = red + 2 * 256 - 64;
+    double* r = red + 48;
     for (int t = 0; t < nterms; ++t) {
       const TermRec tr = lds_term(lterm, t);
       if (tkind[t] != 0) continue;
@@ -1226,7 +1193,7 @@ sim_loop:
       const int d = tr.dim;
       if (trow[t] + d > rowc) rowc = trow[t] + d;
       if ((ord++ % nw) != wv) continue;
-      double* r = red + 288 + 24 * wv;  // private residual scratch of this wavefront
+      double* r = red + 112 + 24 * wv;  // private residual scratch of this wavefront
       double* Jt = JS + trow[t] * nz;
       term_rows(tr, P + tr.poff, se3 + 48 * tse3[t], r, Jt, lane, 64, false);
       const double* W = P + tr.woff;
@@ -1262,10 +1229,10 @@ sim_loop:
         mma_tile<false>(h, JS + ta * 16, 1, nz, JS + tb * 16, nz, 1, kc, lane);
         const int zb = tb * 16 + (lane & 15);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int za = ta * 16 + (lane >> 4) + 4 * q;
+        for (int qq = 0; qq < 4; ++qq) {
+          const int za = ta * 16 + (lane >> 4) + 4 * qq;
           if (za < nz && zb < nz) {
-            double hv = h[q];
+            double hv = h[qq];
             if (ch == 0) {
               if (za == zb) hv += hdg[za];
               if (za < 6 && zb < 6) hv += hbb[6 * za + zb];
@@ -1286,7 +1253,7 @@ sim_loop:
   // ---- pass C: cost terms with dense weights (none in the three Talos problems): HBM read-modify-write path ----
   if (tmeta[1]) {
     __syncthreads();
-    double* r = red + 2 * 256 - 64;
+    double* r = red + 48;
     for (int t = 0; t < nterms; ++t) {
       if (tkind[t] != 2) continue;
       const TermRec tr = lds_term(lterm, t);
@@ -1294,7 +1261,7 @@ sim_loop:
       if (derivs) for (int idx = tid; idx < tr.dim * nz; idx += nthr) JtG[idx] = JS[idx];
       __syncthreads();
       double cst = 0.0;
-      accumulate_cost(KL, kn, tr, P + tr.woff, r, JtG, nz, nz, red, WJ, derivs, cst, tid, nthr);
+      accumulate_cost(KL, kn, tr, P + tr.woff, r, JtG, nz, nz, red + 112, WJ, derivs, cst, tid, nthr);
       if (tid == 0) tcost[t] = cst;
     }
   }
@@ -1321,37 +1288,4 @@ sim_loop:
   // 7 (N + 1) B dispatches that each need the whole LDS of a CU just to find out that the full step was accepted.
   if (TRIAL == 1 && mb.ncand_loop > 0 && cand + 1 < cand0 + mb.ncand_loop) { ++cand; __syncthreads(); goto cand_loop; }
 #undef BELOW
-#undef INSUB
-}
-
-static inline void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout& LT, double* records, double* scratch,
-                                         size_t scratch_stride, bool trial, int cand0 = 0, int ncand = 1, int sim_substeps = 0, double sim_dt = 0.0,
-                                         bool with_derivs = false) {
-  const Layout& L = a.L;
-  MbArgs mb;
-  mb.lds = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m, L.nz);
-  mb.scratch = scratch;
-  mb.scratch_stride = scratch_stride;
-  mb.sim_substeps = sim_substeps; mb.sim_dt = sim_dt;
-  mb.ncand_loop = (trial && !with_derivs && ncand > 1) ? ncand : 0;
-  if (mb.lds.total_bytes > 160 * 1024) throw std::runtime_error("multibody model too large for the LDS budget of the stage kernel");
-  // hipFuncSetAttribute is a per-device setting: remember what was requested on every device (a process may hold handles on several
-  // devices, driven from different threads)
-  static std::atomic<int> attr_bytes_dev[64];
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  std::atomic<int>& attr_bytes = attr_bytes_dev[dev & 63];
-  if (attr_bytes.load() != mb.lds.total_bytes + 1) {
-    // the kernel also owns a few bytes of static LDS, so request exactly what the carve-out needs
-    hipError_t e1 = hipFuncSetAttribute((const void*)k_eval_multibody<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
-    hipError_t e2 = hipFuncSetAttribute((const void*)k_eval_multibody<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
-    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)k_eval_multibody<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
-    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)k_eval_multibody<3>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
-    if (e1 != hipSuccess || e2 != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(LDS) failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-    attr_bytes.store(mb.lds.total_bytes + 1);  // + 1: the zero-initialised slots mean "not set"
-  }
-  if (sim_substeps > 0) hipLaunchKernelGGL(k_eval_multibody<2>, dim3(1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, 0);
-  else if (trial && with_derivs) hipLaunchKernelGGL(k_eval_multibody<3>, dim3(L.N + 1 + (a.spec_knot ? 1 : 0), L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);  // records = the knot records (+ the speculative knot)
-  else if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
-  else hipLaunchKernelGGL(k_eval_multibody<1>, dim3(L.N + 1, L.B, mb.ncand_loop > 0 ? 1 : ncand), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
 }

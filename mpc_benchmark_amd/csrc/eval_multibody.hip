@@ -1,0 +1,46 @@
+// eval_multibody.hip — translation unit of the whole-body stage kernel (K1-K5, K7 of SURVEY.md §8a-2) and its launcher.
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <stdexcept>
+#include <string>
+#include "eval_multibody.h"
+
+void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout& LT, double* records, double* scratch, size_t scratch_stride,
+                           bool trial, int cand0, int ncand, int sim_substeps, double sim_dt, bool with_derivs) {
+  const Layout& L = a.L;
+  MbArgs mb;
+  mb.lds = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m, L.nz);
+  mb.scratch = scratch;
+  mb.scratch_stride = scratch_stride;
+  mb.sim_substeps = sim_substeps; mb.sim_dt = sim_dt;
+  mb.ncand_loop = (trial && !with_derivs && ncand > 1) ? ncand : 0;
+  if (mb.lds.total_bytes > 160 * 1024) throw std::runtime_error("multibody model too large for the LDS budget of the stage kernel");
+  // hipFuncSetAttribute is a per-device setting: remember what was requested on every device (a process may hold handles on several
+  // devices, driven from different threads)
+  static std::atomic<int> attr_bytes_dev[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::atomic<int>& attr_bytes = attr_bytes_dev[dev & 63];
+  if (attr_bytes.load() != mb.lds.total_bytes + 1) {
+    // the kernel also owns a few bytes of static LDS, so request exactly what the carve-out needs
+    hipError_t e1 = hipFuncSetAttribute((const void*)k_eval_multibody<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
+    hipError_t e2 = hipFuncSetAttribute((const void*)k_eval_multibody<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
+    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)k_eval_multibody<2>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
+    if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)k_eval_multibody<3>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
+    if (e1 != hipSuccess || e2 != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(LDS) failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    attr_bytes.store(mb.lds.total_bytes + 1);  // + 1: the zero-initialised slots mean "not set"
+  }
+  if (sim_substeps > 0) hipLaunchKernelGGL(k_eval_multibody<2>, dim3(1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, 0);
+  else if (trial && with_derivs) hipLaunchKernelGGL(k_eval_multibody<3>, dim3(L.N + 1 + (a.spec_knot ? 1 : 0), L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);  // records = the knot records (+ the speculative knot)
+  else if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
+  else hipLaunchKernelGGL(k_eval_multibody<1>, dim3(L.N + 1, L.B, mb.ncand_loop > 0 ? 1 : ncand), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
+}
+
+const void* eval_multibody_kernel(int trial) {
+  switch (trial) {
+    case 0: return (const void*)k_eval_multibody<0>;
+    case 1: return (const void*)k_eval_multibody<1>;
+    case 2: return (const void*)k_eval_multibody<2>;
+    default: return (const void*)k_eval_multibody<3>;
+  }
+}

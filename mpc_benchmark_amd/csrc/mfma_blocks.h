@@ -146,23 +146,24 @@ template <int J> struct CholStep {
   }
 };
 template <> struct CholStep<16> { static DEV void run(double (&)[16], double (&)[16], bool&) {} };
+// (nd = -L: the sign rides on the broadcast operand, so no negated copy of x is kept — 32 VGPRs less, same bits)
 template <int R, int K> struct InvDot {
-  static DEV void run(const double (&d)[16], const double (&nx)[16], double& acc) { fmac_bcast<R>(acc, d[K], nx[K]); InvDot<R, K + 1>::run(d, nx, acc); }  // acc -= L[R][K] x[K]
+  static DEV void run(const double (&nd)[16], const double (&x)[16], double& acc) { fmac_bcast<R>(acc, nd[K], x[K]); InvDot<R, K + 1>::run(nd, x, acc); }  // acc -= L[R][K] x[K]
 };
 template <int R> struct InvDot<R, R> { static DEV void run(const double (&)[16], const double (&)[16], double&) {} };
 template <int R> struct InvRow {
-  static DEV void run(const double (&d)[16], const double (&invd)[16], double (&x)[16], double (&nx)[16], int lane) {
+  static DEV void run(const double (&nd)[16], const double (&invd)[16], double (&x)[16], int lane) {
     double acc = ((lane & 15) == R) ? 1.0 : 0.0;
-    InvDot<R, 0>::run(d, nx, acc);
+    InvDot<R, 0>::run(nd, x, acc);
     x[R] = acc * invd[R];
-    nx[R] = -x[R];
-    InvRow<R + 1>::run(d, invd, x, nx, lane);
+    InvRow<R + 1>::run(nd, invd, x, lane);
   }
 };
-template <> struct InvRow<16> { static DEV void run(const double (&)[16], const double (&)[16], double (&)[16], double (&)[16], int) {} };
+template <> struct InvRow<16> { static DEV void run(const double (&)[16], const double (&)[16], double (&)[16], int) {} };
 
 // One wavefront: Cholesky of the 16x16 block D (lower triangle, leading dimension ld) entirely in registers —
-// lane r (< 16) holds row r — then its inverse.  Writes L back over D (lower part) and L^-1 to LIb (ld 17).
+// lane r (< 16) holds row r — then its inverse.  Writes L back over D (lower part) and L^-1 to LIb (ld 17); LIb == D (ld 17): the
+// inverse REPLACES the block (the blocked routines never read a diagonal block of L again, only its inverse).
 DEV bool chol16_wave(double* D, int ld, double* LIb, int lane) {
   double d[16], x[16], invd[16];
   const int r = lane & 15;
@@ -170,13 +171,14 @@ DEV bool chol16_wave(double* D, int ld, double* LIb, int lane) {
   for (int cidx = 0; cidx < 16; ++cidx) d[cidx] = D[r * ld + cidx];
   bool ok = true;
   CholStep<0>::run(d, invd, ok);
-  double nx[16];
-#pragma unroll
-  for (int cidx = 0; cidx < 16; ++cidx) { x[cidx] = 0.0; nx[cidx] = 0.0; }
-  InvRow<0>::run(d, invd, x, nx, lane);  // lane c of every 16-lane row builds column c of L^-1
-  if (lane < 16) {
+  if (lane < 16 && D != LIb) {
 #pragma unroll
     for (int cidx = 0; cidx < 16; ++cidx) if (cidx <= r) D[r * ld + cidx] = d[cidx];
+  }
+#pragma unroll
+  for (int cidx = 0; cidx < 16; ++cidx) { x[cidx] = 0.0; d[cidx] = -d[cidx]; }
+  InvRow<0>::run(d, invd, x, lane);  // lane c of every 16-lane row builds column c of L^-1
+  if (lane < 16) {
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) LIb[rr * 17 + lane] = x[rr];
   }
@@ -277,3 +279,70 @@ DEV void trsm_bwd_blocked(const double* Lm, int ld, const double* LI, int nb, do
   }
 }
 
+// ---- tile-packed lower block triangle -------------------------------------------------------------------------
+// The whole-body stage kernel keeps M = L L^T as the nb (nb + 1) / 2 tiles of its lower block triangle, tile (bi, bj), bj <= bi, at
+// T + (bi (bi + 1) / 2 + bj) * 272 with leading dimension 17: no storage for the upper triangle, and the inverse of a diagonal block
+// replaces the block (half the LDS of the square layout + separate inverses).
+DEV double* ptile(double* T, int bi, int bj) { return T + (bi * (bi + 1) / 2 + bj) * 272; }
+DEV const double* ctile(const double* T, int bi, int bj) { return T + (bi * (bi + 1) / 2 + bj) * 272; }
+
+// acc (+/-)= A Breg: A(i, k) at A[i * a_is + k * a_ks] in LDS, the 16 x 16 operand B in REGISTERS in the fragment layout of a result tile
+// (register r of lane l = B((l >> 4) + 4 r, l & 15)) — which is exactly what the k-step r of the MFMA wants from lane l, so a chain of
+// dependent tile products (triangular solves) never goes back to LDS with its intermediate results.
+template <bool NEG>
+DEV void mma_tile_rb(d4_t& acc, const double* A, int a_is, int a_ks, const d4_t& B, int lane) {
+  const double* ap = A + (lane & 15) * a_is + (lane >> 4) * a_ks;
+  double a0 = ap[0], a1 = ap[4 * a_ks], a2 = ap[8 * a_ks], a3 = ap[12 * a_ks];
+  if (NEG) { a0 = -a0; a1 = -a1; a2 = -a2; a3 = -a3; }
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, B[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, B[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, B[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, B[3], acc, 0, 0, 0);
+}
+
+// Cholesky of the tile-packed matrix by ONE wavefront (pad rows / columns must be identity): off-diagonal tiles receive L, diagonal
+// tiles the INVERSE of their Cholesky factor.
+DEV bool chol_tiles_wave(double* T, int nb, int lane) {
+  bool ok = true;
+  for (int kb = 0; kb < nb && ok; ++kb) {
+    double* Dk = ptile(T, kb, kb);
+    ok = chol16_wave(Dk, 17, Dk, lane);
+    for (int ri = kb + 1; ri < nb; ++ri) {  // panel: L[ri][kb] = A[ri][kb] LI^T
+      double* Pt = ptile(T, ri, kb);
+      d4_t acc = d4_t{0, 0, 0, 0};
+      mma_tile<false>(acc, Pt, 17, 1, Dk, 1, 17, 16, lane);
+      tile_store(Pt, 17, acc, lane);
+    }
+    for (int ri = kb + 1; ri < nb; ++ri)
+      for (int cj = kb + 1; cj <= ri; ++cj) {  // trailing update: A[ri][cj] -= L[ri][kb] L[cj][kb]^T
+        double* Ct = ptile(T, ri, cj);
+        d4_t acc = tile_load(Ct, 17, lane);
+        mma_tile<true>(acc, ptile(T, ri, kb), 17, 1, ptile(T, cj, kb), 1, 17, 16, lane);
+        tile_store(Ct, 17, acc, lane);
+      }
+  }
+  return ok;
+}
+// B <- L^-1 B / B <- L^-T B on an LDS operand B ((16 nb) x (16 ncb), leading dimension ldb), column blocks dealt to the wavefronts
+DEV void trsm_fwd_tiles(const double* T, int nb, double* Bm, int ldb, int ncb, int wv, int nw, int lane) {
+  for (int cj = wv; cj < ncb; cj += nw)
+    for (int bi = 0; bi < nb; ++bi) {
+      double* Bt = Bm + (bi * 16) * ldb + cj * 16;
+      d4_t acc = tile_load(Bt, ldb, lane);
+      for (int bj = 0; bj < bi; ++bj) mma_tile<true>(acc, ctile(T, bi, bj), 17, 1, Bm + (bj * 16) * ldb + cj * 16, ldb, 1, 16, lane);
+      d4_t acc2 = d4_t{0, 0, 0, 0};
+      mma_tile_rb<false>(acc2, ctile(T, bi, bi), 17, 1, acc, lane);
+      tile_store(Bt, ldb, acc2, lane);
+    }
+}
+DEV void trsm_bwd_tiles(const double* T, int nb, double* Bm, int ldb, int ncb, int wv, int nw, int lane) {
+  for (int cj = wv; cj < ncb; cj += nw)
+    for (int bi = nb - 1; bi >= 0; --bi) {
+      double* Bt = Bm + (bi * 16) * ldb + cj * 16;
+      d4_t acc = tile_load(Bt, ldb, lane);
+      for (int bj = bi + 1; bj < nb; ++bj) mma_tile<true>(acc, ctile(T, bj, bi), 1, 17, Bm + (bj * 16) * ldb + cj * 16, ldb, 1, 16, lane);
+      d4_t acc2 = d4_t{0, 0, 0, 0};
+      mma_tile_rb<false>(acc2, ctile(T, bi, bi), 1, 17, acc, lane);
+      tile_store(Bt, ldb, acc2, lane);
+    }
+}

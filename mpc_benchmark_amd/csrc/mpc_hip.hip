@@ -11,7 +11,8 @@
 #include <utility>
 #include <vector>
 
-#include "eval_multibody.h"
+#include "eval_multibody_host.h"
+#include "eval_reuse_kernels.h"
 #include "eval_vector.h"
 #include "riccati_mfma.h"
 #include "closed_loop.h"
@@ -756,9 +757,9 @@ int mpc_kernel_info(mpc_solver* s, int32_t idx, char* name, int32_t name_cap, in
       e.push_back({"k_eval_vector<1> (linesearch candidate)", (const void*)k_eval_vector<1>, 64, 0, (long long)(L.N + 1) * L.B});
     } else {
       const MbLds ml = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m, L.nz);
-      e.push_back({"k_eval_multibody<0> (stage kernel, value + derivatives)", (const void*)k_eval_multibody<0>, EVAL_THREADS, ml.total_bytes, (long long)(L.N + 1) * L.B});
-      e.push_back({"k_eval_multibody<3> (alpha = 1 candidate with derivatives)", (const void*)k_eval_multibody<3>, EVAL_THREADS, ml.total_bytes, (long long)(L.N + 1) * L.B});
-      e.push_back({"k_eval_multibody<1> (backtracking candidates, values only)", (const void*)k_eval_multibody<1>, EVAL_THREADS, ml.total_bytes, (long long)(L.N + 1) * L.B});
+      e.push_back({"k_eval_multibody<0> (stage kernel, value + derivatives)", eval_multibody_kernel(0), EVAL_THREADS, ml.total_bytes, (long long)(L.N + 1) * L.B});
+      e.push_back({"k_eval_multibody<3> (alpha = 1 candidate with derivatives)", eval_multibody_kernel(3), EVAL_THREADS, ml.total_bytes, (long long)(L.N + 1) * L.B});
+      e.push_back({"k_eval_multibody<1> (backtracking candidates, values only)", eval_multibody_kernel(1), EVAL_THREADS, ml.total_bytes, (long long)(L.N + 1) * L.B});
     }
     const bool small = s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS;
     if (J > 1) {
