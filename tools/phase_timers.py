@@ -39,9 +39,10 @@ for i, name in ric.items():
     print('RIC  %-40s %7.1f us/knot %5.1f%%' % (name, p[i] / knots / (GHZ * 1e3), 100 * p[i] / tot))
 print('RIC  total %.1f us/knot ; series: max rho %.3e, mean terms %.2f, Cholesky fallbacks per knot %.3f' % (
     tot / knots / (GHZ * 1e3), p[20], p[21] / knots, p[22] / knots))
-ev = {0: 'load, FK, joint columns', 1: 'velocities, inertias, composites, U', 2: 'M, bias, contact frames, Jc, Y16', 3: 'chol M (blocked, MFMA)',
-      5: 'Y, S, multipliers, accelerations', 6: 'forces at the solution', 7: 'derivative building blocks', 8: 'right-hand sides R1, R2',
-      9: 'implicit differentiation (blocked solves)', 10: 'SE(3) pre-pass, integrator, [A B]', 29: 'term table: classification, accumulator reset',
+ev = {0: 'load, FK, joint columns', 1: 'velocities, inertias, composites, U', 7: 'derivative pre-pass (Psd, Phi, B_i, Bc, Bt, Tv)',
+      2: 'M tiles, bias, contact frames, Y16', 5: 'chol M, Y, S, multipliers, accelerations (one wave)', 6: 'xdot / wrench record, contact wrenches',
+      3: 'forces at the solution, Psdd, Tq', 8: 'contact rows R2', 9: 'R1 in registers + implicit differentiation',
+      10: 'SE(3) pre-pass, integrator, [A B]', 29: 'term table: classification, accumulator reset',
       11: 'dense-weight terms, cost sum', 12: 'merit, projections'}
 terms = {1: 'state_error', 2: 'control_error', 3: 'frame_placement', 4: 'frame_translation', 5: 'frame_velocity', 6: 'com_translation',
          7: 'centroidal_momentum', 8: 'contact_force', 9: 'mb_wrench_cone', 10: 'centroidal_wrench_cone', 13: 'centroidal_momentum_der'}
