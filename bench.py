@@ -85,7 +85,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from mpc_benchmark_amd import _capi
-    from mpc_benchmark_amd.ensemble import EnsembleMPC, gain_doubles, lq_knot_doubles
+    from mpc_benchmark_amd.ensemble import EnsembleMPC, gain_doubles, lq_knot_doubles, make_bench_shards
     from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
 
     # raises if the HIP library is missing: no CPU fallback
@@ -94,15 +94,9 @@ def main():
         raise RuntimeError("bench.py measures the HIP library only")
     pd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
     nshard = max(1, min(args.streams, args.batch))
-    sizes = [args.batch // nshard + (1 if i < args.batch % nshard else 0) for i in range(nshard)]
-    shards = [EnsembleMPC(pd, batch=sz, library=lib, device=local_rank, seed=20250304 + 1000 * rank + i,
-                          closed_loop=((10, pd.dt / 10) if args.closed_loop else None), forward_mode=(1 if nshard > 1 else 0),
-                          tick_reuse=not args.no_tick_reuse)
-              for i, sz in enumerate(sizes)]
-    if args.legs > 0:
-        for e in shards:
-            e.options.riccati_legs = args.legs
-            e.native.set_options(e.options)
+    # ONE ensemble of batch x world instances (one rng stream, instance order), instance i on GPU i mod G
+    shards = make_bench_shards(pd, lib, args.batch, rank=rank, world=world, streams=args.streams, device=local_rank, legs=args.legs,
+                               tick_reuse=not args.no_tick_reuse, closed_loop=((10, pd.dt / 10) if args.closed_loop else None))
     ens = shards[0]
     legs = int(ens.options.riccati_legs)
     cold = None
@@ -244,6 +238,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # round-end exchange, outside the timed region: every rank receives the result blocks of the whole ensemble
+    gather = None
+    if dist is not None:
+        import torch
+        from mpc_benchmark_amd.ensemble import allgather_results
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        gids, gblk = allgather_results(shards, dist, device=torch.device("cuda", local_rank))
+        gather = {"instances": int(gids.size), "complete": bool(np.array_equal(gids, np.arange(args.batch * world))),
+                  "bytes_per_rank": int(gblk.nbytes // world), "ms": round((time.perf_counter() - tg) * 1e3, 3),
+                  "finite": bool(np.isfinite(gblk).all())}
     prof = {}
     for e in shards:  # per-kernel launches / time summed over the shards
         for kname, (cnt, ms) in e.native.profile_read().items():
@@ -388,6 +393,7 @@ def main():
         "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; the others are within 1e-4 of feasibility)" % (n_conv, args.batch),
         "instance_ticks_without_step": nostep["n"] * world, "diverged_instance_rescues": sum(getattr(e, "rescues", 0) for e in shards),
         "episode_ticks": args.episode, "episode_restarts": sum(getattr(e, "episodes", 0) for e in shards),
+        "ensemble_allgather": gather,
         "roofline": roof, "cpu_baseline": cpu, "roofline_riccati": roof_ric,
         # supplementary: the same kernel against the fp64 matrix-core peak (the sweep is a chain of dependent dense steps on ONE CU
         # per instance, not a streaming kernel — DESIGN.md §5); flops = textbook count of the recursion on the unpadded dimensions

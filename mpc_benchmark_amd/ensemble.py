@@ -15,9 +15,10 @@ from .aligator import _core as core
 
 class EnsembleMPC:
     def __init__(self, problem_def, batch=1, library=None, device=0, seed=20250304, perturb=True, sigma_q=0.02, sigma_v=0.05, perturb_dofs=None,
-                 closed_loop=None, forward_mode=0, tick_reuse=False):
+                 closed_loop=None, forward_mode=0, tick_reuse=False, x0=None):
         """``problem_def``: a FullDynamicsProblem / CentroidalProblem-like builder (``build``, ``stage_for_tick``,
-        ``make_solver``, ``initial_guess``).  ``forward_mode``: mpc_options.forward_mode (1 for shards that share a GPU)."""
+        ``make_solver``, ``initial_guess``).  ``forward_mode``: mpc_options.forward_mode (1 for shards that share a GPU).
+        ``x0`` (batch, nx): explicit initial states (a shard of ``ensemble_initial_states``) instead of drawing them here."""
         self.pd = problem_def
         self.batch = int(batch)
         self.lib = library if library is not None else K.load_hip_library()
@@ -52,29 +53,12 @@ class EnsembleMPC:
             self.native.set_stage(k, desc, params)
         self.tables = tables
         # randomised initial states: joints ~ N(0, sigma_q^2), joint velocities ~ N(0, sigma_v^2)
-        rng = np.random.default_rng(seed)
-        x0 = np.asarray(self.problem.x0_init, dtype=float)
-        self.x0 = np.tile(x0, (self.batch, 1))
-        if perturb and hasattr(space, "model"):
-            nv = space.model.nv
-            for b in range(self.batch):
-                dq = np.zeros(2 * nv)
-                dq[6:nv] = sigma_q * rng.standard_normal(nv - 6)
-                dq[nv + 6:] = sigma_v * rng.standard_normal(nv - 6)
-                if perturb_dofs is not None:  # e.g. upper body only: feet that must stay at rest are not disturbed
-                    keep = np.zeros(nv, dtype=bool)
-                    keep[np.asarray(perturb_dofs, dtype=int)] = True
-                    dq[:nv][~keep] = 0.0
-                    dq[nv:][~keep] = 0.0
-                if b > 0:
-                    xb = space.integrate(x0, dq)
-                    # keep the measured configuration inside the joint limits: the initial state is fixed
-                    # (force_initial_condition), so a violated limit at knot 0 is an infeasible constraint that no
-                    # iteration can repair (two joints of the nominal posture sit exactly on a limit)
-                    mdl = space.model
-                    if hasattr(mdl, "lowerPositionLimit"):
-                        xb[7:mdl.nq] = np.clip(xb[7:mdl.nq], mdl.lowerPositionLimit[7:], mdl.upperPositionLimit[7:])
-                    self.x0[b] = xb
+        if x0 is not None:
+            self.x0 = np.ascontiguousarray(np.asarray(x0, dtype=float).reshape(self.batch, -1))
+        elif perturb and hasattr(space, "model"):
+            self.x0 = ensemble_initial_states(self.problem.x0_init, space, self.batch, seed, sigma_q, sigma_v, perturb_dofs)
+        else:
+            self.x0 = np.tile(np.asarray(self.problem.x0_init, dtype=float), (self.batch, 1))
         # closed_loop = (substeps, dt): the measured state of every tick comes from the simulation stand-in (N2: knot 0's dynamics
         # integrated under the feedback law of the low-level loop) instead of the model's own prediction xs[1]
         self.closed_loop = closed_loop
@@ -182,6 +166,94 @@ class EnsembleMPC:
 
     def results(self, **kw):
         return self.native.get_results(**kw)
+
+
+def ensemble_initial_states(x0, space, total, seed=20250304, sigma_q=0.02, sigma_v=0.05, perturb_dofs=None):
+    """Initial states of an ensemble of ``total`` instances: ONE ``default_rng(seed)`` stream drawn in
+    instance order — joints ~ N(0, sigma_q^2), joint velocities ~ N(0, sigma_v^2) around the nominal state, instance 0 unperturbed.
+    The ensemble does not depend on how it is sharded: rank r of G takes the rows ``shard_instances(total, r, G)``."""
+    rng = np.random.default_rng(seed)
+    x0 = np.asarray(x0, dtype=float)
+    out = np.tile(x0, (int(total), 1))
+    if not hasattr(space, "model"):  # vector-space problems (centroidal): identical instances
+        return out
+    mdl = space.model
+    nv = mdl.nv
+    for b in range(int(total)):
+        dq = np.zeros(2 * nv)
+        dq[6:nv] = sigma_q * rng.standard_normal(nv - 6)
+        dq[nv + 6:] = sigma_v * rng.standard_normal(nv - 6)
+        if perturb_dofs is not None:  # e.g. upper body only: feet that must stay at rest are not disturbed
+            keep = np.zeros(nv, dtype=bool)
+            keep[np.asarray(perturb_dofs, dtype=int)] = True
+            dq[:nv][~keep] = 0.0
+            dq[nv:][~keep] = 0.0
+        if b > 0:
+            xb = space.integrate(x0, dq)
+            # keep the measured configuration inside the joint limits: the initial state is fixed
+            # (force_initial_condition), so a violated limit at knot 0 is an infeasible constraint that no
+            # iteration can repair (two joints of the nominal posture sit exactly on a limit)
+            if hasattr(mdl, "lowerPositionLimit"):
+                xb[7:mdl.nq] = np.clip(xb[7:mdl.nq], mdl.lowerPositionLimit[7:], mdl.upperPositionLimit[7:])
+            out[b] = xb
+    return out
+
+
+def shard_instances(total, rank, world):
+    """Instance i of the ensemble lives on GPU i mod G."""
+    return np.arange(int(rank), int(total), int(world))
+
+
+def make_bench_shards(problem_def, library, batch_per_gpu, rank=0, world=1, streams=1, device=0, seed=20250304, legs=4, tick_reuse=True,
+                      closed_loop=None):
+    """The ensemble(s) bench.py drives on one GPU: this rank's ``batch_per_gpu`` instances of the ``batch_per_gpu * world`` ensemble,
+    split into ``streams`` handles (1: one lock-step ensemble).  Also what tests/test_gpu_bench_config.py checks against the oracle."""
+    prob = problem_def.build(with_terminal_constraint=True) if hasattr(problem_def, "terminal_com_constraint") else problem_def.build()
+    total = int(batch_per_gpu) * int(world)
+    x0s = ensemble_initial_states(prob.x0_init, prob.stages[0].xspace, total, seed)
+    mine = shard_instances(total, rank, world)
+    nshard = max(1, min(int(streams), int(batch_per_gpu)))
+    parts = np.array_split(mine, nshard)
+    shards = []
+    for part in parts:
+        e = EnsembleMPC(problem_def, batch=len(part), library=library, device=device, x0=x0s[part], closed_loop=closed_loop,
+                        forward_mode=(1 if nshard > 1 else 0), tick_reuse=tick_reuse)
+        e.instance_ids = part
+        if legs > 0:
+            e.options.riccati_legs = int(legs)
+            e.native.set_options(e.options)
+        shards.append(e)
+    return shards
+
+
+def result_blocks(shards):
+    """(instance ids, one row per instance: xs | us | K_0 flattened) of the shards of this rank."""
+    rows, ids = [], []
+    for e in shards:
+        r = e.results(gains=True)
+        B = e.batch
+        rows.append(np.concatenate([r["xs"].reshape(B, -1), r["us"].reshape(B, -1), r["K"][:, 0].reshape(B, -1)], axis=1))
+        ids.append(np.asarray(getattr(e, "instance_ids", np.arange(B))))
+    return np.concatenate(ids), np.concatenate(rows)
+
+
+def allgather_results(shards, dist=None, device=None):
+    """Round-end exchange of SURVEY.md §8e: every rank contributes the result blocks (xs, us, K_0) of its instances and receives
+    the whole ensemble, ordered by instance id — ``torch.distributed.all_gather`` (RCCL over xGMI on the GPUs, gloo in the CPU
+    tests).  Not part of a solve: the data path of the MPC ticks has no collective.  Returns (ids, blocks)."""
+    ids, blk = result_blocks(shards)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        order = np.argsort(ids, kind="stable")
+        return ids[order], blk[order]
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(np.concatenate([ids[:, None].astype(np.float64), blk], axis=1)))
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    full = torch.cat(out).cpu().numpy()
+    order = np.argsort(full[:, 0], kind="stable")
+    return full[order, 0].astype(np.int64), full[order, 1:]
 
 
 def lq_knot_doubles(n, m, c):

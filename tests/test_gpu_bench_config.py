@@ -1,0 +1,81 @@
+"""GPU parity AT THE BENCHMARKED CONFIGURATION (BASELINE.json config 5, the per-GPU shard; bench.py's default): 64 instances of the
+N = 100 complete-model full-dynamics OCP, Riccati sweep in 4 legs, tick reuse on, two ticks in flight — built by the same
+``make_bench_shards`` bench.py calls.
+
+* whole ensemble, every instance: bit-identical to the plain path (tick reuse off, synchronous ticks) after 33 MPC ticks, which
+  take the horizon through the first change of the appended stage (double -> single support enters at tick 30,
+  fulldynamic_talos.py:248-266);
+* instances {0, 17, 63} against the CPU oracle (serial sweep) over six ticks across that change, started from the HIP iterate of
+  tick 27: xs, us, K_0 within 1e-6 (BASELINE.json's tolerance), components held one by one."""
+import os
+
+import numpy as np
+import pytest
+
+from mpc_benchmark_amd.ensemble import EnsembleMPC, make_bench_shards
+from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+from tests._metrics import rel_cols, rel_tiles
+
+pytestmark = pytest.mark.gpu
+B, N, T0, T1 = 64, 100, 27, 33
+PICK = [0, 17, 63]
+
+
+def _pipelined_ticks(e, count):
+    """bench.py's driver: tick t + 1 is enqueued before the host looks at tick t."""
+    inflight, nostep = 0, 0
+    for _ in range(count):
+        e.step_async(); inflight += 1
+        if inflight == 2:
+            nostep += sum(1 for s in e.wait() if s.num_iters == 0); inflight -= 1
+    while inflight:
+        nostep += sum(1 for s in e.wait() if s.num_iters == 0); inflight -= 1
+    return nostep
+
+
+def test_bench_default_configuration(hip_lib, oracle_lib):
+    pd = FullDynamicsProblem(horizon=N, complete_model=True)
+    (a,) = make_bench_shards(pd, hip_lib, B, legs=4, tick_reuse=True)     # exactly bench.py's default shard
+    (p,) = make_bench_shards(pd, hip_lib, B, legs=4, tick_reuse=False)    # plain path: every knot evaluated every tick, synchronous
+    for e in (a, p):
+        e.prepare_schedule(T1 + 4)
+        e.cold_solve(max_iters=100)
+    assert _pipelined_ticks(a, T0) == 0  # (an instance-tick without a step would be deferred in the pipelined driver: none here)
+    for _ in range(T0):
+        p.step()
+    ra, rp = a.results(gains=True), p.results(gains=True)
+    for key in ("xs", "us", "K"):
+        assert np.array_equal(ra[key], rp[key]), "tick reuse + two ticks in flight differ from the plain path at tick %d: %s" % (T0, key)
+    # the oracle takes over instances {0, 17, 63} from the HIP iterate of tick T0: same stage ring, shifted iterate, measured state
+    o = EnsembleMPC(FullDynamicsProblem(horizon=N, complete_model=True), batch=len(PICK), library=oracle_lib, x0=a.x0[PICK])
+    o.options.riccati_legs = 1
+    o.options.num_threads = os.cpu_count() or 8  # host threads of the oracle (OpenMP over knots)
+    o.options.max_iters = 1
+    o.native.set_options(o.options)
+    o.prepare_schedule(T1 + 4)
+    for t in range(T0 + 1):  # the ring after T0 + 1 cycles: the tables of ticks 0 .. T0
+        o.native.cycle(*o._table_for_tick(t % pd.t_mpc))
+    o.tick = T0 + 1
+    for t in range(T0, T1):
+        if t == T0:
+            xs, us = ra["xs"][PICK], ra["us"][PICK]
+            xs_s = np.concatenate([xs[:, 1:], xs[:, -1:]], axis=1)  # the warm-start shift of k_shift (csrc/solver_kernels.h)
+            us_s = np.concatenate([us[:, 1:], us[:, -1:]], axis=1)
+            o.native.set_x0(xs[:, 1])  # perfect-model feedback: the predicted next state is the measurement
+            o.native.setup()
+            o.native.run(xs_s, us_s)
+            o.native.set_x0(None)
+        else:
+            o.step()
+        assert _pipelined_ticks(a, 1) == 0
+        p.step()
+        ra, ro = a.results(gains=True), o.results(gains=True)
+        for key, floor in (("xs", 1e-3), ("us", 1e-1)):
+            err = rel_cols(ra[key][PICK], ro[key], floor)
+            assert err < 1e-6, "tick %d: %s deviates from the oracle by %.2e" % (t, key, err)
+        errK = max(rel_tiles(ra["K"][i, 0], ro["K"][j, 0], 1e-6) for j, i in enumerate(PICK))
+        assert errK < 1e-6, "tick %d: K_0 deviates from the oracle by %.2e" % (t, errK)
+    rp = p.results(gains=True)
+    ra = a.results(gains=True)
+    for key in ("xs", "us", "K"):
+        assert np.array_equal(ra[key], rp[key]), "tick reuse + two ticks in flight differ from the plain path at tick %d: %s" % (T1, key)

@@ -4,6 +4,7 @@ import pytest
 
 from mpc_benchmark_amd import aligator
 from mpc_benchmark_amd.problems.kinodynamic import KinodynamicProblem
+from tests._phase_parity import compare
 
 pytestmark = pytest.mark.gpu
 
@@ -37,22 +38,16 @@ def _run_one_iteration(lib, complete_model, seed=3):
 
 @pytest.mark.parametrize("complete_model", [False, True])
 def test_one_iteration_phase_parity(hip_lib, oracle_lib, complete_model):
-    _, sh = _run_one_iteration(hip_lib, complete_model)
+    kp, sh = _run_one_iteration(hip_lib, complete_model)
     _, sr = _run_one_iteration(oracle_lib, complete_model)
     N = len(PATTERN)
-    worst = {}
-    for k in range(N + 1):
-        for q in PHASES + GAINS + STEPS:
-            if k == N and q in ("AB", "f", "E6", "xdot", "xnext", "K", "kff", "du"):
-                continue
-            a, b = sh._native.debug_get(q, k), sr._native.debug_get(q, k)
-            assert a.shape == b.shape, (q, k, a.shape, b.shape)
-            worst[q] = max(worst.get(q, 0.0), _rel(a, b))
+    worst = compare(sh._native, sr._native, PHASES + GAINS + STEPS, range(N + 1), kp.space.ndx, kp.nu, N,
+                    skip_terminal=("AB", "f", "E6", "xdot", "xnext", "K", "kff", "du"))
     tol = {q: 1e-9 for q in PHASES}
     tol.update({q: 1e-7 for q in GAINS + STEPS})
-    tol.update({q: 5e-3 for q in ("Knu", "knu", "dvs")})  # see tests/test_gpu_fulldynamic.py
-    bad = {q: e for q, e in worst.items() if e > tol[q]}
-    assert not bad, "phase dumps deviate from the oracle: %s" % bad
+    tol.update({q + "/dependent": 1.0 for q in ("Knu", "knu", "dvs")})  # see tests/_phase_parity.py
+    bad = {q: e for q, e in worst.items() if not e <= tol[q]}
+    assert not bad, "phase dumps deviate from the oracle: %s (all: %s)" % (bad, worst)
     assert _rel(np.array(sh.results.xs), np.array(sr.results.xs)) < 1e-8
     assert _rel(np.array(sh.results.us), np.array(sr.results.us)) < 1e-7
 
@@ -74,3 +69,47 @@ def test_cold_solve_matches_oracle(hip_lib, oracle_lib):
     print("kinodynamic cold solve iterations: hip %d, oracle %d" % (res["hip"].num_iters, res["ref"].num_iters))
     assert _rel(np.array(res["hip"].xs), np.array(res["ref"].xs)) < 1e-4
     assert _rel(np.array(res["hip"].us), np.array(res["ref"].us)) < 1e-3
+
+
+@pytest.mark.parametrize("horizon,complete_model", [(15, False), (150, True)])
+def test_mpc_ticks_from_the_oracle_iterate(hip_lib, oracle_lib, horizon, complete_model):
+    """The MPC loop of kinodynamic_talos.py:482-490 (one ProxDDP iteration per tick, warm start shifted) on both libraries FROM THE
+    SAME ITERATE: the oracle's converged cold solve is uploaded to the HIP library and to a second oracle handle, then five ticks
+    each.  Cold solves of this OCP take tens of iterations whose linesearch decisions differ at round-off level, so two converged
+    solutions agree only to the solver tolerance (test_cold_solve_matches_oracle: 1e-4); started from one iterate the
+    trajectories must agree to BASELINE.json's 1e-6, component by component (forces ~500 N, joint accelerations ~1, states ~1).
+    (150, True) is BASELINE.json config 4's problem size."""
+    import os
+    from mpc_benchmark_amd.ensemble import EnsembleMPC
+    from tests._metrics import rel_cols
+    ticks = 5
+
+    def handle(lib):
+        e = EnsembleMPC(KinodynamicProblem(horizon=horizon, complete_model=complete_model), batch=1, library=lib, perturb=False)
+        e.options.num_threads = os.cpu_count() or 8
+        e.native.set_options(e.options)
+        e.prepare_schedule(ticks + 4)
+        return e
+
+    ref = handle(oracle_lib)
+    assert ref.cold_solve(max_iters=100)[0].converged
+    start = ref.results(gains=False)
+    traj = {}
+    for name, lib in (("hip", hip_lib), ("ref", oracle_lib)):
+        e = handle(lib)
+        e.options.max_iters = 1
+        e.native.set_options(e.options)
+        e.native.set_x0(e.x0)
+        e.native.setup()
+        e.native.run(start["xs"], start["us"])  # one iteration from the uploaded iterate (tick 0 of the loop)
+        e.native.set_x0(None)  # perfect-model feedback from here on
+        hist = [e.results(gains=True)]
+        for _ in range(ticks):
+            e.step()
+            hist.append(e.results(gains=True))
+        traj[name] = hist
+    for t, (a, b) in enumerate(zip(traj["hip"], traj["ref"])):
+        for key, floor in (("xs", 1e-3), ("us", 1e-2)):
+            err = rel_cols(a[key][0], b[key][0], floor)
+            assert err < 1e-6, "tick %d: %s deviates from the oracle by %.2e" % (t, key, err)
+        assert _rel(a["K"][0, 0], b["K"][0, 0]) < 1e-6, "tick %d: K_0" % t
