@@ -59,6 +59,11 @@ def main():
     ap.add_argument("--no-tick-reuse", action="store_true",
                     help="evaluate every knot afresh each tick (by default the accepted full step is evaluated with derivatives and "
                          "its records serve the next tick: bit-identical results, see mpc_set_tick_reuse in include/mpc_abi.h)")
+    ap.add_argument("--walk", action="store_true",
+                    help="only the walk measurement: every tick regenerates the foot references from the measured state and patches them into "
+                         "the stage tables (FootTrajectory.updateTrajectory + 2 N setReference + terminal CoM rebuild, fulldynamic_talos.py:444-510)")
+    ap.add_argument("--no-walk", action="store_true",
+                    help="only the frozen-reference measurement (by default both run and the LOWER rate is the headline value)")
     ap.add_argument("--closed-loop", action="store_true",
                     help="measured states from the simulation stand-in (10 x 1 ms of knot 0's dynamics under the feedback law, N2) "
                          "instead of perfect-model feedback; the simulation runs inside the timed region")
@@ -94,167 +99,205 @@ def main():
         raise RuntimeError("bench.py measures the HIP library only")
     pd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
     nshard = max(1, min(args.streams, args.batch))
-    # ONE ensemble of batch x world instances (one rng stream, instance order), instance i on GPU i mod G
-    shards = make_bench_shards(pd, lib, args.batch, rank=rank, world=world, streams=args.streams, device=local_rank, legs=args.legs,
-                               tick_reuse=not args.no_tick_reuse, closed_loop=((10, pd.dt / 10) if args.closed_loop else None))
-    ens = shards[0]
-    legs = int(ens.options.riccati_legs)
-    cold = None
-    for e in shards:
-        e.prepare_schedule(args.warmup + args.steps + args.calibration_ticks + 4)
-        c = e.cold_solve(max_iters=100)
-        n_conv = locals().get("n_conv", 0) + sum(bool(st.converged) for st in c)
-        cold = cold or c
-        e.save_episode()
-
-    # instances whose tick was a BCL update / stall without a ProxDDP step (num_iters == 0 in the status of the tick): not a solve
-    nostep = {"n": 0, "on": False}
-
-    def tally(stats):
-        if nostep["on"] and stats:
-            nostep["n"] += sum(1 for st in stats if st.num_iters == 0)
-
-    stagger = {"ms": args.phase_offset_ms}
-    pace = {"period": 0.0, "fast": True, "late": 0}  # state of the shard pacer (kept from the warm-up into the timed region)
-
-    def run_ticks(count):
-        """`count` MPC ticks of every shard (independent ensembles, each on its own handle / stream)."""
-        if nshard == 1:
-            # one ensemble on one stream, two ticks in flight: tick t + 1 is enqueued before the host looks at the status of tick t,
-            # so the stream never runs dry between ticks (no pacer needed: there is nothing to stagger)
-            e, inflight = shards[0], 0
-            for _ in range(count):
-                if e.tick >= args.episode:
-                    while inflight:
-                        tally(e.wait(rescue=True)); inflight -= 1
-                    e.restart_episode()
-                e.step_async(); inflight += 1
-                if inflight == 2:
-                    tally(e.wait(rescue=True)); inflight -= 1
-            while inflight:
-                tally(e.wait(rescue=True)); inflight -= 1
-            return
-        # One host thread drives all shards round-robin: a tick is enqueued on the shard's stream without waiting, and
-        # completed (event on an asynchronous status read-back) right AFTER that shard's next tick has been enqueued.  Shard i starts
-        # i x phase-offset late, so that the sequential Riccati sweep of one shard (few busy CUs) runs beside the per-knot
-        # kernels of the others instead of beside their sweeps.  Automatic offset: the first call (warm-up) times one
-        # lock-step tick T and uses 0.8 T / shards from then on.
-        done_ticks = 0
-        if stagger["ms"] < 0:
-            t_ = time.perf_counter()
-            for e in shards:
-                e.step_async()
-            for e in shards:
-                e.wait(rescue=True)
-            stagger["ms"] = 0.8 * (time.perf_counter() - t_) * 1e3 / nshard  # staggered ticks are ~0.8 of a lock-step one
-            done_ticks = 1
-        if count - done_ticks <= 0:
-            return
-        remaining = count - done_ticks
-        depth = min(2, remaining)  # ticks in flight per shard: while the host looks at tick t, t + 1 runs and t + 2 may wait behind it
-        if args.period_ms > 0:
-            pace["period"] = args.period_ms * 1e-3
-        elif args.period_ms < 0 and pace["period"] <= 0:
-            pace["period"] = stagger["ms"] * 1e-3 * nshard / 0.8  # the lock-step tick measured above: safe, the pacer shortens it
-        period0 = pace["period"]
-        t_next = [time.perf_counter() + i * (period0 / nshard if period0 > 0 else 0.0) for i in range(nshard)]
-
-        def paced(i, e):
-            """Metronome: shard i's ticks are released one period apart, 1 / S of a period after shard i - 1's.  Adaptive
-            period (AIMD): a release that finds the shard's previous tick still running means the device does not keep up
-            (period up 1-3 %); otherwise the period shrinks — 1 % per release until the first late one, 0.1 % afterwards."""
-            if pace["period"] > 0:
-                dt_ = t_next[i] - time.perf_counter()
-                if dt_ > 0:
-                    time.sleep(dt_)
-                if args.period_ms < 0:
-                    in_flight, completed = e.native.poll()
-                    if in_flight > completed:  # the newest tick is still on the device
-                        pace["period"] *= 1.03 if pace["fast"] else 1.01
-                        pace["fast"] = False
-                        pace["late"] += 1
-                    else:
-                        pace["period"] *= 0.99 if pace["fast"] else 0.999
-                t_next[i] = max(t_next[i], time.perf_counter() - pace["period"]) + pace["period"]
-            e.step_async()
-        for i, e in enumerate(shards):
-            if pace["period"] <= 0 and i and stagger["ms"] > 0:
-                time.sleep(stagger["ms"] * 1e-3)
-            paced(i, e)
-        for _ in range(depth - 1):
-            for i, e in enumerate(shards):
-                paced(i, e)
-        for _ in range(remaining - depth):
-            for i, e in enumerate(shards):
-                tally(e.wait(rescue=True))  # the oldest tick of this shard
-                if e.tick >= args.episode:  # end of an episode: drain, back to the start, refill the pipeline
-                    e.wait(rescue=True)
-                    e.restart_episode()
-                    e.step_async()
-                paced(i, e)
-        for _ in range(depth):
-            for e in shards:
-                tally(e.wait(rescue=True))
-
-    # warm-up: every kernel is timed (HIP events on the solver's stream) to find the dominant one and the per-kernel
-    # split; the timed region below then only brackets the dominant kernel, because an event pair between two kernels
-    # costs stream time (the next launch is not dispatched back to back)
-    if nshard > 1 and args.period_ms < 0 and args.calibration_ticks > 0:
-        run_ticks(args.calibration_ticks)  # the pacer converges here; its state carries over
-    for e in shards:
-        e.native.profile(2)
-        e.native.profile(1)
-    run_ticks(args.warmup)
-    warm = {}
-    for e in shards:
-        e.native.profile(0)
-        for kname, (cnt, ms, slot) in e.native.profile_read(slots=True).items():
-            c0, m0, _ = warm.get(kname, (0, 0.0, slot))
-            warm[kname] = (c0 + cnt, m0 + ms, slot)
-    dom_slot = max(warm.values(), key=lambda v: v[1])[2] if warm else 0
-
-    def sync_all():
+    def measure(walk):
+        """One measurement of the ensemble tick: frozen foot references (walk = False) or the reference loop's per-tick problem
+        updates (walk = True: FootTrajectory.updateTrajectory + 2 N setReference + terminal rebuild, EnsembleMPC.enable_walk)."""
+        # SURVEY.md §8d config 5: ONE ensemble of batch x world instances (one rng stream, instance order), instance i on GPU i mod G
+        shards = make_bench_shards(pd, lib, args.batch, rank=rank, world=world, streams=args.streams, device=local_rank, legs=args.legs,
+                                   tick_reuse=not args.no_tick_reuse, closed_loop=((10, pd.dt / 10) if args.closed_loop else None))
+        ens = shards[0]
+        legs = int(ens.options.riccati_legs)
+        # Walk mode: the generator REPLANS from the measured poses during the T_ds ticks before every take-off (27 % of the ticks of
+        # the schedule: T_ds / (T_ds + T_ss)) — on those every knot's reference changes and nothing of the previous tick can be
+        # reused; on the others the references are handed over unchanged.  The first such window starts at tick 100 of the schedule,
+        # far outside a default run, so the timed region is placed to END inside it with the schedule's own share of replanning
+        # ticks: untimed prelude ticks bring the ensemble to tick 100 - 0.73 K - warm-up first.
+        prelude = 0
+        episode = 10 ** 9 if walk else args.episode  # (a walk is not replayed in episodes: its window ends before the first single-support phase reaches knot 0)
+        if walk:
+            from mpc_benchmark_amd.problems import fulldynamic as fdp
+            cyc = fdp.T_DS + fdp.T_SS
+            first_replan = pd.horizon  # the first take-off enters at tick T_ds + horizon of the schedule: its planning window opens T_ds ticks earlier
+            kw = min(args.steps, cyc)
+            start = max(0, first_replan - int(round((1.0 - fdp.T_DS / cyc) * kw)))
+            prelude = max(0, start - args.warmup - (args.calibration_ticks if nshard > 1 else 0))
+        cold, n_conv = None, 0
         for e in shards:
-            e.results(gains=False)  # stream sync of the solver (hipStreamSynchronize + tiny D2H)
+            e.prepare_schedule(prelude + args.warmup + args.steps + args.calibration_ticks + 4)
+            c = e.cold_solve(max_iters=100)
+            n_conv += sum(bool(st.converged) for st in c)
+            worst_unconv = max([locals().get("worst_unconv", 0.0)] + [max(st.prim_infeas, st.dual_infeas) for st in c if not st.converged])
+            cold = cold or c
+            e.save_episode()
+            if walk:
+                e.enable_walk()
+
+        # instances whose tick was a BCL update / stall without a ProxDDP step (num_iters == 0 in the status of the tick): not a solve
+        nostep = {"n": 0, "on": False}
+
+        def tally(stats):
+            if nostep["on"] and stats:
+                nostep["n"] += sum(1 for st in stats if st.num_iters == 0)
+
+        stagger = {"ms": args.phase_offset_ms}
+        pace = {"period": 0.0, "fast": True, "late": 0}  # state of the shard pacer (kept from the warm-up into the timed region)
+
+        def run_ticks(count):
+            """`count` MPC ticks of every shard (independent ensembles, each on its own handle / stream)."""
+            if nshard == 1:
+                # one ensemble on one stream, two ticks in flight: tick t + 1 is enqueued before the host looks at the status of tick t,
+                # so the stream never runs dry between ticks (no pacer needed: there is nothing to stagger)
+                e = shards[0]  # (e.inflight counts the ticks enqueued and not collected; a rescue drains them all)
+                for _ in range(count):
+                    if e.tick >= episode:
+                        while e.inflight:
+                            tally(e.wait(rescue=True))
+                        e.restart_episode()
+                    e.step_async()
+                    if e.inflight == 2:
+                        tally(e.wait(rescue=True))
+                while e.inflight:
+                    tally(e.wait(rescue=True))
+                return
+            # One host thread drives all shards round-robin: a tick is enqueued on the shard's stream without waiting, and
+            # completed (event on an asynchronous status read-back) right AFTER that shard's next tick has been enqueued.  Shard i starts
+            # i x phase-offset late, so that the sequential Riccati sweep of one shard (few busy CUs) runs beside the per-knot
+            # kernels of the others instead of beside their sweeps.  Automatic offset: the first call (warm-up) times one
+            # lock-step tick T and uses 0.8 T / shards from then on.
+            done_ticks = 0
+            if stagger["ms"] < 0:
+                t_ = time.perf_counter()
+                for e in shards:
+                    e.step_async()
+                for e in shards:
+                    e.wait(rescue=True)
+                stagger["ms"] = 0.8 * (time.perf_counter() - t_) * 1e3 / nshard  # staggered ticks are ~0.8 of a lock-step one
+                done_ticks = 1
+            if count - done_ticks <= 0:
+                return
+            remaining = count - done_ticks
+            depth = min(2, remaining)  # ticks in flight per shard: while the host looks at tick t, t + 1 runs and t + 2 may wait behind it
+            if args.period_ms > 0:
+                pace["period"] = args.period_ms * 1e-3
+            elif args.period_ms < 0 and pace["period"] <= 0:
+                pace["period"] = stagger["ms"] * 1e-3 * nshard / 0.8  # the lock-step tick measured above: safe, the pacer shortens it
+            period0 = pace["period"]
+            t_next = [time.perf_counter() + i * (period0 / nshard if period0 > 0 else 0.0) for i in range(nshard)]
+
+            def paced(i, e):
+                """Metronome: shard i's ticks are released one period apart, 1 / S of a period after shard i - 1's.  Adaptive
+                period (AIMD): a release that finds the shard's previous tick still running means the device does not keep up
+                (period up 1-3 %); otherwise the period shrinks — 1 % per release until the first late one, 0.1 % afterwards."""
+                if pace["period"] > 0:
+                    dt_ = t_next[i] - time.perf_counter()
+                    if dt_ > 0:
+                        time.sleep(dt_)
+                    if args.period_ms < 0:
+                        in_flight, completed = e.native.poll()
+                        if in_flight > completed:  # the newest tick is still on the device
+                            pace["period"] *= 1.03 if pace["fast"] else 1.01
+                            pace["fast"] = False
+                            pace["late"] += 1
+                        else:
+                            pace["period"] *= 0.99 if pace["fast"] else 0.999
+                    t_next[i] = max(t_next[i], time.perf_counter() - pace["period"]) + pace["period"]
+                e.step_async()
+            for i, e in enumerate(shards):
+                if pace["period"] <= 0 and i and stagger["ms"] > 0:
+                    time.sleep(stagger["ms"] * 1e-3)
+                paced(i, e)
+            for _ in range(depth - 1):
+                for i, e in enumerate(shards):
+                    paced(i, e)
+            for _ in range(remaining - depth):
+                for i, e in enumerate(shards):
+                    if e.inflight:
+                        tally(e.wait(rescue=True))  # the oldest tick of this shard
+                    if e.tick >= episode:  # end of an episode: drain, back to the start, refill the pipeline
+                        while e.inflight:
+                            e.wait(rescue=True)
+                        e.restart_episode()
+                        e.step_async()
+                    paced(i, e)
+            for e in shards:
+                while e.inflight:
+                    tally(e.wait(rescue=True))
+
+        if prelude:
+            run_ticks(prelude)
+        # warm-up: every kernel is timed (HIP events on the solver's stream) to find the dominant one and the per-kernel
+        # split; the timed region below then only brackets the dominant kernel, because an event pair between two kernels
+        # costs stream time (the next launch is not dispatched back to back)
+        if nshard > 1 and args.period_ms < 0 and args.calibration_ticks > 0:
+            run_ticks(args.calibration_ticks)  # the pacer converges here; its state carries over
+        for e in shards:
+            e.native.profile(2)
+            e.native.profile(1)
+        run_ticks(args.warmup)
+        warm = {}
+        for e in shards:
+            e.native.profile(0)
+            for kname, (cnt, ms, slot) in e.native.profile_read(slots=True).items():
+                c0, m0, _ = warm.get(kname, (0, 0.0, slot))
+                warm[kname] = (c0 + cnt, m0 + ms, slot)
+        dom_slot = max(warm.values(), key=lambda v: v[1])[2] if warm else 0
+
+        def sync_all():
+            for e in shards:
+                e.results(gains=False)  # stream sync of the solver (hipStreamSynchronize + tiny D2H)
+            if dist is not None:
+                import torch
+                torch.cuda.synchronize()
+                dist.barrier()
+
+        for e in shards:
+            e.native.profile(2)
+            e.native.profile(16 * (1 << dom_slot))
+        sync_all()
+        nostep["on"] = True
+        t0 = time.perf_counter()
+        run_ticks(args.steps)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        nostep["on"] = False
+        for e in shards:
+            e.native.profile(0)
         if dist is not None:
             import torch
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        # round-end exchange (SURVEY.md §8e), outside the timed region: every rank receives the result blocks of the whole ensemble
+        gather = None
+        if dist is not None:
+            import torch
+            from mpc_benchmark_amd.ensemble import allgather_results
             torch.cuda.synchronize()
-            dist.barrier()
+            tg = time.perf_counter()
+            gids, gblk = allgather_results(shards, dist, device=torch.device("cuda", local_rank))
+            gather = {"instances": int(gids.size), "complete": bool(np.array_equal(gids, np.arange(args.batch * world))),
+                      "bytes_per_rank": int(gblk.nbytes // world), "ms": round((time.perf_counter() - tg) * 1e3, 3),
+                      "finite": bool(np.isfinite(gblk).all())}
+        prof = {}
+        for e in shards:  # per-kernel launches / time summed over the shards
+            for kname, (cnt, ms) in e.native.profile_read().items():
+                c0, m0 = prof.get(kname, (0, 0.0))
+                prof[kname] = (c0 + cnt, m0 + ms)
+        return dict(shards=shards, ens=ens, legs=legs, cold=cold, n_conv=n_conv, worst_unconv=worst_unconv, nostep=nostep["n"], pace=pace, stagger=stagger, elapsed=elapsed,
+                    prof=prof, warm=warm, gather=gather, replanning_ticks=sum(getattr(e, "replanning_ticks", 0) for e in shards))
 
-    for e in shards:
-        e.native.profile(2)
-        e.native.profile(16 * (1 << dom_slot))
-    sync_all()
-    nostep["on"] = True
-    t0 = time.perf_counter()
-    run_ticks(args.steps)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    nostep["on"] = False
-    for e in shards:
-        e.native.profile(0)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    # round-end exchange (SURVEY.md §8e), outside the timed region: every rank receives the result blocks of the whole ensemble
-    gather = None
-    if dist is not None:
-        import torch
-        from mpc_benchmark_amd.ensemble import allgather_results
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        gids, gblk = allgather_results(shards, dist, device=torch.device("cuda", local_rank))
-        gather = {"instances": int(gids.size), "complete": bool(np.array_equal(gids, np.arange(args.batch * world))),
-                  "bytes_per_rank": int(gblk.nbytes // world), "ms": round((time.perf_counter() - tg) * 1e3, 3),
-                  "finite": bool(np.isfinite(gblk).all())}
-    prof = {}
-    for e in shards:  # per-kernel launches / time summed over the shards
-        for kname, (cnt, ms) in e.native.profile_read().items():
-            c0, m0 = prof.get(kname, (0, 0.0))
-            prof[kname] = (c0 + cnt, m0 + ms)
-
+    modes = [True] if args.walk else ([False] if args.no_walk else [False, True])
+    runs = {}
+    for walk in modes:
+        runs[walk] = measure(walk)
+    # the headline is the LOWER of the two (the reference's loop updates its problem every tick: a number that only holds with frozen
+    # references is not the metric)
+    def rate(m):
+        return (args.batch * args.steps - m["nostep"]) * world / m["elapsed"]
+    head = min(runs, key=lambda w: rate(runs[w]))
+    mres = runs[head]
+    shards, ens, legs, cold, n_conv, pace, stagger, elapsed, prof, warm, gather = (mres[k] for k in ("shards", "ens", "legs", "cold", "n_conv", "pace", "stagger", "elapsed", "prof", "warm", "gather"))
+    nostep = {"n": mres["nostep"]}
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -390,7 +433,12 @@ def main():
         "p50_ms_per_solve_batch1": p50_ms, "p50_riccati_legs": (args.latency_legs if args.legs != 1 else 1),
         "riccati_cuts": ("chain (MPC_LEGS_CHAIN)" if os.environ.get("MPC_LEGS_CHAIN", "0") not in ("", "0") else "tree of pairwise compositions (csrc/legs_tree.h) from three legs on"),
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
-        "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; the others are within 1e-4 of feasibility)" % (n_conv, args.batch),
+        "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; largest primal / dual infeasibility of the others: %.2e)" % (n_conv, args.batch, mres["worst_unconv"]),
+        "tick_mode": ("walk: foot references regenerated and patched every tick (fulldynamic_talos.py:444-510)" if head else "frozen foot references"),
+        "measurements": {("walk" if w else "frozen_references"): {"value": round(rate(r), 2), "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 4),
+                                                                  "replanning_ticks": r["replanning_ticks"],
+                                                                  "kernel_ms_per_step_warmup": {k: round(v[1] / max(1, args.warmup), 4) for k, v in sorted(r["warm"].items(), key=lambda kv: -kv[1][1])[:6]}}
+                         for w, r in runs.items()},
         "instance_ticks_without_step": nostep["n"] * world, "diverged_instance_rescues": sum(getattr(e, "rescues", 0) for e in shards),
         "episode_ticks": args.episode, "episode_restarts": sum(getattr(e, "episodes", 0) for e in shards),
         "ensemble_allgather": gather,

@@ -210,10 +210,17 @@ int mpc_run_shifted_async(mpc_solver* s);
 /* Tick reuse for MPC ticks with max_iters = 1 on whole-body problems (HIP; the oracle accepts and ignores it): the full step
  * of a tick is evaluated WITH derivatives into the knot records; when it is accepted, mpc_run_shifted of the next tick finds
  * the records of its knots 0 .. N-2 in place (one knot on) and only refreshes the multiplier-dependent part.  Results are
- * bit-identical to the plain path.  Parameter updates, set_stage, set_options and mpc_run invalidate the kept records.
+ * bit-identical to the plain path.  mpc_update_stage_params(_batch) compares the incoming values with the host mirror: unchanged
+ * ranges cost nothing, changed ones invalidate the record of THEIR knot only (it is evaluated afresh by the next tick, the others
+ * stay reused); set_stage, set_options and mpc_run invalidate all kept records.
  * A no-op on vector-space problems (centroidal): accepted, nothing changes. */
 int mpc_set_tick_reuse(mpc_solver* s, int32_t on);
 int mpc_wait(mpc_solver* s, mpc_stats* stats);
+/* mpc_wait that also hands over x_next[B][nx] = xs[1] of every instance after the completed tick: the state the next tick takes as its
+ * measurement under perfect-model feedback, i.e. what the reference generators of the loop (foot poses of the measured state,
+ * fulldynamic_talos.py:441-455) need to plan that tick — snapshotted with the status, so the host never waits for a younger tick.
+ * With nothing in flight both return the status (and states) of the last completed tick. */
+int mpc_wait_state(mpc_solver* s, mpc_stats* stats, double* x_next);
 /* Non-blocking look at the asynchronous ticks: *in_flight = ticks enqueued and not yet collected by mpc_wait, *completed = how
  * many of those have already finished on the device (a host-side pacer uses it to tell whether the device keeps up). */
 int mpc_poll(mpc_solver* s, int32_t* in_flight, int32_t* completed);

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "mpc_run_shifted": (C.c_int, [C.c_void_p, C.POINTER(MpcStats)]),
     "mpc_run_shifted_async": (C.c_int, [C.c_void_p]),
     "mpc_wait": (C.c_int, [C.c_void_p, C.POINTER(MpcStats)]),
+    "mpc_wait_state": (C.c_int, [C.c_void_p, C.POINTER(MpcStats), _DP]),
     "mpc_get_results": (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP, _DP, _DP]),
     "mpc_get_stage_data": (C.c_int, [C.c_void_p, C.c_int32, _DP, _DP]),
     "mpc_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, _DP, C.c_int32]),
@@ -259,6 +260,13 @@ class NativeSolver:
         stats = (MpcStats * self.dims.batch)()
         self._check(self.lib.mpc_wait(self._h, stats), "mpc_wait")
         return list(stats)
+
+    def wait_state(self):
+        """-> (stats, x_next[B][nx]): ``wait`` plus xs[1] of every instance after the completed tick (mpc_wait_state)."""
+        stats = (MpcStats * self.dims.batch)()
+        xn = np.zeros((self.dims.batch, self.dims.nx))
+        self._check(self.lib.mpc_wait_state(self._h, stats, _dp(xn)), "mpc_wait_state")
+        return list(stats), xn
 
     def get_results(self, gains=True, multipliers=False):
         d = self.dims

@@ -64,6 +64,22 @@ struct mpc_solver {
   int cycles_since_run = 0;  // the speculation assumes ONE mpc_cycle per tick (replaceStageCircular + cycleAppend of the scripts)
   int khead = 0;
   int* d_spec = nullptr;
+  // per-slot invalidation (mpc_update_stage_params*): slots whose parameters changed since the last pass was enqueued ; dirty_all:
+  // an update on a horizon too long for the mask of SolverArgs
+  std::vector<uint8_t> slot_dirty;
+  bool dirty_all = false;
+  unsigned long long dirty_now[MPC_DIRTY_WORDS] = {};  // knot mask of the pass being enqueued (set in begin_reuse_pass)
+  // parameter patches travel through a pinned ring as ONE host-to-device copy + a scatter kernel, stream-ordered (no host wait)
+  static constexpr int PATCH_RING = 4;
+  char* patch_pin[PATCH_RING] = {};
+  size_t patch_cap[PATCH_RING] = {};
+  hipEvent_t patch_ev[PATCH_RING] = {};
+  int patch_next = 0;
+  char* d_patch = nullptr;
+  size_t d_patch_cap = 0;
+  // the measured state of the NEXT tick (xs[1] of every instance) snapshotted with the status of an asynchronous tick
+  double* h_xnext[2] = {nullptr, nullptr};  // [ASYNC_DEPTH]
+  std::vector<double> leg_mu;  // penalty of every instance when the cut Hessians of the legs were last refreshed
   // asynchronous ticks (mpc_run_shifted_async / mpc_wait): status snapshots in pinned host memory, one event each; up to
   // ASYNC_DEPTH ticks may be in flight, so that the next tick is already queued while the host looks at the previous one
   static constexpr int ASYNC_DEPTH = 2;
@@ -149,6 +165,7 @@ struct mpc_solver {
     a.reuse_on = (a.spec_on && reuse_this_pass) ? 1 : 0;
     a.reuse_k0 = perfect_feedback ? 1 : 0;
     a.spec_knot = a.spec_on ? d_spec_knot : nullptr; a.spec_next = (a.reuse_on && spec_next_now) ? 1 : 0;
+    for (int w = 0; w < MPC_DIRTY_WORDS; ++w) a.dirty[w] = a.reuse_on ? dirty_now[w] : 0ull;
     a.nlegs = eff_legs(); a.legbuf = d_legbuf; a.treebuf = d_treebuf; a.leg_guess = leg_guess_now;
     a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = phase_timers ? d_prof : nullptr;
     return a;
@@ -226,6 +243,8 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->h_desc.assign(N1 * L.max_stage_ints, 0);
   s->h_params.assign(N1 * (size_t)L.max_stage_doubles, 0.0);
   s->h_len.assign(2 * N1, 0);
+  s->slot_dirty.assign(N1, (uint8_t)0);
+  s->leg_mu.assign((size_t)L.B, -1.0);
   // default options
   mpc_options& o = s->opt;
   o.tol = 1e-5; o.mu_init = 1e-8; o.dyn_al_scale = 1e-3; o.reg_init = 1e-9; o.ls_armijo_c1 = 1e-4; o.ls_alpha_min = 1e-7;
@@ -346,6 +365,85 @@ static void spec_clear(mpc_solver* s) {
   if (s->d_spec) HIP_OK(hipMemsetAsync(s->d_spec, 0, s->L.B * sizeof(int), s->stream));
   s->spec_rec_valid = s->spec_next_pending = s->spec_next_now = false;
   s->cycles_since_run = 0;
+  std::fill(s->slot_dirty.begin(), s->slot_dirty.end(), (uint8_t)0);
+  s->dirty_all = false;
+}
+
+// Start of a pass that may reuse records (mpc_run_shifted*): the slots updated since the last pass become the knot mask of this
+// pass; the records the pass leaves behind are consistent with the current parameters again.
+static void begin_reuse_pass(mpc_solver* s) {
+  const int N = s->L.N;
+  for (int w = 0; w < MPC_DIRTY_WORDS; ++w) s->dirty_now[w] = 0ull;
+  bool any = false;
+  for (int sl = 0; sl <= N; ++sl) if (s->slot_dirty[sl]) {
+    any = true;
+    const int k = sl == N ? N : (sl - s->head + N) % N;
+    if (k < 64 * MPC_DIRTY_WORDS) s->dirty_now[k >> 6] |= 1ull << (k & 63);
+  }
+  if (s->dirty_all || (any && N + 1 > 64 * MPC_DIRTY_WORDS)) s->reuse_this_pass = false;  // no per-knot mask for this horizon: evaluate everything
+  std::fill(s->slot_dirty.begin(), s->slot_dirty.end(), (uint8_t)0);
+  s->dirty_all = false;
+}
+
+// One host-to-device copy + a scatter kernel for a set of parameter patches: [count | (dst offset, src offset, length) x count | values].
+__global__ void __launch_bounds__(64) k_scatter_params(double* dst, const char* packed) {
+  const int* hdr = (const int*)packed;
+  const int count = hdr[0];
+  const int* tri = hdr + 4 + 3 * blockIdx.x;
+  const double* vals = (const double*)(packed + (((size_t)(4 + 3 * count) * sizeof(int) + 15) & ~(size_t)15));
+  for (int i = threadIdx.x; i < tri[2]; i += 64) dst[(size_t)tri[0] + i] = vals[(size_t)tri[1] + i];
+}
+
+struct ParamPatch { int slot, offset, len; const double* vals; };
+
+// Patches that differ from the host mirror go to the device (stream-ordered, no host wait) and mark their slot dirty; unchanged
+// ones cost a memcmp.  Returns the number of patches that travelled.
+static int apply_param_patches(mpc_solver* s, const std::vector<ParamPatch>& in) {
+  const Layout& L = s->L;
+  std::vector<ParamPatch> ch;
+  size_t nval = 0;
+  for (const ParamPatch& p : in) {
+    double* hp = s->h_params.data() + (size_t)p.slot * L.max_stage_doubles + p.offset;
+    if (p.len == 0 || std::memcmp(hp, p.vals, p.len * sizeof(double)) == 0) continue;
+    std::memcpy(hp, p.vals, p.len * sizeof(double));
+    s->slot_dirty[p.slot] = 1;
+    ch.push_back(p);
+    nval += p.len;
+  }
+  if (ch.empty()) return 0;
+  const size_t hdr_bytes = ((size_t)(4 + 3 * ch.size()) * sizeof(int) + 15) & ~(size_t)15, bytes = hdr_bytes + nval * sizeof(double);
+  const int rs = s->patch_next;
+  s->patch_next = (s->patch_next + 1) % mpc_solver::PATCH_RING;
+  if (s->patch_pin[rs]) HIP_OK(hipEventSynchronize(s->patch_ev[rs]));  // (the copy that used this slot PATCH_RING calls ago)
+  else HIP_OK(hipEventCreateWithFlags(&s->patch_ev[rs], hipEventDisableTiming));
+  if (s->patch_cap[rs] < bytes) {
+    if (s->patch_pin[rs]) HIP_OK(hipHostFree(s->patch_pin[rs]));
+    s->patch_cap[rs] = bytes * 2 + 4096;
+    HIP_OK(hipHostMalloc((void**)&s->patch_pin[rs], s->patch_cap[rs], hipHostMallocDefault));
+  }
+  if (s->d_patch_cap < bytes) {  // grows rarely (first ticks): the old buffer may still be read by a queued scatter kernel
+    HIP_OK(hipStreamSynchronize(s->stream));
+    if (s->d_patch) HIP_OK(hipFree(s->d_patch));
+    s->d_patch_cap = bytes * 2 + 4096;
+    HIP_OK(hipMalloc((void**)&s->d_patch, s->d_patch_cap));
+  }
+  char* pin = s->patch_pin[rs];
+  int* hdr = (int*)pin;
+  hdr[0] = (int)ch.size(); hdr[1] = hdr[2] = hdr[3] = 0;
+  double* vals = (double*)(pin + hdr_bytes);
+  size_t pos = 0;
+  for (size_t i = 0; i < ch.size(); ++i) {
+    hdr[4 + 3 * i] = (int)((size_t)ch[i].slot * L.max_stage_doubles + ch[i].offset);
+    hdr[4 + 3 * i + 1] = (int)pos;
+    hdr[4 + 3 * i + 2] = ch[i].len;
+    std::memcpy(vals + pos, ch[i].vals, ch[i].len * sizeof(double));
+    pos += ch[i].len;
+  }
+  HIP_OK(hipMemcpyAsync(s->d_patch, pin, bytes, hipMemcpyHostToDevice, s->stream));
+  HIP_OK(hipEventRecord(s->patch_ev[rs], s->stream));
+  hipLaunchKernelGGL(k_scatter_params, dim3((unsigned)ch.size()), dim3(64), 0, s->stream, s->d_stage_params, (const char*)s->d_patch);
+  HIP_OK(hipGetLastError());
+  return (int)ch.size();
 }
 
 // warm-start shift of the iterate (k_shift): from the current pair of buffers into the other one, which becomes the current pair
@@ -530,6 +628,9 @@ static void run_impl(mpc_solver* s, mpc_stats* stats, int passes_enqueued = 0) {
     copy_sync(s, st.data(), s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost);
     int done = 1;
     for (int b = 0; b < L.B; ++b) if (!st[b].done) done = 0;
+    // a BCL update changed the penalty of an instance: the cut Hessians of the legs (calP ~ ... + C^T C / mu) were made for the old
+    // one — the next pass refreshes them with its extra sweeps instead of starting single-sweep legs from a guess for another mu
+    for (int b = 0; b < L.B; ++b) if (!st[b].done && st[b].mu != s->leg_mu[b]) { if (s->leg_mu[b] >= 0.0) s->leg_guess_valid = false; s->leg_mu[b] = st[b].mu; }
     if (const char* tr = getenv("MPC_HIP_TRACE")) {  // developer aid: per-pass solver state of one instance
       const int tb = atoi(tr);
       if (tb >= 0 && tb < L.B) {
@@ -580,6 +681,9 @@ void mpc_destroy(mpc_solver* s) {
   for (auto& p : s->prof) for (auto& e : p.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   for (int i = 0; i < mpc_solver::ASYNC_DEPTH; ++i) { if (s->h_status[i]) (void)hipHostFree(s->h_status[i]); if (s->status_ev[i]) (void)hipEventDestroy(s->status_ev[i]); }
   for (int i = 0; i < mpc_solver::STAGE_RING; ++i) { if (s->stage_pin[i]) (void)hipHostFree(s->stage_pin[i]); if (s->stage_ev[i]) (void)hipEventDestroy(s->stage_ev[i]); }
+  for (int i = 0; i < mpc_solver::PATCH_RING; ++i) { if (s->patch_pin[i]) (void)hipHostFree(s->patch_pin[i]); if (s->patch_ev[i]) (void)hipEventDestroy(s->patch_ev[i]); }
+  for (int i = 0; i < mpc_solver::ASYNC_DEPTH; ++i) if (s->h_xnext[i]) (void)hipHostFree(s->h_xnext[i]);
+  if (s->d_patch) (void)hipFree(s->d_patch);
   for (void* p : s->allocs) (void)hipFree(p);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -659,6 +763,7 @@ int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double*
 int mpc_set_stage(mpc_solver* s, int32_t k, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params) {
   MPC_TRY(s, {
     spec_clear(s);
+    s->leg_guess_valid = false;
     if (k < 0 || k > s->L.N) throw std::runtime_error("stage index out of range");
     upload_stage(s, slot_of(s, k), desc, n_desc, params, n_params);
   })
@@ -667,28 +772,24 @@ int mpc_set_stage(mpc_solver* s, int32_t k, const int32_t* desc, int32_t n_desc,
 int mpc_update_stage_params_batch(mpc_solver* s, int32_t count, const int32_t* ks, const int32_t* offsets, const int32_t* lens,
                                   const double* vals) {
   MPC_TRY(s, {
-    spec_clear(s);
+    std::vector<ParamPatch> patches;
+    patches.reserve(count);
     size_t pos = 0;
     for (int i = 0; i < count; ++i) {
       if (ks[i] < 0 || ks[i] > s->L.N) throw std::runtime_error("stage index out of range");
       if (offsets[i] < 0 || lens[i] < 0 || offsets[i] + lens[i] > s->L.max_stage_doubles) throw std::runtime_error("parameter update out of range");
-      std::memcpy(s->h_params.data() + (size_t)slot_of(s, ks[i]) * s->L.max_stage_doubles + offsets[i], vals + pos, lens[i] * sizeof(double));
-      HIP_OK(hipMemcpyAsync(s->d_stage_params + (size_t)slot_of(s, ks[i]) * s->L.max_stage_doubles + offsets[i], vals + pos,
-                            lens[i] * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      patches.push_back({slot_of(s, ks[i]), offsets[i], lens[i], vals + pos});
       pos += lens[i];
     }
-    HIP_OK(hipStreamSynchronize(s->stream));  // host buffers are not retained past the call
+    apply_param_patches(s, patches);  // (the caller's buffers are copied into pinned memory: not retained past the call)
   })
 }
 
 int mpc_update_stage_params(mpc_solver* s, int32_t k, int32_t offset, const double* vals, int32_t n) {
   MPC_TRY(s, {
-    spec_clear(s);
     if (k < 0 || k > s->L.N) throw std::runtime_error("stage index out of range");
-    if (offset < 0 || offset + n > s->L.max_stage_doubles) throw std::runtime_error("parameter update out of range");
-    std::memcpy(s->h_params.data() + (size_t)slot_of(s, k) * s->L.max_stage_doubles + offset, vals, n * sizeof(double));
-    HIP_OK(hipMemcpyAsync(s->d_stage_params + (size_t)slot_of(s, k) * s->L.max_stage_doubles + offset, vals, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
-    HIP_OK(hipStreamSynchronize(s->stream));
+    if (offset < 0 || n < 0 || offset + n > s->L.max_stage_doubles) throw std::runtime_error("parameter update out of range");
+    apply_param_patches(s, {ParamPatch{slot_of(s, k), offset, n, vals}});
   })
 }
 
@@ -704,9 +805,11 @@ int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* 
       const bool same = s->h_len[2 * last] == n_desc && s->h_len[2 * last + 1] == n_params && std::memcmp(hd, desc, n_desc * sizeof(int32_t)) == 0 &&
                         (n_params == 0 || std::memcmp(hp, params, n_params * sizeof(double)) == 0);
       s->cycles_since_run += 1;
-      s->spec_next_pending = same && s->spec_rec_valid && s->cycles_since_run == 1;
+      // (a last stage whose parameters were patched after the speculative evaluation: the spare record is stale)
+      s->spec_next_pending = same && s->spec_rec_valid && s->cycles_since_run == 1 && !s->slot_dirty[last] && !s->dirty_all;
     }
     upload_stage(s, slot, desc, n_desc, params, n_params);
+    s->slot_dirty[slot] = 0;  // the recycled slot: its record is the speculative one or a fresh evaluation (knot_reused, k = N - 1)
     s->head = (s->head + 1) % s->L.N;
   })
 }
@@ -858,6 +961,7 @@ int mpc_run(mpc_solver* s, const double* xs, const double* us, mpc_stats* stats)
   MPC_TRY(s, {
     spec_clear(s);
     s->reuse_this_pass = false;
+    s->leg_guess_valid = false;  // a fresh iterate: the cut Hessians kept from the last pass belong to another trajectory
     const Layout& L = s->L;
     HIP_OK(hipMemcpyAsync(s->d_xs, xs, (size_t)L.B * (L.N + 1) * L.nx * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipMemcpyAsync(s->d_us, us, (size_t)L.B * L.N * L.m * sizeof(double), hipMemcpyHostToDevice, s->stream));
@@ -869,6 +973,7 @@ int mpc_run_shifted(mpc_solver* s, mpc_stats* stats) {
   MPC_TRY(s, {
     if (s->tick_reuse) { s->khead = (s->khead + 1) % s->L.N; s->reuse_this_pass = true; s->spec_next_now = s->spec_next_pending; }  // the records move one knot on with the iterate
     s->spec_next_pending = false; s->cycles_since_run = 0;
+    begin_reuse_pass(s);
     launch_shift(s);
     run_impl(s, stats);
   })
@@ -885,11 +990,17 @@ int mpc_run_shifted_async(mpc_solver* s) {
     }
     if (s->tick_reuse) { s->khead = (s->khead + 1) % L.N; s->reuse_this_pass = true; s->spec_next_now = s->spec_next_pending; }
     s->spec_next_pending = false; s->cycles_since_run = 0;
+    begin_reuse_pass(s);
     launch_shift(s);
     hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, s->args());
     // with max_iters = 1 one pass takes the step
     launch_pass(s);
     HIP_OK(hipMemcpyAsync(s->h_status[slot], s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost, s->stream));
+    // xs[1] of every instance — the state the next tick will take as its measurement under perfect-model feedback, and what a
+    // reference generator needs to plan that tick (mpc_wait_state) — rides along: B rows of nx doubles out of the iterate
+    if (!s->h_xnext[slot]) HIP_OK(hipHostMalloc((void**)&s->h_xnext[slot], (size_t)L.B * L.nx * sizeof(double), hipHostMallocDefault));
+    HIP_OK(hipMemcpy2DAsync(s->h_xnext[slot], (size_t)L.nx * sizeof(double), s->d_xs + L.nx, (size_t)(L.N + 1) * L.nx * sizeof(double),
+                            (size_t)L.nx * sizeof(double), (size_t)L.B, hipMemcpyDeviceToHost, s->stream));
     HIP_OK(hipEventRecord(s->status_ev[slot], s->stream));
     s->async_pending += 1;
   })
@@ -898,20 +1009,45 @@ int mpc_run_shifted_async(mpc_solver* s) {
 // Completes the OLDEST tick in flight.  If it is also the only one, an instance whose pass was a BCL update without a
 // step gets its further passes now (as mpc_run_shifted does); with a younger tick already queued behind it the instance
 // simply carries on in that tick.
+static void wait_impl(mpc_solver* s, mpc_stats* stats, double* x_next) {
+  const Layout& L = s->L;
+  if (s->async_pending == 0) {  // nothing in flight: the status (and next states) of the last completed tick, read synchronously
+    std::vector<InstState> stv(L.B);
+    copy_sync(s, stv.data(), s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost);
+    report_status(s, L.B, stv.data(), stats);
+    if (x_next) {
+      HIP_OK(hipMemcpy2DAsync(x_next, (size_t)L.nx * sizeof(double), s->d_xs + L.nx, (size_t)(L.N + 1) * L.nx * sizeof(double),
+                              (size_t)L.nx * sizeof(double), (size_t)L.B, hipMemcpyDeviceToHost, s->stream));
+      HIP_OK(hipStreamSynchronize(s->stream));
+    }
+    return;
+  }
+  const int slot = s->async_head;
+  s->async_head = (s->async_head + 1) % mpc_solver::ASYNC_DEPTH;
+  s->async_pending -= 1;
+  HIP_OK(hipEventSynchronize(s->status_ev[slot]));
+  const InstState* st = s->h_status[slot];
+  bool done = true;
+  for (int b = 0; b < L.B; ++b) if (!st[b].done) done = false;
+  if (!done && s->async_pending == 0) {
+    run_impl(s, stats, 1);  // continues from pass 1: the enqueued pass 0 is complete
+    if (x_next) {
+      HIP_OK(hipMemcpy2DAsync(x_next, (size_t)L.nx * sizeof(double), s->d_xs + L.nx, (size_t)(L.N + 1) * L.nx * sizeof(double),
+                              (size_t)L.nx * sizeof(double), (size_t)L.B, hipMemcpyDeviceToHost, s->stream));
+      HIP_OK(hipStreamSynchronize(s->stream));
+    }
+  } else {
+    report_status(s, L.B, st, stats);
+    if (x_next) std::memcpy(x_next, s->h_xnext[slot], (size_t)L.B * L.nx * sizeof(double));
+  }
+}
+
 int mpc_wait(mpc_solver* s, mpc_stats* stats) {
-  MPC_TRY(s, {
-    const Layout& L = s->L;
-    if (s->async_pending == 0) { HIP_OK(hipStreamSynchronize(s->stream)); return 0; }
-    const int slot = s->async_head;
-    s->async_head = (s->async_head + 1) % mpc_solver::ASYNC_DEPTH;
-    s->async_pending -= 1;
-    HIP_OK(hipEventSynchronize(s->status_ev[slot]));
-    const InstState* st = s->h_status[slot];
-    bool done = true;
-    for (int b = 0; b < L.B; ++b) if (!st[b].done) done = false;
-    if (!done && s->async_pending == 0) run_impl(s, stats, 1);  // continues from pass 1: the enqueued pass 0 is complete
-    else report_status(s, L.B, st, stats);
-  })
+  MPC_TRY(s, { wait_impl(s, stats, nullptr); })
+}
+
+int mpc_wait_state(mpc_solver* s, mpc_stats* stats, double* x_next) {
+  MPC_TRY(s, { wait_impl(s, stats, x_next); })
 }
 
 int mpc_poll(mpc_solver* s, int32_t* in_flight, int32_t* completed) {

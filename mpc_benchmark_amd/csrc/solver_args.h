@@ -7,6 +7,8 @@
 // |dphi0| <= MPC_STALL_TOL (1 + |phi0|): no descent left in the inner problem (shared with oracle/solver.hpp)
 #define MPC_STALL_TOL 1e-13
 
+#define MPC_DIRTY_WORDS 4  // per-knot invalidation of tick reuse covers horizons up to 255 knots (longer ones: any update clears all)
+
 struct SolverArgs {
   Layout L;
   mpc_options opt;
@@ -42,6 +44,9 @@ struct SolverArgs {
   // spec_next: this tick's appended stage has the table the speculation assumed (knots N - 1 and N are reused too)
   double* spec_knot;
   int spec_next;
+  // knots (bit k of word k / 64) whose stage parameters changed since their record was written (setReference, a rebuilt terminal
+  // constraint: mpc_update_stage_params): the launch of the current point evaluates them afresh, the others stay reused
+  unsigned long long dirty[MPC_DIRTY_WORDS];
 };
 
 // first knot of leg j (leg nlegs - 1 ends with the terminal knot) — the rule of oracle/solver.hpp leg_start
@@ -56,6 +61,7 @@ DEV double* knot_ptr(const SolverArgs& a, int b, int k) { return a.knots + ((siz
 // knot N: the terminal state and its table are those of the previous tick)
 DEV bool knot_reused(const SolverArgs& a, int b, int k) {
   if (!(a.reuse_on && a.spec[b])) return false;
+  if ((a.dirty[(k >> 6) & (MPC_DIRTY_WORDS - 1)] >> (k & 63)) & 1ull) return false;
   if (k < a.L.N - 1) return k > 0 || a.reuse_k0;
   return a.spec_next != 0;
 }

@@ -63,6 +63,8 @@ class EnsembleMPC:
         # integrated under the feedback law of the low-level loop) instead of the model's own prediction xs[1]
         self.closed_loop = closed_loop
         self.tick = 0
+        self.inflight = 0   # asynchronous ticks enqueued and not yet collected (step_async / wait)
+        self._walk = None   # enable_walk(): the reference loop's per-tick problem updates
 
     # -- stage tables of the schedule ---------------------------------------------------------------
     def _table_for_tick(self, t):
@@ -118,6 +120,8 @@ class EnsembleMPC:
         stats = self.native.run(xs, us)  # max_iters = 1: one warm iteration, as a tick
         self.native.set_x0(None)
         self.episodes = getattr(self, "episodes", 0) + 1
+        if self._walk is not None:
+            self.enable_walk(**self._walk_args)  # countdown lists and foot trajectory back to the start of the schedule
         return stats
 
     def step(self, rescue=False):
@@ -127,11 +131,20 @@ class EnsembleMPC:
         whatever region the caller is timing)."""
         if self.closed_loop:
             self.native.simulate(*self.closed_loop)  # apply us[0] + feedback for one MPC period, measure
+        if self._walk is not None:
+            self._walk_references()
         desc, params = self._table_for_tick(self.tick % self.pd.t_mpc)
         self.native.cycle(desc, params)
+        if self._walk is not None:
+            self._walk_terminal()
         self.native.setup()
         self.tick += 1
         try:
+            if self._walk is not None:
+                self.native.run_shifted_async()
+                stats, xn = self.native.wait_state()
+                self._walk["x_measured"] = xn[0].copy()
+                return stats
             return self.native.run_shifted()
         except RuntimeError as e:
             if not rescue or "factorisation failed" not in str(e):
@@ -141,28 +154,101 @@ class EnsembleMPC:
 
     def step_async(self):
         """Enqueue one tick without waiting (several shards on different streams overlap on the device); ``wait``
-        completes the oldest tick in flight.  Two ticks may be in flight: enqueue tick t + 1, then wait for tick t."""
+        completes the oldest tick in flight.  Two ticks may be in flight: enqueue tick t + 1, then wait for tick t
+        (``self.inflight`` counts them)."""
         if self.closed_loop:
             self.native.simulate(*self.closed_loop)
+        if self._walk is not None:
+            self._walk_references()  # the reference's per-tick updates (fulldynamic_talos.py:444-510) before the stage is cycled
         desc, params = self._table_for_tick(self.tick % self.pd.t_mpc)
         self.native.cycle(desc, params)
+        if self._walk is not None:
+            self._walk_terminal()
         self.native.setup()
         self.native.run_shifted_async()
         self.tick += 1
+        self.inflight += 1
 
     def wait(self, rescue=False):
         """Complete the tick enqueued by ``step_async`` (``rescue`` as in ``step``)."""
         try:
+            self.inflight = max(0, self.inflight - 1)
+            if self._walk is not None:
+                stats, xn = self.native.wait_state()
+                self._walk["x_measured"] = xn[0].copy()  # instance 0's predicted next state: the measurement the generators plan from
+                return stats
             return self.native.wait()
         except RuntimeError as e:
             if not rescue or "factorisation failed" not in str(e):
                 raise
             self.rescues = getattr(self, "rescues", 0) + 1
-            try:  # a younger tick may already be queued behind the failed one: let it drain
-                self.native.wait()
-            except RuntimeError:
-                pass
+            while self.inflight > 0:  # a younger tick may already be queued behind the failed one: let it drain
+                self.inflight -= 1
+                try:
+                    self.native.wait()
+                except RuntimeError:
+                    pass
             return self.cold_solve(max_iters=20)
+
+    # -- the reference loop's per-tick problem updates on the shared stage tables ---------------------------------
+    def enable_walk(self, swing_apex=0.15, x_forward=0.0, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0):
+        """From now on every tick does what the loop body of fulldynamic_talos.py:444-510 does to the problem before solving:
+        ``FootTrajectory.updateTrajectory`` from the measured foot poses, ``setReference`` on the two foot-placement costs of
+        every stage (2 N parameter patches), ``replaceStageCircular``, the terminal CoM constraint rebuilt between the last foot
+        references and the terminal foot references.  The stage tables of an ensemble are shared by its instances, so the
+        references are planned from instance 0's state (the state the last COMPLETED tick predicted: with two ticks in flight
+        that is one tick older than the reference script's measurement) and every instance tracks them."""
+        from . import references as refgen
+        from .problems import fulldynamic
+        from .robot import minipin as pin
+        self._walk_args = dict(swing_apex=swing_apex, x_forward=x_forward, y_forward=y_forward, foot_yaw=foot_yaw, y_gap=y_gap, z_height=z_height)
+        pd, N = self.pd, self.problem.num_steps
+        rb = pd.robot
+        ev = refgen.contact_event_times(pd.contact_phases, N)
+        lf, rf = rb.foot_placements
+        # where the references live in the parameter tables (cost components 3 / 4 of a stage, 2 / 3 of the terminal cost, the
+        # CoM target of the terminal constraint)
+        slots = []
+        st = pd.stage_for_tick(0)
+        core.lower_stage(self.ctx, st.cost, st.dynamics, st.constraints, slots)
+        tslots = []
+        core.lower_stage(self.ctx, self.problem.term_cost, None, self.problem.term_constraints, tslots)
+        self._walk = {
+            "lists": [list(e) for e in ev],  # takeoff_RFs, takeoff_LFs, land_RFs, land_LFs
+            "traj": refgen.FootTrajectory(lf.copy(), rf.copy(), fulldynamic.T_SS, fulldynamic.T_DS, N, swing_apex, x_forward, y_forward, foot_yaw, y_gap, z_height),
+            "data": rb.model.createData(), "pin": pin, "refgen": refgen,
+            "off_lf": slots[3][1], "off_rf": slots[4][1], "toff_lf": tslots[2][1], "toff_rf": tslots[3][1],
+            "toff_com": tslots[len(self.problem.term_cost.components)][1],
+            "x_measured": np.array(self.x0[0]), "patched": 0, "patches": 0, "last": None,
+        }
+        assert slots[3][2] == 12 and slots[4][2] == 12 and tslots[2][2] == 12 and tslots[3][2] == 12 and tslots[len(self.problem.term_cost.components)][2] == 3
+
+    def _walk_references(self):
+        w, N = self._walk, self.problem.num_steps
+        rb, pin, refgen = self.pd.robot, self._walk["pin"], self._walk["refgen"]
+        pin.framesForwardKinematics(rb.model, w["data"], np.asarray(w["x_measured"])[:rb.model.nq])
+        LF_pose, RF_pose = w["data"].oMf[rb.foot_frame_ids[0]].copy(), w["data"].oMf[rb.foot_frame_ids[1]].copy()
+        takeoff_RFs, takeoff_LFs, land_RFs, land_LFs = w["lists"]
+        takeoff_RF, takeoff_LF, land_RF, land_LF = refgen.update_timings(land_LFs, land_RFs, takeoff_LFs, takeoff_RFs)
+        LF_refs, RF_refs = w["traj"].updateTrajectory(takeoff_RF, takeoff_LF, land_RF, land_LF, LF_pose, RF_pose)
+        flat = lambda M: np.concatenate([np.asarray(M.rotation, dtype=float).reshape(-1), np.asarray(M.translation, dtype=float)])
+        batch = []
+        for j in range(N):
+            batch.append((j, w["off_lf"], flat(LF_refs[j])))
+            batch.append((j, w["off_rf"], flat(RF_refs[j])))
+        self.native.update_stage_params_batch(batch)
+        w["last"] = (LF_refs[-1], RF_refs[-1], flat)
+        # ticks on which the generator plans from the measured poses (a foot without a pending landing, a take-off inside the double-
+        # support window): their references change for every knot, so no record of the previous tick can be reused
+        w["replanning"] = (land_LF < 0 or land_RF < 0 or 0 <= takeoff_RF < w["traj"].T_ds or 0 <= takeoff_LF < w["traj"].T_ds)
+        self.replanning_ticks = getattr(self, "replanning_ticks", 0) + int(w["replanning"])
+
+    def _walk_terminal(self):
+        w, N = self._walk, self.problem.num_steps
+        LF_last, RF_last, flat = w["last"]
+        com_final = self.pd.robot.com0.copy()
+        com_final[:2] = 0.5 * (LF_last.translation[:2] + RF_last.translation[:2])
+        self.native.update_stage_params_batch([(N, w["toff_com"], com_final), (N, w["toff_lf"], flat(LF_last)), (N, w["toff_rf"], flat(RF_last))])
 
     def results(self, **kw):
         return self.native.get_results(**kw)

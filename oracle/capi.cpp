@@ -162,6 +162,14 @@ int mpc_wait(mpc_solver* h, mpc_stats* stats) {
   MPC_TRY(h, { if (stats) for (int b = 0; b < h->s.dims.batch; ++b) stats[b] = h->s.inst[b].stats; })
 }
 
+int mpc_wait_state(mpc_solver* h, mpc_stats* stats, double* x_next) {
+  MPC_TRY(h, {
+    Solver& s = h->s;
+    if (stats) for (int b = 0; b < s.dims.batch; ++b) stats[b] = s.inst[b].stats;
+    if (x_next) for (int b = 0; b < s.dims.batch; ++b) std::memcpy(x_next + (size_t)b * s.dims.nx, s.inst[b].xs[1].data(), s.dims.nx * sizeof(double));
+  })
+}
+
 int mpc_get_results(mpc_solver* h, double* xs, double* us, double* K, double* kff, double* vs, double* lams) {
   MPC_TRY(h, {
     Solver& s = h->s;
