@@ -321,6 +321,7 @@ def main():
             # the alpha = 1 candidate: with tick reuse it is evaluated WITH derivatives into the knot records (k_eval_multibody<3>),
             # otherwise value-only candidates (iterate in, merit partials out)
             "k_eval_stage_trial": 8.0 * (W + io) if not args.no_tick_reuse else 8.0 * io * 8,
+            "k_eval_stage_trial_values": 8.0 * io * 8,
             "k_forward": 8.0 * (d.horizon * (m * n + m + n * n + n)),
             "k_duals": 8.0 * (W + G) * 0.5,
             "k_lagrangian": 8.0 * W * 0.5,

@@ -13,81 +13,6 @@
 #include "mfma_blocks.h"
 #include "eval_multibody_host.h"
 
-// ---- 6-vectors --------------------------------------------------------------------------------------------
-struct S6 { double v[6]; };
-DEV S6 ld6(const double* p) { S6 r; for (int i = 0; i < 6; ++i) r.v[i] = p[i]; return r; }
-DEV void st6(double* p, const S6& a) { for (int i = 0; i < 6; ++i) p[i] = a.v[i]; }
-DEV S6 zero6() { S6 r; for (int i = 0; i < 6; ++i) r.v[i] = 0.0; return r; }
-DEV S6 add6(const S6& a, const S6& b) { S6 r; for (int i = 0; i < 6; ++i) r.v[i] = a.v[i] + b.v[i]; return r; }
-DEV S6 sub6(const S6& a, const S6& b) { S6 r; for (int i = 0; i < 6; ++i) r.v[i] = a.v[i] - b.v[i]; return r; }
-DEV S6 scale6(double s, const S6& a) { S6 r; for (int i = 0; i < 6; ++i) r.v[i] = s * a.v[i]; return r; }
-DEV double dot6(const S6& a, const S6& b) { double s = 0; for (int i = 0; i < 6; ++i) s += a.v[i] * b.v[i]; return s; }
-DEV V3 lin(const S6& a) { return v3(a.v[0], a.v[1], a.v[2]); }
-DEV V3 ang(const S6& a) { return v3(a.v[3], a.v[4], a.v[5]); }
-DEV S6 mk6(V3 l, V3 a) { S6 r; r.v[0] = l.x; r.v[1] = l.y; r.v[2] = l.z; r.v[3] = a.x; r.v[4] = a.y; r.v[5] = a.z; return r; }
-// motion x motion and motion x* force
-DEV S6 mcross(const S6& a, const S6& b) { return mk6(cross(ang(a), lin(b)) + cross(lin(a), ang(b)), cross(ang(a), ang(b))); }
-DEV S6 fcross(const S6& a, const S6& f) { return mk6(cross(ang(a), lin(f)), cross(ang(a), ang(f)) + cross(lin(a), lin(f))); }
-DEV S6 mat6_mul(const double* Y, const S6& x) { S6 r; for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < 6; ++j) s += Y[6 * i + j] * x.v[j]; r.v[i] = s; } return r; }
-DEV S6 mat6_tmul(const double* Y, const S6& x) { S6 r; for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < 6; ++j) s += Y[6 * j + i] * x.v[j]; r.v[i] = s; } return r; }
-DEV M3 ldm3(const double* p) { M3 r; for (int i = 0; i < 9; ++i) r.m[i] = p[i]; return r; }
-DEV V3 ldv3(const double* p) { return v3(p[0], p[1], p[2]); }
-// Ad(M)^-1 on a motion, M = (R, p)
-DEV S6 adinv(const M3& R, V3 p, const S6& m) { return mk6(tmul(R, lin(m) - cross(p, ang(m))), tmul(R, ang(m))); }
-
-// ---- SE(3) Jacobians (Barfoot's Q block; right Jacobians as used by Pinocchio's Jlog6 / Jexp6) ------------
-DEV void q_coeffs(double t2, double& a1, double& a2, double& a3) {
-  if (t2 < kSmall2) {
-    a1 = 1.0 / 6 - t2 * (1.0 / 120 - t2 * (1.0 / 5040 - t2 * (1.0 / 362880)));
-    a2 = 1.0 / 24 - t2 * (1.0 / 720 - t2 * (1.0 / 40320 - t2 * (1.0 / 3628800)));
-    a3 = 1.0 / 120 - t2 * (1.0 / 2520 - t2 * (1.0 / 120960 - t2 * (1.0 / 9979200)));
-  } else {
-    const double t = sqrt(t2), s = sin(t), c = cos(t);
-    a1 = (t - s) / (t2 * t); a2 = (t2 + 2 * c - 2) / (2 * t2 * t2); a3 = (2 * t - 3 * s + t * c) / (2 * t2 * t2 * t);
-  }
-}
-DEV M3 add3(const M3& A, const M3& B) { M3 C; for (int i = 0; i < 9; ++i) C.m[i] = A.m[i] + B.m[i]; return C; }
-DEV M3 scl3(double s, const M3& A) { M3 C; for (int i = 0; i < 9; ++i) C.m[i] = s * A.m[i]; return C; }
-DEV M3 Qmat(V3 v, V3 w) {
-  double a1, a2, a3;
-  q_coeffs(dot(w, w), a1, a2, a3);
-  const M3 P = skew_m(v), F = skew_m(w);
-  const M3 FP = mul(F, P), PF = mul(P, F), FPF = mul(FP, F), FF = mul(F, F);
-  M3 Q = scl3(0.5, P);
-  Q = add3(Q, scl3(a1, add3(add3(FP, PF), FPF)));
-  Q = add3(Q, scl3(a2, add3(add3(mul(FF, P), mul(P, FF)), scl3(-3.0, FPF))));
-  Q = add3(Q, scl3(a3, add3(mul(FPF, F), mul(F, FPF))));
-  return Q;
-}
-// out (6x6 row-major) = Jlog6 at M = (R, p)
-DEV void Jlog6(const M3& R, V3 p, double* out) {
-  V3 v, w;
-  log6(R, p, v, w);
-  const double t2 = dot(w, w);
-  double c;
-  if (t2 < kSmall2) c = 1.0 / 12 + t2 * (1.0 / 720 + t2 * (1.0 / 30240 + t2 * (1.0 / 1209600)));
-  else { const double t = sqrt(t2); c = (1.0 - t * cos(0.5 * t) / (2.0 * sin(0.5 * t))) / t2; }
-  const M3 K = skew_m(w), K2 = mul(K, K);
-  M3 Ji;
-  for (int i = 0; i < 9; ++i) Ji.m[i] = ((i % 4 == 0) ? 1.0 : 0.0) + 0.5 * K.m[i] + c * K2.m[i];
-  const M3 Q = Qmat(v3(-v.x, -v.y, -v.z), v3(-w.x, -w.y, -w.z));
-  const M3 B = mul(mul(Ji, Q), Ji);
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-    out[6 * i + j] = Ji.m[3 * i + j]; out[6 * (i + 3) + j + 3] = Ji.m[3 * i + j];
-    out[6 * i + j + 3] = -B.m[3 * i + j]; out[6 * (i + 3) + j] = 0.0;
-  }
-}
-DEV void Jexp6(V3 v, V3 w, double* out) {
-  double A, B, C;
-  so3_coeffs(dot(w, w), A, B, C);
-  const M3 K = skew_m(w), K2 = mul(K, K);
-  const M3 Q = Qmat(v3(-v.x, -v.y, -v.z), v3(-w.x, -w.y, -w.z));
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-    const double jr = ((i == j) ? 1.0 : 0.0) - B * K.m[3 * i + j] + C * K2.m[3 * i + j];
-    out[6 * i + j] = jr; out[6 * (i + 3) + j + 3] = jr; out[6 * i + j + 3] = Q.m[3 * i + j]; out[6 * (i + 3) + j] = 0.0;
-  }
-}
-
 // 6x6 inverse by Gauss-Jordan without pivoting, fully unrolled (registers only); used on M_bb (SPD)
 DEV void inv6_unrolled_mb(const double* A, double* Ainv) {
   double M[6][12];

@@ -68,6 +68,7 @@ struct mpc_solver {
   // an update on a horizon too long for the mask of SolverArgs
   std::vector<uint8_t> slot_dirty;
   bool dirty_all = false;
+  bool spec_skip_pass = false;  // this pass neither reuses records nor writes speculative ones (begin_reuse_pass)
   unsigned long long dirty_now[MPC_DIRTY_WORDS] = {};  // knot mask of the pass being enqueued (set in begin_reuse_pass)
   // parameter patches travel through a pinned ring as ONE host-to-device copy + a scatter kernel, stream-ordered (no host wait)
   static constexpr int PATCH_RING = 4;
@@ -161,7 +162,7 @@ struct mpc_solver {
     a.xs = d_xs; a.us = d_us; a.vs = d_vs; a.lams = d_lams; a.vs_e = d_vs_e; a.lams_e = d_lams_e; a.x0 = d_x0;
     a.dxs = d_dxs; a.dus = d_dus; a.dvs = d_dvs; a.dlams = d_dlams; a.abdz = nullptr;
     a.khead = khead; a.spec = d_spec;
-    a.spec_on = (tick_reuse && opt.max_iters == 1 && L.space == MPC_SPACE_MULTIBODY) ? 1 : 0;
+    a.spec_on = (tick_reuse && opt.max_iters == 1 && L.space == MPC_SPACE_MULTIBODY && !spec_skip_pass) ? 1 : 0;
     a.reuse_on = (a.spec_on && reuse_this_pass) ? 1 : 0;
     a.reuse_k0 = perfect_feedback ? 1 : 0;
     a.spec_knot = a.spec_on ? d_spec_knot : nullptr; a.spec_next = (a.reuse_on && spec_next_now) ? 1 : 0;
@@ -381,6 +382,12 @@ static void begin_reuse_pass(mpc_solver* s) {
     if (k < 64 * MPC_DIRTY_WORDS) s->dirty_now[k >> 6] |= 1ull << (k & 63);
   }
   if (s->dirty_all || (any && N + 1 > 64 * MPC_DIRTY_WORDS)) s->reuse_this_pass = false;  // no per-knot mask for this horizon: evaluate everything
+  // Most knots updated (a replanning tick of the walk: every foot reference changes): the next tick will most likely find its records
+  // stale again, so this pass evaluates its full-step candidate value-only instead of with derivatives into the records (the
+  // derivative work would be thrown away) and reuses nothing — same results, the plain path for one tick.
+  int ndirty = 0;
+  for (int w = 0; w < MPC_DIRTY_WORDS; ++w) ndirty += __builtin_popcountll(s->dirty_now[w]);
+  s->spec_skip_pass = 2 * ndirty > N;
   std::fill(s->slot_dirty.begin(), s->slot_dirty.end(), (uint8_t)0);
   s->dirty_all = false;
 }
@@ -592,7 +599,9 @@ static void launch_pass(mpc_solver* s) {
   s->timed(5, "k_duals", [&] { hipLaunchKernelGGL(k_duals, dim3(L.N + 1, L.B), dim3(256), (L.nz + 3 * L.n + 16 + 3 * L.c) * sizeof(double), s->stream, a); });
   // linesearch: evaluate the full step first; the backtracking candidates alpha = 2^-i, i >= 1, are only
   // evaluated for instances whose full step failed the Armijo test (their workgroups exit immediately otherwise)
-  s->timed(6, "k_eval_stage_trial", [&] { launch_eval(s, true, 0, 1, a.spec_on != 0); });
+  // (two profile slots: with derivatives into the knot records — the launch the roofline is quoted on — or values only)
+  if (a.spec_on || L.space != MPC_SPACE_MULTIBODY) s->timed(6, "k_eval_stage_trial", [&] { launch_eval(s, true, 0, 1, a.spec_on != 0); });
+  else s->timed(17, "k_eval_stage_trial_values", [&] { launch_eval(s, true, 0, 1, false); });
   s->spec_rec_valid = a.spec_on != 0 && a.spec_knot != nullptr;  // (per instance it counts only if the full step is accepted: a.spec[b])
   s->timed(7, "k_linesearch", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(64), 0, s->stream, a, 1); });
   s->timed(10, "k_eval_stage_backtrack", [&] { launch_eval(s, true, 1, L.n_alpha - 1); });
@@ -962,6 +971,7 @@ int mpc_run(mpc_solver* s, const double* xs, const double* us, mpc_stats* stats)
     spec_clear(s);
     s->reuse_this_pass = false;
     s->leg_guess_valid = false;  // a fresh iterate: the cut Hessians kept from the last pass belong to another trajectory
+    s->spec_skip_pass = false;
     const Layout& L = s->L;
     HIP_OK(hipMemcpyAsync(s->d_xs, xs, (size_t)L.B * (L.N + 1) * L.nx * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipMemcpyAsync(s->d_us, us, (size_t)L.B * L.N * L.m * sizeof(double), hipMemcpyHostToDevice, s->stream));

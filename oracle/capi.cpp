@@ -27,7 +27,10 @@ struct mpc_solver {
 extern "C" {
 
 int mpc_abi_version(void) { return MPC_ABI_VERSION; }
-const char* mpc_backend_name(void) { return "oracle-cpu"; }
+#ifndef ORC_BACKEND_NAME
+#define ORC_BACKEND_NAME "oracle-cpu"
+#endif
+const char* mpc_backend_name(void) { return ORC_BACKEND_NAME; }
 
 int mpc_create(const mpc_dims* dims, mpc_solver** out) {
   if (!dims || !out) return -2;

@@ -13,6 +13,11 @@
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
+// The whole-body stage evaluation: the oracle's own (forward-mode AD, stage.hpp) — or, in the build of oracle/cpu_port/ only, the
+// closed-form port that bench.py times as its CPU baseline (never part of the checker library).
+#ifndef ORC_EVAL_MULTIBODY
+#define ORC_EVAL_MULTIBODY eval_multibody
+#endif
 #endif
 #include "stage.hpp"
 
@@ -157,7 +162,7 @@ struct Solver {
     const StageDesc& sd = stages[k];
     if (sd.nc > dims.nc_max) throw std::runtime_error("stage has more constraint rows than nc_max");
     if (dims.space == MPC_SPACE_VECTOR) eval_centroidal(sd, dims.nx, dims.nu, x, u, xnext, kn, derivs);
-    else eval_multibody(model, sd, dims.nu, x, u, xnext, kn, derivs);
+    else ORC_EVAL_MULTIBODY(model, sd, dims.nu, x, u, xnext, kn, derivs);
     if (derivs) {
       const int nz = kn.n + kn.m;
       for (int i = 0; i < nz; ++i) kn.H[i * nz + i] += opt.reg_init;
@@ -933,7 +938,7 @@ struct Solver {
         for (int j = 0; j < n; ++j) su -= in.gains[0].K[i * n + j] * d[j];
         u[i] = su;
       }
-      eval_multibody(model, sd, nu, x.data(), u.data(), x.data(), kn, false);
+      ORC_EVAL_MULTIBODY(model, sd, nu, x.data(), u.data(), x.data(), kn, false);
       x = kn.xnext;
     }
     in.x0 = x;

@@ -1,0 +1,28 @@
+"""Test-side loader of the CPU port (oracle/cpu_port/libmpc_cpu.so): the closed-form host implementation bench.py times as its
+cpu_baseline.  Like the oracle it is measurement / test infrastructure: only tests/ and bench.py's cpu_baseline leg load it."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PORT_DIR = os.path.join(ROOT, "oracle", "cpu_port")
+PORT_LIB = os.path.join(PORT_DIR, "libmpc_cpu.so")
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        deps = [os.path.join(PORT_DIR, f) for f in os.listdir(PORT_DIR) if f.endswith((".cpp", ".hpp"))]
+        deps += [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle")) if f.endswith((".cpp", ".hpp"))]
+        deps.append(os.path.join(ROOT, "mpc_benchmark_amd", "csrc", "se3_math.h"))
+        stale = (not os.path.exists(PORT_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(PORT_LIB) for s in deps)
+        if stale:
+            try:
+                subprocess.run(["make", "-s", "-C", PORT_DIR], check=True)
+            except Exception:
+                if not os.path.exists(PORT_LIB):
+                    raise
+        from mpc_benchmark_amd import _capi
+        _lib = _capi.bind_library(PORT_LIB)
+    return _lib
