@@ -28,6 +28,30 @@ def _p50(v):
     return float(np.percentile(np.asarray(v), 50))
 
 
+def cpu_worker(args):
+    """One instance of the bench OCP on the CPU port (tests/_cpu_port.py), 8 OpenMP threads, 8 legs: a few cold iterations for a
+    warm start, then `--cpu-worker` timed MPC ticks.  Prints one JSON line (tick times and their wall-clock window)."""
+    from tests import _cpu_port
+    from mpc_benchmark_amd.ensemble import EnsembleMPC
+    from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+    pd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
+    e = EnsembleMPC(pd, batch=1, library=_cpu_port.load(), perturb=False)
+    e.options.num_threads, e.options.riccati_legs = 8, 8
+    e.prepare_schedule(args.cpu_worker + 8)
+    e.cold_solve(max_iters=3)
+    e.options.num_threads, e.options.riccati_legs = 8, 8
+    e.native.set_options(e.options)
+    e.step()
+    ms, ends = [], []
+    t_start = time.time()
+    for _ in range(args.cpu_worker):
+        t0 = time.perf_counter()
+        e.step()
+        ms.append((time.perf_counter() - t0) * 1e3)
+        ends.append(time.time())
+    print(json.dumps({"tick_ms": ms, "tick_ends": ends, "t_start": t_start, "t_end": ends[-1]}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,9 +100,12 @@ def main():
                          "than 8 the cuts are resolved by a tree of pairwise compositions, csrc/legs_tree.h)")
     ap.add_argument("--lib", default=None, help="developer option: another build of the same HIP library (kernel tuning variants)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", type=int, default=0, help="(internal) run this many MPC ticks of one instance on the CPU port with 8 threads and print their times")
     ap.add_argument("--no-latency", action="store_true")
     args = ap.parse_args()
 
+    if args.cpu_worker > 0:
+        return cpu_worker(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -394,30 +421,30 @@ def main():
         p50_ms = round(_p50(lat), 4)
         del one
 
-    # ---- CPU baseline: the oracle (a port, not Aligator) on this host's cores, bounded sample ----
+    # ---- CPU baseline: the CPU port (oracle/cpu_port: closed-form derivatives, -O3 -march=native, OpenMP over knots, Riccati sweep in
+    # legs — NOT Aligator, and not the AD checker) on this host's cores, bounded sample.  (i) ONE instance at 8 threads, the setting of
+    # the scripts (setNumThreads(8), fulldynamic_talos.py:385): p50 ms per tick ; (ii) floor(cores / 8) such instances side by side,
+    # one process each: whole-host solves/s — the figure to put next to `value`.
     cpu = None
     if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only: the multi-GPU runs of the same session would time the same host cores again)
-        from tests import _oracle
+        import subprocess
         cores = os.cpu_count() or 1
-        opd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
-        oens = EnsembleMPC(opd, batch=1, library=_oracle.load(), perturb=False)
-        oens.options.num_threads = cores
-        oens.options.riccati_legs = 1  # on the host the serial sweep is the faster one (3.3 against 1.7 solves/s with the 8 legs of the script)
-        oens.prepare_schedule(40)
-        oens.cold_solve(max_iters=3)  # a few iterations are enough to get a warm start
-        oens.options.num_threads = cores
-        oens.options.riccati_legs = 1
-        oens.native.set_options(oens.options)
-        oens.step()
-        ts = time.perf_counter()
-        nt = 0
-        while nt < 3 or (time.perf_counter() - ts < 10.0 and nt < 200):
-            oens.step()
-            nt += 1
-        dtc = time.perf_counter() - ts
-        cpu = {"value": round(nt / dtc, 3), "unit": "solves/s", "cores": cores, "kind": "port",
-               "sample": "%d warm-started MPC ticks (1 ProxDDP iteration each) of ONE instance of the same N=%d %s-model OCP, "
-                         "OpenMP over knots (serial Riccati sweep: faster on the host than the 8 legs of the script), %.1f s" % (nt, args.horizon, args.model, dtc)}
+        nproc = max(1, cores // 8)
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-worker", "20", "--horizon", str(args.horizon), "--model", args.model]
+        one = json.loads(subprocess.run(cmd, check=True, capture_output=True, text=True).stdout.strip().split("\n")[-1])
+        t0c = time.perf_counter()
+        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) for _ in range(nproc)]
+        outs = [json.loads(pr.communicate()[0].strip().split("\n")[-1]) for pr in procs]
+        wall = time.perf_counter() - t0c
+        # every worker reports the wall-clock window of its timed ticks: the host rate is the ticks inside the common window
+        lo, hi = max(o["t_start"] for o in outs), min(o["t_end"] for o in outs)
+        rate = sum(sum(1 for te in o["tick_ends"] if lo < te <= hi) for o in outs) / max(hi - lo, 1e-9)
+        cpu = {"value": round(rate, 2), "unit": "solves/s", "cores": cores, "threads_per_instance": 8, "concurrent_instances": nproc, "kind": "port",
+               "p50_ms_per_solve_one_instance_8_threads": round(_p50(one["tick_ms"]), 2),
+               "sample": "CPU port (closed-form derivatives, -O3 -march=native; not Aligator, not the AD oracle): %d processes x 8 OpenMP threads, each %d "
+                         "warm-started MPC ticks (1 ProxDDP iteration, Riccati sweep in 8 legs) of the same N=%d %s-model OCP, %.1f s wall; the "
+                         "reference's own loop budgets 10 ms per solve at 8 threads (fulldynamic_talos.py:431): real Aligator is expected to be several "
+                         "times faster than this port" % (nproc, len(one["tick_ms"]), args.horizon, args.model, wall)}
 
     # With two ticks in flight per shard an instance whose pass was a BCL update without a step carries on in the next tick instead
     # of getting further passes at once: such instance-ticks are not solves (rank 0's count, the shards of the other ranks are alike)

@@ -15,6 +15,16 @@
 #include <omp.h>
 // The whole-body stage evaluation: the oracle's own (forward-mode AD, stage.hpp) — or, in the build of oracle/cpu_port/ only, the
 // closed-form port that bench.py times as its CPU baseline (never part of the checker library).
+#ifdef ORC_PROFILE
+#include <cstdio>
+namespace orc { struct ProfAcc { double t[16] = {}; double last = 0; ~ProfAcc() { for (int i = 0; i < 16; ++i) if (t[i] > 0) fprintf(stderr, "[orc prof] section %d: %.1f ms\n", i, t[i] * 1e3); } };
+inline ProfAcc& prof_acc() { static ProfAcc a; return a; } }
+#define ORC_PROF_START() do { if (omp_get_thread_num() == 0) orc::prof_acc().last = omp_get_wtime(); } while (0)
+#define ORC_PROF(i) do { if (omp_get_thread_num() == 0) { const double t_ = omp_get_wtime(); orc::prof_acc().t[i] += t_ - orc::prof_acc().last; orc::prof_acc().last = t_; } } while (0)
+#else
+#define ORC_PROF_START() do {} while (0)
+#define ORC_PROF(i) do {} while (0)
+#endif
 #ifndef ORC_EVAL_MULTIBODY
 #define ORC_EVAL_MULTIBODY eval_multibody
 #endif
@@ -288,6 +298,7 @@ struct Solver {
     const Knot& kn = in.knots[k];
     const int m = kn.m, c = kn.c, nz = n + m;
     const int np = Lmn ? n : 0;
+    ORC_PROF_START();
     // 1. change of variable y = Ebar x'
     for (int i = 0; i < 36; ++i) g.T6[i] = (i % 7 == 0) ? 1.0 : 0.0;
     std::vector<double> Ph(Pn), ph(pn), phM;
@@ -311,6 +322,7 @@ struct Solver {
       for (int i = 0; i < 6; ++i) { double s = 0; for (int l = 0; l < 6; ++l) s += g.T6[l * 6 + i] * pn[l]; ph[i] = s; }
       for (int j = 0; j < np; ++j) for (int i = 0; i < 6; ++i) { double s = 0; for (int l = 0; l < 6; ++l) s += g.T6[l * 6 + i] * (*Lmn)[l * np + j]; phM[i * np + j] = s; }
     }
+    ORC_PROF(1);
     // 2. Lam = (I + mud Ph)^-1 ; Pt = Lam Ph ; pt = Lam (Ph ft + ph)
     std::vector<double> Lp(n * n);
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Lp[i * n + j] = mud * 0.5 * (Ph[i * n + j] + Ph[j * n + i]) + (i == j ? 1.0 : 0.0);
@@ -322,6 +334,7 @@ struct Solver {
     trsm_lower(Lp.data(), n, w.data(), 1); trsm_lower_t(Lp.data(), n, w.data(), 1);
     if (np) { trsm_lower(Lp.data(), n, wM.data(), np); trsm_lower_t(Lp.data(), n, wM.data(), np); }
     for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) { const double s = 0.5 * (Pt[i * n + j] + Pt[j * n + i]); Pt[i * n + j] = Pt[j * n + i] = s; }
+    ORC_PROF(2);
     // 3. Hh = H + AB^T Pt AB ; gh = grad + AB^T pt
     std::vector<double> G(n * nz, 0.0), Hh(kn.H), gh(kn.grad), ghM((size_t)nz * np, 0.0);
     for (int i = 0; i < n; ++i) for (int l = 0; l < n; ++l) { const double pv = Pt[i * n + l]; if (pv != 0.0) for (int a = 0; a < nz; ++a) G[i * nz + a] += pv * kn.AB[l * nz + a]; }
@@ -330,9 +343,11 @@ struct Solver {
         const double ab = kn.AB[i * nz + a];
         if (ab == 0.0) continue;
         gh[a] += ab * w[i];
-        for (int b = 0; b < nz; ++b) Hh[a * nz + b] += ab * G[i * nz + b];
+        for (int b = a; b < nz; ++b) Hh[a * nz + b] += ab * G[i * nz + b];  // upper triangle (AB^T Pt AB is symmetric: Pt was symmetrised), mirrored below
         for (int j = 0; j < np; ++j) ghM[a * np + j] += ab * wM[i * np + j];
       }
+    for (int a = 0; a < nz; ++a) for (int b = a + 1; b < nz; ++b) Hh[b * nz + a] = Hh[a * nz + b] - kn.H[a * nz + b] + kn.H[b * nz + a];
+    ORC_PROF(3);
     // 4. stage KKT  [[R, D^T],[D, -mu I]] [U; V] = -[[S^T r],[C d]]
     std::vector<double> Lr(m * m), Ct(c * nz, 0.0), dt_(c, 0.0);
     for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Lr[i * m + j] = 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]);
@@ -346,79 +361,111 @@ struct Solver {
       for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j)
         Lr[i * m + j] = 0.5 * (Hh[(n + i) * nz + n + j] + Hh[(n + j) * nz + n + i]) + (i == j ? rho : 0.0);
     }
+    // Only the ACTIVE rows enter the elimination: an inactive row (zero Jacobian row, Pi_N(z) = 0) decouples — its Schur diagonal is
+    // mu, its gains are zero — so the compacted system gives the same numbers as the full one (same operations in the same order
+    // on the active rows) at a fraction of the work: c = 98 rows on a double-support knot, about a dozen active.
+    std::vector<int> act;
+    act.reserve(c);
     for (int i = 0; i < c; ++i) {
-      bool act;
-      dt_[i] = proj_normal(kn.ctype[i], kn.cval[i] + mu * in.vs_e[k][i], kn.lo[i], kn.hi[i], act);
-      if (act) for (int a = 0; a < nz; ++a) Ct[i * nz + a] = kn.CD[i * nz + a];
+      bool a_;
+      dt_[i] = proj_normal(kn.ctype[i], kn.cval[i] + mu * in.vs_e[k][i], kn.lo[i], kn.hi[i], a_);
+      if (a_) { act.push_back(i); for (int a = 0; a < nz; ++a) Ct[i * nz + a] = kn.CD[i * nz + a]; }
     }
+    const int ca = (int)act.size();
     const int nr = n + 1 + np;  // columns: feedback on dx | feed-forward | feedback on theta
-    std::vector<double> W((size_t)m * nr), Y(m * (c > 0 ? c : 1), 0.0);
+    std::vector<double> W((size_t)m * nr), Yr((size_t)(ca > 0 ? ca : 1) * m, 0.0);  // Yr: row r = L^-1 d_r of active row r (contiguous)
     for (int i = 0; i < m; ++i) {
       for (int a = 0; a < n; ++a) W[i * nr + a] = -Hh[(n + i) * nz + a];
       W[i * nr + n] = -gh[n + i];
       for (int j = 0; j < np; ++j) W[i * nr + n + 1 + j] = -ghM[(n + i) * np + j];
     }
     trsm_lower(Lr.data(), m, W.data(), nr);  // W = L^-1 T
-    std::vector<double> V((size_t)c * nr > 0 ? (size_t)c * nr : 1, 0.0);
-    if (c > 0) {
-      for (int i = 0; i < m; ++i) for (int j = 0; j < c; ++j) Y[i * c + j] = Ct[j * nz + n + i];
-      trsm_lower(Lr.data(), m, Y.data(), c);  // Y = L^-1 D^T
-      std::vector<double> Sc(c * c, 0.0);
-      for (int i = 0; i < c; ++i) for (int j = 0; j < c; ++j) { double s = (i == j) ? mu : 0.0; for (int l = 0; l < m; ++l) s += Y[l * c + i] * Y[l * c + j]; Sc[i * c + j] = s; }
-      if (!chol_lower(Sc.data(), c)) throw std::runtime_error("Riccati: constraint Schur complement not positive definite");
+    std::vector<double> Vc((size_t)(ca > 0 ? ca : 1) * nr, 0.0), Sc((size_t)(ca > 0 ? ca : 1) * ca, 0.0), tmp(nr > m ? nr : m);
+    if (ca > 0) {
+      for (int r = 0; r < ca; ++r) {  // Y = L^-1 D^T, one active row at a time (forward substitution, dot-product form)
+        double* y = Yr.data() + (size_t)r * m;
+        const double* d = Ct.data() + (size_t)act[r] * nz + n;
+        for (int i = 0; i < m; ++i) { double sacc = d[i]; const double* Li = Lr.data() + (size_t)i * m; for (int l = 0; l < i; ++l) sacc -= Li[l] * y[l]; y[i] = sacc / Li[i]; }
+      }
+      for (int r = 0; r < ca; ++r) for (int q = 0; q < ca; ++q) {
+        double sacc = (r == q) ? mu : 0.0;
+        const double *yr = Yr.data() + (size_t)r * m, *yq = Yr.data() + (size_t)q * m;
+        for (int l = 0; l < m; ++l) sacc += yr[l] * yq[l];
+        Sc[(size_t)r * ca + q] = sacc;
+      }
+      if (!chol_lower(Sc.data(), ca)) throw std::runtime_error("Riccati: constraint Schur complement not positive definite");
       // V = Sc^-1 (Y^T W - Bt),  Bt = -[C d 0]
-      for (int i = 0; i < c; ++i)
-        for (int a = 0; a < nr; ++a) {
-          double s = (a < n) ? Ct[i * nz + a] : (a == n ? dt_[i] : 0.0);
-          for (int l = 0; l < m; ++l) s += Y[l * c + i] * W[l * nr + a];
-          V[i * nr + a] = s;
-        }
-      trsm_lower(Sc.data(), c, V.data(), nr); trsm_lower_t(Sc.data(), c, V.data(), nr);
-      for (int l = 0; l < m; ++l) for (int a = 0; a < nr; ++a) { double s = 0; for (int i = 0; i < c; ++i) s += Y[l * c + i] * V[i * nr + a]; W[l * nr + a] -= s; }
+      for (int r = 0; r < ca; ++r) {
+        double* vr = Vc.data() + (size_t)r * nr;
+        const double* cr = Ct.data() + (size_t)act[r] * nz;
+        for (int a = 0; a < nr; ++a) vr[a] = (a < n) ? cr[a] : (a == n ? dt_[act[r]] : 0.0);
+        const double* yr = Yr.data() + (size_t)r * m;
+        for (int l = 0; l < m; ++l) { const double yl = yr[l]; const double* wl = W.data() + (size_t)l * nr; for (int a = 0; a < nr; ++a) vr[a] += yl * wl[a]; }
+      }
+      trsm_lower(Sc.data(), ca, Vc.data(), nr); trsm_lower_t(Sc.data(), ca, Vc.data(), nr);
+      for (int l = 0; l < m; ++l) {
+        for (int a = 0; a < nr; ++a) tmp[a] = 0.0;
+        for (int r = 0; r < ca; ++r) { const double yl = Yr[(size_t)r * m + l]; const double* vr = Vc.data() + (size_t)r * nr; for (int a = 0; a < nr; ++a) tmp[a] += yl * vr[a]; }
+        double* wl = W.data() + (size_t)l * nr;
+        for (int a = 0; a < nr; ++a) wl[a] -= tmp[a];
+      }
     }
     trsm_lower_t(Lr.data(), m, W.data(), nr);  // U = L^-T (W - Y V)
     g.Pt.clear(); g.Mu.clear(); g.Znu.clear();
     if (np) {  // inverse stage KKT matrix applied to [I; 0]: Mu = (Ruu + Da^T Da / mu)^-1, Znu = Sc^-1 Y^T L^-1
       g.Pt = Pt;
-      std::vector<double> W2((size_t)m * m, 0.0), V2((size_t)(c > 0 ? c : 1) * m, 0.0);
+      std::vector<double> W2((size_t)m * m, 0.0), V2((size_t)(ca > 0 ? ca : 1) * m, 0.0);
       for (int i = 0; i < m; ++i) W2[i * m + i] = 1.0;
       trsm_lower(Lr.data(), m, W2.data(), m);
-      if (c > 0) {
-        std::vector<double> Sc2(c * c, 0.0);
-        for (int i = 0; i < c; ++i) for (int j = 0; j < c; ++j) { double s2 = (i == j) ? mu : 0.0; for (int l = 0; l < m; ++l) s2 += Y[l * c + i] * Y[l * c + j]; Sc2[i * c + j] = s2; }
-        chol_lower(Sc2.data(), c);
-        for (int i = 0; i < c; ++i) for (int a = 0; a < m; ++a) { double s2 = 0; for (int l = 0; l < m; ++l) s2 += Y[l * c + i] * W2[l * m + a]; V2[i * m + a] = s2; }
-        trsm_lower(Sc2.data(), c, V2.data(), m); trsm_lower_t(Sc2.data(), c, V2.data(), m);
-        for (int l = 0; l < m; ++l) for (int a = 0; a < m; ++a) { double s2 = 0; for (int i = 0; i < c; ++i) s2 += Y[l * c + i] * V2[i * m + a]; W2[l * m + a] -= s2; }
+      if (ca > 0) {
+        for (int r = 0; r < ca; ++r) {
+          double* vr = V2.data() + (size_t)r * m;
+          const double* yr = Yr.data() + (size_t)r * m;
+          for (int l = 0; l < m; ++l) { const double yl = yr[l]; const double* wl = W2.data() + (size_t)l * m; for (int a = 0; a < m; ++a) vr[a] += yl * wl[a]; }
+        }
+        trsm_lower(Sc.data(), ca, V2.data(), m); trsm_lower_t(Sc.data(), ca, V2.data(), m);
+        for (int l = 0; l < m; ++l) {
+          for (int a = 0; a < m; ++a) tmp[a] = 0.0;
+          for (int r = 0; r < ca; ++r) { const double yl = Yr[(size_t)r * m + l]; const double* vr = V2.data() + (size_t)r * m; for (int a = 0; a < m; ++a) tmp[a] += yl * vr[a]; }
+          for (int a = 0; a < m; ++a) W2[(size_t)l * m + a] -= tmp[a];
+        }
       }
       trsm_lower_t(Lr.data(), m, W2.data(), m);
-      g.Mu = W2; g.Znu.assign(V2.begin(), V2.begin() + (size_t)c * m);
+      g.Mu = W2;
+      g.Znu.assign((size_t)c * m, 0.0);
+      for (int r = 0; r < ca; ++r) std::memcpy(g.Znu.data() + (size_t)act[r] * m, V2.data() + (size_t)r * m, m * sizeof(double));
     }
+    // scatter the active rows back to the row numbering of the stage (inactive rows: zero gains ; their multiplier step is Pi_N(z) / mu = 0)
+    std::vector<double> V((size_t)(c > 0 ? c : 1) * nr, 0.0);
+    for (int i = 0; i < c; ++i) V[(size_t)i * nr + n] = dt_[i] / mu;
+    for (int r = 0; r < ca; ++r) std::memcpy(V.data() + (size_t)act[r] * nr, Vc.data() + (size_t)r * nr, nr * sizeof(double));
     g.K.assign(m * n, 0.0); g.kff.assign(m, 0.0); g.Knu.assign(c * n, 0.0); g.knu.assign(c, 0.0);
     g.Kth.assign((size_t)m * np, 0.0); g.Knuth.assign((size_t)c * np, 0.0);
     for (int i = 0; i < m; ++i) { for (int a = 0; a < n; ++a) g.K[i * n + a] = W[i * nr + a]; g.kff[i] = W[i * nr + n]; for (int j = 0; j < np; ++j) g.Kth[i * np + j] = W[i * nr + n + 1 + j]; }
     for (int i = 0; i < c; ++i) { for (int a = 0; a < n; ++a) g.Knu[i * n + a] = V[i * nr + a]; g.knu[i] = V[i * nr + n]; for (int j = 0; j < np; ++j) g.Knuth[i * np + j] = V[i * nr + n + 1 + j]; }
+    ORC_PROF(4);
     // 5. value function  P = Qh + Sh K + C^T Knu ,  p = qh + Sh k + C^T knu
     g.P.assign(n * n, 0.0); g.p.assign(n, 0.0); g.Lm.assign((size_t)n * np, 0.0);
     for (int a = 0; a < n; ++a) {
       double s = gh[a];
       for (int i = 0; i < m; ++i) s += Hh[a * nz + n + i] * g.kff[i];
-      for (int i = 0; i < c; ++i) s += Ct[i * nz + a] * g.knu[i];
+      for (int r = 0; r < ca; ++r) s += Ct[act[r] * nz + a] * g.knu[act[r]];
       g.p[a] = s;
       for (int b = 0; b < n; ++b) {
         double t = Hh[a * nz + b];
         for (int i = 0; i < m; ++i) t += Hh[a * nz + n + i] * g.K[i * n + b];
-        for (int i = 0; i < c; ++i) t += Ct[i * nz + a] * g.Knu[i * n + b];
+        for (int r = 0; r < ca; ++r) t += Ct[act[r] * nz + a] * g.Knu[act[r] * n + b];
         g.P[a * n + b] = t;
       }
       for (int j = 0; j < np; ++j) {
         double t = ghM[a * np + j];
         for (int i = 0; i < m; ++i) t += Hh[a * nz + n + i] * g.Kth[i * np + j];
-        for (int i = 0; i < c; ++i) t += Ct[i * nz + a] * g.Knuth[i * np + j];
+        for (int r = 0; r < ca; ++r) t += Ct[act[r] * nz + a] * g.Knuth[act[r] * np + j];
         g.Lm[a * np + j] = t;
       }
     }
     for (int a = 0; a < n; ++a) for (int b = a + 1; b < n; ++b) { const double s = 0.5 * (g.P[a * n + b] + g.P[b * n + a]); g.P[a * n + b] = g.P[b * n + a] = s; }
+    ORC_PROF(5);
     // 6. closed-loop next-state map  x' = T Lam (A x + B u + ft - mud ph)  =  Mx x + mx + Mth theta
     std::vector<double> Acl((size_t)n * nr, 0.0);
     for (int i = 0; i < n; ++i) {
@@ -440,6 +487,7 @@ struct Solver {
     }
     g.Mx.assign(n * n, 0.0); g.mx.assign(n, 0.0); g.Mth.assign((size_t)n * np, 0.0);
     for (int i = 0; i < n; ++i) { for (int a = 0; a < n; ++a) g.Mx[i * n + a] = Acl[i * nr + a]; g.mx[i] = Acl[i * nr + n]; for (int j = 0; j < np; ++j) g.Mth[i * np + j] = Acl[i * nr + n + 1 + j]; }
+    ORC_PROF(6);
     // 7. condensed leg: dx_cut = Lm^T dx + Sg theta + sg
     g.Sg.clear(); g.sg.clear(); g.mx0.clear(); g.p0.clear(); g.kff0.clear();
     if (np) {
@@ -454,6 +502,7 @@ struct Solver {
         }
       for (int a = 0; a < np; ++a) for (int b = a + 1; b < np; ++b) { const double s = 0.5 * (g.Sg[a * np + b] + g.Sg[b * np + a]); g.Sg[a * np + b] = g.Sg[b * np + a] = s; }
     }
+    ORC_PROF(7);
   }
 
   void backward(Instance& in) const {
