@@ -418,6 +418,71 @@ sim_loop:
   }
   EV_PROF(7);
 
+  // ---- SE(3)-valued terms: residual and Jacobian block (log map, Jlog6: single-lane work), one term per lane 0 of the wavefronts
+  // w0 .. nw - 1.  Depends on the evaluation point only, so on stages with contact dynamics the wavefronts that idle during the
+  // one-wavefront factorisation chain (P8) do it there.
+  auto se3_prepass = [&](int w0) {
+    const int nws = nw - w0;
+    if (wv >= w0 && lane == 0) {
+      int slot_ = 0;
+      for (int t = 0; t < nterms; ++t) {
+        const TermRec tr = lds_term(lterm, t);
+        const bool se3_state = tr.type == MPC_TERM_STATE_ERROR && tr.i0 < 6;
+        if (!se3_state && tr.type != MPC_TERM_FRAME_PLACEMENT) continue;
+        const int my = slot_++;
+        if (my >= MB_SE3_SLOTS || (my % nws) != wv - w0) continue;
+        const double* tp = P + tr.poff;
+        double* sl = se3 + 48 * my;
+        V3 ev, ew;
+        if (se3_state) {
+          // r = x_ref (-) x on the base ; J = -Jlog6(Mref^-1 M)
+          const M3 Rr = quat_to_rot(tp + 3), Rb = quat_to_rot(q + 3);
+          const V3 pr = v3(tp[0], tp[1], tp[2]), pb = v3(q[0], q[1], q[2]);
+          log6(tmul(Rb, Rr), tmul(Rb, pr - pb), ev, ew);
+          if (derivs) { Jlog6(tmul(Rr, Rb), tmul(Rr, pb - pr), sl + 8); for (int e = 0; e < 36; ++e) sl[8 + e] = -sl[8 + e]; }
+        } else {
+          const int fi = tr.i0, i = mframe[fi];
+          const M3 Ri = ldcm3(oR, nj, i);
+          const M3 Rf = mul(Ri, ldm3(fd + 12 * fi));
+          const V3 pf = mul(Ri, ldv3(fd + 12 * fi + 9)) + ldcv3(op, nj, i);
+          const M3 Rr = ldm3(tp);
+          const V3 pr = ldv3(tp + 9);
+          log6(tmul(Rr, Rf), tmul(Rr, pf - pr), ev, ew);
+          if (derivs) Jlog6(tmul(Rr, Rf), tmul(Rr, pf - pr), sl + 8);
+        }
+        sl[0] = ev.x; sl[1] = ev.y; sl[2] = ev.z; sl[3] = ew.x; sl[4] = ew.y; sl[5] = ew.z;
+      }
+    }
+  };
+  // Selector constraints (joint limits fulldynamic_talos.py:208-209, torque box :206-207): rows of +-1 straight into the record, values
+  // from x / u alone.  Like the SE(3) pre-pass they do not depend on the solve, so on stages with contact dynamics the wavefronts
+  // w0 .. nw - 1 write them while wavefront 0 runs the factorisation chain (64 rows x nz doubles of stores off the critical path).
+  auto selector_rows = [&](int w0) {
+    if (wv < w0) return;
+    const int nws = nw - w0, t0_ = tid - 64 * w0, nt_ = 64 * nws;
+    int row = 0;
+    for (int t = 0; t < nterms; ++t) {
+      const TermRec tr = lds_term(lterm, t);
+      if (tr.role == MPC_ROLE_COST) continue;
+      const int d = tr.dim;
+      if ((tr.type == MPC_TERM_STATE_ERROR && tr.i0 >= 6) || tr.type == MPC_TERM_CONTROL_ERROR) {
+        const double* tp = P + tr.poff;
+        const bool st_ = tr.type == MPC_TERM_STATE_ERROR;
+        for (int i = t0_; i < d; i += nt_) {
+          const int ri = tr.i0 + i;
+          kn[KL.oCV + row + i] = st_ ? ((ri < nv) ? (tp[ri + 1] - q[ri + 1]) : (tp[nq + ri - nv] - v[ri - nv])) : (u[ri] - tp[ri]);
+          kn[KL.oCT + row + i] = (double)tr.role;
+          kn[KL.oLO + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + i] : 0.0;
+          kn[KL.oHI + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + d + i] : 0.0;
+        }
+        const int zc0 = st_ ? tr.i0 : n + tr.i0;
+        const double sgn = st_ ? -1.0 : 1.0;
+        if (derivs) for (int i = wv - w0; i < d; i += nws) for (int z = lane; z < nz; z += 64) kn[KL.oCD + (size_t)(row + i) * KL.nz + z] = (z == zc0 + i) ? sgn : 0.0;
+      }
+      row += d;
+    }
+  };
+
   if (has_dyn) {
     // ---- P7: joint-space inertia (lower block triangle, tile-packed), bias torques, contact frames ---------------
     const int ntile = nbm * (nbm + 1) / 2;
@@ -510,7 +575,7 @@ sim_loop:
         trsm_bwd_tiles(Mt, nbm, V16, 16, 1, 0, 1, lane);
         for (int i = lane; i < nvp; i += 64) { acc[i] = V16[i * 16]; Y16[i * 16 + 12] = 0.0; }  // from here on Y16 = Y (zero padded)
       }
-    }
+    } else { se3_prepass(1); selector_rows(1); }
     __syncthreads();
     if (iflag[0] == 0 || iflag[1] == 0) { if (tid == 0) a.inst[b].done = iflag[0] == 0 ? 5 : 6; return; }
     EV_PROF(5);
@@ -751,40 +816,7 @@ sim_loop:
   }
 
   EV_PROF(9);
-  // ---- SE(3)-valued terms: residual and Jacobian block, one term per wavefront lane 0 (waves 2.. ; 1.. when there are only two) ----
-  {
-    const int w0 = nw > 2 ? 2 : nw - 1, nws = nw - w0;
-    if (wv >= w0 && lane == 0) {
-      int slot_ = 0;
-      for (int t = 0; t < nterms; ++t) {
-        const TermRec tr = lds_term(lterm, t);
-        const bool se3_state = tr.type == MPC_TERM_STATE_ERROR && tr.i0 < 6;
-        if (!se3_state && tr.type != MPC_TERM_FRAME_PLACEMENT) continue;
-        const int my = slot_++;
-        if (my >= MB_SE3_SLOTS || (my % nws) != wv - w0) continue;
-        const double* tp = P + tr.poff;
-        double* sl = se3 + 48 * my;
-        V3 ev, ew;
-        if (se3_state) {
-          // r = x_ref (-) x on the base ; J = -Jlog6(Mref^-1 M)
-          const M3 Rr = quat_to_rot(tp + 3), Rb = quat_to_rot(q + 3);
-          const V3 pr = v3(tp[0], tp[1], tp[2]), pb = v3(q[0], q[1], q[2]);
-          log6(tmul(Rb, Rr), tmul(Rb, pr - pb), ev, ew);
-          if (derivs) { Jlog6(tmul(Rr, Rb), tmul(Rr, pb - pr), sl + 8); for (int e = 0; e < 36; ++e) sl[8 + e] = -sl[8 + e]; }
-        } else {
-          const int fi = tr.i0, i = mframe[fi];
-          const M3 Ri = ldcm3(oR, nj, i);
-          const M3 Rf = mul(Ri, ldm3(fd + 12 * fi));
-          const V3 pf = mul(Ri, ldv3(fd + 12 * fi + 9)) + ldcv3(op, nj, i);
-          const M3 Rr = ldm3(tp);
-          const V3 pr = ldv3(tp + 9);
-          log6(tmul(Rr, Rf), tmul(Rr, pf - pr), ev, ew);
-          if (derivs) Jlog6(tmul(Rr, Rf), tmul(Rr, pf - pr), sl + 8);
-        }
-        sl[0] = ev.x; sl[1] = ev.y; sl[2] = ev.z; sl[3] = ew.x; sl[4] = ew.y; sl[5] = ew.z;
-      }
-    }
-  }
+  if (!has_dyn) se3_prepass(nw > 2 ? 2 : nw - 1);  // (stages with contact dynamics: done beside the factorisation)
   // ---- P12: semi-implicit Euler, gap and its Jacobians ----------------------------------------------------
   if (has_dyn || kino) {
     const double dt = P[desc[4]];
@@ -1086,6 +1118,8 @@ sim_loop:
           hdg[z] += W[i];
         }
         __syncthreads();
+      } else if (has_dyn && ((tr.type == MPC_TERM_STATE_ERROR && tr.i0 >= 6) || tr.type == MPC_TERM_CONTROL_ERROR)) {
+        // (selector constraints of a stage with contact dynamics: written beside the factorisation, selector_rows)
       } else if ((tr.type == MPC_TERM_STATE_ERROR && tr.i0 >= 6) || tr.type == MPC_TERM_CONTROL_ERROR) {
         // selector constraints (joint limits fulldynamic_talos.py:208-209, torque box :206-207): straight into the record
         const bool st_ = tr.type == MPC_TERM_STATE_ERROR;
@@ -1098,6 +1132,25 @@ sim_loop:
         const int zc0 = st_ ? tr.i0 : n + tr.i0;
         const double sgn = st_ ? -1.0 : 1.0;
         if (derivs) for (int i = wv; i < d; i += nw) for (int z = lane; z < nz; z += 64) kn[KL.oCD + (size_t)(row + i) * KL.nz + z] = (z == zc0 + i) ? sgn : 0.0;
+      } else if (tr.type == MPC_TERM_MB_WRENCH_CONE) {
+        // rows of the cone matrix times lambda / d lambda, straight into the record (no staging, no barrier): a row per wavefront
+        for (int i = tid; i < d; i += nthr) {
+          double sres = 0;
+          for (int j = 0; j < 6; ++j) sres += tp[i * 6 + j] * lam[6 * tr.i0 + j];
+          kn[KL.oCV + row + i] = sres;
+          kn[KL.oCT + row + i] = (double)tr.role;
+          kn[KL.oLO + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + i] : 0.0;
+          kn[KL.oHI + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + d + i] : 0.0;
+        }
+        if (derivs) for (int i = wv; i < d; i += nw) {
+          double cw[6];
+          for (int j = 0; j < 6; ++j) cw[j] = tp[i * 6 + j];
+          for (int z = lane; z < nz; z += 64) {
+            double sres = 0;
+            for (int j = 0; j < 6; ++j) sres += cw[j] * DL[(6 * tr.i0 + j) * ldl + z];
+            kn[KL.oCD + (size_t)(row + i) * KL.nz + z] = sres;
+          }
+        }
       } else {
         term_rows(tr, tp, sl, r, JL, tid, nthr, true);
         emit_constraint(KL, kn, tr, P, row, r, JL, nz, nz, derivs, tid, nthr);

