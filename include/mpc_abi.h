@@ -233,6 +233,17 @@ int mpc_get_results(mpc_solver* s, double* xs, double* us, double* K, double* kf
  * xdot[B][ndx], wrenches[B][2][6] (inactive contacts zero). */
 int mpc_get_stage_data(mpc_solver* s, int32_t k, double* xdot, double* wrenches);
 
+/* Solver-state checkpoint (the reference itself only logs, talos_utils.py:113-154): everything a handle needs to
+ * continue a receding-horizon run — the stage tables of the horizon in knot order (ring unrolled), the iterate xs / us, the
+ * multipliers vs / lams, the measured state x0 and the feedback mode, and per instance the penalty and the BCL tolerances — as one
+ * array of doubles (integers stored exactly), portable between the libraries that export this ABI with the same dimensions
+ * (a state saved by the HIP library restores into the oracle and vice versa).  mpc_state_size: doubles needed.  mpc_get_state: fills
+ * buf (cap doubles), returns the count written or -1.  mpc_set_state: restores (dimensions must match mpc_create's); kept records
+ * of tick reuse and the cut-Hessian guesses of the legs are invalidated, so the next tick evaluates everything afresh. */
+int64_t mpc_state_size(mpc_solver* s);
+int64_t mpc_get_state(mpc_solver* s, double* buf, int64_t cap);
+int mpc_set_state(mpc_solver* s, const double* buf, int64_t len);
+
 /* Phase dumps for parity tests: copies the named per-knot quantity of instance b, knot k into out
  * (capacity cap doubles) and returns the number of doubles written (<0 on error).  Names:
  * "H" "grad" "AB" "f" "E6" "cval" "CD" "cost" "P" "p" "K" "kff" "Knu" "knu" "dx" "du" "dvs" "dlams" "xnext".

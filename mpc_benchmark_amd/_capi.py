@@ -91,6 +91,9 @@ _SIGNATURES = {
     "mpc_run_shifted_async": (C.c_int, [C.c_void_p]),
     "mpc_wait": (C.c_int, [C.c_void_p, C.POINTER(MpcStats)]),
     "mpc_wait_state": (C.c_int, [C.c_void_p, C.POINTER(MpcStats), _DP]),
+    "mpc_state_size": (C.c_int64, [C.c_void_p]),
+    "mpc_get_state": (C.c_int64, [C.c_void_p, _DP, C.c_int64]),
+    "mpc_set_state": (C.c_int, [C.c_void_p, _DP, C.c_int64]),
     "mpc_get_results": (C.c_int, [C.c_void_p, _DP, _DP, _DP, _DP, _DP, _DP]),
     "mpc_get_stage_data": (C.c_int, [C.c_void_p, C.c_int32, _DP, _DP]),
     "mpc_debug_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int32, C.c_int32, _DP, C.c_int32]),
@@ -267,6 +270,19 @@ class NativeSolver:
         xn = np.zeros((self.dims.batch, self.dims.nx))
         self._check(self.lib.mpc_wait_state(self._h, stats, _dp(xn)), "mpc_wait_state")
         return list(stats), xn
+
+    def get_state(self):
+        """Checkpoint of the handle (stage tables of the horizon, iterate, multipliers, measured state, penalties): a float64 array,
+        portable between libraries of the same dimensions (mpc_get_state)."""
+        n = int(self.lib.mpc_state_size(self._h))
+        buf = np.zeros(n)
+        if self.lib.mpc_get_state(self._h, _dp(buf), n) != n:
+            self._check(-1, "mpc_get_state")
+        return buf
+
+    def set_state(self, state):
+        state = _f64(state)
+        self._check(self.lib.mpc_set_state(self._h, _dp(state), state.size), "mpc_set_state")
 
     def get_results(self, gains=True, multipliers=False):
         d = self.dims

@@ -958,6 +958,86 @@ int mpc_get_x0(mpc_solver* s, double* x0) {
   })
 }
 
+// ---- solver-state checkpoint (layout shared with oracle/capi.cpp) ---------------------------------------------------------------
+#define MPC_STATE_MAGIC 20250304.0
+#define MPC_STATE_HEADER 16
+static int64_t state_doubles(const mpc_solver* s) {
+  const Layout& L = s->L;
+  const int64_t N1 = L.N + 1;
+  return MPC_STATE_HEADER + N1 * (2 + (int64_t)L.max_stage_ints + L.max_stage_doubles) +
+         (int64_t)L.B * (N1 * L.nx + (int64_t)L.N * L.m + N1 * L.c + N1 * L.n + L.nx + 4);
+}
+
+int64_t mpc_state_size(mpc_solver* s) { return s ? state_doubles(s) : -1; }
+
+int64_t mpc_get_state(mpc_solver* s, double* buf, int64_t cap) {
+  if (!s) return -2;
+  try {
+    HIP_OK(hipSetDevice(s->dims.device));
+    const Layout& L = s->L;
+    const int64_t need = state_doubles(s), N1 = L.N + 1;
+    if (!buf || cap < need) throw std::runtime_error("get_state: buffer too small (mpc_state_size doubles needed)");
+    HIP_OK(hipStreamSynchronize(s->stream));
+    if (s->async_pending > 0) throw std::runtime_error("get_state: asynchronous ticks in flight (mpc_wait first)");
+    double* o = buf;
+    const double hdr[MPC_STATE_HEADER] = {MPC_STATE_MAGIC, (double)L.B, (double)L.N, (double)L.nx, (double)L.n, (double)L.m, (double)L.c, (double)L.space,
+                                          s->perfect_feedback ? 1.0 : 0.0, (double)L.max_stage_ints, (double)L.max_stage_doubles, 0, 0, 0, 0, 0};
+    std::memcpy(o, hdr, sizeof(hdr)); o += MPC_STATE_HEADER;
+    for (int k = 0; k <= L.N; ++k) {  // knot order: the ring is unrolled
+      const int sl = slot_of(s, k);
+      *o++ = (double)s->h_len[2 * sl]; *o++ = (double)s->h_len[2 * sl + 1];
+      for (int i = 0; i < L.max_stage_ints; ++i) *o++ = i < s->h_len[2 * sl] ? (double)s->h_desc[(size_t)sl * L.max_stage_ints + i] : 0.0;
+      for (int i = 0; i < L.max_stage_doubles; ++i) *o++ = i < s->h_len[2 * sl + 1] ? s->h_params[(size_t)sl * L.max_stage_doubles + i] : 0.0;
+    }
+    copy_sync(s, o, s->d_xs, (size_t)L.B * N1 * L.nx * sizeof(double), hipMemcpyDeviceToHost); o += (size_t)L.B * N1 * L.nx;
+    copy_sync(s, o, s->d_us, (size_t)L.B * L.N * L.m * sizeof(double), hipMemcpyDeviceToHost); o += (size_t)L.B * L.N * L.m;
+    copy_sync(s, o, s->d_vs, (size_t)L.B * N1 * L.c * sizeof(double), hipMemcpyDeviceToHost); o += (size_t)L.B * N1 * L.c;
+    copy_sync(s, o, s->d_lams, (size_t)L.B * N1 * L.n * sizeof(double), hipMemcpyDeviceToHost); o += (size_t)L.B * N1 * L.n;
+    copy_sync(s, o, s->d_x0, (size_t)L.B * L.nx * sizeof(double), hipMemcpyDeviceToHost); o += (size_t)L.B * L.nx;
+    std::vector<InstState> st(L.B);
+    copy_sync(s, st.data(), s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost);
+    for (int b = 0; b < L.B; ++b) { *o++ = st[b].mu; *o++ = st[b].inner_tol; *o++ = st[b].prim_tol; *o++ = 0.0; }
+    return need;
+  } catch (const std::exception& e) { s->err = e.what(); return -1; }
+}
+
+int mpc_set_state(mpc_solver* s, const double* buf, int64_t len) {
+  MPC_TRY(s, {
+    const Layout& L = s->L;
+    const int64_t need = state_doubles(s), N1 = L.N + 1;
+    if (!buf || len < need) throw std::runtime_error("set_state: truncated state");
+    const double* o = buf;
+    if (o[0] != MPC_STATE_MAGIC || (int)o[1] != L.B || (int)o[2] != L.N || (int)o[3] != L.nx || (int)o[4] != L.n || (int)o[5] != L.m || (int)o[6] != L.c ||
+        (int)o[7] != L.space || (int)o[9] != L.max_stage_ints || (int)o[10] != L.max_stage_doubles)
+      throw std::runtime_error("set_state: the state was saved by a handle of other dimensions");
+    HIP_OK(hipStreamSynchronize(s->stream));
+    if (s->async_pending > 0) throw std::runtime_error("set_state: asynchronous ticks in flight (mpc_wait first)");
+    s->perfect_feedback = o[8] != 0.0;
+    o += MPC_STATE_HEADER;
+    spec_clear(s);
+    s->leg_guess_valid = false; s->reuse_this_pass = false; s->spec_skip_pass = false;
+    s->head = 0; s->khead = 0;
+    std::vector<int32_t> desc(L.max_stage_ints);
+    for (int k = 0; k <= L.N; ++k) {
+      const int nd = (int)o[0], np = (int)o[1];
+      o += 2;
+      if (nd < 0 || nd > L.max_stage_ints || np < 0 || np > L.max_stage_doubles) throw std::runtime_error("set_state: corrupt stage table");
+      for (int i = 0; i < L.max_stage_ints; ++i) desc[i] = (int32_t)o[i];
+      if (nd > 0) { s->h_len[2 * k] = -1; upload_stage(s, k, desc.data(), nd, o + L.max_stage_ints, np); }  // (h_len = -1: never equal to the mirror)
+      o += L.max_stage_ints + L.max_stage_doubles;
+    }
+    HIP_OK(hipMemcpyAsync(s->d_xs, o, (size_t)L.B * N1 * L.nx * sizeof(double), hipMemcpyHostToDevice, s->stream)); o += (size_t)L.B * N1 * L.nx;
+    HIP_OK(hipMemcpyAsync(s->d_us, o, (size_t)L.B * L.N * L.m * sizeof(double), hipMemcpyHostToDevice, s->stream)); o += (size_t)L.B * L.N * L.m;
+    HIP_OK(hipMemcpyAsync(s->d_vs, o, (size_t)L.B * N1 * L.c * sizeof(double), hipMemcpyHostToDevice, s->stream)); o += (size_t)L.B * N1 * L.c;
+    HIP_OK(hipMemcpyAsync(s->d_lams, o, (size_t)L.B * N1 * L.n * sizeof(double), hipMemcpyHostToDevice, s->stream)); o += (size_t)L.B * N1 * L.n;
+    HIP_OK(hipMemcpyAsync(s->d_x0, o, (size_t)L.B * L.nx * sizeof(double), hipMemcpyHostToDevice, s->stream)); o += (size_t)L.B * L.nx;
+    std::vector<InstState> st(L.B);
+    copy_sync(s, st.data(), s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost);
+    for (int b = 0; b < L.B; ++b) { st[b].mu = o[0]; st[b].inner_tol = o[1]; st[b].prim_tol = o[2]; o += 4; }
+    copy_sync(s, s->d_inst, st.data(), L.B * sizeof(InstState), hipMemcpyHostToDevice);
+  })
+}
+
 int mpc_setup(mpc_solver* s) {
   MPC_TRY(s, {
     const Layout& L = s->L;

@@ -103,26 +103,19 @@ class EnsembleMPC:
         return stats
 
     def save_episode(self):
-        """Remember the current iterate (normally the cold-solved start) as the beginning of an episode."""
-        r = self.results(gains=False)
-        self._episode = (r["xs"].copy(), r["us"].copy(), self.tick)
+        """Remember the current solver state (normally the cold-solved start) as the beginning of an episode: a checkpoint through
+        the C-ABI (mpc_get_state: stage tables of the horizon, iterate, multipliers, measured state)."""
+        self._episode = (self.native.get_state(), self.tick)
 
     def restart_episode(self):
-        """Back to the saved start: stage tables of the first tick, initial states, one iteration from the saved iterate.
-        The synthetic scenario (frozen foot references, perfect-model feedback, randomised states) is not meant to be replayed
-        far past the first single-support phase; long runs walk it in episodes instead."""
-        xs, us, tick0 = self._episode
-        for k, (desc, params) in enumerate(self.tables):
-            self.native.set_stage(k, desc, params)
+        """Back to the saved start (mpc_set_state).  The synthetic scenario (perfect-model feedback, randomised states) is not meant
+        to be replayed far past the first single-support phase; long runs walk it in episodes instead."""
+        state, tick0 = self._episode
+        self.native.set_state(state)
         self.tick = tick0
-        self.native.set_x0(self.x0)
-        self.native.setup()
-        stats = self.native.run(xs, us)  # max_iters = 1: one warm iteration, as a tick
-        self.native.set_x0(None)
         self.episodes = getattr(self, "episodes", 0) + 1
         if self._walk is not None:
             self.enable_walk(**self._walk_args)  # countdown lists and foot trajectory back to the start of the schedule
-        return stats
 
     def step(self, rescue=False):
         """One MPC tick for every instance of the ensemble (one ProxDDP iteration each).  ``rescue``: an instance whose

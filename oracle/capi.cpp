@@ -173,6 +173,84 @@ int mpc_wait_state(mpc_solver* h, mpc_stats* stats, double* x_next) {
   })
 }
 
+// ---- solver-state checkpoint (layout shared with mpc_benchmark_amd/csrc/mpc_hip.hip) --------------------------------------------------
+#define MPC_STATE_MAGIC 20250304.0
+#define MPC_STATE_HEADER 16
+static int64_t state_doubles(const Solver& s) {
+  const mpc_dims& d = s.dims;
+  const int64_t N1 = d.horizon + 1;
+  return MPC_STATE_HEADER + N1 * (2 + (int64_t)d.max_stage_ints + d.max_stage_doubles) +
+         (int64_t)d.batch * (N1 * d.nx + (int64_t)d.horizon * d.nu + N1 * d.nc_max + N1 * d.ndx + d.nx + 4);
+}
+int64_t mpc_state_size(mpc_solver* h) { return h ? state_doubles(h->s) : -1; }
+
+int64_t mpc_get_state(mpc_solver* h, double* buf, int64_t cap) {
+  if (!h) return -2;
+  try {
+    Solver& s = h->s;
+    const mpc_dims& d = s.dims;
+    const int N = s.N();
+    const int64_t need = state_doubles(s);
+    if (!buf || cap < need) throw std::runtime_error("get_state: buffer too small (mpc_state_size doubles needed)");
+    std::fill(buf, buf + need, 0.0);
+    double* o = buf;
+    const double hdr[MPC_STATE_HEADER] = {MPC_STATE_MAGIC, (double)d.batch, (double)N, (double)d.nx, (double)d.ndx, (double)d.nu, (double)d.nc_max, (double)d.space,
+                                          h->perfect_feedback ? 1.0 : 0.0, (double)d.max_stage_ints, (double)d.max_stage_doubles, 0, 0, 0, 0, 0};
+    std::memcpy(o, hdr, sizeof(hdr)); o += MPC_STATE_HEADER;
+    for (int k = 0; k <= N; ++k) {
+      const StageDesc& sd = s.stages[k];
+      const int nd = MPC_STAGE_HEADER_WORDS + MPC_TERM_WORDS * (int)sd.terms.size();
+      if (nd > d.max_stage_ints || (int)sd.params.size() > d.max_stage_doubles) throw std::runtime_error("get_state: stage table exceeds the capacity of mpc_create");
+      o[0] = nd; o[1] = (double)sd.params.size();
+      double* di = o + 2;
+      di[0] = sd.dyn; di[1] = sd.ncontact; di[2] = sd.cid[0]; di[3] = sd.cid[1]; di[4] = sd.dyn_poff; di[5] = (double)sd.terms.size(); di[6] = sd.nc; di[7] = 0;
+      for (size_t t = 0; t < sd.terms.size(); ++t) {
+        const Term& tr = sd.terms[t];
+        const double w[8] = {(double)tr.type, (double)tr.role, (double)tr.dim, (double)tr.i0, (double)tr.i1, (double)tr.poff, (double)tr.woff, (double)tr.flags};
+        std::memcpy(di + MPC_STAGE_HEADER_WORDS + MPC_TERM_WORDS * t, w, sizeof(w));
+      }
+      std::memcpy(o + 2 + d.max_stage_ints, sd.params.data(), sd.params.size() * sizeof(double));
+      o += 2 + d.max_stage_ints + d.max_stage_doubles;
+    }
+    const int B = d.batch;
+    for (int b = 0; b < B; ++b) for (int k = 0; k <= N; ++k) { std::memcpy(o, s.inst[b].xs[k].data(), d.nx * sizeof(double)); o += d.nx; }
+    for (int b = 0; b < B; ++b) for (int k = 0; k < N; ++k) { std::memcpy(o, s.inst[b].us[k].data(), d.nu * sizeof(double)); o += d.nu; }
+    for (int b = 0; b < B; ++b) for (int k = 0; k <= N; ++k) { std::memcpy(o, s.inst[b].vs[k].data(), std::min<size_t>(d.nc_max, s.inst[b].vs[k].size()) * sizeof(double)); o += d.nc_max; }
+    for (int b = 0; b < B; ++b) for (int k = 0; k <= N; ++k) { std::memcpy(o, s.inst[b].lams[k].data(), d.ndx * sizeof(double)); o += d.ndx; }
+    for (int b = 0; b < B; ++b) { std::memcpy(o, s.inst[b].x0.data(), d.nx * sizeof(double)); o += d.nx; }
+    for (int b = 0; b < B; ++b) { *o++ = s.inst[b].mu; *o++ = s.inst[b].inner_tol; *o++ = s.inst[b].prim_tol; *o++ = 0.0; }
+    return need;
+  } catch (const std::exception& e) { h->err = e.what(); return -1; }
+}
+
+int mpc_set_state(mpc_solver* h, const double* buf, int64_t len) {
+  MPC_TRY(h, {
+    Solver& s = h->s;
+    const mpc_dims& d = s.dims;
+    const int N = s.N(), B = d.batch;
+    if (!buf || len < state_doubles(s)) throw std::runtime_error("set_state: truncated state");
+    const double* o = buf;
+    if (o[0] != MPC_STATE_MAGIC || (int)o[1] != B || (int)o[2] != N || (int)o[3] != d.nx || (int)o[4] != d.ndx || (int)o[5] != d.nu || (int)o[6] != d.nc_max ||
+        (int)o[7] != d.space || (int)o[9] != d.max_stage_ints || (int)o[10] != d.max_stage_doubles)
+      throw std::runtime_error("set_state: the state was saved by a handle of other dimensions");
+    h->perfect_feedback = o[8] != 0.0;
+    o += MPC_STATE_HEADER;
+    std::vector<int32_t> desc(d.max_stage_ints);
+    for (int k = 0; k <= N; ++k) {
+      const int nd = (int)o[0], np = (int)o[1];
+      for (int i = 0; i < d.max_stage_ints; ++i) desc[i] = (int32_t)o[2 + i];
+      if (nd > 0) s.stages[k].parse(desc.data(), nd, o + 2 + d.max_stage_ints, np);
+      o += 2 + d.max_stage_ints + d.max_stage_doubles;
+    }
+    for (int b = 0; b < B; ++b) for (int k = 0; k <= N; ++k) { s.inst[b].xs[k].assign(o, o + d.nx); o += d.nx; }
+    for (int b = 0; b < B; ++b) for (int k = 0; k < N; ++k) { s.inst[b].us[k].assign(o, o + d.nu); o += d.nu; }
+    for (int b = 0; b < B; ++b) for (int k = 0; k <= N; ++k) { std::copy(o, o + std::min<size_t>(d.nc_max, s.inst[b].vs[k].size()), s.inst[b].vs[k].begin()); o += d.nc_max; }
+    for (int b = 0; b < B; ++b) for (int k = 0; k <= N; ++k) { s.inst[b].lams[k].assign(o, o + d.ndx); o += d.ndx; }
+    for (int b = 0; b < B; ++b) { s.inst[b].x0.assign(o, o + d.nx); o += d.nx; }
+    for (int b = 0; b < B; ++b) { s.inst[b].mu = o[0]; s.inst[b].inner_tol = o[1]; s.inst[b].prim_tol = o[2]; o += 4; s.inst[b].tree_guess_valid = false; }
+  })
+}
+
 int mpc_get_results(mpc_solver* h, double* xs, double* us, double* K, double* kff, double* vs, double* lams) {
   MPC_TRY(h, {
     Solver& s = h->s;

@@ -1,0 +1,84 @@
+"""Solver-state checkpoint through the C-ABI (mpc_state_size / mpc_get_state / mpc_set_state): a run continued
+from a restored state reproduces the uninterrupted run — also when the state is restored into a FRESH handle: bit for bit with the
+serial Riccati sweep; with the parallel-in-time sweep to round-off (1e-9), because the value-function guesses the legs keep at
+their cuts from pass to pass are an accelerator, not part of the state (the first pass after a restore refreshes them with its extra
+sweeps).  A state saved by the HIP library restores into the oracle (same layout): the next ticks agree at 1e-6."""
+import numpy as np
+import pytest
+
+from mpc_benchmark_amd.ensemble import EnsembleMPC
+from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+
+
+def _ens(lib, horizon, batch, legs=1, **kw):
+    e = EnsembleMPC(FullDynamicsProblem(horizon=horizon), batch=batch, library=lib, seed=9, sigma_q=0.003, sigma_v=0.006, **kw)
+    e.options.riccati_legs = legs
+    e.native.set_options(e.options)
+    e.prepare_schedule(40)
+    return e
+
+
+def _same(a, b, exact):
+    return np.array_equal(a, b) if exact else float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) < 1e-9
+
+
+def _roundtrip(lib, horizon, batch, legs=1, **kw):
+    kw = dict(kw, legs=legs)
+    a = _ens(lib, horizon, batch, **kw)
+    a.options.tol = 0.0
+    a.cold_solve(max_iters=6)
+    for _ in range(3):
+        a.step()
+    state, tick = a.native.get_state(), a.tick
+    for _ in range(4):
+        a.step()
+    ref = a.results(gains=True)
+    # the same handle, rolled back
+    a.native.set_state(state); a.tick = tick
+    for _ in range(4):
+        a.step()
+    again = a.results(gains=True)
+    # a fresh handle that never solved anything
+    b = _ens(lib, horizon, batch, **kw)
+    b.options.max_iters = 1
+    b.options.tol = 0.0
+    b.native.set_options(b.options)
+    b.native.set_state(state); b.tick = tick
+    for _ in range(4):
+        b.step()
+    fresh = b.results(gains=True)
+    for key in ("xs", "us", "K"):
+        assert _same(again[key], ref[key], legs == 1), key
+        assert _same(fresh[key], ref[key], legs == 1), key
+    return state, tick, ref
+
+
+@pytest.mark.parametrize("legs", [1, 3])
+def test_checkpoint_roundtrip_oracle(oracle_lib, legs):
+    _roundtrip(oracle_lib, 6, 2, legs=legs)
+
+
+def test_state_rejects_other_dimensions(oracle_lib):
+    a, b = _ens(oracle_lib, 6, 2), _ens(oracle_lib, 5, 2)
+    with pytest.raises(RuntimeError, match="other dimensions|truncated"):
+        b.native.set_state(a.native.get_state())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reuse,legs", [(False, 1), (True, 1), (True, 4)])
+def test_checkpoint_roundtrip_hip(hip_lib, reuse, legs):
+    _roundtrip(hip_lib, 12, 3, legs=legs, tick_reuse=reuse)
+
+
+@pytest.mark.gpu
+def test_hip_state_restores_into_the_oracle(hip_lib, oracle_lib):
+    state, tick, ref = _roundtrip(hip_lib, 8, 2)
+    o = _ens(oracle_lib, 8, 2)
+    o.options.max_iters = 1
+    o.native.set_options(o.options)
+    o.native.set_state(state); o.tick = tick
+    for _ in range(4):
+        o.step()
+    r = o.results(gains=True)
+    for key in ("xs", "us"):
+        assert float(np.max(np.abs(r[key] - ref[key])) / max(1.0, np.max(np.abs(ref[key])))) < 1e-6, key
