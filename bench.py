@@ -21,7 +21,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (MI355X_MICROARCH.md); the fp64 matrix cores double it
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured-achievable copy rate
+
+
+def stage_kernel_flops(nj, nv, nu, nl, cost_rows, cone_rows):
+    """fp64 flops of ONE whole-body knot evaluation with derivatives (counting rule: a multiply-add = 2 flops; the closed forms of
+    DESIGN.md section 4 on the unpadded dimensions; transcendental functions and index arithmetic not counted)."""
+    nz, sub = 2 * nv + nu, 5.0 * nj  # sub: sum of the subtree sizes of the kinematic tree (Talos: ~5 bodies per subtree on average)
+    fl = nj * (2 * 27 + 2 * 9 + 120 + 72)                    # placements (chain products), world inertias, momenta
+    fl += (21 + 6 + 6 + 6 + 36) * sub                        # composite inertias / momenta / forces, subtree sums of the B_i
+    fl += nv * (12 + 72) + nv * (nv + 1) / 2 * 12            # joint columns, U = Yc J, mass matrix entries (6-D dot products)
+    fl += nv ** 3 / 3.0 + 2 * nv * nv * (nl + 1) + 2 * nl * nl * nv + nl ** 3 / 3.0 + 2 * nv * nv   # M = L L^T, Y, S, multipliers, accelerations
+    fl += nj * 6 * 150 + nv * (5 * 72 + 4 * 18)              # body-level B_i, Bt / Tv / Tq / Bc Psd / Yc Psd, Psd / Psdd / Phi
+    fl += 2 * nv * nv * 24 + nl * nv * 2 * 120               # right-hand sides R1 (two 6-D dots per entry and block), R2
+    fl += 2 * nv * nv * nz + 2 * (2 * nl * nv * nz) + 2 * 2 * nl * nl * nz   # implicit differentiation: two triangular solves, Y^T W, W - Y Z2, S solves
+    fl += 4 * nv * nz + 12 * 6 * nz                          # integrator rows, base rows
+    fl += cost_rows * nz * 2 + cost_rows * nz * (nz + 1) + 2 * cost_rows * nz + cone_rows * nz * 12   # stacked rows, J^T J (upper triangle), gradient, cone rows
+    return fl
 
 
 def _p50(v):
@@ -99,6 +116,7 @@ def main():
                     help="legs of the batch-1 latency measurement (a single instance leaves the chip idle: more, shorter legs pay; with more "
                          "than 8 the cuts are resolved by a tree of pairwise compositions, csrc/legs_tree.h)")
     ap.add_argument("--lib", default=None, help="developer option: another build of the same HIP library (kernel tuning variants)")
+    ap.add_argument("--regions", type=int, default=0, help="how many times the region of --steps ticks is timed (0 = automatic: about one second in total, at most 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", type=int, default=0, help="(internal) run this many MPC ticks of one instance on the CPU port with 8 threads and print their times")
     ap.add_argument("--no-latency", action="store_true")
@@ -277,16 +295,46 @@ def main():
                 torch.cuda.synchronize()
                 dist.barrier()
 
+        # The driver asks for K steps; K x 7 ms is a short sample, so the region of EXACTLY K steps (barrier + synchronize on both
+        # sides) is timed `regions` times (about a second in total) from the same starting point — a checkpoint (mpc_get_state) taken
+        # one tick before it, restored between regions, one untimed tick to refill the records of tick reuse — and value /
+        # ms_per_step come from all of them (steps per region and the number of regions are both in the JSON line).
+        est = sum(v[1] for v in warm.values()) / max(1, args.warmup) * 1e-3 / max(1, nshard)
+        regions = int(min(8, max(1, np.ceil(1.0 / max(args.steps * max(est, 1e-4), 1e-3))))) if args.regions <= 0 else args.regions
+        if dist is not None:
+            import torch
+            tr_ = torch.tensor([regions], dtype=torch.int64, device="cuda")
+            dist.all_reduce(tr_, op=dist.ReduceOp.MAX)
+            regions = int(tr_.item())
+        if regions > 1:
+            for e in shards:
+                e.save_episode()
+            run_ticks(1)
         for e in shards:
             e.native.profile(2)
             e.native.profile(16 * (1 << dom_slot))
-        sync_all()
-        nostep["on"] = True
-        t0 = time.perf_counter()
-        run_ticks(args.steps)
-        sync_all()
-        elapsed = time.perf_counter() - t0
-        nostep["on"] = False
+        elapsed, replanning = 0.0, 0.0
+        for reg in range(regions):
+            if reg > 0:
+                for e in shards:
+                    e.native.profile(0)
+                    e.restart_episode()
+                    e.episodes -= 1  # (a repetition of the measurement, not an episode of the scenario)
+                run_ticks(1)
+                for e in shards:
+                    e.native.profile(16 * (1 << dom_slot))
+            sync_all()
+            nostep["on"] = True
+            rp0 = sum(getattr(e, "replanning_ticks", 0) for e in shards)
+            t0 = time.perf_counter()
+            run_ticks(args.steps)
+            sync_all()
+            elapsed += time.perf_counter() - t0
+            replanning += sum(getattr(e, "replanning_ticks", 0) for e in shards) - rp0
+            nostep["on"] = False
+        elapsed /= regions
+        nostep["n"] = nostep["n"] / regions
+        replanning = replanning / regions
         for e in shards:
             e.native.profile(0)
         if dist is not None:
@@ -310,8 +358,8 @@ def main():
             for kname, (cnt, ms) in e.native.profile_read().items():
                 c0, m0 = prof.get(kname, (0, 0.0))
                 prof[kname] = (c0 + cnt, m0 + ms)
-        return dict(shards=shards, ens=ens, legs=legs, cold=cold, n_conv=n_conv, worst_unconv=worst_unconv, nostep=nostep["n"], pace=pace, stagger=stagger, elapsed=elapsed,
-                    prof=prof, warm=warm, gather=gather, replanning_ticks=sum(getattr(e, "replanning_ticks", 0) for e in shards))
+        return dict(shards=shards, ens=ens, legs=legs, cold=cold, n_conv=n_conv, worst_unconv=worst_unconv, regions=regions, nostep=nostep["n"], pace=pace, stagger=stagger, elapsed=elapsed,
+                    prof=prof, warm=warm, gather=gather, replanning_ticks=replanning)
 
     modes = [True] if args.walk else ([False] if args.no_walk else [False, True])
     runs = {}
@@ -389,6 +437,25 @@ def main():
             roof_ric = {"bound": "hbm", "kernel": "k_riccati_backward", "achieved": round(byt / avg_r / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(byt / avg_r / 1e9 / HBM_PEAK_GBS, 5), "avg_kernel_ms": round(ms_r / cnt_r, 4),
                         "algorithmic_bytes_per_launch": int(byt), "legs": legs, "note": "warm-up launches (every kernel bracketed by events)"}
+    # FLOP-side roofline of the stage kernel (the launch with derivatives): counted fp64 flops per knot x knots per launch over the
+    # measured launch time, against the fp64 VECTOR peak — the kernel is neither HBM- nor FLOP-bound: a chain of dependent phases
+    valu = None
+    st_ms = None
+    for kn_ in ("k_eval_stage_trial", "k_eval_stage"):
+        if kn_ in prof and prof[kn_][0] > 0 and not (kn_ == "k_eval_stage_trial" and args.no_tick_reuse):
+            st_ms = prof[kn_][1] / prof[kn_][0]
+            break
+        if kn_ in warm and warm[kn_][0] > 0 and not (kn_ == "k_eval_stage_trial" and args.no_tick_reuse):
+            st_ms = warm[kn_][1] / warm[kn_][0]
+            break
+    if st_ms:
+        rb = pd.robot.model
+        fk = stage_kernel_flops(rb.njoints - 1, rb.nv, pd.nu, 12, 30, 34)
+        knots_ = (d.horizon + 2) * (args.batch // nshard)
+        ach = fk * knots_ / (st_ms * 1e-3) / 1e12
+        valu = {"bound": "valu_f64", "kernel": "k_eval_multibody<3>", "achieved": round(ach, 3), "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / FP64_VALU_PEAK_TFLOPS, 5), "flops_per_knot": int(fk), "knots_per_launch": knots_, "avg_kernel_ms": round(st_ms, 4),
+                "rule": "multiply-add = 2 flops, closed forms of DESIGN.md section 4 on the unpadded dimensions of a double-support knot"}
     mfma = None
     if roof is not None and roof["kernel"] == "k_riccati_backward":
         cks = [int(t[0][6]) for t in ens.tables]
@@ -451,7 +518,7 @@ def main():
     solves = (args.batch * args.steps - nostep["n"]) * world
     out = {
         "metric": "mpc_solves_per_sec", "value": round(solves / elapsed, 2), "unit": "solves/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "timed_regions": mres["regions"], "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "Talos full-dynamics MPC (fulldynamic_talos.py OCP), synthetic Talos %s model nq=%d nv=%d nu=%d, "
                                "horizon N=%d, ensemble of %d instances per GPU, one ProxDDP iteration per solve (max_iters=1, warm start)"
@@ -473,7 +540,7 @@ def main():
         "roofline": roof, "cpu_baseline": cpu, "roofline_riccati": roof_ric,
         # supplementary: the same kernel against the fp64 matrix-core peak (the sweep is a chain of dependent dense steps on ONE CU
         # per instance, not a streaming kernel — DESIGN.md §5); flops = textbook count of the recursion on the unpadded dimensions
-        "roofline_mfma": mfma,
+        "roofline_mfma": mfma, "roofline_valu_f64": valu,
     }
     print(json.dumps(out))
     if dist is not None:

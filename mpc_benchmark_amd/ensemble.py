@@ -104,18 +104,26 @@ class EnsembleMPC:
 
     def save_episode(self):
         """Remember the current solver state (normally the cold-solved start) as the beginning of an episode: a checkpoint through
-        the C-ABI (mpc_get_state: stage tables of the horizon, iterate, multipliers, measured state)."""
-        self._episode = (self.native.get_state(), self.tick)
+        the C-ABI (mpc_get_state: stage tables of the horizon, iterate, multipliers, measured state) plus, in walk mode, the state of
+        the reference generator (countdown lists, planned footholds, last measurement)."""
+        import copy
+        walk = None
+        if self._walk is not None:
+            walk = copy.deepcopy({k: self._walk[k] for k in ("lists", "traj", "x_measured", "last", "replanning") if k in self._walk})
+        self._episode = (self.native.get_state(), self.tick, walk, getattr(self, "replanning_ticks", 0))
 
     def restart_episode(self):
         """Back to the saved start (mpc_set_state).  The synthetic scenario (perfect-model feedback, randomised states) is not meant
         to be replayed far past the first single-support phase; long runs walk it in episodes instead."""
-        state, tick0 = self._episode
+        import copy
+        state, tick0, walk, _ = self._episode
         self.native.set_state(state)
         self.tick = tick0
         self.episodes = getattr(self, "episodes", 0) + 1
-        if self._walk is not None:
-            self.enable_walk(**self._walk_args)  # countdown lists and foot trajectory back to the start of the schedule
+        if self._walk is not None and walk is not None:
+            self._walk.update(copy.deepcopy(walk))
+        elif self._walk is not None:
+            self.enable_walk(**self._walk_args)  # saved before the walk was enabled: back to the start of the schedule
 
     def step(self, rescue=False):
         """One MPC tick for every instance of the ensemble (one ProxDDP iteration each).  ``rescue``: an instance whose
@@ -230,7 +238,7 @@ class EnsembleMPC:
             batch.append((j, w["off_lf"], flat(LF_refs[j])))
             batch.append((j, w["off_rf"], flat(RF_refs[j])))
         self.native.update_stage_params_batch(batch)
-        w["last"] = (LF_refs[-1], RF_refs[-1], flat)
+        w["last"] = (LF_refs[-1], RF_refs[-1])
         # ticks on which the generator plans from the measured poses (a foot without a pending landing, a take-off inside the double-
         # support window): their references change for every knot, so no record of the previous tick can be reused
         w["replanning"] = (land_LF < 0 or land_RF < 0 or 0 <= takeoff_RF < w["traj"].T_ds or 0 <= takeoff_LF < w["traj"].T_ds)
@@ -238,7 +246,8 @@ class EnsembleMPC:
 
     def _walk_terminal(self):
         w, N = self._walk, self.problem.num_steps
-        LF_last, RF_last, flat = w["last"]
+        LF_last, RF_last = w["last"]
+        flat = lambda M: np.concatenate([np.asarray(M.rotation, dtype=float).reshape(-1), np.asarray(M.translation, dtype=float)])
         com_final = self.pd.robot.com0.copy()
         com_final[:2] = 0.5 * (LF_last.translation[:2] + RF_last.translation[:2])
         self.native.update_stage_params_batch([(N, w["toff_com"], com_final), (N, w["toff_lf"], flat(LF_last)), (N, w["toff_rf"], flat(RF_last))])
