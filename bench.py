@@ -505,8 +505,8 @@ def main():
         wall = time.perf_counter() - t0c
         # every worker reports the wall-clock window of its timed ticks: the host rate is the ticks inside the common window
         lo, hi = max(o["t_start"] for o in outs), min(o["t_end"] for o in outs)
-        rate = sum(sum(1 for te in o["tick_ends"] if lo < te <= hi) for o in outs) / max(hi - lo, 1e-9)
-        cpu = {"value": round(rate, 2), "unit": "solves/s", "cores": cores, "threads_per_instance": 8, "concurrent_instances": nproc, "kind": "port",
+        cpu_rate = sum(sum(1 for te in o["tick_ends"] if lo < te <= hi) for o in outs) / max(hi - lo, 1e-9)
+        cpu = {"value": round(cpu_rate, 2), "unit": "solves/s", "cores": cores, "threads_per_instance": 8, "concurrent_instances": nproc, "kind": "port",
                "p50_ms_per_solve_one_instance_8_threads": round(_p50(one["tick_ms"]), 2),
                "sample": "CPU port (closed-form derivatives, -O3 -march=native; not Aligator, not the AD oracle): %d processes x 8 OpenMP threads, each %d "
                          "warm-started MPC ticks (1 ProxDDP iteration, Riccati sweep in 8 legs) of the same N=%d %s-model OCP, %.1f s wall; the "

@@ -75,7 +75,8 @@ static_assert(EVAL_THREADS >= 128 && EVAL_THREADS <= 512 && EVAL_THREADS % 64 ==
 // ---- implicit differentiation of the contact dynamics for ONE 16-column block, entirely in registers -----------------
 //   W = L^-1 R1 ; T = Y^T W - R2 ; Z2 = S^-1 T ; Z1 = L^-T (W - Y Z2) ;  d a = -Z1 ,  d lambda = Z2
 // w[bi] = the 16 x 16 tiles of R1 (fragment layout of an MFMA result), t = R2 (rows >= 12 zero).  Mt: tile-packed L with the inverses
-// of the diagonal blocks in place, Y16 = L^-1 Jc^T (nvp x 16, zero padded), LIs = inverse Cholesky factor of S = Y^T Y + mu I.
+// of the diagonal blocks in place, Y16 = L^-1 Jc^T (nvp x 16, zero padded, leading dimension MB_LDY = 17: the row-strided reads of
+// W -= Y Z2 were 8-way bank conflicts at 16), LIs = inverse Cholesky factor of S = Y^T Y + mu I.
 DEV void implicit_diff_block(d4_t (&w)[4], d4_t& t, const double* Mt, const double* Y16, const double* LIs, int nbm, int lane) {
 #pragma unroll
   for (int bi = 0; bi < 4; ++bi) if (bi < nbm) {
@@ -87,13 +88,13 @@ DEV void implicit_diff_block(d4_t (&w)[4], d4_t& t, const double* Mt, const doub
   }
   t = -t;
 #pragma unroll
-  for (int bi = 0; bi < 4; ++bi) if (bi < nbm) mma_tile_rb<false>(t, Y16 + (bi * 16) * 16, 1, 16, w[bi], lane);
+  for (int bi = 0; bi < 4; ++bi) if (bi < nbm) mma_tile_rb<false>(t, Y16 + (bi * 16) * MB_LDY, 1, MB_LDY, w[bi], lane);
   d4_t u = d4_t{0, 0, 0, 0};
   mma_tile_rb<false>(u, LIs, 17, 1, t, lane);
   t = d4_t{0, 0, 0, 0};
   mma_tile_rb<false>(t, LIs, 1, 17, u, lane);
 #pragma unroll
-  for (int bi = 0; bi < 4; ++bi) if (bi < nbm) mma_tile_rb<true>(w[bi], Y16 + (bi * 16) * 16, 16, 1, t, lane);
+  for (int bi = 0; bi < 4; ++bi) if (bi < nbm) mma_tile_rb<true>(w[bi], Y16 + (bi * 16) * MB_LDY, MB_LDY, 1, t, lane);
 #pragma unroll
   for (int bi = 3; bi >= 0; --bi) if (bi < nbm) {
     d4_t acc = w[bi];
@@ -530,7 +531,7 @@ sim_loop:
           if (BELOW(l, mcontact[desc[2 + cc]])) s = adinv(ldm3(cfr + 54 * cc), ldv3(cfr + 54 * cc + 9), ldc6(J, nv, l)).v[j - 6 * cc];
         } else if (j == 12) s = -bias[l] + (l >= nv - nu ? u[l - (nv - nu)] : 0.0);
       }
-      Y16[idx] = s;
+      Y16[l * MB_LDY + j] = s;
     }
     if (tid == 0) { iflag[0] = 1; iflag[1] = 1; }
     __syncthreads();
@@ -540,9 +541,9 @@ sim_loop:
     if (wv == 0) {
       if (!chol_tiles_wave(Mt, nbm, lane)) { if (lane == 0) iflag[0] = 0; }
       else {
-        trsm_fwd_tiles(Mt, nbm, Y16, 16, 1, 0, 1, lane);
+        trsm_fwd_tiles(Mt, nbm, Y16, MB_LDY, 1, 0, 1, lane);
         d4_t g = d4_t{0, 0, 0, 0};
-        mma_tile<false>(g, Y16, 1, 16, Y16, 16, 1, nvp, lane);  // [Y w]^T [Y w]
+        mma_tile<false>(g, Y16, 1, MB_LDY, Y16, MB_LDY, 1, nvp, lane);  // [Y w]^T [Y w]
         const int col = lane & 15;
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
@@ -569,11 +570,11 @@ sim_loop:
         for (int idx = lane; idx < nvp * 16; idx += 64) {
           const int l = idx >> 4, j = idx & 15;
           double s = 0.0;
-          if (j == 0) { s = Y16[l * 16 + 12]; for (int i = 0; i < nl; ++i) s -= Y16[l * 16 + i] * small[32 + i]; }
+          if (j == 0) { s = Y16[l * MB_LDY + 12]; for (int i = 0; i < nl; ++i) s -= Y16[l * MB_LDY + i] * small[32 + i]; }
           V16[idx] = s;
         }
         trsm_bwd_tiles(Mt, nbm, V16, 16, 1, 0, 1, lane);
-        for (int i = lane; i < nvp; i += 64) { acc[i] = V16[i * 16]; Y16[i * 16 + 12] = 0.0; }  // from here on Y16 = Y (zero padded)
+        for (int i = lane; i < nvp; i += 64) { acc[i] = V16[i * 16]; Y16[i * MB_LDY + 12] = 0.0; }  // from here on Y16 = Y (zero padded)
       }
     } else { se3_prepass(1); selector_rows(1); }
     __syncthreads();

@@ -8,6 +8,7 @@
 #define EVAL_THREADS 256  // threads per stage workgroup: 4 wavefronts, two workgroups per CU (measured against 512 = 8 wavefronts with a 128-VGPR cap, profiles/r03_*)
 #endif
 #define MB_SE3_SLOTS 6
+#define MB_LDY 17  // leading dimension of Y16 = L^-1 [Jc^T | r1] (16 columns)
 #define MB_STAGE_CONSTRAINT_ROWS 20  // LDS staging rows for the Jacobian of one constraint term (wrench cone: 17)
 
 // ---- LDS carve-out ------------------------------------------------------------------------------------------
@@ -68,7 +69,7 @@ static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz) {
   const int e1 = o;
   o = b3;
   const int ntile = s.nbm * (s.nbm + 1) / 2;
-  s.Mt = take(ntile * 272); s.Y16 = take(s.nvp * 16); s.Sp = take(272); s.LIs = take(272);
+  s.Mt = take(ntile * 272); s.Y16 = take(s.nvp * MB_LDY); s.Sp = take(272); s.LIs = take(272);
   if (o < e1) o = e1;
   // terms: stacked cost rows (<= 32) / the rows of the constraint being emitted, ld nz, from Yc on (Yc and the stage-2 blocks are dead)
   s.JS = s.Yc;
