@@ -228,6 +228,10 @@ int mpc_poll(mpc_solver* s, int32_t* in_flight, int32_t* completed);
 /* results.xs / results.us / controlFeedbacks() (fulldynamic_talos.py:403-405, :522, :548-550) / feed-forwards / multipliers. Any pointer may be NULL.
  * xs[B][N+1][nx] us[B][N][nu] K[B][N][nu][ndx] kff[B][N][nu] vs[B][N+1][nc_max] lams[B][N+1][ndx] */
 int mpc_get_results(mpc_solver* s, double* xs, double* us, double* K, double* kff, double* vs, double* lams);
+/* The gains of ONE knot: K_k[B][nu][ndx], kff_k[B][nu] (either may be NULL).  The scripts read controlFeedbacks()[0] only
+ * (fulldynamic_talos.py:522, :550): fetching that one block instead of all N (1.9 MB per instance on the complete model) is what
+ * the Python mirror does after every run. */
+int mpc_get_gain(mpc_solver* s, int32_t k, double* K_k, double* kff_k);
 /* workspace.problem_data.stage_data[k].dynamics_data.continuous_data.{xdot, constraint_datas[i].contact_force}
  * (fulldynamic_talos.py:465-480, kinodynamic_talos.py:432)
  * xdot[B][ndx], wrenches[B][2][6] (inactive contacts zero). */

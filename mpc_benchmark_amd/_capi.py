@@ -91,6 +91,7 @@ _SIGNATURES = {
     "mpc_run_shifted_async": (C.c_int, [C.c_void_p]),
     "mpc_wait": (C.c_int, [C.c_void_p, C.POINTER(MpcStats)]),
     "mpc_wait_state": (C.c_int, [C.c_void_p, C.POINTER(MpcStats), _DP]),
+    "mpc_get_gain": (C.c_int, [C.c_void_p, C.c_int32, _DP, _DP]),
     "mpc_state_size": (C.c_int64, [C.c_void_p]),
     "mpc_get_state": (C.c_int64, [C.c_void_p, _DP, C.c_int64]),
     "mpc_set_state": (C.c_int, [C.c_void_p, _DP, C.c_int64]),
@@ -270,6 +271,13 @@ class NativeSolver:
         xn = np.zeros((self.dims.batch, self.dims.nx))
         self._check(self.lib.mpc_wait_state(self._h, stats, _dp(xn)), "mpc_wait_state")
         return list(stats), xn
+
+    def get_gain(self, k=0):
+        """-> (K_k[B][nu][ndx], kff_k[B][nu]) of one knot (mpc_get_gain)."""
+        d = self.dims
+        K, kff = np.zeros((d.batch, d.nu, d.ndx)), np.zeros((d.batch, d.nu))
+        self._check(self.lib.mpc_get_gain(self._h, int(k), _dp(K), _dp(kff)), "mpc_get_gain")
+        return K, kff
 
     def get_state(self):
         """Checkpoint of the handle (stage tables of the horizon, iterate, multipliers, measured state, penalties): a float64 array,

@@ -71,8 +71,10 @@ class _Owned:
             flat = np.asarray(flat, dtype=float).reshape(-1)
             if (node._lowered is not None and not node._dirty and flat.size == size and self._owner_node() is node
                     and off + size <= node._lowered[1].size):
-                node._lowered[1][off:off + size] = flat
-                node._patches.append((off, size))
+                tab = node._lowered[1]
+                if not np.array_equal(tab[off:off + size], flat):  # an unchanged reference (most of the 2 N per tick) costs a compare
+                    tab[off:off + size] = flat
+                    node._patches.append((off, size))
                 return
         self._touch()
 

@@ -29,6 +29,34 @@ class _ArrayList(list):
         return list(self)
 
 
+class _LazyGains:
+    """``results.controlFeedbacks()`` / ``controlFeedforwards()``: element 0 — the only one the scripts read (fulldynamic_talos.py:522,
+    :550) — is fetched with the results; the gains of the other knots (1.9 MB per instance on the complete model) are downloaded when
+    something else is touched.  They are those of the solver's LAST run, like every other field of ``results``."""
+
+    def __init__(self, first, fetch_all):
+        self._first, self._fetch, self._all = first, fetch_all, None
+
+    def _full(self):
+        if self._all is None:
+            self._all = self._fetch()
+        return self._all
+
+    def __getitem__(self, i):
+        if isinstance(i, int) and i == 0:
+            return self._first
+        return self._full()[i]
+
+    def __len__(self):
+        return len(self._full())
+
+    def __iter__(self):
+        return iter(self._full())
+
+    def tolist(self):
+        return list(self._full())
+
+
 class Results:
     def __init__(self):
         self.xs = _ArrayList()
@@ -278,12 +306,14 @@ class SolverProxDDP:
         return bool(self.results.conv)
 
     def _fetch(self, stats):
-        out = self._native.get_results(gains=True, multipliers=False)
+        out = self._native.get_results(gains=False, multipliers=False)
+        K0, k0 = self._native.get_gain(0)
         r = self.results
-        r.xs = _ArrayList(out["xs"][0].copy())
-        r.us = _ArrayList(out["us"][0].copy())
-        r._K = list(out["K"][0].copy())
-        r._kff = list(out["kff"][0].copy())
+        r.xs = _ArrayList(out["xs"][0])
+        r.us = _ArrayList(out["us"][0])
+        nat = self._native
+        r._K = _LazyGains(K0[0], lambda: list(nat.get_results(gains=True)["K"][0]))
+        r._kff = _LazyGains(k0[0], lambda: list(nat.get_results(gains=True)["kff"][0]))
         s = stats[0]
         r.num_iters, r.conv, r.al_iter = s.num_iters, bool(s.converged), s.al_iters
         r.traj_cost, r.merit_value, r.prim_infeas, r.dual_infeas = s.traj_cost, s.merit, s.prim_infeas, s.dual_infeas

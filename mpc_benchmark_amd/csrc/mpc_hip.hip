@@ -1176,6 +1176,18 @@ int mpc_get_results(mpc_solver* s, double* xs, double* us, double* K, double* kf
   })
 }
 
+int mpc_get_gain(mpc_solver* s, int32_t k, double* K_k, double* kff_k) {
+  MPC_TRY(s, {
+    const Layout& L = s->L;
+    if (k < 0 || k >= L.N) throw std::runtime_error("get_gain: knot index out of range");
+    const size_t pitch = (size_t)(L.N + 1) * L.gain_stride * sizeof(double);
+    const double* g = s->d_gains + (size_t)k * L.gain_stride;
+    if (K_k) HIP_OK(hipMemcpy2DAsync(K_k, (size_t)L.m * L.n * sizeof(double), g + L.oK, pitch, (size_t)L.m * L.n * sizeof(double), L.B, hipMemcpyDeviceToHost, s->stream));
+    if (kff_k) HIP_OK(hipMemcpy2DAsync(kff_k, (size_t)L.m * sizeof(double), g + L.ok, pitch, (size_t)L.m * sizeof(double), L.B, hipMemcpyDeviceToHost, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+  })
+}
+
 int mpc_get_stage_data(mpc_solver* s, int32_t k, double* xdot, double* wrenches) {
   MPC_TRY(s, {
     const Layout& L = s->L;

@@ -165,6 +165,19 @@ int mpc_wait(mpc_solver* h, mpc_stats* stats) {
   MPC_TRY(h, { if (stats) for (int b = 0; b < h->s.dims.batch; ++b) stats[b] = h->s.inst[b].stats; })
 }
 
+int mpc_get_gain(mpc_solver* h, int32_t k, double* K_k, double* kff_k) {
+  MPC_TRY(h, {
+    Solver& s = h->s;
+    const int nu = s.dims.nu, n = s.dims.ndx;
+    if (k < 0 || k >= s.N()) throw std::runtime_error("get_gain: knot index out of range");
+    for (int b = 0; b < s.dims.batch; ++b) {
+      const Gains& g = s.inst[b].gains[k];
+      if (K_k) { std::fill(K_k + (size_t)b * nu * n, K_k + (size_t)(b + 1) * nu * n, 0.0); std::memcpy(K_k + (size_t)b * nu * n, g.K.data(), std::min(g.K.size(), (size_t)nu * n) * sizeof(double)); }
+      if (kff_k) { std::fill(kff_k + (size_t)b * nu, kff_k + (size_t)(b + 1) * nu, 0.0); std::memcpy(kff_k + (size_t)b * nu, g.kff.data(), std::min(g.kff.size(), (size_t)nu) * sizeof(double)); }
+    }
+  })
+}
+
 int mpc_wait_state(mpc_solver* h, mpc_stats* stats, double* x_next) {
   MPC_TRY(h, {
     Solver& s = h->s;

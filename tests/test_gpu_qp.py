@@ -73,3 +73,41 @@ def test_id_solver_mirror_hip_equals_oracle():
     for h, r in zip(out["hip"], out["ref"]):
         for xh, xr in zip(h, r):
             assert np.max(np.abs(xh - xr)) / max(1.0, np.max(np.abs(xr))) < 1e-6
+
+
+def test_ikid_solver_mirror_hip_equals_oracle():
+    """The IKIDSolver_f6 mirror (QP_utils.py:584-762: inverse kinematics + inverse dynamics in one QP with the torque box, used at
+    centroidal_talos.py:326, 435) on the synthetic Talos in double and single support: HIP and oracle give the same accelerations,
+    forces and torques, and the solution satisfies dynamics, contact, cone and box conditions."""
+    from mpc_benchmark_amd import qp_utils
+    from mpc_benchmark_amd.robot import dynamics as dyn, minipin as pin
+    from mpc_benchmark_amd.robot.talos_synth import load_talos
+    _, model, _, q0 = load_talos()
+    rng = np.random.default_rng(5)
+    nv = model.nv
+    ids = [model.getFrameId("left_sole_link"), model.getFrameId("right_sole_link")]
+    Kp, Kd = 100.0, 20.0
+    gains = [(np.eye(nv) * Kp, np.eye(nv) * Kd), (np.eye(6) * Kp, np.eye(6) * Kd), None, (np.eye(3) * Kp, np.eye(3) * Kd)]
+    w = 9.81 * pin.computeTotalMass(model)
+    z3, z6, zn = np.zeros(3), np.zeros(6), np.zeros(nv)
+    for cs, forces in (([True, True], np.array([0, 0, 0.5 * w, 0, 0, 0, 0, 0, 0.5 * w, 0, 0, 0], dtype=float)),
+                       ([True, False], np.array([0, 0, w, 0, 0, 0, 0, 0, 0, 0, 0, 0], dtype=float))):
+        v = rng.normal(size=nv) * 0.05
+        q = pin.integrate(model, q0, np.concatenate((np.zeros(6), rng.normal(size=nv - 6) * 0.02)))
+        data = dyn.compute_all_terms(model, model.createData(), q, v)
+        q_diff = np.concatenate((np.zeros(6), rng.normal(size=nv - 6) * 0.01))
+        out = {}
+        for name, lib in (("hip", _capi.load_hip_library()), ("ref", _oracle.load())):
+            solver = qp_utils.IKIDSolver_f6(model, [1.0, 100.0, 1.0, 10.0, 1e-3], gains, 2, 0.8, 0.1, 0.075, ids, model.getFrameId("base_link"),
+                                            model.getFrameId("torso_2_link"), 6, False, library=lib)
+            solver.qp.settings.eps_abs = 1e-6
+            out[name] = solver.solve(data, cs, v, q_diff, zn, z6, z6, z6, z6, z3, z3, z3, z3, forces, np.zeros(6), data.M)
+            assert solver.last_info[0].status == 0
+        for xh, xr in zip(out["hip"], out["ref"]):
+            assert np.max(np.abs(xh - xr)) / max(1.0, np.max(np.abs(xr))) < 1e-6
+        a, f, tau = out["hip"]
+        Jc = np.vstack([dyn.frame_jacobian_local(model, data, i) for i, on in zip(ids, cs) if on])
+        fa = np.concatenate([f[6 * i:6 * i + 6] for i, on in enumerate(cs) if on])
+        S = np.zeros((nv, nv - 6)); S[6:] = np.eye(nv - 6)
+        assert np.max(np.abs(data.M @ a + data.nle - S @ tau - Jc.T @ fa)) < 1e-5
+        assert np.all(np.abs(tau) <= np.asarray(model.effortLimit)[6:] + 1e-5)
