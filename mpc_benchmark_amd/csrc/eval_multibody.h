@@ -910,6 +910,9 @@ sim_loop:
   // no clear, no read-modify-write of the nz x nz block in HBM.  Constraints and the diagonal state / control costs
   // run through the whole workgroup term by term.
   const S6 h0 = ldc6(Hc, nj, 0);
+  // leading dimension of the Jacobian rows staged in LDS: >= nz and = 16 (mod 32) doubles, so that the four k-rows a wavefront reads
+  // per MFMA step of J^T J fall on disjoint banks (ld = nz = 108 gave 2-way conflicts on every operand read of the Hessian flush)
+  const int ldj = mb_ldj(nz);
   double* gacc = Bt;     // nz: gradient accumulator        (the derivative vectors Bt, Tv, Phi are dead by now)
   double* hdg = Tv;      // nz: additions to diag(H)
   double* hbb = Phi;     // 36: additions to the base 6x6 block of H
@@ -954,18 +957,18 @@ sim_loop:
   // whole workgroup (wg, barriers) or one wavefront (LDS operations of a wavefront execute in order: no barrier)
   auto term_rows = [&](const TermRec& tr, const double* tp, const double* sl, double* r, double* Jt, int t0, int nt, bool wg) {
     const int d = tr.dim;
-    if (derivs) for (int idx = t0; idx < d * nz; idx += nt) Jt[idx] = 0.0;
+    if (derivs) for (int idx = t0; idx < d * ldj; idx += nt) Jt[idx] = 0.0;
     if (wg) __syncthreads();
     if (tr.type == MPC_TERM_STATE_ERROR) {
       const double* Jb = sl + 8;  // -Jlog6 block of the base rows
       for (int i = t0; i < d; i += nt) r[i] = state_res(tp, sl, tr.i0 + i);
       if (derivs) for (int i = t0; i < d; i += nt) {
         const int ri = tr.i0 + i;
-        if (ri < 6) { for (int z = 0; z < 6; ++z) Jt[i * nz + z] = Jb[6 * ri + z]; }
-        else Jt[i * nz + ri] = -1.0;
+        if (ri < 6) { for (int z = 0; z < 6; ++z) Jt[i * ldj + z] = Jb[6 * ri + z]; }
+        else Jt[i * ldj + ri] = -1.0;
       }
     } else if (tr.type == MPC_TERM_CONTROL_ERROR) {
-      for (int i = t0; i < d; i += nt) { r[i] = u[tr.i0 + i] - tp[tr.i0 + i]; if (derivs) Jt[i * nz + n + tr.i0 + i] = 1.0; }
+      for (int i = t0; i < d; i += nt) { r[i] = u[tr.i0 + i] - tp[tr.i0 + i]; if (derivs) Jt[i * ldj + n + tr.i0 + i] = 1.0; }
     } else if (tr.type == MPC_TERM_FRAME_PLACEMENT || tr.type == MPC_TERM_FRAME_TRANSLATION || tr.type == MPC_TERM_FRAME_VELOCITY) {
       const int fi = tr.i0, i = mframe[fi];
       const M3 Ri = ldcm3(oR, nj, i);
@@ -976,7 +979,7 @@ sim_loop:
         if (t0 < 6) r[t0] = sl[t0];
         if (derivs) for (int j = t0; j < nv; j += nt) if (BELOW(j, i)) {
           const S6 col = mat6_mul(Jl, adinv(Rf, pf, ldc6(J, nv, j)));
-          for (int rr = 0; rr < 6; ++rr) Jt[rr * nz + j] = col.v[rr];
+          for (int rr = 0; rr < 6; ++rr) Jt[rr * ldj + j] = col.v[rr];
         }
       } else if (tr.type == MPC_TERM_FRAME_TRANSLATION) {
         if (t0 < d) { const double pfa[3] = {pf.x, pf.y, pf.z}; r[t0] = pfa[tr.i1 + t0] - tp[tr.i1 + t0]; }
@@ -984,18 +987,18 @@ sim_loop:
           const S6 Jj = ldc6(J, nv, j);
           const V3 lv = lin(Jj) + cross(ang(Jj), pf);
           const double la[3] = {lv.x, lv.y, lv.z};
-          for (int rr = 0; rr < d; ++rr) Jt[rr * nz + j] = la[tr.i1 + rr];
+          for (int rr = 0; rr < d; ++rr) Jt[rr * ldj + j] = la[tr.i1 + rr];
         }
       } else {
         if (t0 == 0) { const S6 vf = adinv(Rf, pf, ldc6(ov, nj, i)); for (int rr = 0; rr < 6; ++rr) r[rr] = vf.v[rr] - tp[rr]; }
         if (derivs) for (int j = t0; j < nv; j += nt) if (BELOW(j, i)) {
           const S6 cq = adinv(Rf, pf, ldc6(Psd, nv, j)), cv = adinv(Rf, pf, ldc6(J, nv, j));
-          for (int rr = 0; rr < 6; ++rr) { Jt[rr * nz + j] = cq.v[rr]; Jt[rr * nz + nv + j] = cv.v[rr]; }
+          for (int rr = 0; rr < 6; ++rr) { Jt[rr * ldj + j] = cq.v[rr]; Jt[rr * ldj + nv + j] = cv.v[rr]; }
         }
       }
     } else if (tr.type == MPC_TERM_COM_TRANSLATION) {
       if (t0 < d) { const double ca[3] = {com.x, com.y, com.z}; r[t0] = ca[tr.i1 + t0] - tp[tr.i1 + t0]; }
-      if (derivs) for (int j = t0; j < nv; j += nt) for (int rr = 0; rr < d; ++rr) Jt[rr * nz + j] = U[(tr.i1 + rr) * nv + j] / mtot;
+      if (derivs) for (int j = t0; j < nv; j += nt) for (int rr = 0; rr < d; ++rr) Jt[rr * ldj + j] = U[(tr.i1 + rr) * nv + j] / mtot;
     } else if (tr.type == MPC_TERM_CENTROIDAL_MOMENTUM) {
       if (t0 == 0) {
         const V3 hl = lin(h0), ha = ang(h0) - cross(com, lin(h0));
@@ -1009,14 +1012,14 @@ sim_loop:
         const V3 dql = lin(D), dqa = ang(D) - cross(dc, lin(h0)) - cross(com, lin(D));
         const V3 dvl = lin(Uj), dva = ang(Uj) - cross(com, lin(Uj));
         const double cq[6] = {dql.x, dql.y, dql.z, dqa.x, dqa.y, dqa.z}, cv[6] = {dvl.x, dvl.y, dvl.z, dva.x, dva.y, dva.z};
-        for (int rr = 0; rr < 6; ++rr) { Jt[rr * nz + j] = cq[rr]; Jt[rr * nz + nv + j] = cv[rr]; }
+        for (int rr = 0; rr < 6; ++rr) { Jt[rr * ldj + j] = cq[rr]; Jt[rr * ldj + nv + j] = cv[rr]; }
       }
     } else if (tr.type == MPC_TERM_CONTACT_FORCE) {
       if (t0 < 6) r[t0] = lam[6 * tr.i0 + t0] - tp[t0];
-      if (derivs) for (int idx = t0; idx < 6 * nz; idx += nt) Jt[idx] = DL[(6 * tr.i0 + qdiv(idx, mg_nz)) * ldl + (idx - qdiv(idx, mg_nz) * nz)];
+      if (derivs) for (int idx = t0; idx < 6 * nz; idx += nt) { const int i = qdiv(idx, mg_nz), z = idx - i * nz; Jt[i * ldj + z] = DL[(6 * tr.i0 + i) * ldl + z]; }
     } else if (tr.type == MPC_TERM_CENTROIDAL_WRENCH_CONE) {
       for (int i = t0; i < d; i += nt) { double sacc = 0; for (int j = 0; j < 6; ++j) sacc += tp[i * 6 + j] * u[6 * tr.i0 + j]; r[i] = sacc; }
-      if (derivs) for (int idx = t0; idx < d * 6; idx += nt) Jt[(idx / 6) * nz + n + 6 * tr.i0 + idx % 6] = tp[idx];
+      if (derivs) for (int idx = t0; idx < d * 6; idx += nt) Jt[(idx / 6) * ldj + n + 6 * tr.i0 + idx % 6] = tp[idx];
     } else if (tr.type == MPC_TERM_CENTROIDAL_MOMENTUM_DER) {
       // r = [sum f + m g ; sum (p_i - c) x f_i + tau_i]   (kinodynamic_talos.py:125-127); params: g[3], states, frames
       const int nkk = tr.i0;
@@ -1045,16 +1048,16 @@ sim_loop:
             if (BELOW(j, i)) dp_ = lin(Jj) + cross(ang(Jj), pf);
             dang = dang + cross(dp_ - dc, v3(u[6 * cc], u[6 * cc + 1], u[6 * cc + 2]));
           }
-          Jt[3 * nz + j] = dang.x; Jt[4 * nz + j] = dang.y; Jt[5 * nz + j] = dang.z;
+          Jt[3 * ldj + j] = dang.x; Jt[4 * ldj + j] = dang.y; Jt[5 * ldj + j] = dang.z;
         }
         if (t0 < nkk && tp[3 + t0] != 0.0) {
           const int cc = t0, fi = (int)tp[3 + nkk + cc], i = mframe[fi];
           const V3 rr = mul(ldcm3(oR, nj, i), ldv3(fd + 12 * fi + 9)) + ldcv3(op, nj, i) - com;
           const M3 Rx = skew_m(rr);
           for (int e = 0; e < 3; ++e) {
-            Jt[e * nz + n + 6 * cc + e] = 1.0;
-            Jt[(3 + e) * nz + n + 6 * cc + 3 + e] = 1.0;
-            for (int e2 = 0; e2 < 3; ++e2) Jt[(3 + e) * nz + n + 6 * cc + e2] = Rx.m[3 * e + e2];
+            Jt[e * ldj + n + 6 * cc + e] = 1.0;
+            Jt[(3 + e) * ldj + n + 6 * cc + 3 + e] = 1.0;
+            for (int e2 = 0; e2 < 3; ++e2) Jt[(3 + e) * ldj + n + 6 * cc + e2] = Rx.m[3 * e + e2];
           }
         }
       }
@@ -1064,7 +1067,7 @@ sim_loop:
         const int i = qdiv(idx, mg_nz), z = (idx - qdiv(idx, mg_nz) * nz);
         double s = 0;
         for (int j = 0; j < 6; ++j) s += tp[i * 6 + j] * DL[(6 * tr.i0 + j) * ldl + z];
-        Jt[idx] = s;
+        Jt[i * ldj + z] = s;
       }
     }
     if (wg) __syncthreads();
@@ -1154,7 +1157,7 @@ sim_loop:
         }
       } else {
         term_rows(tr, tp, sl, r, JL, tid, nthr, true);
-        emit_constraint(KL, kn, tr, P, row, r, JL, nz, nz, derivs, tid, nthr);
+        emit_constraint(KL, kn, tr, P, row, r, JL, ldj, nz, derivs, tid, nthr);
       }
       if (!is_cost) row += d;
       EV_PROF(13 + tr.type);
@@ -1173,7 +1176,7 @@ sim_loop:
       if (trow[t] + d > rowc) rowc = trow[t] + d;
       if ((ord++ % nw) != wv) continue;
       double* r = red + 112 + 24 * wv;  // private residual scratch of this wavefront
-      double* Jt = JS + trow[t] * nz;
+      double* Jt = JS + trow[t] * ldj;
       term_rows(tr, P + tr.poff, se3 + 48 * tse3[t], r, Jt, lane, 64, false);
       const double* W = P + tr.woff;
       const int wstride = (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) ? 1 : d + 1;
@@ -1184,18 +1187,18 @@ sim_loop:
       }
       if (derivs) {
         if (lane < d) wrs[trow[t] + lane] = sqrt(W[lane * wstride]) * r[lane];
-        for (int idx = lane; idx < d * nz; idx += 64) Jt[idx] *= sqrt(W[(qdiv(idx, mg_nz)) * wstride]);
+        for (int idx = lane; idx < d * nz; idx += 64) { const int i = qdiv(idx, mg_nz), z = idx - i * nz; Jt[i * ldj + z] *= sqrt(W[i * wstride]); }
       }
     }
     EV_PROF(28);
     if (derivs) {
       const int kc = (rowc + 3) & ~3;  // MFMA K granularity: zero rows up to a multiple of 4
       __syncthreads();
-      for (int idx = tid; idx < (kc - rowc) * nz; idx += nthr) JS[rowc * nz + idx] = 0.0;
+      for (int idx = tid; idx < (kc - rowc) * ldj; idx += nthr) JS[rowc * ldj + idx] = 0.0;
       __syncthreads();
       for (int z = tid; z < nz; z += nthr) {
         double g = 0;
-        for (int i = 0; i < rowc; ++i) g += JS[i * nz + z] * wrs[i];
+        for (int i = 0; i < rowc; ++i) g += JS[i * ldj + z] * wrs[i];
         gacc[z] += g;
       }
       // upper block triangle of 16x16 tiles, mirrored on the way out; the first chunk writes, later ones accumulate
@@ -1205,7 +1208,7 @@ sim_loop:
         while (rem >= nzt - ta) { rem -= nzt - ta; ++ta; }
         const int tb = ta + rem;
         d4_t h = d4_t{0, 0, 0, 0};
-        mma_tile<false>(h, JS + ta * 16, 1, nz, JS + tb * 16, nz, 1, kc, lane);
+        mma_tile<false>(h, JS + ta * 16, 1, ldj, JS + tb * 16, ldj, 1, kc, lane);
         const int zb = tb * 16 + (lane & 15);
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
@@ -1237,7 +1240,7 @@ sim_loop:
       if (tkind[t] != 2) continue;
       const TermRec tr = lds_term(lterm, t);
       term_rows(tr, P + tr.poff, se3 + 48 * tse3[t], r, JS, tid, nthr, true);
-      if (derivs) for (int idx = tid; idx < tr.dim * nz; idx += nthr) JtG[idx] = JS[idx];
+      if (derivs) for (int idx = tid; idx < tr.dim * nz; idx += nthr) { const int i = qdiv(idx, mg_nz), z = idx - i * nz; JtG[idx] = JS[i * ldj + z]; }
       __syncthreads();
       double cst = 0.0;
       accumulate_cost(KL, kn, tr, P + tr.woff, r, JtG, nz, nz, red + 112, WJ, derivs, cst, tid, nthr);

@@ -26,6 +26,9 @@
 //  * the derivative blocks that depend on (q, v) only (B_i, their subtree sums, Bt, Tv, Bc Psd, Yc Psd) are formed BEFORE the
 //    factorisation, so the body-level 6 x 6 blocks are dead when M is built and the two share one region; the forces at the
 //    solution follow from Fc += Yc da + sum U_k acc_k - contact wrenches instead of a second pass over the body inertias.
+// leading dimension of the staged Jacobian rows (see eval_multibody.h, P13)
+static inline __host__ __device__ int mb_ldj(int nz) { return ((nz - 16 + 31) / 32) * 32 + 16; }
+
 struct MbLds {
   int nj, nv, nq, nl_max;
   int nvp, nbm, ncb, ldl;  // padded nv, block count of the mass matrix, 16-column blocks of the right-hand sides, leading dim of d lambda
@@ -74,8 +77,8 @@ static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz) {
   // terms: stacked cost rows (<= 32) / the rows of the constraint being emitted, ld nz, from Yc on (Yc and the stage-2 blocks are dead)
   s.JS = s.Yc;
   const int js_rows = 32 > MB_STAGE_CONSTRAINT_ROWS ? 32 : MB_STAGE_CONSTRAINT_ROWS;
-  if (o < s.JS + js_rows * nz + 8) o = (s.JS + js_rows * nz + 8 + 1) & ~1;
-  s.stage_rows = (o - s.JS) / nz;
+  if (o < s.JS + js_rows * mb_ldj(nz) + 8) o = (s.JS + js_rows * mb_ldj(nz) + 8 + 1) & ~1;
+  s.stage_rows = (o - s.JS) / mb_ldj(nz);
   s.DL = take(12 * s.ldl > s.nvp * 16 ? 12 * s.ldl : s.nvp * 16);
   s.V16 = s.DL;
   s.total = o;
