@@ -192,6 +192,9 @@ int mpc_set_x0(mpc_solver* s, const double* x0);
  * the final state becomes the measured state x0 of every instance (as if set by mpc_set_x0), so the next mpc_run_shifted
  * starts from it.  Whole-body contact dynamics only.  mpc_get_x0 reads the measured states back: x0[B][nx]. */
 int mpc_simulate(mpc_solver* s, int32_t substeps, double dt);
+/* The same with a disturbance: f_ext[B][3], a world-frame force applied at the origin of the base link during the whole call (the
+ * 300 N push of fulldynamic_talos.py:433-435, 524-526: device.apply_force(f_disturbance, [0, 0, 0]) on ticks 160 - 170); NULL = none. */
+int mpc_simulate_push(mpc_solver* s, int32_t substeps, double dt, const double* f_ext);
 int mpc_get_x0(mpc_solver* s, double* x0);
 /* solver.setup(problem) (fulldynamic_talos.py:539): reset multipliers, penalty and tolerances (no re-allocation). */
 int mpc_setup(mpc_solver* s);

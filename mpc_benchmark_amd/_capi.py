@@ -82,6 +82,7 @@ _SIGNATURES = {
     "mpc_cycle": (C.c_int, [C.c_void_p, _IP, C.c_int32, _DP, C.c_int32]),
     "mpc_set_x0": (C.c_int, [C.c_void_p, _DP]),
     "mpc_simulate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    "mpc_simulate_push": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _DP]),
     "mpc_set_tick_reuse": (C.c_int, [C.c_void_p, C.c_int32]),
     "mpc_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mpc_get_x0": (C.c_int, [C.c_void_p, _DP]),
@@ -228,6 +229,11 @@ class NativeSolver:
     def simulate(self, substeps, dt):
         """N2: integrate knot 0's dynamics under u = us[0] - K0 difference(x, xs[0]); the result is the next measured state."""
         self._check(self.lib.mpc_simulate(self._h, int(substeps), float(dt)), "mpc_simulate")
+
+    def simulate_push(self, substeps, dt, f_ext):
+        """``simulate`` with a world-frame force at the base origin of every instance: f_ext (B, 3) or (3,) (mpc_simulate_push)."""
+        f = np.ascontiguousarray(np.broadcast_to(_f64(f_ext).reshape(-1, 3), (self.dims.batch, 3)))
+        self._check(self.lib.mpc_simulate_push(self._h, int(substeps), float(dt), _dp(f)), "mpc_simulate_push")
 
     def get_x0(self):
         x0 = np.zeros((self.dims.batch, self.dims.nx))

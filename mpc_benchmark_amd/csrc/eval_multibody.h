@@ -529,7 +529,12 @@ sim_loop:
         if (j < nl) {
           const int cc = j / 6;
           if (BELOW(l, mcontact[desc[2 + cc]])) s = adinv(ldm3(cfr + 54 * cc), ldv3(cfr + 54 * cc + 9), ldc6(J, nv, l)).v[j - 6 * cc];
-        } else if (j == 12) s = -bias[l] + (l >= nv - nu ? u[l - (nv - nu)] : 0.0);
+        } else if (j == 12) {
+          s = -bias[l] + (l >= nv - nu ? u[l - (nv - nu)] : 0.0);
+          // disturbance of the simulation stand-in: a world-frame force f at the base origin acts on the linear base dofs only
+          // (J_l . [f ; p x f] = (R e_l) . f ; the angular dofs cancel)
+          if (TRIAL == 2 && mb.f_ext && l < 3) s += J[0 * nv + l] * mb.f_ext[3 * b] + J[1 * nv + l] * mb.f_ext[3 * b + 1] + J[2 * nv + l] * mb.f_ext[3 * b + 2];
+        }
       }
       Y16[l * MB_LDY + j] = s;
     }

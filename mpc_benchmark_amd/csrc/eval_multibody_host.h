@@ -113,10 +113,12 @@ struct MbArgs {
   int ncand_loop;         // TRIAL == 1: > 0 = the workgroup walks this many candidates itself (grid z = 1)
   int sim_substeps;       // TRIAL == 2 (closed-loop simulation stand-in): integration steps ...
   double sim_dt;          // ... of this length
+  const double* f_ext;    // TRIAL == 2: world-frame force at the base origin per instance [B][3] (mpc_simulate_push), or nullptr
 };
 
 
 // defined in eval_multibody.hip
 void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout& LT, double* records, double* scratch, size_t scratch_stride,
-                           bool trial, int cand0 = 0, int ncand = 1, int sim_substeps = 0, double sim_dt = 0.0, bool with_derivs = false);
+                           bool trial, int cand0 = 0, int ncand = 1, int sim_substeps = 0, double sim_dt = 0.0, bool with_derivs = false,
+                           const double* f_ext = nullptr);
 const void* eval_multibody_kernel(int trial);  // entry point of k_eval_multibody<trial> (occupancy tooling)

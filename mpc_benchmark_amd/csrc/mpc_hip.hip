@@ -64,6 +64,7 @@ struct mpc_solver {
   int cycles_since_run = 0;  // the speculation assumes ONE mpc_cycle per tick (replaceStageCircular + cycleAppend of the scripts)
   int khead = 0;
   int* d_spec = nullptr;
+  double* d_fext = nullptr;  // [B][3] disturbance force of mpc_simulate_push
   // per-slot invalidation (mpc_update_stage_params*): slots whose parameters changed since the last pass was enqueued ; dirty_all:
   // an update on a horizon too long for the mask of SolverArgs
   std::vector<uint8_t> slot_dirty;
@@ -940,15 +941,27 @@ int mpc_profile_read(mpc_solver* s, int32_t slot, char* name, int32_t name_cap, 
   }
 }
 
+static void simulate_impl(mpc_solver* s, int32_t substeps, double dt, const double* f_ext) {
+  if (substeps <= 0 || !(dt > 0.0)) throw std::runtime_error("simulate: substeps and dt must be positive");
+  if (s->L.space != MPC_SPACE_MULTIBODY || s->h_desc[(size_t)slot_of(s, 0) * s->L.max_stage_ints] != MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER)
+    throw std::runtime_error("simulate: only contact-constrained whole-body dynamics are supported");
+  const double* d_f = nullptr;
+  if (f_ext) {  // (a small synchronous upload: the push is an event of a few ticks, not part of the steady loop)
+    if (!s->d_fext) s->d_fext = s->alloc<double>((size_t)s->L.B * 3);
+    copy_sync(s, s->d_fext, f_ext, (size_t)s->L.B * 3 * sizeof(double), hipMemcpyHostToDevice);
+    d_f = s->d_fext;
+  }
+  launch_eval_multibody(s->stream, s->args(), s->LT, s->d_tknots, s->d_mbwork, s->mb_work_stride, true, 0, 1, substeps, dt, false, d_f);
+  HIP_OK(hipGetLastError());
+  s->perfect_feedback = false;
+}
+
 int mpc_simulate(mpc_solver* s, int32_t substeps, double dt) {
-  MPC_TRY(s, {
-    if (substeps <= 0 || !(dt > 0.0)) throw std::runtime_error("simulate: substeps and dt must be positive");
-    if (s->L.space != MPC_SPACE_MULTIBODY || s->h_desc[(size_t)slot_of(s, 0) * s->L.max_stage_ints] != MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER)
-      throw std::runtime_error("simulate: only contact-constrained whole-body dynamics are supported");
-    launch_eval_multibody(s->stream, s->args(), s->LT, s->d_tknots, s->d_mbwork, s->mb_work_stride, true, 0, 1, substeps, dt);
-    HIP_OK(hipGetLastError());
-    s->perfect_feedback = false;
-  })
+  MPC_TRY(s, { simulate_impl(s, substeps, dt, nullptr); })
+}
+
+int mpc_simulate_push(mpc_solver* s, int32_t substeps, double dt, const double* f_ext) {
+  MPC_TRY(s, { simulate_impl(s, substeps, dt, f_ext); })
 }
 
 int mpc_get_x0(mpc_solver* s, double* x0) {

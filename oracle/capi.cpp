@@ -102,6 +102,14 @@ int mpc_set_x0(mpc_solver* h, const double* x0) {
   })
 }
 
+int mpc_simulate_push(mpc_solver* h, int32_t substeps, double dt, const double* f_ext) {
+  MPC_TRY(h, {
+    if (substeps <= 0 || !(dt > 0.0)) throw std::runtime_error("simulate: substeps and dt must be positive");
+    for (int b = 0; b < h->s.dims.batch; ++b) h->s.simulate(h->s.inst[b], substeps, dt, f_ext ? f_ext + 3 * b : nullptr);
+    h->perfect_feedback = false;
+  })
+}
+
 int mpc_simulate(mpc_solver* h, int32_t substeps, double dt) {
   MPC_TRY(h, {
     if (substeps <= 0 || !(dt > 0.0)) throw std::runtime_error("simulate: substeps and dt must be positive");

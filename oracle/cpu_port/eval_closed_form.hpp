@@ -209,7 +209,7 @@ inline void eval_multibody_cf(const Model& m, const StageDesc& sd, int nu, const
     W.Yt.assign((size_t)nv * rc, 0.0);
     for (int l = 0; l < nv; ++l) {
       for (int j = 0; j < nl; ++j) W.Yt[(size_t)l * rc + j] = W.Jc[(size_t)j * nv + l];
-      W.Yt[(size_t)l * rc + nl] = -dot6(W.J[l], W.Fc[W.dof_body[l]]) + (l >= nv - nu ? u[l - (nv - nu)] : 0.0);
+      W.Yt[(size_t)l * rc + nl] = -dot6(W.J[l], W.Fc[W.dof_body[l]]) + (l >= nv - nu ? u[l - (nv - nu)] : 0.0) + (orc::ext_tau() ? orc::ext_tau()[l] : 0.0);
     }
     cf::trsm_fwd(W.L.data(), nv, W.Yt.data(), rc);
     std::vector<double> t(nl > 0 ? nl : 1, 0.0);

@@ -970,7 +970,7 @@ struct Solver {
   // N2: closed-loop simulation stand-in — knot 0's contact dynamics integrated `substeps` times with step
   // `dt` under the feedback law of the low-level loop u = us[0] - K0 difference(x, xs[0]) (fulldynamic_talos.py:512-530);
   // the result becomes the measured state x0 of the next tick.
-  void simulate(Instance& in, int substeps, double dt) const {
+  void simulate(Instance& in, int substeps, double dt, const double* push = nullptr) const {  // push: world-frame force at the base origin (3) or null
     if (dims.space != MPC_SPACE_MULTIBODY || stages[0].dyn != MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER)
       throw std::runtime_error("simulate: only contact-constrained whole-body dynamics are supported");
     const int n = dims.ndx, nu = dims.nu, nx = dims.nx;
@@ -987,7 +987,15 @@ struct Solver {
         for (int j = 0; j < n; ++j) su -= in.gains[0].K[i * n + j] * d[j];
         u[i] = su;
       }
+      std::vector<double> tau;
+      if (push) {  // generalized force of a world-frame force f at the base origin: R^T f on the linear base dofs
+        tau.assign(model.nv, 0.0);
+        const State<double> sx = state_from_x(model, x.data());
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) tau[i] += sx.base.R(j, i) * push[j];
+        ext_tau() = tau.data();
+      }
       ORC_EVAL_MULTIBODY(model, sd, nu, x.data(), u.data(), x.data(), kn, false);
+      ext_tau() = nullptr;
       x = kn.xnext;
     }
     in.x0 = x;

@@ -394,6 +394,10 @@ inline void mb_difference(const Model& m, const double* x0, const double* x1, do
   }
 }
 
+// external generalized force (size nv, Pinocchio's joint-frame convention) added to the right-hand side of the forward dynamics: set
+// only by Solver::simulate around its value-only evaluations (the disturbance of fulldynamic_talos.py:433-435, 524-526)
+inline const double*& ext_tau() { static thread_local const double* p = nullptr; return p; }
+
 inline void eval_multibody(const Model& m, const StageDesc& sd, int nu, const double* x, const double* u, const double* xnext,
                            Knot& kn, bool with_derivs) {
   const int nv = m.nv, n = 2 * nv, nx = m.nq + nv;
@@ -444,7 +448,7 @@ inline void eval_multibody(const Model& m, const StageDesc& sd, int nu, const do
     for (int i = 0; i < nK; ++i) Kinv[i * nK + i] = 1.0;
     solve_dense(Kmat, nK, Kinv, nK);
     std::vector<double> rhs(nK, 0.0);
-    for (int i = 0; i < nv; ++i) rhs[i] = -b[i] + (i >= nv - nu ? u[i - (nv - nu)] : 0.0);
+    for (int i = 0; i < nv; ++i) rhs[i] = -b[i] + (i >= nv - nu ? u[i - (nv - nu)] : 0.0) + (ext_tau() ? ext_tau()[i] : 0.0);
     for (int i = 0; i < nl; ++i) rhs[nv + i] = -gam[i];
     for (int i = 0; i < nv; ++i) { double sacc = 0; for (int j = 0; j < nK; ++j) sacc += Kinv[i * nK + j] * rhs[j]; a[i] = sacc; }
     for (int i = 0; i < nl; ++i) { double sacc = 0; for (int j = 0; j < nK; ++j) sacc += Kinv[(nv + i) * nK + j] * rhs[j]; lam[i] = -sacc; }
