@@ -1063,7 +1063,11 @@ int mpc_run(mpc_solver* s, const double* xs, const double* us, mpc_stats* stats)
   MPC_TRY(s, {
     spec_clear(s);
     s->reuse_this_pass = false;
-    s->leg_guess_valid = false;  // a fresh iterate: the cut Hessians kept from the last pass belong to another trajectory
+    // A multi-iteration solve starts from an iterate the handle has never seen (cold start): the cut Hessians kept from the last pass
+    // belong to another trajectory, the first pass refreshes them with its extra sweeps.  A single iteration (max_iters = 1) is an MPC
+    // tick of the reference loop, whose xs / us are the previous solution shifted by one knot (fulldynamic_talos.py:532-540): the
+    // guesses stay — refreshing them there would cost one sweep per tree level on every tick of the drop-in path.
+    if (s->opt.max_iters > 1) s->leg_guess_valid = false;
     s->spec_skip_pass = false;
     const Layout& L = s->L;
     HIP_OK(hipMemcpyAsync(s->d_xs, xs, (size_t)L.B * (L.N + 1) * L.nx * sizeof(double), hipMemcpyHostToDevice, s->stream));
