@@ -69,6 +69,24 @@ int mpc_qp_solve(mpc_qp_solver* s, const mpc_qp_settings* settings, const double
                  const double* C, const double* l, const double* u, const double* l_box, const double* u_box,
                  double* x, double* y, double* z, double* z_box, mpc_qp_info* info);
 
+/* ---- on-device assembly of the whole-body inverse-dynamics QP (QP_utils.py IDSolver.computeMatrice / solve) ----
+ * The reference builds every QP on the host from Pinocchio quantities (QP_utils.py:120-158: computeAllTerms, frame
+ * Jacobians, M, nle, frame accelerations) and hands dense matrices to proxqp; here the robot model is uploaded once
+ * and one kernel per batch builds A, b, C, l in HBM from (x, a, forces, contact states), after which the QP kernel
+ * runs on them without the matrices crossing PCIe.
+ * mpc_qp_set_model: the same two tables as mpc_set_model (include/mpc_abi.h, MPC_MODEL_* layout).
+ * mpc_qp_solve_id: the handle must have n = 2 nv - 6 + 6 nk, neq = nv + 6 nk, nin = 9 nk, box = 0.
+ *   frames[nk]: model frame indices of the contacts; weights[2]: the diagonal weights of H on da and on df
+ *   (QP_utils.py:98-103; the torque block is zero); cone[9][6]: the wrench-cone rows Cmin (QP_utils.py:76-92);
+ *   kd: Baumgarte velocity gain (QP_utils.py:105); xrob[B][nq+nv], acc[B][nv], forces[B][6 nk],
+ *   contact_states[B][nk] (0/1).  Outputs x[B][n] = (da, df, tau), y, z (may be NULL), info[B]; A_out / b_out /
+ *   C_out / l_out (may be NULL) read the assembled matrices back for inspection. */
+int mpc_qp_set_model(mpc_qp_solver* s, const int32_t* itab, int32_t n_i, const double* dtab, int32_t n_d);
+int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* settings, int32_t nk, const int32_t* frames, const double* weights,
+                    const double* cone, double kd, const double* xrob, const double* acc, const double* forces,
+                    const int32_t* contact_states, double* x, double* y, double* z, mpc_qp_info* info, double* A_out, double* b_out,
+                    double* C_out, double* l_out);
+
 #ifdef __cplusplus
 }
 #endif

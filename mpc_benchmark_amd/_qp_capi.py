@@ -40,6 +40,12 @@ def _bind(lib):
     lib.mpc_qp_default_settings.argtypes = [C.POINTER(QpSettings)]
     lib.mpc_qp_solve.restype = C.c_int
     lib.mpc_qp_solve.argtypes = [C.c_void_p, C.POINTER(QpSettings)] + [_DP] * 13 + [C.POINTER(QpInfo)]
+    _IP = C.POINTER(C.c_int32)
+    lib.mpc_qp_set_model.restype = C.c_int
+    lib.mpc_qp_set_model.argtypes = [C.c_void_p, _IP, C.c_int32, _DP, C.c_int32]
+    lib.mpc_qp_solve_id.restype = C.c_int
+    lib.mpc_qp_solve_id.argtypes = [C.c_void_p, C.POINTER(QpSettings), C.c_int32, _IP, _DP, _DP, C.c_double, _DP, _DP, _DP, _IP,
+                                    _DP, _DP, _DP, C.POINTER(QpInfo), _DP, _DP, _DP, _DP]
     _bound.add(id(lib))
     return lib
 
@@ -86,3 +92,37 @@ class BatchedQP:
         if rc != 0:
             raise RuntimeError("mpc_qp_solve: " + self.lib.mpc_qp_last_error(self._h).decode())
         return x, y, z, zb, list(info)
+
+    # ---- on-device assembly of the inverse-dynamics QP (mpc_qp_set_model / mpc_qp_solve_id) ----
+    def set_model(self, itab, dtab):
+        itab = np.ascontiguousarray(itab, dtype=np.int32); dtab = np.ascontiguousarray(dtab, dtype=np.float64)
+        if self.lib.mpc_qp_set_model(self._h, itab.ctypes.data_as(C.POINTER(C.c_int32)), itab.size, _dp(dtab), dtab.size) != 0:
+            raise RuntimeError("mpc_qp_set_model: " + self.lib.mpc_qp_last_error(self._h).decode())
+        self._nqv, self._nv = int(itab[1]) + int(itab[2]), int(itab[2])
+
+    def solve_id(self, frames, weights, cone, kd, xrob, acc, forces, contact_states, return_matrices=False):
+        """-> x, y, z, info (, (A, b, C, l) as assembled on the device)."""
+        d = self.dims
+        B, n, neq, nin = d.batch, d.n, d.neq, d.nin
+        frames = np.ascontiguousarray(frames, dtype=np.int32); nk = frames.size
+        weights = np.ascontiguousarray(weights, dtype=np.float64)[:2].copy()
+        cone = np.ascontiguousarray(cone, dtype=np.float64)
+        if cone.shape != (9, 6):
+            raise ValueError("cone must be 9 x 6")
+        xrob = np.ascontiguousarray(np.broadcast_to(np.asarray(xrob, dtype=np.float64), (B, self._nqv)))
+        nv = self._nv
+        acc = np.ascontiguousarray(np.broadcast_to(np.asarray(acc, dtype=np.float64), (B, nv)))
+        forces = np.ascontiguousarray(np.broadcast_to(np.asarray(forces, dtype=np.float64), (B, 6 * nk)))
+        cs = np.ascontiguousarray(np.broadcast_to(np.asarray(contact_states, dtype=np.int32), (B, nk)))
+        x = np.zeros((B, n)); y = np.zeros((B, neq)); z = np.zeros((B, nin))
+        mats = (np.zeros((B, neq, n)), np.zeros((B, neq)), np.zeros((B, nin, n)), np.zeros((B, nin))) if return_matrices else (None,) * 4
+        info = (QpInfo * B)()
+        IP = C.POINTER(C.c_int32)
+        rc = self.lib.mpc_qp_solve_id(self._h, C.byref(self.settings), nk, frames.ctypes.data_as(IP), _dp(weights), _dp(cone), float(kd),
+                                      _dp(xrob), _dp(acc), _dp(forces), cs.ctypes.data_as(IP), _dp(x), _dp(y), _dp(z), info,
+                                      _dp(mats[0]), _dp(mats[1]), _dp(mats[2]), _dp(mats[3]))
+        if rc != 0:
+            raise RuntimeError("mpc_qp_solve_id: " + self.lib.mpc_qp_last_error(self._h).decode())
+        if return_matrices:
+            return x, y, z, list(info), mats
+        return x, y, z, list(info)

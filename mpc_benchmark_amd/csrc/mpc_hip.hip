@@ -1308,4 +1308,3 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
 
 }  // extern "C"
 
-#include "qp_host.h"  // batched dense QP (include/mpc_qp_abi.h)

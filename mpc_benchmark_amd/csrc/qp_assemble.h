@@ -1,0 +1,233 @@
+// qp_assemble.h — N3: the matrices of the whole-body inverse-dynamics QP (QP_utils.py:519-551, IDSolver_ulim) assembled ON THE DEVICE
+// from the robot state, instead of numpy on the host + 4 uploads per call.  One workgroup per robot: the rigid-body terms in the
+// world-frame formulation of the stage kernel (eval_multibody.h: joint columns J, composite inertias, M_rc = U_r . J_c, nle_k = J_k . Fc,
+// LOCAL contact Jacobians Ad(M_c)^-1 J and drifts Ad(M_c)^-1 a0), then
+//     A = [[M, -Jc^T, -S], [Jc, 0, 0]],  b = [-nle - M a + Jc^T f ; -gamma - Jc a],  C = blockdiag(Cmin) on the force unknowns,  l = -Cmin f
+// written straight into the solver's device buffers (k_qp_solve reads them next).  gamma carries the reference's velocity damping:
+// rows 0..2 += kd (v_lin + v_ang) of the contact frame (QP_utils.py:528-531 as mirrored in mpc_benchmark_amd/qp_utils.py).
+#pragma once
+#include "device_common.h"
+
+#define QPA_THREADS 256
+
+struct QpAssembleArgs {
+  const int32_t* mi;   // model tables of mpc_set_model (include/mpc_abi.h)
+  const double* md;
+  const double* x;     // [B][nq + nv]
+  const double* acc;   // [B][nv]  acceleration of the MPC solution
+  const double* f;     // [B][6 nk] contact forces of the MPC solution
+  const int32_t* cs;   // [B][nk]  contact states
+  const int32_t* frames;  // [nk] contact frame indices in the model's frame table
+  const double* cone;  // [9][6] rows of Cmin
+  double kd;
+  int nk, n, neq, nin;
+  double *A, *b, *C, *l;  // [B][neq][n], [B][neq], [B][nin][n], [B][nin]
+};
+
+// j is an ancestor of i, or i itself (joints are topologically ordered: parents have smaller indices)
+DEV bool qpa_anc(const int* parent, int i, int j) { while (i > j) i = parent[i]; return i == j; }
+
+__global__ void __launch_bounds__(QPA_THREADS) k_qp_assemble_id(QpAssembleArgs a) {
+  const int bi = blockIdx.x, tid = threadIdx.x, nthr = QPA_THREADS;
+  const int nj = a.mi[0], nq = a.mi[1], nv = a.mi[2], nframes = a.mi[3], nk = a.nk, n = a.n, neq = a.neq, nin = a.nin;
+  const int32_t* mj = a.mi + MPC_MODEL_HEADER_WORDS;
+  const int32_t* mframe = mj + MPC_MODEL_JOINT_WORDS * nj;
+  const double* jd = a.md + MPC_MODEL_HEADER_DOUBLES;
+  const double* fd = jd + MPC_MODEL_JOINT_DOUBLES * nj;
+  const S6 a0 = mk6(v3(-a.md[0], -a.md[1], -a.md[2]), v3(0, 0, 0));
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  // LDS: per body oR (9) op (3) ov oa of Fc (6 each) lR (9) lp (3) Y Yc (36 each) ; per dof J U (6 each) nle ; x ; per contact R p gamma (18) ; Jc [6 nk][nv]
+  double *oR = sm, *op = oR + 9 * nj, *ov = op + 3 * nj, *oa = ov + 6 * nj, *of = oa + 6 * nj, *Fc = of + 6 * nj, *lR = Fc + 6 * nj, *lp = lR + 9 * nj;
+  double *Y = lp + 3 * nj, *Yc = Y + 36 * nj, *J = Yc + 36 * nj, *U = J + 6 * nv, *nle = U + 6 * nv, *xs = nle + nv, *cfr = xs + nq + nv, *Jc = cfr + 18 * nk;
+  double* Ma = Jc + 6 * nk * nv;  // M a (nv)
+  int* parent = (int*)(Ma + nv);
+  int* jkind = parent + nj;
+  int* jidxv = jkind + nj;
+  int* dof_body = jidxv + nj;
+  const double* xg = a.x + (size_t)bi * (nq + nv);
+  for (int i = tid; i < nq + nv; i += nthr) xs[i] = xg[i];
+  for (int i = tid; i < nj; i += nthr) {
+    parent[i] = mj[4 * i]; jkind[i] = mj[4 * i + 1]; jidxv[i] = mj[4 * i + 3];
+    const int nd = (mj[4 * i + 1] == MPC_JOINT_FREEFLYER) ? 6 : 1;
+    for (int d = 0; d < nd; ++d) dof_body[mj[4 * i + 3] + d] = i;
+  }
+  __syncthreads();
+  const double* q = xs;
+  const double* v = xs + nq;
+  // placements
+  for (int i = tid; i < nj; i += nthr) {
+    const M3 Rp = ldm3(jd + 25 * i);
+    const V3 pp = ldv3(jd + 25 * i + 9);
+    M3 Rj;
+    V3 pj = v3(0, 0, 0);
+    if (jkind[i] == MPC_JOINT_FREEFLYER) { Rj = quat_to_rot(q + 3); pj = v3(q[0], q[1], q[2]); }
+    else {
+      const double th = q[jidxv[i] + 1], cs = cos(th), sn = sin(th);
+      const int ax = jkind[i] - MPC_JOINT_RX, b1 = (ax + 1) % 3, b2 = (ax + 2) % 3;
+      for (int e = 0; e < 9; ++e) Rj.m[e] = (e % 4 == 0) ? 1.0 : 0.0;
+      Rj.m[3 * b1 + b1] = cs; Rj.m[3 * b1 + b2] = -sn; Rj.m[3 * b2 + b1] = sn; Rj.m[3 * b2 + b2] = cs;
+    }
+    const M3 Rl = mul(Rp, Rj);
+    const V3 pl = mul(Rp, pj) + pp;
+    for (int e = 0; e < 9; ++e) lR[9 * i + e] = Rl.m[e];
+    lp[3 * i] = pl.x; lp[3 * i + 1] = pl.y; lp[3 * i + 2] = pl.z;
+  }
+  __syncthreads();
+  for (int i = tid; i < nj; i += nthr) {
+    M3 R = ldm3(lR + 9 * i);
+    V3 p = ldv3(lp + 3 * i);
+    for (int j = parent[i]; j >= 0; j = parent[j]) { const M3 Rj = ldm3(lR + 9 * j); p = mul(Rj, p) + ldv3(lp + 3 * j); R = mul(Rj, R); }
+    for (int e = 0; e < 9; ++e) oR[9 * i + e] = R.m[e];
+    op[3 * i] = p.x; op[3 * i + 1] = p.y; op[3 * i + 2] = p.z;
+  }
+  __syncthreads();
+  // world-frame joint columns
+  for (int kd = tid; kd < nv; kd += nthr) {
+    const int i = dof_body[kd], loc = kd - jidxv[i];
+    const M3 R = ldm3(oR + 9 * i);
+    const V3 p = ldv3(op + 3 * i);
+    S6 col;
+    if (jkind[i] == MPC_JOINT_FREEFLYER && loc < 3) col = mk6(v3(R.m[loc], R.m[3 + loc], R.m[6 + loc]), v3(0, 0, 0));
+    else {
+      const int ax = (jkind[i] == MPC_JOINT_FREEFLYER) ? loc - 3 : jkind[i] - MPC_JOINT_RX;
+      const V3 w = v3(R.m[ax], R.m[3 + ax], R.m[6 + ax]);
+      col = mk6(cross(p, w), w);
+    }
+    st6(J + 6 * kd, col);
+  }
+  __syncthreads();
+  // body velocities (sum over the dofs on the path to the body)
+  for (int i = tid; i < nj; i += nthr) {
+    S6 vi = zero6();
+    for (int j = i; j >= 0; j = parent[j]) {
+      const int nd = (jkind[j] == MPC_JOINT_FREEFLYER) ? 6 : 1;
+      for (int d = 0; d < nd; ++d) vi = add6(vi, scale6(v[jidxv[j] + d], ld6(J + 6 * (jidxv[j] + d))));
+    }
+    st6(ov + 6 * i, vi);
+  }
+  __syncthreads();
+  // velocity-product accelerations in the gravity field, world inertias, body forces
+  for (int i = tid; i < nj; i += nthr) {
+    S6 ai = a0;
+    for (int j = i; j >= 0; j = parent[j]) {
+      const int nd = (jkind[j] == MPC_JOINT_FREEFLYER) ? 6 : 1;
+      for (int d = 0; d < nd; ++d) ai = add6(ai, scale6(v[jidxv[j] + d], mcross(ld6(ov + 6 * j), ld6(J + 6 * (jidxv[j] + d)))));
+    }
+    st6(oa + 6 * i, ai);
+    const M3 R = ldm3(oR + 9 * i);
+    const double mass = jd[25 * i + 12];
+    const V3 cw = mul(R, ldv3(jd + 25 * i + 13)) + ldv3(op + 3 * i);
+    const M3 RI = mul(R, ldm3(jd + 25 * i + 16));
+    M3 Iww;
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Iww.m[3 * r + cc] = RI.m[3 * r] * R.m[3 * cc] + RI.m[3 * r + 1] * R.m[3 * cc + 1] + RI.m[3 * r + 2] * R.m[3 * cc + 2];
+    const M3 Sx = skew_m(cw), S2 = mul(Sx, Sx);
+    double* Yi = Y + 36 * i;
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
+      Yi[6 * r + cc] = (r == cc) ? mass : 0.0;
+      Yi[6 * r + cc + 3] = -mass * Sx.m[3 * r + cc];
+      Yi[6 * (r + 3) + cc] = mass * Sx.m[3 * r + cc];
+      Yi[6 * (r + 3) + cc + 3] = Iww.m[3 * r + cc] - mass * S2.m[3 * r + cc];
+    }
+    const S6 vi = ld6(ov + 6 * i);
+    const S6 hi = mat6_mul(Yi, vi);
+    st6(of + 6 * i, add6(mat6_mul(Yi, ai), fcross(vi, hi)));
+  }
+  __syncthreads();
+  // composite inertias and subtree forces
+  for (int idx = tid; idx < 36 * nj; idx += nthr) {
+    const int i = idx / 36, e = idx % 36;
+    double s = 0;
+    for (int j = i; j < nj; ++j) if (qpa_anc(parent, j, i)) s += Y[36 * j + e];
+    Yc[idx] = s;
+  }
+  for (int idx = tid; idx < 6 * nj; idx += nthr) {
+    const int i = idx / 6, e = idx % 6;
+    double s = 0;
+    for (int j = i; j < nj; ++j) if (qpa_anc(parent, j, i)) s += of[6 * j + e];
+    Fc[idx] = s;
+  }
+  __syncthreads();
+  for (int kd = tid; kd < nv; kd += nthr) {
+    st6(U + 6 * kd, mat6_mul(Yc + 36 * dof_body[kd], ld6(J + 6 * kd)));
+    nle[kd] = dot6(ld6(J + 6 * kd), ld6(Fc + 6 * dof_body[kd]));
+  }
+  // contact frames: placement, LOCAL drift gamma = Ad^-1 (a - a0) + kd (v_lin + v_ang) on the linear rows
+  if (tid < nk) {
+    const int fi = a.frames[tid], i = mframe[fi];
+    (void)nframes;
+    const M3 Ri = ldm3(oR + 9 * i);
+    const M3 Rc = mul(Ri, ldm3(fd + 12 * fi));
+    const V3 pc = mul(Ri, ldv3(fd + 12 * fi + 9)) + ldv3(op + 3 * i);
+    double* cf = cfr + 18 * tid;
+    for (int e = 0; e < 9; ++e) cf[e] = Rc.m[e];
+    cf[9] = pc.x; cf[10] = pc.y; cf[11] = pc.z;
+    const S6 g = adinv(Rc, pc, sub6(ld6(oa + 6 * i), a0));
+    const S6 vl = adinv(Rc, pc, ld6(ov + 6 * i));
+    for (int r = 0; r < 6; ++r) cf[12 + r] = g.v[r] + (r < 3 ? a.kd * (vl.v[r] + vl.v[3 + r]) : 0.0);
+  }
+  __syncthreads();
+  const int32_t* cs = a.cs + (size_t)bi * nk;
+  for (int idx = tid; idx < nk * nv; idx += nthr) {
+    const int c = idx / nv, kd = idx % nv;
+    const int i = mframe[a.frames[c]];
+    S6 col = zero6();
+    if (cs[c] && qpa_anc(parent, i, dof_body[kd])) col = adinv(ldm3(cfr + 18 * c), ldv3(cfr + 18 * c + 9), ld6(J + 6 * kd));
+    for (int r = 0; r < 6; ++r) Jc[(6 * c + r) * nv + kd] = col.v[r];
+  }
+  __syncthreads();
+  // ---- the QP matrices ----------------------------------------------------------------------------------------------
+  const double* acc = a.acc + (size_t)bi * nv;
+  const double* f = a.f + (size_t)bi * 6 * nk;
+  double* A = a.A + (size_t)bi * neq * n;
+  double* b = a.b + (size_t)bi * neq;
+  double* C = a.C + (size_t)bi * nin * n;
+  double* l = a.l + (size_t)bi * nin;
+  for (int idx = tid; idx < neq * n; idx += nthr) A[idx] = 0.0;
+  for (int idx = tid; idx < nin * n; idx += nthr) C[idx] = 0.0;
+  __syncthreads();
+  // M (rows of A) and M a
+  for (int r = tid; r < nv; r += nthr) {
+    double ma = 0;
+    const int br = dof_body[r];
+    const S6 Ur = ld6(U + 6 * r), Jr = ld6(J + 6 * r);
+    for (int c = 0; c < nv; ++c) {
+      const int bc = dof_body[c];
+      double s = 0;
+      if (qpa_anc(parent, br, bc)) s = dot6(Ur, ld6(J + 6 * c));
+      else if (qpa_anc(parent, bc, br)) s = dot6(ld6(U + 6 * c), Jr);
+      A[(size_t)r * n + c] = s;
+      ma += s * acc[c];
+    }
+    Ma[r] = ma;
+    if (r >= 6) A[(size_t)r * n + nv + 6 * nk + (r - 6)] = -1.0;  // -S
+  }
+  for (int idx = tid; idx < 6 * nk * nv; idx += nthr) {
+    const int rc = idx / nv, kd = idx % nv;
+    const double jv = Jc[idx];
+    A[(size_t)kd * n + nv + rc] = -jv;         // -Jc^T
+    A[(size_t)(nv + rc) * n + kd] = jv;         // Jc
+  }
+  __syncthreads();
+  for (int r = tid; r < nv; r += nthr) {
+    double s = -nle[r] - Ma[r];
+    for (int rc = 0; rc < 6 * nk; ++rc) s += Jc[rc * nv + r] * f[rc];
+    b[r] = s;
+  }
+  for (int rc = tid; rc < 6 * nk; rc += nthr) {
+    const int c = rc / 6;
+    double s = cs[c] ? -cfr[18 * c + 12 + rc % 6] : 0.0;
+    for (int kd = 0; kd < nv; ++kd) s -= Jc[rc * nv + kd] * acc[kd];
+    b[nv + rc] = s;
+  }
+  for (int idx = tid; idx < 9 * nk; idx += nthr) {
+    const int c = idx / 9, i = idx % 9;
+    double s = 0;
+    if (cs[c]) for (int j = 0; j < 6; ++j) { s -= a.cone[6 * i + j] * f[6 * c + j]; C[(size_t)idx * n + nv + 6 * c + j] = a.cone[6 * i + j]; }
+    l[idx] = s;
+  }
+}
+
+static inline size_t qp_assemble_lds_bytes(int nj, int nv, int nq, int nk) {
+  const size_t dbl = (size_t)(9 + 3 + 6 * 4 + 9 + 3 + 36 + 36) * nj + (size_t)(6 + 6 + 1) * nv + (nq + nv) + 18 * nk + (size_t)6 * nk * nv + nv;
+  return dbl * sizeof(double) + (size_t)(3 * nj + nv) * sizeof(int) + 64;
+}

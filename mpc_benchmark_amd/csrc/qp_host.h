@@ -1,6 +1,7 @@
 // qp_host.h — host side of the batched QP solver (include/mpc_qp_abi.h) for the HIP library; included by mpc_hip.hip.
 #pragma once
 #include "qp_kernel.h"
+#include "qp_assemble.h"
 
 struct mpc_qp_solver {
   mpc_qp_dims d{};
@@ -9,6 +10,13 @@ struct mpc_qp_solver {
   double *dH = nullptr, *dg = nullptr, *dA = nullptr, *db = nullptr, *dC = nullptr, *dl = nullptr, *du = nullptr, *dlb = nullptr, *dub = nullptr;
   double *dx = nullptr, *dy = nullptr, *dz = nullptr;
   mpc_qp_info* dinfo = nullptr;
+  // on-device assembly of the inverse-dynamics QP (mpc_qp_set_model / mpc_qp_solve_id)
+  int32_t* d_mi = nullptr; double* d_md = nullptr;
+  int m_nj = 0, m_nq = 0, m_nv = 0, m_nframes = 0;
+  double *d_xrob = nullptr, *d_acc = nullptr, *d_f = nullptr, *d_cone = nullptr;
+  int32_t *d_cs = nullptr, *d_frames = nullptr;
+  int id_nk = 0;
+  bool id_const_uploaded = false;
   std::vector<void*> allocs;
   std::string err;
   template <class T> T* alloc(size_t count) {
@@ -19,6 +27,33 @@ struct mpc_qp_solver {
     return (T*)p;
   }
 };
+
+// launch k_qp_solve on the handle's device buffers and bring the solution back
+static void qp_launch_and_fetch(mpc_qp_solver* s, const mpc_qp_settings* S, double* x, double* y, double* z, double* z_box, mpc_qp_info* info) {
+  const mpc_qp_dims& d = s->d;
+  const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin, m = nin + (d.box ? n : 0);
+  QpArgs a;
+  a.d = d; a.S = *S;
+  a.H = s->dH; a.g = s->dg; a.A = s->dA; a.b = s->db; a.C = s->dC; a.l = s->dl; a.u = s->du; a.lb = s->dlb; a.ub = s->dub;
+  a.x = s->dx; a.y = s->dy; a.z = s->dz; a.info = s->dinfo; a.lds = s->lds;
+  const dim3 grid(d.batch), blk(QP_THREADS);
+  if (s->lds.mf && s->lds.mats == 1) hipLaunchKernelGGL((k_qp_solve<1, true>), grid, blk, s->lds.total_bytes, s->stream, a);
+  else if (s->lds.mf && s->lds.mats == 2) hipLaunchKernelGGL((k_qp_solve<2, true>), grid, blk, s->lds.total_bytes, s->stream, a);
+  else if (s->lds.mf) hipLaunchKernelGGL((k_qp_solve<0, true>), grid, blk, s->lds.total_bytes, s->stream, a);
+  else if (s->lds.mats) hipLaunchKernelGGL((k_qp_solve<1, false>), grid, blk, s->lds.total_bytes, s->stream, a);
+  else hipLaunchKernelGGL((k_qp_solve<0, false>), grid, blk, s->lds.total_bytes, s->stream, a);
+  HIP_OK(hipGetLastError());
+  HIP_OK(hipMemcpyAsync(x, s->dx, B * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  if (y && neq) HIP_OK(hipMemcpyAsync(y, s->dy, B * neq * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  std::vector<double> zh(B * m);
+  if (m) HIP_OK(hipMemcpyAsync(zh.data(), s->dz, B * m * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+  HIP_OK(hipMemcpyAsync(info, s->dinfo, B * sizeof(mpc_qp_info), hipMemcpyDeviceToHost, s->stream));
+  HIP_OK(hipStreamSynchronize(s->stream));
+  for (size_t bi = 0; bi < B; ++bi) {
+    if (z && nin) std::memcpy(z + bi * nin, zh.data() + bi * m, nin * sizeof(double));
+    if (z_box && d.box) std::memcpy(z_box + bi * n, zh.data() + bi * m + nin, n * sizeof(double));
+  }
+}
 
 extern "C" {
 
@@ -86,32 +121,94 @@ int mpc_qp_solve(mpc_qp_solver* s, const mpc_qp_settings* S, const double* H, co
       if (neq) HIP_OK(hipMemsetAsync(s->dy, 0, B * neq * sizeof(double), s->stream));
       if (m) HIP_OK(hipMemsetAsync(s->dz, 0, B * m * sizeof(double), s->stream));
     }
-    QpArgs a;
-    a.d = d; a.S = *S;
-    a.H = s->dH; a.g = s->dg; a.A = s->dA; a.b = s->db; a.C = s->dC; a.l = s->dl; a.u = s->du; a.lb = s->dlb; a.ub = s->dub;
-    a.x = s->dx; a.y = s->dy; a.z = s->dz; a.info = s->dinfo; a.lds = s->lds;
-    const dim3 grid(d.batch), blk(QP_THREADS);
-    if (s->lds.mf && s->lds.mats == 1) hipLaunchKernelGGL((k_qp_solve<1, true>), grid, blk, s->lds.total_bytes, s->stream, a);
-    else if (s->lds.mf && s->lds.mats == 2) hipLaunchKernelGGL((k_qp_solve<2, true>), grid, blk, s->lds.total_bytes, s->stream, a);
-    else if (s->lds.mf) hipLaunchKernelGGL((k_qp_solve<0, true>), grid, blk, s->lds.total_bytes, s->stream, a);
-    else if (s->lds.mats) hipLaunchKernelGGL((k_qp_solve<1, false>), grid, blk, s->lds.total_bytes, s->stream, a);
-    else hipLaunchKernelGGL((k_qp_solve<0, false>), grid, blk, s->lds.total_bytes, s->stream, a);
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipMemcpyAsync(x, s->dx, B * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    if (y && neq) HIP_OK(hipMemcpyAsync(y, s->dy, B * neq * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    std::vector<double> zh(B * m);
-    if (m) HIP_OK(hipMemcpyAsync(zh.data(), s->dz, B * m * sizeof(double), hipMemcpyDeviceToHost, s->stream));
-    HIP_OK(hipMemcpyAsync(info, s->dinfo, B * sizeof(mpc_qp_info), hipMemcpyDeviceToHost, s->stream));
-    HIP_OK(hipStreamSynchronize(s->stream));
-    for (size_t bi = 0; bi < B; ++bi) {
-      if (z && nin) std::memcpy(z + bi * nin, zh.data() + bi * m, nin * sizeof(double));
-      if (z_box && d.box) std::memcpy(z_box + bi * n, zh.data() + bi * m + nin, n * sizeof(double));
-    }
+    qp_launch_and_fetch(s, S, x, y, z, z_box, info);
     return 0;
   } catch (const std::exception& e) {
     s->err = e.what();
     return -1;
   }
+}
+
+int mpc_qp_set_model(mpc_qp_solver* s, const int32_t* itab, int32_t n_i, const double* dtab, int32_t n_d) {
+  if (!s) return -2;
+  try {
+    HIP_OK(hipSetDevice(s->d.device));
+    if (!itab || !dtab || n_i < MPC_MODEL_HEADER_WORDS) throw std::runtime_error("qp_set_model: model table too short");
+    const int nj = itab[0], nf = itab[3], ncn = itab[4];
+    if (n_i < MPC_MODEL_HEADER_WORDS + MPC_MODEL_JOINT_WORDS * nj + nf + ncn ||
+        n_d < MPC_MODEL_HEADER_DOUBLES + MPC_MODEL_JOINT_DOUBLES * nj + MPC_MODEL_FRAME_DOUBLES * nf + MPC_MODEL_CONTACT_DOUBLES * ncn)
+      throw std::runtime_error("qp_set_model: model table size mismatch");
+    for (int i = 0; i < nj; ++i) {
+      const int32_t* ip = itab + MPC_MODEL_HEADER_WORDS + MPC_MODEL_JOINT_WORDS * i;
+      if (ip[0] >= i) throw std::runtime_error("qp_set_model: joints must be topologically ordered");
+      if ((ip[1] == MPC_JOINT_FREEFLYER) != (i == 0)) throw std::runtime_error("qp_set_model: free-flyer root followed by revolute joints expected");
+    }
+    s->d_mi = s->alloc<int32_t>(n_i); s->d_md = s->alloc<double>(n_d);
+    HIP_OK(hipMemcpyAsync(s->d_mi, itab, n_i * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipMemcpyAsync(s->d_md, dtab, n_d * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));
+    s->m_nj = nj; s->m_nq = itab[1]; s->m_nv = itab[2]; s->m_nframes = nf;
+    s->id_const_uploaded = false;
+    return 0;
+  } catch (const std::exception& e) { s->err = e.what(); return -1; }
+}
+
+int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, const int32_t* frames, const double* weights, const double* cone, double kd,
+                    const double* xrob, const double* acc, const double* forces, const int32_t* contact_states,
+                    double* x, double* y, double* z, mpc_qp_info* info, double* A_out, double* b_out, double* C_out, double* l_out) {
+  if (!s) return -2;
+  try {
+    HIP_OK(hipSetDevice(s->d.device));
+    if (!S || !frames || !weights || !cone || !xrob || !acc || !forces || !contact_states || !x || !info) throw std::runtime_error("qp_solve_id: null argument");
+    if (!s->d_mi) throw std::runtime_error("qp_solve_id: mpc_qp_set_model first");
+    const mpc_qp_dims& d = s->d;
+    const int nv = s->m_nv, nq = s->m_nq;
+    if (nk <= 0 || d.n != 2 * nv - 6 + 6 * nk || d.neq != nv + 6 * nk || d.nin != 9 * nk || d.box)
+      throw std::runtime_error("qp_solve_id: the handle's dimensions are not those of the inverse-dynamics QP (n = 2 nv - 6 + 6 nk, neq = nv + 6 nk, nin = 9 nk, no box)");
+    for (int c = 0; c < nk; ++c) if (frames[c] < 0 || frames[c] >= s->m_nframes) throw std::runtime_error("qp_solve_id: contact frame index out of range");
+    const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin;
+    if (!s->d_xrob || s->id_nk != nk) {
+      s->d_xrob = s->alloc<double>(B * (nq + nv)); s->d_acc = s->alloc<double>(B * nv); s->d_f = s->alloc<double>(B * 6 * nk);
+      s->d_cs = s->alloc<int32_t>(B * nk); s->d_frames = s->alloc<int32_t>(nk); s->d_cone = s->alloc<double>(54);
+      s->id_nk = nk; s->id_const_uploaded = false;
+      HIP_OK(hipFuncSetAttribute((const void*)k_qp_assemble_id, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qp_assemble_lds_bytes(s->m_nj, nv, nq, nk)));
+    }
+    // the constant parts: H = diag(w0 I_nv, w1 I_6nk, 0), g = 0, u = +inf (1e5 as the reference), frames, cone rows
+    {
+      std::vector<double> H(n * n, 0.0), g(n, 0.0), u(nin, 1e5);
+      for (int i = 0; i < nv; ++i) H[(size_t)i * n + i] = weights[0];
+      for (int i = 0; i < 6 * nk; ++i) H[(size_t)(nv + i) * n + nv + i] = weights[1];
+      for (size_t bi = 0; bi < B; ++bi) {
+        HIP_OK(hipMemcpyAsync(s->dH + bi * n * n, H.data(), n * n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        HIP_OK(hipMemcpyAsync(s->dg + bi * n, g.data(), n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        HIP_OK(hipMemcpyAsync(s->du + bi * nin, u.data(), nin * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      }
+      HIP_OK(hipMemcpyAsync(s->d_frames, frames, nk * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+      HIP_OK(hipMemcpyAsync(s->d_cone, cone, 54 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      HIP_OK(hipStreamSynchronize(s->stream));  // (host vectors go out of scope)
+    }
+    HIP_OK(hipMemcpyAsync(s->d_xrob, xrob, B * (nq + nv) * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipMemcpyAsync(s->d_acc, acc, B * nv * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipMemcpyAsync(s->d_f, forces, B * 6 * nk * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipMemcpyAsync(s->d_cs, contact_states, B * nk * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    QpAssembleArgs qa;
+    qa.mi = s->d_mi; qa.md = s->d_md; qa.x = s->d_xrob; qa.acc = s->d_acc; qa.f = s->d_f; qa.cs = s->d_cs; qa.frames = s->d_frames; qa.cone = s->d_cone;
+    qa.kd = kd; qa.nk = nk; qa.n = (int)n; qa.neq = (int)neq; qa.nin = (int)nin;
+    qa.A = s->dA; qa.b = s->db; qa.C = s->dC; qa.l = s->dl;
+    hipLaunchKernelGGL(k_qp_assemble_id, dim3(d.batch), dim3(QPA_THREADS), qp_assemble_lds_bytes(s->m_nj, nv, nq, nk), s->stream, qa);
+    HIP_OK(hipGetLastError());
+    if (!S->warm_start) {
+      HIP_OK(hipMemsetAsync(s->dx, 0, B * n * sizeof(double), s->stream));
+      HIP_OK(hipMemsetAsync(s->dy, 0, B * neq * sizeof(double), s->stream));
+      HIP_OK(hipMemsetAsync(s->dz, 0, B * nin * sizeof(double), s->stream));
+    }
+    if (A_out) HIP_OK(hipMemcpyAsync(A_out, s->dA, B * neq * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (b_out) HIP_OK(hipMemcpyAsync(b_out, s->db, B * neq * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (C_out) HIP_OK(hipMemcpyAsync(C_out, s->dC, B * nin * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (l_out) HIP_OK(hipMemcpyAsync(l_out, s->dl, B * nin * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    qp_launch_and_fetch(s, S, x, y, z, nullptr, info);
+    return 0;
+  } catch (const std::exception& e) { s->err = e.what(); return -1; }
 }
 
 }  // extern "C"

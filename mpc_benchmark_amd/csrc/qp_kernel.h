@@ -9,7 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/mpc_qp_abi.h"
-#include "solver_kernels.h"  // wave_sum, wave_max_nonneg
+#include "solver_args.h"  // wave_sum, wave_max_nonneg
 #include "mfma_blocks.h"    // blocked Cholesky / triangular solves on the matrix cores
 
 #define QP_THREADS 256

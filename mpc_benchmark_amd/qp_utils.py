@@ -99,6 +99,33 @@ class IDSolver_ulim:
         return res
 
 
+    # ---- the whole QP on the device: no Pinocchio-like terms computed on the host, no matrices over PCIe ----
+    def enable_device_assembly(self):
+        """Upload the robot model (the tables of mpc_set_model, with this solver's contact frames registered) so that
+        ``solve_batch_device`` builds M, nle, Jc, gamma and the QP matrices in one kernel per batch (csrc/qp_assemble.h)."""
+        from .aligator._core import LoweringContext
+        if self.force_size != 6:
+            raise NotImplementedError("device assembly is written for 6-D contact wrenches")
+        ctx = LoweringContext()
+        self._frame_idx = np.array([ctx.frame_index(self.model, fid) for fid in self.contact_ids], dtype=np.int32)
+        self.qp.set_model(*ctx.model_tables())
+        self._weights = np.array([self.H[0, 0], self.H[self.model.nv, self.model.nv]])
+
+    def solve_batch_device(self, x, a, forces, cs, return_matrices=False):
+        """``x`` [B][nq+nv], ``a`` [B][nv], ``forces`` [B][6 nk], ``cs`` [B][nk] -> (a_new, new_forces, torque), each [B][...]."""
+        if not hasattr(self, "_frame_idx"):
+            self.enable_device_assembly()
+        out = self.qp.solve_id(self._frame_idx, self._weights, self.Cmin, float(self.baum_Kd[0, 0]), x, a, forces, cs, return_matrices=return_matrices)
+        sol, info = out[0], out[3]
+        self.last_info = info
+        if self.warm_start:
+            self.qp.settings.warm_start = 1
+        nv, fs, nk = self.model.nv, self.force_size, self.nk
+        a = np.broadcast_to(np.asarray(a, dtype=float), (self.batch, nv)); forces = np.broadcast_to(np.asarray(forces, dtype=float), (self.batch, fs * nk))
+        res = (a + sol[:, :nv], forces + sol[:, nv:nv + fs * nk], sol[:, nv + fs * nk:].copy())
+        return res + (out[4],) if return_matrices else res
+
+
 class IKIDSolver_f6:
     """Inverse kinematics + inverse dynamics in one QP (QP_utils.py:584-762, used at centroidal_talos.py:326, 435): unknowns
     ``x = (a, df, tau)``; tasks in the cost — posture (w0), foot accelerations (w1), centroidal momentum rate (w2), base and

@@ -3,10 +3,13 @@
 #include <stdexcept>
 #include <string>
 #include "qp.hpp"
+#include "model.hpp"
 
 struct mpc_qp_solver {
   mpc_qp_dims d;
   std::vector<double> x, y, z;  // previous solution (warm start)
+  orc::Model model;             // mpc_qp_set_model
+  bool has_model = false;
   std::string err;
 };
 
@@ -57,6 +60,102 @@ int mpc_qp_solve(mpc_qp_solver* s, const mpc_qp_settings* S, const double* H, co
     s->err = e.what();
     return -1;
   }
+}
+
+int mpc_qp_set_model(mpc_qp_solver* s, const int32_t* itab, int32_t n_i, const double* dtab, int32_t n_d) {
+  if (!s) return -2;
+  try {
+    s->model = orc::Model();
+    s->model.parse(itab, n_i, dtab, n_d);
+    s->has_model = true;
+    return 0;
+  } catch (const std::exception& e) { s->err = e.what(); return -1; }
+}
+
+// The inverse-dynamics QP of QP_utils.py:120-158 built from recursive Newton-Euler evaluations only: nle = RNEA(q, v, 0),
+// M e_k = RNEA(q, 0, e_k) - RNEA(q, 0, 0), the LOCAL frame Jacobian column k = frame velocity under v = e_k, the drift =
+// frame spatial acceleration under (v, a = 0) without gravity.  (The HIP kernel uses composite inertias and world-frame
+// Jacobian columns: a different route to the same matrices.)
+int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, const int32_t* frames, const double* weights, const double* cone, double kd,
+                    const double* xrob, const double* acc, const double* forces, const int32_t* contact_states,
+                    double* x, double* y, double* z, mpc_qp_info* info, double* A_out, double* b_out, double* C_out, double* l_out) {
+  if (!s) return -2;
+  try {
+    using namespace orc;
+    if (!S || !frames || !weights || !cone || !xrob || !acc || !forces || !contact_states || !x || !info) throw std::runtime_error("qp_solve_id: null argument");
+    if (!s->has_model) throw std::runtime_error("qp_solve_id: mpc_qp_set_model first");
+    const Model& m = s->model;
+    const mpc_qp_dims& d = s->d;
+    const int nv = m.nv, nq = m.nq;
+    if (nk <= 0 || d.n != 2 * nv - 6 + 6 * nk || d.neq != nv + 6 * nk || d.nin != 9 * nk || d.box)
+      throw std::runtime_error("qp_solve_id: the handle's dimensions are not those of the inverse-dynamics QP");
+    for (int c = 0; c < nk; ++c) if (frames[c] < 0 || frames[c] >= (int)m.frame_joint.size()) throw std::runtime_error("qp_solve_id: contact frame index out of range");
+    const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin;
+    std::vector<double> H(B * n * n, 0.0), g(B * n, 0.0), A(B * neq * n, 0.0), b(B * neq, 0.0), C(B * nin * n, 0.0), l(B * nin, 0.0), u(B * nin, 1e5);
+    for (size_t bi = 0; bi < B; ++bi) {
+      double* Hb = H.data() + bi * n * n; double* Ab = A.data() + bi * neq * n; double* bb = b.data() + bi * neq;
+      double* Cb = C.data() + bi * nin * n; double* lb = l.data() + bi * nin;
+      for (int i = 0; i < nv; ++i) Hb[(size_t)i * n + i] = weights[0];
+      for (int i = 0; i < 6 * nk; ++i) Hb[(size_t)(nv + i) * n + nv + i] = weights[1];
+      const double* a0 = acc + bi * nv; const double* f0 = forces + bi * 6 * nk; const int32_t* cs = contact_states + bi * nk;
+      State<double> st = state_from_x(m, xrob + bi * (nq + nv));
+      Kin<double> k;
+      std::vector<double> nle(nv), g0(nv), col(nv), e(nv, 0.0);
+      forward_pass<double>(m, st, nullptr, k, true);
+      rnea_backward<double>(m, k, nullptr, nle.data());
+      State<double> s0 = st; std::fill(s0.v.begin(), s0.v.end(), 0.0);
+      forward_pass<double>(m, s0, nullptr, k, true);
+      rnea_backward<double>(m, k, nullptr, g0.data());
+      std::vector<double> Mm((size_t)nv * nv);
+      for (int c = 0; c < nv; ++c) {
+        e[c] = 1.0;
+        forward_pass<double>(m, s0, e.data(), k, true);
+        rnea_backward<double>(m, k, nullptr, col.data());
+        for (int r = 0; r < nv; ++r) Mm[(size_t)r * nv + c] = col[r] - g0[r];
+        e[c] = 0.0;
+      }
+      std::vector<double> Jc((size_t)6 * nk * nv, 0.0), gamma(6 * nk, 0.0);
+      for (int c = 0; c < nk; ++c) {
+        if (!cs[c]) continue;
+        const int fj = m.frame_joint[frames[c]];
+        const SE3<double>& pl = m.frame_pl[frames[c]];
+        for (int kk = 0; kk < nv; ++kk) {
+          State<double> se = s0; se.v[kk] = 1.0;
+          forward_pass<double>(m, se, nullptr, k, false);
+          const Mot<double> vf = actInv(pl, k.v[fj]);
+          for (int r = 0; r < 3; ++r) { Jc[(size_t)(6 * c + r) * nv + kk] = vf.lin[r]; Jc[(size_t)(6 * c + 3 + r) * nv + kk] = vf.ang[r]; }
+        }
+        forward_pass<double>(m, st, nullptr, k, false);
+        const Mot<double> af = actInv(pl, k.a[fj]), vf = actInv(pl, k.v[fj]);
+        for (int r = 0; r < 3; ++r) { gamma[6 * c + r] = af.lin[r] + kd * (vf.lin[r] + vf.ang[r]); gamma[6 * c + 3 + r] = af.ang[r]; }
+      }
+      for (int r = 0; r < nv; ++r) {
+        double acc_r = -nle[r];
+        for (int c = 0; c < nv; ++c) { Ab[(size_t)r * n + c] = Mm[(size_t)r * nv + c]; acc_r -= Mm[(size_t)r * nv + c] * a0[c]; }
+        for (int c = 0; c < 6 * nk; ++c) { Ab[(size_t)r * n + nv + c] = -Jc[(size_t)c * nv + r]; acc_r += Jc[(size_t)c * nv + r] * f0[c]; }
+        if (r >= 6) Ab[(size_t)r * n + nv + 6 * nk + r - 6] = -1.0;
+        bb[r] = acc_r;
+      }
+      for (int c = 0; c < 6 * nk; ++c) {
+        double v = -gamma[c];
+        for (int kk = 0; kk < nv; ++kk) { Ab[(size_t)(nv + c) * n + kk] = Jc[(size_t)c * nv + kk]; v -= Jc[(size_t)c * nv + kk] * a0[kk]; }
+        bb[nv + c] = v;
+      }
+      for (int c = 0; c < nk; ++c) {
+        if (!cs[c]) continue;
+        for (int r = 0; r < 9; ++r) {
+          double v = 0;
+          for (int j = 0; j < 6; ++j) { Cb[(size_t)(9 * c + r) * n + nv + 6 * c + j] = cone[6 * r + j]; v += cone[6 * r + j] * f0[6 * c + j]; }
+          lb[9 * c + r] = -v;
+        }
+      }
+    }
+    if (A_out) std::memcpy(A_out, A.data(), A.size() * sizeof(double));
+    if (b_out) std::memcpy(b_out, b.data(), b.size() * sizeof(double));
+    if (C_out) std::memcpy(C_out, C.data(), C.size() * sizeof(double));
+    if (l_out) std::memcpy(l_out, l.data(), l.size() * sizeof(double));
+    return mpc_qp_solve(s, S, H.data(), g.data(), A.data(), b.data(), C.data(), l.data(), u.data(), nullptr, nullptr, x, y, z, nullptr, info);
+  } catch (const std::exception& e) { s->err = e.what(); return -1; }
 }
 
 }  // extern "C"

@@ -1,6 +1,7 @@
 """N3 host side on the CPU: the numpy rigid-body terms the QP classes need (against finite differences / energy identities)
 and the IDSolver_ulim mirror end to end on the oracle library (the solution satisfies the dynamics and the cone)."""
 import numpy as np
+import pytest
 
 from tests import _oracle
 from mpc_benchmark_amd import qp_utils
@@ -128,3 +129,46 @@ def test_warm_start_saves_newton_steps():
         assert solver.last_info[0].status == 0
         steps.append(solver.last_info[0].iters_in)
     assert steps[0] >= 2 and steps[1] < steps[0] and steps[2] < steps[0]
+
+
+def _id_cases(model, q0, rng, B):
+    w = 9.81 * pin.computeTotalMass(model)
+    xs, accs, fs, css, items = [], [], [], [], []
+    for i in range(B):
+        v = rng.normal(size=model.nv) * 0.1
+        dq = np.concatenate((rng.normal(size=3) * 0.05, rng.normal(size=3) * 0.1, rng.normal(size=model.nv - 6) * 0.05))
+        q = pin.integrate(model, q0, dq)
+        data = dyn.compute_all_terms(model, model.createData(), q, v)
+        a = rng.normal(size=model.nv) * 0.2
+        cs = [[True, True], [True, False], [False, True]][i % 3]
+        forces = np.array([5, -3, 0.55 * w, 1, -2, 0, -4, 2, 0.45 * w, 0, 1, 0], dtype=float) * np.repeat(np.array(cs, dtype=float), 6)
+        xs.append(np.concatenate((q, v))); accs.append(a); fs.append(forces); css.append(cs)
+        items.append((data, cs, v, a, forces, data.M))
+    return np.array(xs), np.array(accs), np.array(fs), np.array(css, dtype=np.int32), items
+
+
+def test_id_assembly_entry_point_equals_the_host_mirror_on_the_oracle():
+    """mpc_qp_solve_id (the model uploaded once, A, b, C, l built by the library from x, a, forces, contact states): the
+    checker's build of it — RNEA evaluations only — gives the matrices of the numpy mirror of QP_utils.py:120-158 and the
+    same solution."""
+    model, q0 = _model()
+    rng = np.random.default_rng(11)
+    ids = [model.getFrameId("left_sole_link"), model.getFrameId("right_sole_link")]
+    B = 3
+    x, a, f, cs, items = _id_cases(model, q0, rng, B)
+    solver = qp_utils.IDSolver_ulim(model, [1.0, 1e-3], 2, 0.8, 0.1, 0.075, ids, 6, False, library=_oracle.load(), batch=B)
+    solver.qp.settings.eps_abs, solver.qp.settings.max_iter, solver.qp.settings.max_iter_in = 1e-7, 60, 40
+    host = solver.solve_batch(items)
+    dev = solver.solve_batch_device(x, a, f, cs, return_matrices=True)
+    A, b, C, l = dev[3]
+    for i in range(B):
+        Ah, bh, Ch, lh = solver.computeMatrice(*items[i])
+        assert np.max(np.abs(A[i] - Ah)) < 1e-9 * max(1.0, np.max(np.abs(Ah)))
+        assert np.max(np.abs(b[i] - bh)) < 1e-9 * max(1.0, np.max(np.abs(bh)))
+        assert np.array_equal(C[i], Ch) and np.max(np.abs(l[i] - lh)) < 1e-12 * max(1.0, np.max(np.abs(lh)))
+        for k in range(3):
+            assert np.max(np.abs(dev[k][i] - host[i][k])) < 1e-6 * max(1.0, np.max(np.abs(host[i][k])))
+    with pytest.raises(RuntimeError, match="dimensions"):
+        bad = qp_utils.IDSolver_ulim(model, [1.0, 1e-3], 2, 0.8, 0.1, 0.075, ids, 6, False, library=_oracle.load(), batch=1)
+        bad.enable_device_assembly()
+        bad.qp.solve_id(bad._frame_idx[:1], bad._weights, bad.Cmin, 1.0, x[0], a[0], f[0, :6], cs[0, :1])
