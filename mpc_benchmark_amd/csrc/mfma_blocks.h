@@ -323,6 +323,42 @@ DEV bool chol_tiles_wave(double* T, int nb, int lane) {
   }
   return ok;
 }
+// the same by the whole workgroup (nb > 3): diagonal block by wavefront 0, panel and trailing tiles dealt to the wavefronts
+DEV bool chol_tiles(double* T, int nb, int tid, int* flag) {
+  const int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+  if (tid == 0) *flag = 1;
+  __syncthreads();
+  if (nb <= 3) {
+    if (wv == 0) { if (!chol_tiles_wave(T, nb, lane) && lane == 0) *flag = 0; }
+    __syncthreads();
+    return *flag != 0;
+  }
+  for (int kb = 0; kb < nb; ++kb) {
+    double* Dk = ptile(T, kb, kb);
+    if (wv == 0) { if (!chol16_wave(Dk, 17, Dk, lane) && lane == 0) *flag = 0; }
+    __syncthreads();
+    if (*flag == 0) return false;
+    for (int ri = kb + 1 + wv; ri < nb; ri += nw) {
+      double* Pt = ptile(T, ri, kb);
+      d4_t acc = d4_t{0, 0, 0, 0};
+      mma_tile<false>(acc, Pt, 17, 1, Dk, 1, 17, 16, lane);
+      tile_store(Pt, 17, acc, lane);
+    }
+    __syncthreads();
+    const int rem = nb - kb - 1;
+    for (int t = wv; t < rem * (rem + 1) / 2; t += nw) {
+      int ri = 0, acc_t = 0;
+      while (acc_t + ri + 1 <= t) { acc_t += ri + 1; ++ri; }
+      const int cj = t - acc_t;
+      double* Ct = ptile(T, kb + 1 + ri, kb + 1 + cj);
+      d4_t acc = tile_load(Ct, 17, lane);
+      mma_tile<true>(acc, ptile(T, kb + 1 + ri, kb), 17, 1, ptile(T, kb + 1 + cj, kb), 1, 17, 16, lane);
+      tile_store(Ct, 17, acc, lane);
+    }
+    __syncthreads();
+  }
+  return true;
+}
 // B <- L^-1 B / B <- L^-T B on an LDS operand B ((16 nb) x (16 ncb), leading dimension ldb), column blocks dealt to the wavefronts
 DEV void trsm_fwd_tiles(const double* T, int nb, double* Bm, int ldb, int ncb, int wv, int nw, int lane) {
   for (int cj = wv; cj < ncb; cj += nw)

@@ -17,6 +17,7 @@ struct mpc_qp_solver {
   int32_t *d_cs = nullptr, *d_frames = nullptr;
   int id_nk = 0;
   bool id_const_uploaded = false;
+  std::vector<double> id_const;  // weights[2], cone[54], frames[nk] as last uploaded
   std::vector<void*> allocs;
   std::string err;
   template <class T> T* alloc(size_t count) {
@@ -113,6 +114,7 @@ int mpc_qp_solve(mpc_qp_solver* s, const mpc_qp_settings* S, const double* H, co
     if ((d.neq && (!A || !b)) || (d.nin && (!C || !l || !u))) throw std::runtime_error("qp_solve: constraint data missing");
     const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin, m = nin + (d.box ? n : 0);
     auto up = [&](double* dst, const double* src, size_t cnt) { if (cnt) HIP_OK(hipMemcpyAsync(dst, src, cnt * sizeof(double), hipMemcpyHostToDevice, s->stream)); };
+    s->id_const_uploaded = false;  // H, g, u of a later mpc_qp_solve_id are uploaded again
     up(s->dH, H, B * n * n); up(s->dg, g, B * n); up(s->dA, A, B * neq * n); up(s->db, b, B * neq);
     up(s->dC, C, B * nin * n); up(s->dl, l, B * nin); up(s->du, u, B * nin);
     if (d.box) { up(s->dlb, l_box, B * n); up(s->dub, u_box, B * n); }
@@ -173,8 +175,12 @@ int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, cons
       s->id_nk = nk; s->id_const_uploaded = false;
       HIP_OK(hipFuncSetAttribute((const void*)k_qp_assemble_id, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qp_assemble_lds_bytes(s->m_nj, nv, nq, nk)));
     }
-    // the constant parts: H = diag(w0 I_nv, w1 I_6nk, 0), g = 0, u = +inf (1e5 as the reference), frames, cone rows
-    {
+    // the constant parts: H = diag(w0 I_nv, w1 I_6nk, 0), g = 0, u = 1e5 (as the reference), frames, cone rows: uploaded when they change
+    std::vector<double> key(56 + nk);
+    key[0] = weights[0]; key[1] = weights[1];
+    for (int i = 0; i < 54; ++i) key[2 + i] = cone[i];
+    for (int c = 0; c < nk; ++c) key[56 + c] = frames[c];
+    if (!s->id_const_uploaded || key != s->id_const) {
       std::vector<double> H(n * n, 0.0), g(n, 0.0), u(nin, 1e5);
       for (int i = 0; i < nv; ++i) H[(size_t)i * n + i] = weights[0];
       for (int i = 0; i < 6 * nk; ++i) H[(size_t)(nv + i) * n + nv + i] = weights[1];
@@ -186,6 +192,7 @@ int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, cons
       HIP_OK(hipMemcpyAsync(s->d_frames, frames, nk * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
       HIP_OK(hipMemcpyAsync(s->d_cone, cone, 54 * sizeof(double), hipMemcpyHostToDevice, s->stream));
       HIP_OK(hipStreamSynchronize(s->stream));  // (host vectors go out of scope)
+      s->id_const = key; s->id_const_uploaded = true;
     }
     HIP_OK(hipMemcpyAsync(s->d_xrob, xrob, B * (nq + nv) * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipMemcpyAsync(s->d_acc, acc, B * nv * sizeof(double), hipMemcpyHostToDevice, s->stream));

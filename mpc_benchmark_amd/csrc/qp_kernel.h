@@ -27,9 +27,12 @@ static inline QpLds make_qp_lds(int n, int neq, int nin, int m, bool want_mats =
     s.mf = mf ? 1 : 0;
     s.np = (n + 15) & ~15; s.ep = (neq + 15) & ~15; s.ncb = (neq + 1 + 15) / 16;
     if (mf) {
-      s.ldp = s.np + 1; s.ldy = 16 * s.ncb + 1; s.lds = 16 * s.ncb + 1;
-      s.P = take(s.np * s.ldp); s.LIp = take((s.np / 16) * 272); s.Y = take(s.np * s.ldy);
-      s.S = take(16 * s.ncb * s.lds); s.LIs = take((s.ep / 16) * 272); s.ZD = take((s.np > s.ep ? s.np : s.ep) * 17);
+      // P and the Gram matrix G = [Y | w]^T [Y | w] (its leading block becomes S) as the tiles of their lower block triangles
+      // (mfma_blocks.h ptile: 272 doubles each, the inverse of a diagonal factor block replaces the block)
+      const int nbp = s.np / 16;
+      s.ldp = s.lds = 17; s.ldy = 16 * s.ncb + 1; s.LIp = s.LIs = 0;
+      s.P = take(nbp * (nbp + 1) / 2 * 272); s.Y = take(s.np * s.ldy);
+      s.S = take(s.ncb * (s.ncb + 1) / 2 * 272); s.ZD = take((s.np > s.ep ? s.np : s.ep) * 17);
     } else {
       s.ldp = n + 1; s.ldy = neq + 1; s.lds = neq + 1; s.LIp = s.LIs = s.ZD = 0;
       s.P = take(n * (n + 1)); s.Y = take(n * (neq + 1)); s.S = take(neq * (neq + 1));
@@ -140,7 +143,7 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
   const int ldp = a.lds.ldp, lds_ = a.lds.lds, ldy = a.lds.ldy;
   double *Pm = sm + a.lds.P, *Y = sm + a.lds.Y, *Sm = sm + a.lds.S, *v = sm + a.lds.vec;
   const int np = a.lds.np, ep = a.lds.ep, ncb = a.lds.ncb, lane = tid & 63, wv = tid >> 6, nw = QP_THREADS >> 6;
-  double *LIp = sm + a.lds.LIp, *LIs = sm + a.lds.LIs, *ZD = sm + a.lds.ZD;
+  double* ZD = sm + a.lds.ZD;
   // H, A, C: LDS copies when they fit (MATS; every mat-vec below then runs on LDS), else the global arrays (H through its
   // symmetric image so that neighbouring threads read neighbouring addresses)
   const double* H = MATS == 1 ? sm + a.lds.H : Hg;
@@ -233,23 +236,27 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
         if (tid == 0) { int na_ = 0; for (int r = 0; r < nin; ++r) if (zp[r] != 0.0) actl[na_++] = r; flag = na_; }  // active inequality rows (few)
         __syncthreads();
         const int nact = flag;
-        for (int idx = tid; idx < np * np; idx += nthr) {
-          const int j = idx / np, k = idx % np;
+        const int nbp = np >> 4, nbs = ep >> 4;
+        for (int idx = tid; idx < nbp * (nbp + 1) / 2 * 256; idx += nthr) {  // lower block triangle, diagonal tiles in full
+          const int tl = idx >> 8, e = idx & 255;
+          int bi_ = 0;
+          while ((bi_ + 1) * (bi_ + 2) / 2 <= tl) ++bi_;
+          const int j = bi_ * 16 + (e >> 4), k = (tl - bi_ * (bi_ + 1) / 2) * 16 + (e & 15);
           double t = (j == k) ? 1.0 : 0.0;
           if (j < n && k < n) {
             t = H[j * n + k] + (j == k ? S.rho : 0.0);
             for (int q = 0; q < nact; ++q) { const int r = actl[q]; t += C[r * n + j] * C[r * n + k] / mu_in; }
             if (box && j == k && zp[nin + j] != 0.0) t += 1.0 / mu_in;
           }
-          Pm[j * ldp + k] = t;
+          Pm[tl * 272 + (e >> 4) * 17 + (e & 15)] = t;
         }
         for (int idx = tid; idx < 16 * ncb * np; idx += nthr) {  // j fastest: A is read along its rows
           const int i = idx / np, j = idx % np;
           Y[j * ldy + i] = (j < n) ? ((i < neq) ? A[i * n + j] : (i == neq ? r1[j] : 0.0)) : 0.0;
         }
         __syncthreads();
-        if (!chol_blocked(Pm, ldp, np / 16, LIp, tid, &flag)) { status = 2; goto done; }
-        trsm_fwd_blocked(Pm, ldp, LIp, np / 16, Y, ldy, ncb, wv, nw, lane);   // [Y | w] <- L^-1 [A^T | r1]
+        if (!chol_tiles(Pm, nbp, tid, &flag)) { status = 2; goto done; }
+        trsm_fwd_tiles(Pm, nbp, Y, ldy, ncb, wv, nw, lane);   // [Y | w] <- L^-1 [A^T | r1]
         __syncthreads();
         for (int j = tid; j < n; j += nthr) w[j] = Y[j * ldy + neq];
         // G = [Y | w]^T [Y | w] (lower block triangle): S = mu_eq I + G[:neq, :neq], Y^T w = G[neq, :neq]
@@ -260,26 +267,25 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
             while (rem > ri) { rem -= ri + 1; ++ri; }
             d4_t acc = d4_t{0, 0, 0, 0};
             mma_tile<false>(acc, Y + ri * 16, 1, ldy, Y + rem * 16, ldy, 1, np, lane);
-            tile_store(Sm + (ri * 16) * lds_ + rem * 16, lds_, acc, lane);
+            tile_store(ptile(Sm, ri, rem), 17, acc, lane);
           }
         }
         __syncthreads();
-        for (int i = tid; i < neq; i += nthr) yplus[i] = Sm[neq * lds_ + i] + Ax[i] + mu_eq * y[i];  // row neq of G (lower triangle: column index i <= neq)
+        for (int i = tid; i < neq; i += nthr) yplus[i] = ctile(Sm, neq >> 4, i >> 4)[(neq & 15) * 17 + (i & 15)] + Ax[i] + mu_eq * y[i];  // row neq of G
         __syncthreads();
-        for (int idx = tid; idx < ep * ep; idx += nthr) {  // S proper: mu_eq on the diagonal, identity padding, symmetric image
-          const int i = idx / ep, k = idx % ep;
-          if (k <= i) {
-            const double t = (i < neq) ? Sm[i * lds_ + k] + (i == k ? mu_eq : 0.0) : (i == k ? 1.0 : 0.0);
-            Sm[i * lds_ + k] = t;
-          }
+        for (int idx = tid; idx < nbs * (nbs + 1) / 2 * 256; idx += nthr) {  // S proper: mu_eq on the diagonal, identity padding
+          const int tl = idx >> 8, e = idx & 255;
+          int bi_ = 0;
+          while ((bi_ + 1) * (bi_ + 2) / 2 <= tl) ++bi_;
+          const int i = bi_ * 16 + (e >> 4), k = (tl - bi_ * (bi_ + 1) / 2) * 16 + (e & 15);
+          double* el = Sm + tl * 272 + (e >> 4) * 17 + (e & 15);
+          *el = (i < neq && k < neq) ? *el + (i == k ? mu_eq : 0.0) : (i == k ? 1.0 : 0.0);
         }
-        __syncthreads();
-        for (int idx = tid; idx < ep * ep; idx += nthr) { const int i = idx / ep, k = idx % ep; if (k > i) Sm[i * lds_ + k] = Sm[k * lds_ + i]; }
         for (int idx = tid; idx < ep * 16; idx += nthr) { const int i = idx >> 4, c = idx & 15; ZD[i * 17 + c] = (c == 0 && i < neq) ? yplus[i] : 0.0; }
         __syncthreads();
-        if (!chol_blocked(Sm, lds_, ep / 16, LIs, tid, &flag)) { status = 2; goto done; }
-        trsm_fwd_blocked(Sm, lds_, LIs, ep / 16, ZD, 17, 1, wv, nw, lane);
-        trsm_bwd_blocked(Sm, lds_, LIs, ep / 16, ZD, 17, 1, wv, nw, lane);   // (one column block: wavefront 0, its LDS operations in order)
+        if (!chol_tiles(Sm, nbs, tid, &flag)) { status = 2; goto done; }
+        trsm_fwd_tiles(Sm, nbs, ZD, 17, 1, wv, nw, lane);
+        trsm_bwd_tiles(Sm, nbs, ZD, 17, 1, wv, nw, lane);   // (one column block: wavefront 0, its LDS operations in order)
         __syncthreads();
         for (int i = tid; i < neq; i += nthr) yplus[i] = ZD[i * 17];
         __syncthreads();
@@ -290,7 +296,7 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
           ZD[j * 17 + c] = t;
         }
         __syncthreads();
-        trsm_bwd_blocked(Pm, ldp, LIp, np / 16, ZD, 17, 1, wv, nw, lane);    // dx = L^-T (w - Y yplus)
+        trsm_bwd_tiles(Pm, nbp, ZD, 17, 1, wv, nw, lane);    // dx = L^-T (w - Y yplus)
         __syncthreads();
         for (int j = tid; j < n; j += nthr) dx[j] = ZD[j * 17];
         __syncthreads();
