@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--closed-loop", action="store_true",
                     help="measured states from the simulation stand-in (10 x 1 ms of knot 0's dynamics under the feedback law, N2) "
                          "instead of perfect-model feedback; the simulation runs inside the timed region")
+    ap.add_argument("--iters-per-tick", type=int, default=1,
+                    help="ProxDDP iterations per MPC tick: 1 = the reference loop (solver.max_iters = 1, fulldynamic_talos.py:407); 2 = the setting that "
+                         "keeps every randomised instance stable over the whole 1000-tick schedule (DESIGN.md §5).  The default run also reports a walk measurement with 2.")
     ap.add_argument("--legs", type=int, default=4,
                     help="legs of the parallel-in-time Riccati sweep (mpc_options.riccati_legs: linear_solver_choice = LQ_SOLVER_PARALLEL of "
                          "fulldynamic_talos.py:383; the script's setNumThreads(8) is a CPU thread count — 64 instances x 4 legs fill the 256 CUs); "
@@ -144,13 +147,15 @@ def main():
         raise RuntimeError("bench.py measures the HIP library only")
     pd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
     nshard = max(1, min(args.streams, args.batch))
-    def measure(walk):
+    def measure(walk, iters=args.iters_per_tick):
         """One measurement of the ensemble tick: frozen foot references (walk = False) or the reference loop's per-tick problem
         updates (walk = True: FootTrajectory.updateTrajectory + 2 N setReference + terminal rebuild, EnsembleMPC.enable_walk)."""
         # SURVEY.md §8d config 5: ONE ensemble of batch x world instances (one rng stream, instance order), instance i on GPU i mod G
         shards = make_bench_shards(pd, lib, args.batch, rank=rank, world=world, streams=args.streams, device=local_rank, legs=args.legs,
                                    tick_reuse=not args.no_tick_reuse, closed_loop=((10, pd.dt / 10) if args.closed_loop else None))
         ens = shards[0]
+        for e in shards:
+            e.iters_per_tick = int(iters)
         legs = int(ens.options.riccati_legs)
         # Walk mode: the generator REPLANS from the measured poses during the T_ds ticks before every take-off (27 % of the ticks of
         # the schedule: T_ds / (T_ds + T_ss)) — on those every knot's reference changes and nothing of the previous tick can be
@@ -371,6 +376,9 @@ def main():
         return (args.batch * args.steps - m["nostep"]) * world / m["elapsed"]
     head = min(runs, key=lambda w: rate(runs[w]))
     mres = runs[head]
+    # supplementary: the walk with two iterations per tick, the setting under which all 64 randomised instances walk the whole schedule
+    if args.iters_per_tick == 1 and not args.no_walk and world == 1:
+        runs["walk_two_iterations_per_tick"] = measure(True, iters=2)
     shards, ens, legs, cold, n_conv, pace, stagger, elapsed, prof, warm, gather = (mres[k] for k in ("shards", "ens", "legs", "cold", "n_conv", "pace", "stagger", "elapsed", "prof", "warm", "gather"))
     nostep = {"n": mres["nostep"]}
     if rank != 0:
@@ -521,8 +529,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "timed_regions": mres["regions"], "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "Talos full-dynamics MPC (fulldynamic_talos.py OCP), synthetic Talos %s model nq=%d nv=%d nu=%d, "
-                               "horizon N=%d, ensemble of %d instances per GPU, one ProxDDP iteration per solve (max_iters=1, warm start)"
-                               % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch),
+                               "horizon N=%d, ensemble of %d instances per GPU, %d ProxDDP iteration(s) per solve (max_iters=%d, warm start)"
+                               % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch, args.iters_per_tick, args.iters_per_tick),
                    "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "riccati_legs": legs, "tick_reuse": not args.no_tick_reuse, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
         "p50_ms_per_solve_batch1": p50_ms, "p50_riccati_legs": (args.latency_legs if args.legs != 1 else 1),
@@ -530,7 +538,7 @@ def main():
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
         "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; largest primal / dual infeasibility of the others: %.2e)" % (n_conv, args.batch, mres["worst_unconv"]),
         "tick_mode": ("walk: foot references regenerated and patched every tick (fulldynamic_talos.py:444-510)" if head else "frozen foot references"),
-        "measurements": {("walk" if w else "frozen_references"): {"value": round(rate(r), 2), "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 4),
+        "measurements": {(w if isinstance(w, str) else ("walk" if w else "frozen_references")): {"value": round(rate(r), 2), "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 4),
                                                                   "replanning_ticks": r["replanning_ticks"],
                                                                   "kernel_ms_per_step_warmup": {k: round(v[1] / max(1, args.warmup), 4) for k, v in sorted(r["warm"].items(), key=lambda kv: -kv[1][1])[:6]}}
                          for w, r in runs.items()},

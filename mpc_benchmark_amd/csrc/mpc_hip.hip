@@ -43,6 +43,7 @@ struct mpc_solver {
   double *d_knots = nullptr, *d_tknots = nullptr, *d_gains = nullptr, *d_work = nullptr, *d_trial_phi = nullptr, *d_mbwork = nullptr;
   InstState* d_inst = nullptr;
   int* d_all_done = nullptr;
+  int async_passes[2] = {1, 1};  // passes enqueued by mpc_run_shifted_async per slot in flight
   double* d_prof = nullptr;
   bool phase_timers = false;
   std::vector<void*> allocs;
@@ -54,9 +55,9 @@ struct mpc_solver {
   bool have_model = false;
   size_t mb_work_stride = 0;
   bool perfect_feedback = false;
-  int async_passes = 0;
   // tick reuse (mpc_set_tick_reuse): see SolverArgs
-  bool tick_reuse = false, reuse_this_pass = false;
+  bool tick_reuse = false, reuse_this_pass = false, reuse_same_now = false;
+  int pass_in_run = 0;  // index of the pass being enqueued within its run
   // speculative evaluation of the appended knot (eval_multibody.h): the spare records hold one made with the table of the then last
   // stage (spec_rec_valid) ; the stage appended since is that table (spec_next_pending, set by mpc_cycle) ; this pass may use it
   double* d_spec_knot = nullptr;
@@ -163,9 +164,13 @@ struct mpc_solver {
     a.xs = d_xs; a.us = d_us; a.vs = d_vs; a.lams = d_lams; a.vs_e = d_vs_e; a.lams_e = d_lams_e; a.x0 = d_x0;
     a.dxs = d_dxs; a.dus = d_dus; a.dvs = d_dvs; a.dlams = d_dlams; a.abdz = nullptr;
     a.khead = khead; a.spec = d_spec;
-    a.spec_on = (tick_reuse && opt.max_iters == 1 && L.space == MPC_SPACE_MULTIBODY && !spec_skip_pass) ? 1 : 0;
-    a.reuse_on = (a.spec_on && reuse_this_pass) ? 1 : 0;
+    // an MPC tick: one iteration (the reference loop) or a few (max_iters <= 4).  The last pass of a replanning tick (spec_skip_pass)
+    // evaluates its candidate value-only; its first pass reuses nothing.
+    const bool mpc_tick = tick_reuse && opt.max_iters <= 4 && L.space == MPC_SPACE_MULTIBODY;
+    a.spec_on = (mpc_tick && !(spec_skip_pass && pass_in_run >= opt.max_iters - 1)) ? 1 : 0;
+    a.reuse_on = (mpc_tick && reuse_this_pass && !(spec_skip_pass && pass_in_run == 0)) ? 1 : 0;
     a.reuse_k0 = perfect_feedback ? 1 : 0;
+    a.reuse_same = (a.reuse_on && reuse_same_now) ? 1 : 0;
     a.spec_knot = a.spec_on ? d_spec_knot : nullptr; a.spec_next = (a.reuse_on && spec_next_now) ? 1 : 0;
     for (int w = 0; w < MPC_DIRTY_WORDS; ++w) a.dirty[w] = a.reuse_on ? dirty_now[w] : 0ull;
     a.nlegs = eff_legs(); a.legbuf = d_legbuf; a.treebuf = d_treebuf; a.leg_guess = leg_guess_now;
@@ -481,11 +486,16 @@ static void launch_eval(mpc_solver* s, bool trial, int cand0 = 0, int ncand = 1,
 // one pass of the inner loop for every instance that is not done
 static void launch_pass(mpc_solver* s) {
   const Layout& L = s->L;
+  if (s->pass_in_run > 0 && s->tick_reuse && s->opt.max_iters <= 4) {
+    // a further iteration of the same tick: instances whose full step was accepted find their records already written, for the same knots
+    s->reuse_this_pass = true; s->reuse_same_now = true;
+    for (int w = 0; w < MPC_DIRTY_WORDS; ++w) s->dirty_now[w] = 0ull;
+  }
   SolverArgs a = s->args();
   if (a.spec_next) hipLaunchKernelGGL(k_copy_spec, dim3(32, L.B), dim3(256), 0, s->stream, a);  // the appended knot: evaluated speculatively by the previous tick
   s->timed(0, "k_eval_stage", [&] { launch_eval(s, false); });
   if (a.reuse_on) hipLaunchKernelGGL(k_reproject, dim3(L.N + 1, L.B), dim3(256), 0, s->stream, a);  // records kept from the last tick: fresh projections
-  s->reuse_this_pass = false;  // further passes of the same run evaluate everything
+  s->reuse_this_pass = false; s->reuse_same_now = false;
   s->spec_next_now = false;
   s->timed(1, "k_lagrangian", [&] { hipLaunchKernelGGL(k_lagrangian, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   s->timed(2, "k_decide", [&] { hipLaunchKernelGGL(k_decide, dim3(L.B), dim3(128), 0, s->stream, a); });
@@ -632,7 +642,7 @@ static void run_impl(mpc_solver* s, mpc_stats* stats, int passes_enqueued = 0) {
   const int max_passes = s->opt.max_iters + s->opt.max_al_iters + 1;
   std::vector<InstState> st(L.B);
   for (int pass = 0; pass < max_passes; ++pass) {
-    if (pass >= passes_enqueued) launch_pass(s);
+    if (pass >= passes_enqueued) { s->pass_in_run = pass; launch_pass(s); }
     else if (pass + 1 < passes_enqueued) continue;  // only the flag of the last enqueued pass is meaningful
     // one read-back per pass: the per-instance status (the device-side all_done flag says the same as "every done != 0")
     copy_sync(s, st.data(), s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost);
@@ -1100,8 +1110,11 @@ int mpc_run_shifted_async(mpc_solver* s) {
     begin_reuse_pass(s);
     launch_shift(s);
     hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, s->args());
-    // with max_iters = 1 one pass takes the step
-    launch_pass(s);
+    // with max_iters = 1 one pass takes the step; a few iterations per tick (max_iters <= 4) are enqueued together — a younger tick
+    // may be queued behind this one before its status is read; workgroups of instances that are done exit at once
+    const int n_pass = s->opt.max_iters < 1 ? 1 : (s->opt.max_iters > 4 ? 4 : s->opt.max_iters);
+    for (int p = 0; p < n_pass; ++p) { s->pass_in_run = p; launch_pass(s); }
+    s->async_passes[slot] = n_pass;
     HIP_OK(hipMemcpyAsync(s->h_status[slot], s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost, s->stream));
     // xs[1] of every instance — the state the next tick will take as its measurement under perfect-model feedback, and what a
     // reference generator needs to plan that tick (mpc_wait_state) — rides along: B rows of nx doubles out of the iterate
@@ -1137,7 +1150,7 @@ static void wait_impl(mpc_solver* s, mpc_stats* stats, double* x_next) {
   bool done = true;
   for (int b = 0; b < L.B; ++b) if (!st[b].done) done = false;
   if (!done && s->async_pending == 0) {
-    run_impl(s, stats, 1);  // continues from pass 1: the enqueued pass 0 is complete
+    run_impl(s, stats, s->async_passes[slot]);  // continues after the enqueued passes, which are complete
     if (x_next) {
       HIP_OK(hipMemcpy2DAsync(x_next, (size_t)L.nx * sizeof(double), s->d_xs + L.nx, (size_t)(L.N + 1) * L.nx * sizeof(double),
                               (size_t)L.nx * sizeof(double), (size_t)L.B, hipMemcpyDeviceToHost, s->stream));
@@ -1249,7 +1262,15 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
     std::vector<double> v;
     auto mat = [&](const double* src, int rows, int cols, int ld) { v.resize((size_t)rows * cols); for (int i = 0; i < rows; ++i) for (int j = 0; j < cols; ++j) v[(size_t)i * cols + j] = src[(size_t)i * ld + j]; };
     auto dev_vec = [&](const double* d_ptr, int len) { v.resize(len); copy_sync(s, v.data(), d_ptr, len * sizeof(double), hipMemcpyDeviceToHost); };
-    if (nm == "H") mat(kn.data() + L.oH, nzk, nzk, nz);
+    if (nm == "ls") {  // linesearch of the last pass: phi0, dphi0, alpha, backtracking steps, then the merit of every candidate alpha_i = 2^-i (sum over the knots; candidates > 0 only if the pass backtracked)
+      InstState st;
+      copy_sync(s, &st, s->d_inst + b, sizeof(InstState), hipMemcpyDeviceToHost);
+      std::vector<double> tp((size_t)L.n_alpha * (L.N + 1));
+      copy_sync(s, tp.data(), s->d_trial_phi + (size_t)b * L.n_alpha * (L.N + 1), tp.size() * sizeof(double), hipMemcpyDeviceToHost);
+      v = {st.phi0, st.dphi0, st.alpha, (double)st.ls_step};
+      for (int i = 0; i < L.n_alpha; ++i) { double t = 0; for (int kk = 0; kk <= L.N; ++kk) t += tp[(size_t)i * (L.N + 1) + kk]; v.push_back(t); }
+    }
+    else if (nm == "H") mat(kn.data() + L.oH, nzk, nzk, nz);
     else if (nm == "grad") mat(kn.data() + L.oG, 1, nzk, nz);
     else if (nm == "AB") mat(kn.data() + L.oAB, k < L.N ? n : 0, nzk, nz);
     else if (nm == "f") mat(kn.data() + L.oF, 1, k < L.N ? n : 0, n);

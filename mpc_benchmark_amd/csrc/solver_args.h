@@ -28,6 +28,7 @@ struct SolverArgs {
   int spec_on;    // the alpha = 1 candidate of this pass writes full records (k_eval_multibody<3>)
   int reuse_on;   // this tick may reuse records marked valid in spec[]
   int reuse_k0;   // ... knot 0 included (perfect-model feedback: the measured state is the predicted one)
+  int reuse_same; // a further pass of the same run: the records were written by the previous pass's full-step candidate for these very knots (no shift in between)
   int* spec;      // [B] 1: the records of instance b hold the evaluation of its current iterate shifted by one knot
   double* abdz;  // [B][N][n]: [A B] [dx; du] per knot, written by the forward sweep for k_duals (nullptr: k_duals forms it itself)
   double *knots, *gains, *work;
@@ -62,6 +63,7 @@ DEV double* knot_ptr(const SolverArgs& a, int b, int k) { return a.knots + ((siz
 DEV bool knot_reused(const SolverArgs& a, int b, int k) {
   if (!(a.reuse_on && a.spec[b])) return false;
   if ((a.dirty[(k >> 6) & (MPC_DIRTY_WORDS - 1)] >> (k & 63)) & 1ull) return false;
+  if (a.reuse_same) return true;
   if (k < a.L.N - 1) return k > 0 || a.reuse_k0;
   return a.spec_next != 0;
 }

@@ -63,6 +63,9 @@ class EnsembleMPC:
         # integrated under the feedback law of the low-level loop) instead of the model's own prediction xs[1]
         self.closed_loop = closed_loop
         self.tick = 0
+        # ProxDDP iterations per MPC tick: 1 is the reference loop (fulldynamic_talos.py:407) ; 2 keeps randomised ensembles of the synthetic
+        # robot stable over the whole schedule
+        self.iters_per_tick = 1
         self.inflight = 0   # asynchronous ticks enqueued and not yet collected (step_async / wait)
         self._walk = None   # enable_walk(): the reference loop's per-tick problem updates
 
@@ -97,7 +100,7 @@ class EnsembleMPC:
         self.native.set_x0(self.x0)
         self.native.setup()
         stats = self.native.run(xs, us)
-        self.options.max_iters = 1
+        self.options.max_iters = self.iters_per_tick
         self.native.set_options(self.options)
         self.native.set_x0(None)  # perfect-model feedback from here on
         return stats

@@ -44,6 +44,45 @@ def test_walk_with_tick_reuse_is_bit_identical_to_the_plain_path(hip_lib):
         assert np.array_equal(res[True][key], res[False][key]), key
 
 
+def test_two_iterations_per_tick_with_tick_reuse_are_bit_identical_to_the_plain_path(hip_lib):
+    """``iters_per_tick = 2`` (the robust setting of the ensemble driver): the second pass of a tick takes the records the first pass's
+    accepted full-step candidate wrote for the same knots, the first pass of the next tick those of the second — same bits as evaluating
+    everything every pass.  Two ticks in flight, walk mode (replanning and frozen ticks)."""
+    res = {}
+    for reuse in (True, False):
+        pd = FullDynamicsProblem(horizon=40, complete_model=True)
+        (e,) = make_bench_shards(pd, hip_lib, 8, legs=4, tick_reuse=reuse)
+        e.iters_per_tick = 2
+        e.prepare_schedule(40)
+        e.cold_solve(max_iters=100)
+        e.enable_walk()
+        _pipelined(e, 30)
+        res[reuse] = (e.results(gains=True), [int(s.num_iters) for s in e.native.wait()])
+    assert res[True][1] == res[False][1] == [2] * 8
+    for key in ("xs", "us", "K"):
+        assert np.array_equal(res[True][0][key], res[False][0][key]), key
+
+
+def test_two_iterations_per_tick_match_oracle(hip_lib, oracle_lib):
+    traj = {}
+    for name, lib in (("hip", hip_lib), ("ref", oracle_lib)):
+        pd = FullDynamicsProblem(horizon=12)
+        e = EnsembleMPC(pd, batch=2, library=lib, seed=5, sigma_q=0.005, sigma_v=0.01, tick_reuse=(name == "hip"))
+        e.options.tol = 0.0
+        e.iters_per_tick = 2
+        e.prepare_schedule(40)
+        e.cold_solve(max_iters=10)
+        hist = []
+        for _ in range(25):
+            st = e.step()
+            assert all(s.num_iters == 2 for s in st)
+            r = e.results(gains=False)
+            hist.append(np.concatenate([r["xs"].reshape(2, -1), r["us"].reshape(2, -1)], axis=1))
+        traj[name] = np.array(hist)
+    err = rel_cols(traj["hip"].reshape(-1, traj["hip"].shape[-1]), traj["ref"].reshape(-1, traj["ref"].shape[-1]), 1e-3)
+    assert err < 1e-6, err
+
+
 def test_walk_matches_oracle(hip_lib, oracle_lib):
     traj = {}
     for name, lib in (("hip", hip_lib), ("ref", oracle_lib)):
