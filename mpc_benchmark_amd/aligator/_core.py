@@ -28,7 +28,10 @@ def _vec(a, n=None):
 
 
 def _se3_flat(M):
-    return np.concatenate((np.asarray(M.rotation, dtype=float).reshape(-1), np.asarray(M.translation, dtype=float).reshape(-1)))
+    out = np.empty(12)
+    out[:9] = np.asarray(M.rotation, dtype=float).reshape(-1)
+    out[9:] = np.asarray(M.translation, dtype=float).reshape(-1)
+    return out
 
 
 class _Owned:
@@ -72,7 +75,7 @@ class _Owned:
             if (node._lowered is not None and not node._dirty and flat.size == size and self._owner_node() is node
                     and off + size <= node._lowered[1].size):
                 tab = node._lowered[1]
-                if not np.array_equal(tab[off:off + size], flat):  # an unchanged reference (most of the 2 N per tick) costs a compare
+                if (tab[off:off + size] != flat).any():  # an unchanged reference (most of the 2 N per tick) costs a compare
                     tab[off:off + size] = flat
                     node._patches.append((off, size))
                 return
@@ -216,7 +219,21 @@ class FramePlacementResidual(_FrameFunction):
 
     def setReference(self, ref):
         self._ref = ref.copy()
-        self._reference_changed(self._ref_flat())
+        # the 2 N calls per tick of the MPC loops (fulldynamic_talos.py:461-463): _reference_changed's fast path without building the
+        # flat 12-vector — rotation and translation are compared with, and written into, the parameter table where they lie
+        slot = getattr(self, "_slot", None)
+        if slot is not None:
+            node, off, size = slot
+            low = node._lowered
+            if low is not None and not node._dirty and size == 12 and off + 12 <= low[1].size and self._owner_node() is node:
+                seg = low[1][off:off + 12]
+                Rf, tr = np.asarray(self._ref.rotation, dtype=float).reshape(-1), np.asarray(self._ref.translation, dtype=float).reshape(-1)
+                if (seg[:9] != Rf).any() or (seg[9:] != tr).any():
+                    seg[:9] = Rf
+                    seg[9:] = tr
+                    node._patches.append((off, 12))
+                return
+        self._touch()
 
     def getReference(self):
         return self._ref

@@ -158,6 +158,7 @@ class SolverProxDDP:
         self.force_initial_condition = False
         self.reg_init = 1e-9
         self.num_threads = 1
+        self.riccati_legs = None  # None: chosen by _legs()
         self.batch = 1
         self.results = Results()
         self.workspace = None
@@ -168,6 +169,9 @@ class SolverProxDDP:
         self._dims = None
         self._ctx = None
         self._uploaded = None
+        self._opts_raw = None         # option block as last sent to the library
+        self._cycles_since_run = 0    # stages rotated in (replaceStageCircular) since the last run
+        self._last_results = None
 
     def setNumThreads(self, n):
         self.num_threads = int(n)
@@ -180,8 +184,19 @@ class SolverProxDDP:
         o.force_initial_condition = 1 if self.force_initial_condition else 0
         o.rollout_linear = 1 if self.rollout_type == ROLLOUT_LINEAR else 0
         o.num_threads = self.num_threads
-        o.riccati_legs = self.num_threads if self.linear_solver_choice == LQ_SOLVER_PARALLEL else 1
+        o.riccati_legs = self._legs() if self.linear_solver_choice == LQ_SOLVER_PARALLEL else 1
         return o
+
+    def _legs(self):
+        """LQ_SOLVER_PARALLEL + setNumThreads(n) (fulldynamic_talos.py:383-385) asks for a parallel-in-time sweep; how many legs is the
+        backend's business.  The CPU libraries take one leg per thread.  On the GPU the number of host threads means nothing: the
+        sweep of one instance is fastest in 32 legs, an ensemble that fills the device by itself in fewer —
+        256 / batch, at least 4.  ``solver.riccati_legs = n`` overrides.  Same KKT system either way: results equal up to round-off."""
+        if self.riccati_legs is not None:
+            return int(self.riccati_legs)
+        if self._native is not None and self._native.backend.startswith("hip"):
+            return max(4, min(32, 256 // max(1, int(self.batch))))
+        return self.num_threads
 
     # -- lowering / device sync -----------------------------------------------------------------
     def _lower_node(self, node, cost, dynamics, constraints):
@@ -239,13 +254,23 @@ class SolverProxDDP:
             d.device = 0
             self._dims = d
             self._native = K.NativeSolver(self._lib, d)
+            self._reuse_on = False
             self._problem = problem
+            self._opts_raw = None
+            self._last_results = None
             self._uploaded = [None] * (N + 1)
             self.workspace = Workspace(self)
             self._model_uploaded = False
-        self._native.set_options(self._options())
+        self._send_options()
         self._sync(problem)
         self._native.setup()
+
+    def _send_options(self):
+        o = self._options()
+        raw = bytes(o)
+        if raw != self._opts_raw:  # (setup and run of every tick would otherwise each cost a call and, in the library, a reuse reset)
+            self._native.set_options(o)
+            self._opts_raw = raw
 
     def _sync(self, problem):
         """Bring the device copy of the stage tables up to date with the Python objects."""
@@ -261,6 +286,7 @@ class SolverProxDDP:
         for st in problem._cycled:
             desc, params = st._lowered
             nat.cycle(desc, params)
+            self._cycles_since_run += 1
             self._uploaded = self._uploaded[1:N] + [(desc, params), self._uploaded[N]]
         problem._cycled = []
         # 2. dirty nodes: re-lower; upload the parameter table, or the whole stage if its structure changed
@@ -296,12 +322,32 @@ class SolverProxDDP:
         if self._native is None or self._problem is not problem:
             raise RuntimeError("call solver.setup(problem) before solver.run")
         d = self._dims
-        self._native.set_options(self._options())
+        nat = self._native
+        self._send_options()
         self._sync(problem)
-        self._native.set_x0(problem.x0_init)
-        xs = np.array([np.asarray(x, dtype=float) for x in xs_init]).reshape(d.horizon + 1, d.nx)
-        us = np.array([np.asarray(u, dtype=float) for u in us_init]).reshape(d.horizon, d.nu)
-        stats = self._native.run(xs, us)
+        xs = np.asarray(xs_init, dtype=float).reshape(d.horizon + 1, d.nx)
+        us = np.asarray(us_init, dtype=float).reshape(d.horizon, d.nu)
+        x0 = np.asarray(problem.x0_init, dtype=float).reshape(-1)
+        cycles, self._cycles_since_run = self._cycles_since_run, 0
+        prev = self._last_results
+        # The MPC loops pass the previous solution shifted by one knot, after one replaceStageCircular (fulldynamic_talos.py:532-540).
+        # The device still holds that solution: it shifts it itself (nothing to upload) and, on multibody problems, reuses the
+        # evaluation its last accepted full step left behind (tick reuse: bit-identical to evaluating afresh, include/mpc_abi.h).
+        shifted = (prev is not None and cycles == 1 and self.max_iters <= 4 and d.batch == 1
+                   and np.array_equal(xs[1:-1], prev["xs"][0][2:]) and np.array_equal(xs[-1], prev["xs"][0][-1])
+                   and np.array_equal(us[:-1], prev["us"][0][1:]) and np.array_equal(us[-1], prev["us"][0][-1]))
+        if shifted:
+            if not self._reuse_on and d.space == K.SPACE_MULTIBODY:
+                # from the first shifted run on (a handle that only ever gets plain runs keeps its records as the evaluation of the
+                # iterate, which is what the phase dumps of the parity tests read)
+                nat.set_tick_reuse(True)
+                self._reuse_on = True
+            predicted = np.array_equal(x0, prev["xs"][0][1])  # perfect-model feedback: knot 0 is reused as well
+            nat.set_x0(None if predicted else x0)
+            stats = nat.run_shifted()
+        else:
+            nat.set_x0(x0)
+            stats = nat.run(xs, us)
         self._fetch(stats)
         return bool(self.results.conv)
 

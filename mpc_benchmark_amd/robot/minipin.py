@@ -114,7 +114,9 @@ class SE3:
         return SE3()
 
     def copy(self):
-        return SE3(self.rotation.copy(), self.translation.copy())
+        c = SE3.__new__(SE3)
+        c.rotation, c.translation = self.rotation.copy(), self.translation.copy()
+        return c
 
     def __mul__(self, other):
         return SE3(self.rotation @ other.rotation, self.rotation @ other.translation + self.translation)
@@ -371,16 +373,81 @@ def _joint_transform(jm, q):
     return SE3(exp3(w), np.zeros(3))
 
 
+_AXIS = {"JointModelRX": 0, "JointModelRY": 1, "JointModelRZ": 2}
+
+
+def _se3_raw(R, p):
+    M = SE3.__new__(SE3)
+    M.rotation, M.translation = R, p
+    return M
+
+
 def forwardKinematics(model, data, q, v=None):
+    # (plain 3 x 3 arrays in the loop: the MPC loops call this every tick for the measured foot poses)
+    q = np.asarray(q, dtype=float)
+    cq, sq = np.cos(q), np.sin(q)
+    oMi = data.oMi
     for i in range(1, model.njoints):
-        liMi = model.jointPlacements[i] * _joint_transform(model.joints[i], q)
+        jm, pl = model.joints[i], model.jointPlacements[i]
+        k = jm.shortname()
+        if k == "JointModelFreeFlyer":
+            R = pl.rotation @ quat_to_rot(q[jm.idx_q + 3: jm.idx_q + 7])
+            t = pl.rotation @ q[jm.idx_q: jm.idx_q + 3] + pl.translation
+        else:
+            a = _AXIS[k]
+            b, d = (a + 1) % 3, (a + 2) % 3
+            c_, s_ = cq[jm.idx_q], sq[jm.idx_q]
+            P = pl.rotation
+            R = np.empty((3, 3))
+            R[:, a] = P[:, a]                       # P @ Rot(axis a, angle): the axis column stays,
+            R[:, b] = c_ * P[:, b] + s_ * P[:, d]   # the other two rotate into each other
+            R[:, d] = c_ * P[:, d] - s_ * P[:, b]
+            t = pl.translation
         p = model.parents[i]
-        data.oMi[i] = liMi if p == 0 else data.oMi[p] * liMi
+        if p != 0:
+            Mp = oMi[p]
+            t = Mp.rotation @ t + Mp.translation
+            R = Mp.rotation @ R
+        elif t is pl.translation:
+            t = t.copy()
+        oMi[i] = _se3_raw(R, t)
+    if isinstance(data.oMf, _LazyFrames):
+        data.oMf.invalidate()
+
+
+class _LazyFrames:
+    """``data.oMf``: frame placements computed from ``data.oMi`` when they are read (the scripts read two feet out of ~70 frames per
+    tick); ``updateFramePlacements`` marks them stale, which is all Pinocchio's eager update amounts to for a reader."""
+
+    def __init__(self, model, data):
+        self._model, self._data = model, data
+        self._cache = [None] * len(model.frames)
+
+    def invalidate(self):
+        self._cache = [None] * len(self._cache)
+
+    def __len__(self):
+        return len(self._cache)
+
+    def __getitem__(self, i):
+        M = self._cache[i]
+        if M is None:
+            f = self._model.frames[i]
+            M = self._data.oMi[f.parentJoint] * f.placement if f.parentJoint > 0 else f.placement.copy()
+            self._cache[i] = M
+        return M
+
+    def __setitem__(self, i, M):
+        self._cache[i] = M
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self._cache)))
 
 
 def updateFramePlacements(model, data):
-    for i, f in enumerate(model.frames):
-        data.oMf[i] = data.oMi[f.parentJoint] * f.placement if f.parentJoint > 0 else f.placement.copy()
+    if not isinstance(data.oMf, _LazyFrames):
+        data.oMf = _LazyFrames(model, data)
+    data.oMf.invalidate()
 
 
 def framesForwardKinematics(model, data, q):

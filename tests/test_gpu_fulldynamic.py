@@ -36,6 +36,7 @@ def _run_one_iteration(lib, complete_model=False, seed=11, parallel=False):
     solver = fp.make_solver(_native_library=lib)
     if parallel:
         solver.setNumThreads(4)  # LQ_SOLVER_PARALLEL (the scripts' choice, fulldynamic_talos.py:383): four legs of two knots
+        solver.riccati_legs = 4  # (the GPU picks its own number of legs otherwise: SolverProxDDP._legs)
     else:
         solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL  # the raw gains of a parallel-in-time leg depend on its guess of the cut Hessian: the gain dumps are compared on the serial sweep (tests/test_gpu_legs.py covers the leg kernels)
     solver.max_iters = 1

@@ -27,6 +27,7 @@ def _one_iteration(lib, kind, N, legs, complete=False, seed=5):
     if legs == 1:
         solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL
     solver.setNumThreads(legs)
+    solver.riccati_legs = legs  # (the GPU picks its own number of legs otherwise: SolverProxDDP._legs)
     solver.max_iters = 1
     solver.setup(prob)
     xs, us = pd.initial_guess()
@@ -169,6 +170,7 @@ def test_cold_solve_and_mpc_ticks_with_legs(hip_lib, oracle_lib, legs):
         if legs == 1:
             solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL
         solver.setNumThreads(legs)
+        solver.riccati_legs = legs  # (the GPU picks its own number of legs otherwise: SolverProxDDP._legs)
         solver.setup(prob)
         xs, us = fp.initial_guess()
         conv = solver.run(prob, xs, us)
@@ -203,6 +205,7 @@ def test_full_size_workload_with_legs(hip_lib, oracle_lib, nlegs):
             solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL
         else:
             solver.setNumThreads(legs)
+            solver.riccati_legs = legs  # (the GPU picks its own number of legs otherwise: SolverProxDDP._legs)
         solver.max_iters = 1
         solver.setup(prob)
         rng = np.random.default_rng(9)
@@ -227,6 +230,7 @@ def test_short_horizons_with_legs(hip_lib, oracle_lib, horizon, legs):
         if L == 1:
             solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL
         solver.setNumThreads(L)
+        solver.riccati_legs = L  # (the GPU picks its own number of legs otherwise: SolverProxDDP._legs)
         solver.max_iters = 3
         solver.setup(prob)
         rng = np.random.default_rng(3)
@@ -255,6 +259,7 @@ def test_unconstrained_and_flight_stages_with_legs(hip_lib, oracle_lib):
         if L == 1:
             solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL
         solver.setNumThreads(L)
+        solver.riccati_legs = L  # (the GPU picks its own number of legs otherwise: SolverProxDDP._legs)
         solver.max_iters = 1
         solver.setup(prob)
         rng = np.random.default_rng(5)

@@ -49,3 +49,33 @@ def test_closed_loop_simulation_stand_in(oracle_lib):
     r2 = ens.results(gains=False)
     assert np.allclose(r2["xs"][:, 0], x_fine, atol=1e-12)
     assert all(np.isfinite(s.traj_cost) for s in st)
+
+
+def test_shifted_runs_through_the_mirror_equal_plain_runs():
+    """``SolverProxDDP.run`` recognises the MPC loops' warm start — the previous solution shifted by one knot after one
+    replaceStageCircular (fulldynamic_talos.py:532-540) — and lets the library shift its own copy (mpc_run_shifted) instead of
+    uploading it.  Same trajectories as the plain path, tick by tick; a warm start that is NOT the shifted solution takes the plain path."""
+    traj = {}
+    for mode in ("detect", "plain"):
+        fp = FullDynamicsProblem(horizon=10)
+        solver = fp.make_solver(_native_library=_oracle.load())
+        loop = WalkingMPCLoop(fp, solver, start_tick=26)
+        calls = {"shifted": 0, "plain": 0}
+        hist = []
+        for t in range(20):
+            if mode == "plain":
+                solver._last_results = None  # what a fresh handle would see: nothing to shift
+            nat = solver._native
+            if nat is not None and not hasattr(nat, "_counted"):
+                rs, rn = nat.run_shifted, nat.run
+                nat.run_shifted = lambda rs=rs: (calls.__setitem__("shifted", calls["shifted"] + 1), rs())[1]
+                nat.run = lambda xs, us, rn=rn: (calls.__setitem__("plain", calls["plain"] + 1), rn(xs, us))[1]
+                nat._counted = True
+            if mode == "detect" and t == 12:
+                loop.us[3] = loop.us[3] + 1e-3  # the user edits the warm start: no longer the shifted solution
+            loop.tick()
+            hist.append(np.concatenate([np.concatenate(loop.xs), np.concatenate(loop.us)]))
+        traj[mode] = (np.array(hist), dict(calls))
+    assert traj["plain"][1]["shifted"] == 0
+    assert traj["detect"][1]["plain"] == 1 and traj["detect"][1]["shifted"] >= 17, traj["detect"][1]  # (the first tick's handle is created inside setup)
+    assert np.array_equal(traj["detect"][0][:12], traj["plain"][0][:12])

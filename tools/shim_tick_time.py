@@ -18,6 +18,12 @@ for _ in range(40):
     loop.tick()
     tt.append((time.perf_counter() - t0) * 1e3)
 import cProfile, pstats
-cProfile.run('loop.tick()', '/tmp/tick.prof')
-print("p50 %.2f ms  p90 %.2f ms per tick through the aligator mirror (N=100, complete model, batch 1)" % (np.percentile(tt, 50), np.percentile(tt, 90)))
-pstats.Stats('/tmp/tick.prof').sort_stats('cumtime').print_stats(14)
+print("p50 %.2f ms  p90 %.2f ms per tick through the aligator mirror (N=100, complete model, batch 1, riccati_legs %d)" % (
+    np.percentile(tt, 50), np.percentile(tt, 90), solver._legs()))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(40):
+    loop.tick()
+pr.disable()
+print("profile of 40 ticks (times are totals: divide by 40):")
+pstats.Stats(pr).sort_stats('tottime').print_stats(16)
