@@ -614,9 +614,18 @@ static void launch_pass(mpc_solver* s) {
   if (a.spec_on || L.space != MPC_SPACE_MULTIBODY) s->timed(6, "k_eval_stage_trial", [&] { launch_eval(s, true, 0, 1, a.spec_on != 0); });
   else s->timed(17, "k_eval_stage_trial_values", [&] { launch_eval(s, true, 0, 1, false); });
   s->spec_rec_valid = a.spec_on != 0 && a.spec_knot != nullptr;  // (per instance it counts only if the full step is accepted: a.spec[b])
-  s->timed(7, "k_linesearch", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(64), 0, s->stream, a, 1); });
-  s->timed(10, "k_eval_stage_backtrack", [&] { launch_eval(s, true, 1, L.n_alpha - 1); });
-  s->timed(11, "k_linesearch_backtrack", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(64), 0, s->stream, a, 0); });
+  s->timed(7, "k_linesearch", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(64), 0, s->stream, a, 1, 0); });
+  // backtracking in two launches: alpha = 1/2 and 1/4 for every instance whose full step failed, the remaining candidates only for those
+  // that are still undecided (a workgroup walks its candidates one after the other: evaluating all seven at once cost a tick of the
+  // kinodynamic ensemble 17 ms whenever one instance backtracked)
+  // (a small ensemble is latency-bound: one launch for all candidates, as before)
+  const int nc1 = (L.n_alpha - 1 < 2 || (size_t)L.B * (L.N + 1) < 2048) ? L.n_alpha - 1 : 2;
+  s->timed(10, "k_eval_stage_backtrack", [&] { launch_eval(s, true, 1, nc1); });
+  s->timed(11, "k_linesearch_backtrack", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(64), 0, s->stream, a, 0, nc1); });
+  if (L.n_alpha - 1 - nc1 > 0) {
+    s->timed(10, "k_eval_stage_backtrack", [&] { launch_eval(s, true, 1 + nc1, L.n_alpha - 1 - nc1); });
+    s->timed(11, "k_linesearch_backtrack", [&] { hipLaunchKernelGGL(k_linesearch, dim3(L.B), dim3(64), 0, s->stream, a, 0, L.n_alpha); });
+  }
   s->timed(8, "k_accept", [&] { hipLaunchKernelGGL(k_accept, dim3(L.N + 1, L.B), dim3(64), 0, s->stream, a); });
   s->timed(9, "k_after_step", [&] { hipLaunchKernelGGL(k_after_step, dim3(L.B), dim3(1), 0, s->stream, a); });
   HIP_OK(hipGetLastError());

@@ -65,7 +65,7 @@ DEV bool knot_reused(const SolverArgs& a, int b, int k) {
   if ((a.dirty[(k >> 6) & (MPC_DIRTY_WORDS - 1)] >> (k & 63)) & 1ull) return false;
   if (a.reuse_same) return true;
   if (k < a.L.N - 1) return k > 0 || a.reuse_k0;
-  return a.spec_next != 0;
+  return a.spec_next != 0 && a.spec[b] == 1;
 }
 DEV double* gain_ptr(const SolverArgs& a, int b, int k) { return a.gains + ((size_t)b * (a.L.N + 1) + k) * a.L.gain_stride; }
 DEV int stage_slot(const SolverArgs& a, int k) { return k < a.L.N ? (a.head + k) % a.L.N : a.L.N; }

@@ -114,6 +114,9 @@ __global__ void __launch_bounds__(128) k_decide(SolverArgs a) {
       st.al_iters += 1;
       if (st.al_iters >= o.max_al_iters) st.done = 1;
       if (via_stall && (st.stalled >> 8) >= 4) st.done = 1;  // four stalls with no step in between (two full BCL cycles): nothing left to gain
+      // the run of this instance ends here (k_after_step returns early for it): its records stay the evaluation of its iterate, but
+      // whatever speculative record of an appended knot exists belongs to an earlier tick
+      if (st.done && a.spec) a.spec[b] = a.spec_on ? 2 : 0;
     }
   }
   __syncthreads();
@@ -615,10 +618,11 @@ __global__ void __launch_bounds__(256) k_duals(SolverArgs a) {
 // P8: Armijo backtracking over the pre-evaluated candidates alpha_i = 2^-i.  grid B, block 64
 // ------------------------------------------------------------------------------------------------
 // first == 1: only the full step (candidate 0) has been evaluated; accept it if it passes Armijo, otherwise
-// raise ls_more so that the remaining candidates get evaluated.  first == 0: backtrack over all of them.
+// raise ls_more so that the remaining candidates get evaluated.  first == 0: backtrack over the candidates 0 .. upto evaluated so far
+// (two launches: alpha = 1/2, 1/4 first — most backtracking ends there — then the rest for the instances still undecided).
 // one wavefront per instance: the sums over the knots are taken by the lanes (two knots per lane, then the fixed DPP tree of wave_sum:
 // deterministic), not by one thread walking 101 records
-__global__ void __launch_bounds__(64) k_linesearch(SolverArgs a, int first) {
+__global__ void __launch_bounds__(64) k_linesearch(SolverArgs a, int first, int upto) {
   const Layout& L = a.L;
   const int b = blockIdx.x, lane = threadIdx.x;
   InstState& st = a.inst[b];
@@ -651,9 +655,10 @@ __global__ void __launch_bounds__(64) k_linesearch(SolverArgs a, int first) {
     const double phi = knot_sum([&](int k) { return tp[k]; });
     if (phi <= st.phi0 + a.opt.ls_armijo_c1 * alpha * d) break;
     if (step + 1 >= a.opt.ls_max_steps || step + 1 >= L.n_alpha || 0.5 * alpha < a.opt.ls_alpha_min) break;
+    if (step >= upto) return;  // the next candidate is evaluated by the second backtracking launch: undecided, ls_more stays set
     alpha *= 0.5;
   }
-  if (lane == 0) { st.dphi0 = d; st.alpha = alpha; st.ls_step = step; }
+  if (lane == 0) { st.dphi0 = d; st.alpha = alpha; st.ls_step = step; st.ls_more = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -695,8 +700,10 @@ __global__ void k_after_step(SolverArgs a) {
     st.num_iters += 1;
     if (st.num_iters >= a.opt.max_iters) st.done = 1;
   }
-  // the records now hold the evaluation of the accepted iterate iff the full step (the one evaluated with derivatives) was taken
-  if (a.spec) a.spec[blockIdx.x] = (a.spec_on && stepped && st.alpha == 1.0) ? 1 : 0;
+  // the records now hold the evaluation of the accepted iterate iff the full step (the one evaluated with derivatives) was taken (1) ;
+  // after a BCL update without a step (skip_step: no candidate was evaluated) they still hold the evaluation of the unchanged iterate
+  // (2: as 1, but there is no speculative record of the knot the next tick appends) — the next pass only re-projects them
+  if (a.spec) a.spec[blockIdx.x] = !a.spec_on ? 0 : (stepped && st.alpha == 1.0) ? 1 : (!stepped && st.skip_step) ? 2 : 0;
 }
 
 // setup(): multipliers and their estimates to zero, fresh per-instance solver state (mu = mu_init).  One launch instead

@@ -210,16 +210,26 @@ class FootTrajectory:
         if time_to_land <= -1:
             return [pose_init for _ in range(self.nsteps)]
         curve = SwingCurve(pose_init, pose_final, self.swing_apex)
+        ts = np.arange(time_to_land, time_to_land - self.nsteps, -1)  # ticks left until landing at each knot
+        swing = np.nonzero((ts > 0) & (ts <= self.T_ss))[0]
+        # every knot inside the swing in one evaluation: Bernstein basis (k x 9) times the control points; the rotation moves on the
+        # geodesic from R0 to R1 — one logarithm for the curve, one exponential per knot (none if the two rotations are the same)
+        if swing.size:
+            svals = (self.T_ss - ts[swing]).astype(float) / float(self.T_ss)
+            trans = np.atleast_2d(bezier_eval(curve.wps, svals))
+            w = _log3(curve.R0.T @ curve.R1)
+            still = not np.any(w)
         out = []
-        for t in range(time_to_land, time_to_land - self.nsteps, -1):  # t = ticks left until landing at that knot
+        si = 0
+        for t in ts:
             if t <= 0:
                 out.append(pose_final)
             elif t > self.T_ss:
                 out.append(pose_init)
             else:
-                s = float(self.T_ss - t) / float(self.T_ss)
                 pose = pose_init.copy()
-                pose.translation = curve.translation(s)
-                pose.rotation = curve.rotation(s)
+                pose.translation = trans[si].copy()
+                pose.rotation = curve.R0.copy() if still else curve.R0 @ _exp3(svals[si] * w)
+                si += 1
                 out.append(pose)
         return out

@@ -1,21 +1,34 @@
+"""Developer tool (GPU box): tick times of BASELINE config 4 (kinodynamic N = 150, 64 instances, complete model, 4 legs, tick reuse) —
+p50 / p90, how many ticks take more than one pass (a BCL update without a step, then the step), per-kernel time."""
 import os, sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mpc_benchmark_amd import _capi
 from mpc_benchmark_amd.ensemble import EnsembleMPC
 from mpc_benchmark_amd.problems.kinodynamic import KinodynamicProblem
 lib = _capi.load_hip_library()
 kp = KinodynamicProblem(horizon=150, complete_model=True)
-ens = EnsembleMPC(kp, batch=64, library=lib, seed=7, perturb_dofs=range(18, kp.nv))
-ens.prepare_schedule(30)
+ens = EnsembleMPC(kp, batch=64, library=lib, seed=7, perturb_dofs=range(18, kp.nv), tick_reuse=not os.environ.get("NO_REUSE"))
+ens.options.riccati_legs = int(os.environ.get("LEGS", "4")); ens.native.set_options(ens.options)
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+ens.prepare_schedule(T + 10)
 ens.cold_solve(max_iters=100)
 for _ in range(3): ens.step()
 ens.native.profile(2); ens.native.profile(1)
-T=15
-t0=time.perf_counter()
-for _ in range(T): ens.step()
-dt=(time.perf_counter()-t0)/T
+lat, al, ls = [], [], []
+for _ in range(T):
+    t0 = time.perf_counter()
+    st = ens.step()
+    lat.append((time.perf_counter() - t0) * 1e3)
+    al.append(sum(1 for s in st if s.al_iters > 0))
+    ls.append(np.bincount([int(s.ls_steps) for s in st], minlength=8))
 ens.native.profile(0)
-print("kino N=150 B=64: %.2f ms per tick" % (dt*1e3))
-for k,(c,ms) in sorted(ens.native.profile_read().items(), key=lambda kv:-kv[1][1])[:9]:
-    print("  %-26s launches/tick %.2f  ms/tick %.3f" % (k, c/T, ms/T))
+lat = np.array(lat)
+print("kinodynamic N=150 B=64 legs %d: p50 %.2f ms  p90 %.2f ms  mean %.2f ms | ticks in which some instance took a BCL update: %d of %d (instances per such tick: mean %.1f)" % (
+    ens.options.riccati_legs, np.percentile(lat, 50), np.percentile(lat, 90), lat.mean(), sum(1 for a in al if a), T, np.mean([a for a in al if a] or [0])))
+for t, (l, h) in enumerate(zip(lat, ls)):
+    if h[1:].sum():
+        print("  tick %2d %.1f ms: instances by accepted backtracking step (0 = full step .. 7): %s" % (t, l, h.tolist()))
+print("  tick times (ms):", " ".join("%.1f" % v for v in lat))
+for k, (c, ms) in sorted(ens.native.profile_read().items(), key=lambda kv: -kv[1][1])[:9]:
+    print("  %-26s launches/tick %.2f  ms/tick %.3f" % (k, c / T, ms / T))
