@@ -167,6 +167,7 @@ cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of th
   int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = nthr >> 6;
   double *x = sm + S.x, *u = sm + S.u, *xn = sm + S.xn, *cfr = sm + S.cfr, *small = sm + S.small, *red = sm + S.red;
+  double* early = sm + S.early;  // [0,nz) gradient | [nz,2nz) diag(H) | [2nz,2nz+36) base block | [2nz+36, +24) per-term cost | [2nz+60] done flag
   __shared__ int iflag[2];
   __shared__ double s_cost;
   // Jacobian staging in LDS, in the region that is dead once the dynamics derivatives are out (Yc, then the factor of M):
@@ -484,6 +485,79 @@ sim_loop:
     }
   };
 
+  // Cost terms on the state / control error with diagonal weights (fulldynamic_talos.py:176-177: the first two terms of every stage):
+  // value, gradient and Hessian-diagonal contributions need x, u and the SE(3) table only, so wavefront w0 accumulates them beside the
+  // factorisation chain too — in term order into their own accumulators, from which pass B starts (same sums in the same order as
+  // accumulating them there).  Only if the SE(3) slots they read were filled by this very wavefront (its LDS operations execute in order).
+  auto early_costs = [&](int w0) {
+    if (wv != w0) return;
+    const int nws = nw - w0;
+    double *eg = early, *eh = early + nz, *eb = early + 2 * nz, *ec = early + 2 * nz + 36;
+    bool ok = true;
+    { int slot_ = 0;
+      for (int t = 0; t < nterms; ++t) {
+        const TermRec tr = lds_term(lterm, t);
+        const bool se3_state = tr.type == MPC_TERM_STATE_ERROR && tr.i0 < 6;
+        if (!se3_state && tr.type != MPC_TERM_FRAME_PLACEMENT) continue;
+        const int my = slot_++;
+        if (se3_state && tr.role == MPC_ROLE_COST && (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) && (my >= MB_SE3_SLOTS || (my % nws) != 0)) ok = false;
+      } }
+    if (!ok) { if (lane == 0) early[2 * nz + 60] = 0.0; return; }
+    for (int z = lane; z < nz; z += 64) { eg[z] = 0.0; eh[z] = a.opt.reg_init; }
+    if (lane < 36) eb[lane] = 0.0;
+    if (lane < 24) ec[lane] = 0.0;
+    int slot_ = 0;
+    for (int t = 0; t < nterms; ++t) {
+      const TermRec tr = lds_term(lterm, t);
+      const bool se3t = tr.type == MPC_TERM_FRAME_PLACEMENT || (tr.type == MPC_TERM_STATE_ERROR && tr.i0 < 6);
+      const int my = se3t ? slot_++ : 0;
+      if (tr.role != MPC_ROLE_COST || !(tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) || t >= 24) continue;
+      const double* tp = P + tr.poff;
+      const double* W = P + tr.woff;
+      const double* sl = se3 + 48 * my;
+      const int d = tr.dim;
+      if (tr.type == MPC_TERM_STATE_ERROR) {
+        const double* Jb = sl + 8;
+        double cst = 0;
+        for (int i = lane; i < d; i += 64) {
+          const int ri = tr.i0 + i;
+          const double e = (ri < 6) ? sl[ri] : ((ri < nv) ? (tp[ri + 1] - q[ri + 1]) : (tp[nq + ri - nv] - v[ri - nv]));
+          cst += W[i] * e * e;
+        }
+        cst = wave_sum(cst);
+        if (lane == 0) ec[t] = 0.5 * cst;
+        if (derivs) {
+          for (int z = lane; z < n; z += 64) {
+            double g = 0;
+            if (z < 6) { for (int i = 0; i < d && tr.i0 + i < 6; ++i) { const int ri = tr.i0 + i; g += Jb[6 * ri + z] * W[i] * sl[ri]; } }
+            else if (z >= tr.i0 && z < tr.i0 + d) {
+              const double e = (z < nv) ? (tp[z + 1] - q[z + 1]) : (tp[nq + z - nv] - v[z - nv]);
+              g = -W[z - tr.i0] * e; eh[z] += W[z - tr.i0];
+            }
+            eg[z] += g;
+          }
+          if (lane < 36) {
+            const int za = lane / 6, zb = lane % 6;
+            double h = 0;
+            for (int i = 0; i < d && tr.i0 + i < 6; ++i) { const int ri = tr.i0 + i; h += Jb[6 * ri + za] * W[i] * Jb[6 * ri + zb]; }
+            eb[lane] += h;
+          }
+        }
+      } else if (tr.type == MPC_TERM_CONTROL_ERROR) {
+        double cst = 0;
+        for (int i = lane; i < d; i += 64) { const double e = u[tr.i0 + i] - tp[tr.i0 + i]; cst += W[i] * e * e; }
+        cst = wave_sum(cst);
+        if (lane == 0) ec[t] = 0.5 * cst;
+        if (derivs) for (int i = lane; i < d; i += 64) {
+          const int z = n + tr.i0 + i;
+          eg[z] += W[i] * (u[tr.i0 + i] - tp[tr.i0 + i]);
+          eh[z] += W[i];
+        }
+      }
+    }
+    if (lane == 0) early[2 * nz + 60] = 1.0;
+  };
+
   if (has_dyn) {
     // ---- P7: joint-space inertia (lower block triangle, tile-packed), bias torques, contact frames ---------------
     const int ntile = nbm * (nbm + 1) / 2;
@@ -581,7 +655,7 @@ sim_loop:
         trsm_bwd_tiles(Mt, nbm, V16, 16, 1, 0, 1, lane);
         for (int i = lane; i < nvp; i += 64) { acc[i] = V16[i * 16]; Y16[i * MB_LDY + 12] = 0.0; }  // from here on Y16 = Y (zero padded)
       }
-    } else { se3_prepass(1); selector_rows(1); }
+    } else { se3_prepass(1); selector_rows(1); early_costs(1); }
     __syncthreads();
     if (iflag[0] == 0 || iflag[1] == 0) { if (tid == 0) a.inst[b].done = iflag[0] == 0 ? 5 : 6; return; }
     EV_PROF(5);
@@ -927,9 +1001,10 @@ sim_loop:
   int* tse3 = tkind + 48;           // slot in the SE(3) table
   int* tchunk = tkind + 72;         // stack chunk (32 rows each)
   int* tmeta = tkind + 96;          // [0] number of chunks, [1] any dense-weight cost
-  for (int z = tid; z < nz; z += nthr) { gacc[z] = 0.0; hdg[z] = a.opt.reg_init; }
-  for (int i = tid; i < 36; i += nthr) hbb[i] = 0.0;
-  for (int i = tid; i < 24; i += nthr) tcost[i] = 0.0;
+  const bool early_done = has_dyn && early[2 * nz + 60] != 0.0;  // the diagonal state / control costs are in the early accumulators already
+  for (int z = tid; z < nz; z += nthr) { gacc[z] = early_done ? early[z] : 0.0; hdg[z] = early_done ? early[nz + z] : a.opt.reg_init; }
+  for (int i = tid; i < 36; i += nthr) hbb[i] = early_done ? early[2 * nz + i] : 0.0;
+  for (int i = tid; i < 24; i += nthr) tcost[i] = early_done ? early[2 * nz + 36 + i] : 0.0;
   if (tid == 0) {
     int rows = 0, chunk = 0, se3n = 0, dense = 0, nst = 0;
     for (int t = 0; t < nterms; ++t) {
@@ -1089,7 +1164,9 @@ sim_loop:
       const double* sl = se3 + 48 * tse3[t];
       const int d = tr.dim;
       const bool is_cost = tr.role == MPC_ROLE_COST;
-      if (tr.type == MPC_TERM_STATE_ERROR && is_cost) {
+      if (early_done && is_cost && (tr.type == MPC_TERM_STATE_ERROR || tr.type == MPC_TERM_CONTROL_ERROR)) {
+        // (done beside the factorisation: early_costs)
+      } else if (tr.type == MPC_TERM_STATE_ERROR && is_cost) {
         const double* W = P + tr.woff;
         const double* Jb = sl + 8;
         if (wv == 0) {  // cost value: one wavefront, DPP reduction (a single thread walking d residuals costs ~15 us)

@@ -35,7 +35,7 @@ struct MbLds {
   // persistent: body arrays (SoA, ld nj), dof arrays (SoA, ld nv), vectors
   int oR, op, ov, oa, Hc, Fc;
   int J, U, Psd;
-  int x, u, xn, a, lam, gam, bias, cfr, small, se3, red;
+  int x, u, xn, a, lam, gam, bias, cfr, small, se3, red, early;
   // derivative blocks alive from the pre-pass to the right-hand sides (afterwards: gradient / Hessian-diagonal accumulators)
   int Phi, Bt, Tv, BcPsd, YcPsd, Psdd, Tq;
   // time-shared region: [Yc | stage 1: oY Bc oh of  ==  stage 2: Mt Y16 Sp LIs] ; stage 3 (terms): JS from Yc on
@@ -47,7 +47,7 @@ struct MbLds {
   unsigned mg_nv, mg_nj, mg_nz, mg_n;  // magic_div (device_common.h) of the run-time divisors nv, nj, n + nu, n of the per-element loops
 };
 
-#define MB_RED_DOUBLES 304  // [0,16) merit partials | [16,48) sqrt(W) r of the stacked rows | [48,112) residual of a workgroup term | [112,304) 24 per wavefront
+#define MB_RED_DOUBLES (112 + 24 * (EVAL_THREADS / 64))  // [0,16) merit partials | [16,48) sqrt(W) r of the stacked rows | [48,112) residual of a workgroup term | then 24 per wavefront
 
 static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz) {
   MbLds s;
@@ -64,6 +64,7 @@ static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz) {
   s.small = take(6 * 36 + 64);      // integrator 6x6 blocks, scratch, the term table of the stage
   s.se3 = take(MB_SE3_SLOTS * 48);  // per SE(3)-valued term: residual (6), Jacobian block (36 at +8)
   s.red = take(MB_RED_DOUBLES);
+  s.early = take(2 * nz + 36 + 24 + 2);  // diagonal state / control costs accumulated beside the factorisation: gradient | diag(H) | base block | per-term cost | done flag
   s.Phi = take(6 * nv); s.Bt = take(6 * nv); s.Tv = take(6 * nv); s.BcPsd = take(6 * nv); s.YcPsd = take(6 * nv);
   s.Psdd = take(6 * nv); s.Tq = take(6 * nv);
   s.Yc = take(21 * nj);
