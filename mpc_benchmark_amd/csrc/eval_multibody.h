@@ -485,6 +485,33 @@ sim_loop:
     }
   };
 
+  // classification of the term table (one lane; on stages with contact dynamics beside the factorisation chain)
+  unsigned char* tkind = (unsigned char*)(early + 2 * nz + 62);  // 0 workgroup pass, 1 stacked cost (wave pass), 2 dense-weight cost (HBM pass)
+  unsigned char* trow = tkind + 24;    // first stack row of a stacked term
+  unsigned char* tse3 = tkind + 48;    // slot in the SE(3) table
+  unsigned char* tchunk = tkind + 72;  // stack chunk (32 rows each)
+  unsigned char* tmeta = tkind + 96;   // [0] number of chunks, [1] any dense-weight cost
+  auto classify_terms = [&]() {
+    int rows = 0, chunk = 0, se3n = 0, dense = 0, nst = 0;
+    for (int t = 0; t < nterms; ++t) {
+      const TermRec tr = lds_term(lterm, t);
+      const bool se3t = tr.type == MPC_TERM_FRAME_PLACEMENT || (tr.type == MPC_TERM_STATE_ERROR && tr.i0 < 6);
+      tse3[t] = (unsigned char)(se3t ? se3n++ : 0);
+      const bool diag_sel = (tr.type == MPC_TERM_STATE_ERROR || tr.type == MPC_TERM_CONTROL_ERROR) && (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT);
+      int kind = 0;
+      if (tr.role == MPC_ROLE_COST && !diag_sel) {
+        bool wdiag = (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) != 0;
+        if (!wdiag) { const double* W = P + tr.woff; wdiag = true; for (int e = 0; e < tr.dim * tr.dim; ++e) if ((e / tr.dim != e % tr.dim) && W[e] != 0.0) wdiag = false; }
+        if (wdiag && tr.dim <= 24) {
+          kind = 1;
+          if (rows + tr.dim > 32) { ++chunk; rows = 0; }
+          trow[t] = (unsigned char)rows; tchunk[t] = (unsigned char)chunk; rows += tr.dim; ++nst;
+        } else { kind = 2; dense = 1; }
+      }
+      tkind[t] = (unsigned char)kind;
+    }
+    tmeta[0] = (unsigned char)(nst ? chunk + 1 : 0); tmeta[1] = (unsigned char)dense;
+  };
   // Cost terms on the state / control error with diagonal weights (fulldynamic_talos.py:176-177: the first two terms of every stage):
   // value, gradient and Hessian-diagonal contributions need x, u and the SE(3) table only, so wavefront w0 accumulates them beside the
   // factorisation chain too — in term order into their own accumulators, from which pass B starts (same sums in the same order as
@@ -655,7 +682,7 @@ sim_loop:
         trsm_bwd_tiles(Mt, nbm, V16, 16, 1, 0, 1, lane);
         for (int i = lane; i < nvp; i += 64) { acc[i] = V16[i * 16]; Y16[i * MB_LDY + 12] = 0.0; }  // from here on Y16 = Y (zero padded)
       }
-    } else { se3_prepass(1); selector_rows(1); early_costs(1); }
+    } else { se3_prepass(1); selector_rows(1); early_costs(1); if (wv == nw - 1 && lane == 0) classify_terms(); }
     __syncthreads();
     if (iflag[0] == 0 || iflag[1] == 0) { if (tid == 0) a.inst[b].done = iflag[0] == 0 ? 5 : 6; return; }
     EV_PROF(5);
@@ -996,36 +1023,11 @@ sim_loop:
   double* hdg = Tv;      // nz: additions to diag(H)
   double* hbb = Phi;     // 36: additions to the base 6x6 block of H
   double* tcost = small; // per-term cost, summed in term order at the end (deterministic)
-  int* tkind = (int*)(small + 32);  // 0 workgroup pass, 1 stacked cost (wave pass), 2 dense-weight cost (HBM pass)
-  int* trow = tkind + 24;           // first stack row of a stacked term
-  int* tse3 = tkind + 48;           // slot in the SE(3) table
-  int* tchunk = tkind + 72;         // stack chunk (32 rows each)
-  int* tmeta = tkind + 96;          // [0] number of chunks, [1] any dense-weight cost
   const bool early_done = has_dyn && early[2 * nz + 60] != 0.0;  // the diagonal state / control costs are in the early accumulators already
   for (int z = tid; z < nz; z += nthr) { gacc[z] = early_done ? early[z] : 0.0; hdg[z] = early_done ? early[nz + z] : a.opt.reg_init; }
   for (int i = tid; i < 36; i += nthr) hbb[i] = early_done ? early[2 * nz + i] : 0.0;
   for (int i = tid; i < 24; i += nthr) tcost[i] = early_done ? early[2 * nz + 36 + i] : 0.0;
-  if (tid == 0) {
-    int rows = 0, chunk = 0, se3n = 0, dense = 0, nst = 0;
-    for (int t = 0; t < nterms; ++t) {
-      const TermRec tr = lds_term(lterm, t);
-      const bool se3t = tr.type == MPC_TERM_FRAME_PLACEMENT || (tr.type == MPC_TERM_STATE_ERROR && tr.i0 < 6);
-      tse3[t] = se3t ? se3n++ : 0;
-      const bool diag_sel = (tr.type == MPC_TERM_STATE_ERROR || tr.type == MPC_TERM_CONTROL_ERROR) && (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT);
-      int kind = 0;
-      if (tr.role == MPC_ROLE_COST && !diag_sel) {
-        bool wdiag = (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) != 0;
-        if (!wdiag) { const double* W = P + tr.woff; wdiag = true; for (int e = 0; e < tr.dim * tr.dim; ++e) if ((e / tr.dim != e % tr.dim) && W[e] != 0.0) wdiag = false; }
-        if (wdiag && tr.dim <= 24) {
-          kind = 1;
-          if (rows + tr.dim > 32) { ++chunk; rows = 0; }
-          trow[t] = rows; tchunk[t] = chunk; rows += tr.dim; ++nst;
-        } else { kind = 2; dense = 1; }
-      }
-      tkind[t] = kind;
-    }
-    tmeta[0] = nst ? chunk + 1 : 0; tmeta[1] = dense;
-  }
+  if (!has_dyn && tid == 0) classify_terms();  // (stages with contact dynamics: done beside the factorisation)
   __syncthreads();
   EV_PROF(29);
 

@@ -64,7 +64,7 @@ static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz) {
   s.small = take(6 * 36 + 64);      // integrator 6x6 blocks, scratch, the term table of the stage
   s.se3 = take(MB_SE3_SLOTS * 48);  // per SE(3)-valued term: residual (6), Jacobian block (36 at +8)
   s.red = take(MB_RED_DOUBLES);
-  s.early = take(2 * nz + 36 + 24 + 2);  // diagonal state / control costs accumulated beside the factorisation: gradient | diag(H) | base block | per-term cost | done flag
+  s.early = take(2 * nz + 36 + 24 + 2 + 16);  // diagonal state / control costs accumulated beside the factorisation: gradient | diag(H) | base block | per-term cost | done flag | the term classification (bytes)
   s.Phi = take(6 * nv); s.Bt = take(6 * nv); s.Tv = take(6 * nv); s.BcPsd = take(6 * nv); s.YcPsd = take(6 * nv);
   s.Psdd = take(6 * nv); s.Tq = take(6 * nv);
   s.Yc = take(21 * nj);
