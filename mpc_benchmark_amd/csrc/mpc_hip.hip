@@ -102,7 +102,10 @@ struct mpc_solver {
   LkLds lk{};
   LcLds lc{};
   LxLds lx{};
-  bool legs_ok = false;  // the dimensions fit the leg kernels (np <= 80, mp <= 32, LDS carve-outs)
+  bool legs_ok = false;  // the dimensions fit the leg kernels (np <= 80, mp <= 48, at most 256 constraint rows, LDS carve-outs) and MPC_HIP_NO_LEGS is unset; otherwise riccati_legs > 1 silently keeps the serial sweep (mpc_abi.h)
+  // developer knobs, read from the environment ONCE when the handle is created (MPC_LEGS_CHAIN, MPC_LEGS_PLAIN, MPC_TREE_SWEEPS, MPC_HIP_TRACE)
+  bool env_chain = false, env_plain = false;
+  int env_tree_sweeps = 0, env_trace = -1;
   double* d_legbuf = nullptr;
   double* d_treebuf = nullptr;
   TreeDesc tree{};       // tree over the cuts for the current number of legs (legs_tree.h)
@@ -110,8 +113,7 @@ struct mpc_solver {
   // (fewer solves in a row, and the compositions of a level run side by side: 64 x 4 legs 0.38 -> 0.27 ms, batch 1 with 16 legs is only
   // worth it this way) ; MPC_LEGS_CHAIN=1 keeps the chain (tests: its intermediates are compared with the oracle's one to one)
   bool use_tree() const {
-    const char* fe = getenv("MPC_LEGS_CHAIN");
-    return eff_legs() >= 3 && d_treebuf != nullptr && !(fe && atoi(fe) > 0);
+    return eff_legs() >= 3 && d_treebuf != nullptr && !env_chain;
   }
   bool leg_guess_valid = false;  // the leg records hold the cut Hessians of an earlier pass (terminal costs of the legs)
   int leg_guess_now = 0;
@@ -191,6 +193,11 @@ static void copy_sync(mpc_solver* s, void* dst, const void* src, size_t bytes, h
 
 static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->dims = d;
+  { const char* e;
+    e = getenv("MPC_LEGS_CHAIN"); s->env_chain = e && atoi(e) > 0;
+    e = getenv("MPC_LEGS_PLAIN"); s->env_plain = e && atoi(e) > 0;
+    e = getenv("MPC_TREE_SWEEPS"); s->env_tree_sweeps = e ? atoi(e) : 0;
+    e = getenv("MPC_HIP_TRACE"); s->env_trace = e ? atoi(e) : -1; }
   HIP_OK(hipSetDevice(d.device));
   // Own non-blocking stream per handle: the shards of an ensemble on one GPU (several handles) run out of phase, the
   // sequential Riccati sweep of one shard (B workgroups) beside the wide per-knot kernels of the others.  Equal priorities:
@@ -509,13 +516,12 @@ static void launch_pass(mpc_solver* s) {
   const int J = a.nlegs;
   // legs without a value-function guess at the cuts (first pass of the handle): two sweeps, the second from the Hessians the first
   // one found (legs.h) ; MPC_LEGS_PLAIN=1: always one sweep from zero (intermediates comparable with the oracle's)
-  const char* plain_env = getenv("MPC_LEGS_PLAIN");
-  const bool plain = plain_env && atoi(plain_env) > 0;
+  const bool plain = s->env_plain;
   const bool tree = s->use_tree();
   if (tree && s->tree.J != J) s->tree = make_tree_desc(J);
   // (the tree refreshes the guess of a cut from the node that starts there: every cut has seen the true terminal cost after one sweep per level)
   int sweeps = (J > 1 && !plain && !s->leg_guess_valid) ? (tree ? s->tree.nlev + 1 : 2) : 1;
-  if (const char* se = getenv("MPC_TREE_SWEEPS")) { if (tree && !plain && atoi(se) > sweeps) sweeps = atoi(se); }  // developer knob: sweeps per pass
+  if (tree && !plain && s->env_tree_sweeps > sweeps) sweeps = s->env_tree_sweeps;  // developer knob: sweeps per pass
   for (int sweep = 0; sweep < sweeps; ++sweep) {
   s->leg_guess_now = (J > 1 && !plain && (s->leg_guess_valid || sweep > 0)) ? 1 : 0;
   a = s->args();
@@ -660,8 +666,8 @@ static void run_impl(mpc_solver* s, mpc_stats* stats, int passes_enqueued = 0) {
     // a BCL update changed the penalty of an instance: the cut Hessians of the legs (calP ~ ... + C^T C / mu) were made for the old
     // one — the next pass refreshes them with its extra sweeps instead of starting single-sweep legs from a guess for another mu
     for (int b = 0; b < L.B; ++b) if (!st[b].done && st[b].mu != s->leg_mu[b]) { if (s->leg_mu[b] >= 0.0) s->leg_guess_valid = false; s->leg_mu[b] = st[b].mu; }
-    if (const char* tr = getenv("MPC_HIP_TRACE")) {  // developer aid: per-pass solver state of one instance
-      const int tb = atoi(tr);
+    if (s->env_trace >= 0) {  // developer aid: per-pass solver state of one instance
+      const int tb = s->env_trace;
       if (tb >= 0 && tb < L.B) {
         const InstState& t = st[tb];
         fprintf(stderr, "[trace b=%d pass %d] it %d al %d mu %.1e phi0 %.10e dphi0 %.3e alpha %.4g ls %d prim %.3e dual %.3e crit %.3e inner_tol %.1e prim_tol %.1e skip %d stalled %d done %d\n",

@@ -37,6 +37,8 @@ MPC_LEGS_CHAIN=1 python3 tools/legs_phase_timers.py 4 > $OUT/legs_phase_timers.t
 python3 tools/config_sweep.py > $OUT/other_configs.txt 2>&1
 python3 tools/shim_tick_time.py 2>&1 | grep -E 'p50' > $OUT/drop_in_tick.txt
 python3 tools/latency_vs_legs.py > $OUT/latency_vs_legs.txt 2>&1
+python3 tools/kino_tick.py 60 > $OUT/kino_tick.txt 2>&1
+python3 tools/qp_bench.py > $OUT/qp_bench.txt 2>&1
 python3 tools/batch1_kernel_times.py 32 > $OUT/batch1_kernel_times.txt 2>&1
 python3 tools/occupancy_report.py > $OUT/occupancy_kinodynamic.txt 2>&1
 python3 tools/occupancy_report.py --problem full --batches 16,64,256 > $OUT/occupancy_fulldynamic.txt 2>&1

@@ -1,5 +1,5 @@
-import sys, time, numpy as np
-sys.path.insert(0, "/root/repo")
+import os, sys, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mpc_benchmark_amd import _capi
 from mpc_benchmark_amd.ensemble import EnsembleMPC
 from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem

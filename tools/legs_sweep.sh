@@ -1,6 +1,7 @@
+#!/bin/bash
 # usage: bash tools/legs_sweep.sh "<legs list>" "<streams list>" [extra bench args]
 for legs in $1; do for st in $2; do
-  echo "legs=$legs streams=$st"; timeout 300 python bench.py --steps 30 --warmup 3 --legs $legs --streams $st --no-cpu-baseline $3 2>&1 | tail -1 | python -c "
+  echo "legs=$legs streams=$st"; timeout 300 python3 bench.py --steps 30 --warmup 3 --legs $legs --streams $st --no-cpu-baseline $3 2>&1 | tail -1 | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read())
 r=d['roofline']
