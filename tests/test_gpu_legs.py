@@ -346,3 +346,22 @@ def test_ensemble_cold_solve_with_the_tree(hip_lib, mode):
         assert all(out[6][3]) and len(set(out[6][2])) >= 4, (out[6][2], out[6][3])
     same = list(range(6))
     assert _rel(out[6][0][same], out[1][0][same]) < 1e-7 and _rel(out[6][1][same], out[1][1][same]) < 1e-7
+
+
+def test_mirror_picks_the_number_of_legs_for_the_device(hip_lib, oracle_lib):
+    """LQ_SOLVER_PARALLEL + setNumThreads(8) (fulldynamic_talos.py:383-385): one leg per thread on the CPU libraries, 32 legs for one
+    instance on the GPU (256 / batch for ensembles); ``solver.riccati_legs`` overrides; the solution does not depend on it."""
+    res = {}
+    for name, lib, legs in (("hip-auto", hip_lib, None), ("hip-8", hip_lib, 8), ("oracle", oracle_lib, None)):
+        fp = FullDynamicsProblem(horizon=40, complete_model=False)
+        prob = fp.build()
+        solver = fp.make_solver(_native_library=lib)
+        solver.riccati_legs = legs
+        solver.max_iters = 3
+        solver.setup(prob)
+        assert solver._legs() == {"hip-auto": 32, "hip-8": 8, "oracle": 8}[name]
+        xs, us = fp.initial_guess()
+        solver.run(prob, xs, us)
+        res[name] = (np.array(solver.results.xs), np.array(solver.results.us))
+    for name in ("hip-8", "oracle"):
+        assert _rel(res["hip-auto"][0], res[name][0]) < 1e-7 and _rel(res["hip-auto"][1], res[name][1]) < 1e-6, name
