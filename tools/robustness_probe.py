@@ -22,6 +22,9 @@ st = e.cold_solve(max_iters=100)
 print("cold: converged %d/%d" % (sum(bool(s.converged) for s in st), batch))
 if os.environ.get("WALK"):
     e.enable_walk()
+for env, field in (("DYN_SCALE", "dyn_al_scale"), ("ARMIJO", "ls_armijo_c1"), ("REG_INIT", "reg_init"), ("MU_INIT", "mu_init"), ("MU_FACTOR", "bcl_mu_update_factor")):
+    if os.environ.get(env):  # the knobs the scripts leave at upstream defaults that this build could not pin
+        setattr(e.options, field, float(os.environ[env])); e.native.set_options(e.options)
 if os.environ.get("ITERS"):
     e.options.max_iters = int(os.environ["ITERS"]); e.native.set_options(e.options)
 extra_total = 0
