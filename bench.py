@@ -69,6 +69,55 @@ def cpu_worker(args):
     print(json.dumps({"tick_ms": ms, "tick_ends": ends, "t_start": t_start, "t_end": ends[-1]}))
 
 
+def aligator_reference(args):
+    """``--aligator``: the SAME OCP (talos_synth_v1 exported to a real pinocchio.Model, this repo's problem builder bound to the real
+    modules — tools/gen_golden.py) on the REAL reference stack, timed the way fulldynamic_talos.py:538-543 times it: cold solve of <= 100
+    iterations, then `--steps` MPC ticks of replaceStageCircular + cycleAppend + setup + run(max_iters = 1) from the shifted solution,
+    LQ_SOLVER_PARALLEL with 8 threads.  Prints one JSON line.  Needs `import aligator, pinocchio` (Aligator >= 0.10): neither is
+    installable in the build container nor on the GPU box, so this function has never been executed there."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+    import gen_golden as gg
+    aligator, pin = gg.real_stack()
+    if aligator is None:
+        print(json.dumps({"aligator_reference": None, "reason": "the reference stack (aligator, pinocchio) is not importable here"}))
+        return 0
+    builders = gg.bind_real_modules(aligator, pin, gg.export_models(pin))
+    pd = builders["fulldynamic"](horizon=args.horizon, complete_model=(args.model == "complete"))
+    prob = pd.build(with_terminal_constraint=True)
+    solver = pd.make_solver()
+    solver.max_iters = 100
+    solver.setup(prob)
+    xs, us = pd.initial_guess()
+    t0 = time.perf_counter()
+    solver.run(prob, xs, us)
+    cold_ms = (time.perf_counter() - t0) * 1e3
+    cold_iters, cold_conv = int(solver.results.num_iters), bool(solver.results.conv)
+    xs, us = solver.results.xs.tolist(), solver.results.us.tolist()
+    solver.max_iters = 1
+    ms = []
+    for t in range(args.warmup + args.steps):
+        stage = pd.stage_for_tick(t % pd.t_mpc)
+        prob.replaceStageCircular(stage)
+        solver.workspace.cycleAppend(stage.createData())
+        xs = xs[1:] + [xs[-1]]
+        us = us[1:] + [us[-1]]
+        prob.x0_init = xs[0]  # perfect-model feedback, as the GPU measurement
+        t0 = time.perf_counter()
+        solver.setup(prob)
+        solver.run(prob, xs, us)
+        dt = (time.perf_counter() - t0) * 1e3
+        if t >= args.warmup:
+            ms.append(dt)
+        xs, us = solver.results.xs.tolist(), solver.results.us.tolist()
+    ms = sorted(ms)
+    print(json.dumps({"aligator_reference": {"p50_ms_per_solve": ms[len(ms) // 2], "p90_ms_per_solve": ms[int(0.9 * (len(ms) - 1))],
+                                             "solves_per_sec_one_instance": 1e3 * len(ms) / sum(ms), "threads": 8, "steps": args.steps,
+                                             "cold_solve_ms": cold_ms, "cold_solve_iters": cold_iters, "cold_solve_converged": cold_conv,
+                                             "aligator_version": getattr(aligator, "__version__", "?"),
+                                             "problem": "fulldynamic_talos.py OCP on talos_synth_v1/%s, N = %d" % (args.model, args.horizon)}}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,10 +172,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", type=int, default=0, help="(internal) run this many MPC ticks of one instance on the CPU port with 8 threads and print their times")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--aligator", action="store_true", help="time the real aligator.SolverProxDDP on the identical problem instead (where the reference stack is importable) and exit")
     args = ap.parse_args()
 
     if args.cpu_worker > 0:
         return cpu_worker(args)
+    if args.aligator:
+        return aligator_reference(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

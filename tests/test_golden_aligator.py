@@ -129,3 +129,20 @@ def test_hip_matches_aligator_stage_outputs(hip_lib, name):
 @pytest.mark.parametrize("name", PROBLEMS)
 def test_hip_matches_aligator_solves(hip_lib, name):
     _check_solves(hip_lib, name)
+
+
+def test_bench_aligator_hook_reports_the_missing_stack():
+    """`python bench.py --aligator`: times the real Aligator where it is importable; without it one JSON line says so."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        import aligator  # noqa: F401
+        pytest.skip("the reference stack is importable here: run bench.py --aligator by hand")
+    except ImportError:
+        pass
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--aligator"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-400:]
+    line = json.loads(out.stdout.strip().split("\n")[-1])
+    assert line["aligator_reference"] is None and "not importable" in line["reason"]
