@@ -183,7 +183,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MPC_BENCH_FORCE_DIST"):  # (MPC_BENCH_FORCE_DIST=1: exercise the RCCL path with a single rank, developer check)
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
