@@ -113,3 +113,25 @@ def test_mpc_ticks_from_the_oracle_iterate(hip_lib, oracle_lib, horizon, complet
             err = rel_cols(a[key][0], b[key][0], floor)
             assert err < 1e-6, "tick %d: %s deviates from the oracle by %.2e" % (t, key, err)
         assert _rel(a["K"][0, 0], b["K"][0, 0]) < 1e-6, "tick %d: K_0" % t
+
+
+def test_config4_ensemble_walks_its_whole_schedule(hip_lib):
+    """BASELINE.json config 4 (kinodynamic N = 150, 64 instances, complete model, upper body perturbed, 4 legs, tick reuse) over the
+    whole schedule of kinodynamic_talos.py (820 ticks: three steps per foot and the stop) with the reference's ONE iteration per tick:
+    no instance is lost, every tick takes a step, all instances end next to the nominal one."""
+    from mpc_benchmark_amd.ensemble import EnsembleMPC
+    kp = KinodynamicProblem(horizon=150, complete_model=True)
+    ens = EnsembleMPC(kp, batch=64, library=hip_lib, seed=7, perturb_dofs=range(18, kp.nv), tick_reuse=True)
+    ens.options.riccati_legs = 4
+    ens.native.set_options(ens.options)
+    ticks = kp.t_mpc - 1
+    ens.prepare_schedule(ticks + 4)
+    st = ens.cold_solve(max_iters=100)
+    assert all(s.converged for s in st)
+    nostep = 0
+    for _ in range(ticks):
+        st = ens.step()   # raises if the library loses an instance
+        nostep += sum(1 for s in st if s.num_iters == 0)
+    c = np.array([s.traj_cost for s in st])
+    assert nostep == 0 and np.all(np.isfinite(c))
+    assert c.min() > 0.8 * c[0] and c.max() < 1.5 * c[0], (c.min(), c.max(), c[0])  # (standing at the end: the upper-body postures are still settling under their small weights)
