@@ -251,6 +251,14 @@ int64_t mpc_state_size(mpc_solver* s);
 int64_t mpc_get_state(mpc_solver* s, double* buf, int64_t cap);
 int mpc_set_state(mpc_solver* s, const double* buf, int64_t len);
 
+/* Failure policy of an ensemble.  isolate = 0 (default): a failed factorisation on any instance makes the run return an error, as a
+ * single solver would.  isolate = 1: the instance is reported (mpc_stats.converged = -code: 2 / 3 / 4 Riccati blocks, 5 / 6 contact
+ * dynamics), keeps the iterate it had when the pass started failing and is skipped by every later run until it is revived; the other
+ * instances are not affected.  mpc_revive_instance(dst, src): dst takes over the iterate, multipliers and measured state of instance
+ * src (e.g. the nominal one) and takes part again from the next run on. */
+int mpc_set_failure_policy(mpc_solver* s, int32_t isolate);
+int mpc_revive_instance(mpc_solver* s, int32_t dst, int32_t src);
+
 /* Phase dumps for parity tests: copies the named per-knot quantity of instance b, knot k into out
  * (capacity cap doubles) and returns the number of doubles written (<0 on error).  Names:
  * "H" "grad" "AB" "f" "E6" "cval" "CD" "cost" "P" "p" "K" "kff" "Knu" "knu" "dx" "du" "dvs" "dlams" "xnext".

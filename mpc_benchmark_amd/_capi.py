@@ -84,6 +84,8 @@ _SIGNATURES = {
     "mpc_simulate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "mpc_simulate_push": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _DP]),
     "mpc_set_tick_reuse": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mpc_set_failure_policy": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mpc_revive_instance": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "mpc_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mpc_get_x0": (C.c_int, [C.c_void_p, _DP]),
     "mpc_setup": (C.c_int, [C.c_void_p]),
@@ -277,6 +279,13 @@ class NativeSolver:
         xn = np.zeros((self.dims.batch, self.dims.nx))
         self._check(self.lib.mpc_wait_state(self._h, stats, _dp(xn)), "mpc_wait_state")
         return list(stats), xn
+
+    def set_failure_policy(self, isolate):
+        """isolate: a failed instance is reported (``stats.converged = -code``) and skipped until revived instead of failing the run."""
+        self._check(self.lib.mpc_set_failure_policy(self._h, int(bool(isolate))), "mpc_set_failure_policy")
+
+    def revive_instance(self, dst, src=0):
+        self._check(self.lib.mpc_revive_instance(self._h, int(dst), int(src)), "mpc_revive_instance")
 
     def get_gain(self, k=0):
         """-> (K_k[B][nu][ndx], kff_k[B][nu]) of one knot (mpc_get_gain)."""

@@ -56,6 +56,7 @@ struct mpc_solver {
   size_t mb_work_stride = 0;
   bool perfect_feedback = false;
   // tick reuse (mpc_set_tick_reuse): see SolverArgs
+  bool isolate = false;  // mpc_set_failure_policy
   bool tick_reuse = false, reuse_this_pass = false, reuse_same_now = false;
   int pass_in_run = 0;  // index of the pass being enqueued within its run
   // speculative evaluation of the appended knot (eval_multibody.h): the spare records hold one made with the table of the then last
@@ -165,7 +166,7 @@ struct mpc_solver {
     a.stage_desc = d_stage_desc; a.stage_params = d_stage_params; a.model_i = d_model_i; a.model_d = d_model_d;
     a.xs = d_xs; a.us = d_us; a.vs = d_vs; a.lams = d_lams; a.vs_e = d_vs_e; a.lams_e = d_lams_e; a.x0 = d_x0;
     a.dxs = d_dxs; a.dus = d_dus; a.dvs = d_dvs; a.dlams = d_dlams; a.abdz = nullptr;
-    a.khead = khead; a.spec = d_spec;
+    a.khead = khead; a.spec = d_spec; a.isolate = isolate ? 1 : 0;
     // an MPC tick: one iteration (the reference loop) or a few (max_iters <= 4).  The last pass of a replanning tick (spec_skip_pass)
     // evaluates its candidate value-only; its first pass reuses nothing.
     const bool mpc_tick = tick_reuse && opt.max_iters <= 4 && L.space == MPC_SPACE_MULTIBODY;
@@ -642,10 +643,10 @@ static void launch_pass(mpc_solver* s) {
 static void report_status(mpc_solver* s, int B, const InstState* st, mpc_stats* stats) {
   for (int b = 0; b < B; ++b) {
     if (st[b].done >= 2) s->leg_guess_valid = false;  // do not start the legs of the next pass from what a failed sweep left
-    if (st[b].done >= 2) throw std::runtime_error("Riccati factorisation failed on instance " + std::to_string(b) + " (code " + std::to_string(st[b].done) + ")");
+    if (st[b].done >= 2 && !s->isolate) throw std::runtime_error("Riccati factorisation failed on instance " + std::to_string(b) + " (code " + std::to_string(st[b].done) + ")");
     if (!stats) continue;
     mpc_stats& o = stats[b];
-    o.num_iters = st[b].num_iters; o.converged = st[b].converged; o.al_iters = st[b].al_iters; o.ls_steps = st[b].ls_step;
+    o.num_iters = st[b].num_iters; o.converged = st[b].done >= 2 ? -st[b].done : st[b].converged; o.al_iters = st[b].al_iters; o.ls_steps = st[b].ls_step;
     o.traj_cost = st[b].cost; o.merit = st[b].phi0; o.prim_infeas = st[b].prim; o.dual_infeas = st[b].dual; o.mu = st[b].mu; o.alpha = st[b].alpha;
   }
 }
@@ -1243,6 +1244,29 @@ int mpc_get_stage_data(mpc_solver* s, int32_t k, double* xdot, double* wrenches)
       if (xdot) copy_sync(s, xdot + (size_t)b * L.n, kn + L.oXD, L.n * sizeof(double), hipMemcpyDeviceToHost);
       if (wrenches) copy_sync(s, wrenches + (size_t)b * 12, kn + L.oWR, 12 * sizeof(double), hipMemcpyDeviceToHost);
     }
+  })
+}
+
+int mpc_set_failure_policy(mpc_solver* s, int32_t isolate) {
+  MPC_TRY(s, { s->isolate = isolate != 0; })
+}
+
+int mpc_revive_instance(mpc_solver* s, int32_t dst, int32_t src) {
+  MPC_TRY(s, {
+    const Layout& L = s->L;
+    if (dst < 0 || dst >= L.B || src < 0 || src >= L.B || src == dst) throw std::runtime_error("revive_instance: instance index out of range");
+    if (s->async_pending > 0) throw std::runtime_error("revive_instance: ticks in flight (call mpc_wait first)");
+    auto row = [&](double* base, size_t per_inst) {
+      HIP_OK(hipMemcpyAsync(base + (size_t)dst * per_inst, base + (size_t)src * per_inst, per_inst * sizeof(double), hipMemcpyDeviceToDevice, s->stream));
+    };
+    row(s->d_xs, (size_t)(L.N + 1) * L.nx); row(s->d_us, (size_t)L.N * L.m);
+    row(s->d_vs, (size_t)(L.N + 1) * L.c); row(s->d_vs_e, (size_t)(L.N + 1) * L.c);
+    row(s->d_lams, (size_t)(L.N + 2) * L.n); row(s->d_lams_e, (size_t)(L.N + 2) * L.n);
+    row(s->d_x0, (size_t)L.nx);
+    HIP_OK(hipMemcpyAsync(s->d_inst + dst, s->d_inst + src, sizeof(InstState), hipMemcpyDeviceToDevice, s->stream));
+    if (s->d_spec) HIP_OK(hipMemsetAsync(s->d_spec + dst, 0, sizeof(int), s->stream));  // its knot records belong to the old iterate
+    s->leg_guess_valid = false;  // the kept cut Hessians of dst belong to the old iterate as well
+    HIP_OK(hipStreamSynchronize(s->stream));
   })
 }
 

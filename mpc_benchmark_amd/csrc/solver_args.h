@@ -24,6 +24,7 @@ struct SolverArgs {
   // Tick reuse (MPC ticks with max_iters = 1): the full step of tick t is evaluated WITH derivatives straight into the knot
   // records, which are ring-indexed like the stage tables; when it is accepted, tick t + 1 finds the records of its knots
   // 0 .. N-2 already there and only re-projects the constraint values under the fresh multipliers.
+  int isolate;    // mpc_set_failure_policy: a failed instance is remembered (InstState::converged = -code) and skipped instead of failing the run
   int khead;      // ring head of the N running knot records (the terminal record has its own slot)
   int spec_on;    // the alpha = 1 candidate of this pass writes full records (k_eval_multibody<3>)
   int reuse_on;   // this tick may reuse records marked valid in spec[]

@@ -693,6 +693,7 @@ __global__ void k_accept(SolverArgs a) {
 // bookkeeping after a step.  grid B, block 1
 __global__ void k_after_step(SolverArgs a) {
   InstState& st = a.inst[blockIdx.x];
+  if (a.isolate && st.done >= 2 && st.converged >= 0) st.converged = -st.done;  // a failed factorisation: remembered across runs (mpc_set_failure_policy)
   if (st.done) return;
   const bool stepped = !st.skip_step && !(st.stalled & 1);
   if (stepped) {
@@ -718,9 +719,11 @@ __global__ void k_setup(SolverArgs a) {
     for (int i = tid; i < L.c; i += blockDim.x) { a.vs[vrow + i] = 0.0; a.vs_e[vrow + i] = 0.0; }
   }
   if (k == 0 && tid == 0) {
+    const int failed = (a.isolate && a.inst[b].converged < 0) ? a.inst[b].converged : 0;  // (stays out until mpc_revive_instance)
     InstState z;
     memset(&z, 0, sizeof(z));
     z.mu = a.opt.mu_init;
+    z.converged = failed; z.done = -failed;
     a.inst[b] = z;
   }
 }
@@ -732,7 +735,8 @@ __global__ void k_begin_run(SolverArgs a) {
   InstState& st = a.inst[b];
   if (a.opt.force_initial_condition)
     for (int i = tid; i < L.nx; i += blockDim.x) a.xs[(size_t)b * (L.N + 1) * L.nx + i] = a.x0[(size_t)b * L.nx + i];
-  if (tid == 0) {
+  if (tid == 0 && a.isolate && st.converged < 0) { st.done = -st.converged; st.num_iters = 0; st.skip_step = 0; }  // a failed instance sits this run out
+  else if (tid == 0) {
     st.num_iters = 0; st.al_iters = 0; st.converged = 0; st.done = 0; st.skip_step = 0; st.ls_step = 0; st.alpha = 0;
     st.stalled = 0; st.ls_more = 0;
     st.prim_tol = fmax(a.opt.prim_tol0 * pow(st.mu, a.opt.bcl_prim_alpha), a.opt.tol);

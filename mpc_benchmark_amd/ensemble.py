@@ -67,6 +67,8 @@ class EnsembleMPC:
         # robot stable over the whole schedule
         self.iters_per_tick = 1
         self.inflight = 0   # asynchronous ticks enqueued and not yet collected (step_async / wait)
+        self._isolate = None  # enable_failure_isolation(): (auto_revive, source)
+        self.lost, self.revived = [], 0
         self._walk = None   # enable_walk(): the reference loop's per-tick problem updates
 
     # -- stage tables of the schedule ---------------------------------------------------------------
@@ -148,8 +150,8 @@ class EnsembleMPC:
                 self.native.run_shifted_async()
                 stats, xn = self.native.wait_state()
                 self._walk["x_measured"] = xn[0].copy()
-                return stats
-            return self.native.run_shifted()
+                return self._handle_lost(stats)
+            return self._handle_lost(self.native.run_shifted())
         except RuntimeError as e:
             if not rescue or "factorisation failed" not in str(e):
                 raise
@@ -160,6 +162,10 @@ class EnsembleMPC:
         """Enqueue one tick without waiting (several shards on different streams overlap on the device); ``wait``
         completes the oldest tick in flight.  Two ticks may be in flight: enqueue tick t + 1, then wait for tick t
         (``self.inflight`` counts them)."""
+        if getattr(self, "_need_drain", False):
+            self._need_drain = False
+            while self.inflight:
+                self.wait()
         if self.closed_loop:
             self.native.simulate(*self.closed_loop)
         if self._walk is not None:
@@ -180,8 +186,8 @@ class EnsembleMPC:
             if self._walk is not None:
                 stats, xn = self.native.wait_state()
                 self._walk["x_measured"] = xn[0].copy()  # instance 0's predicted next state: the measurement the generators plan from
-                return stats
-            return self.native.wait()
+                return self._handle_lost(stats)
+            return self._handle_lost(self.native.wait())
         except RuntimeError as e:
             if not rescue or "factorisation failed" not in str(e):
                 raise
@@ -193,6 +199,37 @@ class EnsembleMPC:
                 except RuntimeError:
                     pass
             return self.cold_solve(max_iters=20)
+
+    # -- one instance failing does not stop the ensemble -------------------------------------------------------------------
+    def enable_failure_isolation(self, auto_revive=True, source=0):
+        """mpc_set_failure_policy(1): an instance whose factorisation fails is reported (``stats.converged = -code``) and sits out the
+        following ticks instead of failing the whole tick.  ``auto_revive``: as soon as no tick is in flight it is re-seeded from instance
+        ``source`` (the nominal one: iterate, multipliers, measured state — mpc_revive_instance) and takes part again; ``self.lost`` keeps
+        (tick, instance, code), ``self.revived`` counts."""
+        self.native.set_failure_policy(True)
+        self._isolate = (bool(auto_revive), int(source))
+
+    def _handle_lost(self, stats):
+        if self._isolate is None:
+            return stats
+        lost = [b for b, s in enumerate(stats) if s.converged < 0]
+        for b in lost:
+            if not any(t_b == b and done is None for (_, t_b, _, done) in self._lost_open()):
+                self.lost.append([self.tick, b, -int(stats[b].converged), None])
+        auto, src = self._isolate
+        if auto and lost and self.inflight > 0:
+            self._need_drain = True  # step_async completes the ticks in flight before it enqueues the next one: reviving needs an idle handle
+        if auto and lost and self.inflight == 0 and src not in lost:
+            for b in lost:
+                self.native.revive_instance(b, src)
+                self.revived += 1
+                for rec in self.lost:
+                    if rec[1] == b and rec[3] is None:
+                        rec[3] = self.tick
+        return stats
+
+    def _lost_open(self):
+        return [tuple(r) for r in self.lost if r[3] is None]
 
     # -- the reference loop's per-tick problem updates on the shared stage tables ---------------------------------
     def enable_walk(self, swing_apex=0.15, x_forward=0.0, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0):

@@ -13,6 +13,8 @@ struct mpc_solver {
   Solver s;
   std::string err;
   bool perfect_feedback = false;
+  bool isolate = false;        // mpc_set_failure_policy
+  std::vector<int> failed;     // per instance: 0 or the failure code reported as mpc_stats.converged = -code
 };
 
 #define MPC_TRY(h, ...)                  \
@@ -132,8 +134,21 @@ int mpc_setup(mpc_solver* h) { MPC_TRY(h, h->s.setup()) }
 
 static void run_all(mpc_solver* h, mpc_stats* stats) {
   Solver& s = h->s;
+  h->failed.resize(s.dims.batch, 0);
   for (int b = 0; b < s.dims.batch; ++b) {
-    s.run_instance(s.inst[b]);
+    if (h->isolate && h->failed[b]) {  // sits this run out until mpc_revive_instance
+      s.inst[b].stats.num_iters = 0; s.inst[b].stats.converged = -h->failed[b];
+    } else if (!h->isolate) {
+      s.run_instance(s.inst[b]);
+    } else {
+      try {
+        s.run_instance(s.inst[b]);
+      } catch (const std::exception& e) {  // the codes of the HIP library: 2 / 3 / 4 the blocks of the Riccati step, 5 anything else
+        const std::string what = e.what();
+        h->failed[b] = what.find("mu_dyn P") != std::string::npos ? 2 : what.find("control Hessian") != std::string::npos ? 3 : what.find("Schur") != std::string::npos ? 4 : 5;
+        s.inst[b].stats.converged = -h->failed[b];
+      }
+    }
     if (stats) stats[b] = s.inst[b].stats;
   }
 }
@@ -309,6 +324,20 @@ int mpc_get_stage_data(mpc_solver* h, int32_t k, double* xdot, double* wrenches)
       if (xdot) for (int i = 0; i < s.dims.ndx; ++i) xdot[b * s.dims.ndx + i] = i < (int)kn.xdot.size() ? kn.xdot[i] : 0.0;
       if (wrenches) std::memcpy(wrenches + b * 12, kn.wrench, 12 * sizeof(double));
     }
+  })
+}
+
+int mpc_set_failure_policy(mpc_solver* h, int32_t isolate) {
+  MPC_TRY(h, { h->isolate = isolate != 0; })
+}
+
+int mpc_revive_instance(mpc_solver* h, int32_t dst, int32_t src) {
+  MPC_TRY(h, {
+    Solver& s = h->s;
+    if (dst < 0 || dst >= s.dims.batch || src < 0 || src >= s.dims.batch || src == dst) throw std::runtime_error("revive_instance: instance index out of range");
+    s.inst[dst] = s.inst[src];
+    h->failed.resize(s.dims.batch, 0);
+    h->failed[dst] = 0;
   })
 }
 

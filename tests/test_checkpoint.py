@@ -82,3 +82,27 @@ def test_hip_state_restores_into_the_oracle(hip_lib, oracle_lib):
     r = o.results(gains=True)
     for key in ("xs", "us"):
         assert float(np.max(np.abs(r[key] - ref[key])) / max(1.0, np.max(np.abs(ref[key])))) < 1e-6, key
+
+
+def test_failure_policy_and_revive_on_the_oracle(oracle_lib):
+    """mpc_set_failure_policy / mpc_revive_instance (include/mpc_abi.h): reviving instance 1 from instance 0 makes it continue as a copy
+    of instance 0 — iterate, multipliers, measured state — while instance 2 is untouched."""
+    from mpc_benchmark_amd.ensemble import EnsembleMPC
+    from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+    pd = FullDynamicsProblem(horizon=8)
+    e = EnsembleMPC(pd, batch=3, library=oracle_lib, seed=4, sigma_q=0.01, sigma_v=0.02)
+    e.prepare_schedule(12)
+    e.cold_solve(max_iters=8)
+    e.enable_failure_isolation()
+    for _ in range(2):
+        e.step()
+    before = e.results(gains=False)
+    assert not np.array_equal(before["xs"][0], before["xs"][1])
+    e.native.revive_instance(1, 0)
+    st = e.step()
+    r = e.results(gains=False)
+    assert np.array_equal(r["xs"][0], r["xs"][1]) and np.array_equal(r["us"][0], r["us"][1])
+    assert not np.array_equal(r["xs"][0], r["xs"][2])
+    assert all(s.converged >= 0 for s in st) and e.lost == [] and e.revived == 0
+    with pytest.raises(RuntimeError):
+        e.native.revive_instance(1, 1)

@@ -111,3 +111,31 @@ def test_whole_schedule_walk_with_two_iterations_per_tick(hip_lib):
     assert np.max(np.abs(c - c[0])) < 0.05 * abs(c[0])
     r = e.results(gains=False)
     assert np.all(np.isfinite(r["xs"])) and np.all(np.isfinite(r["us"]))
+
+
+def test_failed_instances_are_isolated_and_revived(hip_lib):
+    """mpc_set_failure_policy(1) on the benchmarked ensemble with the reference's ONE iteration per tick, over the stretch of the schedule
+    where perturbed instances are lost: the tick never raises, a lost instance is reported with its code, sits out, is
+    re-seeded from the nominal instance when the handle is idle, and walks on; the nominal instance itself is never lost.  Pipelined
+    driver (two ticks in flight)."""
+    pd = FullDynamicsProblem(horizon=N, complete_model=True)
+    (e,) = make_bench_shards(pd, hip_lib, 32, legs=4, tick_reuse=True)
+    e.prepare_schedule(260)
+    e.cold_solve(max_iters=100)
+    e.enable_failure_isolation(auto_revive=True, source=0)
+    seen_negative = 0
+    for t in range(250):
+        e.step_async()
+        if e.inflight == 2:
+            st = e.wait()
+            seen_negative += sum(1 for s in st if s.converged < 0)
+    while e.inflight:
+        e.wait()
+    assert len(e.lost) >= 1 and e.revived >= 1, (e.lost, e.revived)          # the scenario does lose instances with one iteration per tick
+    assert all(rec[1] != 0 for rec in e.lost)                               # never the nominal one
+    assert all(rec[2] in (2, 3, 4, 5, 6) for rec in e.lost) and seen_negative >= len(e.lost)
+    r = e.results(gains=False)
+    st = e.native.wait()
+    alive = [b for b, s in enumerate(st) if s.converged >= 0]
+    assert 0 in alive and len(alive) >= 28
+    assert np.all(np.isfinite(r["xs"][alive])) and np.all(np.isfinite(r["us"][alive]))

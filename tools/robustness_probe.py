@@ -28,6 +28,8 @@ for env, field in (("DYN_SCALE", "dyn_al_scale"), ("ARMIJO", "ls_armijo_c1"), ("
 if os.environ.get("ITERS"):
     e.options.max_iters = int(os.environ["ITERS"]); e.native.set_options(e.options)
 extra_total = 0
+if os.environ.get("ISOLATE"):  # mpc_set_failure_policy(1) + re-seeding lost instances from the nominal one
+    e.enable_failure_isolation(auto_revive=True, source=0)
 if os.environ.get("NOSETUP"):  # keep multipliers (and mu) across ticks: no per-tick setup()
     e.native.setup = lambda: None
 hist = []
@@ -49,4 +51,4 @@ for t in range(1, ticks + 1):
         print("tick %4d cost nominal %.3e median %.3e max %.3e | alpha<1: %d | iterations beyond one per tick so far %d (%.2f %% of instance ticks)" % (
             t, c[0], np.median(c), c.max(), int((al < 1).sum()), extra_total, 100.0 * extra_total / (t * batch)))
 else:
-    print("no failure in", ticks, "ticks")
+    print("no failure in", ticks, "ticks" + ("; instances lost and revived: %d (%s ...)" % (e.revived, [tuple(r) for r in e.lost[:6]]) if os.environ.get("ISOLATE") else ""))
