@@ -231,6 +231,9 @@ def main():
             worst_unconv = max([locals().get("worst_unconv", 0.0)] + [max(st.prim_infeas, st.dual_infeas) for st in c if not st.converged])
             cold = cold or c
             e.save_episode()
+            # an instance that fails does not stop the ensemble: it is reported, sits out and is re-seeded from the nominal one
+            # (`instances_lost_and_revived` in the JSON line; 0 in the default window)
+            e.enable_failure_isolation(auto_revive=True, source=0)
             if walk:
                 e.enable_walk()
 
@@ -598,6 +601,7 @@ def main():
                                                                   "kernel_ms_per_step_warmup": {k: round(v[1] / max(1, args.warmup), 4) for k, v in sorted(r["warm"].items(), key=lambda kv: -kv[1][1])[:6]}}
                          for w, r in runs.items()},
         "instance_ticks_without_step": nostep["n"] * world, "diverged_instance_rescues": sum(getattr(e, "rescues", 0) for e in shards),
+        "instances_lost_and_revived": sum(getattr(e, "revived", 0) for e in shards),
         "episode_ticks": args.episode, "episode_restarts": sum(getattr(e, "episodes", 0) for e in shards),
         "ensemble_allgather": gather,
         "roofline": roof, "cpu_baseline": cpu, "roofline_riccati": roof_ric,
