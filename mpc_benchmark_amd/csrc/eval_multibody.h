@@ -134,6 +134,7 @@ __global__ void __launch_bounds__(EVAL_THREADS, EVAL_MIN_WAVES) k_eval_multibody
   const double* P = a.stage_params + (size_t)slot * L.max_stage_doubles;
   const int dyn = desc[0];
   const bool has_dyn = dyn == MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER;   // contact-constrained forward dynamics
+  if (has_dyn && !S.contact_dyn) { if (threadIdx.x == 0) a.inst[b].done = 5; return; }  // (host bug guard: this carve-out has no room for the factor of M)
   const bool kino = dyn == MPC_DYN_KINODYNAMICS_SEMIEULER;               // kinodynamics: u = [wrenches ; joint accelerations]
   const int m = (has_dyn || kino) ? nu : 0, nz = n + m, nterms = desc[5], c = desc[6];
   const int nk = has_dyn ? desc[1] : 0, nl = 6 * nk;

@@ -6,10 +6,10 @@
 #include "eval_multibody.h"
 
 void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout& LT, double* records, double* scratch, size_t scratch_stride,
-                           bool trial, int cand0, int ncand, int sim_substeps, double sim_dt, bool with_derivs, const double* f_ext) {
+                           bool trial, int cand0, int ncand, int sim_substeps, double sim_dt, bool with_derivs, const double* f_ext, bool contact_dyn) {
   const Layout& L = a.L;
   MbArgs mb;
-  mb.lds = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m, L.nz);
+  mb.lds = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m, L.nz, contact_dyn);
   mb.scratch = scratch;
   mb.scratch_stride = scratch_stride;
   mb.sim_substeps = sim_substeps; mb.sim_dt = sim_dt; mb.f_ext = f_ext;
@@ -21,7 +21,7 @@ void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::atomic<int>& attr_bytes = attr_bytes_dev[dev & 63];
-  if (attr_bytes.load() != mb.lds.total_bytes + 1) {
+  if (attr_bytes.load() < mb.lds.total_bytes + 1) {  // (the largest request so far stays: the two carve-outs of a process differ)
     // the kernel also owns a few bytes of static LDS, so request exactly what the carve-out needs
     hipError_t e1 = hipFuncSetAttribute((const void*)k_eval_multibody<0>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
     hipError_t e2 = hipFuncSetAttribute((const void*)k_eval_multibody<1>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);

@@ -44,12 +44,15 @@ struct MbLds {
   int total;
   int stage_rows;  // rows of Jacobian staging (ld nz) that fit in the JS region
   int anc_bytes_off, total_bytes;
+  int contact_dyn;  // the carve-out holds the blocks of the contact-constrained dynamics
   unsigned mg_nv, mg_nj, mg_nz, mg_n;  // magic_div (device_common.h) of the run-time divisors nv, nj, n + nu, n of the per-element loops
 };
 
 #define MB_RED_DOUBLES (112 + 24 * (EVAL_THREADS / 64))  // [0,16) merit partials | [16,48) sqrt(W) r of the stacked rows | [48,112) residual of a workgroup term | then 24 per wavefront
 
-static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz) {
+// contact_dyn = false: no stage of the problem has contact-constrained dynamics (kinodynamic / kinematic problems) — the factor of M, the
+// right-hand-side blocks and the d lambda rows are never touched and get no LDS (BASELINE config 4: 88.8 -> 76.7 KB, two workgroups per CU)
+static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz, bool contact_dyn = true) {
   MbLds s;
   s.nj = nj; s.nv = nv; s.nq = nq; s.nl_max = 12;
   s.nvp = (nv + 15) & ~15; s.nbm = s.nvp / 16;
@@ -73,18 +76,20 @@ static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz) {
   const int e1 = o;
   o = b3;
   const int ntile = s.nbm * (s.nbm + 1) / 2;
-  s.Mt = take(ntile * 272); s.Y16 = take(s.nvp * MB_LDY); s.Sp = take(272); s.LIs = take(272);
+  if (contact_dyn) { s.Mt = take(ntile * 272); s.Y16 = take(s.nvp * MB_LDY); s.Sp = take(272); s.LIs = take(272); }
+  else s.Mt = s.Y16 = s.Sp = s.LIs = b3;  // (never dereferenced)
   if (o < e1) o = e1;
   // terms: stacked cost rows (<= 32) / the rows of the constraint being emitted, ld nz, from Yc on (Yc and the stage-2 blocks are dead)
   s.JS = s.Yc;
   const int js_rows = 32 > MB_STAGE_CONSTRAINT_ROWS ? 32 : MB_STAGE_CONSTRAINT_ROWS;
   if (o < s.JS + js_rows * mb_ldj(nz) + 8) o = (s.JS + js_rows * mb_ldj(nz) + 8 + 1) & ~1;
   s.stage_rows = (o - s.JS) / mb_ldj(nz);
-  s.DL = take(12 * s.ldl > s.nvp * 16 ? 12 * s.ldl : s.nvp * 16);
+  s.DL = contact_dyn ? take(12 * s.ldl > s.nvp * 16 ? 12 * s.ldl : s.nvp * 16) : take(2);
   s.V16 = s.DL;
   s.total = o;
   s.anc_bytes_off = o * 8;
   s.total_bytes = o * 8 + 4 * nj * 8 + nv * 4 + nj * 4 * 3 + 64;
+  s.contact_dyn = contact_dyn ? 1 : 0;
   s.mg_nv = magic_div(nv); s.mg_nj = magic_div(nj); s.mg_nz = magic_div(nz); s.mg_n = magic_div(2 * nv);
   return s;
 }
@@ -121,5 +126,5 @@ struct MbArgs {
 // defined in eval_multibody.hip
 void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout& LT, double* records, double* scratch, size_t scratch_stride,
                            bool trial, int cand0 = 0, int ncand = 1, int sim_substeps = 0, double sim_dt = 0.0, bool with_derivs = false,
-                           const double* f_ext = nullptr);
+                           const double* f_ext = nullptr, bool contact_dyn = true);
 const void* eval_multibody_kernel(int trial);  // entry point of k_eval_multibody<trial> (occupancy tooling)

@@ -57,6 +57,7 @@ struct mpc_solver {
   bool perfect_feedback = false;
   // tick reuse (mpc_set_tick_reuse): see SolverArgs
   bool isolate = false;  // mpc_set_failure_policy
+  bool contact_dyn = false;  // some stage uploaded so far has contact-constrained dynamics (sticky): the stage kernel's LDS carve-out holds the factor of M
   bool tick_reuse = false, reuse_this_pass = false, reuse_same_now = false;
   int pass_in_run = 0;  // index of the pass being enqueued within its run
   // speculative evaluation of the appended knot (eval_multibody.h): the spare records hold one made with the table of the then last
@@ -344,6 +345,7 @@ static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_des
   }
   if (nse3 > MB_SE3_SLOTS) throw std::runtime_error("too many SE(3)-valued terms in one stage for the whole-body kernel");
   if (nc != desc[6]) throw std::runtime_error("stage descriptor: constraint row count mismatch");
+  if (desc[0] == MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER) s->contact_dyn = true;
   // receding horizon: the stage that enters the ring usually equals the one that left the slot (same contact phase,
   // same references) — nothing to move then
   int32_t* hd = s->h_desc.data() + (size_t)slot * L.max_stage_ints;
@@ -486,7 +488,7 @@ static void launch_eval(mpc_solver* s, bool trial, int cand0 = 0, int ncand = 1,
     if (!trial) hipLaunchKernelGGL(k_eval_vector<0>, dim3(L.N + 1, L.B, 1), dim3(64), 0, s->stream, a, s->L, s->d_knots, 0);
     else hipLaunchKernelGGL(k_eval_vector<1>, dim3(L.N + 1, L.B, ncand), dim3(64), 0, s->stream, a, s->LT, s->d_tknots, cand0);
   } else {
-    launch_eval_multibody(s->stream, a, s->LT, (trial && !with_derivs) ? s->d_tknots : s->d_knots, s->d_mbwork, s->mb_work_stride, trial, cand0, ncand, 0, 0.0, with_derivs);
+    launch_eval_multibody(s->stream, a, s->LT, (trial && !with_derivs) ? s->d_tknots : s->d_knots, s->d_mbwork, s->mb_work_stride, trial, cand0, ncand, 0, 0.0, with_derivs, nullptr, s->contact_dyn);
   }
   HIP_OK(hipGetLastError());
 }
@@ -895,7 +897,7 @@ int mpc_kernel_info(mpc_solver* s, int32_t idx, char* name, int32_t name_cap, in
       e.push_back({"k_eval_vector<0> (stage kernel, value + derivatives)", (const void*)k_eval_vector<0>, 64, 0, (long long)(L.N + 1) * L.B});
       e.push_back({"k_eval_vector<1> (linesearch candidate)", (const void*)k_eval_vector<1>, 64, 0, (long long)(L.N + 1) * L.B});
     } else {
-      const MbLds ml = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m, L.nz);
+      const MbLds ml = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m, L.nz, s->contact_dyn);
       e.push_back({"k_eval_multibody<0> (stage kernel, value + derivatives)", eval_multibody_kernel(0), EVAL_THREADS, ml.total_bytes, (long long)(L.N + 1) * L.B});
       e.push_back({"k_eval_multibody<3> (alpha = 1 candidate with derivatives)", eval_multibody_kernel(3), EVAL_THREADS, ml.total_bytes, (long long)(L.N + 1) * L.B});
       e.push_back({"k_eval_multibody<1> (backtracking candidates, values only)", eval_multibody_kernel(1), EVAL_THREADS, ml.total_bytes, (long long)(L.N + 1) * L.B});
