@@ -87,6 +87,20 @@ int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* settings, int32_t n
                     const int32_t* contact_states, double* x, double* y, double* z, mpc_qp_info* info, double* A_out, double* b_out,
                     double* C_out, double* l_out);
 
+/* The same for the IK + ID QP of the centroidal pipeline (QP_utils.py:584-762 IKIDSolver_f6, centroidal_talos.py:326, 435): unknowns
+ * (a, df, tau); posture, foot-acceleration, centroidal-momentum-rate and base / torso orientation tasks in the cost, dynamics and
+ * contact-acceleration equalities, wrench cones, torque box.  The handle must have n = 2 nv - 6 + 6 nk, neq = nv + 6 nk, nin = 9 nk,
+ * box = 1, nk = 2.  weights[5] (posture, feet, momentum, orientation, force increments); gains: Kp, Kd of the posture task (nv x nv
+ * each, row-major), of the foot tasks (6 x 6 each), of the orientation tasks (3 x 3 each); l_box / u_box [n] (the torque box, +-inf
+ * elsewhere as large numbers); ik[B][2 nv + 42] per robot: q_diff, dq_diff | per contact: pose error (6), its rate (6) | base_diff,
+ * dbase_diff, torso_diff, dtorso_diff (3 each) | dH (6): the task errors the script computes from its references.  Outputs as
+ * mpc_qp_solve plus the assembled H, g, A, b, C, l (each may be NULL). */
+int mpc_qp_solve_ikid(mpc_qp_solver* s, const mpc_qp_settings* settings, int32_t nk, const int32_t* frames, int32_t base_frame, int32_t torso_frame,
+                      const double* weights, const double* gains, const double* cone, const double* l_box, const double* u_box,
+                      const double* xrob, const double* ik, const double* forces, const int32_t* contact_states,
+                      double* x, double* y, double* z, double* z_box, mpc_qp_info* info,
+                      double* H_out, double* g_out, double* A_out, double* b_out, double* C_out, double* l_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,9 @@ def _bind(lib):
     lib.mpc_qp_solve_id.restype = C.c_int
     lib.mpc_qp_solve_id.argtypes = [C.c_void_p, C.POINTER(QpSettings), C.c_int32, _IP, _DP, _DP, C.c_double, _DP, _DP, _DP, _IP,
                                     _DP, _DP, _DP, C.POINTER(QpInfo), _DP, _DP, _DP, _DP]
+    lib.mpc_qp_solve_ikid.restype = C.c_int
+    lib.mpc_qp_solve_ikid.argtypes = [C.c_void_p, C.POINTER(QpSettings), C.c_int32, _IP, C.c_int32, C.c_int32, _DP, _DP, _DP, _DP, _DP, _DP, _DP, _DP, _IP,
+                                      _DP, _DP, _DP, _DP, C.POINTER(QpInfo), _DP, _DP, _DP, _DP, _DP, _DP]
     _bound.add(id(lib))
     return lib
 
@@ -126,3 +129,26 @@ class BatchedQP:
         if return_matrices:
             return x, y, z, list(info), mats
         return x, y, z, list(info)
+
+    def solve_ikid(self, frames, base_frame, torso_frame, weights, gains, cone, l_box, u_box, xrob, ik, forces, contact_states, return_matrices=False):
+        """mpc_qp_solve_ikid -> x, y, z, z_box, info (, (H, g, A, b, C, l) as assembled by the library)."""
+        d = self.dims
+        B, n, neq, nin = d.batch, d.n, d.neq, d.nin
+        frames = np.ascontiguousarray(frames, dtype=np.int32); nk = frames.size
+        nv = self._nv
+        f64 = lambda a, shape=None: np.ascontiguousarray(a if shape is None else np.broadcast_to(np.asarray(a, dtype=np.float64), shape), dtype=np.float64)
+        weights, gains, cone, l_box, u_box = f64(weights), f64(gains), f64(cone), f64(l_box), f64(u_box)
+        if weights.size != 5 or gains.size != 2 * nv * nv + 90 or cone.shape != (9, 6) or l_box.size != n or u_box.size != n:
+            raise ValueError("solve_ikid: weights[5], gains[2 nv^2 + 90], cone[9][6], l_box / u_box [n] expected")
+        xrob = f64(xrob, (B, self._nqv)); ik = f64(ik, (B, 2 * nv + 42)); forces = f64(forces, (B, 6 * nk))
+        cs = np.ascontiguousarray(np.broadcast_to(np.asarray(contact_states, dtype=np.int32), (B, nk)))
+        x = np.zeros((B, n)); y = np.zeros((B, neq)); z = np.zeros((B, nin)); zb = np.zeros((B, n))
+        mats = (np.zeros((B, n, n)), np.zeros((B, n)), np.zeros((B, neq, n)), np.zeros((B, neq)), np.zeros((B, nin, n)), np.zeros((B, nin))) if return_matrices else (None,) * 6
+        info = (QpInfo * B)()
+        IP = C.POINTER(C.c_int32)
+        rc = self.lib.mpc_qp_solve_ikid(self._h, C.byref(self.settings), nk, frames.ctypes.data_as(IP), int(base_frame), int(torso_frame), _dp(weights), _dp(gains),
+                                        _dp(cone), _dp(l_box), _dp(u_box), _dp(xrob), _dp(ik), _dp(forces), cs.ctypes.data_as(IP),
+                                        _dp(x), _dp(y), _dp(z), _dp(zb), info, *[_dp(m_) for m_ in mats])
+        if rc != 0:
+            raise RuntimeError("mpc_qp_solve_ikid: " + self.lib.mpc_qp_last_error(self._h).decode())
+        return (x, y, z, zb, list(info), mats) if return_matrices else (x, y, z, zb, list(info))

@@ -17,6 +17,9 @@ struct mpc_qp_solver {
   int32_t *d_cs = nullptr, *d_frames = nullptr;
   int id_nk = 0;
   bool id_const_uploaded = false;
+  double *d_ik = nullptr, *d_gains = nullptr, *d_w = nullptr;  // mpc_qp_solve_ikid
+  int ikid_nk = 0;
+  std::vector<double> ikid_const;
   std::vector<double> id_const;  // weights[2], cone[54], frames[nk] as last uploaded
   std::vector<void*> allocs;
   std::string err;
@@ -173,7 +176,7 @@ int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, cons
       s->d_xrob = s->alloc<double>(B * (nq + nv)); s->d_acc = s->alloc<double>(B * nv); s->d_f = s->alloc<double>(B * 6 * nk);
       s->d_cs = s->alloc<int32_t>(B * nk); s->d_frames = s->alloc<int32_t>(nk); s->d_cone = s->alloc<double>(54);
       s->id_nk = nk; s->id_const_uploaded = false;
-      HIP_OK(hipFuncSetAttribute((const void*)k_qp_assemble_id, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qp_assemble_lds_bytes(s->m_nj, nv, nq, nk)));
+      HIP_OK(hipFuncSetAttribute((const void*)k_qp_assemble<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qp_assemble_lds_bytes(s->m_nj, nv, nq, nk)));
     }
     // the constant parts: H = diag(w0 I_nv, w1 I_6nk, 0), g = 0, u = 1e5 (as the reference), frames, cone rows: uploaded when they change
     std::vector<double> key(56 + nk);
@@ -198,11 +201,11 @@ int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, cons
     HIP_OK(hipMemcpyAsync(s->d_acc, acc, B * nv * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipMemcpyAsync(s->d_f, forces, B * 6 * nk * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipMemcpyAsync(s->d_cs, contact_states, B * nk * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
-    QpAssembleArgs qa;
+    QpAssembleArgs qa = {};
     qa.mi = s->d_mi; qa.md = s->d_md; qa.x = s->d_xrob; qa.acc = s->d_acc; qa.f = s->d_f; qa.cs = s->d_cs; qa.frames = s->d_frames; qa.cone = s->d_cone;
     qa.kd = kd; qa.nk = nk; qa.n = (int)n; qa.neq = (int)neq; qa.nin = (int)nin;
     qa.A = s->dA; qa.b = s->db; qa.C = s->dC; qa.l = s->dl;
-    hipLaunchKernelGGL(k_qp_assemble_id, dim3(d.batch), dim3(QPA_THREADS), qp_assemble_lds_bytes(s->m_nj, nv, nq, nk), s->stream, qa);
+    hipLaunchKernelGGL(k_qp_assemble<false>, dim3(d.batch), dim3(QPA_THREADS), qp_assemble_lds_bytes(s->m_nj, nv, nq, nk), s->stream, qa);
     HIP_OK(hipGetLastError());
     if (!S->warm_start) {
       HIP_OK(hipMemsetAsync(s->dx, 0, B * n * sizeof(double), s->stream));
@@ -214,6 +217,84 @@ int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, cons
     if (C_out) HIP_OK(hipMemcpyAsync(C_out, s->dC, B * nin * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     if (l_out) HIP_OK(hipMemcpyAsync(l_out, s->dl, B * nin * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     qp_launch_and_fetch(s, S, x, y, z, nullptr, info);
+    return 0;
+  } catch (const std::exception& e) { s->err = e.what(); return -1; }
+}
+
+int mpc_qp_solve_ikid(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, const int32_t* frames, int32_t base_frame, int32_t torso_frame,
+                      const double* weights, const double* gains, const double* cone, const double* l_box, const double* u_box,
+                      const double* xrob, const double* ik, const double* forces, const int32_t* contact_states,
+                      double* x, double* y, double* z, double* z_box, mpc_qp_info* info,
+                      double* H_out, double* g_out, double* A_out, double* b_out, double* C_out, double* l_out) {
+  if (!s) return -2;
+  try {
+    HIP_OK(hipSetDevice(s->d.device));
+    if (!S || !frames || !weights || !gains || !cone || !l_box || !u_box || !xrob || !ik || !forces || !contact_states || !x || !info) throw std::runtime_error("qp_solve_ikid: null argument");
+    if (!s->d_mi) throw std::runtime_error("qp_solve_ikid: mpc_qp_set_model first");
+    const mpc_qp_dims& d = s->d;
+    const int nv = s->m_nv, nq = s->m_nq;
+    if (nk != 2 || d.n != 2 * nv - 6 + 6 * nk || d.neq != nv + 6 * nk || d.nin != 9 * nk || !d.box)
+      throw std::runtime_error("qp_solve_ikid: two contacts and the handle's dimensions n = 2 nv - 6 + 6 nk, neq = nv + 6 nk, nin = 9 nk, box = 1 expected");
+    for (int c = 0; c < nk + 2; ++c) {
+      const int fi = c < nk ? frames[c] : (c == nk ? base_frame : torso_frame);
+      if (fi < 0 || fi >= s->m_nframes) throw std::runtime_error("qp_solve_ikid: frame index out of range");
+    }
+    const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin, m = nin + n, ngain = (size_t)2 * nv * nv + 90, nik = QPA_IK_DOUBLES(nv);
+    if (!s->d_ik || s->ikid_nk != nk) {
+      if (!s->d_xrob || s->id_nk != nk) {
+        s->d_xrob = s->alloc<double>(B * (nq + nv)); s->d_acc = s->alloc<double>(B * nv); s->d_f = s->alloc<double>(B * 6 * nk);
+        s->d_cs = s->alloc<int32_t>(B * nk); s->d_frames = s->alloc<int32_t>(nk); s->d_cone = s->alloc<double>(54);
+        s->id_nk = nk;
+      }
+      s->d_ik = s->alloc<double>(B * nik); s->d_gains = s->alloc<double>(ngain); s->d_w = s->alloc<double>(8);
+      s->ikid_nk = nk; s->ikid_const.clear();
+      HIP_OK(hipFuncSetAttribute((const void*)k_qp_assemble<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qp_assemble_lds_bytes(s->m_nj, nv, nq, nk, true)));
+    }
+    s->id_const_uploaded = false;  // (H, g, u of a later mpc_qp_solve_id are uploaded again)
+    // constants: weights, gains, cone rows, frames, the torque box and u = 1e5 — uploaded when they change
+    std::vector<double> key;
+    key.reserve(5 + ngain + 54 + 2 * n + nk + 2);
+    key.insert(key.end(), weights, weights + 5); key.insert(key.end(), gains, gains + ngain); key.insert(key.end(), cone, cone + 54);
+    key.insert(key.end(), l_box, l_box + n); key.insert(key.end(), u_box, u_box + n);
+    for (int c = 0; c < nk; ++c) key.push_back(frames[c]);
+    key.push_back(base_frame); key.push_back(torso_frame);
+    if (key != s->ikid_const) {
+      std::vector<double> u(nin, 1e5);
+      HIP_OK(hipMemcpyAsync(s->d_w, weights, 5 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      HIP_OK(hipMemcpyAsync(s->d_gains, gains, ngain * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      HIP_OK(hipMemcpyAsync(s->d_cone, cone, 54 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      HIP_OK(hipMemcpyAsync(s->d_frames, frames, nk * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+      for (size_t bi = 0; bi < B; ++bi) {
+        HIP_OK(hipMemcpyAsync(s->du + bi * nin, u.data(), nin * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        HIP_OK(hipMemcpyAsync(s->dlb + bi * n, l_box, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        HIP_OK(hipMemcpyAsync(s->dub + bi * n, u_box, n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      }
+      HIP_OK(hipStreamSynchronize(s->stream));
+      s->ikid_const = key;
+    }
+    HIP_OK(hipMemcpyAsync(s->d_xrob, xrob, B * (nq + nv) * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipMemcpyAsync(s->d_ik, ik, B * nik * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipMemcpyAsync(s->d_f, forces, B * 6 * nk * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipMemcpyAsync(s->d_cs, contact_states, B * nk * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    QpAssembleArgs qa = {};
+    qa.mi = s->d_mi; qa.md = s->d_md; qa.x = s->d_xrob; qa.f = s->d_f; qa.cs = s->d_cs; qa.frames = s->d_frames; qa.cone = s->d_cone;
+    qa.nk = nk; qa.n = (int)n; qa.neq = (int)neq; qa.nin = (int)nin;
+    qa.A = s->dA; qa.b = s->db; qa.C = s->dC; qa.l = s->dl; qa.H = s->dH; qa.g = s->dg;
+    qa.base_frame = base_frame; qa.torso_frame = torso_frame; qa.w = s->d_w; qa.gains = s->d_gains; qa.ik = s->d_ik;
+    hipLaunchKernelGGL(k_qp_assemble<true>, dim3(d.batch), dim3(QPA_THREADS), qp_assemble_lds_bytes(s->m_nj, nv, nq, nk, true), s->stream, qa);
+    HIP_OK(hipGetLastError());
+    if (!S->warm_start) {
+      HIP_OK(hipMemsetAsync(s->dx, 0, B * n * sizeof(double), s->stream));
+      HIP_OK(hipMemsetAsync(s->dy, 0, B * neq * sizeof(double), s->stream));
+      HIP_OK(hipMemsetAsync(s->dz, 0, B * m * sizeof(double), s->stream));
+    }
+    if (H_out) HIP_OK(hipMemcpyAsync(H_out, s->dH, B * n * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (g_out) HIP_OK(hipMemcpyAsync(g_out, s->dg, B * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (A_out) HIP_OK(hipMemcpyAsync(A_out, s->dA, B * neq * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (b_out) HIP_OK(hipMemcpyAsync(b_out, s->db, B * neq * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (C_out) HIP_OK(hipMemcpyAsync(C_out, s->dC, B * nin * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    if (l_out) HIP_OK(hipMemcpyAsync(l_out, s->dl, B * nin * sizeof(double), hipMemcpyDeviceToHost, s->stream));
+    qp_launch_and_fetch(s, S, x, y, z, z_box, info);
     return 0;
   } catch (const std::exception& e) { s->err = e.what(); return -1; }
 }

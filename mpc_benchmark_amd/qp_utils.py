@@ -191,3 +191,36 @@ class IKIDSolver_f6:
         self.last_info = info
         nv, fs, nk = self.model.nv, self.force_size, self.nk
         return x[0, :nv].copy(), forces + x[0, nv:nv + fs * nk], x[0, nv + fs * nk:].copy()
+
+    # ---- the whole QP on the device (mpc_qp_solve_ikid: csrc/qp_assemble.h) ----
+    def enable_device_assembly(self):
+        from .aligator._core import LoweringContext
+        if self.force_size != 6 or self.nk != 2:
+            raise NotImplementedError("device assembly is written for two 6-D contacts")
+        ctx = LoweringContext()
+        self._frame_idx = np.array([ctx.frame_index(self.model, fid) for fid in self.contact_ids], dtype=np.int32)
+        self._base_idx, self._torso_idx = ctx.frame_index(self.model, self.base_id), ctx.frame_index(self.model, self.torso_id)
+        self.qp.set_model(*ctx.model_tables())
+        K = self.K_gains
+        self._gains = np.concatenate([np.asarray(K[0][0], dtype=float).reshape(-1), np.asarray(K[0][1], dtype=float).reshape(-1),
+                                      np.asarray(K[1][0], dtype=float).reshape(-1), np.asarray(K[1][1], dtype=float).reshape(-1),
+                                      np.asarray(K[3][0], dtype=float).reshape(-1), np.asarray(K[3][1], dtype=float).reshape(-1)])
+
+    def solve_batch_device(self, x, q_diff, dq_diff, LF_diff, dLF_diff, RF_diff, dRF_diff, base_diff, dbase_diff, torso_diff, dtorso_diff, forces, dH, cs,
+                           return_matrices=False):
+        """Every argument per robot ([B][...]): the state ``x`` (nq + nv) and the task errors the script computes from its references.
+        -> (a, new_forces, torque), each [B][...] (, the matrices the library assembled)."""
+        if not hasattr(self, "_frame_idx"):
+            self.enable_device_assembly()
+        B, nv = self.batch, self.model.nv
+        bc = lambda a, k: np.broadcast_to(np.asarray(a, dtype=float), (B, k))
+        ik = np.concatenate([bc(q_diff, nv), bc(dq_diff, nv), bc(LF_diff, 6), bc(dLF_diff, 6), bc(RF_diff, 6), bc(dRF_diff, 6),
+                             bc(base_diff, 3), bc(dbase_diff, 3), bc(torso_diff, 3), bc(dtorso_diff, 3), bc(dH, 6)], axis=1)
+        out = self.qp.solve_ikid(self._frame_idx, self._base_idx, self._torso_idx, self.weights, self._gains, self.Cmin, self.l_box, self.u_box,
+                                 x, ik, forces, cs, return_matrices=return_matrices)
+        sol = out[0]
+        self.last_info = out[4]
+        fs, nk = self.force_size, self.nk
+        forces = np.broadcast_to(np.asarray(forces, dtype=float), (B, fs * nk))
+        res = (sol[:, :nv].copy(), forces + sol[:, nv:nv + fs * nk], sol[:, nv + fs * nk:].copy())
+        return res + (out[5],) if return_matrices else res

@@ -158,4 +158,133 @@ int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, cons
   } catch (const std::exception& e) { s->err = e.what(); return -1; }
 }
 
+// IK + ID QP (QP_utils.py:584-762) built from recursive Newton-Euler evaluations, as mpc_qp_solve_id above: frame Jacobians as frame
+// velocities under unit joint velocities, drifts as frame accelerations of the zero-acceleration motion without gravity, the centroidal
+// momentum matrix as the momentum under unit joint velocities, its drift from the root force of that motion moved to the CoM.
+int mpc_qp_solve_ikid(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, const int32_t* frames, int32_t base_frame, int32_t torso_frame,
+                      const double* weights, const double* gains, const double* cone, const double* l_box, const double* u_box,
+                      const double* xrob, const double* ik, const double* forces, const int32_t* contact_states,
+                      double* x, double* y, double* z, double* z_box, mpc_qp_info* info,
+                      double* H_out, double* g_out, double* A_out, double* b_out, double* C_out, double* l_out) {
+  if (!s) return -2;
+  try {
+    using namespace orc;
+    if (!S || !frames || !weights || !gains || !cone || !l_box || !u_box || !xrob || !ik || !forces || !contact_states || !x || !info) throw std::runtime_error("qp_solve_ikid: null argument");
+    if (!s->has_model) throw std::runtime_error("qp_solve_ikid: mpc_qp_set_model first");
+    const Model& m = s->model;
+    const mpc_qp_dims& d = s->d;
+    const int nv = m.nv, nq = m.nq, nkf = nk + 2;
+    if (nk != 2 || d.n != 2 * nv - 6 + 6 * nk || d.neq != nv + 6 * nk || d.nin != 9 * nk || !d.box)
+      throw std::runtime_error("qp_solve_ikid: two contacts and the handle's dimensions n = 2 nv - 6 + 6 nk, neq = nv + 6 nk, nin = 9 nk, box = 1 expected");
+    std::vector<int> fr(nkf);
+    for (int c = 0; c < nkf; ++c) {
+      fr[c] = c < nk ? frames[c] : (c == nk ? base_frame : torso_frame);
+      if (fr[c] < 0 || fr[c] >= (int)m.frame_joint.size()) throw std::runtime_error("qp_solve_ikid: frame index out of range");
+    }
+    const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin, nik = 2 * nv + 42;
+    const double *Kp0 = gains, *Kd0 = Kp0 + nv * nv, *Kp1 = Kd0 + nv * nv, *Kd1 = Kp1 + 36, *Kp3 = Kd1 + 36, *Kd3 = Kp3 + 9;
+    std::vector<double> H(B * n * n, 0.0), g(B * n, 0.0), A(B * neq * n, 0.0), b(B * neq, 0.0), C(B * nin * n, 0.0), l(B * nin, 0.0), u(B * nin, 1e5), lb(B * n), ub(B * n);
+    for (size_t bi = 0; bi < B; ++bi) {
+      std::copy(l_box, l_box + n, lb.begin() + bi * n); std::copy(u_box, u_box + n, ub.begin() + bi * n);
+      double* Hb = H.data() + bi * n * n; double* gb = g.data() + bi * n; double* Ab = A.data() + bi * neq * n; double* bb = b.data() + bi * neq;
+      double* Cb = C.data() + bi * nin * n; double* lbv = l.data() + bi * nin;
+      const double* f0 = forces + bi * 6 * nk; const int32_t* cs = contact_states + bi * nk; const double* e = ik + bi * nik;
+      State<double> st = state_from_x(m, xrob + bi * (nq + nv));
+      State<double> s0 = st; std::fill(s0.v.begin(), s0.v.end(), 0.0);
+      Kin<double> k;
+      std::vector<double> nle(nv), g0(nv), col(nv), unit(nv, 0.0), Mm((size_t)nv * nv);
+      forward_pass<double>(m, st, nullptr, k, true); rnea_backward<double>(m, k, nullptr, nle.data());
+      forward_pass<double>(m, s0, nullptr, k, true); rnea_backward<double>(m, k, nullptr, g0.data());
+      for (int c = 0; c < nv; ++c) {
+        unit[c] = 1.0;
+        forward_pass<double>(m, s0, unit.data(), k, true); rnea_backward<double>(m, k, nullptr, col.data());
+        for (int r = 0; r < nv; ++r) Mm[(size_t)r * nv + c] = col[r] - g0[r];
+        unit[c] = 0.0;
+      }
+      // frame Jacobians (LOCAL), centroidal momentum matrix
+      std::vector<double> Jf((size_t)6 * nkf * nv, 0.0), Ag((size_t)6 * nv, 0.0), drift(6 * nkf), dAgv(6);
+      for (int kk = 0; kk < nv; ++kk) {
+        State<double> se = s0; se.v[kk] = 1.0;
+        forward_pass<double>(m, se, nullptr, k, false);
+        for (int c = 0; c < nkf; ++c) {
+          const Mot<double> vf = actInv(m.frame_pl[fr[c]], k.v[m.frame_joint[fr[c]]]);
+          for (int r = 0; r < 3; ++r) { Jf[(size_t)(6 * c + r) * nv + kk] = vf.lin[r]; Jf[(size_t)(6 * c + 3 + r) * nv + kk] = vf.ang[r]; }
+        }
+        V3<double> com; Frc<double> hg;
+        centroidal<double>(m, k, com, hg);
+        for (int r = 0; r < 3; ++r) { Ag[(size_t)r * nv + kk] = hg.lin[r]; Ag[(size_t)(3 + r) * nv + kk] = hg.ang[r]; }
+      }
+      forward_pass<double>(m, st, nullptr, k, false);
+      for (int c = 0; c < nkf; ++c) {
+        const Mot<double> af = actInv(m.frame_pl[fr[c]], k.a[m.frame_joint[fr[c]]]);
+        for (int r = 0; r < 3; ++r) { drift[6 * c + r] = af.lin[r]; drift[6 * c + 3 + r] = af.ang[r]; }
+      }
+      {
+        std::vector<double> tau(nv);
+        rnea_backward<double>(m, k, nullptr, tau.data());  // zero joint accelerations, no gravity: the base rows are the net force, base frame
+        V3<double> com; Frc<double> hg;
+        centroidal<double>(m, k, com, hg);
+        Frc<double> fl; for (int r = 0; r < 3; ++r) { fl.lin[r] = tau[r]; fl.ang[r] = tau[3 + r]; }
+        const Frc<double> fw = act(k.oMi[0], fl);
+        const V3<double> ang = fw.ang - cross(com, fw.lin);
+        for (int r = 0; r < 3; ++r) { dAgv[r] = fw.lin[r]; dAgv[3 + r] = ang[r]; }
+      }
+      // task targets
+      std::vector<double> tt(6 * nkf + 6, 0.0), gp(nv, 0.0);
+      for (int c = 0; c < nk; ++c) for (int r = 0; r < 6; ++r) {
+        double v = drift[6 * c + r];
+        for (int j = 0; j < 6; ++j) v -= Kp1[6 * r + j] * e[2 * nv + 12 * c + j] + Kd1[6 * r + j] * e[2 * nv + 12 * c + 6 + j];
+        tt[6 * c + r] = v;
+      }
+      for (int c = nk; c < nkf; ++c) for (int r = 0; r < 3; ++r) {
+        double v = drift[6 * c + 3 + r];
+        const double* ee = e + 2 * nv + 12 * nk + 6 * (c - nk);
+        for (int j = 0; j < 3; ++j) v -= Kp3[3 * r + j] * ee[j] + Kd3[3 * r + j] * ee[3 + j];
+        tt[6 * c + 3 + r] = v;
+      }
+      for (int r = 0; r < 6; ++r) tt[6 * nkf + r] = -(e[2 * nv + 12 * nk + 12 + r] - dAgv[r]);
+      for (int r = 0; r < nv; ++r) { double v = 0; for (int j = 0; j < nv; ++j) v -= Kp0[r * nv + j] * e[j] + Kd0[r * nv + j] * e[nv + j]; gp[r] = v; }
+      // H, g
+      for (int r = 0; r < nv; ++r) for (int c = 0; c < nv; ++c) {
+        double sf = 0, sa = 0, so = 0;
+        for (int rc = 0; rc < 6 * nk; ++rc) sf += Jf[(size_t)rc * nv + r] * Jf[(size_t)rc * nv + c];
+        for (int q = 0; q < 6; ++q) sa += Ag[(size_t)q * nv + r] * Ag[(size_t)q * nv + c];
+        for (int f = nk; f < nkf; ++f) for (int q = 3; q < 6; ++q) so += Jf[(size_t)(6 * f + q) * nv + r] * Jf[(size_t)(6 * f + q) * nv + c];
+        Hb[(size_t)r * n + c] = (r == c ? weights[0] : 0.0) + weights[1] * sf + weights[2] * sa + weights[3] * so;
+      }
+      for (int i = 0; i < 6 * nk; ++i) Hb[(size_t)(nv + i) * n + nv + i] = weights[4];
+      for (int c = 0; c < nv; ++c) {
+        double sf = 0, sa = 0, so = 0;
+        for (int rc = 0; rc < 6 * nk; ++rc) sf += tt[rc] * Jf[(size_t)rc * nv + c];
+        for (int q = 0; q < 6; ++q) sa += tt[6 * nkf + q] * Ag[(size_t)q * nv + c];
+        for (int f = nk; f < nkf; ++f) for (int q = 3; q < 6; ++q) so += tt[6 * f + q] * Jf[(size_t)(6 * f + q) * nv + c];
+        gb[c] = weights[0] * gp[c] + weights[1] * sf + weights[2] * sa + weights[3] * so;
+      }
+      // A, b, C, l
+      for (int r = 0; r < nv; ++r) {
+        double v = -nle[r];
+        for (int c = 0; c < nv; ++c) Ab[(size_t)r * n + c] = Mm[(size_t)r * nv + c];
+        for (int rc = 0; rc < 6 * nk; ++rc) if (cs[rc / 6]) { Ab[(size_t)r * n + nv + rc] = -Jf[(size_t)rc * nv + r]; v += Jf[(size_t)rc * nv + r] * f0[rc]; }
+        if (r >= 6) Ab[(size_t)r * n + nv + 6 * nk + r - 6] = -1.0;
+        bb[r] = v;
+      }
+      for (int rc = 0; rc < 6 * nk; ++rc) if (cs[rc / 6]) {
+        for (int kk = 0; kk < nv; ++kk) Ab[(size_t)(nv + rc) * n + kk] = Jf[(size_t)rc * nv + kk];
+        bb[nv + rc] = -drift[rc];
+      }
+      for (int c = 0; c < nk; ++c) {
+        if (!cs[c]) continue;
+        for (int r = 0; r < 9; ++r) {
+          double v = 0;
+          for (int j = 0; j < 6; ++j) { Cb[(size_t)(9 * c + r) * n + nv + 6 * c + j] = cone[6 * r + j]; v += cone[6 * r + j] * f0[6 * c + j]; }
+          lbv[9 * c + r] = -v;
+        }
+      }
+    }
+    auto out = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
+    out(H_out, H); out(g_out, g); out(A_out, A); out(b_out, b); out(C_out, C); out(l_out, l);
+    return mpc_qp_solve(s, S, H.data(), g.data(), A.data(), b.data(), C.data(), l.data(), u.data(), lb.data(), ub.data(), x, y, z, z_box, info);
+  } catch (const std::exception& e) { s->err = e.what(); return -1; }
+}
+
 }  // extern "C"

@@ -172,3 +172,63 @@ def test_id_assembly_entry_point_equals_the_host_mirror_on_the_oracle():
         bad = qp_utils.IDSolver_ulim(model, [1.0, 1e-3], 2, 0.8, 0.1, 0.075, ids, 6, False, library=_oracle.load(), batch=1)
         bad.enable_device_assembly()
         bad.qp.solve_id(bad._frame_idx[:1], bad._weights, bad.Cmin, 1.0, x[0], a[0], f[0, :6], cs[0, :1])
+
+
+def _ikid_case(model, q0, rng, B):
+    nv = model.nv
+    w = 9.81 * pin.computeTotalMass(model)
+    rows = []
+    for i in range(B):
+        v = rng.normal(size=nv) * 0.1
+        q = pin.integrate(model, q0, np.concatenate((rng.normal(size=3) * 0.05, rng.normal(size=3) * 0.1, rng.normal(size=nv - 6) * 0.05)))
+        cs = [[True, True], [True, False], [False, True]][i % 3]
+        forces = np.array([5, -3, 0.55 * w, 1, -2, 0, -4, 2, 0.45 * w, 0, 1, 0], dtype=float) * np.repeat(np.array(cs, dtype=float), 6)
+        rows.append(dict(x=np.concatenate((q, v)), q=q, v=v, cs=cs, forces=forces,
+                         q_diff=np.concatenate((np.zeros(6), rng.normal(size=nv - 6) * 0.01)), dq_diff=rng.normal(size=nv) * 0.02,
+                         LF=rng.normal(size=6) * 0.01, dLF=rng.normal(size=6) * 0.02, RF=rng.normal(size=6) * 0.01, dRF=rng.normal(size=6) * 0.02,
+                         base=rng.normal(size=3) * 0.01, dbase=rng.normal(size=3) * 0.02, torso=rng.normal(size=3) * 0.01, dtorso=rng.normal(size=3) * 0.02,
+                         dH=rng.normal(size=6) * 0.5))
+    return rows
+
+
+def _ikid_solver(model, lib, batch):
+    nv = model.nv
+    ids = [model.getFrameId("left_sole_link"), model.getFrameId("right_sole_link")]
+    rng = np.random.default_rng(99)
+    Kp_f, Kd_f = np.diag(rng.uniform(50, 150, 6)), np.diag(rng.uniform(10, 30, 6))   # not multiples of the identity: the row / column order is checked
+    gains = [(np.diag(rng.uniform(50, 150, nv)), np.diag(rng.uniform(10, 30, nv))), (Kp_f, Kd_f), None, (np.diag([80.0, 100.0, 120.0]), np.diag([15.0, 20.0, 25.0]))]
+    s = qp_utils.IKIDSolver_f6(model, [1.0, 100.0, 1.0, 10.0, 1e-3], gains, 2, 0.8, 0.1, 0.075, ids, model.getFrameId("base_link"),
+                               model.getFrameId("torso_2_link"), 6, False, library=lib, batch=batch)
+    s.qp.settings.eps_abs, s.qp.settings.max_iter, s.qp.settings.max_iter_in = 1e-5, 200, 100
+    return s
+
+
+def _ikid_compare(solver, model, rows, tol_m=1e-9):
+    B = len(rows)
+    stack = lambda k: np.array([r[k] for r in rows])
+    dev = solver.solve_batch_device(stack("x"), stack("q_diff"), stack("dq_diff"), stack("LF"), stack("dLF"), stack("RF"), stack("dRF"), stack("base"),
+                                    stack("dbase"), stack("torso"), stack("dtorso"), stack("forces"), stack("dH"), np.array([r["cs"] for r in rows], dtype=np.int32),
+                                    return_matrices=True)
+    infos = solver.last_info
+    for i, r in enumerate(rows):
+        data = dyn.compute_all_terms(model, model.createData(), r["q"], r["v"])
+        host = solver.computeMatrice(data, r["cs"], r["v"], r["q_diff"], r["dq_diff"], r["LF"], r["dLF"], r["RF"], r["dRF"], r["base"], r["dbase"],
+                                     r["torso"], r["dtorso"], r["forces"], r["dH"], data.M)
+        for name, got, want in zip(("H", "g", "A", "b", "C", "l"), [m_[i] for m_ in dev[3]], host):
+            assert np.max(np.abs(got - want)) < tol_m * max(1.0, np.max(np.abs(want))), (i, name, np.max(np.abs(got - want)))
+        a, f, tau = solver.solve(data, r["cs"], r["v"], r["q_diff"], r["dq_diff"], r["LF"], r["dLF"], r["RF"], r["dRF"], r["base"], r["dbase"],
+                                 r["torso"], r["dtorso"], r["forces"], r["dH"], data.M) if solver.batch == 1 else (None, None, None)
+        if a is not None:
+            assert np.max(np.abs(dev[0][i] - a)) < 1e-5 and np.max(np.abs(dev[2][i] - tau)) < 1e-4
+    assert all(i.status == 0 for i in infos), [(i.status, i.prim_res, i.dual_res) for i in infos]
+    return dev
+
+
+def test_ikid_assembly_entry_point_equals_the_host_mirror_on_the_oracle():
+    """mpc_qp_solve_ikid: the checker's build of the IK + ID QP (RNEA evaluations, momentum under unit velocities) gives the
+    matrices of the numpy mirror of QP_utils.py:584-762 in double and single support."""
+    model, q0 = _model()
+    rows = _ikid_case(model, q0, np.random.default_rng(21), 3)
+    _ikid_compare(_ikid_solver(model, _oracle.load(), 3), model, rows)
+    one = _ikid_solver(model, _oracle.load(), 1)
+    _ikid_compare(one, model, rows[:1])
