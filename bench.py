@@ -596,6 +596,7 @@ def main():
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
         "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; largest primal / dual infeasibility of the others: %.2e)" % (n_conv, args.batch, mres["worst_unconv"]),
         "tick_mode": ("walk: foot references regenerated and patched every tick (fulldynamic_talos.py:444-510)" if head else "frozen foot references"),
+        "walk_references": "planned once per tick from instance 0's measured state and shared by the instances of an ensemble (its stage tables are shared: DESIGN.md section 5)",
         "measurements": {(w if isinstance(w, str) else ("walk" if w else "frozen_references")): {"value": round(rate(r), 2), "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 4),
                                                                   "replanning_ticks": r["replanning_ticks"],
                                                                   "kernel_ms_per_step_warmup": {k: round(v[1] / max(1, args.warmup), 4) for k, v in sorted(r["warm"].items(), key=lambda kv: -kv[1][1])[:6]}}

@@ -208,11 +208,14 @@ DEV bool chol_blocked_wave(double* A, int ld, int nb, double* LI, int lane) {
   return ok;
 }
 
+#ifndef CHOL_ONE_WAVE_BLOCKS
+#define CHOL_ONE_WAVE_BLOCKS 3
+#endif
 DEV bool chol_blocked(double* A, int ld, int nb, double* LI, int tid, int* flag) {
   const int lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
   if (tid == 0) *flag = 1;
   __syncthreads();
-  if (nb <= 3) {
+  if (nb <= CHOL_ONE_WAVE_BLOCKS) {
     // small matrices: ONE wavefront runs the whole factorisation — its LDS operations execute in order, so the
     // 3 nb - 1 workgroup barriers (and the idle time around the serial 16x16 steps) of the cooperative form go away
     if (wv == 0) {

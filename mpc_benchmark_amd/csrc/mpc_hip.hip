@@ -1318,6 +1318,7 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
     else if (nm == "E6") mat(kn.data() + L.oE6, 6, 6, 6);
     else if (nm == "D12") mat(kn.data() + L.oD12, 1, 74, 74);  // D1_b (36) | Dd_b (36) | dt | valid (layout.h)
     else if (nm == "cval") mat(kn.data() + L.oCV, 1, c, c);
+    else if (nm == "act") mat(kn.data() + L.oACT, 1, c, c);  // active flags of the constraint rows (developer probes)
     else if (nm == "CD") mat(kn.data() + L.oCD, c, nzk, nz);
     else if (nm == "cost") mat(kn.data() + L.oMISC + MISC_COST, 1, 1, 1);
     else if (nm == "xnext") mat(kn.data() + L.oXN, 1, L.nx, L.nx);

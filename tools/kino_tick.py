@@ -6,7 +6,7 @@ import numpy as np
 from mpc_benchmark_amd import _capi
 from mpc_benchmark_amd.ensemble import EnsembleMPC
 from mpc_benchmark_amd.problems.kinodynamic import KinodynamicProblem
-lib = _capi.load_hip_library()
+lib = _capi.bind_library(os.environ["LIB"]) if os.environ.get("LIB") else _capi.load_hip_library()
 kp = KinodynamicProblem(horizon=150, complete_model=True)
 ens = EnsembleMPC(kp, batch=64, library=lib, seed=7, perturb_dofs=range(18, kp.nv), tick_reuse=not os.environ.get("NO_REUSE"))
 ens.options.riccati_legs = int(os.environ.get("LEGS", "4")); ens.native.set_options(ens.options)
