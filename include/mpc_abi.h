@@ -251,6 +251,16 @@ int64_t mpc_state_size(mpc_solver* s);
 int64_t mpc_get_state(mpc_solver* s, double* buf, int64_t cap);
 int mpc_set_state(mpc_solver* s, const double* buf, int64_t len);
 
+/* Per-instance stage parameters.  The stage tables (descriptors AND parameters) of an ensemble are shared by its instances; after
+ * mpc_enable_instance_params every instance has its own copy of the PARAMETER tables, so that references, targets, bounds and weights
+ * can differ from robot to robot (the descriptors — which terms a stage has — stay shared).  mpc_set_stage / mpc_cycle /
+ * mpc_update_stage_params(_batch) keep acting on every instance (a slot that receives a stage table is reset to it in every copy);
+ * mpc_update_instance_params_batch patches the copies of single instances: patch i writes lens[i] doubles at offsets[i] of stage
+ * ks[i] of instance insts[i]; values concatenated in `vals`.  Tick reuse invalidates a patched knot for the whole ensemble.
+ * (mpc_get_state stores the shared tables only.) */
+int mpc_enable_instance_params(mpc_solver* s);
+int mpc_update_instance_params_batch(mpc_solver* s, int32_t count, const int32_t* insts, const int32_t* ks, const int32_t* offsets, const int32_t* lens, const double* vals);
+
 /* Failure policy of an ensemble.  isolate = 0 (default): a failed factorisation on any instance makes the run return an error, as a
  * single solver would.  isolate = 1: the instance is reported (mpc_stats.converged = -code: 2 / 3 / 4 Riccati blocks, 5 / 6 contact
  * dynamics), keeps the iterate it had when the pass started failing and is skipped by every later run until it is revived; the other

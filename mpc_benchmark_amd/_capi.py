@@ -84,6 +84,8 @@ _SIGNATURES = {
     "mpc_simulate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "mpc_simulate_push": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _DP]),
     "mpc_set_tick_reuse": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mpc_enable_instance_params": (C.c_int, [C.c_void_p]),
+    "mpc_update_instance_params_batch": (C.c_int, [C.c_void_p, C.c_int32, _IP, _IP, _IP, _IP, _DP]),
     "mpc_set_failure_policy": (C.c_int, [C.c_void_p, C.c_int32]),
     "mpc_revive_instance": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "mpc_poll": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -279,6 +281,22 @@ class NativeSolver:
         xn = np.zeros((self.dims.batch, self.dims.nx))
         self._check(self.lib.mpc_wait_state(self._h, stats, _dp(xn)), "mpc_wait_state")
         return list(stats), xn
+
+    def enable_instance_params(self):
+        """Every instance gets its own copy of the stage PARAMETER tables (mpc_enable_instance_params)."""
+        self._check(self.lib.mpc_enable_instance_params(self._h), "mpc_enable_instance_params")
+
+    def update_instance_params_batch(self, patches):
+        """``patches``: iterable of (instance, stage k, offset, values)."""
+        patches = list(patches)
+        if not patches:
+            return
+        insts = _i32([p[0] for p in patches]); ks = _i32([p[1] for p in patches]); offs = _i32([p[2] for p in patches])
+        vals = [_f64(p[3]).reshape(-1) for p in patches]
+        lens = _i32([v.size for v in vals])
+        flat = np.ascontiguousarray(np.concatenate(vals))
+        self._check(self.lib.mpc_update_instance_params_batch(self._h, len(patches), insts.ctypes.data_as(_IP), ks.ctypes.data_as(_IP),
+                                                              offs.ctypes.data_as(_IP), lens.ctypes.data_as(_IP), _dp(flat)), "mpc_update_instance_params_batch")
 
     def set_failure_policy(self, isolate):
         """isolate: a failed instance is reported (``stats.converged = -code``) and skipped until revived instead of failing the run."""

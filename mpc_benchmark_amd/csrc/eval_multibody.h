@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(EVAL_THREADS, EVAL_MIN_WAVES) k_eval_multibody
   const int n = L.n, N = L.N, nx = L.nx, nv = S.nv, nq = S.nq, nj = S.nj, nu = L.m;
   const int slot = stage_slot(a, k);
   const int32_t* desc = a.stage_desc + (size_t)slot * L.max_stage_ints;
-  const double* P = a.stage_params + (size_t)slot * L.max_stage_doubles;
+  const double* P = (a.inst_params ? a.inst_params + (size_t)b * (L.N + 1) * L.max_stage_doubles : a.stage_params) + (size_t)slot * L.max_stage_doubles;
   const int dyn = desc[0];
   const bool has_dyn = dyn == MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER;   // contact-constrained forward dynamics
   if (has_dyn && !S.contact_dyn) { if (threadIdx.x == 0) a.inst[b].done = 5; return; }  // (host bug guard: this carve-out has no room for the factor of M)

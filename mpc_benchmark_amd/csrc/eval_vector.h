@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(64) k_eval_vector(SolverArgs a, Layout KL, dou
   const int n = L.n, N = L.N, nx = L.nx, mfull = L.m;
   const int slot = stage_slot(a, k);
   const int32_t* desc = a.stage_desc + (size_t)slot * L.max_stage_ints;
-  const double* P = a.stage_params + (size_t)slot * L.max_stage_doubles;
+  const double* P = (a.inst_params ? a.inst_params + (size_t)b * (L.N + 1) * L.max_stage_doubles : a.stage_params) + (size_t)slot * L.max_stage_doubles;
   const int dyn = desc[0];
   const int m = (dyn == MPC_DYN_NONE) ? 0 : mfull, nzk = n + m, nterms = desc[5], c = desc[6];
   const bool derivs = !TRIAL;

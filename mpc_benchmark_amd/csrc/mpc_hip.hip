@@ -57,6 +57,9 @@ struct mpc_solver {
   bool perfect_feedback = false;
   // tick reuse (mpc_set_tick_reuse): see SolverArgs
   bool isolate = false;  // mpc_set_failure_policy
+  // per-instance stage parameters (mpc_enable_instance_params): every instance has its own copy of the parameter tables [B][N + 1][max_stage_doubles]
+  double* d_inst_params = nullptr;
+  std::vector<double> h_inst_params;
   bool contact_dyn = false;  // some stage uploaded so far has contact-constrained dynamics (sticky): the stage kernel's LDS carve-out holds the factor of M
   bool tick_reuse = false, reuse_this_pass = false, reuse_same_now = false;
   int pass_in_run = 0;  // index of the pass being enqueued within its run
@@ -167,7 +170,7 @@ struct mpc_solver {
     a.stage_desc = d_stage_desc; a.stage_params = d_stage_params; a.model_i = d_model_i; a.model_d = d_model_d;
     a.xs = d_xs; a.us = d_us; a.vs = d_vs; a.lams = d_lams; a.vs_e = d_vs_e; a.lams_e = d_lams_e; a.x0 = d_x0;
     a.dxs = d_dxs; a.dus = d_dus; a.dvs = d_dvs; a.dlams = d_dlams; a.abdz = nullptr;
-    a.khead = khead; a.spec = d_spec; a.isolate = isolate ? 1 : 0;
+    a.khead = khead; a.spec = d_spec; a.isolate = isolate ? 1 : 0; a.inst_params = d_inst_params;
     // an MPC tick: one iteration (the reference loop) or a few (max_iters <= 4).  The last pass of a replanning tick (spec_skip_pass)
     // evaluates its candidate value-only; its first pass reuses nothing.
     const bool mpc_tick = tick_reuse && opt.max_iters <= 4 && L.space == MPC_SPACE_MULTIBODY;
@@ -323,6 +326,22 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   HIP_OK(hipStreamSynchronize(s->stream));
 }
 
+// per-instance parameter tables: a slot that receives a (shared) stage table is reset to it for every instance
+__global__ void __launch_bounds__(256) k_bcast_params(double* inst, const double* shared, int slot, int nslots, int stride) {
+  const int b = blockIdx.y;
+  const double* src = shared + (size_t)slot * stride;
+  double* dst = inst + ((size_t)b * nslots + slot) * stride;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < stride; i += gridDim.x * 256) dst[i] = src[i];
+}
+static void bcast_slot_to_instances(mpc_solver* s, int slot) {
+  if (!s->d_inst_params) return;
+  const Layout& L = s->L;
+  hipLaunchKernelGGL(k_bcast_params, dim3(4, L.B), dim3(256), 0, s->stream, s->d_inst_params, s->d_stage_params, slot, L.N + 1, L.max_stage_doubles);
+  for (int b = 0; b < L.B; ++b)
+    std::memcpy(s->h_inst_params.data() + ((size_t)b * (L.N + 1) + slot) * L.max_stage_doubles, s->h_params.data() + (size_t)slot * L.max_stage_doubles,
+                (size_t)L.max_stage_doubles * sizeof(double));
+}
+
 static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_desc, const double* params, int n_params) {
   const Layout& L = s->L;
   if (n_desc > L.max_stage_ints || n_params > L.max_stage_doubles) throw std::runtime_error("stage table exceeds the capacity given at mpc_create");
@@ -351,8 +370,10 @@ static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_des
   int32_t* hd = s->h_desc.data() + (size_t)slot * L.max_stage_ints;
   double* hp = s->h_params.data() + (size_t)slot * L.max_stage_doubles;
   if (s->h_len[2 * slot] == n_desc && s->h_len[2 * slot + 1] == n_params && std::memcmp(hd, desc, n_desc * sizeof(int32_t)) == 0 &&
-      (n_params == 0 || std::memcmp(hp, params, n_params * sizeof(double)) == 0))
+      (n_params == 0 || std::memcmp(hp, params, n_params * sizeof(double)) == 0)) {
+    bcast_slot_to_instances(s, slot);
     return;
+  }
   std::memcpy(hd, desc, n_desc * sizeof(int32_t));
   if (n_params > 0) std::memcpy(hp, params, n_params * sizeof(double));
   s->h_len[2 * slot] = n_desc; s->h_len[2 * slot + 1] = n_params;
@@ -375,6 +396,7 @@ static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_des
   if (n_params > 0)
     HIP_OK(hipMemcpyAsync(s->d_stage_params + (size_t)slot * L.max_stage_doubles, pin_d, n_params * sizeof(double), hipMemcpyHostToDevice, s->stream));
   HIP_OK(hipEventRecord(s->stage_ev[rs], s->stream));
+  bcast_slot_to_instances(s, slot);
 }
 
 // tick reuse: whatever changes the problem or the iterate behind the solver's back invalidates the kept records
@@ -409,15 +431,17 @@ static void begin_reuse_pass(mpc_solver* s) {
 }
 
 // One host-to-device copy + a scatter kernel for a set of parameter patches: [count | (dst offset, src offset, length) x count | values].
-__global__ void __launch_bounds__(64) k_scatter_params(double* dst, const char* packed) {
+// (inst != nullptr: a patch of the shared tables also goes into every instance's copy — blockIdx.y = instance, inst_stride doubles apart)
+__global__ void __launch_bounds__(64) k_scatter_params(double* dst, const char* packed, double* inst, size_t inst_stride) {
   const int* hdr = (const int*)packed;
   const int count = hdr[0];
   const int* tri = hdr + 4 + 3 * blockIdx.x;
   const double* vals = (const double*)(packed + (((size_t)(4 + 3 * count) * sizeof(int) + 15) & ~(size_t)15));
-  for (int i = threadIdx.x; i < tri[2]; i += 64) dst[(size_t)tri[0] + i] = vals[(size_t)tri[1] + i];
+  double* d = (blockIdx.y == 0) ? dst : inst + (size_t)(blockIdx.y - 1) * inst_stride;
+  for (int i = threadIdx.x; i < tri[2]; i += 64) d[(size_t)tri[0] + i] = vals[(size_t)tri[1] + i];
 }
 
-struct ParamPatch { int slot, offset, len; const double* vals; };
+struct ParamPatch { int slot, offset, len; const double* vals; int inst = -1; };  // inst >= 0: a patch of that instance's own table
 
 // Patches that differ from the host mirror go to the device (stream-ordered, no host wait) and mark their slot dirty; unchanged
 // ones cost a memcmp.  Returns the number of patches that travelled.
@@ -425,11 +449,15 @@ static int apply_param_patches(mpc_solver* s, const std::vector<ParamPatch>& in)
   const Layout& L = s->L;
   std::vector<ParamPatch> ch;
   size_t nval = 0;
+  const size_t istride = (size_t)(L.N + 1) * L.max_stage_doubles;
+  const bool per_inst = !in.empty() && in[0].inst >= 0;  // (a call carries patches of one kind)
   for (const ParamPatch& p : in) {
-    double* hp = s->h_params.data() + (size_t)p.slot * L.max_stage_doubles + p.offset;
+    double* hp = (p.inst >= 0 ? s->h_inst_params.data() + (size_t)p.inst * istride : s->h_params.data()) + (size_t)p.slot * L.max_stage_doubles + p.offset;
     if (p.len == 0 || std::memcmp(hp, p.vals, p.len * sizeof(double)) == 0) continue;
     std::memcpy(hp, p.vals, p.len * sizeof(double));
-    s->slot_dirty[p.slot] = 1;
+    if (p.inst < 0 && s->d_inst_params)
+      for (int b = 0; b < L.B; ++b) std::memcpy(s->h_inst_params.data() + (size_t)b * istride + (size_t)p.slot * L.max_stage_doubles + p.offset, p.vals, p.len * sizeof(double));
+    s->slot_dirty[p.slot] = 1;  // (per slot, for every instance: the knot mask of tick reuse is shared)
     ch.push_back(p);
     nval += p.len;
   }
@@ -456,7 +484,7 @@ static int apply_param_patches(mpc_solver* s, const std::vector<ParamPatch>& in)
   double* vals = (double*)(pin + hdr_bytes);
   size_t pos = 0;
   for (size_t i = 0; i < ch.size(); ++i) {
-    hdr[4 + 3 * i] = (int)((size_t)ch[i].slot * L.max_stage_doubles + ch[i].offset);
+    hdr[4 + 3 * i] = (int)((ch[i].inst >= 0 ? (size_t)ch[i].inst * istride : (size_t)0) + (size_t)ch[i].slot * L.max_stage_doubles + ch[i].offset);
     hdr[4 + 3 * i + 1] = (int)pos;
     hdr[4 + 3 * i + 2] = ch[i].len;
     std::memcpy(vals + pos, ch[i].vals, ch[i].len * sizeof(double));
@@ -464,7 +492,8 @@ static int apply_param_patches(mpc_solver* s, const std::vector<ParamPatch>& in)
   }
   HIP_OK(hipMemcpyAsync(s->d_patch, pin, bytes, hipMemcpyHostToDevice, s->stream));
   HIP_OK(hipEventRecord(s->patch_ev[rs], s->stream));
-  hipLaunchKernelGGL(k_scatter_params, dim3((unsigned)ch.size()), dim3(64), 0, s->stream, s->d_stage_params, (const char*)s->d_patch);
+  if (per_inst) hipLaunchKernelGGL(k_scatter_params, dim3((unsigned)ch.size(), 1), dim3(64), 0, s->stream, s->d_inst_params, (const char*)s->d_patch, (double*)nullptr, (size_t)0);
+  else hipLaunchKernelGGL(k_scatter_params, dim3((unsigned)ch.size(), s->d_inst_params ? 1 + L.B : 1), dim3(64), 0, s->stream, s->d_stage_params, (const char*)s->d_patch, s->d_inst_params, istride);
   HIP_OK(hipGetLastError());
   return (int)ch.size();
 }
@@ -828,6 +857,38 @@ int mpc_update_stage_params(mpc_solver* s, int32_t k, int32_t offset, const doub
     if (k < 0 || k > s->L.N) throw std::runtime_error("stage index out of range");
     if (offset < 0 || n < 0 || offset + n > s->L.max_stage_doubles) throw std::runtime_error("parameter update out of range");
     apply_param_patches(s, {ParamPatch{slot_of(s, k), offset, n, vals}});
+  })
+}
+
+int mpc_enable_instance_params(mpc_solver* s) {
+  MPC_TRY(s, {
+    const Layout& L = s->L;
+    if (s->d_inst_params) return 0;
+    const size_t istride = (size_t)(L.N + 1) * L.max_stage_doubles;
+    s->d_inst_params = s->alloc<double>((size_t)L.B * istride);
+    s->h_inst_params.assign((size_t)L.B * istride, 0.0);
+    for (int sl = 0; sl <= L.N; ++sl) bcast_slot_to_instances(s, sl);
+    spec_clear(s);
+    s->dirty_all = true;
+  })
+}
+
+int mpc_update_instance_params_batch(mpc_solver* s, int32_t count, const int32_t* insts, const int32_t* ks, const int32_t* offsets, const int32_t* lens, const double* vals) {
+  MPC_TRY(s, {
+    if (!s->d_inst_params) throw std::runtime_error("update_instance_params: mpc_enable_instance_params first");
+    std::vector<ParamPatch> patches;
+    patches.reserve(count);
+    size_t pos = 0;
+    for (int i = 0; i < count; ++i) {
+      if (insts[i] < 0 || insts[i] >= s->L.B) throw std::runtime_error("instance index out of range");
+      if (ks[i] < 0 || ks[i] > s->L.N) throw std::runtime_error("stage index out of range");
+      if (offsets[i] < 0 || lens[i] < 0 || offsets[i] + lens[i] > s->L.max_stage_doubles) throw std::runtime_error("parameter update out of range");
+      ParamPatch p{slot_of(s, ks[i]), offsets[i], lens[i], vals + pos};
+      p.inst = insts[i];
+      patches.push_back(p);
+      pos += lens[i];
+    }
+    apply_param_patches(s, patches);
   })
 }
 

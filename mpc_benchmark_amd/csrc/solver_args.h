@@ -16,6 +16,7 @@ struct SolverArgs {
   // stage tables
   const int32_t* stage_desc;
   const double* stage_params;
+  const double* inst_params;  // per-instance copies of the parameter tables [B][N + 1][max_stage_doubles], or nullptr (mpc_enable_instance_params)
   const int32_t* model_i;
   const double* model_d;
   // iterate

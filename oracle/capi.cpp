@@ -60,6 +60,7 @@ int mpc_set_stage(mpc_solver* h, int32_t k, const int32_t* desc, int32_t n_desc,
   MPC_TRY(h, {
     if (k < 0 || k > h->s.N()) throw std::runtime_error("stage index out of range");
     h->s.stages[k].parse(desc, n_desc, params, n_params);
+    for (auto& ip : h->s.inst_params) ip[k] = h->s.stages[k].params;
   })
 }
 
@@ -69,6 +70,7 @@ int mpc_update_stage_params(mpc_solver* h, int32_t k, int32_t offset, const doub
     auto& p = h->s.stages[k].params;
     if (offset < 0 || offset + n > (int)p.size()) throw std::runtime_error("parameter update out of range");
     std::memcpy(p.data() + offset, vals, n * sizeof(double));
+    for (auto& ip : h->s.inst_params) std::memcpy(ip[k].data() + offset, vals, n * sizeof(double));
   })
 }
 
@@ -79,6 +81,32 @@ int mpc_update_stage_params_batch(mpc_solver* h, int32_t count, const int32_t* k
     for (int i = 0; i < count; ++i) {
       if (ks[i] < 0 || ks[i] > h->s.N()) throw std::runtime_error("stage index out of range");
       auto& p = h->s.stages[ks[i]].params;
+      if (offsets[i] < 0 || lens[i] < 0 || offsets[i] + lens[i] > (int)p.size()) throw std::runtime_error("parameter update out of range");
+      std::memcpy(p.data() + offsets[i], vals + pos, lens[i] * sizeof(double));
+      for (auto& ip : h->s.inst_params) std::memcpy(ip[ks[i]].data() + offsets[i], vals + pos, lens[i] * sizeof(double));
+      pos += lens[i];
+    }
+  })
+}
+
+int mpc_enable_instance_params(mpc_solver* h) {
+  MPC_TRY(h, {
+    Solver& s = h->s;
+    if (!s.inst_params.empty()) return 0;
+    s.inst_params.assign(s.dims.batch, std::vector<std::vector<double>>(s.N() + 1));
+    for (auto& ip : s.inst_params) for (int k = 0; k <= s.N(); ++k) ip[k] = s.stages[k].params;
+  })
+}
+
+int mpc_update_instance_params_batch(mpc_solver* h, int32_t count, const int32_t* insts, const int32_t* ks, const int32_t* offsets, const int32_t* lens, const double* vals) {
+  MPC_TRY(h, {
+    Solver& s = h->s;
+    if (s.inst_params.empty()) throw std::runtime_error("update_instance_params: mpc_enable_instance_params first");
+    size_t pos = 0;
+    for (int i = 0; i < count; ++i) {
+      if (insts[i] < 0 || insts[i] >= s.dims.batch) throw std::runtime_error("instance index out of range");
+      if (ks[i] < 0 || ks[i] > s.N()) throw std::runtime_error("stage index out of range");
+      auto& p = s.inst_params[insts[i]][ks[i]];
       if (offsets[i] < 0 || lens[i] < 0 || offsets[i] + lens[i] > (int)p.size()) throw std::runtime_error("parameter update out of range");
       std::memcpy(p.data() + offsets[i], vals + pos, lens[i] * sizeof(double));
       pos += lens[i];
@@ -93,6 +121,10 @@ int mpc_cycle(mpc_solver* h, const int32_t* desc, int32_t n_desc, const double* 
     sd.parse(desc, n_desc, params, n_params);
     for (int k = 0; k + 1 < N; ++k) h->s.stages[k] = std::move(h->s.stages[k + 1]);
     h->s.stages[N - 1] = std::move(sd);
+    for (auto& ip : h->s.inst_params) {  // the appended stage starts from the shared table in every instance
+      for (int k = 0; k + 1 < N; ++k) ip[k] = std::move(ip[k + 1]);
+      ip[N - 1] = h->s.stages[N - 1].params;
+    }
   })
 }
 

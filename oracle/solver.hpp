@@ -127,6 +127,7 @@ struct Solver {
   Model model;
   std::vector<StageDesc> stages;  // N + 1
   std::vector<Instance> inst;
+  std::vector<std::vector<std::vector<double>>> inst_params;  // [B][N + 1]: per-instance parameter tables, empty = shared (mpc_enable_instance_params)
   std::string err;
   bool have_model = false;
 
@@ -168,8 +169,10 @@ struct Solver {
     else mb_integrate(model, x, dx, out);
   }
 
-  void eval_knot(int k, const double* x, const double* u, const double* xnext, Knot& kn, bool derivs) const {
-    const StageDesc& sd = stages[k];
+  void eval_knot(int b, int k, const double* x, const double* u, const double* xnext, Knot& kn, bool derivs) const {
+    StageDesc own;  // per-instance parameters (mpc_enable_instance_params): the shared descriptor with the instance's own parameter table
+    if (!inst_params.empty()) { own = stages[k]; own.params = inst_params[b][k]; }
+    const StageDesc& sd = inst_params.empty() ? stages[k] : own;
     if (sd.nc > dims.nc_max) throw std::runtime_error("stage has more constraint rows than nc_max");
     if (dims.space == MPC_SPACE_VECTOR) eval_centroidal(sd, dims.nx, dims.nu, x, u, xnext, kn, derivs);
     else ORC_EVAL_MULTIBODY(model, sd, dims.nu, x, u, xnext, kn, derivs);
@@ -183,18 +186,18 @@ struct Solver {
   void evaluate(Instance& in, const std::vector<std::vector<double>>& xs, const std::vector<std::vector<double>>& us,
                 std::vector<Knot>& knots, bool derivs) const {
     const int N = dims.horizon;
+    const int b_inst = (int)(&in - inst.data());
     std::string omp_err;
 #pragma omp parallel for schedule(dynamic) num_threads(opt.num_threads > 0 ? opt.num_threads : 1)
     for (int k = 0; k <= N; ++k) {
       try {
-        eval_knot(k, xs[k].data(), k < N ? us[k].data() : nullptr, k < N ? xs[k + 1].data() : nullptr, knots[k], derivs);
+        eval_knot(b_inst, k, xs[k].data(), k < N ? us[k].data() : nullptr, k < N ? xs[k + 1].data() : nullptr, knots[k], derivs);
       } catch (const std::exception& e) {
 #pragma omp critical
         omp_err = e.what();
       }
     }
     if (!omp_err.empty()) throw std::runtime_error(omp_err);
-    (void)in;
   }
 
   double mu_dyn(const Instance& in) const { return in.mu * opt.dyn_al_scale; }

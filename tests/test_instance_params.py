@@ -1,0 +1,87 @@
+"""Per-instance stage parameters (mpc_enable_instance_params / mpc_update_instance_params_batch, include/mpc_abi.h): every instance of an
+ensemble can have its own references.  An ensemble of B instances with per-instance foot references must behave exactly like B separate
+single-instance solvers that each got those references through the shared tables — over MPC ticks with stage cycling, shared patches
+arriving in between, and the appended stage starting from the shared table."""
+import numpy as np
+import pytest
+
+from mpc_benchmark_amd.aligator import _core as core
+from mpc_benchmark_amd.ensemble import EnsembleMPC
+from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+
+N, B, TICKS = 8, 3, 6
+
+
+def _ref_offsets(e):
+    slots = []
+    st = e.pd.stage_for_tick(0)
+    core.lower_stage(e.ctx, st.cost, st.dynamics, st.constraints, slots)
+    assert slots[3][2] == 12 and slots[4][2] == 12
+    return slots[3][1], slots[4][1]
+
+
+def _flat(M, dz):
+    p = np.asarray(M.translation, dtype=float).copy()
+    p[2] += dz
+    return np.concatenate([np.asarray(M.rotation, dtype=float).reshape(-1), p])
+
+
+def _run(lib, legs=1):
+    pd = FullDynamicsProblem(horizon=N)
+    lf, rf = pd.robot.foot_placements
+    ens = EnsembleMPC(pd, batch=B, library=lib, seed=3, sigma_q=0.005, sigma_v=0.01, tick_reuse=True)
+    singles = [EnsembleMPC(FullDynamicsProblem(horizon=N), batch=1, library=lib, x0=ens.x0[b:b + 1], tick_reuse=True) for b in range(B)]
+    for e in [ens] + singles:
+        e.options.riccati_legs = legs
+        e.options.tol = 0.0
+        e.native.set_options(e.options)
+        e.prepare_schedule(TICKS + 4)
+        e.cold_solve(max_iters=6)
+    off_lf, off_rf = _ref_offsets(ens)
+    ens.native.enable_instance_params()
+    out = []
+    for t in range(TICKS):
+        # every instance its own foot references: knot k of instance b is asked to lift the left foot by (b + 1) (k + 1 + t) * 0.2 mm
+        per = [(b, k, off_lf, _flat(lf, 2e-4 * (b + 1) * (k + 1 + t))) for b in range(B) for k in range(N)]
+        ens.native.update_instance_params_batch(per)
+        for b, s in enumerate(singles):
+            s.native.update_stage_params_batch([(k, off_lf, _flat(lf, 2e-4 * (b + 1) * (k + 1 + t))) for k in range(N)])
+        if t == 3:  # a shared patch (all instances): the right-foot reference of knot 2
+            ens.native.update_stage_params_batch([(2, off_rf, _flat(rf, 1e-3))])
+            for s in singles:
+                s.native.update_stage_params_batch([(2, off_rf, _flat(rf, 1e-3))])
+        ens.step()
+        for s in singles:
+            s.step()
+        re = ens.results(gains=True)
+        rs = [s.results(gains=True) for s in singles]
+        out.append((re, rs))
+    return out
+
+
+def _check(out, exact):
+    for t, (re, rs) in enumerate(out):
+        for b in range(B):
+            for key in ("xs", "us", "K"):
+                a, r = re[key][b], rs[b][key][0]
+                if exact:
+                    assert np.array_equal(a, r), (t, b, key)
+                else:
+                    assert np.max(np.abs(a - r)) <= 1e-9 * max(1.0, np.max(np.abs(r))), (t, b, key)
+    # the instances do differ from each other (the references took effect)
+    assert np.max(np.abs(out[-1][0]["us"][0] - out[-1][0]["us"][2])) > 1e-3
+
+
+def test_instance_params_on_the_oracle(oracle_lib):
+    _check(_run(oracle_lib), exact=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("legs", [1, 4])
+def test_instance_params_on_the_device(hip_lib, oracle_lib, legs):
+    out = _run(hip_lib, legs)
+    _check(out, exact=True)
+    ref = _run(oracle_lib, 1)
+    for (re, _), (ro, _) in zip(out, ref):
+        for key, tol in (("xs", 1e-6), ("us", 1e-5)):
+            assert np.max(np.abs(re[key] - ro[key])) < tol * max(1.0, np.max(np.abs(ro[key]))), key
