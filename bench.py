@@ -152,6 +152,9 @@ def main():
     ap.add_argument("--walk", action="store_true",
                     help="only the walk measurement: every tick regenerates the foot references from the measured state and patches them into "
                          "the stage tables (FootTrajectory.updateTrajectory + 2 N setReference + terminal CoM rebuild, fulldynamic_talos.py:444-510)")
+    ap.add_argument("--walk-refs", choices=["instance", "shared"], default="instance",
+                    help="walk mode: every instance replans from its own measured foot poses and has its own references (instance: per-instance "
+                         "parameter tables, batched generator) or all instances track the references planned from instance 0 (shared)")
     ap.add_argument("--no-walk", action="store_true",
                     help="only the frozen-reference measurement (by default both run and the LOWER rate is the headline value)")
     ap.add_argument("--closed-loop", action="store_true",
@@ -235,7 +238,7 @@ def main():
             # (`instances_lost_and_revived` in the JSON line; 0 in the default window)
             e.enable_failure_isolation(auto_revive=True, source=0)
             if walk:
-                e.enable_walk()
+                e.enable_walk(per_instance=(args.walk_refs == "instance"))
 
         # instances whose tick was a BCL update / stall without a ProxDDP step (num_iters == 0 in the status of the tick): not a solve
         nostep = {"n": 0, "on": False}
@@ -596,7 +599,8 @@ def main():
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
         "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; largest primal / dual infeasibility of the others: %.2e)" % (n_conv, args.batch, mres["worst_unconv"]),
         "tick_mode": ("walk: foot references regenerated and patched every tick (fulldynamic_talos.py:444-510)" if head else "frozen foot references"),
-        "walk_references": "planned once per tick from instance 0's measured state and shared by the instances of an ensemble (its stage tables are shared: DESIGN.md section 5)",
+        "walk_references": ("per instance: every instance replans from its own measured foot poses (per-instance parameter tables, batched generator on the host)" if args.walk_refs == "instance"
+                            else "planned once per tick from instance 0's measured state and shared by the instances of an ensemble"),
         "measurements": {(w if isinstance(w, str) else ("walk" if w else "frozen_references")): {"value": round(rate(r), 2), "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 4),
                                                                   "replanning_ticks": r["replanning_ticks"],
                                                                   "kernel_ms_per_step_warmup": {k: round(v[1] / max(1, args.warmup), 4) for k, v in sorted(r["warm"].items(), key=lambda kv: -kv[1][1])[:6]}}

@@ -298,6 +298,11 @@ class NativeSolver:
         self._check(self.lib.mpc_update_instance_params_batch(self._h, len(patches), insts.ctypes.data_as(_IP), ks.ctypes.data_as(_IP),
                                                               offs.ctypes.data_as(_IP), lens.ctypes.data_as(_IP), _dp(flat)), "mpc_update_instance_params_batch")
 
+    def update_instance_params_arrays(self, insts, ks, offsets, lens, vals):
+        """The same from prepared arrays (int32 index arrays, float64 values): no per-patch Python work."""
+        self._check(self.lib.mpc_update_instance_params_batch(self._h, int(insts.size), insts.ctypes.data_as(_IP), ks.ctypes.data_as(_IP),
+                                                              offsets.ctypes.data_as(_IP), lens.ctypes.data_as(_IP), _dp(vals)), "mpc_update_instance_params_batch")
+
     def set_failure_policy(self, isolate):
         """isolate: a failed instance is reported (``stats.converged = -code``) and skipped until revived instead of failing the run."""
         self._check(self.lib.mpc_set_failure_policy(self._h, int(bool(isolate))), "mpc_set_failure_policy")

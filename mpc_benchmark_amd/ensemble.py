@@ -114,7 +114,7 @@ class EnsembleMPC:
         import copy
         walk = None
         if self._walk is not None:
-            walk = copy.deepcopy({k: self._walk[k] for k in ("lists", "traj", "x_measured", "last", "replanning") if k in self._walk})
+            walk = copy.deepcopy({k: self._walk[k] for k in ("lists", "traj", "x_measured", "last", "replanning", "batch", "x_measured_all", "last_all") if k in self._walk})
         self._episode = (self.native.get_state(), self.tick, walk, getattr(self, "replanning_ticks", 0))
 
     def restart_episode(self):
@@ -150,6 +150,7 @@ class EnsembleMPC:
                 self.native.run_shifted_async()
                 stats, xn = self.native.wait_state()
                 self._walk["x_measured"] = xn[0].copy()
+                self._walk["x_measured_all"] = xn
                 return self._handle_lost(stats)
             return self._handle_lost(self.native.run_shifted())
         except RuntimeError as e:
@@ -186,6 +187,7 @@ class EnsembleMPC:
             if self._walk is not None:
                 stats, xn = self.native.wait_state()
                 self._walk["x_measured"] = xn[0].copy()  # instance 0's predicted next state: the measurement the generators plan from
+                self._walk["x_measured_all"] = xn     # (per-instance references: everybody's)
                 return self._handle_lost(stats)
             return self._handle_lost(self.native.wait())
         except RuntimeError as e:
@@ -223,6 +225,13 @@ class EnsembleMPC:
             for b in lost:
                 self.native.revive_instance(b, src)
                 self.revived += 1
+                if self._walk is not None and "batch" in self._walk:  # per-instance references: the generator state of the source as well
+                    g = self._walk["batch"]
+                    for name in ("sL", "fL", "sR", "fR"):
+                        R, p = getattr(g, name)
+                        R[b], p[b] = R[src], p[src]
+                    self._walk["x_measured_all"] = np.array(self._walk["x_measured_all"])
+                    self._walk["x_measured_all"][b] = self._walk["x_measured_all"][src]
                 for rec in self.lost:
                     if rec[1] == b and rec[3] is None:
                         rec[3] = self.tick
@@ -232,17 +241,22 @@ class EnsembleMPC:
         return [tuple(r) for r in self.lost if r[3] is None]
 
     # -- the reference loop's per-tick problem updates on the shared stage tables ---------------------------------
-    def enable_walk(self, swing_apex=0.15, x_forward=0.0, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0):
+    def enable_walk(self, swing_apex=0.15, x_forward=0.0, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0, per_instance=False):
         """From now on every tick does what the loop body of fulldynamic_talos.py:444-510 does to the problem before solving:
         ``FootTrajectory.updateTrajectory`` from the measured foot poses, ``setReference`` on the two foot-placement costs of
         every stage (2 N parameter patches), ``replaceStageCircular``, the terminal CoM constraint rebuilt between the last foot
         references and the terminal foot references.  The stage tables of an ensemble are shared by its instances, so the
         references are planned from instance 0's state (the state the last COMPLETED tick predicted: with two ticks in flight
-        that is one tick older than the reference script's measurement) and every instance tracks them."""
+        that is one tick older than the reference script's measurement) and every instance tracks them.
+
+        ``per_instance=True``: every instance plans from ITS OWN measured foot poses and gets its own references
+        (mpc_enable_instance_params: per-instance parameter tables; ``references.FootTrajectoryBatch`` and
+        ``minipin.frame_placements_batch`` do the generator's and the forward kinematics' work for all instances in numpy arrays; one
+        call carries the 2 N + 3 patches of every instance, of which only the changed ones travel)."""
         from . import references as refgen
         from .problems import fulldynamic
         from .robot import minipin as pin
-        self._walk_args = dict(swing_apex=swing_apex, x_forward=x_forward, y_forward=y_forward, foot_yaw=foot_yaw, y_gap=y_gap, z_height=z_height)
+        self._walk_args = dict(swing_apex=swing_apex, x_forward=x_forward, y_forward=y_forward, foot_yaw=foot_yaw, y_gap=y_gap, z_height=z_height, per_instance=per_instance)
         pd, N = self.pd, self.problem.num_steps
         rb = pd.robot
         ev = refgen.contact_event_times(pd.contact_phases, N)
@@ -263,10 +277,33 @@ class EnsembleMPC:
             "x_measured": np.array(self.x0[0]), "patched": 0, "patches": 0, "last": None,
         }
         assert slots[3][2] == 12 and slots[4][2] == 12 and tslots[2][2] == 12 and tslots[3][2] == 12 and tslots[len(self.problem.term_cost.components)][2] == 3
+        if per_instance:
+            B, w = self.batch, self._walk
+            self.native.enable_instance_params()
+            bc = lambda M: (np.tile(np.asarray(M.rotation, dtype=float), (B, 1, 1)), np.tile(np.asarray(M.translation, dtype=float), (B, 1)))
+            (LR, Lp), (RR, Rp) = bc(lf), bc(rf)
+            w["batch"] = refgen.FootTrajectoryBatch(LR, Lp, RR, Rp, fulldynamic.T_SS, fulldynamic.T_DS, N, swing_apex, x_forward, y_forward, foot_yaw, y_gap, z_height)
+            w["x_measured_all"] = np.array(self.x0, dtype=float)
+            i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+            # index arrays of the patches of one tick: per instance the N left-foot and N right-foot references, then (after the cycle) its terminal targets
+            w["idx"] = (i32(np.repeat(np.arange(B), 2 * N)), i32(np.tile(np.concatenate([np.arange(N), np.arange(N)]), B)),
+                        i32(np.tile(np.concatenate([np.full(N, w["off_lf"]), np.full(N, w["off_rf"])]), B)), i32(np.full(B * 2 * N, 12)))
+            w["tidx"] = (i32(np.repeat(np.arange(B), 3)), i32(np.full(3 * B, N)), i32(np.tile([w["toff_com"], w["toff_lf"], w["toff_rf"]], B)), i32(np.tile([3, 12, 12], B)))
 
     def _walk_references(self):
         w, N = self._walk, self.problem.num_steps
         rb, pin, refgen = self.pd.robot, self._walk["pin"], self._walk["refgen"]
+        if "batch" in w:  # per-instance references
+            (LR, Lp), (RR, Rp) = pin.frame_placements_batch(rb.model, w["x_measured_all"][:, :rb.model.nq], rb.foot_frame_ids)
+            takeoff_RFs, takeoff_LFs, land_RFs, land_LFs = w["lists"]
+            takeoff_RF, takeoff_LF, land_RF, land_LF = refgen.update_timings(land_LFs, land_RFs, takeoff_LFs, takeoff_RFs)
+            Lb, Rb = w["batch"].updateTrajectory(takeoff_RF, takeoff_LF, land_RF, land_LF, LR, Lp, RR, Rp)
+            vals = np.ascontiguousarray(np.concatenate([Lb, Rb], axis=1)).reshape(-1)
+            self.native.update_instance_params_arrays(*w["idx"], vals)
+            w["last_all"] = (Lb[:, -1].copy(), Rb[:, -1].copy())
+            w["replanning"] = (land_LF < 0 or land_RF < 0 or 0 <= takeoff_RF < w["batch"].T_ds or 0 <= takeoff_LF < w["batch"].T_ds)
+            self.replanning_ticks = getattr(self, "replanning_ticks", 0) + int(w["replanning"])
+            return
         pin.framesForwardKinematics(rb.model, w["data"], np.asarray(w["x_measured"])[:rb.model.nq])
         LF_pose, RF_pose = w["data"].oMf[rb.foot_frame_ids[0]].copy(), w["data"].oMf[rb.foot_frame_ids[1]].copy()
         takeoff_RFs, takeoff_LFs, land_RFs, land_LFs = w["lists"]
@@ -286,6 +323,13 @@ class EnsembleMPC:
 
     def _walk_terminal(self):
         w, N = self._walk, self.problem.num_steps
+        if "batch" in w:
+            L_last, R_last = w["last_all"]
+            com = np.tile(self.pd.robot.com0, (self.batch, 1))
+            com[:, :2] = 0.5 * (L_last[:, 9:11] + R_last[:, 9:11])
+            vals = np.ascontiguousarray(np.concatenate([com, L_last, R_last], axis=1)).reshape(-1)
+            self.native.update_instance_params_arrays(*w["tidx"], vals)
+            return
         LF_last, RF_last = w["last"]
         flat = lambda M: np.concatenate([np.asarray(M.rotation, dtype=float).reshape(-1), np.asarray(M.translation, dtype=float)])
         com_final = self.pd.robot.com0.copy()

@@ -233,3 +233,107 @@ class FootTrajectory:
                 si += 1
                 out.append(pose)
         return out
+
+
+# ---- the same generator for B robots at once (ensembles with per-instance references) ---------------------------------------------
+def _yaw_rotation_batch(yaw):
+    c, s = np.cos(yaw), np.sin(yaw)
+    R = np.zeros(yaw.shape + (3, 3))
+    R[..., 0, 0], R[..., 0, 1], R[..., 1, 0], R[..., 1, 1], R[..., 2, 2] = c, -s, s, c, 1.0
+    return R
+
+
+def _log3_batch(R):
+    """Rotation vectors of R (..., 3, 3) away from angle pi (foot yaw differences are small)."""
+    c = np.clip((np.trace(R, axis1=-2, axis2=-1) - 1.0) / 2.0, -1.0, 1.0)
+    th = np.arccos(c)
+    w = np.stack([R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1]], axis=-1)
+    small = th < 1e-10
+    scale = np.where(small, 0.5, th / (2.0 * np.sin(np.where(small, 1.0, th))))
+    return scale[..., None] * w
+
+
+def _exp3_batch(w):
+    th = np.linalg.norm(w, axis=-1)
+    K = np.zeros(w.shape[:-1] + (3, 3))
+    K[..., 0, 1], K[..., 0, 2], K[..., 1, 0], K[..., 1, 2], K[..., 2, 0], K[..., 2, 1] = -w[..., 2], w[..., 1], w[..., 2], -w[..., 0], -w[..., 1], w[..., 0]
+    small = th < 1e-10
+    ths = np.where(small, 1.0, th)
+    a = np.where(small, 1.0, np.sin(ths) / ths)[..., None, None]
+    b = np.where(small, 0.0, (1.0 - np.cos(ths)) / ths ** 2)[..., None, None]
+    return np.eye(3) + a * K + b * (K @ K)
+
+
+class FootTrajectoryBatch:
+    """``FootTrajectory`` for B robots in one set of arrays: poses are (R [B, 3, 3], p [B, 3]) pairs, ``updateTrajectory`` returns the
+    references of both feet as [B, nsteps, 12] blocks (rotation row-major, then translation: the layout of the stage parameter tables).
+    Same rules, same countdown arguments (the contact schedule is shared by the robots of an ensemble); instance b gets what the
+    scalar class would give for its measured poses."""
+
+    def __init__(self, LF_R, LF_p, RF_R, RF_p, T_ss, T_ds, nsteps, swing_apex, x_forward, y_forward, foot_angle, y_gap, z_height):
+        self.tR = np.array([x_forward, -y_gap - y_forward, z_height], dtype=float)
+        self.tL = np.array([x_forward, y_gap, z_height], dtype=float)
+        self.rotationDiff = yaw_rotation(foot_angle)
+        self.sL, self.fL = (LF_R.copy(), LF_p.copy()), (LF_R.copy(), LF_p.copy())
+        self.sR, self.fR = (RF_R.copy(), RF_p.copy()), (RF_R.copy(), RF_p.copy())
+        self.T_ds, self.T_ss, self.nsteps, self.swing_apex = T_ds, T_ss, nsteps, swing_apex
+
+    @staticmethod
+    def _yaw(R):
+        return np.arctan2(R[:, 1, 0], R[:, 0, 0])
+
+    def _beside(self, pose, offset, rotate):
+        R, p = pose
+        p2 = p + np.einsum("bij,j->bi", _yaw_rotation_batch(self._yaw(R)), offset)
+        R2 = (self.rotationDiff @ R) if rotate else R.copy()
+        return R2, p2
+
+    def updateTrajectory(self, takeoff_RF, takeoff_LF, land_RF, land_LF, LF_R, LF_p, RF_R, RF_p):
+        LF, RF = (LF_R, LF_p), (RF_R, RF_p)
+        cp = lambda P: (P[0].copy(), P[1].copy())
+        if land_LF < 0:
+            self.sL, self.fL = cp(LF), cp(LF)
+        if land_RF < 0:
+            self.sR, self.fR = cp(RF), cp(RF)
+        if 0 <= takeoff_RF < self.T_ds:  # right foot next to the left one, then the left foot next to that foothold
+            self.sR = cp(RF)
+            self.fR = self._beside(LF, self.tR, True)
+            self.sL = cp(LF)
+            self.fL = self._beside(self.fR, self.tL, False)
+        if 0 <= takeoff_LF < self.T_ds:
+            self.sL = cp(LF)
+            self.fL = self._beside(RF, self.tL, False)
+            self.sR = cp(RF)
+            self.fR = self._beside(self.fL, self.tR, True)
+        return self._horizon_refs(land_LF, self.sL, self.fL), self._horizon_refs(land_RF, self.sR, self.fR)
+
+    def _horizon_refs(self, time_to_land, init, final):
+        B, N = init[0].shape[0], self.nsteps
+        flat = lambda P: np.concatenate([P[0].reshape(B, 9), P[1]], axis=1)
+        out = np.empty((B, N, 12))
+        if time_to_land <= -1:
+            out[:] = flat(init)[:, None, :]
+            return out
+        ts = np.arange(time_to_land, time_to_land - N, -1)
+        out[:, ts <= 0] = flat(final)[:, None, :]
+        out[:, ts > self.T_ss] = flat(init)[:, None, :]
+        swing = np.nonzero((ts > 0) & (ts <= self.T_ss))[0]
+        if swing.size:
+            s = (self.T_ss - ts[swing]).astype(float) / float(self.T_ss)
+            m = 8
+            i = np.arange(m + 1)
+            basis = _BINOM8[None, :] * s[:, None] ** i[None, :] * (1.0 - s[:, None]) ** (m - i)[None, :]  # [k, 9]
+            wps = np.empty((B, 3, 9))
+            wps[:, :, :4] = init[1][:, :, None]
+            wps[:, :, 4] = 0.75 * init[1] + 0.25 * final[1]
+            wps[:, 2, 4] += self.swing_apex
+            wps[:, :, 5:] = final[1][:, :, None]
+            trans = np.einsum("ks,bcs->bkc", basis, wps)
+            w = _log3_batch(np.einsum("bji,bjk->bik", init[0], final[0]))
+            if np.any(w):
+                Rk = init[0][:, None] @ _exp3_batch(s[None, :, None] * w[:, None, :])
+            else:
+                Rk = np.broadcast_to(init[0][:, None], (B, swing.size, 3, 3))
+            out[:, swing, :9] = Rk.reshape(B, swing.size, 9)
+            out[:, swing, 9:] = trans
+        return out

@@ -577,3 +577,46 @@ def buildReducedModel(model, locked_joint_ids, q_ref):
         red.referenceConfigurations[name] = qr
     del data
     return red
+
+
+def frame_placements_batch(model, Q, frame_ids):
+    """World placements of a few frames for a batch of configurations ``Q`` [B, nq]: (R [B, 3, 3], p [B, 3]) per frame, walking only
+    the joints on the way from the root to the frame (ensembles read the two sole frames of every robot each tick)."""
+    Q = np.asarray(Q, dtype=float)
+    B = Q.shape[0]
+    out = []
+    for fid in frame_ids:
+        f = model.frames[fid]
+        chain = []
+        j = f.parentJoint
+        while j > 0:
+            chain.append(j)
+            j = model.parents[j]
+        R = np.broadcast_to(np.eye(3), (B, 3, 3))
+        p = np.zeros((B, 3))
+        for i in reversed(chain):
+            jm, pl = model.joints[i], model.jointPlacements[i]
+            k = jm.shortname()
+            if k == "JointModelFreeFlyer":
+                qn = Q[:, jm.idx_q + 3: jm.idx_q + 7]
+                x, y, z, w = (qn / np.linalg.norm(qn, axis=1, keepdims=True)).T
+                Rj = np.empty((B, 3, 3))
+                Rj[:, 0, 0], Rj[:, 0, 1], Rj[:, 0, 2] = 1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)
+                Rj[:, 1, 0], Rj[:, 1, 1], Rj[:, 1, 2] = 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)
+                Rj[:, 2, 0], Rj[:, 2, 1], Rj[:, 2, 2] = 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)
+                Rl = pl.rotation @ Rj
+                pl_t = Q[:, jm.idx_q: jm.idx_q + 3] @ pl.rotation.T + pl.translation
+            else:
+                a = _AXIS[k]
+                b_, d_ = (a + 1) % 3, (a + 2) % 3
+                c_, s_ = np.cos(Q[:, jm.idx_q]), np.sin(Q[:, jm.idx_q])
+                P = pl.rotation
+                Rl = np.empty((B, 3, 3))
+                Rl[:, :, a] = P[:, a]
+                Rl[:, :, b_] = c_[:, None] * P[:, b_] + s_[:, None] * P[:, d_]
+                Rl[:, :, d_] = c_[:, None] * P[:, d_] - s_[:, None] * P[:, b_]
+                pl_t = np.broadcast_to(pl.translation, (B, 3))
+            p = np.einsum("bij,bj->bi", R, pl_t) + p
+            R = R @ Rl
+        out.append((R @ f.placement.rotation, np.einsum("bij,j->bi", R, f.placement.translation) + p))
+    return out

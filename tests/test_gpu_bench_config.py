@@ -81,36 +81,44 @@ def test_bench_default_configuration(hip_lib, oracle_lib):
         assert np.array_equal(ra[key], rp[key]), "tick reuse + two ticks in flight differ from the plain path at tick %d: %s" % (T1, key)
 
 
-def test_whole_schedule_walk_with_two_iterations_per_tick(hip_lib):
+@pytest.mark.parametrize("refs", ["shared", "instance"])
+def test_whole_schedule_walk_with_two_iterations_per_tick(hip_lib, refs):
     """Robustness of the benchmarked ensemble over the reference's WHOLE schedule (fulldynamic_talos.py:248-266: 1000 ticks, three steps per
-    foot and the final stop), walk mode (references replanned from the measured state), two ticks in flight, no episode restart, no
-    rescue: with two ProxDDP iterations per tick (``iters_per_tick = 2``) every one of the 64 randomised instances stays with the
-    nominal one to the end.  (With the reference's single iteration per tick the nominal instance walks the schedule and perturbed ones
-    are lost when the first single-support phase reaches the front of the horizon: DESIGN.md §5, tools/robustness_probe.py.)"""
+    foot and the final stop), walk mode, two ticks in flight, no episode restart, no rescue, two ProxDDP iterations per tick
+    (``iters_per_tick = 2``).  References shared by the ensemble (planned from the nominal instance): every one of the 64 randomised
+    instances stays with the nominal one to the end.  References per instance (every instance replans from its own measured foot poses —
+    bench.py's walk): the same with failure isolation on, where at most a handful of the 64 000 instance-ticks end in a re-seed from the
+    nominal instance (one on this seed).  (With the reference's single iteration per tick the nominal instance walks the schedule and
+    perturbed ones are lost when the first single-support phase reaches the front of the horizon: DESIGN.md §5, tools/robustness_probe.py.)"""
     pd = FullDynamicsProblem(horizon=N, complete_model=True)
     (e,) = make_bench_shards(pd, hip_lib, B, legs=4, tick_reuse=True)
     e.iters_per_tick = 2
     e.prepare_schedule(pd.t_mpc + 4)
     e.cold_solve(max_iters=100)
-    e.enable_walk()
+    if refs == "instance":
+        e.enable_failure_isolation(auto_revive=True, source=0)
+    e.enable_walk(per_instance=(refs == "instance"))
     ticks = min(1000, pd.t_mpc - 1)
     worst = 0.0
     for t in range(ticks):
         e.step_async()
         if e.inflight == 2:
-            st = e.wait()   # raises if the library lost an instance (failed factorisation)
-            c = np.array([s.traj_cost for s in st])
+            st = e.wait()   # raises if the library lost an instance (failed factorisation) and isolation is off
+            c = np.array([s.traj_cost for s in st if s.converged >= 0])
             assert np.all(np.isfinite(c))
-            if t > 300:     # the initial perturbations have decayed: every instance walks the nominal gait
+            if t > 300 and refs == "shared":  # the initial perturbations have decayed: every instance walks the nominal gait
                 worst = max(worst, float(np.max(np.abs(c - c[0])) / abs(c[0])))
     while e.inflight:
         st = e.wait()
     assert getattr(e, "rescues", 0) == 0 and e.tick == ticks
+    assert e.revived <= (3 if refs == "instance" else 0), e.lost
+    assert all(rec[1] != 0 for rec in e.lost)
     assert worst < 0.25, worst
-    c = np.array([s.traj_cost for s in st])
-    assert np.max(np.abs(c - c[0])) < 0.05 * abs(c[0])
+    c = np.array([s.traj_cost for s in st if s.converged >= 0])
+    assert len(c) >= B - 1 and np.max(np.abs(c - c[0])) < (0.05 if refs == "shared" else 20.0) * abs(c[0])  # (per-instance footholds: the final stances differ)
     r = e.results(gains=False)
-    assert np.all(np.isfinite(r["xs"])) and np.all(np.isfinite(r["us"]))
+    alive = [b for b, s in enumerate(st) if s.converged >= 0]
+    assert np.all(np.isfinite(r["xs"][alive])) and np.all(np.isfinite(r["us"][alive]))
 
 
 def test_failed_instances_are_isolated_and_revived(hip_lib):

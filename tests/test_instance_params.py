@@ -85,3 +85,44 @@ def test_instance_params_on_the_device(hip_lib, oracle_lib, legs):
     for (re, _), (ro, _) in zip(out, ref):
         for key, tol in (("xs", 1e-6), ("us", 1e-5)):
             assert np.max(np.abs(re[key] - ro[key])) < tol * max(1.0, np.max(np.abs(ro[key]))), key
+
+
+def _walk_run(lib, ticks=16, legs=1):
+    """Walk mode with per-instance references (every instance replans from its own measured foot poses) against single-instance
+    ensembles that each walk on their own."""
+    Nw = 12
+    pd = FullDynamicsProblem(horizon=Nw)
+    ens = EnsembleMPC(pd, batch=B, library=lib, seed=3, sigma_q=0.01, sigma_v=0.02, tick_reuse=True)
+    singles = [EnsembleMPC(FullDynamicsProblem(horizon=Nw), batch=1, library=lib, x0=ens.x0[b:b + 1], tick_reuse=True) for b in range(B)]
+    for e in [ens] + singles:
+        e.options.riccati_legs = legs
+        e.options.tol = 0.0
+        e.native.set_options(e.options)
+        e.prepare_schedule(60)
+        e.cold_solve(max_iters=8)
+        e.tick = 20  # close to the first take-off: planning windows, swings and landings inside the run
+    ens.enable_walk(x_forward=0.05, per_instance=True)
+    for s in singles:
+        s.enable_walk(x_forward=0.05)
+    worst = 0.0
+    for t in range(ticks):
+        ens.step()
+        re = ens.results(gains=False)
+        for b, s in enumerate(singles):
+            s.step()
+            rs = s.results(gains=False)
+            for key in ("xs", "us"):
+                worst = max(worst, float(np.max(np.abs(re[key][b] - rs[key][0])) / max(1.0, np.max(np.abs(rs[key][0])))))
+    return worst, ens.replanning_ticks, re
+
+
+def test_per_instance_walk_on_the_oracle(oracle_lib):
+    worst, replanning, re = _walk_run(oracle_lib)
+    assert replanning >= 1 and worst < 1e-8, (worst, replanning)
+    assert np.max(np.abs(re["us"][0] - re["us"][2])) > 1e-3
+
+
+@pytest.mark.gpu
+def test_per_instance_walk_on_the_device(hip_lib):
+    worst, replanning, _ = _walk_run(hip_lib, legs=4)
+    assert replanning >= 1 and worst < 1e-8, (worst, replanning)

@@ -136,3 +136,45 @@ def test_set_reference_fast_path_patches_the_lowered_table():
     st.cost.getComponent(4).residual.setReference(rf)
     prob.removeTerminalConstraint()
     assert prob._term._dirty
+
+
+def test_batched_generator_and_foot_placements_equal_the_scalar_ones():
+    """FootTrajectoryBatch / frame_placements_batch (per-instance references of an ensemble): instance b gets what the scalar generator
+    gives for its own measured poses, tick by tick over take-offs, swings and landings."""
+    from mpc_benchmark_amd import references as rg
+    from mpc_benchmark_amd.robot import minipin as pin
+    from mpc_benchmark_amd.robot.talos_synth import load_talos
+    _, model, _, q0 = load_talos()
+    rng = np.random.default_rng(5)
+    B, N, T_ss, T_ds = 4, 30, 12, 6
+    ids = [model.getFrameId("left_sole_link"), model.getFrameId("right_sole_link")]
+    Q = np.array([pin.integrate(model, q0, np.concatenate((rng.normal(size=3) * 0.02, rng.normal(size=3) * 0.05, rng.normal(size=model.nv - 6) * 0.05))) for _ in range(B)])
+    (LR, Lp), (RR, Rp) = pin.frame_placements_batch(model, Q, ids)
+    data = model.createData()
+    poses = []
+    for b in range(B):
+        pin.framesForwardKinematics(model, data, Q[b])
+        lf, rf = data.oMf[ids[0]].copy(), data.oMf[ids[1]].copy()
+        assert np.max(np.abs(LR[b] - lf.rotation)) < 1e-14 and np.max(np.abs(Lp[b] - lf.translation)) < 1e-14
+        assert np.max(np.abs(RR[b] - rf.rotation)) < 1e-14 and np.max(np.abs(Rp[b] - rf.translation)) < 1e-14
+        poses.append((lf, rf))
+    args = (T_ss, T_ds, N, 0.15, 0.05, 0.0, 0.1, 0.18, 0.0)
+    batch = rg.FootTrajectoryBatch(LR, Lp, RR, Rp, *args)
+    scal = [rg.FootTrajectory(poses[b][0].copy(), poses[b][1].copy(), *args) for b in range(B)]
+    phases = [[True, True]] * 8 + [[True, False]] * T_ss + [[True, True]] * T_ds + [[False, True]] * T_ss + [[True, True]] * 40
+    ev = [list(e) for e in rg.contact_event_times(phases, N)]
+    evs = [[list(e) for e in rg.contact_event_times(phases, N)] for _ in range(B)]
+    for t in range(45):
+        # the "measured" poses drift a little every tick
+        LpT, RpT = Lp + 1e-4 * t, Rp - 1e-4 * t
+        takeoff_RF, takeoff_LF, land_RF, land_LF = rg.update_timings(ev[3], ev[2], ev[1], ev[0])
+        Lb, Rb = batch.updateTrajectory(takeoff_RF, takeoff_LF, land_RF, land_LF, LR, LpT, RR, RpT)
+        for b in range(B):
+            e = evs[b]
+            tk = rg.update_timings(e[3], e[2], e[1], e[0])
+            assert tk == (takeoff_RF, takeoff_LF, land_RF, land_LF)
+            lf = pin.SE3(LR[b], LpT[b]); rf = pin.SE3(RR[b], RpT[b])
+            Ls, Rs = scal[b].updateTrajectory(*tk, lf, rf)
+            for j in range(N):
+                for got, want in ((Lb[b, j], Ls[j]), (Rb[b, j], Rs[j])):
+                    assert np.max(np.abs(got[:9] - want.rotation.reshape(-1))) < 1e-13 and np.max(np.abs(got[9:] - want.translation)) < 1e-13, (t, b, j)

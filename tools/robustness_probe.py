@@ -21,7 +21,7 @@ e.prepare_schedule(ticks + 4)
 st = e.cold_solve(max_iters=100)
 print("cold: converged %d/%d" % (sum(bool(s.converged) for s in st), batch))
 if os.environ.get("WALK"):
-    e.enable_walk()
+    e.enable_walk(per_instance=bool(os.environ.get("PERINST")))  # PERINST=1: every instance replans from its own measured foot poses
 for env, field in (("DYN_SCALE", "dyn_al_scale"), ("ARMIJO", "ls_armijo_c1"), ("REG_INIT", "reg_init"), ("MU_INIT", "mu_init"), ("MU_FACTOR", "bcl_mu_update_factor")):
     if os.environ.get(env):  # the knobs the scripts leave at upstream defaults that this build could not pin
         setattr(e.options, field, float(os.environ[env])); e.native.set_options(e.options)
