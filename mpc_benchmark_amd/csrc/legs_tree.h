@@ -47,8 +47,8 @@ static inline TreeDesc make_tree_desc(int J) {
   return T;
 }
 
-DEV double* tree_node_ptr(const SolverArgs& a, int b, int inner) { return a.treebuf + ((size_t)b * MPC_MAX_LEGS + inner) * a.L.tree_stride; }
-DEV double* tree_scratch_ptr(const SolverArgs& a, int b) { return tree_node_ptr(a, b, MPC_MAX_LEGS - 1); }  // G of the K_0 path (mp x n)
+DEV double* tree_node_ptr(const SolverArgs& a, int b, int inner) { return a.treebuf + ((size_t)b * a.leg_cap + inner) * a.L.tree_stride; }
+DEV double* tree_scratch_ptr(const SolverArgs& a, int b) { return tree_node_ptr(a, b, a.leg_cap - 1); }  // G of the K_0 path (mp x n)
 
 // Exact K_0 = K_0 + Ku_0 Lm_1 d theta_1 / d x_0, d theta_1 / d x_0 = S_1, S_i = F_i + E_i S_{i+1} along the leftmost path (node 1: the
 // parent of leg 0 ... the root), evaluated from the left with the thin matrix G (m x n):  G_1 = Ku_0 Lm_1 ;  K_0 += G_i F_i ;

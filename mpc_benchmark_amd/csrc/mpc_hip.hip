@@ -113,6 +113,7 @@ struct mpc_solver {
   int env_tree_sweeps = 0, env_trace = -1;
   double* d_legbuf = nullptr;
   double* d_treebuf = nullptr;
+  int leg_cap = 0;  // legs the three leg-indexed buffers (d_work, d_legbuf, d_treebuf) are sized for: they grow on demand (ensure_leg_capacity)
   TreeDesc tree{};       // tree over the cuts for the current number of legs (legs_tree.h)
   // three legs or more: the cuts are resolved by a tree of pairwise compositions (legs_tree.h) instead of the chain of k_leg_consensus
   // (fewer solves in a row, and the compositions of a level run side by side: 64 x 4 legs 0.38 -> 0.27 ms, batch 1 with 16 legs is only
@@ -180,7 +181,7 @@ struct mpc_solver {
     a.reuse_same = (a.reuse_on && reuse_same_now) ? 1 : 0;
     a.spec_knot = a.spec_on ? d_spec_knot : nullptr; a.spec_next = (a.reuse_on && spec_next_now) ? 1 : 0;
     for (int w = 0; w < MPC_DIRTY_WORDS; ++w) a.dirty[w] = a.reuse_on ? dirty_now[w] : 0ull;
-    a.nlegs = eff_legs(); a.legbuf = d_legbuf; a.treebuf = d_treebuf; a.leg_guess = leg_guess_now;
+    a.nlegs = eff_legs(); a.leg_cap = leg_cap; a.legbuf = d_legbuf; a.treebuf = d_treebuf; a.leg_guess = leg_guess_now;
     a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = phase_timers ? d_prof : nullptr;
     return a;
   }
@@ -193,6 +194,32 @@ struct mpc_solver {
 // every other handle on the device: shards of one GPU would then run in lock step.)
 static void copy_sync(mpc_solver* s, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
   HIP_OK(hipMemcpyAsync(dst, src, bytes, kind, s->stream));
+  HIP_OK(hipStreamSynchronize(s->stream));
+}
+
+// The leg-indexed buffers are sized for the number of legs in use (4 in the benchmark: 0.3 GB for 64 instances of the complete model
+// instead of 2.3 GB for MPC_MAX_LEGS = 32) and re-allocated when more are asked for.  Their contents are scratch (d_work) or guesses
+// that a change of the number of legs invalidates anyway (cut Hessians, tree nodes).
+static void ensure_leg_capacity(mpc_solver* s, int legs) {
+  const Layout& L = s->L;
+  int need = legs < 1 ? 1 : legs;
+  if (need >= 3 && need < 4) need = 4;  // (the tree keeps one scratch record per instance beside its inner nodes)
+  if (need <= s->leg_cap) return;
+  HIP_OK(hipStreamSynchronize(s->stream));
+  auto regrow = [&](double*& p, size_t count) {
+    if (p) HIP_OK(hipFree(p));
+    p = nullptr;
+    HIP_OK(hipMalloc((void**)&p, (count ? count : 1) * sizeof(double)));
+    HIP_OK(hipMemsetAsync(p, 0, (count ? count : 1) * sizeof(double), s->stream));
+  };
+  const size_t B = L.B;
+  regrow(s->d_work, B * need * (size_t)L.work_stride);
+  if (s->legs_ok) {
+    regrow(s->d_legbuf, B * (size_t)(need > 1 ? need - 1 : 1) * L.leg_stride);
+    regrow(s->d_treebuf, B * (size_t)need * L.tree_stride);  // inner nodes + one scratch record per instance
+  }
+  s->leg_cap = need;
+  s->leg_guess_valid = false;
   HIP_OK(hipStreamSynchronize(s->stream));
 }
 
@@ -253,7 +280,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   s->d_knots = s->alloc<double>(B * N1 * L.knot_stride);
   s->d_tknots = s->alloc<double>(B * L.n_alpha * N1 * T.knot_stride);
   s->d_gains = s->alloc<double>(B * N1 * L.gain_stride);
-  s->d_work = s->alloc<double>(B * MPC_MAX_LEGS * (size_t)L.work_stride);  // per (leg, instance): the legs of one instance run side by side
+  // d_work (per (leg, instance): the legs of one instance run side by side), d_legbuf, d_treebuf: ensure_leg_capacity
   s->d_trial_phi = s->alloc<double>(B * L.n_alpha * N1);
   s->d_inst = s->alloc<InstState>(B);
   s->d_all_done = s->alloc<int>(4);
@@ -310,8 +337,6 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<64>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    s->d_legbuf = s->alloc<double>(B * (MPC_MAX_LEGS - 1) * (size_t)L.leg_stride);
-    s->d_treebuf = s->alloc<double>(B * MPC_MAX_LEGS * (size_t)L.tree_stride);  // inner nodes + one scratch record per instance
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
@@ -323,6 +348,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<64>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
   }
+  ensure_leg_capacity(s, s->eff_legs());
   HIP_OK(hipStreamSynchronize(s->stream));
 }
 
@@ -737,6 +763,7 @@ int mpc_create(const mpc_dims* dims, mpc_solver** out) {
   } catch (const std::exception& e) {
     fprintf(stderr, "mpc_create: %s\n", e.what());
     for (void* p : s->allocs) (void)hipFree(p);
+    for (double* p : {s->d_work, s->d_legbuf, s->d_treebuf}) if (p) (void)hipFree(p);
     delete s;
     return -1;
   }
@@ -752,6 +779,7 @@ void mpc_destroy(mpc_solver* s) {
   for (int i = 0; i < mpc_solver::ASYNC_DEPTH; ++i) if (s->h_xnext[i]) (void)hipHostFree(s->h_xnext[i]);
   if (s->d_patch) (void)hipFree(s->d_patch);
   for (void* p : s->allocs) (void)hipFree(p);
+  for (double* p : {s->d_work, s->d_legbuf, s->d_treebuf}) if (p) (void)hipFree(p);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -766,6 +794,7 @@ int mpc_set_options(mpc_solver* s, const mpc_options* opt) {
     s->opt = *opt;
     if (s->opt.ls_max_steps > s->L.n_alpha) s->opt.ls_max_steps = s->L.n_alpha;
     if (s->eff_legs() != legs_before) s->leg_guess_valid = false;  // the cuts moved: the kept Hessians belong to other knots
+    ensure_leg_capacity(s, s->eff_legs());
   })
 }
 
@@ -1408,8 +1437,8 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
     }
     else if (nm == "Sg" || nm == "sg" || nm == "Zx" || nm == "zc" || nm == "calP" || nm == "calp" || nm == "theta") {
       // records of parametric leg k (k = leg index here)
-      if (!s->d_legbuf || k >= MPC_MAX_LEGS - 1) throw std::runtime_error("debug_get: no such leg record");
-      const double* lr = s->d_legbuf + ((size_t)b * (MPC_MAX_LEGS - 1) + k) * L.leg_stride;
+      if (!s->d_legbuf || k >= s->leg_cap - 1) throw std::runtime_error("debug_get: no such leg record");
+      const double* lr = s->d_legbuf + ((size_t)b * (s->leg_cap - 1) + k) * L.leg_stride;
       if (nm == "Sg") dev_vec(lr + L.lSg, n * n); else if (nm == "sg") dev_vec(lr + L.lsg, n); else if (nm == "Zx") dev_vec(lr + L.lZx, n * n);
       else if (nm == "zc") dev_vec(lr + L.lzc, n); else if (nm == "calP") dev_vec(lr + L.ldP, n * n);  // what the consensus worked on (the oracle's "calP")
       else if (nm == "calp") dev_vec(lr + L.lcp, n);

@@ -40,6 +40,7 @@ struct SolverArgs {
   double* prof;  // [B][64] phase cycle counters: 0..31 Riccati kernel, 32..63 whole-body stage kernel (knot 1)
   // parallel-in-time Riccati (legs.h): number of legs of this pass (1 = serial sweep) and the per-(instance, leg) records
   int nlegs;
+  int leg_cap;     // capacity (in legs) of legbuf / treebuf / work: grown by mpc_set_options when more legs are asked for
   int leg_guess;   // 1: leg j starts from the Hessian calP_{j+1} its record holds from the previous pass / tick (0: from zero)
   double* legbuf;  // [B][MPC_MAX_LEGS - 1][leg_stride]
   double* treebuf; // [B][MPC_MAX_LEGS - 1][tree_stride]: inner nodes of the tree over the cuts (legs_tree.h)
@@ -55,7 +56,7 @@ struct SolverArgs {
 // first knot of leg j (leg nlegs - 1 ends with the terminal knot) — the rule of oracle/solver.hpp leg_start
 DEV int leg_start(const SolverArgs& a, int j) { return (int)((long long)j * a.L.N / a.nlegs); }
 DEV int leg_of_knot(const SolverArgs& a, int k) { int j = a.nlegs - 1; while (j > 0 && leg_start(a, j) > k) --j; return j; }
-DEV double* leg_ptr(const SolverArgs& a, int b, int j) { return a.legbuf + ((size_t)b * (MPC_MAX_LEGS - 1) + j) * a.L.leg_stride; }
+DEV double* leg_ptr(const SolverArgs& a, int b, int j) { return a.legbuf + ((size_t)b * (a.leg_cap - 1) + j) * a.L.leg_stride; }  // leg_cap: legs the buffers were sized for
 
 DEV int knot_slot(const SolverArgs& a, int k) { return k < a.L.N ? (a.khead + k) % a.L.N : a.L.N; }
 DEV double* knot_ptr(const SolverArgs& a, int b, int k) { return a.knots + ((size_t)b * (a.L.N + 1) + knot_slot(a, k)) * a.L.knot_stride; }
