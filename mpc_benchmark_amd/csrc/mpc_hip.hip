@@ -1409,6 +1409,9 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
     else if (nm == "D12") mat(kn.data() + L.oD12, 1, 74, 74);  // D1_b (36) | Dd_b (36) | dt | valid (layout.h)
     else if (nm == "cval") mat(kn.data() + L.oCV, 1, c, c);
     else if (nm == "act") mat(kn.data() + L.oACT, 1, c, c);  // active flags of the constraint rows (developer probes)
+    else if (nm == "lo") mat(kn.data() + L.oLO, 1, c, c);
+    else if (nm == "hi") mat(kn.data() + L.oHI, 1, c, c);
+    else if (nm == "ctype") mat(kn.data() + L.oCT, 1, c, c);
     else if (nm == "CD") mat(kn.data() + L.oCD, c, nzk, nz);
     else if (nm == "cost") mat(kn.data() + L.oMISC + MISC_COST, 1, 1, 1);
     else if (nm == "xnext") mat(kn.data() + L.oXN, 1, L.nx, L.nx);
