@@ -45,10 +45,17 @@ for t in range(1, ticks + 1):
         print("  costs at the last good tick: nominal %.3e median %.3e, instances above 10x nominal: %s" % (c[0], np.median(c), np.nonzero(c > 10 * abs(c[0]))[0].tolist()))
         break
     extra_total += sum(int(s.num_iters) - 1 for s in st if s.num_iters > 1)
+    if os.environ.get("ADAPT"):  # two iterations on the tick after one that ended with a large primal infeasibility somewhere in the ensemble
+        want = 2 if max(s.prim_infeas for s in st) > float(os.environ["ADAPT"]) else 1
+        if want != e.options.max_iters:
+            e.options.max_iters = want; e.native.set_options(e.options)
+        adapt_ticks = globals().get("adapt_ticks", 0) + (want == 2)
     hist.append([(s.traj_cost, s.merit, s.prim_infeas, s.dual_infeas, s.alpha, s.ls_steps, s.mu) for s in st])
     if t % 50 == 0:
         c = np.array([h[0] for h in hist[-1]]); al = np.array([h[4] for h in hist[-1]])
         print("tick %4d cost nominal %.3e median %.3e max %.3e | alpha<1: %d | iterations beyond one per tick so far %d (%.2f %% of instance ticks)" % (
             t, c[0], np.median(c), c.max(), int((al < 1).sum()), extra_total, 100.0 * extra_total / (t * batch)))
 else:
+    if os.environ.get("ADAPT"):
+        print("ticks run with two iterations:", globals().get("adapt_ticks", 0))
     print("no failure in", ticks, "ticks" + ("; instances lost and revived: %d (%s ...)" % (e.revived, [tuple(r) for r in e.lost[:6]]) if os.environ.get("ISOLATE") else ""))
