@@ -225,16 +225,21 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
   // registers: as in k_leg_consensus (a lane is a row, a wavefront owns every 8th column, the owner of the pivot column leaves the
   // elimination factors in LDS, one barrier per column) ----
   {
-    constexpr int GJ_SLOTS = (2 * NP + 1 + NWC - 1) / NWC;
+    // (TWO columns per barrier: a wavefront owns the column pairs (2 (NWC t + wv), + 1) ; the owner of the pivot pair eliminates its first
+    // column from its second one in registers, picks the second pivot from that, and leaves both factor columns in LDS — the other
+    // wavefronts apply the two eliminations one after the other.  Same pivots, same operations in the same order as one column per
+    // barrier: bit-identical results with half the barriers.)
+    constexpr int GJ_SLOTS = 2 * ((2 * NP + 1 + 2 * NWC - 1) / (2 * NWC));
     double* dinv = fcol;
     int* iperm = used;
-    double* fbuf = Z;                 // [2][128], double-buffered: Mt is dead once the tableau is in registers (Y keeps D for role 1)
-    int* pbuf = (int*)(Z + 256);
+    double* fbuf = Z;                 // [2 pairs][2 columns][128], double-buffered: Mt is dead once the tableau is in registers (Y keeps D for role 1)
+    int* pbuf = (int*)(Z + 512);      // [2 pairs][2]
     const double* R = role == 0 ? Y : X;
     double tq[2][GJ_SLOTS];
+    auto col_of = [&](int sl) { return 2 * NWC * (sl >> 1) + 2 * wv + (sl & 1); };
 #pragma unroll
     for (int sl = 0; sl < GJ_SLOTS; ++sl) {
-      const int cc = NWC * sl + wv;
+      const int cc = col_of(sl);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int r = lane + 64 * h;
@@ -245,40 +250,65 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
     }
     bool used0 = false, used1 = false;
     LEG_BARRIER();
+    // pivot of one column held as (e0, e1) by the lanes of a wavefront, rows already used excluded: row, value, 1 / value
+    auto pick = [&](double e0, double e1, bool u0, bool u1, int& p, double& inv) {
+      const double v0 = (lane < n && !u0) ? fabs(e0) : -1.0, v1 = (lane + 64 < n && !u1) ? fabs(e1) : -1.0;
+      const bool second = v1 > v0;
+      const double vl = second ? v1 : v0;
+      const double vmax = wave_max_nonneg(fmax(vl, 0.0));
+      const unsigned long long mk = __ballot(vl == vmax);
+      const int src = __builtin_amdgcn_readfirstlane(mk ? __ffsll((long long)mk) - 1 : 0);
+      const int ph = __builtin_amdgcn_readlane(second ? 1 : 0, src);
+      p = src + 64 * ph;
+      const double piv = readlane_dyn(ph ? e1 : e0, src);
+      inv = __builtin_amdgcn_rcp(piv);
+      inv = inv * (2.0 - piv * inv);
+      inv = inv * (2.0 - piv * inv);
+    };
 #pragma unroll
-    for (int so = 0; so < (NP + NWC - 1) / NWC; ++so) {
+    for (int tp = 0; tp < (NP + 2 * NWC - 1) / (2 * NWC); ++tp) {
       for (int ow = 0; ow < NWC; ++ow) {  // nw == NWC
-        const int col = NWC * so + ow;
+        const int col = 2 * (NWC * tp + ow);
         if (col >= n) break;
-        double* fb = fbuf + (col & 1) * 128;
+        const bool two = col + 1 < n;
+        const int pb = (NWC * tp + ow) & 1;
+        double* fb = fbuf + pb * 256;
         if (wv == ow) {
-          const double e0 = tq[0][so], e1 = tq[1][so];
-          const double v0 = (lane < n && !used0) ? fabs(e0) : -1.0, v1 = (lane + 64 < n && !used1) ? fabs(e1) : -1.0;
-          const bool second = v1 > v0;
-          const double vl = second ? v1 : v0;
-          const double vmax = wave_max_nonneg(fmax(vl, 0.0));
-          const unsigned long long mk = __ballot(vl == vmax);
-          const int src = __builtin_amdgcn_readfirstlane(mk ? __ffsll((long long)mk) - 1 : 0);
-          const int ph = __builtin_amdgcn_readlane(second ? 1 : 0, src);
-          const int p = src + 64 * ph;
-          const double piv = readlane_dyn(ph ? e1 : e0, src);
-          double inv = __builtin_amdgcn_rcp(piv);
-          inv = inv * (2.0 - piv * inv);
-          inv = inv * (2.0 - piv * inv);
-          fb[lane] = (lane == p || lane >= n) ? 0.0 : e0 * inv;
-          fb[lane + 64] = (lane + 64 == p || lane + 64 >= n) ? 0.0 : e1 * inv;
-          if (lane == 0) { pbuf[col & 1] = p; perm[col] = p; iperm[p] = col; dinv[col] = inv; }
+          int pA, pB = 0;
+          double invA, invB = 0.0;
+          const double a0 = tq[0][2 * tp], a1 = tq[1][2 * tp];
+          pick(a0, a1, used0, used1, pA, invA);
+          const double fA0 = (lane == pA || lane >= n) ? 0.0 : a0 * invA, fA1 = (lane + 64 == pA || lane + 64 >= n) ? 0.0 : a1 * invA;
+          fb[lane] = fA0; fb[lane + 64] = fA1;
+          if (two) {
+            // the second column after the first elimination (what every wavefront will compute for its own columns below)
+            const double b0 = tq[0][2 * tp + 1], b1 = tq[1][2 * tp + 1];
+            const double prB = (pA < 64) ? readlane_dyn(b0, pA) : readlane_dyn(b1, pA - 64);
+            const double c0 = b0 - fA0 * prB, c1 = b1 - fA1 * prB;
+            const bool uA0 = used0 || lane == pA, uA1 = used1 || lane + 64 == pA;
+            pick(c0, c1, uA0, uA1, pB, invB);
+            fb[128 + lane] = (lane == pB || lane >= n) ? 0.0 : c0 * invB;
+            fb[128 + lane + 64] = (lane + 64 == pB || lane + 64 >= n) ? 0.0 : c1 * invB;
+          }
+          if (lane == 0) {
+            pbuf[2 * pb] = pA; perm[col] = pA; iperm[pA] = col; dinv[col] = invA;
+            if (two) { pbuf[2 * pb + 1] = pB; perm[col + 1] = pB; iperm[pB] = col + 1; dinv[col + 1] = invB; }
+          }
         }
         LEG_BARRIER();
-        const int p = __builtin_amdgcn_readfirstlane(pbuf[col & 1]);
-        const double f0 = fb[lane], f1 = fb[lane + 64];
-        if (lane == (p & 63)) { if (p >> 6) used1 = true; else used0 = true; }
-        if (p < 64) {
 #pragma unroll
-          for (int sl = so; sl < GJ_SLOTS; ++sl) { const double pr = readlane_dyn(tq[0][sl], p); tq[0][sl] -= f0 * pr; tq[1][sl] -= f1 * pr; }
-        } else {
+        for (int q = 0; q < 2; ++q) {
+          if (q == 1 && !two) break;
+          const int p = __builtin_amdgcn_readfirstlane(pbuf[2 * pb + q]);
+          const double f0 = fb[128 * q + lane], f1 = fb[128 * q + lane + 64];
+          if (lane == (p & 63)) { if (p >> 6) used1 = true; else used0 = true; }
+          if (p < 64) {
 #pragma unroll
-          for (int sl = so; sl < GJ_SLOTS; ++sl) { const double pr = readlane_dyn(tq[1][sl], p - 64); tq[0][sl] -= f0 * pr; tq[1][sl] -= f1 * pr; }
+            for (int sl = 2 * tp; sl < GJ_SLOTS; ++sl) { const double pr = readlane_dyn(tq[0][sl], p); tq[0][sl] -= f0 * pr; tq[1][sl] -= f1 * pr; }
+          } else {
+#pragma unroll
+            for (int sl = 2 * tp; sl < GJ_SLOTS; ++sl) { const double pr = readlane_dyn(tq[1][sl], p - 64); tq[0][sl] -= f0 * pr; tq[1][sl] -= f1 * pr; }
+          }
         }
       }
     }
@@ -290,7 +320,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
     LEG_BARRIER();
 #pragma unroll
     for (int sl = 0; sl < GJ_SLOTS; ++sl) {
-      const int cc = NWC * sl + wv;
+      const int cc = col_of(sl);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int r = lane + 64 * h;
