@@ -232,8 +232,8 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
     constexpr int GJ_SLOTS = 2 * ((2 * NP + 1 + 2 * NWC - 1) / (2 * NWC));
     double* dinv = fcol;
     int* iperm = used;
-    double* fbuf = Z;                 // [2 pairs][2 columns][128], double-buffered: Mt is dead once the tableau is in registers (Y keeps D for role 1)
-    int* pbuf = (int*)(Z + 512);      // [2 pairs][2]
+    double* fbuf = Z;                 // [2 pairs][2 columns][NP], double-buffered: Mt is dead once the tableau is in registers (Y keeps D for role 1)
+    int* pbuf = (int*)(Z + 4 * NP);   // [2 pairs][2]   (Z holds np x (np + 1) doubles: 272 for np = 16)
     const double* R = role == 0 ? Y : X;
     double tq[2][GJ_SLOTS];
     auto col_of = [&](int sl) { return 2 * NWC * (sl >> 1) + 2 * wv + (sl & 1); };
@@ -272,14 +272,15 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
         if (col >= n) break;
         const bool two = col + 1 < n;
         const int pb = (NWC * tp + ow) & 1;
-        double* fb = fbuf + pb * 256;
+        double* fb = fbuf + pb * 2 * NP;
         if (wv == ow) {
           int pA, pB = 0;
           double invA, invB = 0.0;
           const double a0 = tq[0][2 * tp], a1 = tq[1][2 * tp];
           pick(a0, a1, used0, used1, pA, invA);
           const double fA0 = (lane == pA || lane >= n) ? 0.0 : a0 * invA, fA1 = (lane + 64 == pA || lane + 64 >= n) ? 0.0 : a1 * invA;
-          fb[lane] = fA0; fb[lane + 64] = fA1;
+          if (lane < NP) fb[lane] = fA0;
+          if (lane + 64 < NP) fb[lane + 64] = fA1;
           if (two) {
             // the second column after the first elimination (what every wavefront will compute for its own columns below)
             const double b0 = tq[0][2 * tp + 1], b1 = tq[1][2 * tp + 1];
@@ -287,8 +288,8 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
             const double c0 = b0 - fA0 * prB, c1 = b1 - fA1 * prB;
             const bool uA0 = used0 || lane == pA, uA1 = used1 || lane + 64 == pA;
             pick(c0, c1, uA0, uA1, pB, invB);
-            fb[128 + lane] = (lane == pB || lane >= n) ? 0.0 : c0 * invB;
-            fb[128 + lane + 64] = (lane + 64 == pB || lane + 64 >= n) ? 0.0 : c1 * invB;
+            if (lane < NP) fb[NP + lane] = (lane == pB || lane >= n) ? 0.0 : c0 * invB;
+            if (lane + 64 < NP) fb[NP + lane + 64] = (lane + 64 == pB || lane + 64 >= n) ? 0.0 : c1 * invB;
           }
           if (lane == 0) {
             pbuf[2 * pb] = pA; perm[col] = pA; iperm[pA] = col; dinv[col] = invA;
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
         for (int q = 0; q < 2; ++q) {
           if (q == 1 && !two) break;
           const int p = __builtin_amdgcn_readfirstlane(pbuf[2 * pb + q]);
-          const double f0 = fb[128 * q + lane], f1 = fb[128 * q + lane + 64];
+          const double f0 = (lane < NP) ? fb[NP * q + lane] : 0.0, f1 = (lane + 64 < NP) ? fb[NP * q + lane + 64] : 0.0;
           if (lane == (p & 63)) { if (p >> 6) used1 = true; else used0 = true; }
           if (p < 64) {
 #pragma unroll
