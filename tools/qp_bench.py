@@ -53,3 +53,21 @@ for model, q0, B in ((reduced, qr, 1), (reduced, qr, 64), (reduced, qr, 256), (c
     err = max(np.max(np.abs(dev[k][i] - host[i][k])) for i in range(B) for k in range(3))
     print("IDSolver_ulim nv=%d batch %4d: device assembly + solve %.3f ms per call (%.0f QPs/s) ; host: rigid-body terms in numpy %.1f ms + assembly, upload, solve %.1f ms ; "
           "max difference of (a, f, tau) %.1e" % (model.nv, B, t_dev * 1e3, B / t_dev, t_terms * 1e3, t_host * 1e3, err))
+
+# ---- the IKIDSolver_f6 mirror: the IK + ID QP assembled on the device (mpc_qp_solve_ikid) against host assembly ----
+from tests.test_qp_utils import _ikid_case, _ikid_solver
+for model, q0, B in ((reduced, qr, 64), (reduced, qr, 256), (complete, qc, 256)):
+    rows = _ikid_case(model, q0, np.random.default_rng(4), B)
+    solver = _ikid_solver(model, _capi.load_hip_library(), B)
+    solver.qp.settings.eps_abs, solver.qp.settings.max_iter, solver.qp.settings.max_iter_in = 1e-3, 100, 100  # QP_utils.py:652-657
+    stack = lambda k: np.array([r[k] for r in rows])
+    args = (stack("x"), stack("q_diff"), stack("dq_diff"), stack("LF"), stack("dLF"), stack("RF"), stack("dRF"), stack("base"), stack("dbase"), stack("torso"), stack("dtorso"),
+            stack("forces"), stack("dH"), np.array([r["cs"] for r in rows], dtype=np.int32))
+    for _ in range(3):
+        solver.solve_batch_device(*args)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        solver.solve_batch_device(*args)
+    t_dev = (time.perf_counter() - t0) / 10
+    print("IKIDSolver_f6 nv=%d batch %4d: device assembly + solve %.3f ms per call (%.0f QPs/s), solved %d/%d, Newton steps per QP mean %.1f" % (
+        model.nv, B, t_dev * 1e3, B / t_dev, sum(i.status == 0 for i in solver.last_info), B, np.mean([i.iters_in for i in solver.last_info])))
