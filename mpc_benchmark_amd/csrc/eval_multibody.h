@@ -65,6 +65,28 @@ DEV G36 ldg36(const double* A, int ld, int i) { G36 r; for (int e = 0; e < 36; +
 // lane ids pass through an empty asm at every phase boundary: index arithmetic stays phase-local instead of being
 // kept live (and spilled) across the whole kernel — see RIC_LAUNDER in riccati_mfma.h
 #define EV_LAUNDER() do { asm volatile("" : "+v"(tid)); lane = tid & 63; wv = __builtin_amdgcn_readfirstlane(tid >> 6); } while (0)
+// sum of f(j) over the set bits j of `mm` in ascending order, four operands requested per round (the plain loop — find a bit, load, add,
+// next bit — waits for one LDS round trip per term: 33 of them for the root's subtree sums).  Same additions in the same order.
+template <class F> DEV double mask_sum(unsigned long long mm, F&& f, double s = 0.0) {
+  while (mm) {
+    const int j0 = __builtin_ctzll(mm); mm &= mm - 1;
+    const bool h1 = mm != 0; const int j1 = h1 ? __builtin_ctzll(mm) : j0; mm &= mm - 1;
+    const bool h2 = mm != 0; const int j2 = h2 ? __builtin_ctzll(mm) : j0; mm &= mm - 1;
+    const bool h3 = mm != 0; const int j3 = h3 ? __builtin_ctzll(mm) : j0; mm &= mm - 1;
+    const double a0 = f(j0), a1 = f(j1), a2 = f(j2), a3 = f(j3);
+    s += a0;
+    if (h1) s += a1;
+    if (h2) s += a2;
+    if (h3) s += a3;
+  }
+  return s;
+}
+#define MB_AB_U 8  // loads of d a in flight per thread while [A B] is written
+#ifdef EV_SUBPROF
+#define EV_SUB(slot) EV_PROF(slot)  // developer builds: sub-phases of the one-wavefront solve (tools/phase_timers.py)
+#else
+#define EV_SUB(slot) do {} while (0)
+#endif
 #define EV_PROF(slot) do { EV_LAUNDER(); if (TRIAL == 0 && tid == 0 && a.prof && k == 1) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + 32 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 #ifndef EVAL_MIN_WAVES
@@ -170,6 +192,8 @@ cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of th
   double *x = sm + S.x, *u = sm + S.u, *xn = sm + S.xn, *cfr = sm + S.cfr, *small = sm + S.small, *red = sm + S.red;
   double* early = sm + S.early;  // [0,nz) gradient | [nz,2nz) diag(H) | [2nz,2nz+36) base block | [2nz+36, +24) per-term cost | [2nz+60] done flag
   __shared__ int iflag[2];
+  __shared__ int ccid_s[2];
+  __shared__ int cbody_s[2];  // contact models of the stage and their bodies (two dependent global loads where they were looked up in the loops)
   __shared__ double s_cost;
   // Jacobian staging in LDS, in the region that is dead once the dynamics derivatives are out (Yc, then the factor of M):
   // JS = stacked rows sqrt(W) J of the cost terms (<= 32 rows) ; JL = rows of the constraint term being emitted — the constraints are
@@ -221,14 +245,18 @@ cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of th
       anc[i] = gmask[i]; sub[i] = gmask[nj + i]; dmask[i] = gmask[2 * nj + i];
       const int ndof = (mj[4 * i + 1] == MPC_JOINT_FREEFLYER) ? 6 : 1;
       for (int d = 0; d < ndof; ++d) dof_body[mj[4 * i + 3] + d] = i;
-      unsigned long long bm = 0;
-      for (unsigned long long mm = gmask[nj + i] & ~(1ull << i); mm; mm &= mm - 1) {
-        const int j = __builtin_ctzll(mm);
-        bm |= ((mj[4 * j + 1] == MPC_JOINT_FREEFLYER) ? 63ull : 1ull) << mj[4 * j + 3];
-      }
-      below[i] = bm;
+      below[i] = gmask[3 * nj + i];
     }
     if (tid == 0) s_cost = 0.0;
+    if (has_dyn && tid < nk) { const int cid = desc[2 + tid]; ccid_s[tid] = cid; cbody_s[tid] = mcontact[cid]; }
+  }
+  // model constants of body `tid`, requested here: their round trip to L2 overlaps the loads above and the barrier
+  // (the kernels with derivatives only: the value-only candidates are short of registers right here)
+  constexpr bool JD_PREFETCH = (TRIAL == 0 || TRIAL == 3);
+  double jdl[12];
+  if (JD_PREFETCH && tid < nj) {
+#pragma unroll
+    for (int e = 0; e < 12; ++e) jdl[e] = jd[25 * tid + e];
   }
   __syncthreads();
   const double* q = x;
@@ -262,9 +290,12 @@ sim_loop:
   // ---- P1: local joint transforms (stored in the Bc region), then world placements ----------------------
   double* lR = Bc;
   double* lp = Bc + 9 * nj;
-  for (int i = tid; i < nj; i += nthr) {
-    const M3 Rp = ldm3(jd + 25 * i);
-    const V3 pp = ldv3(jd + 25 * i + 9);
+  if (tid < nj) {  // (nj <= 64: check_multibody_model)
+    const int i = tid;
+    M3 Rp;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Rp.m[e] = JD_PREFETCH ? jdl[e] : jd[25 * i + e];
+    const V3 pp = JD_PREFETCH ? v3(jdl[9], jdl[10], jdl[11]) : ldv3(jd + 25 * i + 9);
     M3 Rj;
     V3 pj = v3(0, 0, 0);
     if (jkind[i] == MPC_JOINT_FREEFLYER) { Rj = quat_to_rot(q + 3); pj = v3(q[0], q[1], q[2]); }
@@ -278,6 +309,11 @@ sim_loop:
     const V3 pl = mul(Rp, pj) + pp;
     for (int e = 0; e < 9; ++e) lR[e * nj + i] = Rl.m[e];
     lp[i] = pl.x; lp[nj + i] = pl.y; lp[2 * nj + i] = pl.z;
+  }
+  double jdi[13];  // mass, centre of mass, inertia of body `tid` (P4): in flight across the placements
+  if (JD_PREFETCH && tid < nj) {
+#pragma unroll
+    for (int e = 0; e < 13; ++e) jdi[e] = jd[25 * tid + 12 + e];
   }
   __syncthreads();
   for (int i = tid; i < nj; i += nthr) {
@@ -311,13 +347,12 @@ sim_loop:
   // ---- P3: body velocities ------------------------------------------------------------------------------
   for (int idx = tid; idx < 6 * nj; idx += nthr) {
     const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-    double s = 0;
-    for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); s += J[e * nv + kd] * v[kd]; }
-    ov[idx] = s;
+    ov[idx] = mask_sum(dmask[i], [&](int kd) { return J[e * nv + kd] * v[kd]; });
   }
   __syncthreads();
   // ---- P4: bias accelerations (gravity field), spatial inertias (packed symmetric), momenta ---------------
-  for (int i = tid; i < nj; i += nthr) {
+  if (tid < nj) {
+    const int i = tid;
     S6 ai = a0;
     for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) {
       const int kd = __builtin_ctzll(mm);
@@ -325,9 +360,12 @@ sim_loop:
     }
     stc6(oa, nj, i, ai);
     const M3 R = ldcm3(oR, nj, i);
-    const double mass = jd[25 * i + 12];
-    const V3 cw = mul(R, ldv3(jd + 25 * i + 13)) + ldcv3(op, nj, i);
-    const M3 RI = mul(R, ldm3(jd + 25 * i + 16));
+    const double mass = JD_PREFETCH ? jdi[0] : jd[25 * i + 12];
+    const V3 cw = mul(R, JD_PREFETCH ? v3(jdi[1], jdi[2], jdi[3]) : ldv3(jd + 25 * i + 13)) + ldcv3(op, nj, i);
+    M3 Ib;
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Ib.m[e] = JD_PREFETCH ? jdi[4 + e] : jd[25 * i + 16 + e];
+    const M3 RI = mul(R, Ib);
     M3 Iww;  // R I R^T
     for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Iww.m[3 * r + cc] = RI.m[3 * r] * R.m[3 * cc] + RI.m[3 * r + 1] * R.m[3 * cc + 1] + RI.m[3 * r + 2] * R.m[3 * cc + 2];
     const M3 Sx = skew_m(cw), S2 = mul(Sx, Sx);
@@ -348,24 +386,18 @@ sim_loop:
   // ---- P5: composite inertias / momenta, bias forces ----------------------------------------------------
   for (int idx = tid; idx < 21 * nj; idx += nthr) {
     const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-    double s = 0;
-    for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += oY[e * nj + j]; }
-    Yc[idx] = s;
+    Yc[idx] = mask_sum(sub[i], [&](int j) { return oY[e * nj + j]; });
   }
   for (int idx = tid; idx < 6 * nj; idx += nthr) {
     const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-    double s = 0;
-    for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += oh[e * nj + j]; }
-    Hc[idx] = s;
+    Hc[idx] = mask_sum(sub[i], [&](int j) { return oh[e * nj + j]; });
   }
   for (int i = tid; i < nj; i += nthr)
     stc6(of, nj, i, add6(sym_mul(ldy21(oY, nj, i), ldc6(oa, nj, i)), fcross(ldc6(ov, nj, i), ldc6(oh, nj, i))));
   __syncthreads();
   for (int idx = tid; idx < 6 * nj; idx += nthr) {
     const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-    double s = 0;
-    for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += of[e * nj + j]; }
-    Fc[idx] = s;
+    Fc[idx] = mask_sum(sub[i], [&](int j) { return of[e * nj + j]; });
   }
   for (int kd = tid; kd < nv; kd += nthr) stc6(U, nv, kd, sym_mul(ldy21(Yc, nj, dof_body[kd]), ldc6(J, nv, kd)));
   // total mass and centre of mass from the composite inertia of the root (Yc is recycled before the terms read them)
@@ -403,9 +435,7 @@ sim_loop:
       __syncthreads();
       for (int idx = tid; idx < 36 * nj; idx += nthr) {
         const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-        double s = 0;
-        for (unsigned long long mm = sub[i]; mm; mm &= mm - 1) { const int j = __builtin_ctzll(mm); s += oY[e * nj + j]; }
-        Bc[idx] = s;
+        Bc[idx] = mask_sum(sub[i], [&](int j) { return oY[e * nj + j]; });
       }
       __syncthreads();
       for (int kd = tid; kd < nv; kd += nthr) {
@@ -604,7 +634,7 @@ sim_loop:
     }
     for (int kd = tid; kd < nv; kd += nthr) bias[kd] = dot6(ldc6(J, nv, kd), ldc6(Fc, nj, dof_body[kd]));
     if (tid < nk) {
-      const int cid = desc[2 + tid], i = mcontact[cid];
+      const int cid = ccid_s[tid], i = cbody_s[tid];
       const double* cm = cd + MPC_MODEL_CONTACT_DOUBLES * cid;
       const M3 Ri = ldcm3(oR, nj, i);
       const M3 Rc = mul(Ri, ldm3(cm));
@@ -630,7 +660,7 @@ sim_loop:
       if (l < nv) {
         if (j < nl) {
           const int cc = j / 6;
-          if (BELOW(l, mcontact[desc[2 + cc]])) s = adinv(ldm3(cfr + 54 * cc), ldv3(cfr + 54 * cc + 9), ldc6(J, nv, l)).v[j - 6 * cc];
+          if (BELOW(l, cbody_s[cc])) s = adinv(ldm3(cfr + 54 * cc), ldv3(cfr + 54 * cc + 9), ldc6(J, nv, l)).v[j - 6 * cc];
         } else if (j == 12) {
           s = -bias[l] + (l >= nv - nu ? u[l - (nv - nu)] : 0.0);
           // disturbance of the simulation stand-in: a world-frame force f at the base origin acts on the linear base dofs only
@@ -648,7 +678,9 @@ sim_loop:
     if (wv == 0) {
       if (!chol_tiles_wave(Mt, nbm, lane)) { if (lane == 0) iflag[0] = 0; }
       else {
+        EV_SUB(3);
         trsm_fwd_tiles(Mt, nbm, Y16, MB_LDY, 1, 0, 1, lane);
+        EV_SUB(4);
         d4_t g = d4_t{0, 0, 0, 0};
         mma_tile<false>(g, Y16, 1, MB_LDY, Y16, MB_LDY, 1, nvp, lane);  // [Y w]^T [Y w]
         const int col = lane & 15;
@@ -661,6 +693,7 @@ sim_loop:
           if (col == 12 && row < nl) small[row] = g[qq] + gam[row];  // t = Y^T w - r2,  r2 = -gamma
         }
         if (!chol16_wave(Sp, 17, LIs, lane) && lane == 0) iflag[1] = 0;
+        EV_SUB(16);
         // z2 = Ls^-T Ls^-1 t ; lambda = -z2
         if (lane < 16) {
           double y = 0;
@@ -673,15 +706,19 @@ sim_loop:
           small[32 + lane] = z;
           if (lane < nl) lam[lane] = -z;
         }
+        EV_SUB(17);
         // V16 column 0 = w - Y z2, then accelerations = L^-T (.)
-        for (int idx = lane; idx < nvp * 16; idx += 64) {
-          const int l = idx >> 4, j = idx & 15;
-          double s = 0.0;
-          if (j == 0) { s = Y16[l * MB_LDY + 12]; for (int i = 0; i < nl; ++i) s -= Y16[l * MB_LDY + i] * small[32 + i]; }
-          V16[idx] = s;
+        // (a lane per ROW: with a lane per entry only the four lanes of column 0 worked, twelve rounds of a dependent nl-term sum)
+        for (int idx = lane; idx < nvp * 16; idx += 64) if (idx & 15) V16[idx] = 0.0;
+        for (int l = lane; l < nvp; l += 64) {
+          double s = Y16[l * MB_LDY + 12];
+          for (int i = 0; i < nl; ++i) s -= Y16[l * MB_LDY + i] * small[32 + i];
+          V16[l * 16] = s;
         }
+        EV_SUB(18);
         trsm_bwd_tiles(Mt, nbm, V16, 16, 1, 0, 1, lane);
         for (int i = lane; i < nvp; i += 64) { acc[i] = V16[i * 16]; Y16[i * MB_LDY + 12] = 0.0; }  // from here on Y16 = Y (zero padded)
+        EV_SUB(19);
       }
     } else { se3_prepass(1); selector_rows(1); early_costs(1); if (wv == nw - 1 && lane == 0) classify_terms(); }
     __syncthreads();
@@ -691,7 +728,7 @@ sim_loop:
       for (int i = tid; i < n; i += nthr) kn[KL.oXD + i] = (i < nv) ? v[i] : acc[i - nv];
       for (int i = tid; i < 12; i += nthr) {
         double wr = 0.0;
-        for (int cc = 0; cc < nk; ++cc) if (desc[2 + cc] == i / 6) wr = lam[6 * cc + i % 6];
+        for (int cc = 0; cc < nk; ++cc) if (ccid_s[cc] == i / 6) wr = lam[6 * cc + i % 6];
         kn[KL.oWR + i] = wr;
       }
       // world-frame wrench of every contact (at the origin), for the forces at the solution
@@ -781,9 +818,7 @@ sim_loop:
     double* da = Tq;  // scratch [6][nj] (Tq is formed afterwards)
     for (int idx = tid; idx < 6 * nj; idx += nthr) {
       const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-      double s = 0;
-      for (unsigned long long mm = dmask[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); s += J[e * nv + kd] * acc[kd]; }
-      da[idx] = s;
+      da[idx] = mask_sum(dmask[i], [&](int kd) { return J[e * nv + kd] * acc[kd]; });
     }
     __syncthreads();
     for (int idx = tid; idx < 6 * nj; idx += nthr) {
@@ -791,8 +826,8 @@ sim_loop:
       double s = Fc[idx];
 #pragma unroll
       for (int bb = 0; bb < 6; ++bb) s += Yc[sym6(e, bb) * nj + i] * da[bb * nj + i];
-      for (unsigned long long mm = below[i]; mm; mm &= mm - 1) { const int kd = __builtin_ctzll(mm); s += U[e * nv + kd] * acc[kd]; }
-      for (int cc = 0; cc < nk; ++cc) if ((anc[mcontact[desc[2 + cc]]] >> i) & 1ull) s -= cfr[54 * cc + 48 + e];
+      s = mask_sum(below[i], [&](int kd) { return U[e * nv + kd] * acc[kd]; }, s);
+      for (int cc = 0; cc < nk; ++cc) if ((anc[cbody_s[cc]] >> i) & 1ull) s -= cfr[54 * cc + 48 + e];
       Fc[idx] = s;
       oa[idx] += da[idx];
     }
@@ -852,13 +887,22 @@ sim_loop:
     EV_PROF(8);
     if (has_dyn) {
       // ---- P10: contact rows R2 = d r2 / d(q, v) into DL (zero padded ; d r2 / du = 0) -------------------------------------
+      // (nk nv <= 2 x 64 entries: one per thread ; its contact's gains are requested before the zero fill and the barrier)
+      int c10_body = 0;
+      double cm10[12];
+      if (tid < nk * nv) {
+        const int cid = ccid_s[qdiv(tid, S.mg_nv)];
+        c10_body = cbody_s[qdiv(tid, S.mg_nv)];
+#pragma unroll
+        for (int r = 0; r < 12; ++r) cm10[r] = cd[MPC_MODEL_CONTACT_DOUBLES * cid + 24 + r];
+      }
       for (int idx = tid; idx < 12 * ldl; idx += nthr) DL[idx] = 0.0;
       __syncthreads();
-      for (int idx = tid; idx < nk * nv; idx += nthr) {
+      if (tid < nk * nv) {
+        const int idx = tid;
         const int cc = qdiv(idx, S.mg_nv), j = (idx - qdiv(idx, S.mg_nv) * nv);
-        const int cid = desc[2 + cc], i = mcontact[cid];
-        if (!BELOW(j, i)) continue;
-        const double* cm = cd + MPC_MODEL_CONTACT_DOUBLES * cid;
+        const int i = c10_body;
+        if (BELOW(j, i)) {
         const M3 Rc = ldm3(cfr + 54 * cc);
         const V3 pc = ldv3(cfr + 54 * cc + 9);
         const int pb = parent[dof_body[j]];
@@ -871,9 +915,11 @@ sim_loop:
         const S6 apsd = adinv(Rc, pc, psd);
         const S6 Jcj = adinv(Rc, pc, Jj);
         const S6 jl = mat6_mul(cfr + 54 * cc + 12, Jcj);
+#pragma unroll
         for (int r = 0; r < 6; ++r) {
-          DL[(6 * cc + r) * ldl + j] = dacq.v[r] + cm[30 + r] * apsd.v[r] + cm[24 + r] * jl.v[r];
-          DL[(6 * cc + r) * ldl + nv + j] = dacv.v[r] + cm[30 + r] * Jcj.v[r];
+          DL[(6 * cc + r) * ldl + j] = dacq.v[r] + cm10[6 + r] * apsd.v[r] + cm10[r] * jl.v[r];
+          DL[(6 * cc + r) * ldl + nv + j] = dacv.v[r] + cm10[6 + r] * Jcj.v[r];
+        }
         }
       }
       __syncthreads();
@@ -986,18 +1032,35 @@ sim_loop:
         kn[KL.oD12 + tid] = s;
       } else if (tid == 72) { kn[KL.oD12 + 72] = dt; kn[KL.oD12 + 73] = 1.0; }
       // dvp = dt * da + [0 I 0];  rows nv..n of AB = dvp; rows 6..nv = dt dvp + [I 0 0]
-      for (int idx = tid; idx < nv * nz; idx += nthr) {
-        const int r = qdiv(idx, mg_nz), z = (idx - qdiv(idx, mg_nz) * nz);
-        const double dvp = dt * dsol[(size_t)r * L.nz + z] + ((z == nv + r) ? 1.0 : 0.0);
-        kn[KL.oAB + (size_t)(nv + r) * KL.nz + z] = dvp;
-        if (r >= 6) kn[KL.oAB + (size_t)r * KL.nz + z] = dt * dvp + ((z == r) ? 1.0 : 0.0);
+      // (d a comes back from the HBM scratch: MB_AB_U loads are requested before the first store — a load per iteration, ordered behind
+      // the stores of the one before, costs a round trip to L2 every time: 16 of them for nv = 38)
+      for (int base = tid; base < nv * nz; base += nthr * MB_AB_U) {
+        double dav[MB_AB_U];
+#pragma unroll
+        for (int uu = 0; uu < MB_AB_U; ++uu) {
+          const int idx = base + uu * nthr, r = qdiv(idx, mg_nz), z = idx - r * nz;
+          dav[uu] = (idx < nv * nz) ? dsol[(size_t)r * L.nz + z] : 0.0;
+        }
+#pragma unroll
+        for (int uu = 0; uu < MB_AB_U; ++uu) {
+          const int idx = base + uu * nthr, r = qdiv(idx, mg_nz), z = idx - r * nz;
+          if (idx < nv * nz) {
+            const double dvp = dt * dav[uu] + ((z == nv + r) ? 1.0 : 0.0);
+            kn[KL.oAB + (size_t)(nv + r) * KL.nz + z] = dvp;
+            if (r >= 6) kn[KL.oAB + (size_t)r * KL.nz + z] = dt * dvp + ((z == r) ? 1.0 : 0.0);
+          }
+        }
       }
-      __syncthreads();
+      __syncthreads();  // (D12)
       // base rows: D1_b [I 0 0] + Dd_b dvp[0:6]
       for (int idx = tid; idx < 6 * nz; idx += nthr) {
         const int r = qdiv(idx, mg_nz), z = (idx - qdiv(idx, mg_nz) * nz);
+        double dl6[6];
+#pragma unroll
+        for (int l = 0; l < 6; ++l) dl6[l] = dsol[(size_t)l * L.nz + z];
         double s = (z < 6) ? D12[6 * r + z] : 0.0;
-        for (int l = 0; l < 6; ++l) s += D12[36 + 6 * r + l] * (dt * dsol[(size_t)l * L.nz + z] + ((z == nv + l) ? 1.0 : 0.0));
+#pragma unroll
+        for (int l = 0; l < 6; ++l) s += D12[36 + 6 * r + l] * (dt * dl6[l] + ((z == nv + l) ? 1.0 : 0.0));
         kn[KL.oAB + (size_t)r * KL.nz + z] = s;
       }
       __syncthreads();
@@ -1223,6 +1286,16 @@ sim_loop:
         if (derivs) for (int i = wv; i < d; i += nw) for (int z = lane; z < nz; z += 64) kn[KL.oCD + (size_t)(row + i) * KL.nz + z] = (z == zc0 + i) ? sgn : 0.0;
       } else if (tr.type == MPC_TERM_MB_WRENCH_CONE) {
         // rows of the cone matrix times lambda / d lambda, straight into the record (no staging, no barrier): a row per wavefront
+        // (the cone rows of ALL the rows of this wavefront are requested first: a row's six parameters loaded when its turn comes
+        // cost a round trip to L2 per row, 2.5 us per contact)
+        constexpr int CONE_RPW = (MB_STAGE_CONSTRAINT_ROWS + EVAL_THREADS / 64 - 1) / (EVAL_THREADS / 64);
+        double cwr[CONE_RPW][6];
+#pragma unroll
+        for (int qr = 0; qr < CONE_RPW; ++qr) {
+          const int i = wv + qr * nw;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) cwr[qr][j] = (derivs && i < d) ? tp[i * 6 + j] : 0.0;
+        }
         for (int i = tid; i < d; i += nthr) {
           double sres = 0;
           for (int j = 0; j < 6; ++j) sres += tp[i * 6 + j] * lam[6 * tr.i0 + j];
@@ -1231,13 +1304,25 @@ sim_loop:
           kn[KL.oLO + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + i] : 0.0;
           kn[KL.oHI + row + i] = (tr.role == MPC_ROLE_BOX) ? P[tr.woff + d + i] : 0.0;
         }
-        if (derivs) for (int i = wv; i < d; i += nw) {
-          double cw[6];
-          for (int j = 0; j < 6; ++j) cw[j] = tp[i * 6 + j];
-          for (int z = lane; z < nz; z += 64) {
-            double sres = 0;
-            for (int j = 0; j < 6; ++j) sres += cw[j] * DL[(6 * tr.i0 + j) * ldl + z];
-            kn[KL.oCD + (size_t)(row + i) * KL.nz + z] = sres;
+        if (derivs) {
+#pragma unroll
+          for (int qr = 0; qr < CONE_RPW; ++qr) {
+            const int i = wv + qr * nw;
+            if (i < d) for (int z = lane; z < nz; z += 64) {
+              double sres = 0;
+#pragma unroll
+              for (int j = 0; j < 6; ++j) sres += cwr[qr][j] * DL[(6 * tr.i0 + j) * ldl + z];
+              kn[KL.oCD + (size_t)(row + i) * KL.nz + z] = sres;
+            }
+          }
+          for (int i = wv + CONE_RPW * nw; i < d; i += nw) {  // (more rows than a cone has: not reached)
+            double cw[6];
+            for (int j = 0; j < 6; ++j) cw[j] = tp[i * 6 + j];
+            for (int z = lane; z < nz; z += 64) {
+              double sres = 0;
+              for (int j = 0; j < 6; ++j) sres += cw[j] * DL[(6 * tr.i0 + j) * ldl + z];
+              kn[KL.oCD + (size_t)(row + i) * KL.nz + z] = sres;
+            }
           }
         }
       } else {
@@ -1265,14 +1350,22 @@ sim_loop:
       term_rows(tr, P + tr.poff, se3 + 48 * tse3[t], r, Jt, lane, 64, false);
       const double* W = P + tr.woff;
       const int wstride = (tr.flags & MPC_TERM_FLAG_DIAG_WEIGHT) ? 1 : d + 1;
+      const double wl = (lane < d) ? W[lane * wstride] : 0.0;  // d <= 24: the weight of row `lane`
       {
-        double cst = (lane < d) ? W[lane * wstride] * r[lane] * r[lane] : 0.0;  // d <= 24
+        double cst = (lane < d) ? wl * r[lane] * r[lane] : 0.0;
         cst = wave_sum(cst);
         if (lane == 0) tcost[t] = 0.5 * cst;
       }
       if (derivs) {
-        if (lane < d) wrs[trow[t] + lane] = sqrt(W[lane * wstride]) * r[lane];
-        for (int idx = lane; idx < d * nz; idx += 64) { const int i = qdiv(idx, mg_nz), z = idx - i * nz; Jt[i * ldj + z] *= sqrt(W[i * wstride]); }
+        // sqrt(W) once per row, handed to the entries of the row through the lanes (a load of W and a square root per ENTRY was a
+        // round trip to L2 in each of the d nz / 64 rounds)
+        const double swl = sqrt(wl);
+        if (lane < d) wrs[trow[t] + lane] = swl * r[lane];
+        for (int idx = lane; idx < ((d * nz + 63) & ~63); idx += 64) {
+          const int i = qdiv(idx, mg_nz), z = idx - i * nz;
+          const double sw = __shfl(swl, i < d ? i : 0);
+          if (idx < d * nz) Jt[i * ldj + z] *= sw;
+        }
       }
     }
     EV_PROF(28);

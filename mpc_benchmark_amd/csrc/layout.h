@@ -8,7 +8,7 @@
 struct Layout {
   int N, B, space, nx, n, m, c, nz;
   int nj;  // moving joints of the multibody model (0 for vector spaces)
-  int model_mask_off;  // int32 offset of the 64-bit tree masks (ancestors | subtree | path dofs, nj each) in the device model table
+  int model_mask_off;  // int32 offset of the 64-bit tree masks (ancestors | subtree | path dofs | dofs strictly below, nj each) in the device model table
   // offsets inside one knot record (doubles)
   int oH, oG, oAB, oF, oE6, oD12, oCV, oCD, oLO, oHI, oDT, oACT, oCT, oMISC, oXD, oWR, oXN, knot_stride;
   // offsets inside one gain record

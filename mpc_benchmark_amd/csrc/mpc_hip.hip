@@ -812,7 +812,7 @@ int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double*
     std::vector<int32_t> ext(itab, itab + n_i);
     if (s->dims.space == MPC_SPACE_MULTIBODY) {
       const int32_t* mj = itab + MPC_MODEL_HEADER_WORDS;
-      std::vector<unsigned long long> anc(nj, 0ull), sub(nj, 0ull), dm(nj, 0ull);
+      std::vector<unsigned long long> anc(nj, 0ull), sub(nj, 0ull), dm(nj, 0ull), below(nj, 0ull);
       std::vector<int> dof_body(nvm, 0);
       for (int i = 0; i < nj; ++i) {
         for (int j = i; j >= 0; j = mj[4 * j]) anc[i] |= 1ull << j;
@@ -822,10 +822,12 @@ int mpc_set_model(mpc_solver* s, const int32_t* itab, int32_t n_i, const double*
       for (int i = 0; i < nj; ++i) {
         for (int j = i; j < nj; ++j) if ((anc[j] >> i) & 1ull) sub[i] |= 1ull << j;
         for (int kd = 0; kd < nvm; ++kd) if ((anc[i] >> dof_body[kd]) & 1ull) dm[i] |= 1ull << kd;
+        for (int j = i + 1; j < nj; ++j)  // dofs of the joints strictly inside the subtree of i
+          if ((sub[i] >> j) & 1ull) below[i] |= ((mj[4 * j + 1] == MPC_JOINT_FREEFLYER) ? 63ull : 1ull) << mj[4 * j + 3];
       }
       if (ext.size() & 1) ext.push_back(0);  // 8-byte alignment of the mask block
       s->L.model_mask_off = (int)ext.size();
-      for (const auto* v : {&anc, &sub, &dm})
+      for (const auto* v : {&anc, &sub, &dm, &below})
         for (int i = 0; i < nj; ++i) { ext.push_back((int32_t)((*v)[i] & 0xffffffffull)); ext.push_back((int32_t)((*v)[i] >> 32)); }
     }
     // a model may be set again (a new contact frame lowered later): the old tables are released, not leaked until destroy

@@ -53,6 +53,9 @@ for i, name in ev.items():
 for t, name in terms.items():
     if e[13 + t] > 0:
         print('EVAL term %-35s %7.1f us %5.1f%%' % (name, e[13 + t] / TICKS / (GHZ * 1e3), 100 * e[13 + t] / etot))
+if os.environ.get("PHASE_SUB"):  # a build with -DEV_SUBPROF: the one-wavefront solve in pieces (slots of terms this problem does not have)
+    for i, name in ((3, 'sub: chol M'), (4, 'sub: Y = L^-1 [Jc^T | r1]'), (16, 'sub: S = Y^T Y, chol S'), (17, 'sub: multipliers'), (18, 'sub: V16 build'), (19, 'sub: accelerations')):
+        print('EVAL %-40s %7.1f us' % (name, e[i] / TICKS / (GHZ * 1e3)))
 print('EVAL %-40s %7.1f us %5.1f%%' % ('stacked cost terms (one per wavefront)', e[28] / TICKS / (GHZ * 1e3), 100 * e[28] / etot))
 print('EVAL %-40s %7.1f us %5.1f%%' % ('Gauss-Newton Hessian flush (MFMA)', e[27] / TICKS / (GHZ * 1e3), 100 * e[27] / etot))
 print('EVAL total %.1f us per workgroup (knot 1 of instance 0)' % (etot / TICKS / (GHZ * 1e3)))
