@@ -9,6 +9,7 @@
 // no further dependency on the tree (DESIGN.md §"Whole-body stage kernel" derives the formulas; they are
 // cross-checked against the AD-based oracle through tests/proto_multibody.py and the GPU parity tests).
 #pragma once
+#include <type_traits>
 #include "eval_common.h"
 #include "mfma_blocks.h"
 #include "eval_multibody_host.h"
@@ -253,6 +254,7 @@ cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of th
   // model constants of body `tid`, requested here: their round trip to L2 overlaps the loads above and the barrier
   // (the kernels with derivatives only: the value-only candidates are short of registers right here)
   constexpr bool JD_PREFETCH = (TRIAL == 0 || TRIAL == 3);
+  const int wv_inertia = nw > 2 ? 2 : 0;  // wavefront that builds the bodies' spatial inertias in P4 (wavefront 0: bias accelerations, 1: contact frames)
   double jdl[12];
   if (JD_PREFETCH && tid < nj) {
 #pragma unroll
@@ -311,9 +313,9 @@ sim_loop:
     lp[i] = pl.x; lp[nj + i] = pl.y; lp[2 * nj + i] = pl.z;
   }
   double jdi[13];  // mass, centre of mass, inertia of body `tid` (P4): in flight across the placements
-  if (JD_PREFETCH && tid < nj) {
+  if (JD_PREFETCH && wv == wv_inertia && lane < nj) {
 #pragma unroll
-    for (int e = 0; e < 13; ++e) jdi[e] = jd[25 * tid + 12 + e];
+    for (int e = 0; e < 13; ++e) jdi[e] = jd[25 * lane + 12 + e];
   }
   __syncthreads();
   for (int i = tid; i < nj; i += nthr) {
@@ -350,6 +352,25 @@ sim_loop:
     ov[idx] = mask_sum(dmask[i], [&](int kd) { return J[e * nv + kd] * v[kd]; });
   }
   __syncthreads();
+  // Contact frames (world placement, placement error of the Baumgarte term, Jlog6): single-lane SE(3) work that needs the placements
+  // only — lane cc of wavefront 1 does it here, beside the bodies' inertias on wavefront 0 (after the factor's inputs it sat on the
+  // critical path: every other thread waited at the barrier).  The error e6 is parked in gam until the M-tiles phase completes gamma.
+  if (has_dyn && wv == 1 && lane < nk) {
+    const int cc = lane, cid = ccid_s[cc], i = cbody_s[cc];
+    const double* cm = cd + MPC_MODEL_CONTACT_DOUBLES * cid;
+    const M3 Ri = ldcm3(oR, nj, i);
+    const M3 Rc = mul(Ri, ldm3(cm));
+    const V3 pc = mul(Ri, ldv3(cm + 9)) + ldcv3(op, nj, i);
+    double* cf = cfr + 54 * cc;
+    for (int e = 0; e < 9; ++e) cf[e] = Rc.m[e];
+    cf[9] = pc.x; cf[10] = pc.y; cf[11] = pc.z;
+    const M3 R2 = ldm3(cm + 12);
+    const V3 p2 = ldv3(cm + 21);
+    V3 ev, ew;
+    log6(tmul(Rc, R2), tmul(Rc, p2 - pc), ev, ew);
+    gam[6 * cc] = ev.x; gam[6 * cc + 1] = ev.y; gam[6 * cc + 2] = ev.z; gam[6 * cc + 3] = ew.x; gam[6 * cc + 4] = ew.y; gam[6 * cc + 5] = ew.z;
+    if (derivs) Jlog6(tmul(R2, Rc), tmul(R2, pc - p2), cf + 12);  // Jlog6(c2Mc1)
+  }
   // ---- P4: bias accelerations (gravity field), spatial inertias (packed symmetric), momenta ---------------
   if (tid < nj) {
     const int i = tid;
@@ -359,6 +380,9 @@ sim_loop:
       ai = add6(ai, scale6(v[kd], mcross(ldc6(ov, nj, dof_body[kd]), ldc6(J, nv, kd))));
     }
     stc6(oa, nj, i, ai);
+  }
+  if (wv == wv_inertia && lane < nj) {  // (its own wavefront: the chain above and the inertias side by side)
+    const int i = lane;
     const M3 R = ldcm3(oR, nj, i);
     const double mass = JD_PREFETCH ? jdi[0] : jd[25 * i + 12];
     const V3 cw = mul(R, JD_PREFETCH ? v3(jdi[1], jdi[2], jdi[3]) : ldv3(jd + 25 * i + 13)) + ldcv3(op, nj, i);
@@ -420,16 +444,33 @@ sim_loop:
       stc6(YcPsd, nv, kd, sym_mul(ldy21(Yc, nj, bk), psd));
     }
     if (has_dyn || kino) {
-      for (int i = tid; i < nj; i += nthr) {
+      // column `col` of B_i for body i = lane: the columns are dealt to the wavefronts (wavefront-uniform, so that the unit vector stays a
+      // compile-time constant and the products with it fold away) — one thread per body did the six columns one after the other, 3 us
+      // with a single wavefront at work.  Every thread reads its body's packed inertia before any column is written over it.
+      {
+        const bool bact = lane < nj;  // (nj <= 64: check_multibody_model)
+        const int i = bact ? lane : 0;
         const Y21 Yl = ldy21(oY, nj, i);
         const S6 vi = ldc6(ov, nj, i), hi = ldc6(oh, nj, i);
-#pragma unroll
-        for (int col = 0; col < 6; ++col) {
+        __syncthreads();
+        auto bcol = [&](auto colc) {
+          constexpr int col = decltype(colc)::value;
           S6 e6 = zero6();
           e6.v[col] = 1.0;
           const S6 r = add6(add6(sym_mul(Yl, mcross(e6, vi)), fcross(e6, hi)), fcross(vi, sym_mul(Yl, e6)));
 #pragma unroll
           for (int row = 0; row < 6; ++row) oY[(6 * row + col) * nj + i] = r.v[row];
+        };
+        for (int col = wv; col < 6; col += nw) {
+          if (!bact) continue;
+          switch (col) {
+            case 0: bcol(std::integral_constant<int, 0>{}); break;
+            case 1: bcol(std::integral_constant<int, 1>{}); break;
+            case 2: bcol(std::integral_constant<int, 2>{}); break;
+            case 3: bcol(std::integral_constant<int, 3>{}); break;
+            case 4: bcol(std::integral_constant<int, 4>{}); break;
+            default: bcol(std::integral_constant<int, 5>{}); break;
+          }
         }
       }
       __syncthreads();
@@ -634,23 +675,14 @@ sim_loop:
     }
     for (int kd = tid; kd < nv; kd += nthr) bias[kd] = dot6(ldc6(J, nv, kd), ldc6(Fc, nj, dof_body[kd]));
     if (tid < nk) {
+      // (the frame, its placement error and Jlog6 were left in cfr / gam by contact_frames(), beside P4)
       const int cid = ccid_s[tid], i = cbody_s[tid];
       const double* cm = cd + MPC_MODEL_CONTACT_DOUBLES * cid;
-      const M3 Ri = ldcm3(oR, nj, i);
-      const M3 Rc = mul(Ri, ldm3(cm));
-      const V3 pc = mul(Ri, ldv3(cm + 9)) + ldcv3(op, nj, i);
-      double* cf = cfr + 54 * tid;
-      for (int e = 0; e < 9; ++e) cf[e] = Rc.m[e];
-      cf[9] = pc.x; cf[10] = pc.y; cf[11] = pc.z;
-      const M3 R2 = ldm3(cm + 12);
-      const V3 p2 = ldv3(cm + 21);
-      V3 ev, ew;
-      log6(tmul(Rc, R2), tmul(Rc, p2 - pc), ev, ew);
-      const S6 e6 = mk6(ev, ew);
+      const M3 Rc = ldm3(cfr + 54 * tid);
+      const V3 pc = ldv3(cfr + 54 * tid + 9);
       const S6 acb = adinv(Rc, pc, sub6(ldc6(oa, nj, i), a0));
       const S6 vcb = adinv(Rc, pc, ldc6(ov, nj, i));
-      for (int r = 0; r < 6; ++r) gam[6 * tid + r] = acb.v[r] + cm[30 + r] * vcb.v[r] - cm[24 + r] * e6.v[r];
-      if (derivs) Jlog6(tmul(R2, Rc), tmul(R2, pc - p2), cf + 12);  // Jlog6(c2Mc1)
+      for (int r = 0; r < 6; ++r) gam[6 * tid + r] = acb.v[r] + cm[30 + r] * vcb.v[r] - cm[24 + r] * gam[6 * tid + r];
     }
     __syncthreads();
     // Y16 = [Jc^T | r1 | 0]  (nvp x 16): the contact columns (LOCAL frame: Ad(M_c)^-1 J) and the dynamics right-hand side r1 = B u - bias
@@ -811,6 +843,47 @@ sim_loop:
     }
   }
 
+  // single-lane SE(3) work of the integrator (P12): part 0 = step, gap, Jlog6(G) ; part 1 = Jexp6, Ad^-1, E6.  Depends on the accelerations
+  // only: on stages with contact dynamics it runs on the wavefront that has one column block less in P11 (7 blocks on 4 wavefronts),
+  // beside the implicit differentiation instead of after it.
+  const double dt_se3 = (has_dyn || kino) ? P[desc[4]] : 0.0;
+  auto step_se3 = [&](int part) {
+    const double dt = dt_se3;
+    double* Jl6 = small; double* Je6 = small + 36; double* Jq6 = small + 72;
+    const V3 dl = v3(dt * (v[0] + dt * acc[0]), dt * (v[1] + dt * acc[1]), dt * (v[2] + dt * acc[2]));
+    const V3 da_ = v3(dt * (v[3] + dt * acc[3]), dt * (v[4] + dt * acc[4]), dt * (v[5] + dt * acc[5]));
+    M3 dR; V3 dp;
+    exp6(dl, da_, dR, dp);
+    const M3 Rb = quat_to_rot(q + 3);
+    const M3 Rn = mul(Rb, dR);
+    const V3 pn = mul(Rb, dp) + v3(q[0], q[1], q[2]);
+    const M3 Rt = quat_to_rot(xn + 3);
+    const M3 GR = tmul(Rt, Rn);
+    const V3 Gp = tmul(Rt, pn - v3(xn[0], xn[1], xn[2]));
+    if (part == 0) {
+      if (derivs) { kn[KL.oXN] = pn.x; kn[KL.oXN + 1] = pn.y; kn[KL.oXN + 2] = pn.z; rot_to_quat(Rn, kn + KL.oXN + 3); }
+      V3 gv, gw;
+      log6(GR, Gp, gv, gw);
+      kn[KL.oF] = gv.x; kn[KL.oF + 1] = gv.y; kn[KL.oF + 2] = gv.z; kn[KL.oF + 3] = gw.x; kn[KL.oF + 4] = gw.y; kn[KL.oF + 5] = gw.z;
+      if (derivs) Jlog6(GR, Gp, Jl6);
+    } else {
+      Jexp6(dl, da_, Je6);
+      // Ad(exp6(delta))^-1 = [[dR^T, -dR^T [dp]x],[0, dR^T]]
+      const M3 Sx = skew_m(dp);
+      const M3 RtS = tmul(dR, Sx);
+      for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
+        Jq6[6 * r + cc] = dR.m[3 * cc + r]; Jq6[6 * (r + 3) + cc + 3] = dR.m[3 * cc + r];
+        Jq6[6 * r + cc + 3] = -RtS.m[3 * r + cc]; Jq6[6 * (r + 3) + cc] = 0.0;
+      }
+      // E6 = -Jlog6(G^-1)
+      double E[36];
+      M3 Gi;
+      for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Gi.m[3 * r + cc] = GR.m[3 * cc + r];
+      const V3 gip = mul(Gi, v3(-Gp.x, -Gp.y, -Gp.z));
+      Jlog6(Gi, gip, E);
+      for (int e = 0; e < 36; ++e) kn[KL.oE6 + e] = -E[e];
+    }
+  };
   // ---- P9: body accelerations and subtree forces AT THE SOLUTION (only the derivative blocks read them):
   //   da_i = sum_{k on the path to i} J_k acc_k ;  Fc_i += Yc_i da_i + sum_{k strictly below i} U_k acc_k - (wrenches of the contacts below i)
   // (sum over the subtree of Y_j da_j, regrouped by dof: the composite inertias and U = Yc J are at hand, the body inertias are not)
@@ -965,6 +1038,7 @@ sim_loop:
 #pragma unroll
         for (int qq = 0; qq < 3; ++qq) DL[(rq + 4 * qq) * ldl + 16 * cj + (lane & 15)] = t[qq];
       }
+      if (wv == nw - 1 && lane < 2) step_se3(lane);  // (P12's single-lane work, on the wavefront with the fewest column blocks)
       __syncthreads();
     }
   }
@@ -980,41 +1054,7 @@ sim_loop:
     double* D12 = small + 108;  // D1_b = Jlog6(G) Jq6 (36) | Dd_b = dt Jlog6(G) Jexp6 (36)   (layout.h, oD12)
     // The SE(3) pieces are single-lane work (log / exp maps and their Jacobians): spread them over the wavefronts
     // — wave 0: step, gap, Jlog6(G) ; wave 1: Jexp6, Ad^-1, E6 ; waves 2..: the SE(3)-valued cost / constraint terms
-    if (tid == 0 || (tid == 64 && derivs)) {
-      const V3 dl = v3(dt * (v[0] + dt * acc[0]), dt * (v[1] + dt * acc[1]), dt * (v[2] + dt * acc[2]));
-      const V3 da_ = v3(dt * (v[3] + dt * acc[3]), dt * (v[4] + dt * acc[4]), dt * (v[5] + dt * acc[5]));
-      M3 dR; V3 dp;
-      exp6(dl, da_, dR, dp);
-      const M3 Rb = quat_to_rot(q + 3);
-      const M3 Rn = mul(Rb, dR);
-      const V3 pn = mul(Rb, dp) + v3(q[0], q[1], q[2]);
-      const M3 Rt = quat_to_rot(xn + 3);
-      const M3 GR = tmul(Rt, Rn);
-      const V3 Gp = tmul(Rt, pn - v3(xn[0], xn[1], xn[2]));
-      if (tid == 0) {
-        if (derivs) { kn[KL.oXN] = pn.x; kn[KL.oXN + 1] = pn.y; kn[KL.oXN + 2] = pn.z; rot_to_quat(Rn, kn + KL.oXN + 3); }
-        V3 gv, gw;
-        log6(GR, Gp, gv, gw);
-        kn[KL.oF] = gv.x; kn[KL.oF + 1] = gv.y; kn[KL.oF + 2] = gv.z; kn[KL.oF + 3] = gw.x; kn[KL.oF + 4] = gw.y; kn[KL.oF + 5] = gw.z;
-        if (derivs) Jlog6(GR, Gp, Jl6);
-      } else {
-        Jexp6(dl, da_, Je6);
-        // Ad(exp6(delta))^-1 = [[dR^T, -dR^T [dp]x],[0, dR^T]]
-        const M3 Sx = skew_m(dp);
-        const M3 RtS = tmul(dR, Sx);
-        for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
-          Jq6[6 * r + cc] = dR.m[3 * cc + r]; Jq6[6 * (r + 3) + cc + 3] = dR.m[3 * cc + r];
-          Jq6[6 * r + cc + 3] = -RtS.m[3 * r + cc]; Jq6[6 * (r + 3) + cc] = 0.0;
-        }
-        // E6 = -Jlog6(G^-1)
-        double E[36];
-        M3 Gi;
-        for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Gi.m[3 * r + cc] = GR.m[3 * cc + r];
-        const V3 gip = mul(Gi, v3(-Gp.x, -Gp.y, -Gp.z));
-        Jlog6(Gi, gip, E);
-        for (int e = 0; e < 36; ++e) kn[KL.oE6 + e] = -E[e];
-      }
-    }
+    if (!(has_dyn && derivs) && (tid == 0 || (tid == 64 && derivs))) step_se3(tid == 0 ? 0 : 1);
     for (int i = 6 + tid; i < n; i += nthr) {
       if (i < nv) { const double vp = v[i] + dt * acc[i]; kn[KL.oF + i] = q[i + 1] + dt * vp - xn[i + 1]; if (derivs) kn[KL.oXN + i + 1] = q[i + 1] + dt * vp; }
       else if (i >= nv) { const int j = i - nv; const double vp = v[j] + dt * acc[j]; kn[KL.oF + i] = vp - xn[nq + j]; if (derivs) kn[KL.oXN + nq + j] = vp; }
