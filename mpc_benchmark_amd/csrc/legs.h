@@ -390,7 +390,17 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds
         mma_tile_2a(lres[sidx], zres[sidx], BA + (t / nb) * 16, 1, ldp, BB + ((t / nb) * 16) * ldp, ldp, 1, LM + (t % nb) * 16, ldp, 1, np, lane);
     }
     LC_PROF(1);
-    if (tid < n) { double s = 0; for (int l = 0; l < n; ++l) s += LM[l * ldp + tid] * phi[l]; sg[tid] += s; }
+    // (by the last two wavefronts — three tiles each above, the first has four — and over the zero-padded np rows with sixteen operands in
+    // flight: a loop of n dependent LDS round trips on wavefronts 0 and 1 kept the other six at the barrier for 2.4 us per knot)
+    {
+      const int ts = tid - (nthr - 128);
+      if (ts >= 0 && ts < n) {
+        double s = 0;
+#pragma unroll 16
+        for (int l = 0; l < np; ++l) s += LM[l * ldp + ts] * phi[l];
+        sg[ts] += s;
+      }
+    }
     LC_PROF(2);
     LEG_BARRIER();
     LC_PROF(3);

@@ -1084,8 +1084,12 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     __syncthreads();
     for (int r = tid; r < n; r += nthr) {
       double t = gh[r];
-      for (int i = 0; i < m; ++i) t += ST[i * np + r] * W[i * lw + np];
-      if (small_ca) { for (int i = 0; i < ca; ++i) t += CTl[i * lw + r] * kvc[i]; }
+#pragma unroll 8
+      for (int i = 0; i < m; ++i) t += ST[i * np + r] * W[i * lw + np];  // (operands of eight terms in flight)
+      if (small_ca) {
+#pragma unroll 4
+        for (int i = 0; i < ca; ++i) t += CTl[i * lw + r] * kvc[i];
+      }
       else { const double* Ct = wk + L.wCt; for (int i = 0; i < ca; ++i) t += Ct[i * nz + r] * kvc[i]; }
       g[L.op + r] = t;
       pvec[r] = t;
