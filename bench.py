@@ -225,7 +225,7 @@ def main():
             first_replan = pd.horizon  # the first take-off enters at tick T_ds + horizon of the schedule: its planning window opens T_ds ticks earlier
             kw = min(args.steps, cyc)
             start = max(0, first_replan - int(round((1.0 - fdp.T_DS / cyc) * kw)))
-            prelude = max(0, start - args.warmup - (args.calibration_ticks if nshard > 1 else 0))
+            prelude = max(0, start - args.warmup - (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0))  # (calibration ticks run with the adaptive pacer only)
         cold, n_conv = None, 0
         for e in shards:
             e.prepare_schedule(prelude + args.warmup + args.steps + args.calibration_ticks + 4)
