@@ -727,14 +727,18 @@ sim_loop:
         if (!chol16_wave(Sp, 17, LIs, lane) && lane == 0) iflag[1] = 0;
         EV_SUB(16);
         // z2 = Ls^-T Ls^-1 t ; lambda = -z2
+        // (sixteen terms for every lane, all operands requested at once: the entries of Ls^-1 above the diagonal are exact zeros, the
+        // sums keep their order and their bits ; with the trip count depending on the lane every term waited for its own LDS round trip)
         if (lane < 16) {
           double y = 0;
-          for (int j = 0; j <= lane; ++j) y += LIs[lane * 17 + j] * ((j < nl) ? small[j] : 0.0);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) y += LIs[lane * 17 + j] * ((j < nl) ? small[j] : 0.0);
           small[16 + lane] = y;
         }
         if (lane < 16) {
           double z = 0;
-          for (int j = lane; j < 16; ++j) z += LIs[j * 17 + lane] * small[16 + j];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) z += LIs[j * 17 + lane] * small[16 + j];
           small[32 + lane] = z;
           if (lane < nl) lam[lane] = -z;
         }

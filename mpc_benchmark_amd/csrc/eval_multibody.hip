@@ -3,6 +3,7 @@
 #include <atomic>
 #include <stdexcept>
 #include <string>
+#define CHOL16_RIGHT_LOOKING  // (mfma_blocks.h: the 16 x 16 inverse with independent updates — pays in this kernel's one-wavefront chain only)
 #include "eval_multibody.h"
 
 void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout& LT, double* records, double* scratch, size_t scratch_stride,

@@ -160,6 +160,23 @@ template <int R> struct InvRow {
   }
 };
 template <> struct InvRow<16> { static DEV void run(const double (&)[16], const double (&)[16], double (&)[16], int) {} };
+// The same inverse RIGHT-looking: once x[K] = (row K of L^-1) is final, every later row R gets its term  x[R] -= L[R][K] x[K]  — fifteen
+// independent instructions instead of a dot product per row whose R terms wait for one another (120 dependent fp64 operations per
+// block).  Each x[R] receives its terms in the order K = 0, 1, ...: the same bits.  Opt-in (CHOL16_RIGHT_LOOKING before this header):
+// the stage kernel's one-wavefront factorisation chain gains 0.6 us per knot, the Riccati sweep loses 5 % with it (more registers live
+// across its tile phases) — profiles/r03_experiments.txt.
+template <int K, int R> struct InvUpd {
+  static DEV void run(const double (&nd)[16], double (&x)[16]) { fmac_bcast<R>(x[R], nd[K], x[K]); InvUpd<K, R + 1>::run(nd, x); }  // x[R] -= L[R][K] x[K]
+};
+template <int K> struct InvUpd<K, 16> { static DEV void run(const double (&)[16], double (&)[16]) {} };
+template <int K> struct InvCol {
+  static DEV void run(const double (&nd)[16], const double (&invd)[16], double (&x)[16]) {
+    x[K] *= invd[K];
+    InvUpd<K, K + 1>::run(nd, x);
+    InvCol<K + 1>::run(nd, invd, x);
+  }
+};
+template <> struct InvCol<16> { static DEV void run(const double (&)[16], const double (&)[16], double (&)[16]) {} };
 
 // One wavefront: Cholesky of the 16x16 block D (lower triangle, leading dimension ld) entirely in registers —
 // lane r (< 16) holds row r — then its inverse.  Writes L back over D (lower part) and L^-1 to LIb (ld 17); LIb == D (ld 17): the
@@ -176,8 +193,13 @@ DEV bool chol16_wave(double* D, int ld, double* LIb, int lane) {
     for (int cidx = 0; cidx < 16; ++cidx) if (cidx <= r) D[r * ld + cidx] = d[cidx];
   }
 #pragma unroll
+#ifdef CHOL16_RIGHT_LOOKING
+  for (int cidx = 0; cidx < 16; ++cidx) { x[cidx] = (r == cidx) ? 1.0 : 0.0; d[cidx] = -d[cidx]; }
+  InvCol<0>::run(d, invd, x);
+#else
   for (int cidx = 0; cidx < 16; ++cidx) { x[cidx] = 0.0; d[cidx] = -d[cidx]; }
   InvRow<0>::run(d, invd, x, lane);  // lane c of every 16-lane row builds column c of L^-1
+#endif
   if (lane < 16) {
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) LIb[rr * 17 + lane] = x[rr];
