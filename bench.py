@@ -536,7 +536,7 @@ def main():
                 "busy_cus": min(256, args.batch // nshard * legs), "frac_of_busy_cus": round(ach / (78.6 * min(256, args.batch // nshard * legs) / 256.0), 5)}
 
     # ---- batch = 1 latency (BASELINE.json config: batch=1 on one MI355X) ----
-    p50_ms = p90_ms = None
+    p50_ms = p90_ms = p95_ms = None
     if not args.no_latency:
         one = EnsembleMPC(pd, batch=1, library=lib, device=local_rank, perturb=False, tick_reuse=not args.no_tick_reuse)
         one.options.riccati_legs = args.latency_legs if args.legs != 1 else 1
@@ -555,6 +555,7 @@ def main():
                 lat.append((time.perf_counter() - ts) * 1e3)
         p50_ms = round(_p50(lat), 4)
         p90_ms = round(sorted(lat)[int(0.9 * (len(lat) - 1))], 4)
+        p95_ms = round(sorted(lat)[int(0.95 * (len(lat) - 1))], 4)  # (p50 and p95 per solve)
         del one
 
     # ---- CPU baseline: the CPU port (oracle/cpu_port: closed-form derivatives, -O3 -march=native, OpenMP over knots, Riccati sweep in
@@ -594,7 +595,7 @@ def main():
                                % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch, args.iters_per_tick, args.iters_per_tick),
                    "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "riccati_legs": legs, "tick_reuse": not args.no_tick_reuse, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
-        "p50_ms_per_solve_batch1": p50_ms, "p90_ms_per_solve_batch1": p90_ms, "latency_ticks": (300 if p50_ms is not None else 0), "p50_riccati_legs": (args.latency_legs if args.legs != 1 else 1),
+        "p50_ms_per_solve_batch1": p50_ms, "p90_ms_per_solve_batch1": p90_ms, "p95_ms_per_solve_batch1": p95_ms, "latency_ticks": (300 if p50_ms is not None else 0), "p50_riccati_legs": (args.latency_legs if args.legs != 1 else 1),
         "riccati_cuts": ("chain (MPC_LEGS_CHAIN)" if os.environ.get("MPC_LEGS_CHAIN", "0") not in ("", "0") else "tree of pairwise compositions (csrc/legs_tree.h) from three legs on"),
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
         "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; largest primal / dual infeasibility of the others: %.2e)" % (n_conv, args.batch, mres["worst_unconv"]),
