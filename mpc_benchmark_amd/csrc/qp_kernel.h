@@ -166,7 +166,9 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
   auto hi = [&](int r) { return r < nin ? u[r] : ub[r - nin]; };
   auto row_dot = [&](int r, const double* xx) {
     if (r >= nin) return xx[r - nin];
-    double t = 0; for (int j = 0; j < n; ++j) t += C[r * n + j] * xx[j]; return t;
+    double t = 0;
+#pragma unroll 8
+      for (int j = 0; j < n; ++j) t += C[r * n + j] * xx[j]; return t;
   };
   auto h_times = [&](const double* vv, double* out) {  // out = H vv  (n <= 128)
     const int c0 = lane < n ? lane : 0, c1 = lane + 64 < n ? lane + 64 : 0;
@@ -192,17 +194,23 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
   // s, zp, Ax, ye at x (multiplier estimates around the current y, z)
   auto eval = [&]() {
     for (int r = tid; r < m; r += nthr) { const double sr = row_dot(r, x); s[r] = sr; zp[r] = qp_zplus(z[r], sr, lo(r), hi(r), mu_in); }
-    for (int i = tid; i < neq; i += nthr) { double t = -b[i]; for (int j = 0; j < n; ++j) t += A[i * n + j] * x[j]; Ax[i] = t; ye[i] = y[i] + t / mu_eq; }
+    for (int i = tid; i < neq; i += nthr) { double t = -b[i];
+#pragma unroll 8
+      for (int j = 0; j < n; ++j) t += A[i * n + j] * x[j]; Ax[i] = t; ye[i] = y[i] + t / mu_eq; }
     __syncthreads();
   };
   for (int outer = 0; outer <= S.max_iter; ++outer) {
     // ---- residuals at (x, y, z) ----
     double rp = 0, rd = 0;
-    for (int i = tid; i < neq; i += nthr) { double t = -b[i]; for (int j = 0; j < n; ++j) t += A[i * n + j] * x[j]; rp = fmax(rp, fabs(t)); }
+    for (int i = tid; i < neq; i += nthr) { double t = -b[i];
+#pragma unroll 8
+      for (int j = 0; j < n; ++j) t += A[i * n + j] * x[j]; rp = fmax(rp, fabs(t)); }
     for (int r = tid; r < m; r += nthr) { const double sr = row_dot(r, x); rp = fmax(rp, fmax(sr - hi(r), lo(r) - sr)); }
     for (int j = tid; j < n; j += nthr) {
       double t = g[j] + hx0[j];
+      #pragma unroll 8
       for (int i = 0; i < neq; ++i) t += A[i * n + j] * y[i];
+      #pragma unroll 8
       for (int r = 0; r < nin; ++r) t += C[r * n + j] * z[r];
       if (box) t += z[nin + j];
       rd = fmax(rd, fabs(t));
@@ -221,9 +229,11 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
       for (int j = tid; j < n; j += nthr) {
         double t = g[j] + S.rho * (x[j] - xk[j]) + hx0[j];
         hx[j] = t;  // H x + g + rho (x - xk): reused by the line search
+        #pragma unroll 8
         for (int r = 0; r < nin; ++r) t += C[r * n + j] * zp[r];
         if (box) t += zp[nin + j];
         r1[j] = -t;
+        #pragma unroll 8
         for (int i = 0; i < neq; ++i) t += A[i * n + j] * ye[i];
         grad[j] = t;
         gn = fmax(gn, fabs(t));
@@ -292,7 +302,9 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
         for (int idx = tid; idx < np * 16; idx += nthr) {
           const int j = idx >> 4, c = idx & 15;
           double t = 0.0;
-          if (c == 0 && j < n) { t = w[j]; for (int i = 0; i < neq; ++i) t -= Y[j * ldy + i] * yplus[i]; }
+          if (c == 0 && j < n) { t = w[j];
+#pragma unroll 8
+            for (int i = 0; i < neq; ++i) t -= Y[j * ldy + i] * yplus[i]; }
           ZD[j * 17 + c] = t;
         }
         __syncthreads();
@@ -330,14 +342,20 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
       // S = mu_eq I + Y^T Y (lower), rhs = Y^T w + (A x - b) + mu_eq y
       for (int idx = tid; idx < neq * neq; idx += nthr) {
         const int i = idx / neq, k = idx % neq;
-        if (k <= i) { double t = (i == k) ? mu_eq : 0.0; for (int j = 0; j < n; ++j) t += Y[j * ldy + i] * Y[j * ldy + k]; Sm[i * lds_ + k] = t; }
+        if (k <= i) { double t = (i == k) ? mu_eq : 0.0;
+#pragma unroll 8
+          for (int j = 0; j < n; ++j) t += Y[j * ldy + i] * Y[j * ldy + k]; Sm[i * lds_ + k] = t; }
       }
-      for (int i = tid; i < neq; i += nthr) { double t = Ax[i] + mu_eq * y[i]; for (int j = 0; j < n; ++j) t += Y[j * ldy + i] * w[j]; yplus[i] = t; }
+      for (int i = tid; i < neq; i += nthr) { double t = Ax[i] + mu_eq * y[i];
+#pragma unroll 8
+        for (int j = 0; j < n; ++j) t += Y[j * ldy + i] * w[j]; yplus[i] = t; }
       __syncthreads();
       if (!qp_chol(Sm, neq, lds_, &flag, tid)) { status = 2; goto done; }
       if (tid < 64) { qp_fwd_wave(Sm, neq, lds_, yplus, tid); qp_bwd_wave(Sm, neq, lds_, yplus, tid); }
       __syncthreads();
-      for (int j = tid; j < n; j += nthr) { double t = w[j]; for (int i = 0; i < neq; ++i) t -= Y[j * ldy + i] * yplus[i]; dx[j] = t; }
+      for (int j = tid; j < n; j += nthr) { double t = w[j];
+#pragma unroll 8
+        for (int i = 0; i < neq; ++i) t -= Y[j * ldy + i] * yplus[i]; dx[j] = t; }
       __syncthreads();
       if (tid < 64) qp_bwd_wave(Pm, n, ldp, dx, tid);
       __syncthreads();
@@ -348,7 +366,9 @@ __global__ void __launch_bounds__(QP_THREADS) k_qp_solve(QpArgs a) {
       __syncthreads();
       double pa0 = 0, pa1 = 0, pe0 = 0, pe1 = 0;
       for (int j = tid; j < n; j += nthr) { pa0 += dx[j] * hx[j]; pa1 += dx[j] * (S.rho * dx[j] + hdx[j]); }
-      for (int i = tid; i < neq; i += nthr) { double t = 0; for (int j = 0; j < n; ++j) t += A[i * n + j] * dx[j]; pe0 += t * ye[i]; pe1 += t * t / mu_eq; }
+      for (int i = tid; i < neq; i += nthr) { double t = 0;
+#pragma unroll 8
+        for (int j = 0; j < n; ++j) t += A[i * n + j] * dx[j]; pe0 += t * ye[i]; pe1 += t * t / mu_eq; }
       const double lin = qp_block_sum(pa0 + pe0, red, tid), quad = qp_block_sum(pa1 + pe1, red, tid);
       // root of the increasing piecewise-linear phi' by ONE wavefront (safeguarded Newton; no workgroup barrier per trial)
       if (tid < 64) {
