@@ -195,6 +195,14 @@ int mpc_simulate(mpc_solver* s, int32_t substeps, double dt);
 /* The same with a disturbance: f_ext[B][3], a world-frame force applied at the origin of the base link during the whole call (the
  * 300 N push of fulldynamic_talos.py:433-435, 524-526: device.apply_force(f_disturbance, [0, 0, 0]) on ticks 160 - 170); NULL = none. */
 int mpc_simulate_push(mpc_solver* s, int32_t substeps, double dt, const double* f_ext);
+/* Torque-driven form — the stand-in for BulletRobot.execute(torques) + p.stepSimulation() and measureState()
+ * (bullet_robot.py:138-145, 172-196; the kinodynamic and centroidal loops apply the torque of their whole-body QP this way,
+ * kinodynamic_talos.py:458, centroidal_talos.py:447): x[B][nx] = the states to start from (NULL: the handle's measured states x0, so that
+ * successive calls continue one another), tau[B][nu] joint torques held during the call.  Knot 0's contact dynamics — its contact set, the
+ * Baumgarte-corrected rigid contacts of the model table — are integrated `substeps` times with step dt (semi-implicit Euler); the final state
+ * becomes the measured state x0 of every instance (mpc_get_x0), wrenches[B][2][6] (may be NULL) receives the contact wrenches of the
+ * last sub-step (LOCAL frame, model contact order, inactive contacts zero).  Whole-body contact dynamics only. */
+int mpc_simulate_torque(mpc_solver* s, const double* x, const double* tau, int32_t substeps, double dt, double* wrenches);
 int mpc_get_x0(mpc_solver* s, double* x0);
 /* solver.setup(problem) (fulldynamic_talos.py:539): reset multipliers, penalty and tolerances (no re-allocation). */
 int mpc_setup(mpc_solver* s);

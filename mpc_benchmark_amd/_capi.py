@@ -83,6 +83,7 @@ _SIGNATURES = {
     "mpc_set_x0": (C.c_int, [C.c_void_p, _DP]),
     "mpc_simulate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "mpc_simulate_push": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _DP]),
+    "mpc_simulate_torque": (C.c_int, [C.c_void_p, _DP, _DP, C.c_int32, C.c_double, _DP]),
     "mpc_set_tick_reuse": (C.c_int, [C.c_void_p, C.c_int32]),
     "mpc_enable_instance_params": (C.c_int, [C.c_void_p]),
     "mpc_update_instance_params_batch": (C.c_int, [C.c_void_p, C.c_int32, _IP, _IP, _IP, _IP, _DP]),
@@ -238,6 +239,17 @@ class NativeSolver:
         """``simulate`` with a world-frame force at the base origin of every instance: f_ext (B, 3) or (3,) (mpc_simulate_push)."""
         f = np.ascontiguousarray(np.broadcast_to(_f64(f_ext).reshape(-1, 3), (self.dims.batch, 3)))
         self._check(self.lib.mpc_simulate_push(self._h, int(substeps), float(dt), _dp(f)), "mpc_simulate_push")
+
+    def simulate_torque(self, x, tau, substeps, dt, wrenches=False):
+        """Torque-driven stand-in for ``BulletRobot.execute`` (mpc_simulate_torque): x (B, nx) or None (continue from the measured
+        states), tau (B, nu).  -> the new measured states (B, nx) [, contact wrenches (B, 2, 6)]."""
+        d = self.dims
+        xa = None if x is None else np.ascontiguousarray(np.broadcast_to(_f64(x).reshape(-1, d.nx), (d.batch, d.nx)))
+        ta = np.ascontiguousarray(np.broadcast_to(_f64(tau).reshape(-1, d.nu), (d.batch, d.nu)))
+        wr = np.zeros((d.batch, 2, 6)) if wrenches else None
+        self._check(self.lib.mpc_simulate_torque(self._h, _dp(xa), _dp(ta), int(substeps), float(dt), _dp(wr)), "mpc_simulate_torque")
+        x0 = self.get_x0()
+        return (x0, wr) if wrenches else x0
 
     def get_x0(self):
         x0 = np.zeros((self.dims.batch, self.dims.nx))

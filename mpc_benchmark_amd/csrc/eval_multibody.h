@@ -226,7 +226,8 @@ cand_loop:  // (TRIAL == 1 with mb.ncand_loop: next backtracking candidate of th
     const double* xs = a.xs + ((size_t)b * (N + 1) + kx) * nx;
     const double* dx = a.dxs + ((size_t)b * (N + 1) + kx) * n;
     if (TRIAL == 2) {
-      for (int i = tid; i < nx; i += nthr) { x[i] = xs[i]; xn[i] = xs[i]; }  // simulated state ; xn = xs[0], the feedback reference
+      const double* xsim = mb.sim_u ? a.x0 + (size_t)b * nx : xs;  // torque-driven form: from the measured state
+      for (int i = tid; i < nx; i += nthr) { x[i] = xsim[i]; xn[i] = xs[i]; }  // simulated state ; xn = xs[0], the feedback reference
     } else if (CAND) {
       if (wv == 0) state_integrate_group(MPC_SPACE_MULTIBODY, nx, n, xs, dx, alpha, x, lane, 64);
       if (wv == 1 && k < N) state_integrate_group(MPC_SPACE_MULTIBODY, nx, n, specw ? xs : xs + nx, specw ? dx : dx + n, alpha, xn, lane, 64);
@@ -269,6 +270,11 @@ sim_loop:
     // feedback law of the low-level loop: u = us[0] - K0 difference(x, xs[0]),  difference(a, b) = b (-) a
     if (!has_dyn) return;
     double* dd = Tq;
+    if (mb.sim_u) {  // mpc_simulate_torque: the caller's joint torques, held over the sub-steps
+      for (int i = tid; i < nu; i += nthr) u[i] = mb.sim_u[(size_t)b * nu + i];
+      __syncthreads();
+      goto sim_u_set;
+    }
     if (tid == 0) {
       const M3 Rx = quat_to_rot(x + 3), R0 = quat_to_rot(xn + 3);
       V3 ev, ew;
@@ -287,6 +293,7 @@ sim_loop:
     }
     __syncthreads();
   }
+sim_u_set:
 #define BELOW(kdof, body) ((anc[(body)] >> dof_body[(kdof)]) & 1ull)
 
   // ---- P1: local joint transforms (stored in the Bc region), then world placements ----------------------
@@ -804,6 +811,12 @@ sim_loop:
     __syncthreads();
     if (++sim_sub < mb.sim_substeps) goto sim_loop;
     for (int i = tid; i < nx; i += nthr) a.x0[(size_t)b * nx + i] = x[i];  // the measured state of the next tick
+    if (mb.sim_wrench)
+      for (int i = tid; i < 12; i += nthr) {
+        double wr = 0.0;
+        for (int cc = 0; cc < nk; ++cc) if (ccid_s[cc] == i / 6) wr = lam[6 * cc + i % 6];
+        mb.sim_wrench[(size_t)b * 12 + i] = wr;
+      }
     return;
   }
   // ---- kinodynamics (kinodynamic_talos.py:107-112): a_joint = u[12:], base acceleration from the momentum balance

@@ -7,13 +7,14 @@
 #include "eval_multibody.h"
 
 void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout& LT, double* records, double* scratch, size_t scratch_stride,
-                           bool trial, int cand0, int ncand, int sim_substeps, double sim_dt, bool with_derivs, const double* f_ext, bool contact_dyn) {
+                           bool trial, int cand0, int ncand, int sim_substeps, double sim_dt, bool with_derivs, const double* f_ext, bool contact_dyn,
+                           const double* sim_u, double* sim_wrench) {
   const Layout& L = a.L;
   MbArgs mb;
   mb.lds = make_mb_lds(L.nj, L.n / 2, L.nx - L.n / 2, L.m, L.nz, contact_dyn);
   mb.scratch = scratch;
   mb.scratch_stride = scratch_stride;
-  mb.sim_substeps = sim_substeps; mb.sim_dt = sim_dt; mb.f_ext = f_ext;
+  mb.sim_substeps = sim_substeps; mb.sim_dt = sim_dt; mb.f_ext = f_ext; mb.sim_u = sim_u; mb.sim_wrench = sim_wrench;
   mb.ncand_loop = (trial && !with_derivs && ncand > 1) ? ncand : 0;
   if (mb.lds.total_bytes > 160 * 1024) throw std::runtime_error("multibody model too large for the LDS budget of the stage kernel");
   // hipFuncSetAttribute is a per-device setting: remember what was requested on every device (a process may hold handles on several

@@ -120,11 +120,14 @@ struct MbArgs {
   int sim_substeps;       // TRIAL == 2 (closed-loop simulation stand-in): integration steps ...
   double sim_dt;          // ... of this length
   const double* f_ext;    // TRIAL == 2: world-frame force at the base origin per instance [B][3] (mpc_simulate_push), or nullptr
+  const double* sim_u;    // TRIAL == 2: joint torques per instance [B][nu] held during the call (mpc_simulate_torque: the start state is
+                          // then a.x0, no feedback law), or nullptr
+  double* sim_wrench;     // TRIAL == 2: contact wrenches of the last sub-step [B][2][6], or nullptr
 };
 
 
 // defined in eval_multibody.hip
 void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout& LT, double* records, double* scratch, size_t scratch_stride,
                            bool trial, int cand0 = 0, int ncand = 1, int sim_substeps = 0, double sim_dt = 0.0, bool with_derivs = false,
-                           const double* f_ext = nullptr, bool contact_dyn = true);
+                           const double* f_ext = nullptr, bool contact_dyn = true, const double* sim_u = nullptr, double* sim_wrench = nullptr);
 const void* eval_multibody_kernel(int trial);  // entry point of k_eval_multibody<trial> (occupancy tooling)

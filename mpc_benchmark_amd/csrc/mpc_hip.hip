@@ -71,6 +71,8 @@ struct mpc_solver {
   int khead = 0;
   int* d_spec = nullptr;
   double* d_fext = nullptr;  // [B][3] disturbance force of mpc_simulate_push
+  double* d_simu = nullptr;  // [B][nu] torques, [B][12] wrenches of mpc_simulate_torque
+  double* d_simwr = nullptr;
   // per-slot invalidation (mpc_update_stage_params*): slots whose parameters changed since the last pass was enqueued ; dirty_all:
   // an update on a horizon too long for the mask of SolverArgs
   std::vector<uint8_t> slot_dirty;
@@ -1082,6 +1084,24 @@ int mpc_simulate(mpc_solver* s, int32_t substeps, double dt) {
 
 int mpc_simulate_push(mpc_solver* s, int32_t substeps, double dt, const double* f_ext) {
   MPC_TRY(s, { simulate_impl(s, substeps, dt, f_ext); })
+}
+
+int mpc_simulate_torque(mpc_solver* s, const double* x, const double* tau, int32_t substeps, double dt, double* wrenches) {
+  MPC_TRY(s, {
+    if (substeps <= 0 || !(dt > 0.0)) throw std::runtime_error("simulate: substeps and dt must be positive");
+    if (!tau) throw std::runtime_error("simulate_torque: tau must not be null");
+    if (s->L.space != MPC_SPACE_MULTIBODY || s->h_desc[(size_t)slot_of(s, 0) * s->L.max_stage_ints] != MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER)
+      throw std::runtime_error("simulate: only contact-constrained whole-body dynamics are supported");
+    const Layout& L = s->L;
+    if (!s->d_simu) { s->d_simu = s->alloc<double>((size_t)L.B * L.m); s->d_simwr = s->alloc<double>((size_t)L.B * 12); }
+    if (x) copy_sync(s, s->d_x0, x, (size_t)L.B * L.nx * sizeof(double), hipMemcpyHostToDevice);
+    copy_sync(s, s->d_simu, tau, (size_t)L.B * L.m * sizeof(double), hipMemcpyHostToDevice);
+    launch_eval_multibody(s->stream, s->args(), s->LT, s->d_tknots, s->d_mbwork, s->mb_work_stride, true, 0, 1, substeps, dt, false, nullptr, true,
+                          s->d_simu, wrenches ? s->d_simwr : nullptr);
+    HIP_OK(hipGetLastError());
+    if (wrenches) copy_sync(s, wrenches, s->d_simwr, (size_t)L.B * 12 * sizeof(double), hipMemcpyDeviceToHost);
+    s->perfect_feedback = false;
+  })
 }
 
 int mpc_get_x0(mpc_solver* s, double* x0) {

@@ -1,12 +1,22 @@
-"""The receding-horizon loop body of fulldynamic_talos.py:438-550 written against the ``aligator`` mirror and the
-reference generators of ``mpc_benchmark_amd.references`` — what a user of the reference script executes every 10 ms,
-minus PyBullet: the next measured state is the state the previous solution predicted ("perfect-model" feedback,
-SURVEY.md §8d).
+"""The receding-horizon loop bodies of the three reference scripts written against the ``aligator`` mirror and the reference
+generators of ``mpc_benchmark_amd.references`` — what a user of the scripts executes every 10 ms, minus PyBullet and the 1 kHz
+low-level loop:
 
-Per tick: foot poses of the measured state -> take-off / landing countdowns -> swing references over the horizon
-(``setReference`` on components 3 / 4 of every stage) -> ``replaceStageCircular`` with the stage of the contact phase that
-enters the horizon -> terminal CoM constraint between the last foot references -> warm-start shift -> ``setup`` + ``run``.
-"""
+  ``WalkingMPCLoop``       fulldynamic_talos.py:438-550   (steps in place: x_forward = 0, :352)
+  ``KinodynamicMPCLoop``   kinodynamic_talos.py:361-497   (walks 0.3 m per step, :257; string-keyed cost components, :384-385;
+                                                           terminal CoM target by ``term_constraints.funcs[0].setReference``, :409;
+                                                           ``cycleProblem`` and no ``setup`` in the loop, :487-490)
+  ``CentroidalMPCLoop``    centroidal_talos.py:353-468    (walks 0.2 m per step, :175; ``contact_poses[i] = ...`` on the three contact maps of
+                                                           every stage, :374-384; the stage is rotated in AFTER the references are written)
+
+Per tick: take-off / landing countdowns -> swing references over the horizon from the MEASURED foot poses -> the references into the
+stages -> ``replaceStageCircular`` with the stage of the contact phase that enters the horizon -> terminal targets -> warm-start shift ->
+``run``.  The measurement comes from the caller (``tick(x_fk=..., x0_init=...)``: a simulator, or the states a run of the reference
+script recorded — tests/test_dropin_fixtures.py replays those) or, by default, from the model itself ("perfect-model" feedback,
+SURVEY.md §8d: the next measured state is the state the previous solution predicted).
+
+``z_height``: height gained per step (0.10 = the "stairs" of BASELINE.json's configuration 4; the ``z_height`` argument of
+``footTrajectory``, talos_utils.py:188-192)."""
 from __future__ import annotations
 
 import numpy as np
@@ -15,11 +25,12 @@ from .. import references as refgen
 from ..robot import minipin as pin
 
 
-class WalkingMPCLoop:
-    def __init__(self, problem_def, solver, swing_apex=0.15, x_forward=0.0, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0,
-                 start_tick=0, move_terminal_constraint=True):
-        """``problem_def``: a FullDynamicsProblem; ``solver``: its ``make_solver()`` (any backend library).
-        ``start_tick`` fast-forwards the contact schedule (the countdown lists are advanced accordingly)."""
+class _MPCLoop:
+    """What the three loops share: countdown lists, generator, warm-start shift, bookkeeping."""
+
+    T_SS = T_DS = None
+
+    def __init__(self, problem_def, solver, swing_apex, x_forward, y_forward, foot_yaw, y_gap, z_height, start_tick=0, cold_iters=None):
         self.pd, self.solver = problem_def, solver
         rb = problem_def.robot
         self.model, self.data = rb.model, rb.model.createData()
@@ -30,12 +41,10 @@ class WalkingMPCLoop:
         ev = refgen.contact_event_times(self.phases, N)
         self.takeoff_RFs, self.takeoff_LFs, self.land_RFs, self.land_LFs = [list(e) for e in ev]
         lf, rf = rb.foot_placements
-        self.foottraj = refgen.FootTrajectory(lf.copy(), rf.copy(), _T_SS(problem_def), _T_DS(problem_def), N, swing_apex, x_forward, y_forward,
-                                              foot_yaw, y_gap, z_height)
-        self.step_params = (x_forward, y_forward, y_gap, z_height, swing_apex)
-        self.move_terminal_constraint = move_terminal_constraint
-        self.problem = problem_def.build(with_terminal_constraint=True)
-        # the horizon initially holds `N` copies of the first stage; fast-forward = the loop below without solving
+        self.foottraj = refgen.FootTrajectory(lf.copy(), rf.copy(), self.T_SS, self.T_DS, N, swing_apex, x_forward, y_forward, foot_yaw, y_gap, z_height)
+        self.step_params = dict(swing_apex=swing_apex, x_forward=x_forward, y_forward=y_forward, foot_yaw=foot_yaw, y_gap=y_gap, z_height=z_height)
+        self.problem = self._build_problem()
+        # the horizon initially holds `N` copies of the first stage; fast-forward = the loop without solving
         self.t = 0
         for _ in range(start_tick):
             refgen.update_timings(self.land_LFs, self.land_RFs, self.takeoff_LFs, self.takeoff_RFs)
@@ -43,21 +52,88 @@ class WalkingMPCLoop:
             self.t += 1
         solver.setup(self.problem)
         xs, us = problem_def.initial_guess()
+        if cold_iters is not None:
+            solver.max_iters = cold_iters
         solver.run(self.problem, xs, us)
+        self.cold = {"num_iters": solver.results.num_iters, "conv": solver.results.conv}
         solver.max_iters = 1
         self.xs, self.us = list(solver.results.xs), list(solver.results.us)
-        self.x_measured = np.array(self.xs[0])
+        self.x_fk = None          # the whole-body state the foot poses are measured at (None: the reference posture)
         self.history = []
 
+    # -- hooks ------------------------------------------------------------------------------------------------------------------------
+    def _build_problem(self):
+        return self.pd.build()
+
+    def _forward_rule(self, takeoff_RF, takeoff_LF, land_RF, land_LF):
+        """the ``foottraj.updateForward`` call some scripts make once the walk is over"""
+
+    # -- one tick -------------------------------------------------------------------------------------------------------------------------
     def foot_poses(self, x):
         pin.framesForwardKinematics(self.model, self.data, np.asarray(x)[:self.model.nq])
         return self.data.oMf[self.lf_id].copy(), self.data.oMf[self.rf_id].copy()
 
-    def tick(self):
-        pd, prob, solver, N = self.pd, self.problem, self.solver, self.N
-        LF_pose, RF_pose = self.foot_poses(self.x_measured)
+    def set_solution(self, xs, us):
+        """Install a previous solution (the warm start of the next tick is its shift): replaying recorded ticks."""
+        self.xs, self.us = [np.array(x) for x in xs], [np.array(u) for u in us]
+
+    def measured_feet(self, x_fk):
+        if x_fk is None:
+            lf, rf = self.pd.robot.foot_placements
+            return lf.copy(), rf.copy()
+        return self.foot_poses(x_fk)
+
+    def plan(self, x_fk):
+        LF_pose, RF_pose = self.measured_feet(x_fk)
         takeoff_RF, takeoff_LF, land_RF, land_LF = refgen.update_timings(self.land_LFs, self.land_RFs, self.takeoff_LFs, self.takeoff_RFs)
+        self._forward_rule(takeoff_RF, takeoff_LF, land_RF, land_LF)
         LF_refs, RF_refs = self.foottraj.updateTrajectory(takeoff_RF, takeoff_LF, land_RF, land_LF, LF_pose, RF_pose)
+        self.timings = (takeoff_RF, takeoff_LF, land_RF, land_LF)
+        return LF_pose, RF_pose, LF_refs, RF_refs
+
+    def _record(self, LF_pose, RF_pose, LF_refs, RF_refs):
+        takeoff_RF, takeoff_LF, land_RF, land_LF = self.timings
+        rec = {"tick": self.t, "LF_ref": LF_refs[0].translation.copy(), "RF_ref": RF_refs[0].translation.copy(),
+               "LF": LF_pose.translation.copy(), "RF": RF_pose.translation.copy(), "takeoff_RF": takeoff_RF, "land_RF": land_RF,
+               "takeoff_LF": takeoff_LF, "land_LF": land_LF}
+        self.history.append(rec)
+        return rec
+
+
+class WalkingMPCLoop(_MPCLoop):
+    """fulldynamic_talos.py:438-550."""
+
+    def __init__(self, problem_def, solver, swing_apex=0.15, x_forward=0.0, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0,
+                 start_tick=0, move_terminal_constraint=True, cold_iters=None, terminal_constraint_at_start=True):
+        """``problem_def``: a FullDynamicsProblem; ``solver``: its ``make_solver()`` (any backend library).
+        ``start_tick`` fast-forwards the contact schedule (the countdown lists are advanced accordingly).
+        ``terminal_constraint_at_start=False``: the cold solve runs without the terminal CoM constraint, as in the script (the constraint
+        first appears in the loop, fulldynamic_talos.py:372 vs :499-507)."""
+        from . import fulldynamic
+        self.T_SS, self.T_DS = fulldynamic.T_SS, fulldynamic.T_DS
+        self.move_terminal_constraint = move_terminal_constraint
+        self._term_at_start = bool(terminal_constraint_at_start)
+        super().__init__(problem_def, solver, swing_apex, x_forward, y_forward, foot_yaw, y_gap, z_height, start_tick, cold_iters)
+        self.x_measured = np.array(self.xs[0])
+
+    def _build_problem(self):
+        return self.pd.build(with_terminal_constraint=self._term_at_start)
+
+    def _forward_rule(self, takeoff_RF, takeoff_LF, land_RF, land_LF):
+        if land_LF == -1:  # fulldynamic_talos.py:448-449
+            p = self.step_params
+            self.foottraj.updateForward(0, 0, p["y_gap"], p["y_forward"], -0.01, 0, p["swing_apex"])
+
+    def tick(self, x_fk=None, x0_init=None):
+        """``x_fk``: the measured whole-body state of this tick (fulldynamic_talos.py:441: forward kinematics at ``x_measured``);
+        ``x0_init``: the initial condition of the solve (:536, the measurement of the tick before).  Default for both: the state the
+        previous solution predicted for this tick."""
+        pd, prob, solver, N = self.pd, self.problem, self.solver, self.N
+        if x0_init is None:
+            x0_init = np.array(self.xs[1])
+        if x_fk is None:  # the script plans from the state that also becomes the initial condition of this solve (x_measured at :441 is
+            x_fk = x0_init  # x_measured_prev at :534-536: the low-level loop in between updates x_measured for the NEXT tick)
+        LF_pose, RF_pose, LF_refs, RF_refs = self.plan(x_fk)
         for j in range(N):
             prob.stages[j].cost.getComponent(3).residual.setReference(LF_refs[j])
             prob.stages[j].cost.getComponent(4).residual.setReference(RF_refs[j])
@@ -65,13 +141,13 @@ class WalkingMPCLoop:
         solver.workspace.cycleAppend(None)
         if self.move_terminal_constraint:
             com_final = pd.robot.com0.copy()
-            com_final[:2] = 0.5 * (LF_refs[-1].translation[:2] + RF_refs[-1].translation[:2])
+            com_final[:2] = (LF_refs[-1].translation[:2] + RF_refs[-1].translation[:2]) / 2
             prob.removeTerminalConstraint()
             prob.addTerminalConstraint(pd.terminal_com_constraint(com_final))
         prob.term_cost.components[2][0].residual.setReference(LF_refs[-1])
         prob.term_cost.components[3][0].residual.setReference(RF_refs[-1])
-        # perfect-model feedback + warm-start shift (fulldynamic_talos.py:532-536)
-        self.x_measured = np.array(self.xs[1])
+        # warm-start shift (fulldynamic_talos.py:532-536)
+        self.x_measured = np.array(x0_init)
         xs = self.xs[1:] + [self.xs[-1]]
         us = self.us[1:] + [self.us[-1]]
         xs[0] = self.x_measured
@@ -80,18 +156,105 @@ class WalkingMPCLoop:
         solver.run(prob, xs, us)
         self.xs, self.us = list(solver.results.xs), list(solver.results.us)
         self.t += 1
-        rec = {"tick": self.t, "LF_ref": LF_refs[0].translation.copy(), "RF_ref": RF_refs[0].translation.copy(),
-               "LF": LF_pose.translation.copy(), "RF": RF_pose.translation.copy(), "takeoff_RF": takeoff_RF, "land_RF": land_RF,
-               "takeoff_LF": takeoff_LF, "land_LF": land_LF}
-        self.history.append(rec)
-        return rec
+        return self._record(LF_pose, RF_pose, LF_refs, RF_refs)
 
 
-def _T_SS(pd):
-    from . import fulldynamic
-    return fulldynamic.T_SS
+class KinodynamicMPCLoop(_MPCLoop):
+    """kinodynamic_talos.py:361-497."""
+
+    def __init__(self, problem_def, solver, swing_apex=0.15, x_forward=0.3, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0, start_tick=0,
+                 cold_iters=None):
+        from . import kinodynamic
+        self.T_SS, self.T_DS = kinodynamic.T_SS, kinodynamic.T_DS
+        super().__init__(problem_def, solver, swing_apex, x_forward, y_forward, foot_yaw, y_gap, z_height, start_tick, cold_iters)
+        self.x_measured = np.array(self.xs[0])
+
+    def _build_problem(self):
+        return self.pd.build(with_terminal_constraint=True)
+
+    def _forward_rule(self, takeoff_RF, takeoff_LF, land_RF, land_LF):
+        if land_RF == -1 and takeoff_RF == -1:  # kinodynamic_talos.py:368-370
+            p = self.step_params
+            self.foottraj.updateForward(0, 0, p["y_gap"], p["y_forward"], 0, 0, p["swing_apex"])
+
+    def tick(self, x_fk=None, x0_init=None):
+        pd, prob, solver, N = self.pd, self.problem, self.solver, self.N
+        if x0_init is None:
+            x0_init = np.array(self.xs[1])
+        if x_fk is None:  # rdata holds the forward kinematics of the last low-level step = the state that becomes x0_init (:414-415, :482-486)
+            x_fk = x0_init
+        LF_pose, RF_pose, LF_refs, RF_refs = self.plan(x_fk)
+        for j in range(N):
+            prob.stages[j].cost.getComponent("left_sole_link_pose_cost").residual.setReference(LF_refs[j])
+            prob.stages[j].cost.getComponent("right_sole_link_pose_cost").residual.setReference(RF_refs[j])
+        prob.replaceStageCircular(pd.stage_for_tick(self.t % pd.t_mpc))
+        com_final = pd.robot.com0.copy()
+        com_final[:2] = (LF_refs[-1].translation[:2] + RF_refs[-1].translation[:2]) / 2
+        prob.term_constraints.funcs[0].setReference(com_final)
+        self.x_measured = np.array(x0_init)
+        xs = self.xs[1:] + [self.xs[-1]]
+        us = self.us[1:] + [self.us[-1]]
+        xs[0] = self.x_measured
+        prob.x0_init = self.x_measured
+        solver.cycleProblem(prob, None)
+        solver.run(prob, xs, us)  # (no setup: kinodynamic_talos.py:487 is commented out)
+        self.xs, self.us = list(solver.results.xs), list(solver.results.us)
+        self.t += 1
+        return self._record(LF_pose, RF_pose, LF_refs, RF_refs)
 
 
-def _T_DS(pd):
-    from . import fulldynamic
-    return fulldynamic.T_DS
+class CentroidalMPCLoop(_MPCLoop):
+    """centroidal_talos.py:353-468.  The OCP has no whole-body model: under perfect-model feedback the feet are where their
+    references put them (the pose planned for this tick by the previous one)."""
+
+    def __init__(self, problem_def, solver, swing_apex=0.15, x_forward=0.2, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0, start_tick=0,
+                 cold_iters=None):
+        from . import centroidal
+        self.T_SS, self.T_DS = centroidal.T_SS, centroidal.T_DS
+        super().__init__(problem_def, solver, swing_apex, x_forward, y_forward, foot_yaw, y_gap, z_height, start_tick, cold_iters)
+        self._feet = None
+
+    def _forward_rule(self, takeoff_RF, takeoff_LF, land_RF, land_LF):
+        if land_RF == -1:  # centroidal_talos.py:365-366
+            p = self.step_params
+            self.foottraj.updateForward(0, 0, p["y_gap"], p["y_forward"], -0.01, 0, p["swing_apex"])
+
+    def measured_feet(self, x_fk):
+        if x_fk is None and self._feet is not None:
+            return self._feet[0].copy(), self._feet[1].copy()
+        return super().measured_feet(x_fk)
+
+    def tick(self, x_fk=None, x0_init=None):
+        """``x_fk``: measured WHOLE-BODY state (foot poses); ``x0_init``: measured centroidal state [c; h_lin; L] (centroidal_talos.py:411-417)."""
+        pd, prob, solver, N = self.pd, self.problem, self.solver, self.N
+        if x0_init is None:
+            x0_init = np.array(self.xs[1])
+        LF_pose, RF_pose, LF_refs, RF_refs = self.plan(x_fk)
+        self._feet = (LF_refs[1], RF_refs[1])
+        for n in range(N):  # centroidal_talos.py:374-384: the stance feet of every stage stand on their references
+            st = prob.stages[n]
+            ode = st.dynamics.differential_dynamics
+            contact_state = ode.contact_map.contact_states
+            for i, refs in ((0, LF_refs), (1, RF_refs)):
+                if contact_state[i]:
+                    ode.contact_map.contact_poses[i] = refs[n].translation
+                    st.cost.getComponent("angular_acc_cost").residual.contact_map.contact_poses[i] = refs[n].translation
+                    st.cost.getComponent("linear_acc_cost").residual.contact_map.contact_poses[i] = refs[n].translation
+        xs = self.xs[1:] + [self.xs[-1]]
+        us = self.us[1:] + [self.us[-1]]
+        xs[0] = np.array(x0_init)
+        prob.x0_init = np.array(x0_init)
+        prob.replaceStageCircular(pd.stage_for_tick(self.t % pd.t_mpc))
+        solver.cycleProblem(prob, None)
+        solver.setup(prob)
+        solver.run(prob, xs, us)
+        self.xs, self.us = list(solver.results.xs), list(solver.results.us)
+        self.t += 1
+        return self._record(LF_pose, RF_pose, LF_refs, RF_refs)
+
+
+def make_loop(problem_def, solver, **kw):
+    """The loop that belongs to a problem definition."""
+    name = type(problem_def).__name__
+    cls = {"FullDynamicsProblem": WalkingMPCLoop, "KinodynamicProblem": KinodynamicMPCLoop, "CentroidalProblem": CentroidalMPCLoop}[name]
+    return cls(problem_def, solver, **kw)

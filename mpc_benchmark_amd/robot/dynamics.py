@@ -143,3 +143,45 @@ def frame_jdot_v_local(model, data, frame_id):
     frame (what QP_utils.py multiplies out as ``getFrameJacobianTimeVariation(...) @ v``)."""
     f = model.frames[frame_id]
     return np.linalg.inv(data.oMf[frame_id].action()) @ data.a0_w[f.parentJoint]
+
+
+def frame_jacobian_time_variation_local(model, data, frame_id):
+    """6 x nv time derivative of the LOCAL frame Jacobian (pin.getFrameJacobianTimeVariation(..., pin.LOCAL)): with J = X_f^-1 S,
+    X_f' = (v_f x) X_f and S_k' = (v_i x) S_k, column k of a supporting joint i is X_f^-1 ((v_i - v_f) x) S_k.  Its product with v is
+    ``frame_jdot_v_local`` (the contributions of v_f cancel: v_f x v_f = 0)."""
+    f = model.frames[frame_id]
+    Ainv = np.linalg.inv(data.oMf[frame_id].action())
+    vf = data.v_w[f.parentJoint]
+    dJ = np.zeros((6, model.nv))
+    for i in range(1, model.njoints):
+        if _supports(model, f.parentJoint, i):
+            jm = model.joints[i]
+            dJ[:, jm.idx_v:jm.idx_v + jm.nv] = Ainv @ _crm(data.v_w[i] - vf) @ data.S[:, jm.idx_v:jm.idx_v + jm.nv]
+    return dJ
+
+
+def centroidal_matrix_time_variation(model, data, v):
+    """dAg/dt (6 x nv; pin.dccrba's ``data.dAg``): Ag = X_c^* [Yc_i S_k] with the composite inertias Yc (world frame, world origin);
+    Yw_j' = (v_j x*) Yw_j - Yw_j (v_j x), S_k' = (v_i x) S_k, and the shift to the centre of mass c moves with c' = h_lin / m.
+    ``dAg @ v`` equals ``data.dAg_v`` (net force of the zero-acceleration motion)."""
+    nj, nv = model.njoints, model.nv
+    S, Yw, vw = data.S, data.Yw, data.v_w
+    dY = [np.zeros((6, 6)) for _ in range(nj)]
+    Yc = [Y.copy() for Y in Yw]
+    for i in range(1, nj):
+        dY[i] = _crf(vw[i]) @ Yw[i] - Yw[i] @ _crm(vw[i])
+    for i in range(nj - 1, 0, -1):
+        p = model.parents[i]
+        if p:
+            Yc[p] = Yc[p] + Yc[i]
+            dY[p] = dY[p] + dY[i]
+    Ao = np.zeros((6, nv)); dAo = np.zeros((6, nv))
+    for i in range(1, nj):
+        jm = model.joints[i]
+        sl = slice(jm.idx_v, jm.idx_v + jm.nv)
+        Ao[:, sl] = Yc[i] @ S[:, sl]
+        dAo[:, sl] = dY[i] @ S[:, sl] + Yc[i] @ (_crm(vw[i]) @ S[:, sl])
+    mtot = sum(Y.mass for Y in model.inertias[1:])
+    c = data.com[0]
+    cdot = Ao[:3] @ np.asarray(v, dtype=float) / mtot
+    return np.vstack((dAo[:3], dAo[3:] - pin.skew(cdot) @ Ao[:3] - pin.skew(c) @ dAo[:3]))

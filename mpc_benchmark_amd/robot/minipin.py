@@ -256,18 +256,38 @@ class JointModel:
         return self._kind
 
 
+class FrameType:
+    OP_FRAME, JOINT, FIXED_JOINT, BODY, SENSOR = 1, 2, 4, 8, 16
+
+
+OP_FRAME = FrameType.OP_FRAME
+
+
 class Frame:
-    def __init__(self, name, parentJoint, placement, parentFrame=0):
+    """``Frame(name, parentJoint, placement)`` (this module's own order) or Pinocchio's
+    ``Frame(name, parentJoint, parentFrame, placement, type)`` (talos_utils.py:48-96)."""
+
+    def __init__(self, name, parentJoint, placement, parentFrame=0, type=FrameType.OP_FRAME):
+        if isinstance(placement, (int, np.integer)) and isinstance(parentFrame, SE3):  # Pinocchio's argument order
+            placement, parentFrame = parentFrame, int(placement)
         self.name = name
         self.parentJoint = int(parentJoint)
         self.parent = int(parentJoint)
         self.parentFrame = parentFrame
         self.placement = placement
+        self.type = type
 
 
 class _Names(list):
+    """``model.names``: Pinocchio's StdVec_StdString has ``.tolist()`` and keeps it under slicing
+    (``rmodel.names[1:].tolist()``, fulldynamic_talos.py:46)."""
+
     def tolist(self):
         return list(self)
+
+    def __getitem__(self, i):
+        r = list.__getitem__(self, i)
+        return _Names(r) if isinstance(i, slice) else r
 
 
 class Data:
@@ -385,6 +405,8 @@ def _se3_raw(R, p):
 def forwardKinematics(model, data, q, v=None):
     # (plain 3 x 3 arrays in the loop: the MPC loops call this every tick for the measured foot poses)
     q = np.asarray(q, dtype=float)
+    data._q = q  # the algorithms that Pinocchio runs on "the data of the last forward kinematics" (computeJointJacobians) read it
+    data._v = None if v is None else np.asarray(v, dtype=float)
     cq, sq = np.cos(q), np.sin(q)
     oMi = data.oMi
     for i in range(1, model.njoints):
@@ -620,3 +642,97 @@ def frame_placements_batch(model, Q, frame_ids):
             R = R @ Rl
         out.append((R @ f.placement.rotation, np.einsum("bij,j->bi", R, f.placement.translation) + p))
     return out
+
+
+# ---- rigid-body algorithms the scripts call around their low-level QPs (kinodynamic_talos.py:424-430, centroidal_talos.py:421-432, -------
+# fulldynamic_talos.py:491-492; QP_utils.py:520-526, 667-674; talos_utils.py:376-400).  Host-side glue, numpy (robot/dynamics.py): the hot
+# path computes the same quantities inside the stage kernel.  One evaluation per (q, v) fills everything; the individual calls are views.
+def _terms(model, data, q=None, v=None):
+    from . import dynamics
+    q = getattr(data, "_q", None) if q is None else np.asarray(q, dtype=float)
+    if q is None:
+        raise RuntimeError("call forwardKinematics(model, data, q) first")
+    if v is None:
+        v = getattr(data, "_v", None)
+        if v is None:
+            v = getattr(data, "_v_terms", None)
+    v = np.zeros(model.nv) if v is None else np.asarray(v, dtype=float)
+    key = (q.tobytes(), v.tobytes())
+    if getattr(data, "_terms_key", None) != key:
+        dynamics.compute_all_terms(model, data, q, v)
+        data._terms_key = key
+        data._v_terms = v
+    return data
+
+
+def computeJointJacobians(model, data, q=None):
+    _terms(model, data, q)
+    return data.S
+
+
+def computeJointJacobiansTimeVariation(model, data, q, v):
+    _terms(model, data, q, v)
+
+
+def crba(model, data, q):
+    """Joint-space inertia matrix, symmetric (the Python binding of Pinocchio fills both triangles)."""
+    return _terms(model, data, q).M
+
+
+def nonLinearEffects(model, data, q, v):
+    return _terms(model, data, q, v).nle
+
+
+def computeCentroidalMomentum(model, data, q=None, v=None):
+    """``data.hg`` = Ag(q) v about the centre of mass, world axes (fulldynamic_talos.py:491-492, centroidal_talos.py:415-417)."""
+    _terms(model, data, q, v)
+    h = data.Ag @ data._v_terms
+    data.hg = Force(h[:3], h[3:])
+    return data.hg
+
+
+def ccrba(model, data, q, v):
+    computeCentroidalMomentum(model, data, q, v)
+    return data.Ag
+
+
+def dccrba(model, data, q, v):
+    """``data.Ag`` and its time derivative ``data.dAg`` (QP_utils.py:696 multiplies ``data.dAg @ v``)."""
+    from . import dynamics
+    _terms(model, data, q, v)
+    data.dAg = dynamics.centroidal_matrix_time_variation(model, data, data._v_terms)
+    computeCentroidalMomentum(model, data, q, v)
+    return data.dAg
+
+
+def getFrameJacobian(model, data, frame_id, reference_frame=LOCAL):
+    from . import dynamics
+    _terms(model, data)
+    J = dynamics.frame_jacobian_local(model, data, frame_id)
+    if reference_frame == LOCAL:
+        return J
+    R = data.oMf[frame_id].rotation
+    if reference_frame == LOCAL_WORLD_ALIGNED:
+        return np.vstack((R @ J[:3], R @ J[3:]))
+    return data.oMf[frame_id].action() @ J
+
+
+def getFrameJacobianTimeVariation(model, data, frame_id, reference_frame=LOCAL):
+    from . import dynamics
+    if reference_frame != LOCAL:
+        raise NotImplementedError("getFrameJacobianTimeVariation: LOCAL only (all the scripts use)")
+    _terms(model, data)
+    return dynamics.frame_jacobian_time_variation_local(model, data, frame_id)
+
+
+def getFrameVelocity(model, data, frame_id, reference_frame=LOCAL):
+    from . import dynamics
+    _terms(model, data)
+    vl = dynamics.frame_velocity_local(model, data, frame_id)
+    if reference_frame == LOCAL:
+        return vl
+    R = data.oMf[frame_id].rotation
+    if reference_frame == LOCAL_WORLD_ALIGNED:
+        return Motion(R @ vl.linear, R @ vl.angular)
+    w = data.oMf[frame_id].action() @ vl.np
+    return Motion(w[:3], w[3:])

@@ -151,6 +151,16 @@ int mpc_simulate(mpc_solver* h, int32_t substeps, double dt) {
     h->perfect_feedback = false;
   })
 }
+int mpc_simulate_torque(mpc_solver* h, const double* x, const double* tau, int32_t substeps, double dt, double* wrenches) {
+  MPC_TRY(h, {
+    if (substeps <= 0 || !(dt > 0.0)) throw std::runtime_error("simulate: substeps and dt must be positive");
+    if (!tau) throw std::runtime_error("simulate_torque: tau must not be null");
+    const int nx = h->s.dims.nx, nu = h->s.dims.nu;
+    for (int b = 0; b < h->s.dims.batch; ++b)
+      h->s.simulate_torque(h->s.inst[b], x ? x + (size_t)b * nx : nullptr, tau + (size_t)b * nu, substeps, dt, wrenches ? wrenches + 12 * b : nullptr);
+    h->perfect_feedback = false;
+  })
+}
 int mpc_get_x0(mpc_solver* h, double* x0) {
   MPC_TRY(h, {
     const int nx = h->s.dims.nx;

@@ -1004,6 +1004,26 @@ struct Solver {
     in.x0 = x;
   }
 
+  // Torque-driven form of the stand-in (bullet_robot.py:138-145 execute + stepSimulation): knot 0's contact dynamics under the given joint
+  // torques, from `x` (null: from the measured state); wrench (12, may be null) = contact wrenches of the last sub-step.
+  void simulate_torque(Instance& in, const double* x_start, const double* tau, int substeps, double dt, double* wrench) const {
+    if (dims.space != MPC_SPACE_MULTIBODY || stages[0].dyn != MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER)
+      throw std::runtime_error("simulate: only contact-constrained whole-body dynamics are supported");
+    const int n = dims.ndx, nu = dims.nu, nx = dims.nx;
+    StageDesc sd = stages[0];
+    sd.params[sd.dyn_poff] = dt;
+    sd.terms.clear(); sd.nc = 0;
+    std::vector<double> x = x_start ? std::vector<double>(x_start, x_start + nx) : in.x0;
+    Knot kn;
+    kn.resize(n, nu, 0, nx);
+    for (int sstep = 0; sstep < substeps; ++sstep) {
+      ORC_EVAL_MULTIBODY(model, sd, nu, x.data(), tau, x.data(), kn, false);
+      x = kn.xnext;
+    }
+    if (wrench) std::memcpy(wrench, kn.wrench, 12 * sizeof(double));
+    in.x0 = x;
+  }
+
   // SolverProxDDP::run for one instance (xs/us already installed)
   void run_instance(Instance& in) {
     if (opt.force_initial_condition) in.xs[0] = in.x0;

@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Drop-in check: run the reference's OWN scripts against this repo's ``aligator`` mirror and turn what they do into fixtures.
+
+BUILD-CONTAINER TOOL.  It needs the reference checkout (``/root/reference`` or ``$MPC_REFERENCE_DIR``) and does nothing without it.  The
+script text, ``talos_utils.py`` and ``QP_utils.py`` are read / imported from there at run time — nothing of the reference is copied into
+this repo; the fixtures hold numbers only (lowered stage tables, their digests, states, trajectories).
+
+What runs: ``fulldynamic_talos.py``, ``kinodynamic_talos.py``, ``centroidal_talos.py`` UNMODIFIED, from their first line through the cold
+solve and ``--ticks`` iterations of their MPC loops (the loop is stopped from outside: the headless simulator stand-in ends the run after
+10 x ticks low-level steps).  The packages the scripts import and that cannot be installed here are replaced by stand-ins
+(tools/dropin/README.md): ``pinocchio`` -> ``mpc_benchmark_amd.robot.minipin`` on the synthetic Talos, ``example_robot_data`` /
+``ndcurves`` / ``proxsuite`` -> ``tools/dropin``, ``bullet_robot`` -> ``mpc_benchmark_amd.bullet_robot`` (headless), ``aligator`` -> the
+mirror under test.  The native library is the CPU oracle (there is no GPU in the build container): the recorded trajectories are the
+ORACLE's, and the ``-m gpu`` tests hold the HIP library to them (tests/test_dropin_fixtures.py).
+
+What is written (``tests/golden/dropin_<script>.npz``):
+  * construction   x0, schedule length, solver attributes, the lowered tables (int32 descriptor, float64 parameters) of the problem as
+                   the script built it (knots 0, N/2, N - 1 and the terminal node in full, a SHA-256 digest of every node) and of every
+                   ``stages_full[t]`` (digest of each, full tables of a sample) — tests hold ``mpc_benchmark_amd/problems/*.py`` to them
+                   bit for bit;
+  * cold solve     results.xs / us / controlFeedbacks()[0], iteration count;
+  * MPC ticks      per tick: the measured state the references were planned from, ``problem.x0_init``, the digest of every node's
+                   tables as uploaded for that solve, and results.xs / us / K_0 — tests replay the ticks through
+                   ``mpc_benchmark_amd/problems/walking_loop.py`` (this repo's restatement of the loop bodies) and compare.
+
+usage:  python tools/check_dropin.py [--scripts fulldynamic,kinodynamic,centroidal] [--ticks 20] [--out tests/golden]
+"""
+import argparse
+import contextlib
+import hashlib
+import io
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("MPC_REFERENCE_DIR", "/root/reference")
+SCRIPTS = {"fulldynamic": "fulldynamic_talos.py", "kinodynamic": "kinodynamic_talos.py", "centroidal": "centroidal_talos.py"}
+
+
+def digest(desc, params):
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(desc, dtype=np.int32).tobytes())
+    h.update(np.ascontiguousarray(params, dtype=np.float64).tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8).copy()
+
+
+class Recorder:
+    """Hooks of the solver mirror: what the script hands to setup / run and what it gets back."""
+
+    def __init__(self):
+        self.first = None       # tables of the problem at the first setup
+        self.runs = []          # one dict per solver.run
+        self.ns = None          # the script's namespace (to read x_measured)
+        self.solver = None
+
+    def tables(self, solver, problem):
+        return [solver._node(problem, k)._lowered for k in range(problem.num_steps + 1)]
+
+
+def install_standins(library, rec):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools", "dropin"))
+    import mpc_benchmark_amd
+    from mpc_benchmark_amd import bullet_robot as headless
+    from mpc_benchmark_amd.aligator import _solver as mirror_solver
+    from mpc_benchmark_amd.robot import minipin
+    ali = mpc_benchmark_amd.install_as_aligator()
+    sys.modules["pinocchio"] = minipin
+    import example_robot_data  # noqa: F401  (tools/dropin)
+    import ndcurves  # noqa: F401
+    import proxsuite
+    proxsuite.set_library(library)
+
+    class RecordingSolver(mirror_solver.SolverProxDDP):
+        def __init__(self, *a, **k):
+            k.setdefault("_native_library", library)
+            super().__init__(*a, **k)
+            rec.solver = self
+
+        def setup(self, problem):
+            super().setup(problem)
+            if rec.first is None:
+                rec.first = [(d.copy(), p.copy()) for d, p in rec.tables(self, problem)]
+
+        def run(self, problem, xs_init=None, us_init=None):
+            item = {"x0_init": np.array(problem.x0_init, dtype=float), "xs_init": np.array(xs_init, dtype=float), "us_init": np.array(us_init, dtype=float),
+                    "max_iters": int(self.max_iters)}
+            t0 = time.time()
+            ok = super().run(problem, xs_init, us_init)
+            item["seconds"] = time.time() - t0
+            tabs = rec.tables(self, problem)
+            item["digests"] = np.stack([digest(d, p) for d, p in tabs])
+            item["tables"] = [(d.copy(), p.copy()) for d, p in tabs]
+            r = self.results
+            item.update(xs=np.array(r.xs), us=np.array(r.us), K0=np.array(r.controlFeedbacks()[0]), num_iters=int(r.num_iters), conv=bool(r.conv),
+                        prim_infeas=float(r.prim_infeas), dual_infeas=float(r.dual_infeas))
+            ns = rec.ns or {}
+            if "x_measured" in ns:
+                item["x_measured"] = np.array(ns["x_measured"], dtype=float)
+            rec.runs.append(item)
+            return ok
+
+    ali.SolverProxDDP = RecordingSolver
+    devices = []
+
+    class HeadlessRobot(headless.BulletRobot):
+        def __init__(self, *a, **k):
+            k.setdefault("library", library)
+            super().__init__(*a, **k)
+            devices.append(self)
+
+    mod = types.ModuleType("bullet_robot")
+    mod.BulletRobot = HeadlessRobot
+    sys.modules["bullet_robot"] = mod
+    if REF not in sys.path:
+        sys.path.append(REF)  # talos_utils.py, QP_utils.py: the reference's own files
+    return devices
+
+
+def run_script(name, ticks, library, verbose=False):
+    """-> (Recorder, namespace, seconds).  Executes the reference script text in a fresh namespace until the device stand-in stops it."""
+    rec = Recorder()
+    for m in ("talos_utils", "QP_utils", "bullet_robot"):
+        sys.modules.pop(m, None)
+    devices = install_standins(library, rec)
+    path = os.path.join(REF, SCRIPTS[name])
+    with open(path) as f:
+        text = f.read()
+    ns = {"__name__": "__dropin__", "__file__": path}
+    rec.ns = ns
+    import mpc_benchmark_amd.bullet_robot as headless
+    orig_init = headless.BulletRobot.initializeJoints
+
+    def init_and_budget(self, q):
+        orig_init(self, q)
+        self.max_steps = 10 * ticks
+
+    headless.BulletRobot.initializeJoints = init_and_budget
+    out = io.StringIO()
+    t0 = time.time()
+    try:
+        with contextlib.redirect_stdout(sys.stdout if verbose else out):
+            exec(compile(text, path, "exec"), ns)
+        stopped = "script ran to its end"
+    except StopIteration as e:
+        stopped = str(e)
+    finally:
+        headless.BulletRobot.initializeJoints = orig_init
+    secs = time.time() - t0
+    rec.stopped, rec.devices = stopped, devices
+    return rec, ns, secs
+
+
+def lower_stage_list(stages):
+    """Lowered tables of free-standing StageModels (``stages_full``) in a fresh context each: what replaceStageCircular uploads."""
+    from mpc_benchmark_amd.aligator import _core as core
+    out = []
+    ctx = core.LoweringContext()
+    for st in stages:
+        out.append(core.lower_stage(ctx, st.cost, st.dynamics, st.constraints))
+    return out, ctx
+
+
+def build_fixture(name, rec, ns):
+    fx = {}
+    solver = rec.solver
+    N = len(rec.first) - 1
+    fx["horizon"] = np.int64(N)
+    fx["schedule_len"] = np.int64(len(ns["stages_full"]))
+    fx["x0"] = np.array(rec.runs[0]["x0_init"])
+    fx["solver_attrs"] = np.array([solver.target_tol, solver.mu_init, float(solver.num_threads), float(solver.rollout_type), float(solver.linear_solver_choice),
+                                   float(solver.force_initial_condition)])
+    fx["contact_phases"] = np.array(ns["contact_phases"], dtype=np.int8)
+    # construction: the problem as built
+    fx["problem_digests"] = np.stack([digest(d, p) for d, p in rec.first])
+    for k in sorted({0, N // 2, N - 1, N}):
+        fx["problem_desc_%d" % k], fx["problem_params_%d" % k] = rec.first[k]
+    full, ctx = lower_stage_list(ns["stages_full"])
+    fx["stages_full_digests"] = np.stack([digest(d, p) for d, p in full])
+    T = len(full)
+    sample = sorted(set([0, 1, T - 1] + list(range(0, T, 37))))
+    fx["stages_full_sample"] = np.array(sample, dtype=np.int64)
+    for t in sample:
+        fx["stages_full_desc_%d" % t], fx["stages_full_params_%d" % t] = full[t]
+    if solver._ctx.model is not None:  # (the centroidal OCP has no robot model: VectorSpace(9))
+        fx["model_itab"], fx["model_dtab"] = solver._ctx.model_tables()
+    # cold solve
+    cold = rec.runs[0]
+    fx["cold_xs"], fx["cold_us"], fx["cold_K0"] = cold["xs"], cold["us"], cold["K0"]
+    fx["cold_iters"] = np.int64(cold["num_iters"])
+    fx["cold_conv"] = np.int64(cold["conv"])
+    fx["cold_infeas"] = np.array([cold["prim_infeas"], cold["dual_infeas"]])
+    # ticks
+    ticks = rec.runs[1:]
+    fx["n_ticks"] = np.int64(len(ticks))
+    if ticks:
+        fx["tick_x0_init"] = np.stack([r["x0_init"] for r in ticks])
+        fx["tick_x_measured"] = np.stack([r["x_measured"] for r in ticks])
+        fx["tick_xs"] = np.stack([r["xs"] for r in ticks])
+        fx["tick_us"] = np.stack([r["us"] for r in ticks])
+        fx["tick_K0"] = np.stack([r["K0"] for r in ticks])
+        fx["tick_digests"] = np.stack([r["digests"] for r in ticks])
+        fx["tick_iters"] = np.array([r["num_iters"] for r in ticks], dtype=np.int64)
+        # consistency of the recorded warm starts with "previous solution shifted by one knot, xs[0] = x0_init" (fulldynamic_talos.py:532-536)
+        prev = cold
+        for r in ticks:
+            xs_w = np.vstack((prev["xs"][1:], prev["xs"][-1:]))
+            xs_w[0] = r["x0_init"]
+            us_w = np.vstack((prev["us"][1:], prev["us"][-1:]))
+            assert np.array_equal(xs_w, r["xs_init"]) and np.array_equal(us_w, r["us_init"]), "warm start is not the shifted previous solution"
+            prev = r
+        for t in sorted({0, len(ticks) // 2, len(ticks) - 1}):
+            for k in sorted({0, N // 2, N - 1, N}):
+                fx["tick%d_desc_%d" % (t, k)], fx["tick%d_params_%d" % (t, k)] = ticks[t]["tables"][k]
+    return fx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scripts", default="fulldynamic,kinodynamic,centroidal")
+    ap.add_argument("--ticks", type=int, default=20)
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    if not os.path.isdir(REF):
+        print("check_dropin: no reference checkout at %s: nothing to do." % REF)
+        return 0
+    sys.path.insert(0, ROOT)
+    from tests import _oracle
+    lib = _oracle.load()
+    os.makedirs(a.out, exist_ok=True)
+    for name in a.scripts.split(","):
+        rec, ns, secs = run_script(name, a.ticks, lib, a.verbose)
+        n_ticks = len(rec.runs) - 1
+        cold = rec.runs[0]
+        print("%-12s %s executed unmodified: cold solve %d iterations (converged %s, infeasibilities %.2e / %.2e, %.1f s), %d MPC ticks; stopped by: %s  [%.0f s]"
+              % (name, SCRIPTS[name], cold["num_iters"], cold["conv"], cold["prim_infeas"], cold["dual_infeas"], cold["seconds"], n_ticks, rec.stopped, secs))
+        if n_ticks < a.ticks:
+            print("  !! only %d of %d ticks ran" % (n_ticks, a.ticks))
+            return 1
+        fx = build_fixture(name, rec, ns)
+        path = os.path.join(a.out, "dropin_%s.npz" % name)
+        np.savez_compressed(path, **fx)
+        print("  -> %s (%.0f KB): %d nodes, %d stages_full, %d ticks" % (path, os.path.getsize(path) / 1024.0, fx["horizon"] + 1, fx["schedule_len"], n_ticks))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
