@@ -77,7 +77,9 @@ int mpc_qp_solve(mpc_qp_solver* s, const mpc_qp_settings* settings, const double
  * mpc_qp_set_model: the same two tables as mpc_set_model (include/mpc_abi.h, MPC_MODEL_* layout).
  * mpc_qp_solve_id: the handle must have n = 2 nv - 6 + 6 nk, neq = nv + 6 nk, nin = 9 nk, box = 0.
  *   frames[nk]: model frame indices of the contacts; weights[2]: the diagonal weights of H on da and on df
- *   (QP_utils.py:98-103; the torque block is zero); cone[9][6]: the wrench-cone rows Cmin (QP_utils.py:76-92);
+ *   (QP_utils.py:98-103; the torque block is zero); cone[2][9][6]: the wrench-cone rows Cmin that go into C (QP_utils.py:466-490), then the rows cone_l that
+ *   form the lower bound l = - cone_l f (QP_utils.py:538-548 writes l out by hand: its rows 2, 3 are f_y -+ mu f_z although rows 2, 3 of Cmin repeat
+ *   the f_x rows — pass both as the reference has them for a bit-for-bit drop-in, or twice the same matrix for a consistent cone);
  *   kd: Baumgarte velocity gain (QP_utils.py:105); xrob[B][nq+nv], acc[B][nv], forces[B][6 nk],
  *   contact_states[B][nk] (0/1).  Outputs x[B][n] = (da, df, tau), y, z (may be NULL), info[B]; A_out / b_out /
  *   C_out / l_out (may be NULL) read the assembled matrices back for inspection. */
@@ -91,7 +93,7 @@ int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* settings, int32_t n
  * (a, df, tau); posture, foot-acceleration, centroidal-momentum-rate and base / torso orientation tasks in the cost, dynamics and
  * contact-acceleration equalities, wrench cones, torque box.  The handle must have n = 2 nv - 6 + 6 nk, neq = nv + 6 nk, nin = 9 nk,
  * box = 1, nk = 2.  weights[5] (posture, feet, momentum, orientation, force increments); gains: Kp, Kd of the posture task (nv x nv
- * each, row-major), of the foot tasks (6 x 6 each), of the orientation tasks (3 x 3 each); l_box / u_box [n] (the torque box, +-inf
+ * each, row-major), of the foot tasks (6 x 6 each), of the orientation tasks (3 x 3 each); cone[2][9][6] as in mpc_qp_solve_id; l_box / u_box [n] (the torque box, +-inf
  * elsewhere as large numbers); ik[B][2 nv + 42] per robot: q_diff, dq_diff | per contact: pose error (6), its rate (6) | base_diff,
  * dbase_diff, torso_diff, dtorso_diff (3 each) | dH (6): the task errors the script computes from its references.  Outputs as
  * mpc_qp_solve plus the assembled H, g, A, b, C, l (each may be NULL). */

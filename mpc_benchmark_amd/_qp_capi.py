@@ -103,15 +103,24 @@ class BatchedQP:
             raise RuntimeError("mpc_qp_set_model: " + self.lib.mpc_qp_last_error(self._h).decode())
         self._nqv, self._nv = int(itab[1]) + int(itab[2]), int(itab[2])
 
-    def solve_id(self, frames, weights, cone, kd, xrob, acc, forces, contact_states, return_matrices=False):
-        """-> x, y, z, info (, (A, b, C, l) as assembled on the device)."""
+    @staticmethod
+    def _cone_pair(cone, cone_l):
+        cone = np.ascontiguousarray(cone, dtype=np.float64)
+        if cone.shape != (9, 6):
+            raise ValueError("cone must be 9 x 6")
+        cone_l = cone if cone_l is None else np.ascontiguousarray(cone_l, dtype=np.float64)
+        if cone_l.shape != (9, 6):
+            raise ValueError("cone_l must be 9 x 6")
+        return np.ascontiguousarray(np.stack([cone, cone_l]))
+
+    def solve_id(self, frames, weights, cone, kd, xrob, acc, forces, contact_states, return_matrices=False, cone_l=None):
+        """-> x, y, z, info (, (A, b, C, l) as assembled on the device).  ``cone``: the rows of C; ``cone_l``: the rows that form
+        l = - cone_l f (default: the same)."""
         d = self.dims
         B, n, neq, nin = d.batch, d.n, d.neq, d.nin
         frames = np.ascontiguousarray(frames, dtype=np.int32); nk = frames.size
         weights = np.ascontiguousarray(weights, dtype=np.float64)[:2].copy()
-        cone = np.ascontiguousarray(cone, dtype=np.float64)
-        if cone.shape != (9, 6):
-            raise ValueError("cone must be 9 x 6")
+        cone = self._cone_pair(cone, cone_l)
         xrob = np.ascontiguousarray(np.broadcast_to(np.asarray(xrob, dtype=np.float64), (B, self._nqv)))
         nv = self._nv
         acc = np.ascontiguousarray(np.broadcast_to(np.asarray(acc, dtype=np.float64), (B, nv)))
@@ -130,15 +139,16 @@ class BatchedQP:
             return x, y, z, list(info), mats
         return x, y, z, list(info)
 
-    def solve_ikid(self, frames, base_frame, torso_frame, weights, gains, cone, l_box, u_box, xrob, ik, forces, contact_states, return_matrices=False):
+    def solve_ikid(self, frames, base_frame, torso_frame, weights, gains, cone, l_box, u_box, xrob, ik, forces, contact_states, return_matrices=False,
+                   cone_l=None):
         """mpc_qp_solve_ikid -> x, y, z, z_box, info (, (H, g, A, b, C, l) as assembled by the library)."""
         d = self.dims
         B, n, neq, nin = d.batch, d.n, d.neq, d.nin
         frames = np.ascontiguousarray(frames, dtype=np.int32); nk = frames.size
         nv = self._nv
         f64 = lambda a, shape=None: np.ascontiguousarray(a if shape is None else np.broadcast_to(np.asarray(a, dtype=np.float64), shape), dtype=np.float64)
-        weights, gains, cone, l_box, u_box = f64(weights), f64(gains), f64(cone), f64(l_box), f64(u_box)
-        if weights.size != 5 or gains.size != 2 * nv * nv + 90 or cone.shape != (9, 6) or l_box.size != n or u_box.size != n:
+        weights, gains, cone, l_box, u_box = f64(weights), f64(gains), self._cone_pair(cone, cone_l), f64(l_box), f64(u_box)
+        if weights.size != 5 or gains.size != 2 * nv * nv + 90 or l_box.size != n or u_box.size != n:
             raise ValueError("solve_ikid: weights[5], gains[2 nv^2 + 90], cone[9][6], l_box / u_box [n] expected")
         xrob = f64(xrob, (B, self._nqv)); ik = f64(ik, (B, 2 * nv + 42)); forces = f64(forces, (B, 6 * nk))
         cs = np.ascontiguousarray(np.broadcast_to(np.asarray(contact_states, dtype=np.int32), (B, nk)))

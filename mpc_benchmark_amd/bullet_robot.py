@@ -7,8 +7,8 @@ What it simulates: the CONTROLLED joints of the complete model (the others stay 
 ``initializeJoints`` — in PyBullet they are held by the default position controller, bullet_robot.py:71-73), one semi-implicit Euler step
 of ``simuStep`` per ``execute(torques)``, with the feet that stand on the ground held by 6-D rigid contacts with Baumgarte correction
 (the contact model of fulldynamic_talos.py:84-96).  A foot is "on the ground" while its sole is within ``ground_tol`` of the ground
-plane z = 0 ... and pushes on it: a contact whose normal force turns negative is released, a free foot that comes down to the ground is
-caught there (its world-side placement is re-captured at the landing pose).  That is a deliberately simple contact rule — enough to
+plane z = 0 ... and pushes on it: a contact whose normal force turns negative is released, a free foot that has left the ground and comes back
+to it is caught there (its world-side placement is re-captured at the landing pose).  That is a deliberately simple contact rule — enough to
 close the loop around the MPC headlessly and deterministically; it is not a physics engine.
 
 Differences from PyBullet worth knowing: ``measureState`` returns the base velocity in the LOCAL frame of the base (Pinocchio's
@@ -26,8 +26,10 @@ from .robot import minipin as pin
 
 
 class BulletRobot:
+    record_default = False  # tools: keep (state, contact flags, sole heights) of every step in ``history``
+
     def __init__(self, controlledJoints, modelPath=None, URDF_filename=None, simuStep=1e-3, rmodelComplete=None, robotPose=(0.0, 0.0, 1.01927),
-                 inertiaOffset=True, talos=True, library=None, contact_frames=("left_sole_link", "right_sole_link"), ground_tol=2e-3):
+                 inertiaOffset=True, talos=True, library=None, contact_frames=("left_sole_link", "right_sole_link"), ground_tol=5e-3):
         if rmodelComplete is None:
             raise ValueError("the complete robot model is needed (5th positional argument, as in the scripts)")
         self._lib = library
@@ -45,7 +47,7 @@ class BulletRobot:
         self.steps = 0
         self.max_steps = None      # tools: stop a script's endless loop after this many execute() calls
         self.history = []          # (q, v) after every step when ``record`` is set
-        self.record = False
+        self.record = bool(self.record_default)
 
     # -- model ------------------------------------------------------------------------------------------------------------------
     def initializeJoints(self, q0CompleteStart):
@@ -70,6 +72,7 @@ class BulletRobot:
         self.ground_z = min(float(self.data.oMf[f].translation[2]) for f in self.frame_ids)
         self.in_contact = [True, True]
         self._z_prev = [float(self.data.oMf[f].translation[2]) for f in self.frame_ids]
+        self._lifted = [False, False]
         self._contact_pose = [self.data.oMf[f].copy() for f in self.frame_ids]
         self._build_native()
 
@@ -140,7 +143,7 @@ class BulletRobot:
         self.steps += 1
         self._update_contacts(wr[0])
         if self.record:
-            self.history.append(self.x.copy())
+            self.history.append((self.x.copy(), tuple(self.in_contact), tuple(self._z_prev)))
 
     def _update_contacts(self, wrenches):
         """Unilateral contact by rule: an active contact whose normal force turned negative is released (the ground cannot pull); a free
@@ -153,7 +156,10 @@ class BulletRobot:
             if self.in_contact[i]:
                 if wrenches[i][2] < 0.0 and sum(self.in_contact) > 1:
                     self.in_contact[i] = False
-            elif z <= self.ground_z + self.ground_tol and z < self._z_prev[i]:
+                    self._lifted[i] = False
+            elif z > self.ground_z + 2.0 * self.ground_tol:
+                self._lifted[i] = True  # (a released foot is caught again only after it has really left the ground)
+            elif z <= self.ground_z + self.ground_tol and self._lifted[i]:
                 pose = self.data.oMf[fid].copy()
                 pose.translation[2] = self.ground_z
                 yaw = np.arctan2(pose.rotation[1, 0], pose.rotation[0, 0])

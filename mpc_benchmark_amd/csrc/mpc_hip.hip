@@ -1375,7 +1375,8 @@ int mpc_revive_instance(mpc_solver* s, int32_t dst, int32_t src) {
     };
     row(s->d_xs, (size_t)(L.N + 1) * L.nx); row(s->d_us, (size_t)L.N * L.m);
     row(s->d_vs, (size_t)(L.N + 1) * L.c); row(s->d_vs_e, (size_t)(L.N + 1) * L.c);
-    row(s->d_lams, (size_t)(L.N + 2) * L.n); row(s->d_lams_e, (size_t)(L.N + 2) * L.n);
+    // the co-state multipliers are indexed (b (N + 1) + k) n by every kernel and by mpc_get_results (the buffers merely carry B n doubles of slack)
+    row(s->d_lams, (size_t)(L.N + 1) * L.n); row(s->d_lams_e, (size_t)(L.N + 1) * L.n);
     row(s->d_x0, (size_t)L.nx);
     HIP_OK(hipMemcpyAsync(s->d_inst + dst, s->d_inst + src, sizeof(InstState), hipMemcpyDeviceToDevice, s->stream));
     if (s->d_spec) HIP_OK(hipMemsetAsync(s->d_spec + dst, 0, sizeof(int), s->stream));  // its knot records belong to the old iterate

@@ -18,7 +18,7 @@ struct QpAssembleArgs {
   const double* f;     // [B][6 nk] contact forces of the MPC solution
   const int32_t* cs;   // [B][nk]  contact states
   const int32_t* frames;  // [nk] contact frame indices in the model's frame table
-  const double* cone;  // [9][6] rows of Cmin
+  const double* cone;  // [2][9][6]: rows of Cmin (-> C), then the rows that form l = - cone_l f (QP_utils.py:538-548 writes l out by hand: its rows 2, 3 use f_y)
   double kd;
   int nk, n, neq, nin;
   double *A, *b, *C, *l;  // [B][neq][n], [B][neq], [B][nin][n], [B][nin]
@@ -150,7 +150,7 @@ DEV void qpa_ikid_tail(const QpAssembleArgs& a, int bi, int tid, int nthr, int n
   for (int idx = tid; idx < 9 * nk; idx += nthr) {
     const int c = idx / 9, i = idx % 9;
     double s = 0;
-    if (cs[c]) for (int j = 0; j < 6; ++j) { s -= a.cone[6 * i + j] * f[6 * c + j]; C[(size_t)idx * n + nv + 6 * c + j] = a.cone[6 * i + j]; }
+    if (cs[c]) for (int j = 0; j < 6; ++j) { s -= a.cone[54 + 6 * i + j] * f[6 * c + j]; C[(size_t)idx * n + nv + 6 * c + j] = a.cone[6 * i + j]; }
     l[idx] = s;
   }
 }
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(QPA_THREADS) k_qp_assemble(QpAssembleArgs a) {
   for (int idx = tid; idx < 9 * nk; idx += nthr) {
     const int c = idx / 9, i = idx % 9;
     double s = 0;
-    if (cs[c]) for (int j = 0; j < 6; ++j) { s -= a.cone[6 * i + j] * f[6 * c + j]; C[(size_t)idx * n + nv + 6 * c + j] = a.cone[6 * i + j]; }
+    if (cs[c]) for (int j = 0; j < 6; ++j) { s -= a.cone[54 + 6 * i + j] * f[6 * c + j]; C[(size_t)idx * n + nv + 6 * c + j] = a.cone[6 * i + j]; }
     l[idx] = s;
   }
 }

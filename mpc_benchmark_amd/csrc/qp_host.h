@@ -1,7 +1,25 @@
 // qp_host.h — host side of the batched QP solver (include/mpc_qp_abi.h) for the HIP library; included by mpc_hip.hip.
 #pragma once
+#include <atomic>
 #include "qp_kernel.h"
 #include "qp_assemble.h"
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device, per-kernel setting shared by all handles: keep the LARGEST request so
+// far (a second handle with a smaller problem must not lower the limit under a handle that is still in use)
+#include <map>
+#include <mutex>
+static void qp_lds_attr_max(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> have;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  int& h = have[{dev, fn}];
+  if (h < bytes) {
+    HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    h = bytes;
+  }
+}
 
 struct mpc_qp_solver {
   mpc_qp_dims d{};
@@ -81,7 +99,7 @@ int mpc_qp_create(const mpc_qp_dims* dims, mpc_qp_solver** out) {
     s->dinfo = s->alloc<mpc_qp_info>(B);
     for (const void* fn : {(const void*)k_qp_solve<0, false>, (const void*)k_qp_solve<1, false>, (const void*)k_qp_solve<0, true>, (const void*)k_qp_solve<1, true>,
                            (const void*)k_qp_solve<2, true>})
-      HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, s->lds.total_bytes));  // (the kernels keep a static int beside the dynamic carve-out)
+      qp_lds_attr_max(fn, s->lds.total_bytes);  // (the kernels keep a static int beside the dynamic carve-out)
     HIP_OK(hipStreamSynchronize(s->stream));
   } catch (const std::exception& e) {
     fprintf(stderr, "mpc_qp_create: %s\n", e.what());
@@ -118,6 +136,7 @@ int mpc_qp_solve(mpc_qp_solver* s, const mpc_qp_settings* S, const double* H, co
     const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin, m = nin + (d.box ? n : 0);
     auto up = [&](double* dst, const double* src, size_t cnt) { if (cnt) HIP_OK(hipMemcpyAsync(dst, src, cnt * sizeof(double), hipMemcpyHostToDevice, s->stream)); };
     s->id_const_uploaded = false;  // H, g, u of a later mpc_qp_solve_id are uploaded again
+    s->ikid_const.clear();         // ... and u, l_box, u_box of a later mpc_qp_solve_ikid
     up(s->dH, H, B * n * n); up(s->dg, g, B * n); up(s->dA, A, B * neq * n); up(s->db, b, B * neq);
     up(s->dC, C, B * nin * n); up(s->dl, l, B * nin); up(s->du, u, B * nin);
     if (d.box) { up(s->dlb, l_box, B * n); up(s->dub, u_box, B * n); }
@@ -174,15 +193,15 @@ int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, cons
     const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin;
     if (!s->d_xrob || s->id_nk != nk) {
       s->d_xrob = s->alloc<double>(B * (nq + nv)); s->d_acc = s->alloc<double>(B * nv); s->d_f = s->alloc<double>(B * 6 * nk);
-      s->d_cs = s->alloc<int32_t>(B * nk); s->d_frames = s->alloc<int32_t>(nk); s->d_cone = s->alloc<double>(54);
+      s->d_cs = s->alloc<int32_t>(B * nk); s->d_frames = s->alloc<int32_t>(nk); s->d_cone = s->alloc<double>(108);
       s->id_nk = nk; s->id_const_uploaded = false;
-      HIP_OK(hipFuncSetAttribute((const void*)k_qp_assemble<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qp_assemble_lds_bytes(s->m_nj, nv, nq, nk)));
+      qp_lds_attr_max((const void*)k_qp_assemble<false>, (int)qp_assemble_lds_bytes(s->m_nj, nv, nq, nk));
     }
     // the constant parts: H = diag(w0 I_nv, w1 I_6nk, 0), g = 0, u = 1e5 (as the reference), frames, cone rows: uploaded when they change
-    std::vector<double> key(56 + nk);
+    std::vector<double> key(110 + nk);
     key[0] = weights[0]; key[1] = weights[1];
-    for (int i = 0; i < 54; ++i) key[2 + i] = cone[i];
-    for (int c = 0; c < nk; ++c) key[56 + c] = frames[c];
+    for (int i = 0; i < 108; ++i) key[2 + i] = cone[i];
+    for (int c = 0; c < nk; ++c) key[110 + c] = frames[c];
     if (!s->id_const_uploaded || key != s->id_const) {
       std::vector<double> H(n * n, 0.0), g(n, 0.0), u(nin, 1e5);
       for (int i = 0; i < nv; ++i) H[(size_t)i * n + i] = weights[0];
@@ -193,7 +212,7 @@ int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, cons
         HIP_OK(hipMemcpyAsync(s->du + bi * nin, u.data(), nin * sizeof(double), hipMemcpyHostToDevice, s->stream));
       }
       HIP_OK(hipMemcpyAsync(s->d_frames, frames, nk * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
-      HIP_OK(hipMemcpyAsync(s->d_cone, cone, 54 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      HIP_OK(hipMemcpyAsync(s->d_cone, cone, 108 * sizeof(double), hipMemcpyHostToDevice, s->stream));
       HIP_OK(hipStreamSynchronize(s->stream));  // (host vectors go out of scope)
       s->id_const = key; s->id_const_uploaded = true;
     }
@@ -243,18 +262,18 @@ int mpc_qp_solve_ikid(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, co
     if (!s->d_ik || s->ikid_nk != nk) {
       if (!s->d_xrob || s->id_nk != nk) {
         s->d_xrob = s->alloc<double>(B * (nq + nv)); s->d_acc = s->alloc<double>(B * nv); s->d_f = s->alloc<double>(B * 6 * nk);
-        s->d_cs = s->alloc<int32_t>(B * nk); s->d_frames = s->alloc<int32_t>(nk); s->d_cone = s->alloc<double>(54);
+        s->d_cs = s->alloc<int32_t>(B * nk); s->d_frames = s->alloc<int32_t>(nk); s->d_cone = s->alloc<double>(108);
         s->id_nk = nk;
       }
       s->d_ik = s->alloc<double>(B * nik); s->d_gains = s->alloc<double>(ngain); s->d_w = s->alloc<double>(8);
       s->ikid_nk = nk; s->ikid_const.clear();
-      HIP_OK(hipFuncSetAttribute((const void*)k_qp_assemble<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qp_assemble_lds_bytes(s->m_nj, nv, nq, nk, true)));
+      qp_lds_attr_max((const void*)k_qp_assemble<true>, (int)qp_assemble_lds_bytes(s->m_nj, nv, nq, nk, true));
     }
     s->id_const_uploaded = false;  // (H, g, u of a later mpc_qp_solve_id are uploaded again)
     // constants: weights, gains, cone rows, frames, the torque box and u = 1e5 — uploaded when they change
     std::vector<double> key;
     key.reserve(5 + ngain + 54 + 2 * n + nk + 2);
-    key.insert(key.end(), weights, weights + 5); key.insert(key.end(), gains, gains + ngain); key.insert(key.end(), cone, cone + 54);
+    key.insert(key.end(), weights, weights + 5); key.insert(key.end(), gains, gains + ngain); key.insert(key.end(), cone, cone + 108);
     key.insert(key.end(), l_box, l_box + n); key.insert(key.end(), u_box, u_box + n);
     for (int c = 0; c < nk; ++c) key.push_back(frames[c]);
     key.push_back(base_frame); key.push_back(torso_frame);
@@ -262,7 +281,7 @@ int mpc_qp_solve_ikid(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, co
       std::vector<double> u(nin, 1e5);
       HIP_OK(hipMemcpyAsync(s->d_w, weights, 5 * sizeof(double), hipMemcpyHostToDevice, s->stream));
       HIP_OK(hipMemcpyAsync(s->d_gains, gains, ngain * sizeof(double), hipMemcpyHostToDevice, s->stream));
-      HIP_OK(hipMemcpyAsync(s->d_cone, cone, 54 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      HIP_OK(hipMemcpyAsync(s->d_cone, cone, 108 * sizeof(double), hipMemcpyHostToDevice, s->stream));
       HIP_OK(hipMemcpyAsync(s->d_frames, frames, nk * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
       for (size_t bi = 0; bi < B; ++bi) {
         HIP_OK(hipMemcpyAsync(s->du + bi * nin, u.data(), nin * sizeof(double), hipMemcpyHostToDevice, s->stream));

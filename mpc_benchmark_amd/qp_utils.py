@@ -21,6 +21,15 @@ from ._qp_capi import BatchedQP
 from .robot import dynamics as dyn
 
 
+def wrench_cone_bound_rows(mu, L, W, force_size=6):
+    """The rows that form the lower bound l = - rows @ f.  The reference writes l out by hand (QP_utils.py:538-548) with rows 2, 3 =
+    f_y -+ mu f_z, while rows 2, 3 of its ``Cmin`` repeat the f_x rows (:466-490): C and l are kept exactly as the reference has them
+    (a drop-in, not a repaired cone: the lateral friction |f_y| <= mu f_z is NOT constrained by that QP either)."""
+    R = wrench_cone_rows(mu, L, W, force_size)
+    R[2, :2], R[3, :2] = (0.0, -1.0), (0.0, 1.0)
+    return R
+
+
 def wrench_cone_rows(mu, L, W, force_size=6):
     """The 9 rows per contact of QP_utils.py:466-490: |fx|, |fy| <= mu fz ; fz >= 0 ; |tau_x| <= W fz ; |tau_y| <= L fz."""
     if force_size == 3:
@@ -40,6 +49,7 @@ class IDSolver_ulim:
         self.n, self.neq, self.nin = 2 * nv - 6 + fs * nk, nv + fs * nk, 9 * nk
         self.S = np.zeros((nv, nv - 6)); self.S[6:] = np.eye(nv - 6)
         self.Cmin = wrench_cone_rows(mu, L, W, fs)
+        self.Cl = wrench_cone_bound_rows(mu, L, W, fs)
         self.H = np.zeros((self.n, self.n))
         self.H[:nv, :nv] = np.eye(nv) * weights[0]
         self.H[nv:nv + fs * nk, nv:nv + fs * nk] = np.eye(fs * nk) * weights[1]
@@ -69,7 +79,7 @@ class IDSolver_ulim:
         C = np.zeros((self.nin, self.n)); l = np.zeros(self.nin)
         for i in range(nk):
             if cs[i]:
-                l[9 * i:9 * (i + 1)] = -self.Cmin @ forces[i * fs:(i + 1) * fs]
+                l[9 * i:9 * (i + 1)] = -self.Cl @ forces[i * fs:(i + 1) * fs]
                 C[9 * i:9 * (i + 1), nv + i * fs:nv + (i + 1) * fs] = self.Cmin
         return A, b, C, l
 
@@ -115,7 +125,7 @@ class IDSolver_ulim:
         """``x`` [B][nq+nv], ``a`` [B][nv], ``forces`` [B][6 nk], ``cs`` [B][nk] -> (a_new, new_forces, torque), each [B][...]."""
         if not hasattr(self, "_frame_idx"):
             self.enable_device_assembly()
-        out = self.qp.solve_id(self._frame_idx, self._weights, self.Cmin, float(self.baum_Kd[0, 0]), x, a, forces, cs, return_matrices=return_matrices)
+        out = self.qp.solve_id(self._frame_idx, self._weights, self.Cmin, float(self.baum_Kd[0, 0]), x, a, forces, cs, return_matrices=return_matrices, cone_l=self.Cl)
         sol, info = out[0], out[3]
         self.last_info = info
         if self.warm_start:
@@ -141,6 +151,7 @@ class IKIDSolver_f6:
         self.n, self.neq, self.nin = 2 * nv - 6 + fs * nk, nv + fs * nk, 9 * nk
         self.S = np.zeros((nv, nv - 6)); self.S[6:] = np.eye(nv - 6)
         self.Cmin = wrench_cone_rows(mu, L, W, fs)
+        self.Cl = wrench_cone_bound_rows(mu, L, W, fs)
         self.l_box = np.full(self.n, -1e5); self.u_box = np.full(self.n, 1e5)
         self.l_box[nv + fs * nk:] = -np.asarray(model.effortLimit)[6:]
         self.u_box[nv + fs * nk:] = np.asarray(model.effortLimit)[6:]
@@ -179,7 +190,7 @@ class IKIDSolver_f6:
                 A[nv + fs * i:nv + fs * (i + 1), :nv] = J[i]
                 b[:nv] += J[i].T @ forces[fs * i:fs * (i + 1)]
                 b[nv + fs * i:nv + fs * (i + 1)] = -dJv[i]
-                l[9 * i:9 * (i + 1)] = -self.Cmin @ forces[fs * i:fs * (i + 1)]
+                l[9 * i:9 * (i + 1)] = -self.Cl @ forces[fs * i:fs * (i + 1)]
                 C[9 * i:9 * (i + 1), nv + fs * i:nv + fs * (i + 1)] = self.Cmin
         return H, g, A, b, C, l
 
@@ -217,7 +228,7 @@ class IKIDSolver_f6:
         ik = np.concatenate([bc(q_diff, nv), bc(dq_diff, nv), bc(LF_diff, 6), bc(dLF_diff, 6), bc(RF_diff, 6), bc(dRF_diff, 6),
                              bc(base_diff, 3), bc(dbase_diff, 3), bc(torso_diff, 3), bc(dtorso_diff, 3), bc(dH, 6)], axis=1)
         out = self.qp.solve_ikid(self._frame_idx, self._base_idx, self._torso_idx, self.weights, self._gains, self.Cmin, self.l_box, self.u_box,
-                                 x, ik, forces, cs, return_matrices=return_matrices)
+                                 x, ik, forces, cs, return_matrices=return_matrices, cone_l=self.Cl)
         sol = out[0]
         self.last_info = out[4]
         fs, nk = self.force_size, self.nk

@@ -145,7 +145,7 @@ int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, cons
         if (!cs[c]) continue;
         for (int r = 0; r < 9; ++r) {
           double v = 0;
-          for (int j = 0; j < 6; ++j) { Cb[(size_t)(9 * c + r) * n + nv + 6 * c + j] = cone[6 * r + j]; v += cone[6 * r + j] * f0[6 * c + j]; }
+          for (int j = 0; j < 6; ++j) { Cb[(size_t)(9 * c + r) * n + nv + 6 * c + j] = cone[6 * r + j]; v += cone[54 + 6 * r + j] * f0[6 * c + j]; }
           lb[9 * c + r] = -v;
         }
       }
@@ -276,7 +276,7 @@ int mpc_qp_solve_ikid(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, co
         if (!cs[c]) continue;
         for (int r = 0; r < 9; ++r) {
           double v = 0;
-          for (int j = 0; j < 6; ++j) { Cb[(size_t)(9 * c + r) * n + nv + 6 * c + j] = cone[6 * r + j]; v += cone[6 * r + j] * f0[6 * c + j]; }
+          for (int j = 0; j < 6; ++j) { Cb[(size_t)(9 * c + r) * n + nv + 6 * c + j] = cone[6 * r + j]; v += cone[54 + 6 * r + j] * f0[6 * c + j]; }
           lbv[9 * c + r] = -v;
         }
       }

@@ -5,7 +5,10 @@ Dual quantities (rows = constraint rows: Knu, knu, dvs, Znu, Knup): the active r
 active set — e.g. more than six active rows of one 17-row wrench cone on a 6-D wrench — have multipliers that the stage KKT system
 fixes through its mu = 1e-8 regularisation only; rounding there is amplified by 1 / mu in BOTH libraries (the oracle itself is 4e-4
 from a pivoted dense KKT solve on such rows, tests/test_oracle_lq.py).  Those rows are identified from the oracle's [C D]
-(``dependent_active_rows``) and reported; every other row is held to the strict tolerance."""
+(``dependent_active_rows``) and reported; every other row is held to the strict tolerance.  What the regularisation DOES determine
+of the dependent rows is their combined action on the controls, ``D_dep^T nu_dep`` (the term of the dependent rows in the
+stage's stationarity condition in u; the dependency is one of the control columns, so the x columns are not pinned): that is compared as '<q>/dependent_combined' and held to a tight tolerance by the callers, so the
+multiplier path of those rows is not left unchecked."""
 import numpy as np
 
 from tests._metrics import dependent_active_rows, rel_rows, rel_tiles
@@ -30,7 +33,7 @@ def dual_rows(nr, k, n, nz):
     Kr = nr.debug_get("Knu", k).reshape(CD.shape[0], -1) if CD.shape[0] else np.zeros((0, n))
     kr = nr.debug_get("knu", k).ravel()[:CD.shape[0]]
     act = np.any(Kr != 0, axis=1) | (kr != 0)
-    return act, dependent_active_rows(CD, act, n)
+    return act, dependent_active_rows(CD, act, n), CD
 
 
 def compare(nh, nr, quantities, knots, n, nu, N, skip_terminal=()):
@@ -48,7 +51,7 @@ def compare(nh, nr, quantities, knots, n, nu, N, skip_terminal=()):
             if q in DUAL:
                 if masks is None:
                     masks = dual_rows(nr, k, n, nz)
-                act, dep = masks
+                act, dep, CD = masks
                 c = act.size
                 if c == 0:
                     continue
@@ -60,6 +63,9 @@ def compare(nh, nr, quantities, knots, n, nu, N, skip_terminal=()):
                     worst[q] = max(worst.get(q, 0.0), rel_rows(a2[good], b2[good], FLOOR))
                 if dep.any():
                     worst[q + "/dependent"] = max(worst.get(q + "/dependent", 0.0), rel_rows(a2[dep], b2[dep], FLOOR))
+                    ca, cb = CD[dep][:, n:].T @ a2[dep], CD[dep][:, n:].T @ b2[dep]  # (nu x cols): what the dependent multipliers do to u together
+                    e = float(np.max(np.abs(ca - cb)) / (np.max(np.abs(cb)) + FLOOR))
+                    worst[q + "/dependent_combined"] = max(worst.get(q + "/dependent_combined", 0.0), e)
             else:
                 worst[q] = max(worst.get(q, 0.0), rel_tiles(_shape(q, a, n, nz), _shape(q, b, n, nz), FLOOR))
     return worst

@@ -106,3 +106,31 @@ def test_failure_policy_and_revive_on_the_oracle(oracle_lib):
     assert all(s.converged >= 0 for s in st) and e.lost == [] and e.revived == 0
     with pytest.raises(RuntimeError):
         e.native.revive_instance(1, 1)
+
+
+def _revive_leaves_the_others_alone(lib):
+    """mpc_revive_instance(dst >= 2, src) without a following mpc_setup: dst has the iterate AND the multipliers of src, every other
+    instance keeps its own (the co-state rows are indexed (b (N + 1) + k) n: a copy with any other stride lands in the neighbours)."""
+    from mpc_benchmark_amd.ensemble import EnsembleMPC
+    from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+    pd = FullDynamicsProblem(horizon=6)
+    e = EnsembleMPC(pd, batch=4, library=lib, seed=5, sigma_q=0.01, sigma_v=0.02)
+    e.prepare_schedule(4)
+    e.cold_solve(max_iters=3)
+    before = e.native.get_results(gains=False, multipliers=True)
+    assert not np.array_equal(before["lams"][1], before["lams"][2])
+    e.native.revive_instance(2, 1)
+    after = e.native.get_results(gains=False, multipliers=True)
+    for key in ("xs", "us", "vs", "lams"):
+        for b in (0, 1, 3):
+            assert np.array_equal(after[key][b], before[key][b]), "%s of instance %d changed" % (key, b)
+        assert np.array_equal(after[key][2], before[key][1]), "%s of the revived instance is not the source's" % key
+
+
+def test_revive_keeps_the_multipliers_of_the_other_instances_oracle(oracle_lib):
+    _revive_leaves_the_others_alone(oracle_lib)
+
+
+@pytest.mark.gpu
+def test_revive_keeps_the_multipliers_of_the_other_instances_hip(hip_lib):
+    _revive_leaves_the_others_alone(hip_lib)
