@@ -70,6 +70,9 @@ class EnsembleMPC:
         self._isolate = None  # enable_failure_isolation(): (auto_revive, source)
         self.lost, self.revived = [], 0
         self._walk = None   # enable_walk(): the reference loop's per-tick problem updates
+        # solver.setup(problem) inside the loop: the full-dynamics and centroidal scripts call it every tick, the kinodynamic one does not
+        # (fulldynamic_talos.py:539, centroidal_talos.py:461, kinodynamic_talos.py:487 commented out): multipliers and penalty carry over there
+        self._setup_each_tick = bool(problem_def.walk_spec().get("setup_each_tick", True)) if hasattr(problem_def, "walk_spec") else True
 
     # -- stage tables of the schedule ---------------------------------------------------------------
     def _table_for_tick(self, t):
@@ -143,7 +146,8 @@ class EnsembleMPC:
         self.native.cycle(desc, params)
         if self._walk is not None:
             self._walk_terminal()
-        self.native.setup()
+        if self._setup_each_tick:
+            self.native.setup()
         self.tick += 1
         try:
             if self._walk is not None:
@@ -175,7 +179,8 @@ class EnsembleMPC:
         self.native.cycle(desc, params)
         if self._walk is not None:
             self._walk_terminal()
-        self.native.setup()
+        if self._setup_each_tick:
+            self.native.setup()
         self.native.run_shifted_async()
         self.tick += 1
         self.inflight += 1
@@ -241,62 +246,97 @@ class EnsembleMPC:
         return [tuple(r) for r in self.lost if r[3] is None]
 
     # -- the reference loop's per-tick problem updates on the shared stage tables ---------------------------------
-    def enable_walk(self, swing_apex=0.15, x_forward=0.0, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0, per_instance=False):
-        """From now on every tick does what the loop body of fulldynamic_talos.py:444-510 does to the problem before solving:
-        ``FootTrajectory.updateTrajectory`` from the measured foot poses, ``setReference`` on the two foot-placement costs of
-        every stage (2 N parameter patches), ``replaceStageCircular``, the terminal CoM constraint rebuilt between the last foot
-        references and the terminal foot references.  The stage tables of an ensemble are shared by its instances, so the
-        references are planned from instance 0's state (the state the last COMPLETED tick predicted: with two ticks in flight
-        that is one tick older than the reference script's measurement) and every instance tracks them.
+    def enable_walk(self, swing_apex=0.15, x_forward=None, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0, per_instance=False):
+        """From now on every tick does what the loop bodies of the scripts do to the problem before solving (fulldynamic_talos.py:444-510,
+        kinodynamic_talos.py:361-409, centroidal_talos.py:357-384): ``FootTrajectory.updateTrajectory`` from the measured foot poses, the
+        references written into every stage of the horizon (``setReference`` on the two foot-placement costs — integer keys 3 / 4 or the
+        string keys of the kinodynamic script — or ``contact_poses[i] = ...`` on the three contact maps of a centroidal stage),
+        ``replaceStageCircular``, the terminal CoM target between the last foot references (and the terminal foot references of the
+        full-dynamics problem).  ``x_forward``: step length (default: the script's — 0 / 0.3 / 0.2 m); ``z_height``: height gained per
+        step (0.10: the stairs of BASELINE.json's kinodynamic configuration; the ``z_height`` argument of ``footTrajectory``,
+        talos_utils.py:188-192).
 
-        ``per_instance=True``: every instance plans from ITS OWN measured foot poses and gets its own references
+        The stage tables of an ensemble are shared by its instances, so the references are planned from instance 0's state (the state
+        the last COMPLETED tick predicted: with two ticks in flight that is one tick older than the reference script's measurement)
+        and every instance tracks them.  The centroidal OCP has no whole-body model: its feet are where their references put them.
+
+        ``per_instance=True`` (whole-body problems): every instance plans from ITS OWN measured foot poses and gets its own references
         (mpc_enable_instance_params: per-instance parameter tables; ``references.FootTrajectoryBatch`` and
         ``minipin.frame_placements_batch`` do the generator's and the forward kinematics' work for all instances in numpy arrays; one
-        call carries the 2 N + 3 patches of every instance, of which only the changed ones travel)."""
+        call carries the patches of every instance, of which only the changed ones travel)."""
         from . import references as refgen
-        from .problems import fulldynamic
         from .robot import minipin as pin
-        self._walk_args = dict(swing_apex=swing_apex, x_forward=x_forward, y_forward=y_forward, foot_yaw=foot_yaw, y_gap=y_gap, z_height=z_height, per_instance=per_instance)
         pd, N = self.pd, self.problem.num_steps
+        spec = pd.walk_spec()
+        if x_forward is None:
+            x_forward = spec["x_forward"]
+        self._walk_args = dict(swing_apex=swing_apex, x_forward=x_forward, y_forward=y_forward, foot_yaw=foot_yaw, y_gap=y_gap, z_height=z_height, per_instance=per_instance)
         rb = pd.robot
         ev = refgen.contact_event_times(pd.contact_phases, N)
         lf, rf = rb.foot_placements
-        # where the references live in the parameter tables (cost components 3 / 4 of a stage, 2 / 3 of the terminal cost, the
-        # CoM target of the terminal constraint)
+        T_SS, T_DS = spec["T_SS"], spec["T_DS"]
+        # where the references live in the parameter tables
         slots = []
         st = pd.stage_for_tick(0)
-        core.lower_stage(self.ctx, st.cost, st.dynamics, st.constraints, slots)
+        desc0, _ = core.lower_stage(self.ctx, st.cost, st.dynamics, st.constraints, slots)
         tslots = []
         core.lower_stage(self.ctx, self.problem.term_cost, None, self.problem.term_constraints, tslots)
-        self._walk = {
+        w = self._walk = {
             "lists": [list(e) for e in ev],  # takeoff_RFs, takeoff_LFs, land_RFs, land_LFs
-            "traj": refgen.FootTrajectory(lf.copy(), rf.copy(), fulldynamic.T_SS, fulldynamic.T_DS, N, swing_apex, x_forward, y_forward, foot_yaw, y_gap, z_height),
-            "data": rb.model.createData(), "pin": pin, "refgen": refgen,
-            "off_lf": slots[3][1], "off_rf": slots[4][1], "toff_lf": tslots[2][1], "toff_rf": tslots[3][1],
-            "toff_com": tslots[len(self.problem.term_cost.components)][1],
-            "x_measured": np.array(self.x0[0]), "patched": 0, "patches": 0, "last": None,
+            "traj": refgen.FootTrajectory(lf.copy(), rf.copy(), T_SS, T_DS, N, swing_apex, x_forward, y_forward, foot_yaw, y_gap, z_height),
+            "data": rb.model.createData(), "pin": pin, "refgen": refgen, "spec": spec, "kind": spec["kind"],
+            "step": dict(swing_apex=swing_apex, x_forward=x_forward, y_forward=y_forward, y_gap=y_gap, z_height=z_height),
+            "x_measured": np.array(self.x0[0]), "patched": 0, "patches": 0, "last": None, "feet": None,
         }
-        assert slots[3][2] == 12 and slots[4][2] == 12 and tslots[2][2] == 12 and tslots[3][2] == 12 and tslots[len(self.problem.term_cost.components)][2] == 3
+        nterm = len(self.problem.term_cost.components)
+        if spec["kind"] == "pose":
+            keys = list(st.cost.components.keys())
+            i_lf, i_rf = keys.index(spec["pose_keys"][0]), keys.index(spec["pose_keys"][1])
+            w["off_lf"], w["off_rf"] = slots[i_lf][1], slots[i_rf][1]
+            assert slots[i_lf][2] == 12 and slots[i_rf][2] == 12
+            w["toff_com"] = tslots[nterm][1]
+            assert tslots[nterm][2] == 3
+            if spec["terminal_feet"]:
+                w["toff_lf"], w["toff_rf"] = tslots[2][1], tslots[3][1]
+                assert tslots[2][2] == 12 and tslots[3][2] == 12
+        else:  # "contact_poses": p0 / p1 of the dynamics parameters and of the two acceleration residuals (include/mpc_abi.h)
+            keys = list(st.cost.components.keys())
+            dyn = int(desc0[4])
+            w["pose_offs"] = [[dyn + 5 + 3 * i, slots[keys.index("angular_acc_cost")][1] + 4 + 4 * i + 1,
+                               slots[keys.index("linear_acc_cost")][1] + 4 + 4 * i + 1] for i in (0, 1)]
+            if per_instance:
+                raise NotImplementedError("per-instance references: whole-body problems only")
         if per_instance:
-            B, w = self.batch, self._walk
+            B = self.batch
             self.native.enable_instance_params()
             bc = lambda M: (np.tile(np.asarray(M.rotation, dtype=float), (B, 1, 1)), np.tile(np.asarray(M.translation, dtype=float), (B, 1)))
             (LR, Lp), (RR, Rp) = bc(lf), bc(rf)
-            w["batch"] = refgen.FootTrajectoryBatch(LR, Lp, RR, Rp, fulldynamic.T_SS, fulldynamic.T_DS, N, swing_apex, x_forward, y_forward, foot_yaw, y_gap, z_height)
+            w["batch"] = refgen.FootTrajectoryBatch(LR, Lp, RR, Rp, T_SS, T_DS, N, swing_apex, x_forward, y_forward, foot_yaw, y_gap, z_height)
             w["x_measured_all"] = np.array(self.x0, dtype=float)
             i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
             # index arrays of the patches of one tick: per instance the N left-foot and N right-foot references, then (after the cycle) its terminal targets
             w["idx"] = (i32(np.repeat(np.arange(B), 2 * N)), i32(np.tile(np.concatenate([np.arange(N), np.arange(N)]), B)),
                         i32(np.tile(np.concatenate([np.full(N, w["off_lf"]), np.full(N, w["off_rf"])]), B)), i32(np.full(B * 2 * N, 12)))
-            w["tidx"] = (i32(np.repeat(np.arange(B), 3)), i32(np.full(3 * B, N)), i32(np.tile([w["toff_com"], w["toff_lf"], w["toff_rf"]], B)), i32(np.tile([3, 12, 12], B)))
+            if spec["terminal_feet"]:
+                w["tidx"] = (i32(np.repeat(np.arange(B), 3)), i32(np.full(3 * B, N)), i32(np.tile([w["toff_com"], w["toff_lf"], w["toff_rf"]], B)), i32(np.tile([3, 12, 12], B)))
+            else:
+                w["tidx"] = (i32(np.arange(B)), i32(np.full(B, N)), i32(np.full(B, w["toff_com"])), i32(np.full(B, 3)))
+
+    def _walk_forward_rule(self, gen, takeoff_RF, takeoff_LF, land_RF, land_LF):
+        """the ``foottraj.updateForward`` call the scripts make once the walk is over (fulldynamic_talos.py:448-449,
+        kinodynamic_talos.py:368-370, centroidal_talos.py:365-366)"""
+        rule, p = self._walk["spec"]["forward_rule"], self._walk["step"]
+        if rule(takeoff_RF, takeoff_LF, land_RF, land_LF):
+            gen.updateForward(0, 0, p["y_gap"], p["y_forward"], self._walk["spec"]["forward_z_left"], 0, p["swing_apex"])
 
     def _walk_references(self):
         w, N = self._walk, self.problem.num_steps
         rb, pin, refgen = self.pd.robot, self._walk["pin"], self._walk["refgen"]
+        takeoff_RFs, takeoff_LFs, land_RFs, land_LFs = w["lists"]
         if "batch" in w:  # per-instance references
             (LR, Lp), (RR, Rp) = pin.frame_placements_batch(rb.model, w["x_measured_all"][:, :rb.model.nq], rb.foot_frame_ids)
-            takeoff_RFs, takeoff_LFs, land_RFs, land_LFs = w["lists"]
             takeoff_RF, takeoff_LF, land_RF, land_LF = refgen.update_timings(land_LFs, land_RFs, takeoff_LFs, takeoff_RFs)
+            self._walk_forward_rule(w["batch"], takeoff_RF, takeoff_LF, land_RF, land_LF)
             Lb, Rb = w["batch"].updateTrajectory(takeoff_RF, takeoff_LF, land_RF, land_LF, LR, Lp, RR, Rp)
             vals = np.ascontiguousarray(np.concatenate([Lb, Rb], axis=1)).reshape(-1)
             self.native.update_instance_params_arrays(*w["idx"], vals)
@@ -304,16 +344,33 @@ class EnsembleMPC:
             w["replanning"] = (land_LF < 0 or land_RF < 0 or 0 <= takeoff_RF < w["batch"].T_ds or 0 <= takeoff_LF < w["batch"].T_ds)
             self.replanning_ticks = getattr(self, "replanning_ticks", 0) + int(w["replanning"])
             return
-        pin.framesForwardKinematics(rb.model, w["data"], np.asarray(w["x_measured"])[:rb.model.nq])
-        LF_pose, RF_pose = w["data"].oMf[rb.foot_frame_ids[0]].copy(), w["data"].oMf[rb.foot_frame_ids[1]].copy()
-        takeoff_RFs, takeoff_LFs, land_RFs, land_LFs = w["lists"]
+        if w["kind"] == "contact_poses":  # no whole-body state: the feet stand where the previous plan put them for this tick
+            if w["feet"] is None:
+                lf, rf = rb.foot_placements
+                w["feet"] = (lf.copy(), rf.copy())
+            LF_pose, RF_pose = w["feet"][0].copy(), w["feet"][1].copy()
+        else:
+            pin.framesForwardKinematics(rb.model, w["data"], np.asarray(w["x_measured"])[:rb.model.nq])
+            LF_pose, RF_pose = w["data"].oMf[rb.foot_frame_ids[0]].copy(), w["data"].oMf[rb.foot_frame_ids[1]].copy()
         takeoff_RF, takeoff_LF, land_RF, land_LF = refgen.update_timings(land_LFs, land_RFs, takeoff_LFs, takeoff_RFs)
+        self._walk_forward_rule(w["traj"], takeoff_RF, takeoff_LF, land_RF, land_LF)
         LF_refs, RF_refs = w["traj"].updateTrajectory(takeoff_RF, takeoff_LF, land_RF, land_LF, LF_pose, RF_pose)
-        flat = lambda M: np.concatenate([np.asarray(M.rotation, dtype=float).reshape(-1), np.asarray(M.translation, dtype=float)])
         batch = []
-        for j in range(N):
-            batch.append((j, w["off_lf"], flat(LF_refs[j])))
-            batch.append((j, w["off_rf"], flat(RF_refs[j])))
+        if w["kind"] == "contact_poses":
+            w["feet"] = (LF_refs[1], RF_refs[1])
+            # knot j holds the stage of schedule index j - N + tick (the first N - tick knots: the initial double-support stage), and only
+            # the feet that stand in that stage get their pose (centroidal_talos.py:374-384: written BEFORE the new stage is rotated in)
+            for j in range(N):
+                cs = self.pd.contact_phases[max(0, j - N + self.tick) % self.pd.t_mpc]
+                for i, refs in ((0, LF_refs), (1, RF_refs)):
+                    if cs[i]:
+                        for off in w["pose_offs"][i]:
+                            batch.append((j, off, np.asarray(refs[j].translation, dtype=float)))
+        else:
+            flat = lambda M: np.concatenate([np.asarray(M.rotation, dtype=float).reshape(-1), np.asarray(M.translation, dtype=float)])
+            for j in range(N):
+                batch.append((j, w["off_lf"], flat(LF_refs[j])))
+                batch.append((j, w["off_rf"], flat(RF_refs[j])))
         self.native.update_stage_params_batch(batch)
         w["last"] = (LF_refs[-1], RF_refs[-1])
         # ticks on which the generator plans from the measured poses (a foot without a pending landing, a take-off inside the double-
@@ -323,18 +380,24 @@ class EnsembleMPC:
 
     def _walk_terminal(self):
         w, N = self._walk, self.problem.num_steps
+        if w["kind"] == "contact_poses":
+            return  # the centroidal problem has no terminal target (centroidal_talos.py:249)
+        feet = w["spec"]["terminal_feet"]
         if "batch" in w:
             L_last, R_last = w["last_all"]
             com = np.tile(self.pd.robot.com0, (self.batch, 1))
             com[:, :2] = 0.5 * (L_last[:, 9:11] + R_last[:, 9:11])
-            vals = np.ascontiguousarray(np.concatenate([com, L_last, R_last], axis=1)).reshape(-1)
+            vals = np.ascontiguousarray(np.concatenate([com, L_last, R_last] if feet else [com], axis=1)).reshape(-1)
             self.native.update_instance_params_arrays(*w["tidx"], vals)
             return
         LF_last, RF_last = w["last"]
         flat = lambda M: np.concatenate([np.asarray(M.rotation, dtype=float).reshape(-1), np.asarray(M.translation, dtype=float)])
         com_final = self.pd.robot.com0.copy()
         com_final[:2] = 0.5 * (LF_last.translation[:2] + RF_last.translation[:2])
-        self.native.update_stage_params_batch([(N, w["toff_com"], com_final), (N, w["toff_lf"], flat(LF_last)), (N, w["toff_rf"], flat(RF_last))])
+        patches = [(N, w["toff_com"], com_final)]
+        if feet:
+            patches += [(N, w["toff_lf"], flat(LF_last)), (N, w["toff_rf"], flat(RF_last))]
+        self.native.update_stage_params_batch(patches)
 
     def results(self, **kw):
         return self.native.get_results(**kw)

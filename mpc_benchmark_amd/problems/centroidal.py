@@ -70,6 +70,9 @@ class CentroidalProblem:
                 stage.addConstraint(cone, constraints.NegativeOrthant())
         return stage
 
+    def stage_key(self, t):
+        return int(t)  # every tick has its own force reference (centroidal_talos.py:132-169)
+
     def stage_for_tick(self, t):
         lf, rf = self.robot.foot_placements
         return self.create_stage(self.contact_phases[t], lf, rf, self.urefs[t])
@@ -79,6 +82,11 @@ class CentroidalProblem:
         stages = [self.create_stage(self.contact_phases[0], lf, rf, self.urefs[0]) for _ in range(self.horizon)]
         term_cost = aligator.CostStack(self.space, self.nu)  # empty, centroidal_talos.py:249
         return aligator.TrajOptProblem(self.x0, stages, term_cost)
+
+    def walk_spec(self):
+        return {"T_SS": T_SS, "T_DS": T_DS, "x_forward": 0.2,                      # centroidal_talos.py:100-101, :175
+                "kind": "contact_poses", "terminal_feet": False,                  # :374-384 ; empty terminal cost, :249
+                "forward_rule": lambda takeoff_RF, takeoff_LF, land_RF, land_LF: land_RF == -1, "forward_z_left": -0.01}  # :365-366
 
     def make_solver(self, **kw):
         solver = aligator.SolverProxDDP(1e-5, 1e-8, **kw)  # centroidal_talos.py:265-277

@@ -114,6 +114,12 @@ class KinodynamicProblem:
             problem.addTerminalConstraint(self.terminal_com_constraint(self.robot.com0))  # :276
         return problem
 
+    def walk_spec(self):
+        return {"T_SS": T_SS, "T_DS": T_DS, "x_forward": 0.3,                      # kinodynamic_talos.py:183-184, :257
+                "kind": "pose", "pose_keys": ("left_sole_link_pose_cost", "right_sole_link_pose_cost"), "terminal_feet": False,  # :384-385, :407-409
+                "forward_rule": lambda takeoff_RF, takeoff_LF, land_RF, land_LF: land_RF == -1 and takeoff_RF == -1, "forward_z_left": 0.0,  # :368-370
+                "setup_each_tick": False}                                                # :487: ``#solver.setup(problem)``
+
     def make_solver(self, **kw):
         solver = aligator.SolverProxDDP(1e-5, 1e-8, **kw)  # kinodynamic_talos.py:281-292
         solver.rollout_type = aligator.ROLLOUT_LINEAR

@@ -278,6 +278,11 @@ class FootTrajectoryBatch:
         self.sR, self.fR = (RF_R.copy(), RF_p.copy()), (RF_R.copy(), RF_p.copy())
         self.T_ds, self.T_ss, self.nsteps, self.swing_apex = T_ds, T_ss, nsteps, swing_apex
 
+    def updateForward(self, x_f_left, x_f_right, y_gap, y_forward, z_height_left, z_height_right, swing_apex):
+        self.tR = np.array([x_f_right, -y_gap - y_forward, z_height_right], dtype=float)
+        self.tL = np.array([x_f_left, y_gap, z_height_left], dtype=float)
+        self.swing_apex = swing_apex
+
     @staticmethod
     def _yaw(R):
         return np.arctan2(R[:, 1, 0], R[:, 0, 0])

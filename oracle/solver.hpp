@@ -556,15 +556,22 @@ struct Solver {
     std::vector<double> zeroP((size_t)n * n, 0.0), zerop(n, 0.0), eye((size_t)n * n, 0.0);
     for (int i = 0; i < n; ++i) eye[i * n + i] = 1.0;
     // the legs are independent of one another
+    std::vector<std::string> leg_err(J);
 #pragma omp parallel for schedule(dynamic) num_threads(opt.num_threads > 0 ? opt.num_threads : 1)
     for (int j = 0; j < J; ++j) {
-      const int s = leg_start(j), e = (j + 1 < J) ? leg_start(j + 1) - 1 : N - 1;
-      for (int k = e; k >= s; --k) {
-        if (j + 1 == J) knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, nullptr, nullptr, nullptr, in.gains[k]);
-        else if (k == e) knot_backward(in, k, (j + 1 < (int)ptil.size() && !ptil[j + 1].empty()) ? ptil[j + 1] : zeroP, zerop, &eye, &zeroP, &zerop, in.gains[k]);
-        else knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, &in.gains[k + 1].Lm, &in.gains[k + 1].Sg, &in.gains[k + 1].sg, in.gains[k]);
+      // an exception must not leave the parallel region (it would end the process): per-leg message, rethrown after the region
+      try {
+        const int s = leg_start(j), e = (j + 1 < J) ? leg_start(j + 1) - 1 : N - 1;
+        for (int k = e; k >= s; --k) {
+          if (j + 1 == J) knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, nullptr, nullptr, nullptr, in.gains[k]);
+          else if (k == e) knot_backward(in, k, (j + 1 < (int)ptil.size() && !ptil[j + 1].empty()) ? ptil[j + 1] : zeroP, zerop, &eye, &zeroP, &zerop, in.gains[k]);
+          else knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, &in.gains[k + 1].Lm, &in.gains[k + 1].Sg, &in.gains[k + 1].sg, in.gains[k]);
+        }
+      } catch (const std::exception& ex) {
+        leg_err[j] = ex.what();
       }
     }
+    for (const std::string& m : leg_err) if (!m.empty()) throw std::runtime_error(m);
     // consensus over the cuts, last to first: true value function (calP, calp) at the start of each leg
     links.assign(J, LegLink());
     std::vector<double> calP = in.gains[leg_start(J - 1)].P, calp = in.gains[leg_start(J - 1)].p;
@@ -661,15 +668,22 @@ struct Solver {
     std::vector<double> zeroP((size_t)n * n, 0.0), zerop(n, 0.0), eye((size_t)n * n, 0.0);
     for (int i = 0; i < n; ++i) eye[i * n + i] = 1.0;
     const std::vector<std::vector<double>>& ptil = in.tree_guess;
+    std::vector<std::string> leg_err(J);
 #pragma omp parallel for schedule(dynamic) num_threads(opt.num_threads > 0 ? opt.num_threads : 1)
     for (int j = 0; j < J; ++j) {
-      const int s = leg_start(j), e = (j + 1 < J) ? leg_start(j + 1) - 1 : N - 1;
-      for (int k = e; k >= s; --k) {
-        if (j + 1 == J) knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, nullptr, nullptr, nullptr, in.gains[k]);
-        else if (k == e) knot_backward(in, k, (j + 1 < (int)ptil.size() && !ptil[j + 1].empty()) ? ptil[j + 1] : zeroP, zerop, &eye, &zeroP, &zerop, in.gains[k]);
-        else knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, &in.gains[k + 1].Lm, &in.gains[k + 1].Sg, &in.gains[k + 1].sg, in.gains[k]);
+      // an exception must not leave the parallel region (it would end the process): per-leg message, rethrown after the region
+      try {
+        const int s = leg_start(j), e = (j + 1 < J) ? leg_start(j + 1) - 1 : N - 1;
+        for (int k = e; k >= s; --k) {
+          if (j + 1 == J) knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, nullptr, nullptr, nullptr, in.gains[k]);
+          else if (k == e) knot_backward(in, k, (j + 1 < (int)ptil.size() && !ptil[j + 1].empty()) ? ptil[j + 1] : zeroP, zerop, &eye, &zeroP, &zerop, in.gains[k]);
+          else knot_backward(in, k, in.gains[k + 1].P, in.gains[k + 1].p, &in.gains[k + 1].Lm, &in.gains[k + 1].Sg, &in.gains[k + 1].sg, in.gains[k]);
+        }
+      } catch (const std::exception& ex) {
+        leg_err[j] = ex.what();
       }
     }
+    for (const std::string& m : leg_err) if (!m.empty()) throw std::runtime_error(m);
     std::vector<TreeNode>& T = in.tree;
     T.clear();
     std::vector<int> level;

@@ -148,6 +148,8 @@ def run_script(name, ticks, library, verbose=False):
         stopped = "script ran to its end"
     except StopIteration as e:
         stopped = str(e)
+    except Exception as e:  # a failed solve ends the run; what was recorded so far is still handed back
+        stopped = "%s: %s" % (type(e).__name__, str(e)[-200:])
     finally:
         headless.BulletRobot.initializeJoints = orig_init
     secs = time.time() - t0

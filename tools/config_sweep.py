@@ -16,13 +16,18 @@ from mpc_benchmark_amd.problems.kinodynamic import KinodynamicProblem
 lib = _capi.load_hip_library()
 
 
-def run(name, pd, batch, ticks, warm, legs=1, **kw):
+def run(name, pd, batch, ticks, warm, legs=1, walk=None, **kw):
+    """``walk``: keyword arguments of EnsembleMPC.enable_walk (the loop body's reference updates every tick; {} = the script's own step length) or
+    None (frozen references)."""
     ens = EnsembleMPC(pd, batch=batch, library=lib, tick_reuse=True, **kw)  # (whole-body problems only; ignored for the centroidal one)
     ens.options.riccati_legs = legs  # parallel-in-time Riccati (csrc/legs.h); 1 = serial sweep
     ens.native.set_options(ens.options)
     name = "%s, legs %d" % (name, legs)
     ens.prepare_schedule(ticks + warm + 4)
     st = ens.cold_solve(max_iters=100)
+    if walk is not None:
+        ens.enable_walk(**walk)
+        name += ", walk" + ("".join(" %s=%s" % kv for kv in walk.items()))
     for _ in range(warm):
         ens.step()
     lat = []
@@ -39,7 +44,7 @@ def run(name, pd, batch, ticks, warm, legs=1, **kw):
 
 
 for legs in (1, 4, 8, 16, 32):
-    run("config 2: centroidal N=100 batch 1", CentroidalProblem(horizon=100), 1, 180, 20, legs=legs, perturb=False)
+    run("config 2: centroidal N=100 batch 1", CentroidalProblem(horizon=100), 1, 180, 130, legs=legs, perturb=False, walk={})  # timed ticks 130 - 310: the first swing
 run("config 2': centroidal N=100 batch 64", CentroidalProblem(horizon=100), 64, 60, 10, legs=4, perturb=False)
 for legs in (1, 4, 8, 16, 32):
     run("config 3: full dynamics N=100 batch 1 (nq=39)", FullDynamicsProblem(horizon=100, complete_model=True), 1, 100, 20, legs=legs, perturb=False)
@@ -50,6 +55,8 @@ for legs in (1, 4):
 for legs in (1, 4):
     kp = KinodynamicProblem(horizon=150, complete_model=True)
     run("config 4: kinodynamic N=150 batch 64 (nq=39)", kp, 64, 20, 3, legs=legs, seed=7, perturb_dofs=range(18, kp.nv))
+    run("config 4: kinodynamic STAIRS N=150 batch 64 (nq=39)", KinodynamicProblem(horizon=150, complete_model=True), 64, 40, 165, legs=legs, seed=7,
+        perturb_dofs=range(18, kp.nv), walk={"z_height": 0.10})  # timed ticks 165 - 205: the first swing at knot 0
 for legs in (1, 4):
     kr = KinodynamicProblem(horizon=150, complete_model=False)
     run("config 4: kinodynamic N=150 batch 64 (nq=29)", kr, 64, 20, 3, legs=legs, seed=7, perturb_dofs=range(18, kr.nv))

@@ -1,5 +1,8 @@
-"""Developer tool (GPU box): tick times of BASELINE config 4 (kinodynamic N = 150, 64 instances, complete model, 4 legs, tick reuse) —
-p50 / p90, how many ticks take more than one pass (a BCL update without a step, then the step), per-kernel time."""
+"""Developer tool (GPU box): tick times of BASELINE config 4 (kinodynamic STAIRS, N = 150, 64 instances, complete model, 4 legs, tick
+reuse) — p50 / p90, how many ticks take more than one pass (a BCL update without a step, then the step), per-kernel time.
+The walk of the script (0.3 m steps, kinodynamic_talos.py:257) with 0.10 m gained per step, references replanned every tick
+(EnsembleMPC.enable_walk); STAIRS=0: flat ground, WALK=0: frozen references (the round-3 form of this measurement), PERINST=1:
+every instance plans from its own foot poses.  START=n: n untimed ticks first (120: the first swing is at knot 0)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,9 +14,11 @@ kp = KinodynamicProblem(horizon=150, complete_model=True)
 ens = EnsembleMPC(kp, batch=64, library=lib, seed=7, perturb_dofs=range(18, kp.nv), tick_reuse=not os.environ.get("NO_REUSE"))
 ens.options.riccati_legs = int(os.environ.get("LEGS", "4")); ens.native.set_options(ens.options)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-ens.prepare_schedule(T + 10)
+ens.prepare_schedule(T + 10 + int(os.environ.get("START", "0")))
 ens.cold_solve(max_iters=100)
-for _ in range(3): ens.step()
+if int(os.environ.get("WALK", "1")):
+    ens.enable_walk(z_height=(0.10 if int(os.environ.get("STAIRS", "1")) else 0.0), per_instance=bool(int(os.environ.get("PERINST", "0"))))
+for _ in range(3 + int(os.environ.get("START", "0"))): ens.step()
 ens.native.profile(2); ens.native.profile(1)
 lat, al, ls = [], [], []
 for _ in range(T):
@@ -24,7 +29,8 @@ for _ in range(T):
     ls.append(np.bincount([int(s.ls_steps) for s in st], minlength=8))
 ens.native.profile(0)
 lat = np.array(lat)
-print("kinodynamic N=150 B=64 legs %d: p50 %.2f ms  p90 %.2f ms  mean %.2f ms | ticks in which some instance took a BCL update: %d of %d (instances per such tick: mean %.1f)" % (
+print("kinodynamic N=150 B=64 %s legs %d: p50 %.2f ms  p90 %.2f ms  mean %.2f ms | ticks in which some instance took a BCL update: %d of %d (instances per such tick: mean %.1f)" % (
+    ("frozen references" if ens._walk is None else "walk, z_height %.2f%s, replanning ticks %d" % (ens._walk_args["z_height"], ", per-instance references" if ens._walk_args["per_instance"] else "", getattr(ens, "replanning_ticks", 0))),
     ens.options.riccati_legs, np.percentile(lat, 50), np.percentile(lat, 90), lat.mean(), sum(1 for a in al if a), T, np.mean([a for a in al if a] or [0])))
 for t, (l, h) in enumerate(zip(lat, ls)):
     if h[1:].sum():
