@@ -7,7 +7,8 @@
 // the kinematic tree every entry of M, d tau/dq, d tau/dv, the contact Jacobians and their derivatives is a
 // 6-dimensional dot product of per-dof vectors, so the nv x nv blocks are filled by all lanes in parallel with
 // no further dependency on the tree (DESIGN.md §"Whole-body stage kernel" derives the formulas; they are
-// cross-checked against the AD-based oracle through tests/proto_multibody.py and the GPU parity tests).
+// cross-checked against the AD-based oracle: on the CPU through its C++ port (oracle/cpu_port/eval_closed_form.hpp, tests/test_cpu_port.py:
+// per-phase dumps at 1e-9), on the GPU through the parity tests).
 #pragma once
 #include <type_traits>
 #include "eval_common.h"

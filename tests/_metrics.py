@@ -96,3 +96,10 @@ def rel_cols(a, b, floor):
     if a.size == 0:
         return 0.0
     return float(np.max(np.max(np.abs(a - b), axis=0) / (np.max(np.abs(b), axis=0) + floor)))
+
+
+def traj_err(xs_a, us_a, xs_b, us_b, x_floor=1e-3, u_floor=1.0):
+    """Deviation of a trajectory (xs [.., nx], us [.., nu]) from a reference one, component by component: every state component against
+    its own range (floor 1e-3: base positions ~1, joint velocities ~1e-2), every control component against its own range (floor 1: torques
+    and forces of 1 .. 500).  States and controls are never normalised by one another."""
+    return max(rel_cols(xs_a, xs_b, x_floor), rel_cols(us_a, us_b, u_floor))

@@ -2,6 +2,8 @@
 import numpy as np
 import pytest
 
+from tests._metrics import traj_err
+
 from mpc_benchmark_amd import aligator
 
 from mpc_benchmark_amd.problems.centroidal import CentroidalProblem
@@ -95,6 +97,8 @@ def test_mpc_loop_with_cycling(hip_lib, oracle_lib):
             solver.setup(prob)
             solver.run(prob, xs, us)
             xs, us = list(solver.results.xs), list(solver.results.us)
-            hist.append(np.concatenate([np.ravel(xs), np.ravel(us)]))
-        traj[name] = np.array(hist)
-    assert _rel(traj["hip"], traj["ref"]) < 1e-6
+            hist.append((np.array(xs), np.array(us)))
+        traj[name] = hist
+    for t, (a, b) in enumerate(zip(traj["hip"], traj["ref"])):
+        e = traj_err(a[0], a[1], b[0], b[1])
+        assert e < 1e-6, "tick %d: %.3e" % (t, e)

@@ -8,7 +8,7 @@ from mpc_benchmark_amd import aligator
 from mpc_benchmark_amd.problems.centroidal import CentroidalProblem
 from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
 from mpc_benchmark_amd.problems.kinodynamic import KinodynamicProblem
-from tests._metrics import rel_rows
+from tests._metrics import rel_cols, rel_rows
 from tests._phase_parity import dual_rows
 
 pytestmark = pytest.mark.gpu
@@ -17,6 +17,16 @@ pytestmark = pytest.mark.gpu
 def _rel(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return float(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b)))) if a.size else 0.0
+
+
+# trajectories and K_0 are held component by component (tests/_metrics.py): a state against its own range (floor 1e-3), a control or a
+# gain column against its own (floor 1) — never a joint angle against the largest torque
+def _relx(a, b):
+    return rel_cols(a, b, 1e-3)
+
+
+def _relu(a, b):
+    return rel_cols(a, b, 1.0)
 
 
 def _one_iteration(lib, kind, N, legs, complete=False, seed=5):
@@ -110,8 +120,8 @@ def test_leg_kernels_against_oracle(hip_lib, oracle_lib, kind, N, legs, complete
             cmp(q, q, k, loose)
         cmp_dual("knu", "knu", k, max(loose, 1e-6))
     assert not bad, (bad[:12], worst)
-    assert _rel(sh.results.controlFeedbacks()[0], so.results.controlFeedbacks()[0]) < 1e-7
-    assert _rel(np.array(sh.results.xs), np.array(so.results.xs)) < loose
+    assert _relu(sh.results.controlFeedbacks()[0], so.results.controlFeedbacks()[0]) < 1e-7
+    assert _relx(np.array(sh.results.xs), np.array(so.results.xs)) < loose
 
 
 @pytest.mark.parametrize("kind,N,legs,complete", [("fulldynamic", 12, 3, False), ("fulldynamic", 16, 4, True), ("fulldynamic", 10, 10, False),
@@ -132,9 +142,9 @@ def test_hip_legs_equal_hip_serial(hip_lib, oracle_lib, kind, N, legs, complete)
             tol = 1e-5 if name == "dlams" else 1e-7
             assert _rel(sl._native.debug_get(name, k), s1._native.debug_get(name, k)) < tol, (name, k)
             assert _rel(sl._native.debug_get(name, k), so._native.debug_get(name, k)) < tol, (name, k, "oracle serial")
-    assert _rel(sl.results.controlFeedbacks()[0], s1.results.controlFeedbacks()[0]) < 1e-8
-    assert _rel(np.array(sl.results.xs), np.array(s1.results.xs)) < 1e-7
-    assert _rel(np.array(sl.results.us), np.array(s1.results.us)) < 1e-7
+    assert _relu(sl.results.controlFeedbacks()[0], s1.results.controlFeedbacks()[0]) < 1e-8
+    assert _relx(np.array(sl.results.xs), np.array(s1.results.xs)) < 1e-7
+    assert _relu(np.array(sl.results.us), np.array(s1.results.us)) < 1e-7
 
 
 @pytest.mark.parametrize("chain", [False, True])
@@ -155,7 +165,7 @@ def test_tree_and_chain_over_the_cuts(hip_lib, oracle_lib, kind, N, legs, chain,
     starts = [j * N // legs for j in range(legs)]
     for j in range(legs - 1):  # co-state parameter at the end of every parametric leg
         assert _rel(sl._native.debug_get("theta", j), so._native.debug_get("theta", j)) < 1e-6, j
-    assert _rel(sl.results.controlFeedbacks()[0], s1.results.controlFeedbacks()[0]) < 1e-8
+    assert _relu(sl.results.controlFeedbacks()[0], s1.results.controlFeedbacks()[0]) < 1e-8
 
 
 @pytest.mark.parametrize("legs", [4, 12])
@@ -189,7 +199,7 @@ def test_cold_solve_and_mpc_ticks_with_legs(hip_lib, oracle_lib, legs):
     assert out["hip_legs"][0][2] and out["hip_legs"][0][3] == out["hip_serial"][0][3] == out["oracle_legs"][0][3]
     for other in ("hip_serial", "oracle_legs"):
         for a, b in zip(out["hip_legs"], out[other]):
-            assert _rel(a[0], b[0]) < 1e-6 and _rel(a[1], b[1]) < 1e-6, other
+            assert _relx(a[0], b[0]) < 1e-6 and _relu(a[1], b[1]) < 1e-6, other
 
 
 @pytest.mark.parametrize("nlegs", [8, 16, 32])
@@ -215,8 +225,8 @@ def test_full_size_workload_with_legs(hip_lib, oracle_lib, nlegs):
         solver.run(prob, xs, us)
         res[tag] = (np.array(solver.results.xs), np.array(solver.results.us), solver.results.controlFeedbacks()[0])
     for other in ("hip_serial", "oracle_serial"):
-        assert _rel(res["hip_legs"][0], res[other][0]) < 1e-7 and _rel(res["hip_legs"][1], res[other][1]) < 1e-7, other
-        assert _rel(res["hip_legs"][2], res[other][2]) < 1e-7, other
+        assert _relx(res["hip_legs"][0], res[other][0]) < 1e-7 and _relu(res["hip_legs"][1], res[other][1]) < 1e-7, other
+        assert _relu(res["hip_legs"][2], res[other][2]) < 1e-7, other
 
 
 @pytest.mark.parametrize("horizon,legs", [(1, 8), (2, 8), (3, 2), (5, 16)])
@@ -239,8 +249,8 @@ def test_short_horizons_with_legs(hip_lib, oracle_lib, horizon, legs):
         prob.x0_init = xs[0]
         solver.run(prob, xs, us)
         out[tag] = (np.array(solver.results.xs), np.array(solver.results.us), solver.results.controlFeedbacks()[0])
-    assert _rel(out["hip_legs"][0], out["oracle_serial"][0]) < 1e-7 and _rel(out["hip_legs"][1], out["oracle_serial"][1]) < 1e-6
-    assert _rel(out["hip_legs"][2], out["oracle_serial"][2]) < 1e-6
+    assert _relx(out["hip_legs"][0], out["oracle_serial"][0]) < 1e-7 and _relu(out["hip_legs"][1], out["oracle_serial"][1]) < 1e-6
+    assert _relu(out["hip_legs"][2], out["oracle_serial"][2]) < 1e-6
 
 
 def test_unconstrained_and_flight_stages_with_legs(hip_lib, oracle_lib):
@@ -268,8 +278,8 @@ def test_unconstrained_and_flight_stages_with_legs(hip_lib, oracle_lib):
         prob.x0_init = xs[0]
         solver.run(prob, xs, us)
         out[tag] = (np.array(solver.results.xs), np.array(solver.results.us), solver.results.controlFeedbacks()[0])
-    assert _rel(out["hip_legs"][0], out["oracle_serial"][0]) < 1e-7 and _rel(out["hip_legs"][1], out["oracle_serial"][1]) < 1e-7
-    assert _rel(out["hip_legs"][2], out["oracle_serial"][2]) < 1e-7
+    assert _relx(out["hip_legs"][0], out["oracle_serial"][0]) < 1e-7 and _relu(out["hip_legs"][1], out["oracle_serial"][1]) < 1e-7
+    assert _relu(out["hip_legs"][2], out["oracle_serial"][2]) < 1e-7
 
 
 def test_ensemble_with_legs_is_deterministic_and_instancewise(hip_lib):
@@ -318,7 +328,7 @@ def test_tree_with_more_workgroups_than_cus(hip_lib):
             rec.append((r["xs"].copy(), r["us"].copy(), r["K"][:, 0].copy()))
         out[legs] = rec
     for a, b in zip(out[8], out[1]):
-        assert _rel(a[0], b[0]) < 1e-8 and _rel(a[1], b[1]) < 1e-8 and _rel(a[2], b[2]) < 1e-8
+        assert _relx(a[0], b[0]) < 1e-8 and _relu(a[1], b[1]) < 1e-8 and _relu(a[2], b[2]) < 1e-8
 
 
 @pytest.mark.parametrize("mode", ["fixed_iterations", "converged"])
@@ -345,7 +355,7 @@ def test_ensemble_cold_solve_with_the_tree(hip_lib, mode):
     if mode == "converged":
         assert all(out[6][3]) and len(set(out[6][2])) >= 4, (out[6][2], out[6][3])
     same = list(range(6))
-    assert _rel(out[6][0][same], out[1][0][same]) < 1e-7 and _rel(out[6][1][same], out[1][1][same]) < 1e-7
+    assert _relx(out[6][0][same], out[1][0][same]) < 1e-7 and _relu(out[6][1][same], out[1][1][same]) < 1e-7
 
 
 def test_mirror_picks_the_number_of_legs_for_the_device(hip_lib, oracle_lib):
@@ -364,4 +374,4 @@ def test_mirror_picks_the_number_of_legs_for_the_device(hip_lib, oracle_lib):
         solver.run(prob, xs, us)
         res[name] = (np.array(solver.results.xs), np.array(solver.results.us))
     for name in ("hip-8", "oracle"):
-        assert _rel(res["hip-auto"][0], res[name][0]) < 1e-7 and _rel(res["hip-auto"][1], res[name][1]) < 1e-6, name
+        assert _relx(res["hip-auto"][0], res[name][0]) < 1e-7 and _relu(res["hip-auto"][1], res[name][1]) < 1e-6, name
