@@ -531,15 +531,14 @@ class QuadraticResidualCost(_Owned):
         self.nu = residual.nu
 
     def copy(self):
-        return QuadraticResidualCost(self.space, self.residual, self.weights)
+        c = QuadraticResidualCost(self.space, self.residual, self.weights)
+        c.__class__ = type(self)  # (a copied QuadraticStateCost / QuadraticControlCost keeps its setTarget)
+        return c
 
 
 class QuadraticStateCost(QuadraticResidualCost):
     def __init__(self, space, nu, target, weights):
         super().__init__(space, StateErrorResidual(space, nu, target), weights)
-
-    def copy(self):
-        return QuadraticResidualCost.copy(self)
 
     def setTarget(self, target):
         self.residual.target = _vec(target, self.space.nx)
@@ -551,9 +550,6 @@ class QuadraticControlCost(QuadraticResidualCost):
         if isinstance(target, (int, np.integer)):
             target = np.zeros(int(target))
         super().__init__(space, ControlErrorResidual(space.ndx, target), weights)
-
-    def copy(self):
-        return QuadraticResidualCost.copy(self)
 
     def setTarget(self, target):
         self.residual.target = _vec(target)

@@ -254,7 +254,10 @@ class EnsembleMPC:
         ``replaceStageCircular``, the terminal CoM target between the last foot references (and the terminal foot references of the
         full-dynamics problem).  ``x_forward``: step length (default: the script's — 0 / 0.3 / 0.2 m); ``z_height``: height gained per
         step (0.10: the stairs of BASELINE.json's kinodynamic configuration; the ``z_height`` argument of ``footTrajectory``,
-        talos_utils.py:188-192).
+        talos_utils.py:188-192).  The scripts themselves only walk on flat ground: with ``z_height != 0`` the height of the posture
+        reference's base (the state cost pins it with a weight of 1e4, kinodynamic_talos.py:74-88) and of the terminal CoM target follow
+        the mean height of the two foot references of their knot — without that a robot that climbs 0.6 m in six steps is asked to keep
+        its pelvis where it started (this build's definition of the stairs variant; flat walks are untouched).
 
         The stage tables of an ensemble are shared by its instances, so the references are planned from instance 0's state (the state
         the last COMPLETED tick predicted: with two ticks in flight that is one tick older than the reference script's measurement)
@@ -296,6 +299,8 @@ class EnsembleMPC:
             assert slots[i_lf][2] == 12 and slots[i_rf][2] == 12
             w["toff_com"] = tslots[nterm][1]
             assert tslots[nterm][2] == 3
+            w["off_xref_z"] = slots[keys.index(spec["state_key"])][1] + 2  # base height of the posture reference (stairs)
+            w["feet_z0"] = 0.5 * (float(lf.translation[2]) + float(rf.translation[2]))
             if spec["terminal_feet"]:
                 w["toff_lf"], w["toff_rf"] = tslots[2][1], tslots[3][1]
                 assert tslots[2][2] == 12 and tslots[3][2] == 12
@@ -317,6 +322,7 @@ class EnsembleMPC:
             # index arrays of the patches of one tick: per instance the N left-foot and N right-foot references, then (after the cycle) its terminal targets
             w["idx"] = (i32(np.repeat(np.arange(B), 2 * N)), i32(np.tile(np.concatenate([np.arange(N), np.arange(N)]), B)),
                         i32(np.tile(np.concatenate([np.full(N, w["off_lf"]), np.full(N, w["off_rf"])]), B)), i32(np.full(B * 2 * N, 12)))
+            w["zidx"] = (i32(np.repeat(np.arange(B), N)), i32(np.tile(np.arange(N), B)), i32(np.full(B * N, w["off_xref_z"])), i32(np.full(B * N, 1)))
             if spec["terminal_feet"]:
                 w["tidx"] = (i32(np.repeat(np.arange(B), 3)), i32(np.full(3 * B, N)), i32(np.tile([w["toff_com"], w["toff_lf"], w["toff_rf"]], B)), i32(np.tile([3, 12, 12], B)))
             else:
@@ -340,6 +346,9 @@ class EnsembleMPC:
             Lb, Rb = w["batch"].updateTrajectory(takeoff_RF, takeoff_LF, land_RF, land_LF, LR, Lp, RR, Rp)
             vals = np.ascontiguousarray(np.concatenate([Lb, Rb], axis=1)).reshape(-1)
             self.native.update_instance_params_arrays(*w["idx"], vals)
+            if w["step"]["z_height"] != 0.0:  # stairs: the posture reference climbs with the feet
+                zref = self.pd.x0[2] + 0.5 * (Lb[:, :, 11] + Rb[:, :, 11]) - w["feet_z0"]
+                self.native.update_instance_params_arrays(*w["zidx"], np.ascontiguousarray(zref).reshape(-1))
             w["last_all"] = (Lb[:, -1].copy(), Rb[:, -1].copy())
             w["replanning"] = (land_LF < 0 or land_RF < 0 or 0 <= takeoff_RF < w["batch"].T_ds or 0 <= takeoff_LF < w["batch"].T_ds)
             self.replanning_ticks = getattr(self, "replanning_ticks", 0) + int(w["replanning"])
@@ -371,6 +380,10 @@ class EnsembleMPC:
             for j in range(N):
                 batch.append((j, w["off_lf"], flat(LF_refs[j])))
                 batch.append((j, w["off_rf"], flat(RF_refs[j])))
+            if w["step"]["z_height"] != 0.0:  # stairs: the posture reference climbs with the feet
+                for j in range(N):
+                    dz = 0.5 * (LF_refs[j].translation[2] + RF_refs[j].translation[2]) - w["feet_z0"]
+                    batch.append((j, w["off_xref_z"], np.array([self.pd.x0[2] + dz])))
         self.native.update_stage_params_batch(batch)
         w["last"] = (LF_refs[-1], RF_refs[-1])
         # ticks on which the generator plans from the measured poses (a foot without a pending landing, a take-off inside the double-
@@ -387,6 +400,8 @@ class EnsembleMPC:
             L_last, R_last = w["last_all"]
             com = np.tile(self.pd.robot.com0, (self.batch, 1))
             com[:, :2] = 0.5 * (L_last[:, 9:11] + R_last[:, 9:11])
+            if w["step"]["z_height"] != 0.0:
+                com[:, 2] += 0.5 * (L_last[:, 11] + R_last[:, 11]) - w["feet_z0"]
             vals = np.ascontiguousarray(np.concatenate([com, L_last, R_last] if feet else [com], axis=1)).reshape(-1)
             self.native.update_instance_params_arrays(*w["tidx"], vals)
             return
@@ -394,6 +409,8 @@ class EnsembleMPC:
         flat = lambda M: np.concatenate([np.asarray(M.rotation, dtype=float).reshape(-1), np.asarray(M.translation, dtype=float)])
         com_final = self.pd.robot.com0.copy()
         com_final[:2] = 0.5 * (LF_last.translation[:2] + RF_last.translation[:2])
+        if w["step"]["z_height"] != 0.0:
+            com_final[2] += 0.5 * (LF_last.translation[2] + RF_last.translation[2]) - w["feet_z0"]
         patches = [(N, w["toff_com"], com_final)]
         if feet:
             patches += [(N, w["toff_lf"], flat(LF_last)), (N, w["toff_rf"], flat(RF_last))]

@@ -140,7 +140,7 @@ class FullDynamicsProblem:
     def walk_spec(self):
         """What the loop body of the script does to the problem every tick (EnsembleMPC.enable_walk, problems/walking_loop.py)."""
         return {"T_SS": T_SS, "T_DS": T_DS, "x_forward": 0.0,                      # fulldynamic_talos.py:248-249, :352
-                "kind": "pose", "pose_keys": (3, 4), "terminal_feet": True,       # :461-463, :499-510
+                "kind": "pose", "state_key": 0, "pose_keys": (3, 4), "terminal_feet": True,       # :461-463, :499-510
                 "forward_rule": lambda takeoff_RF, takeoff_LF, land_RF, land_LF: land_LF == -1, "forward_z_left": -0.01}  # :448-449
 
     def make_solver(self, **kw):

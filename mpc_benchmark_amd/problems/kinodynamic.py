@@ -116,7 +116,7 @@ class KinodynamicProblem:
 
     def walk_spec(self):
         return {"T_SS": T_SS, "T_DS": T_DS, "x_forward": 0.3,                      # kinodynamic_talos.py:183-184, :257
-                "kind": "pose", "pose_keys": ("left_sole_link_pose_cost", "right_sole_link_pose_cost"), "terminal_feet": False,  # :384-385, :407-409
+                "kind": "pose", "state_key": "state_cost", "pose_keys": ("left_sole_link_pose_cost", "right_sole_link_pose_cost"), "terminal_feet": False,  # :384-385, :407-409
                 "forward_rule": lambda takeoff_RF, takeoff_LF, land_RF, land_LF: land_RF == -1 and takeoff_RF == -1, "forward_z_left": 0.0,  # :368-370
                 "setup_each_tick": False}                                                # :487: ``#solver.setup(problem)``
 

@@ -187,9 +187,19 @@ class KinodynamicMPCLoop(_MPCLoop):
         for j in range(N):
             prob.stages[j].cost.getComponent("left_sole_link_pose_cost").residual.setReference(LF_refs[j])
             prob.stages[j].cost.getComponent("right_sole_link_pose_cost").residual.setReference(RF_refs[j])
+        stairs = self.step_params["z_height"] != 0.0
+        if stairs:  # the posture reference and the terminal CoM target climb with the feet (EnsembleMPC.enable_walk: this build's stairs variant)
+            lf0, rf0 = pd.robot.foot_placements
+            z0 = 0.5 * (float(lf0.translation[2]) + float(rf0.translation[2]))
+            for j in range(N):
+                xr = pd.x0.copy()
+                xr[2] += 0.5 * (LF_refs[j].translation[2] + RF_refs[j].translation[2]) - z0
+                prob.stages[j].cost.getComponent("state_cost").setTarget(xr)
         prob.replaceStageCircular(pd.stage_for_tick(self.t % pd.t_mpc))
         com_final = pd.robot.com0.copy()
         com_final[:2] = (LF_refs[-1].translation[:2] + RF_refs[-1].translation[:2]) / 2
+        if stairs:
+            com_final[2] += 0.5 * (LF_refs[-1].translation[2] + RF_refs[-1].translation[2]) - z0
         prob.term_constraints.funcs[0].setReference(com_final)
         self.x_measured = np.array(x0_init)
         xs = self.xs[1:] + [self.xs[-1]]

@@ -85,7 +85,7 @@ def test_leg_kernels_against_oracle(hip_lib, oracle_lib, kind, N, legs, complete
         ones (multipliers fixed by the mu-regularisation only, tests/_phase_parity.py) reported"""
         a, b = nh.debug_get(name_h, k), no.debug_get(name_o, k)
         assert a.shape == b.shape, (name_h, k, a.shape, b.shape)
-        act, dep = dual_rows(no, k, n, n + (nu if k < N else 0))
+        act, dep, _ = dual_rows(no, k, n, n + (nu if k < N else 0))
         if act.size == 0:
             return
         a, b = a.ravel()[:act.size * (a.size // act.size)].reshape(act.size, -1), b.ravel()[:act.size * (b.size // act.size)].reshape(act.size, -1)
