@@ -576,7 +576,10 @@ def main():
         # every worker reports the wall-clock window of its timed ticks: the host rate is the ticks inside the common window
         lo, hi = max(o["t_start"] for o in outs), min(o["t_end"] for o in outs)
         cpu_rate = sum(sum(1 for te in o["tick_ends"] if lo < te <= hi) for o in outs) / max(hi - lo, 1e-9)
+        from tests import _cpu_port, _oracle as _orc
+        stamp, here = _orc.built_on(_cpu_port.PORT_DIR)  # (the first worker rebuilt the library if it came from another host: -march=native)
         cpu = {"value": round(cpu_rate, 2), "unit": "solves/s", "cores": cores, "threads_per_instance": 8, "concurrent_instances": nproc, "kind": "port",
+               "library_built_on": (stamp.split("\n")[0].split(":")[-1].strip() if stamp else "unknown"), "library_built_on_this_host": bool(here),
                "p50_ms_per_solve_one_instance_8_threads": round(_p50(one["tick_ms"]), 2),
                "sample": "CPU port (closed-form derivatives, -O3 -march=native; not Aligator, not the AD oracle): %d processes x 8 OpenMP threads, each %d "
                          "warm-started MPC ticks (1 ProxDDP iteration, Riccati sweep in 8 legs) of the same N=%d %s-model OCP, %.1f s wall; the "
@@ -599,6 +602,9 @@ def main():
         "riccati_cuts": ("chain (MPC_LEGS_CHAIN)" if os.environ.get("MPC_LEGS_CHAIN", "0") not in ("", "0") else "tree of pairwise compositions (csrc/legs_tree.h) from three legs on"),
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
         "cold_solve_converged_instances": "%d/%d within 100 iterations (randomised initial states; largest primal / dual infeasibility of the others: %.2e)" % (n_conv, args.batch, mres["worst_unconv"]),
+        # instances that enter the MPC loop from an unconverged cold solve are counted in `value` (a tick of theirs costs what every tick costs); the
+        # rate of the instances whose cold solve converged, for a reader who does not want them counted
+        "cold_solve_unconverged_instances": int(args.batch - n_conv), "value_cold_converged_instances_only": round(solves / elapsed * n_conv / max(1, args.batch), 2),
         "tick_mode": ("walk: foot references regenerated and patched every tick (fulldynamic_talos.py:444-510)" if head else "frozen foot references"),
         "walk_references": ("per instance: every instance replans from its own measured foot poses (per-instance parameter tables, batched generator on the host)" if args.walk_refs == "instance"
                             else "planned once per tick from instance 0's measured state and shared by the instances of an ensemble"),

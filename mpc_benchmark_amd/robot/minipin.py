@@ -736,3 +736,40 @@ def getFrameVelocity(model, data, frame_id, reference_frame=LOCAL):
         return Motion(R @ vl.linear, R @ vl.angular)
     w = data.oMf[frame_id].action() @ vl.np
     return Motion(w[:3], w[3:])
+
+
+def _quat_to_rot_batch(Q):
+    qn = Q / np.linalg.norm(Q, axis=1, keepdims=True)
+    x, y, z, w = qn.T
+    R = np.empty((Q.shape[0], 3, 3))
+    R[:, 0, 0], R[:, 0, 1], R[:, 0, 2] = 1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)
+    R[:, 1, 0], R[:, 1, 1], R[:, 1, 2] = 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)
+    R[:, 2, 0], R[:, 2, 1], R[:, 2, 2] = 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)
+    return R
+
+
+def difference_batch(model, Q0, Q1):
+    """``difference(model, q0, q1)`` for B configurations at once (free-flyer root followed by revolute joints): [B, nv]."""
+    Q0, Q1 = np.asarray(Q0, dtype=float), np.asarray(Q1, dtype=float)
+    B = Q0.shape[0]
+    d = np.zeros((B, model.nv))
+    for j in model.joints[1:]:
+        if j.shortname() == "JointModelFreeFlyer":
+            R0, R1 = _quat_to_rot_batch(Q0[:, j.idx_q + 3:j.idx_q + 7]), _quat_to_rot_batch(Q1[:, j.idx_q + 3:j.idx_q + 7])
+            R = np.einsum("bji,bjk->bik", R0, R1)
+            p = np.einsum("bji,bj->bi", R0, Q1[:, j.idx_q:j.idx_q + 3] - Q0[:, j.idx_q:j.idx_q + 3])
+            c = np.clip((np.trace(R, axis1=1, axis2=2) - 1.0) / 2.0, -1.0, 1.0)
+            th = np.arccos(c)
+            wv = np.stack([R[:, 2, 1] - R[:, 1, 2], R[:, 0, 2] - R[:, 2, 0], R[:, 1, 0] - R[:, 0, 1]], axis=1)
+            small = th < 1e-8
+            ths = np.where(small, 1.0, th)
+            w = np.where(small[:, None], 0.5 * wv, (ths / (2.0 * np.sin(ths)))[:, None] * wv)
+            K = np.zeros((B, 3, 3))
+            K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -w[:, 2], w[:, 1], w[:, 2], -w[:, 0], -w[:, 1], w[:, 0]
+            coef = np.where(small, 1.0 / 12.0, 1.0 / ths ** 2 - (1 + np.cos(ths)) / (2 * ths * np.sin(ths)))
+            Vinv = np.eye(3) - 0.5 * K + coef[:, None, None] * (K @ K)
+            d[:, j.idx_v:j.idx_v + 3] = np.einsum("bij,bj->bi", Vinv, p)
+            d[:, j.idx_v + 3:j.idx_v + 6] = w
+        else:
+            d[:, j.idx_v] = Q1[:, j.idx_q] - Q0[:, j.idx_q]
+    return d

@@ -8,6 +8,7 @@ PORT_DIR = os.path.join(ROOT, "oracle", "cpu_port")
 PORT_LIB = os.path.join(PORT_DIR, "libmpc_cpu.so")
 
 _lib = None
+REBUILT_HERE = False
 
 
 def load():
@@ -17,6 +18,16 @@ def load():
         deps += [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle")) if f.endswith((".cpp", ".hpp"))]
         deps.append(os.path.join(ROOT, "mpc_benchmark_amd", "csrc", "se3_math.h"))
         stale = (not os.path.exists(PORT_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(PORT_LIB) for s in deps)
+        from tests._oracle import built_on
+        stamp, here = built_on(PORT_DIR)
+        global REBUILT_HERE
+        if stamp is not None and not here:  # built -march=native on another host (the build container): rebuild for this one
+            stale = True
+            REBUILT_HERE = True
+            try:
+                os.remove(PORT_LIB)
+            except OSError:
+                pass
         if stale:
             try:
                 subprocess.run(["make", "-s", "-C", PORT_DIR], check=True)

@@ -10,6 +10,34 @@ ORACLE_LIB = os.path.join(ORACLE_DIR, "libmpc_oracle.so")
 _lib = None
 
 
+def host_stamp():
+    """CPU model + a digest of its ISA flags: the libraries are compiled -march=native, so a build from another host is rebuilt here."""
+    import hashlib
+    model, flags = "", ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if not model and line.startswith("model name"):
+                    model = line.strip()
+                if not flags and line.startswith("flags"):
+                    flags = line
+                if model and flags:
+                    break
+    except OSError:
+        pass
+    return model + "\n" + hashlib.md5(flags.encode()).hexdigest() + "  -\n"
+
+
+def built_on(lib_dir):
+    """-> (stamp text of the host that built the library or None, True if that is this host)"""
+    p = os.path.join(lib_dir, ".build_host")
+    if not os.path.exists(p):
+        return None, False
+    with open(p) as f:
+        txt = f.read()
+    return txt, txt == host_stamp()
+
+
 def build():
     subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
 

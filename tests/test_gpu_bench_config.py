@@ -148,3 +148,62 @@ def test_failed_instances_are_isolated_and_revived(hip_lib):
     alive = [b for b, s in enumerate(st) if s.converged >= 0]
     assert 0 in alive and len(alive) >= 28
     assert np.all(np.isfinite(r["xs"][alive])) and np.all(np.isfinite(r["us"][alive]))
+
+
+def test_bench_walk_with_per_instance_references_matches_oracle(hip_lib, oracle_lib):
+    """The driver's HEADLINE mode at full size — walk, per-instance references, 64 instances, N = 100, complete model, 4 legs, tick reuse —
+    against the oracle, INSIDE the first replanning window (tick >= 100: every instance replans its footholds from its own measured
+    foot poses, every reference of every knot changes): instances {0, 17, 63}, four ticks, xs / us / K_0 within 1e-6 per component.
+    The oracle ensemble (3 instances, serial sweep) takes over the HIP iterate of tick 100 with the same stage ring and countdowns; up
+    to there the references do not depend on the measurements (no take-off inside the planning window, fulldynamic_talos.py:444-459)."""
+    from mpc_benchmark_amd import references as refgen
+    T0w, ticks = 100, 4
+    pd = FullDynamicsProblem(horizon=N, complete_model=True)
+    (a,) = make_bench_shards(pd, hip_lib, B, legs=4, tick_reuse=True)
+    a.prepare_schedule(T0w + ticks + 4)
+    a.cold_solve(max_iters=100)
+    a.enable_walk(per_instance=True)
+    assert _pipelined_ticks(a, T0w - 1) == 0
+    a.step()  # (synchronous: the measurement the next tick plans from is the state THIS tick predicted, as in the oracle's loop below)
+    ra = a.results(gains=True)
+    o = EnsembleMPC(FullDynamicsProblem(horizon=N, complete_model=True), batch=len(PICK), library=oracle_lib, x0=a.x0[PICK])
+    o.options.riccati_legs = 1
+    o.options.num_threads = os.cpu_count() or 8
+    o.options.max_iters = 1
+    o.native.set_options(o.options)
+    o.prepare_schedule(T0w + ticks + 4)
+    for t in range(T0w):
+        o.native.cycle(*o._table_for_tick(t % pd.t_mpc))
+    o.tick = T0w
+    o.enable_walk(per_instance=True)
+    for _ in range(T0w):
+        refgen.update_timings(o._walk["lists"][3], o._walk["lists"][2], o._walk["lists"][1], o._walk["lists"][0])
+    assert o._walk["lists"] == a._walk["lists"]
+    o._walk["x_measured_all"] = np.array(a._walk["x_measured_all"])[PICK].copy()
+    replanned = 0
+    for t in range(ticks):
+        if t == 0:  # the oracle's first tick starts from the HIP iterate (shifted by k_shift's rule), then it walks on its own
+            o._walk_references()
+            o.native.cycle(*o._table_for_tick(o.tick % pd.t_mpc))
+            o._walk_terminal()
+            xs, us = ra["xs"][PICK], ra["us"][PICK]
+            o.native.set_x0(xs[:, 1])
+            o.native.setup()
+            o.native.run(np.concatenate([xs[:, 1:], xs[:, -1:]], axis=1), np.concatenate([us[:, 1:], us[:, -1:]], axis=1))
+            o.native.set_x0(None)
+            o.tick += 1
+            o._walk["x_measured_all"] = o.results(gains=False)["xs"][:, 1].copy()
+        else:
+            o.step()
+        a.step()
+        replanned += int(a._walk["replanning"])
+        ra, ro = a.results(gains=True), o.results(gains=True)
+        for key, floor in (("xs", 1e-3), ("us", 1e-1)):
+            err = rel_cols(ra[key][PICK], ro[key], floor)
+            assert err < 1e-6, "walk tick %d: %s deviates from the oracle by %.2e" % (T0w + t, key, err)
+        errK = max(rel_tiles(ra["K"][i, 0], ro["K"][j, 0], 1e-6) for j, i in enumerate(PICK))
+        assert errK < 1e-6, "walk tick %d: K_0 deviates from the oracle by %.2e" % (T0w + t, errK)
+    assert replanned == ticks, "the compared ticks were meant to be replanning ticks"
+    # the instances really have references of their own by now
+    Lb = a._walk["last_all"][0]
+    assert np.max(np.abs(Lb[PICK[1]] - Lb[PICK[0]])) > 1e-6

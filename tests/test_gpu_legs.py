@@ -143,8 +143,9 @@ def test_hip_legs_equal_hip_serial(hip_lib, oracle_lib, kind, N, legs, complete)
             assert _rel(sl._native.debug_get(name, k), s1._native.debug_get(name, k)) < tol, (name, k)
             assert _rel(sl._native.debug_get(name, k), so._native.debug_get(name, k)) < tol, (name, k, "oracle serial")
     assert _relu(sl.results.controlFeedbacks()[0], s1.results.controlFeedbacks()[0]) < 1e-8
-    assert _relx(np.array(sl.results.xs), np.array(s1.results.xs)) < 1e-7
-    assert _relu(np.array(sl.results.us), np.array(s1.results.us)) < 1e-7
+    # trajectories component by component (a joint velocity of 1e-2 is held against itself, not against the base height): BASELINE.json's 1e-6
+    ex, eu = _relx(np.array(sl.results.xs), np.array(s1.results.xs)), _relu(np.array(sl.results.us), np.array(s1.results.us))
+    assert ex < 1e-6 and eu < 1e-7, (ex, eu)
 
 
 @pytest.mark.parametrize("chain", [False, True])
@@ -225,8 +226,8 @@ def test_full_size_workload_with_legs(hip_lib, oracle_lib, nlegs):
         solver.run(prob, xs, us)
         res[tag] = (np.array(solver.results.xs), np.array(solver.results.us), solver.results.controlFeedbacks()[0])
     for other in ("hip_serial", "oracle_serial"):
-        assert _relx(res["hip_legs"][0], res[other][0]) < 1e-7 and _relu(res["hip_legs"][1], res[other][1]) < 1e-7, other
-        assert _relu(res["hip_legs"][2], res[other][2]) < 1e-7, other
+        ex, eu, ek = _relx(res["hip_legs"][0], res[other][0]), _relu(res["hip_legs"][1], res[other][1]), _relu(res["hip_legs"][2], res[other][2])
+        assert ex < 1e-6 and eu < 1e-7 and ek < 1e-7, (other, ex, eu, ek)  # (states component by component: BASELINE.json's 1e-6)
 
 
 @pytest.mark.parametrize("horizon,legs", [(1, 8), (2, 8), (3, 2), (5, 16)])

@@ -1,0 +1,47 @@
+"""The kinodynamic control pipeline (mpc_benchmark_amd/pipeline.py: MPC tick -> K_0 feedback -> inverse-dynamics QP assembled on the
+library -> torque-driven simulator step, kinodynamic_talos.py:361-497) — on the oracle here (CPU), HIP against the oracle in the GPU test."""
+import numpy as np
+import pytest
+
+from mpc_benchmark_amd.pipeline import KinodynamicPipeline
+from mpc_benchmark_amd.problems.kinodynamic import KinodynamicProblem
+from tests._metrics import rel_cols
+
+
+def _pipeline(lib, batch=2, horizon=40, walk=None):
+    p = KinodynamicPipeline(KinodynamicProblem(horizon=horizon), batch=batch, library=lib, walk=walk, perturb=True, sigma_q=0.005, sigma_v=0.01)
+    p.mpc.options.num_threads = 8
+    p.mpc.native.set_options(p.mpc.options)
+    p.mpc.prepare_schedule(80)
+    assert all(s.converged >= 0 for s in p.cold_solve())  # (a perturbed kinodynamic cold solve may stop at the iteration limit: the loop below is what is checked)
+    return p
+
+
+def test_pipeline_keeps_the_robots_standing_on_the_oracle(oracle_lib):
+    p = _pipeline(oracle_lib, walk={})
+    z0 = p.x[:, 2].copy()
+    for _ in range(25):
+        st = p.tick()
+        assert all(s.converged >= 0 for s in st)
+    assert np.all(np.abs(p.x[:, 2] - z0) < 5e-3), p.x[:, 2] - z0          # nobody falls in 250 simulated milliseconds
+    assert np.all(np.abs(p.torques) <= p.umax + 1e-12)                    # kinodynamic_talos.py:448-456
+    assert np.all(p.forces[:, 2] > 100.0) and np.all(p.forces[:, 8] > 100.0)  # both feet carry weight in double support
+
+
+@pytest.mark.gpu
+def test_pipeline_hip_matches_oracle(hip_lib, oracle_lib):
+    """Eight MPC periods (80 low-level steps: QP + simulator step each) of two perturbed robots: measured states, QP torques and contact
+    forces of the HIP pipeline against the oracle pipeline, tick by tick.  The QP is solved to eps_abs = 1e-3 in <= 10 iterations
+    (QP_utils.py:500-507) by the same algorithm in both libraries: the torques agree far below that tolerance."""
+    ph, po = _pipeline(hip_lib, walk={}), _pipeline(oracle_lib, walk={})
+    ph.mpc.native.set_state(po.mpc.native.get_state())  # same cold-solved start
+    ph._fetch()
+    worst = 0.0
+    for t in range(8):
+        ph.tick(), po.tick()
+        ex = rel_cols(ph.x, po.x, 1e-3)
+        et = rel_cols(ph.torques, po.torques, 1.0)
+        ef = rel_cols(ph.forces, po.forces, 1.0)
+        assert ex < 1e-6 and et < 1e-5 and ef < 1e-5, "tick %d: states %.2e torques %.2e forces %.2e" % (t, ex, et, ef)
+        worst = max(worst, ex, et, ef)
+    print("pipeline: worst deviation over 8 ticks %.3e" % worst)
