@@ -25,6 +25,13 @@ from .aligator import manifolds as _manifolds
 from .robot import minipin as pin
 
 
+def _sim_options():
+    """option block of a simulator handle (never solves: only the library's own consistency checks look at it)"""
+    o = K.default_options(1e-5, 1e-8)
+    o.force_initial_condition, o.rollout_linear = 1, 1
+    return o
+
+
 class BulletRobot:
     record_default = False  # tools: keep (state, contact flags, sole heights) of every step in ``history``
 
@@ -114,7 +121,7 @@ class BulletRobot:
             d.max_stage_doubles = max(t[1].size for t in self._stage_tables.values()) + term[1].size + 1024
             d.device = 0
             self._native = K.NativeSolver(lib, d)
-            self._native.set_options(K.default_options(1e-5, 1e-8))
+            self._native.set_options(_sim_options())
         self._native.set_model(*ctx.model_tables())
         self._native.set_stage(1, *term)
         self._mask_uploaded = None

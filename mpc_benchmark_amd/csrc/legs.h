@@ -316,9 +316,15 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S, 
 // accumulator registers of the matrix cores over the whole leg; Phi and Gamma of the next knot are requested while this one computes.
 // ---------------------------------------------------------------------------------------------------------------------
 struct LcLds { int np, ldp, nb; int LM, BA, BB, vec, total_bytes; unsigned mg_np, mg_ldp; };
+// Leading dimension of the three operands: every matrix-core read of this kernel takes 16 CONSECUTIVE doubles of 4 rows per instruction
+// (ds_read_b64: two groups of 32 lanes, 64 banks of 4 bytes), so two rows of a group must lie half a bank row apart: ld = 16 mod 32
+// doubles (np = 80 itself).  With np + 1 (round 3) row k + 1 began two banks after row k ended its wrap: a 2-way conflict on EVERY operand
+// read (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 30 %, profiles/r03_sq_counters.txt).  Gamma is read through its transpose for that
+// (it is symmetric: -Bc Mu Bc^T - mu_d T (I - mu_d Pt) T^T).
+static inline int lc_ld(int np) { int ld = np; while ((ld & 31) != 16) ++ld; return ld; }
 static inline LcLds make_lc_lds(int n) {
   LcLds s;
-  s.np = (n + 15) & ~15; s.ldp = s.np + 1; s.nb = s.np / 16;
+  s.np = (n + 15) & ~15; s.ldp = lc_ld(s.np); s.nb = s.np / 16;
   s.mg_np = magic_div(s.np); s.mg_ldp = magic_div(s.ldp);
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
@@ -387,7 +393,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds
       const int t = wv + sidx * nw;
       lres[sidx] = d4_t{0, 0, 0, 0}; zres[sidx] = d4_t{0, 0, 0, 0};
       if (t < nb * nb)  // both products read the same columns of Lm': one pass, two accumulator chains
-        mma_tile_2a(lres[sidx], zres[sidx], BA + (t / nb) * 16, 1, ldp, BB + ((t / nb) * 16) * ldp, ldp, 1, LM + (t % nb) * 16, ldp, 1, np, lane);
+        mma_tile_2a(lres[sidx], zres[sidx], BA + (t / nb) * 16, 1, ldp, BB + (t / nb) * 16, 1, ldp, LM + (t % nb) * 16, ldp, 1, np, lane);  // (Gamma^T = Gamma)
     }
     LC_PROF(1);
     // (by the last two wavefronts — three tiles each above, the first has four — and over the zero-padded np rows with sixteen operands in

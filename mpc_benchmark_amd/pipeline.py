@@ -27,6 +27,13 @@ from .problems import common
 from .robot import minipin as pin
 
 
+def _sim_options():
+    """option block of a simulator handle (never solves: only the library's own consistency checks look at it)"""
+    o = K.default_options(1e-5, 1e-8)
+    o.force_initial_condition, o.rollout_linear = 1, 1
+    return o
+
+
 class KinodynamicPipeline:
     def __init__(self, problem_def, batch=1, library=None, walk=None, weights_id=(1.0, 10000.0), substeps=10, sim_dt=1e-3, x0=None, **ens_kw):
         """``problem_def``: a KinodynamicProblem.  ``walk``: keyword arguments of ``EnsembleMPC.enable_walk`` ({} = the script's 0.3 m steps)
@@ -81,7 +88,7 @@ class KinodynamicPipeline:
         d.max_stage_doubles = max(t[1].size for t in self._sim_tables.values()) + term[1].size + 1024
         d.device = self.mpc.dims.device
         self.sim = K.NativeSolver(self.lib, d)
-        self.sim.set_options(K.default_options(1e-5, 1e-8))
+        self.sim.set_options(_sim_options())
         self.sim.set_model(*ctx.model_tables())
         self.sim.set_stage(1, *term)
         self._sim_mask = None
