@@ -135,6 +135,15 @@ typedef struct mpc_options {
   int32_t forward_mode;    /* HIP forward sweep: 0 = automatic, 1 = one workgroup per instance walks the knots (least CU time: ensembles
                             * sharded over several handles of one GPU), 2 = knot-parallel closed-loop transitions first (shortest latency:
                             * a single small ensemble) ; oracle: ignored                */
+  int32_t refine_appended_knot; /* 0 (default): mpc_run_shifted duplicates the last control into the knot that mpc_cycle appended, as the scripts'
+                            * own warm-start shift does (us = us[1:] + [us[-1]], fulldynamic_talos.py:533).  R > 0: when the appended stage has a
+                            * different contact pattern than the stage before it (the duplicated torques then violate the new stage's wrench cone
+                            * by ~150 N: a foot that comes back to the ground pulls), the warm start of that ONE knot is made consistent with its
+                            * own stage first: R Newton steps on u_{N-1} alone, x_{N-1} fixed —
+                            *     du = -(H_uu + D_a^T D_a / mu)^-1 (g_u + D_a^T Pi_N(z)_a / mu)    (the knot's own penalty problem, active rows a)
+                            * then x_N = phi(x_{N-1}, u_{N-1}).  Costs R + 1 evaluations of one knot per instance on the ~1.4 % of the ticks
+                            * where the pattern changes; with it ensembles of randomised instances walk the whole schedule on ONE ProxDDP
+                            * iteration per tick.  Not something Aligator does: a choice of initial guess, off unless asked for. */
 } mpc_options;
 
 typedef struct mpc_stats {

@@ -42,7 +42,7 @@ class MpcOptions(C.Structure):
         "bcl_prim_alpha", "bcl_prim_beta", "bcl_dual_alpha", "bcl_dual_beta",
         "bcl_mu_update_factor", "bcl_mu_lower_bound", "inner_tol0", "prim_tol0")] + [(n, C.c_int32) for n in (
         "max_iters", "max_al_iters", "force_initial_condition", "rollout_linear", "ls_max_steps",
-        "num_threads", "riccati_legs", "forward_mode")]
+        "num_threads", "riccati_legs", "forward_mode", "refine_appended_knot")]
 
 
 def default_options(tol=1e-5, mu_init=1e-8):
@@ -56,6 +56,7 @@ def default_options(tol=1e-5, mu_init=1e-8):
     o.max_iters, o.max_al_iters = 1000, 100
     o.force_initial_condition, o.rollout_linear, o.ls_max_steps = 0, 0, 8
     o.num_threads, o.riccati_legs, o.forward_mode = 1, 1, 0
+    o.refine_appended_knot = 0
     return o
 
 

@@ -151,7 +151,8 @@ __global__ void __launch_bounds__(EVAL_THREADS, EVAL_MIN_WAVES) k_eval_multibody
   constexpr bool CAND = (TRIAL == 1 || TRIAL == 3);  // evaluated at the candidate point x (+) alpha dx
   if (TRIAL != 2 && (st.done || (CAND && st.skip_step))) return;
   if (TRIAL == 1 && cand > 0 && !st.ls_more) return;  // the full step was accepted: no backtracking candidates needed
-  if (TRIAL == 0 && knot_reused(a, b, k)) return;     // tick reuse: the record is there already (k_reproject refreshes its projections)
+  if (TRIAL == 0 && a.only_knot >= 0) { if (k != a.only_knot) return; }  // (refinement of the appended knot: this knot, afresh)
+  else if (TRIAL == 0 && knot_reused(a, b, k)) return;     // tick reuse: the record is there already (k_reproject refreshes its projections)
   const int n = L.n, N = L.N, nx = L.nx, nv = S.nv, nq = S.nq, nj = S.nj, nu = L.m;
   const int slot = stage_slot(a, k);
   const int32_t* desc = a.stage_desc + (size_t)slot * L.max_stage_ints;

@@ -15,6 +15,7 @@ __global__ void __launch_bounds__(64) k_eval_vector(SolverArgs a, Layout KL, dou
   const InstState& st = a.inst[b];
   if (st.done || (TRIAL && st.skip_step)) return;
   if (TRIAL && cand > 0 && !st.ls_more) return;  // the full step was accepted: no backtracking candidates needed
+  if (!TRIAL && a.only_knot >= 0 && k != a.only_knot) return;  // (refinement of the appended knot)
   const int n = L.n, N = L.N, nx = L.nx, mfull = L.m;
   const int slot = stage_slot(a, k);
   const int32_t* desc = a.stage_desc + (size_t)slot * L.max_stage_ints;

@@ -71,6 +71,9 @@ struct mpc_solver {
   int khead = 0;
   int* d_spec = nullptr;
   double* d_fext = nullptr;  // [B][3] disturbance force of mpc_simulate_push
+  int only_knot = -1;              // SolverArgs::only_knot of the launches being enqueued
+  bool appended_changed = false;   // the stage of the last mpc_cycle has another contact pattern than its predecessor (refine_appended_knot)
+  bool refine_now = false;         // ... and this run refines the warm start of the appended knot after k_begin_run
   double* d_simu = nullptr;  // [B][nu] torques, [B][12] wrenches of mpc_simulate_torque
   double* d_simwr = nullptr;
   // per-slot invalidation (mpc_update_stage_params*): slots whose parameters changed since the last pass was enqueued ; dirty_all:
@@ -183,6 +186,7 @@ struct mpc_solver {
     a.reuse_same = (a.reuse_on && reuse_same_now) ? 1 : 0;
     a.spec_knot = a.spec_on ? d_spec_knot : nullptr; a.spec_next = (a.reuse_on && spec_next_now) ? 1 : 0;
     for (int w = 0; w < MPC_DIRTY_WORDS; ++w) a.dirty[w] = a.reuse_on ? dirty_now[w] : 0ull;
+    a.only_knot = only_knot;
     a.nlegs = eff_legs(); a.leg_cap = leg_cap; a.legbuf = d_legbuf; a.treebuf = d_treebuf; a.leg_guess = leg_guess_now;
     a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = phase_timers ? d_prof : nullptr;
     return a;
@@ -710,10 +714,36 @@ static void report_status(mpc_solver* s, int B, const InstState* st, mpc_stats* 
   }
 }
 
+// mpc_options.refine_appended_knot: R x (evaluate knot N - 1 alone, Newton step on its control), one more evaluation, x_N = phi(...).
+// Enqueued after k_begin_run (the stage kernel skips instances that are `done`) and before the first pass, which evaluates knots N - 1
+// and N afresh (begin_refine marked their slots dirty before the knot mask of the pass was taken).
+static void begin_refine(mpc_solver* s) {
+  s->refine_now = s->opt.refine_appended_knot > 0 && s->appended_changed && s->L.N >= 1;
+  s->appended_changed = false;
+  if (s->refine_now) { s->slot_dirty[slot_of(s, s->L.N - 1)] = 1; s->slot_dirty[s->L.N] = 1; }
+}
+static void launch_refine(mpc_solver* s) {
+  if (!s->refine_now) return;
+  s->refine_now = false;
+  const Layout& L = s->L;
+  const bool reuse_keep = s->reuse_this_pass;
+  s->reuse_this_pass = false;  // (plain evaluation of the one knot: no record is taken over)
+  s->only_knot = L.N - 1;
+  for (int it = 0; it <= s->opt.refine_appended_knot; ++it) {
+    s->timed(18, "k_refine_appended_knot", [&] {
+      launch_eval(s, false);
+      hipLaunchKernelGGL(k_refine_knot, dim3(L.B), dim3(256), 0, s->stream, s->args(), it < s->opt.refine_appended_knot ? 0 : 1);
+    });
+  }
+  s->only_knot = -1;
+  s->reuse_this_pass = reuse_keep;
+  HIP_OK(hipGetLastError());
+}
+
 static void run_impl(mpc_solver* s, mpc_stats* stats, int passes_enqueued = 0) {
   const Layout& L = s->L;
   SolverArgs a = s->args();
-  if (passes_enqueued == 0) hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, a);
+  if (passes_enqueued == 0) { hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, a); launch_refine(s); }
   const int max_passes = s->opt.max_iters + s->opt.max_al_iters + 1;
   std::vector<InstState> st(L.B);
   for (int pass = 0; pass < max_passes; ++pass) {
@@ -937,6 +967,8 @@ int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* 
       const bool same = s->h_len[2 * last] == n_desc && s->h_len[2 * last + 1] == n_params && std::memcmp(hd, desc, n_desc * sizeof(int32_t)) == 0 &&
                         (n_params == 0 || std::memcmp(hp, params, n_params * sizeof(double)) == 0);
       s->cycles_since_run += 1;
+      // refine_appended_knot: another dynamics kind / contact list than the stage before it (descriptor words 0 .. 3)
+      s->appended_changed = n_desc >= 4 && s->h_len[2 * last] >= 4 && std::memcmp(hd, desc, 4 * sizeof(int32_t)) != 0;
       // (a last stage whose parameters were patched after the speculative evaluation: the spare record is stale)
       s->spec_next_pending = same && s->spec_rec_valid && s->cycles_since_run == 1 && !s->slot_dirty[last] && !s->dirty_all;
     }
@@ -1201,6 +1233,7 @@ int mpc_setup(mpc_solver* s) {
 
 int mpc_run(mpc_solver* s, const double* xs, const double* us, mpc_stats* stats) {
   MPC_TRY(s, {
+    s->appended_changed = false; s->refine_now = false;  // (an uploaded warm start is the caller's: it stays as it is)
     spec_clear(s);
     s->reuse_this_pass = false;
     // A multi-iteration solve starts from an iterate the handle has never seen (cold start): the cut Hessians kept from the last pass
@@ -1220,6 +1253,7 @@ int mpc_run_shifted(mpc_solver* s, mpc_stats* stats) {
   MPC_TRY(s, {
     if (s->tick_reuse) { s->khead = (s->khead + 1) % s->L.N; s->reuse_this_pass = true; s->spec_next_now = s->spec_next_pending; }  // the records move one knot on with the iterate
     s->spec_next_pending = false; s->cycles_since_run = 0;
+    begin_refine(s);
     begin_reuse_pass(s);
     launch_shift(s);
     run_impl(s, stats);
@@ -1237,9 +1271,11 @@ int mpc_run_shifted_async(mpc_solver* s) {
     }
     if (s->tick_reuse) { s->khead = (s->khead + 1) % L.N; s->reuse_this_pass = true; s->spec_next_now = s->spec_next_pending; }
     s->spec_next_pending = false; s->cycles_since_run = 0;
+    begin_refine(s);
     begin_reuse_pass(s);
     launch_shift(s);
     hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, s->args());
+    launch_refine(s);
     // with max_iters = 1 one pass takes the step; a few iterations per tick (max_iters <= 4) are enqueued together — a younger tick
     // may be queued behind this one before its status is read; workgroups of instances that are done exit at once
     const int n_pass = s->opt.max_iters < 1 ? 1 : (s->opt.max_iters > 4 ? 4 : s->opt.max_iters);

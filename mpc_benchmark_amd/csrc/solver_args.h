@@ -51,6 +51,9 @@ struct SolverArgs {
   // knots (bit k of word k / 64) whose stage parameters changed since their record was written (setReference, a rebuilt terminal
   // constraint: mpc_update_stage_params): the launch of the current point evaluates them afresh, the others stay reused
   unsigned long long dirty[MPC_DIRTY_WORDS];
+  // >= 0: the launch of the current point evaluates THIS knot only, whatever tick reuse says (the warm-start refinement of the appended
+  // knot, mpc_options.refine_appended_knot) ; -1: all knots
+  int only_knot;
 };
 
 // first knot of leg j (leg nlegs - 1 ends with the terminal knot) — the rule of oracle/solver.hpp leg_start

@@ -662,6 +662,70 @@ __global__ void __launch_bounds__(64) k_linesearch(SolverArgs a, int first, int 
 }
 
 // ------------------------------------------------------------------------------------------------
+// mpc_options.refine_appended_knot (include/mpc_abi.h): warm start of the knot mpc_cycle appended, made consistent with its own stage.
+// grid B, block 256.  mode 0: one Newton step on u_{N-1} alone from the record the stage kernel has just written for knot N - 1
+//   (x_{N-1} fixed):  A = sym(H_uu) + D_a^T D_a / mu ,  r = g_u + D_a^T Pi_N(z)_a / mu ,  u -= A^-1 r   (Cholesky in LDS; an indefinite
+//   A leaves u as it is).  mode 1: x_N = phi(x_{N-1}, u_{N-1}) from the record.  Same arithmetic as oracle/solver.hpp refine_appended_knot.
+// ------------------------------------------------------------------------------------------------
+#define MPC_REFINE_MP 48
+__global__ void __launch_bounds__(256) k_refine_knot(SolverArgs a, int mode) {
+  const Layout& L = a.L;
+  const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+  const InstState& st = a.inst[b];
+  if (st.done || st.converged < 0) return;
+  const int N = L.N, n = L.n, nz = L.nz;
+  const double* kn = knot_ptr(a, b, N - 1);
+  if (mode == 1) {
+    double* xN = a.xs + ((size_t)b * (N + 1) + N) * L.nx;
+    for (int i = tid; i < L.nx; i += nthr) xN[i] = kn[L.oXN + i];
+    return;
+  }
+  const int m = (int)kn[L.oMISC + MISC_M], c = (int)kn[L.oMISC + MISC_NC];
+  if (m <= 0 || m > MPC_REFINE_MP) return;
+  const double imu = 1.0 / st.mu;
+  __shared__ double A[MPC_REFINE_MP * (MPC_REFINE_MP + 1)], r[MPC_REFINE_MP];
+  __shared__ int ok;
+  const int ld = MPC_REFINE_MP + 1;
+  for (int idx = tid; idx < m * m; idx += nthr) {
+    const int i = idx / m, j = idx % m;
+    double s = 0.5 * (kn[L.oH + (n + i) * nz + n + j] + kn[L.oH + (n + j) * nz + n + i]);
+    for (int q = 0; q < c; ++q) if (kn[L.oACT + q] != 0.0) s += kn[L.oCD + q * nz + n + i] * kn[L.oCD + q * nz + n + j] * imu;
+    A[i * ld + j] = s;
+  }
+  for (int i = tid; i < m; i += nthr) {
+    double s = kn[L.oG + n + i];
+    for (int q = 0; q < c; ++q) if (kn[L.oACT + q] != 0.0) s += kn[L.oCD + q * nz + n + i] * kn[L.oDT + q] * imu;
+    r[i] = s;
+  }
+  if (tid == 0) ok = 1;
+  __syncthreads();
+  for (int j = 0; j < m; ++j) {  // right-looking Cholesky, lower triangle in place
+    if (tid == 0) { const double d = A[j * ld + j]; if (d > 0.0) A[j * ld + j] = sqrt(d); else ok = 0; }
+    __syncthreads();
+    if (!ok) return;
+    const double dj = A[j * ld + j];
+    for (int i = j + 1 + tid; i < m; i += nthr) A[i * ld + j] /= dj;
+    __syncthreads();
+    for (int idx = tid; idx < (m - j - 1) * (m - j - 1); idx += nthr) {
+      const int i = j + 1 + idx / (m - j - 1), k2 = j + 1 + idx % (m - j - 1);
+      if (k2 <= i) A[i * ld + k2] -= A[i * ld + j] * A[k2 * ld + j];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    for (int i = 0; i < m; ++i) { double s = r[i]; for (int q = 0; q < i; ++q) s -= A[i * ld + q] * r[q]; r[i] = s / A[i * ld + i]; }
+    for (int i = m - 1; i >= 0; --i) { double s = r[i]; for (int q = i + 1; q < m; ++q) s -= A[q * ld + i] * r[q]; r[i] = s / A[i * ld + i]; }
+    bool fin = true;
+    for (int i = 0; i < m; ++i) fin = fin && isfinite(r[i]);
+    ok = fin ? 1 : 0;
+  }
+  __syncthreads();
+  if (!ok) return;
+  double* u = a.us + ((size_t)b * N + N - 1) * L.m;
+  for (int i = tid; i < m; i += nthr) u[i] -= r[i];
+}
+
+// ------------------------------------------------------------------------------------------------
 // P9: accept the step.  grid (N+1, B), block 64
 // ------------------------------------------------------------------------------------------------
 __global__ void k_accept(SolverArgs a) {

@@ -150,7 +150,7 @@ struct Solver {
     opt.bcl_mu_update_factor = 0.01; opt.bcl_mu_lower_bound = 1e-8;
     opt.inner_tol0 = 1.0; opt.prim_tol0 = 1.0;
     opt.max_iters = 100; opt.max_al_iters = 100; opt.force_initial_condition = 1; opt.rollout_linear = 1;
-    opt.ls_max_steps = 8; opt.num_threads = 1; opt.riccati_legs = 1;
+    opt.ls_max_steps = 8; opt.num_threads = 1; opt.riccati_legs = 1; opt.refine_appended_knot = 0;
   }
 
   void init(const mpc_dims& d) {
@@ -1036,6 +1036,42 @@ struct Solver {
       x = kn.xnext;
     }
     in.x0 = x;
+  }
+
+  // mpc_options.refine_appended_knot (include/mpc_abi.h): the knot mpc_cycle appended starts from a control consistent with ITS stage —
+  // R Newton steps on u_{N-1} alone (x_{N-1} fixed) on the knot's own penalty problem, then x_N = phi(x_{N-1}, u_{N-1}).
+  void refine_appended_knot(Instance& in) {
+    const int N = dims.horizon, n = dims.ndx;
+    const int b_inst = (int)(&in - inst.data());
+    if (N < 1 || in.mu <= 0.0) return;
+    Knot kn;
+    for (int it = 0; it < opt.refine_appended_knot; ++it) {
+      eval_knot(b_inst, N - 1, in.xs[N - 1].data(), in.us[N - 1].data(), in.xs[N].data(), kn, true);
+      const int m = kn.m, nz = n + m;
+      if (m <= 0) return;
+      std::vector<double> A((size_t)m * m), rhs(m);
+      for (int i = 0; i < m; ++i) {
+        rhs[i] = kn.grad[n + i];
+        for (int j = 0; j < m; ++j) A[(size_t)i * m + j] = 0.5 * (kn.H[(size_t)(n + i) * nz + n + j] + kn.H[(size_t)(n + j) * nz + n + i]);
+      }
+      for (int r = 0; r < kn.c; ++r) {
+        bool act;
+        const double z = kn.cval[r] + in.mu * in.vs_e[N - 1][r];
+        const double pn = proj_normal(kn.ctype[r], z, kn.lo[r], kn.hi[r], act);
+        if (!act) continue;
+        const double* d = kn.CD.data() + (size_t)r * nz + n;
+        for (int i = 0; i < m; ++i) {
+          rhs[i] += d[i] * pn / in.mu;
+          for (int j = 0; j < m; ++j) A[(size_t)i * m + j] += d[i] * d[j] / in.mu;
+        }
+      }
+      if (!chol_lower(A.data(), m)) return;  // (an indefinite knot Hessian: the warm start stays as it is)
+      trsm_lower(A.data(), m, rhs.data(), 1); trsm_lower_t(A.data(), m, rhs.data(), 1);
+      for (int i = 0; i < m; ++i) if (!std::isfinite(rhs[i])) return;
+      for (int i = 0; i < m; ++i) in.us[N - 1][i] -= rhs[i];
+    }
+    eval_knot(b_inst, N - 1, in.xs[N - 1].data(), in.us[N - 1].data(), in.xs[N].data(), kn, false);
+    in.xs[N] = kn.xnext;
   }
 
   // Torque-driven form of the stand-in (bullet_robot.py:138-145 execute + stepSimulation): knot 0's contact dynamics under the given joint
