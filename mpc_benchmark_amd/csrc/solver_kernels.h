@@ -664,10 +664,29 @@ __global__ void __launch_bounds__(64) k_linesearch(SolverArgs a, int first, int 
 // ------------------------------------------------------------------------------------------------
 // mpc_options.refine_appended_knot (include/mpc_abi.h): warm start of the knot mpc_cycle appended, made consistent with its own stage.
 // grid B, block 256.  mode 0: one Newton step on u_{N-1} alone from the record the stage kernel has just written for knot N - 1
-//   (x_{N-1} fixed):  A = sym(H_uu) + D_a^T D_a / mu ,  r = g_u + D_a^T Pi_N(z)_a / mu ,  u -= A^-1 r   (Cholesky in LDS; an indefinite
-//   A leaves u as it is).  mode 1: x_N = phi(x_{N-1}, u_{N-1}) from the record.  Same arithmetic as oracle/solver.hpp refine_appended_knot.
+// (x_{N-1} fixed), the stage KKT system of that knot with the controls eliminated first (as the Riccati sweep does):
+//     Huu = L L^T ;  Y = L^-1 D_a^T ;  S = Y^T Y + rho I ;  nu = S^-1 (Pi_N(z)_a - Y^T L^-1 g_u) ;  du = -L^-T (L^-1 g_u + Y nu)
+// rho = max(mu, 1e-8 max diag(Y^T Y)): see oracle/solver.hpp refine_appended_knot (same arithmetic) for why not mu itself.
+// An indefinite block or more than MPC_REFINE_MP active rows leave u as it is.  mode 1: x_N = phi(x_{N-1}, u_{N-1}) from the record.
 // ------------------------------------------------------------------------------------------------
 #define MPC_REFINE_MP 48
+// Cholesky of the n x n matrix A (leading dimension ld, lower triangle in place) by the whole workgroup; *ok = 0 if it is not positive definite
+DEV void refine_chol(double* A, int ld, int n, int tid, int nthr, int* ok) {
+  for (int j = 0; j < n; ++j) {
+    if (tid == 0) { const double d = A[j * ld + j]; if (d > 0.0) A[j * ld + j] = sqrt(d); else *ok = 0; }
+    __syncthreads();
+    if (!*ok) return;
+    const double dj = A[j * ld + j];
+    for (int i = j + 1 + tid; i < n; i += nthr) A[i * ld + j] /= dj;
+    __syncthreads();
+    const int r = n - j - 1;
+    for (int idx = tid; idx < r * r; idx += nthr) {
+      const int i = j + 1 + idx / r, k2 = j + 1 + idx % r;
+      if (k2 <= i) A[i * ld + k2] -= A[i * ld + j] * A[k2 * ld + j];
+    }
+    __syncthreads();
+  }
+}
 __global__ void __launch_bounds__(256) k_refine_knot(SolverArgs a, int mode) {
   const Layout& L = a.L;
   const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
@@ -682,47 +701,73 @@ __global__ void __launch_bounds__(256) k_refine_knot(SolverArgs a, int mode) {
   }
   const int m = (int)kn[L.oMISC + MISC_M], c = (int)kn[L.oMISC + MISC_NC];
   if (m <= 0 || m > MPC_REFINE_MP) return;
-  const double imu = 1.0 / st.mu;
-  __shared__ double A[MPC_REFINE_MP * (MPC_REFINE_MP + 1)], r[MPC_REFINE_MP];
-  __shared__ int ok;
-  const int ld = MPC_REFINE_MP + 1;
+  constexpr int ld = MPC_REFINE_MP + 1;
+  __shared__ double A[MPC_REFINE_MP * ld], Y[MPC_REFINE_MP * ld], S[MPC_REFINE_MP * ld], w[MPC_REFINE_MP], nu[MPC_REFINE_MP], v[MPC_REFINE_MP];
+  __shared__ int act[MPC_REFINE_MP], ca_s, ok;
+  if (tid == 0) {
+    int ca = 0;
+    for (int q = 0; q < c; ++q) if (kn[L.oACT + q] != 0.0) { if (ca < MPC_REFINE_MP) act[ca] = q; ++ca; }
+    ca_s = ca; ok = 1;
+  }
   for (int idx = tid; idx < m * m; idx += nthr) {
     const int i = idx / m, j = idx % m;
-    double s = 0.5 * (kn[L.oH + (n + i) * nz + n + j] + kn[L.oH + (n + j) * nz + n + i]);
-    for (int q = 0; q < c; ++q) if (kn[L.oACT + q] != 0.0) s += kn[L.oCD + q * nz + n + i] * kn[L.oCD + q * nz + n + j] * imu;
-    A[i * ld + j] = s;
+    A[i * ld + j] = 0.5 * (kn[L.oH + (n + i) * nz + n + j] + kn[L.oH + (n + j) * nz + n + i]);
   }
-  for (int i = tid; i < m; i += nthr) {
-    double s = kn[L.oG + n + i];
-    for (int q = 0; q < c; ++q) if (kn[L.oACT + q] != 0.0) s += kn[L.oCD + q * nz + n + i] * kn[L.oDT + q] * imu;
-    r[i] = s;
-  }
-  if (tid == 0) ok = 1;
+  for (int i = tid; i < m; i += nthr) w[i] = kn[L.oG + n + i];
   __syncthreads();
-  for (int j = 0; j < m; ++j) {  // right-looking Cholesky, lower triangle in place
-    if (tid == 0) { const double d = A[j * ld + j]; if (d > 0.0) A[j * ld + j] = sqrt(d); else ok = 0; }
-    __syncthreads();
-    if (!ok) return;
-    const double dj = A[j * ld + j];
-    for (int i = j + 1 + tid; i < m; i += nthr) A[i * ld + j] /= dj;
-    __syncthreads();
-    for (int idx = tid; idx < (m - j - 1) * (m - j - 1); idx += nthr) {
-      const int i = j + 1 + idx / (m - j - 1), k2 = j + 1 + idx % (m - j - 1);
-      if (k2 <= i) A[i * ld + k2] -= A[i * ld + j] * A[k2 * ld + j];
+  const int ca = ca_s;
+  if (ca > MPC_REFINE_MP) return;
+  for (int idx = tid; idx < m * ca; idx += nthr) { const int i = idx / ca, q = idx % ca; Y[i * ld + q] = kn[L.oCD + act[q] * nz + n + i]; }
+  for (int q = tid; q < ca; q += nthr) v[q] = kn[L.oDT + act[q]];
+  refine_chol(A, ld, m, tid, nthr, &ok);
+  if (!ok) return;
+  // forward substitutions L [Y | w] = [D_a^T | g_u]: a thread per right-hand side
+  if (tid <= ca) {
+    const int q = tid;
+    for (int i = 0; i < m; ++i) {
+      double t = (q < ca) ? Y[i * ld + q] : w[i];
+      for (int k2 = 0; k2 < i; ++k2) t -= A[i * ld + k2] * ((q < ca) ? Y[k2 * ld + q] : w[k2]);
+      t /= A[i * ld + i];
+      if (q < ca) Y[i * ld + q] = t; else w[i] = t;
     }
+  }
+  __syncthreads();
+  if (ca > 0) {
+    for (int idx = tid; idx < ca * ca; idx += nthr) {
+      const int p = idx / ca, q = idx % ca;
+      double t = 0;
+      for (int i = 0; i < m; ++i) t += Y[i * ld + p] * Y[i * ld + q];
+      S[p * ld + q] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double dmax = 0.0;
+      for (int q = 0; q < ca; ++q) dmax = fmax(dmax, S[q * ld + q]);
+      const double rho = fmax(st.mu, 1e-8 * dmax);
+      for (int q = 0; q < ca; ++q) S[q * ld + q] += rho;
+    }
+    for (int q = tid; q < ca; q += nthr) { double t = v[q]; for (int i = 0; i < m; ++i) t -= Y[i * ld + q] * w[i]; nu[q] = t; }
+    __syncthreads();
+    refine_chol(S, ld, ca, tid, nthr, &ok);
+    if (!ok) return;
+    if (tid == 0) {
+      for (int i = 0; i < ca; ++i) { double t = nu[i]; for (int k2 = 0; k2 < i; ++k2) t -= S[i * ld + k2] * nu[k2]; nu[i] = t / S[i * ld + i]; }
+      for (int i = ca - 1; i >= 0; --i) { double t = nu[i]; for (int k2 = i + 1; k2 < ca; ++k2) t -= S[k2 * ld + i] * nu[k2]; nu[i] = t / S[i * ld + i]; }
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += nthr) { double t = w[i]; for (int q = 0; q < ca; ++q) t += Y[i * ld + q] * nu[q]; w[i] = t; }
     __syncthreads();
   }
   if (tid == 0) {
-    for (int i = 0; i < m; ++i) { double s = r[i]; for (int q = 0; q < i; ++q) s -= A[i * ld + q] * r[q]; r[i] = s / A[i * ld + i]; }
-    for (int i = m - 1; i >= 0; --i) { double s = r[i]; for (int q = i + 1; q < m; ++q) s -= A[q * ld + i] * r[q]; r[i] = s / A[i * ld + i]; }
+    for (int i = m - 1; i >= 0; --i) { double t = w[i]; for (int k2 = i + 1; k2 < m; ++k2) t -= A[k2 * ld + i] * w[k2]; w[i] = t / A[i * ld + i]; }
     bool fin = true;
-    for (int i = 0; i < m; ++i) fin = fin && isfinite(r[i]);
+    for (int i = 0; i < m; ++i) fin = fin && isfinite(w[i]);
     ok = fin ? 1 : 0;
   }
   __syncthreads();
   if (!ok) return;
   double* u = a.us + ((size_t)b * N + N - 1) * L.m;
-  for (int i = tid; i < m; i += nthr) u[i] -= r[i];
+  for (int i = tid; i < m; i += nthr) u[i] -= w[i];
 }
 
 // ------------------------------------------------------------------------------------------------

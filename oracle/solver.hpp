@@ -1039,7 +1039,12 @@ struct Solver {
   }
 
   // mpc_options.refine_appended_knot (include/mpc_abi.h): the knot mpc_cycle appended starts from a control consistent with ITS stage —
-  // R Newton steps on u_{N-1} alone (x_{N-1} fixed) on the knot's own penalty problem, then x_N = phi(x_{N-1}, u_{N-1}).
+  // R Newton steps on u_{N-1} alone (x_{N-1} fixed) on the knot's own penalty problem, then x_N = phi(x_{N-1}, u_{N-1}).  Each step is
+  // the stage KKT system of the knot with the controls eliminated first (as in knot_backward):
+  //     Huu = L L^T ;  Y = L^-1 D_a^T ;  S = Y^T Y + rho I ;  nu = S^-1 (Pi_N(z)_a - Y^T L^-1 g_u) ;  du = -L^-T (L^-1 g_u + Y nu)
+  // with rho = max(mu, 1e-8 max diag(Y^T Y)): the active rows of a wrench cone are linearly dependent (more than six rows on a 6-D
+  // wrench), and with rho = mu = 1e-8 the step is only determined to ~1e-4 (cond(S) ~ 1e12: two libraries, two answers); the relative
+  // floor makes it reproducible to ~1e-8 at the price of an inexact restoration along directions that D_a^T annihilates anyway.
   void refine_appended_knot(Instance& in) {
     const int N = dims.horizon, n = dims.ndx;
     const int b_inst = (int)(&in - inst.data());
@@ -1049,26 +1054,43 @@ struct Solver {
       eval_knot(b_inst, N - 1, in.xs[N - 1].data(), in.us[N - 1].data(), in.xs[N].data(), kn, true);
       const int m = kn.m, nz = n + m;
       if (m <= 0) return;
-      std::vector<double> A((size_t)m * m), rhs(m);
+      std::vector<double> Lr((size_t)m * m), w(m);
       for (int i = 0; i < m; ++i) {
-        rhs[i] = kn.grad[n + i];
-        for (int j = 0; j < m; ++j) A[(size_t)i * m + j] = 0.5 * (kn.H[(size_t)(n + i) * nz + n + j] + kn.H[(size_t)(n + j) * nz + n + i]);
+        w[i] = kn.grad[n + i];
+        for (int j = 0; j < m; ++j) Lr[(size_t)i * m + j] = 0.5 * (kn.H[(size_t)(n + i) * nz + n + j] + kn.H[(size_t)(n + j) * nz + n + i]);
       }
+      std::vector<int> act;
+      std::vector<double> v;
       for (int r = 0; r < kn.c; ++r) {
-        bool act;
-        const double z = kn.cval[r] + in.mu * in.vs_e[N - 1][r];
-        const double pn = proj_normal(kn.ctype[r], z, kn.lo[r], kn.hi[r], act);
-        if (!act) continue;
-        const double* d = kn.CD.data() + (size_t)r * nz + n;
-        for (int i = 0; i < m; ++i) {
-          rhs[i] += d[i] * pn / in.mu;
-          for (int j = 0; j < m; ++j) A[(size_t)i * m + j] += d[i] * d[j] / in.mu;
-        }
+        bool a_;
+        const double pn = proj_normal(kn.ctype[r], kn.cval[r] + in.mu * in.vs_e[N - 1][r], kn.lo[r], kn.hi[r], a_);
+        if (a_) { act.push_back(r); v.push_back(pn); }
       }
-      if (!chol_lower(A.data(), m)) return;  // (an indefinite knot Hessian: the warm start stays as it is)
-      trsm_lower(A.data(), m, rhs.data(), 1); trsm_lower_t(A.data(), m, rhs.data(), 1);
-      for (int i = 0; i < m; ++i) if (!std::isfinite(rhs[i])) return;
-      for (int i = 0; i < m; ++i) in.us[N - 1][i] -= rhs[i];
+      const int ca = (int)act.size();
+      if (ca > 48) return;  // (the HIP kernel's LDS carve-out)
+      if (!chol_lower(Lr.data(), m)) return;  // (an indefinite knot Hessian: the warm start stays as it is)
+      trsm_lower(Lr.data(), m, w.data(), 1);
+      std::vector<double> Y((size_t)m * std::max(ca, 1)), nu(std::max(ca, 1), 0.0);
+      if (ca > 0) {
+        for (int i = 0; i < m; ++i) for (int q = 0; q < ca; ++q) Y[(size_t)i * ca + q] = kn.CD[(size_t)act[q] * nz + n + i];
+        trsm_lower(Lr.data(), m, Y.data(), ca);
+        std::vector<double> S((size_t)ca * ca);
+        double dmax = 0.0;
+        for (int p = 0; p < ca; ++p) for (int q = 0; q < ca; ++q) { double t = 0; for (int i = 0; i < m; ++i) t += Y[(size_t)i * ca + p] * Y[(size_t)i * ca + q]; S[(size_t)p * ca + q] = t; if (p == q) dmax = std::max(dmax, t); }
+        const double rho = std::max(in.mu, 1e-8 * dmax);
+        for (int q = 0; q < ca; ++q) {
+          S[(size_t)q * ca + q] += rho;
+          double t = v[q];
+          for (int i = 0; i < m; ++i) t -= Y[(size_t)i * ca + q] * w[i];
+          nu[q] = t;
+        }
+        if (!chol_lower(S.data(), ca)) return;
+        trsm_lower(S.data(), ca, nu.data(), 1); trsm_lower_t(S.data(), ca, nu.data(), 1);
+        for (int i = 0; i < m; ++i) { double t = w[i]; for (int q = 0; q < ca; ++q) t += Y[(size_t)i * ca + q] * nu[q]; w[i] = t; }
+      }
+      trsm_lower_t(Lr.data(), m, w.data(), 1);
+      for (int i = 0; i < m; ++i) if (!std::isfinite(w[i])) return;
+      for (int i = 0; i < m; ++i) in.us[N - 1][i] -= w[i];
     }
     eval_knot(b_inst, N - 1, in.xs[N - 1].data(), in.us[N - 1].data(), in.xs[N].data(), kn, false);
     in.xs[N] = kn.xnext;
