@@ -163,6 +163,10 @@ def main():
     ap.add_argument("--iters-per-tick", type=int, default=1,
                     help="ProxDDP iterations per MPC tick: 1 = the reference loop (solver.max_iters = 1, fulldynamic_talos.py:407); 2 = the setting that "
                          "keeps every randomised instance stable over the whole 1000-tick schedule (DESIGN.md §5).  The default run also reports a walk measurement with 2.")
+    ap.add_argument("--refine-appended-knot", type=int, default=3,
+                    help="mpc_options.refine_appended_knot: Newton steps on the control of the knot mpc_cycle appends when its contact pattern differs from the "
+                         "stage before it (include/mpc_abi.h) — the warm-start choice under which ensembles of randomised instances walk the whole schedule on "
+                         "one ProxDDP iteration per tick; 0 = the scripts' plain duplicate us[-1] (fulldynamic_talos.py:533)")
     ap.add_argument("--legs", type=int, default=4,
                     help="legs of the parallel-in-time Riccati sweep (mpc_options.riccati_legs: linear_solver_choice = LQ_SOLVER_PARALLEL of "
                          "fulldynamic_talos.py:383; the script's setNumThreads(8) is a CPU thread count — 64 instances x 4 legs fill the 256 CUs); "
@@ -211,6 +215,8 @@ def main():
         ens = shards[0]
         for e in shards:
             e.iters_per_tick = int(iters)
+            e.options.refine_appended_knot = int(args.refine_appended_knot)
+            e.native.set_options(e.options)
         legs = int(ens.options.riccati_legs)
         # Walk mode: the generator REPLANS from the measured poses during the T_ds ticks before every take-off (27 % of the ticks of
         # the schedule: T_ds / (T_ds + T_ss)) — on those every knot's reference changes and nothing of the previous tick can be
@@ -594,9 +600,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "timed_regions": mres["regions"], "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "Talos full-dynamics MPC (fulldynamic_talos.py OCP), synthetic Talos %s model nq=%d nv=%d nu=%d, "
-                               "horizon N=%d, ensemble of %d instances per GPU, %d ProxDDP iteration(s) per solve (max_iters=%d, warm start)"
-                               % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch, args.iters_per_tick, args.iters_per_tick),
-                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "riccati_legs": legs, "tick_reuse": not args.no_tick_reuse, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
+                               "horizon N=%d, ensemble of %d instances per GPU, %d ProxDDP iteration(s) per solve (max_iters=%d, warm start shifted on the device%s)"
+                               % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch, args.iters_per_tick, args.iters_per_tick,
+                                  ", control of the appended knot refined on contact-pattern changes: refine_appended_knot=%d" % args.refine_appended_knot if args.refine_appended_knot > 0 else ""),
+                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "riccati_legs": legs, "tick_reuse": not args.no_tick_reuse, "refine_appended_knot": args.refine_appended_knot, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
         "p50_ms_per_solve_batch1": p50_ms, "p90_ms_per_solve_batch1": p90_ms, "p95_ms_per_solve_batch1": p95_ms, "latency_ticks": (300 if p50_ms is not None else 0), "p50_riccati_legs": (args.latency_legs if args.legs != 1 else 1),
         "riccati_cuts": ("chain (MPC_LEGS_CHAIN)" if os.environ.get("MPC_LEGS_CHAIN", "0") not in ("", "0") else "tree of pairwise compositions (csrc/legs_tree.h) from three legs on"),

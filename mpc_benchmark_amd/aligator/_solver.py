@@ -159,6 +159,7 @@ class SolverProxDDP:
         self.reg_init = 1e-9
         self.num_threads = 1
         self.riccati_legs = None  # None: chosen by _legs()
+        self.refine_appended_knot = 0  # mpc_options.refine_appended_knot (this build's extension: 0 = the scripts' plain warm-start shift)
         self.batch = 1
         self.results = Results()
         self.workspace = None
@@ -185,6 +186,7 @@ class SolverProxDDP:
         o.rollout_linear = 1 if self.rollout_type == ROLLOUT_LINEAR else 0
         o.num_threads = self.num_threads
         o.riccati_legs = self._legs() if self.linear_solver_choice == LQ_SOLVER_PARALLEL else 1
+        o.refine_appended_knot = int(self.refine_appended_knot)
         return o
 
     def _legs(self):

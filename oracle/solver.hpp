@@ -104,17 +104,7 @@ struct Gains {
 // parameter at the cut between its children: x_mid = Zx x_in + Zt theta_out + zc, theta_mid = D x_mid + Lm_right theta_out + p_right
 struct TreeNode { int lo = 0, hi = 0, left = -1, right = -1; std::vector<double> P, p, Lm, Sg, sg, Zx, Zt, zc, D; };
 
-// Experimental globalisation knobs of the round-4 robustness study (environment variables, read once; all off = the documented algorithm):
-//   MPC_X_REJECT=1  a linesearch without an Armijo candidate takes NO step (the iterate stays) instead of the smallest candidate
-//   MPC_X_REJECT=2  ... and raises a Levenberg-Marquardt weight on diag(Hh) tenfold (kept across runs), divided by 3 after every accepted step
-struct XKnobs {
-  int reject = 0;
-  XKnobs() { if (const char* e = std::getenv("MPC_X_REJECT")) reject = std::atoi(e); }
-};
-inline const XKnobs& xknobs() { static XKnobs k; return k; }
-
 struct Instance {
-  double xreg = 0.0;  // experimental Levenberg-Marquardt weight (MPC_X_REJECT=2)
   std::vector<double> x0;
   std::vector<std::vector<double>> xs, us, vs, lams, vs_e, lams_e;
   std::vector<std::vector<double>> dxs, dus, dvs, dlams;
@@ -360,7 +350,6 @@ struct Solver {
         for (int j = 0; j < np; ++j) ghM[a * np + j] += ab * wM[i * np + j];
       }
     for (int a = 0; a < nz; ++a) for (int b = a + 1; b < nz; ++b) Hh[b * nz + a] = Hh[a * nz + b] - kn.H[a * nz + b] + kn.H[b * nz + a];
-    if (in.xreg > 0.0) for (int a = 0; a < nz; ++a) Hh[a * nz + a] += in.xreg;
     ORC_PROF(3);
     // 4. stage KKT  [[R, D^T],[D, -mu I]] [U; V] = -[[S^T r],[C d]]
     std::vector<double> Lr(m * m), Ct(c * nz, 0.0), dt_(c, 0.0);
@@ -989,15 +978,6 @@ struct Solver {
       if (phi <= phi0 + opt.ls_armijo_c1 * alpha * dphi0) break;
       if (step + 1 >= opt.ls_max_steps || 0.5 * alpha < opt.ls_alpha_min) break;
       alpha *= 0.5;
-    }
-    if (xknobs().reject) {
-      const bool ok = phi <= phi0 + opt.ls_armijo_c1 * alpha * dphi0;
-      if (!ok) {  // no acceptable candidate: the iterate stays
-        if (xknobs().reject >= 2) in.xreg = std::min(1e6, std::max(1e-6, in.xreg * 10.0));
-        in.stats.alpha = 0.0; in.stats.ls_steps = step; in.stats.num_iters += 1;
-        return 0;
-      }
-      if (xknobs().reject >= 2) { in.xreg /= 3.0; if (in.xreg < 1e-8) in.xreg = 0.0; }
     }
     in.xs.swap(in.txs); in.us.swap(in.tus); in.vs.swap(in.tvs); in.lams.swap(in.tlams);
     in.stats.alpha = alpha; in.stats.ls_steps = step; in.stats.num_iters += 1;
