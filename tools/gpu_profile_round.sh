@@ -3,7 +3,7 @@
 # separate PMC passes (no trace domains together with --pmc).  Outputs under gpurun_out/$1/; a step that fails stops the
 # script BEFORE anything is copied over the committed profiles/ files.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
