@@ -335,7 +335,11 @@ class SolverProxDDP:
         # The MPC loops pass the previous solution shifted by one knot, after one replaceStageCircular (fulldynamic_talos.py:532-540).
         # The device still holds that solution: it shifts it itself (nothing to upload) and, on multibody problems, reuses the
         # evaluation its last accepted full step left behind (tick reuse: bit-identical to evaluating afresh, include/mpc_abi.h).
+        # (knot 0: the solver overwrites xs[0] with x0_init when force_initial_condition is set — the only mode setup accepts — so the
+        # caller's xs[0] matters only without it; prev holds PRIVATE copies: in-place edits of results.xs / results.us by the caller
+        # are seen as what they are, a warm start that is no longer the pure shift)
         shifted = (prev is not None and cycles == 1 and self.max_iters <= 4 and d.batch == 1
+                   and (self.force_initial_condition or np.array_equal(xs[0], prev["xs"][0][1]))
                    and np.array_equal(xs[1:-1], prev["xs"][0][2:]) and np.array_equal(xs[-1], prev["xs"][0][-1])
                    and np.array_equal(us[:-1], prev["us"][0][1:]) and np.array_equal(us[-1], prev["us"][0][-1]))
         if shifted:
@@ -366,4 +370,4 @@ class SolverProxDDP:
         r.num_iters, r.conv, r.al_iter = s.num_iters, bool(s.converged), s.al_iters
         r.traj_cost, r.merit_value, r.prim_infeas, r.dual_infeas = s.traj_cost, s.merit, s.prim_infeas, s.dual_infeas
         self._last_stats = stats
-        self._last_results = out
+        self._last_results = {"xs": out["xs"].copy(), "us": out["us"].copy()}  # private: results.xs / results.us are the caller's to edit

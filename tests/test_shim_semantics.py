@@ -114,6 +114,35 @@ def test_cycling_and_results_surface(oracle_lib):
     assert tau.shape == (fp.nu,)
 
 
+def test_edited_warm_start_is_not_taken_for_the_shift(oracle_lib):
+    """The MPC loops hand back results.xs / results.us shifted by one knot (fulldynamic_talos.py:532-540): the mirror then lets the device shift
+    its own copy.  A warm start EDITED IN PLACE through the handed-out arrays is no longer that shift and must reach the solver."""
+    def loop(edit):
+        fp = FullDynamicsProblem(horizon=4)
+        prob = fp.build()
+        solver = fp.make_solver(_native_library=oracle_lib)
+        solver.max_iters = 1
+        solver.setup(prob)
+        xs, us = fp.initial_guess()
+        solver.run(prob, xs, us)
+        r = solver.results
+        xs = r.xs.tolist() + [r.xs[-1]]
+        us = r.us.tolist() + [r.us[-1]]
+        xs, us = xs[1:], us[1:]
+        if edit:
+            us[1][:] += 0.5  # in place: the array IS the one results.us handed out
+        prob.replaceStageCircular(fp.create_stage([True, True], *[p.copy() for p in fp.robot.foot_placements]))
+        solver.workspace.cycleAppend(None)
+        prob.x0_init = xs[0]
+        solver.setup(prob)
+        solver.run(prob, xs, us)
+        return np.array(solver.results.us), np.array(us)
+
+    plain, _ = loop(False)
+    edited, start = loop(True)
+    assert not np.allclose(edited, plain, rtol=1e-9, atol=1e-9)  # the edit was not silently ignored
+
+
 def test_unsupported_configuration_fails_loudly(oracle_lib):
     fp = FullDynamicsProblem(horizon=2)
     prob = fp.build()
