@@ -146,4 +146,4 @@ DEV void state_integrate(int space, int nx, int n, const double* x, const double
 // x / d for 0 <= x < 2^32 / d, d >= 2, with mg = magic_div(d) = ceil(2^32 / d) computed on the host: one v_mul_hi_u32 instead of the
 // ~30 instructions of a 32-bit division by a run-time divisor (the LDS fills of the leg kernels divide an index per element)
 DEV int qdiv(int x, unsigned mg) { return (int)__umulhi((unsigned)x, mg); }
-static inline unsigned magic_div(int d) { return (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); }
+static inline constexpr unsigned magic_div(int d) { return (unsigned)((0x100000000ull + (unsigned long long)d - 1) / (unsigned long long)d); }

@@ -106,6 +106,7 @@ struct mpc_solver {
   hipEvent_t stage_ev[STAGE_RING] = {};
   int stage_next = 0;
   RicLds ric{};
+  int ric_fixed = 0;  // 1: the fixed-dimension instantiation of the sweep for (n, m) = (76, 32) applies (riccati_mfma.h)
   ClLds cl{};
   bool use_mfma_riccati = false;
   // parallel-in-time legs (legs.h)
@@ -332,6 +333,12 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
                s->lc.total_bytes <= 160 * 1024 && s->lx.total_bytes <= 160 * 1024 && !getenv("MPC_HIP_NO_LEGS");
   if (s->legs_ok) {
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+    // fixed-dimension instantiations (riccati_mfma.h): the complete Talos model of the full-dynamics OCP
+    s->ric_fixed = 0;
+    if (L.n == 76 && L.m == 32 && L.nz == 108 && ric_same_layout(s->ric, ric_fixed_layout(76, 32, true)) && !getenv("MPC_HIP_GENERIC_DIMS")) {
+      s->ric_fixed = 1;
+      HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+    }
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
@@ -595,6 +602,7 @@ static void launch_pass(mpc_solver* s) {
       // parallel-in-time: workgroup (instance, leg), the last leg first
       if (s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>), dim3(L.B * J), dim3(RIC_SMALL_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
+      else if (s->ric_fixed == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 32>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
       else if (s->ric.sq) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true, true>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, false, true>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
     }

@@ -40,7 +40,15 @@
 // nv, ks, Ke of the structured products, derived inside the phase that uses them (as scalars living across the whole knot loop they
 // push the SGPR spills past what the spill VGPRs hold, and every reload of those drains the loads in flight)
 #define RIC_SQ_DIMS() int n_l_ = n; asm volatile("" : "+s"(n_l_)); const int nv = SQ ? (n_l_ >> 1) : 0, ks = SQ ? (nv & ~3) : 0, Ke = SQ ? ((n_l_ + 3) & ~3) - ks : np; (void)nv; (void)ks; (void)Ke
-#define RIC_PROF(slot) do { RIC_LAUNDER(); if (tid == 0 && a.prof && leg == 0) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
+#ifndef RIC_PROF_TID
+#define RIC_PROF_TID 0  // the thread whose clock is read (developer builds: 64 = wavefront 1, ...)
+#endif
+#ifdef RIC_SUBPROF  // developer build (tools/phase_timers.py, PHASE_SUB=1): the long phases in pieces
+#define RIC_SUB(slot) RIC_PROF(slot)
+#else
+#define RIC_SUB(slot) do { } while (0)
+#endif
+#define RIC_PROF(slot) do { RIC_LAUNDER(); if (tid == RIC_PROF_TID && a.prof && leg == 0) { const long long t1_ = clock64(); a.prof[(size_t)b * 64 + (slot)] += (double)(t1_ - t0_); t0_ = t1_; } } while (0)
 
 struct RicLds {
   int np, mp, nzp, ldl, ldr, nb, nbm, lw, nwb, gfull, st_lds, ovl, sq, nv;  // padded dims, leading dims of L / Lr, block counts, W leading dim / col blocks
@@ -51,8 +59,8 @@ struct RicLds {
   int K2;  // legs: W2 (mp x (mp+1)) | VX2 (16 x (mp+1)) of the [I; 0] solve — inside the PT region when it fits (dead during step 6)
 };
 
-static inline RicLds make_ric_lds(int n, int m, int c, int gfull = 1, int st_lds = 1) {
-  RicLds s;
+static inline constexpr RicLds make_ric_lds(int n, int m, int c, int gfull = 1, int st_lds = 1) {
+  RicLds s{};
   s.st_lds = st_lds;  // 0: Sh^T (mp x np) lives in the L2-resident per-instance scratch instead of LDS (large m)
   s.gfull = gfull;  // 1: G = Pt [A B] kept whole (x part over PT, u part in GP) — needs np x mp doubles for GP instead of np x 16 ;
                     // 2: whole G with its u part in the L2-resident scratch (large m: only the few Ruu tiles read it back)
@@ -140,8 +148,28 @@ DEV double wave_sum_r(double v) { return wave_sum(v); }  // DPP reduction of sol
 // leg other than the last starts from a ZERO value function at its end (its end co-state is a parameter handled by
 // k_leg_condense / k_leg_consensus) and additionally leaves, per knot, the (u,u) and (nu,u) blocks of the inverse stage KKT
 // matrix (Mu, Znu: the solve with the right-hand side [I; 0] rides along in otherwise idle wavefronts).
-template <int RT, int NPMAX, bool SQ = false, bool LEGS = false>
-__global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
+// FN, FM > 0: the state / control dimensions of the problem as compile-time constants (n = FN, m <= FM; layout ric_fixed_layout): every
+// stride, tile count and LDS offset folds into the instructions — the generic kernel spends about half of its issue slots on index
+// arithmetic with run-time dimensions.  The host launches such an instantiation only when its handle's layout is that one (ric_same_layout).
+static inline constexpr RicLds ric_fixed_layout(int n, int m, bool sq) {
+  RicLds s = make_ric_lds(n, m, 0, 1, 1);
+  if (sq) { s.sq = 1; s.nv = n / 2; }
+  return s;
+}
+static inline bool ric_same_layout(const RicLds& x, const RicLds& y) {  // everything but the parts that depend on the number of constraint rows
+  return x.np == y.np && x.mp == y.mp && x.nzp == y.nzp && x.ldl == y.ldl && x.ldr == y.ldr && x.lw == y.lw && x.gfull == y.gfull && x.st_lds == y.st_lds &&
+         x.ovl == y.ovl && x.sq == y.sq && x.nv == y.nv && x.PT == y.PT && x.R1 == y.R1 && x.LP == y.LP && x.LI == y.LI && x.AB == y.AB && x.GP == y.GP &&
+         x.vec == y.vec && x.Lr == y.Lr && x.LIr == y.LIr && x.W == y.W && x.ST == y.ST && x.CT == y.CT && x.VX == y.VX && x.Y == y.Y && x.SC == y.SC &&
+         x.LIs == y.LIs && x.K2 == y.K2;
+}
+template <int RT, int NPMAX, bool SQ = false, bool LEGS = false, int FN = 0, int FM = 0>
+__global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
+  constexpr bool FX = FN > 0;
+  constexpr RicLds SC_ = FX ? ric_fixed_layout(FN, FM, SQ) : RicLds{};
+  // S: the layout — the compile-time one for a fixed-dimension instantiation, with the two members that depend on the row count from the argument
+  RicLds S_ = Srt;
+  if constexpr (FX) { S_ = SC_; S_.iwork = Srt.iwork; S_.total_bytes = Srt.total_bytes; }
+  const RicLds& S = S_;
   constexpr int NWV = RT / 64, NBMAX = NPMAX / 16, NZTMAX = NPMAX > 16 ? 8 : 2;
   constexpr int PT_ROWS = (NPMAX + NWV - 1) / NWV;                                // rows of Pt per wavefront
   constexpr int AB_ROWS = SQ ? (NPMAX / 2 + NWV - 1) / NWV : PT_ROWS;             // register prefetch capacity: rows of [A B] per wavefront (SQ: v rows only)
@@ -151,14 +179,14 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
   constexpr bool CT_PREFETCH = NPMAX <= 80;  // the largest instantiation has no registers to spare for it
   constexpr int CT_ROWS = 16 / NWV, Y_ELEMS = (NPMAX > 16 ? 48 : 16) * 16 / RT + ((NPMAX > 16 ? 48 : 16) * 16 % RT ? 1 : 0);  // per-thread shares of CT (16 rows) and Y (mp x 16)  // lower-triangle tiles of the u rows of Hh a wavefront can keep in registers
   const Layout& L = a.L;
-  const int nthr = blockDim.x, nw = nthr >> 6;
+  constexpr int nthr = RT, nw = RT / 64;  // (the launch uses RT threads)
   // legs: the last leg (the only one with the terminal node, never shorter than the others) is dispatched first
   const int b = LEGS ? (int)(blockIdx.x % L.B) : (int)blockIdx.x, leg = LEGS ? a.nlegs - 1 - (int)(blockIdx.x / L.B) : 0;
   const bool par = LEGS && leg + 1 < a.nlegs;  // parametric leg: zero value function at its end
   int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // re-derived at every phase boundary (RIC_LAUNDER)
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
-  const int n = L.n, nz = L.nz, N = L.N, nr = n + 1;
+  const int n = FX ? FN : L.n, nz = FX ? FN + FM : L.nz, N = L.N, nr = n + 1;
   const int k_top = par ? leg_start(a, leg + 1) - 1 : N - 1, k_bot = LEGS ? leg_start(a, leg) : 0;
   const int np = S.np, ldp = S.np + 1, mp = S.mp, nzp = S.nzp, ldl = S.ldl, ldr = S.ldr, nb = S.nb, nbm = S.nbm, nzt = nzp / 16, lw = S.lw, nwb = S.nwb;
   const double mu = st.mu, mud = mu * a.opt.dyn_al_scale;
@@ -250,6 +278,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     if (tid < n) ft[tid] = pre_f + mud * pre_le;
     if (tid < nz) gpre[tid] = pre_g;
     __syncthreads();
+    RIC_SUB(23);
     {
       int off = 0;
       for (int q = 0; q < wv; ++q) off += iflag[2 + q];
@@ -319,40 +348,13 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     // only: K = nv instead of n in both products of step 5 (ks .. ks + Ke: the v rows, aligned down to the MFMA depth of 4)
     constexpr bool sq = SQ;  // every stage knot of a whole-body problem has dynamics rows (valid flag d12l[73] = 1)
     RIC_PROF(1);
-    // ---- 2. ||Ph||_F ; vv = Ph ft + ph ----
-    {  // one pass over the rows of Ph for both (its padding rows and columns are zero)
-      double ss = 0;
-      for (int i = wv; i < n; i += nw) {
-        double s = 0;
-        for (int j = lane; j < n; j += 64) { const double pv = PT[i * ldp + j]; ss += pv * pv; s += pv * ft[j]; }
-        s = wave_sum_r(s);
-        if (lane == 0) vv[i] = s + ph[i];
-      }
-      ss = wave_sum_r(ss);
-      if (lane == 0) wred[wv] = ss;
-    }
-    __syncthreads();
+    // ---- 2. mx = ft - mu_d ph (the vector of the forward sweep's record): w of step 3c is Pt mx + ph.  [With M = (I + mu_d Ph)^-1,
+    // Pt = M Ph:  w = vv - mu_d Pt vv = M vv  for  vv = Ph ft + ph,  and  M ph = ph - mu_d Pt ph.]  ||Ph||_F^2, which decides the length of
+    // the series, is the trace of its first product Ph Ph (step 3a): no pass over Ph here ----
+    if (tid < np) vv[tid] = (tid < n) ? ft[tid] - mud * ph[tid] : 0.0;
     RIC_PROF(2);
-    // Pt = (I + X)^-1 Ph with X = mu_d Ph, ||X||_2 <= rho = mu_d ||Ph||_F.  mu_d = dyn_al_scale * mu is tiny, so the
-    // Neumann series Ph (I - X + X^2 - ...) reaches double precision after a few terms (remainder <= rho^(nser+1)):
-    // nser in-place Horner steps T <- Ph - mu_d T Ph on the matrix cores replace the n x n factorisation and the
-    // two triangular solves.  Larger rho falls back to the Cholesky path.
-    int nser = 0;
-    {
-      double fro = 0;
-      for (int q = 0; q < nw; ++q) fro += wred[q];
-      const double rho = mud * sqrt(fro);
-      double rem = rho;
-      while (rem > RIC_SERIES_TOL && nser < RIC_MAX_SERIES) { rem *= rho; ++nser; }
-      if (rem > RIC_SERIES_TOL) nser = -1;
-      if (tid == 0 && a.prof) {
-        double* pr = a.prof + (size_t)b * 64;
-        pr[20] = fmax(pr[20], rho); pr[21] += (nser >= 0) ? nser : 0; pr[22] += (nser < 0) ? 1.0 : 0.0;
-      }
-    }
     // [A B] of this knot: issue the HBM loads here (the series below hides their latency), park them in
     // registers, drop them into LDS in step 4
-    RIC_PROF(17);
     double abr[AB_ROWS][2];
     {
       // column of [A B] behind padded column zp (x columns 0..n-1, u columns np..np+m-1), clamped to a valid one so
@@ -376,7 +378,8 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     RIC_PROF(18);
     if (k > k_bot) prefetch_small(k - 1);  // consumed at the top of the next iteration
     RIC_PROF(13);
-    if (nser >= 0 && nser <= 7) {
+    int nser = 0;
+    {
       // ---- 3a. series sum_{i <= nser} (-X)^i Ph, X = mu_d Ph, as a product of factors instead of nser Horner steps:
       //   nser <= 1:  Pt = Ph - mu_d Q,  Q = Ph^2                                  1 product
       //   nser <= 3:  T = Ph - mu_d Q ;  Pt = T + mu_d^2 T Q                       2 products  (I - X)(I + X^2)
@@ -417,16 +420,44 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
           }
         }
       };
-      if (nser >= 1) {
-        products(PT, PT);  // Q = Ph Ph
-        RIC_PROF(14);
-        __syncthreads();   // PT is overwritten below: every wavefront must be done reading it
-        RIC_PROF(15);
+      products(PT, PT);  // Q = Ph Ph
+      {  // ||Ph||_F^2 = trace(Q) (Ph symmetric; its padding is zero): the diagonal elements of the diagonal tiles
+        double tr = 0.0;
+#pragma unroll
+        for (int sidx = 0; sidx < RIC_SERIES_TILES; ++sidx)
+          if (wv + sidx * nw < ntile && tri[sidx] == tcj[sidx]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tr += ((lane >> 4) + 4 * q == (lane & 15)) ? res[sidx][q] : 0.0;
+          }
+        tr = wave_sum_r(tr);
+        if (lane == 0) wred[wv] = tr;
+      }
+      RIC_PROF(14);
+      __syncthreads();   // PT is overwritten below: every wavefront must be done reading it
+      RIC_PROF(15);
+      // Pt = (I + X)^-1 Ph with X = mu_d Ph, ||X||_2 <= rho = mu_d ||Ph||_F.  mu_d = dyn_al_scale * mu is tiny, so the
+      // Neumann series Ph (I - X + X^2 - ...) reaches double precision after a few terms (remainder <= rho^(nser+1)):
+      // products on the matrix cores replace the n x n factorisation and the two triangular solves.  Larger rho falls back
+      // to Horner steps (nser > 7) or to the Cholesky path (nser < 0); PT is still Ph at this point.
+      {
+        double fro = 0;
+        for (int q = 0; q < nw; ++q) fro += wred[q];
+        const double rho = mud * sqrt(fmax(fro, 0.0));
+        double rem = rho;
+        while (rem > RIC_SERIES_TOL && nser < RIC_MAX_SERIES) { rem *= rho; ++nser; }
+        if (rem > RIC_SERIES_TOL) nser = -1;
+        if (tid == RIC_PROF_TID && a.prof && leg == 0) {
+          double* pr = a.prof + (size_t)b * 64;
+          pr[20] = fmax(pr[20], rho); pr[21] += (nser >= 0) ? nser : 0; pr[22] += (nser < 0) ? 1.0 : 0.0;
+        }
+      }
+      RIC_PROF(17);
+      if (nser >= 1 && nser <= 7) {
         update(true, -mud, nser >= 2);   // PT <- Ph - mu_d Q ; LP <- Q
         __syncthreads();
         RIC_PROF(16);
       }
-      if (nser >= 2) {
+      if (nser >= 2 && nser <= 7) {
         products(PT, LP);  // T Q
         RIC_PROF(14);
         __syncthreads();
@@ -435,7 +466,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         __syncthreads();
         RIC_PROF(16);
       }
-      if (nser >= 4) {
+      if (nser >= 4 && nser <= 7) {
         products(LP, LP);  // Q^2
         RIC_PROF(14);
         __syncthreads();
@@ -452,7 +483,8 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         RIC_PROF(16);
       }
       RIC_PROF(3);
-    } else if (nser >= 0) {
+    }
+    if (nser > 7) {
       // ---- 3a'. longer series: Horner steps T <- Ph - mu_d T Ph on the lower block triangle;
       // products first, barrier, then the in-place update of PT
       const int ntile = nb * (nb + 1) / 2;
@@ -490,7 +522,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         RIC_PROF(16);
       }
       RIC_PROF(3);
-    } else {
+    } else if (nser < 0) {
       // ---- 3b. LP <- I + mud Ph = L L^T ; PT <- (L L^T)^-1 PT ----
       for (int i = wv; i < np; i += nw)
         for (int j = lane; j < np; j += 64) LP[i * ldl + j] = mud * PT[i * ldp + j] + (i == j ? 1.0 : 0.0);
@@ -502,7 +534,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       __syncthreads();
     }
     RIC_PROF(5);
-    // w = vv - mud Pt vv, store Pt / yv for the forward sweep (Pt is symmetric up to rounding).  The wavefront that owns
+    // w = Pt mx + ph (step 2; vv holds mx), store Pt for the forward sweep (Pt is symmetric up to rounding).  The wavefront that owns
     // row i of Pt also holds row i of [A B] in registers: its share of gh = grad + [A B]^T w accumulates on the fly.
     double gp0 = 0.0, gp1 = 0.0;
 #pragma unroll
@@ -512,12 +544,13 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         double s = 0;
         for (int j = lane; j < n; j += 64) { const double pv = PT[i * ldp + j]; s += pv * vv[j]; g[L.oMx + i * n + j] = pv; }
         s = wave_sum_r(s);
-        const double wi = vv[i] - mud * s;
+        const double wi = ph[i] + s;
         if (lane == 0) w[i] = wi;
         if constexpr (!SQ) { gp0 += abr[q][0] * wi; gp1 += abr[q][1] * wi; }
       }
     }
-    for (int i = tid; i < n; i += nthr) g[L.omx + i] = ft[i] - mud * ph[i];
+    for (int i = tid; i < n; i += nthr) g[L.omx + i] = vv[i];
+    RIC_SUB(24);
     if (sq) {
       // v rows of PT, each by the wavefront that has just stored it (the q rows stay as they are): row nv + jq <- row jq of
       // Pe^T = Dd^T Pt[q rows] + Pt[v rows], then its v columns <- (. Dd + .) so that the v rows of the product of step 5 are
@@ -623,7 +656,8 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         for (int q = 0; q < 4; ++q) {
           const int rp = zi * 16 + (lane >> 4) + 4 * q;
           const int zr = (rp < n) ? rp : ((rp >= np && rp - np < m) ? n + rp - np : -1);
-          h[q] = (zr >= 0 && zc >= 0) ? kn[L.oH + zr * nz + zc] : 0.0;
+          // clamped address, mask by multiplication: a select makes the load itself conditional (a branch and a wait per element)
+          h[q] = kn[L.oH + (zr >= 0 ? zr : 0) * nz + (zc >= 0 ? zc : 0)] * ((zr >= 0 && zc >= 0) ? 1.0 : 0.0);
         }
       };
       if (ovl) {
@@ -641,6 +675,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         gres[sidx] = d4_t{0, 0, 0, 0};
         if (t < ngt) mma_tile<false>(gres[sidx], PT + ks * ldp + (t / nzt) * 16, 1, ldp, AB + ks * nzp + (t % nzt) * 16, nzp, 1, Ke, lane);  // Pt symmetric
       }
+      RIC_SUB(26);
       __syncthreads();
 #pragma unroll
       for (int sidx = 0; sidx < RIC_G_TILES; ++sidx) {
@@ -663,6 +698,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         }
       }
       __syncthreads();
+      RIC_SUB(27);
       const int nht = nzt * (nzt + 1) / 2, nxt = nb * (nb + 1) / 2;
       // one lower-triangle tile (zi, cj) of Hh = H + [A B]^T G
       auto hh_tile_at = [&](int zi, int cj, d4_t& out, int (&zr)[4], int& zc, const double* hp) {  // hp: the tile's H values, requested earlier (or null)
@@ -673,7 +709,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         for (int q = 0; q < 4; ++q) {  // H loads are in flight while the matrix cores work
           const int rp = zi * 16 + (lane >> 4) + 4 * q;
           zr[q] = (rp < n) ? rp : ((rp >= np && rp - np < m) ? n + rp - np : -1);
-          h[q] = hp ? hp[q] : ((zr[q] >= 0 && zc >= 0) ? kn[L.oH + zr[q] * nz + zc] : 0.0);
+          h[q] = hp ? hp[q] : kn[L.oH + (zr[q] >= 0 ? zr[q] : 0) * nz + (zc >= 0 ? zc : 0)] * ((zr[q] >= 0 && zc >= 0) ? 1.0 : 0.0);  // (see h_request)
         }
         d4_t acc = d4_t{0, 0, 0, 0};
         if (cj < nb) mma_tile<false>(acc, AB + ks * nzp + zi * 16, 1, nzp, PT + ks * ldp + cj * 16, ldp, 1, Ke, lane);
@@ -737,6 +773,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
           }
         }
         __syncthreads();
+        RIC_SUB(28);
         if (wv == 0) { const bool ok = chol_blocked_wave(Lr, ldr, nbm, LIr, lane); if (lane == 0) iflag[0] = ok ? 1 : 0; }
         else {
 #pragma unroll
@@ -753,6 +790,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
           }
           for (int t = xt0; t < nxt; t += nwx) x_tile(t);
         }
+        RIC_SUB(29);
         __syncthreads();  // [A B] is dead from here on: W = -[Sh^T | rh], ST = Sh^T lie over it
         if (wv > 0) {
 #pragma unroll
@@ -931,6 +969,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
     trsm_fwd_blocked(Lr, ldr, LIr, nbm, W, lw, nwb, wv, nw, lane);  // W = L^-1 T
     if (ca > 0 && small_ca && wv == nw - 1) trsm_fwd_blocked(Lr, ldr, LIr, nbm, Yl, 16, 1, 0, 1, lane);  // Y = L^-1 Da^T
     __syncthreads();
+    RIC_SUB(30);
     if (ca > 0) {
       if (small_ca) {
         // Sc = mu I + Y^T Y (pad identity) ; V = [Ca | dt] + Y^T W
@@ -1021,11 +1060,13 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         __syncthreads();
       }
     }
+    RIC_SUB(31);
     trsm_bwd_blocked(Lr, ldr, LIr, nbm, W, lw, nwb, wv, nw, lane);  // U = L^-T (W - Y V)
     if (LEGS && kkt2)
       for (int j2 = 0; j2 < nbm; ++j2)
         if (wv == (nwb + j2) % nw) trsm_bwd_blocked(Lr, ldr, LIr, nbm, W2 + j2 * 16, ldw2, 1, 0, 1, lane);
     __syncthreads();
+    RIC_SUB(4);
     if (LEGS && par) {
       const int mpd = L.mpad;  // == mp
       if (small_ca) {
@@ -1094,6 +1135,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       g[L.op + r] = t;
       pvec[r] = t;
     }
+    RIC_SUB(19);
     // ---- 7. P = Qh + Sh K + Ca^T Kv  ->  PT (next knot's P'): lower block triangle on the MFMA, mirrored into the upper
     // one (P is symmetric); diagonal tiles are symmetrised in place by the wavefront that produced them ----
     if (small_ca) {
@@ -1104,7 +1146,10 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
         const int col = cj * 16 + (lane & 15);
         double qh[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; qh[q] = (row < n && col < n) ? Hh[row * nz + col] : 0.0; }  // Hh: lower block triangle
+        for (int q = 0; q < 4; ++q) {  // Hh: lower block triangle (clamped address, mask by multiplication: unconditional loads, all in flight together)
+          const int row = ri * 16 + (lane >> 4) + 4 * q;
+          qh[q] = Hh[(row < n ? row : 0) * nz + (col < n ? col : 0)] * ((row < n && col < n) ? 1.0 : 0.0);
+        }
         d4_t acc = d4_t{0, 0, 0, 0};
         mma_tile<false>(acc, ST + ri * 16, 1, np, W + cj * 16, lw, 1, mp, lane);
         if (kc > 0) mma_tile<false>(acc, CTl + ri * 16, 1, lw, VXl + cj * 16, lw, 1, kc, lane);
@@ -1158,6 +1203,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds S) {
       }
       __syncthreads();
     }
+    RIC_SUB(25);
     // gain record: P of this knot, row by row (coalesced)
     for (int i = wv; i < n; i += nw)
       for (int j = lane; j < n; j += 64) g[L.oP + i * n + j] = PT[i * ldp + j];

@@ -33,6 +33,10 @@ ric = {0: 'T6 inverse, active-row scan', 1: 'T6 similarity transform of P', 2: '
        14: 'series: tile products', 15: 'series: barrier wait', 16: 'series: in-place update', 3: 'chol n (fallback only)',
        5: 'triangular solves (fallback only)', 6: 'AB prefetch issue, w, store Pt', 7: 'AB to LDS, gh', 8: 'G = Pt [A B], Hh = H + [A B]^T G',
        9: 'KKT operands', 10: 'chol m', 11: 'KKT solve (active rows), gains', 12: 'value function, store gain record'}
+if os.environ.get("PHASE_SUB"):  # a build with -DRIC_SUBPROF (and -DRIC_PROF_TID=64 for the view of wavefront 1): the time up to each mark comes off the phase that contains it
+    ric.update({23: '  0a: prefetched values to LDS, barrier', 24: '  6a: w rows, Pt record', 26: '  8a: G tiles (MFMA)', 27: '  8b: barrier, G to LDS, barrier',
+                28: '  8c: Ruu tiles, two barriers', 29: '  8d: chol Ruu (wave 0) | Sh^T and x tiles of Hh', 30: '  11a: forward solves', 31: '  11b: active rows (Schur complement)',
+                4: '  11c: backward solves', 19: '  12a: gains out, p', 25: '  12b: P tiles'})
 knots = (100 // LEGS) * TICKS
 tot = sum(p[i] for i in ric)
 for i, name in ric.items():
