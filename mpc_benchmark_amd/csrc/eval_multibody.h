@@ -130,17 +130,27 @@ DEV void implicit_diff_block(d4_t (&w)[4], d4_t& t, const double* Mt, const doub
 }
 
 // ============================================================================================================
-template <int TRIAL>
+// FJ, FV, FU > 0: the model's body / velocity / control counts as compile-time constants (a free-flyer model: nq = nv + 1, n = 2 nv; stages
+// with contact-constrained dynamics) — the loop bounds, strides and LDS offsets of the carve-out fold into the instructions, as in the
+// fixed-dimension instantiations of the Riccati sweep (riccati_mfma.h).  The launcher picks such an instantiation only for that model.
+template <int TRIAL, int FJ = 0, int FV = 0, int FU = 0>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_MIN_WAVES) k_eval_multibody(SolverArgs a, Layout KL, double* records, MbArgs mb, int cand0) {
-  const Layout& L = a.L;
-  const MbLds& S = mb.lds;
+  constexpr bool FX = FJ > 0;
+  constexpr MbLds SC_ = FX ? make_mb_lds(FJ, FV, FV + 1, FU, 2 * FV + FU, true) : MbLds{};
+  MbLds S_ = mb.lds;
+  if constexpr (FX) S_ = SC_;
+  const MbLds& S = S_;
+  Layout L_ = a.L;  // (a local copy whose dimension members are the constants: every use of L.n, L.nz, ... below folds)
+  if constexpr (FX) { L_.n = 2 * FV; L_.nx = 2 * FV + 1; L_.m = FU; L_.nz = 2 * FV + FU; L_.nj = FJ; }
+  const Layout& L = L_;
   // TRIAL == 3 with one workgroup more per instance (blockIdx.x == N + 1): the SPECULATIVE evaluation of the knot the next tick appends —
   // the accepted terminal state as a running stage with the table of the current last stage and the last control (what the warm-start
   // shift makes of it).  Its record goes to a spare slot (a.spec_knot) ; if the table of the appended stage turns out to be that one
   // (mpc_cycle compares), the next tick takes it as knot N - 1 instead of evaluating it (k_reproject, knot_reused).
   const bool specw = TRIAL == 3 && (int)blockIdx.x == a.L.N + 1;
   const int k = specw ? a.L.N - 1 : (int)blockIdx.x;  // stage table, control, multipliers
-  const int b = blockIdx.y, nthr = blockDim.x;
+  const int b = blockIdx.y;
+  constexpr int nthr = EVAL_THREADS;  // (the launcher uses EVAL_THREADS threads)
   int cand = blockIdx.z + cand0;
   int tid = threadIdx.x;
   const InstState& st = a.inst[b];

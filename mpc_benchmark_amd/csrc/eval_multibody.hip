@@ -1,6 +1,7 @@
 // eval_multibody.hip — translation unit of the whole-body stage kernel (K1-K5, K7 of SURVEY.md §8a-2) and its launcher.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #define CHOL16_RIGHT_LOOKING  // (mfma_blocks.h: the 16 x 16 inverse with independent updates — pays in this kernel's one-wavefront chain only)
@@ -31,6 +32,22 @@ void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout
     if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)k_eval_multibody<3>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
     if (e1 != hipSuccess || e2 != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(LDS) failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     attr_bytes.store(mb.lds.total_bytes + 1);  // + 1: the zero-initialised slots mean "not set"
+  }
+  // fixed-dimension instantiations (eval_multibody.h): the complete Talos model of the scripts (33 bodies, 38 velocity dofs, 32 actuated joints)
+  const bool talos = L.nj == 33 && L.n == 76 && L.nx == 77 && L.m == 32 && L.nz == 108 && contact_dyn && !getenv("MPC_HIP_GENERIC_DIMS");
+  if (talos && sim_substeps <= 0) {
+    static std::atomic<int> attr_fixed_dev[64];
+    if (attr_fixed_dev[dev & 63].load() < mb.lds.total_bytes + 1) {
+      hipError_t e1 = hipFuncSetAttribute((const void*)k_eval_multibody<0, 33, 38, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
+      if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void*)k_eval_multibody<1, 33, 38, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
+      if (e1 == hipSuccess) e1 = hipFuncSetAttribute((const void*)k_eval_multibody<3, 33, 38, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
+      if (e1 != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(LDS) failed: ") + hipGetErrorString(e1));
+      attr_fixed_dev[dev & 63].store(mb.lds.total_bytes + 1);
+    }
+    if (trial && with_derivs) hipLaunchKernelGGL((k_eval_multibody<3, 33, 38, 32>), dim3(L.N + 1 + (a.spec_knot ? 1 : 0), L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
+    else if (!trial) hipLaunchKernelGGL((k_eval_multibody<0, 33, 38, 32>), dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
+    else hipLaunchKernelGGL((k_eval_multibody<1, 33, 38, 32>), dim3(L.N + 1, L.B, mb.ncand_loop > 0 ? 1 : ncand), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
+    return;
   }
   if (sim_substeps > 0) hipLaunchKernelGGL(k_eval_multibody<2>, dim3(1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, 0);
   else if (trial && with_derivs) hipLaunchKernelGGL(k_eval_multibody<3>, dim3(L.N + 1 + (a.spec_knot ? 1 : 0), L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);  // records = the knot records (+ the speculative knot)

@@ -27,7 +27,7 @@
 //    factorisation, so the body-level 6 x 6 blocks are dead when M is built and the two share one region; the forces at the
 //    solution follow from Fc += Yc da + sum U_k acc_k - contact wrenches instead of a second pass over the body inertias.
 // leading dimension of the staged Jacobian rows (see eval_multibody.h, P13)
-static inline __host__ __device__ int mb_ldj(int nz) { return ((nz - 16 + 31) / 32) * 32 + 16; }
+static inline constexpr __host__ __device__ int mb_ldj(int nz) { return ((nz - 16 + 31) / 32) * 32 + 16; }
 
 struct MbLds {
   int nj, nv, nq, nl_max;
@@ -52,8 +52,8 @@ struct MbLds {
 
 // contact_dyn = false: no stage of the problem has contact-constrained dynamics (kinodynamic / kinematic problems) — the factor of M, the
 // right-hand-side blocks and the d lambda rows are never touched and get no LDS (BASELINE config 4: 88.8 -> 76.7 KB, two workgroups per CU)
-static inline MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz, bool contact_dyn = true) {
-  MbLds s;
+static inline constexpr MbLds make_mb_lds(int nj, int nv, int nq, int nu, int nz, bool contact_dyn = true) {
+  MbLds s{};
   s.nj = nj; s.nv = nv; s.nq = nq; s.nl_max = 12;
   s.nvp = (nv + 15) & ~15; s.nbm = s.nvp / 16;
   s.ncb = (nz + 15) / 16; s.ldl = 16 * s.ncb + 1;

@@ -44,8 +44,8 @@ struct LkLds {
 };
 // LDS plan (np = 80, mp = 48: 153 KB; mp = 32: 140 KB).  PR is one n x n region with three lives: K (stage 1), Pt (stages 2-3),
 // U1 = Mu Bc^T next to Mu (stages 4-5).  TM: rows 0..5 of [M | Bl] (6 x nzp) | columns 0..5 of Pt T^T (np x 6) | 6 x 6 corner of T Pt T^T.
-static inline LkLds make_lk_lds(int n, int m) {
-  LkLds s;
+static inline constexpr LkLds make_lk_lds(int n, int m) {
+  LkLds s{};
   s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.lda = s.nzp + 1; s.ldp = s.np + 1; s.ldm = s.mp + 1;
   s.nb = s.np / 16; s.nbm = s.mp / 16;
   s.mg_nzp = magic_div(s.nzp); s.mg_np = magic_div(s.np); s.mg_mp = magic_div(s.mp);
@@ -61,8 +61,14 @@ static inline LkLds make_lk_lds(int n, int m) {
 // [A B] (knot record); writes Phi, phi for every knot and Gamma, Ku, Knup for the knots of parametric legs.  Everything the NEXT knot of
 // the chunk needs is requested into registers while this one computes (a workgroup owns its CU: 140 - 153 KB of LDS), so only the first
 // knot of a chunk waits for HBM.  MP: padded control dimension (sizes the prefetch registers).
-template <int MP>
-__global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S, int chunk) {
+// FN, FM > 0: state / control dimensions as compile-time constants (see k_riccati_mfma)
+template <int MP, int FN = 0, int FM = 0>
+__global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds Srt, int chunk) {
+  constexpr bool FX = FN > 0;
+  constexpr LkLds SC_ = FX ? make_lk_lds(FN, FM) : LkLds{};
+  LkLds S_ = Srt;
+  if constexpr (FX) S_ = SC_;
+  const LkLds& S = S_;
   constexpr int NAB = (80 * (80 + MP) + LK_THREADS - 1) / LK_THREADS, NK = (MP * 80 + LK_THREADS - 1) / LK_THREADS;
   constexpr int NMU = (MP * MP + LK_THREADS - 1) / LK_THREADS, NZN = (16 * MP + LK_THREADS - 1) / LK_THREADS;
   const Layout& L = a.L;
@@ -72,7 +78,7 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds S, 
   int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
-  const int n = L.n, nz = L.nz, np = S.np, mp = S.mp, nzp = S.nzp, lda = S.lda, ldp = S.ldp, ldm = S.ldm, nb = S.nb, nbm = S.nbm;
+  const int n = FX ? FN : L.n, nz = FX ? FN + FM : L.nz, np = S.np, mp = S.mp, nzp = S.nzp, lda = S.lda, ldp = S.ldp, ldm = S.ldm, nb = S.nb, nbm = S.nbm;
   const int kbeg = blockIdx.x * chunk, kend = (kbeg + chunk < L.N) ? kbeg + chunk : L.N;
   const double mud = st.mu * a.opt.dyn_al_scale;
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -321,9 +327,9 @@ struct LcLds { int np, ldp, nb; int LM, BA, BB, vec, total_bytes; unsigned mg_np
 // doubles (np = 80 itself).  With np + 1 (round 3) row k + 1 began two banks after row k ended its wrap: a 2-way conflict on EVERY operand
 // read (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 30 %, profiles/r03_sq_counters.txt).  Gamma is read through its transpose for that
 // (it is symmetric: -Bc Mu Bc^T - mu_d T (I - mu_d Pt) T^T).
-static inline int lc_ld(int np) { int ld = np; while ((ld & 31) != 16) ++ld; return ld; }
-static inline LcLds make_lc_lds(int n) {
-  LcLds s;
+static inline constexpr int lc_ld(int np) { int ld = np; while ((ld & 31) != 16) ++ld; return ld; }
+static inline constexpr LcLds make_lc_lds(int n) {
+  LcLds s{};
   s.np = (n + 15) & ~15; s.ldp = lc_ld(s.np); s.nb = s.np / 16;
   s.mg_np = magic_div(s.np); s.mg_ldp = magic_div(s.ldp);
   int o = 0;
@@ -335,13 +341,20 @@ static inline LcLds make_lc_lds(int n) {
 #define LC_TILES 4   // nb^2 <= 25 output tiles on 8 wavefronts
 #define LC_STILES 2  // nb (nb + 1) / 2 <= 15 lower-triangle tiles of Sg
 
-__global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds S) {
+template <int FN = 0>
+__global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds Srt) {
+  constexpr bool FX = FN > 0;
+  constexpr LcLds SC_ = FX ? make_lc_lds(FN) : LcLds{};
+  LcLds S_ = Srt;
+  if constexpr (FX) S_ = SC_;
+  const LcLds& S = S_;
   const Layout& L = a.L;
-  const int j = blockIdx.x, b = blockIdx.y, nthr = blockDim.x, nw = nthr >> 6;
+  constexpr int nthr = LK_THREADS, nw = LK_THREADS / 64;
+  const int j = blockIdx.x, b = blockIdx.y;
   int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
-  const int n = L.n, np = S.np, ldp = S.ldp, nb = S.nb;
+  const int n = FX ? FN : L.n, np = S.np, ldp = S.ldp, nb = S.nb;
   const int ks = leg_start(a, j), ke = leg_start(a, j + 1) - 1;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double *LM = sm + S.LM, *BA = sm + S.BA, *BB = sm + S.BB, *sg = sm + S.vec, *phi = sg + np;

@@ -337,6 +337,8 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
     s->ric_fixed = 0;
     if (L.n == 76 && L.m == 32 && L.nz == 108 && ric_same_layout(s->ric, ric_fixed_layout(76, 32, true)) && !getenv("MPC_HIP_GENERIC_DIMS")) {
       s->ric_fixed = 1;
+      HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<32, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
+      HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense<76>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes));
       HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     }
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
@@ -344,7 +346,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes));
+    HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense<0>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
@@ -623,11 +625,15 @@ static void launch_pass(mpc_solver* s) {
       static const int chunk_env = getenv("MPC_LEG_KNOT_CHUNK") ? atoi(getenv("MPC_LEG_KNOT_CHUNK")) : 0;
       const int chunk = chunk_env > 0 ? chunk_env : 1;
       const dim3 grid((L.N + chunk - 1) / chunk, L.B);
-      if (s->lk.mp <= 16) hipLaunchKernelGGL(k_leg_knot<16>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
+      if (s->ric_fixed == 1) hipLaunchKernelGGL((k_leg_knot<32, 76, 32>), grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
+      else if (s->lk.mp <= 16) hipLaunchKernelGGL(k_leg_knot<16>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
       else if (s->lk.mp <= 32) hipLaunchKernelGGL(k_leg_knot<32>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
       else hipLaunchKernelGGL(k_leg_knot<48>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
     });
-    s->timed(13, "k_leg_condense", [&] { hipLaunchKernelGGL(k_leg_condense, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc); });
+    s->timed(13, "k_leg_condense", [&] {
+      if (s->ric_fixed == 1) hipLaunchKernelGGL(k_leg_condense<76>, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc);
+      else hipLaunchKernelGGL(k_leg_condense<0>, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc);
+    });
     if (tree) s->timed(14, "k_leg_consensus", [&] {
       const TreeDesc& T = s->tree;
 #define MPC_TREE_LAUNCH(NPV) do { \
@@ -1043,7 +1049,7 @@ int mpc_kernel_info(mpc_solver* s, int32_t idx, char* name, int32_t name_cap, in
       else e.push_back({"k_riccati_mfma<512,80,false,true> (sweep, legs)", (const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
       const void* lk = s->lk.mp <= 16 ? (const void*)k_leg_knot<16> : (s->lk.mp <= 32 ? (const void*)k_leg_knot<32> : (const void*)k_leg_knot<48>);
       e.push_back({"k_leg_knot", lk, LK_THREADS, s->lk.total_bytes, (long long)L.N * L.B});
-      e.push_back({"k_leg_condense", (const void*)k_leg_condense, LK_THREADS, s->lc.total_bytes, (long long)(J - 1) * L.B});
+      e.push_back({"k_leg_condense", (const void*)k_leg_condense<0>, LK_THREADS, s->lc.total_bytes, (long long)(J - 1) * L.B});
       if (s->use_tree()) {
         const TreeDesc T = make_tree_desc(J);
         const void* lc = s->lx.np == 16 ? (const void*)k_leg_compose<16> : s->lx.np == 32 ? (const void*)k_leg_compose<32> : s->lx.np == 48 ? (const void*)k_leg_compose<48>
