@@ -477,8 +477,8 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_condense(SolverArgs a, LcLds
 // the cuts: cut states (straight into dxs) and co-states theta ; last, the exact feedback gain of knot 0 (controlFeedbacks()[0]).
 // ---------------------------------------------------------------------------------------------------------------------
 struct LxLds { int np, mp, ldp, nb, nbm; int PC, MA, RB, vec, iw, total_bytes; unsigned mg_np, mg_ldp; };
-static inline LxLds make_lx_lds(int n, int m) {
-  LxLds s;
+static inline constexpr LxLds make_lx_lds(int n, int m) {
+  LxLds s{};
   s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.ldp = s.np + 1; s.nb = s.np / 16; s.nbm = s.mp / 16;
   s.mg_np = magic_div(s.np); s.mg_ldp = magic_div(s.ldp);
   int o = 0;

@@ -55,9 +55,11 @@ DEV double* tree_scratch_ptr(const SolverArgs& a, int b) { return tree_node_ptr(
 // G_{i+1} = G_i E_i.  One step per launch of the up-sweep, by a workgroup of its own beside the compositions (node i is complete when
 // level i + 1 starts), the root's step beside the first level of the down-sweep: nothing of it is on the critical path.
 // node < 0: G_1 only.
-template <int NP>
+template <int NP, int FN = 0, int FM = 0>
 DEV void tree_k0_step(const SolverArgs& a, const LxLds& S, const TreeDesc& T, int b, int node, double* sm, int tid, int nthr) {
-  const Layout& L = a.L;
+  Layout L_ = a.L;
+  if constexpr (FN > 0) { L_.n = FN; L_.m = FM; L_.nz = FN + FM; }
+  const Layout& L = L_;
   const int n = L.n, np = S.np, mp = S.mp, ldp = S.ldp, nb = S.nb, nbm = S.nbm, nw = nthr >> 6, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   double *PC = sm + S.PC, *MA = sm + S.MA, *RB = sm + S.RB;
@@ -142,18 +144,26 @@ DEV NodeRef tree_node_ref(const SolverArgs& a, const TreeDesc& T, int b, int nod
 #ifndef LCMP_THREADS
 #define LCMP_THREADS 512  // 8 wavefronts (measured with 1024 — every 16th column, 11 slots per wavefront, 128 VGPRs: 128 B of spills, dearer barriers: 0.502 against 0.507 ms for four levels, the centroidal problem slower)
 #endif
-template <int NP>
-__global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLds S, TreeDesc T, int level) {
+template <int NP, int FN = 0, int FM = 0>  // FN, FM > 0: state / control dimensions as compile-time constants (see k_riccati_mfma)
+__global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLds Srt, TreeDesc T, int level) {
   constexpr int NWC = LCMP_THREADS / 64, LCT = (25 + NWC - 1) / NWC, LCS = (15 + NWC - 1) / NWC;  // wavefronts ; tiles / lower-triangle tiles per wavefront (nb <= 5)
-  const Layout& L = a.L;
-  const int b = blockIdx.y, nthr = blockDim.x, nw = nthr >> 6;
+  constexpr bool FX = FN > 0;
+  constexpr LxLds SC_ = FX ? make_lx_lds(FN, FM) : LxLds{};
+  LxLds S_ = Srt;
+  if constexpr (FX) S_ = SC_;
+  const LxLds& S = S_;
+  Layout L_ = a.L;
+  if constexpr (FX) { L_.n = FN; L_.m = FM; L_.nz = FN + FM; }
+  const Layout& L = L_;
+  const int b = blockIdx.y;
+  constexpr int nthr = LCMP_THREADS, nw = LCMP_THREADS / 64;
   int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
   const int n = L.n, np = S.np, ldp = S.ldp, nb = S.nb;
   if ((int)blockIdx.x == T.lev_cnt[level]) {  // the workgroup of the K_0 path (tree_k0_step): the leftmost node of the level below
     extern __shared__ __attribute__((aligned(16))) double smk[];
-    if (blockIdx.z == 0) tree_k0_step<NP>(a, S, T, b, level == 0 ? -1 : T.lev_first[level - 1], smk, tid, nthr);
+    if (blockIdx.z == 0) tree_k0_step<NP, FN, FM>(a, S, T, b, level == 0 ? -1 : T.lev_first[level - 1], smk, tid, nthr);
     return;
   }
   const int node = T.lev_first[level] + blockIdx.x;
@@ -504,16 +514,24 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
 // value-function Hessian at the cut for the next pass (the leg record's lcP).  Launched after every sweep (the guesses), also the ones
 // whose cut states are not used (first pass of a handle).
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NP>
-__global__ void __launch_bounds__(LK_THREADS) k_leg_tree_down(SolverArgs a, LxLds S, TreeDesc T, int level) {
-  const Layout& L = a.L;
-  const int b = blockIdx.y, nthr = blockDim.x, nw = nthr >> 6;
+template <int NP, int FN = 0, int FM = 0>
+__global__ void __launch_bounds__(LK_THREADS) k_leg_tree_down(SolverArgs a, LxLds Srt, TreeDesc T, int level) {
+  constexpr bool FX = FN > 0;
+  constexpr LxLds SC_ = FX ? make_lx_lds(FN, FM) : LxLds{};
+  LxLds S_ = Srt;
+  if constexpr (FX) S_ = SC_;
+  const LxLds& S = S_;
+  Layout L_ = a.L;
+  if constexpr (FX) { L_.n = FN; L_.m = FM; L_.nz = FN + FM; }
+  const Layout& L = L_;
+  const int b = blockIdx.y;
+  constexpr int nthr = LK_THREADS, nw = LK_THREADS / 64;
   int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const InstState& st = a.inst[b];
   if (st.done || st.skip_step) return;
   const int n = L.n, N = L.N, J = T.J;
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  if ((int)blockIdx.x == T.lev_cnt[level]) { tree_k0_step<NP>(a, S, T, b, T.lev_first[level], sm, tid, nthr); return; }  // (first launch only: the root)
+  if ((int)blockIdx.x == T.lev_cnt[level]) { tree_k0_step<NP, FN, FM>(a, S, T, b, T.lev_first[level], sm, tid, nthr); return; }  // (first launch only: the root)
   const int node = T.lev_first[level] + blockIdx.x;
   double* t = tree_node_ptr(a, b, node - J);
   const int lc = T.left[node], rc = T.right[node], cutleg = T.lo[rc];

@@ -339,6 +339,8 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
       s->ric_fixed = 1;
       HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<32, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
       HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense<76>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes));
+      HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<80, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+      HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<80, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
       HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     }
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
@@ -638,7 +640,9 @@ static void launch_pass(mpc_solver* s) {
       const TreeDesc& T = s->tree;
 #define MPC_TREE_LAUNCH(NPV) do { \
         for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL(k_leg_compose<NPV>, dim3(T.lev_cnt[lev] + 1, L.B, 2), dim3(LCMP_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); } while (0)
-      switch (s->lx.np) {
+      if (s->ric_fixed == 1) {
+        for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL((k_leg_compose<80, 76, 32>), dim3(T.lev_cnt[lev] + 1, L.B, 2), dim3(LCMP_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev);
+      } else switch (s->lx.np) {
         case 16: MPC_TREE_LAUNCH(16); break;
         case 32: MPC_TREE_LAUNCH(32); break;
         case 48: MPC_TREE_LAUNCH(48); break;
@@ -649,7 +653,9 @@ static void launch_pass(mpc_solver* s) {
     });
     if (tree) s->timed(16, "k_leg_tree_down", [&] {
       const TreeDesc& T = s->tree;
-      switch (s->lx.np) {
+      if (s->ric_fixed == 1) {
+        for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL((k_leg_tree_down<80, 76, 32>), dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev);
+      } else switch (s->lx.np) {
         case 16: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<16>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;
         case 32: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<32>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;
         case 48: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<48>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;
