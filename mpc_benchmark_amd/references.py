@@ -68,6 +68,53 @@ def update_timings(land_LFs, land_RFs, takeoff_LFs, takeoff_RFs):
     return head(takeoff_RFs), head(takeoff_LFs), head(land_RFs), head(land_LFs)
 
 
+def shapeState(q_current, v_current, nq, nxq, cj_ids):
+    """The simulator's full state reduced to the controlled joints: base pose and twist as they are, then the position / velocity of
+    every controlled joint (``cj_ids``: joint ids of the full model, the free flyer's id <= 1 skipped) in list order
+    (talos_utils.py:337-348).  ``nq``: configuration dimension of the REDUCED model, ``nxq`` = nq + nv of it."""
+    q_current, v_current = np.asarray(q_current, dtype=float), np.asarray(v_current, dtype=float)
+    ids = np.array([j for j in cj_ids if j > 1], dtype=int)
+    x = np.zeros(nxq)
+    x[:7] = q_current[:7]
+    x[nq:nq + 6] = v_current[:6]
+    x[7:7 + ids.size] = q_current[ids + 5]
+    x[nq + 6:nq + 6 + ids.size] = v_current[ids + 4]
+    return x
+
+
+def compute_ID_references(space, rmodel, rdata, LF_id, RF_id, base_id, torso_id, x0_multibody, x_measured, LF_refs, RF_refs, dt):
+    """Task errors of the inverse-dynamics QP (centroidal_talos.py:408; talos_utils.py:375-402): posture, foot placement (position and
+    ``log3`` orientation), base / torso orientation against the RIGHT foot reference's rotation, and their rates from the next
+    reference sample.  ``rdata`` must hold the forward kinematics (with velocities) and frame placements at ``x_measured``.  Returns
+    q_diff, dq_diff, LF_diff, dLF_diff, RF_diff, dRF_diff, base_diff, dbase_diff, torso_diff, dtorso_diff."""
+    from .robot import minipin as pin
+    nv = rmodel.nv
+    d = -np.asarray(space.difference(x0_multibody, x_measured), dtype=float)
+    q_diff, dq_diff = d[:nv], d[nv:]
+
+    def pose_err(ref0, ref1, fid):
+        vel = pin.getFrameVelocity(rmodel, rdata, fid, pin.LOCAL)
+        M = rdata.oMf[fid]
+        e, de = np.zeros(6), np.zeros(6)
+        e[:3] = ref0.translation - M.translation
+        e[3:] = -pin.log3(ref0.rotation.T @ M.rotation)
+        de[:3] = (ref1.translation - ref0.translation) / dt - vel.linear
+        de[3:] = pin.log3(ref0.rotation.T @ ref1.rotation) / dt - vel.angular
+        return e, de
+
+    LF_diff, dLF_diff = pose_err(LF_refs[0], LF_refs[1], LF_id)
+    RF_diff, dRF_diff = pose_err(RF_refs[0], RF_refs[1], RF_id)
+    yaw_rate = pin.log3(RF_refs[0].rotation.T @ RF_refs[1].rotation) / dt
+
+    def orient_err(fid):
+        return (-pin.log3(RF_refs[0].rotation.T @ rdata.oMf[fid].rotation),
+                yaw_rate - pin.getFrameVelocity(rmodel, rdata, fid, pin.LOCAL).angular)
+
+    base_diff, dbase_diff = orient_err(base_id)
+    torso_diff, dtorso_diff = orient_err(torso_id)
+    return q_diff, dq_diff, LF_diff, dLF_diff, RF_diff, dRF_diff, base_diff, dbase_diff, torso_diff, dtorso_diff
+
+
 # ---- swing curve -----------------------------------------------------------------------------------------------------
 
 _BINOM8 = np.array([comb(8, i) for i in range(9)], dtype=float)

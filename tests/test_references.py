@@ -178,3 +178,30 @@ def test_batched_generator_and_foot_placements_equal_the_scalar_ones():
             for j in range(N):
                 for got, want in ((Lb[b, j], Ls[j]), (Rb[b, j], Rs[j])):
                     assert np.max(np.abs(got[:9] - want.rotation.reshape(-1))) < 1e-13 and np.max(np.abs(got[9:] - want.translation)) < 1e-13, (t, b, j)
+
+
+def test_shape_state_and_id_references_match_the_reference_vectors():
+    """shapeState / compute_ID_references (talos_utils.py:337-348, 375-402; call sites fulldynamic_talos.py:409, 516 and
+    centroidal_talos.py:408) against vectors the reference's own functions produced on seeded inputs (tools/gen_talos_utils_golden.py,
+    run in the build container with pinocchio -> minipin)."""
+    import os
+    from mpc_benchmark_amd import references
+    from mpc_benchmark_amd.aligator import manifolds
+    from mpc_benchmark_amd.problems.common import Robot
+    from mpc_benchmark_amd.robot import minipin as pin
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "talos_utils_vectors.npz"))
+    for q, v, x in zip(g["shape_q"], g["shape_v"], g["shape_x"]):
+        got = references.shapeState(q, v, int(g["shape_nq"]), int(g["shape_nxq"]), [int(j) for j in g["shape_cj_ids"]])
+        assert np.array_equal(got, x)
+    rob = Robot(complete=False)
+    m = rob.model
+    space = manifolds.MultibodyPhaseSpace(m)
+    data = m.createData()
+    LF_id, RF_id, base_id, torso_id = (int(f) for f in g["id_frames"])
+    for x, refs, want in zip(g["id_x"], g["id_refs"], g["id_out"]):
+        pin.forwardKinematics(m, data, x[:m.nq], x[m.nq:])
+        pin.updateFramePlacements(m, data)
+        poses = [pin.SE3(refs[12 * i:12 * i + 9].reshape(3, 3), refs[12 * i + 9:12 * i + 12]) for i in range(4)]
+        out = references.compute_ID_references(space, m, data, LF_id, RF_id, base_id, torso_id, g["id_x0"], x, poses[:2], poses[2:], 0.001)
+        got = np.concatenate([np.asarray(o, dtype=float).reshape(-1) for o in out])
+        assert got.shape == want.shape and np.allclose(got, want, rtol=0, atol=1e-12)
