@@ -130,13 +130,13 @@ DEV void implicit_diff_block(d4_t (&w)[4], d4_t& t, const double* Mt, const doub
 }
 
 // ============================================================================================================
-// FJ, FV, FU > 0: the model's body / velocity / control counts as compile-time constants (a free-flyer model: nq = nv + 1, n = 2 nv; stages
-// with contact-constrained dynamics) — the loop bounds, strides and LDS offsets of the carve-out fold into the instructions, as in the
+// FJ, FV, FU > 0: the model's body / velocity / control counts as compile-time constants (a free-flyer model: nq = nv + 1, n = 2 nv; FCD: the
+// carve-out with the blocks of the contact-constrained dynamics) — the loop bounds, strides and LDS offsets of the carve-out fold into the instructions, as in the
 // fixed-dimension instantiations of the Riccati sweep (riccati_mfma.h).  The launcher picks such an instantiation only for that model.
-template <int TRIAL, int FJ = 0, int FV = 0, int FU = 0>
+template <int TRIAL, int FJ = 0, int FV = 0, int FU = 0, bool FCD = true>
 __global__ void __launch_bounds__(EVAL_THREADS, EVAL_MIN_WAVES) k_eval_multibody(SolverArgs a, Layout KL, double* records, MbArgs mb, int cand0) {
   constexpr bool FX = FJ > 0;
-  constexpr MbLds SC_ = FX ? make_mb_lds(FJ, FV, FV + 1, FU, 2 * FV + FU, true) : MbLds{};
+  constexpr MbLds SC_ = FX ? make_mb_lds(FJ, FV, FV + 1, FU, 2 * FV + FU, FCD) : MbLds{};
   MbLds S_ = mb.lds;
   if constexpr (FX) S_ = SC_;
   const MbLds& S = S_;

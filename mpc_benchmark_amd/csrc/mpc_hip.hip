@@ -106,7 +106,7 @@ struct mpc_solver {
   hipEvent_t stage_ev[STAGE_RING] = {};
   int stage_next = 0;
   RicLds ric{};
-  int ric_fixed = 0;  // 1: the fixed-dimension instantiation of the sweep for (n, m) = (76, 32) applies (riccati_mfma.h)
+  int ric_fixed = 0;  // fixed-dimension instantiations of the sweep and the leg kernels (riccati_mfma.h): 1 = (n, m) = (76, 32), the full-dynamics OCP of the complete Talos ; 2 = (76, 44), its kinodynamic OCP
   ClLds cl{};
   bool use_mfma_riccati = false;
   // parallel-in-time legs (legs.h)
@@ -333,15 +333,24 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
                s->lc.total_bytes <= 160 * 1024 && s->lx.total_bytes <= 160 * 1024 && !getenv("MPC_HIP_NO_LEGS");
   if (s->legs_ok) {
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
-    // fixed-dimension instantiations (riccati_mfma.h): the complete Talos model of the full-dynamics OCP
+    // fixed-dimension instantiations (riccati_mfma.h): the complete Talos model, full-dynamics and kinodynamic OCP
     s->ric_fixed = 0;
-    if (L.n == 76 && L.m == 32 && L.nz == 108 && ric_same_layout(s->ric, ric_fixed_layout(76, 32, true)) && !getenv("MPC_HIP_GENERIC_DIMS")) {
-      s->ric_fixed = 1;
+    if (!getenv("MPC_HIP_GENERIC_DIMS") && L.n == 76) {
+      if (L.m == 32 && L.nz == 108 && ric_same_layout(s->ric, ric_fixed_layout(76, 32, true, 1, 1))) s->ric_fixed = 1;
+      else if (L.m == 44 && L.nz == 120 && ric_same_layout(s->ric, ric_fixed_layout(76, 44, true, 2, 0))) s->ric_fixed = 2;
+    }
+    if (s->ric_fixed == 1) {
+      HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
       HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<32, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
       HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense<76>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes));
       HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<80, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
       HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<80, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-      HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+    } else if (s->ric_fixed == 2) {
+      HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 44, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+      HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<48, 76, 44>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
+      HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense<76>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes));
+      HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<80, 76, 44>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+      HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<80, 76, 44>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
     }
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
@@ -607,6 +616,7 @@ static void launch_pass(mpc_solver* s) {
       if (s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>), dim3(L.B * J), dim3(RIC_SMALL_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
       else if (s->ric_fixed == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 32>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
+      else if (s->ric_fixed == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 44, 2, 0>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
       else if (s->ric.sq) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true, true>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, false, true>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
     }
@@ -628,12 +638,13 @@ static void launch_pass(mpc_solver* s) {
       const int chunk = chunk_env > 0 ? chunk_env : 1;
       const dim3 grid((L.N + chunk - 1) / chunk, L.B);
       if (s->ric_fixed == 1) hipLaunchKernelGGL((k_leg_knot<32, 76, 32>), grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
+      else if (s->ric_fixed == 2) hipLaunchKernelGGL((k_leg_knot<48, 76, 44>), grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
       else if (s->lk.mp <= 16) hipLaunchKernelGGL(k_leg_knot<16>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
       else if (s->lk.mp <= 32) hipLaunchKernelGGL(k_leg_knot<32>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
       else hipLaunchKernelGGL(k_leg_knot<48>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
     });
     s->timed(13, "k_leg_condense", [&] {
-      if (s->ric_fixed == 1) hipLaunchKernelGGL(k_leg_condense<76>, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc);
+      if (s->ric_fixed) hipLaunchKernelGGL(k_leg_condense<76>, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc);
       else hipLaunchKernelGGL(k_leg_condense<0>, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc);
     });
     if (tree) s->timed(14, "k_leg_consensus", [&] {
@@ -642,6 +653,8 @@ static void launch_pass(mpc_solver* s) {
         for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL(k_leg_compose<NPV>, dim3(T.lev_cnt[lev] + 1, L.B, 2), dim3(LCMP_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); } while (0)
       if (s->ric_fixed == 1) {
         for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL((k_leg_compose<80, 76, 32>), dim3(T.lev_cnt[lev] + 1, L.B, 2), dim3(LCMP_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev);
+      } else if (s->ric_fixed == 2) {
+        for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL((k_leg_compose<80, 76, 44>), dim3(T.lev_cnt[lev] + 1, L.B, 2), dim3(LCMP_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev);
       } else switch (s->lx.np) {
         case 16: MPC_TREE_LAUNCH(16); break;
         case 32: MPC_TREE_LAUNCH(32); break;
@@ -655,6 +668,8 @@ static void launch_pass(mpc_solver* s) {
       const TreeDesc& T = s->tree;
       if (s->ric_fixed == 1) {
         for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL((k_leg_tree_down<80, 76, 32>), dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev);
+      } else if (s->ric_fixed == 2) {
+        for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL((k_leg_tree_down<80, 76, 44>), dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev);
       } else switch (s->lx.np) {
         case 16: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<16>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;
         case 32: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<32>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;

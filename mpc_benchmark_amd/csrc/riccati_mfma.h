@@ -151,8 +151,8 @@ DEV double wave_sum_r(double v) { return wave_sum(v); }  // DPP reduction of sol
 // FN, FM > 0: the state / control dimensions of the problem as compile-time constants (n = FN, m <= FM; layout ric_fixed_layout): every
 // stride, tile count and LDS offset folds into the instructions — the generic kernel spends about half of its issue slots on index
 // arithmetic with run-time dimensions.  The host launches such an instantiation only when its handle's layout is that one (ric_same_layout).
-static inline constexpr RicLds ric_fixed_layout(int n, int m, bool sq) {
-  RicLds s = make_ric_lds(n, m, 0, 1, 1);
+static inline constexpr RicLds ric_fixed_layout(int n, int m, bool sq, int gfull = 1, int st_lds = 1) {
+  RicLds s = make_ric_lds(n, m, 0, gfull, st_lds);
   if (sq) { s.sq = 1; s.nv = n / 2; }
   return s;
 }
@@ -162,10 +162,10 @@ static inline bool ric_same_layout(const RicLds& x, const RicLds& y) {  // every
          x.vec == y.vec && x.Lr == y.Lr && x.LIr == y.LIr && x.W == y.W && x.ST == y.ST && x.CT == y.CT && x.VX == y.VX && x.Y == y.Y && x.SC == y.SC &&
          x.LIs == y.LIs && x.K2 == y.K2;
 }
-template <int RT, int NPMAX, bool SQ = false, bool LEGS = false, int FN = 0, int FM = 0>
+template <int RT, int NPMAX, bool SQ = false, bool LEGS = false, int FN = 0, int FM = 0, int FGF = 1, int FST = 1>
 __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
   constexpr bool FX = FN > 0;
-  constexpr RicLds SC_ = FX ? ric_fixed_layout(FN, FM, SQ) : RicLds{};
+  constexpr RicLds SC_ = FX ? ric_fixed_layout(FN, FM, SQ, FGF, FST) : RicLds{};
   // S: the layout — the compile-time one for a fixed-dimension instantiation, with the two members that depend on the row count from the argument
   RicLds S_ = Srt;
   if constexpr (FX) { S_ = SC_; S_.iwork = Srt.iwork; S_.total_bytes = Srt.total_bytes; }
