@@ -1066,6 +1066,8 @@ int mpc_kernel_info(mpc_solver* s, int32_t idx, char* name, int32_t name_cap, in
     const bool small = s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS;
     if (J > 1) {
       if (small) e.push_back({"k_riccati_mfma<256,16,false,true> (sweep, legs)", (const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>, RIC_SMALL_THREADS, s->ric.total_bytes, (long long)L.B * J});
+      else if (s->ric_fixed == 1) e.push_back({"k_riccati_mfma<512,80,true,true,76,32> (sweep, legs, fixed dimensions)", (const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 32>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
+      else if (s->ric_fixed == 2) e.push_back({"k_riccati_mfma<512,80,true,true,76,44,2,0> (sweep, legs, fixed dimensions)", (const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 44, 2, 0>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
       else if (s->ric.sq) e.push_back({"k_riccati_mfma<512,80,true,true> (sweep, legs)", (const void*)k_riccati_mfma<RIC_THREADS, 80, true, true>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
       else e.push_back({"k_riccati_mfma<512,80,false,true> (sweep, legs)", (const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
       const void* lk = s->lk.mp <= 16 ? (const void*)k_leg_knot<16> : (s->lk.mp <= 32 ? (const void*)k_leg_knot<32> : (const void*)k_leg_knot<48>);

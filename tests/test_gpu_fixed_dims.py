@@ -1,0 +1,50 @@
+"""The fixed-dimension instantiations of the hot kernels (dimensions as compile-time constants — the sweep, the
+leg kernels and the stage kernel for the complete Talos model) against the generic ones: same source, same arithmetic, so the
+iterates must agree to round-off (bit for bit unless the compiler contracts a multiply-add in one instantiation and not in the other).
+``MPC_HIP_GENERIC_DIMS=1`` selects the generic kernels (read when a handle is created and at every launch of the stage kernel), so
+the two runs are made one after the other."""
+import os
+
+import numpy as np
+import pytest
+
+from mpc_benchmark_amd.ensemble import EnsembleMPC
+from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+from mpc_benchmark_amd.problems.kinodynamic import KinodynamicProblem
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(hip_lib, make, legs, ticks, generic):
+    if generic:
+        os.environ["MPC_HIP_GENERIC_DIMS"] = "1"
+    else:
+        os.environ.pop("MPC_HIP_GENERIC_DIMS", None)
+    try:
+        e = make(hip_lib)
+        e.options.riccati_legs = legs
+        e.native.set_options(e.options)
+        e.prepare_schedule(ticks + 4)
+        st = e.cold_solve(max_iters=100)
+        for _ in range(ticks):
+            e.step()
+        r = e.results(gains=True)
+        return st, {k: np.array(r[k]) for k in ("xs", "us", "K")}
+    finally:
+        os.environ.pop("MPC_HIP_GENERIC_DIMS", None)
+
+
+@pytest.mark.parametrize("name,legs", [("fulldynamic", 4), ("fulldynamic", 32), ("kinodynamic", 4)])
+def test_fixed_dimension_kernels_equal_the_generic_ones(hip_lib, name, legs):
+    if name == "fulldynamic":
+        make = lambda lib: EnsembleMPC(FullDynamicsProblem(horizon=40, complete_model=True), batch=3, library=lib, seed=5)
+    else:
+        make = lambda lib: EnsembleMPC(KinodynamicProblem(horizon=40, complete_model=True), batch=3, library=lib, seed=5, perturb_dofs=range(18, 38))
+    sf, fixed = _run(hip_lib, make, legs, 6, generic=False)
+    sg, gen = _run(hip_lib, make, legs, 6, generic=True)
+    assert [s.num_iters for s in sf] == [s.num_iters for s in sg]
+    same = all(np.array_equal(fixed[k], gen[k]) for k in fixed)
+    print("%s, %d legs: fixed-dimension and generic kernels %s" % (name, legs, "agree bit for bit" if same else "agree to round-off only"))
+    for k in fixed:
+        scale = np.maximum(1.0, np.abs(gen[k]))
+        assert np.max(np.abs(fixed[k] - gen[k]) / scale) < 1e-9, k
