@@ -2,7 +2,7 @@
 reuse) — p50 / p90, how many ticks take more than one pass (a BCL update without a step, then the step), per-kernel time.
 The walk of the script (0.3 m steps, kinodynamic_talos.py:257) with 0.10 m gained per step, references replanned every tick
 (EnsembleMPC.enable_walk); STAIRS=0: flat ground, WALK=0: frozen references (the round-3 form of this measurement), PERINST=1:
-every instance plans from its own foot poses.  START=n: n untimed ticks first (120: the first swing is at knot 0)."""
+every instance plans from its own foot poses, REFINE=R: mpc_options.refine_appended_knot.  START=n: n untimed ticks first (120: the first swing is at knot 0)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -12,7 +12,9 @@ from mpc_benchmark_amd.problems.kinodynamic import KinodynamicProblem
 lib = _capi.bind_library(os.environ["LIB"]) if os.environ.get("LIB") else _capi.load_hip_library()
 kp = KinodynamicProblem(horizon=150, complete_model=True)
 ens = EnsembleMPC(kp, batch=64, library=lib, seed=7, perturb_dofs=range(18, kp.nv), tick_reuse=not os.environ.get("NO_REUSE"))
-ens.options.riccati_legs = int(os.environ.get("LEGS", "4")); ens.native.set_options(ens.options)
+ens.options.riccati_legs = int(os.environ.get("LEGS", "4"))
+ens.options.refine_appended_knot = int(os.environ.get("REFINE", "0"))  # (mpc_options.refine_appended_knot: Newton steps on the control of the appended knot when the contact pattern changes)
+ens.native.set_options(ens.options)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 ens.prepare_schedule(T + 10 + int(os.environ.get("START", "0")))
 ens.cold_solve(max_iters=100)
