@@ -611,6 +611,8 @@ def main():
                    "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "riccati_legs": legs, "tick_reuse": not args.no_tick_reuse, "refine_appended_knot": args.refine_appended_knot, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
         "p50_ms_per_solve_batch1": p50_ms, "p90_ms_per_solve_batch1": p90_ms, "p95_ms_per_solve_batch1": p95_ms, "latency_ticks": (300 if p50_ms is not None else 0), "p50_riccati_legs": (args.latency_legs if args.legs != 1 else 1),
+        # which instantiations of the hot kernels served the run (dimensions as compile-time constants; MPC_HIP_GENERIC_DIMS=1 forces the generic ones)
+        "kernel_dimensions": {0: "run-time (generic kernels)", 1: "compile-time: n = 76, m = 32 (complete Talos, full dynamics)", 2: "compile-time: n = 76, m = 44 (complete Talos, kinodynamic)"}.get(int(shards[0].native.debug_get("fixed_dims", 0)[0]), "?"),
         "riccati_cuts": ("chain (MPC_LEGS_CHAIN)" if os.environ.get("MPC_LEGS_CHAIN", "0") not in ("", "0") else "tree of pairwise compositions (csrc/legs_tree.h) from three legs on"),
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
         "cold_solve_converged_instances": "%d/%d within %d iterations, %d within the scripts' 100 (randomised initial states; set-up, untimed; largest primal / dual infeasibility of the unconverged ones: %.2e)" % (n_conv, args.batch, args.cold_iters, mres["n_conv100"], mres["worst_unconv"]),

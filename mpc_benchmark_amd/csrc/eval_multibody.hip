@@ -33,16 +33,23 @@ void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout
     if (e1 != hipSuccess || e2 != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(LDS) failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
     attr_bytes.store(mb.lds.total_bytes + 1);  // + 1: the zero-initialised slots mean "not set"
   }
-  // fixed-dimension instantiations (eval_multibody.h) for the complete Talos model of the scripts (33 bodies, 38 velocity dofs): the
-  // full-dynamics OCP (32 joint torques, contact-constrained dynamics) and the kinodynamic one (12 wrench components + 32 joint accelerations)
-  const bool talos = L.nj == 33 && L.n == 76 && L.nx == 77 && !getenv("MPC_HIP_GENERIC_DIMS") && sim_substeps <= 0;
-  const int fixed = !talos ? 0 : (L.m == 32 && L.nz == 108 && contact_dyn) ? 1 : (L.m == 44 && L.nz == 120 && !contact_dyn) ? 2 : 0;
+  // fixed-dimension instantiations (eval_multibody.h):  X(id, bodies, velocity dofs, controls, contact-constrained dynamics)
+  //   1, 2: the complete Talos (33 bodies, 38 dofs), full-dynamics OCP (32 joint torques) and kinodynamic OCP (12 wrench components + 32 joint
+  //   accelerations, no contact-dynamics blocks) ; 3, 4: the Talos with the upper body locked as the scripts lock it (23 bodies, 28 dofs)
+#define MB_FIXED_MODELS(X) X(1, 33, 38, 32, true) X(2, 33, 38, 44, false) X(3, 23, 28, 22, true) X(4, 23, 28, 34, false)
+  int fixed = 0;
+  if (!getenv("MPC_HIP_GENERIC_DIMS") && sim_substeps <= 0) {
+#define X(ID, FJ, FV, FU, FCD) if (L.nj == FJ && L.n == 2 * FV && L.nx == 2 * FV + 1 && L.m == FU && L.nz == 2 * FV + FU && contact_dyn == FCD) fixed = ID;
+    MB_FIXED_MODELS(X)
+#undef X
+  }
   if (fixed) {
-    static std::atomic<int> attr_fixed_dev[2][64];
+    static std::atomic<int> attr_fixed_dev[4][64];
     std::atomic<int>& done = attr_fixed_dev[fixed - 1][dev & 63];
-    const void* fn0 = fixed == 1 ? (const void*)k_eval_multibody<0, 33, 38, 32, true> : (const void*)k_eval_multibody<0, 33, 38, 44, false>;
-    const void* fn1 = fixed == 1 ? (const void*)k_eval_multibody<1, 33, 38, 32, true> : (const void*)k_eval_multibody<1, 33, 38, 44, false>;
-    const void* fn3 = fixed == 1 ? (const void*)k_eval_multibody<3, 33, 38, 32, true> : (const void*)k_eval_multibody<3, 33, 38, 44, false>;
+    const void *fn0 = nullptr, *fn1 = nullptr, *fn3 = nullptr;
+#define X(ID, FJ, FV, FU, FCD) if (fixed == ID) { fn0 = (const void*)k_eval_multibody<0, FJ, FV, FU, FCD>; fn1 = (const void*)k_eval_multibody<1, FJ, FV, FU, FCD>; fn3 = (const void*)k_eval_multibody<3, FJ, FV, FU, FCD>; }
+    MB_FIXED_MODELS(X)
+#undef X
     if (done.load() < mb.lds.total_bytes + 1) {
       hipError_t e1 = hipFuncSetAttribute(fn0, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
       if (e1 == hipSuccess) e1 = hipFuncSetAttribute(fn1, hipFuncAttributeMaxDynamicSharedMemorySize, mb.lds.total_bytes);
@@ -50,13 +57,15 @@ void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout
       if (e1 != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(LDS) failed: ") + hipGetErrorString(e1));
       done.store(mb.lds.total_bytes + 1);
     }
-#define MB_LAUNCH_FIXED(T, GRID, LAY, C0) do { \
-      if (fixed == 1) hipLaunchKernelGGL((k_eval_multibody<T, 33, 38, 32, true>), GRID, dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LAY, records, mb, C0); \
-      else hipLaunchKernelGGL((k_eval_multibody<T, 33, 38, 44, false>), GRID, dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LAY, records, mb, C0); } while (0)
-    if (trial && with_derivs) MB_LAUNCH_FIXED(3, dim3(L.N + 1 + (a.spec_knot ? 1 : 0), L.B, 1), L, 0);
-    else if (!trial) MB_LAUNCH_FIXED(0, dim3(L.N + 1, L.B, 1), L, 0);
-    else MB_LAUNCH_FIXED(1, dim3(L.N + 1, L.B, mb.ncand_loop > 0 ? 1 : ncand), LT, cand0);
-#undef MB_LAUNCH_FIXED
+#define X3(ID, FJ, FV, FU, FCD) else if (fixed == ID) hipLaunchKernelGGL((k_eval_multibody<3, FJ, FV, FU, FCD>), dim3(L.N + 1 + (a.spec_knot ? 1 : 0), L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
+#define X0(ID, FJ, FV, FU, FCD) else if (fixed == ID) hipLaunchKernelGGL((k_eval_multibody<0, FJ, FV, FU, FCD>), dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
+#define X1(ID, FJ, FV, FU, FCD) else if (fixed == ID) hipLaunchKernelGGL((k_eval_multibody<1, FJ, FV, FU, FCD>), dim3(L.N + 1, L.B, mb.ncand_loop > 0 ? 1 : ncand), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
+    if (trial && with_derivs) { if (false) {} MB_FIXED_MODELS(X3) }
+    else if (!trial) { if (false) {} MB_FIXED_MODELS(X0) }
+    else { if (false) {} MB_FIXED_MODELS(X1) }
+#undef X3
+#undef X0
+#undef X1
     return;
   }
   if (sim_substeps > 0) hipLaunchKernelGGL(k_eval_multibody<2>, dim3(1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, 0);

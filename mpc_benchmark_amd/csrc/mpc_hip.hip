@@ -25,6 +25,13 @@
     if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
+// Problems whose dimensions get compile-time instantiations of the sweep and the leg kernels (riccati_mfma.h "FN, FM"):
+//   X(id, n, m, gfull, st_lds, NP, MP)   — (n, m): state / control dimension ; gfull, st_lds: the sweep's LDS plan for them (make_ric_lds) ;
+//   NP, MP: padded state / control dimension (the template arguments of the tree and of k_leg_knot)
+// 1: complete Talos (38 dofs), full dynamics   2: complete Talos, kinodynamic   3: Talos with the upper body locked as the scripts lock it
+// (28 dofs), full dynamics   4: the same, kinodynamic.  The stage kernel has its own list (eval_multibody.hip).
+#define MPC_FIXED_MODELS(X) X(1, 76, 32, 1, 1, 80, 32) X(2, 76, 44, 2, 0, 80, 48) X(3, 56, 22, 1, 1, 64, 32) X(4, 56, 34, 1, 1, 64, 48)
+
 struct mpc_solver {
   mpc_dims dims{};
   mpc_options opt{};
@@ -106,7 +113,7 @@ struct mpc_solver {
   hipEvent_t stage_ev[STAGE_RING] = {};
   int stage_next = 0;
   RicLds ric{};
-  int ric_fixed = 0;  // fixed-dimension instantiations of the sweep and the leg kernels (riccati_mfma.h): 1 = (n, m) = (76, 32), the full-dynamics OCP of the complete Talos ; 2 = (76, 44), its kinodynamic OCP
+  int ric_fixed = 0;  // id of the fixed-dimension instantiations of the sweep and the leg kernels that serve this handle (MPC_FIXED_MODELS below), 0: the generic kernels
   ClLds cl{};
   bool use_mfma_riccati = false;
   // parallel-in-time legs (legs.h)
@@ -333,25 +340,21 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
                s->lc.total_bytes <= 160 * 1024 && s->lx.total_bytes <= 160 * 1024 && !getenv("MPC_HIP_NO_LEGS");
   if (s->legs_ok) {
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
-    // fixed-dimension instantiations (riccati_mfma.h): the complete Talos model, full-dynamics and kinodynamic OCP
+    // fixed-dimension instantiations (MPC_FIXED_MODELS): only when the handle's LDS plan IS the one they were compiled for
     s->ric_fixed = 0;
-    if (!getenv("MPC_HIP_GENERIC_DIMS") && L.n == 76) {
-      if (L.m == 32 && L.nz == 108 && ric_same_layout(s->ric, ric_fixed_layout(76, 32, true, 1, 1))) s->ric_fixed = 1;
-      else if (L.m == 44 && L.nz == 120 && ric_same_layout(s->ric, ric_fixed_layout(76, 44, true, 2, 0))) s->ric_fixed = 2;
+    if (!getenv("MPC_HIP_GENERIC_DIMS") && s->ric.sq) {
+#define X(ID, FN, FM, GF, ST, NPV, MPV) if (!s->ric_fixed && L.n == FN && L.m == FM && L.nz == FN + FM && ric_same_layout(s->ric, ric_fixed_layout(FN, FM, true, GF, ST))) s->ric_fixed = ID;
+      MPC_FIXED_MODELS(X)
+#undef X
     }
-    if (s->ric_fixed == 1) {
-      HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
-      HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<32, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
-      HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense<76>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes));
-      HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<80, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-      HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<80, 76, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    } else if (s->ric_fixed == 2) {
-      HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 44, 2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
-      HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<48, 76, 44>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
-      HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense<76>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes));
-      HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<80, 76, 44>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-      HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<80, 76, 44>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    }
+#define X(ID, FN, FM, GF, ST, NPV, MPV) if (s->ric_fixed == ID) { \
+      HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, FN, FM, GF, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes)); \
+      HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<MPV, FN, FM>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes)); \
+      HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense<FN>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes)); \
+      HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<NPV, FN, FM>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes)); \
+      HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<NPV, FN, FM>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes)); }
+    MPC_FIXED_MODELS(X)
+#undef X
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
     HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
@@ -615,8 +618,9 @@ static void launch_pass(mpc_solver* s) {
       // parallel-in-time: workgroup (instance, leg), the last leg first
       if (s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>), dim3(L.B * J), dim3(RIC_SMALL_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
-      else if (s->ric_fixed == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 32>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
-      else if (s->ric_fixed == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 44, 2, 0>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
+#define X(ID, FN, FM, GF, ST, NPV, MPV) else if (s->ric_fixed == ID) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true, true, FN, FM, GF, ST>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
+      MPC_FIXED_MODELS(X)
+#undef X
       else if (s->ric.sq) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, true, true>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_riccati_mfma<RIC_THREADS, 80, false, true>), dim3(L.B * J), dim3(RIC_THREADS), s->ric.total_bytes, s->stream, a, s->ric);
     }
@@ -637,24 +641,29 @@ static void launch_pass(mpc_solver* s) {
       static const int chunk_env = getenv("MPC_LEG_KNOT_CHUNK") ? atoi(getenv("MPC_LEG_KNOT_CHUNK")) : 0;
       const int chunk = chunk_env > 0 ? chunk_env : 1;
       const dim3 grid((L.N + chunk - 1) / chunk, L.B);
-      if (s->ric_fixed == 1) hipLaunchKernelGGL((k_leg_knot<32, 76, 32>), grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
-      else if (s->ric_fixed == 2) hipLaunchKernelGGL((k_leg_knot<48, 76, 44>), grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
+      if (false) {}
+#define X(ID, FN, FM, GF, ST, NPV, MPV) else if (s->ric_fixed == ID) hipLaunchKernelGGL((k_leg_knot<MPV, FN, FM>), grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
+      MPC_FIXED_MODELS(X)
+#undef X
       else if (s->lk.mp <= 16) hipLaunchKernelGGL(k_leg_knot<16>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
       else if (s->lk.mp <= 32) hipLaunchKernelGGL(k_leg_knot<32>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
       else hipLaunchKernelGGL(k_leg_knot<48>, grid, dim3(LK_THREADS), s->lk.total_bytes, s->stream, a, s->lk, chunk);
     });
     s->timed(13, "k_leg_condense", [&] {
-      if (s->ric_fixed) hipLaunchKernelGGL(k_leg_condense<76>, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc);
+      if (false) {}
+#define X(ID, FN, FM, GF, ST, NPV, MPV) else if (s->ric_fixed == ID) hipLaunchKernelGGL(k_leg_condense<FN>, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc);
+      MPC_FIXED_MODELS(X)
+#undef X
       else hipLaunchKernelGGL(k_leg_condense<0>, dim3(J - 1, L.B), dim3(LK_THREADS), s->lc.total_bytes, s->stream, a, s->lc);
     });
     if (tree) s->timed(14, "k_leg_consensus", [&] {
       const TreeDesc& T = s->tree;
 #define MPC_TREE_LAUNCH(NPV) do { \
         for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL(k_leg_compose<NPV>, dim3(T.lev_cnt[lev] + 1, L.B, 2), dim3(LCMP_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); } while (0)
-      if (s->ric_fixed == 1) {
-        for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL((k_leg_compose<80, 76, 32>), dim3(T.lev_cnt[lev] + 1, L.B, 2), dim3(LCMP_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev);
-      } else if (s->ric_fixed == 2) {
-        for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL((k_leg_compose<80, 76, 44>), dim3(T.lev_cnt[lev] + 1, L.B, 2), dim3(LCMP_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev);
+      if (false) {
+#define X(ID, FN, FM, GF, ST, NPV, MPV) } else if (s->ric_fixed == ID) { for (int lev = 0; lev < T.nlev; ++lev) hipLaunchKernelGGL((k_leg_compose<NPV, FN, FM>), dim3(T.lev_cnt[lev] + 1, L.B, 2), dim3(LCMP_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev);
+      MPC_FIXED_MODELS(X)
+#undef X
       } else switch (s->lx.np) {
         case 16: MPC_TREE_LAUNCH(16); break;
         case 32: MPC_TREE_LAUNCH(32); break;
@@ -666,10 +675,10 @@ static void launch_pass(mpc_solver* s) {
     });
     if (tree) s->timed(16, "k_leg_tree_down", [&] {
       const TreeDesc& T = s->tree;
-      if (s->ric_fixed == 1) {
-        for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL((k_leg_tree_down<80, 76, 32>), dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev);
-      } else if (s->ric_fixed == 2) {
-        for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL((k_leg_tree_down<80, 76, 44>), dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev);
+      if (false) {
+#define X(ID, FN, FM, GF, ST, NPV, MPV) } else if (s->ric_fixed == ID) { for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL((k_leg_tree_down<NPV, FN, FM>), dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev);
+      MPC_FIXED_MODELS(X)
+#undef X
       } else switch (s->lx.np) {
         case 16: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<16>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;
         case 32: for (int lev = T.nlev - 1; lev >= 0; --lev) hipLaunchKernelGGL(k_leg_tree_down<32>, dim3(T.lev_cnt[lev] + (lev == T.nlev - 1 ? 1 : 0), L.B), dim3(LK_THREADS), s->lx.total_bytes, s->stream, a, s->lx, T, lev); break;
@@ -1066,8 +1075,9 @@ int mpc_kernel_info(mpc_solver* s, int32_t idx, char* name, int32_t name_cap, in
     const bool small = s->ric.np == 16 && s->ric.mp == 16 && L.c <= RIC_SMALL_THREADS;
     if (J > 1) {
       if (small) e.push_back({"k_riccati_mfma<256,16,false,true> (sweep, legs)", (const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>, RIC_SMALL_THREADS, s->ric.total_bytes, (long long)L.B * J});
-      else if (s->ric_fixed == 1) e.push_back({"k_riccati_mfma<512,80,true,true,76,32> (sweep, legs, fixed dimensions)", (const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 32>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
-      else if (s->ric_fixed == 2) e.push_back({"k_riccati_mfma<512,80,true,true,76,44,2,0> (sweep, legs, fixed dimensions)", (const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, 76, 44, 2, 0>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
+#define X(ID, FN, FM, GF, ST, NPV, MPV) else if (s->ric_fixed == ID) e.push_back({"k_riccati_mfma<512,80,true,true," #FN "," #FM "," #GF "," #ST "> (sweep, legs, fixed dimensions)", (const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, FN, FM, GF, ST>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
+      MPC_FIXED_MODELS(X)
+#undef X
       else if (s->ric.sq) e.push_back({"k_riccati_mfma<512,80,true,true> (sweep, legs)", (const void*)k_riccati_mfma<RIC_THREADS, 80, true, true>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
       else e.push_back({"k_riccati_mfma<512,80,false,true> (sweep, legs)", (const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
       const void* lk = s->lk.mp <= 16 ? (const void*)k_leg_knot<16> : (s->lk.mp <= 32 ? (const void*)k_leg_knot<32> : (const void*)k_leg_knot<48>);
@@ -1543,6 +1553,7 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
       else if (nm == "calp") dev_vec(lr + L.lcp, n);
       else dev_vec(lr + L.lth, n);
     }
+    else if (nm == "fixed_dims") v = {(double)s->ric_fixed};  // which fixed-dimension instantiations serve this handle (0: the generic kernels)
     else if (nm == "ric_prof") { dev_vec(s->d_prof + (size_t)b * 64, 64); HIP_OK(hipMemsetAsync(s->d_prof + (size_t)b * 64, 0, 64 * sizeof(double), s->stream)); HIP_OK(hipStreamSynchronize(s->stream)); }
     else if (nm == "dx") dev_vec(s->d_dxs + ((size_t)b * (L.N + 1) + k) * n, n);
     else if (nm == "du") { if (k >= L.N) throw std::runtime_error("no du at the terminal knot"); dev_vec(s->d_dus + ((size_t)b * L.N + k) * L.m, L.m); }

@@ -29,19 +29,22 @@ def _run(hip_lib, make, legs, ticks, generic):
         for _ in range(ticks):
             e.step()
         r = e.results(gains=True)
-        return st, {k: np.array(r[k]) for k in ("xs", "us", "K")}
+        return st, {k: np.array(r[k]) for k in ("xs", "us", "K")}, int(e.native.debug_get("fixed_dims", 0)[0])
     finally:
         os.environ.pop("MPC_HIP_GENERIC_DIMS", None)
 
 
-@pytest.mark.parametrize("name,legs", [("fulldynamic", 4), ("fulldynamic", 32), ("kinodynamic", 4)])
-def test_fixed_dimension_kernels_equal_the_generic_ones(hip_lib, name, legs):
+@pytest.mark.parametrize("name,complete,legs,model_id", [("fulldynamic", True, 4, 1), ("fulldynamic", True, 32, 1), ("kinodynamic", True, 4, 2),
+                                                        ("fulldynamic", False, 4, 3), ("kinodynamic", False, 4, 4)])
+def test_fixed_dimension_kernels_equal_the_generic_ones(hip_lib, name, complete, legs, model_id):
     if name == "fulldynamic":
-        make = lambda lib: EnsembleMPC(FullDynamicsProblem(horizon=40, complete_model=True), batch=3, library=lib, seed=5)
+        make = lambda lib: EnsembleMPC(FullDynamicsProblem(horizon=40, complete_model=complete), batch=3, library=lib, seed=5)
     else:
-        make = lambda lib: EnsembleMPC(KinodynamicProblem(horizon=40, complete_model=True), batch=3, library=lib, seed=5, perturb_dofs=range(18, 38))
-    sf, fixed = _run(hip_lib, make, legs, 6, generic=False)
-    sg, gen = _run(hip_lib, make, legs, 6, generic=True)
+        kp = KinodynamicProblem(horizon=40, complete_model=complete)
+        make = lambda lib: EnsembleMPC(kp, batch=3, library=lib, seed=5, perturb_dofs=range(18, kp.nv))
+    sf, fixed, idf = _run(hip_lib, make, legs, 6, generic=False)
+    sg, gen, idg = _run(hip_lib, make, legs, 6, generic=True)
+    assert idf == model_id and idg == 0, "expected the fixed-dimension kernels of model %d, then the generic ones: got %d, %d" % (model_id, idf, idg)
     assert [s.num_iters for s in sf] == [s.num_iters for s in sg]
     same = all(np.array_equal(fixed[k], gen[k]) for k in fixed)
     print("%s, %d legs: fixed-dimension and generic kernels %s" % (name, legs, "agree bit for bit" if same else "agree to round-off only"))
