@@ -143,7 +143,15 @@ typedef struct mpc_options {
                             *     du = -(H_uu + D_a^T D_a / mu)^-1 (g_u + D_a^T Pi_N(z)_a / mu)    (the knot's own penalty problem, active rows a)
                             * then x_N = phi(x_{N-1}, u_{N-1}).  Costs R + 1 evaluations of one knot per instance on the ~1.4 % of the ticks
                             * where the pattern changes; with it ensembles of randomised instances walk the whole schedule on ONE ProxDDP
-                            * iteration per tick.  Not something Aligator does: a choice of initial guess, off unless asked for. */
+                            * iteration per tick.  R < 0: the same |R| steps after EVERY mpc_cycle, whatever the
+                            * appended stage is.  For OCPs whose controls contain the contact forces (the kinodynamic one): the references of
+                            * the appended stage differ from those of the stage before it as a rule (force references ramp before a
+                            * take-off), the duplicated control leaves the appended knot's own active set, and the full step of the tick
+                            * then violates rows the Newton system did not know — the kinodynamic walk spends five consecutive ticks
+                            * backtracking on that (alpha = 1/2 ... 1/128), and none with R = -1.  NOT for the whole-body OCP: there the
+                            * refinement problem of a knot whose duplicated control is already feasible is ill-conditioned (dependent cone
+                            * rows; the nominal instance is lost within 30 ticks) — use R > 0.  Not
+                            * something Aligator does: a choice of initial guess, off unless asked for. */
 } mpc_options;
 
 typedef struct mpc_stats {

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(EVAL_THREADS, EVAL_MIN_WAVES) k_eval_multibody
   // shift makes of it).  Its record goes to a spare slot (a.spec_knot) ; if the table of the appended stage turns out to be that one
   // (mpc_cycle compares), the next tick takes it as knot N - 1 instead of evaluating it (k_reproject, knot_reused).
   const bool specw = TRIAL == 3 && (int)blockIdx.x == a.L.N + 1;
-  const int k = specw ? a.L.N - 1 : (int)blockIdx.x;  // stage table, control, multipliers
+  const int k = specw ? a.L.N - 1 : ((TRIAL == 0 && a.only_knot >= 0) ? a.only_knot : (int)blockIdx.x);  // stage table, control, multipliers (only_knot: the launch is that knot alone)
   const int b = blockIdx.y;
   constexpr int nthr = EVAL_THREADS;  // (the launcher uses EVAL_THREADS threads)
   int cand = blockIdx.z + cand0;

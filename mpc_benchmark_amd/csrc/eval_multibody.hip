@@ -58,7 +58,7 @@ void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout
       done.store(mb.lds.total_bytes + 1);
     }
 #define X3(ID, FJ, FV, FU, FCD) else if (fixed == ID) hipLaunchKernelGGL((k_eval_multibody<3, FJ, FV, FU, FCD>), dim3(L.N + 1 + (a.spec_knot ? 1 : 0), L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
-#define X0(ID, FJ, FV, FU, FCD) else if (fixed == ID) hipLaunchKernelGGL((k_eval_multibody<0, FJ, FV, FU, FCD>), dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
+#define X0(ID, FJ, FV, FU, FCD) else if (fixed == ID) hipLaunchKernelGGL((k_eval_multibody<0, FJ, FV, FU, FCD>), dim3(a.only_knot >= 0 ? 1 : L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
 #define X1(ID, FJ, FV, FU, FCD) else if (fixed == ID) hipLaunchKernelGGL((k_eval_multibody<1, FJ, FV, FU, FCD>), dim3(L.N + 1, L.B, mb.ncand_loop > 0 ? 1 : ncand), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
     if (trial && with_derivs) { if (false) {} MB_FIXED_MODELS(X3) }
     else if (!trial) { if (false) {} MB_FIXED_MODELS(X0) }
@@ -70,7 +70,7 @@ void launch_eval_multibody(hipStream_t stream, const SolverArgs& a, const Layout
   }
   if (sim_substeps > 0) hipLaunchKernelGGL(k_eval_multibody<2>, dim3(1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, 0);
   else if (trial && with_derivs) hipLaunchKernelGGL(k_eval_multibody<3>, dim3(L.N + 1 + (a.spec_knot ? 1 : 0), L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);  // records = the knot records (+ the speculative knot)
-  else if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
+  else if (!trial) hipLaunchKernelGGL(k_eval_multibody<0>, dim3(a.only_knot >= 0 ? 1 : L.N + 1, L.B, 1), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, L, records, mb, 0);
   else hipLaunchKernelGGL(k_eval_multibody<1>, dim3(L.N + 1, L.B, mb.ncand_loop > 0 ? 1 : ncand), dim3(EVAL_THREADS), mb.lds.total_bytes, stream, a, LT, records, mb, cand0);
 }
 

@@ -11,7 +11,7 @@
 template <int TRIAL>
 __global__ void __launch_bounds__(64) k_eval_vector(SolverArgs a, Layout KL, double* records, int cand0) {
   const Layout& L = a.L;
-  const int k = blockIdx.x, b = blockIdx.y, cand = blockIdx.z + cand0, tid = threadIdx.x, nthr = blockDim.x;
+  const int k = (!TRIAL && a.only_knot >= 0) ? a.only_knot : (int)blockIdx.x, b = blockIdx.y, cand = blockIdx.z + cand0, tid = threadIdx.x, nthr = blockDim.x;  // (only_knot: the launch is that knot alone)
   const InstState& st = a.inst[b];
   if (st.done || (TRIAL && st.skip_step)) return;
   if (TRIAL && cand > 0 && !st.ls_more) return;  // the full step was accepted: no backtracking candidates needed

@@ -80,6 +80,7 @@ struct mpc_solver {
   double* d_fext = nullptr;  // [B][3] disturbance force of mpc_simulate_push
   int only_knot = -1;              // SolverArgs::only_knot of the launches being enqueued
   bool appended_changed = false;   // the stage of the last mpc_cycle has another contact pattern than its predecessor (refine_appended_knot)
+  bool appended_any = false;       // a stage was appended since the last run (refine_appended_knot < 0: refine after every cycle)
   bool refine_now = false;         // ... and this run refines the warm start of the appended knot after k_begin_run
   double* d_simu = nullptr;  // [B][nu] torques, [B][12] wrenches of mpc_simulate_torque
   double* d_simwr = nullptr;
@@ -569,7 +570,7 @@ static void launch_eval(mpc_solver* s, bool trial, int cand0 = 0, int ncand = 1,
   SolverArgs a = s->args();
   if (ncand <= 0) return;
   if (L.space == MPC_SPACE_VECTOR) {
-    if (!trial) hipLaunchKernelGGL(k_eval_vector<0>, dim3(L.N + 1, L.B, 1), dim3(64), 0, s->stream, a, s->L, s->d_knots, 0);
+    if (!trial) hipLaunchKernelGGL(k_eval_vector<0>, dim3(a.only_knot >= 0 ? 1 : L.N + 1, L.B, 1), dim3(64), 0, s->stream, a, s->L, s->d_knots, 0);
     else hipLaunchKernelGGL(k_eval_vector<1>, dim3(L.N + 1, L.B, ncand), dim3(64), 0, s->stream, a, s->LT, s->d_tknots, cand0);
   } else {
     launch_eval_multibody(s->stream, a, s->LT, (trial && !with_derivs) ? s->d_tknots : s->d_knots, s->d_mbwork, s->mb_work_stride, trial, cand0, ncand, 0, 0.0, with_derivs, nullptr, s->contact_dyn);
@@ -762,8 +763,8 @@ static void report_status(mpc_solver* s, int B, const InstState* st, mpc_stats* 
 // Enqueued after k_begin_run (the stage kernel skips instances that are `done`) and before the first pass, which evaluates knots N - 1
 // and N afresh (begin_refine marked their slots dirty before the knot mask of the pass was taken).
 static void begin_refine(mpc_solver* s) {
-  s->refine_now = s->opt.refine_appended_knot > 0 && s->appended_changed && s->L.N >= 1;
-  s->appended_changed = false;
+  s->refine_now = s->L.N >= 1 && ((s->opt.refine_appended_knot > 0 && s->appended_changed) || (s->opt.refine_appended_knot < 0 && s->appended_any));
+  s->appended_changed = false; s->appended_any = false;
   if (s->refine_now) { s->slot_dirty[slot_of(s, s->L.N - 1)] = 1; s->slot_dirty[s->L.N] = 1; }
 }
 static void launch_refine(mpc_solver* s) {
@@ -773,10 +774,11 @@ static void launch_refine(mpc_solver* s) {
   const bool reuse_keep = s->reuse_this_pass;
   s->reuse_this_pass = false;  // (plain evaluation of the one knot: no record is taken over)
   s->only_knot = L.N - 1;
-  for (int it = 0; it <= s->opt.refine_appended_knot; ++it) {
+  const int R = s->opt.refine_appended_knot < 0 ? -s->opt.refine_appended_knot : s->opt.refine_appended_knot;
+  for (int it = 0; it <= R; ++it) {
     s->timed(18, "k_refine_appended_knot", [&] {
-      launch_eval(s, false);
-      hipLaunchKernelGGL(k_refine_knot, dim3(L.B), dim3(256), 0, s->stream, s->args(), it < s->opt.refine_appended_knot ? 0 : 1);
+      launch_eval(s, false);  // (only_knot: a grid of one knot per instance)
+      hipLaunchKernelGGL(k_refine_knot, dim3(L.B), dim3(256), 0, s->stream, s->args(), it < R ? 0 : 1);
     });
   }
   s->only_knot = -1;
@@ -1013,6 +1015,7 @@ int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* 
       s->cycles_since_run += 1;
       // refine_appended_knot: another dynamics kind / contact list than the stage before it (descriptor words 0 .. 3)
       s->appended_changed = n_desc >= 4 && s->h_len[2 * last] >= 4 && std::memcmp(hd, desc, 4 * sizeof(int32_t)) != 0;
+      s->appended_any = true;
       // (a last stage whose parameters were patched after the speculative evaluation: the spare record is stale)
       s->spec_next_pending = same && s->spec_rec_valid && s->cycles_since_run == 1 && !s->slot_dirty[last] && !s->dirty_all;
     }
@@ -1280,7 +1283,7 @@ int mpc_setup(mpc_solver* s) {
 
 int mpc_run(mpc_solver* s, const double* xs, const double* us, mpc_stats* stats) {
   MPC_TRY(s, {
-    s->appended_changed = false; s->refine_now = false;  // (an uploaded warm start is the caller's: it stays as it is)
+    s->appended_changed = false; s->appended_any = false; s->refine_now = false;  // (an uploaded warm start is the caller's: it stays as it is)
     spec_clear(s);
     s->reuse_this_pass = false;
     // A multi-iteration solve starts from an iterate the handle has never seen (cold start): the cut Hessians kept from the last pass
@@ -1552,6 +1555,12 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
       else if (nm == "zc") dev_vec(lr + L.lzc, n); else if (nm == "calP") dev_vec(lr + L.ldP, n * n);  // what the consensus worked on (the oracle's "calP")
       else if (nm == "calp") dev_vec(lr + L.lcp, n);
       else dev_vec(lr + L.lth, n);
+    }
+    else if (nm == "ls_knot") {  // knot k of the last pass: merit of every linesearch candidate alpha_i = 2^-i at this knot, then the knot's cost and penalty at the current point (developer probes)
+      std::vector<double> tp((size_t)L.n_alpha * (L.N + 1));
+      copy_sync(s, tp.data(), s->d_trial_phi + (size_t)b * L.n_alpha * (L.N + 1), tp.size() * sizeof(double), hipMemcpyDeviceToHost);
+      for (int i = 0; i < L.n_alpha; ++i) v.push_back(tp[(size_t)i * (L.N + 1) + k]);
+      v.push_back(kn[L.oMISC + MISC_COST]); v.push_back(kn[L.oMISC + MISC_PEN]);
     }
     else if (nm == "fixed_dims") v = {(double)s->ric_fixed};  // which fixed-dimension instantiations serve this handle (0: the generic kernels)
     else if (nm == "ric_prof") { dev_vec(s->d_prof + (size_t)b * 64, 64); HIP_OK(hipMemsetAsync(s->d_prof + (size_t)b * 64, 0, 64 * sizeof(double), s->stream)); HIP_OK(hipStreamSynchronize(s->stream)); }

@@ -14,6 +14,7 @@ struct mpc_solver {
   std::string err;
   bool perfect_feedback = false;
   bool appended_changed = false;  // the stage of the last mpc_cycle has another contact pattern than its predecessor (refine_appended_knot)
+  bool appended_any = false;      // a stage was appended since the last run (refine_appended_knot < 0: refine after every cycle)
   bool isolate = false;        // mpc_set_failure_policy
   std::vector<int> failed;     // per instance: 0 or the failure code reported as mpc_stats.converged = -code
 };
@@ -123,6 +124,7 @@ int mpc_cycle(mpc_solver* h, const int32_t* desc, int32_t n_desc, const double* 
     // (refine_appended_knot: does the appended stage differ in its contact pattern — dynamics kind, contact list — from the one before it?)
     const StageDesc& last = h->s.stages[N - 1];
     h->appended_changed = sd.dyn != last.dyn || sd.ncontact != last.ncontact || sd.cid[0] != last.cid[0] || sd.cid[1] != last.cid[1];
+    h->appended_any = true;
     for (int k = 0; k + 1 < N; ++k) h->s.stages[k] = std::move(h->s.stages[k + 1]);
     h->s.stages[N - 1] = std::move(sd);
     for (auto& ip : h->s.inst_params) {  // the appended stage starts from the shared table in every instance
@@ -201,7 +203,7 @@ static void run_all(mpc_solver* h, mpc_stats* stats) {
 
 int mpc_run(mpc_solver* h, const double* xs, const double* us, mpc_stats* stats) {
   MPC_TRY(h, {
-    h->appended_changed = false;  // (an uploaded warm start is the caller's: it stays as it is)
+    h->appended_changed = false; h->appended_any = false;  // (an uploaded warm start is the caller's: it stays as it is)
     Solver& s = h->s;
     const int N = s.N(), nx = s.dims.nx, nu = s.dims.nu;
     for (int b = 0; b < s.dims.batch; ++b) {
@@ -223,9 +225,10 @@ int mpc_run_shifted(mpc_solver* h, mpc_stats* stats) {
       for (int k = 0; k + 1 < N; ++k) in.us[k] = in.us[k + 1];
       if (h->perfect_feedback) in.x0 = in.xs[0];  // predicted next state becomes the measurement
       in.xs[0] = in.x0;
-      if (s.opt.refine_appended_knot > 0 && h->appended_changed && in.stats.converged >= 0) s.refine_appended_knot(in);
+      // (R > 0: when the appended stage changed its contact pattern ; R < 0: after every cycle, |R| steps)
+      if (((s.opt.refine_appended_knot > 0 && h->appended_changed) || (s.opt.refine_appended_knot < 0 && h->appended_any)) && in.stats.converged >= 0) s.refine_appended_knot(in);
     }
-    h->appended_changed = false;
+    h->appended_changed = false; h->appended_any = false;
     run_all(h, stats);
   })
 }

@@ -1030,7 +1030,8 @@ struct Solver {
     const int b_inst = (int)(&in - inst.data());
     if (N < 1 || in.mu <= 0.0) return;
     Knot kn;
-    for (int it = 0; it < opt.refine_appended_knot; ++it) {
+    const int R = opt.refine_appended_knot < 0 ? -opt.refine_appended_knot : opt.refine_appended_knot;
+    for (int it = 0; it < R; ++it) {
       eval_knot(b_inst, N - 1, in.xs[N - 1].data(), in.us[N - 1].data(), in.xs[N].data(), kn, true);
       const int m = kn.m, nz = n + m;
       if (m <= 0) return;

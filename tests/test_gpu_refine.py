@@ -49,6 +49,42 @@ def test_refined_appended_knot_matches_oracle(hip_lib, oracle_lib):
     print("refine_appended_knot: worst deviation %.3e ; primal infeasibility before the step on the pattern-change ticks: %s" % (worst, refined))
 
 
+@pytest.mark.parametrize("problem", ["kinodynamic"])
+def test_refinement_after_every_cycle_matches_oracle(hip_lib, oracle_lib, problem):
+    """refine_appended_knot < 0: |R| Newton steps on the control of the appended knot after EVERY mpc_cycle (the setting under which the
+    kinodynamic walk takes a full step on every tick: profiles/r04_kino_tick.txt; not meant for the whole-body OCP, include/mpc_abi.h).
+    HIP against the oracle, tick by tick from the oracle's solver state; the one-knot launch of the stage kernel (a grid of one knot per
+    instance) is what evaluates the knot."""
+    from mpc_benchmark_amd.problems.kinodynamic import KinodynamicProblem
+
+    def handle(lib):
+        if problem == "fulldynamic":
+            e = EnsembleMPC(FullDynamicsProblem(horizon=30), batch=2, library=lib, seed=3, sigma_q=0.004, sigma_v=0.01)
+        else:
+            kp = KinodynamicProblem(horizon=40)
+            e = EnsembleMPC(kp, batch=2, library=lib, seed=3, perturb_dofs=range(18, kp.nv))
+        e.options.num_threads = os.cpu_count() or 8
+        e.options.riccati_legs = 1
+        e.options.refine_appended_knot = -2
+        e.native.set_options(e.options)
+        e.prepare_schedule(40)
+        return e
+
+    er, eh = handle(oracle_lib), handle(hip_lib)
+    er.cold_solve(max_iters=100)
+    eh.cold_solve(max_iters=100)
+    worst = 0.0
+    for t in range(34):
+        eh.native.set_state(er.native.get_state())
+        sr, sh = er.step(), eh.step()
+        a, b = eh.results(gains=True), er.results(gains=True)
+        e = max(rel_cols(a["xs"], b["xs"], 1e-3), rel_cols(a["us"], b["us"], 1.0), rel_cols(a["K"][:, 0], b["K"][:, 0], 1.0))
+        assert [s.alpha for s in sh] == [s.alpha for s in sr], (t, [s.alpha for s in sh], [s.alpha for s in sr])
+        assert e < 1e-6, "tick %d: deviates from the oracle by %.3e" % (t, e)
+        worst = max(worst, e)
+    print("refine_appended_knot = -2 (%s): worst deviation %.3e over 34 ticks" % (problem, worst))
+
+
 @pytest.mark.parametrize("refs", ["frozen", "shared", "instance"])
 def test_whole_schedule_walk_with_one_iteration_per_tick(hip_lib, refs):
     """The benchmarked ensemble (64 randomised instances, N = 100, complete model, 4 legs, tick reuse, two ticks in flight) over the

@@ -2,7 +2,7 @@
 reuse) — p50 / p90, how many ticks take more than one pass (a BCL update without a step, then the step), per-kernel time.
 The walk of the script (0.3 m steps, kinodynamic_talos.py:257) with 0.10 m gained per step, references replanned every tick
 (EnsembleMPC.enable_walk); STAIRS=0: flat ground, WALK=0: frozen references (the round-3 form of this measurement), PERINST=1:
-every instance plans from its own foot poses, REFINE=R: mpc_options.refine_appended_knot.  START=n: n untimed ticks first (120: the first swing is at knot 0)."""
+every instance plans from its own foot poses, REFINE=R: mpc_options.refine_appended_knot (negative: after every cycle).  START=n: n untimed ticks first (120: the first swing is at knot 0)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

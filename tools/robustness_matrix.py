@@ -10,7 +10,7 @@ from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
 lib = _capi.load_hip_library()
 ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 999
 for refs in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("frozen", "shared", "instance")):
-    for R in (0, 3):
+    for R in [int(v) for v in os.environ.get("REFINES", "0,3").split(",")]:
         pd = FullDynamicsProblem(horizon=100, complete_model=True)
         (e,) = make_bench_shards(pd, lib, 64, legs=4, tick_reuse=True)
         e.options.refine_appended_knot = R
