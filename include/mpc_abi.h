@@ -148,7 +148,9 @@ typedef struct mpc_options {
                             * the appended stage differ from those of the stage before it as a rule (force references ramp before a
                             * take-off), the duplicated control leaves the appended knot's own active set, and the full step of the tick
                             * then violates rows the Newton system did not know — the kinodynamic walk spends five consecutive ticks
-                            * backtracking on that (alpha = 1/2 ... 1/128), and none with R = -1.  NOT for the whole-body OCP: there the
+                            * backtracking on that (alpha = 1/2 ... 1/128), and none with R = -1.  EXPERIMENTAL: later in the schedule it makes
+                            * most ticks backtrack, and on flat ground it loses instances the plain warm start keeps.
+                            * NOT for the whole-body OCP: there the
                             * refinement problem of a knot whose duplicated control is already feasible is ill-conditioned (dependent cone
                             * rows; the nominal instance is lost within 30 ticks) — use R > 0.  Not
                             * something Aligator does: a choice of initial guess, off unless asked for. */
