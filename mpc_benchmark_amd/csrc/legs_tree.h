@@ -114,6 +114,29 @@ DEV void tree_k0_step(const SolverArgs& a, const LxLds& S, const TreeDesc& T, in
     }
   }
 }
+#ifndef MPC_TREE_GROWTH
+#define MPC_TREE_GROWTH 1e6  // bound on the multipliers of the blocked elimination of k_leg_compose (beyond it: the pivoted Gauss-Jordan)
+#endif
+// 4 x 4 inverse by cofactors (every lane the same 16 values: the result is wave-uniform).  ok: the determinant is a finite non-zero number (the
+// caller bounds the multipliers the block would produce).
+DEV void inv4_cofactor(const double (&m)[16], double (&o)[16], bool& ok) {
+  const double s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
+  const double s3 = m[1] * m[6] - m[5] * m[2], s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
+  const double c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
+  const double c2 = m[8] * m[15] - m[12] * m[11], c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
+  const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
+  ok = isfinite(det) && det != 0.0;
+  const double id = 1.0 / det;
+  o[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;   o[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
+  o[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id; o[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
+  o[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;  o[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
+  o[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id; o[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
+  o[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;   o[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
+  o[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id; o[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
+  o[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id; o[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
+  o[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id; o[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
+}
+
 // condensed form of a node; Lm == nullptr: the node holds the last leg (no end parameter: Lm = Sg = 0, sg = 0)
 struct NodeRef { const double *P, *p, *Lm, *Sg, *sg; };
 DEV NodeRef tree_node_ref(const SolverArgs& a, const TreeDesc& T, int b, int node) {
@@ -231,10 +254,139 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
   LEG_LAUNDER();
   if (role == 0) leg_load_mat<true>(Y, ldp, np, A.Lm, n, tid, nthr, S.mg_np);  // Y <- Lm_a^T
   LEG_BARRIER();
+  // ---- Elimination on the matrix cores first (round 4): Gauss-Jordan on [Mt | R] by PANELS OF FOUR COLUMNS with the pivots on the diagonal.
+  // The tableau lives in accumulator registers as 16 x 16 tiles, a wavefront owns whole column tiles (<= 2: 5 tiles each), so the pivot rows
+  // of a column tile and its update are in ONE wavefront: per panel the owner of the pivot column tile publishes the panel's four columns
+  // (np x 4) and the inverse of its 4 x 4 pivot block through LDS, then every column tile gets  U = Pinv * (its pivot rows)  (one MFMA, the
+  // result lands in the lanes that supply it as the B operand next) and  T -= Panel * U  (one MFMA per tile), the pivot rows become U.
+  // 19 panels of ~2 500 cycles against 38 two-column steps of ~4 600 of the pivoted form below (74 us per level, profiles/r04_legs_phase_timers.txt).
+  // Pivots are NOT searched for outside the 4 x 4 block: a block that is not well conditioned (inv4_cofactor) abandons the attempt — nothing
+  // has been written, Mt / R / rv are as they were — and the pivoted form below does the job.  (rv rides in column n of R: needs n < np.)
+  bool eliminated = false;
+  if ((n & 3) == 0 && n < np && !a.tree_pivoted) {
+    constexpr int NBT = NP / 16, SL = (2 * NBT + NWC - 1) / NWC;  // row tiles ; column tiles per wavefront
+    double* panel = vec + 5 * np;            // [np][4]
+    double* ppS = panel + 4 * np;            // [16] pivot block, then [16] its inverse
+    int* failS = (int*)(ppS + 32);
+    const double* Rsrc = role == 0 ? Y : X;
+    const int g = lane >> 4, c = lane & 15;
+    d4_t col[SL][NBT];
+    int ct[SL];
+#pragma unroll
+    for (int sl = 0; sl < SL; ++sl) {
+      ct[sl] = (wv + nb) % NWC + sl * NWC;
+      if (sl == 0 && ct[sl] >= 2 * nb) ct[sl] = -1;
+      if (sl > 0 && ct[sl] >= 2 * nb) ct[sl] = -1;
+#pragma unroll
+      for (int ri = 0; ri < NBT; ++ri) {
+        col[sl][ri] = d4_t{0, 0, 0, 0};
+        if (ct[sl] >= 0 && ri < nb) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = ri * 16 + g + 4 * r;
+            double v;
+            if (ct[sl] < nb) v = Z[row * ldp + ct[sl] * 16 + c];
+            else { const int cc = (ct[sl] - nb) * 16 + c; v = (role == 0 && cc == n) ? rv[row] : Rsrc[row * ldp + cc]; }
+            col[sl][ri][r] = v;
+          }
+        }
+      }
+    }
+    if (tid == 0) *failS = 0;
+    LEG_BARRIER();
+    bool fail = false;
+    for (int j0 = 0; j0 < n; j0 += 4) {
+      const int rt = j0 >> 4, q = (j0 & 15) >> 2;
+      const int own = (rt + NWC - nb % NWC) % NWC;  // the wavefront whose first slot is column tile rt: (own + nb) % NWC == rt
+      if (wv == own) {
+        // (column tile rt is slot 0 of this wavefront: ct[0] == rt)
+        if ((c >> 2) == q) {
+#pragma unroll
+          for (int ri = 0; ri < NBT; ++ri)
+            if (ri < nb) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) panel[(ri * 16 + g + 4 * r) * 4 + (c & 3)] = col[0][ri][r];
+            }
+          // the pivot block: rows j0 + g (register q of tile (rt, rt)), columns j0 + (c & 3)
+          double pv = 0.0;
+#pragma unroll
+          for (int ri = 0; ri < NBT; ++ri) if (ri == rt) pv = col[0][ri][q];
+          ppS[g * 4 + (c & 3)] = pv;
+        }
+        double pmax = 0.0;  // largest entry of the panel: with the largest entry of the inverse of the pivot block it bounds the multipliers
+        if ((c >> 2) == q) {
+#pragma unroll
+          for (int ri = 0; ri < NBT; ++ri)
+            if (ri < nb) pmax = fmax(pmax, fmax(fmax(fabs(col[0][ri][0]), fabs(col[0][ri][1])), fmax(fabs(col[0][ri][2]), fabs(col[0][ri][3]))));
+        }
+        pmax = wave_max_nonneg(pmax);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wavefront's own LDS writes
+        __builtin_amdgcn_wave_barrier();
+        double pm[16], pi[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pm[i] = ppS[i];
+        bool ok;
+        inv4_cofactor(pm, pi, ok);
+        double imax = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) imax = fmax(imax, fabs(pi[i]));
+        // no pivot is looked for outside the 4 x 4 block: allowed while the multipliers Panel * Pinv stay below MPC_TREE_GROWTH (partial pivoting keeps
+        // them below 1; six digits of the sixteen are what the bound gives away)
+        ok = ok && isfinite(imax) && imax * pmax < MPC_TREE_GROWTH;
+        if (lane < 16) ppS[16 + lane] = pi[lane];
+        if (!ok && lane == 0) *failS = 1;
+      }
+      LEG_BARRIER();
+      if (*failS) { fail = true; break; }
+      const double aop = (c < 4) ? ppS[16 + c * 4 + g] : 0.0;  // A operand of U = Pinv * rows: A(i, k) = Pinv[i][k], i < 4
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) {
+        if (ct[sl] < 0 || (ct[sl] < nb && ct[sl] < rt)) continue;  // no such tile / a column tile of Mt that is already eliminated
+        double prow = 0.0;
+#pragma unroll
+        for (int ri = 0; ri < NBT; ++ri) if (ri == rt) prow = col[sl][ri][q];
+        d4_t u = d4_t{0, 0, 0, 0};
+        u = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, prow, u, 0, 0, 0);
+        const double ub = u[0];  // U[g][column c of the tile]
+#pragma unroll
+        for (int ri = 0; ri < NBT; ++ri) {
+          if (ri < nb) {
+            double av = panel[(ri * 16 + c) * 4 + g];  // A(i = c, k = g) = Panel[row ri * 16 + i][k]
+            if (ri == rt && (c >> 2) == q) av = 0.0;      // the pivot rows are not eliminated from themselves
+            col[sl][ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, ub, col[sl][ri], 0, 0, 0);
+            if (ri == rt) col[sl][ri][q] = ub;
+          }
+        }
+      }
+      LEG_BARRIER();  // the panel buffer is rewritten by the next owner
+    }
+    if (a.prof && tid == 0) atomicAdd(&a.prof[(size_t)b * 64 + (fail ? 30 : 29)], 1.0);  // developer counters (mpc_profile(3)): compositions that took the blocked elimination / fell back to the pivoted one
+    if (!fail) {
+      eliminated = true;
+      double* Rw = role == 0 ? Y : X;
+#pragma unroll
+      for (int sl = 0; sl < SL; ++sl) {
+        if (ct[sl] < nb) continue;
+#pragma unroll
+        for (int ri = 0; ri < NBT; ++ri) {
+          if (ri < nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = ri * 16 + g + 4 * r, cc = (ct[sl] - nb) * 16 + c;
+              const double v = col[sl][ri][r];
+              if (role == 0 && cc == n) { rv[row] = (row < n) ? v : 0.0; Rw[row * ldp + cc] = 0.0; }
+              else Rw[row * ldp + cc] = (row < n && cc < n) ? v : 0.0;
+            }
+          }
+        }
+      }
+      LEG_BARRIER();
+    }
+  }
   // ---- Gauss-Jordan on [Mt | R | rv] (n rows, 2 n + 1 columns; role 0: R = Lm_a^T in Y, role 1: R = Sg_a in X, no rv), tableau in
   // registers: as in k_leg_consensus (a lane is a row, a wavefront owns every 8th column, the owner of the pivot column leaves the
   // elimination factors in LDS, one barrier per column) ----
-  {
+  if (!eliminated) {
     // (TWO columns per barrier: a wavefront owns the column pairs (2 (NWC t + wv), + 1) ; the owner of the pivot pair eliminates its first
     // column from its second one in registers, picks the second pivot from that, and leaves both factor columns in LDS — the other
     // wavefronts apply the two eliminations one after the other.  Same pivots, same operations in the same order as one column per

@@ -196,6 +196,7 @@ struct mpc_solver {
     a.spec_knot = a.spec_on ? d_spec_knot : nullptr; a.spec_next = (a.reuse_on && spec_next_now) ? 1 : 0;
     for (int w = 0; w < MPC_DIRTY_WORDS; ++w) a.dirty[w] = a.reuse_on ? dirty_now[w] : 0ull;
     a.only_knot = only_knot;
+    a.tree_pivoted = getenv("MPC_HIP_TREE_PIVOTED") ? 1 : 0;
     a.nlegs = eff_legs(); a.leg_cap = leg_cap; a.legbuf = d_legbuf; a.treebuf = d_treebuf; a.leg_guess = leg_guess_now;
     a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = phase_timers ? d_prof : nullptr;
     return a;
