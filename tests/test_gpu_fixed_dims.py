@@ -51,3 +51,39 @@ def test_fixed_dimension_kernels_equal_the_generic_ones(hip_lib, name, complete,
     for k in fixed:
         scale = np.maximum(1.0, np.abs(gen[k]))
         assert np.max(np.abs(fixed[k] - gen[k]) / scale) < 1e-9, k
+
+
+@pytest.mark.parametrize("name,legs", [("fulldynamic", 32), ("fulldynamic", 4), ("kinodynamic", 8)])
+def test_blocked_tree_elimination_equals_the_pivoted_one(hip_lib, name, legs):
+    """k_leg_compose eliminates on the matrix cores by panels of four columns with the pivots on the diagonal (bounded multipliers, the pivoted
+    Gauss-Jordan as fallback: DESIGN.md section 4); ``MPC_HIP_TREE_PIVOTED=1`` (read at every launch) keeps the pivoted form.  Same linear systems:
+    the iterates agree to round-off over a cold solve and MPC ticks."""
+    def run(pivoted):
+        if pivoted:
+            os.environ["MPC_HIP_TREE_PIVOTED"] = "1"
+        else:
+            os.environ.pop("MPC_HIP_TREE_PIVOTED", None)
+        try:
+            if name == "fulldynamic":
+                e = EnsembleMPC(FullDynamicsProblem(horizon=96, complete_model=True), batch=2, library=hip_lib, seed=11)
+            else:
+                kp = KinodynamicProblem(horizon=64, complete_model=True)
+                e = EnsembleMPC(kp, batch=2, library=hip_lib, seed=11, perturb_dofs=range(18, kp.nv))
+            e.options.riccati_legs = legs
+            e.native.set_options(e.options)
+            e.prepare_schedule(16)
+            st = e.cold_solve(max_iters=100)
+            for _ in range(10):
+                e.step()
+            r = e.results(gains=True)
+            return [s.num_iters for s in st], {k: np.array(r[k]) for k in ("xs", "us", "K")}
+        finally:
+            os.environ.pop("MPC_HIP_TREE_PIVOTED", None)
+
+    it_b, blocked = run(False)
+    it_p, pivoted = run(True)
+    assert it_b == it_p
+    for k in blocked:
+        scale = np.maximum(1.0, np.abs(pivoted[k]))
+        err = float(np.max(np.abs(blocked[k] - pivoted[k]) / scale))
+        assert err < 1e-6, (k, err)  # (BASELINE.json's tolerance, entry by entry, after a cold solve and ten ticks of two different eliminations)

@@ -8,7 +8,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 step() { echo "== $*" >&2; "$@"; rc=$?; if [ $rc -ne 0 ]; then echo "FAILED (rc $rc): $*" >&2; exit $rc; fi; }
-BENCH_ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-latency --no-walk"  # (frozen references: every candidate launch is the <3> kernel)
+BENCH_ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-latency --no-walk --cold-iters 100"  # (frozen references: every candidate launch is the <3> kernel; the scripts' 100 cold iterations: the tail of a longer cold solve runs with a handful of active instances and would pull the per-kernel averages down)
 step rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o st -- python3 bench.py $BENCH_ARGS > $OUT/bench_under_rocprof.log 2>&1
 TRACE=$(find $OUT/stats -name '*kernel_trace.csv' | head -1)
 [ -n "$TRACE" ] || { echo "no kernel trace" >&2; exit 1; }
