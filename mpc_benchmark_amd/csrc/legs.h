@@ -484,7 +484,7 @@ static inline constexpr LxLds make_lx_lds(int n, int m) {
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
   s.PC = take(s.np * s.ldp); s.MA = take(s.np * s.ldp); s.RB = take(s.np * s.ldp);
-  s.vec = take(8 * s.np + 16 + 112);  // (+ 112: with the free tail of the vectors, the panel / pivot-block scratch of the blocked elimination of k_leg_compose)
+  s.vec = take(8 * s.np + 16 + 128);  // (+ 112: with the free tail of the vectors, the panel / pivot-block scratch of the blocked elimination of k_leg_compose)
   s.iw = o;
   s.total_bytes = o * 8 + (2 * s.np + 8) * 4;
   return s;

@@ -117,26 +117,6 @@ DEV void tree_k0_step(const SolverArgs& a, const LxLds& S, const TreeDesc& T, in
 #ifndef MPC_TREE_GROWTH
 #define MPC_TREE_GROWTH 1e6  // bound on the multipliers of the blocked elimination of k_leg_compose (beyond it: the pivoted Gauss-Jordan)
 #endif
-// 4 x 4 inverse by cofactors (every lane the same 16 values: the result is wave-uniform).  ok: the determinant is a finite non-zero number (the
-// caller bounds the multipliers the block would produce).
-DEV void inv4_cofactor(const double (&m)[16], double (&o)[16], bool& ok) {
-  const double s0 = m[0] * m[5] - m[4] * m[1], s1 = m[0] * m[6] - m[4] * m[2], s2 = m[0] * m[7] - m[4] * m[3];
-  const double s3 = m[1] * m[6] - m[5] * m[2], s4 = m[1] * m[7] - m[5] * m[3], s5 = m[2] * m[7] - m[6] * m[3];
-  const double c5 = m[10] * m[15] - m[14] * m[11], c4 = m[9] * m[15] - m[13] * m[11], c3 = m[9] * m[14] - m[13] * m[10];
-  const double c2 = m[8] * m[15] - m[12] * m[11], c1 = m[8] * m[14] - m[12] * m[10], c0 = m[8] * m[13] - m[12] * m[9];
-  const double det = s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0;
-  ok = isfinite(det) && det != 0.0;
-  const double id = 1.0 / det;
-  o[0] = (m[5] * c5 - m[6] * c4 + m[7] * c3) * id;   o[1] = (-m[1] * c5 + m[2] * c4 - m[3] * c3) * id;
-  o[2] = (m[13] * s5 - m[14] * s4 + m[15] * s3) * id; o[3] = (-m[9] * s5 + m[10] * s4 - m[11] * s3) * id;
-  o[4] = (-m[4] * c5 + m[6] * c2 - m[7] * c1) * id;  o[5] = (m[0] * c5 - m[2] * c2 + m[3] * c1) * id;
-  o[6] = (-m[12] * s5 + m[14] * s2 - m[15] * s1) * id; o[7] = (m[8] * s5 - m[10] * s2 + m[11] * s1) * id;
-  o[8] = (m[4] * c4 - m[5] * c2 + m[7] * c0) * id;   o[9] = (-m[0] * c4 + m[1] * c2 - m[3] * c0) * id;
-  o[10] = (m[12] * s4 - m[13] * s2 + m[15] * s0) * id; o[11] = (-m[8] * s4 + m[9] * s2 - m[11] * s0) * id;
-  o[12] = (-m[4] * c3 + m[5] * c1 - m[6] * c0) * id; o[13] = (m[0] * c3 - m[1] * c1 + m[2] * c0) * id;
-  o[14] = (-m[12] * s3 + m[13] * s1 - m[14] * s0) * id; o[15] = (m[8] * s3 - m[9] * s1 + m[10] * s0) * id;
-}
-
 // condensed form of a node; Lm == nullptr: the node holds the last leg (no end parameter: Lm = Sg = 0, sg = 0)
 struct NodeRef { const double *P, *p, *Lm, *Sg, *sg; };
 DEV NodeRef tree_node_ref(const SolverArgs& a, const TreeDesc& T, int b, int node) {
@@ -260,14 +240,14 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
   // (np x 4) and the inverse of its 4 x 4 pivot block through LDS, then every column tile gets  U = Pinv * (its pivot rows)  (one MFMA, the
   // result lands in the lanes that supply it as the B operand next) and  T -= Panel * U  (one MFMA per tile), the pivot rows become U.
   // 19 panels of ~2 500 cycles against 38 two-column steps of ~4 600 of the pivoted form below (74 us per level, profiles/r04_legs_phase_timers.txt).
-  // Pivots are NOT searched for outside the 4 x 4 block: a block that is not well conditioned (inv4_cofactor) abandons the attempt — nothing
+  // Pivots are NOT searched for outside the 4 x 4 block: a block whose multipliers pass MPC_TREE_GROWTH abandons the attempt — nothing
   // has been written, Mt / R / rv are as they were — and the pivoted form below does the job.  (rv rides in column n of R: needs n < np.)
   bool eliminated = false;
   if ((n & 3) == 0 && n < np && !a.tree_pivoted) {
     constexpr int NBT = NP / 16, SL = (2 * NBT + NWC - 1) / NWC;  // row tiles ; column tiles per wavefront
     double* panel = vec + 5 * np;            // [np][4]
-    double* ppS = panel + 4 * np;            // [16] pivot block, then [16] its inverse
-    int* failS = (int*)(ppS + 32);
+    double* ppS = panel + 4 * np;            // [16] pivot block, [16] its inverse, [4] the terms of its determinant
+    int* failS = (int*)(ppS + 36);
     const double* Rsrc = role == 0 ? Y : X;
     const int g = lane >> 4, c = lane & 15;
     d4_t col[SL][NBT];
@@ -322,18 +302,27 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
         pmax = wave_max_nonneg(pmax);
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wavefront's own LDS writes
         __builtin_amdgcn_wave_barrier();
-        double pm[16], pi[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) pm[i] = ppS[i];
-        bool ok;
-        inv4_cofactor(pm, pi, ok);
-        double imax = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) imax = fmax(imax, fabs(pi[i]));
+        // inverse of the 4 x 4 pivot block, a lane per entry: lane 4 j + i forms the cofactor of element (j, i) — the 3 x 3 minor without row j
+        // and column i — which over the determinant is entry (i, j) of the inverse; the determinant is the expansion along row 0 (lanes 0 .. 3)
+        const int ii = lane & 3, jj = (lane >> 2) & 3;
+        const int r0 = jj == 0 ? 1 : 0, r1 = jj <= 1 ? 2 : 1, r2 = jj <= 2 ? 3 : 2;
+        const int c0 = ii == 0 ? 1 : 0, c1 = ii <= 1 ? 2 : 1, c2 = ii <= 2 ? 3 : 2;
+        const double a00 = ppS[r0 * 4 + c0], a01 = ppS[r0 * 4 + c1], a02 = ppS[r0 * 4 + c2];
+        const double a10 = ppS[r1 * 4 + c0], a11 = ppS[r1 * 4 + c1], a12 = ppS[r1 * 4 + c2];
+        const double a20 = ppS[r2 * 4 + c0], a21 = ppS[r2 * 4 + c1], a22 = ppS[r2 * 4 + c2];
+        const double pji = ppS[jj * 4 + ii];
+        const double minor = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+        const double cof = ((ii + jj) & 1) ? -minor : minor;
+        if (lane < 4) ppS[32 + lane] = pji * cof;  // (row 0: lanes 0 .. 3)
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const double det = (ppS[32] + ppS[33]) + (ppS[34] + ppS[35]);
+        const double pinv = cof / det;
+        const double imax = wave_max_nonneg(lane < 16 ? fabs(pinv) : 0.0);
         // no pivot is looked for outside the 4 x 4 block: allowed while the multipliers Panel * Pinv stay below MPC_TREE_GROWTH (partial pivoting keeps
         // them below 1; six digits of the sixteen are what the bound gives away)
-        ok = ok && isfinite(imax) && imax * pmax < MPC_TREE_GROWTH;
-        if (lane < 16) ppS[16 + lane] = pi[lane];
+        const bool ok = isfinite(det) && det != 0.0 && isfinite(imax) && imax * pmax < MPC_TREE_GROWTH;
+        if (lane < 16) ppS[16 + ii * 4 + jj] = pinv;
         if (!ok && lane == 0) *failS = 1;
       }
       LEG_BARRIER();
