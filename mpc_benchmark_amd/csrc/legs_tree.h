@@ -179,6 +179,9 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
     return;
   }
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  // developer phase timers (mpc_profile(3)): role 0 of the first composition of level 0, instance 0 -> slots 24 .. 28 of its counter block
+  long long tc0_ = clock64();
+#define LCMP_PROF(slot) do { if (a.prof && b == 0 && level == 0 && blockIdx.x == 0 && role == 0 && tid == 0) { const long long t1_ = clock64(); a.prof[(slot)] += (double)(t1_ - tc0_); tc0_ = t1_; } } while (0)
   double *X = sm + S.PC, *Y = sm + S.MA, *Z = sm + S.RB, *vec = sm + S.vec;
   double *pb = vec, *rv = vec + np, *uu = vec + 2 * np, *fcol = vec + 4 * np;  // p_b | right-hand side / t3 | u | 1 / pivots
   int* perm = (int*)(sm + S.iw);
@@ -208,6 +211,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
   }
   for (int i = tid; i < np; i += nthr) pb[i] = (i < n) ? Bn.p[i] : 0.0;
   LEG_BARRIER();
+  LCMP_PROF(24);
   // ---- rv = Sg_a p_b + sg_a ; Mt = I - Sg_a D (to registers, then into Z) ----
   for (int i = wv; i < np; i += nw) {
     double s = 0;
@@ -215,25 +219,29 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
     s = wave_sum(s);
     if (lane == 0) rv[i] = (i < n) ? s + A.sg[i] : 0.0;
   }
+  auto build_mt = [&]() {  // Z <- I - Sg_a D  (Sg_a in X, D in Y)
 #pragma unroll
-  for (int sidx = 0; sidx < LCT; ++sidx) {
-    const int t = wv + sidx * nw;
-    res[sidx] = d4_t{0, 0, 0, 0};
-    if (t < nb * nb) mma_tile<true>(res[sidx], X + ((t / nb) * 16) * ldp, ldp, 1, Y + (t % nb) * 16, ldp, 1, np, lane);
-  }
-#pragma unroll
-  for (int sidx = 0; sidx < LCT; ++sidx) {
-    const int t = wv + sidx * nw;
-    if (t < nb * nb) {
-      const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; Z[row * ldp + col] = res[sidx][q] + (row == col ? 1.0 : 0.0); }  // pad rows: identity
+    for (int sidx = 0; sidx < LCT; ++sidx) {
+      const int t = wv + sidx * nw;
+      res[sidx] = d4_t{0, 0, 0, 0};
+      if (t < nb * nb) mma_tile<true>(res[sidx], X + ((t / nb) * 16) * ldp, ldp, 1, Y + (t % nb) * 16, ldp, 1, np, lane);
     }
-  }
+#pragma unroll
+    for (int sidx = 0; sidx < LCT; ++sidx) {
+      const int t = wv + sidx * nw;
+      if (t < nb * nb) {
+        const int ri = t / nb, cj = t % nb, col = cj * 16 + (lane & 15);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int row = ri * 16 + (lane >> 4) + 4 * q; Z[row * ldp + col] = res[sidx][q] + (row == col ? 1.0 : 0.0); }  // pad rows: identity
+      }
+    }
+  };
+  build_mt();
   LEG_BARRIER();  // role 0: D in Y is dead (it reads D back from the leg record later) ; role 1 keeps D in Y
   LEG_LAUNDER();
   if (role == 0) leg_load_mat<true>(Y, ldp, np, A.Lm, n, tid, nthr, S.mg_np);  // Y <- Lm_a^T
   LEG_BARRIER();
+  LCMP_PROF(25);
   // ---- Elimination on the matrix cores first (round 4): Gauss-Jordan on [Mt | R] by PANELS OF FOUR COLUMNS with the pivots on the diagonal.
   // The tableau lives in accumulator registers as 16 x 16 tiles, a wavefront owns whole column tiles (<= 2: 5 tiles each), so the pivot rows
   // of a column tile and its update are in ONE wavefront: per panel the owner of the pivot column tile publishes the panel's four columns
@@ -243,11 +251,13 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
   // Pivots are NOT searched for outside the 4 x 4 block: a block whose multipliers pass MPC_TREE_GROWTH abandons the attempt — nothing
   // has been written, Mt / R / rv are as they were — and the pivoted form below does the job.  (rv rides in column n of R: needs n < np.)
   bool eliminated = false;
-  if ((n & 3) == 0 && n < np && !a.tree_pivoted) {
+  if ((n & 3) == 0 && n < np && 8 * np + 96 <= np * ldp && !a.tree_pivoted) {
     constexpr int NBT = NP / 16, SL = (2 * NBT + NWC - 1) / NWC;  // row tiles ; column tiles per wavefront
-    double* panel = vec + 5 * np;            // [np][4]
-    double* ppS = panel + 4 * np;            // [16] pivot block, [16] its inverse, [4] the terms of its determinant
-    int* failS = (int*)(ppS + 36);
+    // scratch of the panels, double-buffered (ONE barrier per panel: the owner of the next panel publishes it while the others still update
+    // with this one): a whole n x n buffer that is dead by now — X (Sg_a) for role 0 ; Z (Mt, in registers by then) for role 1, which
+    // rebuilds Mt from Sg_a and D if the attempt is abandoned
+    double* scr = role == 0 ? X : Z;
+    int* failS = (int*)(vec + 5 * np);
     const double* Rsrc = role == 0 ? Y : X;
     const int g = lane >> 4, c = lane & 15;
     d4_t col[SL][NBT];
@@ -255,8 +265,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
 #pragma unroll
     for (int sl = 0; sl < SL; ++sl) {
       ct[sl] = (wv + nb) % NWC + sl * NWC;
-      if (sl == 0 && ct[sl] >= 2 * nb) ct[sl] = -1;
-      if (sl > 0 && ct[sl] >= 2 * nb) ct[sl] = -1;
+      if (ct[sl] >= 2 * nb) ct[sl] = -1;
 #pragma unroll
       for (int ri = 0; ri < NBT; ++ri) {
         col[sl][ri] = d4_t{0, 0, 0, 0};
@@ -273,81 +282,99 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
       }
     }
     if (tid == 0) *failS = 0;
-    LEG_BARRIER();
-    bool fail = false;
-    for (int j0 = 0; j0 < n; j0 += 4) {
-      const int rt = j0 >> 4, q = (j0 & 15) >> 2;
-      const int own = (rt + NWC - nb % NWC) % NWC;  // the wavefront whose first slot is column tile rt: (own + nb) % NWC == rt
-      if (wv == own) {
-        // (column tile rt is slot 0 of this wavefront: ct[0] == rt)
-        if ((c >> 2) == q) {
+    LEG_BARRIER();  // the tableau is in registers: the scratch buffer may be written
+    // the owner of panel (rt, q) — the wavefront whose first slot is column tile rt — publishes the panel's four columns and the inverse of
+    // its 4 x 4 pivot block into buffer `buf`
+    auto publish = [&](int rt, int q, int buf) {
+      const long long tp0_ = clock64();
+      double* panel = scr + buf * (4 * np);     // [np][4]
+      double* ppS = scr + 8 * np + buf * 40;   // [16] pivot block, [16] its inverse, [4] the terms of its determinant
+      double pmax = 0.0;  // largest entry of the panel: with the largest entry of the inverse of the pivot block it bounds the multipliers
+      if ((c >> 2) == q) {
 #pragma unroll
-          for (int ri = 0; ri < NBT; ++ri)
-            if (ri < nb) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) panel[(ri * 16 + g + 4 * r) * 4 + (c & 3)] = col[0][ri][r];
-            }
-          // the pivot block: rows j0 + g (register q of tile (rt, rt)), columns j0 + (c & 3)
-          double pv = 0.0;
-#pragma unroll
-          for (int ri = 0; ri < NBT; ++ri) if (ri == rt) pv = col[0][ri][q];
-          ppS[g * 4 + (c & 3)] = pv;
-        }
-        double pmax = 0.0;  // largest entry of the panel: with the largest entry of the inverse of the pivot block it bounds the multipliers
-        if ((c >> 2) == q) {
-#pragma unroll
-          for (int ri = 0; ri < NBT; ++ri)
-            if (ri < nb) pmax = fmax(pmax, fmax(fmax(fabs(col[0][ri][0]), fabs(col[0][ri][1])), fmax(fabs(col[0][ri][2]), fabs(col[0][ri][3]))));
-        }
-        pmax = wave_max_nonneg(pmax);
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wavefront's own LDS writes
-        __builtin_amdgcn_wave_barrier();
-        // inverse of the 4 x 4 pivot block, a lane per entry: lane 4 j + i forms the cofactor of element (j, i) — the 3 x 3 minor without row j
-        // and column i — which over the determinant is entry (i, j) of the inverse; the determinant is the expansion along row 0 (lanes 0 .. 3)
-        const int ii = lane & 3, jj = (lane >> 2) & 3;
-        const int r0 = jj == 0 ? 1 : 0, r1 = jj <= 1 ? 2 : 1, r2 = jj <= 2 ? 3 : 2;
-        const int c0 = ii == 0 ? 1 : 0, c1 = ii <= 1 ? 2 : 1, c2 = ii <= 2 ? 3 : 2;
-        const double a00 = ppS[r0 * 4 + c0], a01 = ppS[r0 * 4 + c1], a02 = ppS[r0 * 4 + c2];
-        const double a10 = ppS[r1 * 4 + c0], a11 = ppS[r1 * 4 + c1], a12 = ppS[r1 * 4 + c2];
-        const double a20 = ppS[r2 * 4 + c0], a21 = ppS[r2 * 4 + c1], a22 = ppS[r2 * 4 + c2];
-        const double pji = ppS[jj * 4 + ii];
-        const double minor = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
-        const double cof = ((ii + jj) & 1) ? -minor : minor;
-        if (lane < 4) ppS[32 + lane] = pji * cof;  // (row 0: lanes 0 .. 3)
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        const double det = (ppS[32] + ppS[33]) + (ppS[34] + ppS[35]);
-        const double pinv = cof / det;
-        const double imax = wave_max_nonneg(lane < 16 ? fabs(pinv) : 0.0);
-        // no pivot is looked for outside the 4 x 4 block: allowed while the multipliers Panel * Pinv stay below MPC_TREE_GROWTH (partial pivoting keeps
-        // them below 1; six digits of the sixteen are what the bound gives away)
-        const bool ok = isfinite(det) && det != 0.0 && isfinite(imax) && imax * pmax < MPC_TREE_GROWTH;
-        if (lane < 16) ppS[16 + ii * 4 + jj] = pinv;
-        if (!ok && lane == 0) *failS = 1;
-      }
-      LEG_BARRIER();
-      if (*failS) { fail = true; break; }
-      const double aop = (c < 4) ? ppS[16 + c * 4 + g] : 0.0;  // A operand of U = Pinv * rows: A(i, k) = Pinv[i][k], i < 4
-#pragma unroll
-      for (int sl = 0; sl < SL; ++sl) {
-        if (ct[sl] < 0 || (ct[sl] < nb && ct[sl] < rt)) continue;  // no such tile / a column tile of Mt that is already eliminated
-        double prow = 0.0;
-#pragma unroll
-        for (int ri = 0; ri < NBT; ++ri) if (ri == rt) prow = col[sl][ri][q];
-        d4_t u = d4_t{0, 0, 0, 0};
-        u = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, prow, u, 0, 0, 0);
-        const double ub = u[0];  // U[g][column c of the tile]
-#pragma unroll
-        for (int ri = 0; ri < NBT; ++ri) {
+        for (int ri = 0; ri < NBT; ++ri)
           if (ri < nb) {
-            double av = panel[(ri * 16 + c) * 4 + g];  // A(i = c, k = g) = Panel[row ri * 16 + i][k]
-            if (ri == rt && (c >> 2) == q) av = 0.0;      // the pivot rows are not eliminated from themselves
-            col[sl][ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, ub, col[sl][ri], 0, 0, 0);
-            if (ri == rt) col[sl][ri][q] = ub;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) panel[(ri * 16 + g + 4 * r) * 4 + (c & 3)] = col[0][ri][r];
+            pmax = fmax(pmax, fmax(fmax(fabs(col[0][ri][0]), fabs(col[0][ri][1])), fmax(fabs(col[0][ri][2]), fabs(col[0][ri][3]))));
           }
+        // the pivot block: rows j0 + g (register q of tile (rt, rt)), columns j0 + (c & 3)
+        double pv = 0.0;
+#pragma unroll
+        for (int ri = 0; ri < NBT; ++ri) if (ri == rt) pv = col[0][ri][q];
+        ppS[g * 4 + (c & 3)] = pv;
+      }
+      pmax = wave_max_nonneg(pmax);
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the wavefront's own LDS writes
+      __builtin_amdgcn_wave_barrier();
+      // inverse of the 4 x 4 pivot block, a lane per entry: lane 4 j + i forms the cofactor of element (j, i) — the 3 x 3 minor without row j
+      // and column i — which over the determinant is entry (i, j) of the inverse; the determinant is the expansion along row 0 (lanes 0 .. 3)
+      const int ii = lane & 3, jj = (lane >> 2) & 3;
+      const int r0 = jj == 0 ? 1 : 0, r1 = jj <= 1 ? 2 : 1, r2 = jj <= 2 ? 3 : 2;
+      const int c0 = ii == 0 ? 1 : 0, c1 = ii <= 1 ? 2 : 1, c2 = ii <= 2 ? 3 : 2;
+      const double a00 = ppS[r0 * 4 + c0], a01 = ppS[r0 * 4 + c1], a02 = ppS[r0 * 4 + c2];
+      const double a10 = ppS[r1 * 4 + c0], a11 = ppS[r1 * 4 + c1], a12 = ppS[r1 * 4 + c2];
+      const double a20 = ppS[r2 * 4 + c0], a21 = ppS[r2 * 4 + c1], a22 = ppS[r2 * 4 + c2];
+      const double pji = ppS[jj * 4 + ii];
+      const double minor = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+      const double cof = ((ii + jj) & 1) ? -minor : minor;
+      if (lane < 4) ppS[32 + lane] = pji * cof;  // (row 0: lanes 0 .. 3)
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      const double det = (ppS[32] + ppS[33]) + (ppS[34] + ppS[35]);
+      const double pinv = cof / det;
+      const double imax = wave_max_nonneg(lane < 16 ? fabs(pinv) : 0.0);
+      // no pivot is looked for outside the 4 x 4 block: allowed while the multipliers Panel * Pinv stay below MPC_TREE_GROWTH (partial pivoting keeps
+      // them below 1; six digits of the sixteen are what the bound gives away)
+      const bool ok = isfinite(det) && det != 0.0 && isfinite(imax) && imax * pmax < MPC_TREE_GROWTH;
+      if (lane < 16) ppS[16 + ii * 4 + jj] = pinv;
+      if (!ok && lane == 0) *failS = 1;
+      if (a.prof && b == 0 && level == 0 && blockIdx.x == 0 && role == 0 && lane == 0) atomicAdd(&a.prof[28], (double)(clock64() - tp0_));  // (developer timer: the owner's serial piece)
+    };
+    // panel (rt, q) applied to column-tile slot sl of this wavefront
+    auto update = [&](int sl, int rt, int q, int buf) {
+      if (ct[sl] < 0 || (ct[sl] < nb && ct[sl] < rt)) return;  // no such tile / a column tile of Mt that is already eliminated
+      const double* panel = scr + buf * (4 * np);
+      const double* ppS = scr + 8 * np + buf * 40;
+      const double aop = (c < 4) ? ppS[16 + c * 4 + g] : 0.0;  // A operand of U = Pinv * rows: A(i, k) = Pinv[i][k], i < 4
+      double prow = 0.0;
+#pragma unroll
+      for (int ri = 0; ri < NBT; ++ri) if (ri == rt) prow = col[sl][ri][q];
+      d4_t u = d4_t{0, 0, 0, 0};
+      u = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, prow, u, 0, 0, 0);
+      const double ub = u[0];  // U[g][column c of the tile]
+#pragma unroll
+      for (int ri = 0; ri < NBT; ++ri) {
+        if (ri < nb) {
+          double av = panel[(ri * 16 + c) * 4 + g];  // A(i = c, k = g) = Panel[row ri * 16 + i][k]
+          if (ri == rt && (c >> 2) == q) av = 0.0;      // the pivot rows are not eliminated from themselves
+          col[sl][ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av, ub, col[sl][ri], 0, 0, 0);
+          if (ri == rt) col[sl][ri][q] = ub;
         }
       }
-      LEG_BARRIER();  // the panel buffer is rewritten by the next owner
+    };
+    const int npan = n >> 2;
+    if (wv == (NWC - nb % NWC) % NWC) publish(0, 0, 0);  // (the owner of column tile 0)
+    LEG_BARRIER();
+    bool fail = *failS != 0;
+    for (int rt = 0; rt * 16 < n && !fail; ++rt) {  // (the four panels of a column tile unrolled: the register index q of the pivot rows is then a constant)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int pidx = rt * 4 + q;
+        if (pidx >= npan || fail) continue;
+        const int buf = pidx & 1;
+        // the next panel and its owner
+        const int qn = (q + 1) & 3;
+        const int rtn = (q == 3) ? rt + 1 : rt;
+        const bool has_next = pidx + 1 < npan;
+        const bool own_next = has_next && wv == (rtn + NWC - nb % NWC) % NWC;
+        update(0, rt, q, buf);                 // (the pivot column tile of the next panel is a first slot: updated first ...)
+        if (own_next) publish(rtn, qn, buf ^ 1);  // (... and published while the other wavefronts are still updating)
+#pragma unroll
+        for (int sl = 1; sl < SL; ++sl) update(sl, rt, q, buf);
+        LEG_BARRIER();
+        if (*failS) fail = true;
+      }
     }
     if (a.prof && tid == 0) atomicAdd(&a.prof[(size_t)b * 64 + (fail ? 30 : 29)], 1.0);  // developer counters (mpc_profile(3)): compositions that took the blocked elimination / fell back to the pivoted one
     if (!fail) {
@@ -369,6 +396,9 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
           }
         }
       }
+      LEG_BARRIER();
+    } else if (role == 1) {  // the attempt used Z as its scratch: Mt again (role 0 used X, which nobody reads any more)
+      build_mt();
       LEG_BARRIER();
     }
   }
@@ -485,6 +515,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
     }
     LEG_BARRIER();
   }
+  LCMP_PROF(26);
   LEG_LAUNDER();
   // Z <- Lm_b (both roles)
   if (bpar) leg_load_mat<false>(Z, ldp, np, Bn.Lm, n, tid, nthr, S.mg_np);
@@ -644,7 +675,9 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
       }
     }
   }
+  LCMP_PROF(27);
 }
+#undef LCMP_PROF
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_leg_tree_down: one launch per level, top-down (a node is created at a lower level than its parent): grid (nodes of the level, B),
