@@ -510,6 +510,23 @@ DEV void leg_load_mat(double* dst, int ldp, int np, const double* src, int n, in
   }
 }
 
+// the same in two halves, for a load whose latency is to hide behind other work: request into registers now, store into LDS later
+DEV void leg_request_mat(double (&v)[LK_PT], int np, const double* src, int n, int tid, int nthr, unsigned mg_np) {
+#pragma unroll
+  for (int u = 0; u < LK_PT; ++u) {
+    const int idx = tid + u * nthr, i = qdiv(idx, mg_np), c0 = (idx - qdiv(idx, mg_np) * np);
+    const bool ok = idx < np * np && i < n && c0 < n;
+    v[u] = src[ok ? i * n + c0 : 0] * (ok ? 1.0 : 0.0);
+  }
+}
+DEV void leg_store_mat(double* dst, int ldp, int np, const double (&v)[LK_PT], int tid, int nthr, unsigned mg_np) {
+#pragma unroll
+  for (int u = 0; u < LK_PT; ++u) {
+    const int idx = tid + u * nthr, i = qdiv(idx, mg_np), c0 = (idx - qdiv(idx, mg_np) * np);
+    if (idx < np * np) dst[i * ldp + c0] = v[u];
+  }
+}
+
 // broadcast of a double from a wave-uniform lane (v_readlane with a scalar lane index)
 DEV double readlane_dyn(double v, int src_lane) {
   const long long bits = __double_as_longlong(v);

@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
   int* used = perm + np;
   d4_t res[LCT];
   // ---- X <- Sg_a ; Y <- D = P_b - Pg (Pg: lcP of the leg that ends at the cut, read by both roles) ; ldP <- D ----
+  double dreg[LK_PT];  // D, kept in registers by role 0 for the products after the elimination (its buffer is reused in between)
   {
     double pv[LK_PT], po[LK_PT];
 #pragma unroll
@@ -204,6 +205,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
       const int idx = tid + u * nthr, i = qdiv(idx, S.mg_np), c0 = idx - i * np;
       if (idx < np * np) {
         const double d = pv[u] - po[u];
+        dreg[u] = d;
         Y[i * ldp + c0] = d;
         if (role == 0 && i < n && c0 < n) lrc[L.ldP + i * n + c0] = d;  // (the guess itself is refreshed by k_leg_tree_down: the other role reads it too)
       }
@@ -250,6 +252,10 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
   // 19 panels of ~2 500 cycles against 38 two-column steps of ~4 600 of the pivoted form below (74 us per level, profiles/r04_legs_phase_timers.txt).
   // Pivots are NOT searched for outside the 4 x 4 block: a block whose multipliers pass MPC_TREE_GROWTH abandons the attempt — nothing
   // has been written, Mt / R / rv are as they were — and the pivoted form below does the job.  (rv rides in column n of R: needs n < np.)
+  // Lm_b, the operand of the products after the elimination, is requested from HBM now (13 doubles per thread) and dropped into Z when the
+  // elimination is done: its latency was in the open
+  double lmb[LK_PT];
+  if (bpar) leg_request_mat(lmb, np, Bn.Lm, n, tid, nthr, S.mg_np);
   bool eliminated = false;
   if ((n & 3) == 0 && n < np && 8 * np + 96 <= np * ldp && !a.tree_pivoted) {
     constexpr int NBT = NP / 16, SL = (2 * NBT + NWC - 1) / NWC;  // row tiles ; column tiles per wavefront
@@ -518,7 +524,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
   LCMP_PROF(26);
   LEG_LAUNDER();
   // Z <- Lm_b (both roles)
-  if (bpar) leg_load_mat<false>(Z, ldp, np, Bn.Lm, n, tid, nthr, S.mg_np);
+  if (bpar) leg_store_mat(Z, ldp, np, lmb, tid, nthr, S.mg_np);
   else for (int idx = tid; idx < np * ldp; idx += nthr) Z[idx] = 0.0;
   if (role == 1) {
     // ======== role 1: X = T2, Y = D, Z = Lm_b ;  Zt = T2 Lm_b (out, then over T2) ; Sg_ab = Sg_b + Lm_b^T Zt ; E = D Zt + Lm_b ========
@@ -598,10 +604,12 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
     s = wave_sum(s);
     if (lane == 0) out[L.tsg + i] = s + (bpar ? Bn.sg[i] : 0.0);
   }
-  __syncthreads();  // ldP (written at the top by other threads of this workgroup) is read back below ; all reads of Z done
+  LEG_BARRIER();  // all reads of Z done
   LEG_LAUNDER();
-  // ---- Z <- D ; F = D T1 (out, then over T1 in Y) ; u = D t3 + p_b ----
-  leg_load_mat<false>(Z, ldp, np, lrc + L.ldP, n, tid, nthr, S.mg_np);
+  // ---- Z <- D (from the registers that formed it) ; F = D T1 (out, then over T1 in Y) ; u = D t3 + p_b ; Lm_a requested for the step after ----
+  leg_store_mat(Z, ldp, np, dreg, tid, nthr, S.mg_np);
+  double lma[LK_PT];
+  leg_request_mat(lma, np, A.Lm, n, tid, nthr, S.mg_np);
   LEG_BARRIER();
 #pragma unroll
   for (int sidx = 0; sidx < LCT; ++sidx) {
@@ -628,7 +636,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
   }
   LEG_LAUNDER();
   // ---- Z <- Lm_a ; P_ab = P_a + Lm_a F (lower block triangle, mirrored, diagonal tiles symmetrised through X) ; p_ab = p_a + Lm_a u ----
-  leg_load_mat<false>(Z, ldp, np, A.Lm, n, tid, nthr, S.mg_np);
+  leg_store_mat(Z, ldp, np, lma, tid, nthr, S.mg_np);
   LEG_BARRIER();
   {
     const int nst = nb * (nb + 1) / 2;
