@@ -3,6 +3,8 @@
 // ProxDDP iteration, result download); every floating-point operation of the hot path runs on the device.
 // There is no CPU fallback in this file: any HIP failure is reported through the return code.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <map>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -24,6 +26,21 @@
     hipError_t e_ = (expr);                                                                           \
     if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e_)); \
   } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a setting of the (device, kernel) pair, not of a handle: a process may hold handles
+// whose carve-outs differ (another number of constraint rows, another model) — the largest request so far stays
+static void lds_attr_max(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> have;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  int& h = have[{dev, fn}];
+  if (h < bytes) {
+    HIP_OK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    h = bytes;
+  }
+}
 
 // Problems whose dimensions get compile-time instantiations of the sweep and the leg kernels (riccati_mfma.h "FN, FM"):
 //   X(id, n, m, gfull, st_lds, NP, MP)   — (n, m): state / control dimension ; gfull, st_lds: the sweep's LDS plan for them (make_ric_lds) ;
@@ -314,7 +331,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   o.bcl_mu_update_factor = 0.01; o.bcl_mu_lower_bound = 1e-8; o.inner_tol0 = 1.0; o.prim_tol0 = 1.0;
   o.max_iters = 100; o.max_al_iters = 100; o.force_initial_condition = 1; o.rollout_linear = 1; o.ls_max_steps = 8;
   o.num_threads = 1; o.riccati_legs = 1; o.forward_mode = 0;
-  HIP_OK(hipFuncSetAttribute((const void*)k_riccati_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  lds_attr_max((const void*)k_riccati_backward, 160 * 1024);
   s->ric = make_ric_lds(L.n, L.m, L.c, 1);
   if (s->ric.total_bytes > 160 * 1024 && ((L.n + 15) & ~15) * ((L.m + 15) & ~15) <= L.n * L.n) {
     s->ric = make_ric_lds(L.n, L.m, L.c, 2);                                         // whole G, its u part in the L2 scratch (large m)
@@ -326,22 +343,22 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   if (L.space == MPC_SPACE_MULTIBODY && s->ric.gfull && L.n % 2 == 0 && L.n >= 24 && !getenv("MPC_HIP_DENSE_AB")) { s->ric.sq = 1; s->ric.nv = L.n / 2; }
   s->cl = make_cl_lds(L.n, L.m);
   if (s->cl.total_bytes <= 160 * 1024)
-    HIP_OK(hipFuncSetAttribute((const void*)k_closed_loop, hipFuncAttributeMaxDynamicSharedMemorySize, s->cl.total_bytes));
+    lds_attr_max((const void*)k_closed_loop, s->cl.total_bytes);
   s->use_mfma_riccati = s->ric.total_bytes <= 160 * 1024 && (s->ric.st_lds || s->ric.mp * s->ric.np <= L.n * L.nz) && !getenv("MPC_HIP_GENERIC_RICCATI");
   if (s->use_mfma_riccati)
   {
-    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 96, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+    lds_attr_max((const void*)k_riccati_mfma<RIC_THREADS, 96>, s->ric.total_bytes);
+    lds_attr_max((const void*)k_riccati_mfma<RIC_THREADS, 80>, s->ric.total_bytes);
+    lds_attr_max((const void*)k_riccati_mfma<RIC_THREADS, 96, true>, s->ric.total_bytes);
+    lds_attr_max((const void*)k_riccati_mfma<RIC_THREADS, 80, true>, s->ric.total_bytes);
+    lds_attr_max((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16>, s->ric.total_bytes);
   }
   // parallel-in-time legs: every kernel of legs.h keeps three n x n operands (or [A B] + Pt) in LDS
   s->lk = make_lk_lds(L.n, L.m); s->lc = make_lc_lds(L.n); s->lx = make_lx_lds(L.n, L.m);
   s->legs_ok = s->use_mfma_riccati && s->ric.np <= 80 && s->ric.mp <= 48 && L.c <= 256 && s->ric.gfull >= 1 && s->lk.total_bytes <= 160 * 1024 &&
                s->lc.total_bytes <= 160 * 1024 && s->lx.total_bytes <= 160 * 1024 && !getenv("MPC_HIP_NO_LEGS");
   if (s->legs_ok) {
-    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
+    lds_attr_max((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true>, s->ric.total_bytes);
     // fixed-dimension instantiations (MPC_FIXED_MODELS): only when the handle's LDS plan IS the one they were compiled for
     s->ric_fixed = 0;
     if (!getenv("MPC_HIP_GENERIC_DIMS") && s->ric.sq) {
@@ -350,34 +367,34 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
 #undef X
     }
 #define X(ID, FN, FM, GF, ST, NPV, MPV) if (s->ric_fixed == ID) { \
-      HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, FN, FM, GF, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes)); \
-      HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<MPV, FN, FM>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes)); \
-      HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense<FN>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes)); \
-      HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<NPV, FN, FM>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes)); \
-      HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<NPV, FN, FM>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes)); }
+      lds_attr_max((const void*)k_riccati_mfma<RIC_THREADS, 80, true, true, FN, FM, GF, ST>, s->ric.total_bytes); \
+      lds_attr_max((const void*)k_leg_knot<MPV, FN, FM>, s->lk.total_bytes); \
+      lds_attr_max((const void*)k_leg_condense<FN>, s->lc.total_bytes); \
+      lds_attr_max((const void*)k_leg_compose<NPV, FN, FM>, s->lx.total_bytes); \
+      lds_attr_max((const void*)k_leg_tree_down<NPV, FN, FM>, s->lx.total_bytes); }
     MPC_FIXED_MODELS(X)
 #undef X
-    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, s->ric.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_knot<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lk.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_condense<0>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lc.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<64>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_consensus<80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<64>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_compose<80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<16>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<32>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<48>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<64>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
-    HIP_OK(hipFuncSetAttribute((const void*)k_leg_tree_down<80>, hipFuncAttributeMaxDynamicSharedMemorySize, s->lx.total_bytes));
+    lds_attr_max((const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, s->ric.total_bytes);
+    lds_attr_max((const void*)k_riccati_mfma<RIC_SMALL_THREADS, 16, false, true>, s->ric.total_bytes);
+    lds_attr_max((const void*)k_leg_knot<16>, s->lk.total_bytes);
+    lds_attr_max((const void*)k_leg_knot<32>, s->lk.total_bytes);
+    lds_attr_max((const void*)k_leg_knot<48>, s->lk.total_bytes);
+    lds_attr_max((const void*)k_leg_condense<0>, s->lc.total_bytes);
+    lds_attr_max((const void*)k_leg_consensus<16>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_consensus<32>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_consensus<48>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_consensus<64>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_consensus<80>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_compose<16>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_compose<32>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_compose<48>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_compose<64>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_compose<80>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_tree_down<16>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_tree_down<32>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_tree_down<48>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_tree_down<64>, s->lx.total_bytes);
+    lds_attr_max((const void*)k_leg_tree_down<80>, s->lx.total_bytes);
   }
   ensure_leg_capacity(s, s->eff_legs());
   HIP_OK(hipStreamSynchronize(s->stream));
