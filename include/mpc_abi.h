@@ -301,7 +301,10 @@ int mpc_revive_instance(mpc_solver* s, int32_t dst, int32_t src);
  * "H" "grad" "AB" "f" "E6" "cval" "CD" "cost" "P" "p" "K" "kff" "Knu" "knu" "dx" "du" "dvs" "dlams" "xnext".
  * Parallel-in-time sweep (riccati_legs > 1), knots of a leg other than the last: "Mu" "Znu" "Lm" and, HIP, "Phi" "phi" "Gam" "Ku" "Knup" /
  * oracle, "Mx" "Mth" "Kth" "Knuth" "Kexact" (same quantities: Phi = Mx everywhere, Gam = Mth, Ku = Kth, Knup = Knuth at the last knot of a leg) ;
- * with k = index of the leg instead of a knot: "Sg" "sg" (HIP; the oracle keeps them per knot) "Zx" "zc" "calP" "calp" "theta". */
+ * with k = index of the leg instead of a knot: "Sg" "sg" (HIP; the oracle keeps them per knot) "Zx" "zc" "calP" "calp" "theta" ;
+ * HIP only: "ls_knot" (knot k of the last pass: the merit of every linesearch candidate alpha_i = 2^-i at this knot, then the knot's cost
+ * and penalty at the current point), "fixed_dims" (one value: which fixed-dimension instantiations of the hot kernels serve this handle,
+ * 0 = the generic ones ). */
 int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double* out, int32_t cap);
 /* Evaluate (value + derivatives) at the current iterate without stepping; fills the LQ knots. */
 int mpc_debug_evaluate(mpc_solver* s, const double* xs, const double* us);
