@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (MI355X_MICROARCH.md); the fp64 matrix cores double it
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (MI355X_MICROARCH.md); the fp64 matrix cores have the SAME peak (tools/ubench/mfma_f64: 64 clk per v_mfma_f64_16x16x4 per SIMD)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured-achievable copy rate
 
 
@@ -167,7 +167,12 @@ def main():
     ap.add_argument("--iters-per-tick", type=int, default=1,
                     help="ProxDDP iterations per MPC tick: 1 = the reference loop (solver.max_iters = 1, fulldynamic_talos.py:407); 2 = the setting that "
                          "keeps every randomised instance stable over the whole 1000-tick schedule (DESIGN.md §5).  The default run also reports a walk measurement with 2.")
-    ap.add_argument("--refine-appended-knot", type=int, default=3,
+    ap.add_argument("--corrector-prim-tol", type=float, default=20.0,
+                    help="mpc_options.corrector_prim_tol (include/mpc_abi.h): an instance whose one iteration of the tick started from a warm start that is "
+                         "primal-infeasible by more than this, or whose step was shortened by the linesearch, takes one more iteration in the same tick "
+                         "(2 - 5 %% of the instance-ticks of the schedule); the solver mirror's default.  0 = off: exactly max_iters iterations per solve")
+    ap.add_argument("--corrector-window", type=int, default=0, help="mpc_options.corrector_window: 0 = the corrector rule applies to every tick")
+    ap.add_argument("--refine-appended-knot", type=int, default=0,
                     help="mpc_options.refine_appended_knot: Newton steps on the control of the knot mpc_cycle appends when its contact pattern differs from the "
                          "stage before it (include/mpc_abi.h) — the warm-start choice under which ensembles of randomised instances walk the whole schedule on "
                          "one ProxDDP iteration per tick; 0 = the scripts' plain duplicate us[-1] (fulldynamic_talos.py:533)")
@@ -210,7 +215,7 @@ def main():
         raise RuntimeError("bench.py measures the HIP library only")
     pd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
     nshard = max(1, min(args.streams, args.batch))
-    def measure(walk, iters=args.iters_per_tick):
+    def measure(walk, iters=args.iters_per_tick, corrector=None):
         """One measurement of the ensemble tick: frozen foot references (walk = False) or the reference loop's per-tick problem
         updates (walk = True: FootTrajectory.updateTrajectory + 2 N setReference + terminal rebuild, EnsembleMPC.enable_walk)."""
         # SURVEY.md §8d config 5: ONE ensemble of batch x world instances (one rng stream, instance order), instance i on GPU i mod G
@@ -220,6 +225,8 @@ def main():
         for e in shards:
             e.iters_per_tick = int(iters)
             e.options.refine_appended_knot = int(args.refine_appended_knot)
+            e.options.corrector_prim_tol = float(args.corrector_prim_tol if corrector is None else corrector)
+            e.options.corrector_window = int(args.corrector_window)
             e.native.set_options(e.options)
         legs = int(ens.options.riccati_legs)
         # Walk mode: the generator REPLANS from the measured poses during the T_ds ticks before every take-off (27 % of the ticks of
@@ -252,11 +259,13 @@ def main():
                 e.enable_walk(per_instance=(args.walk_refs == "instance"))
 
         # instances whose tick was a BCL update / stall without a ProxDDP step (num_iters == 0 in the status of the tick): not a solve
-        nostep = {"n": 0, "on": False}
+        nostep = {"n": 0, "on": False, "extra": 0, "back": 0}
 
         def tally(stats):
             if nostep["on"] and stats:
                 nostep["n"] += sum(1 for st in stats if st.num_iters == 0)
+                nostep["extra"] += sum(1 for st in stats if st.num_iters > iters)   # took the corrector iteration (mpc_options.corrector_prim_tol)
+                nostep["back"] += sum(1 for st in stats if st.num_iters > 0 and st.alpha < 1.0)
 
         stagger = {"ms": args.phase_offset_ms}
         pace = {"period": 0.0, "fast": True, "late": 0}  # state of the shard pacer (kept from the warm-up into the timed region)
@@ -412,6 +421,8 @@ def main():
             nostep["on"] = False
         elapsed /= regions
         nostep["n"] = nostep["n"] / regions
+        nostep["extra"] = nostep["extra"] / regions
+        nostep["back"] = nostep["back"] / regions
         replanning = replanning / regions
         for e in shards:
             e.native.profile(0)
@@ -436,7 +447,7 @@ def main():
             for kname, (cnt, ms) in e.native.profile_read().items():
                 c0, m0 = prof.get(kname, (0, 0.0))
                 prof[kname] = (c0 + cnt, m0 + ms)
-        return dict(shards=shards, ens=ens, legs=legs, cold=cold, n_conv=n_conv, n_conv100=n_conv100, worst_unconv=worst_unconv, regions=regions, nostep=nostep["n"], pace=pace, stagger=stagger, elapsed=elapsed,
+        return dict(shards=shards, ens=ens, legs=legs, cold=cold, n_conv=n_conv, n_conv100=n_conv100, worst_unconv=worst_unconv, regions=regions, nostep=nostep["n"], corrector_ticks=nostep["extra"], backtracking_ticks=nostep["back"], pace=pace, stagger=stagger, elapsed=elapsed,
                     prof=prof, warm=warm, gather=gather, replanning_ticks=replanning)
 
     modes = [True] if args.walk else ([False] if args.no_walk else [False, True])
@@ -616,7 +627,7 @@ def main():
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
         "p50_ms_per_solve_batch1": p50_ms, "p90_ms_per_solve_batch1": p90_ms, "p95_ms_per_solve_batch1": p95_ms, "latency_ticks": (300 if p50_ms is not None else 0), "p50_riccati_legs": (args.latency_legs if args.legs != 1 else 1),
         # which instantiations of the hot kernels served the run (dimensions as compile-time constants; MPC_HIP_GENERIC_DIMS=1 forces the generic ones)
-        "kernel_dimensions": {0: "run-time (generic kernels)", 1: "compile-time: n = 76, m = 32 (complete Talos, full dynamics)", 2: "compile-time: n = 76, m = 44 (complete Talos, kinodynamic)"}.get(int(shards[0].native.debug_get("fixed_dims", 0)[0]), "?"),
+        "kernel_dimensions": {0: "run-time (generic kernels)", 1: "compile-time: n = 76, m = 32 (complete Talos, full dynamics)", 2: "compile-time: n = 76, m = 44 (complete Talos, kinodynamic)", 3: "compile-time: n = 56, m = 22 (Talos with the upper body locked, full dynamics)", 4: "compile-time: n = 56, m = 34 (Talos with the upper body locked, kinodynamic)"}.get(int(shards[0].native.debug_get("fixed_dims", 0)[0]), "?"),
         "riccati_cuts": ("chain (MPC_LEGS_CHAIN)" if os.environ.get("MPC_LEGS_CHAIN", "0") not in ("", "0") else "tree of pairwise compositions (csrc/legs_tree.h) from three legs on"),
         "cold_solve_iters": int(cold[0].num_iters), "cold_solve_converged": bool(cold[0].converged),
         "cold_solve_converged_instances": "%d/%d within %d iterations, %d within the scripts' 100 (randomised initial states; set-up, untimed; largest primal / dual infeasibility of the unconverged ones: %.2e)" % (n_conv, args.batch, args.cold_iters, mres["n_conv100"], mres["worst_unconv"]),
@@ -628,6 +639,7 @@ def main():
                             else "planned once per tick from instance 0's measured state and shared by the instances of an ensemble"),
         "measurements": {(w if isinstance(w, str) else ("walk" if w else "frozen_references")): {"value": round(rate(r), 2), "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 4),
                                                                   "replanning_ticks": r["replanning_ticks"],
+                                                                  "instance_ticks_with_corrector_iteration": r["corrector_ticks"], "instance_ticks_backtracking": r["backtracking_ticks"],
                                                                   "kernel_ms_per_step_warmup": {k: round(v[1] / max(1, args.warmup), 4) for k, v in sorted(r["warm"].items(), key=lambda kv: -kv[1][1])[:6]}}
                          for w, r in runs.items()},
         "instance_ticks_without_step": nostep["n"] * world, "diverged_instance_rescues": sum(getattr(e, "rescues", 0) for e in shards),

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MPC_ABI_VERSION 1
+#define MPC_ABI_VERSION 2
 
 /* ---- state manifolds -------------------------------------------------------------------- */
 #define MPC_SPACE_VECTOR 0     /* aligator.manifolds.VectorSpace(n)            centroidal_talos.py:46   */
@@ -119,6 +119,15 @@ typedef struct mpc_options {
   double bcl_prim_alpha, bcl_prim_beta, bcl_dual_alpha, bcl_dual_beta;
   double bcl_mu_update_factor, bcl_mu_lower_bound;
   double inner_tol0, prim_tol0;
+  double corrector_prim_tol; /* > 0: an instance whose run has used up max_iters takes ONE more iteration (a "corrector") when the iterate its last
+                            * iteration started from was primal-infeasible by more than this (mpc_stats.prim_infeas: largest constraint violation /
+                            * dynamics gap; N, N m, rad), or when that iteration's step had to be shortened by the linesearch (alpha < 1).  For the MPC loops (max_iters = 1, fulldynamic_talos.py:407): the warm start of a tick is
+                            * the previous solution shifted by one knot with the last control DUPLICATED (:532-534); on the few ticks where the
+                            * appended stage has another contact pattern that duplicate violates the new stage by 100 - 300 N / N m, one Newton
+                            * step of the 1 / mu = 1e8 penalty problem lands on rows its active set did not know, and ensembles of perturbed
+                            * instances are lost within two walking cycles.  A second iteration on exactly those ticks
+                            * (~2 - 5 % of the instance-ticks at 20.0) keeps them.  0 (default of the C-ABI): off.  Not something Aligator is
+                            * known to do: this build's globalisation of an iteration budget of one. */
   int32_t max_iters;       /* solver.max_iters (100 cold, 1 in the MPC loop)           */
   int32_t max_al_iters;
   int32_t force_initial_condition;
@@ -154,6 +163,10 @@ typedef struct mpc_options {
                             * refinement problem of a knot whose duplicated control is already feasible is ill-conditioned (dependent cone
                             * rows; the nominal instance is lost within 30 ticks) — use R > 0.  Not
                             * something Aligator does: a choice of initial guess, off unless asked for. */
+  int32_t corrector_window; /* 0: corrector_prim_tol applies to every run.  K > 0: only to the K runs that follow an mpc_cycle whose appended stage has
+                            * another contact pattern than the stage before it (the ticks on which the duplicated control is inconsistent) — lets
+                            * mpc_run_shifted_async, which enqueues the passes of a tick ahead of their results, enqueue the corrector pass on those
+                            * ticks only.  Same rule in both libraries. */
 } mpc_options;
 
 typedef struct mpc_stats {

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPC_HIP_LIBRARY: developer override pointing at another build of the SAME HIP library (kernel tuning variants)
 HIP_LIBRARY_PATH = os.environ.get("MPC_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libmpc_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # constants mirrored from include/mpc_abi.h
 SPACE_VECTOR, SPACE_MULTIBODY = 0, 1
@@ -40,9 +40,9 @@ class MpcOptions(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "tol", "mu_init", "dyn_al_scale", "reg_init", "ls_armijo_c1", "ls_alpha_min",
         "bcl_prim_alpha", "bcl_prim_beta", "bcl_dual_alpha", "bcl_dual_beta",
-        "bcl_mu_update_factor", "bcl_mu_lower_bound", "inner_tol0", "prim_tol0")] + [(n, C.c_int32) for n in (
+        "bcl_mu_update_factor", "bcl_mu_lower_bound", "inner_tol0", "prim_tol0", "corrector_prim_tol")] + [(n, C.c_int32) for n in (
         "max_iters", "max_al_iters", "force_initial_condition", "rollout_linear", "ls_max_steps",
-        "num_threads", "riccati_legs", "forward_mode", "refine_appended_knot")]
+        "num_threads", "riccati_legs", "forward_mode", "refine_appended_knot", "corrector_window")]
 
 
 def default_options(tol=1e-5, mu_init=1e-8):
@@ -57,6 +57,7 @@ def default_options(tol=1e-5, mu_init=1e-8):
     o.force_initial_condition, o.rollout_linear, o.ls_max_steps = 0, 0, 8
     o.num_threads, o.riccati_legs, o.forward_mode = 1, 1, 0
     o.refine_appended_knot = 0
+    o.corrector_prim_tol, o.corrector_window = 0.0, 0
     return o
 
 

@@ -147,6 +147,9 @@ class Workspace:
         """Data rotation is implicit in the native ring buffer (fulldynamic_talos.py:497)."""
 
 
+DEFAULT_CORRECTOR_PRIM_TOL = 20.0  # N, N m, rad: a contact switch in the appended stage injects 100 - 300, an ordinary tick < 10
+
+
 class SolverProxDDP:
     def __init__(self, tol=1e-6, mu_init=1e-2, max_iters=1000, verbose=VerboseLevel.QUIET, _native_library=None):
         self.target_tol = float(tol)
@@ -160,6 +163,12 @@ class SolverProxDDP:
         self.num_threads = 1
         self.riccati_legs = None  # None: chosen by _legs()
         self.refine_appended_knot = 0  # mpc_options.refine_appended_knot (this build's extension: 0 = the scripts' plain warm-start shift)
+        # mpc_options.corrector_prim_tol / corrector_window (this build's globalisation of an iteration budget of one, include/mpc_abi.h): a run
+        # whose last iteration started from an iterate infeasible by more than this takes one more iteration.  ON by default — it is what lets
+        # the reference's loops (max_iters = 1, fulldynamic_talos.py:407) and ensembles of perturbed robots survive the ticks on which the
+        # duplicated control of the warm-start shift meets a stage of another contact pattern; 0 switches it off.
+        self.corrector_prim_tol = DEFAULT_CORRECTOR_PRIM_TOL
+        self.corrector_window = 0  # every run (ensembles driven asynchronously use a window: EnsembleMPC)
         self.batch = 1
         self.results = Results()
         self.workspace = None
@@ -187,6 +196,8 @@ class SolverProxDDP:
         o.num_threads = self.num_threads
         o.riccati_legs = self._legs() if self.linear_solver_choice == LQ_SOLVER_PARALLEL else 1
         o.refine_appended_knot = int(self.refine_appended_knot)
+        o.corrector_prim_tol = float(self.corrector_prim_tol)
+        o.corrector_window = int(self.corrector_window)
         return o
 
     def _legs(self):

@@ -37,6 +37,7 @@ struct InstState {
   double mu, inner_tol, prim_tol;
   double phi0, dphi0, alpha, cost, prim, dual, crit;
   int32_t num_iters, al_iters, converged, done, skip_step, ls_step, ls_more, stalled;
+  int32_t corrector, pad_;  // corrector: this run has been granted its one extra iteration (mpc_options.corrector_prim_tol)
 };
 
 #define MPC_MAX_LEGS 32  // riccati_legs is clamped to this (and to the horizon) ; measured up to 64: batch 1 is fastest with 32 (1.47 ms against 1.57 with 16), 40 - 64 no better

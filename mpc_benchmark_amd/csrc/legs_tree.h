@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
     // with this one): a whole n x n buffer that is dead by now — X (Sg_a) for role 0 ; Z (Mt, in registers by then) for role 1, which
     // rebuilds Mt from Sg_a and D if the attempt is abandoned
     double* scr = role == 0 ? X : Z;
-    int* failS = (int*)(vec + 5 * np);
+    int* failS = (int*)(vec + 5 * np);  // [2]: one flag per panel buffer, written (0 or 1) whenever the buffer is published
     const double* Rsrc = role == 0 ? Y : X;
     const int g = lane >> 4, c = lane & 15;
     d4_t col[SL][NBT];
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
         }
       }
     }
-    if (tid == 0) *failS = 0;
+    if (tid == 0) { failS[0] = 0; failS[1] = 0; }
     LEG_BARRIER();  // the tableau is in registers: the scratch buffer may be written
     // the owner of panel (rt, q) — the wavefront whose first slot is column tile rt — publishes the panel's four columns and the inverse of
     // its 4 x 4 pivot block into buffer `buf`
@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
       // them below 1; six digits of the sixteen are what the bound gives away)
       const bool ok = isfinite(det) && det != 0.0 && isfinite(imax) && imax * pmax < MPC_TREE_GROWTH;
       if (lane < 16) ppS[16 + ii * 4 + jj] = pinv;
-      if (!ok && lane == 0) *failS = 1;
+      if (lane == 0) failS[buf] = ok ? 0 : 1;
       if (a.prof && b == 0 && level == 0 && blockIdx.x == 0 && role == 0 && lane == 0) atomicAdd(&a.prof[28], (double)(clock64() - tp0_));  // (developer timer: the owner's serial piece)
     };
     // panel (rt, q) applied to column-tile slot sl of this wavefront
@@ -362,7 +362,7 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
     const int npan = n >> 2;
     if (wv == (NWC - nb % NWC) % NWC) publish(0, 0, 0);  // (the owner of column tile 0)
     LEG_BARRIER();
-    bool fail = *failS != 0;
+    bool fail = failS[0] != 0;
     for (int rt = 0; rt * 16 < n && !fail; ++rt) {  // (the four panels of a column tile unrolled: the register index q of the pivot rows is then a constant)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -379,7 +379,9 @@ __global__ void __launch_bounds__(LCMP_THREADS) k_leg_compose(SolverArgs a, LxLd
 #pragma unroll
         for (int sl = 1; sl < SL; ++sl) update(sl, rt, q, buf);
         LEG_BARRIER();
-        if (*failS) fail = true;
+        // the flag of the panel about to be applied (buffer buf ^ 1, published before this barrier): the owner of the panel after it writes
+        // the OTHER flag, so a wavefront that is slow to read cannot see a verdict that belongs to a later panel
+        if (has_next && failS[buf ^ 1]) fail = true;
       }
     }
     if (a.prof && tid == 0) atomicAdd(&a.prof[(size_t)b * 64 + (fail ? 30 : 29)], 1.0);  // developer counters (mpc_profile(3)): compositions that took the blocked elimination / fell back to the pivoted one

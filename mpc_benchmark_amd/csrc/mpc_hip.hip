@@ -98,6 +98,7 @@ struct mpc_solver {
   int only_knot = -1;              // SolverArgs::only_knot of the launches being enqueued
   bool appended_changed = false;   // the stage of the last mpc_cycle has another contact pattern than its predecessor (refine_appended_knot)
   bool appended_any = false;       // a stage was appended since the last run (refine_appended_knot < 0: refine after every cycle)
+  int since_change = 1 << 20;      // mpc_cycle calls since the appended stage last changed its contact pattern (corrector_window)
   bool refine_now = false;         // ... and this run refines the warm start of the appended knot after k_begin_run
   double* d_simu = nullptr;  // [B][nu] torques, [B][12] wrenches of mpc_simulate_torque
   double* d_simwr = nullptr;
@@ -196,6 +197,8 @@ struct mpc_solver {
     return (T*)p;
   }
 
+  // mpc_options.corrector_prim_tol / corrector_window: does the corrector rule apply to the run that starts now? (same rule: oracle/capi.cpp)
+  bool corrector_armed() const { return opt.corrector_prim_tol > 0.0 && (opt.corrector_window <= 0 || since_change < opt.corrector_window); }
   SolverArgs args() const {
     SolverArgs a;
     a.L = L; a.opt = opt; a.head = head;
@@ -213,6 +216,7 @@ struct mpc_solver {
     a.spec_knot = a.spec_on ? d_spec_knot : nullptr; a.spec_next = (a.reuse_on && spec_next_now) ? 1 : 0;
     for (int w = 0; w < MPC_DIRTY_WORDS; ++w) a.dirty[w] = a.reuse_on ? dirty_now[w] : 0ull;
     a.only_knot = only_knot;
+    a.corrector_on = corrector_armed() ? 1 : 0;
     a.tree_pivoted = getenv("MPC_HIP_TREE_PIVOTED") ? 1 : 0;
     a.nlegs = eff_legs(); a.leg_cap = leg_cap; a.legbuf = d_legbuf; a.treebuf = d_treebuf; a.leg_guess = leg_guess_now;
     a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = phase_timers ? d_prof : nullptr;
@@ -808,7 +812,7 @@ static void run_impl(mpc_solver* s, mpc_stats* stats, int passes_enqueued = 0) {
   const Layout& L = s->L;
   SolverArgs a = s->args();
   if (passes_enqueued == 0) { hipLaunchKernelGGL(k_begin_run, dim3(L.B), dim3(64), 0, s->stream, a); launch_refine(s); }
-  const int max_passes = s->opt.max_iters + s->opt.max_al_iters + 1;
+  const int max_passes = s->opt.max_iters + s->opt.max_al_iters + 2;  // (+ 1: the corrector iteration of mpc_options.corrector_prim_tol)
   std::vector<InstState> st(L.B);
   for (int pass = 0; pass < max_passes; ++pass) {
     if (pass >= passes_enqueued) { s->pass_in_run = pass; launch_pass(s); }
@@ -1034,6 +1038,7 @@ int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* 
       // refine_appended_knot: another dynamics kind / contact list than the stage before it (descriptor words 0 .. 3)
       s->appended_changed = n_desc >= 4 && s->h_len[2 * last] >= 4 && std::memcmp(hd, desc, 4 * sizeof(int32_t)) != 0;
       s->appended_any = true;
+      s->since_change = s->appended_changed ? 0 : (s->since_change < (1 << 20) ? s->since_change + 1 : s->since_change);
       // (a last stage whose parameters were patched after the speculative evaluation: the spare record is stale)
       s->spec_next_pending = same && s->spec_rec_valid && s->cycles_since_run == 1 && !s->slot_dirty[last] && !s->dirty_all;
     }
@@ -1101,17 +1106,26 @@ int mpc_kernel_info(mpc_solver* s, int32_t idx, char* name, int32_t name_cap, in
 #undef X
       else if (s->ric.sq) e.push_back({"k_riccati_mfma<512,80,true,true> (sweep, legs)", (const void*)k_riccati_mfma<RIC_THREADS, 80, true, true>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
       else e.push_back({"k_riccati_mfma<512,80,false,true> (sweep, legs)", (const void*)k_riccati_mfma<RIC_THREADS, 80, false, true>, RIC_THREADS, s->ric.total_bytes, (long long)L.B * J});
+      // (the instantiations the launch sites pick: the fixed-dimension ones when the handle's layout is one of MPC_FIXED_MODELS)
       const void* lk = s->lk.mp <= 16 ? (const void*)k_leg_knot<16> : (s->lk.mp <= 32 ? (const void*)k_leg_knot<32> : (const void*)k_leg_knot<48>);
-      e.push_back({"k_leg_knot", lk, LK_THREADS, s->lk.total_bytes, (long long)L.N * L.B});
-      e.push_back({"k_leg_condense", (const void*)k_leg_condense<0>, LK_THREADS, s->lc.total_bytes, (long long)(J - 1) * L.B});
+      const void* lcd = (const void*)k_leg_condense<0>;
+      const char *lk_name = "k_leg_knot", *lcd_name = "k_leg_condense", *lcmp_name = "k_leg_compose (first level of the tree over the cuts)", *ltd_name = "k_leg_tree_down (last level)";
+      const void *lcmp_fixed = nullptr, *ltd_fixed = nullptr;
+#define X(ID, FN, FM, GF, ST, NPV, MPV) if (s->ric_fixed == ID) { lk = (const void*)k_leg_knot<MPV, FN, FM>; lcd = (const void*)k_leg_condense<FN>; lcmp_fixed = (const void*)k_leg_compose<NPV, FN, FM>; ltd_fixed = (const void*)k_leg_tree_down<NPV, FN, FM>; \
+        lk_name = "k_leg_knot<" #MPV "," #FN "," #FM "> (fixed dimensions)"; lcd_name = "k_leg_condense<" #FN "> (fixed dimensions)"; \
+        lcmp_name = "k_leg_compose<" #NPV "," #FN "," #FM "> (first level of the tree over the cuts, fixed dimensions)"; ltd_name = "k_leg_tree_down<" #NPV "," #FN "," #FM "> (last level, fixed dimensions)"; }
+      MPC_FIXED_MODELS(X)
+#undef X
+      e.push_back({lk_name, lk, LK_THREADS, s->lk.total_bytes, (long long)L.N * L.B});
+      e.push_back({lcd_name, lcd, LK_THREADS, s->lc.total_bytes, (long long)(J - 1) * L.B});
       if (s->use_tree()) {
         const TreeDesc T = make_tree_desc(J);
         const void* lc = s->lx.np == 16 ? (const void*)k_leg_compose<16> : s->lx.np == 32 ? (const void*)k_leg_compose<32> : s->lx.np == 48 ? (const void*)k_leg_compose<48>
                        : s->lx.np == 64 ? (const void*)k_leg_compose<64> : (const void*)k_leg_compose<80>;
         const void* ld = s->lx.np == 16 ? (const void*)k_leg_tree_down<16> : s->lx.np == 32 ? (const void*)k_leg_tree_down<32> : s->lx.np == 48 ? (const void*)k_leg_tree_down<48>
                        : s->lx.np == 64 ? (const void*)k_leg_tree_down<64> : (const void*)k_leg_tree_down<80>;
-        e.push_back({"k_leg_compose (first level of the tree over the cuts)", lc, LCMP_THREADS, s->lx.total_bytes, (long long)(T.lev_cnt[0] + 1) * L.B * 2});
-        e.push_back({"k_leg_tree_down (last level)", ld, LK_THREADS, s->lx.total_bytes, (long long)T.lev_cnt[0] * L.B});
+        e.push_back({lcmp_name, lcmp_fixed ? lcmp_fixed : lc, LCMP_THREADS, s->lx.total_bytes, (long long)(T.lev_cnt[0] + 1) * L.B * 2});
+        e.push_back({ltd_name, ltd_fixed ? ltd_fixed : ld, LK_THREADS, s->lx.total_bytes, (long long)T.lev_cnt[0] * L.B});
       } else {
       const void* lx = s->lx.np == 16 ? (const void*)k_leg_consensus<16> : s->lx.np == 32 ? (const void*)k_leg_consensus<32> : s->lx.np == 48 ? (const void*)k_leg_consensus<48>
                      : s->lx.np == 64 ? (const void*)k_leg_consensus<64> : (const void*)k_leg_consensus<80>;
@@ -1234,7 +1248,7 @@ int64_t mpc_get_state(mpc_solver* s, double* buf, int64_t cap) {
     if (s->async_pending > 0) throw std::runtime_error("get_state: asynchronous ticks in flight (mpc_wait first)");
     double* o = buf;
     const double hdr[MPC_STATE_HEADER] = {MPC_STATE_MAGIC, (double)L.B, (double)L.N, (double)L.nx, (double)L.n, (double)L.m, (double)L.c, (double)L.space,
-                                          s->perfect_feedback ? 1.0 : 0.0, (double)L.max_stage_ints, (double)L.max_stage_doubles, 0, 0, 0, 0, 0};
+                                          s->perfect_feedback ? 1.0 : 0.0, (double)L.max_stage_ints, (double)L.max_stage_doubles, (double)(s->since_change + 1) /* 0: a state saved before the field existed */, 0, 0, 0, 0};
     std::memcpy(o, hdr, sizeof(hdr)); o += MPC_STATE_HEADER;
     for (int k = 0; k <= L.N; ++k) {  // knot order: the ring is unrolled
       const int sl = slot_of(s, k);
@@ -1266,6 +1280,7 @@ int mpc_set_state(mpc_solver* s, const double* buf, int64_t len) {
     HIP_OK(hipStreamSynchronize(s->stream));
     if (s->async_pending > 0) throw std::runtime_error("set_state: asynchronous ticks in flight (mpc_wait first)");
     s->perfect_feedback = o[8] != 0.0;
+    s->since_change = (int)o[11] > 0 ? (int)o[11] - 1 : 1 << 20;
     o += MPC_STATE_HEADER;
     spec_clear(s);
     s->leg_guess_valid = false; s->reuse_this_pass = false; s->spec_skip_pass = false;
@@ -1346,7 +1361,8 @@ int mpc_run_shifted_async(mpc_solver* s) {
     launch_refine(s);
     // with max_iters = 1 one pass takes the step; a few iterations per tick (max_iters <= 4) are enqueued together — a younger tick
     // may be queued behind this one before its status is read; workgroups of instances that are done exit at once
-    const int n_pass = s->opt.max_iters < 1 ? 1 : (s->opt.max_iters > 4 ? 4 : s->opt.max_iters);
+    // (corrector_prim_tol: on the runs it applies to — corrector_window — one pass more, which instances that do not need it sit out)
+    const int n_pass = (s->opt.max_iters < 1 ? 1 : (s->opt.max_iters > 4 ? 4 : s->opt.max_iters)) + (s->corrector_armed() ? 1 : 0);
     for (int p = 0; p < n_pass; ++p) { s->pass_in_run = p; launch_pass(s); }
     s->async_passes[slot] = n_pass;
     HIP_OK(hipMemcpyAsync(s->h_status[slot], s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost, s->stream));

@@ -54,6 +54,7 @@ struct SolverArgs {
   // >= 0: the launch of the current point evaluates THIS knot only, whatever tick reuse says (the warm-start refinement of the appended
   // knot, mpc_options.refine_appended_knot) ; -1: all knots
   int only_knot;
+  int corrector_on;  // mpc_options.corrector_prim_tol applies to this run (corrector_window: the host knows which runs follow a change of the contact pattern)
   int tree_pivoted;  // 1: k_leg_compose skips its blocked elimination on the matrix cores and goes straight to the pivoted Gauss-Jordan (MPC_HIP_TREE_PIVOTED=1: developer comparison)
 };
 

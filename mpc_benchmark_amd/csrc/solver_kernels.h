@@ -808,7 +808,10 @@ __global__ void k_after_step(SolverArgs a) {
   if (stepped) {
     st.stalled = 0;
     st.num_iters += 1;
-    if (st.num_iters >= a.opt.max_iters) st.done = 1;
+    // mpc_options.corrector_prim_tol: the budget ends with an iteration that started from an iterate infeasible by more than the tolerance
+    // (st.prim: what k_decide of this pass measured), or whose step was shortened — one more iteration, once per run (oracle/solver.hpp run_instance: the same rule)
+    if (a.corrector_on && !st.corrector && st.num_iters >= a.opt.max_iters && (st.prim > a.opt.corrector_prim_tol || st.alpha < 1.0)) st.corrector = 1;
+    if (st.num_iters >= a.opt.max_iters + st.corrector) st.done = 1;
   }
   // the records now hold the evaluation of the accepted iterate iff the full step (the one evaluated with derivatives) was taken (1) ;
   // after a BCL update without a step (skip_step: no candidate was evaluated) they still hold the evaluation of the unchanged iterate
@@ -847,7 +850,7 @@ __global__ void k_begin_run(SolverArgs a) {
   if (tid == 0 && a.isolate && st.converged < 0) { st.done = -st.converged; st.num_iters = 0; st.skip_step = 0; }  // a failed instance sits this run out
   else if (tid == 0) {
     st.num_iters = 0; st.al_iters = 0; st.converged = 0; st.done = 0; st.skip_step = 0; st.ls_step = 0; st.alpha = 0;
-    st.stalled = 0; st.ls_more = 0;
+    st.stalled = 0; st.ls_more = 0; st.corrector = 0;
     st.prim_tol = fmax(a.opt.prim_tol0 * pow(st.mu, a.opt.bcl_prim_alpha), a.opt.tol);
     st.inner_tol = fmax(a.opt.inner_tol0 * pow(st.mu, a.opt.bcl_dual_alpha), a.opt.tol);
   }

@@ -114,9 +114,11 @@ class KinodynamicPipeline:
         self.xdot0 = self.mpc.native.get_stage_data(0)[0]
 
     def contact_state(self):
-        """[left, right] of knot 0 of the horizon: the stage rotated in N ticks ago (the initial double support before that)."""
+        """[left, right] the low-level loop of this MPC period works with: ``problem.stages[0]`` AFTER this period's
+        ``replaceStageCircular(stages_full[t])`` (kinodynamic_talos.py:393, 419-420) — the stage that was appended at tick t + 1 - N (the
+        initial double support before that), one rotation later than knot 0 of the solution the feedback terms come from."""
         N, t = self.mpc.problem.num_steps, self.mpc.tick
-        return self.pd.contact_phases[max(0, t - N) % self.pd.t_mpc]
+        return self.pd.contact_phases[max(0, t + 1 - N) % self.pd.t_mpc]
 
     def low_level_step(self, cs):
         """One 1 kHz step of kinodynamic_talos.py:411-462 for every robot."""

@@ -14,6 +14,7 @@ struct mpc_solver {
   std::string err;
   bool perfect_feedback = false;
   bool appended_changed = false;  // the stage of the last mpc_cycle has another contact pattern than its predecessor (refine_appended_knot)
+  int since_change = 1 << 20;     // cycles since the appended stage last changed its contact pattern
   bool appended_any = false;      // a stage was appended since the last run (refine_appended_knot < 0: refine after every cycle)
   bool isolate = false;        // mpc_set_failure_policy
   std::vector<int> failed;     // per instance: 0 or the failure code reported as mpc_stats.converged = -code
@@ -125,6 +126,7 @@ int mpc_cycle(mpc_solver* h, const int32_t* desc, int32_t n_desc, const double* 
     const StageDesc& last = h->s.stages[N - 1];
     h->appended_changed = sd.dyn != last.dyn || sd.ncontact != last.ncontact || sd.cid[0] != last.cid[0] || sd.cid[1] != last.cid[1];
     h->appended_any = true;
+    h->since_change = h->appended_changed ? 0 : (h->since_change < (1 << 20) ? h->since_change + 1 : h->since_change);
     for (int k = 0; k + 1 < N; ++k) h->s.stages[k] = std::move(h->s.stages[k + 1]);
     h->s.stages[N - 1] = std::move(sd);
     for (auto& ip : h->s.inst_params) {  // the appended stage starts from the shared table in every instance
@@ -182,6 +184,8 @@ int mpc_setup(mpc_solver* h) { MPC_TRY(h, h->s.setup()) }
 
 static void run_all(mpc_solver* h, mpc_stats* stats) {
   Solver& s = h->s;
+  // mpc_options.corrector_window (csrc/mpc_hip.hip corrector_armed: the same rule)
+  s.corrector_armed = s.opt.corrector_prim_tol > 0.0 && (s.opt.corrector_window <= 0 || h->since_change < s.opt.corrector_window);
   h->failed.resize(s.dims.batch, 0);
   for (int b = 0; b < s.dims.batch; ++b) {
     if (h->isolate && h->failed[b]) {  // sits this run out until mpc_revive_instance
@@ -283,7 +287,7 @@ int64_t mpc_get_state(mpc_solver* h, double* buf, int64_t cap) {
     std::fill(buf, buf + need, 0.0);
     double* o = buf;
     const double hdr[MPC_STATE_HEADER] = {MPC_STATE_MAGIC, (double)d.batch, (double)N, (double)d.nx, (double)d.ndx, (double)d.nu, (double)d.nc_max, (double)d.space,
-                                          h->perfect_feedback ? 1.0 : 0.0, (double)d.max_stage_ints, (double)d.max_stage_doubles, 0, 0, 0, 0, 0};
+                                          h->perfect_feedback ? 1.0 : 0.0, (double)d.max_stage_ints, (double)d.max_stage_doubles, (double)(h->since_change + 1) /* 0: a state saved before the field existed */, 0, 0, 0, 0};
     std::memcpy(o, hdr, sizeof(hdr)); o += MPC_STATE_HEADER;
     for (int k = 0; k <= N; ++k) {
       const StageDesc& sd = s.stages[k];
@@ -322,6 +326,7 @@ int mpc_set_state(mpc_solver* h, const double* buf, int64_t len) {
         (int)o[7] != d.space || (int)o[9] != d.max_stage_ints || (int)o[10] != d.max_stage_doubles)
       throw std::runtime_error("set_state: the state was saved by a handle of other dimensions");
     h->perfect_feedback = o[8] != 0.0;
+    h->since_change = (int)o[11] > 0 ? (int)o[11] - 1 : 1 << 20;
     o += MPC_STATE_HEADER;
     std::vector<int32_t> desc(d.max_stage_ints);
     for (int k = 0; k <= N; ++k) {

@@ -130,6 +130,7 @@ struct Solver {
   std::vector<std::vector<std::vector<double>>> inst_params;  // [B][N + 1]: per-instance parameter tables, empty = shared (mpc_enable_instance_params)
   std::string err;
   bool have_model = false;
+  bool corrector_armed = true;  // mpc_options.corrector_window: set per run by the C-ABI layer (capi.cpp), which sees the mpc_cycle calls
 
   int N() const { return dims.horizon; }
 
@@ -141,6 +142,7 @@ struct Solver {
     opt.inner_tol0 = 1.0; opt.prim_tol0 = 1.0;
     opt.max_iters = 100; opt.max_al_iters = 100; opt.force_initial_condition = 1; opt.rollout_linear = 1;
     opt.ls_max_steps = 8; opt.num_threads = 1; opt.riccati_legs = 1; opt.refine_appended_knot = 0;
+    opt.corrector_prim_tol = 0.0; opt.corrector_window = 0;
   }
 
   void init(const mpc_dims& d) {
@@ -936,6 +938,14 @@ struct Solver {
     in.stats.traj_cost = cost; in.stats.merit = phi0; in.stats.prim_infeas = prim; in.stats.dual_infeas = dual; in.stats.mu = in.mu;
     if (std::getenv("MPC_ORACLE_DEBUG")) fprintf(stderr, "it %d: cost %.10e merit %.10e prim %.3e dual %.3e crit %.3e (inner_tol %.3e) mu %.1e\n", in.stats.num_iters, cost, phi0, prim, dual, crit, in.inner_tol, in.mu);
     if (crit <= in.inner_tol) return 1;
+    static const int x_retry = std::getenv("MPC_X_RETRY") ? std::atoi(std::getenv("MPC_X_RETRY")) : 0;
+    static const double x_fac = std::getenv("MPC_X_RETRY_FAC") ? std::atof(std::getenv("MPC_X_RETRY_FAC")) : 10.0;
+    static const double x_floor = std::getenv("MPC_X_RETRY_FLOOR") ? std::atof(std::getenv("MPC_X_RETRY_FLOOR")) : 1e-6;
+    static const int x_fail = std::getenv("MPC_X_FAIL") ? std::atoi(std::getenv("MPC_X_FAIL")) : 0;
+    static const int x_uonly = std::getenv("MPC_X_UONLY") ? std::atoi(std::getenv("MPC_X_UONLY")) : 0;
+    double reg_extra = 0.0, alpha = 1.0, phi = 0.0, dphi0 = 0.0;
+    int step = 0; bool ok = false;
+    for (int attempt = 0;; ++attempt) {
     if (nlegs() > 1) {
       std::vector<LegLink> links;
       std::vector<std::vector<double>> ptil, calP;
@@ -964,21 +974,25 @@ struct Solver {
       backward(in);
       forward(in);
     }
-    const double dphi0 = dmerit(in);
-    // no descent left in the inner problem (round-off floor of the 1/mu-conditioned system): counts as solved, no step
-    // (MPC_STALL_TOL of csrc/solver_kernels.h)
-    if (std::fabs(dphi0) <= 1e-13 * (1.0 + std::fabs(phi0))) return 2;
-    double alpha = 1.0, phi = 0.0;
-    int step = 0;
+    dphi0 = dmerit(in);
+    if (attempt == 0 && std::fabs(dphi0) <= 1e-13 * (1.0 + std::fabs(phi0))) return 2;
+    alpha = 1.0; step = 0; ok = false;
     for (;; ++step) {
       make_trial(in, alpha);
       evaluate(in, in.txs, in.tus, in.tknots, false);
       phi = merit(in, in.tknots, in.tvs, in.tlams);
       if (std::getenv("MPC_ORACLE_DEBUG")) fprintf(stderr, "  ls: alpha %.4g phi %.10e phi0 %.10e dphi0 %.4e\n", alpha, phi, phi0, dphi0);
-      if (phi <= phi0 + opt.ls_armijo_c1 * alpha * dphi0) break;
+      if (phi <= phi0 + opt.ls_armijo_c1 * alpha * dphi0) { ok = true; break; }
       if (step + 1 >= opt.ls_max_steps || 0.5 * alpha < opt.ls_alpha_min) break;
       alpha *= 0.5;
     }
+    if (ok || attempt >= x_retry) break;
+    const double nr = std::max(x_floor, reg_extra * x_fac);
+    for (int k = 0; k <= dims.horizon; ++k) { Knot& kn = in.knots[k]; const int nz = kn.n + kn.m; for (int i = (x_uonly ? kn.n : 0); i < nz; ++i) kn.H[i * nz + i] += nr - reg_extra; }
+    reg_extra = nr;
+    }
+    if (reg_extra > 0 && std::getenv("MPC_X_VERBOSE")) fprintf(stderr, "[retry] inst %d reg %.1e ok %d alpha %.4g\n", (int)(&in - inst.data()), reg_extra, (int)ok, alpha);
+    if (!ok && x_fail == 1) { in.stats.alpha = 0.0; in.stats.ls_steps = step; in.stats.num_iters += 1; return 0; }
     in.xs.swap(in.txs); in.us.swap(in.tus); in.vs.swap(in.tvs); in.lams.swap(in.tlams);
     in.stats.alpha = alpha; in.stats.ls_steps = step; in.stats.num_iters += 1;
     return 0;
@@ -1034,12 +1048,15 @@ struct Solver {
     for (int it = 0; it < R; ++it) {
       eval_knot(b_inst, N - 1, in.xs[N - 1].data(), in.us[N - 1].data(), in.xs[N].data(), kn, true);
       const int m = kn.m, nz = n + m;
-      if (m <= 0) return;
+      // an abandoned step leaves the control as it is; the remaining steps and the final x_N = phi(x_{N-1}, u_{N-1}) still run (as the launches of
+      // csrc/mpc_hip.hip launch_refine do: k_refine_knot returns from ITS step only)
+      if (m <= 0 || m > 48) continue;
       std::vector<double> Lr((size_t)m * m), w(m);
       for (int i = 0; i < m; ++i) {
         w[i] = kn.grad[n + i];
         for (int j = 0; j < m; ++j) Lr[(size_t)i * m + j] = 0.5 * (kn.H[(size_t)(n + i) * nz + n + j] + kn.H[(size_t)(n + j) * nz + n + i]);
       }
+      bool bad = false;
       std::vector<int> act;
       std::vector<double> v;
       for (int r = 0; r < kn.c; ++r) {
@@ -1048,8 +1065,8 @@ struct Solver {
         if (a_) { act.push_back(r); v.push_back(pn); }
       }
       const int ca = (int)act.size();
-      if (ca > 48) return;  // (the HIP kernel's LDS carve-out)
-      if (!chol_lower(Lr.data(), m)) return;  // (an indefinite knot Hessian: the warm start stays as it is)
+      if (ca > 48) continue;  // (the HIP kernel's LDS carve-out)
+      if (!chol_lower(Lr.data(), m)) continue;  // (an indefinite knot Hessian: this step leaves the control as it is)
       trsm_lower(Lr.data(), m, w.data(), 1);
       std::vector<double> Y((size_t)m * std::max(ca, 1)), nu(std::max(ca, 1), 0.0);
       if (ca > 0) {
@@ -1065,12 +1082,16 @@ struct Solver {
           for (int i = 0; i < m; ++i) t -= Y[(size_t)i * ca + q] * w[i];
           nu[q] = t;
         }
-        if (!chol_lower(S.data(), ca)) return;
+        if (!chol_lower(S.data(), ca)) { bad = true; }
+        if (!bad) {
         trsm_lower(S.data(), ca, nu.data(), 1); trsm_lower_t(S.data(), ca, nu.data(), 1);
         for (int i = 0; i < m; ++i) { double t = w[i]; for (int q = 0; q < ca; ++q) t += Y[(size_t)i * ca + q] * nu[q]; w[i] = t; }
+        }
       }
+      if (bad) continue;
       trsm_lower_t(Lr.data(), m, w.data(), 1);
-      for (int i = 0; i < m; ++i) if (!std::isfinite(w[i])) return;
+      for (int i = 0; i < m; ++i) if (!std::isfinite(w[i])) bad = true;
+      if (bad) continue;
       for (int i = 0; i < m; ++i) in.us[N - 1][i] -= w[i];
     }
     eval_knot(b_inst, N - 1, in.xs[N - 1].data(), in.us[N - 1].data(), in.xs[N].data(), kn, false);
@@ -1104,10 +1125,17 @@ struct Solver {
     update_tols_on_failure(in);
     in.inner_tol = std::max(in.inner_tol, opt.tol); in.prim_tol = std::max(in.prim_tol, opt.tol);
     int stalls = 0;
-    while (in.stats.al_iters < opt.max_al_iters && in.stats.num_iters < opt.max_iters) {
+    // mpc_options.corrector_prim_tol: when the iteration budget ends with an iteration that STARTED from an iterate infeasible by more than the
+    // tolerance (stats.prim_infeas is measured before the step) or whose step had to be shortened (alpha < 1), the instance takes one more
+    // iteration — once per run (k_after_step of
+    // csrc/solver_kernels.h: the same rule)
+    int max_it = opt.max_iters;
+    bool corrected = false;
+    while (in.stats.al_iters < opt.max_al_iters && in.stats.num_iters < max_it) {
       bool inner_conv = false, via_stall = false;
-      while (in.stats.num_iters < opt.max_iters) {
+      while (in.stats.num_iters < max_it) {
         const int r = iterate(in);
+        if (r == 0 && !corrected && corrector_armed && opt.corrector_prim_tol > 0.0 && in.stats.num_iters >= opt.max_iters && (in.stats.prim_infeas > opt.corrector_prim_tol || in.stats.alpha < 1.0)) { corrected = true; ++max_it; }
         if (r == 0) { stalls = 0; continue; }
         inner_conv = true;
         if (r == 2) { via_stall = true; ++stalls; }

@@ -13,6 +13,9 @@ REBUILT_HERE = False
 
 def load():
     global _lib
+    if _lib is None and os.environ.get("MPC_CPU_PORT_LIBRARY"):  # e.g. the sanitizer build (oracle/cpu_port/Makefile: asan-test)
+        from mpc_benchmark_amd import _capi
+        _lib = _capi.bind_library(os.environ["MPC_CPU_PORT_LIBRARY"])
     if _lib is None:
         deps = [os.path.join(PORT_DIR, f) for f in os.listdir(PORT_DIR) if f.endswith((".cpp", ".hpp"))]
         deps += [os.path.join(ROOT, "oracle", f) for f in os.listdir(os.path.join(ROOT, "oracle")) if f.endswith((".cpp", ".hpp"))]

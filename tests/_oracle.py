@@ -44,6 +44,9 @@ def build():
 
 def load():
     global _lib
+    if _lib is None and os.environ.get("MPC_ORACLE_LIBRARY"):  # e.g. the sanitizer build (oracle/Makefile: asan-test)
+        from mpc_benchmark_amd import _capi
+        _lib = _capi.bind_library(os.environ["MPC_ORACLE_LIBRARY"])
     if _lib is None:
         srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".hpp"))]
         stale = (not os.path.exists(ORACLE_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in srcs)

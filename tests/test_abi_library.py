@@ -50,7 +50,7 @@ def test_product_has_no_cpu_fallback(monkeypatch):
 
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_capi.MpcDims) == 10 * 4
-    assert ctypes.sizeof(_capi.MpcOptions) == 14 * 8 + 9 * 4 + 4  # (nine int32 fields, padded to the alignment of the doubles)
+    assert ctypes.sizeof(_capi.MpcOptions) == 15 * 8 + 10 * 4  # (fifteen doubles, ten int32 fields)
     assert ctypes.sizeof(_capi.MpcStats) == 4 * 4 + 6 * 8
 
 

@@ -1,0 +1,75 @@
+"""``mpc_options.corrector_prim_tol`` / ``corrector_window`` (include/mpc_abi.h) on the CPU oracle: a run whose iteration budget ends with an
+iteration that started from an iterate infeasible by more than the tolerance — or whose step was shortened by the linesearch — takes ONE
+more iteration; with a window only on the runs that follow a change of the contact pattern of the appended stage.  The rule the HIP
+library implements on the device (k_after_step) is held to this one in tests/test_gpu_corrector.py."""
+import numpy as np
+
+from mpc_benchmark_amd.ensemble import EnsembleMPC
+from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+
+HORIZON = 6
+
+
+def _ens(lib, tol, window=0, batch=1):
+    e = EnsembleMPC(FullDynamicsProblem(horizon=HORIZON), batch=batch, library=lib, seed=5, sigma_q=0.003, sigma_v=0.006)
+    e.options.riccati_legs = 1
+    e.options.num_threads = 8
+    e.options.corrector_prim_tol = tol
+    e.options.corrector_window = window
+    e.native.set_options(e.options)
+    e.prepare_schedule(40)
+    return e
+
+
+def test_mirror_default_is_on():
+    from mpc_benchmark_amd.aligator import _solver
+    s = _solver.SolverProxDDP(1e-5, 1e-8)
+    o = s._options()
+    assert o.corrector_prim_tol == _solver.DEFAULT_CORRECTOR_PRIM_TOL > 0 and o.corrector_window == 0
+    s.corrector_prim_tol = 0.0
+    assert s._options().corrector_prim_tol == 0.0
+
+
+def test_one_extra_iteration_exactly_when_the_rule_says(oracle_lib):
+    """Tick by tick from the same solver state: the handle without the corrector reports what the FIRST iteration saw (primal infeasibility
+    of the warm start, accepted step length); the handle with it must have taken two iterations exactly when that exceeds the tolerance or
+    the step was shortened — and then ends where two plain iterations end."""
+    tol = 5.0
+    off, on, two = _ens(oracle_lib, 0.0), _ens(oracle_lib, tol), _ens(oracle_lib, 0.0)
+    two.iters_per_tick = 2
+    for e in (off, on, two):
+        e.cold_solve(max_iters=100)
+    fired = []
+    for t in range(34):  # the first single-support stage is appended at tick 30 (T_ds) of the schedule: the duplicated control violates it
+        state = on.native.get_state()
+        off.native.set_state(state); two.native.set_state(state)
+        s_off, s_on, s_two = off.step()[0], on.step()[0], two.step()[0]
+        expect = s_off.prim_infeas > tol or s_off.alpha < 1.0
+        assert s_off.num_iters == 1
+        assert s_on.num_iters == (2 if expect else 1), (t, s_off.prim_infeas, s_off.alpha, s_on.num_iters)
+        ref = (two if expect else off).results(gains=True)
+        got = on.results(gains=True)
+        for key in ("xs", "us", "K"):
+            assert np.array_equal(got[key], ref[key]), (t, key)
+        if expect:
+            fired.append(t)
+    assert 30 in fired and len(fired) <= 6, fired  # (the pattern change and at most a few ticks after it)
+
+
+def test_window_limits_the_rule_to_the_runs_after_a_pattern_change(oracle_lib):
+    """corrector_window = K: with a tolerance every tick exceeds, two iterations on the K runs after the appended stage changed its contact
+    pattern (ticks 30, 31 of the schedule for K = 2) and one everywhere else; the counter survives a checkpoint (mpc_get_state / mpc_set_state)."""
+    e = _ens(oracle_lib, 1e-9, window=2)
+    e.cold_solve(max_iters=100)
+    iters = []
+    state31 = None
+    for t in range(34):
+        if t == 31:
+            state31, tick31 = e.native.get_state(), e.tick
+        iters.append(e.step()[0].num_iters)
+    assert [t for t, n in enumerate(iters) if n == 2] == [30, 31], iters
+    f = _ens(oracle_lib, 1e-9, window=2)  # a fresh handle continues from the checkpoint taken inside the window
+    f.options.max_iters = 1
+    f.native.set_options(f.options)
+    f.native.set_state(state31); f.tick = tick31
+    assert [f.step()[0].num_iters for _ in range(2)] == [2, 1]

@@ -74,6 +74,7 @@ def _check_stage_kinds(lib, name):
         solver = pd.make_solver(_native_library=lib)
         solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL
         solver.max_iters = 1
+        solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
         solver.setup(prob)
         xn = g["eval_%s_xnext" % kname] if "eval_%s_xnext" % kname in g else x
         solver.run(prob, [x, xn], [u])

@@ -42,6 +42,7 @@ def _run_one_iteration(lib, complete_model=False, seed=11, parallel=False):
     else:
         solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL  # the raw gains of a parallel-in-time leg depend on its guess of the cut Hessian: the gain dumps are compared on the serial sweep (tests/test_gpu_legs.py covers the leg kernels)
     solver.max_iters = 1
+    solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
     solver.setup(prob)
     rng = np.random.default_rng(seed)
     xs = [fp.space.integrate(fp.x0, 0.03 * rng.standard_normal(fp.space.ndx)) for _ in range(len(PATTERN) + 1)]
@@ -125,6 +126,7 @@ def test_mpc_ticks_with_cycling_and_references(hip_lib, oracle_lib):
         xs, us = fp.initial_guess()
         solver.run(prob, xs, us)
         solver.max_iters = 1
+        solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
         xs, us = list(solver.results.xs), list(solver.results.us)
         lf, rf = fp.robot.foot_placements
         hist = []

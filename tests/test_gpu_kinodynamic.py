@@ -27,6 +27,7 @@ def _run_one_iteration(lib, complete_model, seed=3):
     solver = kp.make_solver(_native_library=lib)
     solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL  # per-phase parity of the SERIAL sweep: the raw gains of a parallel-in-time leg depend on its guess of the cut Hessian (tests/test_gpu_legs.py covers the legs)
     solver.max_iters = 1
+    solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
     solver.setup(prob)
     rng = np.random.default_rng(seed)
     xs = [kp.space.integrate(kp.x0, 0.03 * rng.standard_normal(kp.space.ndx)) for _ in range(len(PATTERN) + 1)]

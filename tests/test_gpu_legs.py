@@ -39,6 +39,7 @@ def _one_iteration(lib, kind, N, legs, complete=False, seed=5):
     solver.setNumThreads(legs)
     solver.riccati_legs = legs  # (the GPU picks its own number of legs otherwise: SolverProxDDP._legs)
     solver.max_iters = 1
+    solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
     solver.setup(prob)
     xs, us = pd.initial_guess()
     rng = np.random.default_rng(seed)
@@ -188,6 +189,7 @@ def test_cold_solve_and_mpc_ticks_with_legs(hip_lib, oracle_lib, legs):
         r = solver.results
         tr = [(np.array(r.xs), np.array(r.us), conv, r.num_iters)]
         solver.max_iters = 1
+        solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
         xs, us = list(r.xs), list(r.us)
         for _ in range(4):
             xs = xs[1:] + [xs[-1]]; us = us[1:] + [us[-1]]
@@ -218,6 +220,7 @@ def test_full_size_workload_with_legs(hip_lib, oracle_lib, nlegs):
             solver.setNumThreads(legs)
             solver.riccati_legs = legs  # (the GPU picks its own number of legs otherwise: SolverProxDDP._legs)
         solver.max_iters = 1
+        solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
         solver.setup(prob)
         rng = np.random.default_rng(9)
         xs = [fp.space.integrate(fp.x0, 0.01 * rng.standard_normal(fp.space.ndx)) for _ in range(101)]
@@ -272,6 +275,7 @@ def test_unconstrained_and_flight_stages_with_legs(hip_lib, oracle_lib):
         solver.setNumThreads(L)
         solver.riccati_legs = L  # (the GPU picks its own number of legs otherwise: SolverProxDDP._legs)
         solver.max_iters = 1
+        solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
         solver.setup(prob)
         rng = np.random.default_rng(5)
         xs = [fp.space.integrate(fp.x0, 0.02 * rng.standard_normal(fp.space.ndx)) for _ in range(len(pattern) + 1)]

@@ -32,6 +32,7 @@ def test_riccati_step_equals_dense_kkt_centroidal(oracle_lib):
         prob.replaceStageCircular(cp.stage_for_tick(t + 15))  # brings single-support stages in
     solver = cp.make_solver(_native_library=oracle_lib)
     solver.max_iters = 1
+    solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
     solver.setup(prob)
     xs, us = cp.initial_guess()
     rng = np.random.default_rng(5)
@@ -50,6 +51,7 @@ def test_riccati_step_equals_dense_kkt_fulldynamics(oracle_lib):
     prob.addTerminalConstraint(fp.terminal_com_constraint(fp.robot.com0 + 0.01))
     solver = fp.make_solver(_native_library=oracle_lib)
     solver.max_iters = 1
+    solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
     solver.setup(prob)
     rng = np.random.default_rng(2)
     xs = [fp.space.integrate(fp.x0, 0.03 * rng.standard_normal(fp.space.ndx)) for _ in range(5)]
@@ -73,6 +75,7 @@ def test_cold_solve_converges_to_tolerance(oracle_lib, kind):
     assert np.allclose(r.xs[0], prob.x0_init)
     # a converged solution is a fixed point: one more iteration from it does not move
     solver.max_iters = 1
+    solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
     xs2, us2 = list(r.xs), list(r.us)
     solver.setup(prob)
     solver.run(prob, xs2, us2)

@@ -58,6 +58,7 @@ def test_mutations_reach_the_native_tables(oracle_lib):
     prob = cp.build()
     solver = cp.make_solver(_native_library=oracle_lib)
     solver.max_iters = 1
+    solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
     solver.setup(prob)
     xs, us = cp.initial_guess()
     solver.run(prob, xs, us)
@@ -80,6 +81,7 @@ def test_mutations_reach_the_native_tables(oracle_lib):
     prob2 = aligator.TrajOptProblem(cp2.x0, stages, aligator.CostStack(cp2.space, cp2.nu))
     s2 = cp2.make_solver(_native_library=oracle_lib)
     s2.max_iters = 1
+    s2.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
     s2.setup(prob2)
     s2.run(prob2, xs, us)
     assert np.allclose(np.array(s2.results.us), moved, rtol=1e-12, atol=1e-12)
@@ -122,6 +124,7 @@ def test_edited_warm_start_is_not_taken_for_the_shift(oracle_lib):
         prob = fp.build()
         solver = fp.make_solver(_native_library=oracle_lib)
         solver.max_iters = 1
+        solver.corrector_prim_tol = 0.0  # exactly one iteration: the corrector (include/mpc_abi.h) has its own tests
         solver.setup(prob)
         xs, us = fp.initial_guess()
         solver.run(prob, xs, us)

@@ -14,22 +14,26 @@ for refs in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("frozen", "shared
         pd = FullDynamicsProblem(horizon=100, complete_model=True)
         (e,) = make_bench_shards(pd, lib, 64, legs=4, tick_reuse=True)
         e.options.refine_appended_knot = R
+        e.options.corrector_prim_tol = float(os.environ.get("CORRECTOR", "20"))
+        e.options.corrector_window = int(os.environ.get("WINDOW", "0"))
         e.native.set_options(e.options)
         e.prepare_schedule(pd.t_mpc + 4)
         e.cold_solve(max_iters=100)
         e.enable_failure_isolation(auto_revive=True, source=0)
         if refs != "frozen":
             e.enable_walk(per_instance=(refs == "instance"))
-        t0 = time.time(); worst = 0.0; nominal_lost = False
+        t0 = time.time(); worst = 0.0; nominal_lost = False; extra = 0; extra_ticks = 0; back = 0
         for t in range(ticks):
             e.step_async()
             if e.inflight == 2:
                 st = e.wait()
                 worst = max([worst] + [s.prim_infeas for s in st if s.converged >= 0])
+                nx = sum(1 for s in st if s.num_iters > 1); extra += nx; extra_ticks += 1 if nx else 0
+                back += sum(1 for s in st if s.alpha < 1.0 and s.converged >= 0)
                 if st[0].converged < 0 and not nominal_lost:
                     nominal_lost = True; print("   (the nominal instance failed at tick %d)" % t, flush=True)
         while e.inflight:
             e.wait()
-        print("references %-8s refine_appended_knot %d: %3d instance losses in %d ticks (first at tick %s; instances %s) ; largest primal infeasibility before a step %.2e ; %.1f s" % (
-            refs, R, len(e.lost), ticks, e.lost[0][0] if e.lost else "-", sorted(set(r[1] for r in e.lost))[:12], worst, time.time() - t0), flush=True)
+        print("references %-8s refine_appended_knot %d: %3d instance losses in %d ticks (first at tick %s; instances %s) ; largest primal infeasibility before a step %.2e ; corrector %g: %d instance-ticks on %d ticks, %d backtracking instance-ticks ; %.1f s" % (
+            refs, R, len(e.lost), ticks, e.lost[0][0] if e.lost else "-", sorted(set(r[1] for r in e.lost))[:12], worst, e.options.corrector_prim_tol, extra, extra_ticks, back, time.time() - t0), flush=True)
         del e
