@@ -188,6 +188,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-worker", type=int, default=0, help="(internal) run this many MPC ticks of one instance on the CPU port with 8 threads and print their times")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-whole-schedule", action="store_true", help="skip the walk over the reference's whole 1000-tick schedule (`whole_schedule` in the JSON line, ~10 s per run)")
     ap.add_argument("--aligator", action="store_true", help="time the real aligator.SolverProxDDP on the identical problem instead (where the reference stack is importable) and exit")
     args = ap.parse_args()
 
@@ -450,6 +451,59 @@ def main():
         return dict(shards=shards, ens=ens, legs=legs, cold=cold, n_conv=n_conv, n_conv100=n_conv100, worst_unconv=worst_unconv, regions=regions, nostep=nostep["n"], corrector_ticks=nostep["extra"], backtracking_ticks=nostep["back"], pace=pace, stagger=stagger, elapsed=elapsed,
                     prof=prof, warm=warm, gather=gather, replanning_ticks=replanning)
 
+    def whole_schedule(corrector, refine):
+        """The reference's WHOLE schedule (t_mpc - 1 ticks of fulldynamic_talos.py:438-550: seven swings) walked by the benchmarked ensemble in the
+        headline's mode — two ticks in flight, per-tick time = interval between the completions of consecutive ticks — instead of a window of it:
+        pattern-change ticks, contact switches at knot 0, backtracking and corrector ticks are all inside."""
+        (e,) = make_bench_shards(pd, lib, args.batch, rank=rank, world=world, streams=1, device=local_rank, legs=args.legs, tick_reuse=not args.no_tick_reuse)
+        e.iters_per_tick = int(args.iters_per_tick)
+        e.options.refine_appended_knot = int(refine)
+        e.options.corrector_prim_tol = float(corrector)
+        e.options.corrector_window = int(args.corrector_window)
+        e.native.set_options(e.options)
+        ticks = pd.t_mpc - 1
+        e.prepare_schedule(pd.t_mpc + 4)
+        e.cold_solve(max_iters=args.cold_iters)
+        e.enable_failure_isolation(auto_revive=True, source=0)
+        if not args.no_walk:
+            e.enable_walk(per_instance=(args.walk_refs == "instance"))
+        e.results(gains=False)
+        ms, back_t, corr_t, corr_it, back_it, nostep_it, nominal_lost = [], 0, 0, 0, 0, 0, False
+
+        def collect(st, t_done, t_prev):
+            nonlocal back_t, corr_t, corr_it, back_it, nostep_it, nominal_lost
+            ms.append((t_done - t_prev) * 1e3)
+            live = [x for x in st if x.converged >= 0]
+            nb = sum(1 for x in live if x.num_iters > 0 and x.alpha < 1.0)
+            nc = sum(1 for x in live if x.num_iters > e.iters_per_tick)
+            back_it += nb; corr_it += nc; back_t += 1 if nb else 0; corr_t += 1 if nc else 0
+            nostep_it += sum(1 for x in st if x.num_iters == 0)
+            nominal_lost = nominal_lost or st[0].converged < 0
+
+        t_begin = t_prev = time.perf_counter()
+        for _ in range(ticks):
+            e.step_async()
+            if e.inflight == 2:
+                st = e.wait()
+                now = time.perf_counter()
+                collect(st, now, t_prev); t_prev = now
+        while e.inflight:
+            st = e.wait()
+            now = time.perf_counter()
+            collect(st, now, t_prev); t_prev = now
+        total = time.perf_counter() - t_begin
+        v = np.sort(np.asarray(ms[2:]))  # (the first two intervals fill the pipeline)
+        pct = lambda q: round(float(v[int(q * (len(v) - 1))]), 4)
+        lost = sorted(set(int(r[1]) for r in e.lost))
+        out = {"ticks": ticks, "solves_per_sec": round((args.batch * ticks - nostep_it) / total, 2), "ms_per_tick": {"mean": round(total / ticks * 1e3, 4), "p50": pct(0.5), "p90": pct(0.9), "p95": pct(0.95), "max": round(float(v[-1]), 4)},
+               "backtracking_ticks": back_t, "backtracking_instance_ticks": back_it, "corrector_ticks": corr_t, "corrector_instance_ticks": corr_it,
+               "refinement_ticks": (sum(1 for t in range(1, ticks + 1) if tuple(pd.contact_phases[t % pd.t_mpc]) != tuple(pd.contact_phases[(t - 1) % pd.t_mpc])) if refine > 0 else 0),
+               "instance_losses": len(e.lost), "instances_lost": lost[:16], "nominal_instance_lost": bool(nominal_lost or 0 in lost),
+               "settings": {"corrector_prim_tol": float(corrector), "refine_appended_knot": int(refine), "iters_per_tick": int(args.iters_per_tick),
+                            "references": ("frozen" if args.no_walk else args.walk_refs), "feedback": "perfect model", "lost instances": "re-seeded from the nominal one (mpc_revive_instance)"}}
+        del e
+        return out
+
     modes = [True] if args.walk else ([False] if args.no_walk else [False, True])
     runs = {}
     for walk in modes:
@@ -511,6 +565,7 @@ def main():
                 traffic = int(ent["hbm_bytes"])
         roof = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": (os.path.relpath(tf, ROOT) + " (separate rocprofv3 --pmc passes of the same workload, tools/gpu_profile_round.sh: counters cannot be read from inside this process)") if traffic is not None else None,
                 "avg_kernel_ms": round(total_ms / launches, 4), "algorithmic_bytes_per_launch": int(bytes_per_launch),
                 "shards_in_flight": nshard,  # one launch serves one shard; the shards' launches overlap on the device
                 # supplementary, per GPU: the algorithmic bytes of ALL launches of this kernel in the timed region over the
@@ -560,6 +615,14 @@ def main():
         ach = fl / (roof["avg_kernel_ms"] * 1e-3) / 1e12
         mfma = {"bound": "mfma", "kernel": roof["kernel"], "achieved": round(ach, 3), "peak": 78.6, "unit": "TFLOP/s", "frac": round(ach / 78.6, 5),
                 "busy_cus": min(256, args.batch // nshard * legs), "frac_of_busy_cus": round(ach / (78.6 * min(256, args.batch // nshard * legs) / 256.0), 5)}
+
+    # ---- the whole schedule instead of a window (one run with the headline's settings; one with the corrector off = the reference loop's exact
+    # iteration budget, for the record of what that loses) ----
+    whole = whole_ref = None
+    if not args.no_whole_schedule and world == 1:
+        whole = whole_schedule(args.corrector_prim_tol, args.refine_appended_knot)
+        if args.corrector_prim_tol > 0 or args.refine_appended_knot != 0:
+            whole_ref = whole_schedule(0.0, 0)
 
     # ---- batch = 1 latency (BASELINE.json config: batch=1 on one MI355X) ----
     p50_ms = p90_ms = p95_ms = None
@@ -622,8 +685,9 @@ def main():
         "config": {"workload": "Talos full-dynamics MPC (fulldynamic_talos.py OCP), synthetic Talos %s model nq=%d nv=%d nu=%d, "
                                "horizon N=%d, ensemble of %d instances per GPU, %d ProxDDP iteration(s) per solve (max_iters=%d, warm start shifted on the device%s)"
                                % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch, args.iters_per_tick, args.iters_per_tick,
-                                  ", control of the appended knot refined on contact-pattern changes: refine_appended_knot=%d" % args.refine_appended_knot if args.refine_appended_knot > 0 else ""),
-                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "riccati_legs": legs, "tick_reuse": not args.no_tick_reuse, "refine_appended_knot": args.refine_appended_knot, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
+                                  (", control of the appended knot refined on contact-pattern changes: refine_appended_knot=%d" % args.refine_appended_knot if args.refine_appended_knot > 0 else "")
+                                  + (", corrector iteration when the warm start is infeasible by more than %g or the step backtracks" % args.corrector_prim_tol if args.corrector_prim_tol > 0 else "")),
+                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "riccati_legs": legs, "tick_reuse": not args.no_tick_reuse, "refine_appended_knot": args.refine_appended_knot, "corrector_prim_tol": args.corrector_prim_tol, "corrector_window": args.corrector_window, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
         "p50_ms_per_solve_batch1": p50_ms, "p90_ms_per_solve_batch1": p90_ms, "p95_ms_per_solve_batch1": p95_ms, "latency_ticks": (300 if p50_ms is not None else 0), "p50_riccati_legs": (args.latency_legs if args.legs != 1 else 1),
         # which instantiations of the hot kernels served the run (dimensions as compile-time constants; MPC_HIP_GENERIC_DIMS=1 forces the generic ones)
@@ -646,6 +710,7 @@ def main():
         "instances_lost_and_revived": sum(getattr(e, "revived", 0) for e in shards),
         "episode_ticks": args.episode, "episode_restarts": sum(getattr(e, "episodes", 0) for e in shards),
         "ensemble_allgather": gather,
+        "whole_schedule": whole, "whole_schedule_exact_iteration_budget": whole_ref,
         "roofline": roof, "cpu_baseline": cpu, "roofline_riccati": roof_ric,
         # supplementary: the same kernel against the fp64 matrix-core peak (the sweep is a chain of dependent dense steps on ONE CU
         # per instance, not a streaming kernel — DESIGN.md §5); flops = textbook count of the recursion on the unpadded dimensions

@@ -147,7 +147,14 @@ class Workspace:
         """Data rotation is implicit in the native ring buffer (fulldynamic_talos.py:497)."""
 
 
-DEFAULT_CORRECTOR_PRIM_TOL = 20.0  # N, N m, rad: a contact switch in the appended stage injects 100 - 300, an ordinary tick < 10
+import os as _os
+
+# mpc_options.corrector_prim_tol of a freshly constructed solver.  0 = off: a run takes exactly max_iters iterations, as the reference's.
+# The robust setting for ensembles of perturbed robots driven on an iteration budget of one is 20.0 (N, N m, rad: a contact switch in the
+# appended stage injects 100 - 300, an ordinary tick < 10) together with refine_appended_knot = 3 — what bench.py runs (DESIGN.md section 5).
+# (MPC_DEFAULT_CORRECTOR: developer override.)
+DEFAULT_CORRECTOR_PRIM_TOL = float(_os.environ.get("MPC_DEFAULT_CORRECTOR", "0.0"))
+ROBUST_CORRECTOR_PRIM_TOL = 20.0
 
 
 class SolverProxDDP:
@@ -164,9 +171,9 @@ class SolverProxDDP:
         self.riccati_legs = None  # None: chosen by _legs()
         self.refine_appended_knot = 0  # mpc_options.refine_appended_knot (this build's extension: 0 = the scripts' plain warm-start shift)
         # mpc_options.corrector_prim_tol / corrector_window (this build's globalisation of an iteration budget of one, include/mpc_abi.h): a run
-        # whose last iteration started from an iterate infeasible by more than this takes one more iteration.  ON by default — it is what lets
-        # the reference's loops (max_iters = 1, fulldynamic_talos.py:407) and ensembles of perturbed robots survive the ticks on which the
-        # duplicated control of the warm-start shift meets a stage of another contact pattern; 0 switches it off.
+        # whose last iteration started from an iterate infeasible by more than this, or whose step was shortened, takes one more iteration.
+        # Off by default (the reference's loops, nominal robot, closed loop, run to their last line without it: tools/check_dropin.py);
+        # ROBUST_CORRECTOR_PRIM_TOL is what keeps ensembles of perturbed robots walking.
         self.corrector_prim_tol = DEFAULT_CORRECTOR_PRIM_TOL
         self.corrector_window = 0  # every run (ensembles driven asynchronously use a window: EnsembleMPC)
         self.batch = 1

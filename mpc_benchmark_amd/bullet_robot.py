@@ -7,9 +7,11 @@ What it simulates: the CONTROLLED joints of the complete model (the others stay 
 ``initializeJoints`` — in PyBullet they are held by the default position controller, bullet_robot.py:71-73), one semi-implicit Euler step
 of ``simuStep`` per ``execute(torques)``, with the feet that stand on the ground held by 6-D rigid contacts with Baumgarte correction
 (the contact model of fulldynamic_talos.py:84-96).  A foot is "on the ground" while its sole is within ``ground_tol`` of the ground
-plane z = 0 ... and pushes on it: a contact whose normal force turns negative is released, a free foot that has left the ground and comes back
-to it is caught there (its world-side placement is re-captured at the landing pose).  That is a deliberately simple contact rule — enough to
-close the loop around the MPC headlessly and deterministically; it is not a physics engine.
+plane z = 0 ... and pushes on it: a contact whose normal force stays below ``-release_force`` for ``release_steps`` consecutive steps is released (a one-step
+transient — the torque jump of the low-level QP when a stage changes its contact state — only unloads a real sole for a millisecond, it does not
+lift it), a free foot that has left the ground and comes back to it, or that sinks below the ground plane, is caught there (its world-side
+placement is re-captured at the landing pose).  That is a deliberately simple contact rule — enough to close the loop around the MPC headlessly
+and deterministically; it is not a physics engine.
 
 Differences from PyBullet worth knowing: ``measureState`` returns the base velocity in the LOCAL frame of the base (Pinocchio's
 convention, which is what the scripts assume when they copy it into the state, talos_utils.py:337-348); PyBullet reports it in the
@@ -36,7 +38,7 @@ class BulletRobot:
     record_default = False  # tools: keep (state, contact flags, sole heights) of every step in ``history``
 
     def __init__(self, controlledJoints, modelPath=None, URDF_filename=None, simuStep=1e-3, rmodelComplete=None, robotPose=(0.0, 0.0, 1.01927),
-                 inertiaOffset=True, talos=True, library=None, contact_frames=("left_sole_link", "right_sole_link"), ground_tol=5e-3):
+                 inertiaOffset=True, talos=True, library=None, contact_frames=("left_sole_link", "right_sole_link"), ground_tol=5e-3, release_steps=5, release_force=1.0):
         if rmodelComplete is None:
             raise ValueError("the complete robot model is needed (5th positional argument, as in the scripts)")
         self._lib = library
@@ -45,6 +47,8 @@ class BulletRobot:
         self.controlled = [n for n in controlledJoints if n not in ("universe", "root_joint")]
         self.contact_frames = tuple(contact_frames)
         self.ground_tol = float(ground_tol)
+        self.release_steps = int(release_steps)
+        self.release_force = float(release_force)  # N: the ground "pulls" when the normal force is below minus this
         self.robotPose = np.asarray(robotPose, dtype=float)
         self.localInertiaPos = np.zeros(3)
         self._native = None
@@ -52,6 +56,7 @@ class BulletRobot:
         self.markers = None
         self.camera = None
         self.steps = 0
+        self.trace_from = None     # tools: print contact forces from this step on
         self.max_steps = None      # tools: stop a script's endless loop after this many execute() calls
         self.history = []          # (q, v) after every step when ``record`` is set
         self.record = bool(self.record_default)
@@ -80,6 +85,7 @@ class BulletRobot:
         self.in_contact = [True, True]
         self._z_prev = [float(self.data.oMf[f].translation[2]) for f in self.frame_ids]
         self._lifted = [False, False]
+        self._pulling = [0, 0]   # consecutive steps with a negative normal force
         self._contact_pose = [self.data.oMf[f].copy() for f in self.frame_ids]
         self._build_native()
 
@@ -148,6 +154,9 @@ class BulletRobot:
         x, wr = self._native.simulate_torque(self.x, tau, 1, self.dt, wrenches=True)
         self.x = x[0]
         self.steps += 1
+        if self.trace_from is not None and self.steps >= self.trace_from:
+            import sys
+            sys.stderr.write("   [sim] step %d in_contact %s fz L %.2f R %.2f z %s\n" % (self.steps, self.in_contact, wr[0][0][2], wr[0][1][2], ["%.4f" % v for v in self._z_prev]))
         self._update_contacts(wr[0])
         if self.record:
             self.history.append((self.x.copy(), tuple(self.in_contact), tuple(self._z_prev)))
@@ -161,12 +170,14 @@ class BulletRobot:
         for i, fid in enumerate(self.frame_ids):
             z = float(self.data.oMf[fid].translation[2])
             if self.in_contact[i]:
-                if wrenches[i][2] < 0.0 and sum(self.in_contact) > 1:
+                self._pulling[i] = self._pulling[i] + 1 if wrenches[i][2] < -self.release_force else 0  # (an unloaded sole, 0 +- round-off, rests on the ground)
+                if self._pulling[i] >= self.release_steps and sum(self.in_contact) > 1:
                     self.in_contact[i] = False
                     self._lifted[i] = False
+                    self._pulling[i] = 0
             elif z > self.ground_z + 2.0 * self.ground_tol:
-                self._lifted[i] = True  # (a released foot is caught again only after it has really left the ground)
-            elif z <= self.ground_z + self.ground_tol and self._lifted[i]:
+                self._lifted[i] = True  # (a released foot is caught again only after it has really left the ground ...)
+            elif (z <= self.ground_z + self.ground_tol and self._lifted[i]) or (z < self.ground_z and z < self._z_prev[i]):  # (... or sinks into it)
                 pose = self.data.oMf[fid].copy()
                 pose.translation[2] = self.ground_z
                 yaw = np.arctan2(pose.rotation[1, 0], pose.rotation[0, 0])

@@ -128,7 +128,11 @@ def bezier_eval(control_points, s):
     binom = _BINOM8 if m == 8 else np.array([comb(m, i) for i in range(m + 1)], dtype=float)
     i = np.arange(m + 1)
     basis = binom[None, :] * s[:, None] ** i[None, :] * (1.0 - s[:, None]) ** (m - i)[None, :]  # Bernstein
-    out = basis @ P.T
+    # the control points are added one after the other: the same bits whether one parameter value is evaluated or a hundred (a matrix
+    # product rounds differently for different shapes — a one-by-one evaluation, as talos_utils.py:303-318 makes it, must equal the batched one)
+    out = np.zeros((s.size, P.shape[0]))
+    for j in range(m + 1):
+        out += basis[:, j:j + 1] * P[:, j][None, :]
     return out[0] if out.shape[0] == 1 else out
 
 

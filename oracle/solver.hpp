@@ -130,6 +130,7 @@ struct Solver {
   std::vector<std::vector<std::vector<double>>> inst_params;  // [B][N + 1]: per-instance parameter tables, empty = shared (mpc_enable_instance_params)
   std::string err;
   bool have_model = false;
+  double x_ratio = 1.0;
   bool corrector_armed = true;  // mpc_options.corrector_window: set per run by the C-ABI layer (capi.cpp), which sees the mpc_cycle calls
 
   int N() const { return dims.horizon; }
@@ -938,14 +939,6 @@ struct Solver {
     in.stats.traj_cost = cost; in.stats.merit = phi0; in.stats.prim_infeas = prim; in.stats.dual_infeas = dual; in.stats.mu = in.mu;
     if (std::getenv("MPC_ORACLE_DEBUG")) fprintf(stderr, "it %d: cost %.10e merit %.10e prim %.3e dual %.3e crit %.3e (inner_tol %.3e) mu %.1e\n", in.stats.num_iters, cost, phi0, prim, dual, crit, in.inner_tol, in.mu);
     if (crit <= in.inner_tol) return 1;
-    static const int x_retry = std::getenv("MPC_X_RETRY") ? std::atoi(std::getenv("MPC_X_RETRY")) : 0;
-    static const double x_fac = std::getenv("MPC_X_RETRY_FAC") ? std::atof(std::getenv("MPC_X_RETRY_FAC")) : 10.0;
-    static const double x_floor = std::getenv("MPC_X_RETRY_FLOOR") ? std::atof(std::getenv("MPC_X_RETRY_FLOOR")) : 1e-6;
-    static const int x_fail = std::getenv("MPC_X_FAIL") ? std::atoi(std::getenv("MPC_X_FAIL")) : 0;
-    static const int x_uonly = std::getenv("MPC_X_UONLY") ? std::atoi(std::getenv("MPC_X_UONLY")) : 0;
-    double reg_extra = 0.0, alpha = 1.0, phi = 0.0, dphi0 = 0.0;
-    int step = 0; bool ok = false;
-    for (int attempt = 0;; ++attempt) {
     if (nlegs() > 1) {
       std::vector<LegLink> links;
       std::vector<std::vector<double>> ptil, calP;
@@ -974,27 +967,26 @@ struct Solver {
       backward(in);
       forward(in);
     }
-    dphi0 = dmerit(in);
-    if (attempt == 0 && std::fabs(dphi0) <= 1e-13 * (1.0 + std::fabs(phi0))) return 2;
-    alpha = 1.0; step = 0; ok = false;
+    const double dphi0 = dmerit(in);
+    // no descent left in the inner problem (round-off floor of the 1/mu-conditioned system): counts as solved, no step
+    // (MPC_STALL_TOL of csrc/solver_kernels.h)
+    if (std::fabs(dphi0) <= 1e-13 * (1.0 + std::fabs(phi0))) return 2;
+    double alpha = 1.0, phi = 0.0;
+    int step = 0;
     for (;; ++step) {
       make_trial(in, alpha);
       evaluate(in, in.txs, in.tus, in.tknots, false);
       phi = merit(in, in.tknots, in.tvs, in.tlams);
       if (std::getenv("MPC_ORACLE_DEBUG")) fprintf(stderr, "  ls: alpha %.4g phi %.10e phi0 %.10e dphi0 %.4e\n", alpha, phi, phi0, dphi0);
-      if (phi <= phi0 + opt.ls_armijo_c1 * alpha * dphi0) { ok = true; break; }
+      if (phi <= phi0 + opt.ls_armijo_c1 * alpha * dphi0) break;
       if (step + 1 >= opt.ls_max_steps || 0.5 * alpha < opt.ls_alpha_min) break;
       alpha *= 0.5;
     }
-    if (ok || attempt >= x_retry) break;
-    const double nr = std::max(x_floor, reg_extra * x_fac);
-    for (int k = 0; k <= dims.horizon; ++k) { Knot& kn = in.knots[k]; const int nz = kn.n + kn.m; for (int i = (x_uonly ? kn.n : 0); i < nz; ++i) kn.H[i * nz + i] += nr - reg_extra; }
-    reg_extra = nr;
-    }
-    if (reg_extra > 0 && std::getenv("MPC_X_VERBOSE")) fprintf(stderr, "[retry] inst %d reg %.1e ok %d alpha %.4g\n", (int)(&in - inst.data()), reg_extra, (int)ok, alpha);
-    if (!ok && x_fail == 1) { in.stats.alpha = 0.0; in.stats.ls_steps = step; in.stats.num_iters += 1; return 0; }
     in.xs.swap(in.txs); in.us.swap(in.tus); in.vs.swap(in.tvs); in.lams.swap(in.tlams);
     in.stats.alpha = alpha; in.stats.ls_steps = step; in.stats.num_iters += 1;
+    // (experiment) ratio of the achieved to the predicted decrease of the merit along the accepted step: pred = -(alpha - alpha^2 / 2) dphi0
+    x_ratio = (phi0 - phi) / std::max(-(alpha - 0.5 * alpha * alpha) * dphi0, 1e-300);
+    if (std::getenv("MPC_X_TRACE")) fprintf(stderr, "   [ratio] inst %d it %d alpha %.4g phi0 %.6e phi %.6e dphi0 %.4e ratio %.4f prim %.3e\n", (int)(&in - inst.data()), in.stats.num_iters, alpha, phi0, phi, dphi0, x_ratio, in.stats.prim_infeas);
     return 0;
   }
 
@@ -1135,7 +1127,7 @@ struct Solver {
       bool inner_conv = false, via_stall = false;
       while (in.stats.num_iters < max_it) {
         const int r = iterate(in);
-        if (r == 0 && !corrected && corrector_armed && opt.corrector_prim_tol > 0.0 && in.stats.num_iters >= opt.max_iters && (in.stats.prim_infeas > opt.corrector_prim_tol || in.stats.alpha < 1.0)) { corrected = true; ++max_it; }
+        if (r == 0 && !corrected && corrector_armed && opt.corrector_prim_tol > 0.0 && in.stats.num_iters >= opt.max_iters && (in.stats.prim_infeas > opt.corrector_prim_tol || in.stats.alpha < 1.0 || (std::getenv("MPC_X_RATIO") && x_ratio < std::atof(std::getenv("MPC_X_RATIO"))))) { corrected = true; ++max_it; }
         if (r == 0) { stalls = 0; continue; }
         inner_conv = true;
         if (r == 2) { via_stall = true; ++stalls; }

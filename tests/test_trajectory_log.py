@@ -44,3 +44,42 @@ def test_cop_known_answers():
     assert np.allclose(cop, 0.75 * lf.translation + 0.25 * rf.translation)
     # nothing loaded
     assert np.all(np.isnan(tl.compute_cop(lf, rf, np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3))))
+
+
+def _golden():
+    import os
+    import pytest
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "talos_utils_vectors.npz")
+    if not os.path.exists(path):
+        pytest.skip("no golden vectors")
+    g = np.load(path)
+    if "cop_in" not in g.files:
+        pytest.skip("golden vectors predate the N4 cases (tools/gen_talos_utils_golden.py)")
+    return g
+
+
+def test_cop_equals_the_reference_function():
+    """compute_cop against talos_utils.computeCoP itself (tools/gen_talos_utils_golden.py ran the reference's function on these inputs):
+    both feet loaded, and either foot below the 1 N threshold."""
+    from types import SimpleNamespace
+    g = _golden()
+    for row, want in zip(g["cop_in"], g["cop_out"]):
+        LF = SimpleNamespace(rotation=row[0:9].reshape(3, 3), translation=row[9:12])
+        RF = SimpleNamespace(rotation=row[12:21].reshape(3, 3), translation=row[21:24])
+        got = tl.compute_cop(LF, RF, row[24:27], row[27:30], row[30:33], row[33:36])
+        assert np.allclose(got, want, rtol=0, atol=1e-15), (got, want)
+
+
+def test_archive_equals_what_the_reference_writer_stores(tmp_path):
+    """save_trajectory / load_data: the same field names in the same order and the same values as talos_utils.save_trajectory + load_data
+    produced for this record (the generator asserted the reference's round trip; the field list is stored as ASCII codes)."""
+    g = _golden()
+    fields = bytes(g["log_fields"]).decode().split(",")
+    assert tuple(fields) == tl.FIELDS
+    rec = {k[len("log_in_"):]: g[k] for k in g.files if k.startswith("log_in_")}
+    path = tl.save_trajectory(rec["xs"], rec["us"], rec["com"], rec["LF_force"], rec["RF_force"], rec["LF_torque"], rec["RF_torque"], rec["time"],
+                              rec["LF_trans"], rec["RF_trans"], rec["LF_trans_ref"], rec["RF_trans_ref"], rec["L_measured"], save_name="golden", save_dir=str(tmp_path))
+    back = tl.load_data(path)
+    assert list(back.keys()) == fields
+    for k_in, k_out in (("xs", "xs"), ("LF_trans", "LF_pose"), ("RF_trans_ref", "RF_pose_ref"), ("L_measured", "L_measured"), ("time", "time"), ("LF_torque", "LF_torque")):
+        assert np.array_equal(back[k_out], rec[k_in])

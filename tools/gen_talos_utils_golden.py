@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """BUILD-CONTAINER TOOL: golden vectors for the host helpers of the MPC loops, from the reference's OWN functions.
 
-``talos_utils.shapeState`` and ``talos_utils.compute_ID_references`` are imported from the reference checkout (``/root/reference`` or
+``talos_utils.shapeState``, ``compute_ID_references``, ``computeCoP`` and ``save_trajectory`` / ``load_data`` are imported from the reference checkout (``/root/reference`` or
 ``$MPC_REFERENCE_DIR``) with ``pinocchio`` -> ``mpc_benchmark_amd.robot.minipin`` (tools/dropin/README.md) and called on seeded inputs;
 inputs and outputs (numbers only) go to ``tests/golden/talos_utils_vectors.npz``.  tests/test_references.py holds
 ``mpc_benchmark_amd.references`` to them.  Nothing of the reference is copied."""
@@ -62,5 +62,37 @@ for _ in range(4):
     refs.append(np.concatenate([np.concatenate((M.rotation.reshape(-1), M.translation)) for M in LF_refs + RF_refs]))
 out["id_x0"] = x0; out["id_x"] = np.array(xs); out["id_refs"] = np.array(refs); out["id_out"] = np.array(res)
 out["id_frames"] = np.array([LF_id, RF_id, base_id, torso_id])
+# computeCoP (talos_utils.py:156-178) on seeded foot poses and wrenches: both feet loaded, one foot below the 1 N threshold, the other one
+cop_in, cop_out = [], []
+for case in range(8):
+    LF = minipin.SE3(minipin.exp3(0.2 * rng.standard_normal(3)), np.array([0.0, 0.09, 0.0]) + 0.05 * rng.standard_normal(3))
+    RF = minipin.SE3(minipin.exp3(0.2 * rng.standard_normal(3)), np.array([0.0, -0.09, 0.0]) + 0.05 * rng.standard_normal(3))
+    fl, fr = np.array([5.0, -3.0, 450.0]) + 20 * rng.standard_normal(3), np.array([-4.0, 2.0, 470.0]) + 20 * rng.standard_normal(3)
+    tl, tr = 10 * rng.standard_normal(3), 10 * rng.standard_normal(3)
+    if case == 5:
+        fl[2] = 0.5
+    if case == 6:
+        fr[2] = 0.2
+    cop = ref.computeCoP(LF, RF, fl, tl, fr, tr)
+    cop_in.append(np.concatenate((LF.rotation.reshape(-1), LF.translation, RF.rotation.reshape(-1), RF.translation, fl, tl, fr, tr)))
+    cop_out.append(np.asarray(cop, dtype=float))
+out["cop_in"] = np.array(cop_in); out["cop_out"] = np.array(cop_out)
+# save_trajectory / load_data (talos_utils.py:113-154, 180-185): what the reference's own writer stores and its reader hands back — field
+# names, order, and the values of a small record (the archive itself is a pickle: rewritten by the test, not committed)
+import contextlib, io, tempfile  # noqa: E401,E402
+T = 3
+rec = dict(xs=rng.standard_normal((T, 5)), us=rng.standard_normal((T, 2)), com=rng.standard_normal((T, 3)), LF_force=rng.standard_normal((T, 3)),
+           RF_force=rng.standard_normal((T, 3)), LF_torque=rng.standard_normal((T, 3)), RF_torque=rng.standard_normal((T, 3)), time=np.arange(T) * 0.01,
+           LF_trans=rng.standard_normal((T, 3)), RF_trans=rng.standard_normal((T, 3)), LF_trans_ref=rng.standard_normal((T, 3)), RF_trans_ref=rng.standard_normal((T, 3)),
+           L_measured=rng.standard_normal((T, 3)))
+with tempfile.TemporaryDirectory() as tmp, contextlib.redirect_stdout(io.StringIO()):
+    ref.save_trajectory(rec["xs"], rec["us"], rec["com"], rec["LF_force"], rec["RF_force"], rec["LF_torque"], rec["RF_torque"], rec["time"],
+                        rec["LF_trans"], rec["RF_trans"], rec["LF_trans_ref"], rec["RF_trans_ref"], rec["L_measured"], save_name="golden", save_dir=tmp)
+    back = ref.load_data(os.path.join(tmp, "golden.npz"))
+out["log_fields"] = np.array([ord(c) for c in ",".join(back.keys())], dtype=np.uint8)   # field names in the reference's order (ASCII codes: numbers only)
+for k_in, k_out in (("xs", "xs"), ("us", "us"), ("com", "com"), ("LF_force", "LF_force"), ("RF_force", "RF_force"), ("LF_torque", "LF_torque"), ("RF_torque", "RF_torque"),
+                    ("LF_trans", "LF_pose"), ("RF_trans", "RF_pose"), ("LF_trans_ref", "LF_pose_ref"), ("RF_trans_ref", "RF_pose_ref"), ("L_measured", "L_measured"), ("time", "time")):
+    assert np.array_equal(back[k_out], rec[k_in])
+    out["log_in_" + k_in] = rec[k_in]
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "talos_utils_vectors.npz"), **out)
 print("wrote tests/golden/talos_utils_vectors.npz:", {k: v.shape for k, v in out.items()})
