@@ -172,10 +172,11 @@ def main():
                          "primal-infeasible by more than this, or whose step was shortened by the linesearch, takes one more iteration in the same tick "
                          "(2 - 5 %% of the instance-ticks of the schedule); the solver mirror's default.  0 = off: exactly max_iters iterations per solve")
     ap.add_argument("--corrector-window", type=int, default=0, help="mpc_options.corrector_window: 0 = the corrector rule applies to every tick")
-    ap.add_argument("--refine-appended-knot", type=int, default=0,
+    ap.add_argument("--refine-appended-knot", type=int, default=3,
                     help="mpc_options.refine_appended_knot: Newton steps on the control of the knot mpc_cycle appends when its contact pattern differs from the "
-                         "stage before it (include/mpc_abi.h) — the warm-start choice under which ensembles of randomised instances walk the whole schedule on "
-                         "one ProxDDP iteration per tick; 0 = the scripts' plain duplicate us[-1] (fulldynamic_talos.py:533)")
+                         "stage before it (include/mpc_abi.h); 0 = the scripts' plain duplicate us[-1] (fulldynamic_talos.py:533).  With the corrector it is the "
+                         "setting under which all 64 randomised instances walk the whole schedule in every reference mode (`whole_schedule` in the JSON line; "
+                         "the same walk with the plain warm start and with neither is reported beside it)")
     ap.add_argument("--legs", type=int, default=4,
                     help="legs of the parallel-in-time Riccati sweep (mpc_options.riccati_legs: linear_solver_choice = LQ_SOLVER_PARALLEL of "
                          "fulldynamic_talos.py:383; the script's setNumThreads(8) is a CPU thread count — 64 instances x 4 legs fill the 256 CUs); "
@@ -618,11 +619,13 @@ def main():
 
     # ---- the whole schedule instead of a window (one run with the headline's settings; one with the corrector off = the reference loop's exact
     # iteration budget, for the record of what that loses) ----
-    whole = whole_ref = None
+    whole = whole_plain = whole_ref = None
     if not args.no_whole_schedule and world == 1:
         whole = whole_schedule(args.corrector_prim_tol, args.refine_appended_knot)
+        if args.refine_appended_knot != 0 and args.corrector_prim_tol > 0:
+            whole_plain = whole_schedule(args.corrector_prim_tol, 0)   # the scripts' plain warm start (us[-1] duplicated), corrector only
         if args.corrector_prim_tol > 0 or args.refine_appended_knot != 0:
-            whole_ref = whole_schedule(0.0, 0)
+            whole_ref = whole_schedule(0.0, 0)                          # neither: exactly max_iters = 1 iteration per tick from the plain warm start
 
     # ---- batch = 1 latency (BASELINE.json config: batch=1 on one MI355X) ----
     p50_ms = p90_ms = p95_ms = None
@@ -710,7 +713,7 @@ def main():
         "instances_lost_and_revived": sum(getattr(e, "revived", 0) for e in shards),
         "episode_ticks": args.episode, "episode_restarts": sum(getattr(e, "episodes", 0) for e in shards),
         "ensemble_allgather": gather,
-        "whole_schedule": whole, "whole_schedule_exact_iteration_budget": whole_ref,
+        "whole_schedule": whole, "whole_schedule_plain_warm_start": whole_plain, "whole_schedule_exact_iteration_budget": whole_ref,
         "roofline": roof, "cpu_baseline": cpu, "roofline_riccati": roof_ric,
         # supplementary: the same kernel against the fp64 matrix-core peak (the sweep is a chain of dependent dense steps on ONE CU
         # per instance, not a streaming kernel — DESIGN.md §5); flops = textbook count of the recursion on the unpadded dimensions

@@ -167,8 +167,9 @@ template <> struct InvRow<16> { static DEV void run(const double (&)[16], const 
 // across its tile phases) — profiles/r03_experiments.txt.
 template <int K, int R> struct InvUpd {
   static DEV void run(const double (&nd)[16], double (&x)[16]) { fmac_bcast<R>(x[R], nd[K], x[K]); InvUpd<K, R + 1>::run(nd, x); }  // x[R] -= L[R][K] x[K]
+  static DEV void run_neg(double nl, double (&x)[16]) { fmac_bcast<R>(x[R], nl, x[K]); InvUpd<K, R + 1>::run_neg(nl, x); }          // (nl = -column K of L, lane r: -L[r][K])
 };
-template <int K> struct InvUpd<K, 16> { static DEV void run(const double (&)[16], double (&)[16]) {} };
+template <int K> struct InvUpd<K, 16> { static DEV void run(const double (&)[16], double (&)[16]) {} static DEV void run_neg(double, double (&)[16]) {} };
 template <int K> struct InvCol {
   static DEV void run(const double (&nd)[16], const double (&invd)[16], double (&x)[16]) {
     x[K] *= invd[K];
@@ -177,6 +178,28 @@ template <int K> struct InvCol {
   }
 };
 template <> struct InvCol<16> { static DEV void run(const double (&)[16], const double (&)[16], double (&)[16]) {} };
+
+// Factorisation and inverse in ONE pass (CHOL16_FUSED): as soon as column K of L is known (step K of the factorisation), row K of L^-1 is
+// final (x[K] *= 1 / L[K][K]) and every later row takes its term x[R] -= L[R][K] x[K] — the 2 (15 - K) updates of step K (trailing block
+// and inverse) are mutually independent and depend only on the column just scaled, so the dependent chain of the whole block is the 16
+// pivots (broadcast, rsqrt, one Newton step, one multiply), not 16 pivots + 120 accumulations.  Same additions in the same order as
+// InvCol / CholStep: the same bits.
+template <int K> struct FusedStep {
+  static DEV void run(double (&d)[16], double (&x)[16], bool& ok) {
+    const double dkk = bcast_row<K>(d[K]);
+    ok = ok && (dkk > 0.0);
+    double inv = rsqrt(dkk);
+    inv = inv * (1.5 - 0.5 * dkk * inv * inv);
+    const double l = d[K] * inv;   // lane K: sqrt(dkk) ; lanes r > K: L[r][K]
+    d[K] = l;
+    x[K] *= inv;                   // row K of L^-1 (lane c: column c)
+    const double nl = -l;
+    CholCol<K, K + 1>::run(d, l, nl);   // d[C] -= L[r][K] L[C][K], C > K
+    InvUpd<K, K + 1>::run_neg(nl, x);   // x[R] -= L[R][K] x[K], R > K
+    FusedStep<K + 1>::run(d, x, ok);
+  }
+};
+template <> struct FusedStep<16> { static DEV void run(double (&)[16], double (&)[16], bool&) {} };
 
 // One wavefront: Cholesky of the 16x16 block D (lower triangle, leading dimension ld) entirely in registers —
 // lane r (< 16) holds row r — then its inverse.  Writes L back over D (lower part) and L^-1 to LIb (ld 17); LIb == D (ld 17): the
@@ -187,6 +210,21 @@ DEV bool chol16_wave(double* D, int ld, double* LIb, int lane) {
 #pragma unroll
   for (int cidx = 0; cidx < 16; ++cidx) d[cidx] = D[r * ld + cidx];
   bool ok = true;
+#ifdef CHOL16_FUSED
+#pragma unroll
+  for (int cidx = 0; cidx < 16; ++cidx) x[cidx] = (r == cidx) ? 1.0 : 0.0;
+  FusedStep<0>::run(d, x, ok);
+  if (lane < 16 && D != LIb) {
+#pragma unroll
+    for (int cidx = 0; cidx < 16; ++cidx) if (cidx <= r) D[r * ld + cidx] = d[cidx];
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) LIb[rr * 17 + lane] = x[rr];
+  }
+  (void)invd;
+  return ok;
+#endif
   CholStep<0>::run(d, invd, ok);
   if (lane < 16 && D != LIb) {
 #pragma unroll

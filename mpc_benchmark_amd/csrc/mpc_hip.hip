@@ -173,7 +173,9 @@ struct mpc_solver {
   std::vector<ProfSlot> prof;
 
   template <class F> void timed(int slot, const char* name, F&& launch) {
-    if (!profiling || !((prof_mask >> slot) & 1u)) { launch(); return; }
+    // (the launches of a corrector pass — mpc_options.corrector_prim_tol: most workgroups sit it out — are not timed: the per-kernel figures of the
+    // profile describe launches that process every instance)
+    if (!profiling || !((prof_mask >> slot) & 1u) || (pass_in_run >= opt.max_iters && opt.max_iters <= 4 && opt.corrector_prim_tol > 0.0)) { launch(); return; }
     if ((int)prof.size() <= slot) prof.resize(slot + 1);
     ProfSlot& p = prof[slot];
     p.name = name;

@@ -70,6 +70,8 @@ def replay(name, library, tol, window_ticks_per_window=None, digests=True):
     windows = {}
     for w0 in fx["window_starts"]:
         ticks = [int(t) for t in fx["window_ticks"] if w0 <= t < w0 + 7]
+        if ("state_%d" % (int(w0) - 1)) in fx.files:
+            ticks = [t for t in ticks if ("state_%d" % (t - 1)) in fx.files]  # (a loop that carries its multipliers: the ticks that start from a checkpoint)
         windows[int(w0)] = ticks if window_ticks_per_window is None else ticks[:window_ticks_per_window]
     solve_at = {t for ts in windows.values() for t in ts}
     last = max(solve_at) if not digests else T - 1
@@ -77,7 +79,7 @@ def replay(name, library, tol, window_ticks_per_window=None, digests=True):
     for t in range(last + 1):
         solver.solving = t in solve_at
         if solver.solving:
-            if t in windows and ("state_%d" % (t - 1)) in fx.files:  # a loop without a per-tick setup carries its multipliers: from the checkpoint
+            if ("state_%d" % (t - 1)) in fx.files:  # a loop without a per-tick setup carries its multipliers: from the checkpoint taken before this tick
                 solver._native.set_state(fx["state_%d" % (t - 1)])
             loop.set_solution(fx["xs_%d" % (t - 1)], fx["us_%d" % (t - 1)])
         x_fk = pd.robot.x0 if t == 0 else fx["all_x_measured"][t - 1]

@@ -74,8 +74,8 @@ def test_walk_take_off_and_landing_match_the_oracle(hip_lib, oracle_lib, name, z
     print("%s z_height %.2f: worst deviation over %d ticks %.3e; ticks that backtracked: %d" % (name, z_height, ticks, worst, sum(1 for x in alphas if x < 1)))
 
 
-@pytest.mark.parametrize("iters_per_tick,refine", [(1, 0), (2, 0), (1, -1)])
-def test_config4_stairs_whole_schedule(hip_lib, iters_per_tick, refine):
+@pytest.mark.parametrize("iters_per_tick,refine,corrector", [(1, 0, 0.0), (2, 0, 0.0), (1, 0, 20.0)])
+def test_config4_stairs_whole_schedule(hip_lib, iters_per_tick, refine, corrector):
     """BASELINE.json configuration 4 AS STATED: kinodynamic, N = 150, 64 instances (upper body perturbed), complete model, STAIRS — every
     step 0.3 m forward and 0.10 m up (kinodynamic_talos.py:257 with z_height = 0.10), references replanned every tick, over the
     script's schedule.  Two iterations per tick: the whole 820 ticks, nobody lost, the ensemble ends six footholds further and higher,
@@ -83,16 +83,18 @@ def test_config4_stairs_whole_schedule(hip_lib, iters_per_tick, refine):
     tick 650 (``updateForward(0, 0, ...)``, kinodynamic_talos.py:368-370: the foothold planned 0.3 m ahead and one stair up comes back
     beside the stance foot within one tick) is more than one Newton step of the penalty problem absorbs on stairs, also for the
     nominal instance (the flat walk passes it) — perturbed instances that are lost on the way are isolated and
-    re-seeded from the nominal one, which must not fail.  With ``refine_appended_knot = -1`` (the control of the appended knot refined
-    after every cycle, include/mpc_abi.h) ONE iteration per tick walks the whole 820 ticks, closing step included: the nominal instance
-    and most of the perturbed ones all the way (a handful are re-seeded after tick 600)."""
+    re-seeded from the nominal one, which must not fail.  With the corrector (``corrector_prim_tol = 20``, include/mpc_abi.h: a second
+    iteration on the ~2 % of the instance-ticks whose warm start is infeasible by more than that or whose step backtracks) ONE iteration
+    per tick walks the whole 820 ticks, closing step included, and nobody is lost (round 5; ``refine_appended_knot = -1``, round 4's
+    attempt, does not survive a one-ulp change of the references: profiles/r05_kino_stairs_corrector.txt)."""
     kp = KinodynamicProblem(horizon=150, complete_model=True)
     ens = EnsembleMPC(kp, batch=64, library=hip_lib, seed=7, perturb_dofs=range(18, kp.nv), tick_reuse=True)
     ens.options.riccati_legs = 4
     ens.options.refine_appended_knot = refine
+    ens.options.corrector_prim_tol = corrector
     ens.native.set_options(ens.options)
     ens.iters_per_tick = iters_per_tick
-    ticks = kp.t_mpc - 1 if (iters_per_tick == 2 or refine < 0) else 640
+    ticks = kp.t_mpc - 1 if (iters_per_tick == 2 or corrector > 0) else 640
     ens.prepare_schedule(ticks + 4)
     st = ens.cold_solve(max_iters=100)
     assert all(s.converged for s in st)
@@ -103,14 +105,12 @@ def test_config4_stairs_whole_schedule(hip_lib, iters_per_tick, refine):
     r = ens.results(gains=False)
     base = r["xs"][:, 0, :3]
     x0 = kp.robot.x0[:3]
-    print("stairs, %d iteration(s) per tick, refine_appended_knot %d: base displacement of the ensemble after %d ticks: x %.3f .. %.3f  z %.3f .. %.3f ; instances lost and revived: %s" % (
-        iters_per_tick, refine, ticks, (base[:, 0] - x0[0]).min(), (base[:, 0] - x0[0]).max(), (base[:, 2] - x0[2]).min(), (base[:, 2] - x0[2]).max(),
+    print("stairs, %d iteration(s) per tick, corrector %g, refine_appended_knot %d: base displacement of the ensemble after %d ticks: x %.3f .. %.3f  z %.3f .. %.3f ; instances lost and revived: %s" % (
+        iters_per_tick, corrector, refine, ticks, (base[:, 0] - x0[0]).min(), (base[:, 0] - x0[0]).max(), (base[:, 2] - x0[2]).min(), (base[:, 2] - x0[2]).max(),
         [(t, b, c) for t, b, c, _ in ens.lost]))
     assert np.all(np.isfinite(r["xs"]))
     assert all(b != 0 for _, b, _, _ in ens.lost), "the nominal instance failed"
-    assert len(ens.lost) <= (16 if refine < 0 else 6 if iters_per_tick == 1 else 0), ens.lost
-    if refine < 0:
-        assert all(t > 500 for t, _, _, _ in ens.lost), ens.lost
+    assert len(ens.lost) <= (6 if (iters_per_tick == 1 and corrector == 0) else 0), ens.lost
     # steps of 0.3 m / 0.10 m (talos_utils.py:224-246): five of them by tick 640, the closing one after that
     assert np.all(base[:, 0] - x0[0] > 1.1) and np.all(base[:, 2] - x0[2] > 0.35), (base[:, 0].min(), base[:, 2].min())
 

@@ -320,7 +320,7 @@ def main():
             windows = schedule_windows(pd.contact_phases, pd.horizon, defs[name][1], total)
             keep = set(t for w in windows for t in w) | {w[0] - 1 for w in windows}
             setup_each_tick = bool(pd.walk_spec().get("setup_each_tick", True)) if hasattr(pd, "walk_spec") else True
-            rec, ns, secs = run_script(name, total, lib, a.verbose, keep=keep, keep_state=(None if setup_each_tick else {w[0] - 1 for w in windows}))
+            rec, ns, secs = run_script(name, total, lib, a.verbose, keep=keep, keep_state=(None if setup_each_tick else {t - 1 for w in windows for t in w[:5]}))  # (a checkpoint before each of the first five ticks of a window: the multipliers such a loop carries amplify round-off tick over tick)
             n_ticks = len(rec.runs) - 1
             print("%-12s %s executed unmodified over its whole loop: %d of %d MPC ticks; stopped by: %s  [%.0f s]" % (name, SCRIPTS[name], n_ticks, total, rec.stopped, secs))
             if n_ticks < total:
