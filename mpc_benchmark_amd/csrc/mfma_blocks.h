@@ -201,10 +201,109 @@ template <int K> struct FusedStep {
 };
 template <> struct FusedStep<16> { static DEV void run(double (&)[16], double (&)[16], bool&) {} };
 
+// ---- the same block on the matrix cores (round 5) -------------------------------------------------------------------------------------
+// chol16_wave below keeps a row per lane and spends its time issuing ~256 DPP fmacs (v_fmac_f64_dpp row_newbcast: ~28 clocks each,
+// tools/ubench/chol16: 7 200 clocks a block however the dependencies are arranged).  Here the block lives in ACCUMULATOR layout (lane l,
+// register q: row (l >> 4) + 4 q, column l & 15 — all 64 lanes hold different entries) and is factorised right-looking in four panels of
+// four columns:
+//   1. the panel columns (16 x 4) and row block p of W (the running right-hand side of the inverse, W = I - L_done X_done) go through an LDS
+//      scratch: every lane reads the 4 x 4 pivot block (uniform addresses), its own row of the panel and its own column of W's row block;
+//   2. every lane factorises the pivot block T T^T and inverts T in registers (37 dependent fp64 operations, redundantly);
+//   3. lane (x, k) = (l & 15, l >> 4) forms L[x][c0 + k] = sum_k' A[x][c0 + k'] Tinv[k][k'] and X[c0 + k][x] = sum_k' Tinv[k][k'] W[c0 + k'][x]:
+//      one register each, already in the layout of BOTH operands of v_mfma_f64_16x16x4 (A(i, k) in lane i + 16 k, B(k, j) in lane j + 16 k);
+//   4. two MFMAs: A -= Lp Lp^T (trailing block) and W -= Lp Xp.
+// 4 x (LDS round trip + pivot block + 2 MFMAs) instead of 16 pivots + 256 broadcast-fmacs.  `scratch`: 128 doubles of LDS that nobody
+// else touches during the call (the callers pass the output block LIb itself: the rows of the inverse are stored at the end).
+DEV double rsqrt_refined(double d) { double i = rsqrt(d); return i * (1.5 - 0.5 * d * i * i); }
+DEV bool chol16_wave_mfma(double* D, int ld, double* LIb, int lane) {
+  const int g = lane >> 4, c = lane & 15;
+  d4_t t, w;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = g + 4 * q;
+    t[q] = (row >= c) ? D[row * ld + c] : D[c * ld + row];   // the lower triangle, mirrored
+    w[q] = (row == c) ? 1.0 : 0.0;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();   // every lane holds its entries: D / LIb may be overwritten from here on
+  double* P = LIb;        // [16][4] panel columns
+  double* Wp = LIb + 64;  // [4][16] row block p of W
+  double xp[4];           // lane (j = c, k = g): X[4 p + k][j], p = 0 .. 3 (rows of L^-1, stored at the end)
+  bool ok = true;
+  const bool store_l = (D != LIb);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int c0 = 4 * p;
+    if ((c >> 2) == p) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) P[(g + 4 * q) * 4 + (c & 3)] = t[q];
+    }
+    Wp[g * 16 + c] = w[p];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    // pivot block (uniform reads), own panel row, own column of W's row block
+    const double a00 = P[(c0 + 0) * 4 + 0];
+    const double a10 = P[(c0 + 1) * 4 + 0], a11 = P[(c0 + 1) * 4 + 1];
+    const double a20 = P[(c0 + 2) * 4 + 0], a21 = P[(c0 + 2) * 4 + 1], a22 = P[(c0 + 2) * 4 + 2];
+    const double a30 = P[(c0 + 3) * 4 + 0], a31 = P[(c0 + 3) * 4 + 1], a32 = P[(c0 + 3) * 4 + 2], a33 = P[(c0 + 3) * 4 + 3];
+    const double r0 = P[c * 4 + 0], r1 = P[c * 4 + 1], r2 = P[c * 4 + 2], r3 = P[c * 4 + 3];
+    const double w0 = Wp[0 * 16 + c], w1 = Wp[1 * 16 + c], w2 = Wp[2 * 16 + c], w3 = Wp[3 * 16 + c];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();   // (the scratch is rewritten by the next panel)
+    // T T^T = pivot block, M = T^-1
+    ok = ok && (a00 > 0.0);
+    const double i0 = rsqrt_refined(a00);
+    const double t00 = a00 * i0, t10 = a10 * i0, t20 = a20 * i0, t30 = a30 * i0;
+    const double d1 = a11 - t10 * t10;
+    ok = ok && (d1 > 0.0);
+    const double i1 = rsqrt_refined(d1);
+    const double t11 = d1 * i1, t21 = (a21 - t20 * t10) * i1, t31 = (a31 - t30 * t10) * i1;
+    const double d2 = a22 - t20 * t20 - t21 * t21;
+    ok = ok && (d2 > 0.0);
+    const double i2 = rsqrt_refined(d2);
+    const double t22 = d2 * i2, t32 = (a32 - t30 * t20 - t31 * t21) * i2;
+    const double d3 = a33 - t30 * t30 - t31 * t31 - t32 * t32;
+    ok = ok && (d3 > 0.0);
+    const double i3 = rsqrt_refined(d3);
+    const double t33 = d3 * i3;
+    const double m10 = -(t10 * i0) * i1;
+    const double m21 = -(t21 * i1) * i2, m20 = -(t20 * i0 + t21 * m10) * i2;
+    const double m32 = -(t32 * i2) * i3, m31 = -(t31 * i1 + t32 * m21) * i3, m30 = -(t30 * i0 + t31 * m10 + t32 * m20) * i3;
+    // row g of M for this lane (k = g): coefficients of k' = 0 .. 3
+    const double mk0 = g == 0 ? i0 : g == 1 ? m10 : g == 2 ? m20 : m30;
+    const double mk1 = g == 0 ? 0.0 : g == 1 ? i1 : g == 2 ? m21 : m31;
+    const double mk2 = g <= 1 ? 0.0 : g == 2 ? i2 : m32;
+    const double mk3 = g <= 2 ? 0.0 : i3;
+    double lp = ((r0 * mk0 + r1 * mk1) + r2 * mk2) + r3 * mk3;   // L[x][c0 + k], x = c, k = g
+    // the rows of the pivot block itself are T (its strict upper part exactly zero); rows above it take no part any more
+    const int xr = c - c0;
+    if (xr >= 0 && xr < 4) {
+      const double trow0 = xr == 0 ? t00 : xr == 1 ? t10 : xr == 2 ? t20 : t30;
+      const double trow1 = xr == 1 ? t11 : xr == 2 ? t21 : t31;
+      const double trow2 = xr == 2 ? t22 : t32;
+      lp = g > xr ? 0.0 : (g == 0 ? trow0 : g == 1 ? trow1 : g == 2 ? trow2 : t33);
+    }
+    if (xr < 0) lp = 0.0;
+    xp[p] = ((mk0 * w0 + mk1 * w1) + mk2 * w2) + mk3 * w3;       // X[c0 + k][j], j = c, k = g
+    if (store_l && xr >= g) D[c * ld + c0 + g] = lp;
+    const double nlp = -lp;
+    if (p < 3) t = __builtin_amdgcn_mfma_f64_16x16x4f64(nlp, lp, t, 0, 0, 0);       // A -= Lp Lp^T
+    if (p < 3) w = __builtin_amdgcn_mfma_f64_16x16x4f64(nlp, xp[p], w, 0, 0, 0);    // W -= Lp Xp
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) LIb[(4 * p + g) * 17 + c] = xp[p];
+  return ok;
+}
+
 // One wavefront: Cholesky of the 16x16 block D (lower triangle, leading dimension ld) entirely in registers —
 // lane r (< 16) holds row r — then its inverse.  Writes L back over D (lower part) and L^-1 to LIb (ld 17); LIb == D (ld 17): the
 // inverse REPLACES the block (the blocked routines never read a diagonal block of L again, only its inverse).
 DEV bool chol16_wave(double* D, int ld, double* LIb, int lane) {
+#ifdef CHOL16_MFMA
+  return chol16_wave_mfma(D, ld, LIb, lane);
+#endif
   double d[16], x[16], invd[16];
   const int r = lane & 15;
 #pragma unroll
