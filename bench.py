@@ -171,7 +171,10 @@ def main():
                     help="mpc_options.corrector_prim_tol (include/mpc_abi.h): an instance whose one iteration of the tick started from a warm start that is "
                          "primal-infeasible by more than this, or whose step was shortened by the linesearch, takes one more iteration in the same tick "
                          "(2 - 5 %% of the instance-ticks of the schedule); the solver mirror's default.  0 = off: exactly max_iters iterations per solve")
-    ap.add_argument("--corrector-window", type=int, default=0, help="mpc_options.corrector_window: 0 = the corrector rule applies to every tick")
+    ap.add_argument("--corrector-window", type=int, default=8,
+                    help="mpc_options.corrector_window: the corrector rule applies to the K ticks after a change of the contact pattern of the appended stage (0 = to every "
+                         "tick).  With refine_appended_knot = 3 nobody is lost over the whole schedule for K = 8, 40 and 0 alike (profiles/r05_robustness.txt), and the "
+                         "corrector pass is only enqueued on those ticks; with the plain warm start (--refine-appended-knot 0) use 0: the window loses instances there")
     ap.add_argument("--refine-appended-knot", type=int, default=3,
                     help="mpc_options.refine_appended_knot: Newton steps on the control of the knot mpc_cycle appends when its contact pattern differs from the "
                          "stage before it (include/mpc_abi.h); 0 = the scripts' plain duplicate us[-1] (fulldynamic_talos.py:533).  With the corrector it is the "
@@ -460,7 +463,7 @@ def main():
         e.iters_per_tick = int(args.iters_per_tick)
         e.options.refine_appended_knot = int(refine)
         e.options.corrector_prim_tol = float(corrector)
-        e.options.corrector_window = int(args.corrector_window)
+        e.options.corrector_window = int(args.corrector_window) if refine != 0 else 0   # (the plain warm start needs the rule on every tick)
         e.native.set_options(e.options)
         ticks = pd.t_mpc - 1
         e.prepare_schedule(pd.t_mpc + 4)
@@ -500,7 +503,7 @@ def main():
                "backtracking_ticks": back_t, "backtracking_instance_ticks": back_it, "corrector_ticks": corr_t, "corrector_instance_ticks": corr_it,
                "refinement_ticks": (sum(1 for t in range(1, ticks + 1) if tuple(pd.contact_phases[t % pd.t_mpc]) != tuple(pd.contact_phases[(t - 1) % pd.t_mpc])) if refine > 0 else 0),
                "instance_losses": len(e.lost), "instances_lost": lost[:16], "nominal_instance_lost": bool(nominal_lost or 0 in lost),
-               "settings": {"corrector_prim_tol": float(corrector), "refine_appended_knot": int(refine), "iters_per_tick": int(args.iters_per_tick),
+               "settings": {"corrector_prim_tol": float(corrector), "corrector_window": int(e.options.corrector_window), "refine_appended_knot": int(refine), "iters_per_tick": int(args.iters_per_tick),
                             "references": ("frozen" if args.no_walk else args.walk_refs), "feedback": "perfect model", "lost instances": "re-seeded from the nominal one (mpc_revive_instance)"}}
         del e
         return out
@@ -617,16 +620,6 @@ def main():
         mfma = {"bound": "mfma", "kernel": roof["kernel"], "achieved": round(ach, 3), "peak": 78.6, "unit": "TFLOP/s", "frac": round(ach / 78.6, 5),
                 "busy_cus": min(256, args.batch // nshard * legs), "frac_of_busy_cus": round(ach / (78.6 * min(256, args.batch // nshard * legs) / 256.0), 5)}
 
-    # ---- the whole schedule instead of a window (one run with the headline's settings; one with the corrector off = the reference loop's exact
-    # iteration budget, for the record of what that loses) ----
-    whole = whole_plain = whole_ref = None
-    if not args.no_whole_schedule and world == 1:
-        whole = whole_schedule(args.corrector_prim_tol, args.refine_appended_knot)
-        if args.refine_appended_knot != 0 and args.corrector_prim_tol > 0:
-            whole_plain = whole_schedule(args.corrector_prim_tol, 0)   # the scripts' plain warm start (us[-1] duplicated), corrector only
-        if args.corrector_prim_tol > 0 or args.refine_appended_knot != 0:
-            whole_ref = whole_schedule(0.0, 0)                          # neither: exactly max_iters = 1 iteration per tick from the plain warm start
-
     # ---- batch = 1 latency (BASELINE.json config: batch=1 on one MI355X) ----
     p50_ms = p90_ms = p95_ms = None
     if not args.no_latency:
@@ -649,6 +642,16 @@ def main():
         p90_ms = round(sorted(lat)[int(0.9 * (len(lat) - 1))], 4)
         p95_ms = round(sorted(lat)[int(0.95 * (len(lat) - 1))], 4)  # (p50 and p95 per solve)
         del one
+
+    # ---- the whole schedule instead of a window (one run with the headline's settings; one with the corrector off = the reference loop's exact
+    # iteration budget, for the record of what that loses) ----
+    whole = whole_plain = whole_ref = None
+    if not args.no_whole_schedule and world == 1:
+        whole = whole_schedule(args.corrector_prim_tol, args.refine_appended_knot)
+        if args.refine_appended_knot != 0 and args.corrector_prim_tol > 0:
+            whole_plain = whole_schedule(args.corrector_prim_tol, 0)   # the scripts' plain warm start (us[-1] duplicated), corrector only
+        if args.corrector_prim_tol > 0 or args.refine_appended_knot != 0:
+            whole_ref = whole_schedule(0.0, 0)                          # neither: exactly max_iters = 1 iteration per tick from the plain warm start
 
     # ---- CPU baseline: the CPU port (oracle/cpu_port: closed-form derivatives, -O3 -march=native, OpenMP over knots, Riccati sweep in
     # legs — NOT Aligator, and not the AD checker) on this host's cores, bounded sample.  (i) ONE instance at 8 threads, the setting of

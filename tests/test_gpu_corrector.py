@@ -82,11 +82,11 @@ def test_async_ticks_equal_synchronous_ticks(hip_lib, window):
         assert np.array_equal(ra[key], rs[key]), key
 
 
-@pytest.mark.parametrize("refs,refine", [("frozen", 3), ("instance", 3), ("frozen", 0), ("instance", 0)])
-def test_whole_schedule_on_one_iteration_per_tick(hip_lib, refs, refine):
+@pytest.mark.parametrize("refs,refine,window", [("frozen", 3, 8), ("instance", 3, 8), ("instance", 3, 0), ("frozen", 0, 0), ("instance", 0, 0)])
+def test_whole_schedule_on_one_iteration_per_tick(hip_lib, refs, refine, window):
     """BASELINE.json's ensemble as bench.py runs it — 64 randomised instances, N = 100, complete model, 4 legs, tick reuse, two ticks in
     flight, max_iters = 1, corrector 20.0 — over the reference's whole 1000-tick schedule.
-    refine_appended_knot = 3 (bench.py's setting): nobody is lost, with frozen references and with every instance replanning from its own
+    refine_appended_knot = 3 (bench.py's setting, with the corrector on the 8 ticks after a pattern change; also on every tick): nobody is lost, with frozen references and with every instance replanning from its own
     measured feet (round 4, refinement alone: 5 of 64 lost with per-instance references; neither: 40 - 91, the nominal instance among them).
     refine_appended_knot = 0 (the scripts' own warm start, us[-1] duplicated, fulldynamic_talos.py:532-534): the nominal instance walks the
     whole schedule and at most a handful of the 63 perturbed ones are lost and re-seeded (0 - 3 from run to run of the settings explored in
@@ -95,7 +95,7 @@ def test_whole_schedule_on_one_iteration_per_tick(hip_lib, refs, refine):
     (e,) = make_bench_shards(pd, hip_lib, 64, legs=4, tick_reuse=True)
     e.options.refine_appended_knot = refine
     e.options.corrector_prim_tol = 20.0
-    e.options.corrector_window = 0
+    e.options.corrector_window = window
     e.native.set_options(e.options)
     e.iters_per_tick = 1
     e.prepare_schedule(pd.t_mpc + 4)
@@ -113,8 +113,8 @@ def test_whole_schedule_on_one_iteration_per_tick(hip_lib, refs, refine):
             worst_prim = max([worst_prim] + [s.prim_infeas for s in st if s.converged >= 0])
     while e.inflight:
         st = e.wait()
-    print("refine_appended_knot %d + corrector, references %s, 64 instances, %d ticks: lost %s ; %d of %d instance-ticks took the extra iteration ; largest primal infeasibility seen %.2e"
-          % (refine, refs, ticks, [r[:3] for r in e.lost], extra, total, worst_prim))
+    print("refine_appended_knot %d + corrector (window %d), references %s, 64 instances, %d ticks: lost %s ; %d of %d instance-ticks took the extra iteration ; largest primal infeasibility seen %.2e"
+          % (refine, window, refs, ticks, [r[:3] for r in e.lost], extra, total, worst_prim))
     assert getattr(e, "rescues", 0) == 0 and e.tick == ticks
     assert all(r[1] != 0 for r in e.lost), "the nominal instance failed"
     assert len(e.lost) <= (0 if refine else 4), e.lost

@@ -4,7 +4,7 @@
 OUT=${1:-gpurun_out/sq}
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-walk"
+ARGS="--streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-latency --no-walk --no-whole-schedule --corrector-prim-tol 0"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM" \
            "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY" \
