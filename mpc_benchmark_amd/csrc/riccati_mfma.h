@@ -66,8 +66,17 @@ static inline constexpr RicLds make_ric_lds(int n, int m, int c, int gfull = 1, 
                     // 2: whole G with its u part in the L2-resident scratch (large m: only the few Ruu tiles read it back)
   s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.ldl = s.np + 1; s.ldr = s.mp + 1;
   s.nb = s.np / 16; s.nbm = s.mp / 16;
-  s.lw = s.np + 16;  // W = [K | pad | k | pad]: x-columns at 0..n-1, the feed-forward column at np
-  s.nwb = s.lw / 16;
+// Odd leading dimensions for W / CT / VX (np + 17) and Y = Da^T (17) since round 5: the A-operand fetch of  W -= Y VX  walks the ROWS of Y with a
+// stride of 16 doubles (sixteen lanes on one pair of banks), the row-wise passes over W / CT / VX likewise on 96.  SQ_LDS_BANK_CONFLICT /
+// SQ_LDS_IDX_ACTIVE of the sweep 18.1 % -> 14.9 %, 1.607 -> 1.573 ms per launch (profiles/r05_lds_padding.txt); -DRIC_LW_PAD=0 -DRIC_LDY=16: as before.
+#ifndef RIC_LW_PAD
+#define RIC_LW_PAD 1
+#endif
+#ifndef RIC_LDY
+#define RIC_LDY 17
+#endif
+  s.lw = s.np + 16 + RIC_LW_PAD;  // W = [K | pad | k | pad]: x-columns at 0..n-1, the feed-forward column at np
+  s.nwb = (s.np + 16) / 16;
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += (cnt + 1) & ~1; return r; };
   s.PT = take(s.np * (s.np + 1));  // leading dimension np + 1: conflict-free row AND column access
@@ -79,7 +88,7 @@ static inline constexpr RicLds make_ric_lds(int n, int m, int c, int gfull = 1, 
   const int end2 = o;
   o = s.R1;                                                         // phase 3 view (overlaps AB)
   s.Lr = take(s.mp * s.ldr); s.LIr = take(s.nbm * 272); s.W = take(s.mp * s.lw); s.ST = take(st_lds ? s.mp * s.np : 0);
-  s.CT = take(16 * s.lw); s.VX = take(16 * s.lw); s.Y = take(s.mp * 16); s.SC = take(16 * 17); s.LIs = take(272);
+  s.CT = take(16 * s.lw); s.VX = take(16 * s.lw); s.Y = take(s.mp * RIC_LDY); s.SC = take(16 * 17); s.LIs = take(272);
   int end3 = o;
   // Overlap layout: Lr / LIr in the G_u region (dead once the Ruu tiles are done) instead of on top of [A B] — the one-wavefront
   // factorisation of Ruu then runs while the other wavefronts still multiply [A B]^T G_x for the x rows of Hh.  The other
@@ -90,7 +99,7 @@ static inline constexpr RicLds make_ric_lds(int n, int m, int c, int gfull = 1, 
     const int lr = s.GP + ((s.np * s.mp - need) & ~1), lir = lr + ((s.mp * s.ldr + 1) & ~1);  // at the end of the G_u region
     int cur = s.R1;
     auto place = [&](int cnt) { const int r = cur; cur += (cnt + 1) & ~1; return r; };
-    const int w_ = place(s.mp * s.lw), st_ = place(st_lds ? s.mp * s.np : 0), ct_ = place(16 * s.lw), vx_ = place(16 * s.lw), y_ = place(s.mp * 16),
+    const int w_ = place(s.mp * s.lw), st_ = place(st_lds ? s.mp * s.np : 0), ct_ = place(16 * s.lw), vx_ = place(16 * s.lw), y_ = place(s.mp * RIC_LDY),
               sc_ = place(16 * 17), lis_ = place(272);
     if (need <= s.np * s.mp && cur <= lr) {  // everything else fits in front of it: no growth of the carve-out
       s.ovl = 1;
@@ -911,7 +920,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
 #pragma unroll
       for (int e = 0; e < Y_ELEMS; ++e) {
         const int idx = tid + e * nthr, i = idx >> 4, j = idx & 15;
-        if (idx < mp * 16) Yl[idx] = (i < m && j < ca) ? pf_y[e] : 0.0;
+        if (idx < mp * 16) Yl[i * RIC_LDY + j] = (i < m && j < ca) ? pf_y[e] : 0.0;
       }
       } else {
       // CT = [Ca_x | . | dt | .] (16 x lw) ; Y = Da^T (mp x 16)
@@ -926,7 +935,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
       for (int idx = tid; idx < mp * 16; idx += nthr) {
         const int i = idx >> 4, j = idx & 15;
         const int aj = (j < ca) ? act_idx[j] : 0;
-        Yl[idx] = kn[L.oCD + aj * nz + n + (i < m ? i : 0)] * ((i < m && j < ca) ? 1.0 : 0.0);
+        Yl[i * RIC_LDY + j] = kn[L.oCD + aj * nz + n + (i < m ? i : 0)] * ((i < m && j < ca) ? 1.0 : 0.0);
       }
       }
     }
@@ -967,7 +976,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
           trsm_fwd_blocked(Lr, ldr, LIr, nbm, W2 + j2 * 16, ldw2, 1, 0, 1, lane);
         }
     trsm_fwd_blocked(Lr, ldr, LIr, nbm, W, lw, nwb, wv, nw, lane);  // W = L^-1 T
-    if (ca > 0 && small_ca && wv == nw - 1) trsm_fwd_blocked(Lr, ldr, LIr, nbm, Yl, 16, 1, 0, 1, lane);  // Y = L^-1 Da^T
+    if (ca > 0 && small_ca && wv == nw - 1) trsm_fwd_blocked(Lr, ldr, LIr, nbm, Yl, RIC_LDY, 1, 0, 1, lane);  // Y = L^-1 Da^T
     __syncthreads();
     RIC_SUB(30);
     if (ca > 0) {
@@ -975,7 +984,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
         // Sc = mu I + Y^T Y (pad identity) ; V = [Ca | dt] + Y^T W
         if (wv == 0) {
           d4_t acc = d4_t{0, 0, 0, 0};
-          mma_tile<false>(acc, Yl, 1, 16, Yl, 16, 1, mp, lane);
+          mma_tile<false>(acc, Yl, 1, RIC_LDY, Yl, RIC_LDY, 1, mp, lane);
           const int col = lane & 15;
           for (int q = 0; q < 4; ++q) {
             const int row = (lane >> 4) + 4 * q;
@@ -986,14 +995,14 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
         }
         for (int cj = wv; cj < nwb; cj += nw) {
           d4_t acc = tile_load(CTl + cj * 16, lw, lane);
-          mma_tile<false>(acc, Yl, 1, 16, W + cj * 16, lw, 1, mp, lane);
+          mma_tile<false>(acc, Yl, 1, RIC_LDY, W + cj * 16, lw, 1, mp, lane);
           tile_store(VXl + cj * 16, lw, acc, lane);
         }
         if (LEGS && kkt2)
           for (int j2 = 0; j2 < nbm; ++j2)
             if (wv == (nwb + j2) % nw) {
               d4_t acc = d4_t{0, 0, 0, 0};
-              mma_tile<false>(acc, Yl, 1, 16, W2 + j2 * 16, ldw2, 1, mp, lane);
+              mma_tile<false>(acc, Yl, 1, RIC_LDY, W2 + j2 * 16, ldw2, 1, mp, lane);
               tile_store(VX2 + j2 * 16, ldw2, acc, lane);
             }
         __syncthreads();
@@ -1012,7 +1021,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
               for (int ri = 0; ri < nbm; ++ri) {  // W2 -= Y VX2 (own column block: in order within the wavefront)
                 double* Wt = W2 + (ri * 16) * ldw2 + j2 * 16;
                 d4_t acc = tile_load(Wt, ldw2, lane);
-                mma_tile<true>(acc, Yl + (ri * 16) * 16, 16, 1, VX2 + j2 * 16, ldw2, 1, 16, lane);
+                mma_tile<true>(acc, Yl + (ri * 16) * RIC_LDY, RIC_LDY, 1, VX2 + j2 * 16, ldw2, 1, 16, lane);
                 tile_store(Wt, ldw2, acc, lane);
               }
             }
@@ -1022,7 +1031,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
           const int ri = t / nwb, cj = t % nwb;
           double* Wt = W + (ri * 16) * lw + cj * 16;
           d4_t acc = tile_load(Wt, lw, lane);
-          mma_tile<true>(acc, Yl + (ri * 16) * 16, 16, 1, VXl + cj * 16, lw, 1, 16, lane);
+          mma_tile<true>(acc, Yl + (ri * 16) * RIC_LDY, RIC_LDY, 1, VXl + cj * 16, lw, 1, 16, lane);
           tile_store(Wt, lw, acc, lane);
         }
         __syncthreads();
