@@ -467,7 +467,7 @@ int mpc_debug_get(mpc_solver* h, const char* name, int32_t b, int32_t k, double*
     else throw std::runtime_error("debug_get: unknown quantity " + nm);
     const int cnt = (int)v->size();
     if (cnt > cap) throw std::runtime_error("debug_get: output buffer too small");
-    std::memcpy(out, v->data(), cnt * sizeof(double));
+    if (cnt > 0) std::memcpy(out, v->data(), cnt * sizeof(double));  // (an empty quantity: data() may be null)
     return cnt;
   } catch (const std::exception& e) {
     h->err = e.what();

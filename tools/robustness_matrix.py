@@ -12,7 +12,7 @@ ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 999
 for refs in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("frozen", "shared", "instance")):
     for R in [int(v) for v in os.environ.get("REFINES", "0,3").split(",")]:
         pd = FullDynamicsProblem(horizon=100, complete_model=True)
-        (e,) = make_bench_shards(pd, lib, 64, legs=4, tick_reuse=True)
+        (e,) = make_bench_shards(pd, lib, 64, legs=4, tick_reuse=True, seed=int(os.environ.get("SEED", "20250304")))
         e.options.refine_appended_knot = R
         e.options.corrector_prim_tol = float(os.environ.get("CORRECTOR", "20"))
         e.options.corrector_window = int(os.environ.get("WINDOW", "0"))
