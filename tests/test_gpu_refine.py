@@ -122,3 +122,37 @@ def test_whole_schedule_walk_with_one_iteration_per_tick(hip_lib, refs):
     r = e.results(gains=False)
     alive = [b for b, s in enumerate(st) if s.converged >= 0]
     assert np.all(np.isfinite(r["xs"][alive])) and np.all(np.isfinite(r["us"][alive]))
+
+
+def test_abandoned_refinement_steps_agree(hip_lib, oracle_lib):
+    """A refinement step is abandoned when the control Hessian of the appended knot is not positive definite (or the knot has more than 48 active
+    rows: the LDS carve-out of k_refine_knot): the control stays as it is for that step, the remaining steps and x_N = phi(x_{N-1}, u_{N-1}) still run
+    — in BOTH libraries (round 4 review: the oracle returned early and skipped the update of x_N).  Provoked by a negative regularisation on the tick
+    whose appended stage changes the contact pattern: every refinement step gives up, the tick's own factorisation then fails (reported, isolated), and
+    what is left is the shifted warm start with x_N re-integrated from the duplicated control — equal in the two libraries."""
+    er, eh = _handle(oracle_lib, 30, 3), _handle(hip_lib, 30, 3)
+    er.cold_solve(max_iters=100)
+    eh.cold_solve(max_iters=100)
+    for t in range(30):
+        er.step()
+    before = er.results(gains=False)
+    state = er.native.get_state()
+    out = []
+    for e in (er, eh):
+        e.native.set_state(state)
+        e.tick = 30
+        e.enable_failure_isolation(auto_revive=False)
+        e.options.reg_init = -1e12  # every Hessian block indefinite: the refinement steps give up, then the sweep does
+        e.native.set_options(e.options)
+        st = e.step()               # tick 30: the first single-support stage is appended -> the refinement runs, and abandons its steps
+        assert all(s.converged < 0 for s in st), [s.converged for s in st]
+        out.append(e.results(gains=False))
+    a, b = out[1], out[0]
+    N = er.dims.horizon
+    # the iterate is the shifted warm start (the failed tick took no step) ...
+    assert np.array_equal(b["us"][:, :-1], before["us"][:, 1:]) and np.array_equal(b["us"][:, -1], before["us"][:, -1])
+    assert np.array_equal(a["us"], b["us"])
+    # ... with x_N re-integrated from the (unrefined) duplicated control by the refinement's last launch, in both libraries
+    assert not np.allclose(b["xs"][:, N], before["xs"][:, N])
+    err = rel_cols(a["xs"], b["xs"], 1e-3)
+    assert err < 1e-9, "after an abandoned refinement HIP's states are %.3e away from the oracle's" % err
