@@ -159,6 +159,9 @@ def main():
     ap.add_argument("--walk-refs", choices=["instance", "shared"], default="instance",
                     help="walk mode: every instance replans from its own measured foot poses and has its own references (instance: per-instance "
                          "parameter tables, batched generator) or all instances track the references planned from instance 0 (shared)")
+    ap.add_argument("--walk-generator", choices=["host", "device"], default="device",
+                    help="per-instance references: the swing-foot generator in numpy on the host (batched over the instances, hidden behind the ticks in flight) or in the "
+                         "library (mpc_walk_update: one kernel, a workgroup per instance; the default run reports its rate beside the host generator's)")
     ap.add_argument("--no-walk", action="store_true",
                     help="only the frozen-reference measurement (by default both run and the LOWER rate is the headline value)")
     ap.add_argument("--closed-loop", action="store_true",
@@ -220,7 +223,7 @@ def main():
         raise RuntimeError("bench.py measures the HIP library only")
     pd = FullDynamicsProblem(horizon=args.horizon, complete_model=(args.model == "complete"))
     nshard = max(1, min(args.streams, args.batch))
-    def measure(walk, iters=args.iters_per_tick, corrector=None):
+    def measure(walk, iters=args.iters_per_tick, corrector=None, generator=None):
         """One measurement of the ensemble tick: frozen foot references (walk = False) or the reference loop's per-tick problem
         updates (walk = True: FootTrajectory.updateTrajectory + 2 N setReference + terminal rebuild, EnsembleMPC.enable_walk)."""
         # SURVEY.md §8d config 5: ONE ensemble of batch x world instances (one rng stream, instance order), instance i on GPU i mod G
@@ -261,7 +264,8 @@ def main():
             # (`instances_lost_and_revived` in the JSON line; 0 in the default window)
             e.enable_failure_isolation(auto_revive=True, source=0)
             if walk:
-                e.enable_walk(per_instance=(args.walk_refs == "instance"))
+                gen = (generator or args.walk_generator) if args.walk_refs == "instance" else "host"
+                e.enable_walk(per_instance=(args.walk_refs == "instance"), generator=gen)
 
         # instances whose tick was a BCL update / stall without a ProxDDP step (num_iters == 0 in the status of the tick): not a solve
         nostep = {"n": 0, "on": False, "extra": 0, "back": 0}
@@ -470,7 +474,7 @@ def main():
         e.cold_solve(max_iters=args.cold_iters)
         e.enable_failure_isolation(auto_revive=True, source=0)
         if not args.no_walk:
-            e.enable_walk(per_instance=(args.walk_refs == "instance"))
+            e.enable_walk(per_instance=(args.walk_refs == "instance"), generator=(args.walk_generator if args.walk_refs == "instance" else "host"))
         e.results(gains=False)
         ms, back_t, corr_t, corr_it, back_it, nostep_it, nominal_lost = [], 0, 0, 0, 0, 0, False
 
@@ -521,6 +525,8 @@ def main():
     # supplementary: the walk with two iterations per tick, the setting under which all 64 randomised instances walk the whole schedule
     if args.iters_per_tick == 1 and not args.no_walk and world == 1:
         runs["walk_two_iterations_per_tick"] = measure(True, iters=2)
+        if args.walk_refs == "instance" and args.walk_generator == "device":  # the same walk with the numpy generator on the host (rounds 3 - 4)
+            runs["walk_references_generated_on_the_host"] = measure(True, generator="host")
     shards, ens, legs, cold, n_conv, pace, stagger, elapsed, prof, warm, gather = (mres[k] for k in ("shards", "ens", "legs", "cold", "n_conv", "pace", "stagger", "elapsed", "prof", "warm", "gather"))
     nostep = {"n": mres["nostep"]}
     if rank != 0:
@@ -705,7 +711,7 @@ def main():
         # rate of the instances whose cold solve converged, for a reader who does not want them counted
         "cold_solve_unconverged_instances": int(args.batch - n_conv), "value_cold_converged_instances_only": round(solves / elapsed * n_conv / max(1, args.batch), 2),
         "tick_mode": ("walk: foot references regenerated and patched every tick (fulldynamic_talos.py:444-510)" if head else "frozen foot references"),
-        "walk_references": ("per instance: every instance replans from its own measured foot poses (per-instance parameter tables, batched generator on the host)" if args.walk_refs == "instance"
+        "walk_references": ("per instance: every instance replans from its own measured foot poses (per-instance parameter tables, batched generator %s)" % ("in the library: mpc_walk_update" if args.walk_generator == "device" else "on the host") if args.walk_refs == "instance"
                             else "planned once per tick from instance 0's measured state and shared by the instances of an ensemble"),
         "measurements": {(w if isinstance(w, str) else ("walk" if w else "frozen_references")): {"value": round(rate(r), 2), "ms_per_step": round(r["elapsed"] / args.steps * 1e3, 4),
                                                                   "replanning_ticks": r["replanning_ticks"],

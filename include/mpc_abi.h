@@ -301,6 +301,39 @@ int mpc_set_state(mpc_solver* s, const double* buf, int64_t len);
 int mpc_enable_instance_params(mpc_solver* s);
 int mpc_update_instance_params_batch(mpc_solver* s, int32_t count, const int32_t* insts, const int32_t* ks, const int32_t* offsets, const int32_t* lens, const double* vals);
 
+/* Reference generation in the library (round 5; SURVEY.md section 8f N1, second half): the swing-foot generator of the walking loops
+ * (talos_utils.py:187-327 footTrajectory.updateTrajectory / foot_trajectory, called at fulldynamic_talos.py:444-463) for EVERY instance of an ensemble
+ * with per-instance parameter tables, from each instance's own predicted next state xs[1] — forward kinematics of the two sole frames, the foothold
+ * rules, the Bezier swing curve and the 12-double placement references written straight into the instance's tables: no per-tick host work that grows
+ * with the ensemble, nothing but four countdown integers crosses the boundary per tick (HIP: one kernel, a workgroup per instance).
+ *   mpc_walk_init    after mpc_enable_instance_params.  frames: the two sole frames of the model table; offsets: where a running stage / the terminal
+ *                    node keep the references (the lowering's slots; -1 = the problem has no such reference).
+ *   mpc_walk_update  once per tick BEFORE mpc_cycle (as the loops call setReference before replaceStageCircular): the countdowns of
+ *                    talos_utils.update_timings; `forward` != NULL = footTrajectory.updateForward (t_left[3], t_right[3], swing_apex) first.  On a tick
+ *                    whose generator replans (a foot without a pending landing, a take-off inside the double-support window) every knot's reference is
+ *                    rewritten and no record of the previous tick is reused; otherwise only the knot appended by the last mpc_cycle (which came with
+ *                    the shared table's reference) and the terminal node.  Same rules and the same arithmetic in the oracle.
+ *   mpc_walk_get_state / mpc_walk_set_state  start / final poses of both feet per instance, [B][4][12]: tests, and the checkpoint of a loop that is restarted
+ *                    (after set_state the next update rewrites the references of every knot). */
+typedef struct mpc_walk_config {
+  int32_t T_ss, T_ds;
+  int32_t frame_lf, frame_rf;
+  int32_t off_lf, off_rf;        /* running stages: placement references (R row-major 9, p 3)                                  */
+  int32_t off_xref_z;            /* running stages: base height of the posture reference (the stairs variant), or -1          */
+  int32_t toff_com, toff_lf, toff_rf;  /* terminal node: CoM target (3) ; foot references (12 each) or -1                       */
+  double swing_apex;
+  double t_left[3], t_right[3];  /* footTrajectory.translationLeft / translationRight                                         */
+  double rot_diff[9];            /* footTrajectory.rotationDiff                                                               */
+  double com0[3];                /* terminal CoM target = (mid-point of the last foot references in x, y ; com0 z)              */
+  double feet_z0, xref_z0;       /* stairs: posture height = xref_z0 + mean height of the knot's foot references - feet_z0      */
+  double z_follow;               /* 1: stairs variant (off_xref_z, CoM target height follow the feet) ; 0: flat ground          */
+  double lf0[12], rf0[12];       /* initial sole placements                                                                   */
+} mpc_walk_config;
+int mpc_walk_init(mpc_solver* s, const mpc_walk_config* cfg);
+int mpc_walk_update(mpc_solver* s, int32_t takeoff_RF, int32_t takeoff_LF, int32_t land_RF, int32_t land_LF, const double* forward);
+int mpc_walk_get_state(mpc_solver* s, double* out);
+int mpc_walk_set_state(mpc_solver* s, const double* in);
+
 /* Failure policy of an ensemble.  isolate = 0 (default): a failed factorisation on any instance makes the run return an error, as a
  * single solver would.  isolate = 1: the instance is reported (mpc_stats.converged = -code: 2 / 3 / 4 Riccati blocks, 5 / 6 contact
  * dynamics), keeps the iterate it had when the pass started failing and is skipped by every later run until it is revived; the other

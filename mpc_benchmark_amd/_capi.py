@@ -61,6 +61,13 @@ def default_options(tol=1e-5, mu_init=1e-8):
     return o
 
 
+class MpcWalkConfig(C.Structure):
+    """mpc_walk_config of include/mpc_abi.h (reference generation in the library)"""
+    _fields_ = [(n, C.c_int32) for n in ("T_ss", "T_ds", "frame_lf", "frame_rf", "off_lf", "off_rf", "off_xref_z", "toff_com", "toff_lf", "toff_rf")] + [
+        ("swing_apex", C.c_double), ("t_left", C.c_double * 3), ("t_right", C.c_double * 3), ("rot_diff", C.c_double * 9), ("com0", C.c_double * 3),
+        ("feet_z0", C.c_double), ("xref_z0", C.c_double), ("z_follow", C.c_double), ("lf0", C.c_double * 12), ("rf0", C.c_double * 12)]
+
+
 class MpcStats(C.Structure):
     _fields_ = [("num_iters", C.c_int32), ("converged", C.c_int32), ("al_iters", C.c_int32), ("ls_steps", C.c_int32),
                 ("traj_cost", C.c_double), ("merit", C.c_double), ("prim_infeas", C.c_double),
@@ -82,6 +89,10 @@ _SIGNATURES = {
     "mpc_update_stage_params": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _DP, C.c_int32]),
     "mpc_update_stage_params_batch": (C.c_int, [C.c_void_p, C.c_int32, _IP, _IP, _IP, _DP]),
     "mpc_cycle": (C.c_int, [C.c_void_p, _IP, C.c_int32, _DP, C.c_int32]),
+    "mpc_walk_init": (C.c_int, [C.c_void_p, C.POINTER(MpcWalkConfig)]),
+    "mpc_walk_update": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _DP]),
+    "mpc_walk_get_state": (C.c_int, [C.c_void_p, _DP]),
+    "mpc_walk_set_state": (C.c_int, [C.c_void_p, _DP]),
     "mpc_set_x0": (C.c_int, [C.c_void_p, _DP]),
     "mpc_simulate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "mpc_simulate_push": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, _DP]),
@@ -299,6 +310,28 @@ class NativeSolver:
     def enable_instance_params(self):
         """Every instance gets its own copy of the stage PARAMETER tables (mpc_enable_instance_params)."""
         self._check(self.lib.mpc_enable_instance_params(self._h), "mpc_enable_instance_params")
+
+    # -- reference generation in the library (mpc_walk_*) ------------------------------------------------------------------------
+    def walk_init(self, cfg: "MpcWalkConfig"):
+        self._check(self.lib.mpc_walk_init(self._h, C.byref(cfg)), "mpc_walk_init")
+
+    def walk_update(self, takeoff_RF, takeoff_LF, land_RF, land_LF, forward=None):
+        """One tick of the generator for every instance, BEFORE ``cycle``.  ``forward``: (t_left[3], t_right[3], swing_apex) = updateForward."""
+        fw = None
+        if forward is not None:
+            fw = _f64(np.concatenate([np.asarray(forward[0], dtype=float), np.asarray(forward[1], dtype=float), [float(forward[2])]]))
+        self._check(self.lib.mpc_walk_update(self._h, int(takeoff_RF), int(takeoff_LF), int(land_RF), int(land_LF),
+                                             fw.ctypes.data_as(_DP) if fw is not None else None), "mpc_walk_update")
+
+    def walk_get_state(self):
+        """-> [B, 4, 12]: start / final pose of the left foot, start / final pose of the right foot (R row-major, p)."""
+        out = np.zeros((self.dims.batch, 4, 12))
+        self._check(self.lib.mpc_walk_get_state(self._h, out.ctypes.data_as(_DP)), "mpc_walk_get_state")
+        return out
+
+    def walk_set_state(self, plan):
+        plan = _f64(plan).reshape(-1)
+        self._check(self.lib.mpc_walk_set_state(self._h, plan.ctypes.data_as(_DP)), "mpc_walk_set_state")
 
     def update_instance_params_batch(self, patches):
         """``patches``: iterable of (instance, stage k, offset, values)."""

@@ -98,6 +98,10 @@ struct mpc_solver {
   int only_knot = -1;              // SolverArgs::only_knot of the launches being enqueued
   bool appended_changed = false;   // the stage of the last mpc_cycle has another contact pattern than its predecessor (refine_appended_knot)
   bool appended_any = false;       // a stage was appended since the last run (refine_appended_knot < 0: refine after every cycle)
+  // mpc_walk_*: reference generation on the device (k_walk_refs)
+  bool walk_on = false, walk_force_all = false;
+  mpc_walk_config walk{};
+  double* d_walk_state = nullptr;  // [B][48]
   int since_change = 1 << 20;      // mpc_cycle calls since the appended stage last changed its contact pattern (corrector_window)
   bool refine_now = false;         // ... and this run refines the warm start of the appended knot after k_begin_run
   double* d_simu = nullptr;  // [B][nu] torques, [B][12] wrenches of mpc_simulate_torque
@@ -1025,6 +1029,60 @@ int mpc_update_instance_params_batch(mpc_solver* s, int32_t count, const int32_t
   })
 }
 
+int mpc_walk_init(mpc_solver* s, const mpc_walk_config* cfg) {
+  MPC_TRY(s, {
+    const Layout& L = s->L;
+    if (!cfg) throw std::runtime_error("walk_init: null configuration");
+    if (!s->d_inst_params) throw std::runtime_error("walk_init: mpc_enable_instance_params first");
+    if (!s->d_model_i || L.space != MPC_SPACE_MULTIBODY) throw std::runtime_error("walk_init: a whole-body model is needed (mpc_set_model)");
+    const int nf_ = s->h_model_i.size() > 3 ? s->h_model_i[3] : 0;
+    if (cfg->frame_lf < 0 || cfg->frame_lf >= nf_ || cfg->frame_rf < 0 || cfg->frame_rf >= nf_) throw std::runtime_error("walk_init: frame index out of range");
+    for (int off : {cfg->off_lf, cfg->off_rf, cfg->toff_lf, cfg->toff_rf}) if (off >= 0 && off + 12 > L.max_stage_doubles) throw std::runtime_error("walk_init: reference offset out of range");
+    if ((cfg->toff_com >= 0 && cfg->toff_com + 3 > L.max_stage_doubles) || (cfg->off_xref_z >= L.max_stage_doubles)) throw std::runtime_error("walk_init: offset out of range");
+    s->walk = *cfg;
+    if (!s->d_walk_state) s->d_walk_state = s->alloc<double>((size_t)L.B * 48);
+    std::vector<double> st((size_t)L.B * 48);
+    for (int b = 0; b < L.B; ++b) {
+      double* p = st.data() + (size_t)b * 48;
+      std::memcpy(p, cfg->lf0, 96); std::memcpy(p + 12, cfg->lf0, 96); std::memcpy(p + 24, cfg->rf0, 96); std::memcpy(p + 36, cfg->rf0, 96);
+    }
+    copy_sync(s, s->d_walk_state, st.data(), st.size() * sizeof(double), hipMemcpyHostToDevice);
+    s->walk_on = true;
+  })
+}
+
+int mpc_walk_update(mpc_solver* s, int32_t takeoff_RF, int32_t takeoff_LF, int32_t land_RF, int32_t land_LF, const double* forward) {
+  MPC_TRY(s, {
+    const Layout& L = s->L;
+    if (!s->walk_on) throw std::runtime_error("walk_update: mpc_walk_init first");
+    mpc_walk_config& c = s->walk;
+    if (forward) { std::memcpy(c.t_left, forward, 24); std::memcpy(c.t_right, forward + 3, 24); c.swing_apex = forward[6]; }
+    const bool replanning = land_LF < 0 || land_RF < 0 || (takeoff_RF >= 0 && takeoff_RF < c.T_ds) || (takeoff_LF >= 0 && takeoff_LF < c.T_ds);
+    hipLaunchKernelGGL(k_walk_refs, dim3(L.B), dim3(128), 0, s->stream, s->args(), c, s->d_walk_state, (int)takeoff_RF, (int)takeoff_LF, (int)land_RF, (int)land_LF, replanning ? 1 : 0, (replanning || s->walk_force_all) ? 1 : 0);
+    HIP_OK(hipGetLastError());
+    // tick reuse: the records of the knots whose references were rewritten are stale (on a replanning tick: all of them)
+    if (replanning || s->walk_force_all) for (int k = 0; k < L.N; ++k) s->slot_dirty[slot_of(s, k)] = 1;
+    else s->slot_dirty[slot_of(s, L.N - 1)] = 1;
+    s->slot_dirty[L.N] = 1;
+    s->walk_force_all = false;
+  })
+}
+
+int mpc_walk_set_state(mpc_solver* s, const double* in) {
+  MPC_TRY(s, {
+    if (!s->walk_on || !in) throw std::runtime_error("walk_set_state: mpc_walk_init first");
+    copy_sync(s, s->d_walk_state, in, (size_t)s->L.B * 48 * sizeof(double), hipMemcpyHostToDevice);
+    s->walk_force_all = true;
+  })
+}
+
+int mpc_walk_get_state(mpc_solver* s, double* out) {
+  MPC_TRY(s, {
+    if (!s->walk_on || !out) throw std::runtime_error("walk_get_state: mpc_walk_init first");
+    copy_sync(s, out, s->d_walk_state, (size_t)s->L.B * 48 * sizeof(double), hipMemcpyDeviceToHost);
+  })
+}
+
 int mpc_cycle(mpc_solver* s, const int32_t* desc, int32_t n_desc, const double* params, int32_t n_params) {
   MPC_TRY(s, {
     // the slot of stage 0 is recycled for the new last stage: no data movement, only the ring head moves
@@ -1545,6 +1603,11 @@ int mpc_debug_get(mpc_solver* s, const char* name, int32_t b, int32_t k, double*
       copy_sync(s, tp.data(), s->d_trial_phi + (size_t)b * L.n_alpha * (L.N + 1), tp.size() * sizeof(double), hipMemcpyDeviceToHost);
       v = {st.phi0, st.dphi0, st.alpha, (double)st.ls_step};
       for (int i = 0; i < L.n_alpha; ++i) { double t = 0; for (int kk = 0; kk <= L.N; ++kk) t += tp[(size_t)i * (L.N + 1) + kk]; v.push_back(t); }
+    }
+    else if (nm == "inst_params") {  // the parameter table instance b uses at knot k (its own copy after mpc_enable_instance_params, else the shared one)
+      const int slot = slot_of(s, k);
+      const double* src = s->d_inst_params ? s->d_inst_params + ((size_t)b * (L.N + 1) + slot) * L.max_stage_doubles : s->d_stage_params + (size_t)slot * L.max_stage_doubles;
+      dev_vec(src, s->h_len[2 * slot + 1]);
     }
     else if (nm == "H") mat(kn.data() + L.oH, nzk, nzk, nz);
     else if (nm == "grad") mat(kn.data() + L.oG, 1, nzk, nz);

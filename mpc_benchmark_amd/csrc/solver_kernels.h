@@ -874,3 +874,54 @@ __global__ void k_shift(SolverArgs a, const double* xs_in, const double* us_in, 
     for (int i = tid; i < L.m; i += nthr) uo[i] = ui[i];
   }
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// mpc_walk_update (include/mpc_abi.h): the swing-foot reference generator of the walking loops for every instance of an ensemble with per-instance
+// parameter tables.  grid B, block 128.  On a replanning tick two threads run the forward kinematics of the two sole frames at the instance's
+// predicted next state xs[1] and one applies the foothold rules (walk_generator.h) to the instance's plan; then a thread per knot forms the two
+// placement references (Bezier swing curve, geodesic between the rotations) and writes them into the instance's table of that knot — ring-indexed
+// as the stage tables are, BEFORE the rotation of this tick — and the owner of knot N - 1 the terminal node's targets.
+// ------------------------------------------------------------------------------------------------
+#include "walk_generator.h"
+__global__ void __launch_bounds__(128) k_walk_refs(SolverArgs a, mpc_walk_config c, double* state, int takeoff_RF, int takeoff_LF, int land_RF, int land_LF, int replanning, int write_all) {
+  const Layout& L = a.L;
+  const int b = blockIdx.x, tid = threadIdx.x, N = L.N;
+  __shared__ double st[48], meas[24];
+  double* gst = state + (size_t)b * 48;
+  if (replanning) {
+    if (tid < 2) {
+      M3 R; V3 p;
+      const double* q = a.xs + ((size_t)b * (N + 1) + 1) * L.nx;
+      walk_frame_placement(a.model_i, a.model_d, q, tid == 0 ? c.frame_lf : c.frame_rf, R, p);
+      walk_pose_store(meas + 12 * tid, R, p);
+    }
+    if (tid >= 64 && tid < 112) st[tid - 64] = gst[tid - 64];
+    __syncthreads();
+    if (tid == 0) walk_plan(st, meas, meas + 12, takeoff_RF, takeoff_LF, land_RF, land_LF, c.T_ds, c.t_left, c.t_right, c.rot_diff);
+    __syncthreads();
+    if (tid < 48) gst[tid] = st[tid];
+  } else {
+    if (tid < 48) st[tid] = gst[tid];
+    __syncthreads();
+  }
+  double* tables = const_cast<double*>(a.inst_params) + (size_t)b * (N + 1) * L.max_stage_doubles;
+  for (int j = (write_all ? 0 : N - 1) + tid; j < N; j += blockDim.x) {
+    double Lr[12], Rr[12];
+    walk_ref(Lr, st, st + 12, land_LF, j, c.T_ss, c.swing_apex);
+    walk_ref(Rr, st + 24, st + 36, land_RF, j, c.T_ss, c.swing_apex);
+    double* tab = tables + (size_t)stage_slot(a, j) * L.max_stage_doubles;
+    if (c.off_lf >= 0) for (int e = 0; e < 12; ++e) tab[c.off_lf + e] = Lr[e];
+    if (c.off_rf >= 0) for (int e = 0; e < 12; ++e) tab[c.off_rf + e] = Rr[e];
+    if (c.off_xref_z >= 0 && c.z_follow != 0.0) tab[c.off_xref_z] = c.xref_z0 + 0.5 * (Lr[11] + Rr[11]) - c.feet_z0;
+    if (j == N - 1) {  // terminal node: the last foot references and the CoM target between them
+      double* tt = tables + (size_t)N * L.max_stage_doubles;
+      if (c.toff_com >= 0) {
+        tt[c.toff_com] = 0.5 * (Lr[9] + Rr[9]); tt[c.toff_com + 1] = 0.5 * (Lr[10] + Rr[10]);
+        tt[c.toff_com + 2] = c.com0[2] + (c.z_follow != 0.0 ? 0.5 * (Lr[11] + Rr[11]) - c.feet_z0 : 0.0);
+      }
+      if (c.toff_lf >= 0) for (int e = 0; e < 12; ++e) tt[c.toff_lf + e] = Lr[e];
+      if (c.toff_rf >= 0) for (int e = 0; e < 12; ++e) tt[c.toff_rf + e] = Rr[e];
+    }
+  }
+}

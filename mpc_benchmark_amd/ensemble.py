@@ -118,6 +118,8 @@ class EnsembleMPC:
         walk = None
         if self._walk is not None:
             walk = copy.deepcopy({k: self._walk[k] for k in ("lists", "traj", "x_measured", "last", "replanning", "batch", "x_measured_all", "last_all") if k in self._walk})
+            if self._walk.get("device"):
+                walk["device_plan"] = self.native.walk_get_state()
         self._episode = (self.native.get_state(), self.tick, walk, getattr(self, "replanning_ticks", 0))
 
     def restart_episode(self):
@@ -129,7 +131,11 @@ class EnsembleMPC:
         self.tick = tick0
         self.episodes = getattr(self, "episodes", 0) + 1
         if self._walk is not None and walk is not None:
-            self._walk.update(copy.deepcopy(walk))
+            walk = copy.deepcopy(walk)
+            plan = walk.pop("device_plan", None)
+            self._walk.update(walk)
+            if plan is not None:
+                self.native.walk_set_state(plan)
         elif self._walk is not None:
             self.enable_walk(**self._walk_args)  # saved before the walk was enabled: back to the start of the schedule
 
@@ -246,7 +252,7 @@ class EnsembleMPC:
         return [tuple(r) for r in self.lost if r[3] is None]
 
     # -- the reference loop's per-tick problem updates on the shared stage tables ---------------------------------
-    def enable_walk(self, swing_apex=0.15, x_forward=None, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0, per_instance=False):
+    def enable_walk(self, swing_apex=0.15, x_forward=None, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0, per_instance=False, generator="host"):
         """From now on every tick does what the loop bodies of the scripts do to the problem before solving (fulldynamic_talos.py:444-510,
         kinodynamic_talos.py:361-409, centroidal_talos.py:357-384): ``FootTrajectory.updateTrajectory`` from the measured foot poses, the
         references written into every stage of the horizon (``setReference`` on the two foot-placement costs — integer keys 3 / 4 or the
@@ -266,14 +272,21 @@ class EnsembleMPC:
         ``per_instance=True`` (whole-body problems): every instance plans from ITS OWN measured foot poses and gets its own references
         (mpc_enable_instance_params: per-instance parameter tables; ``references.FootTrajectoryBatch`` and
         ``minipin.frame_placements_batch`` do the generator's and the forward kinematics' work for all instances in numpy arrays; one
-        call carries the patches of every instance, of which only the changed ones travel)."""
+        call carries the patches of every instance, of which only the changed ones travel).
+
+        ``generator="device"`` (with ``per_instance=True``): the generator itself runs in the library (mpc_walk_init / mpc_walk_update,
+        include/mpc_abi.h) — forward kinematics of the sole frames at every instance's predicted next state, foothold rules, swing curves and
+        the references written into the instance tables by one kernel; per tick the host only advances the four countdowns."""
         from . import references as refgen
         from .robot import minipin as pin
         pd, N = self.pd, self.problem.num_steps
         spec = pd.walk_spec()
         if x_forward is None:
             x_forward = spec["x_forward"]
-        self._walk_args = dict(swing_apex=swing_apex, x_forward=x_forward, y_forward=y_forward, foot_yaw=foot_yaw, y_gap=y_gap, z_height=z_height, per_instance=per_instance)
+        self._walk_args = dict(swing_apex=swing_apex, x_forward=x_forward, y_forward=y_forward, foot_yaw=foot_yaw, y_gap=y_gap, z_height=z_height, per_instance=per_instance,
+                               generator=generator)
+        if generator not in ("host", "device") or (generator == "device" and not per_instance):
+            raise ValueError("generator: 'host', or 'device' together with per_instance=True")
         rb = pd.robot
         ev = refgen.contact_event_times(pd.contact_phases, N)
         lf, rf = rb.foot_placements
@@ -311,7 +324,28 @@ class EnsembleMPC:
                                slots[keys.index("linear_acc_cost")][1] + 4 + 4 * i + 1] for i in (0, 1)]
             if per_instance:
                 raise NotImplementedError("per-instance references: whole-body problems only")
-        if per_instance:
+        if per_instance and generator == "device":
+            self.native.enable_instance_params()
+            cfg = K.MpcWalkConfig()
+            cfg.T_ss, cfg.T_ds = int(T_SS), int(T_DS)
+            cfg.frame_lf, cfg.frame_rf = (self.ctx.frame_index(rb.model, f) for f in rb.foot_frame_ids)
+            if self.ctx.changed:  # (a frame the stages had not referenced yet)
+                self.native.set_model(*self.ctx.model_tables())
+                self.ctx.changed = False
+            cfg.off_lf, cfg.off_rf, cfg.off_xref_z = int(w["off_lf"]), int(w["off_rf"]), int(w["off_xref_z"])
+            cfg.toff_com = int(w["toff_com"])
+            cfg.toff_lf, cfg.toff_rf = (int(w["toff_lf"]), int(w["toff_rf"])) if spec["terminal_feet"] else (-1, -1)
+            cfg.swing_apex = float(swing_apex)
+            gen = w["traj"]
+            cfg.t_left[:], cfg.t_right[:] = list(gen.translationLeft), list(gen.translationRight)
+            cfg.rot_diff[:] = list(np.asarray(gen.rotationDiff, dtype=float).reshape(-1))
+            cfg.com0[:] = list(np.asarray(rb.com0, dtype=float))
+            cfg.feet_z0, cfg.xref_z0, cfg.z_follow = float(w["feet_z0"]), float(self.pd.x0[2]), (1.0 if z_height != 0.0 else 0.0)
+            flat = lambda M: list(np.concatenate([np.asarray(M.rotation, dtype=float).reshape(-1), np.asarray(M.translation, dtype=float)]))
+            cfg.lf0[:], cfg.rf0[:] = flat(lf), flat(rf)
+            self.native.walk_init(cfg)
+            w["device"] = True
+        elif per_instance:
             B = self.batch
             self.native.enable_instance_params()
             bc = lambda M: (np.tile(np.asarray(M.rotation, dtype=float), (B, 1, 1)), np.tile(np.asarray(M.translation, dtype=float), (B, 1)))
@@ -339,6 +373,17 @@ class EnsembleMPC:
         w, N = self._walk, self.problem.num_steps
         rb, pin, refgen = self.pd.robot, self._walk["pin"], self._walk["refgen"]
         takeoff_RFs, takeoff_LFs, land_RFs, land_LFs = w["lists"]
+        if w.get("device"):  # the generator runs in the library: only the countdowns (and the scripts' updateForward rule) are host work
+            takeoff_RF, takeoff_LF, land_RF, land_LF = refgen.update_timings(land_LFs, land_RFs, takeoff_LFs, takeoff_RFs)
+            forward = None
+            if w["spec"]["forward_rule"](takeoff_RF, takeoff_LF, land_RF, land_LF):
+                p = w["step"]
+                forward = ([0.0, p["y_gap"], w["spec"]["forward_z_left"]], [0.0, -p["y_gap"] - p["y_forward"], 0.0], p["swing_apex"])
+            self.native.walk_update(takeoff_RF, takeoff_LF, land_RF, land_LF, forward)
+            T_ds = w["traj"].T_ds
+            w["replanning"] = (land_LF < 0 or land_RF < 0 or 0 <= takeoff_RF < T_ds or 0 <= takeoff_LF < T_ds)
+            self.replanning_ticks = getattr(self, "replanning_ticks", 0) + int(w["replanning"])
+            return
         if "batch" in w:  # per-instance references
             (LR, Lp), (RR, Rp) = pin.frame_placements_batch(rb.model, w["x_measured_all"][:, :rb.model.nq], rb.foot_frame_ids)
             takeoff_RF, takeoff_LF, land_RF, land_LF = refgen.update_timings(land_LFs, land_RFs, takeoff_LFs, takeoff_RFs)
@@ -396,6 +441,8 @@ class EnsembleMPC:
         if w["kind"] == "contact_poses":
             return  # the centroidal problem has no terminal target (centroidal_talos.py:249)
         feet = w["spec"]["terminal_feet"]
+        if w.get("device"):
+            return  # (written by the generator kernel together with the references)
         if "batch" in w:
             L_last, R_last = w["last_all"]
             com = np.tile(self.pd.robot.com0, (self.batch, 1))
