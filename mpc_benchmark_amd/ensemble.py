@@ -236,6 +236,10 @@ class EnsembleMPC:
             for b in lost:
                 self.native.revive_instance(b, src)
                 self.revived += 1
+                if self._walk is not None and self._walk.get("device"):  # the generator lives in the library: the plan of the source as well
+                    plan = self.native.walk_get_state()
+                    plan[b] = plan[src]
+                    self.native.walk_set_state(plan)   # (the next update rewrites every knot's references)
                 if self._walk is not None and "batch" in self._walk:  # per-instance references: the generator state of the source as well
                     g = self._walk["batch"]
                     for name in ("sL", "fL", "sR", "fR"):
