@@ -130,7 +130,6 @@ struct Solver {
   std::vector<std::vector<std::vector<double>>> inst_params;  // [B][N + 1]: per-instance parameter tables, empty = shared (mpc_enable_instance_params)
   std::string err;
   bool have_model = false;
-  double x_ratio = 1.0;
   bool corrector_armed = true;  // mpc_options.corrector_window: set per run by the C-ABI layer (capi.cpp), which sees the mpc_cycle calls
 
   int N() const { return dims.horizon; }
@@ -984,9 +983,6 @@ struct Solver {
     }
     in.xs.swap(in.txs); in.us.swap(in.tus); in.vs.swap(in.tvs); in.lams.swap(in.tlams);
     in.stats.alpha = alpha; in.stats.ls_steps = step; in.stats.num_iters += 1;
-    // (experiment) ratio of the achieved to the predicted decrease of the merit along the accepted step: pred = -(alpha - alpha^2 / 2) dphi0
-    x_ratio = (phi0 - phi) / std::max(-(alpha - 0.5 * alpha * alpha) * dphi0, 1e-300);
-    if (std::getenv("MPC_X_TRACE")) fprintf(stderr, "   [ratio] inst %d it %d alpha %.4g phi0 %.6e phi %.6e dphi0 %.4e ratio %.4f prim %.3e\n", (int)(&in - inst.data()), in.stats.num_iters, alpha, phi0, phi, dphi0, x_ratio, in.stats.prim_infeas);
     return 0;
   }
 
@@ -1127,7 +1123,7 @@ struct Solver {
       bool inner_conv = false, via_stall = false;
       while (in.stats.num_iters < max_it) {
         const int r = iterate(in);
-        if (r == 0 && !corrected && corrector_armed && opt.corrector_prim_tol > 0.0 && in.stats.num_iters >= opt.max_iters && (in.stats.prim_infeas > opt.corrector_prim_tol || in.stats.alpha < 1.0 || (std::getenv("MPC_X_RATIO") && x_ratio < std::atof(std::getenv("MPC_X_RATIO"))))) { corrected = true; ++max_it; }
+        if (r == 0 && !corrected && corrector_armed && opt.corrector_prim_tol > 0.0 && in.stats.num_iters >= opt.max_iters && (in.stats.prim_infeas > opt.corrector_prim_tol || in.stats.alpha < 1.0)) { corrected = true; ++max_it; }
         if (r == 0) { stalls = 0; continue; }
         inner_conv = true;
         if (r == 2) { via_stall = true; ++stalls; }
