@@ -103,6 +103,27 @@ int mpc_qp_solve_ikid(mpc_qp_solver* s, const mpc_qp_settings* settings, int32_t
                       double* x, double* y, double* z, double* z_box, mpc_qp_info* info,
                       double* H_out, double* g_out, double* A_out, double* b_out, double* C_out, double* l_out);
 
+/* ---- device-side glue of the kinodynamic control pipeline (kinodynamic_talos.py:411-462) ----
+ * `steps` periods of the 1 kHz low-level loop for every robot of the batch, without the host in between.  Per period, on the device:
+ *     d       = difference(x_measured, xs[0])                                             kinodynamic_talos.py:412-418, 424
+ *     a0      = [ base part of xdot(knot 0)'s acceleration ; us[0][6 nk:] - K_0[6 nk:] d ]  :420-431
+ *     forces  =   us[0][:6 nk] - K_0[:6 nk] d                                              :432-434
+ *     (da, df, tau) = the inverse-dynamics QP of mpc_qp_solve_id at (x_measured, a0, forces, contact_states)   :438-446
+ *     tau     = clamp(tau, -tau_max, tau_max)                                              :448-456
+ *     x_measured <- one simulator step of length dt under tau (mpc_simulate_torque)        :458 (device.execute)
+ * `plan`: the MPC handle (include/mpc_abi.h) of the kinodynamic problem, controls u = (contact wrenches [6 nk], joint accelerations
+ * [nv - 6]); its solution xs[0], us[0], the Riccati gain K_0 and xdot of knot 0 are read where the last run left them.  `sim`: the
+ * simulator handle (horizon 1, whole-body contact dynamics with nu = nv - 6, the contact set of its stage 0 — the handle of
+ * mpc_simulate_torque) ; the three handles live on one device and share the batch size.
+ * x[B][nq+nv]: the measured states to start from (NULL: the simulator handle's, so that calls continue one another) ; frames, weights, cone,
+ * kd, contact_states[B][nk] as in mpc_qp_solve_id ; tau_max[nv - 6].  Outputs (each may be NULL): x_prev[B][nq+nv] the measured states BEFORE
+ * the last period (what the script keeps as the next solve's initial condition, :414-415, 482-486), x_out[B][nq+nv] after it,
+ * tau[B][nv-6] and forces[B][6 nk] (= forces + df) of the last period, info[B] of its QP. */
+typedef struct mpc_solver mpc_solver;
+int mpc_qp_low_level_steps(mpc_qp_solver* s, const mpc_qp_settings* settings, mpc_solver* plan, mpc_solver* sim, int32_t nk, const int32_t* frames,
+                           const double* weights, const double* cone, double kd, const int32_t* contact_states, const double* tau_max,
+                           const double* x, int32_t steps, double dt, double* x_prev, double* x_out, double* tau, double* forces, mpc_qp_info* info);
+
 #ifdef __cplusplus
 }
 #endif

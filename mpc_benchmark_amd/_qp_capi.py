@@ -49,6 +49,9 @@ def _bind(lib):
     lib.mpc_qp_solve_ikid.restype = C.c_int
     lib.mpc_qp_solve_ikid.argtypes = [C.c_void_p, C.POINTER(QpSettings), C.c_int32, _IP, C.c_int32, C.c_int32, _DP, _DP, _DP, _DP, _DP, _DP, _DP, _DP, _IP,
                                       _DP, _DP, _DP, _DP, C.POINTER(QpInfo), _DP, _DP, _DP, _DP, _DP, _DP]
+    lib.mpc_qp_low_level_steps.restype = C.c_int
+    lib.mpc_qp_low_level_steps.argtypes = [C.c_void_p, C.POINTER(QpSettings), C.c_void_p, C.c_void_p, C.c_int32, _IP, _DP, _DP, C.c_double, _IP, _DP,
+                                           _DP, C.c_int32, C.c_double, _DP, _DP, _DP, _DP, C.POINTER(QpInfo)]
     _bound.add(id(lib))
     return lib
 
@@ -138,6 +141,31 @@ class BatchedQP:
         if return_matrices:
             return x, y, z, list(info), mats
         return x, y, z, list(info)
+
+    def low_level_steps(self, plan, sim, frames, weights, cone, kd, contact_states, tau_max, steps, dt, x=None, cone_l=None):
+        """mpc_qp_low_level_steps: ``steps`` periods of the kinodynamic low-level loop (feedback terms of the plan's knot 0 -> inverse-dynamics QP ->
+        clamped torque -> simulator step) without the host in between.  ``plan``, ``sim``: NativeSolver handles of the same library.
+        -> x_prev, x, tau, forces, info (states before / after the last period, torques and forces of the last period)."""
+        d = self.dims
+        B = d.batch
+        frames = np.ascontiguousarray(frames, dtype=np.int32); nk = frames.size
+        weights = np.ascontiguousarray(weights, dtype=np.float64)[:2].copy()
+        cone = self._cone_pair(cone, cone_l)
+        nv = self._nv
+        cs = np.ascontiguousarray(np.broadcast_to(np.asarray(contact_states, dtype=np.int32), (B, nk)))
+        tau_max = np.ascontiguousarray(tau_max, dtype=np.float64)
+        if tau_max.size != nv - 6:
+            raise ValueError("tau_max must have nv - 6 entries")
+        if x is not None:
+            x = np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float64), (B, self._nqv)))
+        x_prev = np.zeros((B, self._nqv)); x_out = np.zeros((B, self._nqv)); tau = np.zeros((B, nv - 6)); forces = np.zeros((B, 6 * nk))
+        info = (QpInfo * B)()
+        IP = C.POINTER(C.c_int32)
+        rc = self.lib.mpc_qp_low_level_steps(self._h, C.byref(self.settings), plan._h, sim._h, nk, frames.ctypes.data_as(IP), _dp(weights), _dp(cone), float(kd),
+                                             cs.ctypes.data_as(IP), _dp(tau_max), _dp(x), int(steps), float(dt), _dp(x_prev), _dp(x_out), _dp(tau), _dp(forces), info)
+        if rc != 0:
+            raise RuntimeError("mpc_qp_low_level_steps: " + self.lib.mpc_qp_last_error(self._h).decode())
+        return x_prev, x_out, tau, forces, list(info)
 
     def solve_ikid(self, frames, base_frame, torso_frame, weights, gains, cone, l_box, u_box, xrob, ik, forces, contact_states, return_matrices=False,
                    cone_l=None):

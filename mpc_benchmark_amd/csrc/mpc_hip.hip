@@ -20,6 +20,8 @@
 #include "closed_loop.h"
 #include "legs.h"
 #include "legs_tree.h"
+#include "pipeline_glue.h"
+#include "qp_device_api.h"
 
 #define HIP_OK(expr)                                                                                  \
   do {                                                                                                \
@@ -1276,6 +1278,67 @@ int mpc_simulate_torque(mpc_solver* s, const double* x, const double* tau, int32
     if (wrenches) copy_sync(s, wrenches, s->d_simwr, (size_t)L.B * 12 * sizeof(double), hipMemcpyDeviceToHost);
     s->perfect_feedback = false;
   })
+}
+
+// include/mpc_qp_abi.h: the low-level loop of the kinodynamic pipeline with nothing but the kernels between its stages.  Everything is enqueued on
+// the QP handle's stream (the plan and the simulator are idle: their streams are drained first); one synchronisation at the end.
+int mpc_qp_low_level_steps(mpc_qp_solver* qp, const mpc_qp_settings* S, mpc_solver* plan, mpc_solver* sim, int32_t nk, const int32_t* frames,
+                           const double* weights, const double* cone, double kd, const int32_t* contact_states, const double* tau_max,
+                           const double* x, int32_t steps, double dt, double* x_prev, double* x_out, double* tau, double* forces, mpc_qp_info* info) {
+  if (!qp) return -2;
+  try {
+    if (!S || !plan || !sim || !contact_states || !tau_max) throw std::runtime_error("qp_low_level_steps: null argument");
+    if (steps <= 0 || !(dt > 0.0)) throw std::runtime_error("qp_low_level_steps: steps and dt must be positive");
+    qp_id_prepare(qp, nk, frames, weights, cone);
+    const QpIdBuffers q = qp_id_buffers(qp);
+    const Layout& P = plan->L;
+    const Layout& Z = sim->L;
+    const int nx = q.nq + q.nv, nu = q.nv - 6, nf = 6 * nk;
+    if (plan->dims.device != q.device || sim->dims.device != q.device) throw std::runtime_error("qp_low_level_steps: the three handles must live on one device");
+    if (P.B != q.B || Z.B != q.B) throw std::runtime_error("qp_low_level_steps: the three handles must have the same batch size");
+    if (P.space != MPC_SPACE_MULTIBODY || P.nx != nx || P.n != 2 * q.nv || P.m != nf + nu || P.n > PIPE_MAX_N)
+      throw std::runtime_error("qp_low_level_steps: the plan must be a multibody problem with nx = nq + nv and controls (6 nk contact wrench components, nv - 6 joint accelerations)");
+    if (Z.space != MPC_SPACE_MULTIBODY || Z.nx != nx || Z.m != nu ||
+        sim->h_desc[(size_t)slot_of(sim, 0) * Z.max_stage_ints] != MPC_DYN_MULTIBODY_CONSTRAINT_SEMIEULER)
+      throw std::runtime_error("qp_low_level_steps: the simulator handle must hold whole-body contact dynamics with nu = nv - 6 (the handle of mpc_simulate_torque)");
+    if (plan->async_pending > 0) throw std::runtime_error("qp_low_level_steps: the plan has ticks in flight (mpc_wait first)");
+    HIP_OK(hipStreamSynchronize(plan->stream));
+    HIP_OK(hipStreamSynchronize(sim->stream));
+    if (!sim->d_simu) { sim->d_simu = sim->alloc<double>((size_t)Z.B * Z.m); sim->d_simwr = sim->alloc<double>((size_t)Z.B * 12); HIP_OK(hipStreamSynchronize(sim->stream)); }
+    const size_t B = q.B;
+    double* scr = qp_scratch(qp, B * nx + B * nf + nu);  // x before the last period | forces + df | tau_max
+    double *d_xprev = scr, *d_fnew = scr + B * nx, *d_taumax = d_fnew + B * nf;
+    hipStream_t st = q.stream;
+    if (x) HIP_OK(hipMemcpyAsync(sim->d_x0, x, B * nx * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(q.cs, contact_states, B * nk * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIP_OK(hipMemcpyAsync(d_taumax, tau_max, nu * sizeof(double), hipMemcpyHostToDevice, st));
+    PipeArgs p;
+    p.xs = plan->d_xs; p.us = plan->d_us; p.gains = plan->d_gains; p.knots = plan->d_knots;
+    p.N = P.N; p.nx = nx; p.nq = q.nq; p.nv = q.nv; p.n = P.n; p.m = P.m; p.gain_stride = P.gain_stride; p.oK = P.oK; p.knot_stride = P.knot_stride; p.oXD = P.oXD;
+    p.slot0 = plan->khead % P.N;
+    p.x = sim->d_x0; p.xrob = q.xrob; p.acc = q.acc; p.f = q.f; p.sol = q.sol; p.nk = nk; p.qn = q.n; p.tau_max = d_taumax; p.sim_u = sim->d_simu; p.f_new = d_fnew;
+    const SolverArgs za = sim->args();
+    for (int step = 0; step < steps; ++step) {
+      if (step == steps - 1 && x_prev) HIP_OK(hipMemcpyAsync(d_xprev, sim->d_x0, B * nx * sizeof(double), hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_pipe_feedback, dim3((unsigned)B), dim3(64), 0, st, p);
+      qp_id_enqueue(qp, S, kd);
+      qp_launch_solve(qp, S);
+      hipLaunchKernelGGL(k_pipe_torque, dim3((unsigned)B), dim3(64), 0, st, p);
+      launch_eval_multibody(st, za, sim->LT, sim->d_tknots, sim->d_mbwork, sim->mb_work_stride, true, 0, 1, 1, dt, false, nullptr, true, sim->d_simu, nullptr);
+      HIP_OK(hipGetLastError());
+    }
+    if (x_prev) HIP_OK(hipMemcpyAsync(x_prev, d_xprev, B * nx * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (x_out) HIP_OK(hipMemcpyAsync(x_out, sim->d_x0, B * nx * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (tau) HIP_OK(hipMemcpyAsync(tau, sim->d_simu, B * nu * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (forces) HIP_OK(hipMemcpyAsync(forces, d_fnew, B * nf * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (info) HIP_OK(hipMemcpyAsync(info, q.info, B * sizeof(mpc_qp_info), hipMemcpyDeviceToHost, st));
+    HIP_OK(hipStreamSynchronize(st));
+    sim->perfect_feedback = false;
+    return 0;
+  } catch (const std::exception& e) {
+    qp_set_error(qp, e.what());
+    return -1;
+  }
 }
 
 int mpc_get_x0(mpc_solver* s, double* x0) {

@@ -3,6 +3,7 @@
 #include <atomic>
 #include "qp_kernel.h"
 #include "qp_assemble.h"
+#include "qp_device_api.h"
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-device, per-kernel setting shared by all handles: keep the LARGEST request so
 // far (a second handle with a smaller problem must not lower the limit under a handle that is still in use)
@@ -39,6 +40,7 @@ struct mpc_qp_solver {
   int ikid_nk = 0;
   std::vector<double> ikid_const;
   std::vector<double> id_const;  // weights[2], cone[54], frames[nk] as last uploaded
+  double* d_glue = nullptr; size_t glue_cap = 0;  // scratch of mpc_qp_low_level_steps (pipeline_glue.h)
   std::vector<void*> allocs;
   std::string err;
   template <class T> T* alloc(size_t count) {
@@ -50,10 +52,9 @@ struct mpc_qp_solver {
   }
 };
 
-// launch k_qp_solve on the handle's device buffers and bring the solution back
-static void qp_launch_and_fetch(mpc_qp_solver* s, const mpc_qp_settings* S, double* x, double* y, double* z, double* z_box, mpc_qp_info* info) {
+// launch k_qp_solve on the handle's device buffers
+static void qp_launch(mpc_qp_solver* s, const mpc_qp_settings* S) {
   const mpc_qp_dims& d = s->d;
-  const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin, m = nin + (d.box ? n : 0);
   QpArgs a;
   a.d = d; a.S = *S;
   a.H = s->dH; a.g = s->dg; a.A = s->dA; a.b = s->db; a.C = s->dC; a.l = s->dl; a.u = s->du; a.lb = s->dlb; a.ub = s->dub;
@@ -65,6 +66,13 @@ static void qp_launch_and_fetch(mpc_qp_solver* s, const mpc_qp_settings* S, doub
   else if (s->lds.mats) hipLaunchKernelGGL((k_qp_solve<1, false>), grid, blk, s->lds.total_bytes, s->stream, a);
   else hipLaunchKernelGGL((k_qp_solve<0, false>), grid, blk, s->lds.total_bytes, s->stream, a);
   HIP_OK(hipGetLastError());
+}
+
+// ... and bring the solution back
+static void qp_launch_and_fetch(mpc_qp_solver* s, const mpc_qp_settings* S, double* x, double* y, double* z, double* z_box, mpc_qp_info* info) {
+  const mpc_qp_dims& d = s->d;
+  const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin, m = nin + (d.box ? n : 0);
+  qp_launch(s, S);
   HIP_OK(hipMemcpyAsync(x, s->dx, B * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   if (y && neq) HIP_OK(hipMemcpyAsync(y, s->dy, B * neq * sizeof(double), hipMemcpyDeviceToHost, s->stream));
   std::vector<double> zh(B * m);
@@ -177,60 +185,93 @@ int mpc_qp_set_model(mpc_qp_solver* s, const int32_t* itab, int32_t n_i, const d
   } catch (const std::exception& e) { s->err = e.what(); return -1; }
 }
 
+}  // extern "C"
+
+// buffers and constants of the inverse-dynamics QP (H = diag(w0 I_nv, w1 I_6nk, 0), g = 0, u = 1e5 as the reference, frames, cone rows: uploaded when they change)
+void qp_id_prepare(mpc_qp_solver* s, int32_t nk, const int32_t* frames, const double* weights, const double* cone) {
+  HIP_OK(hipSetDevice(s->d.device));
+  if (!frames || !weights || !cone) throw std::runtime_error("qp_solve_id: null argument");
+  if (!s->d_mi) throw std::runtime_error("qp_solve_id: mpc_qp_set_model first");
+  const mpc_qp_dims& d = s->d;
+  const int nv = s->m_nv, nq = s->m_nq;
+  if (nk <= 0 || d.n != 2 * nv - 6 + 6 * nk || d.neq != nv + 6 * nk || d.nin != 9 * nk || d.box)
+    throw std::runtime_error("qp_solve_id: the handle's dimensions are not those of the inverse-dynamics QP (n = 2 nv - 6 + 6 nk, neq = nv + 6 nk, nin = 9 nk, no box)");
+  for (int c = 0; c < nk; ++c) if (frames[c] < 0 || frames[c] >= s->m_nframes) throw std::runtime_error("qp_solve_id: contact frame index out of range");
+  const size_t B = d.batch, n = d.n, nin = d.nin;
+  if (!s->d_xrob || s->id_nk != nk) {
+    s->d_xrob = s->alloc<double>(B * (nq + nv)); s->d_acc = s->alloc<double>(B * nv); s->d_f = s->alloc<double>(B * 6 * nk);
+    s->d_cs = s->alloc<int32_t>(B * nk); s->d_frames = s->alloc<int32_t>(nk); s->d_cone = s->alloc<double>(108);
+    s->id_nk = nk; s->id_const_uploaded = false;
+    qp_lds_attr_max((const void*)k_qp_assemble<false>, (int)qp_assemble_lds_bytes(s->m_nj, nv, nq, nk));
+  }
+  std::vector<double> key(110 + nk);
+  key[0] = weights[0]; key[1] = weights[1];
+  for (int i = 0; i < 108; ++i) key[2 + i] = cone[i];
+  for (int c = 0; c < nk; ++c) key[110 + c] = frames[c];
+  if (!s->id_const_uploaded || key != s->id_const) {
+    std::vector<double> H(n * n, 0.0), g(n, 0.0), u(nin, 1e5);
+    for (int i = 0; i < nv; ++i) H[(size_t)i * n + i] = weights[0];
+    for (int i = 0; i < 6 * nk; ++i) H[(size_t)(nv + i) * n + nv + i] = weights[1];
+    for (size_t bi = 0; bi < B; ++bi) {
+      HIP_OK(hipMemcpyAsync(s->dH + bi * n * n, H.data(), n * n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      HIP_OK(hipMemcpyAsync(s->dg + bi * n, g.data(), n * sizeof(double), hipMemcpyHostToDevice, s->stream));
+      HIP_OK(hipMemcpyAsync(s->du + bi * nin, u.data(), nin * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    }
+    HIP_OK(hipMemcpyAsync(s->d_frames, frames, nk * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipMemcpyAsync(s->d_cone, cone, 108 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+    HIP_OK(hipStreamSynchronize(s->stream));  // (host vectors go out of scope)
+    s->id_const = key; s->id_const_uploaded = true;
+  }
+}
+
+// assembly + solve of the inverse-dynamics QP from d_xrob / d_acc / d_f / d_cs, enqueued on the handle's stream
+void qp_id_enqueue(mpc_qp_solver* s, const mpc_qp_settings* S, double kd) {
+  const mpc_qp_dims& d = s->d;
+  const int nv = s->m_nv, nq = s->m_nq, nk = s->id_nk;
+  const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin;
+  QpAssembleArgs qa = {};
+  qa.mi = s->d_mi; qa.md = s->d_md; qa.x = s->d_xrob; qa.acc = s->d_acc; qa.f = s->d_f; qa.cs = s->d_cs; qa.frames = s->d_frames; qa.cone = s->d_cone;
+  qa.kd = kd; qa.nk = nk; qa.n = (int)n; qa.neq = (int)neq; qa.nin = (int)nin;
+  qa.A = s->dA; qa.b = s->db; qa.C = s->dC; qa.l = s->dl;
+  hipLaunchKernelGGL(k_qp_assemble<false>, dim3(d.batch), dim3(QPA_THREADS), qp_assemble_lds_bytes(s->m_nj, nv, nq, nk), s->stream, qa);
+  HIP_OK(hipGetLastError());
+  if (!S->warm_start) {
+    HIP_OK(hipMemsetAsync(s->dx, 0, B * n * sizeof(double), s->stream));
+    HIP_OK(hipMemsetAsync(s->dy, 0, B * neq * sizeof(double), s->stream));
+    HIP_OK(hipMemsetAsync(s->dz, 0, B * nin * sizeof(double), s->stream));
+  }
+}
+
+QpIdBuffers qp_id_buffers(mpc_qp_solver* s) {
+  QpIdBuffers o;
+  o.stream = s->stream; o.xrob = s->d_xrob; o.acc = s->d_acc; o.f = s->d_f; o.cs = s->d_cs; o.sol = s->dx; o.info = s->dinfo;
+  o.B = s->d.batch; o.n = s->d.n; o.nq = s->m_nq; o.nv = s->m_nv; o.nk = s->id_nk; o.device = s->d.device;
+  return o;
+}
+void qp_launch_solve(mpc_qp_solver* s, const mpc_qp_settings* S) { qp_launch(s, S); }
+double* qp_scratch(mpc_qp_solver* s, size_t doubles) {
+  if (s->glue_cap < doubles) { s->d_glue = s->alloc<double>(doubles); s->glue_cap = doubles; }
+  return s->d_glue;
+}
+void qp_set_error(mpc_qp_solver* s, const char* what) { s->err = what; }
+
+extern "C" {
+
 int mpc_qp_solve_id(mpc_qp_solver* s, const mpc_qp_settings* S, int32_t nk, const int32_t* frames, const double* weights, const double* cone, double kd,
                     const double* xrob, const double* acc, const double* forces, const int32_t* contact_states,
                     double* x, double* y, double* z, mpc_qp_info* info, double* A_out, double* b_out, double* C_out, double* l_out) {
   if (!s) return -2;
   try {
-    HIP_OK(hipSetDevice(s->d.device));
-    if (!S || !frames || !weights || !cone || !xrob || !acc || !forces || !contact_states || !x || !info) throw std::runtime_error("qp_solve_id: null argument");
-    if (!s->d_mi) throw std::runtime_error("qp_solve_id: mpc_qp_set_model first");
+    if (!S || !xrob || !acc || !forces || !contact_states || !x || !info) throw std::runtime_error("qp_solve_id: null argument");
+    qp_id_prepare(s, nk, frames, weights, cone);
     const mpc_qp_dims& d = s->d;
     const int nv = s->m_nv, nq = s->m_nq;
-    if (nk <= 0 || d.n != 2 * nv - 6 + 6 * nk || d.neq != nv + 6 * nk || d.nin != 9 * nk || d.box)
-      throw std::runtime_error("qp_solve_id: the handle's dimensions are not those of the inverse-dynamics QP (n = 2 nv - 6 + 6 nk, neq = nv + 6 nk, nin = 9 nk, no box)");
-    for (int c = 0; c < nk; ++c) if (frames[c] < 0 || frames[c] >= s->m_nframes) throw std::runtime_error("qp_solve_id: contact frame index out of range");
     const size_t B = d.batch, n = d.n, neq = d.neq, nin = d.nin;
-    if (!s->d_xrob || s->id_nk != nk) {
-      s->d_xrob = s->alloc<double>(B * (nq + nv)); s->d_acc = s->alloc<double>(B * nv); s->d_f = s->alloc<double>(B * 6 * nk);
-      s->d_cs = s->alloc<int32_t>(B * nk); s->d_frames = s->alloc<int32_t>(nk); s->d_cone = s->alloc<double>(108);
-      s->id_nk = nk; s->id_const_uploaded = false;
-      qp_lds_attr_max((const void*)k_qp_assemble<false>, (int)qp_assemble_lds_bytes(s->m_nj, nv, nq, nk));
-    }
-    // the constant parts: H = diag(w0 I_nv, w1 I_6nk, 0), g = 0, u = 1e5 (as the reference), frames, cone rows: uploaded when they change
-    std::vector<double> key(110 + nk);
-    key[0] = weights[0]; key[1] = weights[1];
-    for (int i = 0; i < 108; ++i) key[2 + i] = cone[i];
-    for (int c = 0; c < nk; ++c) key[110 + c] = frames[c];
-    if (!s->id_const_uploaded || key != s->id_const) {
-      std::vector<double> H(n * n, 0.0), g(n, 0.0), u(nin, 1e5);
-      for (int i = 0; i < nv; ++i) H[(size_t)i * n + i] = weights[0];
-      for (int i = 0; i < 6 * nk; ++i) H[(size_t)(nv + i) * n + nv + i] = weights[1];
-      for (size_t bi = 0; bi < B; ++bi) {
-        HIP_OK(hipMemcpyAsync(s->dH + bi * n * n, H.data(), n * n * sizeof(double), hipMemcpyHostToDevice, s->stream));
-        HIP_OK(hipMemcpyAsync(s->dg + bi * n, g.data(), n * sizeof(double), hipMemcpyHostToDevice, s->stream));
-        HIP_OK(hipMemcpyAsync(s->du + bi * nin, u.data(), nin * sizeof(double), hipMemcpyHostToDevice, s->stream));
-      }
-      HIP_OK(hipMemcpyAsync(s->d_frames, frames, nk * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
-      HIP_OK(hipMemcpyAsync(s->d_cone, cone, 108 * sizeof(double), hipMemcpyHostToDevice, s->stream));
-      HIP_OK(hipStreamSynchronize(s->stream));  // (host vectors go out of scope)
-      s->id_const = key; s->id_const_uploaded = true;
-    }
     HIP_OK(hipMemcpyAsync(s->d_xrob, xrob, B * (nq + nv) * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipMemcpyAsync(s->d_acc, acc, B * nv * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipMemcpyAsync(s->d_f, forces, B * 6 * nk * sizeof(double), hipMemcpyHostToDevice, s->stream));
     HIP_OK(hipMemcpyAsync(s->d_cs, contact_states, B * nk * sizeof(int32_t), hipMemcpyHostToDevice, s->stream));
-    QpAssembleArgs qa = {};
-    qa.mi = s->d_mi; qa.md = s->d_md; qa.x = s->d_xrob; qa.acc = s->d_acc; qa.f = s->d_f; qa.cs = s->d_cs; qa.frames = s->d_frames; qa.cone = s->d_cone;
-    qa.kd = kd; qa.nk = nk; qa.n = (int)n; qa.neq = (int)neq; qa.nin = (int)nin;
-    qa.A = s->dA; qa.b = s->db; qa.C = s->dC; qa.l = s->dl;
-    hipLaunchKernelGGL(k_qp_assemble<false>, dim3(d.batch), dim3(QPA_THREADS), qp_assemble_lds_bytes(s->m_nj, nv, nq, nk), s->stream, qa);
-    HIP_OK(hipGetLastError());
-    if (!S->warm_start) {
-      HIP_OK(hipMemsetAsync(s->dx, 0, B * n * sizeof(double), s->stream));
-      HIP_OK(hipMemsetAsync(s->dy, 0, B * neq * sizeof(double), s->stream));
-      HIP_OK(hipMemsetAsync(s->dz, 0, B * nin * sizeof(double), s->stream));
-    }
+    qp_id_enqueue(s, S, kd);
     if (A_out) HIP_OK(hipMemcpyAsync(A_out, s->dA, B * neq * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     if (b_out) HIP_OK(hipMemcpyAsync(b_out, s->db, B * neq * sizeof(double), hipMemcpyDeviceToHost, s->stream));
     if (C_out) HIP_OK(hipMemcpyAsync(C_out, s->dC, B * nin * n * sizeof(double), hipMemcpyDeviceToHost, s->stream));

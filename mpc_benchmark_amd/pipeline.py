@@ -56,6 +56,7 @@ class KinodynamicPipeline:
         self.x_prev = self.x.copy()                      # the measurement of the tick before (the solve's initial condition)
         self.torques = np.zeros((self.batch, m.nv - 6))
         self.forces = np.zeros((self.batch, 12))
+        self._plan_stale = True
 
     # -- simulator stand-in: one handle, horizon 1, whole-body contact dynamics of the three contact patterns ----------------------
     def _build_simulator(self):
@@ -108,6 +109,7 @@ class KinodynamicPipeline:
         return st
 
     def _fetch(self):
+        self._plan_stale = False
         r = self.mpc.native.get_results(gains=False)
         self.xs0, self.us0 = r["xs"][:, 0].copy(), r["us"][:, 0].copy()
         self.K0 = self.mpc.native.get_gain(0)[0]
@@ -121,7 +123,9 @@ class KinodynamicPipeline:
         return self.pd.contact_phases[max(0, t + 1 - N) % self.pd.t_mpc]
 
     def low_level_step(self, cs):
-        """One 1 kHz step of kinodynamic_talos.py:411-462 for every robot."""
+        """One 1 kHz step of kinodynamic_talos.py:411-462 for every robot, the glue between the library calls on the host."""
+        if self._plan_stale:
+            self._fetch()
         nq, nv = self.nq, self.nv
         x = self.x
         d = np.concatenate([pin.difference_batch(self.model, x[:, :nq], self.xs0[:, :nq]), self.xs0[:, nq:] - x[:, nq:]], axis=1)  # space.difference(x_measured, xs[0])
@@ -134,14 +138,26 @@ class KinodynamicPipeline:
         self.torques, self.forces = tau, f_new
         return tau
 
-    def tick(self):
-        """One MPC period: the low-level loop on the current plan, then the next solve from the measurement of the tick before."""
+    def low_level_loop(self, cs):
+        """The ``substeps`` low-level periods of one MPC period inside the library (mpc_qp_low_level_steps: feedback terms, QP, clamp and simulator step chained
+        on the device, one synchronisation).  -> the measured states before the last period (the script reads x_measured BEFORE the last execute of the tick)."""
+        cs_all = np.tile(np.asarray(cs, dtype=np.int32), (self.batch, 1))
+        x_last, self.x, self.torques, self.forces = self.qp.low_level_steps(self.mpc.native, self.sim, cs_all, self.umax, self.substeps, self.sim_dt, x=self.x)
+        return x_last
+
+    def tick(self, host_glue=False):
+        """One MPC period: the low-level loop on the current plan, then the next solve from the measurement of the tick before.  ``host_glue``: the low-level
+        periods one at a time with the small vectors travelling through the host (``low_level_step``: the readable form, what the library call is tested against)."""
         cs = self.contact_state()
         self._set_sim_contacts(cs)
-        x_meas_top = self.x.copy()
-        for _ in range(self.substeps):
-            x_last = self.x.copy()   # (the script's x_measured is read BEFORE the last execute of the tick)
-            self.low_level_step(cs)
+        if host_glue:
+            if self._plan_stale:
+                self._fetch()
+            for _ in range(self.substeps):
+                x_last = self.x.copy()   # (the script's x_measured is read BEFORE the last execute of the tick)
+                self.low_level_step(cs)
+        else:
+            x_last = self.low_level_loop(cs)
         e = self.mpc
         if e._walk is not None:     # the references are planned from the state that becomes the initial condition (walking_loop.py)
             e._walk["x_measured"] = self.x_prev[0].copy()
@@ -150,5 +166,5 @@ class KinodynamicPipeline:
         e.native.set_x0(self.x_prev)
         st = e.step()
         self.x_prev = x_last
-        self._fetch()
+        self._plan_stale = True   # (knot 0 of the new plan is read on the device; the host copies only when the host glue asks)
         return st

@@ -136,6 +136,19 @@ class IDSolver_ulim:
         return res + (out[4],) if return_matrices else res
 
 
+    def low_level_steps(self, plan, sim, cs, tau_max, steps, dt, x=None):
+        """``steps`` periods of the script's low-level loop (kinodynamic_talos.py:411-462) inside the library (mpc_qp_low_level_steps): ``plan`` / ``sim`` the
+        NativeSolver handles of the MPC problem and of the simulator stand-in.  -> x_prev, x, torque, new_forces (of the last period)."""
+        if not hasattr(self, "_frame_idx"):
+            self.enable_device_assembly()
+        x_prev, x_out, tau, forces, info = self.qp.low_level_steps(plan, sim, self._frame_idx, self._weights, self.Cmin, float(self.baum_Kd[0, 0]), cs, tau_max,
+                                                                   steps, dt, x=x, cone_l=self.Cl)
+        self.last_info = info
+        if self.warm_start:
+            self.qp.settings.warm_start = 1
+        return x_prev, x_out, tau, forces
+
+
 class IKIDSolver_f6:
     """Inverse kinematics + inverse dynamics in one QP (QP_utils.py:584-762, used at centroidal_talos.py:326, 435): unknowns
     ``x = (a, df, tau)``; tasks in the cost — posture (w0), foot accelerations (w1), centroidal momentum rate (w2), base and

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 #include "solver.hpp"
+#include "../include/mpc_qp_abi.h"
 
 using namespace orc;
 
@@ -266,6 +267,65 @@ int mpc_simulate_torque(mpc_solver* h, const double* x, const double* tau, int32
     h->perfect_feedback = false;
   })
 }
+// include/mpc_qp_abi.h mpc_qp_low_level_steps: the low-level loop of kinodynamic_talos.py:411-462 as a plain host loop over this library's own
+// entry points (the HIP library does the same with two small kernels between the stages, csrc/pipeline_glue.h)
+extern "C" void orc_qp_set_error(mpc_qp_solver* s, const char* what);  // qp_capi.cpp
+int mpc_qp_low_level_steps(mpc_qp_solver* qp, const mpc_qp_settings* S, mpc_solver* plan, mpc_solver* sim, int32_t nk, const int32_t* frames,
+                           const double* weights, const double* cone, double kd, const int32_t* contact_states, const double* tau_max,
+                           const double* x, int32_t steps, double dt, double* x_prev, double* x_out, double* tau, double* forces, mpc_qp_info* info) {
+  if (!qp) return -2;
+  try {
+    if (!S || !plan || !sim || !contact_states || !tau_max || !frames || !weights || !cone) throw std::runtime_error("qp_low_level_steps: null argument");
+    if (steps <= 0 || !(dt > 0.0)) throw std::runtime_error("qp_low_level_steps: steps and dt must be positive");
+    const Solver& ps = plan->s;
+    Solver& zs = sim->s;
+    const Model& m = ps.model;
+    const int B = ps.dims.batch, nq = m.nq, nv = m.nv, nx = nq + nv, n = 2 * nv, nu = nv - 6, nf = 6 * nk, mu = ps.dims.nu, qn = 2 * nv - 6 + nf;
+    if (zs.dims.batch != B) throw std::runtime_error("qp_low_level_steps: the three handles must have the same batch size");
+    if (ps.dims.space != MPC_SPACE_MULTIBODY || ps.dims.nx != nx || ps.dims.ndx != n || mu != nf + nu)
+      throw std::runtime_error("qp_low_level_steps: the plan must be a multibody problem with nx = nq + nv and controls (6 nk contact wrench components, nv - 6 joint accelerations)");
+    if (zs.dims.space != MPC_SPACE_MULTIBODY || zs.dims.nx != nx || zs.dims.nu != nu)
+      throw std::runtime_error("qp_low_level_steps: the simulator handle must hold whole-body contact dynamics with nu = nv - 6 (the handle of mpc_simulate_torque)");
+    std::vector<double> xm((size_t)B * nx), a0((size_t)B * nv), f0((size_t)B * nf), sol((size_t)B * qn), tq((size_t)B * nu), fn((size_t)B * nf), d(n);
+    std::vector<mpc_qp_info> inf(B);
+    if (x) std::memcpy(xm.data(), x, xm.size() * sizeof(double));
+    else for (int b = 0; b < B; ++b) std::memcpy(xm.data() + (size_t)b * nx, zs.inst[b].x0.data(), nx * sizeof(double));
+    for (int step = 0; step < steps; ++step) {
+      if (step == steps - 1 && x_prev) std::memcpy(x_prev, xm.data(), xm.size() * sizeof(double));
+      for (int b = 0; b < B; ++b) {
+        const Instance& in = ps.inst[b];
+        mb_difference(m, xm.data() + (size_t)b * nx, in.xs[0].data(), d.data());  // difference(x_measured, xs[0])
+        const std::vector<double>& K0 = in.gains[0].K;
+        for (int i = 0; i < mu; ++i) {
+          double su = 0.0;
+          for (int j = 0; j < n; ++j) su += K0[(size_t)i * n + j] * d[j];
+          su = in.us[0][i] - su;
+          if (i < nf) f0[(size_t)b * nf + i] = su; else a0[(size_t)b * nv + 6 + (i - nf)] = su;
+        }
+        for (int i = 0; i < 6; ++i) a0[(size_t)b * nv + i] = in.knots[0].xdot[nv + i];
+      }
+      if (mpc_qp_solve_id(qp, S, nk, frames, weights, cone, kd, xm.data(), a0.data(), f0.data(), contact_states, sol.data(), nullptr, nullptr, inf.data(),
+                          nullptr, nullptr, nullptr, nullptr) != 0)
+        return -1;  // (the QP handle holds the message)
+      for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < nu; ++i) tq[(size_t)b * nu + i] = std::fmin(std::fmax(sol[(size_t)b * qn + nv + nf + i], -tau_max[i]), tau_max[i]);
+        for (int i = 0; i < nf; ++i) fn[(size_t)b * nf + i] = f0[(size_t)b * nf + i] + sol[(size_t)b * qn + nv + i];
+        zs.simulate_torque(zs.inst[b], xm.data() + (size_t)b * nx, tq.data() + (size_t)b * nu, 1, dt, nullptr);
+        std::memcpy(xm.data() + (size_t)b * nx, zs.inst[b].x0.data(), nx * sizeof(double));
+      }
+    }
+    sim->perfect_feedback = false;
+    if (x_out) std::memcpy(x_out, xm.data(), xm.size() * sizeof(double));
+    if (tau) std::memcpy(tau, tq.data(), tq.size() * sizeof(double));
+    if (forces) std::memcpy(forces, fn.data(), fn.size() * sizeof(double));
+    if (info) std::memcpy(info, inf.data(), inf.size() * sizeof(mpc_qp_info));
+    return 0;
+  } catch (const std::exception& e) {
+    orc_qp_set_error(qp, e.what());
+    return -1;
+  }
+}
+
 int mpc_get_x0(mpc_solver* h, double* x0) {
   MPC_TRY(h, {
     const int nx = h->s.dims.nx;

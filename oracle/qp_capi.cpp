@@ -27,6 +27,7 @@ int mpc_qp_create(const mpc_qp_dims* dims, mpc_qp_solver** out) {
 }
 void mpc_qp_destroy(mpc_qp_solver* s) { delete s; }
 const char* mpc_qp_last_error(mpc_qp_solver* s) { return s ? s->err.c_str() : "null handle"; }
+void orc_qp_set_error(mpc_qp_solver* s, const char* what) { if (s) s->err = what; }  // (for mpc_qp_low_level_steps in capi.cpp)
 void mpc_qp_default_settings(mpc_qp_settings* o) {
   o->eps_abs = 1e-5; o->rho = 1e-6; o->mu_eq = 1e-3; o->mu_in = 1e-1; o->mu_min_eq = 1e-9; o->mu_min_in = 1e-8;
   o->mu_update_factor = 0.1; o->alpha_bcl = 0.1; o->beta_bcl = 0.9; o->max_iter = 10000; o->max_iter_in = 1500; o->warm_start = 0; o->reserved = 0;

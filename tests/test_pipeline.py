@@ -28,6 +28,42 @@ def test_pipeline_keeps_the_robots_standing_on_the_oracle(oracle_lib):
     assert np.all(p.forces[:, 2] > 100.0) and np.all(p.forces[:, 8] > 100.0)  # both feet carry weight in double support
 
 
+def _glue_vs_host(lib, ticks, tol):
+    """mpc_qp_low_level_steps (the ten low-level periods inside the library) against the same periods one library call at a time with the feedback terms,
+    the clamp and the bookkeeping of x_measured in numpy (KinodynamicPipeline.low_level_step, kinodynamic_talos.py:411-462)."""
+    pl, ph = _pipeline(lib, walk={}), _pipeline(lib, walk={})
+    worst = 0.0
+    for t in range(ticks):
+        sl, sh = pl.tick(), ph.tick(host_glue=True)
+        ex = rel_cols(pl.x, ph.x, 1e-3)
+        ep = rel_cols(pl.x_prev, ph.x_prev, 1e-3)
+        et = rel_cols(pl.torques, ph.torques, 1.0)
+        ef = rel_cols(pl.forces, ph.forces, 1.0)
+        assert max(ex, ep, et, ef) < tol, "tick %d: states %.2e (before the last period %.2e) torques %.2e forces %.2e" % (t, ex, ep, et, ef)
+        assert [s.num_iters for s in sl] == [s.num_iters for s in sh]
+        worst = max(worst, ex, ep, et, ef)
+    return worst
+
+
+def test_library_low_level_loop_equals_host_glue_on_the_oracle(oracle_lib):
+    print("oracle: library loop against host glue over 6 periods: %.3e" % _glue_vs_host(oracle_lib, 6, 1e-9))
+
+
+def test_low_level_loop_rejects_mismatched_handles(oracle_lib):
+    p = _pipeline(oracle_lib, walk={})
+    other = KinodynamicPipeline(KinodynamicProblem(horizon=40), batch=3, library=oracle_lib)
+    with pytest.raises(RuntimeError, match="same batch size"):
+        p.qp.qp.low_level_steps(p.mpc.native, other.sim, p.qp._frame_idx, p.qp._weights, p.qp.Cmin, 50.0, np.ones((2, 2), dtype=np.int32), p.umax, 1, 1e-3, x=p.x)
+    with pytest.raises(RuntimeError, match="positive"):
+        p.qp.qp.low_level_steps(p.mpc.native, p.sim, p.qp._frame_idx, p.qp._weights, p.qp.Cmin, 50.0, np.ones((2, 2), dtype=np.int32), p.umax, 0, 1e-3, x=p.x)
+
+
+@pytest.mark.gpu
+def test_library_low_level_loop_equals_host_glue_on_the_device(hip_lib):
+    """The two glue kernels (csrc/pipeline_glue.h) between plan, QP and simulator against the numpy glue around the same library calls."""
+    print("HIP: device glue against host glue over 8 periods: %.3e" % _glue_vs_host(hip_lib, 8, 1e-9))
+
+
 @pytest.mark.gpu
 def test_pipeline_hip_matches_oracle(hip_lib, oracle_lib):
     """Eight MPC periods (80 low-level steps: QP + simulator step each) of two perturbed robots: measured states, QP torques and contact

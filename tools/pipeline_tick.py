@@ -25,10 +25,16 @@ for _ in range(T):
     p.tick()
     lat.append((time.perf_counter() - t0) * 1e3)
 lat = np.array(lat)
-# the low-level part alone
+# the low-level part alone: inside the library (mpc_qp_low_level_steps: what tick() runs) and with the glue on the host (the round-4 form)
+cs = p.contact_state(); p._set_sim_contacts(cs)
+p.low_level_loop(cs)
+t0 = time.perf_counter()
+for _ in range(10):
+    p.low_level_loop(cs)
+ll = (time.perf_counter() - t0) / (10 * p.substeps) * 1e3
 t0 = time.perf_counter()
 for _ in range(50):
-    p.low_level_step(p.contact_state())
-ll = (time.perf_counter() - t0) / 50 * 1e3
-print("kinodynamic pipeline, %s model, N = %d, %d robots: MPC period p50 %.2f ms p90 %.2f ms ; one low-level step (ID QP assembled + solved on the device, simulator step, host glue) %.3f ms ; base heights %.4f .. %.4f" % (
-    "complete" if complete else "reduced", N, B, np.percentile(lat, 50), np.percentile(lat, 90), ll, p.x[:, 2].min(), p.x[:, 2].max()))
+    p.low_level_step(cs)
+lh = (time.perf_counter() - t0) / 50 * 1e3
+print("kinodynamic pipeline, %s model, N = %d, %d robots: MPC period p50 %.2f ms p90 %.2f ms ; one low-level step (feedback terms, ID QP assembled + solved, clamp, simulator step: all on the device, one synchronisation per %d steps) %.3f ms ; with the glue on the host %.3f ms ; base heights %.4f .. %.4f" % (
+    "complete" if complete else "reduced", N, B, np.percentile(lat, 50), np.percentile(lat, 90), p.substeps, ll, lh, p.x[:, 2].min(), p.x[:, 2].max()))
