@@ -81,3 +81,31 @@ def test_pipeline_hip_matches_oracle(hip_lib, oracle_lib):
         assert ex < 1e-6 and et < 1e-5 and ef < 1e-5, "tick %d: states %.2e torques %.2e forces %.2e" % (t, ex, et, ef)
         worst = max(worst, ex, et, ef)
     print("pipeline: worst deviation over 8 ticks %.3e" % worst)
+
+
+@pytest.mark.gpu
+def test_pipeline_walks_the_whole_schedule(hip_lib):
+    """kinodynamic_talos.py:361-497 from the first tick to the last for eight perturbed robots, every instance replanning its steps from its own
+    feet: 819 MPC periods = 8 190 low-level periods (feedback terms, inverse-dynamics QP, clamp, simulator step — mpc_qp_low_level_steps), the
+    simulator's contact set following the schedule through six steps.  Nobody falls, every robot ends 1.5 m further (six steps of 0.3 m, the
+    last one closing), the torques stay inside the effort limits.  (profiles/r05_pipeline_walk.txt: the same with 64 robots, 8.9 ms per period.)"""
+    kp = KinodynamicProblem(horizon=100)
+    p = KinodynamicPipeline(kp, batch=8, library=hip_lib, walk={"per_instance": True}, seed=7, perturb_dofs=range(18, kp.nv), tick_reuse=True)
+    p.mpc.options.riccati_legs = 32
+    p.mpc.native.set_options(p.mpc.options)
+    T = kp.t_mpc - 1
+    p.mpc.prepare_schedule(T + 8)
+    p.cold_solve()
+    x0 = p.x.copy()
+    worst_tau, single_support = 0.0, 0
+    for t in range(T):
+        st = p.tick()
+        assert all(s.converged >= 0 for s in st), (t, [s.converged for s in st])
+        assert np.all(np.isfinite(p.x)) and np.all(np.abs(p.x[:, 2] - x0[:, 2]) < 0.05), (t, p.x[:, 2] - x0[:, 2])
+        worst_tau = max(worst_tau, float(np.max(np.abs(p.torques) / p.umax)))
+        single_support += int(not all(p.contact_state()))
+    walked = p.x[:, 0] - x0[:, 0]
+    print("pipeline over %d MPC periods (%d of them in single support): walked %.3f .. %.3f m, largest |tau| / limit %.2f" % (T, single_support, walked.min(), walked.max(), worst_tau))
+    assert single_support > 300
+    assert np.all(walked > 1.4) and np.all(walked < 1.6), walked
+    assert worst_tau <= 1.0 + 1e-12
