@@ -84,6 +84,33 @@ def test_pipeline_hip_matches_oracle(hip_lib, oracle_lib):
 
 
 @pytest.mark.gpu
+def test_pipeline_hip_matches_oracle_into_single_support(hip_lib, oracle_lib):
+    """The two pipelines FREE-RUNNING (never re-synchronised) from the same cold solve through the first take-off: a short horizon (N = 20) puts the
+    contact switch of the low-level loop — the simulator's contact set, the QP's contact states — at period 38; 43 periods = 430 QP + simulator steps, the last
+    50 of them on one foot.  States, torques and contact forces within 1e-6 (measured: 1e-9 while both feet stand, 1.2e-7 at the end; the closed loop
+    amplifies from there — 7e-7 at period 43, 1e-5 at 47, tools/experiments/pipeline_free_running.py)."""
+    def make(lib):
+        p = KinodynamicPipeline(KinodynamicProblem(horizon=20), batch=2, library=lib, walk={}, perturb=True, sigma_q=0.005, sigma_v=0.01)
+        p.mpc.options.num_threads = 8
+        p.mpc.native.set_options(p.mpc.options)
+        p.mpc.prepare_schedule(80)
+        p.cold_solve()
+        return p
+    po, ph = make(oracle_lib), make(hip_lib)
+    ph.mpc.native.set_state(po.mpc.native.get_state())
+    worst, single = 0.0, 0
+    for t in range(43):
+        ph.tick(), po.tick()
+        assert list(ph.contact_state()) == list(po.contact_state())
+        single += int(not all(po.contact_state()))
+        e = max(rel_cols(ph.x, po.x, 1e-3), rel_cols(ph.torques, po.torques, 1.0), rel_cols(ph.forces, po.forces, 1.0))
+        assert e < 1e-6, "period %d (contact state %s): %.2e" % (t, list(po.contact_state()), e)
+        worst = max(worst, e)
+    assert single >= 5
+    print("pipeline free-running into single support: worst deviation over 43 periods %.3e (%d periods on one foot)" % (worst, single))
+
+
+@pytest.mark.gpu
 def test_pipeline_walks_the_whole_schedule(hip_lib):
     """kinodynamic_talos.py:361-497 from the first tick to the last for eight perturbed robots, every instance replanning its steps from its own
     feet: 819 MPC periods = 8 190 low-level periods (feedback terms, inverse-dynamics QP, clamp, simulator step — mpc_qp_low_level_steps), the
