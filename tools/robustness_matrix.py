@@ -12,7 +12,8 @@ ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 999
 for refs in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("frozen", "shared", "instance")):
     for R in [int(v) for v in os.environ.get("REFINES", "0,3").split(",")]:
         pd = FullDynamicsProblem(horizon=100, complete_model=True)
-        (e,) = make_bench_shards(pd, lib, 64, legs=4, tick_reuse=True, seed=int(os.environ.get("SEED", "20250304")))
+        closed = (10, pd.dt / 10) if os.environ.get("CLOSED") else None  # CLOSED=1: measured states from the simulation stand-in (mpc_simulate: 10 x 1 ms of knot 0's contact dynamics under u = us[0] - K_0 difference(x, xs[0])) instead of perfect-model feedback
+        (e,) = make_bench_shards(pd, lib, 64, legs=4, tick_reuse=True, seed=int(os.environ.get("SEED", "20250304")), closed_loop=closed)
         e.options.refine_appended_knot = R
         e.options.corrector_prim_tol = float(os.environ.get("CORRECTOR", "20"))
         e.options.corrector_window = int(os.environ.get("WINDOW", "0"))
@@ -34,6 +35,6 @@ for refs in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("frozen", "shared
                     nominal_lost = True; print("   (the nominal instance failed at tick %d)" % t, flush=True)
         while e.inflight:
             e.wait()
-        print("references %-8s refine_appended_knot %d: %3d instance losses in %d ticks (first at tick %s; instances %s) ; largest primal infeasibility before a step %.2e ; corrector %g: %d instance-ticks on %d ticks, %d backtracking instance-ticks ; %.1f s" % (
+        print(("closed loop (simulated measurements), " if closed else "") + "references %-8s refine_appended_knot %d: %3d instance losses in %d ticks (first at tick %s; instances %s) ; largest primal infeasibility before a step %.2e ; corrector %g: %d instance-ticks on %d ticks, %d backtracking instance-ticks ; %.1f s" % (
             refs, R, len(e.lost), ticks, e.lost[0][0] if e.lost else "-", sorted(set(r[1] for r in e.lost))[:12], worst, e.options.corrector_prim_tol, extra, extra_ticks, back, time.time() - t0), flush=True)
         del e
