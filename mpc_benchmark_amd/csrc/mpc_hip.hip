@@ -49,7 +49,7 @@ static void lds_attr_max(const void* fn, int bytes) {
 //   NP, MP: padded state / control dimension (the template arguments of the tree and of k_leg_knot)
 // 1: complete Talos (38 dofs), full dynamics   2: complete Talos, kinodynamic   3: Talos with the upper body locked as the scripts lock it
 // (28 dofs), full dynamics   4: the same, kinodynamic.  The stage kernel has its own list (eval_multibody.hip).
-#define MPC_FIXED_MODELS(X) X(1, 76, 32, 1, 1, 80, 32) X(2, 76, 44, 2, 0, 80, 48) X(3, 56, 22, 1, 1, 64, 32) X(4, 56, 34, 1, 1, 64, 48)
+#define MPC_FIXED_MODELS(X) X(1, 76, 32, 1, 1, 80, 32) X(2, 76, 44, 3, 0, 80, 48) X(3, 56, 22, 3, 1, 64, 32) X(4, 56, 34, 3, 1, 64, 48)
 
 struct mpc_solver {
   mpc_dims dims{};
@@ -345,14 +345,21 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   o.num_threads = 1; o.riccati_legs = 1; o.forward_mode = 0;
   lds_attr_max((const void*)k_riccati_backward, 160 * 1024);
   s->ric = make_ric_lds(L.n, L.m, L.c, 1);
+  // whole-body dynamics rows come in factored form (layout.h, oD12): the sweep multiplies with the v rows of [A B] only
+  const bool sq_ok = L.space == MPC_SPACE_MULTIBODY && L.n % 2 == 0 && L.n >= 24 && !getenv("MPC_HIP_DENSE_AB");
+  if (sq_ok && (s->ric.total_bytes > 160 * 1024 || !s->ric.ovl) && !getenv("MPC_HIP_FULL_AB")) {
+    // ... and then only those rows need to be in LDS (plan 3 of make_ric_lds): room for G_u and for the factor of Ruu beside [A B] where plan 1 has none (m > 32)
+    RicLds c3 = make_ric_lds(L.n, L.m, L.c, 3);
+    if (c3.total_bytes > 160 * 1024) c3 = make_ric_lds(L.n, L.m, L.c, 3, 0);
+    if (c3.total_bytes <= 160 * 1024 && c3.ovl && (c3.st_lds || c3.mp * c3.np <= L.n * L.nz)) s->ric = c3;
+  }
   if (s->ric.total_bytes > 160 * 1024 && ((L.n + 15) & ~15) * ((L.m + 15) & ~15) <= L.n * L.n) {
     s->ric = make_ric_lds(L.n, L.m, L.c, 2);                                         // whole G, its u part in the L2 scratch (large m)
     if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 2, 0);
   }
   if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0);     // panel-wise G when the whole G does not fit
   if (s->ric.total_bytes > 160 * 1024) s->ric = make_ric_lds(L.n, L.m, L.c, 0, 0);  // large m: Sh^T out of LDS as well
-  // whole-body dynamics rows come in factored form (layout.h, oD12): the sweep multiplies with the v rows of [A B] only
-  if (L.space == MPC_SPACE_MULTIBODY && s->ric.gfull && L.n % 2 == 0 && L.n >= 24 && !getenv("MPC_HIP_DENSE_AB")) { s->ric.sq = 1; s->ric.nv = L.n / 2; }
+  if (sq_ok && s->ric.gfull) { s->ric.sq = 1; s->ric.nv = L.n / 2; }
   s->cl = make_cl_lds(L.n, L.m);
   if (s->cl.total_bytes <= 160 * 1024)
     lds_attr_max((const void*)k_closed_loop, s->cl.total_bytes);

@@ -63,7 +63,12 @@ static inline constexpr RicLds make_ric_lds(int n, int m, int c, int gfull = 1, 
   RicLds s{};
   s.st_lds = st_lds;  // 0: Sh^T (mp x np) lives in the L2-resident per-instance scratch instead of LDS (large m)
   s.gfull = gfull;  // 1: G = Pt [A B] kept whole (x part over PT, u part in GP) — needs np x mp doubles for GP instead of np x 16 ;
-                    // 2: whole G with its u part in the L2-resident scratch (large m: only the few Ruu tiles read it back)
+                    // 2: whole G with its u part in the L2-resident scratch (large m: only the few Ruu tiles read it back) ;
+                    // 3: as 1 for a STRUCTURED problem (SQ kernels only): the sweep touches rows ks = (n / 2) & ~3 .. np of [A B] and nothing else, so the
+                    //    region holds just those (S.AB points ks rows in front of it) — 36 of 80 rows freed at n = 76, which is what lets G_u and the
+                    //    factor of Ruu stay on chip at m = 44 (round 5)
+  const bool g1 = gfull == 1 || gfull == 3;
+  const int ab_skip = gfull == 3 ? ((n / 2) & ~3) : 0;  // rows of [A B] in front of the first one the structured sweep reads
   s.np = (n + 15) & ~15; s.mp = (m + 15) & ~15; s.nzp = s.np + s.mp; s.ldl = s.np + 1; s.ldr = s.mp + 1;
   s.nb = s.np / 16; s.nbm = s.mp / 16;
 // Odd leading dimensions for W / CT / VX (np + 17) and Y = Da^T (17) since round 5: the A-operand fetch of  W -= Y VX  walks the ROWS of Y with a
@@ -84,7 +89,7 @@ static inline constexpr RicLds make_ric_lds(int n, int m, int c, int gfull = 1, 
   s.LP = take(s.np * s.ldl); s.LI = take(s.nb * 272);             // phase 1 view of R1
   const int end1 = o;
   o = s.R1;
-  s.AB = take(s.np * s.nzp); s.GP = take(gfull == 1 ? s.np * s.mp : (s.np * 16 > 8 * s.nzp ? s.np * 16 : 8 * s.nzp));               // phase 2 view (overlaps phase 1)
+  s.AB = take((s.np - ab_skip) * s.nzp) - ab_skip * s.nzp; s.GP = take(g1 ? s.np * s.mp : (s.np * 16 > 8 * s.nzp ? s.np * 16 : 8 * s.nzp));               // phase 2 view (overlaps phase 1)
   const int end2 = o;
   o = s.R1;                                                         // phase 3 view (overlaps AB)
   s.Lr = take(s.mp * s.ldr); s.LIr = take(s.nbm * 272); s.W = take(s.mp * s.lw); s.ST = take(st_lds ? s.mp * s.np : 0);
@@ -94,6 +99,18 @@ static inline constexpr RicLds make_ric_lds(int n, int m, int c, int gfull = 1, 
   // factorisation of Ruu then runs while the other wavefronts still multiply [A B]^T G_x for the x rows of Hh.  The other
   // phase-3 operands are written after those tiles and may lie over [A B] and the head of G_u.
   s.ovl = 0;
+  if (gfull == 3 && s.nbm <= 3) {
+    // compressed [A B]: the phase-3 operands first (over [A B] and G_u: written once both are dead), Lr / LIr behind them — past the end of [A B], which the
+    // other wavefronts still read while wavefront 0 factorises; over the tail of G_u at most, which is dead by then
+    int cur = s.R1;
+    auto place = [&](int cnt) { const int r = cur; cur += (cnt + 1) & ~1; return r; };
+    const int w_ = place(s.mp * s.lw), st_ = place(st_lds ? s.mp * s.np : 0), ct_ = place(16 * s.lw), vx_ = place(16 * s.lw), y_ = place(s.mp * RIC_LDY),
+              sc_ = place(16 * 17), lis_ = place(272);
+    const int lr = cur > s.GP ? cur : s.GP, lir = lr + ((s.mp * s.ldr + 1) & ~1);  // (s.GP = the end of [A B])
+    s.ovl = 1;
+    s.Lr = lr; s.LIr = lir; s.W = w_; s.ST = st_; s.CT = ct_; s.VX = vx_; s.Y = y_; s.SC = sc_; s.LIs = lis_;
+    end3 = lir + ((s.nbm * 272 + 1) & ~1);
+  }
   if (gfull == 1 && s.nbm <= 3) {
     const int need = ((s.mp * s.ldr + 1) & ~1) + ((s.nbm * 272 + 1) & ~1);
     const int lr = s.GP + ((s.np * s.mp - need) & ~1), lir = lr + ((s.mp * s.ldr + 1) & ~1);  // at the end of the G_u region
@@ -184,7 +201,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
   constexpr int AB_ROWS = SQ ? (NPMAX / 2 + NWV - 1) / NWV : PT_ROWS;             // register prefetch capacity: rows of [A B] per wavefront (SQ: v rows only)
   constexpr int RIC_SERIES_TILES = (NBMAX * (NBMAX + 1) / 2 + NWV - 1) / NWV;     // lower-triangle output tiles per wavefront
   constexpr int RIC_G_TILES = (NBMAX * NZTMAX + NWV - 1) / NWV;                   // tiles of G per wavefront
-  constexpr int RIC_U_TILES = NPMAX > 16 ? 2 : 1;
+  constexpr int RIC_U_TILES = NPMAX > 16 ? ((FX && FM > 32) ? 3 : 2) : 1;  // u tiles of Hh a wavefront keeps in registers (m > 32: 21 tiles on 8 wavefronts)
   constexpr bool CT_PREFETCH = NPMAX <= 80;  // the largest instantiation has no registers to spare for it
   constexpr int CT_ROWS = 16 / NWV, Y_ELEMS = (NPMAX > 16 ? 48 : 16) * 16 / RT + ((NPMAX > 16 ? 48 : 16) * 16 % RT ? 1 : 0);  // per-thread shares of CT (16 rows) and Y (mp x 16)  // lower-triangle tiles of the u rows of Hh a wavefront can keep in registers
   const Layout& L = a.L;
