@@ -147,7 +147,7 @@ struct mpc_solver {
   LxLds lx{};
   bool legs_ok = false;  // the dimensions fit the leg kernels (np <= 80, mp <= 48, at most 256 constraint rows, LDS carve-outs) and MPC_HIP_NO_LEGS is unset; otherwise riccati_legs > 1 silently keeps the serial sweep (mpc_abi.h)
   // developer knobs, read from the environment ONCE when the handle is created (MPC_LEGS_CHAIN, MPC_LEGS_PLAIN, MPC_TREE_SWEEPS, MPC_HIP_TRACE)
-  bool env_chain = false, env_plain = false;
+  bool env_chain = false, env_plain = false, env_reject_failed = false;
   int env_tree_sweeps = 0, env_trace = -1;
   double* d_legbuf = nullptr;
   double* d_treebuf = nullptr;
@@ -225,6 +225,7 @@ struct mpc_solver {
     for (int w = 0; w < MPC_DIRTY_WORDS; ++w) a.dirty[w] = a.reuse_on ? dirty_now[w] : 0ull;
     a.only_knot = only_knot;
     a.corrector_on = corrector_armed() ? 1 : 0;
+    a.reject_failed = env_reject_failed ? 1 : 0;
     a.tree_pivoted = getenv("MPC_HIP_TREE_PIVOTED") ? 1 : 0;
     a.nlegs = eff_legs(); a.leg_cap = leg_cap; a.legbuf = d_legbuf; a.treebuf = d_treebuf; a.leg_guess = leg_guess_now;
     a.knots = d_knots; a.gains = d_gains; a.work = d_work; a.trial_phi = d_trial_phi; a.inst = d_inst; a.all_done = d_all_done; a.prof = phase_timers ? d_prof : nullptr;
@@ -273,6 +274,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
   { const char* e;
     e = getenv("MPC_LEGS_CHAIN"); s->env_chain = e && atoi(e) > 0;
     e = getenv("MPC_LEGS_PLAIN"); s->env_plain = e && atoi(e) > 0;
+    e = getenv("MPC_HIP_REJECT_FAILED"); s->env_reject_failed = e && atoi(e) > 0;
     e = getenv("MPC_TREE_SWEEPS"); s->env_tree_sweeps = e ? atoi(e) : 0;
     e = getenv("MPC_HIP_TRACE"); s->env_trace = e ? atoi(e) : -1; }
   HIP_OK(hipSetDevice(d.device));

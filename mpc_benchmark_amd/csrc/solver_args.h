@@ -55,6 +55,7 @@ struct SolverArgs {
   // knot, mpc_options.refine_appended_knot) ; -1: all knots
   int only_knot;
   int corrector_on;  // mpc_options.corrector_prim_tol applies to this run (corrector_window: the host knows which runs follow a change of the contact pattern)
+  int reject_failed;  // developer experiment (MPC_HIP_REJECT_FAILED=1): a linesearch whose last candidate still fails the Armijo test takes NO step instead of that candidate
   int tree_pivoted;  // 1: k_leg_compose skips its blocked elimination on the matrix cores and goes straight to the pivoted Gauss-Jordan (MPC_HIP_TREE_PIVOTED=1: developer comparison)
 };
 

@@ -654,7 +654,7 @@ __global__ void __launch_bounds__(64) k_linesearch(SolverArgs a, int first, int 
     const double* tp = a.trial_phi + ((size_t)b * L.n_alpha + step) * (L.N + 1);
     const double phi = knot_sum([&](int k) { return tp[k]; });
     if (phi <= st.phi0 + a.opt.ls_armijo_c1 * alpha * d) break;
-    if (step + 1 >= a.opt.ls_max_steps || step + 1 >= L.n_alpha || 0.5 * alpha < a.opt.ls_alpha_min) break;
+    if (step + 1 >= a.opt.ls_max_steps || step + 1 >= L.n_alpha || 0.5 * alpha < a.opt.ls_alpha_min) { if (a.reject_failed) alpha = 0.0; break; }
     if (step >= upto) return;  // the next candidate is evaluated by the second backtracking launch: undecided, ls_more stays set
     alpha *= 0.5;
   }
@@ -780,6 +780,7 @@ __global__ void k_accept(SolverArgs a) {
   if (st.done || st.skip_step || (st.stalled & 1)) return;
   const int n = L.n, N = L.N, nx = L.nx, m = L.m;
   const double alpha = st.alpha;
+  if (alpha == 0.0) return;  // (a rejected step, MPC_HIP_REJECT_FAILED: the iterate stays bit for bit)
   double* x = a.xs + ((size_t)b * (N + 1) + k) * nx;
   const double* dx = a.dxs + ((size_t)b * (N + 1) + k) * n;
   __shared__ double xn[160];
