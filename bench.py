@@ -174,6 +174,10 @@ def main():
                     help="mpc_options.corrector_prim_tol (include/mpc_abi.h): an instance whose one iteration of the tick started from a warm start that is "
                          "primal-infeasible by more than this, or whose step was shortened by the linesearch, takes one more iteration in the same tick "
                          "(2 - 5 %% of the instance-ticks of the schedule); the solver mirror's default.  0 = off: exactly max_iters iterations per solve")
+    ap.add_argument("--no-floor", action="store_true",
+                    help="walk with per-instance references: do NOT keep the measured soles on the floor (EnsembleMPC.enable_walk(floor=True), mpc_walk_config.floor_z: an "
+                         "ensemble that feeds the solver's prediction back has no ground, and the script's left-foot target 1 cm below the right foot's height "
+                         "(fulldynamic_talos.py:449) then sinks the footholds 5 - 6 cm over the schedule)")
     ap.add_argument("--corrector-window", type=int, default=8,
                     help="mpc_options.corrector_window: the corrector rule applies to the K ticks after a change of the contact pattern of the appended stage (0 = to every "
                          "tick).  With refine_appended_knot = 3 nobody is lost over the whole schedule for K = 8, 40 and 0 alike (profiles/r05_robustness.txt), and the "
@@ -265,7 +269,7 @@ def main():
             e.enable_failure_isolation(auto_revive=True, source=0)
             if walk:
                 gen = (generator or args.walk_generator) if args.walk_refs == "instance" else "host"
-                e.enable_walk(per_instance=(args.walk_refs == "instance"), generator=gen)
+                e.enable_walk(per_instance=(args.walk_refs == "instance"), generator=gen, floor=(args.walk_refs == "instance" and not args.no_floor))
 
         # instances whose tick was a BCL update / stall without a ProxDDP step (num_iters == 0 in the status of the tick): not a solve
         nostep = {"n": 0, "on": False, "extra": 0, "back": 0}
@@ -459,7 +463,7 @@ def main():
         return dict(shards=shards, ens=ens, legs=legs, cold=cold, n_conv=n_conv, n_conv100=n_conv100, worst_unconv=worst_unconv, regions=regions, nostep=nostep["n"], corrector_ticks=nostep["extra"], backtracking_ticks=nostep["back"], pace=pace, stagger=stagger, elapsed=elapsed,
                     prof=prof, warm=warm, gather=gather, replanning_ticks=replanning)
 
-    def whole_schedule(corrector, refine):
+    def whole_schedule(corrector, refine, floor=True):
         """The reference's WHOLE schedule (t_mpc - 1 ticks of fulldynamic_talos.py:438-550: seven swings) walked by the benchmarked ensemble in the
         headline's mode — two ticks in flight, per-tick time = interval between the completions of consecutive ticks — instead of a window of it:
         pattern-change ticks, contact switches at knot 0, backtracking and corrector ticks are all inside."""
@@ -474,7 +478,8 @@ def main():
         e.cold_solve(max_iters=args.cold_iters)
         e.enable_failure_isolation(auto_revive=True, source=0)
         if not args.no_walk:
-            e.enable_walk(per_instance=(args.walk_refs == "instance"), generator=(args.walk_generator if args.walk_refs == "instance" else "host"))
+            e.enable_walk(per_instance=(args.walk_refs == "instance"), generator=(args.walk_generator if args.walk_refs == "instance" else "host"),
+                          floor=(args.walk_refs == "instance" and not args.no_floor and floor))
         e.results(gains=False)
         ms, back_t, corr_t, corr_it, back_it, nostep_it, nominal_lost = [], 0, 0, 0, 0, 0, False
 
@@ -507,7 +512,7 @@ def main():
                "backtracking_ticks": back_t, "backtracking_instance_ticks": back_it, "corrector_ticks": corr_t, "corrector_instance_ticks": corr_it,
                "refinement_ticks": (sum(1 for t in range(1, ticks + 1) if tuple(pd.contact_phases[t % pd.t_mpc]) != tuple(pd.contact_phases[(t - 1) % pd.t_mpc])) if refine > 0 else 0),
                "instance_losses": len(e.lost), "instances_lost": lost[:16], "nominal_instance_lost": bool(nominal_lost or 0 in lost),
-               "settings": {"corrector_prim_tol": float(corrector), "corrector_window": int(e.options.corrector_window), "refine_appended_knot": int(refine), "iters_per_tick": int(args.iters_per_tick),
+               "settings": {"corrector_prim_tol": float(corrector), "corrector_window": int(e.options.corrector_window), "refine_appended_knot": int(refine), "floor_under_the_measured_soles": bool(args.walk_refs == "instance" and not args.no_floor and floor and not args.no_walk), "iters_per_tick": int(args.iters_per_tick),
                             "references": ("frozen" if args.no_walk else args.walk_refs), "feedback": "perfect model", "lost instances": "re-seeded from the nominal one (mpc_revive_instance)"}}
         del e
         return out
@@ -655,9 +660,9 @@ def main():
     if not args.no_whole_schedule and world == 1:
         whole = whole_schedule(args.corrector_prim_tol, args.refine_appended_knot)
         if args.refine_appended_knot != 0 and args.corrector_prim_tol > 0:
-            whole_plain = whole_schedule(args.corrector_prim_tol, 0)   # the scripts' plain warm start (us[-1] duplicated), corrector only
+            whole_plain = whole_schedule(args.corrector_prim_tol, 0, floor=False)   # the scripts' plain warm start (us[-1] duplicated), corrector only
         if args.corrector_prim_tol > 0 or args.refine_appended_knot != 0:
-            whole_ref = whole_schedule(0.0, 0)                          # neither: exactly max_iters = 1 iteration per tick from the plain warm start
+            whole_ref = whole_schedule(0.0, 0, floor=False)                       # neither: exactly max_iters = 1 iteration per tick from the plain warm start
 
     # ---- CPU baseline: the CPU port (oracle/cpu_port: closed-form derivatives, -O3 -march=native, OpenMP over knots, Riccati sweep in
     # legs — NOT Aligator, and not the AD checker) on this host's cores, bounded sample.  (i) ONE instance at 8 threads, the setting of
@@ -699,7 +704,7 @@ def main():
                                % (args.model, pd.robot.nq, pd.robot.nv, pd.nu, args.horizon, args.batch, args.iters_per_tick, args.iters_per_tick,
                                   (", control of the appended knot refined on contact-pattern changes: refine_appended_knot=%d" % args.refine_appended_knot if args.refine_appended_knot > 0 else "")
                                   + (", corrector iteration when the warm start is infeasible by more than %g or the step backtracks" % args.corrector_prim_tol if args.corrector_prim_tol > 0 else "")),
-                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "riccati_legs": legs, "tick_reuse": not args.no_tick_reuse, "refine_appended_knot": args.refine_appended_knot, "corrector_prim_tol": args.corrector_prim_tol, "corrector_window": args.corrector_window, "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
+                   "horizon": args.horizon, "batch_per_gpu": args.batch, "streams_per_gpu": nshard, "riccati_legs": legs, "tick_reuse": not args.no_tick_reuse, "refine_appended_knot": args.refine_appended_knot, "corrector_prim_tol": args.corrector_prim_tol, "corrector_window": args.corrector_window, "floor_under_the_measured_soles": bool(args.walk_refs == "instance" and not args.no_floor and not args.no_walk), "shard_period_ms": round(pace["period"] * 1e3, 3), "late_releases": pace["late"], "pacer_calibration_ticks": (args.calibration_ticks if (nshard > 1 and args.period_ms < 0) else 0), "shard_phase_offset_ms": round(max(0.0, stagger["ms"]), 3) if nshard > 1 else 0.0, "feedback": "simulated (10 x 1 ms, state-feedback law)" if args.closed_loop else "perfect model", "robot": "talos_synth_v1/" + args.model,
                    "parallelism": "ensemble sharded over %d GPU(s), no data-path collective" % world},
         "p50_ms_per_solve_batch1": p50_ms, "p90_ms_per_solve_batch1": p90_ms, "p95_ms_per_solve_batch1": p95_ms, "latency_ticks": (300 if p50_ms is not None else 0), "p50_riccati_legs": (args.latency_legs if args.legs != 1 else 1),
         # which instantiations of the hot kernels served the run (dimensions as compile-time constants; MPC_HIP_GENERIC_DIMS=1 forces the generic ones)

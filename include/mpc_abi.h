@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MPC_ABI_VERSION 2
+#define MPC_ABI_VERSION 3
 
 /* ---- state manifolds -------------------------------------------------------------------- */
 #define MPC_SPACE_VECTOR 0     /* aligator.manifolds.VectorSpace(n)            centroidal_talos.py:46   */
@@ -328,6 +328,10 @@ typedef struct mpc_walk_config {
   double feet_z0, xref_z0;       /* stairs: posture height = xref_z0 + mean height of the knot's foot references - feet_z0      */
   double z_follow;               /* 1: stairs variant (off_xref_z, CoM target height follow the feet) ; 0: flat ground          */
   double lf0[12], rf0[12];       /* initial sole placements                                                                   */
+  double floor_z;                /* (ABI 3) no foothold is planned below this height: the floor stops a foot.  Loops that feed the solver's own prediction
+                                  * back (no simulator, no ground) otherwise sink: fulldynamic_talos.py:449 aims the left foot 1 cm BELOW the right one's
+                                  * height at every step, which a floor stops and a prediction does not (5 - 6 cm over the reference's seven swings).
+                                  * <= -1e300: no floor (stairs).                                                                    */
 } mpc_walk_config;
 int mpc_walk_init(mpc_solver* s, const mpc_walk_config* cfg);
 int mpc_walk_update(mpc_solver* s, int32_t takeoff_RF, int32_t takeoff_LF, int32_t land_RF, int32_t land_LF, const double* forward);

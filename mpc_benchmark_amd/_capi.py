@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPC_HIP_LIBRARY: developer override pointing at another build of the SAME HIP library (kernel tuning variants)
 HIP_LIBRARY_PATH = os.environ.get("MPC_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libmpc_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # constants mirrored from include/mpc_abi.h
 SPACE_VECTOR, SPACE_MULTIBODY = 0, 1
@@ -65,7 +65,7 @@ class MpcWalkConfig(C.Structure):
     """mpc_walk_config of include/mpc_abi.h (reference generation in the library)"""
     _fields_ = [(n, C.c_int32) for n in ("T_ss", "T_ds", "frame_lf", "frame_rf", "off_lf", "off_rf", "off_xref_z", "toff_com", "toff_lf", "toff_rf")] + [
         ("swing_apex", C.c_double), ("t_left", C.c_double * 3), ("t_right", C.c_double * 3), ("rot_diff", C.c_double * 9), ("com0", C.c_double * 3),
-        ("feet_z0", C.c_double), ("xref_z0", C.c_double), ("z_follow", C.c_double), ("lf0", C.c_double * 12), ("rf0", C.c_double * 12)]
+        ("feet_z0", C.c_double), ("xref_z0", C.c_double), ("z_follow", C.c_double), ("lf0", C.c_double * 12), ("rf0", C.c_double * 12), ("floor_z", C.c_double)]
 
 
 class MpcStats(C.Structure):

@@ -899,7 +899,7 @@ __global__ void __launch_bounds__(128) k_walk_refs(SolverArgs a, mpc_walk_config
     }
     if (tid >= 64 && tid < 112) st[tid - 64] = gst[tid - 64];
     __syncthreads();
-    if (tid == 0) walk_plan(st, meas, meas + 12, takeoff_RF, takeoff_LF, land_RF, land_LF, c.T_ds, c.t_left, c.t_right, c.rot_diff);
+    if (tid == 0) walk_plan(st, meas, meas + 12, takeoff_RF, takeoff_LF, land_RF, land_LF, c.T_ds, c.t_left, c.t_right, c.rot_diff, c.floor_z);
     __syncthreads();
     if (tid < 48) gst[tid] = st[tid];
   } else {

@@ -37,28 +37,30 @@ DEV void walk_pose_store(double* o, const M3& R, V3 p) { for (int e = 0; e < 9; 
 DEV void walk_pose_copy(double* o, const double* s) { for (int e = 0; e < 12; ++e) o[e] = s[e]; }
 
 // the foothold beside `pose`: translation moved by `offset` in the pose's yaw frame, rotation turned by rot_diff when asked (talos_utils.py:221-225)
-DEV void walk_beside(double* o, const double* pose, const double* offset, const double* rot_diff, bool rotate) {
+// floor_z: no foothold is planned below this height (mpc_walk_config.floor_z ; <= -1e300: no floor)
+DEV void walk_beside(double* o, const double* pose, const double* offset, const double* rot_diff, bool rotate, double floor_z) {
   const double yaw = atan2(pose[3], pose[0]), c = cos(yaw), s = sin(yaw);
   o[9] = pose[9] + c * offset[0] - s * offset[1];
   o[10] = pose[10] + s * offset[0] + c * offset[1];
   o[11] = pose[11] + offset[2];
+  if (floor_z > -1e300 && o[11] < floor_z) o[11] = floor_z;
   if (rotate) { const M3 R2 = mul(ldm3(rot_diff), ldm3(pose)); for (int e = 0; e < 9; ++e) o[e] = R2.m[e]; }
   else for (int e = 0; e < 9; ++e) o[e] = pose[e];
 }
 
 // footTrajectory.updateTrajectory's rules on the state st = [start_L | final_L | start_R | final_R] (12 doubles each) from the measured sole poses
 DEV void walk_plan(double* st, const double* LF, const double* RF, int takeoff_RF, int takeoff_LF, int land_RF, int land_LF, int T_ds,
-                   const double* t_left, const double* t_right, const double* rot_diff) {
+                   const double* t_left, const double* t_right, const double* rot_diff, double floor_z) {
   double *sL = st, *fL = st + 12, *sR = st + 24, *fR = st + 36;
   if (land_LF < 0) { walk_pose_copy(sL, LF); walk_pose_copy(fL, LF); }
   if (land_RF < 0) { walk_pose_copy(sR, RF); walk_pose_copy(fR, RF); }
   if (takeoff_RF >= 0 && takeoff_RF < T_ds) {  // the right foot next to the left one, then the left foot next to that foothold
-    walk_pose_copy(sR, RF); walk_beside(fR, LF, t_right, rot_diff, true);
-    walk_pose_copy(sL, LF); walk_beside(fL, fR, t_left, rot_diff, false);
+    walk_pose_copy(sR, RF); walk_beside(fR, LF, t_right, rot_diff, true, floor_z);
+    walk_pose_copy(sL, LF); walk_beside(fL, fR, t_left, rot_diff, false, floor_z);
   }
   if (takeoff_LF >= 0 && takeoff_LF < T_ds) {
-    walk_pose_copy(sL, LF); walk_beside(fL, RF, t_left, rot_diff, false);
-    walk_pose_copy(sR, RF); walk_beside(fR, fL, t_right, rot_diff, true);
+    walk_pose_copy(sL, LF); walk_beside(fL, RF, t_left, rot_diff, false, floor_z);
+    walk_pose_copy(sR, RF); walk_beside(fR, fL, t_right, rot_diff, true, floor_z);
   }
 }
 

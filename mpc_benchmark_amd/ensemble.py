@@ -7,6 +7,8 @@ warm-start shift and the feedback happen in ``mpc_run_shifted``.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import _capi as K
@@ -256,7 +258,7 @@ class EnsembleMPC:
         return [tuple(r) for r in self.lost if r[3] is None]
 
     # -- the reference loop's per-tick problem updates on the shared stage tables ---------------------------------
-    def enable_walk(self, swing_apex=0.15, x_forward=None, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0, per_instance=False, generator="host"):
+    def enable_walk(self, swing_apex=0.15, x_forward=None, y_forward=0.0, foot_yaw=0.0, y_gap=0.18, z_height=0.0, per_instance=False, generator="host", floor=False):
         """From now on every tick does what the loop bodies of the scripts do to the problem before solving (fulldynamic_talos.py:444-510,
         kinodynamic_talos.py:361-409, centroidal_talos.py:357-384): ``FootTrajectory.updateTrajectory`` from the measured foot poses, the
         references written into every stage of the horizon (``setReference`` on the two foot-placement costs — integer keys 3 / 4 or the
@@ -280,7 +282,13 @@ class EnsembleMPC:
 
         ``generator="device"`` (with ``per_instance=True``): the generator itself runs in the library (mpc_walk_init / mpc_walk_update,
         include/mpc_abi.h) — forward kinematics of the sole frames at every instance's predicted next state, foothold rules, swing curves and
-        the references written into the instance tables by one kernel; per tick the host only advances the four countdowns."""
+        the references written into the instance tables by one kernel; per tick the host only advances the four countdowns.
+
+        ``floor=True`` (per-instance references, flat walks): no foothold is planned below the height of the initial footholds — the floor stops a foot.
+        An ensemble that feeds the solver's own prediction back has no ground; the full-dynamics script aims the left foot 1 cm below the right one's
+        height at every step (fulldynamic_talos.py:449, ``forward_z_left``), which a floor stops and a prediction does not: without this the footholds of
+        the benchmark ensemble sink 5 - 6 cm over the schedule's seven swings and the instances lost late in the schedule are lost on those stretched
+        legs.  The mirror loops (a simulator with a floor measures their states) do not need it."""
         from . import references as refgen
         from .robot import minipin as pin
         pd, N = self.pd, self.problem.num_steps
@@ -288,7 +296,9 @@ class EnsembleMPC:
         if x_forward is None:
             x_forward = spec["x_forward"]
         self._walk_args = dict(swing_apex=swing_apex, x_forward=x_forward, y_forward=y_forward, foot_yaw=foot_yaw, y_gap=y_gap, z_height=z_height, per_instance=per_instance,
-                               generator=generator)
+                               generator=generator, floor=floor)
+        if floor is not False and floor is not None and (not per_instance or z_height != 0.0):
+            raise ValueError("floor=True: per-instance references on flat ground")
         if generator not in ("host", "device") or (generator == "device" and not per_instance):
             raise ValueError("generator: 'host', or 'device' together with per_instance=True")
         rb = pd.robot
@@ -307,6 +317,7 @@ class EnsembleMPC:
             "data": rb.model.createData(), "pin": pin, "refgen": refgen, "spec": spec, "kind": spec["kind"],
             "step": dict(swing_apex=swing_apex, x_forward=x_forward, y_forward=y_forward, y_gap=y_gap, z_height=z_height),
             "x_measured": np.array(self.x0[0]), "patched": 0, "patches": 0, "last": None, "feet": None,
+            "floor_z": (None if floor is False or floor is None else float(min(lf.translation[2], rf.translation[2])) if floor is True else float(floor)),  # (a number: that height — tests)
         }
         nterm = len(self.problem.term_cost.components)
         if spec["kind"] == "pose":
@@ -347,6 +358,7 @@ class EnsembleMPC:
             cfg.feet_z0, cfg.xref_z0, cfg.z_follow = float(w["feet_z0"]), float(self.pd.x0[2]), (1.0 if z_height != 0.0 else 0.0)
             flat = lambda M: list(np.concatenate([np.asarray(M.rotation, dtype=float).reshape(-1), np.asarray(M.translation, dtype=float)]))
             cfg.lf0[:], cfg.rf0[:] = flat(lf), flat(rf)
+            cfg.floor_z = w["floor_z"] if w["floor_z"] is not None else -1e308
             self.native.walk_init(cfg)
             w["device"] = True
         elif per_instance:
@@ -355,6 +367,7 @@ class EnsembleMPC:
             bc = lambda M: (np.tile(np.asarray(M.rotation, dtype=float), (B, 1, 1)), np.tile(np.asarray(M.translation, dtype=float), (B, 1)))
             (LR, Lp), (RR, Rp) = bc(lf), bc(rf)
             w["batch"] = refgen.FootTrajectoryBatch(LR, Lp, RR, Rp, T_SS, T_DS, N, swing_apex, x_forward, y_forward, foot_yaw, y_gap, z_height)
+            w["batch"].floor_z = w["floor_z"]
             w["x_measured_all"] = np.array(self.x0, dtype=float)
             i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
             # index arrays of the patches of one tick: per instance the N left-foot and N right-foot references, then (after the cycle) its terminal targets

@@ -328,6 +328,7 @@ class FootTrajectoryBatch:
         self.sL, self.fL = (LF_R.copy(), LF_p.copy()), (LF_R.copy(), LF_p.copy())
         self.sR, self.fR = (RF_R.copy(), RF_p.copy()), (RF_R.copy(), RF_p.copy())
         self.T_ds, self.T_ss, self.nsteps, self.swing_apex = T_ds, T_ss, nsteps, swing_apex
+        self.floor_z = None  # EnsembleMPC.enable_walk(floor=...): no foothold is planned below this height (mpc_walk_config.floor_z)
 
     def updateForward(self, x_f_left, x_f_right, y_gap, y_forward, z_height_left, z_height_right, swing_apex):
         self.tR = np.array([x_f_right, -y_gap - y_forward, z_height_right], dtype=float)
@@ -341,6 +342,8 @@ class FootTrajectoryBatch:
     def _beside(self, pose, offset, rotate):
         R, p = pose
         p2 = p + np.einsum("bij,j->bi", _yaw_rotation_batch(self._yaw(R)), offset)
+        if self.floor_z is not None:
+            p2[:, 2] = np.maximum(p2[:, 2], self.floor_z)
         R2 = (self.rotationDiff @ R) if rotate else R.copy()
         return R2, p2
 

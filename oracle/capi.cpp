@@ -176,7 +176,7 @@ int mpc_walk_update(mpc_solver* h, int32_t takeoff_RF, int32_t takeoff_LF, int32
         double LF[12], RF[12];
         WALKGEN_NS::walk_frame_placement(h->model_itab.data(), h->model_dtab.data(), q, c.frame_lf, R, p); WALKGEN_NS::walk_pose_store(LF, R, p);
         WALKGEN_NS::walk_frame_placement(h->model_itab.data(), h->model_dtab.data(), q, c.frame_rf, R, p); WALKGEN_NS::walk_pose_store(RF, R, p);
-        WALKGEN_NS::walk_plan(st, LF, RF, takeoff_RF, takeoff_LF, land_RF, land_LF, c.T_ds, c.t_left, c.t_right, c.rot_diff);
+        WALKGEN_NS::walk_plan(st, LF, RF, takeoff_RF, takeoff_LF, land_RF, land_LF, c.T_ds, c.t_left, c.t_right, c.rot_diff, c.floor_z);
       }
       double L[12], Rr[12];
       for (int j = (replanning || h->walk_force_all) ? 0 : N - 1; j < N; ++j) {

@@ -82,7 +82,7 @@ def test_async_ticks_equal_synchronous_ticks(hip_lib, window):
         assert np.array_equal(ra[key], rs[key]), key
 
 
-@pytest.mark.parametrize("refs,refine,window", [("frozen", 3, 8), ("instance", 3, 8), ("device", 3, 8), ("instance", 3, 0), ("frozen", 0, 0), ("instance", 0, 0)])
+@pytest.mark.parametrize("refs,refine,window", [("frozen", 3, 8), ("instance", 3, 8), ("device", 3, 8), ("device-floor", 3, 8), ("instance", 3, 0), ("frozen", 0, 0), ("instance", 0, 0)])
 def test_whole_schedule_on_one_iteration_per_tick(hip_lib, refs, refine, window):
     """BASELINE.json's ensemble as bench.py runs it — 64 randomised instances, N = 100, complete model, 4 legs, tick reuse, two ticks in
     flight, max_iters = 1, corrector 20.0 — over the reference's whole 1000-tick schedule.
@@ -102,7 +102,7 @@ def test_whole_schedule_on_one_iteration_per_tick(hip_lib, refs, refine, window)
     e.cold_solve(max_iters=100)
     e.enable_failure_isolation(auto_revive=True, source=0)
     if refs != "frozen":   # "device": the reference generator in the library (mpc_walk_*), which is what bench.py runs ; "instance": the numpy generator
-        e.enable_walk(per_instance=True, generator="device" if refs == "device" else "host")
+        e.enable_walk(per_instance=True, generator="device" if refs.startswith("device") else "host", floor=refs.endswith("floor"))   # "device-floor": bench.py's setting
     ticks = min(1000, pd.t_mpc - 1)
     extra, total, worst_prim = 0, 0, 0.0
     for t in range(ticks):

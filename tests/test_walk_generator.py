@@ -55,6 +55,28 @@ def test_library_generator_equals_the_host_generator_on_the_oracle(oracle_lib, p
     print("%s %s: parameter tables of host and library generator within %.1e over %d ticks" % (problem.__name__, walk, worst, T))
 
 
+def test_floor_is_the_same_rule_in_both_generators(oracle_lib):
+    """``enable_walk(floor=...)`` / ``mpc_walk_config.floor_z``: no foothold is planned below the floor.  The full-dynamics walk aims its left foot 1 cm
+    below the right one's height (fulldynamic_talos.py:449); with the floor at the initial footholds' height — and, to make every target hit it, 3 mm above —
+    the final poses of both generators stop there, their tables stay equal at 1e-12, and the start poses remain what was measured."""
+    worst = compare_generators(oracle_lib, FullDynamicsProblem, 45, 1e-12, floor=0.003)
+    with_floor, without = _ens(oracle_lib, FullDynamicsProblem, "device", floor=0.003), _ens(oracle_lib, FullDynamicsProblem, "device")
+    for _ in range(10):   # (the plan is made inside the double-support window before a take-off: from tick 1 on)
+        with_floor.step(); without.step()
+    pf, p0 = with_floor.native.walk_get_state(), without.native.walk_get_state()
+    assert np.all(pf[:, [1, 3], 11] == 0.003) and np.all(p0[:, [1, 3], 11] < 0.003)   # final poses of both feet: z at the floor / where the rules put them
+    assert np.all(pf[:, [0, 2], 11] < 0.003)                                          # start poses: as measured
+    with pytest.raises(ValueError):
+        _ens(oracle_lib, KinodynamicProblem, "device", z_height=0.10, floor=True)   # stairs have no flat floor
+    print("floor: tables of host and library generator within %.1e over 45 ticks" % worst)
+
+
+@pytest.mark.gpu
+def test_floor_rule_on_the_device(hip_lib):
+    worst = compare_generators(hip_lib, FullDynamicsProblem, 45, 1e-9, lockstep=False, floor=0.003)
+    print("floor (HIP): parameter tables of host and device generator within %.1e" % worst)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("problem,walk", [(FullDynamicsProblem, {}), (KinodynamicProblem, {"z_height": 0.10})])
 def test_library_generator_equals_the_host_generator_on_the_device(hip_lib, problem, walk):

@@ -22,7 +22,7 @@ for refs in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("frozen", "shared
         e.cold_solve(max_iters=100)
         e.enable_failure_isolation(auto_revive=True, source=0)
         if refs != "frozen":
-            e.enable_walk(per_instance=(refs == "instance"), generator=("device" if refs == "instance" and os.environ.get("GENERATOR", "host") == "device" else "host"))  # GENERATOR=device: mpc_walk_* (bench.py's path)
+            e.enable_walk(per_instance=(refs == "instance"), generator=("device" if refs == "instance" and os.environ.get("GENERATOR", "host") == "device" else "host"), floor=(refs == "instance" and bool(os.environ.get("FLOOR"))))  # GENERATOR=device: mpc_walk_* (bench.py's path) ; FLOOR=1: the measured soles stay on the floor
         t0 = time.time(); worst = 0.0; nominal_lost = False; extra = 0; extra_ticks = 0; back = 0
         for t in range(ticks):
             e.step_async()
