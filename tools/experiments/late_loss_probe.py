@@ -10,15 +10,15 @@ seed, inst = int(sys.argv[1]), int(sys.argv[2])
 t_from = int(sys.argv[3]) if len(sys.argv) > 3 else 600
 pd = FullDynamicsProblem(horizon=100, complete_model=True)
 (e,) = make_bench_shards(pd, _capi.load_hip_library(), 64, legs=4, tick_reuse=True, seed=seed)
-e.options.refine_appended_knot = 3; e.options.corrector_prim_tol = 20.0; e.options.corrector_window = 8
+e.options.refine_appended_knot = int(os.environ.get("REFINE", "3")); e.options.corrector_prim_tol = float(os.environ.get("CORRECTOR", "20")); e.options.corrector_window = int(os.environ.get("WINDOW", "8"))
 e.native.set_options(e.options)
 e.prepare_schedule(pd.t_mpc + 4)
 e.cold_solve(max_iters=100)
 e.enable_failure_isolation(auto_revive=False)
-e.enable_walk(per_instance=True, generator="device")
+e.enable_walk(per_instance=True, generator="device", floor=bool(os.environ.get("FLOOR")))
 for t in range(999):
     st = e.step()
-    if t >= t_from and (t % 10 == 0 or st[inst].alpha < 1.0 or st[inst].num_iters > 1 or st[inst].converged < 0):
+    if t >= t_from and (t % int(os.environ.get("EVERY", "10")) == 0 or st[inst].alpha < 1.0 or st[inst].num_iters > 1 or st[inst].converged < 0):
         plan = np.asarray(e.native.walk_get_state()).reshape(64, 48)
         r = e.results(gains=False)
         def yx(p): return "(%.3f %.3f %.3f)" % (p[9], p[10], p[11])
