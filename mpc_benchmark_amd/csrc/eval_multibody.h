@@ -83,6 +83,43 @@ template <class F> DEV double mask_sum(unsigned long long mm, F&& f, double s = 
   }
   return s;
 }
+// ---- sums over the kinematic tree on the matrix cores (round 6) -----------------------------------------------------------------------------
+// Every "sum over the bodies of a subtree" / "sum over the dofs on the path to the root" is a product with a 0 / 1 matrix: OUT(r, c) = sum_k A(r, k) bit_k(mask[c]).
+// mask_sum above does it a lane per entry: a data-dependent loop of bit scans and dependent LDS loads whose trip count is the root's (33) in every wavefront that
+// holds one of its entries — a third of the kernel's vector instructions.  Here one wavefront forms a 16 x 16 tile of OUT with ceil(K / 4) MFMAs: lane l supplies
+// A(l & 15, 4 s + (l >> 4)) (a callable: clamped LDS reads) and the bit 4 s + (l >> 4) of the mask of column l & 15 as a double.  Exact products (x 0 or x 1), fp64
+// accumulation in ascending k like the loop — only the association of the additions differs.  Columns >= nc get a zero mask; rows past the operand's last are
+// whatever the callable returns for them (finite: it clamps) and are not stored.
+template <class FA> DEV d4_t mask_tile(FA&& aval, const unsigned long long* mask, int c0, int nc, int K, int lane, d4_t acc = d4_t{0, 0, 0, 0}) {
+  const int col = c0 + (lane & 15), kk = lane >> 4, row = lane & 15;
+  unsigned long long mm = mask[col < nc ? col : nc - 1];
+  if (col >= nc) mm = 0ull;
+  mm >>= kk;
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const double bv = (double)(unsigned)(mm & 1ull);
+    mm >>= 4;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aval(row, k0 + kk), bv, acc, 0, 0, 0);
+  }
+  return acc;
+}
+// rows r0 + (l >> 4) + 4 q < nr, columns c0 + (l & 15) < nc of a result tile into a structure-of-arrays block (row r at out[r * ld + .])
+DEV void tile_store_soa(double* out, int ld, int r0, int nr, int c0, int nc, const d4_t& v, int lane) {
+  const int c = c0 + (lane & 15);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int r = r0 + (lane >> 4) + 4 * q; if (r < nr && c < nc) out[r * ld + c] = v[q]; }
+}
+// OUT (nr x nc, SoA ld ldo) = A (nr x K, SoA lda) x bits(mask): the tiles dealt to the wavefronts w0, w0 + 1, ... (nws of them), tile index offset t0 so that several
+// products of one phase share the wavefronts evenly
+DEV int tree_sum_mfma(double* out, int ldo, const double* A, int lda, int nr, const unsigned long long* mask, int nc, int K, int wv, int nws, int t0, int lane) {
+  const int rt = (nr + 15) >> 4, ct = (nc + 15) >> 4;
+  for (int t = 0; t < rt * ct; ++t) {
+    if ((t0 + t) % nws != wv) continue;
+    const int r0 = 16 * (t / ct), c0 = 16 * (t % ct);
+    const d4_t acc = mask_tile([&](int row, int k) { const int r = r0 + row; return A[(r < nr ? r : nr - 1) * lda + (k < K ? k : K - 1)]; }, mask, c0, nc, K, lane);
+    tile_store_soa(out, ldo, r0, nr, c0, nc, acc, lane);
+  }
+  return t0 + rt * ct;
+}
 #define MB_AB_U 8  // loads of d a in flight per thread while [A B] is written
 #ifdef EV_SUBPROF
 #define EV_SUB(slot) EV_PROF(slot)  // developer builds: sub-phases of the one-wavefront solve (tools/phase_timers.py)
@@ -152,7 +189,15 @@ __global__ void __launch_bounds__(EVAL_THREADS, EVAL_MIN_WAVES) k_eval_multibody
   const int b = blockIdx.y;
   constexpr int nthr = EVAL_THREADS;  // (the launcher uses EVAL_THREADS threads)
   int cand = blockIdx.z + cand0;
+#ifdef EV_ROTATE
+  // The single-wavefront phases (tree recursions with a lane per body, the factorisation chain) all run on "wavefront 0".  The wavefronts of
+  // a workgroup go to the four SIMDs of a CU in order, so the wavefronts 0 of the two workgroups sharing a CU sit on the SAME SIMD and
+  // take turns while the other three SIMDs idle.  Rotate the roles by a per-workgroup amount: thread ids are only ever used as roles.
+  const unsigned lin_ = blockIdx.y * gridDim.x + blockIdx.x, j_ = lin_ >> 3;
+  int tid = (threadIdx.x + 64 * ((j_ + (j_ >> 5)) & (EVAL_THREADS / 64 - 1))) & (EVAL_THREADS - 1);
+#else
   int tid = threadIdx.x;
+#endif
   const InstState& st = a.inst[b];
   // TRIAL: 0 full evaluation, 1 value-only linesearch candidate, 3 the alpha = 1 candidate WITH derivatives, written into the knot
   // records themselves (tick reuse: if the full step is accepted these are the records of the next tick, one knot on),
@@ -366,10 +411,17 @@ sim_u_set:
   __syncthreads();
   EV_PROF(0);
   // ---- P3: body velocities ------------------------------------------------------------------------------
+#ifdef EV_TREE_MFMA
+  for (int t = wv; t < ((nj + 15) >> 4); t += nw) {  // ov = (J diag(v)) x bits(dmask): 6 x nv times nv x nj
+    const d4_t acc = mask_tile([&](int row, int k) { const int r = row < 6 ? row : 5, kc = k < nv ? k : nv - 1; return J[r * nv + kc] * v[kc]; }, dmask, 16 * t, nj, nv, lane);
+    tile_store_soa(ov, nj, 0, 6, 16 * t, nj, acc, lane);
+  }
+#else
   for (int idx = tid; idx < 6 * nj; idx += nthr) {
     const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
     ov[idx] = mask_sum(dmask[i], [&](int kd) { return J[e * nv + kd] * v[kd]; });
   }
+#endif
   __syncthreads();
   // Contact frames (world placement, placement error of the Baumgarte term, Jlog6): single-lane SE(3) work that needs the placements
   // only — lane cc of wavefront 1 does it here, beside the bodies' inertias on wavefront 0 (after the factor's inputs it sat on the
@@ -427,6 +479,16 @@ sim_u_set:
   }
   __syncthreads();
   // ---- P5: composite inertias / momenta, bias forces ----------------------------------------------------
+#ifdef EV_TREE_MFMA
+  // composite inertias and momenta: Yc = oY x bits(sub), Hc = oh x bits(sub) — tiles over the wavefronts ; the bias forces of the bodies by the lanes of the
+  // last wavefront first (its tiles come after)
+  if (wv == nw - 1 && lane < nj) stc6(of, nj, lane, add6(sym_mul(ldy21(oY, nj, lane), ldc6(oa, nj, lane)), fcross(ldc6(ov, nj, lane), ldc6(oh, nj, lane))));
+  { int t5 = tree_sum_mfma(Yc, nj, oY, nj, 21, sub, nj, nj, wv, nw, 0, lane);
+    tree_sum_mfma(Hc, nj, oh, nj, 6, sub, nj, nj, wv, nw, t5, lane); }
+  __syncthreads();
+  tree_sum_mfma(Fc, nj, of, nj, 6, sub, nj, nj, wv, nw, 0, lane);
+  if (wv == nw - 1 && lane < nv) stc6(U, nv, lane, sym_mul(ldy21(Yc, nj, dof_body[lane]), ldc6(J, nv, lane)));  // (nv <= 64: check_multibody_model)
+#else
   for (int idx = tid; idx < 21 * nj; idx += nthr) {
     const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
     Yc[idx] = mask_sum(sub[i], [&](int j) { return oY[e * nj + j]; });
@@ -443,6 +505,7 @@ sim_u_set:
     Fc[idx] = mask_sum(sub[i], [&](int j) { return of[e * nj + j]; });
   }
   for (int kd = tid; kd < nv; kd += nthr) stc6(U, nv, kd, sym_mul(ldy21(Yc, nj, dof_body[kd]), ldc6(J, nv, kd)));
+#endif
   // total mass and centre of mass from the composite inertia of the root (Yc is recycled before the terms read them)
   const double mtot = Yc[0];
   const V3 com = v3(Yc[sym6(1, 5) * nj] / mtot, Yc[sym6(2, 3) * nj] / mtot, Yc[sym6(0, 4) * nj] / mtot);
@@ -493,10 +556,14 @@ sim_u_set:
         }
       }
       __syncthreads();
+#ifdef EV_TREE_MFMA
+      tree_sum_mfma(Bc, nj, oY, nj, 36, sub, nj, nj, wv, nw, 0, lane);
+#else
       for (int idx = tid; idx < 36 * nj; idx += nthr) {
         const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
         Bc[idx] = mask_sum(sub[i], [&](int j) { return oY[e * nj + j]; });
       }
+#endif
       __syncthreads();
       for (int kd = tid; kd < nv; kd += nthr) {
         const int bk = dof_body[kd];
@@ -679,7 +746,38 @@ sim_u_set:
   if (has_dyn) {
     // ---- P7: joint-space inertia (lower block triangle, tile-packed), bias torques, contact frames ---------------
     const int ntile = nbm * (nbm + 1) / 2;
+#ifdef EV_M_MFMA
+    // a tile per wavefront: U^T J (entry (r, c) with c on the path to r) and J^T U (r on the path to c) as two depth-6 products on the matrix cores, the tree
+    // masks pick one — 8 operand reads and 4 MFMAs for 256 entries where a lane per entry read 12 doubles for each of its six
+    for (int t = wv; t < ntile; t += nw) {
+      int bi = 0;
+      while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+      const int bj = t - bi * (bi + 1) / 2, kk4 = lane >> 4;
+      const int ra = 16 * bi + (lane & 15), rc = ra < nv ? ra : nv - 1, ca = 16 * bj + (lane & 15), cl = ca < nv ? ca : nv - 1;
+      const double a0 = U[kk4 * nv + rc], a1 = (kk4 < 2) ? U[(4 + kk4) * nv + rc] : 0.0, b0 = J[kk4 * nv + cl], b1 = (kk4 < 2) ? J[(4 + kk4) * nv + cl] : 0.0;
+      const double e0 = J[kk4 * nv + rc], e1 = (kk4 < 2) ? J[(4 + kk4) * nv + rc] : 0.0, f0 = U[kk4 * nv + cl], f1 = (kk4 < 2) ? U[(4 + kk4) * nv + cl] : 0.0;
+      d4_t p1 = d4_t{0, 0, 0, 0}, p2 = d4_t{0, 0, 0, 0};
+      p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, p1, 0, 0, 0);
+      p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0, f0, p2, 0, 0, 0);
+      p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, p1, 0, 0, 0);
+      p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1, f1, p2, 0, 0, 0);
+      const int j = lane & 15, cc = 16 * bj + j;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = (lane >> 4) + 4 * q, r = 16 * bi + i;
+        double s = (r == cc) ? 1.0 : 0.0;  // identity padding
+        if (r < nv && cc < nv) {
+          s = 0;
+          if (BELOW(cc, dof_body[r])) s = p1[q];
+          else if (BELOW(r, dof_body[cc])) s = p2[q];
+        }
+        Mt[t * 272 + i * 17 + j] = s;
+      }
+    }
+    for (int idx = tid; idx < 0; idx += nthr) {
+#else
     for (int idx = tid; idx < ntile * 256; idx += nthr) {
+#endif
       const int t = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
       int bi = 0;
       while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
@@ -876,6 +974,11 @@ sim_u_set:
   // only: on stages with contact dynamics it runs on the wavefront that has one column block less in P11 (7 blocks on 4 wavefronts),
   // beside the implicit differentiation instead of after it.
   const double dt_se3 = (has_dyn || kino) ? P[desc[4]] : 0.0;
+#ifdef EV_DIRECT_AB
+  const bool direct_ab = has_dyn && 6 * nz <= 21 * nj;  // the base rows of d a fit in the region of Yc (every Talos model ; else: the HBM scratch)
+#else
+  const bool direct_ab = false;
+#endif
   auto step_se3 = [&](int part) {
     const double dt = dt_se3;
     double* Jl6 = small; double* Je6 = small + 36; double* Jq6 = small + 72;
@@ -918,6 +1021,38 @@ sim_u_set:
   // (sum over the subtree of Y_j da_j, regrouped by dof: the composite inertias and U = Yc J are at hand, the body inertias are not)
   if (derivs && (has_dyn || kino)) {
     double* da = Tq;  // scratch [6][nj] (Tq is formed afterwards)
+#ifdef EV_TREE_MFMA
+    // da = (J diag(acc)) x bits(dmask) and the "dofs strictly below" part of the forces, (U diag(acc)) x bits(below), as tiles: wavefront t does column tile t of
+    // both (the second into its registers), then the rest of the update on its own columns after the barrier
+    d4_t fbel = d4_t{0, 0, 0, 0};
+    const int ctn = (nj + 15) >> 4;
+    if (wv < ctn) {
+      const d4_t acc_ = mask_tile([&](int row, int k) { const int r = row < 6 ? row : 5, kc = k < nv ? k : nv - 1; return J[r * nv + kc] * acc[kc]; }, dmask, 16 * wv, nj, nv, lane);
+      tile_store_soa(da, nj, 0, 6, 16 * wv, nj, acc_, lane);
+      fbel = mask_tile([&](int row, int k) { const int r = row < 6 ? row : 5, kc = k < nv ? k : nv - 1; return U[r * nv + kc] * acc[kc]; }, below, 16 * wv, nj, nv, lane);
+    }
+    for (int t = nw + wv; t < ctn; t += nw) {  // (models with more than 16 nw bodies: not the Talos — the plain form for the remaining columns)
+      for (int idx = lane; idx < 6 * 16; idx += 64) { const int e = idx >> 4, i = 16 * t + (idx & 15); if (i < nj) da[e * nj + i] = mask_sum(dmask[i], [&](int kd) { return J[e * nv + kd] * acc[kd]; }); }
+    }
+    __syncthreads();
+    for (int t = wv; t < ctn; t += nw) {
+      const int i = 16 * t + (lane & 15);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int e = (lane >> 4) + 4 * q;
+        if (e < 6 && i < nj) {
+          const int idx = e * nj + i;
+          double s = Fc[idx];
+#pragma unroll
+          for (int bb = 0; bb < 6; ++bb) s += Yc[sym6(e, bb) * nj + i] * da[bb * nj + i];
+          s += (t < nw) ? fbel[q] : mask_sum(below[i], [&](int kd) { return U[e * nv + kd] * acc[kd]; });
+          for (int cc = 0; cc < nk; ++cc) if ((anc[cbody_s[cc]] >> i) & 1ull) s -= cfr[54 * cc + 48 + e];
+          Fc[idx] = s;
+          oa[idx] += da[idx];
+        }
+      }
+    }
+#else
     for (int idx = tid; idx < 6 * nj; idx += nthr) {
       const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
       da[idx] = mask_sum(dmask[i], [&](int kd) { return J[e * nv + kd] * acc[kd]; });
@@ -933,6 +1068,7 @@ sim_u_set:
       Fc[idx] = s;
       oa[idx] += da[idx];
     }
+#endif
     __syncthreads();
     // Psdd (needs the parents' accelerations at the solution) and Tq = Yc Psdd + Bc Psd + J x* Fc
     for (int kd = tid; kd < nv; kd += nthr) {
@@ -1025,16 +1161,69 @@ sim_u_set:
         }
       }
       __syncthreads();
+      double* dbase = Yc;  // [6][nz]: base rows of d a (direct_ab)
       // ---- P11: R1 = d r1 / d(q, v, u) built in registers, one 16-column block per wavefront at a time, and the whole chain of
       // blocked solves on it without touching LDS for the intermediate results (implicit_diff_block)
       const int n2 = 2 * nv;
+#ifdef EV_P11PROF  // developer build: where the time of P11 goes, per wavefront (slots 16 + wv: its column blocks ; 3: the SE(3) work of the last one ; 4: R1 of wave 0's first block)
+      const long long tp11_ = clock64();
+#endif
       for (int cj = wv; cj < ncb; cj += nw) {
         const int z = 16 * cj + (lane & 15), rq = lane >> 4;
         const int kind = z < nv ? 0 : (z < n2 ? 1 : (z < n2 + nu ? 2 : 3));
         const int j = kind == 0 ? z : (kind == 1 ? z - nv : 0);
         const int bj = dof_body[j];
+#ifndef EV_R1_MFMA
         const S6 c1 = ldc6(kind ? Phi : Psdd, nv, j), c2 = ldc6(kind ? J : Psd, nv, j), c3 = ldc6(kind ? Tv : Tq, nv, j);
+#endif
         d4_t w[4], t;
+#ifdef EV_R1_MFMA
+        // Both candidates of every entry as tile products on the matrix cores — [U ; Bt]^T [c1 ; c2] (depth 12: row r below column j) and J^T c3 (depth 6,
+        // padded to 8: row r above column j) — then the tree masks pick one.  10 operand reads and 5 MFMAs per 16 x 16 tile where the lane-per-entry form
+        // read 4 x (12 .. 24) doubles and issued as many multiply-adds.  Operands: A(row, e) of lane (row = l & 15, e = 4 s + (l >> 4)), B(e, column l & 15).
+        {
+          const int kk4 = lane >> 4, jc = j;  // (j: the dof of this lane's column, 0 for the control columns — finite operands, masked below)
+          const double* c1p = kind ? Phi : Psdd; const double* c2p = kind ? J : Psd; const double* c3p = kind ? Tv : Tq;
+          // B operands of the five k-steps (rows e = kk4, 4 + kk4, 8 + kk4 of [c1 ; c2] and e = kk4, 4 + kk4 of [c3 ; 0])
+          const double b0 = c1p[kk4 * nv + jc];
+          const double b1 = (kk4 < 2) ? c1p[(4 + kk4) * nv + jc] : c2p[(kk4 - 2) * nv + jc];
+          const double b2 = c2p[(2 + kk4) * nv + jc];
+          const double d0 = c3p[kk4 * nv + jc];
+          const double d1 = (kk4 < 2) ? c3p[(4 + kk4) * nv + jc] : 0.0;
+          const unsigned long long ancj = anc[bj];
+#pragma unroll
+          for (int bi = 0; bi < 4; ++bi) {
+            w[bi] = d4_t{0, 0, 0, 0};
+            if (bi < nbm) {
+              const int ra = 16 * bi + (lane & 15), rc = ra < nv ? ra : nv - 1;
+              const double a0 = U[kk4 * nv + rc];
+              const double a1 = (kk4 < 2) ? U[(4 + kk4) * nv + rc] : Bt[(kk4 - 2) * nv + rc];
+              const double a2 = Bt[(2 + kk4) * nv + rc];
+              const double e0 = J[kk4 * nv + rc];
+              const double e1 = (kk4 < 2) ? J[(4 + kk4) * nv + rc] : 0.0;
+              d4_t p1 = d4_t{0, 0, 0, 0}, p2 = d4_t{0, 0, 0, 0};
+              p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, p1, 0, 0, 0);
+              p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e0, d0, p2, 0, 0, 0);
+              p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, p1, 0, 0, 0);
+              p2 = __builtin_amdgcn_mfma_f64_16x16x4f64(e1, d1, p2, 0, 0, 0);
+              p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, p1, 0, 0, 0);
+#pragma unroll
+              for (int qq = 0; qq < 4; ++qq) {
+                const int r = 16 * bi + rq + 4 * qq;
+                double val = 0.0;
+                if (r < nv) {
+                  if (kind < 2) {
+                    const int br = dof_body[r];
+                    if ((anc[br] >> bj) & 1ull) val = p1[qq];
+                    else if ((ancj >> br) & 1ull) val = p2[qq];
+                  } else if (kind == 2 && r == nv - nu + (z - n2)) val = -1.0;  // d r1 / du = -B
+                }
+                w[bi][qq] = val;
+              }
+            }
+          }
+        }
+#else
 #pragma unroll
         for (int bi = 0; bi < 4; ++bi) {
 #pragma unroll
@@ -1051,23 +1240,46 @@ sim_u_set:
             w[bi][qq] = val;
           }
         }
+#endif
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) t[qq] = (qq < 3) ? DL[(rq + 4 * qq) * ldl + 16 * cj + (lane & 15)] : 0.0;
+#ifdef EV_P11PROF
+        if (TRIAL == 0 && a.prof && k == 1 && tid == 0 && cj == wv) a.prof[(size_t)b * 64 + 32 + 4] += (double)(clock64() - tp11_);
+#endif
         implicit_diff_block(w, t, Mt, Y16, LIs, nbm, lane);
-        // d a = -Z1 to the HBM scratch (read back by the integrator through L2), d lambda = Z2 stays in LDS for the force terms
+        // d a = -Z1: the velocity rows of [A B] (dvp = dt da + [0 I 0]) and the joint-position rows (dt dvp + [I 0 0]) leave for the record
+        // straight from the result registers (a fragment is 4 rows x 16 consecutive columns per store: whole 128-byte segments) ; only the six
+        // base rows of d a, which the integrator combines with the SE(3) blocks of P12, are kept — in LDS (dbase: the region of Yc, dead since P9).
+        // (Rounds 3 - 5 sent all of d a through an HBM scratch and read it back in P12: 33 KB out and in per knot, 16 rounds of loads.)
+        // d lambda = Z2 stays in LDS for the force terms.
         if (z < nz) {
 #pragma unroll
           for (int bi = 0; bi < 4; ++bi)
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
               const int r = 16 * bi + rq + 4 * qq;
-              if (bi < nbm && r < nv) dsol[(size_t)r * L.nz + z] = -w[bi][qq];
+              if (bi < nbm && r < nv) {
+                if (direct_ab) {
+                  const double dav = -w[bi][qq];
+                  const double dvp = dt_se3 * dav + ((z == nv + r) ? 1.0 : 0.0);
+                  kn[KL.oAB + (size_t)(nv + r) * KL.nz + z] = dvp;
+                  if (r >= 6) kn[KL.oAB + (size_t)r * KL.nz + z] = dt_se3 * dvp + ((z == r) ? 1.0 : 0.0);
+                  else dbase[r * nz + z] = dav;
+                } else dsol[(size_t)r * L.nz + z] = -w[bi][qq];
+              }
             }
         }
 #pragma unroll
         for (int qq = 0; qq < 3; ++qq) DL[(rq + 4 * qq) * ldl + 16 * cj + (lane & 15)] = t[qq];
       }
+#ifdef EV_P11PROF
+      const long long tp11b_ = clock64();
+      if (TRIAL == 0 && a.prof && k == 1 && lane == 0) a.prof[(size_t)b * 64 + 32 + 16 + wv] += (double)(tp11b_ - tp11_);
+#endif
       if (wv == nw - 1 && lane < 2) step_se3(lane);  // (P12's single-lane work, on the wavefront with the fewest column blocks)
+#ifdef EV_P11PROF
+      if (TRIAL == 0 && a.prof && k == 1 && lane == 0 && wv == nw - 1) a.prof[(size_t)b * 64 + 32 + 3] += (double)(clock64() - tp11b_);
+#endif
       __syncthreads();
     }
   }
@@ -1103,7 +1315,7 @@ sim_u_set:
       // dvp = dt * da + [0 I 0];  rows nv..n of AB = dvp; rows 6..nv = dt dvp + [I 0 0]
       // (d a comes back from the HBM scratch: MB_AB_U loads are requested before the first store — a load per iteration, ordered behind
       // the stores of the one before, costs a round trip to L2 every time: 16 of them for nv = 38)
-      for (int base = tid; base < nv * nz; base += nthr * MB_AB_U) {
+      if (!direct_ab) for (int base = tid; base < nv * nz; base += nthr * MB_AB_U) {
         double dav[MB_AB_U];
 #pragma unroll
         for (int uu = 0; uu < MB_AB_U; ++uu) {
@@ -1126,7 +1338,7 @@ sim_u_set:
         const int r = qdiv(idx, mg_nz), z = (idx - qdiv(idx, mg_nz) * nz);
         double dl6[6];
 #pragma unroll
-        for (int l = 0; l < 6; ++l) dl6[l] = dsol[(size_t)l * L.nz + z];
+        for (int l = 0; l < 6; ++l) dl6[l] = direct_ab ? Yc[l * nz + z] : dsol[(size_t)l * L.nz + z];
         double s = (z < 6) ? D12[6 * r + z] : 0.0;
 #pragma unroll
         for (int l = 0; l < 6; ++l) s += D12[36 + 6 * r + l] * (dt * dl6[l] + ((z == nv + l) ? 1.0 : 0.0));

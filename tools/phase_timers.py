@@ -60,6 +60,9 @@ for t, name in terms.items():
 if os.environ.get("PHASE_SUB"):  # a build with -DEV_SUBPROF: the one-wavefront solve in pieces (slots of terms this problem does not have)
     for i, name in ((3, 'sub: chol M'), (4, 'sub: Y = L^-1 [Jc^T | r1]'), (16, 'sub: S = Y^T Y, chol S'), (17, 'sub: multipliers'), (18, 'sub: V16 build'), (19, 'sub: accelerations')):
         print('EVAL %-40s %7.1f us' % (name, e[i] / TICKS / (GHZ * 1e3)))
+if os.environ.get("PHASE_P11"):  # a build with -DEV_P11PROF: P11 per wavefront
+    for i, name in ((16, 'P11 wave 0: its column blocks'), (17, 'P11 wave 1'), (18, 'P11 wave 2'), (19, 'P11 wave 3 (one block less)'), (3, 'P11 wave 3: SE(3) work of the integrator'), (4, 'P11 wave 0: R1 of its first block')):
+        print('EVAL %-40s %7.1f us' % (name, e[i] / TICKS / (GHZ * 1e3)))
 print('EVAL %-40s %7.1f us %5.1f%%' % ('stacked cost terms (one per wavefront)', e[28] / TICKS / (GHZ * 1e3), 100 * e[28] / etot))
 print('EVAL %-40s %7.1f us %5.1f%%' % ('Gauss-Newton Hessian flush (MFMA)', e[27] / TICKS / (GHZ * 1e3), 100 * e[27] / etot))
 print('EVAL total %.1f us per workgroup (knot 1 of instance 0)' % (etot / TICKS / (GHZ * 1e3)))
