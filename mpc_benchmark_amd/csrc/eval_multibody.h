@@ -166,6 +166,104 @@ DEV void implicit_diff_block(d4_t (&w)[4], d4_t& t, const double* Mt, const doub
   }
 }
 
+// ---- the 16 x 16 Cholesky + inverse of mfma_blocks.h for a block whose rows / columns from NC on are identity padding (round 6) -------------------------
+// chol16_wave spends its time issuing 16 pivots + 240 broadcast multiply-adds whatever the block holds.  The LAST diagonal block of the joint-space inertia has
+// nv mod 16 real columns (6 of 16 for the complete Talos: 38 = 32 + 6) and the contact block S has 6 contacts' rows (6 or 12 of 16): their padding factorises to
+// itself.  Only the leading NC x NC part is worked on — NC (NC - 1) multiply-adds instead of 240 (30 for NC = 6, 132 for NC = 12) — with the same operations in
+// the same order on that part: the same bits as chol16_wave (CHOL16_RIGHT_LOOKING form).
+template <int J, int C, int END> struct CholColN {
+  static DEV void run(double (&d)[16], double l, double nl) { fmac_bcast<C>(d[C], l, nl); CholColN<J, C + 1, END>::run(d, l, nl); }
+};
+template <int J, int END> struct CholColN<J, END, END> { static DEV void run(double (&)[16], double, double) {} };
+template <int J, int END> struct CholStepN {
+  static DEV void run(double (&d)[16], double (&invd)[16], bool& ok) {
+    const double djj = bcast_row<J>(d[J]);
+    ok = ok && (djj > 0.0);
+    double inv = rsqrt(djj);
+    inv = inv * (1.5 - 0.5 * djj * inv * inv);
+    invd[J] = inv;
+    const double l = d[J] * inv;
+    d[J] = l;
+    CholColN<J, J + 1, END>::run(d, l, -l);
+    CholStepN<J + 1, END>::run(d, invd, ok);
+  }
+};
+template <int END> struct CholStepN<END, END> { static DEV void run(double (&)[16], double (&)[16], bool&) {} };
+template <int K, int R, int END> struct InvUpdN {
+  static DEV void run(const double (&nd)[16], double (&x)[16]) { fmac_bcast<R>(x[R], nd[K], x[K]); InvUpdN<K, R + 1, END>::run(nd, x); }
+};
+template <int K, int END> struct InvUpdN<K, END, END> { static DEV void run(const double (&)[16], double (&)[16]) {} };
+template <int K, int END> struct InvColN {
+  static DEV void run(const double (&nd)[16], const double (&invd)[16], double (&x)[16]) {
+    x[K] *= invd[K];
+    InvUpdN<K, K + 1, END>::run(nd, x);
+    InvColN<K + 1, END>::run(nd, invd, x);
+  }
+};
+template <int END> struct InvColN<END, END> { static DEV void run(const double (&)[16], const double (&)[16], double (&)[16]) {} };
+template <int NC> DEV bool chol16_wave_n(double* D, int ld, double* LIb, int lane) {
+  if constexpr (NC >= 16) return chol16_wave(D, ld, LIb, lane);
+  double d[16], x[16], invd[16];
+  const int r = lane & 15;
+#pragma unroll
+  for (int cidx = 0; cidx < 16; ++cidx) { d[cidx] = (cidx < NC) ? D[r * ld + cidx] : 0.0; invd[cidx] = 1.0; }
+  bool ok = true;
+  CholStepN<0, NC>::run(d, invd, ok);
+  if (lane < 16 && D != LIb) {
+#pragma unroll
+    for (int cidx = 0; cidx < NC; ++cidx) if (cidx <= r) D[r * ld + cidx] = d[cidx];   // (the padding part of the lower triangle is identity already)
+  }
+#pragma unroll
+  for (int cidx = 0; cidx < 16; ++cidx) { x[cidx] = (r == cidx) ? 1.0 : 0.0; d[cidx] = -d[cidx]; }
+  InvColN<0, NC>::run(d, invd, x);
+  if (lane < 16) {
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) LIb[rr * 17 + lane] = x[rr];
+  }
+  return ok;
+}
+// chol_tiles_wave (mfma_blocks.h) with NLAST real columns in the last diagonal block
+template <int NLAST> DEV bool chol_tiles_wave_last(double* T, int nb, int lane) {
+  bool ok = true;
+  for (int kb = 0; kb < nb && ok; ++kb) {
+    double* Dk = ptile(T, kb, kb);
+    ok = (kb == nb - 1) ? chol16_wave_n<NLAST>(Dk, 17, Dk, lane) : chol16_wave(Dk, 17, Dk, lane);
+    for (int ri = kb + 1; ri < nb; ++ri) {  // panel: L[ri][kb] = A[ri][kb] LI^T
+      double* Pt = ptile(T, ri, kb);
+      d4_t acc = d4_t{0, 0, 0, 0};
+      mma_tile<false>(acc, Pt, 17, 1, Dk, 1, 17, 16, lane);
+      tile_store(Pt, 17, acc, lane);
+    }
+    for (int ri = kb + 1; ri < nb; ++ri)
+      for (int cj = kb + 1; cj <= ri; ++cj) {  // trailing update: A[ri][cj] -= L[ri][kb] L[cj][kb]^T
+        double* Ct = ptile(T, ri, cj);
+        d4_t acc = tile_load(Ct, 17, lane);
+        mma_tile<true>(acc, ptile(T, ri, kb), 17, 1, ptile(T, cj, kb), 1, 17, 16, lane);
+        tile_store(Ct, 17, acc, lane);
+      }
+  }
+  return ok;
+}
+
+// Barfoot's Q block with the series coefficients handed in (q_coeffs depends on |w| only: Q(v, w) and Q(-v, -w) share them)
+DEV M3 Qmat_c(V3 v, V3 w, double a1, double a2, double a3) {
+  const M3 P = skew_m(v), F = skew_m(w);
+  const M3 FP = mul(F, P), PF = mul(P, F), FPF = mul(FP, F), FF = mul(F, F);
+  M3 Q = scl3(0.5, P);
+  Q = add3(Q, scl3(a1, add3(add3(FP, PF), FPF)));
+  Q = add3(Q, scl3(a2, add3(add3(mul(FF, P), mul(P, FF)), scl3(-3.0, FPF))));
+  Q = add3(Q, scl3(a3, add3(mul(FPF, F), mul(F, FPF))));
+  return Q;
+}
+// 6 x 6 (row-major) [[Ji, -Ji Q Ji], [0, Ji]] scaled by sgn: Jlog6 from its pieces
+DEV void jlog6_blocks(const M3& Ji, const M3& Q, double sgn, double* out) {
+  const M3 Bm = mul(mul(Ji, Q), Ji);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    out[6 * i + j] = sgn * Ji.m[3 * i + j]; out[6 * (i + 3) + j + 3] = sgn * Ji.m[3 * i + j];
+    out[6 * i + j + 3] = -sgn * Bm.m[3 * i + j]; out[6 * (i + 3) + j] = 0.0;
+  }
+}
+
 // ============================================================================================================
 // FJ, FV, FU > 0: the model's body / velocity / control counts as compile-time constants (a free-flyer model: nq = nv + 1, n = 2 nv; FCD: the
 // carve-out with the blocks of the contact-constrained dynamics) — the loop bounds, strides and LDS offsets of the carve-out fold into the instructions, as in the
@@ -189,15 +287,7 @@ __global__ void __launch_bounds__(EVAL_THREADS, EVAL_MIN_WAVES) k_eval_multibody
   const int b = blockIdx.y;
   constexpr int nthr = EVAL_THREADS;  // (the launcher uses EVAL_THREADS threads)
   int cand = blockIdx.z + cand0;
-#ifdef EV_ROTATE
-  // The single-wavefront phases (tree recursions with a lane per body, the factorisation chain) all run on "wavefront 0".  The wavefronts of
-  // a workgroup go to the four SIMDs of a CU in order, so the wavefronts 0 of the two workgroups sharing a CU sit on the SAME SIMD and
-  // take turns while the other three SIMDs idle.  Rotate the roles by a per-workgroup amount: thread ids are only ever used as roles.
-  const unsigned lin_ = blockIdx.y * gridDim.x + blockIdx.x, j_ = lin_ >> 3;
-  int tid = (threadIdx.x + 64 * ((j_ + (j_ >> 5)) & (EVAL_THREADS / 64 - 1))) & (EVAL_THREADS - 1);
-#else
   int tid = threadIdx.x;
-#endif
   const InstState& st = a.inst[b];
   // TRIAL: 0 full evaluation, 1 value-only linesearch candidate, 3 the alpha = 1 candidate WITH derivatives, written into the knot
   // records themselves (tick reuse: if the full step is accepted these are the records of the next tick, one knot on),
@@ -411,17 +501,10 @@ sim_u_set:
   __syncthreads();
   EV_PROF(0);
   // ---- P3: body velocities ------------------------------------------------------------------------------
-#ifdef EV_TREE_MFMA
   for (int t = wv; t < ((nj + 15) >> 4); t += nw) {  // ov = (J diag(v)) x bits(dmask): 6 x nv times nv x nj
     const d4_t acc = mask_tile([&](int row, int k) { const int r = row < 6 ? row : 5, kc = k < nv ? k : nv - 1; return J[r * nv + kc] * v[kc]; }, dmask, 16 * t, nj, nv, lane);
     tile_store_soa(ov, nj, 0, 6, 16 * t, nj, acc, lane);
   }
-#else
-  for (int idx = tid; idx < 6 * nj; idx += nthr) {
-    const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-    ov[idx] = mask_sum(dmask[i], [&](int kd) { return J[e * nv + kd] * v[kd]; });
-  }
-#endif
   __syncthreads();
   // Contact frames (world placement, placement error of the Baumgarte term, Jlog6): single-lane SE(3) work that needs the placements
   // only — lane cc of wavefront 1 does it here, beside the bodies' inertias on wavefront 0 (after the factor's inputs it sat on the
@@ -479,7 +562,6 @@ sim_u_set:
   }
   __syncthreads();
   // ---- P5: composite inertias / momenta, bias forces ----------------------------------------------------
-#ifdef EV_TREE_MFMA
   // composite inertias and momenta: Yc = oY x bits(sub), Hc = oh x bits(sub) — tiles over the wavefronts ; the bias forces of the bodies by the lanes of the
   // last wavefront first (its tiles come after)
   if (wv == nw - 1 && lane < nj) stc6(of, nj, lane, add6(sym_mul(ldy21(oY, nj, lane), ldc6(oa, nj, lane)), fcross(ldc6(ov, nj, lane), ldc6(oh, nj, lane))));
@@ -488,24 +570,6 @@ sim_u_set:
   __syncthreads();
   tree_sum_mfma(Fc, nj, of, nj, 6, sub, nj, nj, wv, nw, 0, lane);
   if (wv == nw - 1 && lane < nv) stc6(U, nv, lane, sym_mul(ldy21(Yc, nj, dof_body[lane]), ldc6(J, nv, lane)));  // (nv <= 64: check_multibody_model)
-#else
-  for (int idx = tid; idx < 21 * nj; idx += nthr) {
-    const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-    Yc[idx] = mask_sum(sub[i], [&](int j) { return oY[e * nj + j]; });
-  }
-  for (int idx = tid; idx < 6 * nj; idx += nthr) {
-    const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-    Hc[idx] = mask_sum(sub[i], [&](int j) { return oh[e * nj + j]; });
-  }
-  for (int i = tid; i < nj; i += nthr)
-    stc6(of, nj, i, add6(sym_mul(ldy21(oY, nj, i), ldc6(oa, nj, i)), fcross(ldc6(ov, nj, i), ldc6(oh, nj, i))));
-  __syncthreads();
-  for (int idx = tid; idx < 6 * nj; idx += nthr) {
-    const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-    Fc[idx] = mask_sum(sub[i], [&](int j) { return of[e * nj + j]; });
-  }
-  for (int kd = tid; kd < nv; kd += nthr) stc6(U, nv, kd, sym_mul(ldy21(Yc, nj, dof_body[kd]), ldc6(J, nv, kd)));
-#endif
   // total mass and centre of mass from the composite inertia of the root (Yc is recycled before the terms read them)
   const double mtot = Yc[0];
   const V3 com = v3(Yc[sym6(1, 5) * nj] / mtot, Yc[sym6(2, 3) * nj] / mtot, Yc[sym6(0, 4) * nj] / mtot);
@@ -556,14 +620,7 @@ sim_u_set:
         }
       }
       __syncthreads();
-#ifdef EV_TREE_MFMA
       tree_sum_mfma(Bc, nj, oY, nj, 36, sub, nj, nj, wv, nw, 0, lane);
-#else
-      for (int idx = tid; idx < 36 * nj; idx += nthr) {
-        const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-        Bc[idx] = mask_sum(sub[i], [&](int j) { return oY[e * nj + j]; });
-      }
-#endif
       __syncthreads();
       for (int kd = tid; kd < nv; kd += nthr) {
         const int bk = dof_body[kd];
@@ -746,7 +803,6 @@ sim_u_set:
   if (has_dyn) {
     // ---- P7: joint-space inertia (lower block triangle, tile-packed), bias torques, contact frames ---------------
     const int ntile = nbm * (nbm + 1) / 2;
-#ifdef EV_M_MFMA
     // a tile per wavefront: U^T J (entry (r, c) with c on the path to r) and J^T U (r on the path to c) as two depth-6 products on the matrix cores, the tree
     // masks pick one — 8 operand reads and 4 MFMAs for 256 entries where a lane per entry read 12 doubles for each of its six
     for (int t = wv; t < ntile; t += nw) {
@@ -773,22 +829,6 @@ sim_u_set:
         }
         Mt[t * 272 + i * 17 + j] = s;
       }
-    }
-    for (int idx = tid; idx < 0; idx += nthr) {
-#else
-    for (int idx = tid; idx < ntile * 256; idx += nthr) {
-#endif
-      const int t = idx >> 8, i = (idx >> 4) & 15, j = idx & 15;
-      int bi = 0;
-      while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-      const int bj = t - bi * (bi + 1) / 2, r = 16 * bi + i, cc = 16 * bj + j;
-      double s = (r == cc) ? 1.0 : 0.0;  // identity padding
-      if (r < nv && cc < nv) {
-        s = 0;
-        if (BELOW(cc, dof_body[r])) s = dot6(ldc6(U, nv, r), ldc6(J, nv, cc));
-        else if (BELOW(r, dof_body[cc])) s = dot6(ldc6(U, nv, cc), ldc6(J, nv, r));
-      }
-      Mt[t * 272 + i * 17 + j] = s;
     }
     for (int kd = tid; kd < nv; kd += nthr) bias[kd] = dot6(ldc6(J, nv, kd), ldc6(Fc, nj, dof_body[kd]));
     if (tid < nk) {
@@ -825,7 +865,12 @@ sim_u_set:
     // ---- P8: M = L L^T ; Y = L^-1 [Jc^T | r1] ; S = Y^T Y + mu I = Ls Ls^T ; multipliers — ONE wavefront, no barrier inside (its LDS
     // operations execute in order) ; then the accelerations
     if (wv == 0) {
+#ifdef EV_CHOL_N
+      constexpr int NLAST_M = FX ? ((FV % 16) ? (FV % 16) : 16) : 16;  // real columns of the last diagonal block of M (fixed dimensions: known ; else: all 16)
+      if (!chol_tiles_wave_last<NLAST_M>(Mt, nbm, lane)) { if (lane == 0) iflag[0] = 0; }
+#else
       if (!chol_tiles_wave(Mt, nbm, lane)) { if (lane == 0) iflag[0] = 0; }
+#endif
       else {
         EV_SUB(3);
         trsm_fwd_tiles(Mt, nbm, Y16, MB_LDY, 1, 0, 1, lane);
@@ -841,7 +886,12 @@ sim_u_set:
           Sp[row * 17 + col] = sv;
           if (col == 12 && row < nl) small[row] = g[qq] + gam[row];  // t = Y^T w - r2,  r2 = -gamma
         }
+#ifdef EV_CHOL_N
+        const bool s_ok = (nl == 12) ? chol16_wave_n<12>(Sp, 17, LIs, lane) : ((nl == 6) ? chol16_wave_n<6>(Sp, 17, LIs, lane) : chol16_wave(Sp, 17, LIs, lane));
+        if (!s_ok && lane == 0) iflag[1] = 0;
+#else
         if (!chol16_wave(Sp, 17, LIs, lane) && lane == 0) iflag[1] = 0;
+#endif
         EV_SUB(16);
         // z2 = Ls^-T Ls^-1 t ; lambda = -z2
         // (sixteen terms for every lane, all operands requested at once: the entries of Ls^-1 above the diagonal are exact zeros, the
@@ -970,58 +1020,89 @@ sim_u_set:
     }
   }
 
-  // single-lane SE(3) work of the integrator (P12): part 0 = step, gap, Jlog6(G) ; part 1 = Jexp6, Ad^-1, E6.  Depends on the accelerations
-  // only: on stages with contact dynamics it runs on the wavefront that has one column block less in P11 (7 blocks on 4 wavefronts),
-  // beside the implicit differentiation instead of after it.
+  // single-lane SE(3) work of the integrator (P12): step, gap and its Jacobian blocks Jlog6(G), Jexp6(delta), Ad(exp6(delta))^-1, E6 = -Jlog6(G^-1).  Depends on the
+  // accelerations only: on stages with contact dynamics it runs on the wavefront that has one column block less in P11 (7 blocks on 4 wavefronts), beside
+  // the implicit differentiation instead of after it.
   const double dt_se3 = (has_dyn || kino) ? P[desc[4]] : 0.0;
-#ifdef EV_DIRECT_AB
   const bool direct_ab = has_dyn && 6 * nz <= 21 * nj;  // the base rows of d a fit in the region of Yc (every Talos model ; else: the HBM scratch)
-#else
-  const bool direct_ab = false;
-#endif
-  auto step_se3 = [&](int part) {
+  // ONE lane, ONE logarithm (round 6).  Rounds 3 - 5 split this over two lanes whose parts each began with exp6 and ended in a Jlog6 that recomputed the
+  // logarithm just taken — 33 calls of sin / cos / atan2 between them, 13 us on the two diverged lanes of a wavefront the other three waited for at the end of
+  // P11.  Here: exp6 once ; (gv, gw) = log6(G) once ; log6(G^-1) = -(gv, gw) exactly, so Jlog6(G^-1) (E6) takes the same series coefficients with the signs of
+  // its odd terms flipped ; Jexp6 shares so3_coeffs with exp6.  9 calls.
+  // In three pieces, so that on stages with contact dynamics most of it runs where wavefronts idle (P10 occupies two of four): x1 = Jexp6(delta), Ad^-1 (needs
+  // the step only) ; x2a = step, gap, logarithm and the series coefficients, parked in `red` (free until the merit) ; x2b = Jlog6(G), E6 from them.
+  struct Se3Exp { V3 dl, da_; double A, B, C, td2; M3 Kd, Kd2, dR; V3 dp; };
+  auto se3_exp = [&]() {
+    Se3Exp e;
     const double dt = dt_se3;
-    double* Jl6 = small; double* Je6 = small + 36; double* Jq6 = small + 72;
-    const V3 dl = v3(dt * (v[0] + dt * acc[0]), dt * (v[1] + dt * acc[1]), dt * (v[2] + dt * acc[2]));
-    const V3 da_ = v3(dt * (v[3] + dt * acc[3]), dt * (v[4] + dt * acc[4]), dt * (v[5] + dt * acc[5]));
-    M3 dR; V3 dp;
-    exp6(dl, da_, dR, dp);
+    e.dl = v3(dt * (v[0] + dt * acc[0]), dt * (v[1] + dt * acc[1]), dt * (v[2] + dt * acc[2]));
+    e.da_ = v3(dt * (v[3] + dt * acc[3]), dt * (v[4] + dt * acc[4]), dt * (v[5] + dt * acc[5]));
+    e.td2 = dot(e.da_, e.da_);
+    so3_coeffs(e.td2, e.A, e.B, e.C);
+    e.Kd = skew_m(e.da_); e.Kd2 = mul(e.Kd, e.Kd);
+    for (int i = 0; i < 9; ++i) e.dR.m[i] = ((i % 4 == 0) ? 1.0 : 0.0) + e.A * e.Kd.m[i] + e.B * e.Kd2.m[i];
+    const V3 wv_ = cross(e.da_, e.dl);
+    e.dp = e.dl + e.B * wv_ + e.C * cross(e.da_, wv_);
+    return e;
+  };
+  auto se3_x1 = [&]() {  // Jexp6(delta) and Ad(exp6(delta))^-1 = [[dR^T, -dR^T [dp]x],[0, dR^T]]
+    double* Je6 = small + 36; double* Jq6 = small + 72;
+    const Se3Exp e = se3_exp();
+    double b1, b2, b3;
+    q_coeffs(e.td2, b1, b2, b3);
+    const M3 Qe = Qmat_c(v3(-e.dl.x, -e.dl.y, -e.dl.z), v3(-e.da_.x, -e.da_.y, -e.da_.z), b1, b2, b3);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+      const double jr = ((i == j) ? 1.0 : 0.0) - e.B * e.Kd.m[3 * i + j] + e.C * e.Kd2.m[3 * i + j];
+      Je6[6 * i + j] = jr; Je6[6 * (i + 3) + j + 3] = jr; Je6[6 * i + j + 3] = Qe.m[3 * i + j]; Je6[6 * (i + 3) + j] = 0.0;
+    }
+    const M3 Sx = skew_m(e.dp);
+    const M3 RtS = tmul(e.dR, Sx);
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
+      Jq6[6 * r + cc] = e.dR.m[3 * cc + r]; Jq6[6 * (r + 3) + cc + 3] = e.dR.m[3 * cc + r];
+      Jq6[6 * r + cc + 3] = -RtS.m[3 * r + cc]; Jq6[6 * (r + 3) + cc] = 0.0;
+    }
+  };
+  auto se3_x2a = [&](double* park) {  // step, next state, gap = log6(G) ; park: gv (3), gw (3), c, a1, a2, a3
+    const Se3Exp e = se3_exp();
     const M3 Rb = quat_to_rot(q + 3);
-    const M3 Rn = mul(Rb, dR);
-    const V3 pn = mul(Rb, dp) + v3(q[0], q[1], q[2]);
+    const M3 Rn = mul(Rb, e.dR);
+    const V3 pn = mul(Rb, e.dp) + v3(q[0], q[1], q[2]);
     const M3 Rt = quat_to_rot(xn + 3);
     const M3 GR = tmul(Rt, Rn);
     const V3 Gp = tmul(Rt, pn - v3(xn[0], xn[1], xn[2]));
-    if (part == 0) {
-      if (derivs) { kn[KL.oXN] = pn.x; kn[KL.oXN + 1] = pn.y; kn[KL.oXN + 2] = pn.z; rot_to_quat(Rn, kn + KL.oXN + 3); }
-      V3 gv, gw;
-      log6(GR, Gp, gv, gw);
-      kn[KL.oF] = gv.x; kn[KL.oF + 1] = gv.y; kn[KL.oF + 2] = gv.z; kn[KL.oF + 3] = gw.x; kn[KL.oF + 4] = gw.y; kn[KL.oF + 5] = gw.z;
-      if (derivs) Jlog6(GR, Gp, Jl6);
-    } else {
-      Jexp6(dl, da_, Je6);
-      // Ad(exp6(delta))^-1 = [[dR^T, -dR^T [dp]x],[0, dR^T]]
-      const M3 Sx = skew_m(dp);
-      const M3 RtS = tmul(dR, Sx);
-      for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
-        Jq6[6 * r + cc] = dR.m[3 * cc + r]; Jq6[6 * (r + 3) + cc + 3] = dR.m[3 * cc + r];
-        Jq6[6 * r + cc + 3] = -RtS.m[3 * r + cc]; Jq6[6 * (r + 3) + cc] = 0.0;
-      }
-      // E6 = -Jlog6(G^-1)
-      double E[36];
-      M3 Gi;
-      for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) Gi.m[3 * r + cc] = GR.m[3 * cc + r];
-      const V3 gip = mul(Gi, v3(-Gp.x, -Gp.y, -Gp.z));
-      Jlog6(Gi, gip, E);
-      for (int e = 0; e < 36; ++e) kn[KL.oE6 + e] = -E[e];
-    }
+    if (derivs) { kn[KL.oXN] = pn.x; kn[KL.oXN + 1] = pn.y; kn[KL.oXN + 2] = pn.z; rot_to_quat(Rn, kn + KL.oXN + 3); }
+    const V3 gw = log3(GR);
+    const double t2 = dot(gw, gw);
+    double c;
+    if (t2 < kSmall2) c = 1.0 / 12 + t2 * (1.0 / 720 + t2 * (1.0 / 30240 + t2 * (1.0 / 1209600)));
+    else { const double t = sqrt(t2), sh = sin(0.5 * t), ch = cos(0.5 * t); c = (1.0 - t * ch / (2.0 * sh)) / t2; }
+    const V3 wp = cross(gw, Gp);
+    const V3 gv = Gp - 0.5 * wp + c * cross(gw, wp);
+    kn[KL.oF] = gv.x; kn[KL.oF + 1] = gv.y; kn[KL.oF + 2] = gv.z; kn[KL.oF + 3] = gw.x; kn[KL.oF + 4] = gw.y; kn[KL.oF + 5] = gw.z;
+    if (!derivs) return;
+    double a1, a2, a3;
+    q_coeffs(t2, a1, a2, a3);
+    park[0] = gv.x; park[1] = gv.y; park[2] = gv.z; park[3] = gw.x; park[4] = gw.y; park[5] = gw.z; park[6] = c; park[7] = a1; park[8] = a2; park[9] = a3;
   };
+  auto se3_x2b = [&](const double* park) {  // Jlog6(G) -> small[0, 36) ; E6 = -Jlog6(G^-1) -> record
+    double* Jl6 = small;
+    const V3 gv = v3(park[0], park[1], park[2]), gw = v3(park[3], park[4], park[5]);
+    const double c = park[6], a1 = park[7], a2 = park[8], a3 = park[9];
+    const M3 K = skew_m(gw), K2 = mul(K, K);
+    M3 Ji, Jn;
+    for (int i = 0; i < 9; ++i) { const double e = ((i % 4 == 0) ? 1.0 : 0.0) + c * K2.m[i]; Ji.m[i] = e + 0.5 * K.m[i]; Jn.m[i] = e - 0.5 * K.m[i]; }
+    jlog6_blocks(Ji, Qmat_c(v3(-gv.x, -gv.y, -gv.z), v3(-gw.x, -gw.y, -gw.z), a1, a2, a3), 1.0, Jl6);   // Jlog6(G)
+    double E[36];
+    jlog6_blocks(Jn, Qmat_c(gv, gw, a1, a2, a3), -1.0, E);                                              // E6 = -Jlog6(G^-1)
+    for (int e = 0; e < 36; ++e) kn[KL.oE6 + e] = E[e];
+  };
+  double* se3_park = red;  // (10 doubles ; `red` is not used before the merit)
+  auto step_se3_fused = [&]() { if (derivs) se3_x1(); se3_x2a(se3_park); if (derivs) se3_x2b(se3_park); };  // (one lane: its LDS operations execute in order)
   // ---- P9: body accelerations and subtree forces AT THE SOLUTION (only the derivative blocks read them):
   //   da_i = sum_{k on the path to i} J_k acc_k ;  Fc_i += Yc_i da_i + sum_{k strictly below i} U_k acc_k - (wrenches of the contacts below i)
   // (sum over the subtree of Y_j da_j, regrouped by dof: the composite inertias and U = Yc J are at hand, the body inertias are not)
   if (derivs && (has_dyn || kino)) {
     double* da = Tq;  // scratch [6][nj] (Tq is formed afterwards)
-#ifdef EV_TREE_MFMA
     // da = (J diag(acc)) x bits(dmask) and the "dofs strictly below" part of the forces, (U diag(acc)) x bits(below), as tiles: wavefront t does column tile t of
     // both (the second into its registers), then the rest of the update on its own columns after the barrier
     d4_t fbel = d4_t{0, 0, 0, 0};
@@ -1052,23 +1133,6 @@ sim_u_set:
         }
       }
     }
-#else
-    for (int idx = tid; idx < 6 * nj; idx += nthr) {
-      const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-      da[idx] = mask_sum(dmask[i], [&](int kd) { return J[e * nv + kd] * acc[kd]; });
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 6 * nj; idx += nthr) {
-      const int e = qdiv(idx, S.mg_nj), i = idx - e * nj;
-      double s = Fc[idx];
-#pragma unroll
-      for (int bb = 0; bb < 6; ++bb) s += Yc[sym6(e, bb) * nj + i] * da[bb * nj + i];
-      s = mask_sum(below[i], [&](int kd) { return U[e * nv + kd] * acc[kd]; }, s);
-      for (int cc = 0; cc < nk; ++cc) if ((anc[cbody_s[cc]] >> i) & 1ull) s -= cfr[54 * cc + 48 + e];
-      Fc[idx] = s;
-      oa[idx] += da[idx];
-    }
-#endif
     __syncthreads();
     // Psdd (needs the parents' accelerations at the solution) and Tq = Yc Psdd + Bc Psd + J x* Fc
     for (int kd = tid; kd < nv; kd += nthr) {
@@ -1160,6 +1224,11 @@ sim_u_set:
         }
         }
       }
+#ifdef EV_SE3_SPLIT
+      // (the contact rows above occupy nk nv <= 128 threads: the last two wavefronts do the integrator's single-lane work that needs the step only)
+      if (wv == (nw > 2 ? nw - 2 : nw - 1) && lane == 0) se3_x1();
+      if (wv == nw - 1 && lane == 0) se3_x2a(se3_park);
+#endif
       __syncthreads();
       double* dbase = Yc;  // [6][nz]: base rows of d a (direct_ab)
       // ---- P11: R1 = d r1 / d(q, v, u) built in registers, one 16-column block per wavefront at a time, and the whole chain of
@@ -1168,16 +1237,25 @@ sim_u_set:
 #ifdef EV_P11PROF  // developer build: where the time of P11 goes, per wavefront (slots 16 + wv: its column blocks ; 3: the SE(3) work of the last one ; 4: R1 of wave 0's first block)
       const long long tp11_ = clock64();
 #endif
+      // the tree tables of this lane's rows (16 bi + (l >> 4) + 4 qq), once for all its column blocks and unconditionally: inside the entry loop each was a
+      // dependent pair of LDS reads behind two branches
+      int rbr_[16];
+      unsigned long long ranc_[16];
+#pragma unroll
+      for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const int r_ = 16 * bi + (lane >> 4) + 4 * qq;
+          rbr_[4 * bi + qq] = (bi < nbm) ? dof_body[r_ < nv ? r_ : nv - 1] : 0;
+        }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ranc_[e] = ((e >> 2) < nbm) ? anc[rbr_[e]] : 0ull;
       for (int cj = wv; cj < ncb; cj += nw) {
         const int z = 16 * cj + (lane & 15), rq = lane >> 4;
         const int kind = z < nv ? 0 : (z < n2 ? 1 : (z < n2 + nu ? 2 : 3));
         const int j = kind == 0 ? z : (kind == 1 ? z - nv : 0);
         const int bj = dof_body[j];
-#ifndef EV_R1_MFMA
-        const S6 c1 = ldc6(kind ? Phi : Psdd, nv, j), c2 = ldc6(kind ? J : Psd, nv, j), c3 = ldc6(kind ? Tv : Tq, nv, j);
-#endif
         d4_t w[4], t;
-#ifdef EV_R1_MFMA
         // Both candidates of every entry as tile products on the matrix cores — [U ; Bt]^T [c1 ; c2] (depth 12: row r below column j) and J^T c3 (depth 6,
         // padded to 8: row r above column j) — then the tree masks pick one.  10 operand reads and 5 MFMAs per 16 x 16 tile where the lane-per-entry form
         // read 4 x (12 .. 24) doubles and issued as many multiply-adds.  Operands: A(row, e) of lane (row = l & 15, e = 4 s + (l >> 4)), B(e, column l & 15).
@@ -1210,37 +1288,14 @@ sim_u_set:
 #pragma unroll
               for (int qq = 0; qq < 4; ++qq) {
                 const int r = 16 * bi + rq + 4 * qq;
-                double val = 0.0;
-                if (r < nv) {
-                  if (kind < 2) {
-                    const int br = dof_body[r];
-                    if ((anc[br] >> bj) & 1ull) val = p1[qq];
-                    else if ((ancj >> br) & 1ull) val = p2[qq];
-                  } else if (kind == 2 && r == nv - nu + (z - n2)) val = -1.0;  // d r1 / du = -B
-                }
-                w[bi][qq] = val;
+                const bool m1 = (ranc_[4 * bi + qq] >> bj) & 1ull, m2 = (ancj >> rbr_[4 * bi + qq]) & 1ull;
+                const double vt = m1 ? p1[qq] : (m2 ? p2[qq] : 0.0);
+                const double vu = (kind == 2 && r == nv - nu + (z - n2)) ? -1.0 : 0.0;  // d r1 / du = -B
+                w[bi][qq] = (r < nv) ? (kind < 2 ? vt : vu) : 0.0;
               }
             }
           }
         }
-#else
-#pragma unroll
-        for (int bi = 0; bi < 4; ++bi) {
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int r = 16 * bi + rq + 4 * qq;
-            double val = 0.0;
-            if (bi < nbm && r < nv) {
-              if (kind < 2) {
-                const int br = dof_body[r];
-                if ((anc[br] >> bj) & 1ull) val = dot6(ldc6(U, nv, r), c1) + dot6(ldc6(Bt, nv, r), c2);
-                else if ((anc[bj] >> br) & 1ull) val = dot6(ldc6(J, nv, r), c3);
-              } else if (kind == 2 && r == nv - nu + (z - n2)) val = -1.0;  // d r1 / du = -B
-            }
-            w[bi][qq] = val;
-          }
-        }
-#endif
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) t[qq] = (qq < 3) ? DL[(rq + 4 * qq) * ldl + 16 * cj + (lane & 15)] : 0.0;
 #ifdef EV_P11PROF
@@ -1276,7 +1331,11 @@ sim_u_set:
       const long long tp11b_ = clock64();
       if (TRIAL == 0 && a.prof && k == 1 && lane == 0) a.prof[(size_t)b * 64 + 32 + 16 + wv] += (double)(tp11b_ - tp11_);
 #endif
-      if (wv == nw - 1 && lane < 2) step_se3(lane);  // (P12's single-lane work, on the wavefront with the fewest column blocks)
+#ifdef EV_SE3_SPLIT
+      if (wv == nw - 1 && lane == 0) se3_x2b(se3_park);  // (what is left of P12's single-lane work, on the wavefront with the fewest column blocks)
+#else
+      if (wv == nw - 1 && lane == 0) step_se3_fused();  // (P12's single-lane work, on the wavefront with the fewest column blocks)
+#endif
 #ifdef EV_P11PROF
       if (TRIAL == 0 && a.prof && k == 1 && lane == 0 && wv == nw - 1) a.prof[(size_t)b * 64 + 32 + 3] += (double)(clock64() - tp11b_);
 #endif
@@ -1295,7 +1354,7 @@ sim_u_set:
     double* D12 = small + 108;  // D1_b = Jlog6(G) Jq6 (36) | Dd_b = dt Jlog6(G) Jexp6 (36)   (layout.h, oD12)
     // The SE(3) pieces are single-lane work (log / exp maps and their Jacobians): spread them over the wavefronts
     // — wave 0: step, gap, Jlog6(G) ; wave 1: Jexp6, Ad^-1, E6 ; waves 2..: the SE(3)-valued cost / constraint terms
-    if (!(has_dyn && derivs) && (tid == 0 || (tid == 64 && derivs))) step_se3(tid == 0 ? 0 : 1);
+    if (!(has_dyn && derivs) && tid == 0) step_se3_fused();
     for (int i = 6 + tid; i < n; i += nthr) {
       if (i < nv) { const double vp = v[i] + dt * acc[i]; kn[KL.oF + i] = q[i + 1] + dt * vp - xn[i + 1]; if (derivs) kn[KL.oXN + i + 1] = q[i + 1] + dt * vp; }
       else if (i >= nv) { const int j = i - nv; const double vp = v[j] + dt * acc[j]; kn[KL.oF + i] = vp - xn[nq + j]; if (derivs) kn[KL.oXN + nq + j] = vp; }

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -102,6 +103,7 @@ struct mpc_solver {
   bool appended_any = false;       // a stage was appended since the last run (refine_appended_knot < 0: refine after every cycle)
   // mpc_walk_*: reference generation on the device (k_walk_refs)
   bool walk_on = false, walk_force_all = false;
+  std::vector<uint8_t> walk_poisoned;  // per ring slot: the host mirror of the ranges k_walk_refs writes holds NaN (see mpc_walk_update)
   mpc_walk_config walk{};
   double* d_walk_state = nullptr;  // [B][48]
   int since_change = 1 << 20;      // mpc_cycle calls since the appended stage last changed its contact pattern (corrector_window)
@@ -435,6 +437,7 @@ static void bcast_slot_to_instances(mpc_solver* s, int slot) {
   for (int b = 0; b < L.B; ++b)
     std::memcpy(s->h_inst_params.data() + ((size_t)b * (L.N + 1) + slot) * L.max_stage_doubles, s->h_params.data() + (size_t)slot * L.max_stage_doubles,
                 (size_t)L.max_stage_doubles * sizeof(double));
+  if (!s->walk_poisoned.empty()) s->walk_poisoned[slot] = 0;  // (the mirror of this slot holds real values again)
 }
 
 static void upload_stage(mpc_solver* s, int slot, const int32_t* desc, int n_desc, const double* params, int n_params) {
@@ -550,6 +553,7 @@ static int apply_param_patches(mpc_solver* s, const std::vector<ParamPatch>& in)
     double* hp = (p.inst >= 0 ? s->h_inst_params.data() + (size_t)p.inst * istride : s->h_params.data()) + (size_t)p.slot * L.max_stage_doubles + p.offset;
     if (p.len == 0 || std::memcmp(hp, p.vals, p.len * sizeof(double)) == 0) continue;
     std::memcpy(hp, p.vals, p.len * sizeof(double));
+    if (!s->walk_poisoned.empty()) s->walk_poisoned[p.slot] = 0;  // (a host patch put real values into the mirror of this slot: the next device-generated tick poisons it again)
     if (p.inst < 0 && s->d_inst_params)
       for (int b = 0; b < L.B; ++b) std::memcpy(s->h_inst_params.data() + (size_t)b * istride + (size_t)p.slot * L.max_stage_doubles + p.offset, p.vals, p.len * sizeof(double));
     s->slot_dirty[p.slot] = 1;  // (per slot, for every instance: the knot mask of tick reuse is shared)
@@ -1075,6 +1079,27 @@ int mpc_walk_update(mpc_solver* s, int32_t takeoff_RF, int32_t takeoff_LF, int32
     if (replanning || s->walk_force_all) for (int k = 0; k < L.N; ++k) s->slot_dirty[slot_of(s, k)] = 1;
     else s->slot_dirty[slot_of(s, L.N - 1)] = 1;
     s->slot_dirty[L.N] = 1;
+    // The kernel wrote the references straight into d_inst_params: the host mirror that mpc_update_instance_params_batch compares its patches with no longer
+    // says what the device holds.  Poison the written ranges (NaN never memcmp-equals a caller's values), so that a host patch of the same offsets after a
+    // device-generated tick always travels — switching an ensemble from the device generator to the host one, or mixing the two APIs, stays correct.
+    // (Once per slot until a host patch or a stage upload rewrites its mirror: nothing per tick in steady state.)
+    {
+      if (s->walk_poisoned.size() != (size_t)(L.N + 1)) s->walk_poisoned.assign(L.N + 1, 0);
+      const double qnan = std::numeric_limits<double>::quiet_NaN();
+      const size_t istride = (size_t)(L.N + 1) * L.max_stage_doubles;
+      auto poison = [&](int slot, int off, int len) {
+        if (off < 0) return;
+        for (int b = 0; b < L.B; ++b) std::fill_n(s->h_inst_params.data() + (size_t)b * istride + (size_t)slot * L.max_stage_doubles + off, len, qnan);
+      };
+      for (int k = (replanning || s->walk_force_all) ? 0 : L.N - 1; k < L.N; ++k) {
+        const int sl = slot_of(s, k);
+        if (s->walk_poisoned[sl]) continue;
+        poison(sl, c.off_lf, 12); poison(sl, c.off_rf, 12);
+        if (c.z_follow != 0.0) poison(sl, c.off_xref_z, 1);
+        s->walk_poisoned[sl] = 1;
+      }
+      if (!s->walk_poisoned[L.N]) { poison(L.N, c.toff_com, 3); poison(L.N, c.toff_lf, 12); poison(L.N, c.toff_rf, 12); s->walk_poisoned[L.N] = 1; }
+    }
     s->walk_force_all = false;
   })
 }
@@ -1435,6 +1460,9 @@ int mpc_set_state(mpc_solver* s, const double* buf, int64_t len) {
     copy_sync(s, st.data(), s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost);
     for (int b = 0; b < L.B; ++b) { st[b].mu = o[0]; st[b].inner_tol = o[1]; st[b].prim_tol = o[2]; o += 4; }
     copy_sync(s, s->d_inst, st.data(), L.B * sizeof(InstState), hipMemcpyHostToDevice);
+    // every stage went through upload_stage above, which hands the instances the SHARED tables again: with the reference generator in the library the next
+    // mpc_walk_update must rewrite the references of every knot, not only of the appended one
+    s->walk_force_all = s->walk_on;
   })
 }
 

@@ -150,6 +150,9 @@ int mpc_walk_init(mpc_solver* h, const mpc_walk_config* cfg) {
     if (h->model_itab.empty() || s.dims.space != MPC_SPACE_MULTIBODY) throw std::runtime_error("walk_init: a whole-body model is needed (mpc_set_model)");
     const int nf = h->model_itab[3];
     if (cfg->frame_lf < 0 || cfg->frame_lf >= nf || cfg->frame_rf < 0 || cfg->frame_rf >= nf) throw std::runtime_error("walk_init: frame index out of range");
+    // (the same range checks and messages as the HIP library: the offsets are used for 96-byte copies into the instance tables)
+    for (int off : {cfg->off_lf, cfg->off_rf, cfg->toff_lf, cfg->toff_rf}) if (off >= 0 && off + 12 > s.dims.max_stage_doubles) throw std::runtime_error("walk_init: reference offset out of range");
+    if ((cfg->toff_com >= 0 && cfg->toff_com + 3 > s.dims.max_stage_doubles) || (cfg->off_xref_z >= s.dims.max_stage_doubles)) throw std::runtime_error("walk_init: offset out of range");
     h->walk = *cfg;
     h->walk_state.assign((size_t)s.dims.batch * 48, 0.0);
     for (int b = 0; b < s.dims.batch; ++b) {
@@ -489,9 +492,13 @@ int mpc_set_state(mpc_solver* h, const double* buf, int64_t len) {
     for (int k = 0; k <= N; ++k) {
       const int nd = (int)o[0], np = (int)o[1];
       for (int i = 0; i < d.max_stage_ints; ++i) desc[i] = (int32_t)o[2 + i];
-      if (nd > 0) s.stages[k].parse(desc.data(), nd, o + 2 + d.max_stage_ints, np);
+      if (nd > 0) {
+        s.stages[k].parse(desc.data(), nd, o + 2 + d.max_stage_ints, np);
+        for (auto& ip : s.inst_params) ip[k] = s.stages[k].params;  // (as mpc_set_stage: the instances start from the shared table again)
+      }
       o += 2 + d.max_stage_ints + d.max_stage_doubles;
     }
+    h->walk_force_all = h->walk_on;  // the next mpc_walk_update rewrites the references of every knot
     for (int b = 0; b < B; ++b) for (int k = 0; k <= N; ++k) { s.inst[b].xs[k].assign(o, o + d.nx); o += d.nx; }
     for (int b = 0; b < B; ++b) for (int k = 0; k < N; ++k) { s.inst[b].us[k].assign(o, o + d.nu); o += d.nu; }
     for (int b = 0; b < B; ++b) for (int k = 0; k <= N; ++k) { std::copy(o, o + std::min<size_t>(d.nc_max, s.inst[b].vs[k].size()), s.inst[b].vs[k].begin()); o += d.nc_max; }

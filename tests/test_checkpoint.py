@@ -134,3 +134,101 @@ def test_revive_keeps_the_multipliers_of_the_other_instances_oracle(oracle_lib):
 @pytest.mark.gpu
 def test_revive_keeps_the_multipliers_of_the_other_instances_hip(hip_lib):
     _revive_leaves_the_others_alone(hip_lib)
+
+
+# ---- restore with the reference generator in the library (mpc_walk_init / mpc_walk_update) -----------------------------------------------------------
+def _restore_mid_swing(lib, exact):
+    """mpc_set_state re-uploads every stage, which hands all instances the SHARED parameter tables again.  With ``generator="device"`` the next
+    mpc_walk_update must therefore rewrite the references of EVERY knot (not only of the appended one), in both libraries: an ensemble restored in the middle
+    of a swing — the plan on the device untouched, no mpc_walk_set_state — must carry the tables of the uninterrupted run and continue like it."""
+    import copy
+    from tests.test_walk_generator import _ens
+    e = _ens(lib, FullDynamicsProblem, "device")
+    N, B = e.dims.horizon, e.batch
+    for _ in range(42):   # through the planning window (the T_ds = 30 ticks before the take-off: ticks 8 .. 37 at this horizon) into the swing
+        e.step()
+    assert not e._walk["replanning"]
+    state, tick, lists = e.native.get_state(), e.tick, copy.deepcopy(e._walk["lists"])
+    plan = e.native.walk_get_state()
+
+    def tables():
+        return [[e.native.debug_get("inst_params", k, b).copy() for k in range(N + 1)] for b in range(B)]
+    for _ in range(4):
+        e.step()
+        assert not e._walk["replanning"]
+    assert np.array_equal(plan, e.native.walk_get_state())   # (nothing was planned in between: the device plan is the one of the checkpoint)
+    ref_t, ref = tables(), e.results(gains=True)
+    e.native.set_state(state); e.tick = tick; e._walk["lists"] = copy.deepcopy(lists)
+    for _ in range(4):
+        e.step()
+    got_t, got = tables(), e.results(gains=True)
+    for b in range(B):
+        for k in range(N + 1):
+            assert np.array_equal(ref_t[b][k], got_t[b][k]), "instance %d knot %d: table after the restore differs by %.3e" % (b, k, np.max(np.abs(ref_t[b][k] - got_t[b][k])))
+    for key in ("xs", "us", "K"):
+        assert _same(got[key], ref[key], exact), key
+
+
+def test_restore_mid_swing_with_the_library_generator_oracle(oracle_lib):
+    _restore_mid_swing(oracle_lib, True)
+
+
+@pytest.mark.gpu
+def test_restore_mid_swing_with_the_library_generator_hip(hip_lib):
+    _restore_mid_swing(hip_lib, True)
+
+
+def _host_patch_after_device_tick(lib):
+    """The two ways of writing per-instance references may be mixed: after device-generated ticks a host patch of the same offsets must reach the
+    library even when its values equal what the HOST last put there (the HIP library compares host patches with a host mirror that the device generator
+    does not maintain: it poisons the ranges it writes, so that the comparison can never match)."""
+    from tests.test_walk_generator import _ens
+    e = _ens(lib, FullDynamicsProblem, "device")
+    off, N = int(e._walk["off_lf"]), e.dims.horizon
+    mine = np.arange(12, dtype=float) + 0.5
+    for _ in range(8):                                                    # (the planning window of the first take-off opens at tick 8 at this horizon)
+        e.step()
+    e.native.update_instance_params_batch([(1, j, off, mine) for j in range(N)])   # the host writes: tables and mirror hold `mine`
+    assert all(np.array_equal(e.native.debug_get("inst_params", j, 1)[off:off + 12], mine) for j in range(N))
+    for _ in range(3):                                                    # device-generated ticks inside the planning window: every knot rewritten
+        e.step()
+        assert e._walk["replanning"]
+    assert all(not np.array_equal(e.native.debug_get("inst_params", j, 1)[off:off + 12], mine) for j in range(N))   # the generator's values are in the tables
+    e.native.update_instance_params_batch([(1, j, off, mine) for j in range(N)])   # the same values again
+    for j in range(N):
+        assert np.array_equal(e.native.debug_get("inst_params", j, 1)[off:off + 12], mine), "knot %d: the host patch was dropped" % j
+
+
+def test_host_patch_after_device_generated_ticks_oracle(oracle_lib):
+    _host_patch_after_device_tick(oracle_lib)
+
+
+@pytest.mark.gpu
+def test_host_patch_after_device_generated_ticks_hip(hip_lib):
+    _host_patch_after_device_tick(hip_lib)
+
+
+def _bad_walk_offsets(lib):
+    """mpc_walk_init checks the offsets of the reference slots against the size of the parameter tables — the same error in both libraries (they are used
+    for 96-byte copies into the instance tables)."""
+    from tests.test_walk_generator import _ens
+    e = _ens(lib, FullDynamicsProblem, "host")
+    e2 = _ens(lib, FullDynamicsProblem, "device")
+    cap = int(e2.dims.max_stage_doubles)
+    from mpc_benchmark_amd import _capi as K
+    for field, val in (("off_lf", cap - 11), ("toff_rf", cap - 3), ("toff_com", cap - 2), ("off_xref_z", cap)):
+        cfg = K.MpcWalkConfig()
+        cfg.T_ss, cfg.T_ds, cfg.frame_lf, cfg.frame_rf = 80, 30, 0, 1
+        cfg.off_lf = cfg.off_rf = cfg.toff_lf = cfg.toff_rf = cfg.toff_com = cfg.off_xref_z = -1
+        setattr(cfg, field, val)
+        with pytest.raises(RuntimeError, match="out of range"):
+            e2.native.walk_init(cfg)
+
+
+def test_walk_init_rejects_offsets_outside_the_tables_oracle(oracle_lib):
+    _bad_walk_offsets(oracle_lib)
+
+
+@pytest.mark.gpu
+def test_walk_init_rejects_offsets_outside_the_tables_hip(hip_lib):
+    _bad_walk_offsets(hip_lib)

@@ -1,3 +1,5 @@
+"""Developer experiment (GPU box): the kinodynamic control pipeline of the HIP library and of the oracle free-running side by side (tests/test_pipeline.py):
+per period the deviations of states / torques / forces and the step lengths the two solves accepted."""
 import sys
 sys.path.insert(0, ".")
 import numpy as np
@@ -16,5 +18,6 @@ def mk(lib):
 po, ph = mk(_oracle.load()), mk(_capi.load_hip_library())
 ph.mpc.native.set_state(po.mpc.native.get_state())
 for t in range(50):
-    ph.tick(); po.tick()
-    print(t, list(po.contact_state()), "%.2e %.2e %.2e" % (rel_cols(ph.x, po.x, 1e-3), rel_cols(ph.torques, po.torques, 1.0), rel_cols(ph.forces, po.forces, 1.0)))
+    sh, so = ph.tick(), po.tick()
+    print(t, list(po.contact_state()), "%.2e %.2e %.2e" % (rel_cols(ph.x, po.x, 1e-3), rel_cols(ph.torques, po.torques, 1.0), rel_cols(ph.forces, po.forces, 1.0)),
+          "alpha hip", [s.alpha for s in sh], "oracle", [s.alpha for s in so], "iters", [s.num_iters for s in sh], [s.num_iters for s in so])
