@@ -865,12 +865,8 @@ sim_u_set:
     // ---- P8: M = L L^T ; Y = L^-1 [Jc^T | r1] ; S = Y^T Y + mu I = Ls Ls^T ; multipliers — ONE wavefront, no barrier inside (its LDS
     // operations execute in order) ; then the accelerations
     if (wv == 0) {
-#ifdef EV_CHOL_N
       constexpr int NLAST_M = FX ? ((FV % 16) ? (FV % 16) : 16) : 16;  // real columns of the last diagonal block of M (fixed dimensions: known ; else: all 16)
       if (!chol_tiles_wave_last<NLAST_M>(Mt, nbm, lane)) { if (lane == 0) iflag[0] = 0; }
-#else
-      if (!chol_tiles_wave(Mt, nbm, lane)) { if (lane == 0) iflag[0] = 0; }
-#endif
       else {
         EV_SUB(3);
         trsm_fwd_tiles(Mt, nbm, Y16, MB_LDY, 1, 0, 1, lane);
@@ -886,12 +882,8 @@ sim_u_set:
           Sp[row * 17 + col] = sv;
           if (col == 12 && row < nl) small[row] = g[qq] + gam[row];  // t = Y^T w - r2,  r2 = -gamma
         }
-#ifdef EV_CHOL_N
         const bool s_ok = (nl == 12) ? chol16_wave_n<12>(Sp, 17, LIs, lane) : ((nl == 6) ? chol16_wave_n<6>(Sp, 17, LIs, lane) : chol16_wave(Sp, 17, LIs, lane));
         if (!s_ok && lane == 0) iflag[1] = 0;
-#else
-        if (!chol16_wave(Sp, 17, LIs, lane) && lane == 0) iflag[1] = 0;
-#endif
         EV_SUB(16);
         // z2 = Ls^-T Ls^-1 t ; lambda = -z2
         // (sixteen terms for every lane, all operands requested at once: the entries of Ls^-1 above the diagonal are exact zeros, the
@@ -1029,44 +1021,22 @@ sim_u_set:
   // logarithm just taken — 33 calls of sin / cos / atan2 between them, 13 us on the two diverged lanes of a wavefront the other three waited for at the end of
   // P11.  Here: exp6 once ; (gv, gw) = log6(G) once ; log6(G^-1) = -(gv, gw) exactly, so Jlog6(G^-1) (E6) takes the same series coefficients with the signs of
   // its odd terms flipped ; Jexp6 shares so3_coeffs with exp6.  9 calls.
-  // In three pieces, so that on stages with contact dynamics most of it runs where wavefronts idle (P10 occupies two of four): x1 = Jexp6(delta), Ad^-1 (needs
-  // the step only) ; x2a = step, gap, logarithm and the series coefficients, parked in `red` (free until the merit) ; x2b = Jlog6(G), E6 from them.
-  struct Se3Exp { V3 dl, da_; double A, B, C, td2; M3 Kd, Kd2, dR; V3 dp; };
-  auto se3_exp = [&]() {
-    Se3Exp e;
+  auto step_se3_fused = [&]() {
     const double dt = dt_se3;
-    e.dl = v3(dt * (v[0] + dt * acc[0]), dt * (v[1] + dt * acc[1]), dt * (v[2] + dt * acc[2]));
-    e.da_ = v3(dt * (v[3] + dt * acc[3]), dt * (v[4] + dt * acc[4]), dt * (v[5] + dt * acc[5]));
-    e.td2 = dot(e.da_, e.da_);
-    so3_coeffs(e.td2, e.A, e.B, e.C);
-    e.Kd = skew_m(e.da_); e.Kd2 = mul(e.Kd, e.Kd);
-    for (int i = 0; i < 9; ++i) e.dR.m[i] = ((i % 4 == 0) ? 1.0 : 0.0) + e.A * e.Kd.m[i] + e.B * e.Kd2.m[i];
-    const V3 wv_ = cross(e.da_, e.dl);
-    e.dp = e.dl + e.B * wv_ + e.C * cross(e.da_, wv_);
-    return e;
-  };
-  auto se3_x1 = [&]() {  // Jexp6(delta) and Ad(exp6(delta))^-1 = [[dR^T, -dR^T [dp]x],[0, dR^T]]
-    double* Je6 = small + 36; double* Jq6 = small + 72;
-    const Se3Exp e = se3_exp();
-    double b1, b2, b3;
-    q_coeffs(e.td2, b1, b2, b3);
-    const M3 Qe = Qmat_c(v3(-e.dl.x, -e.dl.y, -e.dl.z), v3(-e.da_.x, -e.da_.y, -e.da_.z), b1, b2, b3);
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-      const double jr = ((i == j) ? 1.0 : 0.0) - e.B * e.Kd.m[3 * i + j] + e.C * e.Kd2.m[3 * i + j];
-      Je6[6 * i + j] = jr; Je6[6 * (i + 3) + j + 3] = jr; Je6[6 * i + j + 3] = Qe.m[3 * i + j]; Je6[6 * (i + 3) + j] = 0.0;
-    }
-    const M3 Sx = skew_m(e.dp);
-    const M3 RtS = tmul(e.dR, Sx);
-    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
-      Jq6[6 * r + cc] = e.dR.m[3 * cc + r]; Jq6[6 * (r + 3) + cc + 3] = e.dR.m[3 * cc + r];
-      Jq6[6 * r + cc + 3] = -RtS.m[3 * r + cc]; Jq6[6 * (r + 3) + cc] = 0.0;
-    }
-  };
-  auto se3_x2a = [&](double* park) {  // step, next state, gap = log6(G) ; park: gv (3), gw (3), c, a1, a2, a3
-    const Se3Exp e = se3_exp();
+    double* Jl6 = small; double* Je6 = small + 36; double* Jq6 = small + 72;
+    const V3 dl = v3(dt * (v[0] + dt * acc[0]), dt * (v[1] + dt * acc[1]), dt * (v[2] + dt * acc[2]));
+    const V3 da_ = v3(dt * (v[3] + dt * acc[3]), dt * (v[4] + dt * acc[4]), dt * (v[5] + dt * acc[5]));
+    const double td2 = dot(da_, da_);
+    double A, B, C;
+    so3_coeffs(td2, A, B, C);
+    const M3 Kd = skew_m(da_), Kd2 = mul(Kd, Kd);
+    M3 dR;
+    for (int i = 0; i < 9; ++i) dR.m[i] = ((i % 4 == 0) ? 1.0 : 0.0) + A * Kd.m[i] + B * Kd2.m[i];
+    const V3 wv_ = cross(da_, dl);
+    const V3 dp = dl + B * wv_ + C * cross(da_, wv_);
     const M3 Rb = quat_to_rot(q + 3);
-    const M3 Rn = mul(Rb, e.dR);
-    const V3 pn = mul(Rb, e.dp) + v3(q[0], q[1], q[2]);
+    const M3 Rn = mul(Rb, dR);
+    const V3 pn = mul(Rb, dp) + v3(q[0], q[1], q[2]);
     const M3 Rt = quat_to_rot(xn + 3);
     const M3 GR = tmul(Rt, Rn);
     const V3 Gp = tmul(Rt, pn - v3(xn[0], xn[1], xn[2]));
@@ -1082,12 +1052,6 @@ sim_u_set:
     if (!derivs) return;
     double a1, a2, a3;
     q_coeffs(t2, a1, a2, a3);
-    park[0] = gv.x; park[1] = gv.y; park[2] = gv.z; park[3] = gw.x; park[4] = gw.y; park[5] = gw.z; park[6] = c; park[7] = a1; park[8] = a2; park[9] = a3;
-  };
-  auto se3_x2b = [&](const double* park) {  // Jlog6(G) -> small[0, 36) ; E6 = -Jlog6(G^-1) -> record
-    double* Jl6 = small;
-    const V3 gv = v3(park[0], park[1], park[2]), gw = v3(park[3], park[4], park[5]);
-    const double c = park[6], a1 = park[7], a2 = park[8], a3 = park[9];
     const M3 K = skew_m(gw), K2 = mul(K, K);
     M3 Ji, Jn;
     for (int i = 0; i < 9; ++i) { const double e = ((i % 4 == 0) ? 1.0 : 0.0) + c * K2.m[i]; Ji.m[i] = e + 0.5 * K.m[i]; Jn.m[i] = e - 0.5 * K.m[i]; }
@@ -1095,9 +1059,22 @@ sim_u_set:
     double E[36];
     jlog6_blocks(Jn, Qmat_c(gv, gw, a1, a2, a3), -1.0, E);                                              // E6 = -Jlog6(G^-1)
     for (int e = 0; e < 36; ++e) kn[KL.oE6 + e] = E[e];
+    // Jexp6(delta)
+    double b1, b2, b3;
+    q_coeffs(td2, b1, b2, b3);
+    const M3 Qe = Qmat_c(v3(-dl.x, -dl.y, -dl.z), v3(-da_.x, -da_.y, -da_.z), b1, b2, b3);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+      const double jr = ((i == j) ? 1.0 : 0.0) - B * Kd.m[3 * i + j] + C * Kd2.m[3 * i + j];
+      Je6[6 * i + j] = jr; Je6[6 * (i + 3) + j + 3] = jr; Je6[6 * i + j + 3] = Qe.m[3 * i + j]; Je6[6 * (i + 3) + j] = 0.0;
+    }
+    // Ad(exp6(delta))^-1 = [[dR^T, -dR^T [dp]x],[0, dR^T]]
+    const M3 Sx = skew_m(dp);
+    const M3 RtS = tmul(dR, Sx);
+    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
+      Jq6[6 * r + cc] = dR.m[3 * cc + r]; Jq6[6 * (r + 3) + cc + 3] = dR.m[3 * cc + r];
+      Jq6[6 * r + cc + 3] = -RtS.m[3 * r + cc]; Jq6[6 * (r + 3) + cc] = 0.0;
+    }
   };
-  double* se3_park = red;  // (10 doubles ; `red` is not used before the merit)
-  auto step_se3_fused = [&]() { if (derivs) se3_x1(); se3_x2a(se3_park); if (derivs) se3_x2b(se3_park); };  // (one lane: its LDS operations execute in order)
   // ---- P9: body accelerations and subtree forces AT THE SOLUTION (only the derivative blocks read them):
   //   da_i = sum_{k on the path to i} J_k acc_k ;  Fc_i += Yc_i da_i + sum_{k strictly below i} U_k acc_k - (wrenches of the contacts below i)
   // (sum over the subtree of Y_j da_j, regrouped by dof: the composite inertias and U = Yc J are at hand, the body inertias are not)
@@ -1224,11 +1201,6 @@ sim_u_set:
         }
         }
       }
-#ifdef EV_SE3_SPLIT
-      // (the contact rows above occupy nk nv <= 128 threads: the last two wavefronts do the integrator's single-lane work that needs the step only)
-      if (wv == (nw > 2 ? nw - 2 : nw - 1) && lane == 0) se3_x1();
-      if (wv == nw - 1 && lane == 0) se3_x2a(se3_park);
-#endif
       __syncthreads();
       double* dbase = Yc;  // [6][nz]: base rows of d a (direct_ab)
       // ---- P11: R1 = d r1 / d(q, v, u) built in registers, one 16-column block per wavefront at a time, and the whole chain of
@@ -1331,11 +1303,7 @@ sim_u_set:
       const long long tp11b_ = clock64();
       if (TRIAL == 0 && a.prof && k == 1 && lane == 0) a.prof[(size_t)b * 64 + 32 + 16 + wv] += (double)(tp11b_ - tp11_);
 #endif
-#ifdef EV_SE3_SPLIT
-      if (wv == nw - 1 && lane == 0) se3_x2b(se3_park);  // (what is left of P12's single-lane work, on the wavefront with the fewest column blocks)
-#else
       if (wv == nw - 1 && lane == 0) step_se3_fused();  // (P12's single-lane work, on the wavefront with the fewest column blocks)
-#endif
 #ifdef EV_P11PROF
       if (TRIAL == 0 && a.prof && k == 1 && lane == 0 && wv == nw - 1) a.prof[(size_t)b * 64 + 32 + 3] += (double)(clock64() - tp11b_);
 #endif
