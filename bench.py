@@ -78,11 +78,17 @@ def aligator_reference(args):
     installable in the build container nor on the GPU box, so this function has never been executed there."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
     import gen_golden as gg
-    aligator, pin = gg.real_stack()
-    if aligator is None:
-        print(json.dumps({"aligator_reference": None, "reason": "the reference stack (aligator, pinocchio) is not importable here"}))
-        return 0
-    builders = gg.bind_real_modules(aligator, pin, gg.export_models(pin))
+    standins = bool(os.environ.get("MPC_ALIGATOR_STANDINS"))  # rehearsal of this function's own plumbing against the repo's mirror (tests): times THIS build, labelled so
+    if standins:
+        aligator, pin = gg.standin_stack()
+        from mpc_benchmark_amd.problems.fulldynamic import FullDynamicsProblem
+        builders = {"fulldynamic": FullDynamicsProblem}
+    else:
+        aligator, pin = gg.real_stack()
+        if aligator is None:
+            print(json.dumps({"aligator_reference": None, "reason": "the reference stack (aligator, pinocchio) is not importable here"}))
+            return 0
+        builders = gg.bind_real_modules(aligator, pin, gg.export_models(pin))
     pd = builders["fulldynamic"](horizon=args.horizon, complete_model=(args.model == "complete"))
     prob = pd.build(with_terminal_constraint=True)
     solver = pd.make_solver()
@@ -114,7 +120,8 @@ def aligator_reference(args):
     print(json.dumps({"aligator_reference": {"p50_ms_per_solve": ms[len(ms) // 2], "p90_ms_per_solve": ms[int(0.9 * (len(ms) - 1))],
                                              "solves_per_sec_one_instance": 1e3 * len(ms) / sum(ms), "threads": 8, "steps": args.steps,
                                              "cold_solve_ms": cold_ms, "cold_solve_iters": cold_iters, "cold_solve_converged": cold_conv,
-                                             "aligator_version": getattr(aligator, "__version__", "?"),
+                                             "aligator_version": getattr(aligator, "__version__", "?") if not standins else "STAND-INS: this repo's mirror on its own library (a rehearsal of the hook, NOT the reference)",
+                                             "standins": standins,
                                              "problem": "fulldynamic_talos.py OCP on talos_synth_v1/%s, N = %d" % (args.model, args.horizon)}}))
     return 0
 

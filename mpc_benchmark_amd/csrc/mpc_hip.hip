@@ -90,6 +90,7 @@ struct mpc_solver {
   bool contact_dyn = false;  // some stage uploaded so far has contact-constrained dynamics (sticky): the stage kernel's LDS carve-out holds the factor of M
   bool tick_reuse = false, reuse_this_pass = false, reuse_same_now = false;
   int pass_in_run = 0;  // index of the pass being enqueued within its run
+  bool pass_is_corrector = false;  // the pass being enqueued is the extra one mpc_run_shifted_async adds for the corrector rule (most workgroups sit it out)
   // speculative evaluation of the appended knot (eval_multibody.h): the spare records hold one made with the table of the then last
   // stage (spec_rec_valid) ; the stage appended since is that table (spec_next_pending, set by mpc_cycle) ; this pass may use it
   double* d_spec_knot = nullptr;
@@ -183,7 +184,8 @@ struct mpc_solver {
   template <class F> void timed(int slot, const char* name, F&& launch) {
     // (the launches of a corrector pass — mpc_options.corrector_prim_tol: most workgroups sit it out — are not timed: the per-kernel figures of the
     // profile describe launches that process every instance)
-    if (!profiling || !((prof_mask >> slot) & 1u) || (pass_in_run >= opt.max_iters && opt.max_iters <= 4 && opt.corrector_prim_tol > 0.0)) { launch(); return; }
+    // (only that pass: in the synchronous run the passes after max_iters are BCL updates / extra iterations that serve every instance)
+    if (!profiling || !((prof_mask >> slot) & 1u) || pass_is_corrector) { launch(); return; }
     if ((int)prof.size() <= slot) prof.resize(slot + 1);
     ProfSlot& p = prof[slot];
     p.name = name;
@@ -1523,7 +1525,8 @@ int mpc_run_shifted_async(mpc_solver* s) {
     // may be queued behind this one before its status is read; workgroups of instances that are done exit at once
     // (corrector_prim_tol: on the runs it applies to — corrector_window — one pass more, which instances that do not need it sit out)
     const int n_pass = (s->opt.max_iters < 1 ? 1 : (s->opt.max_iters > 4 ? 4 : s->opt.max_iters)) + (s->corrector_armed() ? 1 : 0);
-    for (int p = 0; p < n_pass; ++p) { s->pass_in_run = p; launch_pass(s); }
+    for (int p = 0; p < n_pass; ++p) { s->pass_in_run = p; s->pass_is_corrector = s->corrector_armed() && p == n_pass - 1; launch_pass(s); }
+    s->pass_is_corrector = false;
     s->async_passes[slot] = n_pass;
     HIP_OK(hipMemcpyAsync(s->h_status[slot], s->d_inst, L.B * sizeof(InstState), hipMemcpyDeviceToHost, s->stream));
     // xs[1] of every instance — the state the next tick will take as its measurement under perfect-model feedback, and what a

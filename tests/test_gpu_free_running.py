@@ -14,14 +14,14 @@ from tests._metrics import rel_cols
 pytestmark = pytest.mark.gpu
 
 
-def _handle(lib, refine, corrector, horizon=30, complete=False, sigma=(0.004, 0.01)):
+def _handle(lib, refine, corrector, horizon=30, complete=False, sigma=(0.004, 0.01), schedule=60):
     e = EnsembleMPC(FullDynamicsProblem(horizon=horizon, complete_model=complete), batch=2, library=lib, seed=3, sigma_q=sigma[0], sigma_v=sigma[1])
     e.options.num_threads = os.cpu_count() or 8
     e.options.riccati_legs = 1
     e.options.refine_appended_knot = refine
     e.options.corrector_prim_tol = corrector
     e.native.set_options(e.options)
-    e.prepare_schedule(60)
+    e.prepare_schedule(schedule)
     e.cold_solve(max_iters=100)
     return e
 
@@ -43,15 +43,16 @@ def test_free_running_walk_stays_with_the_oracle(hip_lib, oracle_lib, refine, co
 def test_free_running_walk_at_full_size(hip_lib, oracle_lib):
     """BASELINE.json's problem itself — complete model nq = 39, N = 100, instances perturbed as the benchmark's (sigma_q 0.02, sigma_v 0.05), the
     reference loop's exact iteration budget, serial sweep in both libraries — free-running through the first take-off entering the horizon: within 1e-6
-    per component on every tick (measured: <= 6e-8 over 125 ticks including the landing at tick 110 and its backtracking ticks,
-    profiles/r05_free_running.txt — the trajectory criterion of BASELINE.json held by the LOOP, not by one Newton step at a time)."""
-    er, eh = (_handle(lib, 0, 0.0, horizon=100, complete=True, sigma=(0.02, 0.05)) for lib in (oracle_lib, hip_lib))
+    per component on every one of 125 ticks, including the landing at tick 110 and its backtracking ticks (round 5 measured <= 6e-8 there,
+    profiles/r05_free_running.txt, and ran 36 of them as a test) — the trajectory criterion of BASELINE.json held by the LOOP, not by one Newton step at a time."""
+    TICKS = 125
+    er, eh = (_handle(lib, 0, 0.0, horizon=100, complete=True, sigma=(0.02, 0.05), schedule=TICKS + 10) for lib in (oracle_lib, hip_lib))
     worst = 0.0
-    for t in range(36):
+    for t in range(TICKS):
         sr, sh = er.step(), eh.step()
         assert [s.alpha for s in sh] == [s.alpha for s in sr], (t, [s.alpha for s in sh], [s.alpha for s in sr])
         a, b = eh.results(gains=True), er.results(gains=True)
         e = max(rel_cols(a["xs"], b["xs"], 1e-3), rel_cols(a["us"], b["us"], 1.0), rel_cols(a["K"][:, 0], b["K"][:, 0], 1.0))
         assert e < 1e-6, "tick %d of the free-running loops: HIP is %.3e away from the oracle" % (t, e)
         worst = max(worst, e)
-    print("free-running at full size: worst deviation over 36 ticks %.3e" % worst)
+    print("free-running at full size: worst deviation over %d ticks %.3e" % (TICKS, worst))

@@ -20,6 +20,10 @@ What it does
                          centroidal_talos.py:265-288)
   4. tests/test_golden_aligator.py consumes the files (auto-skips while they are absent).
 
+Rehearsal: ``generate(out_dir, ..., standin_lib=<library handle>)`` runs steps 2 - 4 against this repo's own mirror (tests/test_golden_aligator.py::
+test_rehearsal_*, into a temporary directory): every line of the dumps and of the six consumers has executed before someone with the stack runs them.  What
+it writes is NOT golden — the numbers are this build's own.
+
 usage:  python tools/gen_golden.py [--problems fulldynamic,kinodynamic,centroidal] [--horizon 20] [--out tests/golden]
 """
 import argparse
@@ -44,6 +48,15 @@ def real_stack():
         print("gen_golden: `aligator` resolves to this repo's mirror, not to the real package: nothing to do.")
         return None, None
     return aligator, pinocchio
+
+
+def standin_stack():
+    """``--standins`` / MPC_ALIGATOR_STANDINS=1: this repo's own mirror and its Pinocchio stand-in in the place of the real packages — a PLUMBING REHEARSAL
+    of steps 2 - 4 (builders, dumps, file layout, consumers), so that the first person with the real stack is not the first to execute this code.  The
+    numbers it writes come from this build itself: they are NOT golden vectors and prove no parity."""
+    from mpc_benchmark_amd import aligator as mirror
+    from mpc_benchmark_amd.robot import minipin
+    return mirror, minipin
 
 
 def export_models(pin):
@@ -124,7 +137,48 @@ def dump_stage(out, tag, stage, x, u):
             pass
 
 
-def dump_problem(out, aligator, name, builder, horizon):
+def dump_stage_standin(out, tag, stage, x, u, pd, aligator, lib):
+    """The rehearsal's stand-in for ``dump_stage``: the mirror's StageData is a placeholder (the native library owns the workspace), so the same arrays
+    come from a one-knot problem solved for one iteration by ``lib`` (the caller's library handle: tests pass the CPU checker) — read back through
+    ``mpc_debug_get`` exactly as tests/test_golden_aligator.py reads the quantities it compares them with."""
+    prob = aligator.TrajOptProblem(x, [stage], aligator.CostStack(stage.xspace, stage.nu))
+    solver = pd.make_solver(_native_library=lib)
+    solver.linear_solver_choice = aligator.LQ_SOLVER_SERIAL
+    solver.max_iters = 1
+    solver.corrector_prim_tol = 0.0
+    solver.setup(prob)
+    solver.run(prob, [x, x], [u])
+    nat = solver._native
+    try:
+        xnext = nat.debug_get("xnext", 0).ravel()
+    except RuntimeError:
+        xnext = None
+    if xnext is not None and xnext.size == np.asarray(x).size:
+        solver.run(prob, [x, xnext], [u])  # zero dynamics gap, as dump_stage
+    else:
+        xnext = None
+    n, nu = stage.xspace.ndx, stage.nu
+    out[tag + "_x"], out[tag + "_u"] = np.array(x), np.array(u)
+    out[tag + "_cost"] = np.array([nat.debug_get("cost", 0)[0]])
+    grad = nat.debug_get("grad", 0).ravel()
+    H = nat.debug_get("H", 0).reshape(n + nu, n + nu)
+    out[tag + "_Lx"], out[tag + "_Lu"] = grad[:n], grad[n:]
+    out[tag + "_Lxx"], out[tag + "_Lxu"], out[tag + "_Luu"] = H[:n, :n], H[:n, n:], H[n:, n:]
+    if xnext is not None:
+        AB = nat.debug_get("AB", 0).reshape(n, n + nu)
+        out[tag + "_xnext"], out[tag + "_dyn_Jx"], out[tag + "_dyn_Ju"] = xnext, AB[:, :n], AB[:, n:]
+    dims = [int(f.nr) for f in stage.constraints.funcs]
+    if dims:
+        cval = nat.debug_get("cval", 0).ravel()
+        CD = nat.debug_get("CD", 0).reshape(sum(dims), n + nu)
+        r0 = 0
+        for i, d in enumerate(dims):
+            out["%s_c%d_value" % (tag, i)] = cval[r0:r0 + d]
+            out["%s_c%d_Jx" % (tag, i)], out["%s_c%d_Ju" % (tag, i)] = CD[r0:r0 + d, :n], CD[r0:r0 + d, n:]
+            r0 += d
+
+
+def dump_problem(out, aligator, name, builder, horizon, standin_lib=None):
     pd = builder(horizon=horizon)
     rb = getattr(pd, "robot", None)
     if rb is not None:
@@ -151,13 +205,16 @@ def dump_problem(out, aligator, name, builder, horizon):
             space = st.xspace
             x = space.integrate(np.array(pd.x0), 0.03 * rng.standard_normal(space.ndx))
             u = (getattr(pd, "u_init", np.zeros(st.nu)) + rng.standard_normal(st.nu) * (15.0 if name == "fulldynamic" else 1.0))
-            dump_stage(out, "eval_" + kname, st, x, u)
+            if standin_lib is not None:
+                dump_stage_standin(out, "eval_" + kname, st, x, u, pd, aligator, standin_lib)
+            else:
+                dump_stage(out, "eval_" + kname, st, x, u)
         except Exception as e:  # noqa: BLE001
             print("gen_golden[%s]: stage kind %s skipped: %s" % (name, kname, e))
     # the scripts' solves: one iteration, then to convergence
     for tag, iters in (("iter1", 1), ("conv", 100)):
         prob = pd.build(with_terminal_constraint=True) if name == "fulldynamic" else pd.build()
-        solver = pd.make_solver()
+        solver = pd.make_solver() if standin_lib is None else pd.make_solver(_native_library=standin_lib)
         solver.max_iters = iters
         solver.setup(prob)
         xs, us = pd.initial_guess()
@@ -167,7 +224,32 @@ def dump_problem(out, aligator, name, builder, horizon):
         out[tag + "_K0"] = np.array(r.controlFeedbacks()[0])
         out[tag + "_stats"] = np.array([r.num_iters, float(r.conv), r.traj_cost, r.prim_infeas, r.dual_infeas])
     out["horizon"] = np.array([horizon])
-    out["versions"] = np.array([getattr(aligator, "__version__", "?")])
+    out["versions"] = np.array([getattr(aligator, "__version__", "?") if standin_lib is None else "STAND-INS (rehearsal: not golden vectors)"])
+
+
+def generate(out_dir, problems, horizon, complete=False, standin_lib=None):
+    """Steps 1 - 3 for the named problems into ``out_dir`` -> the files written.  ``standin_lib``: the rehearsal (see standin_stack): steps 2 - 3 against the mirror
+    with the caller's library handle ; step 1 (the export through the real pinocchio) has no stand-in — the builders load the committed joint table themselves."""
+    if standin_lib is None:
+        aligator, pin = real_stack()
+        if aligator is None:
+            return []
+        builders = bind_real_modules(aligator, pin, export_models(pin))
+    else:
+        aligator, _ = standin_stack()
+        from mpc_benchmark_amd.problems import centroidal, fulldynamic, kinodynamic
+        builders = {"fulldynamic": fulldynamic.FullDynamicsProblem, "kinodynamic": kinodynamic.KinodynamicProblem, "centroidal": centroidal.CentroidalProblem}
+    os.makedirs(out_dir, exist_ok=True)
+    written = []
+    for name in problems:
+        out = {}
+        b = builders[name]
+        dump_problem(out, aligator, name, (lambda horizon, b=b: b(horizon=horizon, complete_model=complete)) if name != "centroidal" else b, horizon, standin_lib=standin_lib)
+        path = os.path.join(out_dir, "aligator_%s%s.npz" % (name, "_complete" if complete else ""))
+        np.savez_compressed(path, **out)
+        print("gen_golden: wrote %s (%d arrays)%s" % (path, len(out), "" if standin_lib is None else "  [STAND-INS: a rehearsal of the plumbing, NOT golden vectors]"))
+        written.append(path)
+    return written
 
 
 def main():
@@ -177,19 +259,7 @@ def main():
     ap.add_argument("--complete", action="store_true", help="complete model (nq = 39) instead of the scripts' reduced one")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     args = ap.parse_args()
-    aligator, pin = real_stack()
-    if aligator is None:
-        return 0
-    models = export_models(pin)
-    builders = bind_real_modules(aligator, pin, models)
-    os.makedirs(args.out, exist_ok=True)
-    for name in args.problems.split(","):
-        out = {}
-        b = builders[name]
-        dump_problem(out, aligator, name, (lambda horizon, b=b: b(horizon=horizon, complete_model=args.complete)) if name != "centroidal" else b, args.horizon)
-        path = os.path.join(args.out, "aligator_%s%s.npz" % (name, "_complete" if args.complete else ""))
-        np.savez_compressed(path, **out)
-        print("gen_golden: wrote %s (%d arrays)" % (path, len(out)))
+    generate(args.out, args.problems.split(","), args.horizon, complete=args.complete)
     return 0
 
 
