@@ -42,10 +42,12 @@ def _solve(lib, name, horizon, iters):
     return solver.results
 
 
-def _check_solves(lib, name):
+def _check_solves(lib, name, tags=("iter1", "conv")):
     g = _load(name)
     horizon = int(g["horizon"][0])
     for tag, iters in (("iter1", 1), ("conv", 100)):
+        if tag not in tags:
+            continue
         r = _solve(lib, name, horizon, iters)
         assert int(g[tag + "_stats"][0]) == r.num_iters, "%s %s: Aligator took %d iterations, this build %d" % (name, tag, int(g[tag + "_stats"][0]), r.num_iters)
         for key, val, floor in (("xs", np.array(r.xs), 1e-3), ("us", np.array(r.us), 1e-2)):
@@ -190,7 +192,9 @@ def test_rehearsal_hip_consumers_run(rehearsal_dir, hip_lib, name, monkeypatch):
     read from a file)."""
     monkeypatch.setenv("MPC_GOLDEN_DIR", rehearsal_dir)
     _check_stage_kinds(hip_lib, name)
-    _check_solves(hip_lib, name)
+    # (the one-iteration solve only: the iteration at which a cold solve to 1e-5 stops is decided at round-off level — 90 against 95 iterations between the two
+    # libraries on the kinodynamic problem — which is why the parity tests proper run fixed iteration counts, DESIGN.md section 6)
+    _check_solves(hip_lib, name, tags=("iter1",))
 
 
 @pytest.mark.gpu

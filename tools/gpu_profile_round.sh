@@ -3,7 +3,7 @@
 # separate PMC passes (no trace domains together with --pmc).  Outputs under gpurun_out/$1/; a step that fails stops the
 # script BEFORE anything is copied over the committed profiles/ files.
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -42,6 +42,10 @@ python3 tools/qp_bench.py > $OUT/qp_bench.txt 2>&1
 python3 tools/batch1_kernel_times.py 32 > $OUT/batch1_kernel_times.txt 2>&1
 python3 tools/occupancy_report.py > $OUT/occupancy_kinodynamic.txt 2>&1
 python3 tools/occupancy_report.py --problem full --batches 16,64,256 > $OUT/occupancy_fulldynamic.txt 2>&1
+tools/pmc/sq_counters.sh $OUT/sq > $OUT/sq_counters.txt 2>&1
+PHASE_BATCH=64 python3 tools/phase_timers.py > $OUT/phase_timers_batch64.txt 2>&1
+python3 tools/legs_phase_timers.py 4 64 > $OUT/legs_phase_timers_batch64.txt 2>&1
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_driver_args.log 2> $OUT/bench_driver_args.err
 # the raw per-dispatch CSVs are large: keep only the summaries
 find $OUT -name '*counter_collection.csv' -size +2M -delete
 find $OUT -name '*kernel_trace.csv' -size +8M -delete
