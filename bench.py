@@ -153,14 +153,27 @@ def launch_ranks(args, argv):
     th = [threading.Thread(target=drain, args=(r,), daemon=True) for r in range(n)]
     for t in th:
         t.start()
-    rcs = []
+    rcs = [None] * n
     try:
-        for r, pr in enumerate(procs):
-            rcs.append(pr.wait())
-            if rcs[-1] != 0:  # a rank that failed leaves the others waiting at a barrier: end them (the exact processes started above)
+        while any(rc is None for rc in rcs):
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = pr.poll()
+            if any(rc not in (None, 0) for rc in rcs):
+                # a rank that failed (no such GPU, a library that does not load ...) leaves the others waiting at the rendezvous or at a barrier — for
+                # minutes: end them at once (the exact processes started above)
                 for q in procs:
                     if q.poll() is None:
                         q.terminate()
+                for r, pr in enumerate(procs):
+                    if rcs[r] is None:
+                        try:
+                            rcs[r] = pr.wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            pr.kill()
+                            rcs[r] = pr.wait()
+                break
+            time.sleep(0.05)
     finally:
         for q in procs:
             if q.poll() is None:
@@ -280,11 +293,19 @@ def main():
     if args.gpus != world and rank == 0:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE = %d: the line reports n_gpus = %d (the ranks that actually ran)\n" % (args.gpus, world, world))
     selftest = bool(args.selftest_cpu)
+    if selftest and os.environ.get("MPC_BENCH_TEST_FAIL_RANK") == str(rank):  # (tests: a rank that dies before the rendezvous, like one whose GPU does not exist)
+        sys.exit(3)
     dist = None
     tdev = None  # where the few tensors of the rendezvous live (the GPU of this rank ; the host in the self-test)
     if world > 1 or os.environ.get("MPC_BENCH_FORCE_DIST"):  # (MPC_BENCH_FORCE_DIST=1: exercise the RCCL path with a single rank, developer check)
         import torch
         import torch.distributed as dist
+        if world == 1 and "RANK" not in os.environ:  # (MPC_BENCH_FORCE_DIST without a launcher: a one-rank rendezvous on the loopback interface)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port_ = sk.getsockname()[1]
+            os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port_))
         if selftest:
             tdev = torch.device("cpu")
             dist.init_process_group("gloo")
@@ -697,12 +718,22 @@ def main():
             with open(tf_) as fh:
                 kk_ = json.load(fh).get("kernels", {})
             traffic_tick = 0.0
-            for sname, (cnt, _ms, _slot) in warm.items():
+            # (the counter figures are those of FULL launches — every knot of every instance: the launches that serve only the dirty knots of a tick or the
+            # instances that backtrack, `partial` below, enter with their share of a full launch's time instead of a full launch's bytes)
+            partial = {"k_eval_stage": "k_eval_stage_trial", "k_eval_stage_backtrack": "k_eval_stage_trial_values"}
+            for sname, (cnt, ms_, _slot) in warm.items():
                 pat = slot_kernel.get(sname)
                 ent = next((v for k_, v in kk_.items() if pat and pat in k_ and "hbm_bytes" in v), None)
-                if ent is not None:
+                if ent is None:
+                    continue
+                if sname in partial:
+                    full = warm.get(partial[sname]) or warm.get("k_eval_stage_trial")
+                    if not full or full[1] <= 0:
+                        continue
+                    traffic_tick += ent["hbm_bytes"] * min(1.0, (ms_ / max(cnt, 1)) / (full[1] / max(full[0], 1))) * cnt / args.warmup
+                else:
                     traffic_tick += ent["hbm_bytes"] * cnt / args.warmup
-                    counted.append(sname)
+                counted.append(sname)
         roof_tick = {"bound": "hbm", "achieved": round(ach_t, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_t / HBM_PEAK_GBS, 5),
                      "algorithmic_bytes_per_step": int(tick_bytes), "rule": "SURVEY.md 8d: 8 [sum_{k<N} (2 W_k + G_k) + 2 W_N + IO] per instance and iteration x instances per step",
                      "traffic_per_step": (int(traffic_tick) if traffic_tick else None),

@@ -286,7 +286,10 @@ int mpc_get_stage_data(mpc_solver* s, int32_t k, double* xdot, double* wrenches)
  * array of doubles (integers stored exactly), portable between the libraries that export this ABI with the same dimensions
  * (a state saved by the HIP library restores into the oracle and vice versa).  mpc_state_size: doubles needed.  mpc_get_state: fills
  * buf (cap doubles), returns the count written or -1.  mpc_set_state: restores (dimensions must match mpc_create's); kept records
- * of tick reuse and the cut-Hessian guesses of the legs are invalidated, so the next tick evaluates everything afresh. */
+ * of tick reuse and the cut-Hessian guesses of the legs are invalidated, so the next tick evaluates everything afresh.  Per-instance parameter
+ * tables (mpc_enable_instance_params) are NOT part of the state: every instance is handed the shared tables of the restored stages again, and with the
+ * reference generator in the library (mpc_walk_init) the next mpc_walk_update rewrites the references of every knot from its plan (mpc_walk_get_state /
+ * mpc_walk_set_state carry the plan itself).  Both libraries behave the same (tests/test_checkpoint.py). */
 int64_t mpc_state_size(mpc_solver* s);
 int64_t mpc_get_state(mpc_solver* s, double* buf, int64_t cap);
 int mpc_set_state(mpc_solver* s, const double* buf, int64_t len);
@@ -297,7 +300,8 @@ int mpc_set_state(mpc_solver* s, const double* buf, int64_t len);
  * mpc_update_stage_params(_batch) keep acting on every instance (a slot that receives a stage table is reset to it in every copy);
  * mpc_update_instance_params_batch patches the copies of single instances: patch i writes lens[i] doubles at offsets[i] of stage
  * ks[i] of instance insts[i]; values concatenated in `vals`.  Tick reuse invalidates a patched knot for the whole ensemble.
- * (mpc_get_state stores the shared tables only.) */
+ * (mpc_get_state stores the shared tables only.)  May be mixed with mpc_walk_update on the same offsets: a patch that follows device-generated ticks always
+ * reaches the device (the HIP library compares patches with a host mirror and skips unchanged ones; the generator marks what it wrote as unknown there). */
 int mpc_enable_instance_params(mpc_solver* s);
 int mpc_update_instance_params_batch(mpc_solver* s, int32_t count, const int32_t* insts, const int32_t* ks, const int32_t* offsets, const int32_t* lens, const double* vals);
 

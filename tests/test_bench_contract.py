@@ -91,3 +91,13 @@ def test_gpus_n_launches_n_ranks(cpu_lib):
 def test_launcher_fails_when_a_rank_fails(cpu_lib):
     out, rows = _run(["--selftest-cpu", "--lib", "/nonexistent/libmpc.so", "--gpus", "2", "--no-latency", "--no-whole-schedule", "--no-cpu-baseline"] + SMALL)
     assert out.returncode != 0 and not rows
+
+
+def test_launcher_does_not_wait_for_a_rendezvous_that_cannot_happen(cpu_lib):
+    """One rank dies before it joins (on the GPU box: `--gpus 2` where there is one GPU): the other would wait ten minutes for it at the rendezvous.  The launcher
+    ends it at once and fails."""
+    import time
+    t0 = time.time()
+    out = subprocess.run([sys.executable, BENCH, "--selftest-cpu", "--lib", cpu_lib, "--gpus", "2", "--no-latency", "--no-whole-schedule", "--no-cpu-baseline"] + SMALL,
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict({k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE")}, MPC_BENCH_TEST_FAIL_RANK="1"))
+    assert out.returncode != 0 and time.time() - t0 < 120 and "ranks failed" in out.stderr
