@@ -20,7 +20,8 @@
 // the difference:
 //  * the nz right-hand sides of the implicit differentiation never exist in LDS: every wavefront builds its 16-column block of
 //    R = [d r1 ; d r2] in REGISTERS in MFMA fragment layout and runs the whole chain of blocked triangular solves there
-//    (mma_tile_rb), the result d a goes to the per-workgroup HBM scratch `dsol` (L2-resident), d lambda (12 rows) to LDS;
+//    (mma_tile_rb); the rows of [A B] that d a determines leave for the record straight from the result registers (round 6; the kinodynamic stages,
+//    whose d a is a closed form, still pass it through the per-workgroup HBM scratch `dsol`), d lambda (12 rows) goes to LDS;
 //  * M = L L^T is kept tile-packed (lower block triangle, inverses of the diagonal blocks in place), no separate contact Jacobian,
 //    composite inertias packed symmetric (21 of 36);
 //  * the derivative blocks that depend on (q, v) only (B_i, their subtree sums, Bt, Tv, Bc Psd, Yc Psd) are formed BEFORE the
