@@ -1059,6 +1059,19 @@ sim_u_set:
     double E[36];
     jlog6_blocks(Jn, Qmat_c(gv, gw, a1, a2, a3), -1.0, E);                                              // E6 = -Jlog6(G^-1)
     for (int e = 0; e < 36; ++e) kn[KL.oE6 + e] = E[e];
+    {
+      // T6 = (-E6)^-1, the base-frame change the Riccati sweep applies to the co-state: -E6 = Jlog6(G^-1) and Jlog6(M)^-1 = Jexp6(log6(M)), so T6 = Jexp6(-gv, -gw) in closed
+      // form — its Q block is the one E6 just used.  (The sweep inverted -E6 numerically on ONE lane per knot, 511 threads waiting at a barrier.)
+      double A6, B6, C6;
+      so3_coeffs(t2, A6, B6, C6);
+      const M3 Q6 = Qmat_c(gv, gw, a1, a2, a3);
+      double T6o[36];
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        const double jr = ((i == j) ? 1.0 : 0.0) + B6 * K.m[3 * i + j] + C6 * K2.m[3 * i + j];
+        T6o[6 * i + j] = jr; T6o[6 * (i + 3) + j + 3] = jr; T6o[6 * i + j + 3] = Q6.m[3 * i + j]; T6o[6 * (i + 3) + j] = 0.0;
+      }
+      for (int e = 0; e < 36; ++e) kn[KL.oT6k + e] = T6o[e];
+    }
     // Jexp6(delta)
     double b1, b2, b3;
     q_coeffs(td2, b1, b2, b3);

@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(64) k_eval_vector(SolverArgs a, Layout KL, dou
         kn[KL.oF + i] = xp - xn[i];
         if (derivs) { kn[KL.oXD + i] = xd[i]; kn[KL.oXN + i] = xp; }
       }
-      if (derivs) for (int i = 0; i < 36; ++i) kn[KL.oE6 + i] = (i % 7 == 0) ? -1.0 : 0.0;
+      if (derivs) for (int i = 0; i < 36; ++i) { kn[KL.oE6 + i] = (i % 7 == 0) ? -1.0 : 0.0; kn[KL.oT6k + i] = (i % 7 == 0) ? 1.0 : 0.0; }
     }
     __syncthreads();
   }

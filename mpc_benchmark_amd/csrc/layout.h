@@ -10,7 +10,7 @@ struct Layout {
   int nj;  // moving joints of the multibody model (0 for vector spaces)
   int model_mask_off;  // int32 offset of the 64-bit tree masks (ancestors | subtree | path dofs | dofs strictly below, nj each) in the device model table
   // offsets inside one knot record (doubles)
-  int oH, oG, oAB, oF, oE6, oD12, oCV, oCD, oLO, oHI, oDT, oACT, oCT, oMISC, oXD, oWR, oXN, knot_stride;
+  int oH, oG, oAB, oF, oE6, oT6k, oD12, oCV, oCD, oLO, oHI, oDT, oACT, oCT, oMISC, oXD, oWR, oXN, knot_stride;  // (oT6k: T6 = (-E6)^-1, written beside E6 by the whole-body stage kernel)
   // offsets inside one gain record
   int oP, op, oK, ok, oKnu, oknu, oMx, omx, oT6, oPhi, ophi, gain_stride;
   // parallel-in-time legs (legs.h), knots of a parametric leg: (u,u) and (nu,u) blocks of the inverse stage KKT matrix (Riccati sweep),
@@ -48,7 +48,7 @@ static inline void make_layout(Layout& L) {
   const int n = L.n, m = L.m, c = L.c, nz = L.nz = n + m;
   int o = 0;
   auto take = [&](int cnt) { int r = o; o += align2(cnt); return r; };
-  L.oH = take(nz * nz); L.oG = take(nz); L.oAB = take(n * nz); L.oF = take(n); L.oE6 = take(36);
+  L.oH = take(nz * nz); L.oG = take(nz); L.oAB = take(n * nz); L.oF = take(n); L.oE6 = take(36); L.oT6k = take(36);
   // structure of the semi-implicit Euler rows: [A B]_q = D1 [I 0 0] + Dd [A B]_v with D1, Dd = identity, dt on the joints and 6x6 on the
   // base: D1_b (36) | Dd_b (36) | dt | valid flag — the Riccati sweep then multiplies with the v rows of [A B] only
   L.oD12 = take(74);

@@ -314,7 +314,7 @@ static void create_impl(mpc_solver* s, const mpc_dims& d) {
     auto take = [&](int cnt) { int r = o; o += align2(cnt); return r; };
     T.oCV = take(L.c); T.oCT = take(L.c); T.oLO = take(L.c); T.oHI = take(L.c); T.oDT = take(L.c); T.oACT = take(L.c);
     T.oF = take(L.n); T.oMISC = take(MISC_COUNT);
-    T.oH = T.oG = T.oAB = T.oE6 = T.oD12 = T.oCD = T.oXD = T.oWR = T.oXN = 0;  // never written in value-only mode
+    T.oH = T.oG = T.oAB = T.oE6 = T.oT6k = T.oD12 = T.oCD = T.oXD = T.oWR = T.oXN = 0;  // never written in value-only mode
     T.knot_stride = o;
   }
   if (s->riccati_lds() > 160 * 1024) throw std::runtime_error("problem dimensions exceed the LDS budget of the Riccati kernel");

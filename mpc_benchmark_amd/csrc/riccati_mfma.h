@@ -198,7 +198,11 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
     const int row = wv * 64 + lane;
     pre_m = kp[L.oMISC + MISC_M]; pre_c = kp[L.oMISC + MISC_NC];
     pre_act = kp[L.oACT + (row < L.c ? row : 0)];
+#ifdef RIC_T6_INVERT
     pre_e6 = kp[L.oE6 + (tid < 36 ? tid : 0)];
+#else
+    pre_e6 = kp[L.oT6k + (tid < 36 ? tid : 0)];  // T6 = (-E6)^-1 itself, left beside E6 by the stage kernel in closed form (round 6)
+#endif
     pre_f = kp[L.oF + (tid < n ? tid : 0)];
     pre_le = a.lams_e[((size_t)b * (N + 1) + kk + 1) * n + (tid < n ? tid : 0)];
     pre_g = kp[L.oG + (tid < nz ? tid : 0)];
@@ -216,7 +220,11 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
     const bool is_act = (arow < c) && (pre_act != 0.0);
     const unsigned long long amask = __ballot(is_act);
     if (lane == 0) iflag[2 + wv] = __popcll(amask);
+#ifdef RIC_T6_INVERT
     if (tid < 36) e6l[tid] = -pre_e6;
+#else
+    if (tid < 36) t6l[tid] = ff ? pre_e6 : ((tid % 7 == 0) ? 1.0 : 0.0);
+#endif
     if (tid < n) ft[tid] = pre_f + mud * pre_le;
     if (tid < nz) gpre[tid] = pre_g;
     __syncthreads();
@@ -229,8 +237,10 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
         int ca_ = 0;
         for (int q = 0; q < nw; ++q) ca_ += iflag[2 + q];
         iflag[1] = ca_;
+#ifdef RIC_T6_INVERT
         if (ff) inv6_unrolled(e6l, t6l);
         else for (int i2 = 0; i2 < 36; ++i2) t6l[i2] = (i2 % 7 == 0) ? 1.0 : 0.0;
+#endif
       }
     }
     __syncthreads();
@@ -261,6 +271,31 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
     const double* T6 = t6l;  // LDS copy; the gain record gets it below
     if (tid < 36) g[L.oT6 + tid] = t6l[tid];
     if (SQ && tid < 74) d12l[tid] = dreg;
+#ifndef RIC_T6_FOUR_BARRIERS
+    if (ff) {
+      // Ph = T^T P' T with T = diag(T6, I): only the first six rows / columns change, and P' is symmetric (step 7 symmetrises it exactly).  B = P'[:, 0:6] T6 (n x 6)
+      // from the old PT ; then columns 0..5 <- B on the rows >= 6 and, mirrored, rows 0..5 <- B^T ; the 6 x 6 corner <- T6^T B[0:6].  Two barriers (round 3 - 5: the
+      // column pass and the row pass one after the other through a scratch, four barriers).
+      double* tmp = LP;  // scratch (LP is dead here)
+      for (int idx = tid; idx < n * 6; idx += nthr) {
+        const int i = idx / 6, j = idx % 6;
+        double s = 0;
+        for (int l = 0; l < 6; ++l) s += PT[i * ldp + l] * T6[l * 6 + j];
+        tmp[idx] = s;
+      }
+      if (tid >= nthr - 6) { const int i = tid - (nthr - 6); double s = 0; for (int l = 0; l < 6; ++l) s += T6[l * 6 + i] * pvec[l]; ph[i] = s; }
+      for (int i = 6 + tid; i < n; i += nthr) ph[i] = pvec[i];
+      __syncthreads();
+      for (int idx = tid; idx < n * 6; idx += nthr) {
+        const int i = idx / 6, j = idx % 6;
+        if (i >= 6) { const double v = tmp[idx]; PT[i * ldp + j] = v; PT[j * ldp + i] = v; }
+        else { double s = 0; for (int l = 0; l < 6; ++l) s += T6[l * 6 + i] * tmp[l * 6 + j]; PT[i * ldp + j] = s; }
+      }
+    } else {
+      for (int i = tid; i < n; i += nthr) ph[i] = pvec[i];
+    }
+    __syncthreads();
+#else
     if (ff) {
       double* tmp = LP;  // scratch (LP is dead here)
       for (int idx = tid; idx < n * 6; idx += nthr) {
@@ -286,6 +321,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
       for (int i = tid; i < n; i += nthr) ph[i] = pvec[i];
     }
     __syncthreads();
+#endif
     // Structured knot: [A B]_q = D1 [I 0 0] + Dd [A B]_v (semi-implicit Euler), so Pt [A B] and [A B]^T G need the v rows of [A B]
     // only: K = nv instead of n in both products of step 5 (ks .. ks + Ke: the v rows, aligned down to the MFMA depth of 4)
     constexpr bool sq = SQ;  // every stage knot of a whole-body problem has dynamics rows (valid flag d12l[73] = 1)
