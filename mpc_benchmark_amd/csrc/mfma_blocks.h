@@ -215,7 +215,10 @@ template <> struct FusedStep<16> { static DEV void run(double (&)[16], double (&
 // 4 x (LDS round trip + pivot block + 2 MFMAs) instead of 16 pivots + 256 broadcast-fmacs.  `scratch`: 128 doubles of LDS that nobody
 // else touches during the call (the callers pass the output block LIb itself: the rows of the inverse are stored at the end).
 DEV double rsqrt_refined(double d) { double i = rsqrt(d); return i * (1.5 - 0.5 * d * i * i); }
-DEV bool chol16_wave_mfma(double* D, int ld, double* LIb, int lane) {
+// ncols (wavefront-uniform): rows / columns from ncols on are identity padding — their panels factorise to themselves and are skipped (the Schur block of a knot
+// with three active rows works on one panel instead of four)
+DEV bool chol16_wave_mfma(double* D, int ld, double* LIb, int lane, int ncols = 16) {
+  const int npan = (ncols + 3) >> 2;
   const int g = lane >> 4, c = lane & 15;
   d4_t t, w;
 #pragma unroll
@@ -234,6 +237,7 @@ DEV bool chol16_wave_mfma(double* D, int ld, double* LIb, int lane) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int c0 = 4 * p;
+    if (p >= npan) { xp[p] = w[p]; continue; }   // identity pivot block: X rows = the rows of W (lane (j = c, k = g) holds W[4 p + g][c] in w[p])
     if ((c >> 2) == p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) P[(g + 4 * q) * 4 + (c & 3)] = t[q];
@@ -287,8 +291,8 @@ DEV bool chol16_wave_mfma(double* D, int ld, double* LIb, int lane) {
     xp[p] = ((mk0 * w0 + mk1 * w1) + mk2 * w2) + mk3 * w3;       // X[c0 + k][j], j = c, k = g
     if (store_l && xr >= g) D[c * ld + c0 + g] = lp;
     const double nlp = -lp;
-    if (p < 3) t = __builtin_amdgcn_mfma_f64_16x16x4f64(nlp, lp, t, 0, 0, 0);       // A -= Lp Lp^T
-    if (p < 3) w = __builtin_amdgcn_mfma_f64_16x16x4f64(nlp, xp[p], w, 0, 0, 0);    // W -= Lp Xp
+    if (p + 1 < npan) t = __builtin_amdgcn_mfma_f64_16x16x4f64(nlp, lp, t, 0, 0, 0);       // A -= Lp Lp^T
+    if (p + 1 < npan) w = __builtin_amdgcn_mfma_f64_16x16x4f64(nlp, xp[p], w, 0, 0, 0);    // W -= Lp Xp
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
@@ -300,9 +304,9 @@ DEV bool chol16_wave_mfma(double* D, int ld, double* LIb, int lane) {
 // One wavefront: Cholesky of the 16x16 block D (lower triangle, leading dimension ld) entirely in registers —
 // lane r (< 16) holds row r — then its inverse.  Writes L back over D (lower part) and L^-1 to LIb (ld 17); LIb == D (ld 17): the
 // inverse REPLACES the block (the blocked routines never read a diagonal block of L again, only its inverse).
-DEV bool chol16_wave(double* D, int ld, double* LIb, int lane) {
+DEV bool chol16_wave(double* D, int ld, double* LIb, int lane, int ncols = 16) {
 #ifdef CHOL16_MFMA
-  return chol16_wave_mfma(D, ld, LIb, lane);
+  return chol16_wave_mfma(D, ld, LIb, lane, ncols);
 #endif
   double d[16], x[16], invd[16];
   const int r = lane & 15;
@@ -347,10 +351,12 @@ DEV bool chol16_wave(double* D, int ld, double* LIb, int lane) {
 // Blocked Cholesky of the (16 nb) x (16 nb) matrix A in LDS (lower triangle; pad rows/cols must be identity).
 // L overwrites the lower block triangle, LI[bi] (272 doubles each, ld 17) receives the inverse of diagonal block bi.
 // the whole blocked factorisation by ONE wavefront (nb <= 3): its LDS operations execute in order, no workgroup barrier
-DEV bool chol_blocked_wave(double* A, int ld, int nb, double* LI, int lane) {
+// n_real: rows / columns from n_real on are identity padding (only the last diagonal block can hold some: chol16_wave skips its padding panels)
+DEV bool chol_blocked_wave(double* A, int ld, int nb, double* LI, int lane, int n_real = 1 << 20) {
   bool ok = true;
   for (int kb = 0; kb < nb && ok; ++kb) {
-    ok = chol16_wave(A + (kb * 16) * ld + kb * 16, ld, LI + kb * 272, lane);
+    const int nc_ = n_real - 16 * kb;
+    ok = chol16_wave(A + (kb * 16) * ld + kb * 16, ld, LI + kb * 272, lane, nc_ < 16 ? (nc_ > 0 ? nc_ : 0) : 16);
     for (int ri = kb + 1; ri < nb; ++ri) {
       d4_t acc = d4_t{0, 0, 0, 0};
       mma_tile<false>(acc, A + (ri * 16) * ld + kb * 16, ld, 1, LI + kb * 272, 1, 17, 16, lane);

@@ -14,6 +14,13 @@
 #include <utility>
 #include <vector>
 
+// The 16 x 16 Cholesky + inverse of this translation unit (the Riccati sweep's Ruu and Schur blocks, the leg kernels) on the matrix cores (mfma_blocks.h
+// chol16_wave_mfma, built and measured in round 5, when its 1.2 x on the block did not show in the tick): since round 6 the factorisation of Ruu by wavefront 0 is no
+// longer hidden behind the x tiles of the other seven, and it does: sweep 1.527 -> 1.507 ms per launch, parity tests unchanged.  (The stage kernel's translation unit
+// keeps the register form: its chain is not bound by the block.)
+#ifndef CHOL16_REGISTER_FORM
+#define CHOL16_MFMA
+#endif
 #include "eval_multibody_host.h"
 #include "eval_reuse_kernels.h"
 #include "eval_vector.h"

@@ -752,7 +752,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
         }
         __syncthreads();
         RIC_SUB(28);
-        if (wv == 0) { const bool ok = chol_blocked_wave(Lr, ldr, nbm, LIr, lane); if (lane == 0) iflag[0] = ok ? 1 : 0; }
+        if (wv == 0) { const bool ok = chol_blocked_wave(Lr, ldr, nbm, LIr, lane, m); if (lane == 0) iflag[0] = ok ? 1 : 0; }  // (rows >= m of Lr: identity)
         else {
 #pragma unroll
           for (int sidx = 0; sidx < RIC_U_TILES; ++sidx) {
@@ -977,7 +977,7 @@ __global__ void __launch_bounds__(RT) k_riccati_mfma(SolverArgs a, RicLds Srt) {
         __syncthreads();
         if (tid == 0) iflag[0] = 1;
         __syncthreads();
-        if (wv == 0) { if (!chol16_wave(SCl, 17, LIs, lane) && lane == 0) iflag[0] = 0; }
+        if (wv == 0) { if (!chol16_wave(SCl, 17, LIs, lane, ca) && lane == 0) iflag[0] = 0; }  // (rows / columns >= ca of Sc are identity)
         __syncthreads();
         if (iflag[0] == 0) { if (tid == 0) a.inst[b].done = 4; return; }
         trsm_fwd_blocked(SCl, 17, LIs, 1, VXl, lw, nwb, wv, nw, lane);
