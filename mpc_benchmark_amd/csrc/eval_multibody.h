@@ -166,62 +166,6 @@ DEV void implicit_diff_block(d4_t (&w)[4], d4_t& t, const double* Mt, const doub
   }
 }
 
-// ---- the 16 x 16 Cholesky + inverse of mfma_blocks.h for a block whose rows / columns from NC on are identity padding (round 6) -------------------------
-// chol16_wave spends its time issuing 16 pivots + 240 broadcast multiply-adds whatever the block holds.  The LAST diagonal block of the joint-space inertia has
-// nv mod 16 real columns (6 of 16 for the complete Talos: 38 = 32 + 6) and the contact block S has 6 contacts' rows (6 or 12 of 16): their padding factorises to
-// itself.  Only the leading NC x NC part is worked on — NC (NC - 1) multiply-adds instead of 240 (30 for NC = 6, 132 for NC = 12) — with the same operations in
-// the same order on that part: the same bits as chol16_wave (CHOL16_RIGHT_LOOKING form).
-template <int J, int C, int END> struct CholColN {
-  static DEV void run(double (&d)[16], double l, double nl) { fmac_bcast<C>(d[C], l, nl); CholColN<J, C + 1, END>::run(d, l, nl); }
-};
-template <int J, int END> struct CholColN<J, END, END> { static DEV void run(double (&)[16], double, double) {} };
-template <int J, int END> struct CholStepN {
-  static DEV void run(double (&d)[16], double (&invd)[16], bool& ok) {
-    const double djj = bcast_row<J>(d[J]);
-    ok = ok && (djj > 0.0);
-    double inv = rsqrt(djj);
-    inv = inv * (1.5 - 0.5 * djj * inv * inv);
-    invd[J] = inv;
-    const double l = d[J] * inv;
-    d[J] = l;
-    CholColN<J, J + 1, END>::run(d, l, -l);
-    CholStepN<J + 1, END>::run(d, invd, ok);
-  }
-};
-template <int END> struct CholStepN<END, END> { static DEV void run(double (&)[16], double (&)[16], bool&) {} };
-template <int K, int R, int END> struct InvUpdN {
-  static DEV void run(const double (&nd)[16], double (&x)[16]) { fmac_bcast<R>(x[R], nd[K], x[K]); InvUpdN<K, R + 1, END>::run(nd, x); }
-};
-template <int K, int END> struct InvUpdN<K, END, END> { static DEV void run(const double (&)[16], double (&)[16]) {} };
-template <int K, int END> struct InvColN {
-  static DEV void run(const double (&nd)[16], const double (&invd)[16], double (&x)[16]) {
-    x[K] *= invd[K];
-    InvUpdN<K, K + 1, END>::run(nd, x);
-    InvColN<K + 1, END>::run(nd, invd, x);
-  }
-};
-template <int END> struct InvColN<END, END> { static DEV void run(const double (&)[16], const double (&)[16], double (&)[16]) {} };
-template <int NC> DEV bool chol16_wave_n(double* D, int ld, double* LIb, int lane) {
-  if constexpr (NC >= 16) return chol16_wave(D, ld, LIb, lane);
-  double d[16], x[16], invd[16];
-  const int r = lane & 15;
-#pragma unroll
-  for (int cidx = 0; cidx < 16; ++cidx) { d[cidx] = (cidx < NC) ? D[r * ld + cidx] : 0.0; invd[cidx] = 1.0; }
-  bool ok = true;
-  CholStepN<0, NC>::run(d, invd, ok);
-  if (lane < 16 && D != LIb) {
-#pragma unroll
-    for (int cidx = 0; cidx < NC; ++cidx) if (cidx <= r) D[r * ld + cidx] = d[cidx];   // (the padding part of the lower triangle is identity already)
-  }
-#pragma unroll
-  for (int cidx = 0; cidx < 16; ++cidx) { x[cidx] = (r == cidx) ? 1.0 : 0.0; d[cidx] = -d[cidx]; }
-  InvColN<0, NC>::run(d, invd, x);
-  if (lane < 16) {
-#pragma unroll
-    for (int rr = 0; rr < 16; ++rr) LIb[rr * 17 + lane] = x[rr];
-  }
-  return ok;
-}
 // chol_tiles_wave (mfma_blocks.h) with NLAST real columns in the last diagonal block
 template <int NLAST> DEV bool chol_tiles_wave_last(double* T, int nb, int lane) {
   bool ok = true;

@@ -14,13 +14,10 @@
 #include <utility>
 #include <vector>
 
-// The 16 x 16 Cholesky + inverse of this translation unit (the Riccati sweep's Ruu and Schur blocks, the leg kernels) on the matrix cores (mfma_blocks.h
-// chol16_wave_mfma, built and measured in round 5, when its 1.2 x on the block did not show in the tick): since round 6 the factorisation of Ruu by wavefront 0 is no
-// longer hidden behind the x tiles of the other seven, and it does: sweep 1.527 -> 1.507 ms per launch, parity tests unchanged.  (The stage kernel's translation unit
-// keeps the register form: its chain is not bound by the block.)
-#ifndef CHOL16_REGISTER_FORM
-#define CHOL16_MFMA
-#endif
+// (-DCHOL16_MFMA: the 16 x 16 Cholesky + inverse of this translation unit — the sweep's Ruu and Schur blocks, the leg kernels — on the matrix cores, mfma_blocks.h
+// chol16_wave_mfma.  Round 6 measured it again: sweep 1.527 -> 1.507 ms per launch, 1.461 with its identity panels skipped — and the kinodynamic stairs ensemble, whose
+// closing step is decided at round-off level, lost an instance it keeps with the register form (tests/test_gpu_walk_all_problems.py).  Not the default: the register form
+// with the padding columns left out — chol16_wave(..., ncols), the same bits on the real ones — gets the Schur block's share without touching a single result.)
 #include "eval_multibody_host.h"
 #include "eval_reuse_kernels.h"
 #include "eval_vector.h"
