@@ -965,7 +965,8 @@ sim_u_set:
   // logarithm just taken — 33 calls of sin / cos / atan2 between them, 13 us on the two diverged lanes of a wavefront the other three waited for at the end of
   // P11.  Here: exp6 once ; (gv, gw) = log6(G) once ; log6(G^-1) = -(gv, gw) exactly, so Jlog6(G^-1) (E6) takes the same series coefficients with the signs of
   // its odd terms flipped ; Jexp6 shares so3_coeffs with exp6.  9 calls.
-  auto step_se3_fused = [&]() {
+  // mode 0: everything ; 1: everything but Jexp6(delta) / Ad^-1 ; 2: only those two (they need the step alone: EV_SE3_X1 runs them on a wavefront that idles in P10)
+  auto step_se3_fused = [&](int mode = 0) {
     const double dt = dt_se3;
     double* Jl6 = small; double* Je6 = small + 36; double* Jq6 = small + 72;
     const V3 dl = v3(dt * (v[0] + dt * acc[0]), dt * (v[1] + dt * acc[1]), dt * (v[2] + dt * acc[2]));
@@ -978,6 +979,24 @@ sim_u_set:
     for (int i = 0; i < 9; ++i) dR.m[i] = ((i % 4 == 0) ? 1.0 : 0.0) + A * Kd.m[i] + B * Kd2.m[i];
     const V3 wv_ = cross(da_, dl);
     const V3 dp = dl + B * wv_ + C * cross(da_, wv_);
+    if (mode != 1 && derivs) {
+      // Jexp6(delta)
+      double b1, b2, b3;
+      q_coeffs(td2, b1, b2, b3);
+      const M3 Qe = Qmat_c(v3(-dl.x, -dl.y, -dl.z), v3(-da_.x, -da_.y, -da_.z), b1, b2, b3);
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        const double jr = ((i == j) ? 1.0 : 0.0) - B * Kd.m[3 * i + j] + C * Kd2.m[3 * i + j];
+        Je6[6 * i + j] = jr; Je6[6 * (i + 3) + j + 3] = jr; Je6[6 * i + j + 3] = Qe.m[3 * i + j]; Je6[6 * (i + 3) + j] = 0.0;
+      }
+      // Ad(exp6(delta))^-1 = [[dR^T, -dR^T [dp]x],[0, dR^T]]
+      const M3 Sx = skew_m(dp);
+      const M3 RtS = tmul(dR, Sx);
+      for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
+        Jq6[6 * r + cc] = dR.m[3 * cc + r]; Jq6[6 * (r + 3) + cc + 3] = dR.m[3 * cc + r];
+        Jq6[6 * r + cc + 3] = -RtS.m[3 * r + cc]; Jq6[6 * (r + 3) + cc] = 0.0;
+      }
+    }
+    if (mode == 2) return;
     const M3 Rb = quat_to_rot(q + 3);
     const M3 Rn = mul(Rb, dR);
     const V3 pn = mul(Rb, dp) + v3(q[0], q[1], q[2]);
@@ -1015,21 +1034,6 @@ sim_u_set:
         T6o[6 * i + j] = jr; T6o[6 * (i + 3) + j + 3] = jr; T6o[6 * i + j + 3] = Q6.m[3 * i + j]; T6o[6 * (i + 3) + j] = 0.0;
       }
       for (int e = 0; e < 36; ++e) kn[KL.oT6k + e] = T6o[e];
-    }
-    // Jexp6(delta)
-    double b1, b2, b3;
-    q_coeffs(td2, b1, b2, b3);
-    const M3 Qe = Qmat_c(v3(-dl.x, -dl.y, -dl.z), v3(-da_.x, -da_.y, -da_.z), b1, b2, b3);
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
-      const double jr = ((i == j) ? 1.0 : 0.0) - B * Kd.m[3 * i + j] + C * Kd2.m[3 * i + j];
-      Je6[6 * i + j] = jr; Je6[6 * (i + 3) + j + 3] = jr; Je6[6 * i + j + 3] = Qe.m[3 * i + j]; Je6[6 * (i + 3) + j] = 0.0;
-    }
-    // Ad(exp6(delta))^-1 = [[dR^T, -dR^T [dp]x],[0, dR^T]]
-    const M3 Sx = skew_m(dp);
-    const M3 RtS = tmul(dR, Sx);
-    for (int r = 0; r < 3; ++r) for (int cc = 0; cc < 3; ++cc) {
-      Jq6[6 * r + cc] = dR.m[3 * cc + r]; Jq6[6 * (r + 3) + cc + 3] = dR.m[3 * cc + r];
-      Jq6[6 * r + cc + 3] = -RtS.m[3 * r + cc]; Jq6[6 * (r + 3) + cc] = 0.0;
     }
   };
   // ---- P9: body accelerations and subtree forces AT THE SOLUTION (only the derivative blocks read them):
@@ -1158,6 +1162,8 @@ sim_u_set:
         }
         }
       }
+      // (the contact rows above occupy nk nv <= 128 threads = two wavefronts: the third does the part of the integrator's single-lane work that needs the step only)
+      if (nw > 2 && wv == nw - 2 && lane == 0) step_se3_fused(2);
       __syncthreads();
       double* dbase = Yc;  // [6][nz]: base rows of d a (direct_ab)
       // ---- P11: R1 = d r1 / d(q, v, u) built in registers, one 16-column block per wavefront at a time, and the whole chain of
@@ -1260,7 +1266,7 @@ sim_u_set:
       const long long tp11b_ = clock64();
       if (TRIAL == 0 && a.prof && k == 1 && lane == 0) a.prof[(size_t)b * 64 + 32 + 16 + wv] += (double)(tp11b_ - tp11_);
 #endif
-      if (wv == nw - 1 && lane == 0) step_se3_fused();  // (P12's single-lane work, on the wavefront with the fewest column blocks)
+      if (wv == nw - 1 && lane == 0) step_se3_fused(nw > 2 ? 1 : 0);  // (P12's single-lane work, on the wavefront with the fewest column blocks ; Jexp6 / Ad^-1: done in P10)
 #ifdef EV_P11PROF
       if (TRIAL == 0 && a.prof && k == 1 && lane == 0 && wv == nw - 1) a.prof[(size_t)b * 64 + 32 + 3] += (double)(clock64() - tp11b_);
 #endif
