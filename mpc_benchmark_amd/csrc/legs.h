@@ -258,6 +258,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds Srt
         ures[sidx] = d4_t{0, 0, 0, 0};
         if (t < nbm * nb) mma_tile<false>(ures[sidx], MU + ((t / nb) * 16) * ldm, ldm, 1, AB + ((t % nb) * 16) * lda + np, 1, lda, mp, lane);
       }
+#ifdef LK_SUBPROF
+      LK_PROF(7);
+#endif
       if (ca <= 16) {
         for (int cj = wv; cj < nb; cj += nw) {
           d4_t acc = d4_t{0, 0, 0, 0};
@@ -274,6 +277,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds Srt
           g[L.oKnup + idx] = -s;
         }
       }
+#ifdef LK_SUBPROF
+      LK_PROF(8);
+#endif
 #pragma unroll
       for (int sidx = 0; sidx < 2; ++sidx) {
         const int t = wv + sidx * nw;
@@ -287,6 +293,9 @@ __global__ void __launch_bounds__(LK_THREADS) k_leg_knot(SolverArgs a, LkLds Srt
           }
         }
       }
+#ifdef LK_SUBPROF
+      LK_PROF(9);
+#endif
       LEG_BARRIER();
       LK_PROF(5);
       // ---- stage 5: Gamma = -Bc U1 - mu_d (T T^T - mu_d T Pt T^T) ; T Pt T^T: rows / columns 0..5 from PT6 / c6 (symmetric), the rest is Pt

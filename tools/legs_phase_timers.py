@@ -34,6 +34,8 @@ q = ens.native.debug_get('ric_prof', 0, b=1)[32:] if False else None
 
 kn = {0: 'loads: [A B], K to LDS, Pt to registers', 1: 'A + B K, y0, Pt to LDS', 2: '(I - mu_d Pt)[Acl | B], in place', 3: 'T6 rows, Phi / phi out, Pt T^T',
       4: 'Mu, Znu in, T Pt T^T', 5: 'U1 = Mu Bc^T, Knup, Ku out', 6: 'Gamma'}
+if os.environ.get("LK_SUB"):  # a library built with -DLK_SUBPROF: stage 4 in pieces (their time comes off slot 5)
+    kn.update({7: '  4a: U1 tiles (MFMA)', 8: '  4b: Knup tiles', 9: '  4c: U1 -> LDS, Ku out'})
 tk = sum(pk[i] for i in kn)
 for i, nm in kn.items():
     print('KNOT %-44s %7.1f us %5.1f%%' % (nm, pk[i] / TICKS / (GHZ * 1e3), 100 * pk[i] / tk))
